@@ -1,0 +1,125 @@
+/*
+ * nerficg_hip.h -- C ABI of libnerficg_hip.so, the MI355X (gfx950) replacement for the native ops behind
+ * nerficg's src/Methods plugins.  Plain pointers + sizes, no torch types.  All pointers are DEVICE pointers unless a
+ * parameter is documented as host.  `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ * Every function returns NRC_OK (0) or a negative NRC_ERR_* code; nothing is allocated and nothing synchronises
+ * inside the library (workspaces are caller-provided), so every entry point is hipGraph-capturable.
+ *
+ * Each group cites the reference interface it replaces (paths relative to the nerficg repository root).
+ */
+#ifndef NERFICG_HIP_H
+#define NERFICG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nrc_stream_t;
+
+enum {
+    NRC_OK = 0,
+    NRC_ERR_INVALID = -1, /* bad argument (null pointer, negative size, unsupported configuration) */
+    NRC_ERR_LAUNCH = -2,  /* hipGetLastError() != hipSuccess after a launch */
+    NRC_ERR_UNSUPPORTED = -3
+};
+
+/* library identification; also used by the loader's symbol check */
+int nrc_abi_version(void);
+const char* nrc_build_info(void);
+
+/* =====================================================================================================
+ * Group 1 -- VolumeRenderingV2  (replaces the pybind module of
+ *            src/Methods/InstantNGP/VolumeRenderingV2/csrc/binding.cpp:234-250)
+ * dtypes are fixed like in the reference: f32 data, i64 rays_a / alive_indices / hits_voxel_idx,
+ * i32 counter / N_eff_samples / Morton codes, u8 bitfield.  All arrays dense row-major.
+ * ===================================================================================================== */
+
+/* binding.cpp:4-16 -> intersection.cu:59-100.  hits_t (n_rays,max_hits,2) and hits_voxel_idx (n_rays,max_hits) are
+ * fully written (-1 fill, then hits, then sorted ascending by t1 like the reference's torch::sort). hit_cnt (n_rays). */
+int nrc_ray_aabb_intersect(const float* rays_o, const float* rays_d, const float* centers, const float* half_sizes,
+                           int64_t n_rays, int64_t n_voxels, int32_t max_hits, int32_t* hit_cnt, float* hits_t,
+                           int64_t* hits_voxel_idx, nrc_stream_t stream);
+/* binding.cpp:19-31 -> intersection.cu:156-196 */
+int nrc_ray_sphere_intersect(const float* rays_o, const float* rays_d, const float* centers, const float* radii,
+                             int64_t n_rays, int64_t n_spheres, int32_t max_hits, int32_t* hit_cnt, float* hits_t,
+                             int64_t* hits_sphere_idx, nrc_stream_t stream);
+/* binding.cpp:46-50 -> raymarching.cu:72-88.  coords (n,3) i32 -> indices (n) i32 */
+int nrc_morton3D(const int32_t* coords, int64_t n, int32_t* indices, nrc_stream_t stream);
+/* binding.cpp:53-57 -> raymarching.cu:103-119 */
+int nrc_morton3D_invert(const int32_t* indices, int64_t n, int32_t* coords, nrc_stream_t stream);
+/* binding.cpp:34-43 -> raymarching.cu:143-161.  grid_dtype: 0 = f32, 1 = f16.  n_bytes = len(bitfield); grid has 8*n_bytes cells. */
+int nrc_packbits(const void* density_grid, int32_t grid_dtype, int64_t n_bytes, float density_threshold,
+                 uint8_t* density_bitfield, nrc_stream_t stream);
+
+/* binding.cpp:60-81 -> raymarching.cu:283-332, split in two calls so that the caller can allocate exactly
+ * counter[0] sample rows instead of the reference's n_rays*max_samples zero-filled rows.
+ *   _count : marches every ray once, writes rays_a (n_rays,3) = (ray_idx, start_idx, n_samples) in RAY ORDER with
+ *            start_idx = exclusive prefix sum (deterministic; the reference's order is atomic-arrival order) and
+ *            counter[0] = total samples, counter[1] = n_rays.  workspace: nrc_raymarching_train_ws_bytes(n_rays) bytes.
+ *   _write : marches again and writes xyzs/dirs (total,3), deltas/ts (total). */
+int64_t nrc_raymarching_train_ws_bytes(int64_t n_rays);
+int nrc_raymarching_train_count(const float* rays_o, const float* rays_d, const float* hits_t,
+                                const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
+                                const float* noise, int32_t grid_size, int32_t max_samples, int64_t n_rays,
+                                int64_t* rays_a, int32_t* counter, void* workspace, nrc_stream_t stream);
+int nrc_raymarching_train_write(const float* rays_o, const float* rays_d, const float* hits_t,
+                                const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
+                                const float* noise, int32_t grid_size, int32_t max_samples, int64_t n_rays,
+                                const int64_t* rays_a, float* xyzs, float* dirs, float* deltas, float* ts,
+                                nrc_stream_t stream);
+/* binding.cpp:84-106 -> raymarching.cu:407-454.  hits_t (n_total_rays,2) is advanced in place.  Outputs
+ * (n_alive,N_samples[,3]) are fully written (zero beyond N_eff_samples), N_eff_samples (n_alive) i32. */
+int nrc_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t, const int64_t* alive_indices,
+                         int64_t n_alive, const uint8_t* density_bitfield, int32_t cascades, float scale,
+                         float exp_step_factor, int32_t grid_size, int32_t max_samples, int32_t N_samples, float* xyzs,
+                         float* dirs, float* deltas, float* ts, int32_t* N_eff_samples, nrc_stream_t stream);
+
+/* binding.cpp:109-126 -> volumerendering.cu:48-84.  rays_a (n_rays,3) i64; sample arrays have n_samples rows.
+ * Outputs are fully written: total_samples (n_rays) i64, opacity/depth (n_rays), rgb (n_rays,3), ws (n_samples). */
+int nrc_composite_train_fw(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
+                           const int64_t* rays_a, int64_t n_rays, int64_t n_samples, float T_threshold,
+                           int64_t* total_samples, float* opacity, float* depth, float* rgb, float* ws,
+                           nrc_stream_t stream);
+/* binding.cpp:129-163 -> volumerendering.cu:154-202 */
+int nrc_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb, const float* dL_dws,
+                           const float* sigmas, const float* rgbs, const float* ws, const float* deltas, const float* ts,
+                           const int64_t* rays_a, const float* opacity, const float* depth, const float* rgb,
+                           int64_t n_rays, int64_t n_samples, float T_threshold, float* dL_dsigmas, float* dL_drgbs,
+                           nrc_stream_t stream);
+/* binding.cpp:166-194 -> volumerendering.cu:252-285.  In place on opacity/depth/rgb (n_total_rays[,3]) and on
+ * alive_indices (entries of dead rays become -1). */
+int nrc_composite_test_fw(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
+                          int64_t* alive_indices, int64_t n_alive, int32_t N_samples, float T_threshold,
+                          const int32_t* N_eff_samples, float* opacity, float* depth, float* rgb, nrc_stream_t stream);
+/* binding.cpp:197-209 -> losses.cu:64-109 */
+int nrc_distortion_loss_fw(const float* ws, const float* deltas, const float* ts, const int64_t* rays_a, int64_t n_rays,
+                           int64_t n_samples, float* loss, float* ws_inclusive_scan, float* wts_inclusive_scan,
+                           nrc_stream_t stream);
+/* binding.cpp:212-231 -> losses.cu:145-174 */
+int nrc_distortion_loss_bw(const float* dL_dloss, const float* ws_inclusive_scan, const float* wts_inclusive_scan,
+                           const float* ws, const float* deltas, const float* ts, const int64_t* rays_a, int64_t n_rays,
+                           int64_t n_samples, float* dL_dws, nrc_stream_t stream);
+
+/* =====================================================================================================
+ * Group 2 -- MortonEncoding._C  (replaces src/CudaUtils/MortonEncoding/MortonEncoding/morton_encoding.cu:48-79)
+ * positions (n,3) f32 -> codes (n) i64.  The bounding cube (reference: host aminmax, :54-57) is reduced on device
+ * into `workspace` (nrc_morton_encode_ws_bytes(n) bytes) by the same call.
+ * ===================================================================================================== */
+int64_t nrc_morton_encode_ws_bytes(int64_t n);
+int nrc_morton_encode(const float* positions, int64_t n, int64_t* codes, void* workspace, nrc_stream_t stream);
+
+/* =====================================================================================================
+ * Group 5 -- ray generation (replaces PerspectiveCamera.compute_local_ray_directions src/Cameras/Perspective.py:64-94
+ * + View.get_rays / cam_to_world src/Datasets/utils.py:1033-1074 for undistorted perspective cameras).
+ * intrinsics (HOST, 4 doubles): focal_x, focal_y, center_x, center_y.  c2w (HOST, 16 doubles, row-major 4x4).
+ * Outputs (H*W,3) f32 each, y-major then x; any output pointer may be NULL.
+ * ===================================================================================================== */
+int nrc_generate_rays(int32_t width, int32_t height, const double* intrinsics, const double* c2w, float* origin,
+                      float* direction, float* view_direction, nrc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFICG_HIP_H */

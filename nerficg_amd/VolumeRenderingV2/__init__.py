@@ -1,0 +1,310 @@
+"""nerficg_amd.VolumeRenderingV2 -- drop-in for the reference's CUDA extension module `VolumeRenderingV2`
+(src/Methods/InstantNGP/VolumeRenderingV2/csrc/binding.cpp:234-250) and its autograd layer
+(src/Methods/InstantNGP/VolumeRenderingV2/custom_functions.py), backed by libnerficg_hip.so.
+
+Same function names, argument order, dtypes, in-place behaviour and error behaviour (RuntimeError on non-device /
+non-contiguous input, csrc/include/utils.h:4-6).  Outputs are allocated here ("callee allocates" stays true at the
+Python level); the C ABI underneath takes raw pointers.  Differences, all documented in DESIGN.md:
+  * raymarching_train returns sample arrays with exactly counter[0] rows (the reference returns n_rays*max_samples
+    zero-filled rows and its only caller slices them, custom_functions.py:114-119); rays_a is in ray order.
+  * launches go to torch's CURRENT stream (the reference uses the legacy default stream).
+"""
+from __future__ import annotations
+
+import torch
+from torch.amp import custom_bwd, custom_fwd
+
+from .. import _lib
+
+__all__ = [
+    'ray_aabb_intersect', 'ray_sphere_intersect', 'morton3D', 'morton3D_invert', 'packbits', 'raymarching_train',
+    'raymarching_test', 'composite_train_fw', 'composite_train_bw', 'composite_test_fw', 'distortion_loss_fw',
+    'distortion_loss_bw', 'RayAABBIntersector', 'RaySphereIntersector', 'RayMarcher', 'VolumeRenderer', 'TruncExp',
+    'DistortionLoss',
+]
+
+_f32, _i32, _i64, _u8 = torch.float32, torch.int32, torch.int64, torch.uint8
+
+
+def _chk(*pairs) -> None:
+    for t, name, dtype in pairs:
+        _lib.check_input(t, name, dtype)
+
+
+# ----------------------------------------------------------------------------------------------- raw ops (binding.cpp)
+def ray_aabb_intersect(rays_o, rays_d, centers, half_sizes, max_hits: int):
+    """binding.cpp:4-16. Returns [hit_cnt (N) i32, hits_t (N,max_hits,2) f32, hits_voxel_idx (N,max_hits) i64]."""
+    _chk((rays_o, 'rays_o', _f32), (rays_d, 'rays_d', _f32), (centers, 'centers', _f32), (half_sizes, 'half_sizes', _f32))
+    n, v = rays_o.shape[0], centers.shape[0]
+    dev = rays_o.device
+    hit_cnt = torch.empty(n, dtype=_i32, device=dev)
+    hits_t = torch.empty(n, max_hits, 2, dtype=_f32, device=dev)
+    hits_idx = torch.empty(n, max_hits, dtype=_i64, device=dev)
+    _lib.check(_lib.load().nrc_ray_aabb_intersect(
+        _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(centers), _lib.ptr(half_sizes), n, v, int(max_hits),
+        _lib.ptr(hit_cnt), _lib.ptr(hits_t), _lib.ptr(hits_idx), _lib.stream_of(rays_o)), 'ray_aabb_intersect')
+    return [hit_cnt, hits_t, hits_idx]
+
+
+def ray_sphere_intersect(rays_o, rays_d, centers, radii, max_hits: int):
+    """binding.cpp:19-31."""
+    _chk((rays_o, 'rays_o', _f32), (rays_d, 'rays_d', _f32), (centers, 'centers', _f32), (radii, 'radii', _f32))
+    n, v = rays_o.shape[0], centers.shape[0]
+    dev = rays_o.device
+    hit_cnt = torch.empty(n, dtype=_i32, device=dev)
+    hits_t = torch.empty(n, max_hits, 2, dtype=_f32, device=dev)
+    hits_idx = torch.empty(n, max_hits, dtype=_i64, device=dev)
+    _lib.check(_lib.load().nrc_ray_sphere_intersect(
+        _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(centers), _lib.ptr(radii), n, v, int(max_hits),
+        _lib.ptr(hit_cnt), _lib.ptr(hits_t), _lib.ptr(hits_idx), _lib.stream_of(rays_o)), 'ray_sphere_intersect')
+    return [hit_cnt, hits_t, hits_idx]
+
+
+def morton3D(coords):
+    """binding.cpp:46-50. coords (N,3) i32 -> (N) i32."""
+    _chk((coords, 'coords', _i32))
+    out = torch.empty(coords.shape[0], dtype=_i32, device=coords.device)
+    _lib.check(_lib.load().nrc_morton3D(_lib.ptr(coords), coords.shape[0], _lib.ptr(out), _lib.stream_of(coords)), 'morton3D')
+    return out
+
+
+def morton3D_invert(indices):
+    """binding.cpp:53-57. indices (N) i32 -> (N,3) i32."""
+    _chk((indices, 'indices', _i32))
+    out = torch.empty(indices.shape[0], 3, dtype=_i32, device=indices.device)
+    _lib.check(_lib.load().nrc_morton3D_invert(_lib.ptr(indices), indices.shape[0], _lib.ptr(out), _lib.stream_of(indices)),
+               'morton3D_invert')
+    return out
+
+
+def packbits(density_grid, density_threshold: float, density_bitfield) -> None:
+    """binding.cpp:34-43. In place on density_bitfield (u8, numel = grid.numel()/8)."""
+    _chk((density_grid, 'density_grid', None), (density_bitfield, 'density_bitfield', _u8))
+    if density_grid.dtype == _f32:
+        dt = 0
+    elif density_grid.dtype == torch.float16:
+        dt = 1
+    else:
+        raise RuntimeError(f'packbits: unsupported density_grid dtype {density_grid.dtype}')
+    _lib.check(_lib.load().nrc_packbits(_lib.ptr(density_grid), dt, density_bitfield.shape[0], float(density_threshold),
+                                        _lib.ptr(density_bitfield), _lib.stream_of(density_grid)), 'packbits')
+
+
+def raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades: int, scale: float, exp_step_factor: float, noise,
+                      grid_size: int, max_samples: int):
+    """binding.cpp:60-81. Returns [rays_a (N,3) i64, xyzs (M,3), dirs (M,3), deltas (M), ts (M), counter (2) i32], M = counter[0]."""
+    _chk((rays_o, 'rays_o', _f32), (rays_d, 'rays_d', _f32), (hits_t, 'hits_t', _f32),
+         (density_bitfield, 'density_bitfield', _u8), (noise, 'noise', _f32))
+    lib = _lib.load()
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    st = _lib.stream_of(rays_o)
+    rays_a = torch.empty(n, 3, dtype=_i64, device=dev)
+    counter = torch.empty(2, dtype=_i32, device=dev)
+    ws = torch.empty(max(int(lib.nrc_raymarching_train_ws_bytes(n)), 1), dtype=_u8, device=dev)
+    args = (_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(hits_t), _lib.ptr(density_bitfield), int(cascades), float(scale),
+            float(exp_step_factor), _lib.ptr(noise), int(grid_size), int(max_samples), n)
+    _lib.check(lib.nrc_raymarching_train_count(*args, _lib.ptr(rays_a), _lib.ptr(counter), _lib.ptr(ws), st), 'raymarching_train(count)')
+    total = int(counter[0].item())  # same host sync the reference pays when slicing by counter[0] (custom_functions.py:112-119)
+    xyzs = torch.empty(total, 3, dtype=_f32, device=dev)
+    dirs = torch.empty(total, 3, dtype=_f32, device=dev)
+    deltas = torch.empty(total, dtype=_f32, device=dev)
+    ts = torch.empty(total, dtype=_f32, device=dev)
+    _lib.check(lib.nrc_raymarching_train_write(*args, _lib.ptr(rays_a), _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas),
+                                               _lib.ptr(ts), st), 'raymarching_train(write)')
+    return [rays_a, xyzs, dirs, deltas, ts, counter]
+
+
+def raymarching_test(rays_o, rays_d, hits_t, alive_indices, density_bitfield, cascades: int, scale: float,
+                     exp_step_factor: float, grid_size: int, max_samples: int, N_samples: int):
+    """binding.cpp:84-106. hits_t is advanced in place. Returns [xyzs (A,S,3), dirs (A,S,3), deltas (A,S), ts (A,S), N_eff (A) i32]."""
+    _chk((rays_o, 'rays_o', _f32), (rays_d, 'rays_d', _f32), (hits_t, 'hits_t', _f32), (alive_indices, 'alive_indices', _i64),
+         (density_bitfield, 'density_bitfield', _u8))
+    a = alive_indices.shape[0]
+    dev = rays_o.device
+    xyzs = torch.empty(a, N_samples, 3, dtype=_f32, device=dev)
+    dirs = torch.empty(a, N_samples, 3, dtype=_f32, device=dev)
+    deltas = torch.empty(a, N_samples, dtype=_f32, device=dev)
+    ts = torch.empty(a, N_samples, dtype=_f32, device=dev)
+    n_eff = torch.empty(a, dtype=_i32, device=dev)
+    _lib.check(_lib.load().nrc_raymarching_test(
+        _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(hits_t), _lib.ptr(alive_indices), a, _lib.ptr(density_bitfield),
+        int(cascades), float(scale), float(exp_step_factor), int(grid_size), int(max_samples), int(N_samples),
+        _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas), _lib.ptr(ts), _lib.ptr(n_eff), _lib.stream_of(rays_o)), 'raymarching_test')
+    return [xyzs, dirs, deltas, ts, n_eff]
+
+
+def composite_train_fw(sigmas, rgbs, deltas, ts, rays_a, T_threshold: float):
+    """binding.cpp:109-126. Returns [total_samples (N) i64, opacity (N), depth (N), rgb (N,3), ws (M)]."""
+    _chk((sigmas, 'sigmas', _f32), (rgbs, 'rgbs', _f32), (deltas, 'deltas', _f32), (ts, 'ts', _f32), (rays_a, 'rays_a', _i64))
+    n, m = rays_a.shape[0], sigmas.shape[0]
+    dev = sigmas.device
+    total = torch.empty(n, dtype=_i64, device=dev)
+    opacity = torch.empty(n, dtype=_f32, device=dev)
+    depth = torch.empty(n, dtype=_f32, device=dev)
+    rgb = torch.empty(n, 3, dtype=_f32, device=dev)
+    ws = torch.empty(m, dtype=_f32, device=dev)
+    _lib.check(_lib.load().nrc_composite_train_fw(
+        _lib.ptr(sigmas), _lib.ptr(rgbs), _lib.ptr(deltas), _lib.ptr(ts), _lib.ptr(rays_a), n, m, float(T_threshold),
+        _lib.ptr(total), _lib.ptr(opacity), _lib.ptr(depth), _lib.ptr(rgb), _lib.ptr(ws), _lib.stream_of(sigmas)), 'composite_train_fw')
+    return [total, opacity, depth, rgb, ws]
+
+
+def composite_train_bw(dL_dopacity, dL_ddepth, dL_drgb, dL_dws, sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb,
+                       T_threshold: float):
+    """binding.cpp:129-163. Returns [dL_dsigmas (M), dL_drgbs (M,3)]."""
+    _chk((dL_dopacity, 'dL_dopacity', _f32), (dL_ddepth, 'dL_ddepth', _f32), (dL_drgb, 'dL_drgb', _f32), (dL_dws, 'dL_dws', _f32),
+         (sigmas, 'sigmas', _f32), (rgbs, 'rgbs', _f32), (ws, 'ws', _f32), (deltas, 'deltas', _f32), (ts, 'ts', _f32),
+         (rays_a, 'rays_a', _i64), (opacity, 'opacity', _f32), (depth, 'depth', _f32), (rgb, 'rgb', _f32))
+    n, m = rays_a.shape[0], sigmas.shape[0]
+    dev = sigmas.device
+    dL_dsigmas = torch.empty(m, dtype=_f32, device=dev)
+    dL_drgbs = torch.empty(m, 3, dtype=_f32, device=dev)
+    _lib.check(_lib.load().nrc_composite_train_bw(
+        _lib.ptr(dL_dopacity), _lib.ptr(dL_ddepth), _lib.ptr(dL_drgb), _lib.ptr(dL_dws), _lib.ptr(sigmas), _lib.ptr(rgbs),
+        _lib.ptr(ws), _lib.ptr(deltas), _lib.ptr(ts), _lib.ptr(rays_a), _lib.ptr(opacity), _lib.ptr(depth), _lib.ptr(rgb), n, m,
+        float(T_threshold), _lib.ptr(dL_dsigmas), _lib.ptr(dL_drgbs), _lib.stream_of(sigmas)), 'composite_train_bw')
+    return [dL_dsigmas, dL_drgbs]
+
+
+def composite_test_fw(sigmas, rgbs, deltas, ts, hits_t, alive_indices, T_threshold: float, N_eff_samples, opacity, depth, rgb) -> None:
+    """binding.cpp:166-194. In place on opacity/depth/rgb and alive_indices. `hits_t` is accepted and unused, as in the reference kernel."""
+    _chk((sigmas, 'sigmas', _f32), (rgbs, 'rgbs', _f32), (deltas, 'deltas', _f32), (ts, 'ts', _f32), (hits_t, 'hits_t', _f32),
+         (alive_indices, 'alive_indices', _i64), (N_eff_samples, 'N_eff_samples', _i32), (opacity, 'opacity', _f32),
+         (depth, 'depth', _f32), (rgb, 'rgb', _f32))
+    a = alive_indices.shape[0]
+    n_samples = sigmas.shape[1] if sigmas.dim() == 2 else 1
+    _lib.check(_lib.load().nrc_composite_test_fw(
+        _lib.ptr(sigmas), _lib.ptr(rgbs), _lib.ptr(deltas), _lib.ptr(ts), _lib.ptr(alive_indices), a, int(n_samples),
+        float(T_threshold), _lib.ptr(N_eff_samples), _lib.ptr(opacity), _lib.ptr(depth), _lib.ptr(rgb), _lib.stream_of(sigmas)),
+        'composite_test_fw')
+
+
+def distortion_loss_fw(ws, deltas, ts, rays_a):
+    """binding.cpp:197-209. Returns [loss (N), ws_inclusive_scan (M), wts_inclusive_scan (M)]."""
+    _chk((ws, 'ws', _f32), (deltas, 'deltas', _f32), (ts, 'ts', _f32), (rays_a, 'rays_a', _i64))
+    n, m = rays_a.shape[0], ws.shape[0]
+    dev = ws.device
+    loss = torch.empty(n, dtype=_f32, device=dev)
+    ws_i = torch.empty(m, dtype=_f32, device=dev)
+    wts_i = torch.empty(m, dtype=_f32, device=dev)
+    _lib.check(_lib.load().nrc_distortion_loss_fw(_lib.ptr(ws), _lib.ptr(deltas), _lib.ptr(ts), _lib.ptr(rays_a), n, m,
+                                                  _lib.ptr(loss), _lib.ptr(ws_i), _lib.ptr(wts_i), _lib.stream_of(ws)), 'distortion_loss_fw')
+    return [loss, ws_i, wts_i]
+
+
+def distortion_loss_bw(dL_dloss, ws_inclusive_scan, wts_inclusive_scan, ws, deltas, ts, rays_a):
+    """binding.cpp:212-231. Returns dL_dws (M)."""
+    _chk((dL_dloss, 'dL_dloss', _f32), (ws_inclusive_scan, 'ws_inclusive_scan', _f32), (wts_inclusive_scan, 'wts_inclusive_scan', _f32),
+         (ws, 'ws', _f32), (deltas, 'deltas', _f32), (ts, 'ts', _f32), (rays_a, 'rays_a', _i64))
+    n, m = rays_a.shape[0], ws.shape[0]
+    out = torch.empty(m, dtype=_f32, device=ws.device)
+    _lib.check(_lib.load().nrc_distortion_loss_bw(
+        _lib.ptr(dL_dloss), _lib.ptr(ws_inclusive_scan), _lib.ptr(wts_inclusive_scan), _lib.ptr(ws), _lib.ptr(deltas),
+        _lib.ptr(ts), _lib.ptr(rays_a), n, m, _lib.ptr(out), _lib.stream_of(ws)), 'distortion_loss_bw')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- autograd layer
+class RayAABBIntersector(torch.autograd.Function):
+    """custom_functions.py:8-32."""
+
+    @staticmethod
+    @custom_fwd(cast_inputs=torch.float32, device_type='cuda')
+    def forward(ctx, rays_o, rays_d, center, half_size, max_hits):
+        return tuple(ray_aabb_intersect(rays_o, rays_d, center, half_size, max_hits))
+
+
+class RaySphereIntersector(torch.autograd.Function):
+    """custom_functions.py:35-58."""
+
+    @staticmethod
+    @custom_fwd(cast_inputs=torch.float32, device_type='cuda')
+    def forward(ctx, rays_o, rays_d, center, radii, max_hits):
+        return tuple(ray_sphere_intersect(rays_o, rays_d, center, radii, max_hits))
+
+
+def _segment_sum(src: torch.Tensor, rays_a: torch.Tensor) -> torch.Tensor:
+    """CSR segmented sum over the per-ray sample segments (the reference uses torch_scatter.segment_csr,
+    custom_functions.py:131-135; its indptr construction assumes rays_a rows are stored in segment order, which
+    holds here by construction)."""
+    n = rays_a.shape[0]
+    out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    seg = torch.repeat_interleave(torch.arange(n, device=src.device), rays_a[:, 2])
+    out.index_add_(0, seg, src)
+    return out
+
+
+class RayMarcher(torch.autograd.Function):
+    """custom_functions.py:61-137."""
+
+    @staticmethod
+    @custom_fwd(cast_inputs=torch.float32, device_type='cuda')
+    def forward(ctx, rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, grid_size, max_samples):
+        noise = torch.rand_like(rays_o[:, 0])
+        rays_a, xyzs, dirs, deltas, ts, counter = raymarching_train(
+            rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, noise, grid_size, max_samples)
+        total_samples = counter[0]
+        ctx.save_for_backward(rays_a, ts)
+        return rays_a, xyzs, dirs, deltas, ts, total_samples
+
+    @staticmethod
+    @custom_bwd(device_type='cuda')
+    def backward(ctx, dL_drays_a, dL_dxyzs, dL_ddirs, dL_ddeltas, dL_dts, dL_dtotal_samples):
+        rays_a, ts = ctx.saved_tensors
+        dL_drays_o = _segment_sum(dL_dxyzs, rays_a)
+        dL_drays_d = _segment_sum(dL_dxyzs * ts[:, None] + dL_ddirs, rays_a)
+        return dL_drays_o, dL_drays_d, None, None, None, None, None, None, None
+
+
+class VolumeRenderer(torch.autograd.Function):
+    """custom_functions.py:140-194."""
+
+    @staticmethod
+    @custom_fwd(cast_inputs=torch.float32, device_type='cuda')
+    def forward(ctx, sigmas, rgbs, deltas, ts, rays_a, T_threshold):
+        total_samples, opacity, depth, rgb, ws = composite_train_fw(sigmas, rgbs, deltas, ts, rays_a, T_threshold)
+        ctx.save_for_backward(sigmas, rgbs, deltas, ts, rays_a, opacity, depth, rgb, ws)
+        ctx.T_threshold = T_threshold
+        return total_samples.sum(), opacity, depth, rgb, ws
+
+    @staticmethod
+    @custom_bwd(device_type='cuda')
+    def backward(ctx, dL_dtotal_samples, dL_dopacity, dL_ddepth, dL_drgb, dL_dws):
+        sigmas, rgbs, deltas, ts, rays_a, opacity, depth, rgb, ws = ctx.saved_tensors
+        dL_dsigmas, dL_drgbs = composite_train_bw(
+            dL_dopacity.contiguous(), dL_ddepth.contiguous(), dL_drgb.contiguous(), dL_dws.contiguous(), sigmas, rgbs, ws,
+            deltas, ts, rays_a, opacity, depth, rgb, ctx.T_threshold)
+        return dL_dsigmas, dL_drgbs, None, None, None, None
+
+
+class TruncExp(torch.autograd.Function):
+    """custom_functions.py:197-208: fwd exp(x), bwd g * exp(clamp(x, -15, 15))."""
+
+    @staticmethod
+    @custom_fwd(cast_inputs=torch.float32, device_type='cuda')
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    @custom_bwd(device_type='cuda')
+    def backward(ctx, dL_dout):
+        x = ctx.saved_tensors[0]
+        return dL_dout * torch.exp(x.clamp(-15, 15))
+
+
+class DistortionLoss(torch.autograd.Function):
+    """custom_functions.py:211-252."""
+
+    @staticmethod
+    def forward(ctx, ws, deltas, ts, rays_a):
+        loss, ws_inclusive_scan, wts_inclusive_scan = distortion_loss_fw(ws, deltas, ts, rays_a)
+        ctx.save_for_backward(ws_inclusive_scan, wts_inclusive_scan, ws, deltas, ts, rays_a)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dL_dloss):
+        ws_inclusive_scan, wts_inclusive_scan, ws, deltas, ts, rays_a = ctx.saved_tensors
+        dL_dws = distortion_loss_bw(dL_dloss.contiguous(), ws_inclusive_scan, wts_inclusive_scan, ws, deltas, ts, rays_a)
+        return dL_dws, None, None, None

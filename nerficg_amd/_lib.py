@@ -1,0 +1,93 @@
+"""nerficg_amd/_lib.py -- loads libnerficg_hip.so (the C-ABI HIP library) with ctypes.
+
+The prototypes are parsed from include/nerficg_hip.h, so the Python bindings cannot drift from the header.
+There is NO CPU fallback: if the library is missing or a GPU op is called without a GPU, this fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import re
+from functools import lru_cache
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+HEADER = PKG.parent / 'include' / 'nerficg_hip.h'
+LIB_PATH = PKG / 'lib' / 'libnerficg_hip.so'
+
+ERRORS = {0: 'NRC_OK', -1: 'NRC_ERR_INVALID', -2: 'NRC_ERR_LAUNCH', -3: 'NRC_ERR_UNSUPPORTED'}
+
+_SCALARS = {
+    'int': ctypes.c_int, 'int32_t': ctypes.c_int32, 'uint32_t': ctypes.c_uint32, 'int64_t': ctypes.c_int64,
+    'uint64_t': ctypes.c_uint64, 'float': ctypes.c_float, 'double': ctypes.c_double, 'nrc_stream_t': ctypes.c_void_p,
+}
+
+
+class NativeLibraryError(ImportError):
+    pass
+
+
+def parse_header(path: Path = HEADER) -> dict[str, tuple[str, list[tuple[str, str]]]]:
+    """Returns {symbol: (return_type, [(ctype_string, arg_name), ...])} for every prototype in the header."""
+    text = re.sub(r'/\*.*?\*/', ' ', path.read_text(), flags=re.S)
+    text = re.sub(r'//[^\n]*', ' ', text)
+    protos: dict[str, tuple[str, list[tuple[str, str]]]] = {}
+    for m in re.finditer(r'\b(int|int64_t|const\s+char\s*\*)\s+(nrc_\w+)\s*\(([^;{]*?)\)\s*;', text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        parsed = []
+        args = ' '.join(args.split())
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                mm = re.match(r'(.*?)(\w+)$', a)
+                parsed.append((mm.group(1).strip(), mm.group(2)))
+        protos[name] = (' '.join(ret.split()), parsed)
+    return protos
+
+
+def _ctype(type_str: str):
+    if '*' in type_str:
+        return ctypes.c_void_p
+    base = type_str.replace('const', '').strip()
+    return _SCALARS[base]
+
+
+@lru_cache(maxsize=1)
+def load() -> ctypes.CDLL:
+    if not LIB_PATH.exists():
+        raise NativeLibraryError(
+            f'{LIB_PATH} is missing: build the HIP extension first (python -m nerficg_amd.build). '
+            'nerficg_amd has no CPU fallback.')
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (ret, args) in parse_header().items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f'{LIB_PATH} does not export {name} declared in {HEADER.name}') from e
+        fn.argtypes = [_ctype(t) for t, _ in args]
+        fn.restype = ctypes.c_char_p if 'char' in ret else (ctypes.c_int64 if ret == 'int64_t' else ctypes.c_int)
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError(f'{what} failed: {ERRORS.get(status, status)}')
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t) -> ctypes.c_void_p:
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def check_input(t, name: str, dtype=None) -> None:
+    """CHECK_INPUT of the reference (csrc/include/utils.h:4-6): CUDA(HIP) tensor + contiguous, RuntimeError otherwise."""
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must be a CUDA tensor')
+    if not t.is_contiguous():
+        raise RuntimeError(f'{name} must be contiguous')
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f'{name} must have dtype {dtype}, got {t.dtype}')

@@ -1,0 +1,77 @@
+// common.h -- shared device helpers for the gfx950 (MI355X, CDNA4) kernels of libnerficg_hip.so.
+// wave = 64 lanes everywhere; no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nerficg_hip.h"
+
+#define NRC_WAVE 64
+
+#define NRC_LAUNCH_CHECK()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return NRC_ERR_LAUNCH;        \
+    } while (0)
+
+static inline int64_t nrc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- wave-level primitives (64-wide) ---------------------------------------------------------
+__device__ __forceinline__ int nrc_lane() { return __lane_id(); }
+
+// inclusive scans over the lanes of a G-lane group (G power of two <= 64), Hillis-Steele with DPP-lowered shuffles
+template <int G>
+__device__ __forceinline__ float nrc_group_incl_sum(float v, int lane_in_group) {
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+        const float o = __shfl_up(v, d, G);
+        if (lane_in_group >= d) v += o;
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float nrc_group_incl_prod(float v, int lane_in_group) {
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+        const float o = __shfl_up(v, d, G);
+        if (lane_in_group >= d) v *= o;
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float nrc_group_sum(float v) {
+#pragma unroll
+    for (int d = G / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, G);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ int nrc_group_sum_i(int v) {
+#pragma unroll
+    for (int d = G / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, G);
+    return v;
+}
+__device__ __forceinline__ int nrc_wave_incl_sum_i(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one int per thread (blockDim.x == 256 -> 4 waves). `smem` needs 8 ints.
+__device__ __forceinline__ int nrc_block256_excl_scan_i(int v, int* smem, int* block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = nrc_wave_incl_sum_i(v, lane);
+    if (lane == 63) smem[wave] = incl;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int s = smem[w];
+        if (w < wave) base += s;
+    }
+    if (block_total) *block_total = smem[0] + smem[1] + smem[2] + smem[3];
+    __syncthreads();
+    return base + incl - v;
+}

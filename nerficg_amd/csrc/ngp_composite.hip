@@ -1,0 +1,328 @@
+// ngp_composite.hip -- front-to-back alpha compositing (train fw/bw, test fw) and the distortion loss for gfx950.
+//
+// Reference semantics: volumerendering.cu:6-45 (train fw), :87-151 (train bw), :205-249 (test fw);
+// losses.cu:9-61 (fw), :112-142 (bw).  The reference walks one ray per THREAD, serially, so neighbouring lanes read
+// addresses one ray-length apart.  Here one wave (or a G-lane group of a wave) owns a ray and walks it 64 (G) samples at
+// a time: every load/store is a contiguous 256-byte (sigmas/deltas/ts/ws) or 768-byte (rgbs) segment, the running
+// transmittance is a wave-level multiplicative scan, the per-ray sums are wave reductions.  HBM-bound by design:
+//   fw : 28 B read + 4 B written per sample ; bw : 44 B read + 16 B written per sample.
+// f32 sums are therefore tree-ordered instead of serial; the tolerance against the oracle is stated in the tests.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float alpha_of(float sigma, float delta) { return 1.0f - __expf(-sigma * delta); }
+
+// Transmittance bookkeeping for one G-lane chunk.  `a` = alpha of this lane's sample (0 for lanes past the ray end).
+// carry = T before the chunk.  Returns T before / after this lane's sample and updates carry to T after the chunk.
+template <int G>
+__device__ __forceinline__ void chunk_transmittance(float a, int gl, float& carry, float& T_before, float& T_after) {
+    const float incl = nrc_group_incl_prod<G>(1.0f - a, gl);
+    float excl = __shfl_up(incl, 1, G);
+    if (gl == 0) excl = 1.0f;
+    T_before = carry * excl;
+    T_after = carry * incl;
+    carry = __shfl(T_after, G - 1, G);
+}
+// index (within the G-lane group) of the first lane with valid && T_after <= thr, or G if none
+template <int G>
+__device__ __forceinline__ int first_saturated(bool sat, int lane) {
+    const unsigned long long m = __ballot(sat);
+    unsigned long long gm = m;
+    if constexpr (G < 64) gm = (m >> (lane & ~(G - 1))) & ((1ull << G) - 1ull);
+    return gm ? __ffsll((long long)gm) - 1 : G;
+}
+
+// ------------------------------------------------------------------------------------------------ train forward
+__global__ void __launch_bounds__(256) k_composite_train_fw(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                            const float* __restrict__ deltas, const float* __restrict__ ts,
+                                                            const int64_t* __restrict__ rays_a, int64_t n_rays, float thr,
+                                                            int64_t* __restrict__ total_samples, float* __restrict__ opacity,
+                                                            float* __restrict__ depth, float* __restrict__ rgb,
+                                                            float* __restrict__ ws) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_rays) return;
+    const int64_t ray_idx = rays_a[3 * n], start = rays_a[3 * n + 1];
+    const int N = (int)rays_a[3 * n + 2];
+    float carry = 1.0f, accR = 0.f, accG = 0.f, accB = 0.f, accD = 0.f, accO = 0.f;
+    int counted = N;
+    for (int c = 0; c < N; c += 64) {
+        const int i = c + lane;
+        const bool valid = i < N;
+        const int64_t s = start + i;
+        float a = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, tt = 0.f;
+        if (valid) {
+            a = alpha_of(sigmas[s], deltas[s]);
+            cr = rgbs[3 * s]; cg = rgbs[3 * s + 1]; cb = rgbs[3 * s + 2];
+            tt = ts[s];
+        }
+        float Tb, Ta;
+        chunk_transmittance<64>(a, lane, carry, Tb, Ta);
+        const int fs = first_saturated<64>(valid && Ta <= thr, lane);
+        if (valid && lane <= fs) {
+            const float w = a * Tb;
+            accR += w * cr; accG += w * cg; accB += w * cb; accD += w * tt; accO += w;
+            ws[s] = w;
+        }
+        if (fs < 64) { counted = c + fs; break; }  // the saturating sample is composited but not counted (:41-44)
+    }
+    accR = nrc_group_sum<64>(accR); accG = nrc_group_sum<64>(accG); accB = nrc_group_sum<64>(accB);
+    accD = nrc_group_sum<64>(accD); accO = nrc_group_sum<64>(accO);
+    if (lane == 0) {
+        rgb[3 * ray_idx] = accR; rgb[3 * ray_idx + 1] = accG; rgb[3 * ray_idx + 2] = accB;
+        depth[ray_idx] = accD; opacity[ray_idx] = accO;
+        total_samples[ray_idx] = counted;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ train backward
+__global__ void __launch_bounds__(256) k_composite_train_bw(
+    const float* __restrict__ dL_dopacity, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_drgb,
+    const float* __restrict__ dL_dws, const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+    const float* __restrict__ ws, const float* __restrict__ deltas, const float* __restrict__ ts,
+    const int64_t* __restrict__ rays_a, const float* __restrict__ opacity, const float* __restrict__ depth,
+    const float* __restrict__ rgb, int64_t n_rays, float thr, float* __restrict__ dL_dsigmas, float* __restrict__ dL_drgbs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_rays) return;
+    const int64_t ray_idx = rays_a[3 * n], start = rays_a[3 * n + 1];
+    const int N = (int)rays_a[3 * n + 2];
+    if (N <= 0) return;
+    const float R = rgb[3 * ray_idx], Gc = rgb[3 * ray_idx + 1], B = rgb[3 * ray_idx + 2];
+    const float O = opacity[ray_idx], D = depth[ray_idx];
+    const float gR = dL_drgb[3 * ray_idx], gG = dL_drgb[3 * ray_idx + 1], gB = dL_drgb[3 * ray_idx + 2];
+    const float gO = dL_dopacity[ray_idx], gD = dL_ddepth[ray_idx];
+    // pass 1: sum over the whole ray of dL_dws * ws  (volumerendering.cu:119-123)
+    float part = 0.f;
+    for (int c = lane; c < N; c += 64) part += dL_dws[start + c] * ws[start + c];
+    const float dws_sum = nrc_group_sum<64>(part);
+    // pass 2
+    float carry = 1.0f, cr_ = 0.f, cg_ = 0.f, cb_ = 0.f, cd_ = 0.f, cs_ = 0.f;  // running prefix carries
+    for (int c = 0; c < N; c += 64) {
+        const int i = c + lane;
+        const bool valid = i < N;
+        const int64_t s = start + i;
+        float a = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, tt = 0.f, dl = 0.f, gw = 0.f, wsv = 0.f;
+        if (valid) {
+            dl = deltas[s];
+            a = alpha_of(sigmas[s], dl);
+            sr = rgbs[3 * s]; sg = rgbs[3 * s + 1]; sb = rgbs[3 * s + 2];
+            tt = ts[s]; gw = dL_dws[s]; wsv = ws[s];
+        }
+        float Tb, Ta;
+        chunk_transmittance<64>(a, lane, carry, Tb, Ta);
+        const float w = a * Tb;
+        const float r = cr_ + nrc_group_incl_sum<64>(w * sr, lane);
+        const float g = cg_ + nrc_group_incl_sum<64>(w * sg, lane);
+        const float b = cb_ + nrc_group_incl_sum<64>(w * sb, lane);
+        const float d = cd_ + nrc_group_incl_sum<64>(w * tt, lane);
+        const float sc = cs_ + nrc_group_incl_sum<64>(gw * wsv, lane);
+        cr_ = __shfl(r, 63, 64); cg_ = __shfl(g, 63, 64); cb_ = __shfl(b, 63, 64); cd_ = __shfl(d, 63, 64); cs_ = __shfl(sc, 63, 64);
+        const int fs = first_saturated<64>(valid && Ta <= thr, lane);
+        if (valid && lane <= fs) {
+            dL_drgbs[3 * s] = gR * w; dL_drgbs[3 * s + 1] = gG * w; dL_drgbs[3 * s + 2] = gB * w;
+            dL_dsigmas[s] = dl * (gR * (sr * Ta - (R - r)) + gG * (sg * Ta - (Gc - g)) + gB * (sb * Ta - (B - b)) +
+                                  gO * (1 - O) + gD * (tt * Ta - (D - d)) + Ta * gw - (dws_sum - sc));
+        }
+        if (fs < 64) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ test forward
+// G lanes per alive ray (G = smallest power of two >= N_samples, capped at 64): rows of N_samples samples.
+template <int G>
+__global__ void __launch_bounds__(256) k_composite_test_fw(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                           const float* __restrict__ deltas, const float* __restrict__ ts,
+                                                           int64_t* __restrict__ alive, int64_t n_alive, int N_samples,
+                                                           float thr, const int32_t* __restrict__ n_eff,
+                                                           float* __restrict__ opacity, float* __restrict__ depth,
+                                                           float* __restrict__ rgb) {
+    const int lane = threadIdx.x & 63, gl = lane & (G - 1);
+    const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    // groups past the end still take part in the wave-wide ballots/shuffles below with N = 0
+    const bool live = n < n_alive;
+    const int N = live ? n_eff[n] : 0;
+    const int64_t r = live ? alive[n] : 0;
+    float carry = (live && N > 0) ? 1.0f - opacity[r] : 1.0f;
+    float accR = 0.f, accG = 0.f, accB = 0.f, accD = 0.f, accO = 0.f;
+    bool dead = false, done = N <= 0;
+    // all groups of a wave iterate together until every group is done (uniform trip count for the cross-lane ops)
+    const int maxN = [&] { int m = N; for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64)); return m; }();
+    for (int c = 0; c < maxN; c += G) {
+        const int i = c + gl;
+        const bool valid = !done && i < N;
+        const int64_t s = n * N_samples + i;
+        float a = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, tt = 0.f;
+        if (valid) {
+            a = alpha_of(sigmas[s], deltas[s]);
+            cr = rgbs[3 * s]; cg = rgbs[3 * s + 1]; cb = rgbs[3 * s + 2];
+            tt = ts[s];
+        }
+        float Tb, Ta;
+        chunk_transmittance<G>(a, gl, carry, Tb, Ta);
+        const int fs = first_saturated<G>(valid && Ta <= thr, lane);
+        if (valid && gl <= fs) {
+            const float w = a * Tb;
+            accR += w * cr; accG += w * cg; accB += w * cb; accD += w * tt; accO += w;
+        }
+        if (fs < G && !done) { dead = true; done = true; }
+        if (c + G >= N) done = true;
+    }
+    accR = nrc_group_sum<G>(accR); accG = nrc_group_sum<G>(accG); accB = nrc_group_sum<G>(accB);
+    accD = nrc_group_sum<G>(accD); accO = nrc_group_sum<G>(accO);
+    if (live && gl == 0) {
+        if (N == 0) { alive[n] = -1; return; }  // no hit (:222-225)
+        rgb[3 * r] += accR; rgb[3 * r + 1] += accG; rgb[3 * r + 2] += accB;
+        depth[r] += accD; opacity[r] += accO;
+        if (dead) alive[n] = -1;  // saturated (:243-246)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ distortion loss
+__global__ void __launch_bounds__(256) k_distortion_fw(const float* __restrict__ ws, const float* __restrict__ deltas,
+                                                       const float* __restrict__ ts, const int64_t* __restrict__ rays_a,
+                                                       int64_t n_rays, float* __restrict__ loss, float* __restrict__ ws_incl,
+                                                       float* __restrict__ wts_incl) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_rays) return;
+    const int64_t ray_idx = rays_a[3 * n], start = rays_a[3 * n + 1];
+    const int N = (int)rays_a[3 * n + 2];
+    float cw = 0.f, cwt = 0.f, acc = 0.f;
+    for (int c = 0; c < N; c += 64) {
+        const int i = c + lane;
+        const bool valid = i < N;
+        const int64_t s = start + i;
+        const float w = valid ? ws[s] : 0.f, dl = valid ? deltas[s] : 0.f, wt = valid ? w * ts[s] : 0.f;
+        const float wi = cw + nrc_group_incl_sum<64>(w, lane), wti = cwt + nrc_group_incl_sum<64>(wt, lane);
+        float we = __shfl_up(wi, 1, 64), wte = __shfl_up(wti, 1, 64);
+        if (lane == 0) { we = cw; wte = cwt; }
+        if (valid) {
+            ws_incl[s] = wi; wts_incl[s] = wti;
+            acc += 2 * (wti * we - wi * wte) + 1.0f / 3 * w * w * dl;
+        }
+        cw = __shfl(wi, 63, 64); cwt = __shfl(wti, 63, 64);
+    }
+    acc = nrc_group_sum<64>(acc);
+    if (lane == 0) loss[ray_idx] = acc;
+}
+__global__ void __launch_bounds__(256) k_distortion_bw(const float* __restrict__ dL_dloss, const float* __restrict__ ws_incl,
+                                                       const float* __restrict__ wts_incl, const float* __restrict__ ws,
+                                                       const float* __restrict__ deltas, const float* __restrict__ ts,
+                                                       const int64_t* __restrict__ rays_a, int64_t n_rays,
+                                                       float* __restrict__ dL_dws) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_rays) return;
+    const int64_t ray_idx = rays_a[3 * n], start = rays_a[3 * n + 1];
+    const int N = (int)rays_a[3 * n + 2];
+    if (N <= 0) return;
+    const int64_t end = start + N - 1;
+    const float ws_sum = ws_incl[end], wts_sum = wts_incl[end], g = dL_dloss[ray_idx];
+    for (int64_t s = start + lane; s <= end; s += 64) {
+        const float t = ts[s];
+        const float prev = s == start ? 0.0f : (t * ws_incl[s - 1] - wts_incl[s - 1]);
+        float v = g * 2 * (prev + (wts_sum - wts_incl[s] - t * (ws_sum - ws_incl[s])));
+        v += g * 2.0f / 3 * ws[s] * deltas[s];
+        dL_dws[s] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrc_composite_train_fw(const float* sigmas, const float* rgbs, const float* deltas, const float* ts, const int64_t* rays_a,
+                           int64_t n_rays, int64_t n_samples, float T_threshold, int64_t* total_samples, float* opacity,
+                           float* depth, float* rgb, float* ws, nrc_stream_t stream) {
+    if (n_rays < 0 || n_samples < 0) return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_samples > 0) { if (!ws) return NRC_ERR_INVALID; hipMemsetAsync(ws, 0, n_samples * sizeof(float), s); }
+    if (n_rays == 0) return NRC_OK;
+    if (!rays_a || !total_samples || !opacity || !depth || !rgb || (n_samples > 0 && (!sigmas || !rgbs || !deltas || !ts))) return NRC_ERR_INVALID;
+    // rows of rays_a name their output slot (ray_idx); slots never named keep the reference's zero initialisation
+    hipMemsetAsync(total_samples, 0, n_rays * sizeof(int64_t), s);
+    hipMemsetAsync(opacity, 0, n_rays * sizeof(float), s);
+    hipMemsetAsync(depth, 0, n_rays * sizeof(float), s);
+    hipMemsetAsync(rgb, 0, n_rays * 3 * sizeof(float), s);
+    hipLaunchKernelGGL(k_composite_train_fw, dim3(nrc_cdiv(n_rays, 4)), dim3(256), 0, s, sigmas, rgbs, deltas, ts, rays_a, n_rays,
+                       T_threshold, total_samples, opacity, depth, rgb, ws);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb, const float* dL_dws,
+                           const float* sigmas, const float* rgbs, const float* ws, const float* deltas, const float* ts,
+                           const int64_t* rays_a, const float* opacity, const float* depth, const float* rgb, int64_t n_rays,
+                           int64_t n_samples, float T_threshold, float* dL_dsigmas, float* dL_drgbs, nrc_stream_t stream) {
+    if (n_rays < 0 || n_samples < 0) return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_samples > 0) {
+        if (!dL_dsigmas || !dL_drgbs) return NRC_ERR_INVALID;
+        hipMemsetAsync(dL_dsigmas, 0, n_samples * sizeof(float), s);
+        hipMemsetAsync(dL_drgbs, 0, n_samples * 3 * sizeof(float), s);
+    }
+    if (n_rays == 0 || n_samples == 0) return NRC_OK;
+    if (!dL_dopacity || !dL_ddepth || !dL_drgb || !dL_dws || !sigmas || !rgbs || !ws || !deltas || !ts || !rays_a || !opacity || !depth || !rgb)
+        return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_composite_train_bw, dim3(nrc_cdiv(n_rays, 4)), dim3(256), 0, s, dL_dopacity, dL_ddepth, dL_drgb, dL_dws,
+                       sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb, n_rays, T_threshold, dL_dsigmas, dL_drgbs);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_composite_test_fw(const float* sigmas, const float* rgbs, const float* deltas, const float* ts, int64_t* alive,
+                          int64_t n_alive, int32_t N_samples, float T_threshold, const int32_t* n_eff, float* opacity,
+                          float* depth, float* rgb, nrc_stream_t stream) {
+    if (n_alive < 0 || N_samples < 1) return NRC_ERR_INVALID;
+    if (n_alive == 0) return NRC_OK;
+    if (!sigmas || !rgbs || !deltas || !ts || !alive || !n_eff || !opacity || !depth || !rgb) return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+#define NRC_CT(G)                                                                                                          \
+    hipLaunchKernelGGL(k_composite_test_fw<G>, dim3(nrc_cdiv(n_alive * G, 256)), dim3(256), 0, s, sigmas, rgbs, deltas, ts, \
+                       alive, n_alive, N_samples, T_threshold, n_eff, opacity, depth, rgb)
+    if (N_samples <= 1) NRC_CT(1);
+    else if (N_samples <= 2) NRC_CT(2);
+    else if (N_samples <= 4) NRC_CT(4);
+    else if (N_samples <= 8) NRC_CT(8);
+    else if (N_samples <= 16) NRC_CT(16);
+    else if (N_samples <= 32) NRC_CT(32);
+    else NRC_CT(64);
+#undef NRC_CT
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_distortion_loss_fw(const float* ws, const float* deltas, const float* ts, const int64_t* rays_a, int64_t n_rays,
+                           int64_t n_samples, float* loss, float* ws_incl, float* wts_incl, nrc_stream_t stream) {
+    if (n_rays < 0 || n_samples < 0) return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_samples > 0) {
+        if (!ws_incl || !wts_incl) return NRC_ERR_INVALID;
+        hipMemsetAsync(ws_incl, 0, n_samples * sizeof(float), s);
+        hipMemsetAsync(wts_incl, 0, n_samples * sizeof(float), s);
+    }
+    if (n_rays == 0) return NRC_OK;
+    if (!loss || !rays_a || (n_samples > 0 && (!ws || !deltas || !ts))) return NRC_ERR_INVALID;
+    hipMemsetAsync(loss, 0, n_rays * sizeof(float), s);
+    hipLaunchKernelGGL(k_distortion_fw, dim3(nrc_cdiv(n_rays, 4)), dim3(256), 0, s, ws, deltas, ts, rays_a, n_rays, loss, ws_incl, wts_incl);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_distortion_loss_bw(const float* dL_dloss, const float* ws_incl, const float* wts_incl, const float* ws,
+                           const float* deltas, const float* ts, const int64_t* rays_a, int64_t n_rays, int64_t n_samples,
+                           float* dL_dws, nrc_stream_t stream) {
+    if (n_rays < 0 || n_samples < 0) return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_samples > 0) { if (!dL_dws) return NRC_ERR_INVALID; hipMemsetAsync(dL_dws, 0, n_samples * sizeof(float), s); }
+    if (n_rays == 0 || n_samples == 0) return NRC_OK;
+    if (!dL_dloss || !ws_incl || !wts_incl || !ws || !deltas || !ts || !rays_a) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_distortion_bw, dim3(nrc_cdiv(n_rays, 4)), dim3(256), 0, s, dL_dloss, ws_incl, wts_incl, ws, deltas, ts,
+                       rays_a, n_rays, dL_dws);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,592 @@
+// ngp_march.hip -- occupancy-grid utilities, ray/box and ray/sphere intersection, DDA ray marching (train + test),
+// Morton codes and ray generation for gfx950.
+//
+// BUILD NOTE: this translation unit is compiled with -ffp-contract=off.  Everything here decides *indices* (which
+// cell, how many samples, where a ray starts) from f32 arithmetic, and the parity contract for indices is bit-exact
+// against oracle/ngp_oracle.c, which is built without FMA contraction as well.
+//
+// Reference semantics (never copied, restated for wave64 / deterministic compaction):
+//   raymarching.cu:11-60 (helpers) :62-161 (morton, packbits) :166-332 (train) :335-454 (test)
+//   intersection.cu:5-196, morton_encoding.cu:15-74, Cameras/Perspective.py:64-94, Datasets/utils.py:1033-1074
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+#define SQRT3 1.73205080757f
+
+namespace {
+
+__device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+__device__ __forceinline__ float signf_(float x) { return copysignf(1.0f, x); }
+
+__device__ __forceinline__ float calc_dt(float t, float esf, int max_samples, int grid_size, float scale) {
+    return clampf(t * esf, SQRT3 / max_samples, SQRT3 * 2 * scale / grid_size);
+}
+__device__ __forceinline__ int mip_from_pos(float x, float y, float z, int cascades) {
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int e; frexpf(mx, &e);
+    return min(cascades - 1, max(0, e + 1));
+}
+__device__ __forceinline__ int mip_from_dt(float dt, int grid_size, int cascades) {
+    int e; frexpf(dt * grid_size, &e);
+    return min(cascades - 1, max(0, e));
+}
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+__device__ __forceinline__ uint32_t morton3D_invert(uint32_t x) {
+    x = x & 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, dxi, dyi, dzi;
+};
+__device__ __forceinline__ Ray load_ray(const float* __restrict__ o, const float* __restrict__ d, int64_t r) {
+    Ray q;
+    q.ox = o[3 * r]; q.oy = o[3 * r + 1]; q.oz = o[3 * r + 2];
+    q.dx = d[3 * r]; q.dy = d[3 * r + 1]; q.dz = d[3 * r + 2];
+    q.dxi = 1.0f / q.dx; q.dyi = 1.0f / q.dy; q.dzi = 1.0f / q.dz;
+    return q;
+}
+
+struct MarchCfg {
+    const uint8_t* __restrict__ bitfield;
+    int cascades, grid_size, max_samples;
+    float scale, esf, dt_scale;  // dt_scale: `scale` (train) or `(float)cascades` (test kernel quirk, raymarching.cu:370)
+    uint32_t grid_size3;
+    float grid_size_inv;
+};
+
+// One DDA step.  Returns true when the cell containing o + t d is occupied (sample taken at t with step dt);
+// otherwise advances t to beyond the cell's exit face.  x,y,z,dt are outputs for the occupied case.
+__device__ __forceinline__ bool march_step(const Ray& q, const MarchCfg& c, float& t, float& x, float& y, float& z, float& dt) {
+    x = q.ox + t * q.dx; y = q.oy + t * q.dy; z = q.oz + t * q.dz;
+    dt = calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale);
+    const int mip = max(mip_from_pos(x, y, z, c.cascades), mip_from_dt(dt, c.grid_size, c.cascades));
+    const float mip_bound = fminf(scalbnf(1.0f, mip - 1), c.scale);
+    const float mip_bound_inv = 1 / mip_bound;
+    const int nx = (int)clampf(0.5f * (x * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
+    const int ny = (int)clampf(0.5f * (y * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
+    const int nz = (int)clampf(0.5f * (z * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
+    const uint32_t idx = (uint32_t)mip * c.grid_size3 + morton3D(nx, ny, nz);
+    const bool occ = c.bitfield[idx >> 3] & (1 << (idx & 7));
+    if (occ) return true;
+    const float tx = (((nx + 0.5f + 0.5f * signf_(q.dx)) * c.grid_size_inv * 2 - 1) * mip_bound - x) * q.dxi;
+    const float ty = (((ny + 0.5f + 0.5f * signf_(q.dy)) * c.grid_size_inv * 2 - 1) * mip_bound - y) * q.dyi;
+    const float tz = (((nz + 0.5f + 0.5f * signf_(q.dz)) * c.grid_size_inv * 2 - 1) * mip_bound - z) * q.dzi;
+    const float t_target = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    do { t += calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale); } while (t < t_target);
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------ small utilities
+__global__ void k_morton3D(const int32_t* __restrict__ coords, int64_t n, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (int32_t)morton3D(coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]);
+}
+__global__ void k_morton3D_invert(const int32_t* __restrict__ idx, int64_t n, int32_t* __restrict__ coords) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t ind = idx[i];  // arithmetic shifts on the signed value, like the reference (raymarching.cu:97-100)
+    coords[3 * i + 0] = (int32_t)morton3D_invert((uint32_t)(ind >> 0));
+    coords[3 * i + 1] = (int32_t)morton3D_invert((uint32_t)(ind >> 1));
+    coords[3 * i + 2] = (int32_t)morton3D_invert((uint32_t)(ind >> 2));
+}
+
+// packbits: one lane owns 8 consecutive cells = two 16-byte loads (f32) / one 16-byte load (f16), one byte out.
+// Four lanes are merged with DPP so that a lane quartet issues a single 4-byte store.
+template <typename T>
+__global__ void k_packbits_unaligned(const T* __restrict__ grid, int64_t n_bytes, float thr, uint8_t* __restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_bytes) return;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) bits |= (uint32_t)((float)grid[8 * n + i] > thr) << i;
+    out[n] = (uint8_t)bits;
+}
+template <typename T>
+__global__ void k_packbits(const T* __restrict__ grid, int64_t n_bytes, float thr, uint8_t* __restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bits = 0;
+    if (n < n_bytes) {
+        if constexpr (sizeof(T) == 4) {
+            const float4 a = reinterpret_cast<const float4*>(grid)[2 * n];
+            const float4 b = reinterpret_cast<const float4*>(grid)[2 * n + 1];
+            bits = (a.x > thr) | ((a.y > thr) << 1) | ((a.z > thr) << 2) | ((a.w > thr) << 3) | ((b.x > thr) << 4) |
+                   ((b.y > thr) << 5) | ((b.z > thr) << 6) | ((b.w > thr) << 7);
+        } else {
+            const uint4 raw = reinterpret_cast<const uint4*>(grid)[n];
+            const __half* h = reinterpret_cast<const __half*>(&raw);
+#pragma unroll
+            for (int i = 0; i < 8; i++) bits |= (uint32_t)(__half2float(h[i]) > thr) << i;
+        }
+    }
+    // gather the 4 bytes of a lane quartet into its first lane
+    const uint32_t b1 = __shfl_down(bits, 1, 4), b2 = __shfl_down(bits, 2, 4), b3 = __shfl_down(bits, 3, 4);
+    if ((threadIdx.x & 3) == 0 && n < n_bytes) {
+        if (n + 3 < n_bytes) reinterpret_cast<uint32_t*>(out)[n >> 2] = bits | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        else {
+            out[n] = (uint8_t)bits;
+            if (n + 1 < n_bytes) out[n + 1] = (uint8_t)b1;
+            if (n + 2 < n_bytes) out[n + 2] = (uint8_t)b2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ intersections
+__device__ __forceinline__ void sort_hits(float* ht, int64_t* hv, int max_hits) {
+    // ascending by t1 (unused -1 slots first), the order torch::sort gives the reference (intersection.cu:94-97)
+    for (int i = 1; i < max_hits; i++) {
+        const float a = ht[2 * i], b = ht[2 * i + 1];
+        const int64_t v = hv[i];
+        int j = i - 1;
+        while (j >= 0 && ht[2 * j] > a) {
+            ht[2 * j + 2] = ht[2 * j]; ht[2 * j + 3] = ht[2 * j + 1]; hv[j + 1] = hv[j];
+            j--;
+        }
+        ht[2 * j + 2] = a; ht[2 * j + 3] = b; hv[j + 1] = v;
+    }
+}
+
+// one lane per ray, loop over the (few) primitives: deterministic slot order (voxel order), no atomics.
+template <bool SPHERE>
+__global__ void k_ray_prim_intersect(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                     const float* __restrict__ centers, const float* __restrict__ ext, int64_t n_rays,
+                                     int64_t n_prims, int max_hits, int32_t* __restrict__ hit_cnt,
+                                     float* __restrict__ hits_t, int64_t* __restrict__ hits_idx) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
+    const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
+    float* ht = hits_t + r * max_hits * 2;
+    int64_t* hv = hits_idx + r * max_hits;
+    for (int i = 0; i < max_hits; i++) { ht[2 * i] = -1.0f; ht[2 * i + 1] = -1.0f; hv[i] = -1; }
+    int cnt = 0;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    for (int64_t v = 0; v < n_prims; v++) {
+        const float cx = centers[3 * v], cy = centers[3 * v + 1], cz = centers[3 * v + 2];
+        float t1, t2;
+        if constexpr (!SPHERE) {
+            const float hx = ext[3 * v], hy = ext[3 * v + 1], hz = ext[3 * v + 2];
+            const float ax = (cx - hx - ox) * ix, bx = (cx + hx - ox) * ix;
+            const float ay = (cy - hy - oy) * iy, by = (cy + hy - oy) * iy;
+            const float az = (cz - hz - oz) * iz, bz = (cz + hz - oz) * iz;
+            t1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+            t2 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            if (t1 > t2) { t1 = -1.0f; t2 = -1.0f; }
+        } else {
+            const float px = ox - cx, py = oy - cy, pz = oz - cz;
+            const float a = dx * dx + dy * dy + dz * dz;
+            const float half_b = dx * px + dy * py + dz * pz;
+            const float c = (px * px + py * py + pz * pz) - ext[v] * ext[v];
+            const float disc = half_b * half_b - a * c;
+            t1 = -1.0f; t2 = -1.0f;
+            if (!(disc < 0)) { const float sq = sqrtf(disc); t1 = (-half_b - sq) / a; t2 = (-half_b + sq) / a; }
+        }
+        if (t2 > 0) {
+            if (cnt < max_hits) { ht[2 * cnt] = fmaxf(t1, 0.0f); ht[2 * cnt + 1] = t2; hv[cnt] = v; }
+            cnt++;
+        }
+    }
+    hit_cnt[r] = cnt;
+    if (max_hits > 1) sort_hits(ht, hv, max_hits);
+}
+
+// ------------------------------------------------------------------------------------------------ ray marching (train)
+// Stage A: per-ray sample count (pass 1 of raymarching.cu:200-234) + per-block sums.
+__global__ void __launch_bounds__(256) k_march_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                     const float* __restrict__ hits_t, const float* __restrict__ noise,
+                                                     MarchCfg c, int64_t n_rays, int32_t* __restrict__ counts,
+                                                     int32_t* __restrict__ block_sums) {
+    __shared__ int smem[8];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int n = 0;
+    if (r < n_rays) {
+        const Ray q = load_ray(rays_o, rays_d, r);
+        float t1 = hits_t[2 * r];
+        const float t2 = hits_t[2 * r + 1];
+        if (t1 >= 0) t1 += calc_dt(t1, c.esf, c.max_samples, c.grid_size, c.scale) * noise[r];
+        float t = t1, x, y, z, dt;
+        while (0 <= t && t < t2 && n < c.max_samples) {
+            if (march_step(q, c, t, x, y, z, dt)) { t += dt; n++; }
+        }
+        counts[r] = n;
+    }
+    int total;
+    (void)nrc_block256_excl_scan_i(n, smem, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+// Stage B: exclusive scan of the block sums by ONE 1024-thread block (n_blocks <= a few thousand) -> block offsets, total.
+__global__ void __launch_bounds__(1024) k_scan_block_sums(int32_t* __restrict__ block_sums, int64_t n_blocks,
+                                                          int64_t n_rays, int32_t* __restrict__ counter) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_blocks; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int v = i < n_blocks ? block_sums[i] : 0;
+        const int incl = nrc_wave_incl_sum_i(v, lane);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int off = carry_s;
+        for (int w = 0; w < wave; w++) off += wave_tot[w];
+        if (i < n_blocks) block_sums[i] = off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { counter[0] = carry_s; counter[1] = (int32_t)n_rays; }
+}
+// Stage C: rays_a[r] = (r, block_offset + in-block exclusive scan, count)
+__global__ void __launch_bounds__(256) k_assign_rays_a(const int32_t* __restrict__ counts, const int32_t* __restrict__ block_offs,
+                                                       int64_t n_rays, int64_t* __restrict__ rays_a) {
+    __shared__ int smem[8];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n = r < n_rays ? counts[r] : 0;
+    const int excl = nrc_block256_excl_scan_i(n, smem, nullptr);
+    if (r < n_rays) {
+        rays_a[3 * r] = r;
+        rays_a[3 * r + 1] = (int64_t)block_offs[blockIdx.x] + excl;
+        rays_a[3 * r + 2] = n;
+    }
+}
+// Stage D: pass 2 (raymarching.cu:243-279): emit the samples of each ray into its reserved, contiguous segment.
+__global__ void __launch_bounds__(256) k_march_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                     const float* __restrict__ hits_t, const float* __restrict__ noise,
+                                                     MarchCfg c, int64_t n_rays, const int64_t* __restrict__ rays_a,
+                                                     float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                     float* __restrict__ deltas, float* __restrict__ ts) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_rays) return;
+    const int64_t r = rays_a[3 * n], start = rays_a[3 * n + 1];
+    const int N = (int)rays_a[3 * n + 2];
+    if (N == 0) return;
+    const Ray q = load_ray(rays_o, rays_d, r);
+    float t1 = hits_t[2 * r];
+    const float t2 = hits_t[2 * r + 1];
+    if (t1 >= 0) t1 += calc_dt(t1, c.esf, c.max_samples, c.grid_size, c.scale) * noise[r];
+    float t = t1, x, y, z, dt;
+    int s = 0;
+    while (t < t2 && s < N) {
+        if (march_step(q, c, t, x, y, z, dt)) {
+            const int64_t k = start + s;
+            xyzs[3 * k] = x; xyzs[3 * k + 1] = y; xyzs[3 * k + 2] = z;
+            dirs[3 * k] = q.dx; dirs[3 * k + 1] = q.dy; dirs[3 * k + 2] = q.dz;
+            ts[k] = t; deltas[k] = dt;
+            t += dt; s++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ray marching (test)
+__global__ void __launch_bounds__(256) k_march_test(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                    float* __restrict__ hits_t, const int64_t* __restrict__ alive,
+                                                    int64_t n_alive, MarchCfg c, int N_samples, float* __restrict__ xyzs,
+                                                    float* __restrict__ dirs, float* __restrict__ deltas,
+                                                    float* __restrict__ ts, int32_t* __restrict__ n_eff) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_alive) return;
+    const int64_t r = alive[n];
+    const Ray q = load_ray(rays_o, rays_d, r);
+    float t = hits_t[2 * r];
+    const float t2 = hits_t[2 * r + 1];
+    float x, y, z, dt, t_next = t;
+    int s = 0;
+    const int64_t base = n * N_samples;
+    while (t < t2 && s < N_samples) {
+        if (march_step(q, c, t, x, y, z, dt)) {
+            const int64_t k = base + s;
+            xyzs[3 * k] = x; xyzs[3 * k + 1] = y; xyzs[3 * k + 2] = z;
+            dirs[3 * k] = q.dx; dirs[3 * k + 1] = q.dy; dirs[3 * k + 2] = q.dz;
+            ts[k] = t; deltas[k] = dt;
+            t += dt; s++;
+            t_next = t;  // the reference stores t after every ACCEPTED sample only (raymarching.cu:390)
+        }
+    }
+    if (s > 0) hits_t[2 * r] = t_next;
+    n_eff[n] = s;
+    // the reference returns torch::zeros outputs: clear the unused tail of this ray's rows
+    for (int k = s; k < N_samples; k++) {
+        const int64_t j = base + k;
+        xyzs[3 * j] = 0.f; xyzs[3 * j + 1] = 0.f; xyzs[3 * j + 2] = 0.f;
+        dirs[3 * j] = 0.f; dirs[3 * j + 1] = 0.f; dirs[3 * j + 2] = 0.f;
+        ts[j] = 0.f; deltas[j] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 63-bit Morton codes
+__device__ __forceinline__ uint64_t split_by_3(uint32_t a) {
+    uint64_t x = a & 0x1fffff;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+// grid-stride min/max; partial[b*6 + {0..2}] = min xyz, {3..5} = max xyz
+__global__ void __launch_bounds__(256) k_bounds_partial(const float* __restrict__ pos, int64_t n, float* __restrict__ partial) {
+    __shared__ float sm[4][6];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const float v = pos[3 * i + k]; mn[k] = fminf(mn[k], v); mx[k] = fmaxf(mx[k], v); }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { mn[k] = wave_min(mn[k]); mx[k] = wave_max(mx[k]); }
+    if (lane == 0) { for (int k = 0; k < 3; k++) { sm[wave][k] = mn[k]; sm[wave][3 + k] = mx[k]; } }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sm[0][threadIdx.x];
+        for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
+        partial[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+// final[0..2] = min, final[3] = cube size (max extent)
+__global__ void __launch_bounds__(64) k_bounds_final(const float* __restrict__ partial, int n_partial, float* __restrict__ fin) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = threadIdx.x; i < n_partial; i += 64) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], partial[i * 6 + k]); mx[k] = fmaxf(mx[k], partial[i * 6 + 3 + k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { mn[k] = wave_min(mn[k]); mx[k] = wave_max(mx[k]); }
+    if (threadIdx.x == 0) {
+        fin[0] = mn[0]; fin[1] = mn[1]; fin[2] = mn[2];
+        fin[3] = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
+    }
+}
+__global__ void k_morton_encode(const float* __restrict__ pos, int64_t n, const float* __restrict__ fin, int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float rcp = 1.0f / fin[3];
+    const float factor = 2097151.0f;
+    // __saturatef semantics: clamp to [0,1], NaN -> 0
+    const float nx = fminf(fmaxf((pos[3 * i] - fin[0]) * rcp, 0.0f), 1.0f);
+    const float ny = fminf(fmaxf((pos[3 * i + 1] - fin[1]) * rcp, 0.0f), 1.0f);
+    const float nz = fminf(fmaxf((pos[3 * i + 2] - fin[2]) * rcp, 0.0f), 1.0f);
+    const uint32_t x = (uint32_t)(nx * factor), y = (uint32_t)(ny * factor), z = (uint32_t)(nz * factor);
+    out[i] = (int64_t)(split_by_3(x) | split_by_3(y) << 1 | split_by_3(z) << 2);
+}
+
+// ------------------------------------------------------------------------------------------------ ray generation
+struct RayGenCfg {
+    int width, height;
+    float min_x, max_x, min_y, max_y, step_x, step_y;  // torch.linspace(start, end, steps) in f32
+    float R[9], pos[3];                                // c2w rotation (row-major) and position as f32
+};
+// torch.linspace f32 device formula: idx < steps/2 ? start + step*idx : end - step*(steps-idx-1)
+__device__ __forceinline__ float linspace_at(float start, float end, float step, int steps, int idx) {
+    return idx < steps / 2 ? start + step * idx : end - step * (steps - idx - 1);
+}
+__global__ void __launch_bounds__(256) k_generate_rays(RayGenCfg g, float* __restrict__ origin, float* __restrict__ direction,
+                                                       float* __restrict__ view_dir) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = (int64_t)g.width * g.height;
+    if (i >= n) return;
+    const int px = (int)(i % g.width), py = (int)(i / g.width);
+    const float lx = linspace_at(g.min_x, g.max_x, g.step_x, g.width, px);
+    const float ly = linspace_at(g.min_y, g.max_y, g.step_y, g.height, py);
+    // dir = local @ R^T  (Datasets/utils.py:1035): dir[k] = sum_j local[j] * R[k][j], local = (lx, ly, 1)
+    const float dx = lx * g.R[0] + ly * g.R[1] + g.R[2];
+    const float dy = lx * g.R[3] + ly * g.R[4] + g.R[5];
+    const float dz = lx * g.R[6] + ly * g.R[7] + g.R[8];
+    if (direction) { direction[3 * i] = dx; direction[3 * i + 1] = dy; direction[3 * i + 2] = dz; }
+    if (origin) { origin[3 * i] = g.pos[0]; origin[3 * i + 1] = g.pos[1]; origin[3 * i + 2] = g.pos[2]; }
+    if (view_dir) {
+        // torch.nn.functional.normalize: v / max(||v||_2, 1e-12)
+        const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+        view_dir[3 * i] = dx / nrm; view_dir[3 * i + 1] = dy / nrm; view_dir[3 * i + 2] = dz / nrm;
+    }
+}
+
+MarchCfg make_cfg(const uint8_t* bitfield, int cascades, float scale, float esf, int grid_size, int max_samples, float dt_scale) {
+    MarchCfg c;
+    c.bitfield = bitfield; c.cascades = cascades; c.grid_size = grid_size; c.max_samples = max_samples;
+    c.scale = scale; c.esf = esf; c.dt_scale = dt_scale;
+    c.grid_size3 = (uint32_t)grid_size * grid_size * grid_size;
+    c.grid_size_inv = 1.0f / grid_size;
+    return c;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+int nrc_morton3D(const int32_t* coords, int64_t n, int32_t* indices, nrc_stream_t stream) {
+    if (n < 0 || (n > 0 && (!coords || !indices))) return NRC_ERR_INVALID;
+    if (n == 0) return NRC_OK;
+    hipLaunchKernelGGL(k_morton3D, dim3(nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, coords, n, indices);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_morton3D_invert(const int32_t* indices, int64_t n, int32_t* coords, nrc_stream_t stream) {
+    if (n < 0 || (n > 0 && (!coords || !indices))) return NRC_ERR_INVALID;
+    if (n == 0) return NRC_OK;
+    hipLaunchKernelGGL(k_morton3D_invert, dim3(nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, indices, n, coords);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_packbits(const void* grid, int32_t grid_dtype, int64_t n_bytes, float thr, uint8_t* bitfield, nrc_stream_t stream) {
+    if (n_bytes < 0 || (n_bytes > 0 && (!grid || !bitfield)) || (grid_dtype != 0 && grid_dtype != 1)) return NRC_ERR_INVALID;
+    if (n_bytes == 0) return NRC_OK;
+    const bool aligned = (((uintptr_t)grid & 15) == 0) && (((uintptr_t)bitfield & 3) == 0);
+    if (!aligned) {
+        if (grid_dtype == 0)
+            hipLaunchKernelGGL(k_packbits_unaligned<float>, dim3(nrc_cdiv(n_bytes, 256)), dim3(256), 0, (hipStream_t)stream,
+                               (const float*)grid, n_bytes, thr, bitfield);
+        else
+            hipLaunchKernelGGL(k_packbits_unaligned<__half>, dim3(nrc_cdiv(n_bytes, 256)), dim3(256), 0, (hipStream_t)stream,
+                               (const __half*)grid, n_bytes, thr, bitfield);
+    } else if (grid_dtype == 0)
+        hipLaunchKernelGGL(k_packbits<float>, dim3(nrc_cdiv(n_bytes, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)grid, n_bytes, thr, bitfield);
+    else
+        hipLaunchKernelGGL(k_packbits<__half>, dim3(nrc_cdiv(n_bytes, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const __half*)grid, n_bytes, thr, bitfield);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_ray_aabb_intersect(const float* rays_o, const float* rays_d, const float* centers, const float* half_sizes,
+                           int64_t n_rays, int64_t n_voxels, int32_t max_hits, int32_t* hit_cnt, float* hits_t,
+                           int64_t* hits_voxel_idx, nrc_stream_t stream) {
+    if (n_rays < 0 || n_voxels < 0 || max_hits < 1) return NRC_ERR_INVALID;
+    if (n_rays == 0) return NRC_OK;
+    if (!rays_o || !rays_d || !hit_cnt || !hits_t || !hits_voxel_idx || (n_voxels > 0 && (!centers || !half_sizes))) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_ray_prim_intersect<false>, dim3(nrc_cdiv(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
+                       rays_d, centers, half_sizes, n_rays, n_voxels, max_hits, hit_cnt, hits_t, hits_voxel_idx);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_ray_sphere_intersect(const float* rays_o, const float* rays_d, const float* centers, const float* radii,
+                             int64_t n_rays, int64_t n_spheres, int32_t max_hits, int32_t* hit_cnt, float* hits_t,
+                             int64_t* hits_sphere_idx, nrc_stream_t stream) {
+    if (n_rays < 0 || n_spheres < 0 || max_hits < 1) return NRC_ERR_INVALID;
+    if (n_rays == 0) return NRC_OK;
+    if (!rays_o || !rays_d || !hit_cnt || !hits_t || !hits_sphere_idx || (n_spheres > 0 && (!centers || !radii))) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_ray_prim_intersect<true>, dim3(nrc_cdiv(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
+                       rays_d, centers, radii, n_rays, n_spheres, max_hits, hit_cnt, hits_t, hits_sphere_idx);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int64_t nrc_raymarching_train_ws_bytes(int64_t n_rays) {
+    if (n_rays < 0) return NRC_ERR_INVALID;
+    // counts[n_rays] + block_sums[ceil(n_rays/256)], both i32, 256-byte aligned sections
+    const int64_t a = (n_rays * 4 + 255) / 256 * 256;
+    const int64_t b = (nrc_cdiv(n_rays, 256) * 4 + 255) / 256 * 256;
+    return a + b + 256;
+}
+int nrc_raymarching_train_count(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* bitfield,
+                                int32_t cascades, float scale, float esf, const float* noise, int32_t grid_size,
+                                int32_t max_samples, int64_t n_rays, int64_t* rays_a, int32_t* counter, void* workspace,
+                                nrc_stream_t stream) {
+    if (n_rays < 0 || !counter || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_rays == 0) { hipMemsetAsync(counter, 0, 8, s); return NRC_OK; }
+    if (!rays_o || !rays_d || !hits_t || !bitfield || !noise || !rays_a || !workspace) return NRC_ERR_INVALID;
+    const int64_t nb = nrc_cdiv(n_rays, 256);
+    int32_t* counts = (int32_t*)workspace;
+    int32_t* block_sums = (int32_t*)((char*)workspace + (n_rays * 4 + 255) / 256 * 256);
+    const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, scale);
+    hipLaunchKernelGGL(k_march_count, dim3(nb), dim3(256), 0, s, rays_o, rays_d, hits_t, noise, c, n_rays, counts, block_sums);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, n_rays, counter);
+    hipLaunchKernelGGL(k_assign_rays_a, dim3(nb), dim3(256), 0, s, counts, block_sums, n_rays, rays_a);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_raymarching_train_write(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* bitfield,
+                                int32_t cascades, float scale, float esf, const float* noise, int32_t grid_size,
+                                int32_t max_samples, int64_t n_rays, const int64_t* rays_a, float* xyzs, float* dirs,
+                                float* deltas, float* ts, nrc_stream_t stream) {
+    if (n_rays < 0 || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
+    if (n_rays == 0) return NRC_OK;
+    if (!rays_o || !rays_d || !hits_t || !bitfield || !noise || !rays_a) return NRC_ERR_INVALID;
+    const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, scale);
+    hipLaunchKernelGGL(k_march_write, dim3(nrc_cdiv(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, hits_t,
+                       noise, c, n_rays, rays_a, xyzs, dirs, deltas, ts);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t, const int64_t* alive, int64_t n_alive,
+                         const uint8_t* bitfield, int32_t cascades, float scale, float esf, int32_t grid_size,
+                         int32_t max_samples, int32_t N_samples, float* xyzs, float* dirs, float* deltas, float* ts,
+                         int32_t* n_eff, nrc_stream_t stream) {
+    if (n_alive < 0 || cascades < 1 || grid_size < 1 || max_samples < 1 || N_samples < 1) return NRC_ERR_INVALID;
+    if (n_alive == 0) return NRC_OK;
+    if (!rays_o || !rays_d || !hits_t || !alive || !bitfield || !xyzs || !dirs || !deltas || !ts || !n_eff) return NRC_ERR_INVALID;
+    const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, (float)cascades);
+    hipLaunchKernelGGL(k_march_test, dim3(nrc_cdiv(n_alive, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, hits_t,
+                       alive, n_alive, c, N_samples, xyzs, dirs, deltas, ts, n_eff);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int64_t nrc_morton_encode_ws_bytes(int64_t n) {
+    (void)n;
+    return (1024 * 6 + 4) * (int64_t)sizeof(float);
+}
+int nrc_morton_encode(const float* positions, int64_t n, int64_t* codes, void* workspace, nrc_stream_t stream) {
+    if (n < 0) return NRC_ERR_INVALID;
+    if (n == 0) return NRC_OK;
+    if (!positions || !codes || !workspace) return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    float* fin = partial + 1024 * 6;
+    const int nb = (int)(nrc_cdiv(n, 256) < 1024 ? nrc_cdiv(n, 256) : 1024);
+    hipLaunchKernelGGL(k_bounds_partial, dim3(nb), dim3(256), 0, s, positions, n, partial);
+    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, s, partial, nb, fin);
+    hipLaunchKernelGGL(k_morton_encode, dim3(nrc_cdiv(n, 256)), dim3(256), 0, s, positions, n, fin, codes);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_generate_rays(int32_t width, int32_t height, const double* intr, const double* c2w, float* origin, float* direction,
+                      float* view_direction, nrc_stream_t stream) {
+    if (width < 1 || height < 1 || !intr || !c2w) return NRC_ERR_INVALID;
+    RayGenCfg g;
+    g.width = width; g.height = height;
+    const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+    // Perspective.py:73-79 (python doubles, rounded to f32 when torch.linspace materialises its scalars)
+    g.min_x = (float)((0.5 - cx) / fx); g.max_x = (float)((width - 1 + 0.5 - cx) / fx);
+    g.min_y = (float)((0.5 - cy) / fy); g.max_y = (float)((height - 1 + 0.5 - cy) / fy);
+    g.step_x = width > 1 ? (g.max_x - g.min_x) / (float)(width - 1) : 0.0f;
+    g.step_y = height > 1 ? (g.max_y - g.min_y) / (float)(height - 1) : 0.0f;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) g.R[3 * r + c] = (float)c2w[4 * r + c];
+        g.pos[r] = (float)c2w[4 * r + 3];
+    }
+    const int64_t n = (int64_t)width * height;
+    hipLaunchKernelGGL(k_generate_rays, dim3(nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, g, origin, direction, view_direction);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+"""oracle -- Python face of the CPU oracle (oracle/*.c built into oracle/liboracle.so by oracle/Makefile).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg. The
+product package nerficg_amd never imports this module.  All functions take and return numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from functools import lru_cache
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / 'liboracle.so'
+
+f32, i32, i64, u8 = np.float32, np.int32, np.int64, np.uint8
+_P = ctypes.c_void_p
+
+
+def build(force: bool = False) -> Path:
+    srcs = sorted(HERE.glob('*.c'))
+    if force or not LIB.exists() or any(s.stat().st_mtime > LIB.stat().st_mtime for s in srcs + [HERE / 'Makefile']):
+        subprocess.run(['make', '-C', str(HERE), '-B', 'liboracle.so'], check=True, capture_output=True)
+    return LIB
+
+
+@lru_cache(maxsize=1)
+def lib() -> ctypes.CDLL:
+    build()
+    return ctypes.CDLL(str(LIB))
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_P)
+
+
+def _call(name, *args, restype=None):
+    fn = getattr(lib(), name)
+    fn.restype = restype
+    conv = []
+    for a in args:
+        if isinstance(a, np.ndarray):
+            conv.append(_p(a))
+        elif isinstance(a, float):
+            conv.append(ctypes.c_float(a))
+        elif isinstance(a, (int, np.integer)):
+            conv.append(ctypes.c_int64(int(a)))
+        elif a is None:
+            conv.append(None)
+        else:
+            conv.append(a)
+    return fn(*conv)
+
+
+def _i(v):  # C `int` argument
+    return ctypes.c_int(int(v))
+
+
+# ------------------------------------------------------------------------------------------------ VolumeRenderingV2
+def morton3D(coords):
+    coords = _c(coords, i32)
+    out = np.empty(coords.shape[0], i32)
+    _call('oracle_morton3D', coords, coords.shape[0], out)
+    return out
+
+
+def morton3D_invert(indices):
+    indices = _c(indices, i32)
+    out = np.empty((indices.shape[0], 3), i32)
+    _call('oracle_morton3D_invert', indices, indices.shape[0], out)
+    return out
+
+
+def packbits(grid, thr):
+    grid = _c(grid, f32).reshape(-1)
+    out = np.empty(grid.size // 8, u8)
+    _call('oracle_packbits', grid, out.size, float(thr), out)
+    return out
+
+
+def ray_aabb_intersect(rays_o, rays_d, centers, half_sizes, max_hits):
+    rays_o, rays_d, centers, half_sizes = _c(rays_o, f32), _c(rays_d, f32), _c(centers, f32), _c(half_sizes, f32)
+    n = rays_o.shape[0]
+    cnt, ht, hv = np.empty(n, i32), np.empty((n, max_hits, 2), f32), np.empty((n, max_hits), i64)
+    _call('oracle_ray_aabb_intersect', rays_o, rays_d, centers, half_sizes, n, centers.shape[0], _i(max_hits), cnt, ht, hv)
+    return cnt, ht, hv
+
+
+def ray_sphere_intersect(rays_o, rays_d, centers, radii, max_hits):
+    rays_o, rays_d, centers, radii = _c(rays_o, f32), _c(rays_d, f32), _c(centers, f32), _c(radii, f32)
+    n = rays_o.shape[0]
+    cnt, ht, hv = np.empty(n, i32), np.empty((n, max_hits, 2), f32), np.empty((n, max_hits), i64)
+    _call('oracle_ray_sphere_intersect', rays_o, rays_d, centers, radii, n, centers.shape[0], _i(max_hits), cnt, ht, hv)
+    return cnt, ht, hv
+
+
+def raymarching_train(rays_o, rays_d, hits_t, bitfield, cascades, scale, exp_step_factor, noise, grid_size, max_samples):
+    rays_o, rays_d, hits_t, noise = _c(rays_o, f32), _c(rays_d, f32), _c(hits_t, f32), _c(noise, f32)
+    bitfield = _c(bitfield, u8)
+    n = rays_o.shape[0]
+    common = (rays_o, rays_d, hits_t, bitfield, _i(cascades), float(scale), float(exp_step_factor), noise, _i(grid_size),
+              _i(max_samples), n)
+    total = _call('oracle_raymarching_train', *common, None, None, None, None, None, None, restype=ctypes.c_int64)
+    rays_a = np.empty((n, 3), i64)
+    xyzs, dirs = np.zeros((total, 3), f32), np.zeros((total, 3), f32)
+    deltas, ts = np.zeros(total, f32), np.zeros(total, f32)
+    counter = np.zeros(2, i32)
+    _call('oracle_raymarching_train', *common, rays_a, xyzs, dirs, deltas, ts, counter, restype=ctypes.c_int64)
+    return rays_a, xyzs, dirs, deltas, ts, counter
+
+
+def raymarching_test(rays_o, rays_d, hits_t, alive, bitfield, cascades, scale, exp_step_factor, grid_size, max_samples, N_samples):
+    """hits_t is modified in place (must be a contiguous float32 array)."""
+    rays_o, rays_d, alive, bitfield = _c(rays_o, f32), _c(rays_d, f32), _c(alive, i64), _c(bitfield, u8)
+    assert hits_t.dtype == f32 and hits_t.flags.c_contiguous
+    a = alive.shape[0]
+    xyzs, dirs = np.zeros((a, N_samples, 3), f32), np.zeros((a, N_samples, 3), f32)
+    deltas, ts = np.zeros((a, N_samples), f32), np.zeros((a, N_samples), f32)
+    n_eff = np.zeros(a, i32)
+    _call('oracle_raymarching_test', rays_o, rays_d, hits_t, alive, a, bitfield, _i(cascades), float(scale),
+          float(exp_step_factor), _i(grid_size), _i(max_samples), _i(N_samples), xyzs, dirs, deltas, ts, n_eff)
+    return xyzs, dirs, deltas, ts, n_eff
+
+
+def composite_train_fw(sigmas, rgbs, deltas, ts, rays_a, T_threshold):
+    sigmas, rgbs, deltas, ts, rays_a = _c(sigmas, f32), _c(rgbs, f32), _c(deltas, f32), _c(ts, f32), _c(rays_a, i64)
+    n, m = rays_a.shape[0], sigmas.shape[0]
+    total, opacity, depth, rgb, ws = np.empty(n, i64), np.empty(n, f32), np.empty(n, f32), np.empty((n, 3), f32), np.empty(m, f32)
+    _call('oracle_composite_train_fw', sigmas, rgbs, deltas, ts, rays_a, n, m, float(T_threshold), total, opacity, depth, rgb, ws)
+    return total, opacity, depth, rgb, ws
+
+
+def composite_train_bw(dL_dopacity, dL_ddepth, dL_drgb, dL_dws, sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb, T_threshold):
+    a = [_c(x, f32) for x in (dL_dopacity, dL_ddepth, dL_drgb, dL_dws, sigmas, rgbs, ws, deltas, ts)]
+    rays_a = _c(rays_a, i64)
+    b = [_c(x, f32) for x in (opacity, depth, rgb)]
+    n, m = rays_a.shape[0], a[4].shape[0]
+    ds, dr = np.empty(m, f32), np.empty((m, 3), f32)
+    _call('oracle_composite_train_bw', *a, rays_a, *b, n, m, float(T_threshold), ds, dr)
+    return ds, dr
+
+
+def composite_test_fw(sigmas, rgbs, deltas, ts, alive, T_threshold, n_eff, opacity, depth, rgb):
+    """alive / opacity / depth / rgb are modified in place."""
+    sigmas, rgbs, deltas, ts, n_eff = _c(sigmas, f32), _c(rgbs, f32), _c(deltas, f32), _c(ts, f32), _c(n_eff, i32)
+    for arr, dt in ((alive, i64), (opacity, f32), (depth, f32), (rgb, f32)):
+        assert arr.dtype == dt and arr.flags.c_contiguous
+    _call('oracle_composite_test_fw', sigmas, rgbs, deltas, ts, alive, alive.shape[0], _i(sigmas.shape[1]), float(T_threshold),
+          n_eff, opacity, depth, rgb)
+
+
+def distortion_loss_fw(ws, deltas, ts, rays_a):
+    ws, deltas, ts, rays_a = _c(ws, f32), _c(deltas, f32), _c(ts, f32), _c(rays_a, i64)
+    n, m = rays_a.shape[0], ws.shape[0]
+    loss, wi, wti = np.empty(n, f32), np.empty(m, f32), np.empty(m, f32)
+    _call('oracle_distortion_loss_fw', ws, deltas, ts, rays_a, n, m, loss, wi, wti)
+    return loss, wi, wti
+
+
+def distortion_loss_bw(dL_dloss, ws_incl, wts_incl, ws, deltas, ts, rays_a):
+    a = [_c(x, f32) for x in (dL_dloss, ws_incl, wts_incl, ws, deltas, ts)]
+    rays_a = _c(rays_a, i64)
+    out = np.empty(a[3].shape[0], f32)
+    _call('oracle_distortion_loss_bw', *a, rays_a, rays_a.shape[0], a[3].shape[0], out)
+    return out
+
+
+def morton_encode(positions):
+    positions = _c(positions, f32)
+    out = np.empty(positions.shape[0], i64)
+    _call('oracle_morton_encode', positions, positions.shape[0], out)
+    return out

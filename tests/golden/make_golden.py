@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the *reference's own* pure-PyTorch code.
+
+Runs ONLY in the build container (needs /root/reference). The reference never travels to the GPU box;
+what travels are the small .npz fixtures this script writes next to itself. Recipe = SURVEY.md Appendix B.
+
+Vectors produced (reference symbol -> fixture):
+  PerspectiveCamera.compute_local_ray_directions / View.get_rays   -> raygen.npz          (a1, a2)
+  PerspectiveCamera.get_projection_matrix + GS settings marshalling -> projection.npz      (a24)
+  FrequencyEncoding.forward                                         -> freqenc.npz         (a5)
+  generate_samples / generate_samples_from_pdf / integrate_samples  -> nerf_sampling.npz   (a7-a9)
+  convert_sh_features / build_covariances / quaternion_to_rotation  -> gs_utils.npz        (a26)
+  LRDecayPolicy, apply_background_color, RandomSequentialSampler    -> misc.npz
+"""
+import importlib.util
+import math
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path('/root/reference/src')
+OUT = Path(__file__).resolve().parent
+
+
+def install_shims():
+    class Munch(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+        def __delattr__(self, k):
+            del self[k]
+
+        @classmethod
+        def fromDict(cls, d):
+            out = cls()
+            for k, v in d.items():
+                out[k] = cls.fromDict(v) if isinstance(v, dict) else v
+            return out
+
+        def toDict(self):
+            return {k: (v.toDict() if isinstance(v, Munch) else v) for k, v in self.items()}
+
+        def copy(self):
+            return type(self).fromDict(self.toDict())
+
+    m = types.ModuleType('munch')
+    m.Munch = Munch
+    sys.modules['munch'] = m
+
+    def stub(name, **attrs):
+        mod = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(mod, k, v)
+        sys.modules[name] = mod
+        return mod
+
+    stub('natsort', natsorted=sorted)
+    stub('plyfile', PlyData=object, PlyElement=object)
+    tv = stub('torchvision')
+    tv.io = stub('torchvision.io')
+    tv.utils = stub('torchvision.utils', _normalized_flow_to_image=None)
+    tm = stub('torchmetrics', Metric=type('Metric', (), {}))
+    tm.image = stub('torchmetrics.image')
+    tm.functional = stub('torchmetrics.functional', peak_signal_noise_ratio=None)
+    tm.functional.image = stub('torchmetrics.functional.image', peak_signal_noise_ratio=None)
+
+
+def main():
+    install_shims()
+    sys.path.insert(0, str(REF))
+    import Framework
+    defaults = dict(RANDOM_SEED=1618033989, ANOMALY_DETECTION=False)
+    Framework.config = Framework.ConfigWrapper.fromDict({
+        'GLOBAL': {**defaults, 'GPU_INDICES': None, 'DEFAULT_DEVICE': torch.device('cpu'), 'METHOD_TYPE': 'NeRF'},
+        'TRAINING': {'WANDB': {'ACTIVATE': False}},
+    })
+    from Cameras.Perspective import PerspectiveCamera
+    from Cameras.utils import SharedCameraSettings, fov_to_focal, quaternion_to_rotation_matrix
+    from Datasets.utils import View, apply_background_color
+    from Methods.NeRF.utils import FrequencyEncoding, generate_samples, generate_samples_from_pdf, integrate_samples
+    from Optim.lr_utils import LRDecayPolicy
+    from Optim.Samplers.utils import RandomSequentialSampler
+
+    spec = importlib.util.spec_from_file_location('gs_utils', REF / 'Methods/GaussianSplatting/utils.py')
+    gs_utils = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gs_utils)
+
+    g = torch.Generator().manual_seed(0)
+
+    # ---------------------------------------------------------------- raygen (a1, a2)
+    def lookat_pose(theta, phi, radius):
+        # camera on an orbit, looking at the origin; colmap convention: x right, y down, z forward
+        pos = np.array([radius * math.cos(phi) * math.cos(theta), radius * math.sin(phi), radius * math.cos(phi) * math.sin(theta)])
+        fwd = -pos / np.linalg.norm(pos)
+        up = np.array([0.0, -1.0, 0.0])
+        right = np.cross(fwd, up)
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        c2w = np.eye(4)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, pos
+        return c2w.astype(np.float64)
+
+    ray_cases = {}
+    for tag, (w, h) in {'64': (64, 64), '800': (800, 800), '53x31': (53, 31)}.items():
+        settings = SharedCameraSettings(background_color=torch.tensor([1.0, 1.0, 1.0]), near_plane=2.0, far_plane=6.0)
+        focal = fov_to_focal(0.6911112070083618) * w
+        cam = PerspectiveCamera(shared_settings=settings, width=w, height=h, focal_x=focal, focal_y=focal)
+        if tag == '53x31':
+            cam = PerspectiveCamera(shared_settings=settings, width=w, height=h, focal_x=focal, focal_y=focal * 1.1,
+                                    center_x=w / 2 + 1.25, center_y=h / 2 - 0.75)
+        c2w = lookat_pose(0.7, 0.4, 4.0311)
+        view = View(camera=cam, camera_index=0, frame_idx=0, global_frame_idx=0, c2w=c2w)
+        rays = view.get_rays()
+        local = cam.compute_local_ray_directions()
+        if tag == '800':  # keep fixture small: corner / centre / a strided subset
+            idx = torch.cat([torch.tensor([0, 799, 800 * 799, 800 * 800 - 1, 800 * 400 + 400]), torch.arange(0, 640000, 6397)])
+        else:
+            idx = torch.arange(w * h)
+        ray_cases[f'{tag}_intr'] = np.array([w, h, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y], dtype=np.float64)
+        ray_cases[f'{tag}_c2w'] = c2w
+        ray_cases[f'{tag}_idx'] = idx.numpy()
+        ray_cases[f'{tag}_local'] = local[idx].numpy()
+        ray_cases[f'{tag}_origin'] = rays.origin[idx].numpy()
+        ray_cases[f'{tag}_direction'] = rays.direction[idx].numpy()
+        ray_cases[f'{tag}_view_direction'] = rays.view_direction[idx].numpy()
+    np.savez_compressed(OUT / 'raygen.npz', **ray_cases)
+
+    # ---------------------------------------------------------------- projection / GS settings (a24)
+    settings = SharedCameraSettings(background_color=torch.tensor([0.0, 0.0, 0.0]), near_plane=0.01, far_plane=100.0)
+    cam = PerspectiveCamera(shared_settings=settings, width=1297, height=840, focal_x=1160.3, focal_y=1158.9, center_x=650.1, center_y=418.7)
+    c2w = lookat_pose(1.1, 0.3, 3.5)
+    view = View(camera=cam, camera_index=0, frame_idx=0, global_frame_idx=0, c2w=c2w)
+    P = cam.get_projection_matrix()
+    w2cT = view.w2c.T
+    np.savez_compressed(
+        OUT / 'projection.npz',
+        intr=np.array([cam.width, cam.height, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y, 0.01, 100.0], dtype=np.float64),
+        c2w=c2w, P=P.numpy(), P_invz=cam.get_projection_matrix(invert_z=True).numpy(),
+        viewmatrix=w2cT.numpy(), projmatrix=(w2cT @ P.T).numpy(),
+        tanfov=np.array([cam.width / cam.focal_x * 0.5, cam.height / cam.focal_y * 0.5], dtype=np.float64),
+        campos=view.position.numpy(), viewport=cam.get_viewport_transform().numpy(),
+    )
+
+    # ---------------------------------------------------------------- frequency encoding (a5)
+    x = torch.rand(97, 3, generator=g) * 4 - 2
+    np.savez_compressed(
+        OUT / 'freqenc.npz', x=x.numpy(),
+        pos10=FrequencyEncoding(10, True)(x).numpy(), dir4=FrequencyEncoding(4, True)(x).numpy(),
+        noappend6=FrequencyEncoding(6, False)(x).numpy(),
+    )
+
+    # ---------------------------------------------------------------- NeRF sampling / integration (a7-a9)
+    class _R:  # the minimal RayBatch surface generate_samples touches
+        def __init__(self, n):
+            self.dtype, self.device, self.n = torch.float32, torch.device('cpu'), n
+
+        def __len__(self):
+            return self.n
+
+    n_rays, n_coarse, n_fine = 37, 64, 192
+    depth = generate_samples(_R(n_rays), n_coarse, 2.0, 6.0, False)
+    torch.manual_seed(1)
+    depth_rand = generate_samples(_R(n_rays), n_coarse, 2.0, 6.0, True)
+    torch.manual_seed(1)
+    depth_rand_u = torch.rand(n_rays, n_coarse)
+    dirs = torch.randn(n_rays, 3, generator=g)
+    dens = torch.rand(n_rays, n_coarse, generator=g) * 3
+    dens[3] = 0.0            # empty ray (T stays 1 -> depth 0 branch)
+    dens[5] *= 40.0          # saturating ray
+    cols = torch.rand(n_rays, n_coarse, 3, generator=g)
+    bg = torch.tensor([1.0, 0.5, 0.25])
+    rgb, dpt, alpha, w = integrate_samples(depth, dirs, dens, cols, bg)
+    rgb_nobg, _, _, _ = integrate_samples(depth, dirs, dens, cols, None)
+    fine = generate_samples_from_pdf(depth, w, n_fine, False)
+    torch.manual_seed(2)
+    fine_rand = generate_samples_from_pdf(depth, w, n_fine, True)
+    torch.manual_seed(2)
+    fine_rand_u = torch.rand(n_rays, n_fine)
+    np.savez_compressed(
+        OUT / 'nerf_sampling.npz', depth=depth.numpy(), depth_rand=depth_rand.numpy(), depth_rand_u=depth_rand_u.numpy(),
+        dirs=dirs.numpy(), dens=dens.numpy(), cols=cols.numpy(), bg=bg.numpy(), rgb=rgb.numpy(), rgb_nobg=rgb_nobg.numpy(),
+        depth_out=dpt.numpy(), alpha=alpha.numpy(), weights=w.numpy(), fine=fine.numpy(), fine_rand=fine_rand.numpy(),
+        fine_rand_u=fine_rand_u.numpy(),
+    )
+
+    # ---------------------------------------------------------------- GS utils (a26)
+    n = 211
+    sh = torch.randn(n, 3, 16, generator=g) * 0.4
+    vd = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    scales = torch.exp(torch.randn(n, 3, generator=g) * 0.5 + math.log(0.01))
+    quats = torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=-1)
+    cov = gs_utils.build_covariances(scales, quats)
+    out = dict(sh=sh.numpy(), view_dirs=vd.numpy(), scales=scales.numpy(), quats=quats.numpy(), cov=cov.numpy(),
+               cov_upper=gs_utils.extract_upper_triangular_matrix(cov).numpy(),
+               rot=quaternion_to_rotation_matrix(quats, normalize=False).numpy(),
+               rot_unnormalized_in=(quats * 1.7).numpy(), rot_normalized=quaternion_to_rotation_matrix(quats * 1.7, normalize=True).numpy())
+    for deg in range(4):
+        out[f'rgb_deg{deg}'] = gs_utils.convert_sh_features(sh.clone(), vd, deg).numpy()
+    out['rgb_to_sh0'] = gs_utils.rgb_to_sh0(torch.linspace(0, 1, 7)).numpy()
+    np.savez_compressed(OUT / 'gs_utils.npz', **out)
+
+    # ---------------------------------------------------------------- misc host logic
+    pol = LRDecayPolicy(lr_init=1.6e-4, lr_final=1.6e-6, lr_delay_steps=100, lr_delay_mult=0.01, max_steps=30000)
+    its = np.array([0, 1, 50, 99, 100, 1000, 15000, 29999, 30000, 40000], dtype=np.int64)
+    torch.manual_seed(0)
+    sampler = RandomSequentialSampler(num_elements=1000)
+    draws = [sampler.get(300).numpy().copy() for _ in range(5)]  # wraps (reshuffle) on the 4th draw
+    raw = torch.rand(5, 3, generator=g)
+    al = torch.rand(5, 1, generator=g)
+    np.savez_compressed(
+        OUT / 'misc.npz', lr_its=its, lr_vals=np.array([pol(int(i)) for i in its]),
+        sampler_draws=np.stack(draws), bgc_raw=raw.numpy(), bgc_alpha=al.numpy(),
+        bgc_out=apply_background_color(raw, al, torch.tensor([0.2, 0.4, 0.6]), is_chw=False).numpy(),
+    )
+    print('golden fixtures written to', OUT)
+    for f in sorted(OUT.glob('*.npz')):
+        print(f'  {f.name}: {f.stat().st_size} B')
+
+
+if __name__ == '__main__':
+    main()
