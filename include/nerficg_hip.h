@@ -28,6 +28,8 @@ enum {
 /* library identification; also used by the loader's symbol check */
 int nrc_abi_version(void);
 const char* nrc_build_info(void);
+/* text of the HIP error behind the calling thread's most recent NRC_ERR_LAUNCH */
+const char* nrc_last_error(void);
 
 /* =====================================================================================================
  * Group 1 -- VolumeRenderingV2  (replaces the pybind module of
@@ -109,6 +111,44 @@ int nrc_distortion_loss_bw(const float* dL_dloss, const float* ws_inclusive_scan
  * ===================================================================================================== */
 int64_t nrc_morton_encode_ws_bytes(int64_t n);
 int nrc_morton_encode(const float* positions, int64_t n, int64_t* codes, void* workspace, nrc_stream_t stream);
+
+/* =====================================================================================================
+ * Group 3 -- tinycudann subset  (replaces the tiny-cuda-nn modules built at src/Methods/InstantNGP/Model.py:58-114 and
+ *            queried at src/Methods/InstantNGP/Renderer.py:48-60; external dependency src/Thirdparty/TinyCudaNN.py:10)
+ * Networks: input encoding (32 features) -> 64-wide ReLU MLP (n_hidden 1 or 2, no bias) -> 16 padded outputs.
+ *   encoding 0: multiresolution hash grid, n_levels 16 x 2 features, fp16 table of nrc_grid_layout()[n_levels] entries
+ *   encoding 1: [SphericalHarmonics degree 4 of input dims 0..2 | Identity of input dims 3..18]
+ * weights_f16: [W0 (64,32) | hidden (64,64) x (n_hidden-1) | Wout (16,64)] row-major fp16 (rows >= n_out_rows read as 0).
+ * ===================================================================================================== */
+
+/* HOST helper: entry offsets of the levels, offsets_host[n_levels+1] (last = total entries); NULL only validates */
+int nrc_grid_layout(int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale,
+                    uint32_t* offsets_host);
+/* fp32 master parameters -> fp16 compute copy */
+int nrc_f32_to_f16(const float* src, void* dst_f16, int64_t n, nrc_stream_t stream);
+/* NetworkWithInputEncoding.forward.  input: encoding 0 -> (M,3) f32 in [0,1], input_ld ignored; encoding 1 -> (M,input_ld>=19)
+ * fp16 rows [d01(3) | features(16)].  out_act: 0 none, 1 sigmoid.  out (M,out_ld) fp16, columns [0,n_store) written
+ * (n_store in {4,8,12,16}).  save_in (M,32) fp16 and save_acts (n_hidden,M,64) fp16 receive the encoded inputs and the
+ * post-ReLU activations for the backward pass (both NULL for inference). */
+int nrc_nwie_forward(int32_t encoding, const void* input, int32_t input_ld, int64_t M, const void* weights_f16,
+                     const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
+                     float per_level_scale, int32_t n_hidden, int32_t out_act, int32_t n_out_rows, void* out_f16,
+                     int32_t out_ld, int32_t n_store, void* save_in, void* save_acts, nrc_stream_t stream);
+/* NetworkWithInputEncoding.backward through the MLP.  d_out / out: (M,out_ld) fp16 (upstream gradient of, and the forward
+ * value of, the stored output columns).  Upstream gradients are multiplied by loss_scale before they are rounded to fp16
+ * MFMA operands and every result is divided by it again (tiny-cuda-nn's internal loss scale).  grad_weights: f32, layout
+ * of weights_f16, ACCUMULATED atomically (caller zeroes).  d_in (M,32) f32 = gradient w.r.t. the 32 encoded inputs. */
+int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int32_t out_act, int32_t n_out_rows,
+                      const void* d_out_f16, const void* out_f16, int32_t out_ld, const void* save_in,
+                      const void* save_acts, float loss_scale, float* grad_weights, float* d_in, nrc_stream_t stream);
+/* hash-grid backward: grad_table (entries,2) f32 += trilinear scatter of d_features (M, 2*n_levels) f32 (caller zeroes) */
+int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t n_levels, int32_t log2_hashmap_size,
+                      int32_t base_resolution, float per_level_scale, float* grad_table, nrc_stream_t stream);
+/* InstantNGPRayRenderingComponent.query_model (Renderer.py:48-53) in one launch: xyz01 (M,3) f32 in [0,1], dirs (M,3) f32 unit
+ * vectors -> sigmas (M) f32 = exp(fp16 feature 0), rgbs (M,3) f32 = fp16 sigmoid outputs. */
+int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const void* density_weights_f16,
+                        const void* color_weights_f16, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
+                        int32_t base_resolution, float per_level_scale, float* sigmas, float* rgbs, nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 5 -- ray generation (replaces PerspectiveCamera.compute_local_ray_directions src/Cameras/Perspective.py:64-94

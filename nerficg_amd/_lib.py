@@ -70,7 +70,10 @@ def load() -> ctypes.CDLL:
 
 def check(status: int, what: str) -> None:
     if status != 0:
-        raise RuntimeError(f'{what} failed: {ERRORS.get(status, status)}')
+        detail = ''
+        if status == -2:
+            detail = f' ({load().nrc_last_error().decode()})'
+        raise RuntimeError(f'{what} failed: {ERRORS.get(status, status)}{detail}')
 
 
 def ptr(t):

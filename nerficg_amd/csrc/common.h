@@ -8,10 +8,16 @@
 
 #define NRC_WAVE 64
 
+void nrc_set_last_hip_error(int e);  // lib_info.hip
+
+// hipGetLastError() is per-thread and sticky across ALL HIP users of the thread (torch included): clear it on entry so that
+// NRC_LAUNCH_CHECK() reports only errors raised by this library's own launches.
+#define NRC_ENTER() (void)hipGetLastError()
+
 #define NRC_LAUNCH_CHECK()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \
-        if (e__ != hipSuccess) return NRC_ERR_LAUNCH;        \
+        if (e__ != hipSuccess) { nrc_set_last_hip_error((int)e__); return NRC_ERR_LAUNCH; } \
     } while (0)
 
 static inline int64_t nrc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

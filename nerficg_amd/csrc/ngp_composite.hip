@@ -236,6 +236,7 @@ extern "C" {
 int nrc_composite_train_fw(const float* sigmas, const float* rgbs, const float* deltas, const float* ts, const int64_t* rays_a,
                            int64_t n_rays, int64_t n_samples, float T_threshold, int64_t* total_samples, float* opacity,
                            float* depth, float* rgb, float* ws, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n_rays < 0 || n_samples < 0) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (n_samples > 0) { if (!ws) return NRC_ERR_INVALID; hipMemsetAsync(ws, 0, n_samples * sizeof(float), s); }
@@ -256,6 +257,7 @@ int nrc_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
                            const float* sigmas, const float* rgbs, const float* ws, const float* deltas, const float* ts,
                            const int64_t* rays_a, const float* opacity, const float* depth, const float* rgb, int64_t n_rays,
                            int64_t n_samples, float T_threshold, float* dL_dsigmas, float* dL_drgbs, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n_rays < 0 || n_samples < 0) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (n_samples > 0) {
@@ -275,6 +277,7 @@ int nrc_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
 int nrc_composite_test_fw(const float* sigmas, const float* rgbs, const float* deltas, const float* ts, int64_t* alive,
                           int64_t n_alive, int32_t N_samples, float T_threshold, const int32_t* n_eff, float* opacity,
                           float* depth, float* rgb, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n_alive < 0 || N_samples < 1) return NRC_ERR_INVALID;
     if (n_alive == 0) return NRC_OK;
     if (!sigmas || !rgbs || !deltas || !ts || !alive || !n_eff || !opacity || !depth || !rgb) return NRC_ERR_INVALID;
@@ -296,6 +299,7 @@ int nrc_composite_test_fw(const float* sigmas, const float* rgbs, const float* d
 
 int nrc_distortion_loss_fw(const float* ws, const float* deltas, const float* ts, const int64_t* rays_a, int64_t n_rays,
                            int64_t n_samples, float* loss, float* ws_incl, float* wts_incl, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n_rays < 0 || n_samples < 0) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (n_samples > 0) {
@@ -314,6 +318,7 @@ int nrc_distortion_loss_fw(const float* ws, const float* deltas, const float* ts
 int nrc_distortion_loss_bw(const float* dL_dloss, const float* ws_incl, const float* wts_incl, const float* ws,
                            const float* deltas, const float* ts, const int64_t* rays_a, int64_t n_rays, int64_t n_samples,
                            float* dL_dws, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n_rays < 0 || n_samples < 0) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (n_samples > 0) { if (!dL_dws) return NRC_ERR_INVALID; hipMemsetAsync(dL_dws, 0, n_samples * sizeof(float), s); }

@@ -440,6 +440,7 @@ MarchCfg make_cfg(const uint8_t* bitfield, int cascades, float scale, float esf,
 extern "C" {
 
 int nrc_morton3D(const int32_t* coords, int64_t n, int32_t* indices, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n < 0 || (n > 0 && (!coords || !indices))) return NRC_ERR_INVALID;
     if (n == 0) return NRC_OK;
     hipLaunchKernelGGL(k_morton3D, dim3(nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, coords, n, indices);
@@ -447,6 +448,7 @@ int nrc_morton3D(const int32_t* coords, int64_t n, int32_t* indices, nrc_stream_
     return NRC_OK;
 }
 int nrc_morton3D_invert(const int32_t* indices, int64_t n, int32_t* coords, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n < 0 || (n > 0 && (!coords || !indices))) return NRC_ERR_INVALID;
     if (n == 0) return NRC_OK;
     hipLaunchKernelGGL(k_morton3D_invert, dim3(nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, indices, n, coords);
@@ -454,6 +456,7 @@ int nrc_morton3D_invert(const int32_t* indices, int64_t n, int32_t* coords, nrc_
     return NRC_OK;
 }
 int nrc_packbits(const void* grid, int32_t grid_dtype, int64_t n_bytes, float thr, uint8_t* bitfield, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n_bytes < 0 || (n_bytes > 0 && (!grid || !bitfield)) || (grid_dtype != 0 && grid_dtype != 1)) return NRC_ERR_INVALID;
     if (n_bytes == 0) return NRC_OK;
     const bool aligned = (((uintptr_t)grid & 15) == 0) && (((uintptr_t)bitfield & 3) == 0);
@@ -477,6 +480,7 @@ int nrc_packbits(const void* grid, int32_t grid_dtype, int64_t n_bytes, float th
 int nrc_ray_aabb_intersect(const float* rays_o, const float* rays_d, const float* centers, const float* half_sizes,
                            int64_t n_rays, int64_t n_voxels, int32_t max_hits, int32_t* hit_cnt, float* hits_t,
                            int64_t* hits_voxel_idx, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n_rays < 0 || n_voxels < 0 || max_hits < 1) return NRC_ERR_INVALID;
     if (n_rays == 0) return NRC_OK;
     if (!rays_o || !rays_d || !hit_cnt || !hits_t || !hits_voxel_idx || (n_voxels > 0 && (!centers || !half_sizes))) return NRC_ERR_INVALID;
@@ -488,6 +492,7 @@ int nrc_ray_aabb_intersect(const float* rays_o, const float* rays_d, const float
 int nrc_ray_sphere_intersect(const float* rays_o, const float* rays_d, const float* centers, const float* radii,
                              int64_t n_rays, int64_t n_spheres, int32_t max_hits, int32_t* hit_cnt, float* hits_t,
                              int64_t* hits_sphere_idx, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n_rays < 0 || n_spheres < 0 || max_hits < 1) return NRC_ERR_INVALID;
     if (n_rays == 0) return NRC_OK;
     if (!rays_o || !rays_d || !hit_cnt || !hits_t || !hits_sphere_idx || (n_spheres > 0 && (!centers || !radii))) return NRC_ERR_INVALID;
@@ -508,6 +513,7 @@ int nrc_raymarching_train_count(const float* rays_o, const float* rays_d, const 
                                 int32_t cascades, float scale, float esf, const float* noise, int32_t grid_size,
                                 int32_t max_samples, int64_t n_rays, int64_t* rays_a, int32_t* counter, void* workspace,
                                 nrc_stream_t stream) {
+    NRC_ENTER();
     if (n_rays < 0 || !counter || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (n_rays == 0) { hipMemsetAsync(counter, 0, 8, s); return NRC_OK; }
@@ -526,6 +532,7 @@ int nrc_raymarching_train_write(const float* rays_o, const float* rays_d, const 
                                 int32_t cascades, float scale, float esf, const float* noise, int32_t grid_size,
                                 int32_t max_samples, int64_t n_rays, const int64_t* rays_a, float* xyzs, float* dirs,
                                 float* deltas, float* ts, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n_rays < 0 || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
     if (n_rays == 0) return NRC_OK;
     if (!rays_o || !rays_d || !hits_t || !bitfield || !noise || !rays_a) return NRC_ERR_INVALID;
@@ -539,6 +546,7 @@ int nrc_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t
                          const uint8_t* bitfield, int32_t cascades, float scale, float esf, int32_t grid_size,
                          int32_t max_samples, int32_t N_samples, float* xyzs, float* dirs, float* deltas, float* ts,
                          int32_t* n_eff, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n_alive < 0 || cascades < 1 || grid_size < 1 || max_samples < 1 || N_samples < 1) return NRC_ERR_INVALID;
     if (n_alive == 0) return NRC_OK;
     if (!rays_o || !rays_d || !hits_t || !alive || !bitfield || !xyzs || !dirs || !deltas || !ts || !n_eff) return NRC_ERR_INVALID;
@@ -554,6 +562,7 @@ int64_t nrc_morton_encode_ws_bytes(int64_t n) {
     return (1024 * 6 + 4) * (int64_t)sizeof(float);
 }
 int nrc_morton_encode(const float* positions, int64_t n, int64_t* codes, void* workspace, nrc_stream_t stream) {
+    NRC_ENTER();
     if (n < 0) return NRC_ERR_INVALID;
     if (n == 0) return NRC_OK;
     if (!positions || !codes || !workspace) return NRC_ERR_INVALID;
@@ -570,6 +579,7 @@ int nrc_morton_encode(const float* positions, int64_t n, int64_t* codes, void* w
 
 int nrc_generate_rays(int32_t width, int32_t height, const double* intr, const double* c2w, float* origin, float* direction,
                       float* view_direction, nrc_stream_t stream) {
+    NRC_ENTER();
     if (width < 1 || height < 1 || !intr || !c2w) return NRC_ERR_INVALID;
     RayGenCfg g;
     g.width = width; g.height = height;

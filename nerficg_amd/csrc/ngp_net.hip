@@ -1,0 +1,622 @@
+// ngp_net.hip -- fused "input encoding + tiny MLP" forward kernels (tinycudann subset used by nerficg's InstantNGP:
+// src/Methods/InstantNGP/Model.py:58-114, queried at src/Methods/InstantNGP/Renderer.py:48-60).
+//
+//   ENC_GRID  : 16-level x 2-feature multiresolution hash grid (fp16 table) -> 32 inputs
+//   ENC_SH_ID : degree-4 spherical harmonics of 3 dims (16) + identity of 16 dims -> 32 inputs
+//   MLP       : 32 -> 64 (xN_HIDDEN, ReLU) -> 16 (padded), fp16 weights/activations, f32 accumulation on MFMA
+//
+// One wave owns a tile of 32 samples: two lanes per sample gather 8 levels x 8 corners each straight into the B
+// fragments of the first MFMA; activations never leave registers between layers (see ngp_net.h).  Weights (<= 14 KB)
+// live in the wave's VGPRs for the whole persistent loop.  Per sample the kernel reads 12 B (+ the gathers, served by
+// L2 / Infinity Cache: the 24.4 MB table never streams from HBM twice) and writes 8-32 B.
+#include "ngp_net.h"
+
+namespace {
+
+enum { ENC_GRID = 0, ENC_SH_ID = 1 };
+enum { ACT_NONE = 0, ACT_SIGMOID = 1 };
+
+// ---- first-layer B fragments from the encodings -------------------------------------------------------------------
+__device__ __forceinline__ void encode_grid(const float* __restrict__ x, int64_t i, int hh, const __half2* __restrict__ table,
+                                            const GridCfg& g, h8 (&B)[2]) {
+    const float px = x[3 * i], py = x[3 * i + 1], pz = x[3 * i + 2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int l0 = 8 * s + q, l1 = 8 * s + 4 + q;  // level of lane half 0 / 1 (uniform indices -> SGPR loads + select)
+            const float scale = hh ? g.scale[l1] : g.scale[l0];
+            const uint32_t res = hh ? g.res[l1] : g.res[l0];
+            const uint32_t size = hh ? g.size[l1] : g.size[l0];
+            const uint32_t off = hh ? g.offset[l1] : g.offset[l0];
+            const bool hashed = hh ? g.hashed[l1] : g.hashed[l0];
+            Corner8 c;
+            grid_corners(px, py, pz, scale, res, size, off, hashed, c);
+            float f0, f1;
+            grid_level_features(table, c, f0, f1);
+            B[s][2 * q] = (_Float16)f0;
+            B[s][2 * q + 1] = (_Float16)f1;
+        }
+    }
+}
+// input row: [d01 (3) | h (16)] fp16, row stride `ld` halves
+__device__ __forceinline__ void encode_sh_id(const __half* __restrict__ in, int ld, int64_t i, int hh, h8 (&B)[2]) {
+    const _Float16* row = reinterpret_cast<const _Float16*>(in) + i * ld;
+    float sh[16];
+    sh4_eval((float)row[0] * 2.f - 1.f, (float)row[1] * 2.f - 1.f, (float)row[2] * 2.f - 1.f, sh);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        B[0][j] = (_Float16)(hh ? sh[8 + j] : sh[j]);
+        B[1][j] = row[3 + 8 * hh + j];
+    }
+}
+
+// ---- generic per-network forward -----------------------------------------------------------------------------------
+template <int ENC, int N_HIDDEN, int OUT_ACT, bool SAVE>
+__global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input, int in_ld, int64_t M, const __half* __restrict__ W,
+                                                  const __half2* __restrict__ table, GridCfg g, int n_out_rows,
+                                                  __half* __restrict__ out, int out_ld, int n_store, __half* __restrict__ save_in,
+                                                  __half* __restrict__ save_acts) {
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int64_t n_tiles = (M + 31) / 32;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+
+    h8 A0[2][2], AH[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1][2][4], AO[4];
+    const __half* Wp = W;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int s = 0; s < 2; s++) A0[mt][s] = load_w_frag<false>(Wp, 32, 64, mt, s, r, hh);
+    Wp += 64 * 32;
+#pragma unroll
+    for (int l = 0; l < N_HIDDEN - 1; l++) {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) AH[l][mt][s] = load_w_frag<true>(Wp, 64, 64, mt, s, r, hh);
+        Wp += 64 * 64;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) AO[s] = load_w_frag<true>(Wp, 64, n_out_rows, 0, s, r, hh);
+
+    for (int64_t tile = wave0; tile < n_tiles; tile += n_waves) {
+        const int64_t i = tile * 32 + r;
+        const bool valid = i < M;
+        const int64_t ic = valid ? i : M - 1;
+        h8 B[2];
+        if constexpr (ENC == ENC_GRID) encode_grid(reinterpret_cast<const float*>(input), ic, hh, table, g, B);
+        else encode_sh_id(reinterpret_cast<const __half*>(input), in_ld, ic, hh, B);
+        if constexpr (SAVE) {
+            if (valid) {
+                _Float16* p = reinterpret_cast<_Float16*>(save_in) + i * 32 + 8 * hh;
+                *reinterpret_cast<h8*>(p) = B[0];
+                *reinterpret_cast<h8*>(p + 16) = B[1];
+            }
+        }
+        f16v acc[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) acc[mt] = NRC_MFMA(A0[mt][s], B[s], acc[mt]);
+        h8 H[4];
+#pragma unroll
+        for (int l = 0; l < N_HIDDEN; l++) {
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
+            if constexpr (SAVE) {
+                if (valid) {
+                    _Float16* p = reinterpret_cast<_Float16*>(save_acts) + ((int64_t)l * M + i) * 64 + 4 * hh;
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        h4 lo, hi;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { lo[j] = H[s][j]; hi[j] = H[s][4 + j]; }
+                        *reinterpret_cast<h4*>(p + 16 * s) = lo;
+                        *reinterpret_cast<h4*>(p + 16 * s + 8) = hi;
+                    }
+                }
+            }
+            if (l + 1 < N_HIDDEN) {
+                acc[0] = zero16(); acc[1] = zero16();
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int s = 0; s < 4; s++) acc[mt] = NRC_MFMA(AH[l][mt][s], H[s], acc[mt]);
+            }
+        }
+        f16v o = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; s++) o = NRC_MFMA(AO[s], H[s], o);
+        if (valid) {
+            h4 lo, hi;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float a = o[j], b = o[4 + j];
+                if constexpr (OUT_ACT == ACT_SIGMOID) { a = 1.f / (1.f + expf(-a)); b = 1.f / (1.f + expf(-b)); }
+                lo[j] = (_Float16)a; hi[j] = (_Float16)b;
+            }
+            _Float16* p = reinterpret_cast<_Float16*>(out) + i * out_ld;
+            if (4 * hh < n_store) *reinterpret_cast<h4*>(p + 4 * hh) = lo;
+            if (8 + 4 * hh < n_store) *reinterpret_cast<h4*>(p + 8 + 4 * hh) = hi;
+        }
+    }
+}
+
+// ---- fully fused query: xyz01 (M,3), dir (M,3) -> sigma (M) f32, rgb (M,3) f32 ------------------------------------
+// density net (grid -> 64 -> 16) , sigma = exp(h0) , colour net (SH(dir) | h -> 64 -> 64 -> 3, sigmoid) in ONE pass:
+// the 16 density features stay in registers and become the colour net's identity inputs (ACC order).
+__global__ void __launch_bounds__(256) k_ngp_query_fused(const float* __restrict__ xyz01, const float* __restrict__ dirs, int64_t M,
+                                                         const __half* __restrict__ Wd, const __half* __restrict__ Wc,
+                                                         const __half2* __restrict__ table, GridCfg g,
+                                                         float* __restrict__ sigmas, float* __restrict__ rgbs) {
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int64_t n_tiles = (M + 31) / 32;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+
+    h8 D0[2][2], DO[4], C0[2][2], C1[2][4], CO[4];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int s = 0; s < 2; s++) D0[mt][s] = load_w_frag<false>(Wd, 32, 64, mt, s, r, hh);
+#pragma unroll
+    for (int s = 0; s < 4; s++) DO[s] = load_w_frag<true>(Wd + 64 * 32, 64, 16, 0, s, r, hh);
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+        C0[mt][0] = load_w_frag<false>(Wc, 32, 64, mt, 0, r, hh);  // SH coefficients: natural order
+        C0[mt][1] = load_w_frag<true>(Wc, 32, 64, mt, 1, r, hh);   // density features: ACC order
+#pragma unroll
+        for (int s = 0; s < 4; s++) C1[mt][s] = load_w_frag<true>(Wc + 64 * 32, 64, 64, mt, s, r, hh);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) CO[s] = load_w_frag<true>(Wc + 64 * 32 + 64 * 64, 64, 16, 0, s, r, hh);
+
+    for (int64_t tile = wave0; tile < n_tiles; tile += n_waves) {
+        const int64_t i = tile * 32 + r;
+        const bool valid = i < M;
+        const int64_t ic = valid ? i : M - 1;
+        h8 B[2];
+        encode_grid(xyz01, ic, hh, table, g, B);
+        f16v acc[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) acc[mt] = NRC_MFMA(D0[mt][s], B[s], acc[mt]);
+        h8 H[4];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
+        f16v o = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; s++) o = NRC_MFMA(DO[s], H[s], o);
+        // colour-net inputs: k-step 0 = SH(dir) (natural), k-step 1 = fp16(h) straight from the accumulator (ACC order)
+        h8 X[2];
+        X[1] = acc_to_frag(o, 0);
+        {
+            // the reference feeds fp16(d*0.5+0.5) and tiny-cuda-nn maps it back with *2-1 (Renderer.py:52)
+            float sh[16];
+            const float dx = (float)(_Float16)(dirs[3 * ic] * 0.5f + 0.5f) * 2.f - 1.f;
+            const float dy = (float)(_Float16)(dirs[3 * ic + 1] * 0.5f + 0.5f) * 2.f - 1.f;
+            const float dz = (float)(_Float16)(dirs[3 * ic + 2] * 0.5f + 0.5f) * 2.f - 1.f;
+            sh4_eval(dx, dy, dz, sh);
+#pragma unroll
+            for (int j = 0; j < 8; j++) X[0][j] = (_Float16)(hh ? sh[8 + j] : sh[j]);
+        }
+        const float sigma = expf((float)X[1][0]);  // TruncExp forward on the fp16 feature 0 (lane half 0, element 0)
+        acc[0] = zero16(); acc[1] = zero16();
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) acc[mt] = NRC_MFMA(C0[mt][s], X[s], acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
+        acc[0] = zero16(); acc[1] = zero16();
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) acc[mt] = NRC_MFMA(C1[mt][s], H[s], acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
+        o = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; s++) o = NRC_MFMA(CO[s], H[s], o);
+        if (valid && hh == 0) {
+            sigmas[i] = sigma;
+#pragma unroll
+            for (int c = 0; c < 3; c++) rgbs[3 * i + c] = (float)(_Float16)(1.f / (1.f + expf(-o[c])));
+        }
+    }
+}
+
+__global__ void k_f32_to_f16(const float* __restrict__ src, __half* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(dst) + i) = o;
+    } else {
+        for (int64_t k = i; k < n; k++) dst[k] = __float2half(src[k]);
+    }
+}
+
+int make_grid_cfg(int n_levels, int log2_T, int base_res, float pls, GridCfg& g, uint32_t* offsets_out) {
+    if (n_levels < 1 || n_levels > NRC_MAX_LEVELS || log2_T < 1 || log2_T > 30 || base_res < 1 || !(pls > 0.f)) return NRC_ERR_INVALID;
+    const float log2_pls = log2f(pls);
+    uint32_t off = 0;
+    for (int l = 0; l < NRC_MAX_LEVELS; l++) { g.offset[l] = 0; g.size[l] = 8; g.res[l] = 2; g.hashed[l] = 0; g.scale[l] = 1.f; }
+    for (int l = 0; l < n_levels; l++) {
+        const float scale = exp2f(l * log2_pls) * base_res - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(scale) + 1;
+        const uint32_t max_params = 0xffffffffu / 2;
+        uint32_t n = powf((float)res, 3.0f) > (float)max_params ? max_params : res * res * res;
+        n = (n + 7u) / 8u * 8u;
+        if (n > (1u << log2_T)) n = 1u << log2_T;
+        // the dense path is taken while the running stride fits (see oracle/tcnn_oracle.c grid_index)
+        uint64_t stride = 1;
+        bool hashed = false;
+        for (int d = 0; d < 3; d++) { if (stride <= n) stride *= res; }
+        hashed = n < stride;
+        g.offset[l] = off; g.size[l] = n; g.res[l] = res; g.hashed[l] = hashed ? 1u : 0u; g.scale[l] = scale;
+        if (offsets_out) offsets_out[l] = off;
+        off += n;
+    }
+    if (offsets_out) offsets_out[n_levels] = off;
+    return NRC_OK;
+}
+
+int pick_blocks(int64_t M) {
+    const int64_t need = nrc_cdiv(nrc_cdiv(M, 32), 4);
+    return (int)(need < 2048 ? (need > 0 ? need : 1) : 2048);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrc_grid_layout(int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, uint32_t* offsets_host) {
+    GridCfg g;
+    return make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, offsets_host);
+}
+
+int nrc_f32_to_f16(const float* src, void* dst, int64_t n, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n < 0 || (n > 0 && (!src || !dst))) return NRC_ERR_INVALID;
+    if (n == 0) return NRC_OK;
+    hipLaunchKernelGGL(k_f32_to_f16, dim3(nrc_cdiv(nrc_cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, src, (__half*)dst, n);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_nwie_forward(int32_t encoding, const void* input, int32_t input_ld, int64_t M, const void* weights_f16, const void* table_f16,
+                     int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale,
+                     int32_t n_hidden, int32_t out_act, int32_t n_out_rows, void* out_f16, int32_t out_ld, int32_t n_store,
+                     void* save_in, void* save_acts, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (M < 0 || !weights_f16 || n_out_rows < 1 || n_out_rows > 16 || out_ld < n_store || n_store < 4 || n_store > 16 || (n_store & 3)) return NRC_ERR_INVALID;
+    if (encoding != ENC_GRID && encoding != ENC_SH_ID) return NRC_ERR_UNSUPPORTED;
+    if (n_hidden < 1 || n_hidden > 2 || (out_act != ACT_NONE && out_act != ACT_SIGMOID)) return NRC_ERR_UNSUPPORTED;
+    if (M == 0) return NRC_OK;
+    if (!input || !out_f16) return NRC_ERR_INVALID;
+    GridCfg g;
+    if (encoding == ENC_GRID) {
+        if (n_levels != 16 || !table_f16) return NRC_ERR_UNSUPPORTED;  // 16 levels x 2 features = the 32 MLP inputs
+        const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
+        if (rc != NRC_OK) return rc;
+    } else {
+        make_grid_cfg(1, 4, 2, 2.f, g, nullptr);
+        if (input_ld < 19) return NRC_ERR_INVALID;
+    }
+    const bool save = save_in && save_acts;
+    if ((save_in == nullptr) != (save_acts == nullptr)) return NRC_ERR_INVALID;
+    const dim3 grid(pick_blocks(M)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define NRC_FWD(E, H, A, S)                                                                                                   \
+    hipLaunchKernelGGL((k_nwie_fwd<E, H, A, S>), grid, block, 0, s, input, (int)input_ld, M, (const __half*)weights_f16,       \
+                       (const __half2*)table_f16, g, (int)n_out_rows, (__half*)out_f16, (int)out_ld, (int)n_store,             \
+                       (__half*)save_in, (__half*)save_acts)
+#define NRC_FWD_S(E, H, A) do { if (save) NRC_FWD(E, H, A, true); else NRC_FWD(E, H, A, false); } while (0)
+#define NRC_FWD_A(E, H) do { if (out_act == ACT_SIGMOID) NRC_FWD_S(E, H, ACT_SIGMOID); else NRC_FWD_S(E, H, ACT_NONE); } while (0)
+    if (encoding == ENC_GRID) { if (n_hidden == 1) NRC_FWD_A(ENC_GRID, 1); else NRC_FWD_A(ENC_GRID, 2); }
+    else { if (n_hidden == 1) NRC_FWD_A(ENC_SH_ID, 1); else NRC_FWD_A(ENC_SH_ID, 2); }
+#undef NRC_FWD_A
+#undef NRC_FWD_S
+#undef NRC_FWD
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const void* density_weights_f16,
+                        const void* color_weights_f16, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
+                        int32_t base_resolution, float per_level_scale, float* sigmas, float* rgbs, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (M < 0 || !density_weights_f16 || !color_weights_f16 || !table_f16) return NRC_ERR_INVALID;
+    if (n_levels != 16) return NRC_ERR_UNSUPPORTED;
+    if (M == 0) return NRC_OK;
+    if (!xyz01 || !dirs || !sigmas || !rgbs) return NRC_ERR_INVALID;
+    GridCfg g;
+    const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
+    if (rc != NRC_OK) return rc;
+    hipLaunchKernelGGL(k_ngp_query_fused, dim3(pick_blocks(M)), dim3(256), 0, (hipStream_t)stream, xyz01, dirs, M,
+                       (const __half*)density_weights_f16, (const __half*)color_weights_f16, (const __half2*)table_f16, g, sigmas, rgbs);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// Backward
+// =====================================================================================================================
+namespace {
+
+#define LDP 40  // LDS row pitch in halves (32 samples + 8 pad = 80 B: keeps ds_read_b128 16-byte aligned, spreads banks)
+
+// B-style fragment (this lane = one sample) -> transposed LDS image T[neuron][sample]
+template <bool ACC_ORDER>
+__device__ __forceinline__ void stage_frag_T(_Float16* T, const h8& f, int s, int c, int hh) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int n = ACC_ORDER ? (16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)) : (16 * s + 8 * hh + j);
+        T[n * LDP + c] = f[j];
+    }
+}
+// fragment whose k index is the SAMPLE: row/col `n` of the transposed image, samples 16s + 8hh .. +7
+__device__ __forceinline__ h8 read_T_frag(const _Float16* T, int n, int s, int hh) {
+    return *reinterpret_cast<const h8*>(T + n * LDP + 16 * s + 8 * hh);
+}
+__device__ __forceinline__ h8 zero_h8() {
+    h8 f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) f[j] = (_Float16)0.f;
+    return f;
+}
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// dZ = (H > 0) ? dH : 0 as next B fragments; H fragments (ACC order) coincide element-for-element with the D layout
+__device__ __forceinline__ h8 masked_grad_frag(const f16v& acc, int g, const h8& H) {
+    h8 f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) f[j] = (float)H[j] > 0.f ? (_Float16)acc[8 * g + j] : (_Float16)0.f;
+    return f;
+}
+__device__ __forceinline__ h8 load_acc_order_frag(const _Float16* row64, int s, int hh) {
+    const h4 a = *reinterpret_cast<const h4*>(row64 + 16 * s + 4 * hh);
+    const h4 b = *reinterpret_cast<const h4*>(row64 + 16 * s + 8 + 4 * hh);
+    h8 f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { f[j] = a[j]; f[4 + j] = b[j]; }
+    return f;
+}
+// atomically accumulate a 32x32 D tile (rows = out neuron, cols = in neuron) into a row-major f32 gradient matrix
+__device__ __forceinline__ void atomic_add_tile(float* __restrict__ G, int ld, int n_rows, int mt, int nt, const f16v& acc, float mul, int c, int hh) {
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int row = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        if (row < n_rows) atomicAdd(G + (size_t)row * ld + 32 * nt + c, acc[reg] * mul);
+    }
+}
+
+template <int N_HIDDEN, int OUT_ACT>
+__global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __restrict__ W, int n_out_rows, const __half* __restrict__ d_out,
+                                                  const __half* __restrict__ out, int out_ld, const __half* __restrict__ save_in,
+                                                  const __half* __restrict__ save_acts, float loss_scale, float* __restrict__ dW,
+                                                  float* __restrict__ d_in) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[4][2][64 * LDP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    _Float16* T_act = lds[wv][0];
+    _Float16* T_dz = lds[wv][1];
+    const int64_t n_tiles = (M + 31) / 32;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, n_waves = (int64_t)gridDim.x * 4;
+    const float inv_scale = 1.0f / loss_scale;
+
+    const __half* W0 = W;
+    const __half* W1 = W + 64 * 32;                                   // only when N_HIDDEN == 2
+    const __half* Wo = W + 64 * 32 + (N_HIDDEN - 1) * 64 * 64;
+    // transposed weights as A operands of the back-propagation products
+    h8 WoT[2], W1T[N_HIDDEN > 1 ? 2 : 1][4], W0T[4];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) WoT[mt] = load_wT_frag<false>(Wo, 64, n_out_rows, 64, mt, 0, r, hh);
+    if constexpr (N_HIDDEN > 1) {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) W1T[mt][s] = load_wT_frag<true>(W1, 64, 64, 64, mt, s, r, hh);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) W0T[s] = load_wT_frag<true>(W0, 32, 64, 32, 0, s, r, hh);
+
+    f16v gWo[2] = {zero16(), zero16()};
+    f16v gW1[N_HIDDEN > 1 ? 2 : 1][2];
+    f16v gW0[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int a = 0; a < (N_HIDDEN > 1 ? 2 : 1); a++) { gW1[a][0] = zero16(); gW1[a][1] = zero16(); }
+
+    for (int64_t tile = wave0; tile < n_tiles; tile += n_waves) {
+        const int64_t i = tile * 32 + r;
+        const bool valid = i < M;
+        const int64_t ic = valid ? i : M - 1;
+        // ---- saved forward state of this sample
+        const _Float16* xin = reinterpret_cast<const _Float16*>(save_in) + ic * 32;
+        h8 X[2] = {*reinterpret_cast<const h8*>(xin + 8 * hh), *reinterpret_cast<const h8*>(xin + 16 + 8 * hh)};
+        h8 H0[4], H1[4];
+        {
+            const _Float16* a0 = reinterpret_cast<const _Float16*>(save_acts) + ic * 64;
+#pragma unroll
+            for (int s = 0; s < 4; s++) H0[s] = load_acc_order_frag(a0, s, hh);
+            if constexpr (N_HIDDEN > 1) {
+                const _Float16* a1 = reinterpret_cast<const _Float16*>(save_acts) + ((int64_t)M + ic) * 64;
+#pragma unroll
+                for (int s = 0; s < 4; s++) H1[s] = load_acc_order_frag(a1, s, hh);
+            }
+        }
+        h8 (&HL)[4] = N_HIDDEN > 1 ? H1 : H0;  // last hidden layer
+        // ---- dZ of the output layer (natural order over the 16 padded output rows)
+        h8 dZo = zero_h8();
+        if (valid) {
+            const _Float16* g = reinterpret_cast<const _Float16*>(d_out) + i * out_ld;
+            const _Float16* y = reinterpret_cast<const _Float16*>(out) + i * out_ld;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int row = 8 * hh + j;
+                if (row < out_ld) {
+                    float v = (float)g[row];
+                    if constexpr (OUT_ACT == ACT_SIGMOID) { const float yy = (float)y[row]; v = v * yy * (1.f - yy); }
+                    dZo[j] = (_Float16)(v * loss_scale);
+                }
+            }
+        }
+        // ---- dWout += dZo^T . HL   (k = samples, through the transposed LDS images)
+        stage_frag_T<false>(T_dz, dZo, 0, r, hh);
+#pragma unroll
+        for (int s = 0; s < 4; s++) stage_frag_T<true>(T_act, HL[s], s, r, hh);
+        wave_lds_sync();
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const h8 a = r < 16 ? read_T_frag(T_dz, r, s, hh) : zero_h8();
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) gWo[nt] = NRC_MFMA(a, read_T_frag(T_act, 32 * nt + r, s, hh), gWo[nt]);
+        }
+        wave_lds_sync();
+        // ---- dHL^T = Wout^T . dZo^T ; dZL = relu'(HL) * dHL
+        f16v acc[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) acc[mt] = NRC_MFMA(WoT[mt], dZo, acc[mt]);
+        h8 dZ[4];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int gq = 0; gq < 2; gq++) dZ[2 * mt + gq] = masked_grad_frag(acc[mt], gq, HL[2 * mt + gq]);
+        if constexpr (N_HIDDEN > 1) {
+            // ---- dW1 += dZ1^T . H0
+#pragma unroll
+            for (int s = 0; s < 4; s++) { stage_frag_T<true>(T_dz, dZ[s], s, r, hh); stage_frag_T<true>(T_act, H0[s], s, r, hh); }
+            wave_lds_sync();
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++) {
+                    const h8 a = read_T_frag(T_dz, 32 * mt + r, s, hh);
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++) gW1[mt][nt] = NRC_MFMA(a, read_T_frag(T_act, 32 * nt + r, s, hh), gW1[mt][nt]);
+                }
+            wave_lds_sync();
+            // ---- dH0^T = W1^T . dZ1^T ; dZ0 = relu'(H0) * dH0
+            acc[0] = zero16(); acc[1] = zero16();
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) acc[mt] = NRC_MFMA(W1T[mt][s], dZ[s], acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) dZ[2 * mt + gq] = masked_grad_frag(acc[mt], gq, H0[2 * mt + gq]);
+        }
+        // ---- dW0 += dZ0^T . X
+#pragma unroll
+        for (int s = 0; s < 4; s++) stage_frag_T<true>(T_dz, dZ[s], s, r, hh);
+        stage_frag_T<false>(T_act, X[0], 0, r, hh);
+        stage_frag_T<false>(T_act, X[1], 1, r, hh);
+        wave_lds_sync();
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const h8 b = read_T_frag(T_act, r, s, hh);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) gW0[mt] = NRC_MFMA(read_T_frag(T_dz, 32 * mt + r, s, hh), b, gW0[mt]);
+        }
+        wave_lds_sync();
+        // ---- d_in^T = W0^T . dZ0^T  (32 input features x 32 samples), unscaled f32
+        f16v din = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; s++) din = NRC_MFMA(W0T[s], dZ[s], din);
+        if (valid && d_in) {
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                float4 v = make_float4(din[4 * gq] * inv_scale, din[4 * gq + 1] * inv_scale, din[4 * gq + 2] * inv_scale, din[4 * gq + 3] * inv_scale);
+                *reinterpret_cast<float4*>(d_in + i * 32 + 8 * gq + 4 * hh) = v;
+            }
+        }
+    }
+    // ---- flush the wave's weight-gradient accumulators (layout of W): two 128-byte row segments per atomic instruction
+    float* gW0p = dW;
+    float* gW1p = dW + 64 * 32;
+    float* gWop = dW + 64 * 32 + (N_HIDDEN - 1) * 64 * 64;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) atomic_add_tile(gW0p, 32, 64, mt, 0, gW0[mt], inv_scale, r, hh);
+    if constexpr (N_HIDDEN > 1) {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) atomic_add_tile(gW1p, 64, 64, mt, nt, gW1[mt][nt], inv_scale, r, hh);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) atomic_add_tile(gWop, 64, n_out_rows, 0, nt, gWo[nt], inv_scale, r, hh);
+}
+
+// hash-grid backward: one lane per (sample, level); scatter-add of w_corner * dL/dfeature into the f32 table gradient
+__global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, GridCfg g,
+                                                  int n_levels, float* __restrict__ grad_table) {
+    const int level = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const float2 gf = *reinterpret_cast<const float2*>(d_feat + i * 2 * n_levels + 2 * level);
+    if (gf.x == 0.f && gf.y == 0.f) return;
+    Corner8 c;
+    grid_corners(x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scale[level], g.res[level], g.size[level], g.offset[level], g.hashed[level] != 0, c);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        float* p = grad_table + 2 * (size_t)c.e[k];
+        atomicAdd(p, c.w[k] * gf.x);
+        atomicAdd(p + 1, c.w[k] * gf.y);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int32_t out_act, int32_t n_out_rows, const void* d_out_f16,
+                      const void* out_f16, int32_t out_ld, const void* save_in, const void* save_acts, float loss_scale,
+                      float* grad_weights, float* d_in, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (M < 0 || !weights_f16 || !grad_weights || n_out_rows < 1 || n_out_rows > 16 || out_ld < 4 || out_ld > 16 || !(loss_scale > 0.f)) return NRC_ERR_INVALID;
+    if (n_hidden < 1 || n_hidden > 2 || (out_act != ACT_NONE && out_act != ACT_SIGMOID)) return NRC_ERR_UNSUPPORTED;
+    if (M == 0) return NRC_OK;
+    if (!d_out_f16 || !out_f16 || !save_in || !save_acts) return NRC_ERR_INVALID;
+    const int64_t need = nrc_cdiv(nrc_cdiv(M, 32), 4);
+    const dim3 grid((unsigned)(need < 512 ? need : 512)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define NRC_BWD(H, A)                                                                                                          \
+    hipLaunchKernelGGL((k_nwie_bwd<H, A>), grid, block, 0, s, M, (const __half*)weights_f16, (int)n_out_rows, (const __half*)d_out_f16, \
+                       (const __half*)out_f16, (int)out_ld, (const __half*)save_in, (const __half*)save_acts, loss_scale, grad_weights, d_in)
+    if (n_hidden == 1) { if (out_act == ACT_SIGMOID) NRC_BWD(1, ACT_SIGMOID); else NRC_BWD(1, ACT_NONE); }
+    else { if (out_act == ACT_SIGMOID) NRC_BWD(2, ACT_SIGMOID); else NRC_BWD(2, ACT_NONE); }
+#undef NRC_BWD
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t n_levels, int32_t log2_hashmap_size,
+                      int32_t base_resolution, float per_level_scale, float* grad_table, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (M < 0 || !grad_table) return NRC_ERR_INVALID;
+    if (M == 0) return NRC_OK;
+    if (!x01 || !d_features) return NRC_ERR_INVALID;
+    GridCfg g;
+    const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
+    if (rc != NRC_OK) return rc;
+    hipLaunchKernelGGL(k_grid_bwd, dim3((unsigned)nrc_cdiv(M, 256), n_levels), dim3(256), 0, (hipStream_t)stream, x01, M, d_features, g,
+                       (int)n_levels, grad_table);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+}  // extern "C"

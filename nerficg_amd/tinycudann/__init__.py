@@ -1,0 +1,202 @@
+"""nerficg_amd.tinycudann -- the subset of the tiny-cuda-nn PyTorch API that nerficg imports through
+src/Thirdparty/TinyCudaNN.py (`from tinycudann import *`) and uses in src/Methods/InstantNGP/Model.py:36,40-41,58-120:
+
+    NetworkWithInputEncoding(n_input_dims, n_output_dims, encoding_config, network_config, seed)
+        .params (flat f32 nn.Parameter: MLP weights first, encoding table after), .n_output_dims, .jit_fusion
+        __call__((M, n_input_dims) CUDA tensor) -> (M, n_output_dims) fp16
+    free_temporary_memory(), supports_jit_fusion()
+
+backed by hand-written gfx950 kernels (libnerficg_hip.so: nrc_nwie_forward / nrc_nwie_backward / nrc_grid_backward).
+Supported configurations = the family the reference instantiates (anything else raises, loudly):
+  encoding  {'otype':'Grid','type':'Hash', n_levels 16, n_features_per_level 2, interpolation 'Linear', any
+             log2_hashmap_size / base_resolution / per_level_scale}   with n_input_dims == 3
+            {'otype':'Composite','nested':[{'n_dims_to_encode':3,'otype':'SphericalHarmonics','degree':4},
+             {'otype':'Identity'}]}                                    with n_input_dims == 19
+  network   {'otype':'FullyFusedMLP','activation':'ReLU','output_activation':'None'|'Sigmoid','n_neurons':64,
+             'n_hidden_layers': 1|2}                                   with n_output_dims <= 16
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+from .. import _lib
+
+__all__ = ['NetworkWithInputEncoding', 'free_temporary_memory', 'supports_jit_fusion']
+
+_WIDTH = 64
+_PAD = 16
+LOSS_SCALE = 128.0  # tiny-cuda-nn's internal loss scale for fp16 backward activations
+
+
+def free_temporary_memory() -> None:
+    """tiny-cuda-nn frees its own arena here; this build allocates through torch's caching allocator."""
+    return None
+
+
+def supports_jit_fusion() -> bool:
+    """Encoding + MLP are always one fused kernel in this build (the flag `jit_fusion` is accepted and has no effect)."""
+    return True
+
+
+def _grid_offsets(cfg: dict) -> list[int]:
+    offs = (ctypes.c_uint32 * (cfg['n_levels'] + 1))()
+    _lib.check(_lib.load().nrc_grid_layout(cfg['n_levels'], cfg['log2_hashmap_size'], cfg['base_resolution'],
+                                           float(cfg['per_level_scale']), ctypes.cast(offs, ctypes.c_void_p)), 'grid_layout')
+    return list(offs)
+
+
+class _NWIEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, params, module):
+        m = x.shape[0]
+        dev = x.device
+        lib = _lib.load()
+        w16 = module._half_params()
+        need_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])  # grad mode is off inside Function.forward
+        out = torch.empty(m, module._out_ld, dtype=torch.float16, device=dev)
+        save_in = torch.empty(m, 32, dtype=torch.float16, device=dev) if need_grad else None
+        save_acts = torch.empty(module.n_hidden, m, _WIDTH, dtype=torch.float16, device=dev) if need_grad else None
+        if module.encoding == 0:
+            xin = x.detach().to(torch.float32).contiguous()
+            in_ld = 3
+        else:
+            xin = x.detach().to(torch.float16).contiguous()
+            in_ld = xin.shape[1]
+        g = module.grid_cfg
+        _lib.check(lib.nrc_nwie_forward(
+            module.encoding, _lib.ptr(xin), in_ld, m, _lib.ptr(w16), _lib.ptr(module._table16()), g['n_levels'],
+            g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), module.n_hidden, module.out_act,
+            _PAD, _lib.ptr(out), module._out_ld, module._out_ld, _lib.ptr(save_in), _lib.ptr(save_acts),
+            _lib.stream_of(out)), 'nwie_forward')
+        if need_grad:
+            ctx.module = module
+            ctx.x_dtype = x.dtype
+            ctx.x_requires_grad = x.requires_grad
+            ctx.save_for_backward(xin, out, save_in, save_acts, w16)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        xin, out, save_in, save_acts, w16 = ctx.saved_tensors
+        module = ctx.module
+        lib = _lib.load()
+        m = xin.shape[0]
+        dev = xin.device
+        d_out = d_out.to(torch.float16).contiguous()
+        grad_params = torch.zeros(module.params.numel(), dtype=torch.float32, device=dev)
+        d_in = torch.empty(m, 32, dtype=torch.float32, device=dev)
+        st = _lib.stream_of(d_out)
+        _lib.check(lib.nrc_nwie_backward(
+            m, _lib.ptr(w16), module.n_hidden, module.out_act, _PAD, _lib.ptr(d_out), _lib.ptr(out), module._out_ld,
+            _lib.ptr(save_in), _lib.ptr(save_acts), LOSS_SCALE, _lib.ptr(grad_params), _lib.ptr(d_in), st), 'nwie_backward')
+        grad_x = None
+        if module.encoding == 0:
+            g = module.grid_cfg
+            table_grad = grad_params[module.n_mlp_params:]
+            _lib.check(lib.nrc_grid_backward(_lib.ptr(xin), m, _lib.ptr(d_in), g['n_levels'], g['log2_hashmap_size'],
+                                             g['base_resolution'], float(g['per_level_scale']), _lib.ptr(table_grad), st), 'grid_backward')
+        elif ctx.x_requires_grad:
+            # gradient w.r.t. the identity-encoded dims; the SH-encoded direction dims get zeros (view directions are data,
+            # never optimised by the reference: Renderer.py:40 feeds rays.view_direction)
+            grad_x = torch.zeros(m, xin.shape[1], dtype=ctx.x_dtype, device=dev)
+            grad_x[:, 3:19] = d_in[:, 16:32].to(ctx.x_dtype)
+        return grad_x, grad_params, None
+
+
+class NetworkWithInputEncoding(torch.nn.Module):
+    def __init__(self, n_input_dims: int, n_output_dims: int, encoding_config: dict, network_config: dict, seed: int = 1337) -> None:
+        super().__init__()
+        self.n_input_dims = int(n_input_dims)
+        self.n_output_dims = int(n_output_dims)
+        self.encoding_config = encoding_config
+        self.network_config = network_config
+        self.seed = int(seed)
+        self.jit_fusion = False
+        self.loss_scale = LOSS_SCALE
+        # ---- network
+        if network_config.get('otype') not in ('FullyFusedMLP', 'CutlassMLP'):
+            raise RuntimeError(f"nerficg_amd.tinycudann: unsupported network otype {network_config.get('otype')!r}")
+        if str(network_config.get('activation', 'ReLU')).lower() != 'relu':
+            raise RuntimeError('nerficg_amd.tinycudann: only ReLU hidden activations are implemented')
+        if int(network_config.get('n_neurons', 64)) != _WIDTH:
+            raise RuntimeError('nerficg_amd.tinycudann: only n_neurons == 64 is implemented')
+        self.n_hidden = int(network_config.get('n_hidden_layers', 1))
+        if self.n_hidden not in (1, 2):
+            raise RuntimeError('nerficg_amd.tinycudann: n_hidden_layers must be 1 or 2')
+        oa = str(network_config.get('output_activation', 'None')).lower()
+        if oa not in ('none', 'sigmoid'):
+            raise RuntimeError(f'nerficg_amd.tinycudann: unsupported output_activation {oa!r}')
+        self.out_act = 1 if oa == 'sigmoid' else 0
+        if not 1 <= self.n_output_dims <= _PAD:
+            raise RuntimeError('nerficg_amd.tinycudann: n_output_dims must be in [1, 16]')
+        self._out_ld = 4 * ((self.n_output_dims + 3) // 4)  # stored output columns (the rest of the padded 16 is never read)
+        # ---- encoding
+        ot = str(encoding_config.get('otype', ''))
+        self.grid_cfg = dict(n_levels=1, log2_hashmap_size=4, base_resolution=2, per_level_scale=2.0)
+        n_table = 0
+        if ot in ('Grid', 'HashGrid'):
+            if str(encoding_config.get('type', 'Hash')) != 'Hash' or str(encoding_config.get('interpolation', 'Linear')) != 'Linear':
+                raise RuntimeError('nerficg_amd.tinycudann: only Hash grids with Linear interpolation are implemented')
+            if int(encoding_config.get('n_levels', 16)) != 16 or int(encoding_config.get('n_features_per_level', 2)) != 2 or self.n_input_dims != 3:
+                raise RuntimeError('nerficg_amd.tinycudann: the grid encoding is implemented for 3 input dims, 16 levels x 2 features')
+            self.encoding = 0
+            self.grid_cfg = dict(n_levels=16, log2_hashmap_size=int(encoding_config.get('log2_hashmap_size', 19)),
+                                 base_resolution=int(encoding_config.get('base_resolution', 16)),
+                                 per_level_scale=float(encoding_config.get('per_level_scale', 2.0)))
+            self.grid_offsets = _grid_offsets(self.grid_cfg)
+            n_table = self.grid_offsets[-1] * 2
+        elif ot == 'Composite':
+            nested = encoding_config.get('nested', [])
+            ok = (len(nested) == 2 and nested[0].get('otype') == 'SphericalHarmonics' and int(nested[0].get('degree', 0)) == 4
+                  and int(nested[0].get('n_dims_to_encode', 0)) == 3 and nested[1].get('otype') == 'Identity' and self.n_input_dims == 19)
+            if not ok:
+                raise RuntimeError('nerficg_amd.tinycudann: Composite encoding must be [SphericalHarmonics(degree 4, 3 dims), Identity(16 dims)]')
+            self.encoding = 1
+        else:
+            raise RuntimeError(f'nerficg_amd.tinycudann: unsupported encoding otype {ot!r}')
+        # ---- parameters: [W0 (64,32) | hidden (64,64)... | Wout (16,64)] then the grid table (Model.py:40 slices on this order)
+        self.n_mlp_params = _WIDTH * 32 + (self.n_hidden - 1) * _WIDTH * _WIDTH + _PAD * _WIDTH
+        gen = torch.Generator(device='cpu').manual_seed(self.seed)
+        chunks = []
+        shapes = [(_WIDTH, 32)] + [(_WIDTH, _WIDTH)] * (self.n_hidden - 1) + [(_PAD, _WIDTH)]
+        for fan_out, fan_in in shapes:  # Xavier uniform, like tiny-cuda-nn's FullyFusedMLP::initialize_params
+            s = math.sqrt(6.0 / (fan_in + fan_out))
+            chunks.append((torch.rand(fan_out * fan_in, generator=gen) * 2 - 1) * s)
+        if n_table:
+            chunks.append((torch.rand(n_table, generator=gen) * 2 - 1) * 1e-4)  # grid init U(-1e-4, 1e-4)
+        self.params = torch.nn.Parameter(torch.cat(chunks).to(torch.float32), requires_grad=True)
+        self._half = None
+        self._half_key = None
+
+    # fp16 compute copy of the fp32 master parameters, refreshed when the parameter tensor changes
+    def _refresh_half(self) -> None:
+        p = self.params
+        key = (p.data_ptr(), p._version, p.device)
+        if self._half is None or self._half_key != key:
+            if not p.is_cuda:
+                raise RuntimeError('nerficg_amd.tinycudann: parameters must live on the GPU (no CPU fallback)')
+            half = torch.empty(p.numel(), dtype=torch.float16, device=p.device)
+            _lib.check(_lib.load().nrc_f32_to_f16(_lib.ptr(p.detach()), _lib.ptr(half), p.numel(), _lib.stream_of(half)), 'f32_to_f16')
+            self._half, self._half_key = half, key
+
+    def _half_params(self) -> torch.Tensor:
+        self._refresh_half()
+        return self._half
+
+    def _table16(self):
+        return self._half[self.n_mlp_params:] if self.encoding == 0 else None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError('nerficg_amd.tinycudann: input must be a CUDA tensor (no CPU fallback)')
+        if x.dim() != 2 or x.shape[1] != self.n_input_dims:
+            raise RuntimeError(f'nerficg_amd.tinycudann: expected input of shape (M, {self.n_input_dims}), got {tuple(x.shape)}')
+        out = _NWIEFunction.apply(x, self.params, self)
+        return out[:, :self.n_output_dims]
+
+    def extra_repr(self) -> str:
+        return f'n_input_dims={self.n_input_dims}, n_output_dims={self.n_output_dims}, seed={self.seed}, encoding={self.encoding_config}, network={self.network_config}'

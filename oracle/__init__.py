@@ -176,3 +176,74 @@ def morton_encode(positions):
     out = np.empty(positions.shape[0], i64)
     _call('oracle_morton_encode', positions, positions.shape[0], out)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ tinycudann subset
+def round_half(a):
+    """fp16 round trip (numpy's float16 conversion is IEEE round-to-nearest-even, same as oracle_round_to_half)."""
+    return np.asarray(a, f32).astype(np.float16).astype(f32)
+
+
+def grid_layout(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.3819128800):
+    offsets = np.zeros(n_levels + 1, np.uint32)
+    scales = np.zeros(n_levels, f32)
+    res = np.zeros(n_levels, np.uint32)
+    fn = lib().oracle_grid_layout
+    fn.restype = ctypes.c_uint32
+    total = fn(_i(n_levels), _i(log2_hashmap_size), _i(base_resolution), ctypes.c_float(per_level_scale), _p(offsets), _p(scales), _p(res))
+    return int(total), offsets, scales, res
+
+
+def grid_encode_fw(x01, table, n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.3819128800):
+    """x01 (M,3) f32 in [0,1]; table (entries,2) fp16-representable f32 -> (M, 2*n_levels) fp16-rounded f32."""
+    x01, table = _c(x01, f32), _c(table, f32)
+    out = np.empty((x01.shape[0], 2 * n_levels), f32)
+    _call('oracle_grid_encode_fw', x01, x01.shape[0], table, _i(n_levels), _i(log2_hashmap_size), _i(base_resolution),
+          float(per_level_scale), out)
+    return out
+
+
+def grid_encode_bw(x01, d_out, n_entries, n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.3819128800):
+    x01, d_out = _c(x01, f32), _c(d_out, f32)
+    grad = np.zeros((n_entries, 2), f32)
+    _call('oracle_grid_encode_bw', x01, x01.shape[0], d_out, _i(n_levels), _i(log2_hashmap_size), _i(base_resolution),
+          float(per_level_scale), grad)
+    return grad
+
+
+def sh4_encode(d01):
+    d01 = _c(d01, f32)
+    out = np.empty((d01.shape[0], 16), f32)
+    _call('oracle_sh4_encode', d01, d01.shape[0], out)
+    return out
+
+
+def mlp_fw(x, W, n_in=32, width=64, n_hidden=1, n_out_pad=16, out_act=0, want_acts=False):
+    """x (M,n_in), W flat -- both fp16-representable f32. Returns out (M,n_out_pad) [, acts (n_hidden,M,width)]."""
+    x, W = _c(x, f32), _c(W, f32)
+    m = x.shape[0]
+    out = np.empty((m, n_out_pad), f32)
+    acts = np.empty((n_hidden, m, width), f32) if want_acts else None
+    _call('oracle_mlp_fw', x, m, W, _i(n_in), _i(width), _i(n_hidden), _i(n_out_pad), _i(out_act), out, acts)
+    return (out, acts) if want_acts else out
+
+
+def mlp_bw(x, W, out, acts, d_out, n_in=32, width=64, n_hidden=1, n_out_pad=16, out_act=0):
+    x, W, out, acts, d_out = _c(x, f32), _c(W, f32), _c(out, f32), _c(acts, f32), _c(d_out, f32)
+    m = x.shape[0]
+    dW = np.empty_like(W)
+    d_in = np.empty((m, n_in), f32)
+    _call('oracle_mlp_bw', x, m, W, _i(n_in), _i(width), _i(n_hidden), _i(n_out_pad), _i(out_act), out, acts, d_out, dW, d_in)
+    return dW, d_in
+
+
+def ngp_query(xyz01, dirs, Wd, Wc, table, **grid_kw):
+    """InstantNGPRayRenderingComponent.query_model (src/Methods/InstantNGP/Renderer.py:48-53) on the oracle pieces:
+    h = density_net(grid(x)); sigma = exp(h[:,0]); rgb = color_net([SH4(fp16(d*.5+.5)) | h])[:, :3]."""
+    enc = grid_encode_fw(xyz01, table, **grid_kw)
+    h = mlp_fw(enc, Wd, n_hidden=1, out_act=0)
+    sigma = np.exp(h[:, 0].astype(f32))
+    d01 = round_half(_c(dirs, f32) * f32(0.5) + f32(0.5))
+    cin = np.concatenate([sh4_encode(d01), h], axis=1)
+    rgb = mlp_fw(cin, Wc, n_hidden=2, out_act=1)[:, :3]
+    return sigma.astype(f32), rgb, h

@@ -1,0 +1,223 @@
+"""GPU parity of the tinycudann replacement (hash grid + SH + fused MLP, forward and backward) against
+oracle/tcnn_oracle.c.  fp16 storage / f32 accumulation on both sides; the MFMA's accumulation order differs from the
+oracle's serial fmaf chain, so outputs agree to fp16 rounding: tolerance 2 fp16 ulps of the value range (stated per test).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+PLS = float(np.exp(np.log(2048 * 1.0 / 16) / 15))  # Model.py:68 with SCALE 0.5
+GRID = dict(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=PLS)
+ENC_GRID = {'otype': 'Grid', 'type': 'Hash', 'n_levels': 16, 'n_features_per_level': 2, 'log2_hashmap_size': 19,
+            'base_resolution': 16, 'per_level_scale': PLS, 'interpolation': 'Linear'}
+ENC_COMP = {'otype': 'Composite', 'nested': [{'n_dims_to_encode': 3, 'otype': 'SphericalHarmonics', 'degree': 4}, {'otype': 'Identity'}]}
+NET_D = {'otype': 'FullyFusedMLP', 'activation': 'ReLU', 'output_activation': 'None', 'n_neurons': 64, 'n_hidden_layers': 1}
+NET_C = {'otype': 'FullyFusedMLP', 'activation': 'ReLU', 'output_activation': 'Sigmoid', 'n_neurons': 64, 'n_hidden_layers': 2}
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.to(dtype) if dtype is not None else t).to(DEV)
+
+
+@pytest.fixture(scope='module')
+def tcnn():
+    import nerficg_amd.tinycudann as m
+    return m
+
+
+@pytest.fixture(scope='module')
+def density_net(tcnn):
+    net = tcnn.NetworkWithInputEncoding(3, 16, ENC_GRID, NET_D, seed=7).to(DEV)
+    # amplify the table so that the encoded features are O(0.1) (the U(-1e-4,1e-4) init would test nothing)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(3)
+        net.params[net.n_mlp_params:] = ((torch.rand(net.params.numel() - net.n_mlp_params, generator=g) * 2 - 1) * 0.5).to(DEV)
+    return net
+
+
+@pytest.fixture(scope='module')
+def color_net(tcnn):
+    return tcnn.NetworkWithInputEncoding(19, 3, ENC_COMP, NET_C, seed=11).to(DEV)
+
+
+def _half_np(t):
+    return t.detach().float().cpu().numpy().astype(np.float16).astype(np.float32)
+
+
+def test_param_layout_matches_reference_expectations(density_net, color_net):
+    total, offsets, _, _ = oracle.grid_layout(**GRID)
+    assert total == 6098120 and density_net.grid_offsets == list(offsets)
+    # src/Methods/InstantNGP/Model.py:80-89,115: 3072 MLP params first in encoding_xyz.params, len(color.params) == 7168
+    assert density_net.n_mlp_params == 3072 and density_net.params.numel() == 3072 + 2 * total
+    assert color_net.params.numel() == 7168 and color_net.n_output_dims == 3 and density_net.n_output_dims == 16
+    assert 'params' in dict(density_net.named_parameters())
+
+
+@pytest.mark.parametrize('m', [1, 31, 32, 1000, 70001])
+def test_density_network_forward(density_net, m):
+    rng = np.random.default_rng(m)
+    x = rng.random((m, 3)).astype(np.float32)
+    x[0] = [0.0, 1.0, 0.5] if m > 0 else x[0]  # domain corners
+    with torch.no_grad():
+        out = density_net(T(x))
+    assert out.dtype == torch.float16 and out.shape == (m, 16)
+    p = _half_np(density_net.params)
+    enc = oracle.grid_encode_fw(x, p[3072:].reshape(-1, 2), **GRID)
+    ref = oracle.mlp_fw(enc, p[:3072], n_hidden=1, out_act=0)
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * scale)
+
+
+def test_grid_encoding_alone_bit_level(density_net):
+    """Identity-like MLP probe: with W0 = [I32 ; 0] and Wout rows picking features, the network output reproduces 16 encoded features;
+    the interpolation itself is f32 fmaf in the same order on both sides -> fp16 results equal except for f32 rounding ties."""
+    net = density_net
+    saved = net.params.detach().clone()
+    try:
+        with torch.no_grad():
+            w0 = torch.zeros(64, 32)
+            w0[:32] = torch.eye(32)
+            wo = torch.zeros(16, 64)
+            wo[torch.arange(16), torch.arange(16) * 2] = 1.0  # feature 0 of each level
+            net.params[:3072] = torch.cat([w0.reshape(-1), wo.reshape(-1)]).to(DEV)
+            # positive table so that ReLU is the identity
+            net.params[3072:] = net.params[3072:].abs()
+        x = np.random.default_rng(0).random((5000, 3)).astype(np.float32)
+        with torch.no_grad():
+            out = net(T(x)).float().cpu().numpy()
+        p = _half_np(net.params)
+        enc = oracle.grid_encode_fw(x, p[3072:].reshape(-1, 2), **GRID)
+        ref = enc[:, 0::2]
+        assert np.mean(out != ref) < 2e-3 and np.abs(out - ref).max() <= 2 ** -10 * np.abs(ref).max()
+    finally:
+        with torch.no_grad():
+            net.params.copy_(saved)
+
+
+@pytest.mark.parametrize('m', [1, 33, 4096])
+def test_color_network_forward(color_net, m):
+    rng = np.random.default_rng(m + 5)
+    d = rng.normal(size=(m, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    h = (rng.normal(size=(m, 16)) * 0.5).astype(np.float16)
+    x = torch.cat([T(d * 0.5 + 0.5).half(), T(h)], dim=-1)
+    with torch.no_grad():
+        out = color_net(x)
+    assert out.shape == (m, 3) and out.dtype == torch.float16
+    p = _half_np(color_net.params)
+    d01 = (d * np.float32(0.5) + np.float32(0.5)).astype(np.float16).astype(np.float32)
+    cin = np.concatenate([oracle.sh4_encode(d01), h.astype(np.float32)], 1)
+    ref = oracle.mlp_fw(cin, p, n_hidden=2, out_act=1)[:, :3]
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=0, atol=2e-3)  # sigmoid outputs in (0,1): 2 fp16 ulps
+
+
+def test_fused_query_matches_two_network_path_and_oracle(density_net, color_net):
+    from nerficg_amd import ngp
+    rng = np.random.default_rng(9)
+    m = 50_000
+    x = rng.random((m, 3)).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    sig, rgb = ngp.query_fused(density_net, color_net, T(x), T(d))
+    pd, pc = _half_np(density_net.params), _half_np(color_net.params)
+    r_sig, r_rgb, r_h = oracle.ngp_query(x, d, pd[:3072], pc, pd[3072:].reshape(-1, 2), **GRID)
+    # sigma = exp(fp16 h0): one fp16 ulp of h0 (|h0| <= ~4 -> 2^-8) moves sigma by 0.4 %
+    np.testing.assert_allclose(sig.cpu().numpy(), r_sig, rtol=1.2e-2)
+    assert np.mean(np.abs(sig.cpu().numpy() / r_sig - 1) > 1e-6) < 0.2  # most samples: identical fp16 h0
+    np.testing.assert_allclose(rgb.cpu().numpy(), r_rgb, rtol=0, atol=3e-3)
+    # and against the reference-shaped two-network path (Renderer.py:48-53)
+    with torch.no_grad():
+        h = density_net(T(x))
+        sig2 = torch.exp(h[:, 0].float())
+        rgb2 = color_net(torch.cat([(T(d) * 0.5 + 0.5).to(h.dtype), h], dim=-1)).float()
+    assert torch.equal(sig2, sig)
+    assert (rgb2 - rgb).abs().max().item() <= 2e-3
+
+
+def test_color_network_backward(color_net):
+    rng = np.random.default_rng(21)
+    m = 3000
+    d = rng.normal(size=(m, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    h = (rng.normal(size=(m, 16)) * 0.5).astype(np.float16)
+    x = torch.cat([T(d * 0.5 + 0.5).half(), T(h)], dim=-1).requires_grad_(True)
+    color_net.zero_grad()
+    out = color_net(x)
+    g_out = (rng.normal(size=(m, 3)) * 0.01).astype(np.float16)
+    out.backward(T(g_out))
+    p = _half_np(color_net.params)
+    d01 = (d * np.float32(0.5) + np.float32(0.5)).astype(np.float16).astype(np.float32)
+    cin = np.concatenate([oracle.sh4_encode(d01), h.astype(np.float32)], 1)
+    ref_out, acts = oracle.mlp_fw(cin, p, n_hidden=2, out_act=1, want_acts=True)
+    g_pad = np.zeros((m, 16), np.float32)
+    g_pad[:, :3] = g_out.astype(np.float32) * 128.0  # the internal loss scale is applied before the fp16 rounding of dZ
+    dW, d_in = oracle.mlp_bw(cin, p, ref_out, acts, g_pad, n_hidden=2, out_act=1)
+    dW /= 128.0
+    d_in /= 128.0
+    got = color_net.params.grad.cpu().numpy()
+    np.testing.assert_allclose(got, dW, rtol=2e-2, atol=2e-3 * np.abs(dW).max())
+    gx = x.grad.float().cpu().numpy()
+    assert np.all(gx[:, :3] == 0)
+    np.testing.assert_allclose(gx[:, 3:], d_in[:, 16:], rtol=2e-2, atol=2e-3 * np.abs(d_in).max())
+
+
+def test_density_network_backward_grid_and_mlp(density_net):
+    rng = np.random.default_rng(22)
+    m = 5000
+    x = rng.random((m, 3)).astype(np.float32)
+    density_net.zero_grad()
+    out = density_net(T(x))
+    g_out = (rng.normal(size=(m, 16)) * 0.01).astype(np.float16)
+    out.backward(T(g_out))
+    p = _half_np(density_net.params)
+    enc = oracle.grid_encode_fw(x, p[3072:].reshape(-1, 2), **GRID)
+    ref_out, acts = oracle.mlp_fw(enc, p[:3072], n_hidden=1, out_act=0, want_acts=True)
+    dW, d_in = oracle.mlp_bw(enc, p[:3072], ref_out, acts, g_out.astype(np.float32) * 128.0, n_hidden=1, out_act=0)
+    dW /= 128.0
+    d_in /= 128.0
+    got = density_net.params.grad.cpu().numpy()
+    np.testing.assert_allclose(got[:3072], dW, rtol=2e-2, atol=2e-3 * np.abs(dW).max())
+    g_table = oracle.grid_encode_bw(x, d_in, 6098120, **GRID)
+    got_t = got[3072:].reshape(-1, 2)
+    # coarse levels accumulate thousands of atomics per entry (order-dependent f32 sums): relative to the level's scale
+    np.testing.assert_allclose(got_t, g_table, rtol=3e-2, atol=3e-3 * np.abs(g_table).max())
+    assert np.count_nonzero(got_t) > 0 and np.array_equal(got_t == 0, g_table == 0) or np.mean((got_t == 0) != (g_table == 0)) < 1e-4
+
+
+def test_unsupported_configs_raise(tcnn):
+    with pytest.raises(RuntimeError):
+        tcnn.NetworkWithInputEncoding(3, 16, {**ENC_GRID, 'n_levels': 8}, NET_D)
+    with pytest.raises(RuntimeError):
+        tcnn.NetworkWithInputEncoding(3, 16, ENC_GRID, {**NET_D, 'n_neurons': 128})
+    with pytest.raises(RuntimeError):
+        tcnn.NetworkWithInputEncoding(3, 16, ENC_GRID, NET_D).to(DEV)(torch.zeros(4, 3))
+    assert tcnn.supports_jit_fusion() is True and tcnn.free_temporary_memory() is None
+
+
+def test_amp_training_step_updates_params(density_net, color_net):
+    """One optimisation step through both networks under autocast + GradScaler(128), as InstantNGP/Trainer.py:79-94."""
+    import nerficg_amd.VolumeRenderingV2 as vr
+    params = [density_net.params, color_net.params]
+    before = [p.detach().clone() for p in params]
+    opt = torch.optim.Adam(params, lr=1e-2, eps=1e-15, betas=(0.9, 0.99))
+    scaler = torch.amp.GradScaler(init_scale=128.0)
+    x = torch.rand(4096, 3, device=DEV)
+    d = torch.nn.functional.normalize(torch.randn(4096, 3, device=DEV), dim=-1)
+    with torch.amp.autocast('cuda'):
+        h = density_net(x)
+        sig = vr.TruncExp.apply(h[:, 0])
+        rgb = color_net(torch.cat([(d * 0.5 + 0.5).to(h.dtype), h], dim=-1))
+        loss = ((rgb.float() - 0.25) ** 2).mean() + 1e-3 * sig.mean()
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    for b, p in zip(before, params):
+        assert torch.isfinite(p).all() and not torch.equal(b, p.detach())
+    with torch.no_grad():
+        for b, p in zip(before, params):
+            p.copy_(b)
