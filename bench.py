@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: InstantNGP image rendering throughput (Mrays/s) on the lego-shaped synthetic workload.
+
+A "step" = one pass of the hot path (ray generation -> box test -> DDA march -> hash-grid encode -> tiny MLPs ->
+alpha compositing -> finalisation) over ONE 800x800 image (640 000 rays) per rank, through the C-ABI HIP library
+(InstantNGPRenderer.render_image_fused).  Inputs (occupancy bitfield, fp16 parameter copies) are resident in HBM
+before the timed region.  With N ranks every rank renders its own pose of the seeded orbit each step (weak scaling:
+rays are independent units, no data-path collective -- SURVEY.md 8e); the barrier + max-over-ranks timing follows the
+driver contract.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (metric/value/... + "roofline" for the dominant kernel + "cpu_baseline").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+W = H = 800
+N_POSES = 100
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_SAMPLE = 512 + 12 + 8  # 16 levels x 8 corners x 2 feat x 2 B gathers + 12 B sample record + 8 B packed output
+FLOP_PER_SAMPLE = 2 * (64 * 32 + 32 * 64 + 64 * 32 + 64 * 64 + 32 * 64)  # MFMA work actually issued (padded 32-row output tiles)
+QUERY_KERNEL = 'k_ngp_query_fused<MODE_RECORDS>'
+
+
+def build_scene(device):
+    import torch
+    from nerficg_amd.instant_ngp import Camera, InstantNGPModel, InstantNGPRenderer
+    from tests import scenes
+    model = InstantNGPModel(RANDOM_SEED=0, device=device)  # tcnn-style init: Xavier MLPs, table U(-1e-4, 1e-4), seed 0
+    with torch.no_grad():
+        model.occupancy_bitfield.copy_(torch.from_numpy(scenes.sphere_bitfield(128, 0.5, 0.35, 1)).to(device))  # solid |x| < 0.35
+    renderer = InstantNGPRenderer(model)
+    fx, fy, cx, cy = scenes.lego_intrinsics(W, H)
+    cam = Camera(width=W, height=H, focal_x=fx, focal_y=fy, center_x=cx, center_y=cy, near_plane=0.2, far_plane=1000.0,
+                 background_color=torch.ones(3))
+    rng = np.random.default_rng(0)
+    poses = [scenes.orbit_pose(float(rng.uniform(0, 2 * math.pi)), float(rng.uniform(-0.5, 0.9)), scenes.LEGO_RADIUS) for _ in range(N_POSES)]
+    return model, renderer, cam, poses
+
+
+def time_query_kernel(renderer, cam, pose, reps=5):
+    """Average duration of the dominant kernel (sample-record query) measured with HIP events on the launch stream."""
+    import torch
+    from nerficg_amd import _lib
+    import ctypes
+    m = renderer.model
+    out = renderer.render_image_fused(cam, pose, return_stats=True)
+    total = out['n_samples']
+    ws = next(iter(renderer._fused_ws.values()))
+    lib = _lib.load()
+    f3 = lambda t: (ctypes.c_float * 3)(*[float(v) for v in t.reshape(-1).tolist()])
+    mn, sz = f3(m.xyz_min), f3(m.xyz_size)
+    g = m.encoding_xyz.grid_cfg
+    st = _lib.stream_of(ws['ts'])
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        _lib.check(lib.nrc_ngp_query_samples(
+            _lib.ptr(ws['ts']), _lib.ptr(ws['rid']), _lib.ptr(ws['ray_od']), total, ctypes.cast(mn, ctypes.c_void_p),
+            ctypes.cast(sz, ctypes.c_void_p), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
+            _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
+            _lib.ptr(ws['packed']), st), 'ngp_query_samples')
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    return ms, total
+
+
+def cpu_baseline(cam_full, pose, model_params, crop=96):
+    """The CPU oracle (kind "port": the reference has no CPU path for InstantNGP) on a bounded sample: a crop x crop central
+    window of the same camera/pose/scene, all host cores (OpenMP in the encode/MLP loops)."""
+    import oracle
+    from tests import scenes
+    pd, pc, bitfield = model_params
+    fx, fy, cx, cy = scenes.lego_intrinsics(W, H)
+    # central crop = same rays as the full image's centre window
+    o, _, d = scenes.numpy_rays(crop, crop, pose, fx, fy, cx - (W - crop) / 2, cy - (H - crop) / 2)
+    t0 = time.perf_counter()
+    _, ht, _ = oracle.ray_aabb_intersect(o, d, np.zeros((1, 3), np.float32), np.full((1, 3), 0.5, np.float32), 1)
+    hits = ht[:, 0].copy()
+    hits[:, 0] = np.maximum(hits[:, 0], np.float32(0.2))
+    rays_a, xyzs, dirs, deltas, ts, counter = oracle.raymarching_train(o, d, hits, bitfield, 1, 0.5, 0.0, np.zeros(len(o), np.float32), 128, 1024)
+    x01 = (xyzs + np.float32(0.5)) / np.float32(1.0)
+    sig, rgb, _ = oracle.ngp_query(x01, dirs, pd[:3072], pc, pd[3072:].reshape(-1, 2), n_levels=16, log2_hashmap_size=19, base_resolution=16,
+                                   per_level_scale=float(math.exp(math.log(2048 * 1.0 / 16) / 15)))
+    oracle.composite_train_fw(sig, rgb, deltas, ts, rays_a, 1e-4)
+    dt = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    return {'value': round(len(o) / dt / 1e6, 6), 'unit': 'Mrays/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{crop}x{crop} central crop of one 800x800 pose ({len(o)} rays, {int(counter[0])} samples), oracle/*.c with OpenMP, {dt:.2f} s',
+            'msamples_per_s': round(int(counter[0]) / dt / 1e6, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=device)
+
+    model, renderer, cam, poses = build_scene(device)
+
+    def step(i):
+        return renderer.render_image_fused(cam, poses[(i * world + rank) % N_POSES], return_stats=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    samples = 0
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        samples += step(args.warmup + i)['n_samples']
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([samples], device=device, dtype=torch.int64)
+        dist.all_reduce(s)
+        samples = int(s.item())
+
+    if rank == 0:
+        rays = W * H * args.steps * world
+        value = rays / elapsed / 1e6
+        q_ms, q_samples = time_query_kernel(renderer, cam, poses[args.warmup % N_POSES])
+        achieved = BYTES_PER_SAMPLE * q_samples / (q_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = ROOT / 'profiles' / 'pmc_summary.json'
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get(QUERY_KERNEL, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        result = {
+            'metric': 'Mrays/s (INGP lego)', 'value': round(value, 4), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f16 (tables, weights, activations) / f32 (accumulate, march, composite)', 'data': 'synthetic',
+            'config': {'workload': 'ingp_lego: 800x800 image render per rank per step (640000 rays), solid-sphere occupancy r<0.35, '
+                                   'random-init hash grid (T=2^19, L=16, F=2) + 64-wide MLPs, seed 0, 100 seeded orbit poses',
+                       'rays_per_step_per_gpu': W * H, 'samples_per_ray': round(samples / rays, 3), 'parallelism': f'rays x{world} (weak)'},
+            'msamples_per_s': round(samples / elapsed / 1e6, 3),
+            'roofline': {'bound': 'hbm', 'kernel': QUERY_KERNEL, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'algorithmic_bytes_per_sample': BYTES_PER_SAMPLE,
+                         'kernel_ms': round(q_ms, 4), 'samples_per_launch': q_samples,
+                         'mfma_tflops': round(FLOP_PER_SAMPLE * q_samples / (q_ms * 1e-3) / 1e12, 2)},
+        }
+        if not args.no_cpu_baseline:
+            pd = model.encoding_xyz.params.detach().half().float().cpu().numpy()
+            pc = model.color_mlp_with_encoding.params.detach().half().float().cpu().numpy()
+            result['cpu_baseline'] = cpu_baseline(cam, poses[0], (pd, pc, model.occupancy_bitfield.cpu().numpy()))
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -8,6 +8,7 @@
 //   fw : 28 B read + 4 B written per sample ; bw : 44 B read + 16 B written per sample.
 // f32 sums are therefore tree-ordered instead of serial; the tolerance against the oracle is stated in the tests.
 #include "common.h"
+#include <hip/hip_fp16.h>
 
 namespace {
 
@@ -229,6 +230,57 @@ __global__ void __launch_bounds__(256) k_distortion_bw(const float* __restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ image compositor (fused pipeline)
+// One wave per ray over packed (h0, r, g, b) fp16 sample values: sigma = exp(h0) (TruncExp), alpha compositing with the
+// inference early-out (volumerendering.cu:205-249 semantics, T <= thr kills the ray after compositing that sample) and the
+// finalisation of InstantNGPRayRenderingComponent.render_rays_inference (Renderer.py:133-138).  20 B read per sample.
+__global__ void __launch_bounds__(256) k_composite_image(const __half* __restrict__ packed, const float* __restrict__ dts,
+                                                         const float* __restrict__ ts, const int64_t* __restrict__ rays_a,
+                                                         int64_t n_rays, float thr, float bg_r, float bg_g, float bg_b,
+                                                         float* __restrict__ rgb, float* __restrict__ alpha_out,
+                                                         float* __restrict__ depth_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_rays) return;
+    const int64_t start = rays_a[3 * n + 1];
+    const int N = (int)rays_a[3 * n + 2];
+    float carry = 1.0f, accR = 0.f, accG = 0.f, accB = 0.f, accD = 0.f, accO = 0.f;
+    for (int c = 0; c < N; c += 64) {
+        const int i = c + lane;
+        const bool valid = i < N;
+        const int64_t s = start + i;
+        float a = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, tt = 0.f;
+        if (valid) {
+            const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(packed) + 4 * s);
+            const __half2 p01 = *reinterpret_cast<const __half2*>(&raw.x), p23 = *reinterpret_cast<const __half2*>(&raw.y);
+            const float2 f01 = __half22float2(p01), f23 = __half22float2(p23);
+            a = alpha_of(expf(f01.x), dts[s]);
+            cr = f01.y; cg = f23.x; cb = f23.y;
+            tt = ts[s];
+        }
+        float Tb, Ta;
+        chunk_transmittance<64>(a, lane, carry, Tb, Ta);
+        const int fs = first_saturated<64>(valid && Ta <= thr, lane);
+        if (valid && lane <= fs) {
+            const float w = a * Tb;
+            accR += w * cr; accG += w * cg; accB += w * cb; accD += w * tt; accO += w;
+        }
+        if (fs < 64) break;
+    }
+    accR = nrc_group_sum<64>(accR); accG = nrc_group_sum<64>(accG); accB = nrc_group_sum<64>(accB);
+    accD = nrc_group_sum<64>(accD); accO = nrc_group_sum<64>(accO);
+    if (lane == 0) {
+        const float al = fminf(fmaxf(accO, 0.f), 1.f);
+        const float T = 1.f - al;
+        rgb[3 * n] = fminf(fmaxf(accR + T * bg_r, 0.f), 1.f);
+        rgb[3 * n + 1] = fminf(fmaxf(accG + T * bg_g, 0.f), 1.f);
+        rgb[3 * n + 2] = fminf(fmaxf(accB + T * bg_b, 0.f), 1.f);
+        alpha_out[n] = al;
+        depth_out[n] = T < 1.0f ? accD / al : 0.0f;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -326,6 +378,18 @@ int nrc_distortion_loss_bw(const float* dL_dloss, const float* ws_incl, const fl
     if (!dL_dloss || !ws_incl || !wts_incl || !ws || !deltas || !ts || !rays_a) return NRC_ERR_INVALID;
     hipLaunchKernelGGL(k_distortion_bw, dim3(nrc_cdiv(n_rays, 4)), dim3(256), 0, s, dL_dloss, ws_incl, wts_incl, ws, deltas, ts,
                        rays_a, n_rays, dL_dws);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_ngp_composite_image(const void* packed_f16, const float* dts, const float* ts, const int64_t* rays_a, int64_t n_rays,
+                            float T_threshold, const float* bg3_host, float* rgb, float* alpha, float* depth, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_rays < 0 || !bg3_host) return NRC_ERR_INVALID;
+    if (n_rays == 0) return NRC_OK;
+    if (!rays_a || !rgb || !alpha || !depth) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_composite_image, dim3(nrc_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, (const __half*)packed_f16, dts, ts,
+                       rays_a, n_rays, T_threshold, bg3_host[0], bg3_host[1], bg3_host[2], rgb, alpha, depth);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -425,6 +425,86 @@ __global__ void __launch_bounds__(256) k_generate_rays(RayGenCfg g, float* __res
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ fused image pipeline, stage 1
+// Camera rays are generated on the fly (no ray tensors read from HBM): pixel -> ray (View.get_rays semantics) -> shift by the
+// model centre (InstantNGP/Renderer.py:39) -> slab test against the model box (intersection.cu:5-22, :51) -> near/far clamp
+// (Renderer.py:42-43) -> DDA march with the TEST kernel's step rule (raymarching.cu:367-401).  Each ray's (o, d, t1, t2) is
+// kept (32 B/ray) for the later stages.
+struct RenderCam {
+    RayGenCfg g;
+    float center[3], half[3];
+    float near_plane, far_plane;
+    int64_t ray_begin;  // first pixel (row-major) of this shard
+};
+__device__ __forceinline__ void camera_ray(const RenderCam& cam, int64_t pix, Ray& q, float& t1, float& t2) {
+    const int px = (int)(pix % cam.g.width), py = (int)(pix / cam.g.width);
+    const float lx = linspace_at(cam.g.min_x, cam.g.max_x, cam.g.step_x, cam.g.width, px);
+    const float ly = linspace_at(cam.g.min_y, cam.g.max_y, cam.g.step_y, cam.g.height, py);
+    const float dx = lx * cam.g.R[0] + ly * cam.g.R[1] + cam.g.R[2];
+    const float dy = lx * cam.g.R[3] + ly * cam.g.R[4] + cam.g.R[5];
+    const float dz = lx * cam.g.R[6] + ly * cam.g.R[7] + cam.g.R[8];
+    const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+    q.dx = dx / nrm; q.dy = dy / nrm; q.dz = dz / nrm;
+    q.ox = cam.g.pos[0] - cam.center[0]; q.oy = cam.g.pos[1] - cam.center[1]; q.oz = cam.g.pos[2] - cam.center[2];
+    q.dxi = 1.0f / q.dx; q.dyi = 1.0f / q.dy; q.dzi = 1.0f / q.dz;
+    const float ax = (0.f - cam.half[0] - q.ox) * q.dxi, bx = (0.f + cam.half[0] - q.ox) * q.dxi;
+    const float ay = (0.f - cam.half[1] - q.oy) * q.dyi, by = (0.f + cam.half[1] - q.oy) * q.dyi;
+    const float az = (0.f - cam.half[2] - q.oz) * q.dzi, bz = (0.f + cam.half[2] - q.oz) * q.dzi;
+    float a = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    float b = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    if (a > b) { a = -1.0f; b = -1.0f; }
+    if (b > 0) a = fmaxf(a, 0.0f); else { a = -1.0f; b = -1.0f; }  // hits_t keeps -1 unless t2 > 0 (intersection.cu:48-53)
+    t1 = fmaxf(a, cam.near_plane);
+    t2 = fminf(b, cam.far_plane);
+}
+__global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c, int64_t n_rays, float* __restrict__ ray_od,
+                                                      float* __restrict__ ray_t, int32_t* __restrict__ counts,
+                                                      int32_t* __restrict__ block_sums) {
+    __shared__ int smem[8];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int n = 0;
+    if (r < n_rays) {
+        Ray q; float t1, t2;
+        camera_ray(cam, cam.ray_begin + r, q, t1, t2);
+        float t = t1, x, y, z, dt;
+        while (t < t2 && n < c.max_samples) {
+            if (march_step(q, c, t, x, y, z, dt)) { t += dt; n++; }
+        }
+        counts[r] = n;
+        float* od = ray_od + 6 * r;
+        od[0] = q.ox; od[1] = q.oy; od[2] = q.oz; od[3] = q.dx; od[4] = q.dy; od[5] = q.dz;
+        ray_t[2 * r] = t1; ray_t[2 * r + 1] = t2;
+    }
+    int total;
+    (void)nrc_block256_excl_scan_i(n, smem, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+// stage 3: emit the compact sample records (t, dt, ray id) = 12 B/sample; positions are recomputed by the consumer
+__global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_rays, const float* __restrict__ ray_od,
+                                                      const float* __restrict__ ray_t, const int64_t* __restrict__ rays_a,
+                                                      float* __restrict__ ts, float* __restrict__ dts, int32_t* __restrict__ rid) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rays) return;
+    const int64_t start = rays_a[3 * r + 1];
+    const int N = (int)rays_a[3 * r + 2];
+    if (N == 0) return;
+    const float* od = ray_od + 6 * r;
+    Ray q;
+    q.ox = od[0]; q.oy = od[1]; q.oz = od[2]; q.dx = od[3]; q.dy = od[4]; q.dz = od[5];
+    q.dxi = 1.0f / q.dx; q.dyi = 1.0f / q.dy; q.dzi = 1.0f / q.dz;
+    float t = ray_t[2 * r], x, y, z, dt;
+    const float t2 = ray_t[2 * r + 1];
+    int s = 0;
+    while (t < t2 && s < N) {
+        if (march_step(q, c, t, x, y, z, dt)) {
+            const int64_t k = start + s;
+            ts[k] = t; dts[k] = dt; rid[k] = (int32_t)r;
+            t += dt; s++;
+        }
+    }
+}
+
 MarchCfg make_cfg(const uint8_t* bitfield, int cascades, float scale, float esf, int grid_size, int max_samples, float dt_scale) {
     MarchCfg c;
     c.bitfield = bitfield; c.cascades = cascades; c.grid_size = grid_size; c.max_samples = max_samples;
@@ -573,6 +653,60 @@ int nrc_morton_encode(const float* positions, int64_t n, int64_t* codes, void* w
     hipLaunchKernelGGL(k_bounds_partial, dim3(nb), dim3(256), 0, s, positions, n, partial);
     hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, s, partial, nb, fin);
     hipLaunchKernelGGL(k_morton_encode, dim3(nrc_cdiv(n, 256)), dim3(256), 0, s, positions, n, fin, codes);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+
+static void fill_raygen(RayGenCfg& g, int32_t width, int32_t height, const double* intr, const double* c2w) {
+    g.width = width; g.height = height;
+    const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+    g.min_x = (float)((0.5 - cx) / fx); g.max_x = (float)((width - 1 + 0.5 - cx) / fx);
+    g.min_y = (float)((0.5 - cy) / fy); g.max_y = (float)((height - 1 + 0.5 - cy) / fy);
+    g.step_x = width > 1 ? (g.max_x - g.min_x) / (float)(width - 1) : 0.0f;
+    g.step_y = height > 1 ? (g.max_y - g.min_y) / (float)(height - 1) : 0.0f;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) g.R[3 * r + c] = (float)c2w[4 * r + c];
+        g.pos[r] = (float)c2w[4 * r + 3];
+    }
+}
+
+int64_t nrc_ngp_render_ws_bytes(int64_t n_rays) { return nrc_raymarching_train_ws_bytes(n_rays); }
+
+int nrc_ngp_render_count(int32_t width, int32_t height, const double* intr, const double* c2w, const float* center3, const float* half3,
+                         float near_plane, float far_plane, int64_t ray_begin, int64_t n_rays, const uint8_t* bitfield,
+                         int32_t cascades, float scale, float esf, int32_t grid_size, int32_t max_samples, float* ray_od,
+                         float* ray_t, int64_t* rays_a, int32_t* counter, void* workspace, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (width < 1 || height < 1 || !intr || !c2w || !center3 || !half3 || n_rays < 0 || ray_begin < 0 ||
+        ray_begin + n_rays > (int64_t)width * height || cascades < 1 || grid_size < 1 || max_samples < 1 || !counter)
+        return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_rays == 0) { hipMemsetAsync(counter, 0, 8, s); return NRC_OK; }
+    if (!bitfield || !ray_od || !ray_t || !rays_a || !workspace) return NRC_ERR_INVALID;
+    RenderCam cam;
+    fill_raygen(cam.g, width, height, intr, c2w);
+    for (int k = 0; k < 3; k++) { cam.center[k] = center3[k]; cam.half[k] = half3[k]; }
+    cam.near_plane = near_plane; cam.far_plane = far_plane; cam.ray_begin = ray_begin;
+    const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, (float)cascades);
+    const int64_t nb = nrc_cdiv(n_rays, 256);
+    int32_t* counts = (int32_t*)workspace;
+    int32_t* block_sums = (int32_t*)((char*)workspace + (n_rays * 4 + 255) / 256 * 256);
+    hipLaunchKernelGGL(k_render_count, dim3(nb), dim3(256), 0, s, cam, c, n_rays, ray_od, ray_t, counts, block_sums);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, n_rays, counter);
+    hipLaunchKernelGGL(k_assign_rays_a, dim3(nb), dim3(256), 0, s, counts, block_sums, n_rays, rays_a);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_ngp_render_write(int64_t n_rays, const uint8_t* bitfield, int32_t cascades, float scale, float esf, int32_t grid_size,
+                         int32_t max_samples, const float* ray_od, const float* ray_t, const int64_t* rays_a, float* ts, float* dts,
+                         int32_t* rid, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_rays < 0 || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
+    if (n_rays == 0) return NRC_OK;
+    if (!bitfield || !ray_od || !ray_t || !rays_a) return NRC_ERR_INVALID;
+    const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, (float)cascades);
+    hipLaunchKernelGGL(k_render_write, dim3(nrc_cdiv(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, c, n_rays, ray_od, ray_t, rays_a, ts, dts, rid);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

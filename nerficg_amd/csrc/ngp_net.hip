@@ -144,13 +144,22 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
     }
 }
 
-// ---- fully fused query: xyz01 (M,3), dir (M,3) -> sigma (M) f32, rgb (M,3) f32 ------------------------------------
+// ---- fully fused query ------------------------------------------------------------------------------------------------
 // density net (grid -> 64 -> 16) , sigma = exp(h0) , colour net (SH(dir) | h -> 64 -> 64 -> 3, sigmoid) in ONE pass:
 // the 16 density features stay in registers and become the colour net's identity inputs (ACC order).
-__global__ void __launch_bounds__(256) k_ngp_query_fused(const float* __restrict__ xyz01, const float* __restrict__ dirs, int64_t M,
-                                                         const __half* __restrict__ Wd, const __half* __restrict__ Wc,
-                                                         const __half2* __restrict__ table, GridCfg g,
-                                                         float* __restrict__ sigmas, float* __restrict__ rgbs) {
+//   MODE_ARRAYS  : xyz01 (M,3) f32 + dirs (M,3) f32                 -> sigmas (M) f32, rgbs (M,3) f32
+//   MODE_RECORDS : sample records (t, ray id) + per-ray (o,d) table  -> packed (h0, r, g, b) fp16 = 8 B/sample
+//                  (lossless: rgb ARE fp16 values, sigma = exp(fp16 h0) is re-derived by the compositor)
+enum { MODE_ARRAYS = 0, MODE_RECORDS = 1 };
+struct QueryIn {
+    const float* xyz01; const float* dirs;                       // MODE_ARRAYS
+    const float* ts; const int32_t* rid; const float* ray_od;    // MODE_RECORDS
+    float mn[3], sz[3];                                          // xyz_min, xyz_size of the model box (Renderer.py:50)
+};
+template <int MODE>
+__global__ void __launch_bounds__(256) k_ngp_query_fused(QueryIn in, int64_t M, const __half* __restrict__ Wd, const __half* __restrict__ Wc,
+                                                         const __half2* __restrict__ table, GridCfg g, float* __restrict__ sigmas,
+                                                         float* __restrict__ rgbs, __half* __restrict__ packed) {
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int64_t n_tiles = (M + 31) / 32;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
@@ -176,8 +185,24 @@ __global__ void __launch_bounds__(256) k_ngp_query_fused(const float* __restrict
         const int64_t i = tile * 32 + r;
         const bool valid = i < M;
         const int64_t ic = valid ? i : M - 1;
+        float px, py, pz, dx, dy, dz;
+        if constexpr (MODE == MODE_ARRAYS) {
+            px = in.xyz01[3 * ic]; py = in.xyz01[3 * ic + 1]; pz = in.xyz01[3 * ic + 2];
+            dx = in.dirs[3 * ic]; dy = in.dirs[3 * ic + 1]; dz = in.dirs[3 * ic + 2];
+        } else {
+            const float t = in.ts[ic];
+            const float* od = in.ray_od + 6 * (int64_t)in.rid[ic];
+            dx = od[3]; dy = od[4]; dz = od[5];
+            // same roundings as the op-by-op path: xyz = o + t*d (mul, add: raymarching.cu:368), then (xyz - min) / size in torch
+            px = __fdiv_rn(__fsub_rn(__fadd_rn(od[0], __fmul_rn(t, dx)), in.mn[0]), in.sz[0]);
+            py = __fdiv_rn(__fsub_rn(__fadd_rn(od[1], __fmul_rn(t, dy)), in.mn[1]), in.sz[1]);
+            pz = __fdiv_rn(__fsub_rn(__fadd_rn(od[2], __fmul_rn(t, dz)), in.mn[2]), in.sz[2]);
+        }
         h8 B[2];
-        encode_grid(xyz01, ic, hh, table, g, B);
+        {
+            const float xyz[3] = {px, py, pz};
+            encode_grid(xyz, 0, hh, table, g, B);
+        }
         f16v acc[2] = {zero16(), zero16()};
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
@@ -197,14 +222,14 @@ __global__ void __launch_bounds__(256) k_ngp_query_fused(const float* __restrict
         {
             // the reference feeds fp16(d*0.5+0.5) and tiny-cuda-nn maps it back with *2-1 (Renderer.py:52)
             float sh[16];
-            const float dx = (float)(_Float16)(dirs[3 * ic] * 0.5f + 0.5f) * 2.f - 1.f;
-            const float dy = (float)(_Float16)(dirs[3 * ic + 1] * 0.5f + 0.5f) * 2.f - 1.f;
-            const float dz = (float)(_Float16)(dirs[3 * ic + 2] * 0.5f + 0.5f) * 2.f - 1.f;
-            sh4_eval(dx, dy, dz, sh);
+            const float ex = (float)(_Float16)__fadd_rn(__fmul_rn(dx, 0.5f), 0.5f) * 2.f - 1.f;
+            const float ey = (float)(_Float16)__fadd_rn(__fmul_rn(dy, 0.5f), 0.5f) * 2.f - 1.f;
+            const float ez = (float)(_Float16)__fadd_rn(__fmul_rn(dz, 0.5f), 0.5f) * 2.f - 1.f;
+            sh4_eval(ex, ey, ez, sh);
 #pragma unroll
             for (int j = 0; j < 8; j++) X[0][j] = (_Float16)(hh ? sh[8 + j] : sh[j]);
         }
-        const float sigma = expf((float)X[1][0]);  // TruncExp forward on the fp16 feature 0 (lane half 0, element 0)
+        const _Float16 h0 = X[1][0];  // fp16 density feature 0 (lane half 0, element 0)
         acc[0] = zero16(); acc[1] = zero16();
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
@@ -227,9 +252,17 @@ __global__ void __launch_bounds__(256) k_ngp_query_fused(const float* __restrict
 #pragma unroll
         for (int s = 0; s < 4; s++) o = NRC_MFMA(CO[s], H[s], o);
         if (valid && hh == 0) {
-            sigmas[i] = sigma;
+            h4 pk;
+            pk[0] = h0;
 #pragma unroll
-            for (int c = 0; c < 3; c++) rgbs[3 * i + c] = (float)(_Float16)(1.f / (1.f + expf(-o[c])));
+            for (int c = 0; c < 3; c++) pk[1 + c] = (_Float16)(1.f / (1.f + expf(-o[c])));
+            if constexpr (MODE == MODE_ARRAYS) {
+                sigmas[i] = expf((float)h0);  // TruncExp forward (custom_functions.py:201-204)
+#pragma unroll
+                for (int c = 0; c < 3; c++) rgbs[3 * i + c] = (float)pk[1 + c];
+            } else {
+                *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(packed) + 4 * i) = pk;
+            }
         }
     }
 }
@@ -342,8 +375,33 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
     GridCfg g;
     const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
     if (rc != NRC_OK) return rc;
-    hipLaunchKernelGGL(k_ngp_query_fused, dim3(pick_blocks(M)), dim3(256), 0, (hipStream_t)stream, xyz01, dirs, M,
-                       (const __half*)density_weights_f16, (const __half*)color_weights_f16, (const __half2*)table_f16, g, sigmas, rgbs);
+    QueryIn in = {};
+    in.xyz01 = xyz01; in.dirs = dirs;
+    hipLaunchKernelGGL(k_ngp_query_fused<MODE_ARRAYS>, dim3(pick_blocks(M)), dim3(256), 0, (hipStream_t)stream, in, M,
+                       (const __half*)density_weights_f16, (const __half*)color_weights_f16, (const __half2*)table_f16, g, sigmas, rgbs,
+                       (__half*)nullptr);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_ngp_query_samples(const float* ts, const int32_t* rid, const float* ray_od, int64_t M, const float* xyz_min3,
+                          const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
+                          const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
+                          float per_level_scale, void* packed_f16, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (M < 0 || !density_weights_f16 || !color_weights_f16 || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
+    if (n_levels != 16) return NRC_ERR_UNSUPPORTED;
+    if (M == 0) return NRC_OK;
+    if (!ts || !rid || !ray_od || !packed_f16) return NRC_ERR_INVALID;
+    GridCfg g;
+    const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
+    if (rc != NRC_OK) return rc;
+    QueryIn in = {};
+    in.ts = ts; in.rid = rid; in.ray_od = ray_od;
+    for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
+    hipLaunchKernelGGL(k_ngp_query_fused<MODE_RECORDS>, dim3(pick_blocks(M)), dim3(256), 0, (hipStream_t)stream, in, M,
+                       (const __half*)density_weights_f16, (const __half*)color_weights_f16, (const __half2*)table_f16, g,
+                       (float*)nullptr, (float*)nullptr, (__half*)packed_f16);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -1,0 +1,313 @@
+"""nerficg_amd.instant_ngp -- host-side mirror of the reference's InstantNGP method for the hot path
+(src/Methods/InstantNGP/Model.py, src/Methods/InstantNGP/Renderer.py), written against nerficg_amd's drop-in modules.
+
+Same class / method / attribute names and argument meaning as the reference, minus its Framework plumbing (config
+objects, View/RayBatch dataclasses): rays are plain (N,3) tensors, cameras are the small `Camera` record below.  The
+reference's own method package keeps working unchanged when its native imports are redirected; this
+mirror exists so that parity tests and bench.py can drive the identical call sequence on a box without the reference.
+
+On top of the mirrored op-by-op path, `InstantNGPRenderer.render_image_fused` is the MI355X-native restructuring of
+render_image (no ray tensors, no per-iteration host syncs) -- it must produce the same image (tests/test_gpu_render_parity.py).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import VolumeRenderingV2 as VolumeRenderingCuda
+from . import _lib
+from . import tinycudann as tcnn
+from .raygen import generate_rays
+
+
+def next_multiple(value, multiple: int) -> int:
+    """src/Methods/InstantNGP/utils.py:10-11"""
+    return int(((value + multiple - 1) // multiple) * multiple)
+
+
+@dataclass
+class Camera:
+    """The fields of PerspectiveCamera / SharedCameraSettings the hot path reads (src/Cameras/Perspective.py:16-37)."""
+    width: int
+    height: int
+    focal_x: float
+    focal_y: float
+    center_x: float | None = None
+    center_y: float | None = None
+    near_plane: float = 0.2
+    far_plane: float = 1000.0
+    background_color: torch.Tensor = field(default_factory=lambda: torch.ones(3))
+
+    def __post_init__(self) -> None:
+        if self.center_x is None:
+            self.center_x = self.width / 2
+        if self.center_y is None:
+            self.center_y = self.height / 2
+
+
+class InstantNGPModel(torch.nn.Module):
+    """src/Methods/InstantNGP/Model.py:15-123 (defaults = the @Framework.Configurable.configure block :14-30)."""
+
+    def __init__(self, SCALE: float = 0.5, RESOLUTION: int = 128, CENTER=(0.0, 0.0, 0.0), HASHGRID_N_LEVELS: int = 16,
+                 HASHGRID_N_FEATURES_PER_LEVEL: int = 2, HASHGRID_LOG2_SIZE: int = 19, HASHGRID_BASE_RESOLUTION: int = 16,
+                 HASHGRID_TARGET_RESOLUTION: int = 2048, N_DENSITY_OUTPUT_FEATURES: int = 16, N_DENSITY_NEURONS: int = 64,
+                 N_DENSITY_LAYERS: int = 1, DIR_SH_ENCODING_DEGREE: int = 4, N_COLOR_NEURONS: int = 64, N_COLOR_LAYERS: int = 2,
+                 RANDOM_SEED: int = 1618033989, device: str | torch.device = 'cuda') -> None:
+        super().__init__()
+        self.SCALE, self.RESOLUTION, self.CENTER = SCALE, RESOLUTION, list(CENTER)
+        dev = torch.device(device)
+        self.center = torch.tensor([self.CENTER], dtype=torch.float32, device=dev)
+        self.xyz_min = -torch.ones(1, 3, device=dev) * SCALE
+        self.xyz_max = torch.ones(1, 3, device=dev) * SCALE
+        self.xyz_size = self.xyz_max - self.xyz_min
+        self.half_size = self.xyz_size / 2
+        self.cascades = max(1 + int(math.ceil(math.log2(2 * SCALE))), 1)
+        g = torch.arange(RESOLUTION, dtype=torch.int32, device=dev)
+        self.grid_coords = torch.stack(torch.meshgrid([g, g, g], indexing='xy'), dim=-1).reshape(-1, 3).contiguous()
+        self.register_buffer('occupancy_grid', torch.zeros(self.cascades, RESOLUTION ** 3, device=dev))
+        self.register_buffer('occupancy_bitfield', torch.zeros(self.cascades * RESOLUTION ** 3 // 8, dtype=torch.uint8, device=dev))
+        self.encoding_xyz = tcnn.NetworkWithInputEncoding(
+            n_input_dims=3, n_output_dims=N_DENSITY_OUTPUT_FEATURES,
+            encoding_config={
+                'otype': 'Grid', 'type': 'Hash', 'n_levels': HASHGRID_N_LEVELS, 'n_features_per_level': HASHGRID_N_FEATURES_PER_LEVEL,
+                'log2_hashmap_size': HASHGRID_LOG2_SIZE, 'base_resolution': HASHGRID_BASE_RESOLUTION,
+                'per_level_scale': math.exp(math.log(HASHGRID_TARGET_RESOLUTION * (2 * SCALE) / HASHGRID_BASE_RESOLUTION) / (HASHGRID_N_LEVELS - 1)),
+                'interpolation': 'Linear'},
+            network_config={'otype': 'FullyFusedMLP', 'activation': 'ReLU', 'output_activation': 'None',
+                            'n_neurons': N_DENSITY_NEURONS, 'n_hidden_layers': N_DENSITY_LAYERS},
+            seed=RANDOM_SEED).to(dev)
+        n_params_mlp = 0
+        n_inputs = next_multiple(HASHGRID_N_FEATURES_PER_LEVEL * HASHGRID_N_LEVELS, 16)
+        for _ in range(N_DENSITY_LAYERS):
+            n_params_mlp += next_multiple(N_DENSITY_NEURONS * n_inputs, 16)
+            n_inputs = N_DENSITY_NEURONS
+        n_params_mlp += next_multiple(self.encoding_xyz.n_output_dims, 16) * n_inputs
+        self.n_params_encoding_mlp = n_params_mlp
+        self.color_mlp_with_encoding = tcnn.NetworkWithInputEncoding(
+            n_input_dims=3 + self.encoding_xyz.n_output_dims, n_output_dims=3,
+            encoding_config={'otype': 'Composite', 'nested': [
+                {'n_dims_to_encode': 3, 'otype': 'SphericalHarmonics', 'degree': DIR_SH_ENCODING_DEGREE}, {'otype': 'Identity'}]},
+            network_config={'otype': 'FullyFusedMLP', 'activation': 'ReLU', 'output_activation': 'Sigmoid',
+                            'n_neurons': N_COLOR_NEURONS, 'n_hidden_layers': N_COLOR_LAYERS},
+            seed=RANDOM_SEED).to(dev)
+        self.n_mlp_params = len(self.color_mlp_with_encoding.params) + self.n_params_encoding_mlp
+
+    def weight_decay_mlp(self) -> torch.Tensor:
+        """Model.py:38-44"""
+        loss = self.encoding_xyz.params[:self.n_params_encoding_mlp].pow(2).sum()
+        loss = loss + self.color_mlp_with_encoding.params.pow(2).sum()
+        return loss / self.n_mlp_params
+
+
+class InstantNGPRayRenderingComponent(torch.nn.Module):
+    """src/Methods/InstantNGP/Renderer.py:19-138"""
+
+    def __init__(self, model: InstantNGPModel) -> None:
+        super().__init__()
+        self.model = model
+
+    def forward(self, origin: torch.Tensor, view_direction: torch.Tensor, camera: Camera, max_samples: int, bg_color: torch.Tensor,
+                exponential_steps: bool, train_mode: bool) -> dict[str, torch.Tensor]:
+        rays_o = origin - self.model.center
+        rays_d = view_direction.contiguous()
+        hits_t = VolumeRenderingCuda.RayAABBIntersector.apply(rays_o, rays_d, torch.zeros((1, 3), device=rays_o.device), self.model.half_size, 1)[1]
+        hits_t[..., 0].clamp_min_(camera.near_plane)
+        hits_t[..., 1].clamp_max_(camera.far_plane)
+        exp_step_factor = 1 / 256 if exponential_steps else 0.0
+        render_fn = self.render_rays_training if train_mode else self.render_rays_inference
+        return render_fn(rays_o, rays_d, hits_t, max_samples, bg_color, exp_step_factor)
+
+    def query_model(self, x: torch.Tensor, d: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        h = self.model.encoding_xyz((x - self.model.xyz_min) / self.model.xyz_size)
+        sigmas = VolumeRenderingCuda.TruncExp.apply(h[:, 0])
+        rgbs = self.model.color_mlp_with_encoding(torch.cat([(d * 0.5 + 0.5).to(h.dtype), h], dim=-1))
+        return sigmas, rgbs
+
+    def query_density(self, x: torch.Tensor) -> torch.Tensor:
+        h = self.model.encoding_xyz((x - self.model.xyz_min) / self.model.xyz_size)
+        return VolumeRenderingCuda.TruncExp.apply(h[:, 0])
+
+    @torch.amp.autocast('cuda')
+    def render_rays_training(self, rays_o, rays_d, hits_t, max_samples, bg_color, exp_step_factor) -> dict[str, torch.Tensor]:
+        rays_a, xyzs, dirs, deltas, ts, rm_samples = VolumeRenderingCuda.RayMarcher.apply(
+            rays_o, rays_d, hits_t[:, 0], self.model.occupancy_bitfield, self.model.cascades, self.model.SCALE, exp_step_factor,
+            self.model.RESOLUTION, max_samples)
+        sigmas, rgbs = self.query_model(xyzs, dirs)
+        vr_samples, alpha, depth, rgb, ws = VolumeRenderingCuda.VolumeRenderer.apply(sigmas, rgbs.contiguous(), deltas, ts, rays_a, 1e-4)
+        rgb = rgb + bg_color * (1 - alpha[:, None])
+        depth = depth / (alpha + 1e-6)
+        return {'rgb': rgb, 'alpha': alpha, 'depth': depth, 'rm_samples': rm_samples}
+
+    @torch.no_grad()
+    def render_rays_inference(self, rays_o, rays_d, hits_t, max_samples, bg_color, exp_step_factor, fused_query: bool = False) -> dict[str, torch.Tensor]:
+        """Renderer.py:86-138, statement for statement.  `fused_query` swaps query_model for the single-kernel equivalent."""
+        n_rays = len(rays_o)
+        device = rays_o.device
+        rgb = torch.zeros(n_rays, 3, device=device)
+        alpha = torch.zeros(n_rays, device=device)
+        depth = torch.zeros(n_rays, device=device)
+        alive_indices = torch.arange(n_rays, device=device)
+        min_samples = 1 if exp_step_factor == 0 else 4
+        samples = 0
+        hits = hits_t[:, 0]
+        while samples < max_samples:
+            n_alive = len(alive_indices)
+            if n_alive == 0:
+                break
+            n_samples = max(min(n_rays // n_alive, 64), min_samples)
+            samples += n_samples
+            xyzs, dirs, deltas, ts, n_eff_samples = VolumeRenderingCuda.raymarching_test(
+                rays_o, rays_d, hits, alive_indices, self.model.occupancy_bitfield, self.model.cascades, self.model.SCALE,
+                exp_step_factor, self.model.RESOLUTION, max_samples, n_samples)
+            xyzs = xyzs.reshape(-1, 3)
+            dirs = dirs.reshape(-1, 3)
+            valid_mask = (dirs != 0).any(dim=1)
+            if valid_mask.sum() == 0:
+                break
+            sigmas = torch.zeros(len(xyzs), device=device)
+            rgbs = torch.zeros(len(xyzs), 3, device=device)
+            if fused_query:
+                from .ngp import query_fused
+                x01 = ((xyzs[valid_mask] - self.model.xyz_min) / self.model.xyz_size).contiguous()
+                _sigmas, _rgbs = query_fused(self.model.encoding_xyz, self.model.color_mlp_with_encoding, x01, dirs[valid_mask].contiguous())
+            else:
+                with torch.amp.autocast('cuda'):
+                    _sigmas, _rgbs = self.query_model(xyzs[valid_mask], dirs[valid_mask])
+            sigmas[valid_mask], rgbs[valid_mask] = _sigmas.float(), _rgbs.float()
+            sigmas = sigmas.reshape(-1, n_samples)
+            rgbs = rgbs.reshape(-1, n_samples, 3)
+            VolumeRenderingCuda.composite_test_fw(sigmas, rgbs, deltas, ts, hits, alive_indices, 1e-4, n_eff_samples, alpha, depth, rgb)
+            alive_indices = alive_indices[alive_indices >= 0]
+        alpha.clamp_(0, 1)
+        transmittance = 1 - alpha
+        rgb += transmittance[:, None] * bg_color
+        rgb.clamp_(0, 1)
+        depth = torch.where(transmittance < 1.0, depth / alpha, 0.0)
+        return {'rgb': rgb, 'alpha': alpha, 'depth': depth}
+
+
+class InstantNGPRenderer:
+    """src/Methods/InstantNGP/Renderer.py:141-272 (MAX_SAMPLES / EXPONENTIAL_STEPS / DENSITY_THRESHOLD defaults :141-145)."""
+
+    def __init__(self, model: InstantNGPModel, MAX_SAMPLES: int = 1024, EXPONENTIAL_STEPS: bool = False, DENSITY_THRESHOLD: float = 0.01) -> None:
+        self.model = model
+        self.MAX_SAMPLES, self.EXPONENTIAL_STEPS, self.DENSITY_THRESHOLD = MAX_SAMPLES, EXPONENTIAL_STEPS, DENSITY_THRESHOLD
+        self.ray_rendering_component = InstantNGPRayRenderingComponent(model)
+        self.density_threshold = DENSITY_THRESHOLD * MAX_SAMPLES / 3 ** 0.5
+        self._fused_ws: dict = {}
+
+    def render_rays(self, origin, view_direction, camera: Camera, train_mode: bool = False, custom_bg_color: torch.Tensor | None = None):
+        bg = custom_bg_color if custom_bg_color is not None else camera.background_color.to(origin.device)
+        return self.ray_rendering_component(origin, view_direction, camera, self.MAX_SAMPLES, bg, self.EXPONENTIAL_STEPS, train_mode)
+
+    def render_image(self, camera: Camera, c2w: np.ndarray, to_chw: bool = False) -> dict[str, torch.Tensor]:
+        """Renderer.py:172-180: view.get_rays() -> render_rays -> reshape to images."""
+        rays = generate_rays(camera.width, camera.height, camera.focal_x, camera.focal_y, camera.center_x, camera.center_y, c2w,
+                             device=self.model.center.device, want_direction=False)
+        out = self.render_rays(rays['origin'], rays['view_direction'], camera)
+        for key in out:
+            out[key] = out[key].reshape(camera.height, camera.width, -1)
+            if to_chw:
+                out[key] = out[key].permute(2, 0, 1)
+        return out
+
+    # ---------------------------------------------------------------- MI355X-native image pipeline
+    @torch.no_grad()
+    def render_image_fused(self, camera: Camera, c2w: np.ndarray, ray_begin: int = 0, n_rays: int | None = None,
+                           return_stats: bool = False) -> dict[str, torch.Tensor]:
+        """Same image as render_image (flat (n_rays, C) layout for a pixel range), four device stages and ONE host sync
+        (the sample count, to size the record buffers)."""
+        m = self.model
+        lib = _lib.load()
+        dev = m.center.device
+        total_px = camera.width * camera.height
+        n = total_px - ray_begin if n_rays is None else int(n_rays)
+        c2w = np.ascontiguousarray(np.asarray(c2w, dtype=np.float64))
+        if c2w.shape == (3, 4):
+            c2w = np.vstack([c2w, [0.0, 0.0, 0.0, 1.0]])
+        intr = (ctypes.c_double * 4)(camera.focal_x, camera.focal_y, camera.center_x, camera.center_y)
+        mat = (ctypes.c_double * 16)(*c2w.reshape(-1).tolist())
+        f3 = lambda t: (ctypes.c_float * 3)(*[float(v) for v in t.reshape(-1).tolist()])
+        key = (n, str(dev))
+        ws = self._fused_ws.get(key)
+        if ws is None:
+            ws = dict(ray_od=torch.empty(n, 6, device=dev), ray_t=torch.empty(n, 2, device=dev),
+                      rays_a=torch.empty(n, 3, dtype=torch.int64, device=dev), counter=torch.empty(2, dtype=torch.int32, device=dev),
+                      scratch=torch.empty(max(int(lib.nrc_ngp_render_ws_bytes(n)), 1), dtype=torch.uint8, device=dev),
+                      rgb=torch.empty(n, 3, device=dev), alpha=torch.empty(n, device=dev), depth=torch.empty(n, device=dev), cap=0)
+            self._fused_ws = {key: ws}
+        st = _lib.stream_of(ws['ray_od'])
+        esf = 1 / 256 if self.EXPONENTIAL_STEPS else 0.0
+        center, half = f3(m.center), f3(m.half_size)
+        _lib.check(lib.nrc_ngp_render_count(
+            camera.width, camera.height, ctypes.cast(intr, ctypes.c_void_p), ctypes.cast(mat, ctypes.c_void_p),
+            ctypes.cast(center, ctypes.c_void_p), ctypes.cast(half, ctypes.c_void_p), float(camera.near_plane), float(camera.far_plane),
+            int(ray_begin), n, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION, self.MAX_SAMPLES,
+            _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['rays_a']), _lib.ptr(ws['counter']), _lib.ptr(ws['scratch']), st),
+            'ngp_render_count')
+        total = int(ws['counter'][0].item())
+        if total > ws['cap']:
+            cap = int(total * 1.25) + 1024
+            ws.update(ts=torch.empty(cap, device=dev), dts=torch.empty(cap, device=dev), rid=torch.empty(cap, dtype=torch.int32, device=dev),
+                      packed=torch.empty(cap, 4, dtype=torch.float16, device=dev), cap=cap)
+        if total > 0:
+            _lib.check(lib.nrc_ngp_render_write(n, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION,
+                                                self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['rays_a']),
+                                                _lib.ptr(ws['ts']), _lib.ptr(ws['dts']), _lib.ptr(ws['rid']), st), 'ngp_render_write')
+            g = m.encoding_xyz.grid_cfg
+            mn, sz = f3(m.xyz_min), f3(m.xyz_size)
+            _lib.check(lib.nrc_ngp_query_samples(
+                _lib.ptr(ws['ts']), _lib.ptr(ws['rid']), _lib.ptr(ws['ray_od']), total, ctypes.cast(mn, ctypes.c_void_p),
+                ctypes.cast(sz, ctypes.c_void_p), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
+                _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
+                _lib.ptr(ws['packed']), st), 'ngp_query_samples')
+        bg = f3(camera.background_color.float().cpu())
+        _lib.check(lib.nrc_ngp_composite_image(_lib.ptr(ws.get('packed')), _lib.ptr(ws.get('dts')), _lib.ptr(ws.get('ts')), _lib.ptr(ws['rays_a']),
+                                               n, 1e-4, ctypes.cast(bg, ctypes.c_void_p), _lib.ptr(ws['rgb']), _lib.ptr(ws['alpha']),
+                                               _lib.ptr(ws['depth']), st), 'ngp_composite_image')
+        out = {'rgb': ws['rgb'], 'alpha': ws['alpha'], 'depth': ws['depth']}
+        if return_stats:
+            out['n_samples'] = total
+        return out
+
+    # ---------------------------------------------------------------- occupancy grid (Renderer.py:183-206, 247-272)
+    @torch.no_grad()
+    def get_occupancy_grid_cells(self):
+        indices = VolumeRenderingCuda.morton3D(self.model.grid_coords).long()
+        return [(indices, self.model.grid_coords)] * self.model.cascades
+
+    @torch.no_grad()
+    def sample_occupancy_grid(self, n_samples: int, density_threshold: float):
+        cells = []
+        dev = self.model.occupancy_grid.device
+        for c in range(self.model.cascades):
+            coords1 = torch.randint(self.model.RESOLUTION, (n_samples, 3), dtype=torch.int32, device=dev)
+            indices1 = VolumeRenderingCuda.morton3D(coords1).long()
+            indices2 = torch.nonzero(self.model.occupancy_grid[c] > density_threshold)[:, 0]
+            if len(indices2) > 0:
+                rand_idx = torch.randint(len(indices2), (n_samples,), device=dev)
+                indices2 = indices2[rand_idx]
+            coords2 = VolumeRenderingCuda.morton3D_invert(indices2.int())
+            cells += [(torch.cat([indices1, indices2]), torch.cat([coords1, coords2]))]
+        return cells
+
+    @torch.no_grad()
+    @torch.amp.autocast('cuda')
+    def update_occupancy_grid(self, warmup: bool = False, decay: float = 0.95) -> None:
+        m = self.model
+        occupancy_grid_tmp = torch.zeros_like(m.occupancy_grid)
+        cells = self.get_occupancy_grid_cells() if warmup else self.sample_occupancy_grid(m.RESOLUTION ** 3 // 4, self.density_threshold)
+        for c in range(m.cascades):
+            indices, coords = cells[c]
+            s = min(2 ** (c - 1), m.SCALE)
+            half_grid_size = s / m.RESOLUTION
+            xyzs_w = (coords / (m.RESOLUTION - 1) * 2 - 1) * (s - half_grid_size)
+            xyzs_w += (torch.rand_like(xyzs_w) * 2 - 1) * half_grid_size
+            occupancy_grid_tmp[c, indices] = self.ray_rendering_component.query_density(xyzs_w)
+        m.occupancy_grid = torch.where(m.occupancy_grid < 0, m.occupancy_grid, torch.maximum(m.occupancy_grid * decay, occupancy_grid_tmp))
+        mean_density = m.occupancy_grid[m.occupancy_grid > 0].mean().item()
+        VolumeRenderingCuda.packbits(m.occupancy_grid, min(mean_density, self.density_threshold), m.occupancy_bitfield)
