@@ -1,0 +1,37 @@
+/*
+ * oracle/gs_oracle.c -- instantiates oracle/gs_oracle_impl.h for float (gsf_*: parity oracle) and double (gsd_*: finite-
+ * difference reference for the analytic backward).  TEST INFRASTRUCTURE ONLY.  See gs_oracle_impl.h for the citations and
+ * the "parity unpinned" statement.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int IMIN(int a, int b) { return a < b ? a : b; }
+static inline int IMAX(int a, int b) { return a > b ? a : b; }
+
+#define REAL float
+#define FN(name) gsf_##name
+#define SQRT sqrtf
+#define EXP expf
+#define CEIL ceilf
+#define FMIN fminf
+#define FMAX fmaxf
+#include "gs_oracle_impl.h"
+#undef REAL
+#undef FN
+#undef SQRT
+#undef EXP
+#undef CEIL
+#undef FMIN
+#undef FMAX
+
+#define REAL double
+#define FN(name) gsd_##name
+#define SQRT sqrt
+#define EXP exp
+#define CEIL ceil
+#define FMIN fmin
+#define FMAX fmax
+#include "gs_oracle_impl.h"
