@@ -73,7 +73,7 @@ def time_query_kernel(renderer, cam, pose, reps=5):
             _lib.ptr(ws['ts']), _lib.ptr(ws['rid']), _lib.ptr(ws['ray_od']), total, ctypes.cast(mn, ctypes.c_void_p),
             ctypes.cast(sz, ctypes.c_void_p), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
             _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
-            _lib.ptr(ws['packed']), st), 'ngp_query_samples')
+            _lib.ptr(ws['packed']), _lib.ptr(ws['qws']), st), 'ngp_query_samples')
         b.record()
     torch.cuda.synchronize()
     ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))

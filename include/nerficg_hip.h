@@ -144,11 +144,14 @@ int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int3
 /* hash-grid backward: grad_table (entries,2) f32 += trilinear scatter of d_features (M, 2*n_levels) f32 (caller zeroes) */
 int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t n_levels, int32_t log2_hashmap_size,
                       int32_t base_resolution, float per_level_scale, float* grad_table, nrc_stream_t stream);
-/* InstantNGPRayRenderingComponent.query_model (Renderer.py:48-53) in one launch: xyz01 (M,3) f32 in [0,1], dirs (M,3) f32 unit
+/* InstantNGPRayRenderingComponent.query_model (Renderer.py:48-53) as an encode + MLP kernel pair over Infinity-Cache sized
+ * chunks (workspace: nrc_ngp_query_ws_bytes(M) bytes): xyz01 (M,3) f32 in [0,1], dirs (M,3) f32 unit
  * vectors -> sigmas (M) f32 = exp(fp16 feature 0), rgbs (M,3) f32 = fp16 sigmoid outputs. */
+int64_t nrc_ngp_query_ws_bytes(int64_t M);
 int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const void* density_weights_f16,
                         const void* color_weights_f16, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
-                        int32_t base_resolution, float per_level_scale, float* sigmas, float* rgbs, nrc_stream_t stream);
+                        int32_t base_resolution, float per_level_scale, float* sigmas, float* rgbs, void* workspace,
+                        nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 6 -- fused InstantNGP image pipeline (MI355X-native restructuring of InstantNGPRenderer.render_image ->
@@ -158,7 +161,8 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
  *                             count per ray; writes ray_od (n,6) = (o - centre, d), ray_t (n,2), rays_a (n,3) in ray order,
  *                             counter[0] = total samples.  intr/c2w/center3/half3 are HOST pointers.
  *   2. nrc_ngp_render_write : sample records ts, dts (f32) and rid (i32), counter[0] rows.
- *   3. nrc_ngp_query_samples: records -> packed (h0, r, g, b) fp16 (sigma = exp(h0)); xyz_min3/xyz_size3 HOST pointers.
+ *   3. nrc_ngp_query_samples: records -> packed (h0, r, g, b) fp16 (sigma = exp(h0)); xyz_min3/xyz_size3 HOST pointers;
+ *                             workspace: nrc_ngp_query_ws_bytes(M) bytes.
  *   4. nrc_ngp_composite_image: packed values -> rgb (n,3), alpha (n), depth (n) incl. background / clamps (bg3 HOST).
  * rays [ray_begin, ray_begin + n_rays) of the H*W image: the multi-GPU shard is a contiguous pixel range.
  * ===================================================================================================== */
@@ -175,7 +179,7 @@ int nrc_ngp_render_write(int64_t n_rays, const uint8_t* density_bitfield, int32_
 int nrc_ngp_query_samples(const float* ts, const int32_t* rid, const float* ray_od, int64_t M, const float* xyz_min3,
                           const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
-                          float per_level_scale, void* packed_f16, nrc_stream_t stream);
+                          float per_level_scale, void* packed_f16, void* workspace, nrc_stream_t stream);
 int nrc_ngp_composite_image(const void* packed_f16, const float* dts, const float* ts, const int64_t* rays_a,
                             int64_t n_rays, float T_threshold, const float* bg3, float* rgb, float* alpha, float* depth,
                             nrc_stream_t stream);

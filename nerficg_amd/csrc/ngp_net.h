@@ -24,6 +24,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 #define NRC_MAX_LEVELS 16
 
 struct GridCfg {
+    uint32_t total_entries;           // sum of the level sizes
     uint32_t offset[NRC_MAX_LEVELS];  // first entry of the level (in entries of n_features halves)
     uint32_t size[NRC_MAX_LEVELS];    // entries in the level
     uint32_t res[NRC_MAX_LEVELS];
@@ -77,11 +78,14 @@ __device__ __forceinline__ h8 load_wT_frag(const __half* __restrict__ W, int ld,
 }
 
 // ---- D tile -> next layer's B fragments --------------------------------------------------------------------------
+// ReLU is applied AFTER the f32->f16 conversion as a packed fp16 max (same value: rounding is monotone and keeps 0),
+// which halves the VALU work of the activation.
 __device__ __forceinline__ h8 acc_to_frag_relu(const f16v& acc, int g) {
     h8 f;
 #pragma unroll
-    for (int j = 0; j < 8; j++) f[j] = (_Float16)fmaxf(acc[8 * g + j], 0.f);
-    return f;
+    for (int j = 0; j < 8; j++) f[j] = (_Float16)acc[8 * g + j];
+    const h8 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    return __builtin_elementwise_max(f, z);
 }
 __device__ __forceinline__ h8 acc_to_frag(const f16v& acc, int g) {
     h8 f;
@@ -93,10 +97,11 @@ __device__ __forceinline__ h8 acc_to_frag(const f16v& acc, int g) {
 #define NRC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 // ---- hash-grid encoding of one sample for one level -> (f0, f1) --------------------------------------------------
-__device__ __forceinline__ uint32_t grid_entry(uint32_t x, uint32_t y, uint32_t z, uint32_t res, uint32_t size, bool hashed) {
-    if (hashed) return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) & (size - 1u);
-    return (x + y * res + z * res * res) % size;
-}
+// Entry index of a corner.  Dense levels: x + y*res + z*res^2, wrapped once at `size` (inputs in [0,1] never exceed
+// 2*size; anything beyond is clamped into the level so that the gather stays in bounds).  Hashed levels: the spatial hash
+// x ^ y*2654435761 ^ z*805459861 masked to the power-of-two level size.  Both forms share per-axis partial terms that are
+// computed once per level (the +1 corner is the term plus its multiplier), and the choice is a select, not a branch: the
+// two halves of a wave work on different levels, so a branch on `hashed` would serialise them.
 struct Corner8 {
     uint32_t e[8];
     float w[8];
@@ -108,24 +113,102 @@ __device__ __forceinline__ void grid_corners(float px, float py, float pz, float
     const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
     const float wx1 = fx - flx, wy1 = fy - fly, wz1 = fz - flz;
     const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
+    // weight products in the order (x*y)*z, as in the oracle
+    const float wxy[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+    const uint32_t my = hashed ? 2654435761u : res, mz = hashed ? 805459861u : res * res;
+    const uint32_t ty0 = gy * my, tz0 = gz * mz;
+    const uint32_t ty[2] = {ty0, ty0 + my}, tz[2] = {tz0, tz0 + mz};
+    const uint32_t mask = size - 1u;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const uint32_t qx = gx + (k & 1), qy = gy + ((k >> 1) & 1), qz = gz + ((k >> 2) & 1);
-        // weight product in the order x, y, z (matches the oracle's loop)
-        c.w[k] = (((k & 1) ? wx1 : wx0) * ((k & 2) ? wy1 : wy0)) * ((k & 4) ? wz1 : wz0);
-        c.e[k] = off + grid_entry(qx, qy, qz, res, size, hashed);
+        const uint32_t qx = gx + (k & 1), a = ty[(k >> 1) & 1], b = tz[(k >> 2) & 1];
+        const uint32_t h = (qx ^ a ^ b) & mask;
+        uint32_t d = qx + a + b;
+        d = d >= size ? d - size : d;
+        d = min(d, mask);
+        c.w[k] = wxy[k & 3] * ((k & 4) ? wz1 : wz0);
+        c.e[k] = off + (hashed ? h : d);
     }
 }
-__device__ __forceinline__ void grid_level_features(const __half2* __restrict__ table, const Corner8& c, float& f0, float& f1) {
-    __half2 v[8];
+// fp16 feature pairs are fetched with buffer loads: one 128-bit descriptor for the table, 32-bit byte offsets per lane
+// (no 64-bit address arithmetic per gather; out-of-range offsets return 0 instead of faulting)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_table_rsrc(const void* table, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(table), /*stride*/ 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void grid_level_features(__amdgpu_buffer_rsrc_t rsrc, const Corner8& c, float& f0, float& f1) {
+    uint32_t v[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = table[c.e[k]];
+    for (int k = 0; k < 8; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, c.e[k] << 2, 0, 0);
     f0 = 0.f; f1 = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const float2 t = __half22float2(v[k]);
+        const __half2 hv = *reinterpret_cast<const __half2*>(&v[k]);
+        const float2 t = __half22float2(hv);
         f0 = fmaf(c.w[k], t.x, f0);
         f1 = fmaf(c.w[k], t.y, f1);
+    }
+}
+
+
+// ---- split-phase encoding: issue the 64 gathers of a sample now, interpolate later ------------------------------------
+// The texture-address path is the bottleneck of the encoding (one distinct cache line per clock per CU); the only way to
+// keep it busy while the same wave runs its MFMA chain is to have the NEXT tile's gathers in flight across that chain.
+struct GridPending {
+    uint32_t raw[2][4][8];  // fp16x2 table entries of the 8 corners, [k-step][level in step][corner]
+    float fr[2][4][3];      // fractional cell coordinates
+};
+__device__ __forceinline__ void encode_grid_issue(float px, float py, float pz, int hh, __amdgpu_buffer_rsrc_t table, const GridCfg& g,
+                                                  GridPending& pd) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int l0 = 8 * s + q, l1 = 8 * s + 4 + q;
+            const float scale = hh ? g.scale[l1] : g.scale[l0];
+            const uint32_t res = hh ? g.res[l1] : g.res[l0];
+            const uint32_t size = hh ? g.size[l1] : g.size[l0];
+            const uint32_t off = hh ? g.offset[l1] : g.offset[l0];
+            const bool hashed = hh ? g.hashed[l1] : g.hashed[l0];
+            const float fx = fmaf(scale, px, 0.5f), fy = fmaf(scale, py, 0.5f), fz = fmaf(scale, pz, 0.5f);
+            const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+            const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
+            pd.fr[s][q][0] = fx - flx; pd.fr[s][q][1] = fy - fly; pd.fr[s][q][2] = fz - flz;
+            const uint32_t my = hashed ? 2654435761u : res, mz = hashed ? 805459861u : res * res;
+            const uint32_t ty0 = gy * my, tz0 = gz * mz;
+            const uint32_t ty[2] = {ty0, ty0 + my}, tz[2] = {tz0, tz0 + mz};
+            const uint32_t mask = size - 1u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t qx = gx + (k & 1), a = ty[(k >> 1) & 1], b = tz[(k >> 2) & 1];
+                const uint32_t h = (qx ^ a ^ b) & mask;
+                uint32_t d = qx + a + b;
+                d = d >= size ? d - size : d;
+                d = min(d, mask);
+                pd.raw[s][q][k] = __builtin_amdgcn_raw_buffer_load_b32(table, (off + (hashed ? h : d)) << 2, 0, 0);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void encode_grid_finish(const GridPending& pd, h8 (&B)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float wx1 = pd.fr[s][q][0], wy1 = pd.fr[s][q][1], wz1 = pd.fr[s][q][2];
+            const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
+            const float wxy[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+            float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float w = wxy[k & 3] * ((k & 4) ? wz1 : wz0);
+                const __half2 hv = *reinterpret_cast<const __half2*>(&pd.raw[s][q][k]);
+                const float2 t = __half22float2(hv);
+                f0 = fmaf(w, t.x, f0);
+                f1 = fmaf(w, t.y, f1);
+            }
+            B[s][2 * q] = (_Float16)f0;
+            B[s][2 * q + 1] = (_Float16)f1;
+        }
     }
 }
 

@@ -10,6 +10,7 @@
 // live in the wave's VGPRs for the whole persistent loop.  Per sample the kernel reads 12 B (+ the gathers, served by
 // L2 / Infinity Cache: the 24.4 MB table never streams from HBM twice) and writes 8-32 B.
 #include "ngp_net.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -17,9 +18,7 @@ enum { ENC_GRID = 0, ENC_SH_ID = 1 };
 enum { ACT_NONE = 0, ACT_SIGMOID = 1 };
 
 // ---- first-layer B fragments from the encodings -------------------------------------------------------------------
-__device__ __forceinline__ void encode_grid(const float* __restrict__ x, int64_t i, int hh, const __half2* __restrict__ table,
-                                            const GridCfg& g, h8 (&B)[2]) {
-    const float px = x[3 * i], py = x[3 * i + 1], pz = x[3 * i + 2];
+__device__ __forceinline__ void encode_grid(float px, float py, float pz, int hh, __amdgpu_buffer_rsrc_t table, const GridCfg& g, h8 (&B)[2]) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
 #pragma unroll
@@ -60,6 +59,7 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int64_t n_tiles = (M + 31) / 32;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
 
     h8 A0[2][2], AH[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1][2][4], AO[4];
     const __half* Wp = W;
@@ -84,7 +84,10 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
         const bool valid = i < M;
         const int64_t ic = valid ? i : M - 1;
         h8 B[2];
-        if constexpr (ENC == ENC_GRID) encode_grid(reinterpret_cast<const float*>(input), ic, hh, table, g, B);
+        if constexpr (ENC == ENC_GRID) {
+            const float* xp = reinterpret_cast<const float*>(input) + 3 * ic;
+            encode_grid(xp[0], xp[1], xp[2], hh, trs, g, B);
+        }
         else encode_sh_id(reinterpret_cast<const __half*>(input), in_ld, ic, hh, B);
         if constexpr (SAVE) {
             if (valid) {
@@ -144,70 +147,114 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
     }
 }
 
-// ---- fully fused query ------------------------------------------------------------------------------------------------
-// density net (grid -> 64 -> 16) , sigma = exp(h0) , colour net (SH(dir) | h -> 64 -> 64 -> 3, sigmoid) in ONE pass:
-// the 16 density features stay in registers and become the colour net's identity inputs (ACC order).
-//   MODE_ARRAYS  : xyz01 (M,3) f32 + dirs (M,3) f32                 -> sigmas (M) f32, rgbs (M,3) f32
-//   MODE_RECORDS : sample records (t, ray id) + per-ray (o,d) table  -> packed (h0, r, g, b) fp16 = 8 B/sample
-//                  (lossless: rgb ARE fp16 values, sigma = exp(fp16 h0) is re-derived by the compositor)
-enum { MODE_ARRAYS = 0, MODE_RECORDS = 1 };
+// ---- query pipeline: encode kernel + MLP kernel --------------------------------------------------------------------
+// Measured on MI355X (profiles/r01_*): a single kernel that gathers AND runs the MFMA chain is pinned at 1-2 waves per SIMD
+// by its register footprint and cannot keep the texture-address path busy (18-36 ms for 77 M samples, whichever way it was
+// scheduled), while its two halves run in 6.5 ms (gathers, latency hidden by 8 waves/SIMD) and 2.8 ms (MFMA) on their own.
+// The pipeline is therefore split at the 32 encoded features (64 B/sample, fp16, level-major so that both sides are
+// coalesced) and processed in chunks small enough for the features to stay in the 256 MB Infinity Cache.
+//
+//   k_grid_encode : one lane per (sample, level).  blockIdx%8 selects the level pair {x, x+8}: workgroups that share an XCD
+//                   (round-robin dispatch) gather from the same two levels, so each 4 MB L2 serves <= 4 MB of table instead of
+//                   all 24.4 MB (placement affects speed only).
+//   k_ngp_mlp     : density net -> sigma -> colour net from the level-major features; weights as LDS-resident A fragments.
+enum { SRC_ARRAYS = 0, SRC_RECORDS = 1 };
 struct QueryIn {
-    const float* xyz01; const float* dirs;                       // MODE_ARRAYS
-    const float* ts; const int32_t* rid; const float* ray_od;    // MODE_RECORDS
+    const float* xyz01; const float* dirs;                       // SRC_ARRAYS
+    const float* ts; const int32_t* rid; const float* ray_od;    // SRC_RECORDS
     float mn[3], sz[3];                                          // xyz_min, xyz_size of the model box (Renderer.py:50)
 };
-template <int MODE>
-__global__ void __launch_bounds__(256) k_ngp_query_fused(QueryIn in, int64_t M, const __half* __restrict__ Wd, const __half* __restrict__ Wc,
-                                                         const __half2* __restrict__ table, GridCfg g, float* __restrict__ sigmas,
-                                                         float* __restrict__ rgbs, __half* __restrict__ packed) {
-    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const int64_t n_tiles = (M + 31) / 32;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
-
-    h8 D0[2][2], DO[4], C0[2][2], C1[2][4], CO[4];
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int s = 0; s < 2; s++) D0[mt][s] = load_w_frag<false>(Wd, 32, 64, mt, s, r, hh);
-#pragma unroll
-    for (int s = 0; s < 4; s++) DO[s] = load_w_frag<true>(Wd + 64 * 32, 64, 16, 0, s, r, hh);
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-        C0[mt][0] = load_w_frag<false>(Wc, 32, 64, mt, 0, r, hh);  // SH coefficients: natural order
-        C0[mt][1] = load_w_frag<true>(Wc, 32, 64, mt, 1, r, hh);   // density features: ACC order
-#pragma unroll
-        for (int s = 0; s < 4; s++) C1[mt][s] = load_w_frag<true>(Wc + 64 * 32, 64, 64, mt, s, r, hh);
+template <int SRC>
+__device__ __forceinline__ void fetch_pos(const QueryIn& in, int64_t i, float& px, float& py, float& pz) {
+    if constexpr (SRC == SRC_ARRAYS) {
+        px = in.xyz01[3 * i]; py = in.xyz01[3 * i + 1]; pz = in.xyz01[3 * i + 2];
+    } else {
+        const float t = in.ts[i];
+        const float* od = in.ray_od + 6 * (int64_t)in.rid[i];
+        // same roundings as the op-by-op path: xyz = o + t*d (mul, add: raymarching.cu:368), then (xyz - min) / size in torch
+        px = __fdiv_rn(__fsub_rn(__fadd_rn(od[0], __fmul_rn(t, od[3])), in.mn[0]), in.sz[0]);
+        py = __fdiv_rn(__fsub_rn(__fadd_rn(od[1], __fmul_rn(t, od[4])), in.mn[1]), in.sz[1]);
+        pz = __fdiv_rn(__fsub_rn(__fadd_rn(od[2], __fmul_rn(t, od[5])), in.mn[2]), in.sz[2]);
     }
-#pragma unroll
-    for (int s = 0; s < 4; s++) CO[s] = load_w_frag<true>(Wc + 64 * 32 + 64 * 64, 64, 16, 0, s, r, hh);
+}
+template <int SRC>
+__device__ __forceinline__ void fetch_dir(const QueryIn& in, int64_t i, float& dx, float& dy, float& dz) {
+    if constexpr (SRC == SRC_ARRAYS) {
+        dx = in.dirs[3 * i]; dy = in.dirs[3 * i + 1]; dz = in.dirs[3 * i + 2];
+    } else {
+        const float* od = in.ray_od + 6 * (int64_t)in.rid[i];
+        dx = od[3]; dy = od[4]; dz = od[5];
+    }
+}
 
+// feat: level-major [16][n] fp16x2 for the samples [base, base+n)
+template <int SRC>
+__global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ table, GridCfg g,
+                                                     __half2* __restrict__ feat) {
+    const int xg = blockIdx.x & 7;
+    const int64_t j = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    if (j >= n) return;
+    float px, py, pz;
+    fetch_pos<SRC>(in, base + j, px, py, pz);
+    const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int level = xg + 8 * half;  // block-uniform: level constants are scalar loads, the dense/hash choice is a scalar branch
+        Corner8 c;
+        grid_corners(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], g.hashed[level] != 0, c);
+        float f0, f1;
+        grid_level_features(trs, c, f0, f1);
+        feat[(int64_t)level * n + j] = __floats2half2_rn(f0, f1);
+    }
+}
+
+template <int SRC>
+__global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ feat,
+                                                    const __half* __restrict__ Wd, const __half* __restrict__ Wc, float* __restrict__ sigmas,
+                                                    float* __restrict__ rgbs, __half* __restrict__ packed) {
+    enum { F_D0 = 0, F_DO = 4, F_C0 = 8, F_C1 = 12, F_CO = 20, N_FRAG = 24 };
+    __shared__ h8 wlds[N_FRAG][64];
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    for (int f = threadIdx.x >> 6; f < N_FRAG; f += 4) {
+        h8 v;
+        if (f < F_DO) v = load_w_frag<false>(Wd, 32, 64, (f - F_D0) >> 1, (f - F_D0) & 1, r, hh);
+        else if (f < F_C0) v = load_w_frag<true>(Wd + 64 * 32, 64, 16, 0, f - F_DO, r, hh);
+        else if (f < F_C1) {
+            const int mt = (f - F_C0) >> 1, s = (f - F_C0) & 1;  // k-step 0 = SH coefficients (natural), 1 = density features (ACC order)
+            v = s == 0 ? load_w_frag<false>(Wc, 32, 64, mt, 0, r, hh) : load_w_frag<true>(Wc, 32, 64, mt, 1, r, hh);
+        } else if (f < F_CO) v = load_w_frag<true>(Wc + 64 * 32, 64, 64, (f - F_C1) >> 2, (f - F_C1) & 3, r, hh);
+        else v = load_w_frag<true>(Wc + 64 * 32 + 64 * 64, 64, 16, 0, f - F_CO, r, hh);
+        wlds[f][lane] = v;
+    }
+    __syncthreads();
+#define D0(mt, s) wlds[F_D0 + 2 * (mt) + (s)][lane]
+#define DO(s) wlds[F_DO + (s)][lane]
+#define C0(mt, s) wlds[F_C0 + 2 * (mt) + (s)][lane]
+#define C1(mt, s) wlds[F_C1 + 4 * (mt) + (s)][lane]
+#define CO(s) wlds[F_CO + (s)][lane]
     for (int64_t tile = wave0; tile < n_tiles; tile += n_waves) {
-        const int64_t i = tile * 32 + r;
-        const bool valid = i < M;
-        const int64_t ic = valid ? i : M - 1;
-        float px, py, pz, dx, dy, dz;
-        if constexpr (MODE == MODE_ARRAYS) {
-            px = in.xyz01[3 * ic]; py = in.xyz01[3 * ic + 1]; pz = in.xyz01[3 * ic + 2];
-            dx = in.dirs[3 * ic]; dy = in.dirs[3 * ic + 1]; dz = in.dirs[3 * ic + 2];
-        } else {
-            const float t = in.ts[ic];
-            const float* od = in.ray_od + 6 * (int64_t)in.rid[ic];
-            dx = od[3]; dy = od[4]; dz = od[5];
-            // same roundings as the op-by-op path: xyz = o + t*d (mul, add: raymarching.cu:368), then (xyz - min) / size in torch
-            px = __fdiv_rn(__fsub_rn(__fadd_rn(od[0], __fmul_rn(t, dx)), in.mn[0]), in.sz[0]);
-            py = __fdiv_rn(__fsub_rn(__fadd_rn(od[1], __fmul_rn(t, dy)), in.mn[1]), in.sz[1]);
-            pz = __fdiv_rn(__fsub_rn(__fadd_rn(od[2], __fmul_rn(t, dz)), in.mn[2]), in.sz[2]);
-        }
+        const int64_t j = tile * 32 + r;
+        const bool valid = j < n;
+        const int64_t jc = valid ? j : n - 1;
+        // first-layer B fragments: element (2q, 2q+1) of k-step s <- features of level 8s + 4hh + q (128-byte coalesced per level)
         h8 B[2];
-        {
-            const float xyz[3] = {px, py, pz};
-            encode_grid(xyz, 0, hh, table, g, B);
-        }
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const __half2 v = feat[(int64_t)(8 * s + 4 * hh + q) * n + jc];
+                B[s][2 * q] = *reinterpret_cast<const _Float16*>(&v.x);
+                B[s][2 * q + 1] = *reinterpret_cast<const _Float16*>(&v.y);
+            }
+        float dx, dy, dz;
+        fetch_dir<SRC>(in, base + jc, dx, dy, dz);
         f16v acc[2] = {zero16(), zero16()};
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-            for (int s = 0; s < 2; s++) acc[mt] = NRC_MFMA(D0[mt][s], B[s], acc[mt]);
+            for (int s = 0; s < 2; s++) acc[mt] = NRC_MFMA(D0(mt, s), B[s], acc[mt]);
         h8 H[4];
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
@@ -215,7 +262,7 @@ __global__ void __launch_bounds__(256) k_ngp_query_fused(QueryIn in, int64_t M, 
             for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
         f16v o = zero16();
 #pragma unroll
-        for (int s = 0; s < 4; s++) o = NRC_MFMA(DO[s], H[s], o);
+        for (int s = 0; s < 4; s++) o = NRC_MFMA(DO(s), H[s], o);
         // colour-net inputs: k-step 0 = SH(dir) (natural), k-step 1 = fp16(h) straight from the accumulator (ACC order)
         h8 X[2];
         X[1] = acc_to_frag(o, 0);
@@ -227,14 +274,14 @@ __global__ void __launch_bounds__(256) k_ngp_query_fused(QueryIn in, int64_t M, 
             const float ez = (float)(_Float16)__fadd_rn(__fmul_rn(dz, 0.5f), 0.5f) * 2.f - 1.f;
             sh4_eval(ex, ey, ez, sh);
 #pragma unroll
-            for (int j = 0; j < 8; j++) X[0][j] = (_Float16)(hh ? sh[8 + j] : sh[j]);
+            for (int jj = 0; jj < 8; jj++) X[0][jj] = (_Float16)(hh ? sh[8 + jj] : sh[jj]);
         }
         const _Float16 h0 = X[1][0];  // fp16 density feature 0 (lane half 0, element 0)
         acc[0] = zero16(); acc[1] = zero16();
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-            for (int s = 0; s < 2; s++) acc[mt] = NRC_MFMA(C0[mt][s], X[s], acc[mt]);
+            for (int s = 0; s < 2; s++) acc[mt] = NRC_MFMA(C0(mt, s), X[s], acc[mt]);
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
 #pragma unroll
@@ -243,20 +290,21 @@ __global__ void __launch_bounds__(256) k_ngp_query_fused(QueryIn in, int64_t M, 
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) acc[mt] = NRC_MFMA(C1[mt][s], H[s], acc[mt]);
+            for (int s = 0; s < 4; s++) acc[mt] = NRC_MFMA(C1(mt, s), H[s], acc[mt]);
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
 #pragma unroll
             for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
         o = zero16();
 #pragma unroll
-        for (int s = 0; s < 4; s++) o = NRC_MFMA(CO[s], H[s], o);
+        for (int s = 0; s < 4; s++) o = NRC_MFMA(CO(s), H[s], o);
         if (valid && hh == 0) {
             h4 pk;
             pk[0] = h0;
 #pragma unroll
             for (int c = 0; c < 3; c++) pk[1 + c] = (_Float16)(1.f / (1.f + expf(-o[c])));
-            if constexpr (MODE == MODE_ARRAYS) {
+            const int64_t i = base + j;
+            if constexpr (SRC == SRC_ARRAYS) {
                 sigmas[i] = expf((float)h0);  // TruncExp forward (custom_functions.py:201-204)
 #pragma unroll
                 for (int c = 0; c < 3; c++) rgbs[3 * i + c] = (float)pk[1 + c];
@@ -265,6 +313,11 @@ __global__ void __launch_bounds__(256) k_ngp_query_fused(QueryIn in, int64_t M, 
             }
         }
     }
+#undef D0
+#undef DO
+#undef C0
+#undef C1
+#undef CO
 }
 
 __global__ void k_f32_to_f16(const float* __restrict__ src, __half* __restrict__ dst, int64_t n) {
@@ -299,6 +352,7 @@ int make_grid_cfg(int n_levels, int log2_T, int base_res, float pls, GridCfg& g,
         if (offsets_out) offsets_out[l] = off;
         off += n;
     }
+    g.total_entries = off;
     if (offsets_out) offsets_out[n_levels] = off;
     return NRC_OK;
 }
@@ -309,6 +363,22 @@ int pick_blocks(int64_t M) {
 }
 
 }  // namespace
+
+#define NRC_QUERY_CHUNK (int64_t(2) << 20)  // samples per encode/MLP round: 2 Mi x 64 B of features = 128 MB, Infinity-Cache resident
+
+template <int SRC>
+static int run_query(const QueryIn& in, int64_t M, const void* wd, const void* wc, const void* table, const GridCfg& g, float* sigmas,
+                     float* rgbs, void* packed, void* workspace, hipStream_t s) {
+    __half2* feat = (__half2*)workspace;
+    for (int64_t base = 0; base < M; base += NRC_QUERY_CHUNK) {
+        const int64_t n = (M - base) < NRC_QUERY_CHUNK ? (M - base) : NRC_QUERY_CHUNK;
+        hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)(nrc_cdiv(n, 256) * 8)), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat);
+        hipLaunchKernelGGL(k_ngp_mlp<SRC>, dim3(pick_blocks(n)), dim3(256), 0, s, in, base, n, (const __half2*)feat, (const __half*)wd,
+                           (const __half*)wc, sigmas, rgbs, (__half*)packed);
+    }
+    return NRC_OK;
+}
+
 
 extern "C" {
 
@@ -364,22 +434,27 @@ int nrc_nwie_forward(int32_t encoding, const void* input, int32_t input_ld, int6
     return NRC_OK;
 }
 
+
+int64_t nrc_ngp_query_ws_bytes(int64_t M) {
+    if (M < 0) return NRC_ERR_INVALID;
+    const int64_t c = M < NRC_QUERY_CHUNK ? M : NRC_QUERY_CHUNK;
+    return (c > 0 ? c : 1) * 64 + 256;
+}
+
 int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const void* density_weights_f16,
                         const void* color_weights_f16, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
-                        int32_t base_resolution, float per_level_scale, float* sigmas, float* rgbs, nrc_stream_t stream) {
+                        int32_t base_resolution, float per_level_scale, float* sigmas, float* rgbs, void* workspace, nrc_stream_t stream) {
     NRC_ENTER();
     if (M < 0 || !density_weights_f16 || !color_weights_f16 || !table_f16) return NRC_ERR_INVALID;
     if (n_levels != 16) return NRC_ERR_UNSUPPORTED;
     if (M == 0) return NRC_OK;
-    if (!xyz01 || !dirs || !sigmas || !rgbs) return NRC_ERR_INVALID;
+    if (!xyz01 || !dirs || !sigmas || !rgbs || !workspace) return NRC_ERR_INVALID;
     GridCfg g;
     const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
     if (rc != NRC_OK) return rc;
     QueryIn in = {};
     in.xyz01 = xyz01; in.dirs = dirs;
-    hipLaunchKernelGGL(k_ngp_query_fused<MODE_ARRAYS>, dim3(pick_blocks(M)), dim3(256), 0, (hipStream_t)stream, in, M,
-                       (const __half*)density_weights_f16, (const __half*)color_weights_f16, (const __half2*)table_f16, g, sigmas, rgbs,
-                       (__half*)nullptr);
+    run_query<SRC_ARRAYS>(in, M, density_weights_f16, color_weights_f16, table_f16, g, sigmas, rgbs, nullptr, workspace, (hipStream_t)stream);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
@@ -387,21 +462,19 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
 int nrc_ngp_query_samples(const float* ts, const int32_t* rid, const float* ray_od, int64_t M, const float* xyz_min3,
                           const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
-                          float per_level_scale, void* packed_f16, nrc_stream_t stream) {
+                          float per_level_scale, void* packed_f16, void* workspace, nrc_stream_t stream) {
     NRC_ENTER();
     if (M < 0 || !density_weights_f16 || !color_weights_f16 || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
     if (n_levels != 16) return NRC_ERR_UNSUPPORTED;
     if (M == 0) return NRC_OK;
-    if (!ts || !rid || !ray_od || !packed_f16) return NRC_ERR_INVALID;
+    if (!ts || !rid || !ray_od || !packed_f16 || !workspace) return NRC_ERR_INVALID;
     GridCfg g;
     const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
     if (rc != NRC_OK) return rc;
     QueryIn in = {};
     in.ts = ts; in.rid = rid; in.ray_od = ray_od;
     for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
-    hipLaunchKernelGGL(k_ngp_query_fused<MODE_RECORDS>, dim3(pick_blocks(M)), dim3(256), 0, (hipStream_t)stream, in, M,
-                       (const __half*)density_weights_f16, (const __half*)color_weights_f16, (const __half2*)table_f16, g,
-                       (float*)nullptr, (float*)nullptr, (__half*)packed_f16);
+    run_query<SRC_RECORDS>(in, M, density_weights_f16, color_weights_f16, table_f16, g, nullptr, nullptr, packed_f16, workspace, (hipStream_t)stream);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -253,7 +253,8 @@ class InstantNGPRenderer:
         if total > ws['cap']:
             cap = int(total * 1.25) + 1024
             ws.update(ts=torch.empty(cap, device=dev), dts=torch.empty(cap, device=dev), rid=torch.empty(cap, dtype=torch.int32, device=dev),
-                      packed=torch.empty(cap, 4, dtype=torch.float16, device=dev), cap=cap)
+                      packed=torch.empty(cap, 4, dtype=torch.float16, device=dev),
+                      qws=torch.empty(int(lib.nrc_ngp_query_ws_bytes(cap)), dtype=torch.uint8, device=dev), cap=cap)
         if total > 0:
             _lib.check(lib.nrc_ngp_render_write(n, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION,
                                                 self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['rays_a']),
@@ -264,7 +265,7 @@ class InstantNGPRenderer:
                 _lib.ptr(ws['ts']), _lib.ptr(ws['rid']), _lib.ptr(ws['ray_od']), total, ctypes.cast(mn, ctypes.c_void_p),
                 ctypes.cast(sz, ctypes.c_void_p), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
                 _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
-                _lib.ptr(ws['packed']), st), 'ngp_query_samples')
+                _lib.ptr(ws['packed']), _lib.ptr(ws['qws']), st), 'ngp_query_samples')
         bg = f3(camera.background_color.float().cpu())
         _lib.check(lib.nrc_ngp_composite_image(_lib.ptr(ws.get('packed')), _lib.ptr(ws.get('dts')), _lib.ptr(ws.get('ts')), _lib.ptr(ws['rays_a']),
                                                n, 1e-4, ctypes.cast(bg, ctypes.c_void_p), _lib.ptr(ws['rgb']), _lib.ptr(ws['alpha']),

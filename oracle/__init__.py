@@ -247,3 +247,65 @@ def ngp_query(xyz01, dirs, Wd, Wc, table, **grid_kw):
     cin = np.concatenate([sh4_encode(d01), h], axis=1)
     rgb = mlp_fw(cin, Wc, n_hidden=2, out_act=1)[:, :3]
     return sigma.astype(f32), rgb, h
+
+
+# ------------------------------------------------------------------------------------------------ 3DGS rasterizer
+class GSState:
+    """Everything the rasterizer keeps between forward and backward (geometry / binning / image state)."""
+
+
+def gs_forward(means3D, opacities, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, W, H, bg, sh_degree=3, shs=None,
+               colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, dtype=np.float32):
+    """GaussianRasterizer.forward (call sites src/Methods/GaussianSplatting/Renderer.py:60-81). viewmatrix/projmatrix are the
+    (4,4) arrays the reference passes (w2c.T and w2c.T @ P.T), shs (P,16,3). Returns (color (3,H,W), radii (P), state)."""
+    pre = 'gsf_' if dtype == np.float32 else 'gsd_'
+    ft = ctypes.c_float if dtype == np.float32 else ctypes.c_double
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dtype)
+    means3D, opacities, viewmatrix, projmatrix, campos, bg = c(means3D), c(opacities).reshape(-1), c(viewmatrix), c(projmatrix), c(campos), c(bg)
+    shs, colors_precomp, scales, rotations, cov3D_precomp = c(shs), c(colors_precomp), c(scales), c(rotations), c(cov3D_precomp)
+    P = means3D.shape[0]
+    M = 0 if shs is None else shs.shape[1]
+    st = GSState()
+    st.dtype, st.P, st.M, st.D, st.W, st.H = dtype, P, M, sh_degree, W, H
+    st.radii = np.zeros(P, i32); st.depths = np.zeros(P, dtype); st.points_xy = np.zeros((P, 2), dtype)
+    st.conic_opacity = np.zeros((P, 4), dtype); st.rgb = np.zeros((P, 3), dtype); st.clamped = np.zeros((P, 3), u8)
+    st.cov3D = np.zeros((P, 6), dtype); st.tiles_touched = np.zeros(P, np.uint32)
+    fn = getattr(lib(), pre + 'preprocess')
+    fn.restype = ctypes.c_int64
+    n = fn(_i(P), _i(sh_degree), _i(M), _i(W), _i(H), _p(means3D), _p(shs), _p(colors_precomp), _p(opacities), _p(scales), ft(scale_modifier),
+           _p(rotations), _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix), _p(campos), ft(tan_fovx), ft(tan_fovy), _p(st.radii), _p(st.depths),
+           _p(st.points_xy), _p(st.conic_opacity), _p(st.rgb), _p(st.clamped), _p(st.cov3D), _p(st.tiles_touched))
+    st.num_rendered = int(n)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    st.point_list = np.zeros(max(st.num_rendered, 1), i32); st.ranges = np.zeros((gx * gy, 2), np.uint32)
+    st.n_contrib = np.zeros(H * W, np.uint32); st.final_T = np.zeros(H * W, dtype)
+    color = np.zeros((3, H, W), dtype)
+    fn = getattr(lib(), pre + 'bin_and_render')
+    fn.restype = None
+    fn(_i(P), _i(W), _i(H), _p(bg), _p(st.radii), _p(st.depths), _p(st.points_xy), _p(st.conic_opacity), _p(st.rgb), ctypes.c_int64(st.num_rendered),
+       _p(st.point_list), _p(st.ranges), _p(color), _p(st.n_contrib), _p(st.final_T))
+    st.inputs = dict(means3D=means3D, shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
+                     viewmatrix=viewmatrix, projmatrix=projmatrix, campos=campos, bg=bg, tan_fovx=tan_fovx, tan_fovy=tan_fovy,
+                     scale_modifier=scale_modifier)
+    return color, st.radii.copy(), st
+
+
+def gs_backward(st, dL_dpix):
+    """Returns dict of gradients: mean2D (P,3), conic (P,4), opacity (P), color (P,3), mean3D (P,3), cov3D (P,6), sh (P,M,3), scale (P,3), rot (P,4)."""
+    dtype = st.dtype
+    pre = 'gsf_' if dtype == np.float32 else 'gsd_'
+    ft = ctypes.c_float if dtype == np.float32 else ctypes.c_double
+    g = np.ascontiguousarray(dL_dpix, dtype=dtype)
+    P, M = st.P, max(st.M, 1)
+    out = dict(mean2D=np.zeros((P, 3), dtype), conic=np.zeros((P, 4), dtype), opacity=np.zeros(P, dtype), color=np.zeros((P, 3), dtype),
+               mean3D=np.zeros((P, 3), dtype), cov3D=np.zeros((P, 6), dtype), sh=np.zeros((P, M, 3), dtype), scale=np.zeros((P, 3), dtype),
+               rot=np.zeros((P, 4), dtype))
+    a = st.inputs
+    fn = getattr(lib(), pre + 'backward')
+    fn.restype = None
+    fn(_i(P), _i(st.D), _i(st.M), _i(st.W), _i(st.H), _p(a['bg']), _p(a['means3D']), _p(a['shs']), _p(a['colors_precomp']), _p(a['scales']),
+       ft(a['scale_modifier']), _p(a['rotations']), _p(a['cov3D_precomp']), _p(a['viewmatrix']), _p(a['projmatrix']), _p(a['campos']),
+       ft(a['tan_fovx']), ft(a['tan_fovy']), _p(st.radii), _p(st.points_xy), _p(st.conic_opacity), _p(st.rgb), _p(st.clamped), _p(st.cov3D),
+       _p(st.point_list), _p(st.ranges), _p(st.n_contrib), _p(st.final_T), _p(g), _p(out['mean2D']), _p(out['conic']), _p(out['opacity']),
+       _p(out['color']), _p(out['mean3D']), _p(out['cov3D']), _p(out['sh']), _p(out['scale']), _p(out['rot']))
+    return out

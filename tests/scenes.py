@@ -80,3 +80,40 @@ def random_ragged_rays(rng, n_rays, max_len, empty_frac=0.15):
     starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
     rays_a = np.stack([np.arange(n_rays), starts, lens], -1).astype(np.int64)
     return rays_a, int(lens.sum())
+
+
+# ------------------------------------------------------------------------------------------------ 3DGS synthetic scenes
+def gs_camera(width, height, c2w, fx=None, fy=None, near=0.01, far=100.0):
+    """Settings marshalling of GaussianSplatting/Renderer.py:60-74 in numpy: returns viewmatrix (= w2c.T), projmatrix
+    (= w2c.T @ P.T), tanfovx, tanfovy, campos.  P = PerspectiveCamera.get_projection_matrix (Cameras/Perspective.py:96-119)."""
+    fx = 1.2 * width if fx is None else fx
+    fy = fx if fy is None else fy
+    cx, cy = width / 2, height / 2
+    R, t = c2w[:3, :3], c2w[:3, 3]
+    w2c = np.eye(4)
+    w2c[:3, :3] = R.T
+    w2c[:3, 3] = R.T @ -t
+    hw, hh = width * 0.5, height * 0.5
+    P = np.array([[fx / hw, 0.0, (cx - hw) / hw, 0.0], [0.0, fy / hh, (cy - hh) / hh, 0.0],
+                  [0.0, 0.0, (far + near) / (far - near), -2.0 * far * near / (far - near)], [0.0, 0.0, 1.0, 0.0]], dtype=np.float32)
+    vm = w2c.astype(np.float32).T
+    pm = vm @ P.T
+    return dict(viewmatrix=np.ascontiguousarray(vm), projmatrix=np.ascontiguousarray(pm.astype(np.float32)), tanfovx=width / fx * 0.5,
+                tanfovy=height / fy * 0.5, campos=t.astype(np.float32), width=width, height=height)
+
+
+def gs_random_scene(n, seed=0, extent=1.5, log_scale_mean=math.log(0.01), log_scale_std=0.5, sh_degree=3):
+    """SURVEY 8(d) C3 synthetic Gaussians: positions U([-extent,extent]^3) + a ground-plane cluster, log-scales N(log 0.01, 0.5^2),
+    unit quaternions, opacity logits N(0, 2^2), SH dc U(-1,1), rest N(0, 0.1^2)."""
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-extent, extent, size=(n, 3)).astype(np.float32)
+    k = n // 4
+    pos[:k, 1] = (extent * 0.6 + rng.normal(size=k) * 0.02).astype(np.float32)  # ground plane (y down)
+    scales = np.exp(rng.normal(size=(n, 3)) * log_scale_std + log_scale_mean).astype(np.float32)
+    q = rng.normal(size=(n, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    opac = (1.0 / (1.0 + np.exp(-rng.normal(size=n) * 2.0))).astype(np.float32)
+    shs = np.zeros((n, 16, 3), np.float32)
+    shs[:, 0] = rng.uniform(-1, 1, size=(n, 3))
+    shs[:, 1:] = rng.normal(size=(n, 15, 3)) * 0.1
+    return dict(means3D=pos, scales=scales, rotations=q, opacities=opac, shs=shs, sh_degree=sh_degree)
