@@ -59,7 +59,7 @@ def time_query_kernel(renderer, cam, pose, reps=5):
     import ctypes
     m = renderer.model
     out = renderer.render_image_fused(cam, pose, return_stats=True)
-    total = out['n_samples']
+    rows, total = out['n_rows'], out['n_samples']
     ws = next(iter(renderer._fused_ws.values()))
     lib = _lib.load()
     f3 = lambda t: (ctypes.c_float * 3)(*[float(v) for v in t.reshape(-1).tolist()])
@@ -70,7 +70,7 @@ def time_query_kernel(renderer, cam, pose, reps=5):
     for a, b in evs:
         a.record()
         _lib.check(lib.nrc_ngp_query_samples(
-            _lib.ptr(ws['ts']), _lib.ptr(ws['rid']), _lib.ptr(ws['ray_od']), total, ctypes.cast(mn, ctypes.c_void_p),
+            _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, ctypes.cast(mn, ctypes.c_void_p),
             ctypes.cast(sz, ctypes.c_void_p), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
             _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
             _lib.ptr(ws['packed']), _lib.ptr(ws['qws']), st), 'ngp_query_samples')

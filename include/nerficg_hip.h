@@ -156,33 +156,36 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
 /* =====================================================================================================
  * Group 6 -- fused InstantNGP image pipeline (MI355X-native restructuring of InstantNGPRenderer.render_image ->
  *            render_rays_inference, src/Methods/InstantNGP/Renderer.py:30-46,86-138,172-180): no ray tensors, no
- *            per-iteration host syncs, 12-byte sample records, 8-byte sample values.
+ *            per-iteration host syncs, 4-byte sample records, 8-byte sample values, TILE-INTERLEAVED sample layout:
+ *            a tile = 8x8 pixels (lane = (y&7)*8 + (x&7)); sample k of lane l of local tile T is slot
+ *            (tile_off[T] + k) * 64 + l.  A shard is a range of tiles [tile_begin, tile_begin + n_tiles) of the
+ *            ceil(W/8) x ceil(H/8) tile grid (row-major); per-ray arrays have n_tiles*64 entries.
  *   1. nrc_ngp_render_count : pixel -> ray (Group 5 semantics) -> centre shift, box slab test, near/far clamp -> DDA sample
- *                             count per ray; writes ray_od (n,6) = (o - centre, d), ray_t (n,2), rays_a (n,3) in ray order,
- *                             counter[0] = total samples.  intr/c2w/center3/half3 are HOST pointers.
- *   2. nrc_ngp_render_write : sample records ts, dts (f32) and rid (i32), counter[0] rows.
- *   3. nrc_ngp_query_samples: records -> packed (h0, r, g, b) fp16 (sigma = exp(h0)); xyz_min3/xyz_size3 HOST pointers;
- *                             workspace: nrc_ngp_query_ws_bytes(M) bytes.
- *   4. nrc_ngp_composite_image: packed values -> rgb (n,3), alpha (n), depth (n) incl. background / clamps (bg3 HOST).
- * rays [ray_begin, ray_begin + n_rays) of the H*W image: the multi-GPU shard is a contiguous pixel range.
+ *                             count; writes ray_od (n,6) = (o - centre, d), ray_t (n,2), ray_cnt (n), tile_rows (n_tiles),
+ *                             tile_off (n_tiles+1), counter = (total rows, n_tiles).  intr/c2w/center3/half3: HOST pointers.
+ *   2. nrc_ngp_render_write : ts (rows*64) f32 (-1 = hole), row_tile (rows) i32.
+ *   3. nrc_ngp_query_samples: slots -> packed (h0, r, g, b) fp16 (sigma = exp(h0)); xyz_min3/xyz_size3 HOST pointers;
+ *                             workspace: nrc_ngp_query_ws_bytes(rows*64) bytes.
+ *   4. nrc_ngp_composite_image: serial per-ray compositing + background / clamps (bg3 HOST) into full-image buffers
+ *                             rgb (H*W,3), alpha (H*W), depth (H*W) -- only the shard's pixels are written.
  * ===================================================================================================== */
-int64_t nrc_ngp_render_ws_bytes(int64_t n_rays);
 int nrc_ngp_render_count(int32_t width, int32_t height, const double* intrinsics, const double* c2w, const float* center3,
-                         const float* half3, float near_plane, float far_plane, int64_t ray_begin, int64_t n_rays,
+                         const float* half3, float near_plane, float far_plane, int64_t tile_begin, int64_t n_tiles,
                          const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
-                         int32_t grid_size, int32_t max_samples, float* ray_od, float* ray_t, int64_t* rays_a,
-                         int32_t* counter, void* workspace, nrc_stream_t stream);
-int nrc_ngp_render_write(int64_t n_rays, const uint8_t* density_bitfield, int32_t cascades, float scale,
+                         int32_t grid_size, int32_t max_samples, float* ray_od, float* ray_t, int32_t* ray_cnt,
+                         int32_t* tile_rows, int32_t* tile_off, int32_t* counter, nrc_stream_t stream);
+int nrc_ngp_render_write(int64_t n_tiles, const uint8_t* density_bitfield, int32_t cascades, float scale,
                          float exp_step_factor, int32_t grid_size, int32_t max_samples, const float* ray_od,
-                         const float* ray_t, const int64_t* rays_a, float* ts, float* dts, int32_t* rid,
+                         const float* ray_t, const int32_t* ray_cnt, const int32_t* tile_off, float* ts, int32_t* row_tile,
                          nrc_stream_t stream);
-int nrc_ngp_query_samples(const float* ts, const int32_t* rid, const float* ray_od, int64_t M, const float* xyz_min3,
+int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, const float* xyz_min3,
                           const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                           float per_level_scale, void* packed_f16, void* workspace, nrc_stream_t stream);
-int nrc_ngp_composite_image(const void* packed_f16, const float* dts, const float* ts, const int64_t* rays_a,
-                            int64_t n_rays, float T_threshold, const float* bg3, float* rgb, float* alpha, float* depth,
-                            nrc_stream_t stream);
+int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32_t* ray_cnt, const int32_t* tile_off,
+                            int32_t width, int32_t height, int64_t tile_begin, int64_t n_tiles, int32_t cascades,
+                            float exp_step_factor, int32_t grid_size, int32_t max_samples, float T_threshold,
+                            const float* bg3, float* rgb, float* alpha, float* depth, nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 5 -- ray generation (replaces PerspectiveCamera.compute_local_ray_directions src/Cameras/Perspective.py:64-94

@@ -232,52 +232,51 @@ __global__ void __launch_bounds__(256) k_distortion_bw(const float* __restrict__
 
 
 // ------------------------------------------------------------------------------------------------ image compositor (fused pipeline)
-// One wave per ray over packed (h0, r, g, b) fp16 sample values: sigma = exp(h0) (TruncExp), alpha compositing with the
-// inference early-out (volumerendering.cu:205-249 semantics, T <= thr kills the ray after compositing that sample) and the
-// finalisation of InstantNGPRayRenderingComponent.render_rays_inference (Renderer.py:133-138).  20 B read per sample.
-__global__ void __launch_bounds__(256) k_composite_image(const __half* __restrict__ packed, const float* __restrict__ dts,
-                                                         const float* __restrict__ ts, const int64_t* __restrict__ rays_a,
-                                                         int64_t n_rays, float thr, float bg_r, float bg_g, float bg_b,
-                                                         float* __restrict__ rgb, float* __restrict__ alpha_out,
+// Tile-interleaved layout (see ngp_march.hip): one wave per 8x8 pixel tile, lane = ray.  Row k holds the k-th sample of the
+// 64 rays: 512-byte (packed values) + 256-byte (t) coalesced reads per row.  Each lane composites ITS ray serially, in the
+// reference's order, with the inference early-out (volumerendering.cu:205-249: a ray dies after compositing the sample
+// that brings T <= threshold) and the finalisation of render_rays_inference (Renderer.py:133-138).  sigma = exp(h0)
+// (TruncExp), dt re-derived from t with the test kernel's step rule (raymarching.cu:370).
+__global__ void __launch_bounds__(256) k_composite_image(const __half* __restrict__ packed, const float* __restrict__ ts,
+                                                         const int32_t* __restrict__ ray_cnt, const int32_t* __restrict__ tile_off,
+                                                         int width, int height, int tiles_x, int64_t tile_begin, int64_t n_tiles,
+                                                         float esf, float dt_min, float dt_max, float thr, float bg_r, float bg_g,
+                                                         float bg_b, float* __restrict__ rgb, float* __restrict__ alpha_out,
                                                          float* __restrict__ depth_out) {
     const int lane = threadIdx.x & 63;
-    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= n_rays) return;
-    const int64_t start = rays_a[3 * n + 1];
-    const int N = (int)rays_a[3 * n + 2];
-    float carry = 1.0f, accR = 0.f, accG = 0.f, accB = 0.f, accD = 0.f, accO = 0.f;
-    for (int c = 0; c < N; c += 64) {
-        const int i = c + lane;
-        const bool valid = i < N;
-        const int64_t s = start + i;
-        float a = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, tt = 0.f;
-        if (valid) {
+    const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (lt >= n_tiles) return;
+    const int64_t tile = tile_begin + lt;
+    const int px = (int)(tile % tiles_x) * 8 + (lane & 7), py = (int)(tile / tiles_x) * 8 + (lane >> 3);
+    const bool inside = px < width && py < height;
+    const int64_t row0 = tile_off[lt];
+    const int N = inside ? ray_cnt[lt * 64 + lane] : 0;
+    float T = 1.0f, accR = 0.f, accG = 0.f, accB = 0.f, accD = 0.f, accO = 0.f;
+    bool alive = N > 0;
+    for (int k = 0; __any(alive); k++) {
+        if (alive) {
+            const int64_t s = (row0 + k) * 64 + lane;
             const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(packed) + 4 * s);
-            const __half2 p01 = *reinterpret_cast<const __half2*>(&raw.x), p23 = *reinterpret_cast<const __half2*>(&raw.y);
-            const float2 f01 = __half22float2(p01), f23 = __half22float2(p23);
-            a = alpha_of(expf(f01.x), dts[s]);
-            cr = f01.y; cg = f23.x; cb = f23.y;
-            tt = ts[s];
+            const float2 f01 = __half22float2(*reinterpret_cast<const __half2*>(&raw.x));
+            const float2 f23 = __half22float2(*reinterpret_cast<const __half2*>(&raw.y));
+            const float t = ts[s];
+            const float dt = fmaxf(dt_min, fminf(t * esf, dt_max));
+            const float a = alpha_of(expf(f01.x), dt);
+            const float w = a * T;
+            accR += w * f01.y; accG += w * f23.x; accB += w * f23.y; accD += w * t; accO += w;
+            T *= 1.0f - a;
+            if (T <= thr || k + 1 >= N) alive = false;
         }
-        float Tb, Ta;
-        chunk_transmittance<64>(a, lane, carry, Tb, Ta);
-        const int fs = first_saturated<64>(valid && Ta <= thr, lane);
-        if (valid && lane <= fs) {
-            const float w = a * Tb;
-            accR += w * cr; accG += w * cg; accB += w * cb; accD += w * tt; accO += w;
-        }
-        if (fs < 64) break;
     }
-    accR = nrc_group_sum<64>(accR); accG = nrc_group_sum<64>(accG); accB = nrc_group_sum<64>(accB);
-    accD = nrc_group_sum<64>(accD); accO = nrc_group_sum<64>(accO);
-    if (lane == 0) {
+    if (inside) {
+        const int64_t n = (int64_t)py * width + px;
         const float al = fminf(fmaxf(accO, 0.f), 1.f);
-        const float T = 1.f - al;
-        rgb[3 * n] = fminf(fmaxf(accR + T * bg_r, 0.f), 1.f);
-        rgb[3 * n + 1] = fminf(fmaxf(accG + T * bg_g, 0.f), 1.f);
-        rgb[3 * n + 2] = fminf(fmaxf(accB + T * bg_b, 0.f), 1.f);
+        const float Tr = 1.f - al;
+        rgb[3 * n] = fminf(fmaxf(accR + Tr * bg_r, 0.f), 1.f);
+        rgb[3 * n + 1] = fminf(fmaxf(accG + Tr * bg_g, 0.f), 1.f);
+        rgb[3 * n + 2] = fminf(fmaxf(accB + Tr * bg_b, 0.f), 1.f);
         alpha_out[n] = al;
-        depth_out[n] = T < 1.0f ? accD / al : 0.0f;
+        depth_out[n] = Tr < 1.0f ? accD / al : 0.0f;
     }
 }
 
@@ -382,14 +381,20 @@ int nrc_distortion_loss_bw(const float* dL_dloss, const float* ws_incl, const fl
     return NRC_OK;
 }
 
-int nrc_ngp_composite_image(const void* packed_f16, const float* dts, const float* ts, const int64_t* rays_a, int64_t n_rays,
-                            float T_threshold, const float* bg3_host, float* rgb, float* alpha, float* depth, nrc_stream_t stream) {
+int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32_t* ray_cnt, const int32_t* tile_off, int32_t width,
+                            int32_t height, int64_t tile_begin, int64_t n_tiles, int32_t cascades, float exp_step_factor,
+                            int32_t grid_size, int32_t max_samples, float T_threshold, const float* bg3_host, float* rgb, float* alpha,
+                            float* depth, nrc_stream_t stream) {
     NRC_ENTER();
-    if (n_rays < 0 || !bg3_host) return NRC_ERR_INVALID;
-    if (n_rays == 0) return NRC_OK;
-    if (!rays_a || !rgb || !alpha || !depth) return NRC_ERR_INVALID;
-    hipLaunchKernelGGL(k_composite_image, dim3(nrc_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, (const __half*)packed_f16, dts, ts,
-                       rays_a, n_rays, T_threshold, bg3_host[0], bg3_host[1], bg3_host[2], rgb, alpha, depth);
+    if (n_tiles < 0 || tile_begin < 0 || width < 1 || height < 1 || !bg3_host || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
+    if (n_tiles == 0) return NRC_OK;
+    if (!ray_cnt || !tile_off || !rgb || !alpha || !depth) return NRC_ERR_INVALID;
+    const int tiles_x = (width + 7) / 8;
+    // calc_dt of the test kernel (raymarching.cu:11-13 with `cascades` in place of `scale`, :370)
+    const float dt_min = 1.73205080757f / max_samples, dt_max = 1.73205080757f * 2 * (float)cascades / grid_size;
+    hipLaunchKernelGGL(k_composite_image, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, (const __half*)packed_f16, ts, ray_cnt,
+                       tile_off, (int)width, (int)height, tiles_x, tile_begin, n_tiles, exp_step_factor, dt_min, dt_max, T_threshold,
+                       bg3_host[0], bg3_host[1], bg3_host[2], rgb, alpha, depth);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -458,51 +458,99 @@ __device__ __forceinline__ void camera_ray(const RenderCam& cam, int64_t pix, Ra
     t1 = fmaxf(a, cam.near_plane);
     t2 = fminf(b, cam.far_plane);
 }
-__global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c, int64_t n_rays, float* __restrict__ ray_od,
-                                                      float* __restrict__ ray_t, int32_t* __restrict__ counts,
-                                                      int32_t* __restrict__ block_sums) {
-    __shared__ int smem[8];
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// Tile-interleaved sample layout (the MI355X-native core of the image pipeline).
+// A tile = 8x8 pixels = one wave, lane = pixel (lx = lane & 7, ly = lane >> 3).  Sample k of the ray on lane l of tile T lives
+// in slot (tile_off[T] + k) * 64 + l: a "row" holds the k-th samples of the 64 rays of a tile.  Consequences:
+//   * every kernel of the pipeline reads and writes rows = 256-byte coalesced segments (the ray-major layout of the
+//     reference makes each lane stride through its own ray: one cache line per lane per access);
+//   * the 64 samples of a row are neighbours in space (adjacent pixels, same step), so the hash-grid gathers of a wave
+//     fall into few cache lines -- the texture-address path (one distinct line per clock per CU) is THE bottleneck of
+//     the encoding, see profiles/;
+//   * a sample record shrinks to its t (4 B): the ray is implied by the slot, dt is a function of t;
+//   * compositing walks a ray serially per lane in exactly the reference's order (volumerendering.cu:205-249).
+// Rays of a tile with fewer samples leave holes in the tail rows (ts = -1).
+__device__ __forceinline__ int64_t tile_pixel(const RayGenCfg& g, int64_t tile, int lane, int tiles_x) {
+    const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
+    const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+    return (px < g.width && py < g.height) ? (int64_t)py * g.width + px : -1;
+}
+__global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c, int tiles_x, int64_t tile_begin, int64_t n_tiles,
+                                                      float* __restrict__ ray_od, float* __restrict__ ray_t,
+                                                      int32_t* __restrict__ ray_cnt, int32_t* __restrict__ tile_rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // local tile
+    if (lt >= n_tiles) return;
+    const int64_t pix = tile_pixel(cam.g, tile_begin + lt, lane, tiles_x);
+    const int64_t q = lt * 64 + lane;
     int n = 0;
-    if (r < n_rays) {
-        Ray q; float t1, t2;
-        camera_ray(cam, cam.ray_begin + r, q, t1, t2);
+    Ray ry = {0.f, 0.f, 0.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    float t1 = 0.f, t2 = -1.f;
+    if (pix >= 0) {
+        camera_ray(cam, pix, ry, t1, t2);
         float t = t1, x, y, z, dt;
         while (t < t2 && n < c.max_samples) {
-            if (march_step(q, c, t, x, y, z, dt)) { t += dt; n++; }
+            if (march_step(ry, c, t, x, y, z, dt)) { t += dt; n++; }
         }
-        counts[r] = n;
-        float* od = ray_od + 6 * r;
-        od[0] = q.ox; od[1] = q.oy; od[2] = q.oz; od[3] = q.dx; od[4] = q.dy; od[5] = q.dz;
-        ray_t[2 * r] = t1; ray_t[2 * r + 1] = t2;
     }
-    int total;
-    (void)nrc_block256_excl_scan_i(n, smem, &total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    float* od = ray_od + 6 * q;
+    od[0] = ry.ox; od[1] = ry.oy; od[2] = ry.oz; od[3] = ry.dx; od[4] = ry.dy; od[5] = ry.dz;
+    ray_t[2 * q] = t1; ray_t[2 * q + 1] = t2;
+    ray_cnt[q] = n;
+    int m = n;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    if (lane == 0) tile_rows[lt] = m;
 }
-// stage 3: emit the compact sample records (t, dt, ray id) = 12 B/sample; positions are recomputed by the consumer
-__global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_rays, const float* __restrict__ ray_od,
-                                                      const float* __restrict__ ray_t, const int64_t* __restrict__ rays_a,
-                                                      float* __restrict__ ts, float* __restrict__ dts, int32_t* __restrict__ rid) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_rays) return;
-    const int64_t start = rays_a[3 * r + 1];
-    const int N = (int)rays_a[3 * r + 2];
-    if (N == 0) return;
-    const float* od = ray_od + 6 * r;
-    Ray q;
-    q.ox = od[0]; q.oy = od[1]; q.oz = od[2]; q.dx = od[3]; q.dy = od[4]; q.dz = od[5];
-    q.dxi = 1.0f / q.dx; q.dyi = 1.0f / q.dy; q.dzi = 1.0f / q.dz;
-    float t = ray_t[2 * r], x, y, z, dt;
-    const float t2 = ray_t[2 * r + 1];
+// exclusive scan of tile_rows -> tile_off[0..n_tiles] (tile_off[n_tiles] = total rows); counter = (total rows, n_tiles)
+__global__ void __launch_bounds__(1024) k_scan_tiles(const int32_t* __restrict__ tile_rows, int64_t n_tiles, int32_t* __restrict__ tile_off,
+                                                     int32_t* __restrict__ counter) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_tiles; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int v = i < n_tiles ? tile_rows[i] : 0;
+        const int incl = nrc_wave_incl_sum_i(v, lane);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int off = carry_s;
+        for (int w = 0; w < wave; w++) off += wave_tot[w];
+        if (i < n_tiles) tile_off[i] = off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { tile_off[n_tiles] = carry_s; counter[0] = carry_s; counter[1] = (int32_t)n_tiles; }
+}
+// second march: ts[(tile_off + k) * 64 + lane] = t of the k-th sample; holes = -1; row_tile[row] = local tile of the row
+__global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tiles, const float* __restrict__ ray_od,
+                                                      const float* __restrict__ ray_t, const int32_t* __restrict__ ray_cnt,
+                                                      const int32_t* __restrict__ tile_off, float* __restrict__ ts,
+                                                      int32_t* __restrict__ row_tile) {
+    const int lane = threadIdx.x & 63;
+    const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (lt >= n_tiles) return;
+    const int64_t q = lt * 64 + lane;
+    const int64_t row0 = tile_off[lt];
+    const int rows = tile_off[lt + 1] - (int)row0;
+    const int N = ray_cnt[q];
+    for (int k = lane; k < rows; k += 64) row_tile[row0 + k] = (int32_t)lt;
+    const float* od = ray_od + 6 * q;
+    Ray ry;
+    ry.ox = od[0]; ry.oy = od[1]; ry.oz = od[2]; ry.dx = od[3]; ry.dy = od[4]; ry.dz = od[5];
+    ry.dxi = 1.0f / ry.dx; ry.dyi = 1.0f / ry.dy; ry.dzi = 1.0f / ry.dz;
+    float t = ray_t[2 * q], x, y, z, dt;
+    const float t2 = ray_t[2 * q + 1];
     int s = 0;
     while (t < t2 && s < N) {
-        if (march_step(q, c, t, x, y, z, dt)) {
-            const int64_t k = start + s;
-            ts[k] = t; dts[k] = dt; rid[k] = (int32_t)r;
+        if (march_step(ry, c, t, x, y, z, dt)) {
+            ts[(row0 + s) * 64 + lane] = t;
             t += dt; s++;
         }
     }
+    for (int k = N; k < rows; k++) ts[(row0 + k) * 64 + lane] = -1.0f;
 }
 
 MarchCfg make_cfg(const uint8_t* bitfield, int cascades, float scale, float esf, int grid_size, int max_samples, float dt_scale) {
@@ -671,42 +719,40 @@ static void fill_raygen(RayGenCfg& g, int32_t width, int32_t height, const doubl
     }
 }
 
-int64_t nrc_ngp_render_ws_bytes(int64_t n_rays) { return nrc_raymarching_train_ws_bytes(n_rays); }
-
 int nrc_ngp_render_count(int32_t width, int32_t height, const double* intr, const double* c2w, const float* center3, const float* half3,
-                         float near_plane, float far_plane, int64_t ray_begin, int64_t n_rays, const uint8_t* bitfield,
+                         float near_plane, float far_plane, int64_t tile_begin, int64_t n_tiles, const uint8_t* bitfield,
                          int32_t cascades, float scale, float esf, int32_t grid_size, int32_t max_samples, float* ray_od,
-                         float* ray_t, int64_t* rays_a, int32_t* counter, void* workspace, nrc_stream_t stream) {
+                         float* ray_t, int32_t* ray_cnt, int32_t* tile_rows, int32_t* tile_off, int32_t* counter, nrc_stream_t stream) {
     NRC_ENTER();
-    if (width < 1 || height < 1 || !intr || !c2w || !center3 || !half3 || n_rays < 0 || ray_begin < 0 ||
-        ray_begin + n_rays > (int64_t)width * height || cascades < 1 || grid_size < 1 || max_samples < 1 || !counter)
+    if (width < 1 || height < 1 || !intr || !c2w || !center3 || !half3 || n_tiles < 0 || tile_begin < 0 || cascades < 1 ||
+        grid_size < 1 || max_samples < 1 || !counter || !tile_off)
         return NRC_ERR_INVALID;
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    if (tile_begin + n_tiles > (int64_t)tiles_x * tiles_y) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (n_rays == 0) { hipMemsetAsync(counter, 0, 8, s); return NRC_OK; }
-    if (!bitfield || !ray_od || !ray_t || !rays_a || !workspace) return NRC_ERR_INVALID;
+    if (n_tiles > 0 && (!bitfield || !ray_od || !ray_t || !ray_cnt || !tile_rows)) return NRC_ERR_INVALID;
     RenderCam cam;
     fill_raygen(cam.g, width, height, intr, c2w);
     for (int k = 0; k < 3; k++) { cam.center[k] = center3[k]; cam.half[k] = half3[k]; }
-    cam.near_plane = near_plane; cam.far_plane = far_plane; cam.ray_begin = ray_begin;
+    cam.near_plane = near_plane; cam.far_plane = far_plane; cam.ray_begin = 0;
     const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, (float)cascades);
-    const int64_t nb = nrc_cdiv(n_rays, 256);
-    int32_t* counts = (int32_t*)workspace;
-    int32_t* block_sums = (int32_t*)((char*)workspace + (n_rays * 4 + 255) / 256 * 256);
-    hipLaunchKernelGGL(k_render_count, dim3(nb), dim3(256), 0, s, cam, c, n_rays, ray_od, ray_t, counts, block_sums);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, n_rays, counter);
-    hipLaunchKernelGGL(k_assign_rays_a, dim3(nb), dim3(256), 0, s, counts, block_sums, n_rays, rays_a);
+    if (n_tiles > 0)
+        hipLaunchKernelGGL(k_render_count, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, s, cam, c, tiles_x, tile_begin, n_tiles, ray_od, ray_t,
+                           ray_cnt, tile_rows);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_rows, n_tiles, tile_off, counter);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
-int nrc_ngp_render_write(int64_t n_rays, const uint8_t* bitfield, int32_t cascades, float scale, float esf, int32_t grid_size,
-                         int32_t max_samples, const float* ray_od, const float* ray_t, const int64_t* rays_a, float* ts, float* dts,
-                         int32_t* rid, nrc_stream_t stream) {
+int nrc_ngp_render_write(int64_t n_tiles, const uint8_t* bitfield, int32_t cascades, float scale, float esf, int32_t grid_size,
+                         int32_t max_samples, const float* ray_od, const float* ray_t, const int32_t* ray_cnt, const int32_t* tile_off,
+                         float* ts, int32_t* row_tile, nrc_stream_t stream) {
     NRC_ENTER();
-    if (n_rays < 0 || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
-    if (n_rays == 0) return NRC_OK;
-    if (!bitfield || !ray_od || !ray_t || !rays_a) return NRC_ERR_INVALID;
+    if (n_tiles < 0 || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
+    if (n_tiles == 0) return NRC_OK;
+    if (!bitfield || !ray_od || !ray_t || !ray_cnt || !tile_off || !ts || !row_tile) return NRC_ERR_INVALID;
     const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, (float)cascades);
-    hipLaunchKernelGGL(k_render_write, dim3(nrc_cdiv(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, c, n_rays, ray_od, ray_t, rays_a, ts, dts, rid);
+    hipLaunchKernelGGL(k_render_write, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, c, n_tiles, ray_od, ray_t, ray_cnt,
+                       tile_off, ts, row_tile);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -158,23 +158,27 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
 //                   (round-robin dispatch) gather from the same two levels, so each 4 MB L2 serves <= 4 MB of table instead of
 //                   all 24.4 MB (placement affects speed only).
 //   k_ngp_mlp     : density net -> sigma -> colour net from the level-major features; weights as LDS-resident A fragments.
-enum { SRC_ARRAYS = 0, SRC_RECORDS = 1 };
+enum { SRC_ARRAYS = 0, SRC_TILED = 1 };
 struct QueryIn {
-    const float* xyz01; const float* dirs;                       // SRC_ARRAYS
-    const float* ts; const int32_t* rid; const float* ray_od;    // SRC_RECORDS
-    float mn[3], sz[3];                                          // xyz_min, xyz_size of the model box (Renderer.py:50)
+    const float* xyz01; const float* dirs;                          // SRC_ARRAYS: sample i = row i of both arrays
+    const float* ts; const int32_t* row_tile; const float* ray_od;  // SRC_TILED: slot i = (row i>>6, lane i&63), ray = row_tile[row]*64 + lane
+    float mn[3], sz[3];                                             // xyz_min, xyz_size of the model box (Renderer.py:50)
 };
+// returns false for a hole of the tiled layout (no sample in this slot)
 template <int SRC>
-__device__ __forceinline__ void fetch_pos(const QueryIn& in, int64_t i, float& px, float& py, float& pz) {
+__device__ __forceinline__ bool fetch_pos(const QueryIn& in, int64_t i, float& px, float& py, float& pz) {
     if constexpr (SRC == SRC_ARRAYS) {
         px = in.xyz01[3 * i]; py = in.xyz01[3 * i + 1]; pz = in.xyz01[3 * i + 2];
+        return true;
     } else {
         const float t = in.ts[i];
-        const float* od = in.ray_od + 6 * (int64_t)in.rid[i];
+        if (t < 0.f) { px = py = pz = 0.f; return false; }
+        const float* od = in.ray_od + 6 * ((int64_t)in.row_tile[i >> 6] * 64 + (i & 63));
         // same roundings as the op-by-op path: xyz = o + t*d (mul, add: raymarching.cu:368), then (xyz - min) / size in torch
         px = __fdiv_rn(__fsub_rn(__fadd_rn(od[0], __fmul_rn(t, od[3])), in.mn[0]), in.sz[0]);
         py = __fdiv_rn(__fsub_rn(__fadd_rn(od[1], __fmul_rn(t, od[4])), in.mn[1]), in.sz[1]);
         pz = __fdiv_rn(__fsub_rn(__fadd_rn(od[2], __fmul_rn(t, od[5])), in.mn[2]), in.sz[2]);
+        return true;
     }
 }
 template <int SRC>
@@ -182,7 +186,7 @@ __device__ __forceinline__ void fetch_dir(const QueryIn& in, int64_t i, float& d
     if constexpr (SRC == SRC_ARRAYS) {
         dx = in.dirs[3 * i]; dy = in.dirs[3 * i + 1]; dz = in.dirs[3 * i + 2];
     } else {
-        const float* od = in.ray_od + 6 * (int64_t)in.rid[i];
+        const float* od = in.ray_od + 6 * ((int64_t)in.row_tile[i >> 6] * 64 + (i & 63));
         dx = od[3]; dy = od[4]; dz = od[5];
     }
 }
@@ -195,11 +199,12 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
     const int64_t j = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
     if (j >= n) return;
     float px, py, pz;
-    fetch_pos<SRC>(in, base + j, px, py, pz);
+    const bool live = fetch_pos<SRC>(in, base + j, px, py, pz);
     const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         const int level = xg + 8 * half;  // block-uniform: level constants are scalar loads, the dense/hash choice is a scalar branch
+        if (!live) { feat[(int64_t)level * n + j] = __floats2half2_rn(0.f, 0.f); continue; }
         Corner8 c;
         grid_corners(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], g.hashed[level] != 0, c);
         float f0, f1;
@@ -236,8 +241,12 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
 #define CO(s) wlds[F_CO + (s)][lane]
     for (int64_t tile = wave0; tile < n_tiles; tile += n_waves) {
         const int64_t j = tile * 32 + r;
-        const bool valid = j < n;
+        bool valid = j < n;
         const int64_t jc = valid ? j : n - 1;
+        if constexpr (SRC == SRC_TILED) {
+            valid = valid && in.ts[base + jc] >= 0.f;
+            if (__ballot(valid) == 0ull) continue;  // a half row of holes
+        }
         // first-layer B fragments: element (2q, 2q+1) of k-step s <- features of level 8s + 4hh + q (128-byte coalesced per level)
         h8 B[2];
 #pragma unroll
@@ -459,22 +468,23 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
     return NRC_OK;
 }
 
-int nrc_ngp_query_samples(const float* ts, const int32_t* rid, const float* ray_od, int64_t M, const float* xyz_min3,
+int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, const float* xyz_min3,
                           const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                           float per_level_scale, void* packed_f16, void* workspace, nrc_stream_t stream) {
     NRC_ENTER();
-    if (M < 0 || !density_weights_f16 || !color_weights_f16 || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
+    const int64_t M = n_rows * 64;
+    if (n_rows < 0 || !density_weights_f16 || !color_weights_f16 || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
     if (n_levels != 16) return NRC_ERR_UNSUPPORTED;
     if (M == 0) return NRC_OK;
-    if (!ts || !rid || !ray_od || !packed_f16 || !workspace) return NRC_ERR_INVALID;
+    if (!ts || !row_tile || !ray_od || !packed_f16 || !workspace) return NRC_ERR_INVALID;
     GridCfg g;
     const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
     if (rc != NRC_OK) return rc;
     QueryIn in = {};
-    in.ts = ts; in.rid = rid; in.ray_od = ray_od;
+    in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od;
     for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
-    run_query<SRC_RECORDS>(in, M, density_weights_f16, color_weights_f16, table_f16, g, nullptr, nullptr, packed_f16, workspace, (hipStream_t)stream);
+    run_query<SRC_TILED>(in, M, density_weights_f16, color_weights_f16, table_f16, g, nullptr, nullptr, packed_f16, workspace, (hipStream_t)stream);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

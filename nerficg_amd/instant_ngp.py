@@ -216,64 +216,77 @@ class InstantNGPRenderer:
         return out
 
     # ---------------------------------------------------------------- MI355X-native image pipeline
+    @staticmethod
+    def n_image_tiles(camera: Camera) -> int:
+        return ((camera.width + 7) // 8) * ((camera.height + 7) // 8)
+
     @torch.no_grad()
-    def render_image_fused(self, camera: Camera, c2w: np.ndarray, ray_begin: int = 0, n_rays: int | None = None,
-                           return_stats: bool = False) -> dict[str, torch.Tensor]:
-        """Same image as render_image (flat (n_rays, C) layout for a pixel range), four device stages and ONE host sync
-        (the sample count, to size the record buffers)."""
+    def render_image_fused(self, camera: Camera, c2w: np.ndarray, tile_begin: int = 0, n_tiles: int | None = None,
+                           return_stats: bool = False, out: dict | None = None) -> dict[str, torch.Tensor]:
+        """Same image as render_image, flat (H*W, C) pixel-major buffers, through the tile-interleaved device pipeline
+        (include/nerficg_hip.h group 6): four device stages and ONE host sync (the row count, to size the sample buffers).
+        A shard renders the 8x8-pixel tiles [tile_begin, tile_begin + n_tiles) and writes only their pixels (pass `out` to
+        accumulate several shards into the same buffers)."""
         m = self.model
         lib = _lib.load()
         dev = m.center.device
-        total_px = camera.width * camera.height
-        n = total_px - ray_begin if n_rays is None else int(n_rays)
+        total_tiles = self.n_image_tiles(camera)
+        nt = total_tiles - tile_begin if n_tiles is None else int(n_tiles)
+        n = nt * 64
         c2w = np.ascontiguousarray(np.asarray(c2w, dtype=np.float64))
         if c2w.shape == (3, 4):
             c2w = np.vstack([c2w, [0.0, 0.0, 0.0, 1.0]])
         intr = (ctypes.c_double * 4)(camera.focal_x, camera.focal_y, camera.center_x, camera.center_y)
         mat = (ctypes.c_double * 16)(*c2w.reshape(-1).tolist())
         f3 = lambda t: (ctypes.c_float * 3)(*[float(v) for v in t.reshape(-1).tolist()])
-        key = (n, str(dev))
+        hw = camera.width * camera.height
+        key = (nt, hw, str(dev))
         ws = self._fused_ws.get(key)
         if ws is None:
-            ws = dict(ray_od=torch.empty(n, 6, device=dev), ray_t=torch.empty(n, 2, device=dev),
-                      rays_a=torch.empty(n, 3, dtype=torch.int64, device=dev), counter=torch.empty(2, dtype=torch.int32, device=dev),
-                      scratch=torch.empty(max(int(lib.nrc_ngp_render_ws_bytes(n)), 1), dtype=torch.uint8, device=dev),
-                      rgb=torch.empty(n, 3, device=dev), alpha=torch.empty(n, device=dev), depth=torch.empty(n, device=dev), cap=0)
+            ws = dict(ray_od=torch.empty(max(n, 1), 6, device=dev), ray_t=torch.empty(max(n, 1), 2, device=dev),
+                      ray_cnt=torch.empty(max(n, 1), dtype=torch.int32, device=dev), tile_rows=torch.empty(max(nt, 1), dtype=torch.int32, device=dev),
+                      tile_off=torch.empty(nt + 1, dtype=torch.int32, device=dev), counter=torch.empty(2, dtype=torch.int32, device=dev),
+                      rgb=torch.zeros(hw, 3, device=dev), alpha=torch.zeros(hw, device=dev), depth=torch.zeros(hw, device=dev), cap=0)
             self._fused_ws = {key: ws}
+        if out is None:
+            out = {'rgb': ws['rgb'], 'alpha': ws['alpha'], 'depth': ws['depth']}
         st = _lib.stream_of(ws['ray_od'])
         esf = 1 / 256 if self.EXPONENTIAL_STEPS else 0.0
         center, half = f3(m.center), f3(m.half_size)
         _lib.check(lib.nrc_ngp_render_count(
             camera.width, camera.height, ctypes.cast(intr, ctypes.c_void_p), ctypes.cast(mat, ctypes.c_void_p),
             ctypes.cast(center, ctypes.c_void_p), ctypes.cast(half, ctypes.c_void_p), float(camera.near_plane), float(camera.far_plane),
-            int(ray_begin), n, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION, self.MAX_SAMPLES,
-            _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['rays_a']), _lib.ptr(ws['counter']), _lib.ptr(ws['scratch']), st),
-            'ngp_render_count')
-        total = int(ws['counter'][0].item())
-        if total > ws['cap']:
-            cap = int(total * 1.25) + 1024
-            ws.update(ts=torch.empty(cap, device=dev), dts=torch.empty(cap, device=dev), rid=torch.empty(cap, dtype=torch.int32, device=dev),
-                      packed=torch.empty(cap, 4, dtype=torch.float16, device=dev),
-                      qws=torch.empty(int(lib.nrc_ngp_query_ws_bytes(cap)), dtype=torch.uint8, device=dev), cap=cap)
-        if total > 0:
-            _lib.check(lib.nrc_ngp_render_write(n, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION,
-                                                self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['rays_a']),
-                                                _lib.ptr(ws['ts']), _lib.ptr(ws['dts']), _lib.ptr(ws['rid']), st), 'ngp_render_write')
+            int(tile_begin), nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION, self.MAX_SAMPLES,
+            _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']), _lib.ptr(ws['tile_off']),
+            _lib.ptr(ws['counter']), st), 'ngp_render_count')
+        rows = int(ws['counter'][0].item())
+        if rows > ws['cap']:
+            cap = int(rows * 1.25) + 64
+            ws.update(ts=torch.empty(cap * 64, device=dev), row_tile=torch.empty(cap, dtype=torch.int32, device=dev),
+                      packed=torch.empty(cap * 64, 4, dtype=torch.float16, device=dev),
+                      qws=torch.empty(int(lib.nrc_ngp_query_ws_bytes(cap * 64)), dtype=torch.uint8, device=dev), cap=cap)
+        if rows > 0:
+            _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION,
+                                                self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']),
+                                                _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), st), 'ngp_render_write')
             g = m.encoding_xyz.grid_cfg
             mn, sz = f3(m.xyz_min), f3(m.xyz_size)
             _lib.check(lib.nrc_ngp_query_samples(
-                _lib.ptr(ws['ts']), _lib.ptr(ws['rid']), _lib.ptr(ws['ray_od']), total, ctypes.cast(mn, ctypes.c_void_p),
+                _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, ctypes.cast(mn, ctypes.c_void_p),
                 ctypes.cast(sz, ctypes.c_void_p), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
                 _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
                 _lib.ptr(ws['packed']), _lib.ptr(ws['qws']), st), 'ngp_query_samples')
         bg = f3(camera.background_color.float().cpu())
-        _lib.check(lib.nrc_ngp_composite_image(_lib.ptr(ws.get('packed')), _lib.ptr(ws.get('dts')), _lib.ptr(ws.get('ts')), _lib.ptr(ws['rays_a']),
-                                               n, 1e-4, ctypes.cast(bg, ctypes.c_void_p), _lib.ptr(ws['rgb']), _lib.ptr(ws['alpha']),
-                                               _lib.ptr(ws['depth']), st), 'ngp_composite_image')
-        out = {'rgb': ws['rgb'], 'alpha': ws['alpha'], 'depth': ws['depth']}
+        _lib.check(lib.nrc_ngp_composite_image(
+            _lib.ptr(ws.get('packed')), _lib.ptr(ws.get('ts')), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_off']), camera.width, camera.height,
+            int(tile_begin), nt, m.cascades, float(esf), m.RESOLUTION, self.MAX_SAMPLES, 1e-4, ctypes.cast(bg, ctypes.c_void_p),
+            _lib.ptr(out['rgb']), _lib.ptr(out['alpha']), _lib.ptr(out['depth']), st), 'ngp_composite_image')
+        res = dict(out)
         if return_stats:
-            out['n_samples'] = total
-        return out
+            res['n_rows'] = rows
+            res['n_slots'] = rows * 64
+            res['n_samples'] = int(ws['ray_cnt'][:n].sum().item()) if n > 0 else 0
+        return res
 
     # ---------------------------------------------------------------- occupancy grid (Renderer.py:183-206, 247-272)
     @torch.no_grad()

@@ -94,17 +94,21 @@ def test_fused_image_equals_op_by_op_image_and_oracle(setup, w, h, pose):
     assert 0.2 < hit.float().mean().item() < 0.8 and fused['alpha'].std().item() > 0.05
 
 
-def test_fused_image_shards_concatenate(setup):
-    """Multi-GPU sharding unit: contiguous pixel ranges rendered separately reproduce the full image bit for bit."""
+def test_fused_image_shards_compose(setup):
+    """Multi-GPU sharding unit: disjoint ranges of 8x8 tiles rendered separately reproduce the full image bit for bit
+    (image size not a multiple of 8: edge tiles are partially outside)."""
     _, renderer = setup
     cam = make_camera(70, 50)
     c2w = scenes.orbit_pose(1.3, 0.2, scenes.LEGO_RADIUS)
     full = {k: v.clone() for k, v in renderer.render_image_fused(cam, c2w).items()}
-    n = 70 * 50
-    cuts = [0, 1111, 1112, 2900, n]
-    parts = [{k: v.clone() for k, v in renderer.render_image_fused(cam, c2w, ray_begin=a, n_rays=b - a).items()} for a, b in zip(cuts[:-1], cuts[1:])]
+    nt = renderer.n_image_tiles(cam)
+    assert nt == 9 * 7
+    out = {'rgb': torch.full((70 * 50, 3), -1.0, device=DEV), 'alpha': torch.full((70 * 50,), -1.0, device=DEV), 'depth': torch.full((70 * 50,), -1.0, device=DEV)}
+    cuts = [0, 11, 12, 40, nt]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        renderer.render_image_fused(cam, c2w, tile_begin=a, n_tiles=b - a, out=out)
     for k in ('rgb', 'alpha', 'depth'):
-        assert torch.equal(torch.cat([p[k] for p in parts]), full[k]), k
+        assert torch.equal(out[k], full[k]), k
 
 
 def test_inference_loop_with_fused_query_matches(setup):
