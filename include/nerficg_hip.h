@@ -161,7 +161,7 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
  *            (tile_off[T] + k) * 64 + l.  A shard is a range of tiles [tile_begin, tile_begin + n_tiles) of the
  *            ceil(W/8) x ceil(H/8) tile grid (row-major); per-ray arrays have n_tiles*64 entries.
  *   1. nrc_ngp_render_count : pixel -> ray (Group 5 semantics) -> centre shift, box slab test, near/far clamp -> DDA sample
- *                             count; writes ray_od (n,6) = (o - centre, d), ray_t (n,2), ray_cnt (n), tile_rows (n_tiles),
+ *                             count; writes ray_od (n_tiles,6,64) = per-tile SoA of (o - centre, d), ray_t (n,2), ray_cnt (n), tile_rows (n_tiles),
  *                             tile_off (n_tiles+1), counter = (total rows, n_tiles).  intr/c2w/center3/half3: HOST pointers.
  *   2. nrc_ngp_render_write : ts (rows*64) f32 (-1 = hole), row_tile (rows) i32.
  *   3. nrc_ngp_query_samples: slots -> packed (h0, r, g, b) fp16 (sigma = exp(h0)); xyz_min3/xyz_size3 HOST pointers;
@@ -182,6 +182,11 @@ int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float*
                           const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                           float per_level_scale, void* packed_f16, void* workspace, nrc_stream_t stream);
+/* stage 3a on its own (the dominant kernel of the pipeline; used by bench.py's roofline leg): hash-grid features of the first
+ * n_rows (<= 32768) rows, level-major fp16x2 [16][n_rows*64] */
+int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, const float* xyz_min3,
+                           const float* xyz_size3, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
+                           int32_t base_resolution, float per_level_scale, void* features_f16, nrc_stream_t stream);
 int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32_t* ray_cnt, const int32_t* tile_off,
                             int32_t width, int32_t height, int64_t tile_begin, int64_t n_tiles, int32_t cascades,
                             float exp_step_factor, int32_t grid_size, int32_t max_samples, float T_threshold,

@@ -492,8 +492,8 @@ __global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c,
             if (march_step(ry, c, t, x, y, z, dt)) { t += dt; n++; }
         }
     }
-    float* od = ray_od + 6 * q;
-    od[0] = ry.ox; od[1] = ry.oy; od[2] = ry.oz; od[3] = ry.dx; od[4] = ry.dy; od[5] = ry.dz;
+    float* od = ray_od + lt * 384 + lane;  // per-tile SoA [6][64]: every component is one 256-byte row
+    od[0] = ry.ox; od[64] = ry.oy; od[128] = ry.oz; od[192] = ry.dx; od[256] = ry.dy; od[320] = ry.dz;
     ray_t[2 * q] = t1; ray_t[2 * q + 1] = t2;
     ray_cnt[q] = n;
     int m = n;
@@ -537,9 +537,9 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
     const int rows = tile_off[lt + 1] - (int)row0;
     const int N = ray_cnt[q];
     for (int k = lane; k < rows; k += 64) row_tile[row0 + k] = (int32_t)lt;
-    const float* od = ray_od + 6 * q;
+    const float* od = ray_od + lt * 384 + lane;
     Ray ry;
-    ry.ox = od[0]; ry.oy = od[1]; ry.oz = od[2]; ry.dx = od[3]; ry.dy = od[4]; ry.dz = od[5];
+    ry.ox = od[0]; ry.oy = od[64]; ry.oz = od[128]; ry.dx = od[192]; ry.dy = od[256]; ry.dz = od[320];
     ry.dxi = 1.0f / ry.dx; ry.dyi = 1.0f / ry.dy; ry.dzi = 1.0f / ry.dz;
     float t = ray_t[2 * q], x, y, z, dt;
     const float t2 = ray_t[2 * q + 1];

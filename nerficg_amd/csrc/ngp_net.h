@@ -135,10 +135,31 @@ __device__ __forceinline__ void grid_corners(float px, float py, float pz, float
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_table_rsrc(const void* table, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(table), /*stride*/ 0, (int)bytes, 0x00020000);
 }
+// The two x-neighbours of a corner pair sit next to each other in the table (dense: e+1; hashed: (x ^ h) and ((x+1) ^ h)
+// differ only in the low bits unless x crosses a power-of-two boundary), so one 16-byte aligned load usually returns both
+// (3 out of 4 positions).  The texture-cache access rate (one line per clock per CU), not bandwidth, bounds the encoding:
+// 4 wide loads + a predicated narrow load for the straddling quarter = 5 accesses per level instead of 8.
+__device__ __forceinline__ uint32_t pick4(const uint4& q, uint32_t i) {
+    const uint32_t lo = (i & 1) ? q.y : q.x, hi = (i & 1) ? q.w : q.z;
+    return (i & 2) ? hi : lo;
+}
 __device__ __forceinline__ void grid_level_features(__amdgpu_buffer_rsrc_t rsrc, const Corner8& c, float& f0, float& f1) {
     uint32_t v[8];
+    uint4 quad[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, c.e[k] << 2, 0, 0);
+    for (int p = 0; p < 4; p++) {
+        const uint32_t base = c.e[2 * p] & ~3u;
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base << 2, 0, 0);
+        quad[p] = make_uint4(raw[0], raw[1], raw[2], raw[3]);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const uint32_t e0 = c.e[2 * p], e1 = c.e[2 * p + 1], base = e0 & ~3u;
+        v[2 * p] = pick4(quad[p], e0 & 3u);
+        uint32_t other = pick4(quad[p], e1 & 3u);
+        if ((e1 & ~3u) != base) other = __builtin_amdgcn_raw_buffer_load_b32(rsrc, e1 << 2, 0, 0);
+        v[2 * p + 1] = other;
+    }
     f0 = 0.f; f1 = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -148,7 +169,6 @@ __device__ __forceinline__ void grid_level_features(__amdgpu_buffer_rsrc_t rsrc,
         f1 = fmaf(c.w[k], t.y, f1);
     }
 }
-
 
 // ---- split-phase encoding: issue the 64 gathers of a sample now, interpolate later ------------------------------------
 // The texture-address path is the bottleneck of the encoding (one distinct cache line per clock per CU); the only way to

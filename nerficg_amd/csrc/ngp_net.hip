@@ -10,7 +10,6 @@
 // live in the wave's VGPRs for the whole persistent loop.  Per sample the kernel reads 12 B (+ the gathers, served by
 // L2 / Infinity Cache: the 24.4 MB table never streams from HBM twice) and writes 8-32 B.
 #include "ngp_net.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -154,9 +153,10 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
 // The pipeline is therefore split at the 32 encoded features (64 B/sample, fp16, level-major so that both sides are
 // coalesced) and processed in chunks small enough for the features to stay in the 256 MB Infinity Cache.
 //
-//   k_grid_encode : one lane per (sample, level).  blockIdx%8 selects the level pair {x, x+8}: workgroups that share an XCD
-//                   (round-robin dispatch) gather from the same two levels, so each 4 MB L2 serves <= 4 MB of table instead of
-//                   all 24.4 MB (placement affects speed only).
+//   k_grid_encode : one lane per sample, all 16 levels (128 gathers, issued as 16-byte pair loads).  Bound by the L1
+//                   texture-cache access rate (~1 line / clk / CU: TCP_TOTAL_CACHE_ACCESSES / GRBM_GUI_ACTIVE in profiles/).
+//                   An XCD-affine variant (blockIdx%8 -> level pair, so that each 4 MB L2 serves 2 levels) was measured:
+//                   L2 hit rate 91 %, but the 8x repeated sample fetch cost more than it saved (12.2 vs 10.9 ms / image).
 //   k_ngp_mlp     : density net -> sigma -> colour net from the level-major features; weights as LDS-resident A fragments.
 enum { SRC_ARRAYS = 0, SRC_TILED = 1 };
 struct QueryIn {
@@ -173,11 +173,14 @@ __device__ __forceinline__ bool fetch_pos(const QueryIn& in, int64_t i, float& p
     } else {
         const float t = in.ts[i];
         if (t < 0.f) { px = py = pz = 0.f; return false; }
-        const float* od = in.ray_od + 6 * ((int64_t)in.row_tile[i >> 6] * 64 + (i & 63));
+        const float* od = in.ray_od + (int64_t)in.row_tile[i >> 6] * 384 + (i & 63);  // per-tile SoA [6][64]
         // same roundings as the op-by-op path: xyz = o + t*d (mul, add: raymarching.cu:368), then (xyz - min) / size in torch
-        px = __fdiv_rn(__fsub_rn(__fadd_rn(od[0], __fmul_rn(t, od[3])), in.mn[0]), in.sz[0]);
-        py = __fdiv_rn(__fsub_rn(__fadd_rn(od[1], __fmul_rn(t, od[4])), in.mn[1]), in.sz[1]);
-        pz = __fdiv_rn(__fsub_rn(__fadd_rn(od[2], __fmul_rn(t, od[5])), in.mn[2]), in.sz[2]);
+        px = __fsub_rn(__fadd_rn(od[0], __fmul_rn(t, od[192])), in.mn[0]);
+        py = __fsub_rn(__fadd_rn(od[64], __fmul_rn(t, od[256])), in.mn[1]);
+        pz = __fsub_rn(__fadd_rn(od[128], __fmul_rn(t, od[320])), in.mn[2]);
+        if (in.sz[0] != 1.0f || in.sz[1] != 1.0f || in.sz[2] != 1.0f) {  // x / 1.0f == x exactly: skip the IEEE division for the unit box
+            px = __fdiv_rn(px, in.sz[0]); py = __fdiv_rn(py, in.sz[1]); pz = __fdiv_rn(pz, in.sz[2]);
+        }
         return true;
     }
 }
@@ -186,24 +189,22 @@ __device__ __forceinline__ void fetch_dir(const QueryIn& in, int64_t i, float& d
     if constexpr (SRC == SRC_ARRAYS) {
         dx = in.dirs[3 * i]; dy = in.dirs[3 * i + 1]; dz = in.dirs[3 * i + 2];
     } else {
-        const float* od = in.ray_od + 6 * ((int64_t)in.row_tile[i >> 6] * 64 + (i & 63));
-        dx = od[3]; dy = od[4]; dz = od[5];
+        const float* od = in.ray_od + (int64_t)in.row_tile[i >> 6] * 384 + (i & 63);
+        dx = od[192]; dy = od[256]; dz = od[320];
     }
 }
 
-// feat: level-major [16][n] fp16x2 for the samples [base, base+n)
+// feat: level-major [16][n] fp16x2 for the samples [base, base+n).  One lane per sample, all 16 levels.
 template <int SRC>
 __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ table, GridCfg g,
-                                                     __half2* __restrict__ feat) {
-    const int xg = blockIdx.x & 7;
-    const int64_t j = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+                                                         __half2* __restrict__ feat) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     float px, py, pz;
     const bool live = fetch_pos<SRC>(in, base + j, px, py, pz);
     const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const int level = xg + 8 * half;  // block-uniform: level constants are scalar loads, the dense/hash choice is a scalar branch
+#pragma unroll 4
+    for (int level = 0; level < 16; level++) {
         if (!live) { feat[(int64_t)level * n + j] = __floats2half2_rn(0.f, 0.f); continue; }
         Corner8 c;
         grid_corners(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], g.hashed[level] != 0, c);
@@ -381,7 +382,7 @@ static int run_query(const QueryIn& in, int64_t M, const void* wd, const void* w
     __half2* feat = (__half2*)workspace;
     for (int64_t base = 0; base < M; base += NRC_QUERY_CHUNK) {
         const int64_t n = (M - base) < NRC_QUERY_CHUNK ? (M - base) : NRC_QUERY_CHUNK;
-        hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)(nrc_cdiv(n, 256) * 8)), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat);
+        hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat);
         hipLaunchKernelGGL(k_ngp_mlp<SRC>, dim3(pick_blocks(n)), dim3(256), 0, s, in, base, n, (const __half2*)feat, (const __half*)wd,
                            (const __half*)wc, sigmas, rgbs, (__half*)packed);
     }
@@ -464,6 +465,27 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
     QueryIn in = {};
     in.xyz01 = xyz01; in.dirs = dirs;
     run_query<SRC_ARRAYS>(in, M, density_weights_f16, color_weights_f16, table_f16, g, sigmas, rgbs, nullptr, workspace, (hipStream_t)stream);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, const float* xyz_min3,
+                           const float* xyz_size3, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
+                           int32_t base_resolution, float per_level_scale, void* features_f16, nrc_stream_t stream) {
+    NRC_ENTER();
+    const int64_t n = n_rows * 64;
+    if (n_rows < 0 || n > NRC_QUERY_CHUNK || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
+    if (n_levels != 16) return NRC_ERR_UNSUPPORTED;
+    if (n == 0) return NRC_OK;
+    if (!ts || !row_tile || !ray_od || !features_f16) return NRC_ERR_INVALID;
+    GridCfg g;
+    const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
+    if (rc != NRC_OK) return rc;
+    QueryIn in = {};
+    in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od;
+    for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
+    hipLaunchKernelGGL(k_grid_encode<SRC_TILED>, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, (int64_t)0, n,
+                       (const __half2*)table_f16, g, (__half2*)features_f16);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
