@@ -193,6 +193,41 @@ int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32
                             const float* bg3, float* rgb, float* alpha, float* depth, nrc_stream_t stream);
 
 /* =====================================================================================================
+ * Group 4 -- diff_gaussian_rasterization  (replaces the external CUDA rasterizer pinned at
+ *            src/Thirdparty/DiffGaussianRasterization.py:9 behind src/Methods/GaussianSplatting/Renderer.py:60-81,94-153,163-183)
+ * P Gaussians, SH degree D (0..3), M = SH coefficients per Gaussian in `shs` (P,M,3); exactly one of shs | colors_precomp (P,3)
+ * and exactly one of (scales (P,3), rotations (P,4)) | cov3D_precomp (P,6).  viewmatrix / projmatrix (16 floats each, the
+ * (4,4) tensors the reference passes: w2c.T and w2c.T @ P.T), campos (3), bg (3) are HOST pointers.  16x16-pixel tiles.
+ * Per-Gaussian state (geometry buffer): radii (P) i32, depths (P), points_xy (P,2), conic_opacity (P,4), rgb (P,3),
+ * clamped (P) u8 bit mask (bit c = channel c clamped), cov3D (P,6), tiles_touched (P) u32.
+ * Binning state: tile_counts, tile_fill (n_tiles) u32, ranges (n_tiles,2) u32, keys (num_rendered) u64, point_list
+ * (num_rendered) i32.  Image state: n_contrib (H*W) u32, final_T (H*W).
+ *   nrc_gs_preprocess : stages 1-2; *num_rendered (DEVICE i64) = number of (tile, Gaussian) instances -- the caller reads it
+ *                       to size keys / point_list (the reference's rasterizer pays the same device->host read).
+ *   nrc_gs_bin_render : stages 3-5 -> out_color (3,H,W) = C + T * bg, n_contrib, final_T.
+ *   nrc_gs_backward   : dL_dpix (3,H,W) -> every gradient (all fully written; dL_dmean2D (P,3) is the screen-space gradient
+ *                       consumed by densification, src/Methods/GaussianSplatting/Model.py:258).
+ * ===================================================================================================== */
+int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs,
+                      const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                      const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                      const float* campos, float tan_fovx, float tan_fovy, int32_t* radii, float* depths, float* points_xy,
+                      float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched,
+                      uint32_t* tile_counts, uint32_t* ranges, uint32_t* tile_fill, int64_t* num_rendered, nrc_stream_t stream);
+int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg, const int32_t* radii, const float* depths,
+                      const float* points_xy, const float* conic_opacity, const float* rgb, const uint32_t* ranges,
+                      uint32_t* tile_fill, uint64_t* keys, int32_t* point_list, float* out_color, uint32_t* n_contrib,
+                      float* final_T, nrc_stream_t stream);
+int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg, const float* means3D, const float* shs,
+                    const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                    float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
+                    const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list,
+                    const uint32_t* ranges, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
+                    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, nrc_stream_t stream);
+
+/* =====================================================================================================
  * Group 5 -- ray generation (replaces PerspectiveCamera.compute_local_ray_directions src/Cameras/Perspective.py:64-94
  * + View.get_rays / cam_to_world src/Datasets/utils.py:1033-1074 for undistorted perspective cameras).
  * intrinsics (HOST, 4 doubles): focal_x, focal_y, center_x, center_y.  c2w (HOST, 16 doubles, row-major 4x4).

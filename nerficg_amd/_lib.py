@@ -18,7 +18,7 @@ ERRORS = {0: 'NRC_OK', -1: 'NRC_ERR_INVALID', -2: 'NRC_ERR_LAUNCH', -3: 'NRC_ERR
 
 _SCALARS = {
     'int': ctypes.c_int, 'int32_t': ctypes.c_int32, 'uint32_t': ctypes.c_uint32, 'int64_t': ctypes.c_int64,
-    'uint64_t': ctypes.c_uint64, 'float': ctypes.c_float, 'double': ctypes.c_double, 'nrc_stream_t': ctypes.c_void_p,
+    'uint64_t': ctypes.c_uint64, 'uint8_t': ctypes.c_uint8, 'float': ctypes.c_float, 'double': ctypes.c_double, 'nrc_stream_t': ctypes.c_void_p,
 }
 
 

@@ -24,6 +24,7 @@ COMMON_FLAGS = ['-O3', '-fPIC', f'--offload-arch={ARCH}', '-std=c++17', '-Wall',
 # translation units whose f32 arithmetic decides integer indices: no FMA contraction (bit-exact vs oracle/)
 PER_FILE_FLAGS = {
     'ngp_march.hip': ['-ffp-contract=off'],
+    'gs_raster.hip': ['-ffp-contract=off'],
 }
 
 

@@ -1,0 +1,710 @@
+// gs_raster.hip -- 3D Gaussian Splatting tile rasterizer for gfx950, forward and backward.
+//
+// Replaces diff-gaussian-rasterization @ 59f5f77e (src/Thirdparty/DiffGaussianRasterization.py:9) behind the call sites of
+// src/Methods/GaussianSplatting/Renderer.py:60-81,94-153,163-183.  Algorithm = Kerbl et al. 2023; conventions and the
+// statement the kernels are checked against: oracle/gs_oracle_impl.h.
+//
+// BUILD NOTE: compiled with -ffp-contract=off.  Radii, tile rectangles and the depth keys that order the blend are integer
+// decisions taken from f32 arithmetic and must be bit-exact against the oracle (which is built the same way).
+//
+// MI355X-native structure (vs the reference's pipeline: inclusive scan -> key duplication -> DEVICE-WIDE 64-bit radix sort ->
+// range search, ~100 B of HBM traffic per (tile, Gaussian) instance):
+//   1. k_preprocess   one lane per Gaussian: cull, cov3D, EWA cov2D, conic, radius, SH -> RGB; counts instances per TILE.
+//   2. k_scan_tiles   exclusive scan of the per-tile counts = the tile ranges (no key search pass).
+//   3. k_scatter      every Gaussian drops (depth bits << 32 | id) into its tiles' segments (8 B written per instance).
+//   4. k_sort_tiles   one workgroup per tile sorts ITS segment by (depth, id) inside LDS (bitonic, 64-bit keys; segments
+//                     larger than the LDS budget fall back to the same network in global memory) and emits the id list.
+//                     The order (depth, then index) is exactly what a stable radix sort over (tile | depth) keys produces.
+//   5. k_render       16x16-pixel tile per workgroup (4 waves), 256-Gaussian batches staged in LDS, front-to-back blend.
+//   => 20 B of traffic per instance instead of ~100, and no global sort.
+// Backward:
+//   6. k_render_bw    same tiles, back-to-front; per-Gaussian gradients are reduced ACROSS THE WAVE with DPP shuffles and
+//                     leave as one atomic per wave and quantity (the reference issues one atomic per PIXEL and quantity).
+//   7. k_preprocess_bw one lane per Gaussian: conic -> cov2D -> cov3D -> scale/rotation, mean2D -> mean3D, colour -> SH.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+#define TILE 16
+#define BATCH 256
+#define SORT_LDS_CAP 8192  // 64-bit keys sorted in LDS per tile (64 KB)
+
+namespace {
+
+struct GsCam {
+    float view[16], proj[16], campos[3];
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+    int W, H, gx, gy, D, M;
+};
+
+__device__ __forceinline__ void xform43(const float* p, const float* m, float* o) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+__device__ __forceinline__ void xform44(const float* p, const float* m, float* o) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+    o[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+}
+__device__ __forceinline__ void quat_R(const float* q, float* R) {
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - r * z);     R[2] = 2 * (x * z + r * y);
+    R[3] = 2 * (x * y + r * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - r * x);
+    R[6] = 2 * (x * z - r * y);     R[7] = 2 * (y * z + r * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+__device__ __forceinline__ void cov3d(const float* scale, float mod, const float* q, float* c) {
+    float R[9], A[9];
+    quat_R(q, R);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) A[3 * i + k] = R[3 * i + k] * (mod * scale[k]);
+    c[0] = A[0] * A[0] + A[1] * A[1] + A[2] * A[2];
+    c[1] = A[0] * A[3] + A[1] * A[4] + A[2] * A[5];
+    c[2] = A[0] * A[6] + A[1] * A[7] + A[2] * A[8];
+    c[3] = A[3] * A[3] + A[4] * A[4] + A[5] * A[5];
+    c[4] = A[3] * A[6] + A[4] * A[7] + A[5] * A[8];
+    c[5] = A[6] * A[6] + A[7] * A[7] + A[8] * A[8];
+}
+__device__ __forceinline__ void proj_jac(const float* t_in, float fx, float fy, float tanx, float tany, const float* vm, float* Mx,
+                                         float* My, float* t_cl, int* gx, int* gy) {
+    const float limx = 1.3f * tanx, limy = 1.3f * tany;
+    const float txtz = t_in[0] / t_in[2], tytz = t_in[1] / t_in[2];
+    t_cl[0] = fminf(limx, fmaxf(-limx, txtz)) * t_in[2];
+    t_cl[1] = fminf(limy, fmaxf(-limy, tytz)) * t_in[2];
+    t_cl[2] = t_in[2];
+    *gx = (txtz < -limx || txtz > limx) ? 0 : 1;
+    *gy = (tytz < -limy || tytz > limy) ? 0 : 1;
+    const float j00 = fx / t_cl[2], j02 = -(fx * t_cl[0]) / (t_cl[2] * t_cl[2]);
+    const float j11 = fy / t_cl[2], j12 = -(fy * t_cl[1]) / (t_cl[2] * t_cl[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        Mx[k] = j00 * vm[0 + 4 * k] + j02 * vm[2 + 4 * k];
+        My[k] = j11 * vm[1 + 4 * k] + j12 * vm[2 + 4 * k];
+    }
+}
+__device__ __forceinline__ void sym_mul(const float* c, const float* v, float* o) {
+    o[0] = c[0] * v[0] + c[1] * v[1] + c[2] * v[2];
+    o[1] = c[1] * v[0] + c[3] * v[1] + c[4] * v[2];
+    o[2] = c[2] * v[0] + c[4] * v[1] + c[5] * v[2];
+}
+
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+__constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                               -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
+
+__device__ __forceinline__ void sh_color(int deg, const float* pos, const float* campos, const float* sh, float* rgb, uint8_t* clamped) {
+    float d[3] = {pos[0] - campos[0], pos[1] - campos[1], pos[2] - campos[2]};
+    const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    d[0] /= len; d[1] /= len; d[2] /= len;
+    const float x = d[0], y = d[1], z = d[2];
+    uint8_t mask = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float r = SH_C0 * sh[c];
+        if (deg > 0) {
+            r = r - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = r + SH_C2[0] * xy * sh[12 + c] + SH_C2[1] * yz * sh[15 + c] + SH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + c] +
+                    SH_C2[3] * xz * sh[21 + c] + SH_C2[4] * (xx - yy) * sh[24 + c];
+                if (deg > 2) {
+                    r = r + SH_C3[0] * y * (3.0f * xx - yy) * sh[27 + c] + SH_C3[1] * xy * z * sh[30 + c] +
+                        SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + c] + SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + c] +
+                        SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + c] + SH_C3[5] * z * (xx - yy) * sh[42 + c] +
+                        SH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + c];
+                }
+            }
+        }
+        r += 0.5f;
+        if (r < 0) mask |= (uint8_t)(1u << c);
+        rgb[c] = r < 0 ? 0 : r;
+    }
+    *clamped = mask;
+}
+__device__ __forceinline__ void tile_rect(const float* p, int radius, int gx, int gy, int* rmin, int* rmax) {
+    rmin[0] = min(gx, max(0, (int)((p[0] - radius) / TILE)));
+    rmin[1] = min(gy, max(0, (int)((p[1] - radius) / TILE)));
+    rmax[0] = min(gx, max(0, (int)((p[0] + radius + TILE - 1) / TILE)));
+    rmax[1] = min(gy, max(0, (int)((p[1] + radius + TILE - 1) / TILE)));
+}
+
+// ------------------------------------------------------------------------------------------------ 1. preprocess
+__global__ void __launch_bounds__(256) k_preprocess(int P, GsCam cam, const float* __restrict__ means3D, const float* __restrict__ shs,
+                                                    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                                                    const float* __restrict__ scales, const float* __restrict__ rotations,
+                                                    const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii,
+                                                    float* __restrict__ depths, float* __restrict__ points_xy,
+                                                    float* __restrict__ conic_opacity, float* __restrict__ rgb, uint8_t* __restrict__ clamped,
+                                                    float* __restrict__ cov3D, uint32_t* __restrict__ tiles_touched,
+                                                    uint32_t* __restrict__ tile_counts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    radii[i] = 0; tiles_touched[i] = 0; depths[i] = 0.f;
+    points_xy[2 * i] = 0.f; points_xy[2 * i + 1] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) conic_opacity[4 * i + k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) rgb[3 * i + k] = 0.f;
+    clamped[i] = 0;
+    const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+    float pv[3];
+    xform43(p, cam.view, pv);
+    float c3[6];
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * i + k];
+    } else {
+        const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        const float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+        cov3d(s, cam.scale_modifier, q, c3);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) cov3D[6 * i + k] = c3[k];
+    if (pv[2] <= 0.2f) return;
+    float ph[4];
+    xform44(p, cam.proj, ph);
+    const float pw = 1.0f / (ph[3] + 0.0000001f);
+    const float ndc[2] = {ph[0] * pw, ph[1] * pw};
+    float tc[3], Mx[3], My[3], sx[3], sy[3];
+    int gmx, gmy;
+    proj_jac(pv, cam.focal_x, cam.focal_y, cam.tan_fovx, cam.tan_fovy, cam.view, Mx, My, tc, &gmx, &gmy);
+    sym_mul(c3, Mx, sx); sym_mul(c3, My, sy);
+    const float cov[3] = {Mx[0] * sx[0] + Mx[1] * sx[1] + Mx[2] * sx[2] + 0.3f, Mx[0] * sy[0] + Mx[1] * sy[1] + Mx[2] * sy[2],
+                          My[0] * sy[0] + My[1] * sy[1] + My[2] * sy[2] + 0.3f};
+    const float det = cov[0] * cov[2] - cov[1] * cov[1];
+    if (det == 0.0f) return;
+    const float det_inv = 1.0f / det;
+    const float conic[3] = {cov[2] * det_inv, -cov[1] * det_inv, cov[0] * det_inv};
+    const float mid = 0.5f * (cov[0] + cov[2]);
+    const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+    const int my_radius = (int)ceilf(3.0f * sqrtf(fmaxf(lambda1, lambda2)));
+    const float pix[2] = {((ndc[0] + 1.0f) * cam.W - 1.0f) * 0.5f, ((ndc[1] + 1.0f) * cam.H - 1.0f) * 0.5f};
+    int rmin[2], rmax[2];
+    tile_rect(pix, my_radius, cam.gx, cam.gy, rmin, rmax);
+    if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) return;
+    if (colors_precomp) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) rgb[3 * i + k] = colors_precomp[3 * i + k];
+    } else {
+        float col[3];
+        uint8_t cl;
+        sh_color(cam.D, p, cam.campos, shs + (size_t)i * cam.M * 3, col, &cl);
+#pragma unroll
+        for (int k = 0; k < 3; k++) rgb[3 * i + k] = col[k];
+        clamped[i] = cl;
+    }
+    depths[i] = pv[2]; radii[i] = my_radius;
+    points_xy[2 * i] = pix[0]; points_xy[2 * i + 1] = pix[1];
+    conic_opacity[4 * i] = conic[0]; conic_opacity[4 * i + 1] = conic[1]; conic_opacity[4 * i + 2] = conic[2];
+    conic_opacity[4 * i + 3] = opacities[i];
+    tiles_touched[i] = (uint32_t)((rmax[1] - rmin[1]) * (rmax[0] - rmin[0]));
+    for (int y = rmin[1]; y < rmax[1]; y++)
+        for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&tile_counts[y * cam.gx + x], 1u);
+}
+
+// ------------------------------------------------------------------------------------------------ 2. tile ranges
+__global__ void __launch_bounds__(1024) k_scan_tiles(const uint32_t* __restrict__ counts, int n, uint32_t* __restrict__ ranges,
+                                                     uint32_t* __restrict__ fill, int64_t* __restrict__ num_rendered) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < n ? counts[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (int w = 0; w < wave; w++) off += wave_tot[w];
+        if (i < n) { ranges[2 * i] = off + incl - v; ranges[2 * i + 1] = off + incl; fill[i] = 0u; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *num_rendered = (int64_t)carry_s;
+}
+
+// ------------------------------------------------------------------------------------------------ 3. scatter instances
+__global__ void __launch_bounds__(256) k_scatter(int P, int gx, int gy, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+                                                 const float* __restrict__ points_xy, const uint32_t* __restrict__ ranges,
+                                                 uint32_t* __restrict__ fill, uint64_t* __restrict__ keys) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P || radii[i] <= 0) return;
+    const float pxy[2] = {points_xy[2 * i], points_xy[2 * i + 1]};
+    int rmin[2], rmax[2];
+    tile_rect(pxy, radii[i], gx, gy, rmin, rmax);
+    const uint64_t key = ((uint64_t)__float_as_uint(depths[i]) << 32) | (uint32_t)i;
+    for (int y = rmin[1]; y < rmax[1]; y++)
+        for (int x = rmin[0]; x < rmax[0]; x++) {
+            const int t = y * gx + x;
+            const uint32_t slot = atomicAdd(&fill[t], 1u);
+            keys[ranges[2 * t] + slot] = key;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ 4. per-tile sort
+// Normalised bitonic network on 64-bit keys: every compare-exchange puts the smaller key at the lower index, the first
+// step of each merge pairs i with its mirror i ^ (k-1).  Partners beyond n are skipped (they behave like +inf, which
+// never has to move), so any n is sorted in place without padding.  `a` may be LDS or global memory.
+__device__ __forceinline__ void bitonic_sort_any(uint64_t* a, int n) {
+    for (int k = 2; (k >> 1) < n; k <<= 1) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int l = i ^ (k - 1);
+            if (l > i && l < n) {
+                const uint64_t x = a[i], y = a[l];
+                if (x > y) { a[i] = y; a[l] = x; }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const int l = i ^ j;
+                if (l > i && l < n) {
+                    const uint64_t x = a[i], y = a[l];
+                    if (x > y) { a[i] = y; a[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_sort_tiles(const uint32_t* __restrict__ ranges, uint64_t* __restrict__ keys,
+                                                    int32_t* __restrict__ point_list) {
+    __shared__ uint64_t lds[SORT_LDS_CAP];
+    const int t = blockIdx.x;
+    const uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
+    const int n = (int)(r1 - r0);
+    if (n == 0) return;
+    if (n <= SORT_LDS_CAP) {
+        for (int i = threadIdx.x; i < n; i += 256) lds[i] = keys[r0 + i];
+        __syncthreads();
+        bitonic_sort_any(lds, n);
+        for (int i = threadIdx.x; i < n; i += 256) point_list[r0 + i] = (int32_t)(uint32_t)lds[i];
+    } else {
+        // oversized segment (> 8192 Gaussians on one tile): the same network directly on the global segment; the workgroup is
+        // the only reader/writer of it and __syncthreads() orders its own global accesses
+        bitonic_sort_any(keys + r0, n);
+        for (int i = threadIdx.x; i < n; i += 256) point_list[r0 + i] = (int32_t)(uint32_t)keys[r0 + i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 5. render
+__global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
+                                                const float* __restrict__ points_xy, const float* __restrict__ conic_opacity,
+                                                const float* __restrict__ rgb, float bg0, float bg1, float bg2, float* __restrict__ out_color,
+                                                uint32_t* __restrict__ n_contrib, float* __restrict__ final_T) {
+    __shared__ int s_id[BATCH];
+    __shared__ float2 s_xy[BATCH];
+    __shared__ float4 s_co[BATCH];
+    __shared__ float s_rgb[BATCH * 3];
+    const int tile = blockIdx.y * cam.gx + blockIdx.x;
+    const int px = blockIdx.x * TILE + (threadIdx.x & 15), py = blockIdx.y * TILE + (threadIdx.x >> 4);
+    const bool inside = px < cam.W && py < cam.H;
+    const float fx = (float)px, fy = (float)py;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    uint32_t contributor = 0, last = 0;
+    for (uint32_t base = r0; base < r1; base += BATCH) {
+        if (__syncthreads_count(done) == 256) break;
+        const uint32_t k = base + threadIdx.x;
+        if (k < r1) {
+            const int id = point_list[k];
+            s_id[threadIdx.x] = id;
+            s_xy[threadIdx.x] = make_float2(points_xy[2 * id], points_xy[2 * id + 1]);
+            s_co[threadIdx.x] = *reinterpret_cast<const float4*>(conic_opacity + 4 * id);
+            s_rgb[3 * threadIdx.x] = rgb[3 * id]; s_rgb[3 * threadIdx.x + 1] = rgb[3 * id + 1]; s_rgb[3 * threadIdx.x + 2] = rgb[3 * id + 2];
+        }
+        __syncthreads();
+        const int nb = (int)min((uint32_t)BATCH, r1 - base);
+        for (int j = 0; !done && j < nb; j++) {
+            contributor++;
+            const float2 xy = s_xy[j];
+            const float dx = xy.x - fx, dy = xy.y - fy;
+            const float4 co = s_co[j];
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, co.w * expf(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float test_T = T * (1 - alpha);
+            if (test_T < 0.0001f) { done = true; continue; }
+            C0 += s_rgb[3 * j] * alpha * T; C1 += s_rgb[3 * j + 1] * alpha * T; C2 += s_rgb[3 * j + 2] * alpha * T;
+            T = test_T;
+            last = contributor;
+        }
+        __syncthreads();
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * cam.W + px, hw = (size_t)cam.H * cam.W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = C0 + T * bg0; out_color[hw + pix] = C1 + T * bg1; out_color[2 * hw + pix] = C2 + T * bg2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 6. render backward
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
+                                                   const float* __restrict__ points_xy, const float* __restrict__ conic_opacity,
+                                                   const float* __restrict__ rgb, float bg0, float bg1, float bg2,
+                                                   const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
+                                                   const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D,
+                                                   float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor) {
+    __shared__ int s_id[BATCH];
+    __shared__ float2 s_xy[BATCH];
+    __shared__ float4 s_co[BATCH];
+    __shared__ float s_rgb[BATCH * 3];
+    const int tile = blockIdx.y * cam.gx + blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int px = blockIdx.x * TILE + (threadIdx.x & 15), py = blockIdx.y * TILE + (threadIdx.x >> 4);
+    const bool inside = px < cam.W && py < cam.H;
+    const float fx = (float)px, fy = (float)py;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    const int n_tile = (int)(r1 - r0);
+    const size_t pix = (size_t)py * cam.W + px, hw = (size_t)cam.H * cam.W;
+    const float T_final = inside ? final_T[pix] : 0.f;
+    float T = T_final;
+    const int last = inside ? (int)n_contrib[pix] : 0;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    const float g0 = inside ? dL_dpix[pix] : 0.f, g1 = inside ? dL_dpix[hw + pix] : 0.f, g2 = inside ? dL_dpix[2 * hw + pix] : 0.f;
+    const float bg_dot = bg0 * g0 + bg1 * g1 + bg2 * g2;
+    const float ddelx_dx = 0.5f * cam.W, ddely_dy = 0.5f * cam.H;
+    // batches are taken from the END of the tile list: position p (0-based from the front) has contributor number p + 1
+    for (int done_cnt = 0; done_cnt < n_tile; done_cnt += BATCH) {
+        __syncthreads();
+        const int nb = min(BATCH, n_tile - done_cnt);
+        if ((int)threadIdx.x < nb) {
+            const int id = point_list[r1 - 1 - done_cnt - threadIdx.x];
+            s_id[threadIdx.x] = id;
+            s_xy[threadIdx.x] = make_float2(points_xy[2 * id], points_xy[2 * id + 1]);
+            s_co[threadIdx.x] = *reinterpret_cast<const float4*>(conic_opacity + 4 * id);
+            s_rgb[3 * threadIdx.x] = rgb[3 * id]; s_rgb[3 * threadIdx.x + 1] = rgb[3 * id + 1]; s_rgb[3 * threadIdx.x + 2] = rgb[3 * id + 2];
+        }
+        __syncthreads();
+        for (int j = 0; j < nb; j++) {
+            const int pos = n_tile - 1 - done_cnt - j;  // index from the front
+            bool active = inside && pos < last;
+            float G = 0.f, alpha = 0.f, dx = 0.f, dy = 0.f;
+            float4 co = s_co[j];
+            if (active) {
+                const float2 xy = s_xy[j];
+                dx = xy.x - fx; dy = xy.y - fy;
+                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                if (power > 0.0f) active = false;
+                else {
+                    G = expf(power);
+                    alpha = fminf(0.99f, co.w * G);
+                    if (alpha < 1.0f / 255.0f) active = false;
+                }
+            }
+            if (__ballot(active) == 0ull) continue;  // nobody in this wave sees the Gaussian
+            float d_c0 = 0.f, d_c1 = 0.f, d_c2 = 0.f, d_mx = 0.f, d_my = 0.f, d_cx = 0.f, d_cy = 0.f, d_cw = 0.f, d_op = 0.f;
+            if (active) {
+                T = T / (1 - alpha);
+                const float dch = alpha * T;
+                const float c0 = s_rgb[3 * j], c1 = s_rgb[3 * j + 1], c2 = s_rgb[3 * j + 2];
+                acc0 = last_alpha * lc0 + (1 - last_alpha) * acc0; lc0 = c0;
+                acc1 = last_alpha * lc1 + (1 - last_alpha) * acc1; lc1 = c1;
+                acc2 = last_alpha * lc2 + (1 - last_alpha) * acc2; lc2 = c2;
+                float dL_dalpha = (c0 - acc0) * g0;
+                dL_dalpha += (c1 - acc1) * g1;
+                dL_dalpha += (c2 - acc2) * g2;
+                d_c0 = dch * g0; d_c1 = dch * g1; d_c2 = dch * g2;
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1 - alpha)) * bg_dot;
+                const float dL_dG = co.w * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                const float dG_ddely = -gdy * co.z - gdx * co.y;
+                d_mx = dL_dG * dG_ddelx * ddelx_dx; d_my = dL_dG * dG_ddely * ddely_dy;
+                d_cx = -0.5f * gdx * dx * dL_dG; d_cy = -0.5f * gdx * dy * dL_dG; d_cw = -0.5f * gdy * dy * dL_dG;
+                d_op = G * dL_dalpha;
+            }
+            // wave-level reduction, then ONE atomic per wave and quantity
+            d_c0 = wave_sum(d_c0); d_c1 = wave_sum(d_c1); d_c2 = wave_sum(d_c2);
+            d_mx = wave_sum(d_mx); d_my = wave_sum(d_my);
+            d_cx = wave_sum(d_cx); d_cy = wave_sum(d_cy); d_cw = wave_sum(d_cw); d_op = wave_sum(d_op);
+            if (lane == 0) {
+                const int id = s_id[j];
+                atomicAdd(dL_dcolor + 3 * id, d_c0); atomicAdd(dL_dcolor + 3 * id + 1, d_c1); atomicAdd(dL_dcolor + 3 * id + 2, d_c2);
+                atomicAdd(dL_dmean2D + 3 * id, d_mx); atomicAdd(dL_dmean2D + 3 * id + 1, d_my);
+                atomicAdd(dL_dconic + 4 * id, d_cx); atomicAdd(dL_dconic + 4 * id + 1, d_cy); atomicAdd(dL_dconic + 4 * id + 3, d_cw);
+                atomicAdd(dL_dopacity + id, d_op);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 7. preprocess backward
+__global__ void __launch_bounds__(256) k_preprocess_bw(int P, GsCam cam, const float* __restrict__ means3D, const float* __restrict__ shs,
+                                                       int use_sh, const float* __restrict__ scales, const float* __restrict__ rotations,
+                                                       int use_scale_rot, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
+                                                       const float* __restrict__ cov3D, const float* __restrict__ dL_dmean2D,
+                                                       const float* __restrict__ dL_dconic, const float* __restrict__ dL_dcolor,
+                                                       float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+                                                       float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P || !(radii[i] > 0)) return;
+    const float mean[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+    float c3[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) c3[k] = cov3D[6 * i + k];
+    const float fx = cam.focal_x, fy = cam.focal_y;
+    const float* vm = cam.view;
+    float t[3], tc[3], Mx[3], My[3], sx[3], sy[3];
+    int gmx, gmy;
+    xform43(mean, vm, t);
+    proj_jac(t, fx, fy, cam.tan_fovx, cam.tan_fovy, vm, Mx, My, tc, &gmx, &gmy);
+    sym_mul(c3, Mx, sx); sym_mul(c3, My, sy);
+    const float a = Mx[0] * sx[0] + Mx[1] * sx[1] + Mx[2] * sx[2] + 0.3f;
+    const float b = Mx[0] * sy[0] + Mx[1] * sy[1] + Mx[2] * sy[2];
+    const float c = My[0] * sy[0] + My[1] * sy[1] + My[2] * sy[2] + 0.3f;
+    const float gcx = dL_dconic[4 * i], gcy = dL_dconic[4 * i + 1], gcz = dL_dconic[4 * i + 3];
+    const float denom = a * c - b * b;
+    const float denom2inv = 1.0f / (denom * denom + 0.0000001f);
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    float o[6] = {0, 0, 0, 0, 0, 0};
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-c * c * gcx + 2 * b * c * gcy + (denom - a * c) * gcz);
+        dL_dc = denom2inv * (-a * a * gcz + 2 * a * b * gcy + (denom - a * c) * gcx);
+        dL_db = denom2inv * 2 * (b * c * gcx - (denom + 2 * b * b) * gcy + a * b * gcz);
+        o[0] = Mx[0] * Mx[0] * dL_da + Mx[0] * My[0] * dL_db + My[0] * My[0] * dL_dc;
+        o[3] = Mx[1] * Mx[1] * dL_da + Mx[1] * My[1] * dL_db + My[1] * My[1] * dL_dc;
+        o[5] = Mx[2] * Mx[2] * dL_da + Mx[2] * My[2] * dL_db + My[2] * My[2] * dL_dc;
+        o[1] = 2 * Mx[0] * Mx[1] * dL_da + (Mx[0] * My[1] + Mx[1] * My[0]) * dL_db + 2 * My[0] * My[1] * dL_dc;
+        o[2] = 2 * Mx[0] * Mx[2] * dL_da + (Mx[0] * My[2] + Mx[2] * My[0]) * dL_db + 2 * My[0] * My[2] * dL_dc;
+        o[4] = 2 * Mx[2] * Mx[1] * dL_da + (Mx[1] * My[2] + Mx[2] * My[1]) * dL_db + 2 * My[1] * My[2] * dL_dc;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = o[k];
+    float dMx[3], dMy[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dMx[k] = 2 * sx[k] * dL_da + sy[k] * dL_db; dMy[k] = 2 * sy[k] * dL_dc + sx[k] * dL_db; }
+    float dJ00 = 0, dJ02 = 0, dJ11 = 0, dJ12 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        dJ00 += vm[0 + 4 * k] * dMx[k]; dJ02 += vm[2 + 4 * k] * dMx[k];
+        dJ11 += vm[1 + 4 * k] * dMy[k]; dJ12 += vm[2 + 4 * k] * dMy[k];
+    }
+    const float tz = 1.0f / tc[2], tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = (float)gmx * -fx * tz2 * dJ02;
+    const float dty = (float)gmy * -fy * tz2 * dJ12;
+    const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * tc[0]) * tz3 * dJ02 + (2 * fy * tc[1]) * tz3 * dJ12;
+    float dmean[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) dmean[k] = vm[0 + 4 * k] * dtx + vm[1 + 4 * k] * dty + vm[2 + 4 * k] * dtz;
+    const float* pm = cam.proj;
+    float mh[4];
+    xform44(mean, pm, mh);
+    const float mw = 1.0f / (mh[3] + 0.0000001f);
+    const float mul1 = mh[0] * mw * mw, mul2 = mh[1] * mw * mw;
+    const float g2x = dL_dmean2D[3 * i], g2y = dL_dmean2D[3 * i + 1];
+    dmean[0] += (pm[0] * mw - pm[3] * mul1) * g2x + (pm[1] * mw - pm[3] * mul2) * g2y;
+    dmean[1] += (pm[4] * mw - pm[7] * mul1) * g2x + (pm[5] * mw - pm[7] * mul2) * g2y;
+    dmean[2] += (pm[8] * mw - pm[11] * mul1) * g2x + (pm[9] * mw - pm[11] * mul2) * g2y;
+    if (use_sh) {
+        const float dir0[3] = {mean[0] - cam.campos[0], mean[1] - cam.campos[1], mean[2] - cam.campos[2]};
+        const float sum2 = dir0[0] * dir0[0] + dir0[1] * dir0[1] + dir0[2] * dir0[2];
+        const float len = sqrtf(sum2);
+        const float x = dir0[0] / len, y = dir0[1] / len, z = dir0[2] / len;
+        const float* sh = shs + (size_t)i * cam.M * 3;
+        float* gsh = dL_dsh + (size_t)i * cam.M * 3;
+        const uint8_t cl = clamped[i];
+        float dRGB[3], ddir[3] = {0, 0, 0};
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) dRGB[ch] = ((cl >> ch) & 1) ? 0.f : dL_dcolor[3 * i + ch];
+        float Bv[16], Bx[16], By[16], Bz[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { Bv[k] = 0; Bx[k] = 0; By[k] = 0; Bz[k] = 0; }
+        const int D = cam.D;
+        Bv[0] = SH_C0;
+        if (D > 0) {
+            Bv[1] = -SH_C1 * y; By[1] = -SH_C1;
+            Bv[2] = SH_C1 * z;  Bz[2] = SH_C1;
+            Bv[3] = -SH_C1 * x; Bx[3] = -SH_C1;
+            if (D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z;
+                const float c0 = SH_C2[0], c1 = SH_C2[1], c2 = SH_C2[2], c3_ = SH_C2[3], c4 = SH_C2[4];
+                Bv[4] = c0 * x * y; Bx[4] = c0 * y; By[4] = c0 * x;
+                Bv[5] = c1 * y * z; By[5] = c1 * z; Bz[5] = c1 * y;
+                Bv[6] = c2 * (2 * zz - xx - yy); Bx[6] = c2 * -2 * x; By[6] = c2 * -2 * y; Bz[6] = c2 * 4 * z;
+                Bv[7] = c3_ * x * z; Bx[7] = c3_ * z; Bz[7] = c3_ * x;
+                Bv[8] = c4 * (xx - yy); Bx[8] = c4 * 2 * x; By[8] = c4 * -2 * y;
+                if (D > 2) {
+                    const float e0 = SH_C3[0], e1 = SH_C3[1], e2 = SH_C3[2], e3 = SH_C3[3], e4 = SH_C3[4], e5 = SH_C3[5], e6 = SH_C3[6];
+                    Bv[9] = e0 * y * (3 * xx - yy); Bx[9] = e0 * 6 * x * y; By[9] = e0 * (3 * xx - 3 * yy);
+                    Bv[10] = e1 * x * y * z; Bx[10] = e1 * y * z; By[10] = e1 * x * z; Bz[10] = e1 * x * y;
+                    Bv[11] = e2 * y * (4 * zz - xx - yy); Bx[11] = e2 * -2 * x * y; By[11] = e2 * (4 * zz - xx - 3 * yy); Bz[11] = e2 * 8 * y * z;
+                    Bv[12] = e3 * z * (2 * zz - 3 * xx - 3 * yy); Bx[12] = e3 * -6 * x * z; By[12] = e3 * -6 * y * z; Bz[12] = e3 * (6 * zz - 3 * xx - 3 * yy);
+                    Bv[13] = e4 * x * (4 * zz - xx - yy); Bx[13] = e4 * (4 * zz - 3 * xx - yy); By[13] = e4 * -2 * x * y; Bz[13] = e4 * 8 * x * z;
+                    Bv[14] = e5 * z * (xx - yy); Bx[14] = e5 * 2 * x * z; By[14] = e5 * -2 * y * z; Bz[14] = e5 * (xx - yy);
+                    Bv[15] = e6 * x * (xx - 3 * yy); Bx[15] = e6 * (3 * xx - 3 * yy); By[15] = e6 * -6 * x * y;
+                }
+            }
+        }
+        const int nb = (D + 1) * (D + 1);
+        for (int k = 0; k < nb; k++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                gsh[3 * k + ch] = Bv[k] * dRGB[ch];
+                ddir[0] += Bx[k] * sh[3 * k + ch] * dRGB[ch];
+                ddir[1] += By[k] * sh[3 * k + ch] * dRGB[ch];
+                ddir[2] += Bz[k] * sh[3 * k + ch] * dRGB[ch];
+            }
+        const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        dmean[0] += ((sum2 - dir0[0] * dir0[0]) * ddir[0] - dir0[1] * dir0[0] * ddir[1] - dir0[2] * dir0[0] * ddir[2]) * inv32;
+        dmean[1] += (-dir0[0] * dir0[1] * ddir[0] + (sum2 - dir0[1] * dir0[1]) * ddir[1] - dir0[2] * dir0[1] * ddir[2]) * inv32;
+        dmean[2] += (-dir0[0] * dir0[2] * ddir[0] - dir0[1] * dir0[2] * ddir[1] + (sum2 - dir0[2] * dir0[2]) * ddir[2]) * inv32;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) dL_dmean3D[3 * i + k] = dmean[k];
+    if (use_scale_rot) {
+        const float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+        const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        const float mod = cam.scale_modifier;
+        float R[9], A[9], Gs[9], dA[9], dR[9];
+        quat_R(q, R);
+#pragma unroll
+        for (int r_ = 0; r_ < 3; r_++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) A[3 * r_ + k] = R[3 * r_ + k] * (mod * s[k]);
+        Gs[0] = o[0]; Gs[1] = 0.5f * o[1]; Gs[2] = 0.5f * o[2];
+        Gs[3] = 0.5f * o[1]; Gs[4] = o[3]; Gs[5] = 0.5f * o[4];
+        Gs[6] = 0.5f * o[2]; Gs[7] = 0.5f * o[4]; Gs[8] = o[5];
+#pragma unroll
+        for (int r_ = 0; r_ < 3; r_++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) dA[3 * r_ + k] = 2 * (Gs[3 * r_] * A[k] + Gs[3 * r_ + 1] * A[3 + k] + Gs[3 * r_ + 2] * A[6 + k]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            dL_dscale[3 * i + k] = mod * (dA[k] * R[k] + dA[3 + k] * R[3 + k] + dA[6 + k] * R[6 + k]);
+#pragma unroll
+            for (int r_ = 0; r_ < 3; r_++) dR[3 * r_ + k] = dA[3 * r_ + k] * (mod * s[k]);
+        }
+        const float r = q[0], x = q[1], y = q[2], z = q[3];
+        dL_drot[4 * i] = 2 * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+        dL_drot[4 * i + 1] = 2 * (y * dR[1] + z * dR[2] + y * dR[3] - 2 * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2 * x * dR[8]);
+        dL_drot[4 * i + 2] = 2 * (-2 * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2 * y * dR[8]);
+        dL_drot[4 * i + 3] = 2 * (-2 * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2 * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+    }
+}
+
+int make_cam(GsCam& cam, int W, int H, int D, int M, const float* view, const float* proj, const float* campos, float tanx, float tany,
+             float scale_modifier) {
+    if (W < 1 || H < 1 || D < 0 || D > 3 || !view || !proj || !campos || !(tanx > 0.f) || !(tany > 0.f)) return NRC_ERR_INVALID;
+    for (int k = 0; k < 16; k++) { cam.view[k] = view[k]; cam.proj[k] = proj[k]; }
+    for (int k = 0; k < 3; k++) cam.campos[k] = campos[k];
+    cam.tan_fovx = tanx; cam.tan_fovy = tany;
+    cam.focal_x = W / (2.0f * tanx); cam.focal_y = H / (2.0f * tany);
+    cam.scale_modifier = scale_modifier;
+    cam.W = W; cam.H = H; cam.gx = (W + TILE - 1) / TILE; cam.gy = (H + TILE - 1) / TILE; cam.D = D; cam.M = M;
+    return NRC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs,
+                      const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                      const float* rotations, const float* cov3D_precomp, const float* viewmatrix_host, const float* projmatrix_host,
+                      const float* campos_host, float tan_fovx, float tan_fovy, int32_t* radii, float* depths, float* points_xy,
+                      float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched, uint32_t* tile_counts,
+                      uint32_t* ranges, uint32_t* tile_fill, int64_t* num_rendered, nrc_stream_t stream) {
+    NRC_ENTER();
+    GsCam cam;
+    const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, tan_fovx, tan_fovy, scale_modifier);
+    if (rc != NRC_OK) return rc;
+    if (P < 0 || !tile_counts || !ranges || !tile_fill || !num_rendered) return NRC_ERR_INVALID;
+    if (P > 0) {
+        if ((shs == nullptr) == (colors_precomp == nullptr)) return NRC_ERR_INVALID;                      // exactly one colour source
+        if (((scales != nullptr) && (rotations != nullptr)) == (cov3D_precomp != nullptr)) return NRC_ERR_INVALID;  // exactly one covariance source
+        if (shs && M < (D + 1) * (D + 1)) return NRC_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int n_tiles = cam.gx * cam.gy;
+    hipMemsetAsync(tile_counts, 0, sizeof(uint32_t) * n_tiles, s);
+    if (P > 0) {
+        if (!means3D || !opacities || !radii || !depths || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !tiles_touched) return NRC_ERR_INVALID;
+        hipLaunchKernelGGL(k_preprocess, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam, means3D, shs, colors_precomp, opacities, scales, rotations,
+                           cov3D_precomp, radii, depths, points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched, tile_counts);
+    }
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, n_tiles, ranges, tile_fill, num_rendered);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, const int32_t* radii, const float* depths, const float* points_xy,
+                      const float* conic_opacity, const float* rgb, const uint32_t* ranges, uint32_t* tile_fill, uint64_t* keys,
+                      int32_t* point_list, float* out_color, uint32_t* n_contrib, float* final_T, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (P < 0 || W < 1 || H < 1 || !bg_host || !ranges || !tile_fill || !out_color || !n_contrib || !final_T) return NRC_ERR_INVALID;
+    GsCam cam = {};
+    cam.W = W; cam.H = H; cam.gx = (W + TILE - 1) / TILE; cam.gy = (H + TILE - 1) / TILE;
+    hipStream_t s = (hipStream_t)stream;
+    if (P > 0) {
+        if (!radii || !depths || !points_xy || !conic_opacity || !rgb || !keys || !point_list) return NRC_ERR_INVALID;
+        hipLaunchKernelGGL(k_scatter, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, ranges, tile_fill, keys);
+        hipLaunchKernelGGL(k_sort_tiles, dim3(cam.gx * cam.gy), dim3(256), 0, s, ranges, keys, point_list);
+    }
+    hipLaunchKernelGGL(k_render, dim3(cam.gx, cam.gy), dim3(256), 0, s, cam, ranges, point_list, points_xy, conic_opacity, rgb, bg_host[0],
+                       bg_host[1], bg_host[2], out_color, n_contrib, final_T);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg_host, const float* means3D, const float* shs,
+                    const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                    const float* cov3D_precomp, const float* viewmatrix_host, const float* projmatrix_host, const float* campos_host,
+                    float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
+                    const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list, const uint32_t* ranges,
+                    const uint32_t* n_contrib, const float* final_T, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                    float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                    float* dL_drot, nrc_stream_t stream) {
+    NRC_ENTER();
+    GsCam cam;
+    const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, tan_fovx, tan_fovy, scale_modifier);
+    if (rc != NRC_OK) return rc;
+    if (P < 0 || !bg_host) return NRC_ERR_INVALID;
+    if (P == 0) return NRC_OK;
+    if (!means3D || !radii || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !point_list || !ranges || !n_contrib || !final_T ||
+        !dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+        return NRC_ERR_INVALID;
+    const int use_sh = colors_precomp == nullptr, use_sr = cov3D_precomp == nullptr;
+    if ((use_sh && (!shs || !dL_dsh)) || (use_sr && (!scales || !rotations || !dL_dscale || !dL_drot))) return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    hipMemsetAsync(dL_dmean2D, 0, sizeof(float) * 3 * P, s);
+    hipMemsetAsync(dL_dconic, 0, sizeof(float) * 4 * P, s);
+    hipMemsetAsync(dL_dopacity, 0, sizeof(float) * P, s);
+    hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * P, s);
+    hipMemsetAsync(dL_dmean3D, 0, sizeof(float) * 3 * P, s);
+    hipMemsetAsync(dL_dcov3D, 0, sizeof(float) * 6 * P, s);
+    if (use_sh) hipMemsetAsync(dL_dsh, 0, sizeof(float) * 3 * (size_t)M * P, s);
+    if (use_sr) { hipMemsetAsync(dL_dscale, 0, sizeof(float) * 3 * P, s); hipMemsetAsync(dL_drot, 0, sizeof(float) * 4 * P, s); }
+    hipLaunchKernelGGL(k_render_bw, dim3(cam.gx, cam.gy), dim3(256), 0, s, cam, ranges, point_list, points_xy, conic_opacity, rgb, bg_host[0],
+                       bg_host[1], bg_host[2], n_contrib, final_T, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+    hipLaunchKernelGGL(k_preprocess_bw, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam, means3D, shs, use_sh, scales, rotations, use_sr, radii,
+                       clamped, cov3D, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+"""nerficg_amd.diff_gaussian_rasterization -- drop-in for the `diff_gaussian_rasterization` package the reference imports
+through src/Thirdparty/DiffGaussianRasterization.py:17 (pinned upstream commit 59f5f77e, :9) and drives from
+src/Methods/GaussianSplatting/Renderer.py:60-81,94-153,163-183:
+
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix,
+                                  sh_degree, campos, prefiltered, debug)
+    GaussianRasterizer(raster_settings)(means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                                        rotations=None, cov3D_precomp=None) -> (color (3,H,W) f32, radii (P,) i32)
+    GaussianRasterizer.markVisible(positions) -> bool mask
+
+Gradients flow to every provided input and to `means2D` (the screen-space gradient that densification reads,
+src/Methods/GaussianSplatting/Model.py:258).  Backed by libnerficg_hip.so (nrc_gs_*); no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import NamedTuple
+
+import torch
+
+from .. import _lib
+
+__all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'rasterize_gaussians']
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _host_f32(t: torch.Tensor, n: int):
+    v = t.detach().to(dtype=torch.float32).reshape(-1).cpu()
+    if v.numel() != n:
+        raise RuntimeError(f'expected {n} values, got {v.numel()}')
+    return (ctypes.c_float * n)(*v.tolist())
+
+
+def _p(arr):
+    return ctypes.cast(arr, ctypes.c_void_p)
+
+
+def _opt(t):
+    """Absent optional inputs arrive as torch.Tensor([]) (1-D, empty), like in the upstream package; a provided tensor of an
+    empty scene has more dimensions."""
+    return None if t is None or (t.dim() <= 1 and t.numel() == 0) else t
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        lib = _lib.load()
+        dev = means3D.device
+        f32 = torch.float32
+        prep = lambda t: None if _opt(t) is None else t.detach().to(f32).contiguous()
+        means3D_c, sh_c, col_c, op_c = prep(means3D), prep(sh), prep(colors_precomp), prep(opacities)
+        sc_c, rot_c, cov_c = prep(scales), prep(rotations), prep(cov3Ds_precomp)
+        if not means3D.is_cuda:
+            raise RuntimeError('means3D must be a CUDA tensor')
+        P = means3D_c.shape[0]
+        W, H = int(rs.image_width), int(rs.image_height)
+        D = int(rs.sh_degree)
+        M = 0 if sh_c is None else int(sh_c.shape[1])
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        nt = gx * gy
+        # the four small camera tensors cross to the host in ONE copy
+        packed = torch.cat([rs.viewmatrix.reshape(-1).float(), rs.projmatrix.reshape(-1).float(), rs.campos.reshape(-1).float(),
+                            rs.bg.reshape(-1).float().to(rs.viewmatrix.device)]).cpu()
+        vm, pm = (ctypes.c_float * 16)(*packed[:16].tolist()), (ctypes.c_float * 16)(*packed[16:32].tolist())
+        cp, bg = (ctypes.c_float * 3)(*packed[32:35].tolist()), (ctypes.c_float * 3)(*packed[35:38].tolist())
+        i32, u8 = torch.int32, torch.uint8
+        n1 = max(P, 1)
+        radii = torch.empty(n1, dtype=i32, device=dev)
+        depths = torch.empty(n1, dtype=f32, device=dev)
+        points_xy = torch.empty(n1, 2, dtype=f32, device=dev)
+        conic_opacity = torch.empty(n1, 4, dtype=f32, device=dev)
+        rgb = torch.empty(n1, 3, dtype=f32, device=dev)
+        clamped = torch.empty(n1, dtype=u8, device=dev)
+        cov3D = torch.empty(n1, 6, dtype=f32, device=dev)
+        tiles_touched = torch.empty(n1, dtype=i32, device=dev)
+        tile_counts = torch.empty(nt, dtype=i32, device=dev)
+        tile_fill = torch.empty(nt, dtype=i32, device=dev)
+        ranges = torch.empty(nt, 2, dtype=i32, device=dev)
+        num_rendered = torch.empty(1, dtype=torch.int64, device=dev)
+        st = _lib.stream_of(radii)
+        _lib.check(lib.nrc_gs_preprocess(
+            P, D, M, W, H, _lib.ptr(means3D_c), _lib.ptr(sh_c), _lib.ptr(col_c), _lib.ptr(op_c), _lib.ptr(sc_c), float(rs.scale_modifier),
+            _lib.ptr(rot_c), _lib.ptr(cov_c), _p(vm), _p(pm), _p(cp), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(depths),
+            _lib.ptr(points_xy), _lib.ptr(conic_opacity), _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(tiles_touched),
+            _lib.ptr(tile_counts), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(num_rendered), st), 'gs_preprocess')
+        n_inst = int(num_rendered.item())
+        keys = torch.empty(max(n_inst, 1), dtype=torch.int64, device=dev)
+        point_list = torch.empty(max(n_inst, 1), dtype=i32, device=dev)
+        color = torch.empty(3, H, W, dtype=f32, device=dev)
+        n_contrib = torch.empty(H * W, dtype=i32, device=dev)
+        final_T = torch.empty(H * W, dtype=f32, device=dev)
+        _lib.check(lib.nrc_gs_bin_render(P, W, H, _p(bg), _lib.ptr(radii), _lib.ptr(depths), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
+                                         _lib.ptr(rgb), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(keys), _lib.ptr(point_list),
+                                         _lib.ptr(color), _lib.ptr(n_contrib), _lib.ptr(final_T), st), 'gs_bin_render')
+        ctx.raster_settings = rs
+        ctx.host = (vm, pm, cp, bg)
+        ctx.dims = (P, D, M, W, H)
+        ctx.num_rendered = n_inst
+        ctx.has = (sh_c is not None, col_c is not None, sc_c is not None, cov_c is not None)
+        ctx.opacity_shape = tuple(opacities.shape)
+        ctx.save_for_backward(means3D_c, sh_c if sh_c is not None else torch.empty(0), col_c if col_c is not None else torch.empty(0),
+                              sc_c if sc_c is not None else torch.empty(0), rot_c if rot_c is not None else torch.empty(0),
+                              cov_c if cov_c is not None else torch.empty(0), radii, points_xy, conic_opacity, rgb, clamped, cov3D,
+                              point_list, ranges, n_contrib, final_T)
+        ctx.debug_state = dict(depths=depths, tiles_touched=tiles_touched, keys=keys)
+        radii_out = radii[:P]
+        ctx.mark_non_differentiable(radii_out)
+        return color, radii_out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out_color, _grad_radii):
+        (means3D, sh, col, sc, rot, cov, radii, points_xy, conic_opacity, rgb, clamped, cov3D, point_list, ranges, n_contrib,
+         final_T) = ctx.saved_tensors
+        has_sh, has_col, has_sr, has_cov = ctx.has
+        P, D, M, W, H = ctx.dims
+        rs = ctx.raster_settings
+        vm, pm, cp, bg = ctx.host
+        lib = _lib.load()
+        dev = means3D.device
+        f32 = torch.float32
+        g = grad_out_color.to(f32).contiguous()
+        n1 = max(P, 1)
+        dmean2D = torch.empty(n1, 3, dtype=f32, device=dev)
+        dconic = torch.empty(n1, 4, dtype=f32, device=dev)
+        dopacity = torch.empty(n1, dtype=f32, device=dev)
+        dcolor = torch.empty(n1, 3, dtype=f32, device=dev)
+        dmean3D = torch.empty(n1, 3, dtype=f32, device=dev)
+        dcov3D = torch.empty(n1, 6, dtype=f32, device=dev)
+        dsh = torch.empty(n1, max(M, 1), 3, dtype=f32, device=dev) if has_sh else None
+        dscale = torch.empty(n1, 3, dtype=f32, device=dev) if has_sr else None
+        drot = torch.empty(n1, 4, dtype=f32, device=dev) if has_sr else None
+        _lib.check(lib.nrc_gs_backward(
+            P, D, M, W, H, _p(bg), _lib.ptr(means3D), _lib.ptr(sh if has_sh else None), _lib.ptr(col if has_col else None),
+            _lib.ptr(sc if has_sr else None), float(rs.scale_modifier), _lib.ptr(rot if has_sr else None), _lib.ptr(cov if has_cov else None),
+            _p(vm), _p(pm), _p(cp), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
+            _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(point_list), _lib.ptr(ranges), _lib.ptr(n_contrib), _lib.ptr(final_T),
+            _lib.ptr(g), _lib.ptr(dmean2D), _lib.ptr(dconic), _lib.ptr(dopacity), _lib.ptr(dcolor), _lib.ptr(dmean3D), _lib.ptr(dcov3D),
+            _lib.ptr(dsh), _lib.ptr(dscale), _lib.ptr(drot), _lib.stream_of(g)), 'gs_backward')
+        return (dmean3D[:P], dmean2D[:P], dsh[:P] if has_sh else None, dcolor[:P] if has_col else None,
+                dopacity[:P].reshape(ctx.opacity_shape), dscale[:P] if has_sr else None, drot[:P] if has_sr else None,
+                dcov3D[:P] if has_cov else None, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(torch.nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings) -> None:
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Frustum test of the upstream rasterizer: view-space z > 0.2."""
+        with torch.no_grad():
+            vm = self.raster_settings.viewmatrix.to(positions.device, torch.float32)  # (4,4) = w2c.T
+            z = positions.float() @ vm[:3, 2] + vm[3, 2]
+            return z > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        return rasterize_gaussians(means3D, means2D, empty if shs is None else shs, empty if colors_precomp is None else colors_precomp, opacities,
+                                   empty if scales is None else scales, empty if rotations is None else rotations,
+                                   empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings)
