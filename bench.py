@@ -36,7 +36,6 @@ CHUNK_ROWS = 32768             # rows (x64 sample slots) per encode/MLP round of
 # reads + 4 B sample record (t) + 64 B of encoded features written (fp16 x 32)
 ENC_BYTES_PER_SAMPLE = 512 + 4 + 64
 DOMINANT_KERNEL = 'k_grid_encode<SRC_TILED>'
-XX
 
 
 def build_scene(device):
@@ -82,6 +81,63 @@ def time_dominant_kernel(renderer, cam, pose, reps=20):
     torch.cuda.synchronize()
     ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
     return ms, rows * 64, live
+
+
+# ------------------------------------------------------------------------------------------------ 3DGS leg (secondary metric)
+GS_W, GS_H = 1297, 840  # gs_garden.yaml: IMAGE_SCALE_FACTOR 0.25 of Mip-NeRF360 garden
+
+
+def build_gs_scene(device, n=1_000_000, seed=0):
+    """1 M synthetic Gaussians (positions U([-1.5,1.5]^3) + ground-plane cluster, log-scales N(log 0.01, 0.5^2), unit
+    quaternions, opacity logits N(0, 2^2), SH degree 3), 1297x840 camera, black background."""
+    import torch
+    from nerficg_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from tests import scenes
+    sc = scenes.gs_random_scene(n, seed=seed)
+    cam = scenes.gs_camera(GS_W, GS_H, scenes.orbit_pose(0.8, 0.35, 4.5))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    settings = GaussianRasterizationSettings(
+        image_height=GS_H, image_width=GS_W, tanfovx=cam['tanfovx'], tanfovy=cam['tanfovy'], bg=torch.zeros(3, device=device), scale_modifier=1.0,
+        viewmatrix=T(cam['viewmatrix']), projmatrix=T(cam['projmatrix']), sh_degree=3, campos=T(cam['campos']), prefiltered=False, debug=False)
+    t = {k: T(v) for k, v in sc.items() if k != 'sh_degree'}
+    t['opacities'] = t['opacities'][:, None].contiguous()
+    return dict(rast=GaussianRasterizer(settings), tensors=t, n=n, scene=sc, cam=cam)
+
+
+def time_gs(gs, reps=5):
+    import torch
+    t = gs['tensors']
+    rast = gs['rast']
+    n = gs['n']
+
+    def fwd(grad):
+        args = {k: (v.detach().requires_grad_(grad)) for k, v in t.items()}
+        m2d = torch.zeros_like(args['means3D'], requires_grad=grad)
+        color, radii = rast(means3D=args['means3D'], means2D=m2d, opacities=args['opacities'], shs=args['shs'], scales=args['scales'],
+                            rotations=args['rotations'])
+        return color, radii
+
+    color, radii = fwd(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        color, radii = fwd(False)
+    torch.cuda.synchronize()
+    t_fwd = (time.perf_counter() - t0) / reps
+    g = torch.rand_like(color)
+    color, radii = fwd(True)
+    color.backward(g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        color, radii = fwd(True)
+        color.backward(g)
+    torch.cuda.synchronize()
+    t_fb = (time.perf_counter() - t0) / reps
+    n_inst = color.grad_fn.num_rendered if color.grad_fn is not None else -1
+    return {'msplats_per_s_fwd': round(n / t_fwd / 1e6, 2), 'msplats_per_s_fwd_bwd': round(n / t_fb / 1e6, 2), 'ms_fwd': round(t_fwd * 1e3, 3),
+            'ms_fwd_bwd': round(t_fb * 1e3, 3), 'gaussians': n, 'visible': int((radii > 0).sum().item()), 'instances': int(n_inst),
+            'image': f'{GS_W}x{GS_H}'}
 
 
 def cpu_baseline(cam_full, pose, model_params, crop=96):

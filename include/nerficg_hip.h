@@ -208,16 +208,19 @@ int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32
  *   nrc_gs_backward   : dL_dpix (3,H,W) -> every gradient (all fully written; dL_dmean2D (P,3) is the screen-space gradient
  *                       consumed by densification, src/Methods/GaussianSplatting/Model.py:258).
  * ===================================================================================================== */
+/* bytes of the per-workgroup tile-histogram matrix `bin_hist` used by the LDS binning path (0 = image too large, pass NULL) */
+int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H);
 int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs,
                       const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                       const float* campos, float tan_fovx, float tan_fovy, int32_t* radii, float* depths, float* points_xy,
                       float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched,
-                      uint32_t* tile_counts, uint32_t* ranges, uint32_t* tile_fill, int64_t* num_rendered, nrc_stream_t stream);
+                      uint32_t* tile_counts, uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t* num_rendered,
+                      nrc_stream_t stream);
 int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg, const int32_t* radii, const float* depths,
                       const float* points_xy, const float* conic_opacity, const float* rgb, const uint32_t* ranges,
-                      uint32_t* tile_fill, uint64_t* keys, int32_t* point_list, float* out_color, uint32_t* n_contrib,
-                      float* final_T, nrc_stream_t stream);
+                      uint32_t* tile_fill, const uint32_t* bin_hist, uint64_t* keys, int32_t* point_list, float* out_color,
+                      uint32_t* n_contrib, float* final_T, nrc_stream_t stream);
 int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg, const float* means3D, const float* shs,
                     const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,

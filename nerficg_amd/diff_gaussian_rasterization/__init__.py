@@ -92,12 +92,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         tile_fill = torch.empty(nt, dtype=i32, device=dev)
         ranges = torch.empty(nt, 2, dtype=i32, device=dev)
         num_rendered = torch.empty(1, dtype=torch.int64, device=dev)
+        hist_bytes = int(lib.nrc_gs_bin_hist_bytes(P, W, H))
+        bin_hist = torch.empty(hist_bytes // 4, dtype=i32, device=dev) if hist_bytes > 0 else None
         st = _lib.stream_of(radii)
         _lib.check(lib.nrc_gs_preprocess(
             P, D, M, W, H, _lib.ptr(means3D_c), _lib.ptr(sh_c), _lib.ptr(col_c), _lib.ptr(op_c), _lib.ptr(sc_c), float(rs.scale_modifier),
             _lib.ptr(rot_c), _lib.ptr(cov_c), _p(vm), _p(pm), _p(cp), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(depths),
             _lib.ptr(points_xy), _lib.ptr(conic_opacity), _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(tiles_touched),
-            _lib.ptr(tile_counts), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(num_rendered), st), 'gs_preprocess')
+            _lib.ptr(tile_counts), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(bin_hist), _lib.ptr(num_rendered), st), 'gs_preprocess')
         n_inst = int(num_rendered.item())
         keys = torch.empty(max(n_inst, 1), dtype=torch.int64, device=dev)
         point_list = torch.empty(max(n_inst, 1), dtype=i32, device=dev)
@@ -105,7 +107,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         n_contrib = torch.empty(H * W, dtype=i32, device=dev)
         final_T = torch.empty(H * W, dtype=f32, device=dev)
         _lib.check(lib.nrc_gs_bin_render(P, W, H, _p(bg), _lib.ptr(radii), _lib.ptr(depths), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
-                                         _lib.ptr(rgb), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(keys), _lib.ptr(point_list),
+                                         _lib.ptr(rgb), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(bin_hist), _lib.ptr(keys), _lib.ptr(point_list),
                                          _lib.ptr(color), _lib.ptr(n_contrib), _lib.ptr(final_T), st), 'gs_bin_render')
         ctx.raster_settings = rs
         ctx.host = (vm, pm, cp, bg)
