@@ -104,8 +104,10 @@ def build_gs_scene(device, n=1_000_000, seed=0):
     return dict(rast=GaussianRasterizer(settings), tensors=t, n=n, scene=sc, cam=cam)
 
 
-def time_gs(gs, reps=5):
+def time_gs(gs, reps=5, barrier=None):
     import torch
+    if barrier is None:
+        barrier = torch.cuda.synchronize
     t = gs['tensors']
     rast = gs['rast']
     n = gs['n']
@@ -118,26 +120,45 @@ def time_gs(gs, reps=5):
         return color, radii
 
     color, radii = fwd(False)
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
         color, radii = fwd(False)
-    torch.cuda.synchronize()
+    barrier()
     t_fwd = (time.perf_counter() - t0) / reps
     g = torch.rand_like(color)
     color, radii = fwd(True)
     color.backward(g)
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
         color, radii = fwd(True)
         color.backward(g)
-    torch.cuda.synchronize()
+    barrier()
     t_fb = (time.perf_counter() - t0) / reps
     n_inst = color.grad_fn.num_rendered if color.grad_fn is not None else -1
     return {'msplats_per_s_fwd': round(n / t_fwd / 1e6, 2), 'msplats_per_s_fwd_bwd': round(n / t_fb / 1e6, 2), 'ms_fwd': round(t_fwd * 1e3, 3),
             'ms_fwd_bwd': round(t_fb * 1e3, 3), 'gaussians': n, 'visible': int((radii > 0).sum().item()), 'instances': int(n_inst),
             'image': f'{GS_W}x{GS_H}'}
+
+
+def gs_cpu_baseline(n=250000, w=648, h=420):
+    """CPU oracle (kind "port": the reference refuses CPU mode for GaussianSplatting, Renderer.py:32-33) on a bounded sample of the
+    same synthetic distribution: n Gaussians on a 1/2-scale image, single thread (the oracle rasterizer is scalar C)."""
+    import oracle
+    from tests import scenes
+    sc = scenes.gs_random_scene(n, seed=0)
+    cam = scenes.gs_camera(w, h, scenes.orbit_pose(0.8, 0.35, 4.5))
+    t0 = time.perf_counter()
+    col, radii, st = oracle.gs_forward(sc['means3D'], sc['opacities'], cam['viewmatrix'], cam['projmatrix'], cam['campos'], cam['tanfovx'], cam['tanfovy'],
+                                       w, h, np.zeros(3, np.float32), sh_degree=3, shs=sc['shs'], scales=sc['scales'], rotations=sc['rotations'])
+    t_f = time.perf_counter() - t0
+    g = np.ones((3, h, w), np.float32)
+    t0 = time.perf_counter()
+    oracle.gs_backward(st, g)
+    t_b = time.perf_counter() - t0
+    return {'value': round(n / t_f / 1e6, 5), 'value_fwd_bwd': round(n / (t_f + t_b) / 1e6, 5), 'unit': 'Msplats/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n} Gaussians, {w}x{h} image, {st.num_rendered} instances, oracle/gs_oracle.c scalar, fwd {t_f:.2f} s + bwd {t_b:.2f} s'}
 
 
 def cpu_baseline(cam_full, pose, model_params, crop=96):
@@ -171,6 +192,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-gs', action='store_true', help='skip the secondary 3DGS leg')
+    ap.add_argument('--gs-gaussians', type=int, default=1_000_000)
     args = ap.parse_args()
 
     import torch
@@ -213,6 +236,20 @@ def main():
         dist.all_reduce(s)
         samples = int(s.item())
 
+    # ---- secondary metric: 3DGS rasterizer forward / forward+backward on the 1 M-Gaussian synthetic scene (every rank its own copy)
+    gs_res = None
+    if not args.no_gs:
+        gs = build_gs_scene(device, args.gs_gaussians)
+        gs_res = time_gs(gs, reps=max(3, args.steps // 2), barrier=barrier)
+        if world > 1:
+            t = torch.tensor([gs_res['ms_fwd'], gs_res['ms_fwd_bwd']], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gs_res['ms_fwd'], gs_res['ms_fwd_bwd'] = float(t[0]), float(t[1])
+        n_g = gs_res['gaussians'] * world
+        gs_res['msplats_per_s_fwd'] = round(n_g / gs_res['ms_fwd'] / 1e3, 2)
+        gs_res['msplats_per_s_fwd_bwd'] = round(n_g / gs_res['ms_fwd_bwd'] / 1e3, 2)
+        del gs
+
     if rank == 0:
         rays = W * H * args.steps * world
         value = rays / elapsed / 1e6
@@ -240,7 +277,23 @@ def main():
                          'note': 'table (24.4 MB) is L2/Infinity-Cache resident: the kernel is bound by the L1 texture-cache access rate, '
                                  'not by HBM; achieved = algorithmic bytes / kernel time'},
         }
+        if gs_res is not None:
+            # bytes_fwd = 308 P_vis + 148 D + 20 H W ; bytes_bwd ~ 76 D + 472 P_vis + 20 H W
+            b_fwd = 308 * gs_res['visible'] + 148 * gs_res['instances'] + 20 * GS_W * GS_H
+            b_bwd = 76 * gs_res['instances'] + 472 * gs_res['visible'] + 20 * GS_W * GS_H
+            result['secondary'] = {
+                'metric': 'Msplats/s (3DGS, 1 M synthetic Gaussians, 1297x840)', 'value_fwd': gs_res['msplats_per_s_fwd'],
+                'value_fwd_bwd': gs_res['msplats_per_s_fwd_bwd'], 'unit': 'Msplats/s', 'ms_fwd': gs_res['ms_fwd'], 'ms_fwd_bwd': gs_res['ms_fwd_bwd'],
+                'gaussians_per_gpu': gs_res['gaussians'], 'visible': gs_res['visible'], 'instances': gs_res['instances'], 'dtype': 'f32',
+                'roofline': {'bound': 'hbm', 'scope': 'whole forward / forward+backward (all rasterizer kernels)',
+                             'achieved_fwd': round(b_fwd / (gs_res['ms_fwd'] * 1e-3) / 1e9, 2),
+                             'achieved_fwd_bwd': round((b_fwd + b_bwd) / (gs_res['ms_fwd_bwd'] * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac_fwd': round(b_fwd / (gs_res['ms_fwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             'frac_fwd_bwd': round((b_fwd + b_bwd) / (gs_res['ms_fwd_bwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             'algorithmic_bytes_fwd': b_fwd, 'algorithmic_bytes_bwd': b_bwd}}
         if not args.no_cpu_baseline:
+            if gs_res is not None:
+                result['secondary']['cpu_baseline'] = gs_cpu_baseline()
             pd = model.encoding_xyz.params.detach().half().float().cpu().numpy()
             pc = model.color_mlp_with_encoding.params.detach().half().float().cpu().numpy()
             result['cpu_baseline'] = cpu_baseline(cam, poses[0], (pd, pc, model.occupancy_bitfield.cpu().numpy()))

@@ -53,6 +53,10 @@ def _ctype(type_str: str):
 
 @lru_cache(maxsize=1)
 def load() -> ctypes.CDLL:
+    # torch ships its own libamdhip64: it must be in the process BEFORE our library is loaded so that both resolve to ONE HIP
+    # runtime (loading ours first pulls /opt/rocm's copy and the kernels then launch on a runtime that has no device context:
+    # "no ROCm-capable device is detected")
+    import torch  # noqa: F401
     if not LIB_PATH.exists():
         raise NativeLibraryError(
             f'{LIB_PATH} is missing: build the HIP extension first (python -m nerficg_amd.build). '
