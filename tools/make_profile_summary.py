@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""tools/make_profile_summary.py -- turns gpurun_out/profiles_raw (tools/collect_profiles.sh) into the committed summaries:
+profiles/r01_bench_kernel_stats.csv, profiles/r01_pmc_summary.md, profiles/pmc_summary.json (read by bench.py for roofline.traffic)."""
+import collections, csv, glob, json, re, shutil, sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+RAW = ROOT / 'gpurun_out' / 'profiles_raw'
+OUT = ROOT / 'profiles'
+OUT.mkdir(exist_ok=True)
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name).replace('void ', '')
+    return name.split('(')[0]
+
+
+stats = sorted(glob.glob(str(RAW / 'bench_stats' / '*' / '*kernel_stats.csv')))
+if stats:
+    shutil.copy(stats[0], OUT / 'r01_bench_kernel_stats.csv')
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(str(RAW / 'pmc*' / '*' / '*counter_collection.csv')):
+    for r in csv.DictReader(open(f)):
+        acc[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+keep = ('k_grid_encode', 'k_ngp_mlp', 'k_render', 'k_composite_image', 'k_preprocess', 'k_scatter', 'k_sort_tiles', 'k_tile_', 'k_scan_tiles')
+lines = ['# rocprofv3 --pmc summary (MI355X, round 1)', '',
+         'Collected by `tools/collect_profiles.sh` (one `--pmc` group per run, `--kernel-trace` only), averaged per kernel over all launches of',
+         '`tools/bench_query.py` (InstantNGP 800x800 image pipeline) and `tools/bench_gs.py` (3DGS, 1 M Gaussians, 1297x840).',
+         'FETCH_SIZE / WRITE_SIZE are in KiB as reported; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950',
+         '(other widths uncalibrated) -- both the raw value and the 2x-corrected read bytes are listed.', '']
+summary = {}
+for k in sorted(acc):
+    if not any(k.startswith(p) for p in keep):
+        continue
+    c = {n: sum(v) / len(v) for n, v in acc[k].items()}
+    lines.append(f'## {k}')
+    lines.append('')
+    lines.append('| counter | mean per launch | launches |')
+    lines.append('|---|---|---|')
+    for n in sorted(c):
+        lines.append(f'| {n} | {c[n]:.1f} | {len(acc[k][n])} |')
+    fetch, write = c.get('FETCH_SIZE'), c.get('WRITE_SIZE')
+    derived = {}
+    if fetch is not None and write is not None:
+        derived['hbm_bytes_per_launch_raw'] = int((fetch + write) * 1024)
+        derived['hbm_bytes_per_launch'] = int((2 * fetch + write) * 1024)
+    if 'TCP_TOTAL_CACHE_ACCESSES_sum' in c and 'GRBM_GUI_ACTIVE' in c:
+        cyc = c['GRBM_GUI_ACTIVE'] / 8.0  # sum over 8 XCDs
+        derived['kernel_cycles'] = int(cyc)
+        derived['tcp_accesses_per_clk_per_cu'] = round(c['TCP_TOTAL_CACHE_ACCESSES_sum'] / 256.0 / cyc, 3)
+        if 'TCP_TCC_READ_REQ_sum' in c:
+            derived['l1_hit_rate'] = round(1 - c['TCP_TCC_READ_REQ_sum'] / c['TCP_TOTAL_CACHE_ACCESSES_sum'], 3)
+    if 'TCC_HIT_sum' in c and 'TCC_MISS_sum' in c and c['TCC_HIT_sum'] + c['TCC_MISS_sum'] > 0:
+        derived['l2_hit_rate'] = round(c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']), 3)
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'SQ_BUSY_CYCLES' in c and c['SQ_BUSY_CYCLES'] > 0:
+        derived['mfma_busy_over_sq_busy'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_BUSY_CYCLES'], 3)
+    if derived:
+        lines.append('')
+        lines.append('derived: ' + ', '.join(f'{a} = {b}' for a, b in derived.items()))
+    lines.append('')
+    key = k.replace('<1>', '<SRC_TILED>').replace('<0>', '<SRC_ARRAYS>')
+    summary[key] = {**{n: round(v, 1) for n, v in c.items()}, **derived}
+(OUT / 'r01_pmc_summary.md').write_text('\n'.join(lines))
+(OUT / 'pmc_summary.json').write_text(json.dumps(summary, indent=1, sort_keys=True))
+print('\n'.join(lines[:8]))
+for k, v in summary.items():
+    print(k, {a: v[a] for a in ('hbm_bytes_per_launch', 'tcp_accesses_per_clk_per_cu', 'l1_hit_rate', 'l2_hit_rate', 'mfma_busy_over_sq_busy') if a in v})
