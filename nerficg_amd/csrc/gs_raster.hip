@@ -215,15 +215,119 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, GsCam cam, const floa
 // (ds atomics), pass 2 (after a column scan over the NB x n_tiles matrix) turns the histogram into LDS cursors and scatters
 // the slice's instances: every instance costs two LDS atomics and one 8-byte store, no global atomic at all (the first
 // version spent 2.4 ms of a 4 ms forward on 16.7 M atomics onto 4 346 addresses, profiles/r01_gs_*).
+// ---- depth pre-sort of the P Gaussians (LSD radix, 4 x 8 bits, stable: equal depths keep ascending index) ---------------
+// Sorting the P Gaussians once by depth (8 B x P x 4 passes) replaces sorting the D >> P instances per tile: when the slices of
+// the binning passes below are taken from the depth-ordered list, every tile's segment arrives as a concatenation of
+// depth-ordered sub-segments (one per slice), and only those tiny sub-segments have to be sorted.
+#define RS_ITEMS 16                  // keys per thread per block
+#define RS_TILE (256 * RS_ITEMS)     // keys per block
+__global__ void __launch_bounds__(256) k_depth_keys(int P, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    keys[i] = radii[i] > 0 ? __float_as_uint(depths[i]) : 0xffffffffu;  // invisible Gaussians go last
+    vals[i] = (uint32_t)i;
+}
+__global__ void __launch_bounds__(256) k_radix_count(int n, int shift, int nblk, const uint32_t* __restrict__ keys, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const int i = base + r * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    counts[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];  // digit-major: the scan order of a stable LSD pass
+}
+__global__ void __launch_bounds__(1024) k_scan_u32(uint32_t* __restrict__ a, int n) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 4096) {
+        const int i = base + 4 * threadIdx.x;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i + k) < n ? a[i + k] : 0u;
+        const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = tsum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (int w = 0; w < wave; w++) off += wave_tot[w];
+        uint32_t run = off + incl - tsum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((i + k) < n) a[i + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + incl;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_radix_scatter(int n, int shift, int nblk, const uint32_t* __restrict__ keys_in,
+                                                       const uint32_t* __restrict__ vals_in, const uint32_t* __restrict__ offsets,
+                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t base_s[256];
+    __shared__ uint32_t whist[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    base_s[threadIdx.x] = offsets[(size_t)threadIdx.x * nblk + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; w++) whist[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE;
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const int i = base + r * 256 + threadIdx.x;
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys_in[i] : 0u, val = valid ? vals_in[i] : 0u;
+        const uint32_t d = (key >> shift) & 255u;
+        // lanes of this wave holding the same digit (8 ballots), rank among them in lane order = stable
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t rank_w = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank_w == 0) whist[wave][d] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t off = base_s[d];
+            for (int w = 0; w < wave; w++) off += whist[w][d];
+            keys_out[off + rank_w] = key;
+            vals_out[off + rank_w] = val;
+        }
+        __syncthreads();
+        {
+            uint32_t t = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) { t += whist[w][threadIdx.x]; whist[w][threadIdx.x] = 0; }
+            base_s[threadIdx.x] += t;
+        }
+        __syncthreads();
+    }
+}
+
 #define GS_MAX_LDS_TILES 16384
-__global__ void __launch_bounds__(256) k_tile_hist(int P, int chunk, int gx, int gy, const int32_t* __restrict__ radii,
-                                                   const float* __restrict__ points_xy, uint32_t* __restrict__ hist) {
+__global__ void __launch_bounds__(256) k_tile_hist(int P, int chunk, int gx, int gy, const uint32_t* __restrict__ order,
+                                                   const int32_t* __restrict__ radii, const float* __restrict__ points_xy,
+                                                   uint32_t* __restrict__ hist) {
     extern __shared__ uint32_t lh[];
     const int n_tiles = gx * gy;
     for (int t = threadIdx.x; t < n_tiles; t += 256) lh[t] = 0u;
     __syncthreads();
     const int begin = blockIdx.x * chunk, end = min(P, begin + chunk);
-    for (int i = begin + threadIdx.x; i < end; i += 256) {
+    for (int j = begin + threadIdx.x; j < end; j += 256) {
+        const int i = (int)order[j];  // depth order
         const int r = radii[i];
         if (r <= 0) continue;
         const float pxy[2] = {points_xy[2 * i], points_xy[2 * i + 1]};
@@ -236,33 +340,54 @@ __global__ void __launch_bounds__(256) k_tile_hist(int P, int chunk, int gx, int
     uint32_t* out = hist + (size_t)blockIdx.x * n_tiles;
     for (int t = threadIdx.x; t < n_tiles; t += 256) out[t] = lh[t];
 }
+// column sums / column exclusive scans of the NB x n_tiles histogram matrix: 64 tiles x 4 slice groups per workgroup
 __global__ void __launch_bounds__(256) k_tile_totals(int nb, int n_tiles, const uint32_t* __restrict__ hist, uint32_t* __restrict__ counts) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_tiles) return;
+    __shared__ uint32_t part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tx;
+    const int per = (nb + 3) / 4, b0 = ty * per, b1 = min(nb, b0 + per);
     uint32_t s = 0;
-    for (int b = 0; b < nb; b++) s += hist[(size_t)b * n_tiles + t];
-    counts[t] = s;
+    if (t < n_tiles) {
+#pragma unroll 8
+        for (int b = b0; b < b1; b++) s += hist[(size_t)b * n_tiles + t];
+    }
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && t < n_tiles) counts[t] = part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
 }
 __global__ void __launch_bounds__(256) k_tile_bases(int nb, int n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ hist) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint32_t part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tx;
+    const int per = (nb + 3) / 4, b0 = ty * per, b1 = min(nb, b0 + per);
+    uint32_t s = 0;
+    if (t < n_tiles) {
+#pragma unroll 8
+        for (int b = b0; b < b1; b++) s += hist[(size_t)b * n_tiles + t];
+    }
+    part[ty][tx] = s;
+    __syncthreads();
     if (t >= n_tiles) return;
     uint32_t run = ranges[2 * t];
-    for (int b = 0; b < nb; b++) {
+    for (int g = 0; g < ty; g++) run += part[g][tx];
+    for (int b = b0; b < b1; b++) {
         const uint32_t c = hist[(size_t)b * n_tiles + t];
         hist[(size_t)b * n_tiles + t] = run;
         run += c;
     }
 }
-__global__ void __launch_bounds__(256) k_scatter_lds(int P, int chunk, int gx, int gy, const int32_t* __restrict__ radii,
-                                                     const float* __restrict__ depths, const float* __restrict__ points_xy,
-                                                     const uint32_t* __restrict__ bases, uint64_t* __restrict__ keys) {
+__global__ void __launch_bounds__(256) k_scatter_lds(int P, int chunk, int gx, int gy, const uint32_t* __restrict__ order,
+                                                     const int32_t* __restrict__ radii, const float* __restrict__ depths,
+                                                     const float* __restrict__ points_xy, const uint32_t* __restrict__ bases,
+                                                     uint64_t* __restrict__ keys) {
     extern __shared__ uint32_t cur[];
     const int n_tiles = gx * gy;
     const uint32_t* in = bases + (size_t)blockIdx.x * n_tiles;
     for (int t = threadIdx.x; t < n_tiles; t += 256) cur[t] = in[t];
     __syncthreads();
     const int begin = blockIdx.x * chunk, end = min(P, begin + chunk);
-    for (int i = begin + threadIdx.x; i < end; i += 256) {
+    for (int j = begin + threadIdx.x; j < end; j += 256) {
+        const int i = (int)order[j];
         const int r = radii[i];
         if (r <= 0) continue;
         const float pxy[2] = {points_xy[2 * i], points_xy[2 * i + 1]};
@@ -347,6 +472,77 @@ __device__ __forceinline__ void bitonic_sort_any(uint64_t* a, int n) {
         }
     }
 }
+// Per-tile finishing sort for the depth-presorted path: the tile's list is the concatenation of NB sub-segments (one per
+// binning slice, boundaries = the cursor bases), already ordered relative to each other and a few elements long each.  The
+// workgroup walks the list in LDS-sized windows aligned to sub-segment boundaries and runs a SEGMENTED odd-even transposition
+// sort on the window: uniform control flow (no per-lane sorting loops), max-sub-segment-length phases of one compare-exchange
+// per pair that does not straddle a boundary.  Sub-segments longer than SEG_LONG get the bitonic network first (rare).
+#define SEG_WIN 4096
+#define SEG_MAX_NB 1024
+#define SEG_LONG 64
+__global__ void __launch_bounds__(256) k_sort_segments(int nb, int n_tiles, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ bases,
+                                                       uint64_t* __restrict__ keys, int32_t* __restrict__ point_list) {
+    __shared__ uint64_t win[SEG_WIN];
+    __shared__ uint32_t seg[SEG_MAX_NB + 1];
+    __shared__ uint8_t starts[SEG_WIN + 1];
+    __shared__ int s_end_sh, maxlen_sh;
+    const int t = blockIdx.x;
+    const uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
+    if (r1 == r0) return;
+    // the histogram matrix still holds the START of every sub-segment (b, t) (the scatter consumed a copy as its cursors)
+    for (int b = threadIdx.x; b < nb; b += 256) seg[b] = bases[(size_t)b * n_tiles + t];
+    if (threadIdx.x == 0) seg[nb] = r1;
+    __syncthreads();
+    int s0 = 0;
+    while (s0 < nb) {
+        const uint32_t w0 = seg[s0];
+        if (w0 >= r1) break;
+        if (threadIdx.x == 0) { s_end_sh = s0; maxlen_sh = 0; }
+        __syncthreads();
+        for (int b = s0 + threadIdx.x; b < nb; b += 256)
+            if (seg[b + 1] - w0 <= SEG_WIN) atomicMax(&s_end_sh, b + 1);  // last sub-segment that still fits the window
+        __syncthreads();
+        const int s1 = s_end_sh;
+        if (s1 == s0) {  // one sub-segment larger than the window: bitonic network in global memory
+            const uint32_t a = seg[s0], e = seg[s0 + 1];
+            bitonic_sort_any(keys + a, (int)(e - a));
+            for (uint32_t i = a + threadIdx.x; i < e; i += 256) point_list[i] = (int32_t)(uint32_t)keys[i];
+            __syncthreads();
+            s0 = s0 + 1;
+            continue;
+        }
+        const uint32_t w1 = seg[s1];
+        const int n = (int)(w1 - w0);
+        for (int i = threadIdx.x; i < n; i += 256) { win[i] = keys[w0 + i]; starts[i] = 0; }
+        __syncthreads();
+        for (int b = s0 + threadIdx.x; b < s1; b += 256) {
+            const int len = (int)(seg[b + 1] - seg[b]);
+            if (len > 0) { starts[seg[b] - w0] = 1; atomicMax(&maxlen_sh, len); }
+        }
+        __syncthreads();
+        int phases = maxlen_sh;
+        if (phases > SEG_LONG) {
+            for (int b = s0; b < s1; b++) {
+                const int len = (int)(seg[b + 1] - seg[b]);
+                if (len > SEG_LONG) bitonic_sort_any(win + (seg[b] - w0), len);  // uniform branch: seg[] is shared
+            }
+            phases = SEG_LONG;
+        }
+        for (int ph = 0; ph < phases; ph++) {
+            for (int i = 2 * threadIdx.x + (ph & 1); i + 1 < n; i += 512) {
+                if (!starts[i + 1]) {
+                    const uint64_t x = win[i], y = win[i + 1];
+                    if (x > y) { win[i] = y; win[i + 1] = x; }
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = threadIdx.x; i < n; i += 256) point_list[w0 + i] = (int32_t)(uint32_t)win[i];
+        __syncthreads();
+        s0 = s1;
+    }
+}
+
 // capacity classes: a workgroup only handles tiles whose segment length lies in (LO, CAP] so that small tiles do not reserve
 // the LDS of the largest ones (LDS, not registers, limits how many tiles a CU sorts concurrently)
 template <int LO, int CAP>
@@ -445,6 +641,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
     __shared__ float2 s_xy[BATCH];
     __shared__ float4 s_co[BATCH];
     __shared__ float s_rgb[BATCH * 3];
+    __shared__ float s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 4 waves, flushed once per batch
     const int tile = blockIdx.y * cam.gx + blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int px = blockIdx.x * TILE + (threadIdx.x & 15), py = blockIdx.y * TILE + (threadIdx.x >> 4);
@@ -464,6 +661,8 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
     for (int done_cnt = 0; done_cnt < n_tile; done_cnt += BATCH) {
         __syncthreads();
         const int nb = min(BATCH, n_tile - done_cnt);
+#pragma unroll
+        for (int q = 0; q < 9; q++) s_acc[threadIdx.x][q] = 0.f;
         if ((int)threadIdx.x < nb) {
             const int id = point_list[r1 - 1 - done_cnt - threadIdx.x];
             s_id[threadIdx.x] = id;
@@ -516,12 +715,24 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             d_c0 = wave_sum_to_lane63(d_c0); d_c1 = wave_sum_to_lane63(d_c1); d_c2 = wave_sum_to_lane63(d_c2);
             d_mx = wave_sum_to_lane63(d_mx); d_my = wave_sum_to_lane63(d_my);
             d_cx = wave_sum_to_lane63(d_cx); d_cy = wave_sum_to_lane63(d_cy); d_cw = wave_sum_to_lane63(d_cw); d_op = wave_sum_to_lane63(d_op);
-            if (lane == 63) {
-                const int id = s_id[j];
-                atomicAdd(dL_dcolor + 3 * id, d_c0); atomicAdd(dL_dcolor + 3 * id + 1, d_c1); atomicAdd(dL_dcolor + 3 * id + 2, d_c2);
-                atomicAdd(dL_dmean2D + 3 * id, d_mx); atomicAdd(dL_dmean2D + 3 * id + 1, d_my);
-                atomicAdd(dL_dconic + 4 * id, d_cx); atomicAdd(dL_dconic + 4 * id + 1, d_cy); atomicAdd(dL_dconic + 4 * id + 3, d_cw);
-                atomicAdd(dL_dopacity + id, d_op);
+            if (lane == 63) {  // LDS atomics: the 4 waves of the tile meet here, the global atomics happen once per (tile, Gaussian)
+                float* a = s_acc[j];
+                atomicAdd(a + 0, d_c0); atomicAdd(a + 1, d_c1); atomicAdd(a + 2, d_c2); atomicAdd(a + 3, d_mx); atomicAdd(a + 4, d_my);
+                atomicAdd(a + 5, d_cx); atomicAdd(a + 6, d_cy); atomicAdd(a + 7, d_cw); atomicAdd(a + 8, d_op);
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nb) {
+            const float* a = s_acc[threadIdx.x];
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 9; q++) any = any || (a[q] != 0.f);
+            if (any) {
+                const int id = s_id[threadIdx.x];
+                atomicAdd(dL_dcolor + 3 * id, a[0]); atomicAdd(dL_dcolor + 3 * id + 1, a[1]); atomicAdd(dL_dcolor + 3 * id + 2, a[2]);
+                atomicAdd(dL_dmean2D + 3 * id, a[3]); atomicAdd(dL_dmean2D + 3 * id + 1, a[4]);
+                atomicAdd(dL_dconic + 4 * id, a[5]); atomicAdd(dL_dconic + 4 * id + 1, a[6]); atomicAdd(dL_dconic + 4 * id + 3, a[7]);
+                atomicAdd(dL_dopacity + id, a[8]);
             }
         }
     }
@@ -681,8 +892,23 @@ __global__ void __launch_bounds__(256) k_preprocess_bw(int P, GsCam cam, const f
     }
 }
 
-int gs_bin_blocks(int P) { const int nb = (int)nrc_cdiv(P, 256); return nb < 256 ? (nb > 0 ? nb : 1) : 256; }
+int gs_bin_blocks(int P) { const int nb = (int)nrc_cdiv(P, 256); return nb < SEG_MAX_NB ? (nb > 0 ? nb : 1) : SEG_MAX_NB; }
 int gs_bin_chunk(int P) { const int nb = gs_bin_blocks(P); return (int)(nrc_cdiv(nrc_cdiv(P, nb), 256) * 256); }
+// binning workspace: [hist NB x n_tiles][keyA P][valA P][keyB P][valB P][radix counts 256 x nblk]   (all u32)
+struct BinWs { uint32_t *hist, *keyA, *valA, *keyB, *valB, *counts; int nblk; };
+int64_t gs_bin_ws_words(int P, int n_tiles) {
+    const int64_t nblk = nrc_cdiv(P > 0 ? P : 1, RS_TILE);
+    return (int64_t)gs_bin_blocks(P) * n_tiles + 4 * (int64_t)(P > 0 ? P : 1) + 256 * nblk + 64;
+}
+BinWs gs_bin_ws(uint32_t* base, int P, int n_tiles) {
+    BinWs w;
+    const int64_t p1 = P > 0 ? P : 1;
+    w.nblk = (int)nrc_cdiv(p1, RS_TILE);
+    w.hist = base;
+    w.keyA = w.hist + (int64_t)gs_bin_blocks(P) * n_tiles;
+    w.valA = w.keyA + p1; w.keyB = w.valA + p1; w.valB = w.keyB + p1; w.counts = w.valB + p1;
+    return w;
+}
 
 int make_cam(GsCam& cam, int W, int H, int D, int M, const float* view, const float* proj, const float* campos, float tanx, float tany,
              float scale_modifier) {
@@ -704,7 +930,7 @@ int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H) {
     if (P < 0 || W < 1 || H < 1) return NRC_ERR_INVALID;
     const int64_t n_tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     if (n_tiles > GS_MAX_LDS_TILES) return 0;  // global-atomic fallback: no histogram matrix
-    return (int64_t)gs_bin_blocks(P) * n_tiles * (int64_t)sizeof(uint32_t);
+    return gs_bin_ws_words(P, (int)n_tiles) * (int64_t)sizeof(uint32_t);
 }
 
 int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs,
@@ -734,13 +960,23 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                            lds_path ? (uint32_t*)nullptr : tile_counts);
         if (lds_path) {
             const int nb = gs_bin_blocks(P), chunk = gs_bin_chunk(P);
-            hipLaunchKernelGGL(k_tile_hist, dim3(nb), dim3(256), n_tiles * sizeof(uint32_t), s, P, chunk, cam.gx, cam.gy, radii, points_xy, bin_hist);
-            hipLaunchKernelGGL(k_tile_totals, dim3(nrc_cdiv(n_tiles, 256)), dim3(256), 0, s, nb, n_tiles, bin_hist, tile_counts);
+            const BinWs w = gs_bin_ws(bin_hist, P, n_tiles);
+            // depth pre-sort of the Gaussians: 4 stable 8-bit passes, (keyA,valA) -> ... -> (keyA,valA); valA = depth order
+            hipLaunchKernelGGL(k_depth_keys, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, radii, depths, w.keyA, w.valA);
+            for (int pass = 0; pass < 4; pass++) {
+                const uint32_t *ki = (pass & 1) ? w.keyB : w.keyA, *vi = (pass & 1) ? w.valB : w.valA;
+                uint32_t *ko = (pass & 1) ? w.keyA : w.keyB, *vo = (pass & 1) ? w.valA : w.valB;
+                hipLaunchKernelGGL(k_radix_count, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk, ki, w.counts);
+                hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, w.counts, 256 * w.nblk);
+                hipLaunchKernelGGL(k_radix_scatter, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk, ki, vi, w.counts, ko, vo);
+            }
+            hipLaunchKernelGGL(k_tile_hist, dim3(nb), dim3(256), n_tiles * sizeof(uint32_t), s, P, chunk, cam.gx, cam.gy, w.valA, radii, points_xy, w.hist);
+            hipLaunchKernelGGL(k_tile_totals, dim3(nrc_cdiv(n_tiles, 64)), dim3(256), 0, s, nb, n_tiles, w.hist, tile_counts);
         }
     }
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, n_tiles, ranges, tile_fill, num_rendered);
     if (P > 0 && lds_path)
-        hipLaunchKernelGGL(k_tile_bases, dim3(nrc_cdiv(n_tiles, 256)), dim3(256), 0, s, gs_bin_blocks(P), n_tiles, ranges, bin_hist);
+        hipLaunchKernelGGL(k_tile_bases, dim3(nrc_cdiv(n_tiles, 64)), dim3(256), 0, s, gs_bin_blocks(P), n_tiles, ranges, gs_bin_ws(bin_hist, P, n_tiles).hist);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
@@ -756,14 +992,19 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
     if (P > 0) {
         if (!radii || !depths || !points_xy || !conic_opacity || !rgb || !keys || !point_list) return NRC_ERR_INVALID;
         const int n_tiles = cam.gx * cam.gy;
-        if (n_tiles <= GS_MAX_LDS_TILES && bin_hist)
-            hipLaunchKernelGGL(k_scatter_lds, dim3(gs_bin_blocks(P)), dim3(256), n_tiles * sizeof(uint32_t), s, P, gs_bin_chunk(P), cam.gx, cam.gy, radii,
-                               depths, points_xy, bin_hist, keys);
-        else
+        if (n_tiles <= GS_MAX_LDS_TILES && bin_hist) {
+            const BinWs w = gs_bin_ws(const_cast<uint32_t*>(bin_hist), P, n_tiles);
+            const int nb = gs_bin_blocks(P);
+            // the scatter consumes a COPY of the bases as LDS cursors; the matrix keeps the sub-segment starts for the finishing sort
+            hipLaunchKernelGGL(k_scatter_lds, dim3(nb), dim3(256), n_tiles * sizeof(uint32_t), s, P, gs_bin_chunk(P), cam.gx, cam.gy, w.valA, radii,
+                               depths, points_xy, w.hist, keys);
+            hipLaunchKernelGGL(k_sort_segments, dim3(n_tiles), dim3(256), 0, s, nb, n_tiles, ranges, w.hist, keys, point_list);
+        } else {
             hipLaunchKernelGGL(k_scatter, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, ranges, tile_fill, keys);
-        hipLaunchKernelGGL((k_sort_tiles<0, 1024>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
-        hipLaunchKernelGGL((k_sort_tiles<1024, 4096>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
-        hipLaunchKernelGGL((k_sort_tiles<4096, SORT_LDS_CAP>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
+            hipLaunchKernelGGL((k_sort_tiles<0, 1024>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
+            hipLaunchKernelGGL((k_sort_tiles<1024, 4096>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
+            hipLaunchKernelGGL((k_sort_tiles<4096, SORT_LDS_CAP>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
+        }
     }
     hipLaunchKernelGGL(k_render, dim3(cam.gx, cam.gy), dim3(256), 0, s, cam, ranges, point_list, points_xy, conic_opacity, rgb, bg_host[0],
                        bg_host[1], bg_host[2], out_color, n_contrib, final_T);
