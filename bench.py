@@ -194,6 +194,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gs', action='store_true', help='skip the secondary 3DGS leg')
     ap.add_argument('--gs-gaussians', type=int, default=1_000_000)
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the code path)')
     args = ap.parse_args()
 
     import torch
@@ -203,11 +204,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    device = torch.device('cuda', local_dev)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=device)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(args.backend)
+    red_dev = device if args.backend == 'nccl' else torch.device('cpu')  # where the tiny timing reductions live
 
     model, renderer, cam, poses = build_scene(device)
 
@@ -229,10 +236,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        s = torch.tensor([samples], device=device, dtype=torch.int64)
+        s = torch.tensor([samples], device=red_dev, dtype=torch.int64)
         dist.all_reduce(s)
         samples = int(s.item())
 
@@ -242,7 +249,7 @@ def main():
         gs = build_gs_scene(device, args.gs_gaussians)
         gs_res = time_gs(gs, reps=max(3, args.steps // 2), barrier=barrier)
         if world > 1:
-            t = torch.tensor([gs_res['ms_fwd'], gs_res['ms_fwd_bwd']], device=device, dtype=torch.float64)
+            t = torch.tensor([gs_res['ms_fwd'], gs_res['ms_fwd_bwd']], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             gs_res['ms_fwd'], gs_res['ms_fwd_bwd'] = float(t[0]), float(t[1])
         n_g = gs_res['gaussians'] * world

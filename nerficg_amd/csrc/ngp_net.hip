@@ -724,21 +724,46 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
     for (int nt = 0; nt < 2; nt++) atomic_add_tile(gWop, 64, n_out_rows, 0, nt, gWo[nt], inv_scale, r, hh);
 }
 
-// hash-grid backward: one lane per (sample, level); scatter-add of w_corner * dL/dfeature into the f32 table gradient
+// hash-grid backward: one lane per (sample, level); scatter-add of w_corner * dL/dfeature into the f32 table gradient.
+// Scattered f32 atomics run at ~20 G/s chip-wide (MI355X_MICROARCH.md, "64 lanes in 64 different rows"), far below what the
+// rest of the step needs, so their NUMBER is what matters: neighbouring lanes are consecutive samples of a ray and, on all but
+// the finest levels, hit the same table entries.  Each corner's contributions are therefore combined over RUNS of equal entry
+// index inside the wave (segmented DPP scan: ~50 VALU ops, free next to the atomic unit) and only the last lane of a run
+// issues the atomic.
 __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, GridCfg g,
                                                   int n_levels, float* __restrict__ grad_table) {
     const int level = blockIdx.y;
+    const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    const float2 gf = *reinterpret_cast<const float2*>(d_feat + i * 2 * n_levels + 2 * level);
-    if (gf.x == 0.f && gf.y == 0.f) return;
+    const bool in_range = i < M;
+    const int64_t ic = in_range ? i : M - 1;
+    float2 gf = *reinterpret_cast<const float2*>(d_feat + ic * 2 * n_levels + 2 * level);
+    const bool live = in_range && !(gf.x == 0.f && gf.y == 0.f);
+    if (__ballot(live) == 0ull) return;
     Corner8 c;
-    grid_corners(x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scale[level], g.res[level], g.size[level], g.offset[level], g.hashed[level] != 0, c);
+    grid_corners(x[3 * ic], x[3 * ic + 1], x[3 * ic + 2], g.scale[level], g.res[level], g.size[level], g.offset[level], g.hashed[level] != 0, c);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        float* p = grad_table + 2 * (size_t)c.e[k];
-        atomicAdd(p, c.w[k] * gf.x);
-        atomicAdd(p + 1, c.w[k] * gf.y);
+        const uint32_t key = live ? c.e[k] : (0xffffff00u | (uint32_t)lane);  // dead lanes: unique keys, they only split runs
+        float v0 = live ? c.w[k] * gf.x : 0.f, v1 = live ? c.w[k] * gf.y : 0.f;
+        const uint32_t prev = __shfl_up(key, 1, 64), next = __shfl_down(key, 1, 64);
+        const bool head = lane == 0 || prev != key, tail = lane == 63 || next != key;
+        int start = head ? lane : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(start, d, 64);
+            if (lane >= d) start = max(start, o);
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o0 = __shfl_up(v0, d, 64), o1 = __shfl_up(v1, d, 64);
+            if (lane - d >= start) { v0 += o0; v1 += o1; }
+        }
+        if (live && tail) {
+            float* p = grad_table + 2 * (size_t)key;
+            atomicAdd(p, v0);
+            atomicAdd(p + 1, v1);
+        }
     }
 }
 

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""tools/bench_train.py -- InstantNGP training-iteration throughput through the drop-in modules (Trainer.py:79-94 sequence)."""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np
+import torch
+import bench
+from nerficg_amd.raygen import generate_rays
+
+n_rays = int(sys.argv[1]) if len(sys.argv) > 1 else 2200
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = torch.device('cuda', 0)
+model, renderer, cam, poses = bench.build_scene(dev)
+rays = [generate_rays(cam.width, cam.height, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y, p, device=dev, want_direction=False) for p in poses[:4]]
+origin = torch.cat([r['origin'] for r in rays]); vdir = torch.cat([r['view_direction'] for r in rays])
+g = torch.Generator(device='cpu').manual_seed(0)
+perm = torch.randperm(origin.shape[0], generator=g).to(dev)
+opt = torch.optim.Adam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), fused=True)
+scaler = torch.amp.GradScaler(init_scale=128.0, growth_interval=10 ** 9)
+target = torch.rand(origin.shape[0], 3, device=dev)
+
+def step(i):
+    ids = perm[(i * n_rays) % (perm.numel() - n_rays):][:n_rays]
+    with torch.amp.autocast('cuda'):
+        bg = torch.rand(3, device=dev)
+        out = renderer.render_rays(origin[ids], vdir[ids], cam, train_mode=True, custom_bg_color=bg)
+        loss = torch.nn.functional.mse_loss(out['rgb'].float(), target[ids]) + 0.5e-6 * model.weight_decay_mlp()
+    scaler.scale(loss).backward()
+    scaler.step(opt); scaler.update(); opt.zero_grad()
+    return int(out['rm_samples'].item())
+
+for i in range(3):
+    s = step(i)
+torch.cuda.synchronize(); t0 = time.perf_counter(); tot = 0
+for i in range(iters):
+    tot += step(3 + i)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / iters
+print(f'train iteration: {dt * 1e3:.2f} ms, {n_rays} rays, {tot / iters:.0f} samples/iter -> {n_rays / dt / 1e6:.3f} Mrays/s, {tot / iters / dt / 1e6:.1f} Msamples/s')
