@@ -11,6 +11,7 @@ Vectors produced (reference symbol -> fixture):
   generate_samples / generate_samples_from_pdf / integrate_samples  -> nerf_sampling.npz   (a7-a9)
   convert_sh_features / build_covariances / quaternion_to_rotation  -> gs_utils.npz        (a26)
   LRDecayPolicy, apply_background_color, RandomSequentialSampler    -> misc.npz
+  NeRFBlock.forward / NeRFRayRenderingComponent.forward (tiny model) -> nerf_render.npz         (a6, a10)
 """
 import importlib.util
 import math
@@ -221,6 +222,32 @@ def main():
         sampler_draws=np.stack(draws), bgc_raw=raw.numpy(), bgc_alpha=al.numpy(),
         bgc_out=apply_background_color(raw, al, torch.tensor([0.2, 0.4, 0.6]), is_chw=False).numpy(),
     )
+    # ---------------------------------------------------------------- NeRF block + hierarchical renderer (a6, a10), tiny width
+    from Methods.NeRF.Model import NeRFBlock
+    from Methods.NeRF.Renderer import NeRFRayRenderingComponent
+    from Datasets.utils import RayBatch
+    torch.manual_seed(0)
+    kw = dict(n_layers=8, n_color_layers=1, n_features=32, n_frequencies_position=10, n_frequencies_direction=4, encoding_append_input=True,
+              input_skips=[5], activation_function='relu')
+    coarse, fine = NeRFBlock(**kw), NeRFBlock(**kw)
+    nr = 23
+    origin = torch.tensor([0.0, 0.0, -4.0]).expand(nr, 3).contiguous()
+    direction = torch.cat([torch.randn(nr, 2, generator=g) * 0.15, torch.ones(nr, 1)], dim=-1)
+    vdir = torch.nn.functional.normalize(direction, dim=-1)
+    rays = RayBatch(origin=origin, direction=direction, view_direction=vdir, timestamp=torch.zeros(nr, 1))
+    settings = SharedCameraSettings(background_color=torch.tensor([1.0, 1.0, 1.0]), near_plane=2.0, far_plane=6.0)
+    cam = PerspectiveCamera(shared_settings=settings, width=8, height=8, focal_x=10.0, focal_y=10.0)
+    comp = NeRFRayRenderingComponent(coarse, fine)
+    with torch.no_grad():
+        out = comp(rays, cam, ray_batch_size=10, n_samples_coarse_nerf=16, n_samples_nerf=24, randomize_samples=False, random_noise_density=0.0)
+        pts = torch.randn(40, 3, generator=g)
+        dens, col = fine(pts, vdir[:1].expand(40, 3).contiguous())
+    blob = {f'coarse.{k}': v.numpy() for k, v in coarse.state_dict().items()}
+    blob.update({f'fine.{k}': v.numpy() for k, v in fine.state_dict().items()})
+    blob.update(origin=origin.numpy(), direction=direction.numpy(), view_direction=vdir.numpy(), block_pts=pts.numpy(), block_dens=dens.numpy(),
+                block_col=col.numpy(), **{f'out_{k}': v.numpy() for k, v in out.items()})
+    np.savez_compressed(OUT / 'nerf_render.npz', **blob)
+
     print('golden fixtures written to', OUT)
     for f in sorted(OUT.glob('*.npz')):
         print(f'  {f.name}: {f.stat().st_size} B')

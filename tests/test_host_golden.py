@@ -32,3 +32,59 @@ def test_sh_conversion_and_covariances(golden_dir):
     np.testing.assert_allclose(gs.quaternion_to_rotation_matrix(quats, normalize=False).numpy(), g['rot'], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(gs.quaternion_to_rotation_matrix(torch.from_numpy(g['rot_unnormalized_in'])).numpy(), g['rot_normalized'], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(gs.rgb_to_sh0(torch.linspace(0, 1, 7)).numpy(), g['rgb_to_sh0'], rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ vanilla NeRF path (config 1)
+def test_frequency_encoding(golden_dir):
+    from nerficg_amd import nerf
+    g = np.load(golden_dir / 'freqenc.npz')
+    x = torch.from_numpy(g['x'])
+    np.testing.assert_allclose(nerf.FrequencyEncoding(10, True)(x).numpy(), g['pos10'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(nerf.FrequencyEncoding(4, True)(x).numpy(), g['dir4'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(nerf.FrequencyEncoding(6, False)(x).numpy(), g['noappend6'], rtol=1e-6, atol=1e-6)
+    assert nerf.FrequencyEncoding(10, True).get_n_outputs(3) == 63 and nerf.FrequencyEncoding(4, True).get_n_outputs(3) == 27
+
+
+def test_sampling_and_integration(golden_dir):
+    from nerficg_amd import nerf
+    g = np.load(golden_dir / 'nerf_sampling.npz')
+    n = g['depth'].shape[0]
+    depth = nerf.generate_samples(n, 64, 2.0, 6.0, False)
+    np.testing.assert_array_equal(depth.numpy(), g['depth'])
+    torch.manual_seed(1)
+    np.testing.assert_allclose(nerf.generate_samples(n, 64, 2.0, 6.0, True).numpy(), g['depth_rand'], rtol=1e-6)
+    rgb, dpt, alpha, w = nerf.integrate_samples(depth, torch.from_numpy(g['dirs']), torch.from_numpy(g['dens']), torch.from_numpy(g['cols']), torch.from_numpy(g['bg']))
+    np.testing.assert_allclose(rgb.numpy(), g['rgb'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dpt.numpy(), g['depth_out'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(alpha.numpy(), g['alpha'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(w.numpy(), g['weights'], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(nerf.generate_samples_from_pdf(depth, w, 192, False).numpy(), g['fine'], rtol=1e-6, atol=1e-6)
+    torch.manual_seed(2)
+    np.testing.assert_allclose(nerf.generate_samples_from_pdf(depth, w, 192, True).numpy(), g['fine_rand'], rtol=1e-6, atol=1e-6)
+
+
+def test_nerf_block_and_hierarchical_renderer(golden_dir):
+    from nerficg_amd import nerf
+    g = np.load(golden_dir / 'nerf_render.npz')
+    kw = dict(n_layers=8, n_color_layers=1, n_features=32, n_frequencies_position=10, n_frequencies_direction=4, encoding_append_input=True, input_skips=[5])
+    coarse, fine = nerf.NeRFBlock(**kw), nerf.NeRFBlock(**kw)
+    for name, block in (('coarse', coarse), ('fine', fine)):
+        sd = {k[len(name) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + '.')}
+        block.load_state_dict(sd, strict=True)  # identical module / parameter names as the reference
+    with torch.no_grad():
+        dens, col = fine(torch.from_numpy(g['block_pts']), torch.from_numpy(g['view_direction'][:1]).expand(40, 3).contiguous())
+        out = nerf.render_rays(coarse, fine, torch.from_numpy(g['origin']), torch.from_numpy(g['direction']), torch.from_numpy(g['view_direction']),
+                               2.0, 6.0, torch.ones(3), ray_batch_size=10, n_samples_coarse_nerf=16, n_samples_nerf=24)
+    np.testing.assert_allclose(dens.numpy(), g['block_dens'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(col.numpy(), g['block_col'], rtol=1e-5, atol=1e-6)
+    for k in ('rgb', 'alpha', 'depth', 'rgb_coarse', 'alpha_coarse', 'depth_coarse'):
+        np.testing.assert_allclose(out[k].numpy(), g[f'out_{k}'], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+def test_random_sequential_sampler_defines_the_ray_indices(golden_dir):
+    from nerficg_amd.samplers import RandomSequentialSampler
+    g = np.load(golden_dir / 'misc.npz')
+    torch.manual_seed(0)
+    s = RandomSequentialSampler(1000)
+    draws = np.stack([s.get(300).numpy().copy() for _ in range(5)])
+    np.testing.assert_array_equal(draws, g['sampler_draws'])  # includes the reshuffle on wrap-around
