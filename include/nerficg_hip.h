@@ -165,7 +165,8 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
  *                             tile_off (n_tiles+1), counter = (total rows, n_tiles).  intr/c2w/center3/half3: HOST pointers.
  *   2. nrc_ngp_render_write : ts (rows*64) f32 (-1 = hole), row_tile (rows) i32.
  *   3. nrc_ngp_query_samples: slots -> packed (h0, r, g, b) fp16 (sigma = exp(h0)); xyz_min3/xyz_size3 HOST pointers;
- *                             workspace: nrc_ngp_query_ws_bytes(rows*64) bytes.
+ *                             n_ray_tiles = tiles in ray_od (their SH coefficients are evaluated once per ray);
+ *                             workspace: nrc_ngp_query_samples_ws_bytes(rows, n_ray_tiles) bytes.
  *   4. nrc_ngp_composite_image: serial per-ray compositing + background / clamps (bg3 HOST) into full-image buffers
  *                             rgb (H*W,3), alpha (H*W), depth (H*W) -- only the shard's pixels are written.
  * ===================================================================================================== */
@@ -178,12 +179,13 @@ int nrc_ngp_render_write(int64_t n_tiles, const uint8_t* density_bitfield, int32
                          float exp_step_factor, int32_t grid_size, int32_t max_samples, const float* ray_od,
                          const float* ray_t, const int32_t* ray_cnt, const int32_t* tile_off, float* ts, int32_t* row_tile,
                          nrc_stream_t stream);
-int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, const float* xyz_min3,
-                          const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
+int64_t nrc_ngp_query_samples_ws_bytes(int64_t n_rows, int64_t n_ray_tiles);
+int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
+                          const float* xyz_min3, const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                           float per_level_scale, void* packed_f16, void* workspace, nrc_stream_t stream);
 /* stage 3a on its own (the dominant kernel of the pipeline; used by bench.py's roofline leg): hash-grid features of the first
- * n_rows (<= 32768) rows, level-major fp16x2 [16][n_rows*64] */
+ * n_rows (<= 32768) rows, fragment-major: the 16-byte vector [((j>>5)*4 + ((g + (j>>5))&3))*32 + (j&31)] = levels 4g..4g+3 (fp16x2) of slot j */
 int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, const float* xyz_min3,
                            const float* xyz_size3, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
                            int32_t base_resolution, float per_level_scale, void* features_f16, nrc_stream_t stream);

@@ -194,30 +194,77 @@ __device__ __forceinline__ void fetch_dir(const QueryIn& in, int64_t i, float& d
     }
 }
 
-// feat: level-major [16][n] fp16x2 for the samples [base, base+n).  One lane per sample, all 16 levels.
+// feat: FRAGMENT-major fp16 features of the samples [base, base+n): the 16-byte vector
+//   feat[((j >> 5) * 4 + ((g + (j >> 5)) & 3)) * 32 + (j & 31)]   holds levels 4g .. 4g+3 (2 features each) of sample j,
+// which is, bit for bit, the first-layer B fragment of k-step g>>1 for lane half g&1 of the MFMA wave that owns samples
+// 32*(j>>5) .. +31: the encoder writes 4 coalesced 16-byte stores per sample, the MLP kernel reads 2 coalesced 16-byte loads
+// per lane and needs no unpacking.  The group position inside a tile's 2 KB record rotates with the tile index: all waves
+// of the chip reach group g at about the same time, and un-rotated they would all write the same quarter of the memory
+// channels (measured: 0.262 ms vs 0.22 ms per 2 Mi samples).  One lane per sample, all 16 levels.
 template <int SRC>
 __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ table, GridCfg g,
-                                                         __half2* __restrict__ feat) {
+                                                         uint4* __restrict__ feat) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     float px, py, pz;
     const bool live = fetch_pos<SRC>(in, base + j, px, py, pz);
     const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
-#pragma unroll 4
-    for (int level = 0; level < 16; level++) {
-        if (!live) { feat[(int64_t)level * n + j] = __floats2half2_rn(0.f, 0.f); continue; }
-        Corner8 c;
-        grid_corners(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], g.hashed[level] != 0, c);
-        float f0, f1;
-        grid_level_features(trs, c, f0, f1);
-        feat[(int64_t)level * n + j] = __floats2half2_rn(f0, f1);
+    uint4* out = feat + ((j >> 5) * 4) * 32 + (j & 31);
+    const int rot = (int)((j >> 5) & 3);
+#pragma unroll 1
+    for (int grp = 0; grp < 4; grp++) {
+        uint32_t v[4] = {0u, 0u, 0u, 0u};
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int level = 4 * grp + q;
+                Corner8 c;
+                grid_corners(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], g.hashed[level] != 0, c);
+                float f0, f1;
+                grid_level_features(trs, c, f0, f1);
+                const __half2 h = __floats2half2_rn(f0, f1);
+                v[q] = *reinterpret_cast<const uint32_t*>(&h);
+                // finish this level before the next one starts: otherwise the compiler sinks all four interpolations below the
+                // last gather and the 4 x 20 live registers cut the occupancy from 8 to 3 waves per SIMD
+                asm volatile("" : "+v"(v[q]));
+            }
+        }
+        out[((grp + rot) & 3) * 32] = make_uint4(v[0], v[1], v[2], v[3]);
     }
 }
 
+// SH degree 4 of the ray direction as the colour net's k-step-0 B fragments, once per RAY of the tiled layout:
+//   ray_sh[(tile * 2 + hh) * 64 + lane] = fp16 coefficients 8hh .. 8hh+7 of ray (tile, lane)
+// (a sample's direction is its ray's: evaluating per sample would repeat ~80 VALU instructions 120 times per ray)
+__device__ __forceinline__ void sh4_fragments(float dx, float dy, float dz, h8& lo, h8& hi) {
+    // the reference feeds fp16(d*0.5+0.5) and tiny-cuda-nn maps it back with *2-1 (Renderer.py:52)
+    float sh[16];
+    const float ex = (float)(_Float16)__fadd_rn(__fmul_rn(dx, 0.5f), 0.5f) * 2.f - 1.f;
+    const float ey = (float)(_Float16)__fadd_rn(__fmul_rn(dy, 0.5f), 0.5f) * 2.f - 1.f;
+    const float ez = (float)(_Float16)__fadd_rn(__fmul_rn(dz, 0.5f), 0.5f) * 2.f - 1.f;
+    sh4_eval(ex, ey, ez, sh);
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) { lo[jj] = (_Float16)sh[jj]; hi[jj] = (_Float16)sh[8 + jj]; }
+}
+__global__ void __launch_bounds__(256) k_ray_sh(const float* __restrict__ ray_od, int64_t n_ray_tiles, h8* __restrict__ ray_sh) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ray_tiles * 64) return;
+    const int64_t tile = i >> 6;
+    const int lane = (int)(i & 63);
+    const float* od = ray_od + tile * 384 + lane;
+    h8 lo, hi;
+    sh4_fragments(od[192], od[256], od[320], lo, hi);
+    ray_sh[(tile * 2) * 64 + lane] = lo;
+    ray_sh[(tile * 2 + 1) * 64 + lane] = hi;
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 template <int SRC>
-__global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ feat,
-                                                    const __half* __restrict__ Wd, const __half* __restrict__ Wc, float* __restrict__ sigmas,
-                                                    float* __restrict__ rgbs, __half* __restrict__ packed) {
+__global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, int64_t n, const uint4* __restrict__ feat,
+                                                    const h8* __restrict__ ray_sh, const __half* __restrict__ Wd,
+                                                    const __half* __restrict__ Wc, float* __restrict__ sigmas, float* __restrict__ rgbs,
+                                                    __half* __restrict__ packed) {
     enum { F_D0 = 0, F_DO = 4, F_C0 = 8, F_C1 = 12, F_CO = 20, N_FRAG = 24 };
     __shared__ h8 wlds[N_FRAG][64];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
@@ -243,23 +290,29 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
     for (int64_t tile = wave0; tile < n_tiles; tile += n_waves) {
         const int64_t j = tile * 32 + r;
         bool valid = j < n;
-        const int64_t jc = valid ? j : n - 1;
+        const int64_t i = base + (valid ? j : n - 1);
         if constexpr (SRC == SRC_TILED) {
-            valid = valid && in.ts[base + jc] >= 0.f;
+            valid = valid && in.ts[i] >= 0.f;
             if (__ballot(valid) == 0ull) continue;  // a half row of holes
         }
-        // first-layer B fragments: element (2q, 2q+1) of k-step s <- features of level 8s + 4hh + q (128-byte coalesced per level)
-        h8 B[2];
-#pragma unroll
-        for (int s = 0; s < 2; s++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const __half2 v = feat[(int64_t)(8 * s + 4 * hh + q) * n + jc];
-                B[s][2 * q] = *reinterpret_cast<const _Float16*>(&v.x);
-                B[s][2 * q + 1] = *reinterpret_cast<const _Float16*>(&v.y);
-            }
-        float dx, dy, dz;
-        fetch_dir<SRC>(in, base + jc, dx, dy, dz);
+        // first-layer B fragments straight from the encoder's fragment-major records (512 contiguous bytes per half wave);
+        // element (2q, 2q+1) of k-step s <- features of level 8s + 4hh + q
+        h8 B[2], X[2];
+        {
+            const uint4* fp = feat + tile * 128 + r;
+            const int rot = (int)(tile & 3);
+            const uint4 b0 = fp[((hh + rot) & 3) * 32], b1 = fp[((2 + hh + rot) & 3) * 32];
+            B[0] = *reinterpret_cast<const h8*>(&b0);
+            B[1] = *reinterpret_cast<const h8*>(&b1);
+        }
+        // colour-net k-step 0 = SH(dir) (natural order)
+        if constexpr (SRC == SRC_TILED) {
+            X[0] = ray_sh[((int64_t)in.row_tile[i >> 6] * 2 + hh) * 64 + (i & 63)];
+        } else {
+            h8 lo, hi;
+            sh4_fragments(in.dirs[3 * i], in.dirs[3 * i + 1], in.dirs[3 * i + 2], lo, hi);
+            X[0] = hh ? hi : lo;
+        }
         f16v acc[2] = {zero16(), zero16()};
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
@@ -273,19 +326,8 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
         f16v o = zero16();
 #pragma unroll
         for (int s = 0; s < 4; s++) o = NRC_MFMA(DO(s), H[s], o);
-        // colour-net inputs: k-step 0 = SH(dir) (natural), k-step 1 = fp16(h) straight from the accumulator (ACC order)
-        h8 X[2];
+        // colour-net k-step 1 = fp16(h) straight from the accumulator (ACC order)
         X[1] = acc_to_frag(o, 0);
-        {
-            // the reference feeds fp16(d*0.5+0.5) and tiny-cuda-nn maps it back with *2-1 (Renderer.py:52)
-            float sh[16];
-            const float ex = (float)(_Float16)__fadd_rn(__fmul_rn(dx, 0.5f), 0.5f) * 2.f - 1.f;
-            const float ey = (float)(_Float16)__fadd_rn(__fmul_rn(dy, 0.5f), 0.5f) * 2.f - 1.f;
-            const float ez = (float)(_Float16)__fadd_rn(__fmul_rn(dz, 0.5f), 0.5f) * 2.f - 1.f;
-            sh4_eval(ex, ey, ez, sh);
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) X[0][jj] = (_Float16)(hh ? sh[8 + jj] : sh[jj]);
-        }
         const _Float16 h0 = X[1][0];  // fp16 density feature 0 (lane half 0, element 0)
         acc[0] = zero16(); acc[1] = zero16();
 #pragma unroll
@@ -312,8 +354,7 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
             h4 pk;
             pk[0] = h0;
 #pragma unroll
-            for (int c = 0; c < 3; c++) pk[1 + c] = (_Float16)(1.f / (1.f + expf(-o[c])));
-            const int64_t i = base + j;
+            for (int c = 0; c < 3; c++) pk[1 + c] = (_Float16)fast_sigmoid(o[c]);
             if constexpr (SRC == SRC_ARRAYS) {
                 sigmas[i] = expf((float)h0);  // TruncExp forward (custom_functions.py:201-204)
 #pragma unroll
@@ -376,15 +417,29 @@ int pick_blocks(int64_t M) {
 
 #define NRC_QUERY_CHUNK (int64_t(2) << 20)  // samples per encode/MLP round: 2 Mi x 64 B of features = 128 MB, Infinity-Cache resident
 
+// workspace: [features of one chunk: roundup32(chunk) x 64 B][ray_sh: n_ray_tiles x 2 KB (tiled layout only)]
+static int64_t query_feat_bytes(int64_t M) {
+    const int64_t c = M < NRC_QUERY_CHUNK ? M : NRC_QUERY_CHUNK;
+    return ((c > 0 ? c : 1) + 31) / 32 * 32 * 64 + 256;
+}
+
 template <int SRC>
-static int run_query(const QueryIn& in, int64_t M, const void* wd, const void* wc, const void* table, const GridCfg& g, float* sigmas,
-                     float* rgbs, void* packed, void* workspace, hipStream_t s) {
-    __half2* feat = (__half2*)workspace;
+static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void* table, const GridCfg& g, uint4* feat, hipStream_t s) {
+    hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat);
+}
+
+template <int SRC>
+static int run_query(const QueryIn& in, int64_t M, int64_t n_ray_tiles, const void* wd, const void* wc, const void* table, const GridCfg& g,
+                     float* sigmas, float* rgbs, void* packed, void* workspace, hipStream_t s) {
+    uint4* feat = (uint4*)workspace;
+    h8* ray_sh = (h8*)((char*)workspace + query_feat_bytes(M));
+    if constexpr (SRC == SRC_TILED)
+        hipLaunchKernelGGL(k_ray_sh, dim3((unsigned)nrc_cdiv(n_ray_tiles * 64, 256)), dim3(256), 0, s, in.ray_od, n_ray_tiles, ray_sh);
     for (int64_t base = 0; base < M; base += NRC_QUERY_CHUNK) {
         const int64_t n = (M - base) < NRC_QUERY_CHUNK ? (M - base) : NRC_QUERY_CHUNK;
-        hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat);
-        hipLaunchKernelGGL(k_ngp_mlp<SRC>, dim3(pick_blocks(n)), dim3(256), 0, s, in, base, n, (const __half2*)feat, (const __half*)wd,
-                           (const __half*)wc, sigmas, rgbs, (__half*)packed);
+        launch_encode<SRC>(in, base, n, table, g, feat, s);
+        hipLaunchKernelGGL(k_ngp_mlp<SRC>, dim3(pick_blocks(n)), dim3(256), 0, s, in, base, n, (const uint4*)feat, (const h8*)ray_sh,
+                           (const __half*)wd, (const __half*)wc, sigmas, rgbs, (__half*)packed);
     }
     return NRC_OK;
 }
@@ -447,8 +502,12 @@ int nrc_nwie_forward(int32_t encoding, const void* input, int32_t input_ld, int6
 
 int64_t nrc_ngp_query_ws_bytes(int64_t M) {
     if (M < 0) return NRC_ERR_INVALID;
-    const int64_t c = M < NRC_QUERY_CHUNK ? M : NRC_QUERY_CHUNK;
-    return (c > 0 ? c : 1) * 64 + 256;
+    return query_feat_bytes(M);
+}
+
+int64_t nrc_ngp_query_samples_ws_bytes(int64_t n_rows, int64_t n_ray_tiles) {
+    if (n_rows < 0 || n_ray_tiles < 0) return NRC_ERR_INVALID;
+    return query_feat_bytes(n_rows * 64) + n_ray_tiles * 2048 + 256;
 }
 
 int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const void* density_weights_f16,
@@ -464,7 +523,7 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
     if (rc != NRC_OK) return rc;
     QueryIn in = {};
     in.xyz01 = xyz01; in.dirs = dirs;
-    run_query<SRC_ARRAYS>(in, M, density_weights_f16, color_weights_f16, table_f16, g, sigmas, rgbs, nullptr, workspace, (hipStream_t)stream);
+    run_query<SRC_ARRAYS>(in, M, 0, density_weights_f16, color_weights_f16, table_f16, g, sigmas, rgbs, nullptr, workspace, (hipStream_t)stream);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
@@ -484,29 +543,28 @@ int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float
     QueryIn in = {};
     in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od;
     for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
-    hipLaunchKernelGGL(k_grid_encode<SRC_TILED>, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, (int64_t)0, n,
-                       (const __half2*)table_f16, g, (__half2*)features_f16);
+    launch_encode<SRC_TILED>(in, 0, n, table_f16, g, (uint4*)features_f16, (hipStream_t)stream);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
 
-int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, const float* xyz_min3,
+int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles, const float* xyz_min3,
                           const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                           float per_level_scale, void* packed_f16, void* workspace, nrc_stream_t stream) {
     NRC_ENTER();
     const int64_t M = n_rows * 64;
-    if (n_rows < 0 || !density_weights_f16 || !color_weights_f16 || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
+    if (n_rows < 0 || n_ray_tiles < 0 || !density_weights_f16 || !color_weights_f16 || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
     if (n_levels != 16) return NRC_ERR_UNSUPPORTED;
     if (M == 0) return NRC_OK;
-    if (!ts || !row_tile || !ray_od || !packed_f16 || !workspace) return NRC_ERR_INVALID;
+    if (!ts || !row_tile || !ray_od || !packed_f16 || !workspace || n_ray_tiles == 0) return NRC_ERR_INVALID;
     GridCfg g;
     const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
     if (rc != NRC_OK) return rc;
     QueryIn in = {};
     in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od;
     for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
-    run_query<SRC_TILED>(in, M, density_weights_f16, color_weights_f16, table_f16, g, nullptr, nullptr, packed_f16, workspace, (hipStream_t)stream);
+    run_query<SRC_TILED>(in, M, n_ray_tiles, density_weights_f16, color_weights_f16, table_f16, g, nullptr, nullptr, packed_f16, workspace, (hipStream_t)stream);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

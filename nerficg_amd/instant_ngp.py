@@ -264,7 +264,7 @@ class InstantNGPRenderer:
             cap = int(rows * 1.25) + 64
             ws.update(ts=torch.empty(cap * 64, device=dev), row_tile=torch.empty(cap, dtype=torch.int32, device=dev),
                       packed=torch.empty(cap * 64, 4, dtype=torch.float16, device=dev),
-                      qws=torch.empty(int(lib.nrc_ngp_query_ws_bytes(cap * 64)), dtype=torch.uint8, device=dev), cap=cap)
+                      qws=torch.empty(int(lib.nrc_ngp_query_samples_ws_bytes(cap, nt)), dtype=torch.uint8, device=dev), cap=cap)
         if rows > 0:
             _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION,
                                                 self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']),
@@ -272,7 +272,7 @@ class InstantNGPRenderer:
             g = m.encoding_xyz.grid_cfg
             mn, sz = f3(m.xyz_min), f3(m.xyz_size)
             _lib.check(lib.nrc_ngp_query_samples(
-                _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, ctypes.cast(mn, ctypes.c_void_p),
+                _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(mn, ctypes.c_void_p),
                 ctypes.cast(sz, ctypes.c_void_p), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
                 _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
                 _lib.ptr(ws['packed']), _lib.ptr(ws['qws']), st), 'ngp_query_samples')
