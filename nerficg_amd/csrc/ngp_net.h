@@ -130,6 +130,40 @@ __device__ __forceinline__ void grid_corners(float px, float py, float pz, float
         c.e[k] = off + (hashed ? h : d);
     }
 }
+// Same corners when the level (hence `hashed`) is uniform over the wave: the index form is a template argument chosen by a
+// scalar branch, which halves the integer work per corner (k_grid_encode / k_grid_bwd are VALU co-limited: profiles/).
+template <bool HASHED>
+__device__ __forceinline__ void grid_corners_u(float px, float py, float pz, float scale, uint32_t res, uint32_t size, uint32_t off, Corner8& c) {
+    const float fx = fmaf(scale, px, 0.5f), fy = fmaf(scale, py, 0.5f), fz = fmaf(scale, pz, 0.5f);
+    const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+    const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
+    const float wx1 = fx - flx, wy1 = fy - fly, wz1 = fz - flz;
+    const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
+    const float wxy[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+    const uint32_t my = HASHED ? 2654435761u : res, mz = HASHED ? 805459861u : res * res;
+    const uint32_t ty0 = gy * my, tz0 = gz * mz;
+    const uint32_t ty[2] = {ty0, ty0 + my}, tz[2] = {tz0, tz0 + mz};
+    const uint32_t mask = size - 1u;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const uint32_t a = ty[p & 1], b = tz[p >> 1];
+        const uint32_t yz = HASHED ? (a ^ b) : (a + b);
+#pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+            const int k = 2 * p + dx;
+            uint32_t e;
+            if constexpr (HASHED) {
+                e = ((gx + dx) ^ yz) & mask;
+            } else {
+                e = gx + dx + yz;
+                e = e >= size ? e - size : e;
+                e = min(e, mask);
+            }
+            c.w[k] = wxy[k & 3] * ((k & 4) ? wz1 : wz0);
+            c.e[k] = off + e;
+        }
+    }
+}
 // fp16 feature pairs are fetched with buffer loads: one 128-bit descriptor for the table, 32-bit byte offsets per lane
 // (no 64-bit address arithmetic per gather; out-of-range offsets return 0 instead of faulting)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_table_rsrc(const void* table, uint32_t bytes) {

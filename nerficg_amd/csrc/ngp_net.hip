@@ -219,7 +219,8 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
             for (int q = 0; q < 4; q++) {
                 const int level = 4 * grp + q;
                 Corner8 c;
-                grid_corners(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], g.hashed[level] != 0, c);
+                if (g.hashed[level]) grid_corners_u<true>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
+                else grid_corners_u<false>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
                 float f0, f1;
                 grid_level_features(trs, c, f0, f1);
                 const __half2 h = __floats2half2_rn(f0, f1);
@@ -799,7 +800,8 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, i
     const bool live = in_range && !(gf.x == 0.f && gf.y == 0.f);
     if (__ballot(live) == 0ull) return;
     Corner8 c;
-    grid_corners(x[3 * ic], x[3 * ic + 1], x[3 * ic + 2], g.scale[level], g.res[level], g.size[level], g.offset[level], g.hashed[level] != 0, c);
+    if (g.hashed[level]) grid_corners_u<true>(x[3 * ic], x[3 * ic + 1], x[3 * ic + 2], g.scale[level], g.res[level], g.size[level], g.offset[level], c);
+    else grid_corners_u<false>(x[3 * ic], x[3 * ic + 1], x[3 * ic + 2], g.scale[level], g.res[level], g.size[level], g.offset[level], c);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const uint32_t key = live ? c.e[k] : (0xffffff00u | (uint32_t)lane);  // dead lanes: unique keys, they only split runs
