@@ -210,15 +210,13 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, GsCam cam, const floa
     }
 }
 
-// ---- binning without contended global atomics -----------------------------------------------------------------------
-// NB persistent workgroups each own a contiguous slice of the Gaussians.  Pass 1 builds the slice's tile histogram in LDS
-// (ds atomics), pass 2 (after a column scan over the NB x n_tiles matrix) turns the histogram into LDS cursors and scatters
-// the slice's instances: every instance costs two LDS atomics and one 8-byte store, no global atomic at all (the first
-// version spent 2.4 ms of a 4 ms forward on 16.7 M atomics onto 4 346 addresses, profiles/r01_gs_*).
+// ---- binning without global atomics and without a per-tile sort ----------------------------------------------------------
+// History (profiles/): v1 global atomics onto 4 346 tile counters = 2.4 ms of a 4 ms forward; v2 LDS histograms per
+// workgroup slice + (tile|depth) keys + per-tile bitonic sorts; v3 depth pre-sort + LDS-atomic scatter + segmented finishing
+// sort (0.39 ms); v4 (this one) depth pre-sort + STABLE wave walk, which makes the scatter itself produce the sorted lists.
 // ---- depth pre-sort of the P Gaussians (LSD radix, 4 x 8 bits, stable: equal depths keep ascending index) ---------------
-// Sorting the P Gaussians once by depth (8 B x P x 4 passes) replaces sorting the D >> P instances per tile: when the slices of
-// the binning passes below are taken from the depth-ordered list, every tile's segment arrives as a concatenation of
-// depth-ordered sub-segments (one per slice), and only those tiny sub-segments have to be sorted.
+// Sorting the P Gaussians once by depth (8 B x P x 4 passes) replaces sorting the D >> P instances per tile: the binning
+// passes below take their slices from the depth-ordered list and keep that order inside every tile.
 #define RS_ITEMS 16                  // keys per thread per block
 #define RS_TILE (256 * RS_ITEMS)     // keys per block
 __global__ void __launch_bounds__(256) k_depth_keys(int P, const int32_t* __restrict__ radii, const float* __restrict__ depths,
@@ -228,7 +226,9 @@ __global__ void __launch_bounds__(256) k_depth_keys(int P, const int32_t* __rest
     keys[i] = radii[i] > 0 ? __float_as_uint(depths[i]) : 0xffffffffu;  // invisible Gaussians go last
     vals[i] = (uint32_t)i;
 }
-__global__ void __launch_bounds__(256) k_radix_count(int n, int shift, int nblk, const uint32_t* __restrict__ keys, uint32_t* __restrict__ counts) {
+// counts: digit-major [256][nblk4] (rows padded to a multiple of 4 for 16-byte loads); tot[256] = digit totals (atomics)
+__global__ void __launch_bounds__(256) k_radix_count(int n, int shift, int nblk4, const uint32_t* __restrict__ keys, uint32_t* __restrict__ counts,
+                                                     uint32_t* __restrict__ tot) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -239,48 +239,45 @@ __global__ void __launch_bounds__(256) k_radix_count(int n, int shift, int nblk,
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    counts[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];  // digit-major: the scan order of a stable LSD pass
+    const uint32_t c = h[threadIdx.x];
+    counts[(size_t)threadIdx.x * nblk4 + blockIdx.x] = c;  // digit-major: the scan order of a stable LSD pass
+    if (c) atomicAdd(&tot[threadIdx.x], c);
 }
-__global__ void __launch_bounds__(1024) k_scan_u32(uint32_t* __restrict__ a, int n) {
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
+// The global offset of (digit d, block b) = sum of tot[d' < d] + sum of counts[d][b' < b]: every scatter workgroup derives its
+// 256 offsets itself (thread d reads a prefix of row d with 16-byte loads) instead of waiting for a scan kernel over the whole
+// 256 x nblk matrix, which is latency-bound in a single workgroup (37 us per pass measured, more than count + scatter together).
+__global__ void __launch_bounds__(256) k_radix_scatter(int n, int shift, int nblk4, const uint32_t* __restrict__ keys_in,
+                                                       const uint32_t* __restrict__ vals_in, const uint32_t* __restrict__ counts,
+                                                       const uint32_t* __restrict__ tot, uint32_t* __restrict__ keys_out,
+                                                       uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t base_s[256];
+    __shared__ uint32_t whist[4][256];
+    __shared__ uint32_t wtot[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 4096) {
-        const int i = base + 4 * threadIdx.x;
-        uint32_t v[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = (i + k) < n ? a[i + k] : 0u;
-        const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
-        uint32_t incl = tsum;
+    {
+        const uint32_t mine = tot[threadIdx.x];
+        uint32_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t o = __shfl_up(incl, d, 64);
             if (lane >= d) incl += o;
         }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t off = carry_s;
-        for (int w = 0; w < wave; w++) off += wave_tot[w];
-        uint32_t run = off + incl - tsum;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if ((i + k) < n) a[i + k] = run;
-            run += v[k];
+        if (lane == 63) wtot[wave] = incl;
+        const uint32_t* row = counts + (size_t)threadIdx.x * nblk4;
+        const int nb = (int)blockIdx.x;
+        uint32_t pre = 0;
+        int b = 0;
+#pragma unroll 4
+        for (; b + 4 <= nb; b += 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(row + b);
+            pre += v.x + v.y + v.z + v.w;
         }
+        for (; b < nb; b++) pre += row[b];
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = off + incl;
-        __syncthreads();
+        uint32_t off = incl - mine + pre;
+        for (int w = 0; w < wave; w++) off += wtot[w];
+        base_s[threadIdx.x] = off;
     }
-}
-__global__ void __launch_bounds__(256) k_radix_scatter(int n, int shift, int nblk, const uint32_t* __restrict__ keys_in,
-                                                       const uint32_t* __restrict__ vals_in, const uint32_t* __restrict__ offsets,
-                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-    __shared__ uint32_t base_s[256];
-    __shared__ uint32_t whist[4][256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    base_s[threadIdx.x] = offsets[(size_t)threadIdx.x * nblk + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < 4; w++) whist[w][threadIdx.x] = 0;
     __syncthreads();
@@ -318,85 +315,154 @@ __global__ void __launch_bounds__(256) k_radix_scatter(int n, int shift, int nbl
 }
 
 #define GS_MAX_LDS_TILES 16384
-__global__ void __launch_bounds__(256) k_tile_hist(int P, int chunk, int gx, int gy, const uint32_t* __restrict__ order,
-                                                   const int32_t* __restrict__ radii, const float* __restrict__ points_xy,
-                                                   uint32_t* __restrict__ hist) {
-    extern __shared__ uint32_t lh[];
-    const int n_tiles = gx * gy;
-    for (int t = threadIdx.x; t < n_tiles; t += 256) lh[t] = 0u;
+#define GS_SLICE_MAX 2048  // slices = waves of the binning passes
+#define GS_GROUPS 32       // slice groups of the two-level column scan over the slices x tiles matrix
+// ---- stable binning: one WAVE per slice of the depth-ordered Gaussians ----------------------------------------------------
+// Counting pass: lane = Gaussian, LDS atomics (order is irrelevant for counts).
+// slice = blockIdx.  (An XCD-contiguous mapping -- slice = (blockIdx % 8) * nb/8 + blockIdx / 8, so that the id writes falling
+// into one cache line come from one XCD's L2 -- was measured slower, 172 vs 138 us: the invisible tail of the depth order then
+// sits on one XCD and the other seven carry 8/7 of the work.)
+__device__ __forceinline__ int xcd_slice(int nb) { return (int)blockIdx.x < nb ? (int)blockIdx.x : -1; }
+__global__ void __launch_bounds__(64) k_bin_count(int P, int nb, int chunk, int gx, int gy, const uint32_t* __restrict__ order,
+                                                  const int32_t* __restrict__ radii, const float* __restrict__ points_xy,
+                                                  uint32_t* __restrict__ hist) {
+    extern __shared__ uint32_t lt[];
+    const int n_tiles = gx * gy, lane = threadIdx.x;
+    const int slice = xcd_slice(nb);
+    if (slice < 0) return;
+    for (int t = lane; t < n_tiles; t += 64) lt[t] = 0u;
     __syncthreads();
-    const int begin = blockIdx.x * chunk, end = min(P, begin + chunk);
-    for (int j = begin + threadIdx.x; j < end; j += 256) {
-        const int i = (int)order[j];  // depth order
-        const int r = radii[i];
+    const int begin = slice * chunk, end = min(P, begin + chunk);
+    for (int j = begin + lane; j < end; j += 64) {
+        const int id = (int)order[j];
+        const int r = radii[id];
         if (r <= 0) continue;
-        const float pxy[2] = {points_xy[2 * i], points_xy[2 * i + 1]};
+        const float pxy[2] = {points_xy[2 * id], points_xy[2 * id + 1]};
         int rmin[2], rmax[2];
         tile_rect(pxy, r, gx, gy, rmin, rmax);
         for (int y = rmin[1]; y < rmax[1]; y++)
-            for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&lh[y * gx + x], 1u);
+            for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&lt[y * gx + x], 1u);
     }
     __syncthreads();
-    uint32_t* out = hist + (size_t)blockIdx.x * n_tiles;
-    for (int t = threadIdx.x; t < n_tiles; t += 256) out[t] = lh[t];
+    uint32_t* row = hist + (size_t)slice * n_tiles;
+    for (int t = lane; t < n_tiles; t += 64) row[t] = lt[t];
 }
-// column sums / column exclusive scans of the NB x n_tiles histogram matrix: 64 tiles x 4 slice groups per workgroup
-__global__ void __launch_bounds__(256) k_tile_totals(int nb, int n_tiles, const uint32_t* __restrict__ hist, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t part[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int t = blockIdx.x * 64 + tx;
-    const int per = (nb + 3) / 4, b0 = ty * per, b1 = min(nb, b0 + per);
-    uint32_t s = 0;
-    if (t < n_tiles) {
-#pragma unroll 8
-        for (int b = b0; b < b1; b++) s += hist[(size_t)b * n_tiles + t];
-    }
-    part[ty][tx] = s;
+// Scatter pass: the wave walks its slice in depth order, one Gaussian per step, lanes = the tiles of that Gaussian's rectangle.
+// The tiles of one rectangle are distinct, so the per-tile cursors in LDS are plain read-modify-writes (no atomics), and because
+// steps run in program order every tile receives its Gaussians in depth order: the ids land directly in their final, sorted
+// positions -- no (tile|depth) keys, no per-tile sort.  (A variant with four 16-lane Gaussians per step and a claim byte per tile
+// to detect shared tiles was measured at 2x the time: rectangles are heavy-tailed, large ones need 4x the rounds at 16 lanes.)
+__global__ void __launch_bounds__(64) k_bin_scatter(int P, int nb, int chunk, int gx, int gy, const uint32_t* __restrict__ order,
+                                                    const int32_t* __restrict__ radii, const float* __restrict__ points_xy,
+                                                    const uint32_t* __restrict__ bases, int32_t* __restrict__ point_list) {
+    extern __shared__ uint32_t lt[];
+    const int n_tiles = gx * gy, lane = threadIdx.x;
+    const int slice = xcd_slice(nb);
+    if (slice < 0) return;
+    const uint32_t* row = bases + (size_t)slice * n_tiles;
+    for (int t = lane; t < n_tiles; t += 64) lt[t] = row[t];
     __syncthreads();
-    if (ty == 0 && t < n_tiles) counts[t] = part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
+    const int begin = slice * chunk, end = min(P, begin + chunk);
+    for (int j0 = begin; j0 < end; j0 += 64) {
+        const int j = j0 + lane;
+        int id = 0;
+        uint32_t org = 0u, ext = 0u;  // x0 | y0 << 16,  w | h << 16
+        if (j < end) {
+            id = (int)order[j];
+            const int r = radii[id];
+            if (r > 0) {
+                const float pxy[2] = {points_xy[2 * id], points_xy[2 * id + 1]};
+                int rmin[2], rmax[2];
+                tile_rect(pxy, r, gx, gy, rmin, rmax);
+                org = (uint32_t)rmin[0] | (uint32_t)rmin[1] << 16;
+                ext = (uint32_t)(rmax[0] - rmin[0]) | (uint32_t)(rmax[1] - rmin[1]) << 16;
+                if ((ext & 0xffffu) == 0u || (ext >> 16) == 0u) ext = 0u;
+            }
+        }
+        const uint32_t wq = ext & 0xffffu;
+        const uint32_t magic = wq > 1u ? 0xffffffffu / wq + 1u : 0u;  // c / w == umulhi(c, magic) for c < 2^16, w >= 2
+        unsigned long long todo = __ballot(ext != 0u);
+        while (todo) {
+            const int u = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint32_t uorg = (uint32_t)__builtin_amdgcn_readlane((int)org, u), uext = (uint32_t)__builtin_amdgcn_readlane((int)ext, u);
+            const int uid = __builtin_amdgcn_readlane(id, u);
+            const uint32_t um = (uint32_t)__builtin_amdgcn_readlane((int)magic, u);
+            const int ux0 = uorg & 0xffffu, uy0 = uorg >> 16, uw = uext & 0xffffu, uh = uext >> 16;
+            const int un = uw * uh;
+            for (int c0 = 0; c0 < un; c0 += 64) {
+                const int c = c0 + lane;
+                if (c < un) {
+                    const int yy = uw == 1 ? c : (int)__umulhi((uint32_t)c, um);
+                    const int t = (uy0 + yy) * gx + ux0 + (c - yy * uw);
+                    const uint32_t slot = lt[t];
+                    lt[t] = slot + 1u;
+                    point_list[slot] = uid;
+                }
+            }
+        }
+    }
 }
-__global__ void __launch_bounds__(256) k_tile_bases(int nb, int n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t part[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+// column sums per slice group: part[g][t] = sum of hist[b][t] over the slices b of group g   (64 tiles x 4 groups per workgroup)
+__global__ void __launch_bounds__(256) k_tile_totals(int nb, int n_tiles, const uint32_t* __restrict__ hist, uint32_t* __restrict__ part) {
+    const int tx = threadIdx.x & 63, g = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int t = blockIdx.x * 64 + tx;
-    const int per = (nb + 3) / 4, b0 = ty * per, b1 = min(nb, b0 + per);
-    uint32_t s = 0;
-    if (t < n_tiles) {
-#pragma unroll 8
-        for (int b = b0; b < b1; b++) s += hist[(size_t)b * n_tiles + t];
-    }
-    part[ty][tx] = s;
-    __syncthreads();
+    const int per = (nb + GS_GROUPS - 1) / GS_GROUPS, b0 = min(nb, g * per), b1 = min(nb, b0 + per);
     if (t >= n_tiles) return;
-    uint32_t run = ranges[2 * t];
-    for (int g = 0; g < ty; g++) run += part[g][tx];
+    uint32_t s = 0;
+#pragma unroll 8
+    for (int b = b0; b < b1; b++) s += hist[(size_t)b * n_tiles + t];
+    part[(size_t)g * n_tiles + t] = s;
+}
+// hist[b][t] <- first output position of slice b in tile t (exclusive column scan inside the group, seeded with the group base)
+__global__ void __launch_bounds__(256) k_tile_bases(int nb, int n_tiles, const uint32_t* __restrict__ part, uint32_t* __restrict__ hist) {
+    const int tx = threadIdx.x & 63, g = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int t = blockIdx.x * 64 + tx;
+    const int per = (nb + GS_GROUPS - 1) / GS_GROUPS, b0 = min(nb, g * per), b1 = min(nb, b0 + per);
+    if (t >= n_tiles) return;
+    uint32_t run = part[(size_t)g * n_tiles + t];
+#pragma unroll 8
     for (int b = b0; b < b1; b++) {
         const uint32_t c = hist[(size_t)b * n_tiles + t];
         hist[(size_t)b * n_tiles + t] = run;
         run += c;
     }
 }
-__global__ void __launch_bounds__(256) k_scatter_lds(int P, int chunk, int gx, int gy, const uint32_t* __restrict__ order,
-                                                     const int32_t* __restrict__ radii, const float* __restrict__ depths,
-                                                     const float* __restrict__ points_xy, const uint32_t* __restrict__ bases,
-                                                     uint64_t* __restrict__ keys) {
-    extern __shared__ uint32_t cur[];
-    const int n_tiles = gx * gy;
-    const uint32_t* in = bases + (size_t)blockIdx.x * n_tiles;
-    for (int t = threadIdx.x; t < n_tiles; t += 256) cur[t] = in[t];
+// tile ranges from the group sums; part[g][t] becomes the first output position of group g in tile t
+__global__ void __launch_bounds__(1024) k_scan_tiles_grouped(uint32_t* __restrict__ part, int n, uint32_t* __restrict__ ranges,
+                                                             uint32_t* __restrict__ fill, int64_t* __restrict__ num_rendered) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    const int begin = blockIdx.x * chunk, end = min(P, begin + chunk);
-    for (int j = begin + threadIdx.x; j < end; j += 256) {
-        const int i = (int)order[j];
-        const int r = radii[i];
-        if (r <= 0) continue;
-        const float pxy[2] = {points_xy[2 * i], points_xy[2 * i + 1]};
-        int rmin[2], rmax[2];
-        tile_rect(pxy, r, gx, gy, rmin, rmax);
-        const uint64_t key = ((uint64_t)__float_as_uint(depths[i]) << 32) | (uint32_t)i;
-        for (int y = rmin[1]; y < rmax[1]; y++)
-            for (int x = rmin[0]; x < rmax[0]; x++) keys[atomicAdd(&cur[y * gx + x], 1u)] = key;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        uint32_t pv[GS_GROUPS];
+        uint32_t v = 0;
+#pragma unroll
+        for (int g = 0; g < GS_GROUPS; g++) { pv[g] = i < n ? part[(size_t)g * n + i] : 0u; v += pv[g]; }
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (int w = 0; w < wave; w++) off += wave_tot[w];
+        if (i < n) {
+            uint32_t run = off + incl - v;
+            ranges[2 * i] = run; ranges[2 * i + 1] = off + incl; fill[i] = 0u;
+#pragma unroll
+            for (int g = 0; g < GS_GROUPS; g++) { part[(size_t)g * n + i] = run; run += pv[g]; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + incl;
+        __syncthreads();
     }
+    if (threadIdx.x == 0) *num_rendered = (int64_t)carry_s;
 }
 
 // ------------------------------------------------------------------------------------------------ 2. tile ranges
@@ -472,77 +538,6 @@ __device__ __forceinline__ void bitonic_sort_any(uint64_t* a, int n) {
         }
     }
 }
-// Per-tile finishing sort for the depth-presorted path: the tile's list is the concatenation of NB sub-segments (one per
-// binning slice, boundaries = the cursor bases), already ordered relative to each other and a few elements long each.  The
-// workgroup walks the list in LDS-sized windows aligned to sub-segment boundaries and runs a SEGMENTED odd-even transposition
-// sort on the window: uniform control flow (no per-lane sorting loops), max-sub-segment-length phases of one compare-exchange
-// per pair that does not straddle a boundary.  Sub-segments longer than SEG_LONG get the bitonic network first (rare).
-#define SEG_WIN 4096
-#define SEG_MAX_NB 1024
-#define SEG_LONG 64
-__global__ void __launch_bounds__(256) k_sort_segments(int nb, int n_tiles, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ bases,
-                                                       uint64_t* __restrict__ keys, int32_t* __restrict__ point_list) {
-    __shared__ uint64_t win[SEG_WIN];
-    __shared__ uint32_t seg[SEG_MAX_NB + 1];
-    __shared__ uint8_t starts[SEG_WIN + 1];
-    __shared__ int s_end_sh, maxlen_sh;
-    const int t = blockIdx.x;
-    const uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
-    if (r1 == r0) return;
-    // the histogram matrix still holds the START of every sub-segment (b, t) (the scatter consumed a copy as its cursors)
-    for (int b = threadIdx.x; b < nb; b += 256) seg[b] = bases[(size_t)b * n_tiles + t];
-    if (threadIdx.x == 0) seg[nb] = r1;
-    __syncthreads();
-    int s0 = 0;
-    while (s0 < nb) {
-        const uint32_t w0 = seg[s0];
-        if (w0 >= r1) break;
-        if (threadIdx.x == 0) { s_end_sh = s0; maxlen_sh = 0; }
-        __syncthreads();
-        for (int b = s0 + threadIdx.x; b < nb; b += 256)
-            if (seg[b + 1] - w0 <= SEG_WIN) atomicMax(&s_end_sh, b + 1);  // last sub-segment that still fits the window
-        __syncthreads();
-        const int s1 = s_end_sh;
-        if (s1 == s0) {  // one sub-segment larger than the window: bitonic network in global memory
-            const uint32_t a = seg[s0], e = seg[s0 + 1];
-            bitonic_sort_any(keys + a, (int)(e - a));
-            for (uint32_t i = a + threadIdx.x; i < e; i += 256) point_list[i] = (int32_t)(uint32_t)keys[i];
-            __syncthreads();
-            s0 = s0 + 1;
-            continue;
-        }
-        const uint32_t w1 = seg[s1];
-        const int n = (int)(w1 - w0);
-        for (int i = threadIdx.x; i < n; i += 256) { win[i] = keys[w0 + i]; starts[i] = 0; }
-        __syncthreads();
-        for (int b = s0 + threadIdx.x; b < s1; b += 256) {
-            const int len = (int)(seg[b + 1] - seg[b]);
-            if (len > 0) { starts[seg[b] - w0] = 1; atomicMax(&maxlen_sh, len); }
-        }
-        __syncthreads();
-        int phases = maxlen_sh;
-        if (phases > SEG_LONG) {
-            for (int b = s0; b < s1; b++) {
-                const int len = (int)(seg[b + 1] - seg[b]);
-                if (len > SEG_LONG) bitonic_sort_any(win + (seg[b] - w0), len);  // uniform branch: seg[] is shared
-            }
-            phases = SEG_LONG;
-        }
-        for (int ph = 0; ph < phases; ph++) {
-            for (int i = 2 * threadIdx.x + (ph & 1); i + 1 < n; i += 512) {
-                if (!starts[i + 1]) {
-                    const uint64_t x = win[i], y = win[i + 1];
-                    if (x > y) { win[i] = y; win[i + 1] = x; }
-                }
-            }
-            __syncthreads();
-        }
-        for (int i = threadIdx.x; i < n; i += 256) point_list[w0 + i] = (int32_t)(uint32_t)win[i];
-        __syncthreads();
-        s0 = s1;
-    }
-}
-
 // capacity classes: a workgroup only handles tiles whose segment length lies in (LO, CAP] so that small tiles do not reserve
 // the LDS of the largest ones (LDS, not registers, limits how many tiles a CU sorts concurrently)
 template <int LO, int CAP>
@@ -892,21 +887,32 @@ __global__ void __launch_bounds__(256) k_preprocess_bw(int P, GsCam cam, const f
     }
 }
 
-int gs_bin_blocks(int P) { const int nb = (int)nrc_cdiv(P, 256); return nb < SEG_MAX_NB ? (nb > 0 ? nb : 1) : SEG_MAX_NB; }
-int gs_bin_chunk(int P) { const int nb = gs_bin_blocks(P); return (int)(nrc_cdiv(nrc_cdiv(P, nb), 256) * 256); }
-// binning workspace: [hist NB x n_tiles][keyA P][valA P][keyB P][valB P][radix counts 256 x nblk]   (all u32)
-struct BinWs { uint32_t *hist, *keyA, *valA, *keyB, *valB, *counts; int nblk; };
+// slices = waves; all of them should be resident at once: 160 KB of LDS per CU, (4 B x n_tiles) per wave, 256 CUs
+int gs_bin_blocks(int P, int n_tiles) {
+    int per_cu = (int)((160 * 1024) / ((int64_t)n_tiles * 4 + 512));
+    per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+    const int cap = per_cu * 256 < GS_SLICE_MAX ? per_cu * 256 : GS_SLICE_MAX;
+    const int nb = (int)nrc_cdiv(P, 256);
+    return nb < cap ? (nb > 0 ? nb : 1) : cap;
+}
+int gs_bin_chunk(int P, int n_tiles) { const int nb = gs_bin_blocks(P, n_tiles); return (int)(nrc_cdiv(nrc_cdiv(P > 0 ? P : 1, nb), 64) * 64); }
+// binning workspace: [hist NB x n_tiles][part GS_GROUPS x n_tiles][keyA P][valA P][keyB P][valB P][pad][radix counts 256 x nblk4][tot 4 x 256]  (u32)
+struct BinWs { uint32_t *hist, *part, *keyA, *valA, *keyB, *valB, *counts, *tot; int nblk, nblk4; };
 int64_t gs_bin_ws_words(int P, int n_tiles) {
     const int64_t nblk = nrc_cdiv(P > 0 ? P : 1, RS_TILE);
-    return (int64_t)gs_bin_blocks(P) * n_tiles + 4 * (int64_t)(P > 0 ? P : 1) + 256 * nblk + 64;
+    return (int64_t)(gs_bin_blocks(P, n_tiles) + GS_GROUPS) * n_tiles + 4 * (int64_t)(P > 0 ? P : 1) + 256 * (nblk + 4) + 1024 + 64;
 }
 BinWs gs_bin_ws(uint32_t* base, int P, int n_tiles) {
     BinWs w;
     const int64_t p1 = P > 0 ? P : 1;
     w.nblk = (int)nrc_cdiv(p1, RS_TILE);
     w.hist = base;
-    w.keyA = w.hist + (int64_t)gs_bin_blocks(P) * n_tiles;
-    w.valA = w.keyA + p1; w.keyB = w.valA + p1; w.valB = w.keyB + p1; w.counts = w.valB + p1;
+    w.part = w.hist + (int64_t)gs_bin_blocks(P, n_tiles) * n_tiles;
+    w.keyA = w.part + (int64_t)GS_GROUPS * n_tiles;
+    w.valA = w.keyA + p1; w.keyB = w.valA + p1; w.valB = w.keyB + p1;
+    w.nblk4 = (w.nblk + 3) / 4 * 4;
+    w.counts = base + ((w.valB + p1 - base) + 3) / 4 * 4;  // 16-byte aligned rows (base itself comes 256-byte aligned from the caller)
+    w.tot = w.counts + (int64_t)256 * w.nblk4;
     return w;
 }
 
@@ -959,24 +965,25 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                            cov3D_precomp, radii, depths, points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched,
                            lds_path ? (uint32_t*)nullptr : tile_counts);
         if (lds_path) {
-            const int nb = gs_bin_blocks(P), chunk = gs_bin_chunk(P);
+            const int nb = gs_bin_blocks(P, n_tiles), chunk = gs_bin_chunk(P, n_tiles);
             const BinWs w = gs_bin_ws(bin_hist, P, n_tiles);
             // depth pre-sort of the Gaussians: 4 stable 8-bit passes, (keyA,valA) -> ... -> (keyA,valA); valA = depth order
             hipLaunchKernelGGL(k_depth_keys, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, radii, depths, w.keyA, w.valA);
+            hipMemsetAsync(w.tot, 0, sizeof(uint32_t) * 4 * 256, s);
             for (int pass = 0; pass < 4; pass++) {
                 const uint32_t *ki = (pass & 1) ? w.keyB : w.keyA, *vi = (pass & 1) ? w.valB : w.valA;
                 uint32_t *ko = (pass & 1) ? w.keyA : w.keyB, *vo = (pass & 1) ? w.valA : w.valB;
-                hipLaunchKernelGGL(k_radix_count, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk, ki, w.counts);
-                hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, w.counts, 256 * w.nblk);
-                hipLaunchKernelGGL(k_radix_scatter, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk, ki, vi, w.counts, ko, vo);
+                hipLaunchKernelGGL(k_radix_count, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk4, ki, w.counts, w.tot + 256 * pass);
+                hipLaunchKernelGGL(k_radix_scatter, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk4, ki, vi, w.counts, w.tot + 256 * pass, ko, vo);
             }
-            hipLaunchKernelGGL(k_tile_hist, dim3(nb), dim3(256), n_tiles * sizeof(uint32_t), s, P, chunk, cam.gx, cam.gy, w.valA, radii, points_xy, w.hist);
-            hipLaunchKernelGGL(k_tile_totals, dim3(nrc_cdiv(n_tiles, 64)), dim3(256), 0, s, nb, n_tiles, w.hist, tile_counts);
+            const dim3 cgrid((unsigned)nrc_cdiv(n_tiles, 64), GS_GROUPS / 4);
+            hipLaunchKernelGGL(k_bin_count, dim3((nb + 7) / 8 * 8), dim3(64), n_tiles * sizeof(uint32_t), s, P, nb, chunk, cam.gx, cam.gy, w.valA, radii, points_xy, w.hist);
+            hipLaunchKernelGGL(k_tile_totals, cgrid, dim3(256), 0, s, nb, n_tiles, w.hist, w.part);
+            hipLaunchKernelGGL(k_scan_tiles_grouped, dim3(1), dim3(1024), 0, s, w.part, n_tiles, ranges, tile_fill, num_rendered);
+            hipLaunchKernelGGL(k_tile_bases, cgrid, dim3(256), 0, s, nb, n_tiles, w.part, w.hist);
         }
     }
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, n_tiles, ranges, tile_fill, num_rendered);
-    if (P > 0 && lds_path)
-        hipLaunchKernelGGL(k_tile_bases, dim3(nrc_cdiv(n_tiles, 64)), dim3(256), 0, s, gs_bin_blocks(P), n_tiles, ranges, gs_bin_ws(bin_hist, P, n_tiles).hist);
+    if (!(P > 0 && lds_path)) hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, n_tiles, ranges, tile_fill, num_rendered);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
@@ -994,11 +1001,12 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
         const int n_tiles = cam.gx * cam.gy;
         if (n_tiles <= GS_MAX_LDS_TILES && bin_hist) {
             const BinWs w = gs_bin_ws(const_cast<uint32_t*>(bin_hist), P, n_tiles);
-            const int nb = gs_bin_blocks(P);
-            // the scatter consumes a COPY of the bases as LDS cursors; the matrix keeps the sub-segment starts for the finishing sort
-            hipLaunchKernelGGL(k_scatter_lds, dim3(nb), dim3(256), n_tiles * sizeof(uint32_t), s, P, gs_bin_chunk(P), cam.gx, cam.gy, w.valA, radii,
-                               depths, points_xy, w.hist, keys);
-            hipLaunchKernelGGL(k_sort_segments, dim3(n_tiles), dim3(256), 0, s, nb, n_tiles, ranges, w.hist, keys, point_list);
+            // the same depth-ordered walk as the counting pass, now with the scanned matrix rows as LDS cursors: ids land sorted
+            static const hipError_t lds_attr = hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+            (void)lds_attr;  // tile grids above 12 K tiles need more than the default 64 KB of dynamic LDS
+            const int nb = gs_bin_blocks(P, n_tiles);
+            hipLaunchKernelGGL(k_bin_scatter, dim3((nb + 7) / 8 * 8), dim3(64), n_tiles * 4, s, P, nb, gs_bin_chunk(P, n_tiles), cam.gx, cam.gy,
+                               w.valA, radii, points_xy, w.hist, point_list);
         } else {
             hipLaunchKernelGGL(k_scatter, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, ranges, tile_fill, keys);
             hipLaunchKernelGGL((k_sort_tiles<0, 1024>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
