@@ -134,16 +134,15 @@ __device__ __forceinline__ void tile_rect(const float* p, int radius, int gx, in
 }
 
 // ------------------------------------------------------------------------------------------------ 1. preprocess
-__global__ void __launch_bounds__(256) k_preprocess(int P, GsCam cam, const float* __restrict__ means3D, const float* __restrict__ shs,
-                                                    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
-                                                    const float* __restrict__ scales, const float* __restrict__ rotations,
-                                                    const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii,
-                                                    float* __restrict__ depths, float* __restrict__ points_xy,
-                                                    float* __restrict__ conic_opacity, float* __restrict__ rgb, uint8_t* __restrict__ clamped,
-                                                    float* __restrict__ cov3D, uint32_t* __restrict__ tiles_touched,
-                                                    uint32_t* __restrict__ tile_counts) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
+// one Gaussian; sh_row = its SH coefficients (LDS copy, see k_preprocess)
+__device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const float* __restrict__ means3D, const float* sh_row,
+                                               const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                                               const float* __restrict__ scales, const float* __restrict__ rotations,
+                                               const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii,
+                                               float* __restrict__ depths, float* __restrict__ points_xy,
+                                               float* __restrict__ conic_opacity, float* __restrict__ rgb, uint8_t* __restrict__ clamped,
+                                               float* __restrict__ cov3D, uint32_t* __restrict__ tiles_touched,
+                                               uint32_t* __restrict__ tile_counts) {
     radii[i] = 0; tiles_touched[i] = 0; depths[i] = 0.f;
     points_xy[2 * i] = 0.f; points_xy[2 * i + 1] = 0.f;
 #pragma unroll
@@ -194,7 +193,7 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, GsCam cam, const floa
     } else {
         float col[3];
         uint8_t cl;
-        sh_color(cam.D, p, cam.campos, shs + (size_t)i * cam.M * 3, col, &cl);
+        sh_color(cam.D, p, cam.campos, sh_row, col, &cl);
 #pragma unroll
         for (int k = 0; k < 3; k++) rgb[3 * i + k] = col[k];
         clamped[i] = cl;
@@ -208,6 +207,34 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, GsCam cam, const floa
         for (int y = rmin[1]; y < rmax[1]; y++)
             for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&tile_counts[y * cam.gx + x], 1u);
     }
+}
+// Workgroup = 128 Gaussians; their SH coefficients (one contiguous 128 x 3M float block) are staged through LDS with coalesced
+// loads -- a lane walking its own 192-byte row touches 48 cache lines per wave instruction (same staging as k_preprocess_bw).
+#define PRE_BLOCK 128
+#define PRE_MAXM 16
+__global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam, const float* __restrict__ means3D, const float* __restrict__ shs,
+                                                          const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                                                          const float* __restrict__ scales, const float* __restrict__ rotations,
+                                                          const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii,
+                                                          float* __restrict__ depths, float* __restrict__ points_xy,
+                                                          float* __restrict__ conic_opacity, float* __restrict__ rgb, uint8_t* __restrict__ clamped,
+                                                          float* __restrict__ cov3D, uint32_t* __restrict__ tiles_touched,
+                                                          uint32_t* __restrict__ tile_counts) {
+    __shared__ float s_sh[PRE_BLOCK * (3 * PRE_MAXM + 1)];
+    const int first = blockIdx.x * PRE_BLOCK, i = first + threadIdx.x;
+    const int row_len = 3 * cam.M, pitch = row_len + 1;
+    if (shs) {
+        const int count = min(PRE_BLOCK, P - first);
+        const float* src = shs + (size_t)first * row_len;
+        for (int k = threadIdx.x; k < count * row_len; k += PRE_BLOCK) {
+            const int r = k / row_len;
+            s_sh[r * pitch + (k - r * row_len)] = src[k];
+        }
+        __syncthreads();
+    }
+    if (i < P)
+        preprocess_one(i, cam, means3D, s_sh + threadIdx.x * pitch, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, depths,
+                       points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched, tile_counts);
 }
 
 // ---- binning without global atomics and without a per-tile sort ----------------------------------------------------------
@@ -562,6 +589,10 @@ __global__ void __launch_bounds__(256) k_sort_tiles(const uint32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ 5. render
+// thread -> pixel of the 16x16 tile: every wave owns an 8x8 quadrant (not a 16x4 strip), so that fewer Gaussians of the tile list
+// touch a given wave (smaller perimeter) and more steps are skipped with the whole wave inactive
+__device__ __forceinline__ int tile_px(unsigned t) { return (int)((t & 7u) + ((t >> 6) & 1u) * 8u); }
+__device__ __forceinline__ int tile_py(unsigned t) { return (int)(((t >> 3) & 7u) + (t >> 7) * 8u); }
 __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
                                                 const float* __restrict__ points_xy, const float* __restrict__ conic_opacity,
                                                 const float* __restrict__ rgb, float bg0, float bg1, float bg2, float* __restrict__ out_color,
@@ -571,7 +602,7 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
     __shared__ float4 s_co[BATCH];
     __shared__ float s_rgb[BATCH * 3];
     const int tile = blockIdx.y * cam.gx + blockIdx.x;
-    const int px = blockIdx.x * TILE + (threadIdx.x & 15), py = blockIdx.y * TILE + (threadIdx.x >> 4);
+    const int px = blockIdx.x * TILE + tile_px(threadIdx.x), py = blockIdx.y * TILE + tile_py(threadIdx.x);
     const bool inside = px < cam.W && py < cam.H;
     const float fx = (float)px, fy = (float)py;
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
@@ -642,7 +673,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
     __shared__ float s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 4 waves, flushed once per batch
     const int tile = blockIdx.y * cam.gx + blockIdx.x;
     const int lane = threadIdx.x & 63;
-    const int px = blockIdx.x * TILE + (threadIdx.x & 15), py = blockIdx.y * TILE + (threadIdx.x >> 4);
+    const int px = blockIdx.x * TILE + tile_px(threadIdx.x), py = blockIdx.y * TILE + tile_py(threadIdx.x);
     const bool inside = px < cam.W && py < cam.H;
     const float fx = (float)px, fy = (float)py;
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
@@ -1028,7 +1059,8 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
     hipMemsetAsync(tile_counts, 0, sizeof(uint32_t) * n_tiles, s);
     if (P > 0) {
         if (!means3D || !opacities || !radii || !depths || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !tiles_touched) return NRC_ERR_INVALID;
-        hipLaunchKernelGGL(k_preprocess, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam, means3D, shs, colors_precomp, opacities, scales, rotations,
+        if (shs && M > PRE_MAXM) return NRC_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(k_preprocess, dim3(nrc_cdiv(P, PRE_BLOCK)), dim3(PRE_BLOCK), 0, s, P, cam, means3D, shs, colors_precomp, opacities, scales, rotations,
                            cov3D_precomp, radii, depths, points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched,
                            lds_path ? (uint32_t*)nullptr : tile_counts);
         if (lds_path) {
