@@ -152,6 +152,8 @@ def _march_inputs(width, height, cascades=1, scale=0.5, radius=0.35, pose=(0.7, 
     dict(w=61, h=47, cascades=3, scale=2.0, esf=1.0 / 256, max_samples=1024),
     dict(w=40, h=40, cascades=1, scale=0.5, esf=0.0, max_samples=37),   # max_samples cap reached
     dict(w=1, h=1, cascades=1, scale=0.5, esf=0.0, max_samples=1024),
+    dict(w=256, h=160, cascades=1, scale=0.5, esf=0.0, max_samples=1024),  # > 32768 rays: thread-per-ray kernels (below: wave-per-ray)
+    dict(w=97, h=33, cascades=2, scale=1.0, esf=1.0 / 256, max_samples=64),
 ])
 def test_raymarching_train_bit_exact(vr, cfg):
     o, d, hits, bitfield = _march_inputs(cfg['w'], cfg['h'], cfg['cascades'], cfg['scale'], radius=0.35 * cfg['scale'] / 0.5)
