@@ -137,13 +137,17 @@ int nrc_nwie_forward(int32_t encoding, const void* input, int32_t input_ld, int6
 /* NetworkWithInputEncoding.backward through the MLP.  d_out / out: (M,out_ld) fp16 (upstream gradient of, and the forward
  * value of, the stored output columns).  Upstream gradients are multiplied by loss_scale before they are rounded to fp16
  * MFMA operands and every result is divided by it again (tiny-cuda-nn's internal loss scale).  grad_weights: f32, layout
- * of weights_f16, ACCUMULATED atomically (caller zeroes).  d_in (M,32) f32 = gradient w.r.t. the 32 encoded inputs. */
+ * of weights_f16, ACCUMULATED atomically (caller zeroes).  d_in f32 = gradient w.r.t. the 32 encoded inputs, laid out (M,32)
+ * (d_in_pair_major = 0) or as 16 feature pairs [16][M][2] (d_in_pair_major = 1: the layout nrc_grid_backward reads coalesced). */
 int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int32_t out_act, int32_t n_out_rows,
                       const void* d_out_f16, const void* out_f16, int32_t out_ld, const void* save_in,
-                      const void* save_acts, float loss_scale, float* grad_weights, float* d_in, nrc_stream_t stream);
-/* hash-grid backward: grad_table (entries,2) f32 += trilinear scatter of d_features (M, 2*n_levels) f32 (caller zeroes) */
-int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t n_levels, int32_t log2_hashmap_size,
-                      int32_t base_resolution, float per_level_scale, float* grad_table, nrc_stream_t stream);
+                      const void* save_acts, float loss_scale, float* grad_weights, float* d_in, int32_t d_in_pair_major,
+                      nrc_stream_t stream);
+/* hash-grid backward: grad_table (entries,2) f32 += trilinear scatter of d_features f32, (M, 2*n_levels) or pair-major
+ * [n_levels][M][2] (caller zeroes grad_table) */
+int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
+                      int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table,
+                      nrc_stream_t stream);
 /* InstantNGPRayRenderingComponent.query_model (Renderer.py:48-53) as an encode + MLP kernel pair over Infinity-Cache sized
  * chunks (workspace: nrc_ngp_query_ws_bytes(M) bytes): xyz01 (M,3) f32 in [0,1], dirs (M,3) f32 unit
  * vectors -> sigmas (M) f32 = exp(fp16 feature 0), rgbs (M,3) f32 = fp16 sigmoid outputs. */

@@ -631,7 +631,7 @@ template <int N_HIDDEN, int OUT_ACT>
 __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __restrict__ W, int n_out_rows, const __half* __restrict__ d_out,
                                                   const __half* __restrict__ out, int out_ld, const __half* __restrict__ save_in,
                                                   const __half* __restrict__ save_acts, float loss_scale, float* __restrict__ dW,
-                                                  float* __restrict__ d_in) {
+                                                  float* __restrict__ d_in, int d_in_pair_major) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[4][2][64 * LDP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     _Float16* T_act = lds[wv][0];
@@ -763,7 +763,13 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 float4 v = make_float4(din[4 * gq] * inv_scale, din[4 * gq + 1] * inv_scale, din[4 * gq + 2] * inv_scale, din[4 * gq + 3] * inv_scale);
-                *reinterpret_cast<float4*>(d_in + i * 32 + 8 * gq + 4 * hh) = v;
+                if (d_in_pair_major) {  // [16 pairs][M][2]: what the grid backward reads, coalesced over the samples
+                    const int pair = 4 * gq + 2 * hh;
+                    *reinterpret_cast<float2*>(d_in + ((int64_t)pair * M + i) * 2) = make_float2(v.x, v.y);
+                    *reinterpret_cast<float2*>(d_in + ((int64_t)(pair + 1) * M + i) * 2) = make_float2(v.z, v.w);
+                } else {
+                    *reinterpret_cast<float4*>(d_in + i * 32 + 8 * gq + 4 * hh) = v;
+                }
             }
         }
     }
@@ -783,20 +789,20 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
     for (int nt = 0; nt < 2; nt++) atomic_add_tile(gWop, 64, n_out_rows, 0, nt, gWo[nt], inv_scale, r, hh);
 }
 
-// hash-grid backward: one lane per (sample, level); scatter-add of w_corner * dL/dfeature into the f32 table gradient.
-// Scattered f32 atomics run at ~20 G/s chip-wide (MI355X_MICROARCH.md, "64 lanes in 64 different rows"), far below what the
-// rest of the step needs, so their NUMBER is what matters: neighbouring lanes are consecutive samples of a ray and, on all but
-// the finest levels, hit the same table entries.  Each corner's contributions are therefore combined over RUNS of equal entry
-// index inside the wave (segmented DPP scan: ~50 VALU ops, free next to the atomic unit) and only the last lane of a run
-// issues the atomic.
-__global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, GridCfg g,
-                                                  int n_levels, float* __restrict__ grad_table) {
-    const int level = blockIdx.y;
+// hash-grid backward, small / dense levels: one lane per (sample, level); scatter-add of w_corner * dL/dfeature into the f32 table
+// gradient.  Neighbouring lanes are consecutive samples of a ray and, on all but the finest levels, hit the same table entries:
+// each corner's contributions are combined over RUNS of equal entry index inside the wave (segmented scan) and only the last lane
+// of a run issues the atomic.  d_feat: pair-major [n_levels][M][2] or sample-major (M, 2 n_levels).
+struct LevelList { int n; int level[NRC_MAX_LEVELS]; };
+__global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, int pair_major, GridCfg g,
+                                                  int n_levels, LevelList ll, float* __restrict__ grad_table) {
+    const int level = ll.level[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool in_range = i < M;
     const int64_t ic = in_range ? i : M - 1;
-    float2 gf = *reinterpret_cast<const float2*>(d_feat + ic * 2 * n_levels + 2 * level);
+    const float2 gf = pair_major ? *reinterpret_cast<const float2*>(d_feat + ((int64_t)level * M + ic) * 2)
+                                 : *reinterpret_cast<const float2*>(d_feat + ic * 2 * n_levels + 2 * level);
     const bool live = in_range && !(gf.x == 0.f && gf.y == 0.f);
     if (__ballot(live) == 0ull) return;
     Corner8 c;
@@ -808,21 +814,72 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, i
         float v0 = live ? c.w[k] * gf.x : 0.f, v1 = live ? c.w[k] * gf.y : 0.f;
         const uint32_t prev = __shfl_up(key, 1, 64), next = __shfl_down(key, 1, 64);
         const bool head = lane == 0 || prev != key, tail = lane == 63 || next != key;
-        int start = head ? lane : 0;
+        if (__ballot(!head) != 0ull) {  // some run is longer than one lane
+            int start = head ? lane : 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(start, d, 64);
-            if (lane >= d) start = max(start, o);
-        }
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(start, d, 64);
+                if (lane >= d) start = max(start, o);
+            }
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const float o0 = __shfl_up(v0, d, 64), o1 = __shfl_up(v1, d, 64);
-            if (lane - d >= start) { v0 += o0; v1 += o1; }
+            for (int d = 1; d < 64; d <<= 1) {
+                const float o0 = __shfl_up(v0, d, 64), o1 = __shfl_up(v1, d, 64);
+                if (lane - d >= start) { v0 += o0; v1 += o1; }
+            }
         }
         if (live && tail) {
             float* p = grad_table + 2 * (size_t)key;
             atomicAdd(p, v0);
             atomicAdd(p + 1, v1);
+        }
+    }
+}
+
+// hash-grid backward, hashed levels of a large batch: OWNERSHIP instead of atomics.  Scattered f32 atomics run at ~20 G/s on this
+// chip whatever their locality (measured per level: 4.2 M atomics = 0.2 ms, 1.3 of the 1.5 ms of the whole backward), and a
+// sample's corners on these levels are pseudo-random, so nothing can be combined.  Instead every workgroup OWNS a 16 K-entry
+// slice of one level's table, keeps it in LDS (128 KB), walks ALL samples, recomputes their eight corner indices and keeps the
+// ones that fall into its slice (LDS atomics).  32x redundant index arithmetic, zero global atomics; the slice is added to the
+// gradient table with plain coalesced read-modify-writes (the workgroup is its only writer).
+#define OWN_ENTRIES 16384
+#define OWN_THREADS 1024
+struct OwnedCfg { int n_levels; int level[NRC_MAX_LEVELS]; int unit0[NRC_MAX_LEVELS + 1]; };
+__global__ void __launch_bounds__(OWN_THREADS) k_grid_bwd_owned(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, GridCfg g,
+                                                                OwnedCfg oc, float* __restrict__ grad_table) {
+    extern __shared__ float own_acc[];  // [OWN_ENTRIES][2]
+    int li = 0;
+    while (li + 1 < oc.n_levels && (int)blockIdx.x >= oc.unit0[li + 1]) li++;
+    const int level = oc.level[li];
+    const uint32_t chunk = (uint32_t)((int)blockIdx.x - oc.unit0[li]);
+    const uint32_t lo = g.offset[level] + chunk * OWN_ENTRIES;
+    const uint32_t n_own = min((uint32_t)OWN_ENTRIES, g.size[level] - chunk * OWN_ENTRIES);
+    for (uint32_t j = threadIdx.x; j < 2 * n_own; j += OWN_THREADS) own_acc[j] = 0.f;
+    __syncthreads();
+    const float scale = g.scale[level];
+    const uint32_t res = g.res[level], size = g.size[level], off = g.offset[level];
+    const float2* gfp = reinterpret_cast<const float2*>(d_feat) + (int64_t)level * M;
+    for (int64_t i = threadIdx.x; i < M; i += OWN_THREADS) {
+        const float2 gf = gfp[i];
+        if (gf.x == 0.f && gf.y == 0.f) continue;
+        Corner8 c;
+        grid_corners_u<true>(x[3 * i], x[3 * i + 1], x[3 * i + 2], scale, res, size, off, c);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t rel = c.e[k] - lo;
+            if (rel < n_own) {
+                atomicAdd(&own_acc[2 * rel], c.w[k] * gf.x);
+                atomicAdd(&own_acc[2 * rel + 1], c.w[k] * gf.y);
+            }
+        }
+    }
+    __syncthreads();
+    float2* out = reinterpret_cast<float2*>(grad_table) + lo;
+    for (uint32_t j = threadIdx.x; j < n_own; j += OWN_THREADS) {
+        const float a0 = own_acc[2 * j], a1 = own_acc[2 * j + 1];
+        if (a0 != 0.f || a1 != 0.f) {
+            float2 v = out[j];
+            v.x += a0; v.y += a1;
+            out[j] = v;
         }
     }
 }
@@ -833,7 +890,7 @@ extern "C" {
 
 int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int32_t out_act, int32_t n_out_rows, const void* d_out_f16,
                       const void* out_f16, int32_t out_ld, const void* save_in, const void* save_acts, float loss_scale,
-                      float* grad_weights, float* d_in, nrc_stream_t stream) {
+                      float* grad_weights, float* d_in, int32_t d_in_pair_major, nrc_stream_t stream) {
     NRC_ENTER();
     if (M < 0 || !weights_f16 || !grad_weights || n_out_rows < 1 || n_out_rows > 16 || out_ld < 4 || out_ld > 16 || !(loss_scale > 0.f)) return NRC_ERR_INVALID;
     if (n_hidden < 1 || n_hidden > 2 || (out_act != ACT_NONE && out_act != ACT_SIGMOID)) return NRC_ERR_UNSUPPORTED;
@@ -844,7 +901,7 @@ int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int3
     hipStream_t s = (hipStream_t)stream;
 #define NRC_BWD(H, A)                                                                                                          \
     hipLaunchKernelGGL((k_nwie_bwd<H, A>), grid, block, 0, s, M, (const __half*)weights_f16, (int)n_out_rows, (const __half*)d_out_f16, \
-                       (const __half*)out_f16, (int)out_ld, (const __half*)save_in, (const __half*)save_acts, loss_scale, grad_weights, d_in)
+                       (const __half*)out_f16, (int)out_ld, (const __half*)save_in, (const __half*)save_acts, loss_scale, grad_weights, d_in, (int)d_in_pair_major)
     if (n_hidden == 1) { if (out_act == ACT_SIGMOID) NRC_BWD(1, ACT_SIGMOID); else NRC_BWD(1, ACT_NONE); }
     else { if (out_act == ACT_SIGMOID) NRC_BWD(2, ACT_SIGMOID); else NRC_BWD(2, ACT_NONE); }
 #undef NRC_BWD
@@ -852,8 +909,8 @@ int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int3
     return NRC_OK;
 }
 
-int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t n_levels, int32_t log2_hashmap_size,
-                      int32_t base_resolution, float per_level_scale, float* grad_table, nrc_stream_t stream) {
+int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
+                      int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table, nrc_stream_t stream) {
     NRC_ENTER();
     if (M < 0 || !grad_table) return NRC_ERR_INVALID;
     if (M == 0) return NRC_OK;
@@ -861,8 +918,31 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
     GridCfg g;
     const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
     if (rc != NRC_OK) return rc;
-    hipLaunchKernelGGL(k_grid_bwd, dim3((unsigned)nrc_cdiv(M, 256), n_levels), dim3(256), 0, (hipStream_t)stream, x01, M, d_features, g,
-                       (int)n_levels, grad_table);
+    // ownership path: hashed levels of a large, pair-major batch (its cost is ~32 x M index computations per level whatever M is
+    // worth in atomics, plus a 128 KB slice flush per workgroup: below ~16 K samples the atomics are cheaper)
+    static const bool allow_owned = [] { const char* e = getenv("NRC_GRID_BWD_OWNED"); return !(e && e[0] == '0'); }();
+    const bool owned = allow_owned && d_features_pair_major && M >= 16384;
+    LevelList ll; ll.n = 0;
+    OwnedCfg oc; oc.n_levels = 0; oc.unit0[0] = 0;
+    for (int l = 0; l < n_levels; l++) {
+        if (owned && g.hashed[l]) {
+            oc.level[oc.n_levels] = l;
+            oc.unit0[oc.n_levels + 1] = oc.unit0[oc.n_levels] + (int)nrc_cdiv(g.size[l], OWN_ENTRIES);
+            oc.n_levels++;
+        } else {
+            ll.level[ll.n++] = l;
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (ll.n > 0)
+        hipLaunchKernelGGL(k_grid_bwd, dim3((unsigned)nrc_cdiv(M, 256), ll.n), dim3(256), 0, s, x01, M, d_features, (int)d_features_pair_major, g,
+                           (int)n_levels, ll, grad_table);
+    if (oc.n_levels > 0) {
+        static const hipError_t attr = hipFuncSetAttribute((const void*)k_grid_bwd_owned, hipFuncAttributeMaxDynamicSharedMemorySize, OWN_ENTRIES * 8);
+        (void)attr;
+        hipLaunchKernelGGL(k_grid_bwd_owned, dim3((unsigned)oc.unit0[oc.n_levels]), dim3(OWN_THREADS), OWN_ENTRIES * 8, s, x01, M, d_features, g, oc,
+                           grad_table);
+    }
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -88,16 +88,17 @@ class _NWIEFunction(torch.autograd.Function):
         dev = xin.device
         d_out = d_out.to(torch.float16).contiguous()
         grad_params = torch.zeros(module.params.numel(), dtype=torch.float32, device=dev)
+        pair_major = 1 if module.encoding == 0 else 0  # the grid backward reads [16 levels][m][2]
         d_in = torch.empty(m, 32, dtype=torch.float32, device=dev)
         st = _lib.stream_of(d_out)
         _lib.check(lib.nrc_nwie_backward(
             m, _lib.ptr(w16), module.n_hidden, module.out_act, _PAD, _lib.ptr(d_out), _lib.ptr(out), module._out_ld,
-            _lib.ptr(save_in), _lib.ptr(save_acts), LOSS_SCALE, _lib.ptr(grad_params), _lib.ptr(d_in), st), 'nwie_backward')
+            _lib.ptr(save_in), _lib.ptr(save_acts), LOSS_SCALE, _lib.ptr(grad_params), _lib.ptr(d_in), pair_major, st), 'nwie_backward')
         grad_x = None
         if module.encoding == 0:
             g = module.grid_cfg
             table_grad = grad_params[module.n_mlp_params:]
-            _lib.check(lib.nrc_grid_backward(_lib.ptr(xin), m, _lib.ptr(d_in), g['n_levels'], g['log2_hashmap_size'],
+            _lib.check(lib.nrc_grid_backward(_lib.ptr(xin), m, _lib.ptr(d_in), pair_major, g['n_levels'], g['log2_hashmap_size'],
                                              g['base_resolution'], float(g['per_level_scale']), _lib.ptr(table_grad), st), 'grid_backward')
         elif ctx.x_requires_grad:
             # gradient w.r.t. the identity-encoded dims; the SH-encoded direction dims get zeros (view directions are data,

@@ -166,9 +166,9 @@ def test_color_network_backward(color_net):
     np.testing.assert_allclose(gx[:, 3:], d_in[:, 16:], rtol=2e-2, atol=2e-3 * np.abs(d_in).max())
 
 
-def test_density_network_backward_grid_and_mlp(density_net):
+@pytest.mark.parametrize('m', [5000, 20011])  # >= 16384 samples: hashed levels take the ownership (LDS slice) backward, below: atomics
+def test_density_network_backward_grid_and_mlp(density_net, m):
     rng = np.random.default_rng(22)
-    m = 5000
     x = rng.random((m, 3)).astype(np.float32)
     density_net.zero_grad()
     out = density_net(T(x))
