@@ -35,6 +35,8 @@ CHUNK_ROWS = 32768             # rows (x64 sample slots) per encode/MLP round of
 # dominant kernel = k_grid_encode.  Algorithmic bytes per LIVE sample: 16 levels x 8 corners x 2 features x 2 B of table
 # reads + 4 B sample record (t) + 64 B of encoded features written (fp16 x 32)
 ENC_BYTES_PER_SAMPLE = 512 + 4 + 64
+MLP_FLOP_PER_SAMPLE = 20480   # 10 240 MAC per sample (layer widths padded to 16)
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16 MFMA peak, MI355X_MICROARCH.md
 DOMINANT_KERNEL = 'k_grid_encode<SRC_TILED>'
 
 
@@ -54,33 +56,58 @@ def build_scene(device):
     return model, renderer, cam, poses
 
 
-def time_dominant_kernel(renderer, cam, pose, reps=20):
-    """Average duration of the dominant kernel (k_grid_encode: 128 hash-grid gathers per sample) over one Infinity-Cache sized
-    chunk of the image's sample rows, measured with HIP events on the launch stream (torch's current stream = our launch stream)."""
+def time_dominant_kernel(renderer, cam, pose, reps=3):
+    """Average launch duration of the dominant kernel (k_grid_encode: 128 hash-grid gathers per sample) and of its partner
+    (k_ngp_mlp) over ALL Infinity-Cache sized chunks of one image's sample rows, measured with HIP events on the launch stream
+    (torch's current stream = our launch stream).  Returns (encode ms, slots per launch, live samples per launch, mlp ms)."""
     import torch
     from nerficg_amd import _lib
     import ctypes
     m = renderer.model
     out = renderer.render_image_fused(cam, pose, return_stats=True)
     ws = next(iter(renderer._fused_ws.values()))
-    rows = min(out['n_rows'], CHUNK_ROWS)
-    live = int((ws['ts'][:rows * 64] >= 0).sum().item())
+    n_rows = out['n_rows']
+    chunks = [(r0, min(CHUNK_ROWS, n_rows - r0)) for r0 in range(0, n_rows, CHUNK_ROWS)]  # the launches of one image
+    live = int((ws['ts'][:n_rows * 64] >= 0).sum().item())
     lib = _lib.load()
     f3 = lambda t: (ctypes.c_float * 3)(*[float(v) for v in t.reshape(-1).tolist()])
     mn, sz = f3(m.xyz_min), f3(m.xyz_size)
     g = m.encoding_xyz.grid_cfg
     st = _lib.stream_of(ws['ts'])
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in evs:
-        a.record()
+    nt = renderer.n_image_tiles(cam)
+    dev = ws['ts'].device
+    feat = torch.empty(CHUNK_ROWS * 64 * 64 + 256, dtype=torch.uint8, device=dev)
+    sh_ws = torch.empty(nt * 2048, dtype=torch.uint8, device=dev)
+    vp = ctypes.c_void_p
+
+    def encode(r0, rows):
         _lib.check(lib.nrc_ngp_encode_samples(
-            _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, ctypes.cast(mn, ctypes.c_void_p),
-            ctypes.cast(sz, ctypes.c_void_p), _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'],
-            g['base_resolution'], float(g['per_level_scale']), _lib.ptr(ws['qws']), st), 'ngp_encode_samples')
+            vp(ws['ts'].data_ptr() + r0 * 256), vp(ws['row_tile'].data_ptr() + r0 * 4), _lib.ptr(ws['ray_od']), rows, ctypes.cast(mn, vp),
+            ctypes.cast(sz, vp), _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'],
+            g['base_resolution'], float(g['per_level_scale']), _lib.ptr(feat), st), 'ngp_encode_samples')
+
+    def mlp(r0, rows):
+        _lib.check(lib.nrc_ngp_mlp_samples(
+            vp(ws['ts'].data_ptr() + r0 * 256), vp(ws['row_tile'].data_ptr() + r0 * 4), _lib.ptr(ws['ray_od']), rows, nt, _lib.ptr(feat),
+            _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
+            vp(ws['packed'].data_ptr() + r0 * 512), _lib.ptr(sh_ws), st), 'ngp_mlp_samples')
+
+    def timed(fn):  # every chunk of the image, `reps` times, back to back between ONE pair of events on the launch stream
+        fn(*chunks[0])
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            for c in chunks:
+                fn(*c)
         b.record()
-    torch.cuda.synchronize()
-    ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
-    return ms, rows * 64, live
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / (reps * len(chunks))
+
+    ms = timed(encode)
+    ms_mlp = timed(mlp)  # includes the (tiny) per-ray SH kernel
+    live = live / len(chunks)  # average live samples per launch
+    rows = n_rows / len(chunks)
+    return ms, int(rows * 64), int(live), ms_mlp
 
 
 # ------------------------------------------------------------------------------------------------ 3DGS leg (secondary metric)
@@ -260,7 +287,7 @@ def main():
     if rank == 0:
         rays = W * H * args.steps * world
         value = rays / elapsed / 1e6
-        k_ms, k_slots, k_live = time_dominant_kernel(renderer, cam, poses[args.warmup % N_POSES])
+        k_ms, k_slots, k_live, mlp_ms = time_dominant_kernel(renderer, cam, poses[args.warmup % N_POSES])
         achieved = ENC_BYTES_PER_SAMPLE * k_live / (k_ms * 1e-3) / 1e9
         traffic = None
         pmc = ROOT / 'profiles' / 'pmc_summary.json'
@@ -283,6 +310,10 @@ def main():
                          'kernel_ms': round(k_ms, 4), 'samples_per_launch': k_live, 'slots_per_launch': k_slots,
                          'note': 'table (24.4 MB) is L2/Infinity-Cache resident: the kernel is bound by the L1 texture-cache access rate, '
                                  'not by HBM; achieved = algorithmic bytes / kernel time'},
+            # second kernel of the pair: the tiny-MLP chain on MFMA (20 480 FLOP per sample, padded layer widths)
+            'roofline_mfma': {'bound': 'mfma', 'kernel': 'k_ngp_mlp<SRC_TILED>', 'achieved': round(MLP_FLOP_PER_SAMPLE * k_live / (mlp_ms * 1e-3) / 1e12, 2),
+                              'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(MLP_FLOP_PER_SAMPLE * k_live / (mlp_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                              'traffic': None, 'kernel_ms': round(mlp_ms, 4), 'flop_per_sample': MLP_FLOP_PER_SAMPLE, 'samples_per_launch': k_live},
         }
         if gs_res is not None:
             # bytes_fwd = 308 P_vis + 148 D + 20 H W ; bytes_bwd ~ 76 D + 472 P_vis + 20 H W

@@ -193,6 +193,11 @@ int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float*
 int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, const float* xyz_min3,
                            const float* xyz_size3, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
                            int32_t base_resolution, float per_level_scale, void* features_f16, nrc_stream_t stream);
+/* stage 3b on its own (the MFMA kernel; bench.py's second roofline object): features as written by nrc_ngp_encode_samples for the
+ * first n_rows (<= 32768) rows -> packed (h0, r, g, b) fp16; ray_sh_workspace: n_ray_tiles * 2048 bytes */
+int nrc_ngp_mlp_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
+                        const void* features_f16, const void* density_weights_f16, const void* color_weights_f16,
+                        void* packed_f16, void* ray_sh_workspace, nrc_stream_t stream);
 int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32_t* ray_cnt, const int32_t* tile_off,
                             int32_t width, int32_t height, int64_t tile_begin, int64_t n_tiles, int32_t cascades,
                             float exp_step_factor, int32_t grid_size, int32_t max_samples, float T_threshold,

@@ -13,10 +13,10 @@ model, renderer, cam, poses = bench.build_scene(dev)
 for i in range(2):
     renderer.render_image_fused(cam, poses[i])
 torch.cuda.synchronize()
-ms, slots, n = bench.time_dominant_kernel(renderer, cam, poses[2], reps=reps)
+ms, slots, n, ms_mlp = bench.time_dominant_kernel(renderer, cam, poses[2], reps=reps)
 t0 = time.perf_counter()
 for i in range(reps):
     renderer.render_image_fused(cam, poses[2])
 torch.cuda.synchronize()
 tot = (time.perf_counter() - t0) / reps * 1e3
-print(f'encode kernel {ms:.3f} ms for {n} live samples ({slots} slots) = {n / ms / 1e6:.3f} Gsamples/s ; whole image {tot:.3f} ms = {800 * 800 / tot / 1e3:.2f} Mrays/s')
+print(f'encode kernel {ms:.3f} ms, mlp kernel {ms_mlp:.3f} ms per launch of {n} live samples ({slots} slots) = {n / ms / 1e6:.3f} Gsamples/s ; whole image {tot:.3f} ms = {800 * 800 / tot / 1e3:.2f} Mrays/s')
