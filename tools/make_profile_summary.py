@@ -11,21 +11,34 @@ OUT.mkdir(exist_ok=True)
 
 
 def short(name):
+    m = re.match(r'_ZN12_GLOBAL__N_1(\d+)', name)  # rocprofv3 leaves some template instances mangled
+    if m:
+        n = int(m.group(1))
+        base, rest = name[m.end():m.end() + n], name[m.end() + n:]
+        t = re.match(r'I((?:L[ib]\d+E)+)E', rest)
+        if t:
+            base += '<' + ', '.join(re.findall(r'L[ib](\d+)E', t.group(1))) + '>'
+        return base
     name = re.sub(r'\(anonymous namespace\)::', '', name).replace('void ', '')
     return name.split('(')[0]
 
 
 stats = sorted(glob.glob(str(RAW / 'bench_stats' / '*' / '*kernel_stats.csv')))
 if stats:
-    shutil.copy(stats[0], OUT / 'r01_bench_kernel_stats.csv')
+    shutil.copy(stats[-1], OUT / 'r01_bench_kernel_stats.csv')
+tstats = sorted(glob.glob(str(RAW / 'train_stats' / '*' / '*kernel_stats.csv')))
+if tstats:
+    shutil.copy(tstats[-1], OUT / 'r01_train_kernel_stats.csv')
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(str(RAW / 'pmc*' / '*' / '*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         acc[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
-keep = ('k_grid_encode', 'k_ngp_mlp', 'k_render', 'k_composite_image', 'k_preprocess', 'k_scatter', 'k_sort_tiles', 'k_tile_', 'k_scan_tiles')
+keep = ('k_grid_encode', 'k_ngp_mlp', 'k_render', 'k_composite_image', 'k_preprocess', 'k_bin_', 'k_radix_', 'k_tile_', 'k_scan_tiles', 'k_march_wave',
+        'k_grid_bwd', 'k_nwie_', 'k_composite_train')
 lines = ['# rocprofv3 --pmc summary (MI355X, round 1)', '',
          'Collected by `tools/collect_profiles.sh` (one `--pmc` group per run, `--kernel-trace` only), averaged per kernel over all launches of',
-         '`tools/bench_query.py` (InstantNGP 800x800 image pipeline) and `tools/bench_gs.py` (3DGS, 1 M Gaussians, 1297x840).',
+         '`tools/bench_query.py` (InstantNGP 800x800 image pipeline), `tools/bench_gs.py` (3DGS, 1 M Gaussians, 1297x840) and `tools/bench_train.py`',
+         '(InstantNGP training iteration, 2200 rays / 264 K samples).',
          'FETCH_SIZE / WRITE_SIZE are in KiB as reported; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950',
          '(other widths uncalibrated) -- both the raw value and the 2x-corrected read bytes are listed.', '']
 summary = {}
@@ -52,16 +65,22 @@ for k in sorted(acc):
             derived['l1_hit_rate'] = round(1 - c['TCP_TCC_READ_REQ_sum'] / c['TCP_TOTAL_CACHE_ACCESSES_sum'], 3)
     if 'TCC_HIT_sum' in c and 'TCC_MISS_sum' in c and c['TCC_HIT_sum'] + c['TCC_MISS_sum'] > 0:
         derived['l2_hit_rate'] = round(c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']), 3)
-    if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'SQ_BUSY_CYCLES' in c and c['SQ_BUSY_CYCLES'] > 0:
-        derived['mfma_busy_over_sq_busy'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_BUSY_CYCLES'], 3)
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'GRBM_GUI_ACTIVE' in c and c['GRBM_GUI_ACTIVE'] > 0:
+        # busy cycles are summed over the 1024 SIMDs (checked: = MFMA count x 32 cycles); kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs
+        derived['mfma_pipe_busy_frac'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * c['GRBM_GUI_ACTIVE'] / 8.0), 3)
+    if 'SQ_INSTS_VALU_MFMA_MOPS_F16' in c and 'GRBM_GUI_ACTIVE' in c and c['GRBM_GUI_ACTIVE'] > 0:
+        # one MOP = 512 FLOP; clock taken as 2.4 GHz
+        derived['mfma_tflops_issued'] = round(c['SQ_INSTS_VALU_MFMA_MOPS_F16'] * 512 / (c['GRBM_GUI_ACTIVE'] / 8.0 / 2.4e9) / 1e12, 1)
     if derived:
         lines.append('')
         lines.append('derived: ' + ', '.join(f'{a} = {b}' for a, b in derived.items()))
     lines.append('')
-    key = k.replace('<1>', '<SRC_TILED>').replace('<0>', '<SRC_ARRAYS>')
+    key = k
+    if k.startswith('k_grid_encode') or k.startswith('k_ngp_mlp'):
+        key = re.sub(r'<1(, \d+)?>', '<SRC_TILED>', re.sub(r'<0(, \d+)?>', '<SRC_ARRAYS>', k))
     summary[key] = {**{n: round(v, 1) for n, v in c.items()}, **derived}
 (OUT / 'r01_pmc_summary.md').write_text('\n'.join(lines))
 (OUT / 'pmc_summary.json').write_text(json.dumps(summary, indent=1, sort_keys=True))
 print('\n'.join(lines[:8]))
 for k, v in summary.items():
-    print(k, {a: v[a] for a in ('hbm_bytes_per_launch', 'tcp_accesses_per_clk_per_cu', 'l1_hit_rate', 'l2_hit_rate', 'mfma_busy_over_sq_busy') if a in v})
+    print(k, {a: v[a] for a in ('hbm_bytes_per_launch', 'tcp_accesses_per_clk_per_cu', 'l1_hit_rate', 'l2_hit_rate', 'mfma_pipe_busy_frac', 'mfma_tflops_issued') if a in v})
