@@ -213,6 +213,43 @@ def cpu_baseline(cam_full, pose, model_params, crop=96):
             'msamples_per_s': round(int(counter[0]) / dt / 1e6, 4)}
 
 
+def time_train(model, renderer, cam, poses, n_rays=2200, iters=15):
+    """InstantNGP training iteration through the drop-in modules (Trainer.py:79-94 sequence: sample rays -> render_rays training
+    path -> MSE + weight decay -> GradScaler(128) backward -> Adam), rank 0 only, reported next to the headline metric."""
+    import torch
+    from nerficg_amd.raygen import generate_rays
+    dev = model.encoding_xyz.params.device
+    rays = [generate_rays(cam.width, cam.height, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y, p, device=dev, want_direction=False)
+            for p in poses[:2]]
+    origin = torch.cat([r['origin'] for r in rays]); vdir = torch.cat([r['view_direction'] for r in rays])
+    perm = torch.randperm(origin.shape[0], generator=torch.Generator(device='cpu').manual_seed(0)).to(dev)
+    saved = [p.detach().clone() for p in model.parameters()]
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), fused=True)
+    scaler = torch.amp.GradScaler(init_scale=128.0, growth_interval=10 ** 9)
+    target = torch.rand(origin.shape[0], 3, device=dev)
+
+    def step(i):
+        ids = perm[(i * n_rays) % (perm.numel() - n_rays):][:n_rays]
+        with torch.amp.autocast('cuda'):
+            out = renderer.render_rays(origin[ids], vdir[ids], cam, train_mode=True, custom_bg_color=torch.rand(3, device=dev))
+            loss = torch.nn.functional.mse_loss(out['rgb'].float(), target[ids]) + 0.5e-6 * model.weight_decay_mlp()
+        scaler.scale(loss).backward()
+        scaler.step(opt); scaler.update(); opt.zero_grad()
+        return int(out['rm_samples'].item())
+
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); tot = 0
+    for i in range(iters):
+        tot += step(3 + i)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / iters
+    with torch.no_grad():  # the benchmark must not depend on the order of its legs
+        for p, q in zip(model.parameters(), saved):
+            p.copy_(q)
+    return {'metric': 'InstantNGP training iteration (drop-in modules, fwd + bwd + Adam)', 'ms_per_iteration': round(dt * 1e3, 3), 'rays': n_rays,
+            'samples_per_iteration': int(tot / iters), 'msamples_per_s': round(tot / iters / dt / 1e6, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -220,6 +257,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gs', action='store_true', help='skip the secondary 3DGS leg')
+    ap.add_argument('--no-train', action='store_true', help='skip the InstantNGP training-iteration leg')
     ap.add_argument('--gs-gaussians', type=int, default=1_000_000)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the code path)')
     args = ap.parse_args()
@@ -329,6 +367,11 @@ def main():
                              'frac_fwd': round(b_fwd / (gs_res['ms_fwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              'frac_fwd_bwd': round((b_fwd + b_bwd) / (gs_res['ms_fwd_bwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              'algorithmic_bytes_fwd': b_fwd, 'algorithmic_bytes_bwd': b_bwd}}
+        if not args.no_train:
+            try:
+                result['training'] = time_train(model, renderer, cam, poses)
+            except Exception as e:  # never lose the headline line over the extra leg
+                result['training'] = {'error': repr(e)[:200]}
         if not args.no_cpu_baseline:
             if gs_res is not None:
                 result['secondary']['cpu_baseline'] = gs_cpu_baseline()
