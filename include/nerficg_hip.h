@@ -158,6 +158,18 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
                         nrc_stream_t stream);
 
 /* =====================================================================================================
+ * Group 7 -- SSIM map and its gradient (3DGS loss): replaces fused_ssim as imported at
+ *            src/Thirdparty/FusedSSIM.py:15 and called at src/Optim/Losses/DSSIM.py:11-18.  Images are (planes, H, W) f32 with
+ *            planes = batch * channels; 11x11 Gaussian window (sigma 1.5), zero "same" padding.  The three derivative maps
+ *            (d ssim / d mu1, d sigma1^2, d sigma12) are written when all three pointers are non-null (training).
+ * ===================================================================================================== */
+int nrc_ssim_forward(const float* img1, const float* img2, int64_t planes, int32_t H, int32_t W, float C1, float C2, float* ssim_map,
+                     float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, nrc_stream_t stream);
+int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int32_t H, int32_t W, const float* dL_dmap,
+                      const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
+                      nrc_stream_t stream);
+
+/* =====================================================================================================
  * Group 6 -- fused InstantNGP image pipeline (MI355X-native restructuring of InstantNGPRenderer.render_image ->
  *            render_rays_inference, src/Methods/InstantNGP/Renderer.py:30-46,86-138,172-180): no ray tensors, no
  *            per-iteration host syncs, 4-byte sample records, 8-byte sample values, TILE-INTERLEAVED sample layout:

@@ -1,0 +1,156 @@
+// ssim.hip -- SSIM map + gradient w.r.t. the first image (the 3DGS photometric loss term).
+// Replaces the external package fused-ssim as the reference uses it: src/Thirdparty/FusedSSIM.py:10-15,
+// src/Optim/Losses/DSSIM.py:11-18, src/Methods/GaussianSplatting/Loss.py:14-15.
+// 11x11 Gaussian window (sigma 1.5), zero "same" padding, per channel plane; see oracle/ssim_oracle.c for the formulas.
+//
+// HBM-bound stencil: a 16x16 output tile per workgroup; the 26x26 input halo tile of both images is staged in LDS once, the
+// horizontal pass of the five moments (x1, x2, x1^2, x2^2, x1 x2) goes LDS -> LDS, the vertical pass LDS -> registers.  Training
+// mode also stores the three partial-derivative maps, so the backward pass is one more separable blur of three maps
+// (the window is symmetric: the adjoint of the blur is the blur).  Algorithmic bytes per pixel and channel: forward 8 B read +
+// 4 (+12 training) written; backward 24 B read + 4 written.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace {
+
+#define ST 16          // output tile edge
+#define SR 5           // window radius
+#define SI (ST + 2 * SR)  // 26: input tile edge
+#define SP (SI + 1)    // LDS pitch
+
+__constant__ float SSIM_G[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f, 0.10936068743467331f,
+                                 0.21300552785396576f,  0.26601171493530273f,   0.21300552785396576f,  0.10936068743467331f,
+                                 0.036000773310661316f, 0.0075987582094967365f, 0.001028380123898387f};
+
+template <bool TRAIN>
+__global__ void __launch_bounds__(256) k_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W, float C1, float C2,
+                                                  float* __restrict__ ssim_map, float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
+                                                  float* __restrict__ dm_dsigma12) {
+    __shared__ float s1[SI][SP], s2[SI][SP];
+    __shared__ float xb[5][SI][ST + 1];
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const int x0 = blockIdx.x * ST - SR, y0 = blockIdx.y * ST - SR;
+    for (int k = threadIdx.x; k < SI * SI; k += 256) {
+        const int r = k / SI, c = k - r * SI, y = y0 + r, x = x0 + c;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        s1[r][c] = in ? img1[plane + (size_t)y * W + x] : 0.f;
+        s2[r][c] = in ? img2[plane + (size_t)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < SI * ST; k += 256) {
+        const int r = k / ST, c = k - r * ST;
+        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+        for (int t = 0; t < 11; t++) {
+            const float g = SSIM_G[t], u = s1[r][c + t], v = s2[r][c + t];
+            a += g * u; b += g * v; aa += g * u * u; bb += g * v * v; ab += g * u * v;
+        }
+        xb[0][r][c] = a; xb[1][r][c] = b; xb[2][r][c] = aa; xb[3][r][c] = bb; xb[4][r][c] = ab;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = blockIdx.x * ST + tx, y = blockIdx.y * ST + ty;
+    float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 11; t++) {
+        const float g = SSIM_G[t];
+#pragma unroll
+        for (int q = 0; q < 5; q++) m[q] += g * xb[q][ty + t][tx];
+    }
+    if (x >= W || y >= H) return;
+    const float mu1 = m[0], mu2 = m[1];
+    const float sg1 = m[2] - mu1 * mu1, sg2 = m[3] - mu2 * mu2, sg12 = m[4] - mu1 * mu2;
+    const float A = mu1 * mu1 + mu2 * mu2 + C1, B = sg1 + sg2 + C2, C = 2.f * mu1 * mu2 + C1, D = 2.f * sg12 + C2;
+    const float iAB = 1.f / (A * B);
+    const size_t o = plane + (size_t)y * W + x;
+    ssim_map[o] = C * D * iAB;
+    if (TRAIN) {
+        dm_dmu1[o] = (mu2 * 2.f * D) * iAB - (mu2 * 2.f * C) * iAB - (mu1 * 2.f * C * D) * iAB / A + (mu1 * 2.f * C * D) * iAB / B;
+        dm_dsigma1_sq[o] = (-C * D) * iAB / B;
+        dm_dsigma12[o] = (2.f * C) * iAB;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
+                                                  const float* __restrict__ dL_dmap, const float* __restrict__ dm_dmu1,
+                                                  const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
+                                                  float* __restrict__ dL_dimg1) {
+    __shared__ float p[3][SI][SP];
+    __shared__ float xb[3][SI][ST + 1];
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const int x0 = blockIdx.x * ST - SR, y0 = blockIdx.y * ST - SR;
+    for (int k = threadIdx.x; k < SI * SI; k += 256) {
+        const int r = k / SI, c = k - r * SI, y = y0 + r, x = x0 + c;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        const size_t o = plane + (size_t)y * W + x;
+        const float dl = in ? dL_dmap[o] : 0.f;
+        p[0][r][c] = in ? dl * dm_dmu1[o] : 0.f;
+        p[1][r][c] = in ? dl * dm_dsigma1_sq[o] : 0.f;
+        p[2][r][c] = in ? dl * dm_dsigma12[o] : 0.f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < SI * ST; k += 256) {
+        const int r = k / ST, c = k - r * ST;
+        float a[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 11; t++) {
+            const float g = SSIM_G[t];
+#pragma unroll
+            for (int q = 0; q < 3; q++) a[q] += g * p[q][r][c + t];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) xb[q][r][c] = a[q];
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = blockIdx.x * ST + tx, y = blockIdx.y * ST + ty;
+    float b[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 11; t++) {
+        const float g = SSIM_G[t];
+#pragma unroll
+        for (int q = 0; q < 3; q++) b[q] += g * xb[q][ty + t][tx];
+    }
+    if (x >= W || y >= H) return;
+    const size_t o = plane + (size_t)y * W + x;
+    dL_dimg1[o] = b[0] + 2.f * img1[o] * b[1] + img2[o] * b[2];
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrc_ssim_forward(const float* img1, const float* img2, int64_t planes, int32_t H, int32_t W, float C1, float C2, float* ssim_map,
+                     float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (planes < 0 || H < 1 || W < 1 || planes > 65535) return NRC_ERR_INVALID;
+    if (planes == 0) return NRC_OK;
+    if (!img1 || !img2 || !ssim_map) return NRC_ERR_INVALID;
+    const bool train = dm_dmu1 || dm_dsigma1_sq || dm_dsigma12;
+    if (train && !(dm_dmu1 && dm_dsigma1_sq && dm_dsigma12)) return NRC_ERR_INVALID;
+    const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, (unsigned)planes);
+    if (train)
+        hipLaunchKernelGGL(k_ssim_fwd<true>, grid, dim3(256), 0, (hipStream_t)stream, img1, img2, (int)H, (int)W, C1, C2, ssim_map, dm_dmu1, dm_dsigma1_sq,
+                           dm_dsigma12);
+    else
+        hipLaunchKernelGGL(k_ssim_fwd<false>, grid, dim3(256), 0, (hipStream_t)stream, img1, img2, (int)H, (int)W, C1, C2, ssim_map, dm_dmu1, dm_dsigma1_sq,
+                           dm_dsigma12);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int32_t H, int32_t W, const float* dL_dmap, const float* dm_dmu1,
+                      const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (planes < 0 || H < 1 || W < 1 || planes > 65535) return NRC_ERR_INVALID;
+    if (planes == 0) return NRC_OK;
+    if (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1) return NRC_ERR_INVALID;
+    const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, (unsigned)planes);
+    hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(256), 0, (hipStream_t)stream, img1, img2, (int)H, (int)W, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+                       dL_dimg1);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+}  // extern "C"

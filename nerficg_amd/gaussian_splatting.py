@@ -13,7 +13,7 @@ import torch
 
 __all__ = ['PerspectiveCamera', 'get_projection_matrix', 'invert_3d_affine', 'make_raster_settings', 'quaternion_to_rotation_matrix',
            'build_covariances', 'extract_upper_triangular_matrix', 'convert_sh_features', 'rgb_to_sh0', 'sh0_to_rgb', 'Gaussians',
-           'render_image_training', 'render_image_inference']
+           'render_image_training', 'render_image_inference', 'training_loss']
 
 
 @dataclass
@@ -182,3 +182,13 @@ def render_image_inference(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np
                           opacities=gaussians.get_opacities, scales=gaussians.get_scales, rotations=gaussians.get_rotations)
     image.clamp_(0.0, 1.0)
     return {'rgb': image if to_chw else image.permute(1, 2, 0)}
+
+
+def training_loss(image: torch.Tensor, target: torch.Tensor, lambda_l1: float = 0.8, lambda_dssim: float = 0.2) -> torch.Tensor:
+    """GaussianSplattingLoss (src/Methods/GaussianSplatting/Loss.py:11-23, weights Trainer.py:34-35): lambda_l1 * L1 + lambda_dssim *
+    (1 - SSIM) on (3, H, W) images, SSIM through the HIP kernels (nerficg_amd.fused_ssim; DSSIM.py:11-18 adds the batch dimension)."""
+    from .fused_ssim import fused_ssim
+    l1 = torch.nn.functional.l1_loss(image, target)
+    a = image[None] if image.dim() == 3 else image
+    b = target[None] if target.dim() == 3 else target
+    return lambda_l1 * l1 + lambda_dssim * (1.0 - fused_ssim(a, b))

@@ -309,3 +309,22 @@ def gs_backward(st, dL_dpix):
        _p(st.point_list), _p(st.ranges), _p(st.n_contrib), _p(st.final_T), _p(g), _p(out['mean2D']), _p(out['conic']), _p(out['opacity']),
        _p(out['color']), _p(out['mean3D']), _p(out['cov3D']), _p(out['sh']), _p(out['scale']), _p(out['rot']))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ SSIM (3DGS loss; ssim_oracle.c)
+def ssim_forward(img1, img2, C1=0.01 ** 2, C2=0.03 ** 2, train=True):
+    """img (..., H, W) f32 -> ssim_map and (train) the maps d ssim / d mu1, d sigma1^2, d sigma12 (same shape)."""
+    a, b = _c(img1, f32), _c(img2, f32)
+    H, W = a.shape[-2:]
+    planes = a.size // (H * W)
+    out = [np.empty_like(a) for _ in range(4 if train else 1)]
+    _call('oracle_ssim_forward', a, b, planes, H, W, float(C1), float(C2), out[0], *(out[1:] if train else (None, None, None)))
+    return out if train else out[0]
+
+
+def ssim_backward(img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12):
+    a, b = _c(img1, f32), _c(img2, f32)
+    H, W = a.shape[-2:]
+    out = np.empty_like(a)
+    _call('oracle_ssim_backward', a, b, a.size // (H * W), H, W, _c(dL_dmap, f32), _c(dm_dmu1, f32), _c(dm_dsigma1_sq, f32), _c(dm_dsigma12, f32), out)
+    return out
