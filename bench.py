@@ -224,7 +224,8 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=15):
     origin = torch.cat([r['origin'] for r in rays]); vdir = torch.cat([r['view_direction'] for r in rays])
     perm = torch.randperm(origin.shape[0], generator=torch.Generator(device='cpu').manual_seed(0)).to(dev)
     saved = [p.detach().clone() for p in model.parameters()]
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), fused=True)
+    from nerficg_amd.apex_optimizers import FusedAdam
+    opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)  # Trainer.py:35
     scaler = torch.amp.GradScaler(init_scale=128.0, growth_interval=10 ** 9)
     target = torch.rand(origin.shape[0], 3, device=dev)
 

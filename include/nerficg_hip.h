@@ -158,6 +158,17 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
                         nrc_stream_t stream);
 
 /* =====================================================================================================
+ * Group 8 -- fused Adam step: replaces apex.optimizers.FusedAdam (src/Thirdparty/Apex.py:17) as constructed at
+ *            src/Methods/InstantNGP/Trainer.py:33-38 and src/Methods/GaussianSplatting/Model.py:131-136.  One flat f32 tensor
+ *            per call, all four pointers 16-byte aligned.  bias_correction_k = 1 - beta_k^step (host).  adam_w_mode = 0: L2
+ *            weight decay added to the gradient (apex ADAM_MODE_0), 1: decoupled.  grad_scale / found_inf: optional DEVICE
+ *            scalars of torch.amp.GradScaler (gradient divided by *grad_scale; the whole step is skipped when *found_inf != 0).
+ * ===================================================================================================== */
+int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t adam_w_mode, float bias_correction1,
+                  float bias_correction2, const float* grad_scale, const float* found_inf, nrc_stream_t stream);
+
+/* =====================================================================================================
  * Group 7 -- SSIM map and its gradient (3DGS loss): replaces fused_ssim as imported at
  *            src/Thirdparty/FusedSSIM.py:15 and called at src/Optim/Losses/DSSIM.py:11-18.  Images are (planes, H, W) f32 with
  *            planes = batch * channels; 11x11 Gaussian window (sigma 1.5), zero "same" padding.  The three derivative maps

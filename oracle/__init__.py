@@ -328,3 +328,13 @@ def ssim_backward(img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12):
     out = np.empty_like(a)
     _call('oracle_ssim_backward', a, b, a.size // (H * W), H, W, _c(dL_dmap, f32), _c(dm_dmu1, f32), _c(dm_dsigma1_sq, f32), _c(dm_dsigma12, f32), out)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ Adam (adam_oracle.c)
+def adam_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adam_w_mode=False, grad_scale=1.0, found_inf=False):
+    """In-place on copies; returns (p, m, v) after one step number `step` (1-based)."""
+    p, m, v = _c(p, f32).copy(), _c(m, f32).copy(), _c(v, f32).copy()
+    bc1, bc2 = 1.0 - betas[0] ** step, 1.0 - betas[1] ** step
+    _call('oracle_adam_step', p, _c(g, f32), m, v, p.size, float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+          int(bool(adam_w_mode)), float(bc1), float(bc2), float(grad_scale), int(bool(found_inf)))
+    return p, m, v

@@ -1,0 +1,69 @@
+"""GPU: nerficg_amd.apex_optimizers.FusedAdam (HIP, C ABI group 8) against oracle/adam_oracle.c, with and without torch.amp.GradScaler,
+and under the reference's optimizer-state surgery (src/Optim/adam_utils.py)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+
+
+@pytest.mark.parametrize('n', [1, 7, 4096, 100003])
+def test_fused_adam_matches_oracle(n):
+    from nerficg_amd.apex_optimizers import FusedAdam
+    rng = np.random.default_rng(n)
+    p0 = rng.normal(size=n).astype(np.float32)
+    tp = torch.nn.Parameter(torch.from_numpy(p0.copy()).to(DEV))
+    opt = FusedAdam([tp], lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)  # Trainer.py:35
+    p, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    for step in range(1, 5):
+        g = (rng.normal(size=n) * 10.0 ** rng.integers(-6, 1, size=n)).astype(np.float32)
+        tp.grad = torch.from_numpy(g.copy()).to(DEV)
+        opt.step()
+        p, m, v = oracle.adam_step(p, g, m, v, step, 1e-2, (0.9, 0.99), 1e-15)
+        np.testing.assert_allclose(tp.detach().cpu().numpy(), p, rtol=1e-6, atol=1e-7)  # same f32 operation order; sqrt/div correctly rounded
+    st = opt.state[tp]
+    np.testing.assert_allclose(st['exp_avg'].cpu().numpy(), m, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(st['exp_avg_sq'].cpu().numpy(), v, rtol=1e-6, atol=1e-20)
+    assert opt.param_groups[0]['step'] == 4
+    opt.zero_grad()
+    assert tp.grad is None
+
+
+def test_fused_adam_with_grad_scaler_and_inf_skip():
+    from nerficg_amd.apex_optimizers import FusedAdam
+    rng = np.random.default_rng(1)
+    p0 = rng.normal(size=5000).astype(np.float32)
+    tp = torch.nn.Parameter(torch.from_numpy(p0.copy()).to(DEV))
+    opt = FusedAdam([tp], lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
+    scaler = torch.amp.GradScaler(init_scale=128.0, growth_interval=10 ** 9)  # Trainer.py:44
+    x = torch.from_numpy(rng.normal(size=5000).astype(np.float32)).to(DEV)
+    loss = (tp * x).sum()
+    scaler.scale(loss).backward()
+    scaler.step(opt); scaler.update(); opt.zero_grad()
+    p, m, v = oracle.adam_step(p0, x.cpu().numpy() * 128.0, np.zeros_like(p0), np.zeros_like(p0), 1, 1e-2, (0.9, 0.99), 1e-15, grad_scale=128.0)
+    np.testing.assert_allclose(tp.detach().cpu().numpy(), p, rtol=1e-6, atol=1e-7)
+    before = tp.detach().clone()
+    loss = (tp * x).sum() * float('inf')
+    scaler.scale(loss).backward()
+    scaler.step(opt); scaler.update(); opt.zero_grad()
+    assert torch.equal(tp.detach(), before) and scaler.get_scale() == 64.0  # step skipped on the device, scale backed off
+
+
+def test_param_group_surgery_like_adam_utils():
+    """prune_param_groups / extend_param_groups (adam_utils.py:21-61) rebuild the parameter and move the state entry."""
+    from nerficg_amd.apex_optimizers import FusedAdam
+    a = torch.nn.Parameter(torch.rand(100, 3, device=DEV))
+    opt = FusedAdam([{'params': [a], 'lr': 1e-3, 'name': 'positions'}], lr=0.0, eps=1e-15, adam_w_mode=False)  # Model.py:133
+    a.grad = torch.rand_like(a); opt.step()
+    mask = torch.arange(100, device=DEV) % 2 == 0
+    group = opt.param_groups[0]
+    state = opt.state[a]
+    new = torch.nn.Parameter(torch.cat((a[mask], torch.rand(10, 3, device=DEV))))
+    for k in ('exp_avg', 'exp_avg_sq'):
+        state[k] = torch.cat((state[k][mask], torch.zeros(10, 3, device=DEV)))
+    opt.state.pop(a); opt.state[new] = state; group['params'][0] = new
+    new.grad = torch.rand_like(new); opt.step()
+    assert group['step'] == 2 and torch.isfinite(new).all() and opt.state[new]['exp_avg'].shape == (60, 3)
