@@ -130,10 +130,13 @@ int nrc_f32_to_f16(const float* src, void* dst_f16, int64_t n, nrc_stream_t stre
  * fp16 rows [d01(3) | features(16)].  out_act: 0 none, 1 sigmoid.  out (M,out_ld) fp16, columns [0,n_store) written
  * (n_store in {4,8,12,16}).  save_in (M,32) fp16 and save_acts (n_hidden,M,64) fp16 receive the encoded inputs and the
  * post-ReLU activations for the backward pass (both NULL for inference). */
+/* workspace (optional, grid encoding only): nrc_nwie_forward_ws_bytes(M) bytes -> the encoding runs as its own kernel (faster);
+ * NULL -> one kernel gathers and runs the MLP. */
+int64_t nrc_nwie_forward_ws_bytes(int64_t M);
 int nrc_nwie_forward(int32_t encoding, const void* input, int32_t input_ld, int64_t M, const void* weights_f16,
                      const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                      float per_level_scale, int32_t n_hidden, int32_t out_act, int32_t n_out_rows, void* out_f16,
-                     int32_t out_ld, int32_t n_store, void* save_in, void* save_acts, nrc_stream_t stream);
+                     int32_t out_ld, int32_t n_store, void* save_in, void* save_acts, void* workspace, nrc_stream_t stream);
 /* NetworkWithInputEncoding.backward through the MLP.  d_out / out: (M,out_ld) fp16 (upstream gradient of, and the forward
  * value of, the stored output columns).  Upstream gradients are multiplied by loss_scale before they are rounded to fp16
  * MFMA operands and every result is divided by it again (tiny-cuda-nn's internal loss scale).  grad_weights: f32, layout

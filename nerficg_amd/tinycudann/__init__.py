@@ -66,10 +66,11 @@ class _NWIEFunction(torch.autograd.Function):
             xin = x.detach().to(torch.float16).contiguous()
             in_ld = xin.shape[1]
         g = module.grid_cfg
+        ws = torch.empty(int(lib.nrc_nwie_forward_ws_bytes(m)), dtype=torch.uint8, device=dev) if module.encoding == 0 else None
         _lib.check(lib.nrc_nwie_forward(
             module.encoding, _lib.ptr(xin), in_ld, m, _lib.ptr(w16), _lib.ptr(module._table16()), g['n_levels'],
             g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), module.n_hidden, module.out_act,
-            _PAD, _lib.ptr(out), module._out_ld, module._out_ld, _lib.ptr(save_in), _lib.ptr(save_acts),
+            _PAD, _lib.ptr(out), module._out_ld, module._out_ld, _lib.ptr(save_in), _lib.ptr(save_acts), _lib.ptr(ws),
             _lib.stream_of(out)), 'nwie_forward')
         if need_grad:
             ctx.module = module
