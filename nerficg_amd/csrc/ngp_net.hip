@@ -1008,6 +1008,92 @@ __global__ void __launch_bounds__(OWN_THREADS) k_grid_bwd_owned(const float* __r
     }
 }
 
+// Same ownership scheme with a sparse inner loop.  On a hashed level the slice of a corner, (index >> 14), depends only on its
+// (y, z) part: index = (x ^ y P1 ^ z P2) & mask and x < 2^14, so x cannot touch the slice bits.  A sample therefore has four
+// candidate slices, and seven samples out of eight have none in the slice this workgroup owns.  The main loop only computes the four
+// (y, z) hashes and queues the few samples that do hit (per-wave LDS queue); whenever 64 are queued the wave processes them
+// densely (all lanes busy) with the full corner arithmetic.  ~70 instead of ~140 instructions per sample and slice.
+#define OWN_Q 128  // queue entries per wave
+__global__ void __launch_bounds__(OWN_THREADS) k_grid_bwd_owned_q(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, GridCfg g,
+                                                                  OwnedCfg oc, float* __restrict__ grad_table) {
+    extern __shared__ float own_acc[];  // [OWN_ENTRIES][2] then the queues
+    uint32_t* queue = reinterpret_cast<uint32_t*>(own_acc + 2 * OWN_ENTRIES) + (threadIdx.x >> 6) * OWN_Q;
+    int li = 0;
+    while (li + 1 < oc.n_levels && (int)blockIdx.x >= oc.unit0[li + 1]) li++;
+    const int level = oc.level[li];
+    const uint32_t chunk = (uint32_t)((int)blockIdx.x - oc.unit0[li]);
+    const uint32_t lo = g.offset[level] + chunk * OWN_ENTRIES;
+    const uint32_t n_own = min((uint32_t)OWN_ENTRIES, g.size[level] - chunk * OWN_ENTRIES);
+    for (uint32_t j = threadIdx.x; j < 2 * n_own; j += OWN_THREADS) own_acc[j] = 0.f;
+    __syncthreads();
+    const float scale = g.scale[level];
+    const uint32_t res = g.res[level], size = g.size[level], off = g.offset[level], mask = size - 1u;
+    const float2* gfp = reinterpret_cast<const float2*>(d_feat) + (int64_t)level * M;
+    const int lane = threadIdx.x & 63;
+    auto scatter = [&](int64_t i) {  // all eight corners of sample i, the ones inside the slice are accumulated
+        const float2 gf = gfp[i];
+        Corner8 c;
+        grid_corners_u<true>(x[3 * i], x[3 * i + 1], x[3 * i + 2], scale, res, size, off, c);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t rel = c.e[k] - lo;
+            if (rel < n_own) {
+                atomicAdd(&own_acc[2 * rel], c.w[k] * gf.x);
+                atomicAdd(&own_acc[2 * rel + 1], c.w[k] * gf.y);
+            }
+        }
+    };
+    int qn = 0;  // wave-uniform
+    // four samples per lane and turn, their loads issued together: with one sample per turn the loop was bound by the latency of its
+    // two dependent loads at 4 waves per SIMD (480 us), not by instructions
+    enum { UNR = 4 };
+    const int64_t M_pad = (M + OWN_THREADS * UNR - 1) / (OWN_THREADS * UNR) * (OWN_THREADS * UNR);
+    for (int64_t i0 = threadIdx.x; i0 < M_pad; i0 += OWN_THREADS * UNR) {
+        float2 gfv[UNR];
+        float yv[UNR], zv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int64_t i = i0 + (int64_t)u * OWN_THREADS;
+            const int64_t ic = i < M ? i : M - 1;
+            gfv[u] = gfp[ic];
+            yv[u] = x[3 * ic + 1]; zv[u] = x[3 * ic + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int64_t i = i0 + (int64_t)u * OWN_THREADS;
+            bool hit = false;
+            if (i < M && !(gfv[u].x == 0.f && gfv[u].y == 0.f)) {
+                const float fy = fmaf(scale, yv[u], 0.5f), fz = fmaf(scale, zv[u], 0.5f);
+                const uint32_t gy = (uint32_t)(int32_t)floorf(fy), gz = (uint32_t)(int32_t)floorf(fz);
+                const uint32_t ty0 = gy * 2654435761u, tz0 = gz * 805459861u;
+                const uint32_t ty1 = ty0 + 2654435761u, tz1 = tz0 + 805459861u;
+                hit = (((ty0 ^ tz0) & mask) >> 14) == chunk || (((ty1 ^ tz0) & mask) >> 14) == chunk || (((ty0 ^ tz1) & mask) >> 14) == chunk ||
+                      (((ty1 ^ tz1) & mask) >> 14) == chunk;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                if (hit) queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+                qn += __popcll(m);
+                if (qn >= 64) {
+                    qn -= 64;
+                    scatter((int64_t)queue[qn + lane]);
+                }
+            }
+        }
+    }
+    if (lane < qn) scatter((int64_t)queue[lane]);
+    __syncthreads();
+    float2* out = reinterpret_cast<float2*>(grad_table) + lo;
+    for (uint32_t j = threadIdx.x; j < n_own; j += OWN_THREADS) {
+        const float a0 = own_acc[2 * j], a1 = own_acc[2 * j + 1];
+        if (a0 != 0.f || a1 != 0.f) {
+            float2 v = out[j];
+            v.x += a0; v.y += a1;
+            out[j] = v;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1063,9 +1149,18 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
                            (int)n_levels, ll, grad_table);
     if (oc.n_levels > 0) {
         static const hipError_t attr = hipFuncSetAttribute((const void*)k_grid_bwd_owned, hipFuncAttributeMaxDynamicSharedMemorySize, OWN_ENTRIES * 8);
-        (void)attr;
-        hipLaunchKernelGGL(k_grid_bwd_owned, dim3((unsigned)oc.unit0[oc.n_levels]), dim3(OWN_THREADS), OWN_ENTRIES * 8, s, x01, M, d_features, g, oc,
-                           grad_table);
+        static const hipError_t attr_q = hipFuncSetAttribute((const void*)k_grid_bwd_owned_q, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             OWN_ENTRIES * 8 + (OWN_THREADS / 64) * OWN_Q * 4);
+        (void)attr; (void)attr_q;
+        bool sparse_ok = M < (int64_t(1) << 32);  // queue entries are 32-bit sample indices; x corners must stay below the slice bits
+        for (int k = 0; k < oc.n_levels; k++) sparse_ok = sparse_ok && g.res[oc.level[k]] + 1u < (uint32_t)OWN_ENTRIES && g.size[oc.level[k]] >= (uint32_t)OWN_ENTRIES;
+        static const bool allow_q = [] { const char* e = getenv("NRC_GRID_BWD_SPARSE"); return !(e && e[0] == '0'); }();
+        if (sparse_ok && allow_q)
+            hipLaunchKernelGGL(k_grid_bwd_owned_q, dim3((unsigned)oc.unit0[oc.n_levels]), dim3(OWN_THREADS), OWN_ENTRIES * 8 + (OWN_THREADS / 64) * OWN_Q * 4,
+                               s, x01, M, d_features, g, oc, grad_table);
+        else
+            hipLaunchKernelGGL(k_grid_bwd_owned, dim3((unsigned)oc.unit0[oc.n_levels]), dim3(OWN_THREADS), OWN_ENTRIES * 8, s, x01, M, d_features, g, oc,
+                               grad_table);
     }
     NRC_LAUNCH_CHECK();
     return NRC_OK;
