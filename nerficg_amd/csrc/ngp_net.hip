@@ -1106,8 +1106,11 @@ int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int3
     if (n_hidden < 1 || n_hidden > 2 || (out_act != ACT_NONE && out_act != ACT_SIGMOID)) return NRC_ERR_UNSUPPORTED;
     if (M == 0) return NRC_OK;
     if (!d_out_f16 || !out_f16 || !save_in || !save_acts) return NRC_ERR_INVALID;
+    // every wave ends with an atomic flush of its weight-gradient accumulators (3 072 / 7 168 values): the number of waves, not the
+    // batch, sets that cost -- one workgroup per CU (NRC_BWD_BLOCKS env override for experiments)
+    static const int max_blocks = [] { const char* e = getenv("NRC_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
     const int64_t need = nrc_cdiv(nrc_cdiv(M, 32), 4);
-    const dim3 grid((unsigned)(need < 512 ? need : 512)), block(256);
+    const dim3 grid((unsigned)(need < max_blocks ? need : max_blocks)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define NRC_BWD(H, A)                                                                                                          \
     hipLaunchKernelGGL((k_nwie_bwd<H, A>), grid, block, 0, s, M, (const __half*)weights_f16, (int)n_out_rows, (const __half*)d_out_f16, \
