@@ -28,3 +28,29 @@ print('mean n_contrib per pixel', nc.mean(), ' mean tile max(last)', tmax.mean()
 print('sum over tiles of max(last) =', tmax.sum(), ' (x4 waves =', 4 * tmax.sum(), ') sum strips', strips.sum(), ' pixel-steps', nc.sum())
 r = sv['radii'].cpu().numpy()
 print('visible', (r > 0).sum(), 'radius px: mean', r[r > 0].mean(), 'median', np.median(r[r > 0]), 'p90', np.percentile(r[r > 0], 90), 'max', r.max())
+
+# ---- activity of the backward walk: per (tile, Gaussian of the blended prefix), how many 8x8 quadrants / pixels take part
+pl = sv['point_list'].long(); xy = sv['points_xy']; co = sv['conic_opacity']
+ncd = sv['n_contrib'].reshape(H, W)
+rng = np.random.default_rng(0)
+tot_pairs = act_quads = act_pix = any_tile = 0
+for t in rng.choice(gx * gy, 60, replace=False):
+    ty, tx = divmod(int(t), gx)
+    r0, r1 = int(ranges[t, 0]), int(ranges[t, 1])
+    ys = torch.arange(ty * 16, min(ty * 16 + 16, H), device=xy.device); xs = torch.arange(tx * 16, min(tx * 16 + 16, W), device=xy.device)
+    last = ncd[ys][:, xs].long()                                    # (h, w)
+    n = int(last.max())
+    if n == 0:
+        continue
+    ids = pl[r0:r0 + n]
+    dx = xy[ids, 0][:, None, None] - xs[None, None, :].float(); dy = xy[ids, 1][:, None, None] - ys[None, :, None].float()
+    c = co[ids]
+    power = -0.5 * (c[:, 0, None, None] * dx * dx + c[:, 2, None, None] * dy * dy) - c[:, 1, None, None] * dx * dy
+    alpha = torch.clamp(c[:, 3, None, None] * torch.exp(power), max=0.99)
+    act = (power <= 0) & (alpha >= 1.0 / 255.0) & (torch.arange(n, device=xy.device)[:, None, None] < last[None])
+    hh, ww = act.shape[1], act.shape[2]
+    pad = torch.zeros(n, 16, 16, dtype=torch.bool, device=xy.device); pad[:, :hh, :ww] = act
+    q = pad.reshape(n, 2, 8, 2, 8).any(dim=4).any(dim=2)             # (n, 2, 2) quadrants
+    tot_pairs += n; act_quads += int(q.sum()); act_pix += int(act.sum()); any_tile += int(q.reshape(n, 4).any(dim=1).sum())
+print(f'backward walk: {tot_pairs} (tile,Gaussian) pairs sampled; active quadrants per pair {act_quads / tot_pairs:.2f} of 4; '
+      f'pairs with any active quadrant {any_tile / tot_pairs:.2f}; active pixels per pair {act_pix / tot_pairs:.1f} of 256')
