@@ -1,7 +1,10 @@
 """Host-side mirrors (pure torch, CPU) against golden vectors generated from the reference's own Python
 (tests/golden/make_golden.py): projection / rasterizer-settings marshalling, SH -> RGB, covariance construction,
 quaternion -> rotation.  These are the in-tree pins of SURVEY.md 8(c) for a24 and a26."""
+from pathlib import Path
+
 import numpy as np
+import pytest
 import torch
 
 from nerficg_amd import gaussian_splatting as gs
@@ -88,3 +91,29 @@ def test_random_sequential_sampler_defines_the_ray_indices(golden_dir):
     s = RandomSequentialSampler(1000)
     draws = np.stack([s.get(300).numpy().copy() for _ in range(5)])
     np.testing.assert_array_equal(draws, g['sampler_draws'])  # includes the reshuffle on wrap-around
+
+
+def test_ray_batch_container_and_pool_sampler():
+    """RayBatch / RayCollection / RayPoolSampler semantics (Datasets/utils.py:537-690, DatasetSamplers.py:53-66) on CPU tensors."""
+    from nerficg_amd.rays import RayBatch, RayCollection, RayPoolSampler
+    n = 50
+    o, d = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3), torch.ones(n, 3)
+    rgb = torch.rand(n, 3)
+    b = RayBatch(origin=o, direction=d, rgb=rgb)
+    assert len(b) == n and b.has_annotations and b.as_tensor.shape == (n, 9) and b[...] is b and len(b[3]) == 1
+    ids = torch.tensor([4, 1, 7])
+    sub = b[ids]
+    assert torch.equal(sub.origin, o[ids]) and torch.equal(sub.rgb, rgb[ids]) and sub.view_direction is None
+    parts = b.split(16)
+    assert [len(p) for p in parts] == [16, 16, 16, 2] and torch.equal(RayBatch.cat(parts).origin, o)
+    with pytest.raises(ValueError):
+        RayBatch(origin=o, direction=d[:10])
+    with pytest.raises(ValueError):
+        RayBatch.cat([b, RayBatch(origin=o, direction=d)])
+    col = RayCollection(rays=b, rays_per_view=(20, 30))
+    assert len(col) == 2 and torch.equal(col[1].origin, o[20:]) and col.all_rays is b
+    g = np.load(Path(__file__).parent / 'golden' / 'misc.npz')
+    torch.manual_seed(0)
+    pool = RayPoolSampler(RayBatch(origin=torch.zeros(1000, 3), direction=torch.zeros(1000, 3)))
+    draws = np.stack([pool.get(300)['ray_ids'].numpy().copy() for _ in range(5)])
+    np.testing.assert_array_equal(draws, g['sampler_draws'])  # the reference's RandomSequentialSampler draws define the ray ids
