@@ -31,7 +31,7 @@ sys.path.insert(0, str(ROOT))
 W = H = 800
 N_POSES = 100
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-CHUNK_ROWS = 32768             # rows (x64 sample slots) per encode/MLP round of the library (NRC_QUERY_CHUNK)
+CHUNK_ROWS = 131072  # rows of 64 slots per encode/MLP launch = the library's NRC_QUERY_CHUNK (8 Mi slots)
 # dominant kernel = k_grid_encode.  Algorithmic bytes per LIVE sample: 16 levels x 8 corners x 2 features x 2 B of table
 # reads + 4 B sample record (t) + 64 B of encoded features written (fp16 x 32)
 ENC_BYTES_PER_SAMPLE = 512 + 4 + 64
@@ -58,7 +58,7 @@ def build_scene(device):
 
 def time_dominant_kernel(renderer, cam, pose, reps=3):
     """Average launch duration of the dominant kernel (k_grid_encode: 128 hash-grid gathers per sample) and of its partner
-    (k_ngp_mlp) over ALL Infinity-Cache sized chunks of one image's sample rows, measured with HIP events on the launch stream
+    (k_ngp_mlp) over ALL chunks (launches) of one image's sample rows, measured with HIP events on the launch stream
     (torch's current stream = our launch stream).  Returns (encode ms, slots per launch, live samples per launch, mlp ms)."""
     import torch
     from nerficg_amd import _lib

@@ -200,6 +200,9 @@ int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int3
  *   4. nrc_ngp_composite_image: serial per-ray compositing + background / clamps (bg3 HOST) into full-image buffers
  *                             rgb (H*W,3), alpha (H*W), depth (H*W) -- only the shard's pixels are written.
  * ===================================================================================================== */
+/* pixel footprint of a tile (tile width x height = 64; the tile grid is ceil(W / tw) x ceil(H / th), row-major) */
+int nrc_ngp_tile_width(void);
+int nrc_ngp_tile_height(void);
 int nrc_ngp_render_count(int32_t width, int32_t height, const double* intrinsics, const double* c2w, const float* center3,
                          const float* half3, float near_plane, float far_plane, int64_t tile_begin, int64_t n_tiles,
                          const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
@@ -215,12 +218,12 @@ int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float*
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                           float per_level_scale, void* packed_f16, void* workspace, nrc_stream_t stream);
 /* stage 3a on its own (the dominant kernel of the pipeline; used by bench.py's roofline leg): hash-grid features of the first
- * n_rows (<= 32768) rows, fragment-major: the 16-byte vector [((j>>5)*4 + ((g + (j>>5))&3))*32 + (j&31)] = levels 4g..4g+3 (fp16x2) of slot j */
+ * n_rows (<= 131072) rows, fragment-major: the 16-byte vector [((j>>5)*4 + ((g + (j>>5))&3))*32 + (j&31)] = levels 4g..4g+3 (fp16x2) of slot j */
 int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, const float* xyz_min3,
                            const float* xyz_size3, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
                            int32_t base_resolution, float per_level_scale, void* features_f16, nrc_stream_t stream);
 /* stage 3b on its own (the MFMA kernel; bench.py's second roofline object): features as written by nrc_ngp_encode_samples for the
- * first n_rows (<= 32768) rows -> packed (h0, r, g, b) fp16; ray_sh_workspace: n_ray_tiles * 2048 bytes */
+ * first n_rows (<= 131072) rows -> packed (h0, r, g, b) fp16; ray_sh_workspace: n_ray_tiles * 2048 bytes */
 int nrc_ngp_mlp_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
                         const void* features_f16, const void* density_weights_f16, const void* color_weights_f16,
                         void* packed_f16, void* ray_sh_workspace, nrc_stream_t stream);

@@ -81,3 +81,11 @@ __device__ __forceinline__ int nrc_block256_excl_scan_i(int v, int* smem, int* b
     __syncthreads();
     return base + incl - v;
 }
+
+// Pixel footprint of a sample-layout tile (= one wave) of the fused InstantNGP image pipeline: 2^NRC_TILE_W_LOG2 x 64/2^NRC_TILE_W_LOG2.
+#ifndef NRC_TILE_W_LOG2
+#define NRC_TILE_W_LOG2 3
+#endif
+#define NRC_TILE_W (1 << NRC_TILE_W_LOG2)
+#define NRC_TILE_H (64 >> NRC_TILE_W_LOG2)
+

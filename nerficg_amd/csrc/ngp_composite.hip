@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256) k_composite_image(const __half* __restric
     const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (lt >= n_tiles) return;
     const int64_t tile = tile_begin + lt;
-    const int px = (int)(tile % tiles_x) * 8 + (lane & 7), py = (int)(tile / tiles_x) * 8 + (lane >> 3);
+    const int px = (int)(tile % tiles_x) * NRC_TILE_W + (lane & (NRC_TILE_W - 1)), py = (int)(tile / tiles_x) * NRC_TILE_H + (lane >> NRC_TILE_W_LOG2);
     const bool inside = px < width && py < height;
     const int64_t row0 = tile_off[lt];
     const int N = inside ? ray_cnt[lt * 64 + lane] : 0;
@@ -389,7 +389,7 @@ int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32
     if (n_tiles < 0 || tile_begin < 0 || width < 1 || height < 1 || !bg3_host || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
     if (n_tiles == 0) return NRC_OK;
     if (!ray_cnt || !tile_off || !rgb || !alpha || !depth) return NRC_ERR_INVALID;
-    const int tiles_x = (width + 7) / 8;
+    const int tiles_x = (width + NRC_TILE_W - 1) / NRC_TILE_W;
     // calc_dt of the test kernel (raymarching.cu:11-13 with `cascades` in place of `scale`, :370)
     const float dt_min = 1.73205080757f / max_samples, dt_max = 1.73205080757f * 2 * (float)cascades / grid_size;
     hipLaunchKernelGGL(k_composite_image, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, (const __half*)packed_f16, ts, ray_cnt,

@@ -552,7 +552,7 @@ __device__ __forceinline__ void camera_ray(const RenderCam& cam, int64_t pix, Ra
 // Rays of a tile with fewer samples leave holes in the tail rows (ts = -1).
 __device__ __forceinline__ int64_t tile_pixel(const RayGenCfg& g, int64_t tile, int lane, int tiles_x) {
     const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
-    const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+    const int px = tx * NRC_TILE_W + (lane & (NRC_TILE_W - 1)), py = ty * NRC_TILE_H + (lane >> NRC_TILE_W_LOG2);
     return (px < g.width && py < g.height) ? (int64_t)py * g.width + px : -1;
 }
 __global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c, int tiles_x, int64_t tile_begin, int64_t n_tiles,
@@ -818,7 +818,7 @@ int nrc_ngp_render_count(int32_t width, int32_t height, const double* intr, cons
     if (width < 1 || height < 1 || !intr || !c2w || !center3 || !half3 || n_tiles < 0 || tile_begin < 0 || cascades < 1 ||
         grid_size < 1 || max_samples < 1 || !counter || !tile_off)
         return NRC_ERR_INVALID;
-    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    const int tiles_x = (width + NRC_TILE_W - 1) / NRC_TILE_W, tiles_y = (height + NRC_TILE_H - 1) / NRC_TILE_H;
     if (tile_begin + n_tiles > (int64_t)tiles_x * tiles_y) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (n_tiles > 0 && (!bitfield || !ray_od || !ray_t || !ray_cnt || !tile_rows)) return NRC_ERR_INVALID;

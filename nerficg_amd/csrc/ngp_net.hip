@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
 // by its register footprint and cannot keep the texture-address path busy (18-36 ms for 77 M samples, whichever way it was
 // scheduled), while its two halves run in 6.5 ms (gathers, latency hidden by 8 waves/SIMD) and 2.8 ms (MFMA) on their own.
 // The pipeline is therefore split at the 32 encoded features (64 B/sample, fp16, level-major so that both sides are
-// coalesced) and processed in chunks small enough for the features to stay in the 256 MB Infinity Cache.
+// coalesced) and processed in chunks of NRC_QUERY_CHUNK slots.
 //
 //   k_grid_encode : one lane per sample, all 16 levels (128 gathers, issued as 16-byte pair loads).  Bound by the L1
 //                   texture-cache access rate (~1 line / clk / CU: TCP_TOTAL_CACHE_ACCESSES / GRBM_GUI_ACTIVE in profiles/).
@@ -494,7 +494,8 @@ int pick_blocks(int64_t M) {
 
 }  // namespace
 
-#define NRC_QUERY_CHUNK (int64_t(2) << 20)  // samples per encode/MLP round: 2 Mi x 64 B of features = 128 MB, Infinity-Cache resident
+#define NRC_QUERY_CHUNK (int64_t(8) << 20)  // samples per encode/MLP round (512 MB of features).  Measured per 800x800 image: 2 Mi 11.0 ms,
+                                            // 4 Mi 10.5, 8 Mi 10.15, 16 Mi 10.17 -- the gaps between 2 x 38 launches cost more than features spilling past the Infinity Cache
 
 // workspace: [features of one chunk: roundup32(chunk) x 64 B][ray_sh: n_ray_tiles x 2 KB (tiled layout only)]
 static int64_t query_feat_bytes(int64_t M) {

@@ -218,7 +218,9 @@ class InstantNGPRenderer:
     # ---------------------------------------------------------------- MI355X-native image pipeline
     @staticmethod
     def n_image_tiles(camera: Camera) -> int:
-        return ((camera.width + 7) // 8) * ((camera.height + 7) // 8)
+        lib = _lib.load()
+        tw, th = int(lib.nrc_ngp_tile_width()), int(lib.nrc_ngp_tile_height())
+        return ((camera.width + tw - 1) // tw) * ((camera.height + th - 1) // th)
 
     @torch.no_grad()
     def render_image_fused(self, camera: Camera, c2w: np.ndarray, tile_begin: int = 0, n_tiles: int | None = None,
