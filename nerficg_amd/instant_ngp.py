@@ -327,3 +327,53 @@ class InstantNGPRenderer:
         m.occupancy_grid = torch.where(m.occupancy_grid < 0, m.occupancy_grid, torch.maximum(m.occupancy_grid * decay, occupancy_grid_tmp))
         mean_density = m.occupancy_grid[m.occupancy_grid > 0].mean().item()
         VolumeRenderingCuda.packbits(m.occupancy_grid, min(mean_density, self.density_threshold), m.occupancy_bitfield)
+
+    @torch.no_grad()
+    def carve_occupancy_grid(self, views, subtractive: bool = False, use_alpha: bool = False) -> None:
+        """Renderer.py:208-245.  `views`: iterable of (Camera, c2w (4,4), alpha (1,H,W) tensor or None) -- the fields of a dataset View the
+        reference reads.  Cells outside every frustum (subtractive=False) / outside any frustum (True) get -1 (never sampled again by
+        update_occupancy_grid), the others 0; the kept set is dilated by one cell (3x3x3)."""
+        m = self.model
+        dev = m.occupancy_grid.device
+        cells = self.get_occupancy_grid_cells()
+        cell_positions_world = []
+        for c in range(m.cascades):
+            _, coords = cells[c]
+            s = min(2 ** (c - 1), m.SCALE)
+            half_grid_size = s / m.RESOLUTION
+            cell_positions_world.append((coords / (m.RESOLUTION - 1) * 2 - 1) * (s - half_grid_size) + m.center)
+        remaining_cells = torch.full_like(m.occupancy_grid, fill_value=subtractive, dtype=torch.bool, device=dev)
+        dilation_kernel_2d = torch.ones(1, 1, 3, 3, device=dev)
+        for camera, c2w, alpha_gt in views:
+            if use_alpha and alpha_gt is not None:
+                alpha_gt = torch.nn.functional.conv2d(alpha_gt.to(dev)[None], dilation_kernel_2d, padding=1)[0] > 0.0
+            for c in range(m.cascades):
+                xy_screen, _, in_frustum = project_points(camera, c2w, cell_positions_world[c])
+                if use_alpha and alpha_gt is not None:
+                    xy_screen = torch.floor(xy_screen[in_frustum]).long()
+                    alpha_values = alpha_gt[:, xy_screen[:, 1], xy_screen[:, 0]] > 0.0
+                    in_frustum[in_frustum.clone()] = alpha_values[0]
+                remaining_cells[c] = remaining_cells[c] & in_frustum if subtractive else remaining_cells[c] | in_frustum
+        dilation_kernel_3d = torch.ones(1, 1, 3, 3, 3, device=dev)
+        for c in range(m.cascades):
+            # `remaining_cells[c]` is indexed like grid_coords (x-major meshgrid order), exactly as in the reference
+            dilated = torch.nn.functional.conv3d(remaining_cells[c].reshape(1, 1, m.RESOLUTION, m.RESOLUTION, m.RESOLUTION).float(),
+                                                 dilation_kernel_3d, padding=1)
+            values = torch.where(dilated.flatten() > 0.0, 0.0, -1.0)
+            m.occupancy_grid[c, cells[c][0]] = values
+
+
+def project_points(camera: Camera, c2w, xyz_world: torch.Tensor, z_culling: bool = True):
+    """View.project_points (src/Datasets/utils.py:1040-1044): world_to_cam (:1027-1031, (x - position) @ R) then
+    PerspectiveCamera.cam_to_screen (src/Cameras/Perspective.py:39-52, undistorted)."""
+    c2w = torch.as_tensor(np.asarray(c2w, dtype=np.float64)[:4, :4], dtype=xyz_world.dtype, device=xyz_world.device)
+    xyz_cam = (xyz_world - c2w[:3, 3]) @ c2w[:3, :3]
+    depth = xyz_cam[:, 2]
+    focals = torch.tensor((camera.focal_x, camera.focal_y), device=xyz_world.device, dtype=xyz_world.dtype)
+    screen_size = torch.tensor((camera.width, camera.height), device=xyz_world.device, dtype=xyz_world.dtype)
+    center = torch.tensor((camera.center_x, camera.center_y), device=xyz_world.device, dtype=xyz_world.dtype)
+    xy_screen = xyz_cam[:, :2] / depth.clamp_min(1.0e-8)[:, None] * focals + center
+    in_frustum = ((xy_screen >= 0) & (xy_screen < screen_size)).all(dim=-1)
+    if z_culling:
+        in_frustum &= (depth > camera.near_plane) & (depth < camera.far_plane)
+    return xy_screen, depth, in_frustum

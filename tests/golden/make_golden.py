@@ -133,6 +133,15 @@ def main():
         ray_cases[f'{tag}_origin'] = rays.origin[idx].numpy()
         ray_cases[f'{tag}_direction'] = rays.direction[idx].numpy()
         ray_cases[f'{tag}_view_direction'] = rays.view_direction[idx].numpy()
+    # View.project_points (Datasets/utils.py:1040-1044 -> Perspective.cam_to_screen :39-52), used by carve_occupancy_grid (a19)
+    settings = SharedCameraSettings(background_color=torch.tensor([1.0, 1.0, 1.0]), near_plane=0.2, far_plane=1000.0)
+    cam = PerspectiveCamera(shared_settings=settings, width=53, height=31, focal_x=60.0, focal_y=66.0, center_x=53 / 2 + 1.25, center_y=31 / 2 - 0.75)
+    c2w = lookat_pose(2.1, -0.3, 1.7)
+    view = View(camera=cam, camera_index=0, frame_idx=0, global_frame_idx=0, c2w=c2w)
+    pts = (torch.rand(400, 3, generator=g) * 2 - 1) * 1.5
+    xy, depth, inside = view.project_points(pts)
+    ray_cases.update(proj_intr=np.array([53, 31, 60.0, 66.0, cam.center_x, cam.center_y, 0.2, 1000.0]), proj_c2w=c2w, proj_pts=pts.numpy(),
+                     proj_xy=xy.numpy(), proj_depth=depth.numpy(), proj_in_frustum=inside.numpy())
     np.savez_compressed(OUT / 'raygen.npz', **ray_cases)
 
     # ---------------------------------------------------------------- projection / GS settings (a24)

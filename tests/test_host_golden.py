@@ -117,3 +117,16 @@ def test_ray_batch_container_and_pool_sampler():
     pool = RayPoolSampler(RayBatch(origin=torch.zeros(1000, 3), direction=torch.zeros(1000, 3)))
     draws = np.stack([pool.get(300)['ray_ids'].numpy().copy() for _ in range(5)])
     np.testing.assert_array_equal(draws, g['sampler_draws'])  # the reference's RandomSequentialSampler draws define the ray ids
+
+
+def test_project_points_matches_reference_view(golden_dir):
+    from nerficg_amd.instant_ngp import Camera, project_points
+    g = np.load(golden_dir / 'raygen.npz')
+    w, h, fx, fy, cx, cy, near, far = g['proj_intr']
+    cam = Camera(width=int(w), height=int(h), focal_x=float(fx), focal_y=float(fy), center_x=float(cx), center_y=float(cy), near_plane=float(near),
+                 far_plane=float(far))
+    xy, depth, inside = project_points(cam, g['proj_c2w'], torch.from_numpy(g['proj_pts']))
+    np.testing.assert_array_equal(inside.numpy(), g['proj_in_frustum'])
+    np.testing.assert_allclose(depth.numpy(), g['proj_depth'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(xy.numpy()[g['proj_in_frustum']], g['proj_xy'][g['proj_in_frustum']], rtol=1e-5, atol=1e-4)
+    assert 0 < g['proj_in_frustum'].sum() < len(g['proj_in_frustum'])

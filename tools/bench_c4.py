@@ -11,7 +11,7 @@ from nerficg_amd import parallel
 dev = torch.device('cuda', 0)
 model, renderer, cam, poses = bench.build_scene(dev)
 W, H = 1600, 1060
-big = Camera(width=W, height=H, focal_x=cam.focal_x * W / cam.width, focal_y=cam.focal_x * W / cam.width, center_x=0.0, center_y=0.0,
+big = Camera(width=W, height=H, focal_x=cam.focal_x * W / cam.width, focal_y=cam.focal_x * W / cam.width, center_x=W / 2, center_y=H / 2,
              near_plane=cam.near_plane, far_plane=cam.far_plane, background_color=cam.background_color)
 nt = renderer.n_image_tiles(big)
 b3, e3 = parallel.shard_range(nt, 3, 8)
