@@ -67,6 +67,7 @@ struct MarchCfg {
     float scale, esf, dt_scale;  // dt_scale: `scale` (train) or `(float)cascades` (test kernel quirk, raymarching.cu:370)
     uint32_t grid_size3;
     float grid_size_inv;
+    float mip0_bound, mip0_bound_inv;  // cascades == 1: the mip level is always 0, its bound and reciprocal are constants (same f32 values)
 };
 
 // The cell containing o + t d: sample position, step, occupancy bit and (for an empty cell) the t beyond which the march resumes.
@@ -74,9 +75,13 @@ struct MarchCfg {
 __device__ __forceinline__ bool cell_probe(const Ray& q, const MarchCfg& c, float t, float& x, float& y, float& z, float& dt, float& t_target) {
     x = q.ox + t * q.dx; y = q.oy + t * q.dy; z = q.oz + t * q.dz;
     dt = calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale);
-    const int mip = max(mip_from_pos(x, y, z, c.cascades), mip_from_dt(dt, c.grid_size, c.cascades));
-    const float mip_bound = fminf(scalbnf(1.0f, mip - 1), c.scale);
-    const float mip_bound_inv = 1 / mip_bound;
+    int mip = 0;
+    float mip_bound = c.mip0_bound, mip_bound_inv = c.mip0_bound_inv;
+    if (c.cascades > 1) {  // wave-uniform; with one cascade min(cascades - 1, .) pins the level to 0 and the frexp / scalbn / divide drop out
+        mip = max(mip_from_pos(x, y, z, c.cascades), mip_from_dt(dt, c.grid_size, c.cascades));
+        mip_bound = fminf(scalbnf(1.0f, mip - 1), c.scale);
+        mip_bound_inv = 1 / mip_bound;
+    }
     const int nx = (int)clampf(0.5f * (x * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
     const int ny = (int)clampf(0.5f * (y * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
     const int nz = (int)clampf(0.5f * (z * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
@@ -640,6 +645,8 @@ MarchCfg make_cfg(const uint8_t* bitfield, int cascades, float scale, float esf,
     c.scale = scale; c.esf = esf; c.dt_scale = dt_scale;
     c.grid_size3 = (uint32_t)grid_size * grid_size * grid_size;
     c.grid_size_inv = 1.0f / grid_size;
+    c.mip0_bound = fminf(0.5f, scale);  // fminf(scalbnf(1, -1), scale)
+    c.mip0_bound_inv = 1.0f / c.mip0_bound;
     return c;
 }
 
