@@ -253,19 +253,32 @@ __global__ void __launch_bounds__(256) k_composite_image(const __half* __restric
     const int N = inside ? ray_cnt[lt * 64 + lane] : 0;
     float T = 1.0f, accR = 0.f, accG = 0.f, accB = 0.f, accD = 0.f, accO = 0.f;
     bool alive = N > 0;
-    for (int k = 0; __any(alive); k++) {
-        if (alive) {
-            const int64_t s = (row0 + k) * 64 + lane;
-            const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(packed) + 4 * s);
-            const float2 f01 = __half22float2(*reinterpret_cast<const __half2*>(&raw.x));
-            const float2 f23 = __half22float2(*reinterpret_cast<const __half2*>(&raw.y));
-            const float t = ts[s];
-            const float dt = fmaxf(dt_min, fminf(t * esf, dt_max));
-            const float a = alpha_of(expf(f01.x), dt);
-            const float w = a * T;
-            accR += w * f01.y; accG += w * f23.x; accB += w * f23.y; accD += w * t; accO += w;
-            T *= 1.0f - a;
-            if (T <= thr || k + 1 >= N) alive = false;
+    // four rows per turn, their loads issued together (a row's loads depend on nothing but k): the serial per-lane loop was bound by
+    // one exposed load latency per sample
+    enum { CU = 4 };
+    for (int k = 0; __any(alive); k += CU) {
+        uint2 raw[CU];
+        float tv[CU];
+#pragma unroll
+        for (int u = 0; u < CU; u++) {
+            const bool in = alive && k + u < N;
+            const int64_t s = (row0 + (in ? k + u : 0)) * 64 + lane;
+            raw[u] = in ? *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(packed) + 4 * s) : make_uint2(0u, 0u);
+            tv[u] = in ? ts[s] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < CU; u++) {
+            if (alive && k + u < N) {
+                const float2 f01 = __half22float2(*reinterpret_cast<const __half2*>(&raw[u].x));
+                const float2 f23 = __half22float2(*reinterpret_cast<const __half2*>(&raw[u].y));
+                const float t = tv[u];
+                const float dt = fmaxf(dt_min, fminf(t * esf, dt_max));
+                const float a = alpha_of(expf(f01.x), dt);
+                const float w = a * T;
+                accR += w * f01.y; accG += w * f23.x; accB += w * f23.y; accD += w * t; accO += w;
+                T *= 1.0f - a;
+                if (T <= thr || k + u + 1 >= N) alive = false;
+            }
         }
     }
     if (inside) {
