@@ -204,68 +204,6 @@ __device__ __forceinline__ void grid_level_features(__amdgpu_buffer_rsrc_t rsrc,
     }
 }
 
-// ---- split-phase encoding: issue the 64 gathers of a sample now, interpolate later ------------------------------------
-// The texture-address path is the bottleneck of the encoding (one distinct cache line per clock per CU); the only way to
-// keep it busy while the same wave runs its MFMA chain is to have the NEXT tile's gathers in flight across that chain.
-struct GridPending {
-    uint32_t raw[2][4][8];  // fp16x2 table entries of the 8 corners, [k-step][level in step][corner]
-    float fr[2][4][3];      // fractional cell coordinates
-};
-__device__ __forceinline__ void encode_grid_issue(float px, float py, float pz, int hh, __amdgpu_buffer_rsrc_t table, const GridCfg& g,
-                                                  GridPending& pd) {
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int l0 = 8 * s + q, l1 = 8 * s + 4 + q;
-            const float scale = hh ? g.scale[l1] : g.scale[l0];
-            const uint32_t res = hh ? g.res[l1] : g.res[l0];
-            const uint32_t size = hh ? g.size[l1] : g.size[l0];
-            const uint32_t off = hh ? g.offset[l1] : g.offset[l0];
-            const bool hashed = hh ? g.hashed[l1] : g.hashed[l0];
-            const float fx = fmaf(scale, px, 0.5f), fy = fmaf(scale, py, 0.5f), fz = fmaf(scale, pz, 0.5f);
-            const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-            const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
-            pd.fr[s][q][0] = fx - flx; pd.fr[s][q][1] = fy - fly; pd.fr[s][q][2] = fz - flz;
-            const uint32_t my = hashed ? 2654435761u : res, mz = hashed ? 805459861u : res * res;
-            const uint32_t ty0 = gy * my, tz0 = gz * mz;
-            const uint32_t ty[2] = {ty0, ty0 + my}, tz[2] = {tz0, tz0 + mz};
-            const uint32_t mask = size - 1u;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t qx = gx + (k & 1), a = ty[(k >> 1) & 1], b = tz[(k >> 2) & 1];
-                const uint32_t h = (qx ^ a ^ b) & mask;
-                uint32_t d = qx + a + b;
-                d = d >= size ? d - size : d;
-                d = min(d, mask);
-                pd.raw[s][q][k] = __builtin_amdgcn_raw_buffer_load_b32(table, (off + (hashed ? h : d)) << 2, 0, 0);
-            }
-        }
-    }
-}
-__device__ __forceinline__ void encode_grid_finish(const GridPending& pd, h8 (&B)[2]) {
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float wx1 = pd.fr[s][q][0], wy1 = pd.fr[s][q][1], wz1 = pd.fr[s][q][2];
-            const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
-            const float wxy[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
-            float f0 = 0.f, f1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const float w = wxy[k & 3] * ((k & 4) ? wz1 : wz0);
-                const __half2 hv = *reinterpret_cast<const __half2*>(&pd.raw[s][q][k]);
-                const float2 t = __half22float2(hv);
-                f0 = fmaf(w, t.x, f0);
-                f1 = fmaf(w, t.y, f1);
-            }
-            B[s][2 * q] = (_Float16)f0;
-            B[s][2 * q + 1] = (_Float16)f1;
-        }
-    }
-}
-
 // ---- SH degree 4 (16 coefficients) of a direction in [-1,1]^3 ------------------------------------------------------
 __device__ __forceinline__ void sh4_eval(float x, float y, float z, float* o) {
     const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
