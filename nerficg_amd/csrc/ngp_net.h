@@ -204,6 +204,22 @@ __device__ __forceinline__ void grid_level_features(__amdgpu_buffer_rsrc_t rsrc,
     }
 }
 
+// dense (coarse) levels: the lanes of a wave share a handful of cache lines, so the cost of a gather is its data return, not its
+// tag lookups -- eight 4-byte loads (256 B per wave instruction) beat four 16-byte loads (1 KB per wave instruction) there
+__device__ __forceinline__ void grid_level_features_narrow(__amdgpu_buffer_rsrc_t rsrc, const Corner8& c, float& f0, float& f1) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, c.e[k] << 2, 0, 0);
+    f0 = 0.f; f1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const __half2 hv = *reinterpret_cast<const __half2*>(&v[k]);
+        const float2 t = __half22float2(hv);
+        f0 = fmaf(c.w[k], t.x, f0);
+        f1 = fmaf(c.w[k], t.y, f1);
+    }
+}
+
 // ---- SH degree 4 (16 coefficients) of a direction in [-1,1]^3 ------------------------------------------------------
 __device__ __forceinline__ void sh4_eval(float x, float y, float z, float* o) {
     const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
