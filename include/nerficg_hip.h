@@ -161,6 +161,15 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
                         nrc_stream_t stream);
 
 /* =====================================================================================================
+ * Group 9 -- mean squared distance to the 3 nearest neighbours (3DGS scale initialisation): replaces simple_knn._C.distCUDA2
+ *            (src/Thirdparty/SimpleKNN.py:17-18, used at src/Optim/knn_utils.py:34-38).  The points must arrive in Morton order
+ *            (Group 2 codes + a sort: nerficg_amd/simple_knn does both); out_sorted[i] belongs to sorted point i.  n >= 4.
+ *            workspace: nrc_knn3_ws_bytes(n) bytes.  Exact (not approximate) neighbours.
+ * ===================================================================================================== */
+int64_t nrc_knn3_ws_bytes(int64_t n);
+int nrc_knn3_mean_sq_dist(const float* points_morton_sorted, int64_t n, float* out_sorted, void* workspace, nrc_stream_t stream);
+
+/* =====================================================================================================
  * Group 8 -- fused Adam step: replaces apex.optimizers.FusedAdam (src/Thirdparty/Apex.py:17) as constructed at
  *            src/Methods/InstantNGP/Trainer.py:33-38 and src/Methods/GaussianSplatting/Model.py:131-136.  One flat f32 tensor
  *            per call, all four pointers 16-byte aligned.  bias_correction_k = 1 - beta_k^step (host).  adam_w_mode = 0: L2

@@ -24,7 +24,9 @@ COMMON_FLAGS = ['-O3', '-fPIC', f'--offload-arch={ARCH}', '-std=c++17', '-Wall',
 # translation units whose f32 arithmetic decides integer indices: no FMA contraction (bit-exact vs oracle/)
 PER_FILE_FLAGS = {
     'ngp_march.hip': ['-ffp-contract=off'],
-    'adam.hip': ['-ffp-contract=off'],  # HBM-bound anyway; keeps the update bit-identical to oracle/adam_oracle.c
+    'adam.hip': ['-ffp-contract=off'],
+    'knn.hip': ['-ffp-contract=off'],   # squared distances decide the neighbour set: same f32 sequence as oracle/knn_oracle.c
+  # HBM-bound anyway; keeps the update bit-identical to oracle/adam_oracle.c
     # + no atomic optimizer: it rewrites the one-lane LDS atomics of k_render_bw into 15-instruction wave-reduction loops
     'gs_raster.hip': ['-ffp-contract=off', '-mllvm', '-amdgpu-atomic-optimizer-strategy=None'],
 }

@@ -338,3 +338,11 @@ def adam_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0
     _call('oracle_adam_step', p, _c(g, f32), m, v, p.size, float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
           int(bool(adam_w_mode)), float(bc1), float(bc2), float(grad_scale), int(bool(found_inf)))
     return p, m, v
+
+
+# ------------------------------------------------------------------------------------------------ 3-NN (knn_oracle.c)
+def knn3_mean_sq_dist(points):
+    p = _c(points, f32)
+    out = np.empty(p.shape[0], f32)
+    _call('oracle_knn3_mean_sq_dist', p, p.shape[0], out)
+    return out

@@ -29,12 +29,13 @@ def test_shim_modules_export_the_expected_names(monkeypatch):
     assert hasattr(dgr, 'GaussianRasterizationSettings') and hasattr(dgr, 'GaussianRasterizer')
     assert callable(importlib.import_module('fused_ssim').fused_ssim)
     assert importlib.import_module('apex.optimizers').FusedAdam.__name__ == 'FusedAdam'
+    assert callable(importlib.import_module('simple_knn')._C.distCUDA2)
     seg = importlib.import_module('torch_scatter').segment_csr
     src = torch.arange(12, dtype=torch.float32).reshape(6, 2)
     out = seg(src, torch.tensor([0, 2, 2, 6]))
     assert torch.equal(out, torch.stack([src[0:2].sum(0), torch.zeros(2), src[2:6].sum(0)]))
     for name in ('VolumeRenderingV2', 'MortonEncoding', 'MortonEncoding._C', 'tinycudann', 'diff_gaussian_rasterization', 'fused_ssim', 'apex', 'apex.optimizers',
-                 'torch_scatter'):
+                 'torch_scatter', 'simple_knn'):
         sys.modules.pop(name, None)
 
 
@@ -54,6 +55,8 @@ import Thirdparty.DiffGaussianRasterization as dgr
 import Thirdparty.FusedSSIM as fs
 import Thirdparty.Apex as apex
 import Thirdparty.TorchScatter as ts
+import Thirdparty.SimpleKNN as knn
+assert callable(knn.compute_mean_squared_knn_distances)
 import CudaUtils.MortonEncoding as me
 import Methods.InstantNGP.VolumeRenderingV2 as vr
 assert tcnn.NetworkWithInputEncoding.__module__.startswith('nerficg_amd')
