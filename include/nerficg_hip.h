@@ -161,36 +161,51 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
                         nrc_stream_t stream);
 
 /* =====================================================================================================
- * Group 9 -- mean squared distance to the 3 nearest neighbours (3DGS scale initialisation): replaces simple_knn._C.distCUDA2
- *            (src/Thirdparty/SimpleKNN.py:17-18, used at src/Optim/knn_utils.py:34-38).  The points must arrive in Morton order
- *            (Group 2 codes + a sort: nerficg_amd/simple_knn does both); out_sorted[i] belongs to sorted point i.  n >= 4.
- *            workspace: nrc_knn3_ws_bytes(n) bytes.  Exact (not approximate) neighbours.
+ * Group 4 -- diff_gaussian_rasterization  (replaces the external CUDA rasterizer pinned at
+ *            src/Thirdparty/DiffGaussianRasterization.py:9 behind src/Methods/GaussianSplatting/Renderer.py:60-81,94-153,163-183)
+ * P Gaussians, SH degree D (0..3), M = SH coefficients per Gaussian in `shs` (P,M,3); exactly one of shs | colors_precomp (P,3)
+ * and exactly one of (scales (P,3), rotations (P,4)) | cov3D_precomp (P,6).  viewmatrix / projmatrix (16 floats each, the
+ * (4,4) tensors the reference passes: w2c.T and w2c.T @ P.T), campos (3), bg (3) are HOST pointers.  16x16-pixel tiles.
+ * Per-Gaussian state (geometry buffer): radii (P) i32, depths (P), points_xy (P,2), conic_opacity (P,4), rgb (P,3),
+ * clamped (P) u8 bit mask (bit c = channel c clamped), cov3D (P,6), tiles_touched (P) u32.
+ * Binning state: tile_counts, tile_fill (n_tiles) u32, ranges (n_tiles,2) u32, keys (num_rendered) u64, point_list
+ * (num_rendered) i32.  Image state: n_contrib (H*W) u32, final_T (H*W).
+ *   nrc_gs_preprocess : stages 1-2; *num_rendered (DEVICE i64) = number of (tile, Gaussian) instances -- the caller reads it
+ *                       to size keys / point_list (the reference's rasterizer pays the same device->host read).
+ *   nrc_gs_bin_render : stages 3-5 -> out_color (3,H,W) = C + T * bg, n_contrib, final_T.
+ *   nrc_gs_backward   : dL_dpix (3,H,W) -> every gradient (all fully written; dL_dmean2D (P,3) is the screen-space gradient
+ *                       consumed by densification, src/Methods/GaussianSplatting/Model.py:258).
  * ===================================================================================================== */
-int64_t nrc_knn3_ws_bytes(int64_t n);
-int nrc_knn3_mean_sq_dist(const float* points_morton_sorted, int64_t n, float* out_sorted, void* workspace, nrc_stream_t stream);
-
-/* =====================================================================================================
- * Group 8 -- fused Adam step (SURVEY 8f): replaces apex.optimizers.FusedAdam (src/Thirdparty/Apex.py:17) as constructed at
- *            src/Methods/InstantNGP/Trainer.py:33-38 and src/Methods/GaussianSplatting/Model.py:131-136.  One flat f32 tensor
- *            per call, all four pointers 16-byte aligned.  bias_correction_k = 1 - beta_k^step (host).  adam_w_mode = 0: L2
- *            weight decay added to the gradient (apex ADAM_MODE_0), 1: decoupled.  grad_scale / found_inf: optional DEVICE
- *            scalars of torch.amp.GradScaler (gradient divided by *grad_scale; the whole step is skipped when *found_inf != 0).
- * ===================================================================================================== */
-int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, int32_t adam_w_mode, float bias_correction1,
-                  float bias_correction2, const float* grad_scale, const float* found_inf, nrc_stream_t stream);
-
-/* =====================================================================================================
- * Group 7 -- SSIM map and its gradient (3DGS loss; SURVEY 8f): replaces fused_ssim as imported at
- *            src/Thirdparty/FusedSSIM.py:15 and called at src/Optim/Losses/DSSIM.py:11-18.  Images are (planes, H, W) f32 with
- *            planes = batch * channels; 11x11 Gaussian window (sigma 1.5), zero "same" padding.  The three derivative maps
- *            (d ssim / d mu1, d sigma1^2, d sigma12) are written when all three pointers are non-null (training).
- * ===================================================================================================== */
-int nrc_ssim_forward(const float* img1, const float* img2, int64_t planes, int32_t H, int32_t W, float C1, float C2, float* ssim_map,
-                     float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, nrc_stream_t stream);
-int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int32_t H, int32_t W, const float* dL_dmap,
-                      const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
+/* bytes of the per-workgroup tile-histogram matrix `bin_hist` used by the LDS binning path (0 = image too large, pass NULL) */
+int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H);
+int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs,
+                      const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                      const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                      const float* campos, float tan_fovx, float tan_fovy, int32_t* radii, float* depths, float* points_xy,
+                      float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched,
+                      uint32_t* tile_counts, uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t* num_rendered,
                       nrc_stream_t stream);
+int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg, const int32_t* radii, const float* depths,
+                      const float* points_xy, const float* conic_opacity, const float* rgb, const uint32_t* ranges,
+                      uint32_t* tile_fill, const uint32_t* bin_hist, uint64_t* keys, int32_t* point_list, float* out_color,
+                      uint32_t* n_contrib, float* final_T, nrc_stream_t stream);
+int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg, const float* means3D, const float* shs,
+                    const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                    float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
+                    const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list,
+                    const uint32_t* ranges, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
+                    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, nrc_stream_t stream);
+
+/* =====================================================================================================
+ * Group 5 -- ray generation (replaces PerspectiveCamera.compute_local_ray_directions src/Cameras/Perspective.py:64-94
+ * + View.get_rays / cam_to_world src/Datasets/utils.py:1033-1074 for undistorted perspective cameras).
+ * intrinsics (HOST, 4 doubles): focal_x, focal_y, center_x, center_y.  c2w (HOST, 16 doubles, row-major 4x4).
+ * Outputs (H*W,3) f32 each, y-major then x; any output pointer may be NULL.
+ * ===================================================================================================== */
+int nrc_generate_rays(int32_t width, int32_t height, const double* intrinsics, const double* c2w, float* origin,
+                      float* direction, float* view_direction, nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 6 -- fused InstantNGP image pipeline (MI355X-native restructuring of InstantNGPRenderer.render_image ->
@@ -242,51 +257,36 @@ int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32
                             const float* bg3, float* rgb, float* alpha, float* depth, nrc_stream_t stream);
 
 /* =====================================================================================================
- * Group 4 -- diff_gaussian_rasterization  (replaces the external CUDA rasterizer pinned at
- *            src/Thirdparty/DiffGaussianRasterization.py:9 behind src/Methods/GaussianSplatting/Renderer.py:60-81,94-153,163-183)
- * P Gaussians, SH degree D (0..3), M = SH coefficients per Gaussian in `shs` (P,M,3); exactly one of shs | colors_precomp (P,3)
- * and exactly one of (scales (P,3), rotations (P,4)) | cov3D_precomp (P,6).  viewmatrix / projmatrix (16 floats each, the
- * (4,4) tensors the reference passes: w2c.T and w2c.T @ P.T), campos (3), bg (3) are HOST pointers.  16x16-pixel tiles.
- * Per-Gaussian state (geometry buffer): radii (P) i32, depths (P), points_xy (P,2), conic_opacity (P,4), rgb (P,3),
- * clamped (P) u8 bit mask (bit c = channel c clamped), cov3D (P,6), tiles_touched (P) u32.
- * Binning state: tile_counts, tile_fill (n_tiles) u32, ranges (n_tiles,2) u32, keys (num_rendered) u64, point_list
- * (num_rendered) i32.  Image state: n_contrib (H*W) u32, final_T (H*W).
- *   nrc_gs_preprocess : stages 1-2; *num_rendered (DEVICE i64) = number of (tile, Gaussian) instances -- the caller reads it
- *                       to size keys / point_list (the reference's rasterizer pays the same device->host read).
- *   nrc_gs_bin_render : stages 3-5 -> out_color (3,H,W) = C + T * bg, n_contrib, final_T.
- *   nrc_gs_backward   : dL_dpix (3,H,W) -> every gradient (all fully written; dL_dmean2D (P,3) is the screen-space gradient
- *                       consumed by densification, src/Methods/GaussianSplatting/Model.py:258).
+ * Group 7 -- SSIM map and its gradient (3DGS loss; SURVEY 8f): replaces fused_ssim as imported at
+ *            src/Thirdparty/FusedSSIM.py:15 and called at src/Optim/Losses/DSSIM.py:11-18.  Images are (planes, H, W) f32 with
+ *            planes = batch * channels; 11x11 Gaussian window (sigma 1.5), zero "same" padding.  The three derivative maps
+ *            (d ssim / d mu1, d sigma1^2, d sigma12) are written when all three pointers are non-null (training).
  * ===================================================================================================== */
-/* bytes of the per-workgroup tile-histogram matrix `bin_hist` used by the LDS binning path (0 = image too large, pass NULL) */
-int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H);
-int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs,
-                      const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
-                      const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                      const float* campos, float tan_fovx, float tan_fovy, int32_t* radii, float* depths, float* points_xy,
-                      float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched,
-                      uint32_t* tile_counts, uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t* num_rendered,
+int nrc_ssim_forward(const float* img1, const float* img2, int64_t planes, int32_t H, int32_t W, float C1, float C2, float* ssim_map,
+                     float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, nrc_stream_t stream);
+int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int32_t H, int32_t W, const float* dL_dmap,
+                      const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
                       nrc_stream_t stream);
-int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg, const int32_t* radii, const float* depths,
-                      const float* points_xy, const float* conic_opacity, const float* rgb, const uint32_t* ranges,
-                      uint32_t* tile_fill, const uint32_t* bin_hist, uint64_t* keys, int32_t* point_list, float* out_color,
-                      uint32_t* n_contrib, float* final_T, nrc_stream_t stream);
-int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg, const float* means3D, const float* shs,
-                    const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
-                    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
-                    float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
-                    const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list,
-                    const uint32_t* ranges, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
-                    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-                    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, nrc_stream_t stream);
 
 /* =====================================================================================================
- * Group 5 -- ray generation (replaces PerspectiveCamera.compute_local_ray_directions src/Cameras/Perspective.py:64-94
- * + View.get_rays / cam_to_world src/Datasets/utils.py:1033-1074 for undistorted perspective cameras).
- * intrinsics (HOST, 4 doubles): focal_x, focal_y, center_x, center_y.  c2w (HOST, 16 doubles, row-major 4x4).
- * Outputs (H*W,3) f32 each, y-major then x; any output pointer may be NULL.
+ * Group 8 -- fused Adam step (SURVEY 8f): replaces apex.optimizers.FusedAdam (src/Thirdparty/Apex.py:17) as constructed at
+ *            src/Methods/InstantNGP/Trainer.py:33-38 and src/Methods/GaussianSplatting/Model.py:131-136.  One flat f32 tensor
+ *            per call, all four pointers 16-byte aligned.  bias_correction_k = 1 - beta_k^step (host).  adam_w_mode = 0: L2
+ *            weight decay added to the gradient (apex ADAM_MODE_0), 1: decoupled.  grad_scale / found_inf: optional DEVICE
+ *            scalars of torch.amp.GradScaler (gradient divided by *grad_scale; the whole step is skipped when *found_inf != 0).
  * ===================================================================================================== */
-int nrc_generate_rays(int32_t width, int32_t height, const double* intrinsics, const double* c2w, float* origin,
-                      float* direction, float* view_direction, nrc_stream_t stream);
+int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t adam_w_mode, float bias_correction1,
+                  float bias_correction2, const float* grad_scale, const float* found_inf, nrc_stream_t stream);
+
+/* =====================================================================================================
+ * Group 9 -- mean squared distance to the 3 nearest neighbours (3DGS scale initialisation): replaces simple_knn._C.distCUDA2
+ *            (src/Thirdparty/SimpleKNN.py:17-18, used at src/Optim/knn_utils.py:34-38).  The points must arrive in Morton order
+ *            (Group 2 codes + a sort: nerficg_amd/simple_knn does both); out_sorted[i] belongs to sorted point i.  n >= 4.
+ *            workspace: nrc_knn3_ws_bytes(n) bytes.  Exact (not approximate) neighbours.
+ * ===================================================================================================== */
+int64_t nrc_knn3_ws_bytes(int64_t n);
+int nrc_knn3_mean_sq_dist(const float* points_morton_sorted, int64_t n, float* out_sorted, void* workspace, nrc_stream_t stream);
 
 #ifdef __cplusplus
 }
