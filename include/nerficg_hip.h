@@ -271,7 +271,7 @@ int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int3
 /* =====================================================================================================
  * Group 8 -- fused Adam step: replaces apex.optimizers.FusedAdam (src/Thirdparty/Apex.py:17) as constructed at
  *            src/Methods/InstantNGP/Trainer.py:33-38 and src/Methods/GaussianSplatting/Model.py:131-136.  One flat f32 tensor
- *            per call, all four pointers 16-byte aligned.  bias_correction_k = 1 - beta_k^step (host).  adam_w_mode = 0: L2
+ *            per call (16-byte aligned pointers take the vector path).  bias_correction_k = 1 - beta_k^step (host).  adam_w_mode = 0: L2
  *            weight decay added to the gradient (apex ADAM_MODE_0), 1: decoupled.  grad_scale / found_inf: optional DEVICE
  *            scalars of torch.amp.GradScaler (gradient divided by *grad_scale; the whole step is skipped when *found_inf != 0).
  * ===================================================================================================== */

@@ -9,6 +9,7 @@
 
 namespace {
 
+template <bool ALIGNED>
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                                               float lr, float beta1, float beta2, float eps, float weight_decay, int adam_w_mode, float bc1, float bc2,
                                               const float* __restrict__ grad_scale, const float* __restrict__ found_inf) {
@@ -17,7 +18,7 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= n) return;
     float pv[4], gv[4], mv[4], vv[4];
-    const bool full = i0 + 3 < n;
+    const bool full = ALIGNED && i0 + 3 < n;  // 16-byte vector access needs all four pointers aligned (views into larger tensors may not be)
     if (full) {
         *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + i0);
         *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + i0);
@@ -61,9 +62,14 @@ int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     if (n < 0 || !(bias_correction1 > 0.f) || !(bias_correction2 > 0.f)) return NRC_ERR_INVALID;
     if (n == 0) return NRC_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq) return NRC_ERR_INVALID;
-    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) return NRC_ERR_INVALID;  // float4 access
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)nrc_cdiv(nrc_cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
-                       beta1, beta2, eps, weight_decay, (int)adam_w_mode, bias_correction1, bias_correction2, grad_scale, found_inf);
+    const bool aligned = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) == 0);
+    const dim3 grid((unsigned)nrc_cdiv(nrc_cdiv(n, 4), 256));
+    if (aligned)
+        hipLaunchKernelGGL(k_adam<true>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
+                           (int)adam_w_mode, bias_correction1, bias_correction2, grad_scale, found_inf);
+    else
+        hipLaunchKernelGGL(k_adam<false>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
+                           (int)adam_w_mode, bias_correction1, bias_correction2, grad_scale, found_inf);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

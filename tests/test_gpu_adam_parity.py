@@ -32,6 +32,20 @@ def test_fused_adam_matches_oracle(n):
     assert tp.grad is None
 
 
+def test_fused_adam_on_a_misaligned_view():
+    from nerficg_amd.apex_optimizers import FusedAdam
+    rng = np.random.default_rng(3)
+    base = torch.from_numpy(rng.normal(size=1001).astype(np.float32)).to(DEV)
+    tp = torch.nn.Parameter(base[1:])  # data pointer 4 bytes past a 16-byte boundary
+    p0 = tp.detach().cpu().numpy().copy()
+    opt = FusedAdam([tp], lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
+    g = rng.normal(size=1000).astype(np.float32)
+    tp.grad = torch.from_numpy(g).to(DEV)
+    opt.step()
+    p, _, _ = oracle.adam_step(p0, g, np.zeros_like(p0), np.zeros_like(p0), 1, 1e-2, (0.9, 0.99), 1e-15)
+    np.testing.assert_allclose(tp.detach().cpu().numpy(), p, rtol=1e-6, atol=1e-7)
+
+
 def test_fused_adam_with_grad_scaler_and_inf_skip():
     from nerficg_amd.apex_optimizers import FusedAdam
     rng = np.random.default_rng(1)
