@@ -241,6 +241,26 @@ int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float*
                           const float* xyz_min3, const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                           float per_level_scale, void* packed_f16, void* workspace, nrc_stream_t stream);
+/* Layer-major variant of steps 2-4: rows ordered by sample index k first (all tiles' k = 0, then k = 1, ...), so that consecutive
+ * chunks of rows are depth slabs of the image; after every slab the finished tiles (all rays saturated below T_threshold or out of
+ * samples) write their pixels and their remaining rows are skipped -- the early termination of the reference's alive-ray loop
+ * (src/Methods/InstantNGP/Renderer.py:118-132) at slab granularity, without host round trips.  Same image as steps 2-4.
+ *   nrc_ngp_render_write_layers: like step 2, plus layer_off (max_samples + 1) i32 and row_of (rows) i32 = the row of (tile, k).
+ *   nrc_ngp_render_layers      : steps 3 + 4 interleaved per slab; workspace nrc_ngp_render_layers_ws_bytes(rows, n_tiles);
+ *                                skipped_rows (optional, 1 i32): number of rows the early termination saved. */
+int nrc_ngp_render_write_layers(int64_t n_tiles, const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
+                                int32_t grid_size, int32_t max_samples, const float* ray_od, const float* ray_t, const int32_t* ray_cnt,
+                                const int32_t* tile_rows, const int32_t* tile_off, float* ts, int32_t* row_tile, int32_t* layer_off,
+                                int32_t* row_of, nrc_stream_t stream);
+int64_t nrc_ngp_render_layers_ws_bytes(int64_t n_rows, int64_t n_ray_tiles);
+int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
+                          const float* xyz_min3, const float* xyz_size3, const void* density_weights_f16,
+                          const void* color_weights_f16, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
+                          int32_t base_resolution, float per_level_scale, const int32_t* ray_cnt, const int32_t* tile_rows,
+                          const int32_t* tile_off, const int32_t* row_of, int32_t width, int32_t height, int64_t tile_begin,
+                          int32_t cascades, float exp_step_factor, int32_t grid_size, int32_t max_samples, float T_threshold,
+                          const float* bg3_host, void* packed_f16, float* rgb, float* alpha, float* depth, int32_t* skipped_rows,
+                          void* workspace, nrc_stream_t stream);
 /* stage 3a on its own (the dominant kernel of the pipeline; used by bench.py's roofline leg): hash-grid features of the first
  * n_rows (<= 131072) rows, fragment-major: the 16-byte vector [((j>>5)*4 + ((g + (j>>5))&3))*32 + (j&31)] = levels 4g..4g+3 (fp16x2) of slot j */
 int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, const float* xyz_min3,

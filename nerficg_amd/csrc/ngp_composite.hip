@@ -293,7 +293,103 @@ __global__ void __launch_bounds__(256) k_composite_image(const __half* __restric
     }
 }
 
+// ---- layer-major image compositing: one call per chunk of rows, front to back ------------------------------------------------
+// State per ray (T and the five running sums), per tile the next layer k to consume and an alive flag.  A tile is finished when
+// none of its rays is alive (saturated or out of samples) or its rows are exhausted; it then writes its pixels once and its flag
+// drops, which turns its remaining rows into holes for the encode / MLP kernels of the following chunks.
+__global__ void __launch_bounds__(256) k_layers_init(int64_t n_tiles, const int32_t* __restrict__ ray_cnt, float* __restrict__ state,
+                                                     uint8_t* __restrict__ ray_alive, int32_t* __restrict__ next_k, uint8_t* __restrict__ tile_alive,
+                                                     int32_t* __restrict__ skipped_rows) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q == 0 && skipped_rows) *skipped_rows = 0;
+    if (q >= n_tiles * 64) return;
+    state[q] = 1.0f;  // T; the sums follow as planes of n_tiles * 64 floats
+#pragma unroll
+    for (int c = 1; c < 6; c++) state[c * n_tiles * 64 + q] = 0.f;
+    ray_alive[q] = ray_cnt[q] > 0;
+    if ((q & 63) == 0) { next_k[q >> 6] = 0; tile_alive[q >> 6] = 1; }
+}
+__global__ void __launch_bounds__(256) k_composite_layers(const __half* __restrict__ packed, const float* __restrict__ ts,
+                                                          const int32_t* __restrict__ ray_cnt, const int32_t* __restrict__ tile_rows,
+                                                          const int32_t* __restrict__ tile_off, const int32_t* __restrict__ row_of, int64_t row_end,
+                                                          int width, int height, int tiles_x, int64_t tile_begin, int64_t n_tiles, float esf,
+                                                          float dt_min, float dt_max, float thr, float bg_r, float bg_g, float bg_b,
+                                                          float* __restrict__ state, uint8_t* __restrict__ ray_alive, int32_t* __restrict__ next_k,
+                                                          uint8_t* __restrict__ tile_alive, float* __restrict__ rgb, float* __restrict__ alpha_out,
+                                                          float* __restrict__ depth_out, int32_t* __restrict__ skipped_rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (lt >= n_tiles || !tile_alive[lt]) return;
+    const int R = tile_rows[lt];
+    const int64_t base = tile_off[lt], q = lt * 64 + lane, plane = n_tiles * 64;
+    int k = next_k[lt];
+    if (k < R && (int64_t)row_of[base + k] >= row_end) return;  // nothing of this tile in the chunk
+    const int N = ray_cnt[q];
+    float T = state[q], accR = state[plane + q], accG = state[2 * plane + q], accB = state[3 * plane + q], accD = state[4 * plane + q],
+          accO = state[5 * plane + q];
+    bool alive = ray_alive[q] != 0;
+    while (k < R && __any(alive)) {
+        const int64_t row = row_of[base + k];
+        if (row >= row_end) break;
+        if (alive) {
+            const int64_t s = row * 64 + lane;
+            const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(packed) + 4 * s);
+            const float2 f01 = __half22float2(*reinterpret_cast<const __half2*>(&raw.x));
+            const float2 f23 = __half22float2(*reinterpret_cast<const __half2*>(&raw.y));
+            const float t = ts[s];
+            const float dt = fmaxf(dt_min, fminf(t * esf, dt_max));
+            const float a = alpha_of(expf(f01.x), dt);
+            const float w = a * T;
+            accR += w * f01.y; accG += w * f23.x; accB += w * f23.y; accD += w * t; accO += w;
+            T *= 1.0f - a;
+            if (T <= thr || k + 1 >= N) alive = false;
+        }
+        k++;
+    }
+    const bool finished = !__any(alive) || k >= R;
+    if (!finished) {
+        state[q] = T; state[plane + q] = accR; state[2 * plane + q] = accG; state[3 * plane + q] = accB; state[4 * plane + q] = accD;
+        state[5 * plane + q] = accO;
+        ray_alive[q] = alive;
+        if (lane == 0) next_k[lt] = k;
+        return;
+    }
+    if (lane == 0) {
+        tile_alive[lt] = 0;
+        if (skipped_rows && k < R) atomicAdd(skipped_rows, R - k);  // rows no kernel will touch any more (statistics for the caller)
+    }
+    const int64_t tile = tile_begin + lt;
+    const int px = (int)(tile % tiles_x) * NRC_TILE_W + (lane & (NRC_TILE_W - 1)), py = (int)(tile / tiles_x) * NRC_TILE_H + (lane >> NRC_TILE_W_LOG2);
+    if (px < width && py < height) {
+        const int64_t n = (int64_t)py * width + px;
+        const float al = fminf(fmaxf(accO, 0.f), 1.f);
+        const float Tr = 1.f - al;
+        rgb[3 * n] = fminf(fmaxf(accR + Tr * bg_r, 0.f), 1.f);
+        rgb[3 * n + 1] = fminf(fmaxf(accG + Tr * bg_g, 0.f), 1.f);
+        rgb[3 * n + 2] = fminf(fmaxf(accB + Tr * bg_b, 0.f), 1.f);
+        alpha_out[n] = al;
+        depth_out[n] = Tr < 1.0f ? accD / al : 0.0f;
+    }
+}
+
 }  // namespace
+
+// internal launchers used by nrc_ngp_render_layers (ngp_net.hip)
+void nrc_launch_layers_init(int64_t n_tiles, const int32_t* ray_cnt, float* state, uint8_t* ray_alive, int32_t* next_k, uint8_t* tile_alive,
+                            int32_t* skipped_rows, hipStream_t s) {
+    hipLaunchKernelGGL(k_layers_init, dim3((unsigned)nrc_cdiv(n_tiles * 64, 256)), dim3(256), 0, s, n_tiles, ray_cnt, state, ray_alive, next_k, tile_alive,
+                       skipped_rows);
+}
+void nrc_launch_composite_layers(const void* packed, const float* ts, const int32_t* ray_cnt, const int32_t* tile_rows, const int32_t* tile_off,
+                                 const int32_t* row_of, int64_t row_end, int width, int height, int64_t tile_begin, int64_t n_tiles, int cascades, float esf,
+                                 int grid_size, int max_samples, float thr, const float* bg3, float* state, uint8_t* ray_alive, int32_t* next_k,
+                                 uint8_t* tile_alive, float* rgb, float* alpha, float* depth, int32_t* skipped_rows, hipStream_t s) {
+    const int tiles_x = (width + NRC_TILE_W - 1) / NRC_TILE_W;
+    const float dt_min = 1.73205080757f / max_samples, dt_max = 1.73205080757f * 2 * (float)cascades / grid_size;
+    hipLaunchKernelGGL(k_composite_layers, dim3((unsigned)nrc_cdiv(n_tiles, 4)), dim3(256), 0, s, (const __half*)packed, ts, ray_cnt, tile_rows, tile_off,
+                       row_of, row_end, width, height, tiles_x, tile_begin, n_tiles, esf, dt_min, dt_max, thr, bg3[0], bg3[1], bg3[2], state, ray_alive,
+                       next_k, tile_alive, rgb, alpha, depth, skipped_rows);
+}
 
 extern "C" {
 

@@ -610,11 +610,53 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(const int32_t* __restrict__
     }
     if (threadIdx.x == 0) { tile_off[n_tiles] = carry_s; counter[0] = carry_s; counter[1] = (int32_t)n_tiles; }
 }
-// second march: ts[(tile_off + k) * 64 + lane] = t of the k-th sample; holes = -1; row_tile[row] = local tile of the row
+// ---- slab-major row order (front-to-back processing with early termination, see nrc_ngp_render_layers) -------------------------
+// Row k of tile T normally sits at tile_off[T] + k.  In slab order the rows of all tiles with k in [0, G) come first (tile after
+// tile, k ascending inside a tile), then k in [G, 2G), ...:
+//   row_of[tile_off[T] + k] = slab_off[k / G] + sum over T' < T of rows_in_slab(T', k / G) + k % G
+// so that a chunk of consecutive rows is a slab of the image in DEPTH and the chunks of an image can be composited front to back.
+// G = 16 consecutive samples of a tile stay adjacent: with G = 1 (pure layer order) the encoder lost 24 % to worse cache reuse
+// between neighbouring waves.
+#define NRC_SLAB_G 16
+__device__ __forceinline__ int rows_in_slab(int tile_rows, int slab) { return min(NRC_SLAB_G, max(0, tile_rows - slab * NRC_SLAB_G)); }
+__global__ void __launch_bounds__(256) k_slab_totals(const int32_t* __restrict__ tile_rows, int64_t n_tiles, int32_t* __restrict__ slab_tot) {
+    __shared__ int smem[8];
+    const int slab = blockIdx.x;
+    int acc = 0;
+    for (int64_t t = threadIdx.x; t < n_tiles; t += 256) acc += rows_in_slab(tile_rows[t], slab);
+    int total;
+    (void)nrc_block256_excl_scan_i(acc, smem, &total);
+    if (threadIdx.x == 0) slab_tot[slab] = total;
+}
+__global__ void k_slab_offsets(int n_slabs, int32_t* __restrict__ slab_off) {  // in: totals, out: exclusive prefix (+ grand total at [n_slabs])
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int run = 0;
+    for (int s = 0; s < n_slabs; s++) { const int c = slab_off[s]; slab_off[s] = run; run += c; }
+    slab_off[n_slabs] = run;
+}
+__global__ void __launch_bounds__(256) k_slab_rows(const int32_t* __restrict__ tile_rows, const int32_t* __restrict__ tile_off, int64_t n_tiles,
+                                                   const int32_t* __restrict__ slab_off, int32_t* __restrict__ row_of) {
+    __shared__ int smem[8];
+    const int slab = blockIdx.x;
+    const int first = slab_off[slab];
+    if (slab_off[slab + 1] == first) return;
+    int running = 0;
+    for (int64_t base = 0; base < n_tiles; base += 256) {
+        const int64_t t = base + threadIdx.x;
+        const int c = t < n_tiles ? rows_in_slab(tile_rows[t], slab) : 0;
+        int total;
+        const int excl = nrc_block256_excl_scan_i(c, smem, &total);
+        for (int j = 0; j < c; j++) row_of[tile_off[t] + slab * NRC_SLAB_G + j] = first + running + excl + j;
+        running += total;
+        __syncthreads();
+    }
+}
+// second march: ts[row(k) * 64 + lane] = t of the k-th sample; holes = -1; row_tile[row] = local tile of the row;
+// row(k) = tile_off + k (tile-major) or row_of[tile_off + k] (layer-major)
 __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tiles, const float* __restrict__ ray_od,
                                                       const float* __restrict__ ray_t, const int32_t* __restrict__ ray_cnt,
                                                       const int32_t* __restrict__ tile_off, float* __restrict__ ts,
-                                                      int32_t* __restrict__ row_tile) {
+                                                      int32_t* __restrict__ row_tile, const int32_t* __restrict__ row_of) {
     const int lane = threadIdx.x & 63;
     const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (lt >= n_tiles) return;
@@ -622,7 +664,8 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
     const int64_t row0 = tile_off[lt];
     const int rows = tile_off[lt + 1] - (int)row0;
     const int N = ray_cnt[q];
-    for (int k = lane; k < rows; k += 64) row_tile[row0 + k] = (int32_t)lt;
+    auto row_at = [&](int k) -> int64_t { return row_of ? (int64_t)row_of[row0 + k] : row0 + k; };
+    for (int k = lane; k < rows; k += 64) row_tile[row_at(k)] = (int32_t)lt;
     const float* od = ray_od + lt * 384 + lane;
     Ray ry;
     ry.ox = od[0]; ry.oy = od[64]; ry.oz = od[128]; ry.dx = od[192]; ry.dy = od[256]; ry.dz = od[320];
@@ -632,11 +675,11 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
     int s = 0;
     while (t < t2 && s < N) {
         if (march_step(ry, c, t, x, y, z, dt)) {
-            ts[(row0 + s) * 64 + lane] = t;
+            ts[row_at(s) * 64 + lane] = t;
             t += dt; s++;
         }
     }
-    for (int k = N; k < rows; k++) ts[(row0 + k) * 64 + lane] = -1.0f;
+    for (int k = N; k < rows; k++) ts[row_at(k) * 64 + lane] = -1.0f;
 }
 
 MarchCfg make_cfg(const uint8_t* bitfield, int cascades, float scale, float esf, int grid_size, int max_samples, float dt_scale) {
@@ -850,7 +893,25 @@ int nrc_ngp_render_write(int64_t n_tiles, const uint8_t* bitfield, int32_t casca
     if (!bitfield || !ray_od || !ray_t || !ray_cnt || !tile_off || !ts || !row_tile) return NRC_ERR_INVALID;
     const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, (float)cascades);
     hipLaunchKernelGGL(k_render_write, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, c, n_tiles, ray_od, ray_t, ray_cnt,
-                       tile_off, ts, row_tile);
+                       tile_off, ts, row_tile, (const int32_t*)nullptr);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_ngp_render_write_layers(int64_t n_tiles, const uint8_t* bitfield, int32_t cascades, float scale, float esf, int32_t grid_size,
+                                int32_t max_samples, const float* ray_od, const float* ray_t, const int32_t* ray_cnt, const int32_t* tile_rows,
+                                const int32_t* tile_off, float* ts, int32_t* row_tile, int32_t* layer_off, int32_t* row_of, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_tiles < 0 || cascades < 1 || grid_size < 1 || max_samples < 1 || max_samples > 1024) return NRC_ERR_INVALID;
+    if (n_tiles == 0) return NRC_OK;
+    if (!bitfield || !ray_od || !ray_t || !ray_cnt || !tile_rows || !tile_off || !ts || !row_tile || !layer_off || !row_of) return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, (float)cascades);
+    const int n_slabs = (max_samples + NRC_SLAB_G - 1) / NRC_SLAB_G;
+    hipLaunchKernelGGL(k_slab_totals, dim3(n_slabs), dim3(256), 0, s, tile_rows, n_tiles, layer_off);
+    hipLaunchKernelGGL(k_slab_offsets, dim3(1), dim3(64), 0, s, n_slabs, layer_off);
+    hipLaunchKernelGGL(k_slab_rows, dim3(n_slabs), dim3(256), 0, s, tile_rows, tile_off, n_tiles, (const int32_t*)layer_off, row_of);
+    hipLaunchKernelGGL(k_render_write, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, s, c, n_tiles, ray_od, ray_t, ray_cnt, tile_off, ts, row_tile,
+                       (const int32_t*)row_of);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -169,6 +169,7 @@ enum { SRC_ARRAYS = 0, SRC_TILED = 1 };
 struct QueryIn {
     const float* xyz01; const float* dirs;                          // SRC_ARRAYS: sample i = row i of both arrays
     const float* ts; const int32_t* row_tile; const float* ray_od;  // SRC_TILED: slot i = (row i>>6, lane i&63), ray = row_tile[row]*64 + lane
+    const uint8_t* tile_alive;                                      // SRC_TILED, optional: rows of finished tiles are treated as holes
     float mn[3], sz[3];                                             // xyz_min, xyz_size of the model box (Renderer.py:50)
 };
 // returns false for a hole of the tiled layout (no sample in this slot)
@@ -179,8 +180,9 @@ __device__ __forceinline__ bool fetch_pos(const QueryIn& in, int64_t i, float& p
         return true;
     } else {
         const float t = in.ts[i];
-        if (t < 0.f) { px = py = pz = 0.f; return false; }
-        const float* od = in.ray_od + (int64_t)in.row_tile[i >> 6] * 384 + (i & 63);  // per-tile SoA [6][64]
+        const int32_t rt = in.row_tile[i >> 6];
+        if (t < 0.f || (in.tile_alive && !in.tile_alive[rt])) { px = py = pz = 0.f; return false; }
+        const float* od = in.ray_od + (int64_t)rt * 384 + (i & 63);  // per-tile SoA [6][64]
         // same roundings as the op-by-op path: xyz = o + t*d (mul, add: raymarching.cu:368), then (xyz - min) / size in torch
         px = __fsub_rn(__fadd_rn(od[0], __fmul_rn(t, od[192])), in.mn[0]);
         py = __fsub_rn(__fadd_rn(od[64], __fmul_rn(t, od[256])), in.mn[1]);
@@ -312,8 +314,9 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
         ti.b0 = fp[((hh + rot) & 3) * 32];
         ti.b1 = fp[((2 + hh + rot) & 3) * 32];
         if constexpr (SRC == SRC_TILED) {
-            ti.t = in.ts[i];
-            ti.sh = ray_sh[((int64_t)in.row_tile[i >> 6] * 2 + hh) * 64 + (i & 63)];
+            const int32_t rt = in.row_tile[i >> 6];
+            ti.t = (in.tile_alive && !in.tile_alive[rt]) ? -1.f : in.ts[i];
+            ti.sh = ray_sh[((int64_t)rt * 2 + hh) * 64 + (i & 63)];
         } else {
             ti.t = 0.f;
             ti.dx = in.dirs[3 * i]; ti.dy = in.dirs[3 * i + 1]; ti.dz = in.dirs[3 * i + 2];
@@ -698,6 +701,66 @@ int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float*
     in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od;
     for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
     run_query<SRC_TILED>(in, M, n_ray_tiles, density_weights_f16, color_weights_f16, table_f16, g, nullptr, nullptr, packed_f16, workspace, (hipStream_t)stream);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+/* workspace of the layer-major pipeline: [features of one chunk][ray_sh][state 6 x n f32][ray_alive n u8][next_k nt i32][tile_alive nt u8] */
+static int64_t layers_state_bytes(int64_t n_ray_tiles) {
+    const int64_t n = n_ray_tiles * 64;
+    return (n * 6 * 4 + n + n_ray_tiles * 4 + n_ray_tiles + 1023) / 256 * 256;
+}
+int64_t nrc_ngp_render_layers_ws_bytes(int64_t n_rows, int64_t n_ray_tiles) {
+    if (n_rows < 0 || n_ray_tiles < 0) return NRC_ERR_INVALID;
+    return query_feat_bytes(n_rows * 64) + n_ray_tiles * 2048 + 256 + layers_state_bytes(n_ray_tiles);
+}
+
+int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles, const float* xyz_min3,
+                          const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16, const void* table_f16,
+                          int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, const int32_t* ray_cnt,
+                          const int32_t* tile_rows, const int32_t* tile_off, const int32_t* row_of, int32_t width, int32_t height, int64_t tile_begin,
+                          int32_t cascades, float exp_step_factor, int32_t grid_size, int32_t max_samples, float T_threshold, const float* bg3_host,
+                          void* packed_f16, float* rgb, float* alpha, float* depth, int32_t* skipped_rows, void* workspace, nrc_stream_t stream) {
+    NRC_ENTER();
+    const int64_t M = n_rows * 64;
+    if (n_rows < 0 || n_ray_tiles < 1 || !density_weights_f16 || !color_weights_f16 || !table_f16 || !xyz_min3 || !xyz_size3 || !bg3_host ||
+        width < 1 || height < 1 || tile_begin < 0 || cascades < 1 || grid_size < 1 || max_samples < 1)
+        return NRC_ERR_INVALID;
+    if (n_levels != 16) return NRC_ERR_UNSUPPORTED;
+    if (!ray_od || !ray_cnt || !tile_rows || !tile_off || !rgb || !alpha || !depth || !workspace) return NRC_ERR_INVALID;
+    if (M > 0 && (!ts || !row_tile || !row_of || !packed_f16)) return NRC_ERR_INVALID;
+    GridCfg g;
+    const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
+    if (rc != NRC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    char* wsp = (char*)workspace;
+    uint4* feat = (uint4*)wsp;
+    h8* ray_sh = (h8*)(wsp + query_feat_bytes(M));
+    char* st = wsp + query_feat_bytes(M) + n_ray_tiles * 2048 + 256;
+    const int64_t n = n_ray_tiles * 64;
+    float* state = (float*)st;
+    uint8_t* ray_alive = (uint8_t*)(st + n * 6 * 4);
+    int32_t* next_k = (int32_t*)(st + (n * 6 * 4 + n + 3) / 4 * 4);
+    uint8_t* tile_alive = (uint8_t*)(next_k + n_ray_tiles);
+    QueryIn in = {};
+    in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od; in.tile_alive = tile_alive;
+    for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
+    nrc_launch_layers_init(n_ray_tiles, ray_cnt, state, ray_alive, next_k, tile_alive, skipped_rows, s);
+    hipLaunchKernelGGL(k_ray_sh, dim3((unsigned)nrc_cdiv(n_ray_tiles * 64, 256)), dim3(256), 0, s, ray_od, n_ray_tiles, ray_sh);
+    // front to back: encode + MLP on a slab of rows, composite it, finished tiles drop out of the following slabs.  No host
+    // round trip: slabs behind the last live tile still launch, but their waves return on the alive flag (tens of microseconds).
+    int64_t base = 0;
+    do {
+        const int64_t cn = (M - base) < NRC_QUERY_CHUNK ? (M - base) : NRC_QUERY_CHUNK;
+        if (cn > 0) {
+            launch_encode<SRC_TILED>(in, base, cn, table_f16, g, feat, s);
+            launch_mlp<SRC_TILED>(in, base, cn, feat, ray_sh, density_weights_f16, color_weights_f16, nullptr, nullptr, packed_f16, s);
+        }
+        nrc_launch_composite_layers(packed_f16, ts, ray_cnt, tile_rows, tile_off, row_of, (base + cn) / 64, width, height, tile_begin, n_ray_tiles, cascades,
+                                    exp_step_factor, grid_size, max_samples, T_threshold, bg3_host, state, ray_alive, next_k, tile_alive, rgb, alpha, depth,
+                                    skipped_rows, s);
+        base += NRC_QUERY_CHUNK;
+    } while (base < M);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

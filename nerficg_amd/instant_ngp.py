@@ -224,11 +224,15 @@ class InstantNGPRenderer:
 
     @torch.no_grad()
     def render_image_fused(self, camera: Camera, c2w: np.ndarray, tile_begin: int = 0, n_tiles: int | None = None,
-                           return_stats: bool = False, out: dict | None = None) -> dict[str, torch.Tensor]:
+                           return_stats: bool = False, out: dict | None = None, early_termination: bool | str = 'auto') -> dict[str, torch.Tensor]:
         """Same image as render_image, flat (H*W, C) pixel-major buffers, through the tile-interleaved device pipeline
         (include/nerficg_hip.h group 6): four device stages and ONE host sync (the row count, to size the sample buffers).
         A shard renders the 8x8-pixel tiles [tile_begin, tile_begin + n_tiles) and writes only their pixels (pass `out` to
-        accumulate several shards into the same buffers)."""
+        accumulate several shards into the same buffers).  early_termination: rows in layer order, depth slabs composited front to
+        back, finished tiles skipped in the following slabs (Renderer.py:118-132 at slab granularity); False: one pass over all
+        samples.  Both give the same image.  'auto' (default): slabs as long as they pay -- when a slab frame saved less than 10 % of
+        its rows (e.g. an untrained model: no ray ever saturates, and the slab bookkeeping costs ~7 %) the next 32 frames of this
+        renderer take the single pass, then one slab frame probes again."""
         m = self.model
         lib = _lib.load()
         dev = m.center.device
@@ -248,7 +252,8 @@ class InstantNGPRenderer:
             ws = dict(ray_od=torch.empty(max(n, 1), 6, device=dev), ray_t=torch.empty(max(n, 1), 2, device=dev),
                       ray_cnt=torch.empty(max(n, 1), dtype=torch.int32, device=dev), tile_rows=torch.empty(max(nt, 1), dtype=torch.int32, device=dev),
                       tile_off=torch.empty(nt + 1, dtype=torch.int32, device=dev), counter=torch.empty(2, dtype=torch.int32, device=dev),
-                      rgb=torch.zeros(hw, 3, device=dev), alpha=torch.zeros(hw, device=dev), depth=torch.zeros(hw, device=dev), cap=0)
+                      rgb=torch.zeros(hw, 3, device=dev), alpha=torch.zeros(hw, device=dev), depth=torch.zeros(hw, device=dev), cap=0,
+                      skipped=torch.zeros(1, dtype=torch.int32, device=dev))
             self._fused_ws = {key: ws}
         if out is None:
             out = {'rgb': ws['rgb'], 'alpha': ws['alpha'], 'depth': ws['depth']}
@@ -266,7 +271,44 @@ class InstantNGPRenderer:
             cap = int(rows * 1.25) + 64
             ws.update(ts=torch.empty(cap * 64, device=dev), row_tile=torch.empty(cap, dtype=torch.int32, device=dev),
                       packed=torch.empty(cap * 64, 4, dtype=torch.float16, device=dev),
-                      qws=torch.empty(int(lib.nrc_ngp_query_samples_ws_bytes(cap, nt)), dtype=torch.uint8, device=dev), cap=cap)
+                      qws=torch.empty(int(lib.nrc_ngp_render_layers_ws_bytes(cap, nt)), dtype=torch.uint8, device=dev),
+                      row_of=torch.empty(cap, dtype=torch.int32, device=dev),
+                      layer_off=torch.empty(self.MAX_SAMPLES + 2, dtype=torch.int32, device=dev), cap=cap)
+        bg = f3(camera.background_color.float().cpu())
+        if early_termination == 'auto':
+            pol = ws.setdefault('et_policy', {'prev_rows': 0, 'prev_layered': False, 'skip_frames': 0})
+            if pol['prev_layered'] and pol['prev_rows'] > 0:  # the previous frame is complete by now (we just synchronised on this one's row count)
+                if int(ws['skipped'].item()) < 0.1 * pol['prev_rows']:
+                    pol['skip_frames'] = 32
+            use_layers = pol['skip_frames'] == 0
+            pol['skip_frames'] = max(0, pol['skip_frames'] - 1)
+            pol['prev_rows'], pol['prev_layered'] = rows, use_layers
+        else:
+            use_layers = bool(early_termination)
+        if use_layers and self.MAX_SAMPLES <= 1024:
+            g = m.encoding_xyz.grid_cfg
+            mn, sz = f3(m.xyz_min), f3(m.xyz_size)
+            if rows > 0:
+                _lib.check(lib.nrc_ngp_render_write_layers(
+                    nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION, self.MAX_SAMPLES, _lib.ptr(ws['ray_od']),
+                    _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']), _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']),
+                    _lib.ptr(ws['row_tile']), _lib.ptr(ws['layer_off']), _lib.ptr(ws['row_of']), st), 'ngp_render_write_layers')
+            if 'qws' not in ws:  # an image without a single sample: state + background only
+                ws['qws'] = torch.empty(int(lib.nrc_ngp_render_layers_ws_bytes(0, nt)), dtype=torch.uint8, device=dev)
+            _lib.check(lib.nrc_ngp_render_layers(
+                _lib.ptr(ws.get('ts')), _lib.ptr(ws.get('row_tile')), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(mn, ctypes.c_void_p),
+                ctypes.cast(sz, ctypes.c_void_p), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
+                _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
+                _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']), _lib.ptr(ws['tile_off']), _lib.ptr(ws.get('row_of')), camera.width, camera.height,
+                int(tile_begin), m.cascades, float(esf), m.RESOLUTION, self.MAX_SAMPLES, 1e-4, ctypes.cast(bg, ctypes.c_void_p),
+                _lib.ptr(ws.get('packed')), _lib.ptr(out['rgb']), _lib.ptr(out['alpha']), _lib.ptr(out['depth']), _lib.ptr(ws['skipped']),
+                _lib.ptr(ws['qws']), st), 'ngp_render_layers')
+            res = dict(out)
+            if return_stats:
+                res['n_rows'] = rows
+                res['n_slots'] = rows * 64
+                res['n_samples'] = int(ws['ray_cnt'][:n].sum().item()) if n > 0 else 0
+            return res
         if rows > 0:
             _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION,
                                                 self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']),
@@ -278,7 +320,6 @@ class InstantNGPRenderer:
                 ctypes.cast(sz, ctypes.c_void_p), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
                 _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
                 _lib.ptr(ws['packed']), _lib.ptr(ws['qws']), st), 'ngp_query_samples')
-        bg = f3(camera.background_color.float().cpu())
         _lib.check(lib.nrc_ngp_composite_image(
             _lib.ptr(ws.get('packed')), _lib.ptr(ws.get('ts')), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_off']), camera.width, camera.height,
             int(tile_begin), nt, m.cascades, float(esf), m.RESOLUTION, self.MAX_SAMPLES, 1e-4, ctypes.cast(bg, ctypes.c_void_p),

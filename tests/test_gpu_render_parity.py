@@ -211,3 +211,28 @@ def test_carve_occupancy_grid_matches_an_independent_numpy_statement():
         assert 0 < (expect < 0).sum() < R ** 3
         # cells whose projection lies within float rounding of a frustum edge may differ (f32 on the device vs f64 here)
         assert np.mean(got != expect) < 2e-3, (subtractive, use_alpha, np.mean(got != expect))
+
+
+@pytest.mark.parametrize('table_amp', [2.0, 60.0])  # 60: densities up to e^several -> most rays saturate within a few samples
+def test_layer_ordered_early_termination_gives_the_same_image(table_amp):
+    """Depth-slab processing with finished tiles dropping out (Renderer.py:118-132 semantics at slab granularity) against the
+    single pass over all samples: the per-ray arithmetic is the same sequence, so the images are bit-identical."""
+    from nerficg_amd.instant_ngp import InstantNGPRenderer
+    model = make_model(seed=9, table_amp=table_amp)
+    renderer = InstantNGPRenderer(model)
+    cam = make_camera(200, 152, bg=(0.2, 0.5, 0.9))
+    for pose in ((0.4, 0.3), (2.2, -0.2)):
+        c2w = scenes.orbit_pose(pose[0], pose[1], scenes.LEGO_RADIUS)
+        a = {k: v.clone() for k, v in renderer.render_image_fused(cam, c2w, early_termination=False).items()}
+        b = renderer.render_image_fused(cam, c2w, early_termination=True)
+        for k in ('rgb', 'alpha', 'depth'):
+            assert torch.equal(a[k], b[k]), k
+    if table_amp > 10:
+        assert (a['alpha'] > 0.999).float().mean() > 0.05  # the dense variant does saturate
+    # shards compose in layer order too
+    nt = renderer.n_image_tiles(cam)
+    out = {k: torch.zeros_like(v) for k, v in a.items()}
+    for lo, hi in ((0, nt // 3), (nt // 3, nt)):
+        renderer.render_image_fused(cam, c2w, tile_begin=lo, n_tiles=hi - lo, out=out, early_termination=True)
+    for k in ('rgb', 'alpha', 'depth'):
+        assert torch.equal(a[k], out[k]), k
