@@ -151,6 +151,24 @@ int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int3
 int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
                       int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table,
                       nrc_stream_t stream);
+/* query_model (src/Methods/InstantNGP/Renderer.py:48-53) for TRAINING as one forward and one backward call instead of ~55 small
+ * launches: world positions xyzs (M,3) / directions dirs (M,3) f32 -> sigmas (M), rgbs (M,3) f32 (what VolumeRenderer consumes), and
+ * dL/dsigmas, dL/drgbs -> gradients of both parameter vectors (ACCUMULATED; caller zeroes; layout of the tinycudann modules).
+ * Kept between the calls: x01 (M,3) f32, h (M,16) f16, rgb (M,4) f16, save_in_* (M,32) f16, save_acts_d (1,M,64) / save_acts_c (2,M,64) f16.
+ * forward workspace: nrc_ngp_train_query_ws_bytes(M); backward scratch: nrc_ngp_train_query_scratch_bytes(M). */
+int64_t nrc_ngp_train_query_ws_bytes(int64_t M);
+int64_t nrc_ngp_train_query_scratch_bytes(int64_t M);
+int nrc_ngp_train_query_forward(const float* xyzs, const float* dirs, int64_t M, const float* xyz_min3, const float* xyz_size3,
+                                const void* density_weights_f16, const void* color_weights_f16, const void* table_f16,
+                                int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale,
+                                float* x01, void* h_f16, void* rgb_f16, float* sigmas, float* rgbs, void* save_in_d,
+                                void* save_acts_d, void* save_in_c, void* save_acts_c, void* workspace, nrc_stream_t stream);
+int nrc_ngp_train_query_backward(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01,
+                                 const void* density_weights_f16, const void* color_weights_f16, int32_t n_levels,
+                                 int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, const void* h_f16,
+                                 const void* rgb_f16, const void* save_in_d, const void* save_acts_d, const void* save_in_c,
+                                 const void* save_acts_c, float loss_scale, float* grad_density_params, float* grad_color_params,
+                                 int64_t n_density_mlp_params, void* scratch, nrc_stream_t stream);
 /* InstantNGPRayRenderingComponent.query_model (Renderer.py:48-53) as an encode + MLP kernel pair over Infinity-Cache sized
  * chunks (workspace: nrc_ngp_query_ws_bytes(M) bytes): xyz01 (M,3) f32 in [0,1], dirs (M,3) f32 unit
  * vectors -> sigmas (M) f32 = exp(fp16 feature 0), rgbs (M,3) f32 = fp16 sigmoid outputs. */

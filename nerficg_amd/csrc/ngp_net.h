@@ -240,3 +240,16 @@ __device__ __forceinline__ void sh4_eval(float x, float y, float z, float* o) {
     o[14] = 1.4453057213202769f * z * (x2 - y2);
     o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
+
+// SH degree 4 of a direction as the colour net's k-step-0 B fragments (lo: coefficients 0-7, hi: 8-15)
+__device__ __forceinline__ void sh4_fragments(float dx, float dy, float dz, h8& lo, h8& hi) {
+    // the reference feeds fp16(d*0.5+0.5) and tiny-cuda-nn maps it back with *2-1 (Renderer.py:52)
+    float sh[16];
+    const float ex = (float)(_Float16)__fadd_rn(__fmul_rn(dx, 0.5f), 0.5f) * 2.f - 1.f;
+    const float ey = (float)(_Float16)__fadd_rn(__fmul_rn(dy, 0.5f), 0.5f) * 2.f - 1.f;
+    const float ez = (float)(_Float16)__fadd_rn(__fmul_rn(dz, 0.5f), 0.5f) * 2.f - 1.f;
+    sh4_eval(ex, ey, ez, sh);
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) { lo[jj] = (_Float16)sh[jj]; hi[jj] = (_Float16)sh[8 + jj]; }
+
+}

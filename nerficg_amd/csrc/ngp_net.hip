@@ -13,7 +13,7 @@
 
 namespace {
 
-enum { ENC_GRID = 0, ENC_SH_ID = 1, ENC_FEAT = 2 };  // ENC_FEAT: fragment-major features written by k_grid_encode (see there)
+enum { ENC_GRID = 0, ENC_SH_ID = 1, ENC_FEAT = 2, ENC_DIR_H = 3 };  // ENC_DIR_H: SH of f32 directions + the density net's 16 fp16 outputs (fused training query)  // ENC_FEAT: fragment-major features written by k_grid_encode (see there)
 enum { ACT_NONE = 0, ACT_SIGMOID = 1 };
 
 // ---- first-layer B fragments from the encodings -------------------------------------------------------------------
@@ -92,6 +92,13 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
             const uint4 b0 = fp[((hh + rot) & 3) * 32], b1 = fp[((2 + hh + rot) & 3) * 32];
             B[0] = *reinterpret_cast<const h8*>(&b0);
             B[1] = *reinterpret_cast<const h8*>(&b1);
+        } else if constexpr (ENC == ENC_DIR_H) {
+            // `input` = directions (M,3) f32, `table` = the density network's output rows (M,16) fp16
+            const float* dp = reinterpret_cast<const float*>(input) + 3 * ic;
+            h8 lo, hi;
+            sh4_fragments(dp[0], dp[1], dp[2], lo, hi);
+            B[0] = hh ? hi : lo;
+            B[1] = *reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(table) + ic * 16 + 8 * hh);
         } else {
             encode_sh_id(reinterpret_cast<const __half*>(input), in_ld, ic, hh, B);
         }
@@ -168,6 +175,8 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
 enum { SRC_ARRAYS = 0, SRC_TILED = 1 };
 struct QueryIn {
     const float* xyz01; const float* dirs;                          // SRC_ARRAYS: sample i = row i of both arrays
+    float* x01_out; int normalise;                                  // SRC_ARRAYS, training: xyz01 holds WORLD positions, (x - mn) / sz is applied
+                                                                    // here (torch's two roundings) and written to x01_out for the backward
     const float* ts; const int32_t* row_tile; const float* ray_od;  // SRC_TILED: slot i = (row i>>6, lane i&63), ray = row_tile[row]*64 + lane
     const uint8_t* tile_alive;                                      // SRC_TILED, optional: rows of finished tiles are treated as holes
     float mn[3], sz[3];                                             // xyz_min, xyz_size of the model box (Renderer.py:50)
@@ -177,6 +186,11 @@ template <int SRC>
 __device__ __forceinline__ bool fetch_pos(const QueryIn& in, int64_t i, float& px, float& py, float& pz) {
     if constexpr (SRC == SRC_ARRAYS) {
         px = in.xyz01[3 * i]; py = in.xyz01[3 * i + 1]; pz = in.xyz01[3 * i + 2];
+        if (in.normalise) {
+            px = __fdiv_rn(__fsub_rn(px, in.mn[0]), in.sz[0]); py = __fdiv_rn(__fsub_rn(py, in.mn[1]), in.sz[1]);
+            pz = __fdiv_rn(__fsub_rn(pz, in.mn[2]), in.sz[2]);
+            if (in.x01_out) { in.x01_out[3 * i] = px; in.x01_out[3 * i + 1] = py; in.x01_out[3 * i + 2] = pz; }
+        }
         return true;
     } else {
         const float t = in.ts[i];
@@ -248,16 +262,6 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
 // SH degree 4 of the ray direction as the colour net's k-step-0 B fragments, once per RAY of the tiled layout:
 //   ray_sh[(tile * 2 + hh) * 64 + lane] = fp16 coefficients 8hh .. 8hh+7 of ray (tile, lane)
 // (a sample's direction is its ray's: evaluating per sample would repeat ~80 VALU instructions 120 times per ray)
-__device__ __forceinline__ void sh4_fragments(float dx, float dy, float dz, h8& lo, h8& hi) {
-    // the reference feeds fp16(d*0.5+0.5) and tiny-cuda-nn maps it back with *2-1 (Renderer.py:52)
-    float sh[16];
-    const float ex = (float)(_Float16)__fadd_rn(__fmul_rn(dx, 0.5f), 0.5f) * 2.f - 1.f;
-    const float ey = (float)(_Float16)__fadd_rn(__fmul_rn(dy, 0.5f), 0.5f) * 2.f - 1.f;
-    const float ez = (float)(_Float16)__fadd_rn(__fmul_rn(dz, 0.5f), 0.5f) * 2.f - 1.f;
-    sh4_eval(ex, ey, ez, sh);
-#pragma unroll
-    for (int jj = 0; jj < 8; jj++) { lo[jj] = (_Float16)sh[jj]; hi[jj] = (_Float16)sh[8 + jj]; }
-}
 __global__ void __launch_bounds__(256) k_ray_sh(const float* __restrict__ ray_od, int64_t n_ray_tiles, h8* __restrict__ ray_sh) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_ray_tiles * 64) return;
@@ -1165,6 +1169,44 @@ __global__ void __launch_bounds__(OWN_THREADS) k_grid_bwd_owned_q(const float* _
     }
 }
 
+// ---- fused training query (InstantNGPRayRenderingComponent.query_model, Renderer.py:48-53, as one autograd node) ----------------
+// outputs of the two networks -> what the compositor consumes: sigma = exp(h0) (TruncExp forward, custom_functions.py:201-204),
+// rgb = the colour net's sigmoid outputs, both f32
+__global__ void __launch_bounds__(256) k_train_outputs(const __half* __restrict__ h, const __half* __restrict__ rgb16, int64_t M,
+                                                       float* __restrict__ sigmas, float* __restrict__ rgbs) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    sigmas[i] = expf(__half2float(h[i * 16]));
+    const __half2 a = *reinterpret_cast<const __half2*>(rgb16 + i * 4), b = *reinterpret_cast<const __half2*>(rgb16 + i * 4 + 2);
+    rgbs[3 * i] = __low2float(a); rgbs[3 * i + 1] = __high2float(a); rgbs[3 * i + 2] = __low2float(b);
+}
+// upstream gradients -> the colour net's fp16 d_out rows (M,4) and the TruncExp backward dh0 = dL/dsigma * exp(clamp(h0, -15, 15))
+__global__ void __launch_bounds__(256) k_train_dout(const float* __restrict__ dL_dsigmas, const float* __restrict__ dL_drgbs, const __half* __restrict__ h,
+                                                    int64_t M, __half* __restrict__ d_rgb16, float* __restrict__ dh0) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const float h0 = fminf(15.f, fmaxf(-15.f, __half2float(h[i * 16])));
+    dh0[i] = dL_dsigmas[i] * expf(h0);
+    *reinterpret_cast<__half2*>(d_rgb16 + i * 4) = __floats2half2_rn(dL_drgbs[3 * i], dL_drgbs[3 * i + 1]);
+    *reinterpret_cast<__half2*>(d_rgb16 + i * 4 + 2) = __floats2half2_rn(dL_drgbs[3 * i + 2], 0.f);
+}
+// density net d_out rows (M,16) fp16 = gradient arriving through the colour net's identity-encoded inputs (+ dh0 on column 0)
+__global__ void __launch_bounds__(256) k_density_dout(const float* __restrict__ d_in_color, const float* __restrict__ dh0, int64_t M,
+                                                      __half* __restrict__ d_h16) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const float4* src = reinterpret_cast<const float4*>(d_in_color + i * 32 + 16);
+    __half2 o[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float4 v = src[k];
+        if (k == 0) v.x += dh0[i];
+        o[2 * k] = __floats2half2_rn(v.x, v.y); o[2 * k + 1] = __floats2half2_rn(v.z, v.w);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(d_h16 + i * 16);
+    dst[0] = *reinterpret_cast<const uint4*>(&o[0]); dst[1] = *reinterpret_cast<const uint4*>(&o[4]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1238,6 +1280,75 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
     }
     NRC_LAUNCH_CHECK();
     return NRC_OK;
+}
+
+/* bytes of the scratch the two calls below need: features of all M samples */
+int64_t nrc_ngp_train_query_ws_bytes(int64_t M) { return nrc_nwie_forward_ws_bytes(M); }
+
+int nrc_ngp_train_query_forward(const float* xyzs, const float* dirs, int64_t M, const float* xyz_min3, const float* xyz_size3,
+                                const void* density_weights_f16, const void* color_weights_f16, const void* table_f16, int32_t n_levels,
+                                int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* x01, void* h_f16, void* rgb_f16,
+                                float* sigmas, float* rgbs, void* save_in_d, void* save_acts_d, void* save_in_c, void* save_acts_c, void* workspace,
+                                nrc_stream_t stream) {
+    NRC_ENTER();
+    if (M < 0 || !density_weights_f16 || !color_weights_f16 || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
+    if (n_levels != 16) return NRC_ERR_UNSUPPORTED;
+    if (M == 0) return NRC_OK;
+    if (!xyzs || !dirs || !x01 || !h_f16 || !rgb_f16 || !sigmas || !rgbs || !save_in_d || !save_acts_d || !save_in_c || !save_acts_c || !workspace)
+        return NRC_ERR_INVALID;
+    GridCfg g;
+    const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
+    if (rc != NRC_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    QueryIn qin = {};
+    qin.xyz01 = xyzs; qin.normalise = 1; qin.x01_out = x01;
+    for (int k = 0; k < 3; k++) { qin.mn[k] = xyz_min3[k]; qin.sz[k] = xyz_size3[k]; }
+    launch_encode<SRC_ARRAYS>(qin, 0, M, table_f16, g, (uint4*)workspace, s);
+    const dim3 grid(pick_blocks(M)), block(256);
+    // density net: 32 -> 64 -> 16, linear output, all 16 columns stored (the colour net reads them back)
+    hipLaunchKernelGGL((k_nwie_fwd<ENC_FEAT, 1, ACT_NONE, true>), grid, block, 0, s, (const void*)workspace, 0, M, (const __half*)density_weights_f16,
+                       (const __half2*)table_f16, g, 16, (__half*)h_f16, 16, 16, (__half*)save_in_d, (__half*)save_acts_d);
+    // colour net: [SH(d) | h] -> 64 -> 64 -> 3 (+1 pad), sigmoid
+    hipLaunchKernelGGL((k_nwie_fwd<ENC_DIR_H, 2, ACT_SIGMOID, true>), grid, block, 0, s, (const void*)dirs, 0, M, (const __half*)color_weights_f16,
+                       (const __half2*)h_f16, g, 3, (__half*)rgb_f16, 4, 4, (__half*)save_in_c, (__half*)save_acts_c);
+    hipLaunchKernelGGL(k_train_outputs, dim3((unsigned)nrc_cdiv(M, 256)), dim3(256), 0, s, (const __half*)h_f16, (const __half*)rgb_f16, M, sigmas, rgbs);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_ngp_train_query_backward(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01, const void* density_weights_f16,
+                                 const void* color_weights_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
+                                 float per_level_scale, const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d,
+                                 const void* save_in_c, const void* save_acts_c, float loss_scale, float* grad_density_params, float* grad_color_params,
+                                 int64_t n_density_mlp_params, void* scratch, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (M < 0 || !density_weights_f16 || !color_weights_f16 || !grad_density_params || !grad_color_params || n_density_mlp_params < 0) return NRC_ERR_INVALID;
+    if (M == 0) return NRC_OK;
+    if (!dL_dsigmas || !dL_drgbs || !x01 || !h_f16 || !rgb_f16 || !save_in_d || !save_acts_d || !save_in_c || !save_acts_c || !scratch) return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    // scratch: [d_rgb16 M x 4 f16][dh0 M f32][d_in_color M x 32 f32][d_h16 M x 16 f16][d_in_density 16 x M x 2 f32]
+    char* p = (char*)scratch;
+    __half* d_rgb16 = (__half*)p; p += (M * 8 + 255) / 256 * 256;
+    float* dh0 = (float*)p; p += (M * 4 + 255) / 256 * 256;
+    float* d_in_c = (float*)p; p += M * 128;
+    __half* d_h16 = (__half*)p; p += M * 32;
+    float* d_in_d = (float*)p;
+    const dim3 g1((unsigned)nrc_cdiv(M, 256)), b1(256);
+    hipLaunchKernelGGL(k_train_dout, g1, b1, 0, s, dL_dsigmas, dL_drgbs, (const __half*)h_f16, M, d_rgb16, dh0);
+    int rc = nrc_nwie_backward(M, color_weights_f16, 2, ACT_SIGMOID, 3, d_rgb16, rgb_f16, 4, save_in_c, save_acts_c, loss_scale, grad_color_params, d_in_c, 0, stream);
+    if (rc != NRC_OK) return rc;
+    hipLaunchKernelGGL(k_density_dout, g1, b1, 0, s, (const float*)d_in_c, (const float*)dh0, M, d_h16);
+    rc = nrc_nwie_backward(M, density_weights_f16, 1, ACT_NONE, 16, d_h16, h_f16, 16, save_in_d, save_acts_d, loss_scale, grad_density_params, d_in_d, 1, stream);
+    if (rc != NRC_OK) return rc;
+    rc = nrc_grid_backward(x01, M, d_in_d, 1, n_levels, log2_hashmap_size, base_resolution, per_level_scale, grad_density_params + n_density_mlp_params, stream);
+    if (rc != NRC_OK) return rc;
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int64_t nrc_ngp_train_query_scratch_bytes(int64_t M) {
+    if (M < 0) return NRC_ERR_INVALID;
+    return (M * 8 + 255) / 256 * 256 + (M * 4 + 255) / 256 * 256 + M * 128 + M * 32 + M * 128 + 256;
 }
 
 }  // extern "C"

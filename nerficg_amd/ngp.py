@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-__all__ = ['query_fused']
+__all__ = ['query_fused', 'query_train']
 
 
 def query_fused(density_net, color_net, xyz01: torch.Tensor, dirs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
@@ -29,3 +29,62 @@ def query_fused(density_net, color_net, xyz01: torch.Tensor, dirs: torch.Tensor)
         g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(sig), _lib.ptr(rgb), _lib.ptr(ws),
         _lib.stream_of(sig)), 'ngp_query_fused')
     return sig, rgb
+
+
+class _QueryTrain(torch.autograd.Function):
+    """query_model as ONE autograd node: the reference's sequence (normalise x, grid net, TruncExp, d*0.5+0.5, cat, colour net -- ~25
+    launches forward and ~30 backward through the op-by-op modules) becomes 4 + 6 kernels.  Same arithmetic per sample; gradients reach
+    both parameter vectors, not the sample positions / directions (data, as in the reference)."""
+
+    @staticmethod
+    def forward(ctx, xyzs, dirs, params_d, params_c, density_net, color_net, xyz_min, xyz_size):
+        lib = _lib.load()
+        m, dev = xyzs.shape[0], xyzs.device
+        g = density_net.grid_cfg
+        f16, f32 = torch.float16, torch.float32
+        x01 = torch.empty(m, 3, dtype=f32, device=dev)
+        h = torch.empty(m, 16, dtype=f16, device=dev)
+        rgb16 = torch.empty(m, 4, dtype=f16, device=dev)
+        sigmas = torch.empty(m, dtype=f32, device=dev)
+        rgbs = torch.empty(m, 3, dtype=f32, device=dev)
+        save = [torch.empty(m, 32, dtype=f16, device=dev), torch.empty(1, m, 64, dtype=f16, device=dev),
+                torch.empty(m, 32, dtype=f16, device=dev), torch.empty(2, m, 64, dtype=f16, device=dev)]
+        ws = torch.empty(int(lib.nrc_ngp_train_query_ws_bytes(m)), dtype=torch.uint8, device=dev)
+        wd, wc = density_net._half_params(), color_net._half_params()
+        _lib.check(lib.nrc_ngp_train_query_forward(
+            _lib.ptr(xyzs), _lib.ptr(dirs), m, _lib.ptr(xyz_min), _lib.ptr(xyz_size), _lib.ptr(wd), _lib.ptr(wc), _lib.ptr(density_net._table16()),
+            g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(x01), _lib.ptr(h), _lib.ptr(rgb16),
+            _lib.ptr(sigmas), _lib.ptr(rgbs), _lib.ptr(save[0]), _lib.ptr(save[1]), _lib.ptr(save[2]), _lib.ptr(save[3]), _lib.ptr(ws),
+            _lib.stream_of(sigmas)), 'ngp_train_query_forward')
+        ctx.save_for_backward(x01, h, rgb16, *save, wd, wc)
+        ctx.nets = (density_net, color_net)
+        return sigmas, rgbs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_sigmas, d_rgbs):
+        x01, h, rgb16, sd_in, sd_acts, sc_in, sc_acts, wd, wc = ctx.saved_tensors
+        density_net, color_net = ctx.nets
+        lib = _lib.load()
+        m, dev = x01.shape[0], x01.device
+        g = density_net.grid_cfg
+        gd = torch.zeros(density_net.params.numel(), dtype=torch.float32, device=dev)
+        gc = torch.zeros(color_net.params.numel(), dtype=torch.float32, device=dev)
+        if m > 0:
+            scratch = torch.empty(int(lib.nrc_ngp_train_query_scratch_bytes(m)), dtype=torch.uint8, device=dev)
+            _lib.check(lib.nrc_ngp_train_query_backward(
+                _lib.ptr(d_sigmas.to(torch.float32).contiguous()), _lib.ptr(d_rgbs.to(torch.float32).contiguous()), m, _lib.ptr(x01), _lib.ptr(wd), _lib.ptr(wc),
+                g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(h), _lib.ptr(rgb16), _lib.ptr(sd_in),
+                _lib.ptr(sd_acts), _lib.ptr(sc_in), _lib.ptr(sc_acts), float(density_net.loss_scale), _lib.ptr(gd), _lib.ptr(gc), density_net.n_mlp_params,
+                _lib.ptr(scratch), _lib.stream_of(gd)), 'ngp_train_query_backward')
+        return None, None, gd, gc, None, None, None, None
+
+
+def query_train(density_net, color_net, xyzs: torch.Tensor, dirs: torch.Tensor, xyz_min: torch.Tensor, xyz_size: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """Differentiable query_model for training batches: world positions / unit directions (M,3) f32 -> sigmas (M), rgbs (M,3) f32.
+    xyz_min / xyz_size: HOST tensors (3,) f32 (the model box)."""
+    xyzs = xyzs.detach().to(torch.float32).contiguous()
+    dirs = dirs.detach().to(torch.float32).contiguous()
+    _lib.check_input(xyzs, 'xyzs', torch.float32)
+    _lib.check_input(dirs, 'dirs', torch.float32)
+    return _QueryTrain.apply(xyzs, dirs, density_net.params, color_net.params, density_net, color_net, xyz_min, xyz_size)

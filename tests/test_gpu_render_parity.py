@@ -236,3 +236,38 @@ def test_layer_ordered_early_termination_gives_the_same_image(table_amp):
         renderer.render_image_fused(cam, c2w, tile_begin=lo, n_tiles=hi - lo, out=out, early_termination=True)
     for k in ('rgb', 'alpha', 'depth'):
         assert torch.equal(a[k], out[k]), k
+
+
+@pytest.mark.parametrize('m', [777, 20011])  # >= 16384: the hashed levels take the ownership backward
+def test_fused_training_query_matches_the_op_by_op_modules(m):
+    """nerficg_amd.ngp.query_train (one autograd node) against the statement sequence of query_model (Renderer.py:48-53) through the
+    drop-in modules: same forward bits, gradients within the fp16 rounding of the intermediate d_out tensors."""
+    from nerficg_amd.instant_ngp import InstantNGPRenderer
+    model = make_model(seed=4)
+    comp = InstantNGPRenderer(model).ray_rendering_component
+    rng = np.random.default_rng(m)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    x = T((rng.random((m, 3)) - 0.5).astype(np.float32) * 0.98)
+    d = rng.normal(size=(m, 3)).astype(np.float32)
+    d = T(d / np.linalg.norm(d, axis=1, keepdims=True))
+    gs, gr = T(rng.normal(size=m).astype(np.float32) * 1e-2), T(rng.normal(size=(m, 3)).astype(np.float32) * 1e-2)  # fp16-safe magnitudes
+    res = {}
+    for fused in (False, True):
+        comp.fused_training_query = fused
+        model.zero_grad()
+        with torch.amp.autocast('cuda'):
+            sig, rgb = comp.query_model(x, d)
+        (sig.float() * gs).sum().add((rgb.float() * gr).sum()).backward()
+        res[fused] = (sig.detach().float().clone(), rgb.detach().float().clone(), model.encoding_xyz.params.grad.clone(),
+                      model.color_mlp_with_encoding.params.grad.clone())
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    for k, name in ((2, 'grid net'), (3, 'colour net')):
+        a, b = res[False][k].cpu().numpy(), res[True][k].cpu().numpy()
+        assert np.isfinite(a).all() and np.isfinite(b).all()
+        mlp = slice(0, 3072) if k == 2 else slice(0, a.size)
+        np.testing.assert_allclose(b[mlp], a[mlp], rtol=0, atol=2e-2 * np.abs(a[mlp]).max(), err_msg=name)
+        if k == 2:
+            ta, tb = a[3072:], b[3072:]
+            assert np.abs(ta).max() > 0
+            np.testing.assert_allclose(tb, ta, rtol=0, atol=2e-2 * np.abs(ta).max(), err_msg='hash table')
+            assert np.abs(tb - ta).mean() < 2e-3 * np.abs(ta).mean() + 1e-12
