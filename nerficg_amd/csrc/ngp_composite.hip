@@ -293,6 +293,15 @@ __global__ void __launch_bounds__(256) k_composite_image(const __half* __restric
     }
 }
 
+// up to five output arrays cleared by ONE launch (five hipMemsetAsync calls are five launches of host time in a ~90-launch training step)
+struct ZeroList { uint32_t* p[5]; int64_t words[5]; };
+__global__ void __launch_bounds__(256) k_zero_multi(ZeroList z) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+        if (i < z.words[a]) z.p[a][i] = 0u;
+}
+
 // ---- layer-major image compositing: one call per chunk of rows, front to back ------------------------------------------------
 // State per ray (T and the five running sums), per tile the next layer k to consume and an alive flag.  A tile is finished when
 // none of its rays is alive (saturated or out of samples) or its rows are exhausted; it then writes its pixels once and its flag
@@ -374,6 +383,16 @@ __global__ void __launch_bounds__(256) k_composite_layers(const __half* __restri
 
 }  // namespace
 
+static void zero_arrays(hipStream_t s, void* p0, int64_t b0, void* p1 = nullptr, int64_t b1 = 0, void* p2 = nullptr, int64_t b2 = 0, void* p3 = nullptr,
+                        int64_t b3 = 0, void* p4 = nullptr, int64_t b4 = 0) {
+    ZeroList z;
+    void* ps[5] = {p0, p1, p2, p3, p4};
+    const int64_t bs[5] = {b0, b1, b2, b3, b4};
+    int64_t mx = 0;
+    for (int a = 0; a < 5; a++) { z.p[a] = (uint32_t*)ps[a]; z.words[a] = ps[a] ? bs[a] / 4 : 0; mx = z.words[a] > mx ? z.words[a] : mx; }
+    if (mx > 0) hipLaunchKernelGGL(k_zero_multi, dim3((unsigned)nrc_cdiv(mx, 256)), dim3(256), 0, s, z);
+}
+
 // internal launchers used by nrc_ngp_render_layers (ngp_net.hip)
 void nrc_launch_layers_init(int64_t n_tiles, const int32_t* ray_cnt, float* state, uint8_t* ray_alive, int32_t* next_k, uint8_t* tile_alive,
                             int32_t* skipped_rows, hipStream_t s) {
@@ -399,14 +418,11 @@ int nrc_composite_train_fw(const float* sigmas, const float* rgbs, const float* 
     NRC_ENTER();
     if (n_rays < 0 || n_samples < 0) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (n_samples > 0) { if (!ws) return NRC_ERR_INVALID; hipMemsetAsync(ws, 0, n_samples * sizeof(float), s); }
-    if (n_rays == 0) return NRC_OK;
+    if (n_samples > 0 && !ws) return NRC_ERR_INVALID;
+    if (n_rays == 0) { if (n_samples > 0) zero_arrays(s, ws, n_samples * 4); return NRC_OK; }
     if (!rays_a || !total_samples || !opacity || !depth || !rgb || (n_samples > 0 && (!sigmas || !rgbs || !deltas || !ts))) return NRC_ERR_INVALID;
     // rows of rays_a name their output slot (ray_idx); slots never named keep the reference's zero initialisation
-    hipMemsetAsync(total_samples, 0, n_rays * sizeof(int64_t), s);
-    hipMemsetAsync(opacity, 0, n_rays * sizeof(float), s);
-    hipMemsetAsync(depth, 0, n_rays * sizeof(float), s);
-    hipMemsetAsync(rgb, 0, n_rays * 3 * sizeof(float), s);
+    zero_arrays(s, n_samples > 0 ? ws : nullptr, n_samples * 4, total_samples, n_rays * 8, opacity, n_rays * 4, depth, n_rays * 4, rgb, n_rays * 12);
     hipLaunchKernelGGL(k_composite_train_fw, dim3(nrc_cdiv(n_rays, 4)), dim3(256), 0, s, sigmas, rgbs, deltas, ts, rays_a, n_rays,
                        T_threshold, total_samples, opacity, depth, rgb, ws);
     NRC_LAUNCH_CHECK();
@@ -422,8 +438,7 @@ int nrc_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
     hipStream_t s = (hipStream_t)stream;
     if (n_samples > 0) {
         if (!dL_dsigmas || !dL_drgbs) return NRC_ERR_INVALID;
-        hipMemsetAsync(dL_dsigmas, 0, n_samples * sizeof(float), s);
-        hipMemsetAsync(dL_drgbs, 0, n_samples * 3 * sizeof(float), s);
+        zero_arrays(s, dL_dsigmas, n_samples * 4, dL_drgbs, n_samples * 12);
     }
     if (n_rays == 0 || n_samples == 0) return NRC_OK;
     if (!dL_dopacity || !dL_ddepth || !dL_drgb || !dL_dws || !sigmas || !rgbs || !ws || !deltas || !ts || !rays_a || !opacity || !depth || !rgb)
