@@ -1250,8 +1250,21 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
     const bool owned = allow_owned && d_features_pair_major && M >= 16384;
     LevelList ll; ll.n = 0;
     OwnedCfg oc; oc.n_levels = 0; oc.unit0[0] = 0;
+    // Which hashed levels are owned: the FINEST ones, as many as give one workgroup per CU (256 slices = 8 levels at T = 2^19).  A
+    // ninth level would add a second, mostly idle round of workgroups (352 slices: 0.44 ms instead of 0.23), while the coarser hashed
+    // levels still have long runs of equal entries along a ray and cost 10-60 us each through the run-aggregated atomics.
+    int first_owned = n_levels;
+    if (owned) {
+        int units = 0;
+        for (int l = n_levels - 1; l >= 0 && g.hashed[l]; l--) {
+            const int c = (int)nrc_cdiv(g.size[l], OWN_ENTRIES);
+            if (units + c > 256) break;
+            units += c;
+            first_owned = l;
+        }
+    }
     for (int l = 0; l < n_levels; l++) {
-        if (owned && g.hashed[l]) {
+        if (l >= first_owned) {
             oc.level[oc.n_levels] = l;
             oc.unit0[oc.n_levels + 1] = oc.unit0[oc.n_levels] + (int)nrc_cdiv(g.size[l], OWN_ENTRIES);
             oc.n_levels++;
