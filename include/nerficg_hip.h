@@ -326,6 +326,43 @@ int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int64_t nrc_knn3_ws_bytes(int64_t n);
 int nrc_knn3_mean_sq_dist(const float* points_morton_sorted, int64_t n, float* out_sorted, void* workspace, nrc_stream_t stream);
 
+/* =====================================================================================================
+ * Group 10 -- 3DGS densification bookkeeping on the device: replaces the boolean-mask / torch.cat surgery of
+ *            src/Methods/GaussianSplatting/Model.py:157-246 and src/Optim/adam_utils.py:21-98.
+ *   nrc_gs_densify_stats : add_densification_stats (Model.py:243-246): where radii > 0, grad_accum += |viewspace_grad[:, :2]|,
+ *                          n_observations += 1.  viewspace_grad is (P, ld) f32 (ld = 3 or 4 as the rasterizer hands it out).
+ *   nrc_gs_densify_plan  : densify_and_prune (Model.py:226-241) as a row list.  grads = accum / max(n_obs, 1); clone where
+ *                          grads >= grad_threshold and max exp(log_scale) <= dense_extent (= percent_dense * cameras_extent), split
+ *                          where it is larger; prune where sigmoid(opacity_logit) < min_opacity or (max_scale > 0 and) max scale >
+ *                          max_scale, applied to originals, clones and the two /1.6 children like the reference's final prune.
+ *                          Row o of the resulting arrays comes from Gaussian src[o]; kind[o] = 0 kept original, 1 clone, 2 split
+ *                          child with aux[o] = row of the (2 * counts[4], 3) standard-normal tensor (else -1).  Order as the
+ *                          reference leaves it: originals, clones, children copy 0, children copy 1.  src/kind/aux need 2 * P
+ *                          entries.  counts[5] = {rows out, kept originals, kept clones, kept children per copy, split selected}.
+ *                          grad_accum == n_observations == NULL: prune only.  grad_threshold must be > 0 (a threshold <= 0 would
+ *                          also split the fresh clones; NRC_ERR_UNSUPPORTED).  workspace: nrc_gs_densify_plan_ws_bytes(P).
+ *   nrc_gs_densify_split_children : positions / log-scales of the kind-2 rows (Model.py:196-202): R(q) (z * exp(log_scale)) + p and
+ *                          log(exp(log_scale) / 1.6); z = noise[aux[o]] are the draws of torch.normal(0, std) before scaling.
+ *   nrc_gather_rows      : out[t][o, :] = in[t][src[o], :] for up to 24 f32 tensors of row_floats[t] floats per row in one launch
+ *                          (prune / extend / sort of src/Optim/adam_utils.py:21-98 for every group and both Adam moments at once);
+ *                          tensors with zero_new[t] != 0 get zeros in rows with kind[o] != 0 (the moments of new Gaussians).  in, out,
+ *                          row_floats, zero_new are HOST arrays of n_tensors entries; kind may be NULL (pure permutation / prune).
+ *   nrc_compact_mask     : indices[0..*count) = ascending positions where mask != 0 (u8); workspace nrc_compact_mask_ws_bytes(n).
+ * ===================================================================================================== */
+int nrc_gs_densify_stats(const float* viewspace_grad, int32_t ld, const int32_t* radii, int64_t P, float* grad_accum,
+                         int32_t* n_observations, nrc_stream_t stream);
+int64_t nrc_gs_densify_plan_ws_bytes(int64_t P);
+int nrc_gs_densify_plan(const float* grad_accum, const int32_t* n_observations, const float* log_scales, const float* opacity_logits,
+                        int64_t P, float grad_threshold, float dense_extent, float min_opacity, float max_scale, int32_t* src,
+                        int32_t* kind, int32_t* aux, int32_t* counts, void* workspace, nrc_stream_t stream);
+int nrc_gs_densify_split_children(const int32_t* src, const int32_t* kind, const int32_t* aux, int64_t n_out, const float* positions,
+                                  const float* log_scales, const float* rotations, const float* noise, float* positions_out,
+                                  float* log_scales_out, nrc_stream_t stream);
+int nrc_gather_rows(const float* const* in, float* const* out, const int32_t* row_floats, const int32_t* zero_new, int32_t n_tensors,
+                    const int32_t* src, const int32_t* kind, int64_t n_out, nrc_stream_t stream);
+int64_t nrc_compact_mask_ws_bytes(int64_t n);
+int nrc_compact_mask(const uint8_t* mask, int64_t n, int32_t* indices, int32_t* count, void* workspace, nrc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,8 @@ COMMON_FLAGS = ['-O3', '-fPIC', f'--offload-arch={ARCH}', '-std=c++17', '-Wall',
 PER_FILE_FLAGS = {
     'ngp_march.hip': ['-ffp-contract=off'],
     'adam.hip': ['-ffp-contract=off'],
-    'knn.hip': ['-ffp-contract=off'],   # squared distances decide the neighbour set: same f32 sequence as oracle/knn_oracle.c
+    'knn.hip': ['-ffp-contract=off'],
+    'gs_densify.hip': ['-ffp-contract=off'],   # thresholds decide the row list: same f32 sequence as oracle/gs_densify.py   # squared distances decide the neighbour set: same f32 sequence as oracle/knn_oracle.c
   # HBM-bound anyway; keeps the update bit-identical to oracle/adam_oracle.c
     # + no atomic optimizer: it rewrites the one-lane LDS atomics of k_render_bw into 15-instruction wave-reduction loops
     'gs_raster.hip': ['-ffp-contract=off', '-mllvm', '-amdgpu-atomic-optimizer-strategy=None'],

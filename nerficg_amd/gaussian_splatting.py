@@ -139,7 +139,9 @@ def sh0_to_rgb(sh):
 
 class Gaussians(torch.nn.Module):
     """Parameter store + activation accessors of GaussianSplatting/Model.py:18-87 (exp scales, normalised quaternions, sigmoid
-    opacities, cat[dc, rest] SH features of shape (P, 16, 3))."""
+    opacities, cat[dc, rest] SH features of shape (P, 16, 3)) and the training-time bookkeeping of Model.py:94-284: optimizer setup,
+    densification statistics, densify_and_prune, opacity reset, activation baking, ply export.  The bookkeeping runs on the device through
+    include/nerficg_hip.h group 10 (one classification + scan, one gather over all parameters and Adam moments)."""
 
     def __init__(self, positions, log_scales, rotations, opacity_logits, features_dc, features_rest, sh_degree: int = 3) -> None:
         super().__init__()
@@ -147,17 +149,198 @@ class Gaussians(torch.nn.Module):
         self._positions, self._scales, self._rotations = P(positions), P(log_scales), P(rotations)
         self._opacities, self._features_dc, self._features_rest = P(opacity_logits), P(features_dc), P(features_rest)
         self.active_sh_degree = sh_degree
+        self.max_sh_degree = sh_degree
+        self.optimizer = None
+        self.percent_dense = 0.0
+        self.training_cameras_extent = 1.0
+        self.baked = False
+        self._baked_covariances = None
+        n, dev = positions.shape[0], positions.device
+        self.densification_gradient_accum = torch.zeros((n, 1), dtype=torch.float32, device=dev)
+        self.n_observations = torch.zeros((n, 1), dtype=torch.int32, device=dev)
+
+    @classmethod
+    def from_point_cloud(cls, positions: torch.Tensor, colors: torch.Tensor | None = None, sh_degree: int = 3) -> 'Gaussians':
+        """initialize_from_point_cloud (Model.py:94-119): isotropic scales from the RMS distance to the 3 nearest neighbours
+        (Optim/knn_utils.py:29-40 through the HIP kNN), identity rotations, opacity 0.1, DC colour from rgb."""
+        from .simple_knn import distCUDA2
+        positions = positions.to(torch.float32).contiguous()
+        n, dev = positions.shape[0], positions.device
+        rgbs = torch.full_like(positions, 0.5) if colors is None else colors.to(dev, torch.float32)
+        features = torch.zeros((n, 3, (sh_degree + 1) ** 2), dtype=torch.float32, device=dev)
+        features[:, :3, 0] = rgb_to_sh0(rgbs)
+        distances = distCUDA2(positions).clamp_min(1e-7).sqrt()
+        scales = torch.log(distances)[..., None].repeat(1, 3)
+        rotations = torch.zeros((n, 4), device=dev)
+        rotations[:, 0] = 1
+        opacities = torch.special.logit(torch.full((n, 1), 0.1, dtype=torch.float32, device=dev))
+        out = cls(positions, scales.contiguous(), rotations, opacities, features[:, :, 0:1].transpose(1, 2).contiguous(),
+                  features[:, :, 1:].transpose(1, 2).contiguous(), sh_degree)
+        out.active_sh_degree = 0
+        return out
 
     @property
     def get_positions(self): return self._positions
     @property
-    def get_scales(self): return torch.exp(self._scales)
+    def get_scales(self): return self._scales if self.baked else torch.exp(self._scales)
     @property
-    def get_rotations(self): return torch.nn.functional.normalize(self._rotations)
+    def get_rotations(self): return self._rotations if self.baked else torch.nn.functional.normalize(self._rotations)
     @property
-    def get_opacities(self): return torch.sigmoid(self._opacities)
+    def get_opacities(self): return self._opacities if self.baked else torch.sigmoid(self._opacities)
+    @property
+    def get_features_dc(self): return self._features_dc
+    @property
+    def get_features_rest(self): return self._features_rest
     @property
     def get_features(self): return torch.cat((self._features_dc, self._features_rest), dim=1)
+    @property
+    def get_baked_covariances(self): return self._baked_covariances
+
+    def get_covariances(self, scale_modifier: float) -> torch.Tensor:
+        """Model.py:84-86"""
+        return extract_upper_triangular_matrix(build_covariances(self.get_scales * scale_modifier, self.get_rotations))
+
+    def increase_used_sh_degree(self) -> None:
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    # ---------------------------------------------------------------- optimizer (Model.py:121-150)
+    _GROUP_OF = {'positions': '_positions', 'f_dc': '_features_dc', 'f_rest': '_features_rest', 'opacities': '_opacities', 'scales': '_scales',
+                 'rotations': '_rotations'}
+
+    def training_setup(self, LEARNING_RATE_POSITION_INIT: float = 0.00016, LEARNING_RATE_POSITION_FINAL: float = 0.0000016,
+                       LEARNING_RATE_POSITION_MAX_STEPS: int = 30000, LEARNING_RATE_FEATURE: float = 0.0025, LEARNING_RATE_OPACITY: float = 0.05,
+                       LEARNING_RATE_SCALING: float = 0.005, LEARNING_RATE_ROTATION: float = 0.001, PERCENT_DENSE: float = 0.01,
+                       training_cameras_extent: float | None = None, optimizer_class=None) -> None:
+        """Six single-tensor groups in the reference's order and names; FusedAdam(lr=0, eps=1e-15, adam_w_mode=False) over the HIP step."""
+        from .lr_utils import LRDecayPolicy
+        if training_cameras_extent is not None:
+            self.training_cameras_extent = training_cameras_extent
+        self.percent_dense = PERCENT_DENSE
+        ext = self.training_cameras_extent
+        param_groups = [
+            {'params': [self._positions], 'lr': LEARNING_RATE_POSITION_INIT * ext, 'name': 'positions'},
+            {'params': [self._features_dc], 'lr': LEARNING_RATE_FEATURE, 'name': 'f_dc'},
+            {'params': [self._features_rest], 'lr': LEARNING_RATE_FEATURE / 20.0, 'name': 'f_rest'},
+            {'params': [self._opacities], 'lr': LEARNING_RATE_OPACITY, 'name': 'opacities'},
+            {'params': [self._scales], 'lr': LEARNING_RATE_SCALING, 'name': 'scales'},
+            {'params': [self._rotations], 'lr': LEARNING_RATE_ROTATION, 'name': 'rotations'},
+        ]
+        if optimizer_class is None:
+            from .apex_optimizers import FusedAdam
+            self.optimizer = FusedAdam(param_groups, lr=0.0, eps=1e-15, adam_w_mode=False)
+        else:
+            self.optimizer = optimizer_class(param_groups, lr=0.0, eps=1e-15)
+        self.position_lr_scheduler = LRDecayPolicy(lr_init=LEARNING_RATE_POSITION_INIT * ext, lr_final=LEARNING_RATE_POSITION_FINAL * ext,
+                                                   max_steps=LEARNING_RATE_POSITION_MAX_STEPS)
+
+    def update_learning_rate(self, iteration: int) -> None:
+        for param_group in self.optimizer.param_groups:
+            if param_group['name'] == 'positions':
+                param_group['lr'] = self.position_lr_scheduler(iteration)
+
+    def _adopt(self, tensors: dict[str, torch.Tensor]) -> None:
+        for name, attr in self._GROUP_OF.items():
+            setattr(self, attr, tensors[name])
+
+    # ---------------------------------------------------------------- densification (Model.py:152-246)
+    def reset_opacities(self) -> None:
+        from .adam_utils import replace_param_group_data
+        opacities_new = torch.special.logit(self.get_opacities.clamp_max(0.01))
+        replace_param_group_data(self.optimizer, opacities_new, 'opacities')
+
+    def prune_points(self, prune_mask: torch.Tensor) -> None:
+        from .adam_utils import compact_mask, gather_param_groups, gather_rows
+        idx = compact_mask(~prune_mask)
+        self._adopt(gather_param_groups(self.optimizer, idx, idx.numel(), None, None, 'prune_param_groups'))
+        self.densification_gradient_accum, n_obs = gather_rows([self.densification_gradient_accum, self.n_observations.view(torch.float32)],
+                                                               idx, idx.numel())
+        self.n_observations = n_obs.view(torch.int32)
+
+    @torch.no_grad()
+    def add_densification_stats(self, viewspace_point_tensor: torch.Tensor, visibility: torch.Tensor) -> None:
+        """Model.py:243-246.  `visibility`: the rasterizer's int32 radii (used as they are) or the boolean mask radii > 0."""
+        from . import _lib
+        grad = viewspace_point_tensor.grad if viewspace_point_tensor.grad is not None else viewspace_point_tensor
+        radii = visibility if visibility.dtype == torch.int32 else visibility.to(torch.int32)
+        _lib.check_input(grad, 'viewspace gradient', torch.float32)
+        _lib.check_input(radii, 'radii', torch.int32)
+        lib = _lib.load()
+        _lib.check(lib.nrc_gs_densify_stats(_lib.ptr(grad), grad.shape[1], _lib.ptr(radii), grad.shape[0], _lib.ptr(self.densification_gradient_accum),
+                                            _lib.ptr(self.n_observations), _lib.stream_of(grad)), 'gs_densify_stats')
+
+    @torch.no_grad()
+    def densify_and_prune(self, grad_threshold: float, min_opacity: float, prune_large_gaussians: bool, noise: torch.Tensor | None = None) -> dict[str, int]:
+        """Model.py:226-241 (duplicate, split, prune) as one device plan + one gather.  `noise`: optional (>= 2 * n_split, 3) standard
+        normal draws; by default torch.randn((2 * n_split, 3)) -- the draws torch.normal(mean=0, std=stds) consumes in the reference
+        (normal_(0, 1) into the output, then * std)."""
+        from . import _lib
+        from .adam_utils import gather_param_groups
+        lib = _lib.load()
+        P, dev = self._positions.shape[0], self._positions.device
+        src = torch.empty(2 * max(P, 1), dtype=torch.int32, device=dev)
+        kind, aux = torch.empty_like(src), torch.empty_like(src)
+        counts = torch.zeros(5, dtype=torch.int32, device=dev)
+        ws = torch.empty(int(lib.nrc_gs_densify_plan_ws_bytes(P)), dtype=torch.uint8, device=dev)
+        scales, opac = self._scales.data.contiguous(), self._opacities.data.contiguous()
+        max_scale = float(np.float32(0.1 * self.training_cameras_extent)) if prune_large_gaussians else 0.0
+        _lib.check(lib.nrc_gs_densify_plan(_lib.ptr(self.densification_gradient_accum), _lib.ptr(self.n_observations), _lib.ptr(scales), _lib.ptr(opac), P,
+                                           grad_threshold, self.percent_dense * self.training_cameras_extent, min_opacity, max_scale, _lib.ptr(src),
+                                           _lib.ptr(kind), _lib.ptr(aux), _lib.ptr(counts), _lib.ptr(ws), _lib.stream_of(src)), 'gs_densify_plan')
+        n_out, n_keep, n_dup, n_child, n_split = counts.tolist()  # the one host read: sizes of the new tensors
+        if noise is None:
+            noise = torch.randn((2 * n_split, 3), dtype=torch.float32, device=dev)
+        elif noise.shape[0] < 2 * n_split:
+            raise RuntimeError(f'densify_and_prune: noise has {noise.shape[0]} rows, {2 * n_split} needed')
+        old_pos, old_rot = self._positions.data, self._rotations.data.contiguous()
+        new = gather_param_groups(self.optimizer, src, n_out, kind, None, 'extend_param_groups')
+        if n_child > 0:
+            noise = noise.to(torch.float32).contiguous()
+            _lib.check(lib.nrc_gs_densify_split_children(_lib.ptr(src), _lib.ptr(kind), _lib.ptr(aux), n_out, _lib.ptr(old_pos), _lib.ptr(scales),
+                                                         _lib.ptr(old_rot), _lib.ptr(noise), _lib.ptr(new['positions'].data), _lib.ptr(new['scales'].data),
+                                                         _lib.stream_of(src)), 'gs_densify_split_children')
+        self._adopt(new)
+        self.densification_gradient_accum = torch.zeros((n_out, 1), dtype=torch.float32, device=dev)
+        self.n_observations = torch.zeros((n_out, 1), dtype=torch.int32, device=dev)
+        return {'n_out': n_out, 'n_kept': n_keep, 'n_cloned': n_dup, 'n_split': n_split, 'n_children_kept': 2 * n_child}
+
+    # ---------------------------------------------------------------- export (Model.py:248-318)
+    @torch.no_grad()
+    def bake_activations(self) -> None:
+        """Model.py:248-273: activations folded into the parameters, never-visible Gaussians pruned, Morton order, covariances baked."""
+        from .adam_utils import compact_mask, gather_rows
+        from .MortonEncoding import morton_encode
+        rot, opa, sca = self.get_rotations, self.get_opacities, self.get_scales
+        keep = compact_mask(~(opa.flatten() < 0.00392156862))
+        names = ('_positions', '_rotations', '_features_dc', '_features_rest', '_scales', '_opacities')
+        vals = gather_rows([self._positions.data, rot.contiguous(), self._features_dc.data, self._features_rest.data, sca.contiguous(), opa.contiguous()],
+                           keep, keep.numel())
+        order = torch.argsort(morton_encode(vals[0])).to(torch.int32)
+        vals = gather_rows(vals, order, order.numel())
+        for name, v in zip(names, vals):
+            setattr(self, name, torch.nn.Parameter(v, requires_grad=getattr(self, name).requires_grad))
+        self.baked = True
+        self._baked_covariances = torch.nn.Parameter(self.get_covariances(1.0), requires_grad=False)
+
+    @torch.no_grad()
+    def as_ply_dict(self) -> dict[str, np.ndarray]:
+        """Model.py:275-318: one 'vertex' element, every attribute f4: x y z, f_dc_0..2, f_rest_0..44 (channel-major), opacity (logit),
+        scale_0..2 (log), rot_0..3 (normalised)."""
+        if self.get_positions.shape[0] == 0:
+            return {}
+        positions = self.get_positions.detach().contiguous().cpu().numpy()
+        sh_0 = self.get_features_dc.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy()
+        sh_rest = self.get_features_rest.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy()
+        opacities = self.get_opacities.logit().detach().contiguous().cpu().numpy()
+        scales = self.get_scales.log().detach().contiguous().cpu().numpy()
+        rotations = self.get_rotations.detach().contiguous().cpu().numpy()
+        attributes = np.concatenate((positions, sh_0, sh_rest, opacities, scales, rotations), axis=1)
+        attribute_names = (['x', 'y', 'z'] + ['f_dc_0', 'f_dc_1', 'f_dc_2'] + [f'f_rest_{i}' for i in range(sh_rest.shape[-1])] + ['opacity']
+                           + ['scale_0', 'scale_1', 'scale_2'] + ['rot_0', 'rot_1', 'rot_2', 'rot_3'])
+        vertices = np.empty(positions.shape[0], dtype=[(name, 'f4') for name in attribute_names])
+        for k, name in enumerate(attribute_names):
+            vertices[name] = attributes[:, k]
+        return {'vertex': vertices}
 
 
 def render_image_training(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np.ndarray) -> dict[str, torch.Tensor]:

@@ -12,6 +12,7 @@ Vectors produced (reference symbol -> fixture):
   convert_sh_features / build_covariances / quaternion_to_rotation  -> gs_utils.npz        (a26)
   LRDecayPolicy, apply_background_color, RandomSequentialSampler    -> misc.npz
   NeRFBlock.forward / NeRFRayRenderingComponent.forward (tiny model) -> nerf_render.npz         (a6, a10)
+  Gaussians.densify_and_prune / add_densification_stats / as_ply_dict, adam_utils -> gs_densify.npz (8f rank 3, 4)
 """
 import importlib.util
 import math
@@ -262,5 +263,112 @@ def main():
         print(f'  {f.name}: {f.stat().st_size} B')
 
 
+def make_gs_densify():
+    """3DGS densification bookkeeping -> gs_densify.npz: the reference's own Gaussians class (Model.py:18-284) and
+    Optim/adam_utils.py run on CPU.  Model.py hard-codes device='cuda' in split(); `torch.zeros` is redirected to the CPU for the call and
+    `torch.normal(mean, std)` is replaced by its definition mean + z * std with the standard-normal draws z recorded (they are an INPUT of
+    the kernels: RNG streams are not part of the parity contract)."""
+    install_shims()
+    if str(REF) not in sys.path:
+        sys.path.insert(0, str(REF))
+    import Framework
+    if getattr(Framework, 'config', None) is None or 'GLOBAL' not in Framework.config:
+        Framework.config = Framework.ConfigWrapper.fromDict({
+            'GLOBAL': {'RANDOM_SEED': 1618033989, 'ANOMALY_DETECTION': False, 'GPU_INDICES': None, 'DEFAULT_DEVICE': torch.device('cpu'),
+                       'METHOD_TYPE': 'GaussianSplatting'}, 'TRAINING': {'WANDB': {'ACTIVATE': False}}})
+    # the class only needs these two at densification time: the Morton extension and the proprietary kNN are absent here
+    pk = types.ModuleType('CudaUtils'); pk.__path__ = []
+    me = types.ModuleType('CudaUtils.MortonEncoding'); me.morton_encode = None
+    sys.modules.setdefault('CudaUtils', pk); sys.modules.setdefault('CudaUtils.MortonEncoding', me)
+    sys.modules.setdefault('Thirdparty.SimpleKNN', None)
+    import Methods  # noqa: F401
+    gp = types.ModuleType('Methods.GaussianSplatting'); gp.__path__ = [str(REF / 'Methods/GaussianSplatting')]  # skip the package __init__ (imports the rasterizer)
+    sys.modules['Methods.GaussianSplatting'] = gp
+    from Methods.GaussianSplatting.Model import Gaussians
+    from Optim import adam_utils
+
+    g = torch.Generator().manual_seed(20240612)
+    P = 1000
+    extent, percent_dense = 4.0, 0.01
+    gs = Gaussians(3, False)
+    gs.training_cameras_extent, gs.percent_dense = extent, percent_dense
+    rnd = lambda *shape: torch.randn(*shape, generator=g)  # noqa: E731
+    gs._positions = torch.nn.Parameter(rnd(P, 3) * 2.0)
+    gs._scales = torch.nn.Parameter(torch.log(torch.exp(rnd(P, 3) * 1.2 - 3.2)))       # exp(scale): 0.003 .. 1.5, threshold 0.04, large > 0.4
+    gs._rotations = torch.nn.Parameter(rnd(P, 4) * 1.5)
+    gs._opacities = torch.nn.Parameter(rnd(P, 1) * 3.0 - 2.0)                           # sigmoid: some below 0.005
+    gs._features_dc = torch.nn.Parameter(rnd(P, 1, 3))
+    gs._features_rest = torch.nn.Parameter(rnd(P, 15, 3) * 0.1)
+    names = {'positions': '_positions', 'f_dc': '_features_dc', 'f_rest': '_features_rest', 'opacities': '_opacities', 'scales': '_scales',
+             'rotations': '_rotations'}
+    gs.optimizer = torch.optim.Adam([{'params': [getattr(gs, a)], 'lr': 1e-3, 'name': n} for n, a in names.items()], lr=0.0, eps=1e-15)
+    for a in names.values():
+        getattr(gs, a).grad = rnd(*getattr(gs, a).shape) * 1e-2
+    gs.optimizer.step()   # creates exp_avg / exp_avg_sq
+    gs.optimizer.zero_grad()
+    gs.densification_gradient_accum = torch.rand(P, 1, generator=g) * 1.2e-3
+    gs.n_observations = torch.randint(0, 9, (P, 1), generator=g, dtype=torch.int32)
+    blob = {f'in_{n}': getattr(gs, a).detach().numpy().copy() for n, a in names.items()}
+    for n, a in names.items():
+        st = gs.optimizer.state[getattr(gs, a)]
+        blob[f'in_{n}_exp_avg'], blob[f'in_{n}_exp_avg_sq'] = st['exp_avg'].numpy().copy(), st['exp_avg_sq'].numpy().copy()
+    blob['in_accum'], blob['in_n_obs'] = gs.densification_gradient_accum.numpy().copy(), gs.n_observations.numpy().copy()
+
+    # add_densification_stats (Model.py:243-246)
+    vsp = torch.zeros(P, 3, requires_grad=True)
+    vsp.grad = rnd(P, 3) * 3e-4
+    radii = torch.randint(-1, 30, (P,), generator=g, dtype=torch.int32).clamp_min(0) * (torch.rand(P, generator=g) > 0.3)
+    gs.add_densification_stats(vsp, radii > 0)
+    blob.update(vsp_grad=vsp.grad.numpy().copy(), radii=radii.to(torch.int32).numpy().copy(),
+                stats_accum=gs.densification_gradient_accum.numpy().copy(), stats_n_obs=gs.n_observations.numpy().copy())
+
+    # ply export of the untouched model (Model.py:275-318)
+    ply = gs.as_ply_dict()['vertex']
+    blob['ply_names'] = np.array(ply.dtype.names)
+    blob['ply_rows'] = np.stack([ply[n] for n in ply.dtype.names], axis=1)
+
+    # densify_and_prune (Model.py:226-241) on the CPU
+    noise_log = []
+    real_zeros, real_normal = torch.zeros, torch.normal
+
+    def zeros_cpu(*a, **kw):
+        kw.pop('device', None)
+        return real_zeros(*a, **kw)
+
+    def normal_recorded(mean, std):
+        z = torch.randn(std.shape, generator=g)
+        noise_log.append(z)
+        return mean + z * std
+    torch.zeros, torch.normal = zeros_cpu, normal_recorded
+    try:
+        gs.densify_and_prune(grad_threshold=0.0002, min_opacity=0.005, prune_large_gaussians=True)
+    finally:
+        torch.zeros, torch.normal = real_zeros, real_normal
+    blob['noise'] = noise_log[0].numpy()
+    blob.update(grad_threshold=np.float64(0.0002), min_opacity=np.float64(0.005), extent=np.float64(extent), percent_dense=np.float64(percent_dense))
+    for n, a in names.items():
+        blob[f'out_{n}'] = getattr(gs, a).detach().numpy().copy()
+        st = gs.optimizer.state[getattr(gs, a)]
+        blob[f'out_{n}_exp_avg'], blob[f'out_{n}_exp_avg_sq'] = st['exp_avg'].numpy().copy(), st['exp_avg_sq'].numpy().copy()
+
+    # adam_utils: sort + indexed state reset + opacity reset on the densified model (adam_utils.py:6-18,64-98; Model.py:152-155)
+    n_now = gs._positions.shape[0]
+    order = torch.randperm(n_now, generator=g)
+    sorted_params = adam_utils.sort_param_groups(gs.optimizer, order, ['positions', 'rotations'])
+    idx = torch.randint(0, n_now, (50,), generator=g)
+    adam_utils.reset_state(gs.optimizer, ['positions'], idx)
+    blob.update(sort_order=order.numpy(), reset_idx=idx.numpy(), sorted_positions=sorted_params['positions'].detach().numpy().copy(),
+                sorted_positions_exp_avg=gs.optimizer.state[sorted_params['positions']]['exp_avg'].numpy().copy(),
+                sorted_rotations_exp_avg_sq=gs.optimizer.state[sorted_params['rotations']]['exp_avg_sq'].numpy().copy())
+    gs.reset_opacities()
+    blob['reset_opacities'] = gs.optimizer.param_groups[3]['params'][0].detach().numpy().copy()
+    np.savez_compressed(OUT / 'gs_densify.npz', **blob)
+    print('gs_densify.npz:', (OUT / 'gs_densify.npz').stat().st_size, 'B; rows', P, '->', n_now, '; split noise rows', noise_log[0].shape[0])
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'gs_densify':
+        make_gs_densify()   # only this fixture (the others keep their RNG streams)
+    else:
+        main()
+        make_gs_densify()
