@@ -363,6 +363,22 @@ int nrc_gather_rows(const float* const* in, float* const* out, const int32_t* ro
 int64_t nrc_compact_mask_ws_bytes(int64_t n);
 int nrc_compact_mask(const uint8_t* mask, int64_t n, int32_t* indices, int32_t* count, void* workspace, nrc_stream_t stream);
 
+/* =====================================================================================================
+ * Group 11 -- InstantNGP occupancy-grid maintenance in one call: replaces the scratch-grid index_put, the
+ *            where/maximum EMA, the masked mean pulled to the host and the packbits call of
+ *            src/Methods/InstantNGP/Renderer.py:258-272.  grid (cascades, cells_per_cascade) f32 is updated in place:
+ *            cells >= 0 become max(grid * decay, density sampled for the cell this round (0 if none; the maximum if several)), cells < 0
+ *            (carved) stay.  threshold_out[0] = min(mean of the cells > 0, density_threshold) (NaN when there is none, like the
+ *            reference's empty mean), threshold_out[1] = that mean; bitfield bit = cell > threshold_out[0] (raymarching.cu:138-161).
+ *            cell_indices (cascades, samples_per_cascade) i64 Morton indices, densities the same shape, f32 (dtype 0) or f16 (1).
+ *            Everything stays on the device (threshold_out is a DEVICE pointer to 2 floats).  cells_per_cascade % 8 == 0; grid and
+ *            workspace 16-byte aligned; workspace: nrc_occupancy_update_ws_bytes(cascades * cells_per_cascade).
+ * ===================================================================================================== */
+int64_t nrc_occupancy_update_ws_bytes(int64_t n_cells_total);
+int nrc_occupancy_update(float* grid, const int64_t* cell_indices, const void* densities, int32_t densities_dtype, int32_t cascades,
+                         int64_t cells_per_cascade, int64_t samples_per_cascade, float decay, float density_threshold,
+                         uint8_t* bitfield, float* threshold_out, void* workspace, nrc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

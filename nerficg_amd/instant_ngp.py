@@ -364,19 +364,48 @@ class InstantNGPRenderer:
     @torch.no_grad()
     @torch.amp.autocast('cuda')
     def update_occupancy_grid(self, warmup: bool = False, decay: float = 0.95) -> None:
+        """Renderer.py:247-272.  Cell sampling and jitter draw from torch's generator in the reference's order; the densities of ALL
+        cascades come from one network query, and scratch-grid scatter, EMA, masked mean, threshold and bit packing are one C-ABI call
+        (include/nerficg_hip.h group 11) that leaves the threshold on the device (`self.occupancy_threshold`, 2 floats: used, mean) --
+        the reference's `.item()` host sync is gone."""
         m = self.model
-        occupancy_grid_tmp = torch.zeros_like(m.occupancy_grid)
         cells = self.get_occupancy_grid_cells() if warmup else self.sample_occupancy_grid(m.RESOLUTION ** 3 // 4, self.density_threshold)
+        points = []
         for c in range(m.cascades):
-            indices, coords = cells[c]
+            _, coords = cells[c]
             s = min(2 ** (c - 1), m.SCALE)
             half_grid_size = s / m.RESOLUTION
             xyzs_w = (coords / (m.RESOLUTION - 1) * 2 - 1) * (s - half_grid_size)
             xyzs_w += (torch.rand_like(xyzs_w) * 2 - 1) * half_grid_size
-            occupancy_grid_tmp[c, indices] = self.ray_rendering_component.query_density(xyzs_w)
-        m.occupancy_grid = torch.where(m.occupancy_grid < 0, m.occupancy_grid, torch.maximum(m.occupancy_grid * decay, occupancy_grid_tmp))
-        mean_density = m.occupancy_grid[m.occupancy_grid > 0].mean().item()
-        VolumeRenderingCuda.packbits(m.occupancy_grid, min(mean_density, self.density_threshold), m.occupancy_bitfield)
+            points.append(xyzs_w)
+        per_cascade = max(p.shape[0] for p in points)
+        density = self.ray_rendering_component.query_density(torch.cat(points) if len(points) > 1 else points[0]).reshape(-1)
+        if density.dtype not in (torch.float32, torch.float16):
+            density = density.float()
+        dev = m.occupancy_grid.device
+        if all(p.shape[0] == per_cascade for p in points):
+            indices = torch.stack([cells[c][0] for c in range(m.cascades)]).contiguous()
+            density = density.contiguous()
+        else:  # a cascade without occupied cells draws fewer samples: pad with ignored entries (index -1)
+            indices = torch.full((m.cascades, per_cascade), -1, dtype=torch.int64, device=dev)
+            padded = torch.zeros((m.cascades, per_cascade), dtype=density.dtype, device=dev)
+            o = 0
+            for c, p in enumerate(points):
+                indices[c, :p.shape[0]] = cells[c][0]
+                padded[c, :p.shape[0]] = density[o:o + p.shape[0]]
+                o += p.shape[0]
+            density = padded
+        lib = _lib.load()
+        grid = m.occupancy_grid
+        _lib.check_input(grid, 'occupancy_grid', torch.float32)
+        n_cells = grid.numel()
+        ws_bytes = int(lib.nrc_occupancy_update_ws_bytes(n_cells))
+        if getattr(self, '_occ_ws', None) is None or self._occ_ws.numel() < ws_bytes:
+            self._occ_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            self.occupancy_threshold = torch.zeros(2, dtype=torch.float32, device=dev)
+        _lib.check(lib.nrc_occupancy_update(_lib.ptr(grid), _lib.ptr(indices), _lib.ptr(density), 0 if density.dtype == torch.float32 else 1, m.cascades,
+                                            grid.shape[1], per_cascade, decay, self.density_threshold, _lib.ptr(m.occupancy_bitfield),
+                                            _lib.ptr(self.occupancy_threshold), _lib.ptr(self._occ_ws), _lib.stream_of(grid)), 'occupancy_update')
 
     @torch.no_grad()
     def carve_occupancy_grid(self, views, subtractive: bool = False, use_alpha: bool = False) -> None:

@@ -84,6 +84,28 @@ def packbits(grid, thr):
     return out
 
 
+def occupancy_update(grid, cell_indices, densities, decay, density_threshold):
+    """InstantNGPRenderer.update_occupancy_grid after the density query (src/Methods/InstantNGP/Renderer.py:258-272): scratch grid <- densities
+    by index (the reference's index_put keeps an arbitrary one of several samples of a cell; the maximum is taken here, entries with
+    index < 0 are padding), grid = where(grid < 0, grid, max(grid * decay, scratch)), mean over cells > 0 (f64 accumulation), bitfield at
+    min(mean, density_threshold) with Python's min() NaN behaviour.  Returns (grid, bitfield, threshold_used, mean)."""
+    grid = _c(grid, f32).copy()
+    C, N = grid.shape
+    scratch = np.zeros_like(grid)
+    idx = np.asarray(cell_indices).reshape(C, -1)
+    den = np.asarray(densities).astype(f32).reshape(C, -1)
+    for c in range(C):
+        ok = idx[c] >= 0
+        np.maximum.at(scratch[c], idx[c][ok], den[c][ok])
+    upd = np.maximum(grid * f32(decay), scratch)
+    grid = np.where(grid < 0, grid, upd).astype(f32)
+    pos = grid[grid > 0]
+    mean = f32(pos.astype(np.float64).mean()) if pos.size else f32(np.nan)
+    thr = f32(density_threshold) if f32(density_threshold) < mean else mean
+    bits = np.zeros(C * N // 8, u8) if np.isnan(thr) else packbits(grid, float(thr))
+    return grid, bits, thr, mean
+
+
 def ray_aabb_intersect(rays_o, rays_d, centers, half_sizes, max_hits):
     rays_o, rays_d, centers, half_sizes = _c(rays_o, f32), _c(rays_d, f32), _c(centers, f32), _c(half_sizes, f32)
     n = rays_o.shape[0]

@@ -167,9 +167,58 @@ def test_update_occupancy_grid_runs_and_packs(setup):
     renderer.update_occupancy_grid(warmup=True)
     g = model.occupancy_grid
     assert (g > 0).any()
-    thr = min(g[g > 0].mean().item(), renderer.density_threshold)
-    np.testing.assert_array_equal(model.occupancy_bitfield.cpu().numpy(), oracle.packbits(g.float().cpu().numpy(), thr))
+    used, mean = renderer.occupancy_threshold.tolist()  # stays on the device in production; read here to check it
+    np.testing.assert_allclose(mean, g[g > 0].double().mean().item(), rtol=1e-6)
+    assert used == np.float32(min(mean, renderer.density_threshold))
+    np.testing.assert_array_equal(model.occupancy_bitfield.cpu().numpy(), oracle.packbits(g.float().cpu().numpy(), used))
+    before = g.clone()
     renderer.update_occupancy_grid(warmup=False)
+    assert bool((model.occupancy_grid >= before * 0.95 - 1e-12).all())  # EMA: never below the decayed value
+
+
+@pytest.mark.parametrize('cascades,dtype,n_samples', [(1, torch.float32, 20000), (2, torch.float16, 70001), (3, torch.float32, 0)])
+def test_occupancy_update_call_matches_oracle(cascades, dtype, n_samples):
+    """C ABI group 11 against oracle.occupancy_update (Renderer.py:258-272): grid bit-exact, threshold within f32 rounding of the f64 mean,
+    bitfield bit-exact at the threshold the device used; carved (negative) cells untouched; duplicate and padded (-1) indices."""
+    from nerficg_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(cascades * 1000 + n_samples)
+    N = 64 ** 3
+    grid = (rng.random((cascades, N)) * 0.5).astype(np.float32)
+    grid[rng.random((cascades, N)) < 0.2] = -1.0
+    grid[rng.random((cascades, N)) < 0.3] = 0.0
+    idx = rng.integers(0, N, size=(cascades, n_samples)).astype(np.int64)  # duplicates are certain at these counts
+    if n_samples:
+        idx[:, -5:] = -1
+    den = (rng.random((cascades, n_samples)) * 2.0).astype(np.float16 if dtype == torch.float16 else np.float32)
+    tg = torch.from_numpy(grid.copy()).to(DEV)
+    ti, td = torch.from_numpy(idx).to(DEV), torch.from_numpy(den).to(DEV)
+    bits = torch.full((cascades * N // 8,), 0xAA, dtype=torch.uint8, device=DEV)
+    thr = torch.zeros(2, device=DEV)
+    ws = torch.empty(int(lib.nrc_occupancy_update_ws_bytes(cascades * N)), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.nrc_occupancy_update(_lib.ptr(tg), _lib.ptr(ti), _lib.ptr(td), 0 if dtype == torch.float32 else 1, cascades, N, n_samples, 0.95, 0.01,
+                                        _lib.ptr(bits), _lib.ptr(thr), _lib.ptr(ws), _lib.stream_of(tg)), 'occupancy_update')
+    want_grid, _, want_thr, want_mean = oracle.occupancy_update(grid, idx, den, 0.95, 0.01)
+    np.testing.assert_array_equal(tg.cpu().numpy(), want_grid)
+    used, mean = thr.tolist()
+    np.testing.assert_allclose(mean, want_mean, rtol=1e-6)
+    np.testing.assert_allclose(used, want_thr, rtol=1e-6)
+    np.testing.assert_array_equal(bits.cpu().numpy(), oracle.packbits(want_grid, used))
+
+
+def test_occupancy_update_without_positive_cells_clears_the_bitfield():
+    from nerficg_amd import _lib
+    lib = _lib.load()
+    N = 32 ** 3
+    tg = torch.full((1, N), -1.0, device=DEV)
+    tg[0, ::3] = 0.0
+    bits = torch.full((N // 8,), 0xFF, dtype=torch.uint8, device=DEV)
+    thr = torch.zeros(2, device=DEV)
+    ws = torch.empty(int(lib.nrc_occupancy_update_ws_bytes(N)), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.nrc_occupancy_update(_lib.ptr(tg), None, None, 0, 1, N, 0, 0.95, 0.01, _lib.ptr(bits), _lib.ptr(thr), _lib.ptr(ws), _lib.stream_of(tg)),
+               'occupancy_update')
+    assert bool(torch.isnan(thr).all()) and int(bits.max()) == 0  # the reference's empty mean is NaN: `cell > NaN` is never true
+    assert lib.nrc_occupancy_update(_lib.ptr(tg), None, None, 0, 1, N + 4, 0, 0.95, 0.01, _lib.ptr(bits), _lib.ptr(thr), _lib.ptr(ws), None) == -1
 
 
 def test_carve_occupancy_grid_matches_an_independent_numpy_statement():
