@@ -59,6 +59,11 @@ class InstantNGPModel(torch.nn.Module):
                  RANDOM_SEED: int = 1618033989, device: str | torch.device = 'cuda') -> None:
         super().__init__()
         self.SCALE, self.RESOLUTION, self.CENTER = SCALE, RESOLUTION, list(CENTER)
+        # the configurable parameters travel with checkpoints (Base/Model.py:103-111; nerficg_amd.formats)
+        self.HASHGRID_N_LEVELS, self.HASHGRID_N_FEATURES_PER_LEVEL, self.HASHGRID_LOG2_SIZE = HASHGRID_N_LEVELS, HASHGRID_N_FEATURES_PER_LEVEL, HASHGRID_LOG2_SIZE
+        self.HASHGRID_BASE_RESOLUTION, self.HASHGRID_TARGET_RESOLUTION = HASHGRID_BASE_RESOLUTION, HASHGRID_TARGET_RESOLUTION
+        self.N_DENSITY_OUTPUT_FEATURES, self.N_DENSITY_NEURONS, self.N_DENSITY_LAYERS = N_DENSITY_OUTPUT_FEATURES, N_DENSITY_NEURONS, N_DENSITY_LAYERS
+        self.DIR_SH_ENCODING_DEGREE, self.N_COLOR_NEURONS, self.N_COLOR_LAYERS = DIR_SH_ENCODING_DEGREE, N_COLOR_NEURONS, N_COLOR_LAYERS
         dev = torch.device(device)
         self.center = torch.tensor([self.CENTER], dtype=torch.float32, device=dev)
         self.xyz_min = -torch.ones(1, 3, device=dev) * SCALE

@@ -14,7 +14,7 @@ import torch
 
 from .samplers import RandomSequentialSampler
 
-__all__ = ['RayBatch', 'RayCollection', 'RayPoolSampler', 'rays_of_view']
+__all__ = ['compute_all_rays', 'RayBatch', 'RayCollection', 'RayPoolSampler', 'rays_of_view']
 
 _RAY_FIELDS = ('origin', 'direction', 'view_direction', 'rgb', 'alpha', 'depth', 'timestamp')
 
@@ -129,6 +129,20 @@ def rays_of_view(camera, c2w: np.ndarray, rgb: torch.Tensor | None = None, alpha
     ts = None if timestamp is None else torch.full((camera.width * camera.height, 1), float(timestamp), device=r['origin'].device)
     return RayBatch(origin=r['origin'], direction=r['direction'], view_direction=r['view_direction'], rgb=flat(rgb), alpha=flat(alpha),
                     depth=flat(depth), timestamp=ts)
+
+
+def compute_all_rays(views, store_on_cpu: bool = False, as_ray_collection: bool = False, device='cuda'):
+    """BaseDataset.compute_all_rays / precompute_rays (src/Datasets/Base.py:172-216): the rays of every view of a split, generated on the
+    device (C ABI group 5), concatenated into one RayBatch -- optionally parked in host memory -- or a RayCollection that remembers the
+    per-view ray counts.  `views`: iterable of dicts with the View fields the reference reads: camera, c2w and optionally rgb, alpha,
+    depth ((C, H, W) tensors) and timestamp."""
+    batches, counts = [], []
+    for view in views:
+        batch = rays_of_view(view['camera'], view['c2w'], view.get('rgb'), view.get('alpha'), view.get('depth'), view.get('timestamp'), device=device)
+        counts.append(len(batch))
+        batches.append(batch.cpu() if store_on_cpu else batch)
+    rays = RayBatch.cat(batches)
+    return RayCollection(rays, tuple(counts)) if as_ray_collection else rays
 
 
 class RayPoolSampler:

@@ -13,6 +13,7 @@ Vectors produced (reference symbol -> fixture):
   LRDecayPolicy, apply_background_color, RandomSequentialSampler    -> misc.npz
   NeRFBlock.forward / NeRFRayRenderingComponent.forward (tiny model) -> nerf_render.npz         (a6, a10)
   Gaussians.densify_and_prune / add_densification_stats / as_ply_dict, adam_utils -> gs_densify.npz (8f rank 3, 4)
+  GaussianSplattingModel.save after bake_activations                 -> gs_reference_checkpoint.pt (8f rank 4)
 """
 import importlib.util
 import math
@@ -362,6 +363,27 @@ def make_gs_densify():
                 sorted_rotations_exp_avg_sq=gs.optimizer.state[sorted_params['rotations']]['exp_avg_sq'].numpy().copy())
     gs.reset_opacities()
     blob['reset_opacities'] = gs.optimizer.param_groups[3]['params'][0].detach().numpy().copy()
+    # ---------------------------------------------------------------- checkpoint written by the reference itself (Base/Model.py:103-111)
+    # a small trained-and-baked 3DGS model: bake_activations (Model.py:248-273) needs the Morton extension for the final reordering, which is
+    # absent here -> identity order stand-in (the ORDER is not what this fixture pins; keys, activations and baked covariances are)
+    from Methods.GaussianSplatting import Model as gs_model_module
+    from Methods.GaussianSplatting.Model import GaussianSplattingModel
+    Framework.config.MODEL = Framework.ConfigWrapper.fromDict({})
+    gs_model_module.morton_encode = lambda positions: torch.arange(positions.shape[0])
+    model = GaussianSplattingModel('golden').build()
+    n_small = 48
+    for a in names.values():
+        setattr(model.gaussians, a, torch.nn.Parameter(getattr(gs, a).detach()[:n_small].clone()))
+    model.gaussians.optimizer = torch.optim.Adam([{'params': [getattr(model.gaussians, a)], 'name': n} for n, a in names.items()], lr=0.0)
+    model.gaussians.densification_gradient_accum = torch.zeros(n_small, 1)
+    model.gaussians.n_observations = torch.zeros(n_small, 1, dtype=torch.int32)
+    blob['ckpt_raw_opacities'] = model.gaussians._opacities.detach().numpy().copy()
+    model.gaussians.bake_activations()
+    model.num_iterations_trained = 30000
+    model.creation_date = '2026-01-01-00-00-00'
+    model.output_directory = Path('output/GaussianSplatting/golden_2026-01-01-00-00-00')
+    model.save(OUT / 'gs_reference_checkpoint.pt')
+    print('gs_reference_checkpoint.pt:', (OUT / 'gs_reference_checkpoint.pt').stat().st_size, 'B;', model.gaussians._positions.shape[0], 'Gaussians')
     np.savez_compressed(OUT / 'gs_densify.npz', **blob)
     print('gs_densify.npz:', (OUT / 'gs_densify.npz').stat().st_size, 'B; rows', P, '->', n_now, '; split noise rows', noise_log[0].shape[0])
 
