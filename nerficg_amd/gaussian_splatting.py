@@ -356,13 +356,23 @@ def render_image_training(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np.
 
 
 @torch.no_grad()
-def render_image_inference(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np.ndarray, scale_modifier: float = 1.0, to_chw: bool = False):
-    """GaussianSplatting/Renderer.py:89-155 with the fused SH / covariance paths (USE_FUSED_* = True, the shipped defaults)."""
+def render_image_inference(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np.ndarray, scale_modifier: float = 1.0, to_chw: bool = False,
+                           use_baked_covariance: bool = True):
+    """GaussianSplatting/Renderer.py:89-155 with the fused SH path (USE_FUSED_SH_CONVERSION = True, the shipped default); a baked model
+    (trained checkpoint, Model.py:248-273) is rasterized from its baked covariances like the reference's USE_BAKED_COVARIANCE branch
+    (Renderer.py:129-139), everything else through the in-kernel covariance computation."""
     from .diff_gaussian_rasterization import GaussianRasterizer
     positions = gaussians.get_positions
     rasterizer = GaussianRasterizer(make_raster_settings(cam, c2w, gaussians.active_sh_degree, scale_modifier, positions.device))
-    image, _ = rasterizer(means3D=positions, means2D=torch.empty_like(positions), shs=gaussians.get_features,
-                          opacities=gaussians.get_opacities, scales=gaussians.get_scales, rotations=gaussians.get_rotations)
+    covariances = gaussians.get_baked_covariances if (use_baked_covariance and gaussians.baked) else None
+    if covariances is not None and covariances.shape[0] != positions.shape[0]:
+        covariances = None  # "Baked covariance requested but not available"
+    if covariances is not None:
+        image, _ = rasterizer(means3D=positions, means2D=torch.empty_like(positions), shs=gaussians.get_features, opacities=gaussians.get_opacities,
+                              cov3D_precomp=covariances)
+    else:
+        image, _ = rasterizer(means3D=positions, means2D=torch.empty_like(positions), shs=gaussians.get_features,
+                              opacities=gaussians.get_opacities, scales=gaussians.get_scales, rotations=gaussians.get_rotations)
     image.clamp_(0.0, 1.0)
     return {'rgb': image if to_chw else image.permute(1, 2, 0)}
 
