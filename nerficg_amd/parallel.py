@@ -6,6 +6,10 @@ The reference has no working multi-GPU path: its DataParallel 
 
   * rays / image tiles   -- independent units.  Inference: every rank renders a contiguous range of 8x8-pixel tiles (or its own
                             views); NO data-path collective, only an optional all-gather of the finished pixels.
+  * 3DGS training views  -- view-parallel: every rank rasterizes ANOTHER training view against replicated Gaussians; a Gaussian's gradient is
+                            non-zero only on ranks that saw it, so the reduction moves only the rows visible on at least one rank
+                            (sparse_allreduce_gradients); densification statistics are summed when densification is due and
+                            densify_and_prune runs redundantly on every rank from identically seeded noise.
   * training rays        -- rank r takes ray_ids[r::world] of the batch every rank draws from the same seeded permutation
                             (src/Optim/Samplers/utils.py:8-34), so the global ray set is bit-identical to the single-GPU run;
                             after backward the encoding / MLP (InstantNGP) or Gaussian (3DGS) gradients are summed with ONE
@@ -21,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ['init_distributed', 'world_info', 'shard_ray_ids', 'shard_range', 'allreduce_flat', 'allreduce_gradients',
-           'all_gather_pixels', 'broadcast_parameters']
+           'all_gather_pixels', 'broadcast_parameters', 'sparse_allreduce_gradients', 'allreduce_densification_stats', 'synchronized_noise']
 
 
 def init_distributed(backend: str | None = None, device: torch.device | None = None) -> tuple[int, int]:
@@ -139,3 +143,52 @@ def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0) -> None:
         return
     for p in params:
         dist.broadcast(p.data if isinstance(p, torch.nn.Parameter) else p, src)
+
+
+def sparse_allreduce_gradients(params: Iterable[torch.nn.Parameter], visible: torch.Tensor, average: bool = True) -> int:
+    """View-parallel 3DGS: sums (averages) the per-Gaussian gradients of `params` (each (P, ...)) over all ranks, moving only
+    the rows that are visible on at least one rank.  `visible`: this rank's (P,) boolean mask (radii > 0); rows outside it must have zero
+    gradient here (the rasterizer backward guarantees that).  Protocol: one all-reduce (max) of the byte mask -> the same ascending
+    union index list on every rank -> the union rows of all tensors packed into ONE flat buffer -> reduce-scatter + all-gather ->
+    unpack.  Payload: n_union x 236 B instead of P x 236 B (59 floats per Gaussian).  Returns n_union."""
+    rank, world = world_info()
+    params = [p for p in params if p.grad is not None]
+    if world == 1 or not params:
+        return int(visible.sum().item()) if visible is not None else 0
+    P = visible.shape[0]
+    union = visible.to(torch.uint8).contiguous()
+    dist.all_reduce(union, op=dist.ReduceOp.MAX)
+    idx = torch.nonzero(union, as_tuple=False).flatten()
+    n = idx.numel()
+    if n == 0:
+        return 0
+    rows = []
+    for p in params:
+        if p.grad.shape[0] != P:
+            raise RuntimeError(f'sparse_allreduce_gradients: gradient with {p.grad.shape[0]} rows, visibility mask has {P}')
+        rows.append(p.grad.reshape(P, -1))
+    packed = torch.cat([r[idx] for r in rows], dim=1).contiguous()  # (n_union, 59)
+    allreduce_flat(packed.view(-1), average)
+    off = 0
+    for r in rows:
+        w = r.shape[1]
+        r[idx] = packed[:, off:off + w]
+        off += w
+    return n
+
+
+def allreduce_densification_stats(gaussians) -> None:
+    """Sums densification_gradient_accum / n_observations (GaussianSplatting/Model.py:243-246) over the ranks; call right before
+    densify_and_prune so that every rank classifies from the statistics of ALL views since the last densification."""
+    rank, world = world_info()
+    if world == 1:
+        return
+    dist.all_reduce(gaussians.densification_gradient_accum, op=dist.ReduceOp.SUM)
+    dist.all_reduce(gaussians.n_observations, op=dist.ReduceOp.SUM)
+
+
+def synchronized_noise(n_rows: int, seed: int, device) -> torch.Tensor:
+    """(n_rows, 3) standard-normal draws that are identical on every rank (host generator, then one upload): the `noise` argument of
+    Gaussians.densify_and_prune when the model is replicated -- every rank then performs the same split (Model.py:196-198)."""
+    g = torch.Generator().manual_seed(int(seed))
+    return torch.randn((n_rows, 3), generator=g, dtype=torch.float32).to(device)

@@ -94,3 +94,40 @@ def test_flat_allreduce_and_ragged_pixel_gather():
     exp = [i * 3.0 for i in range(11)]
     assert out[0][0] == exp and out[1][0] == exp
     assert out[0][1] == [[0.0, 0.0]] * 3 + [[1.0, 1.0]] * 4 == out[1][1]
+
+
+def _t_sparse_reduce(rank, world):
+    """View-parallel 3DGS: each rank 'sees' another subset of 500 Gaussians; sparse reduction == dense all-reduce, rows seen by nobody stay 0."""
+    from types import SimpleNamespace
+    from nerficg_amd import parallel
+    g = torch.Generator().manual_seed(100 + rank)
+    P = 500
+    visible = torch.rand(P, generator=g) < (0.3 if rank == 0 else 0.2)
+    shapes = [(P, 3), (P, 1, 3), (P, 15, 3), (P, 1), (P, 3), (P, 4)]
+    params = []
+    for s in shapes:
+        p = torch.nn.Parameter(torch.zeros(s))
+        p.grad = torch.randn(s, generator=g) * visible.view(-1, *([1] * (len(s) - 1)))
+        params.append(p)
+    dense = [p.grad.clone() for p in params]
+    for d in dense:
+        dist.all_reduce(d)
+        d.div_(world)
+    n_union = parallel.sparse_allreduce_gradients(params, visible, average=True)
+    err = max(float((p.grad - d).abs().max()) for p, d in zip(params, dense))
+    u = visible.to(torch.uint8)
+    dist.all_reduce(u, op=dist.ReduceOp.MAX)
+    untouched = max(float(p.grad[u == 0].abs().max()) for p in params)
+    stats = SimpleNamespace(densification_gradient_accum=torch.full((P, 1), float(rank + 1)), n_observations=torch.full((P, 1), rank + 2, dtype=torch.int32))
+    parallel.allreduce_densification_stats(stats)
+    noise = parallel.synchronized_noise(7, seed=5, device='cpu')
+    return err, untouched, n_union, int(u.sum()), float(stats.densification_gradient_accum[3, 0]), int(stats.n_observations[3, 0]), noise.tolist()
+
+
+def test_sparse_gaussian_gradient_reduction_equals_dense_allreduce():
+    out = _run(_t_sparse_reduce)
+    for r in (0, 1):
+        err, untouched, n_union, n_mask, acc, nobs, _ = out[r]
+        assert err < 1e-6 and untouched == 0.0 and n_union == n_mask and 0 < n_union < 500
+        assert acc == 3.0 and nobs == 5
+    assert out[0][6] == out[1][6]  # identical split noise on every rank
