@@ -173,6 +173,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_table_rsrc(const void* ta
 // differ only in the low bits unless x crosses a power-of-two boundary), so one 16-byte aligned load usually returns both
 // (3 out of 4 positions).  The texture-cache access rate (one line per clock per CU), not bandwidth, bounds the encoding:
 // 4 wide loads + a predicated narrow load for the straddling quarter = 5 accesses per level instead of 8.
+// f += w * (fp16 pair) in two v_fma_mix_f32 (f32 FMA reading its fp16 operand in place): the same arithmetic as convert + fmaf
+// without the 16 conversions per level
+__device__ __forceinline__ void fma_half2(float w, uint32_t packed, float& f0, float& f1) {
+#if defined(NRC_NO_FMA_MIX)
+    const __half2 hv = *reinterpret_cast<const __half2*>(&packed);
+    const float2 t = __half22float2(hv);
+    f0 = fmaf(w, t.x, f0);
+    f1 = fmaf(w, t.y, f1);
+#else
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(f0) : "v"(w), "v"(packed));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(f1) : "v"(w), "v"(packed));
+#endif
+}
 __device__ __forceinline__ uint32_t pick4(const uint4& q, uint32_t i) {
     const uint32_t lo = (i & 1) ? q.y : q.x, hi = (i & 1) ? q.w : q.z;
     return (i & 2) ? hi : lo;
@@ -196,12 +209,62 @@ __device__ __forceinline__ void grid_level_features(__amdgpu_buffer_rsrc_t rsrc,
     }
     f0 = 0.f; f1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const __half2 hv = *reinterpret_cast<const __half2*>(&v[k]);
-        const float2 t = __half22float2(hv);
-        f0 = fmaf(c.w[k], t.x, f0);
-        f1 = fmaf(c.w[k], t.y, f1);
+    for (int k = 0; k < 8; k++) fma_half2(c.w[k], v[k], f0, f1);
+}
+
+// Hashed levels: both x-neighbours of ALL four (y, z) pairs straddle or not together -- (x ^ h) and ((x + 1) ^ h) differ by x ^ (x + 1),
+// which does not depend on h.  One predicate, one predicated region for the four fix-up loads.
+__device__ __forceinline__ void grid_level_features_hashed(__amdgpu_buffer_rsrc_t rsrc, const Corner8& c, float& f0, float& f1) {
+    uint32_t v[8];
+    uint4 quad[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (c.e[2 * p] & ~3u) << 2, 0, 0);
+        quad[p] = make_uint4(raw[0], raw[1], raw[2], raw[3]);
     }
+    const bool straddle = ((c.e[0] ^ c.e[1]) & ~3u) != 0u;
+    uint32_t fix[4] = {0u, 0u, 0u, 0u};
+    if (straddle) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) fix[p] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, c.e[2 * p + 1] << 2, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        v[2 * p] = pick4(quad[p], c.e[2 * p] & 3u);
+        const uint32_t other = pick4(quad[p], c.e[2 * p + 1] & 3u);
+        v[2 * p + 1] = straddle ? fix[p] : other;
+    }
+    f0 = 0.f; f1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) fma_half2(c.w[k], v[k], f0, f1);
+}
+// Hashed levels, 8-byte variant: the aligned pair {e0 & ~1, e0 | 1} holds both neighbours whenever x is even; odd x (one predicate for
+// all four pairs, see above) fetches the partner with a 4-byte load.  6 instead of 5 line lookups per sample and level, half the
+// returned bytes, a quarter of the select instructions.
+__device__ __forceinline__ void grid_level_features_pair(__amdgpu_buffer_rsrc_t rsrc, const Corner8& c, float& f0, float& f1) {
+    uint32_t v[8];
+    uint2 pr[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (c.e[2 * p] & ~1u) << 2, 0, 0);
+        pr[p] = make_uint2(raw[0], raw[1]);
+    }
+    const bool apart = (c.e[0] ^ c.e[1]) != 1u;
+    uint32_t fix[4] = {0u, 0u, 0u, 0u};
+    if (apart) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) fix[p] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, c.e[2 * p + 1] << 2, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const bool odd = (c.e[2 * p] & 1u) != 0u;
+        v[2 * p] = odd ? pr[p].y : pr[p].x;
+        const uint32_t other = odd ? pr[p].x : pr[p].y;
+        v[2 * p + 1] = apart ? fix[p] : other;
+    }
+    f0 = 0.f; f1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) fma_half2(c.w[k], v[k], f0, f1);
 }
 
 // dense (coarse) levels: the lanes of a wave share a handful of cache lines, so the cost of a gather is its data return, not its
@@ -212,12 +275,7 @@ __device__ __forceinline__ void grid_level_features_narrow(__amdgpu_buffer_rsrc_
     for (int k = 0; k < 8; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, c.e[k] << 2, 0, 0);
     f0 = 0.f; f1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const __half2 hv = *reinterpret_cast<const __half2*>(&v[k]);
-        const float2 t = __half22float2(hv);
-        f0 = fmaf(c.w[k], t.x, f0);
-        f1 = fmaf(c.w[k], t.y, f1);
-    }
+    for (int k = 0; k < 8; k++) fma_half2(c.w[k], v[k], f0, f1);
 }
 
 // ---- SH degree 4 (16 coefficients) of a direction in [-1,1]^3 ------------------------------------------------------

@@ -226,7 +226,7 @@ __device__ __forceinline__ void fetch_dir(const QueryIn& in, int64_t i, float& d
 // channels (measured: 0.262 ms vs 0.22 ms per 2 Mi samples).  One lane per sample, all 16 levels.
 template <int SRC>
 __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ table, GridCfg g,
-                                                         uint4* __restrict__ feat, int narrow_levels) {
+                                                         uint4* __restrict__ feat, int narrow_levels, int hashed_mode) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     float px, py, pz;
@@ -246,6 +246,8 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
                 if (g.hashed[level]) grid_corners_u<true>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
                 else grid_corners_u<false>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
                 if (level < narrow_levels) grid_level_features_narrow(trs, c, f0, f1);
+                else if (g.hashed[level] && hashed_mode == 1) grid_level_features_hashed(trs, c, f0, f1);
+                else if (g.hashed[level] && hashed_mode == 2) grid_level_features_pair(trs, c, f0, f1);
                 else grid_level_features(trs, c, f0, f1);
                 const __half2 h = __floats2half2_rn(f0, f1);
                 v[q] = *reinterpret_cast<const uint32_t*>(&h);
@@ -519,7 +521,9 @@ static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void
     int narrow = 0;
     if (narrow_env >= 0) narrow = narrow_env;
     else while (narrow < NRC_MAX_LEVELS && !g.hashed[narrow] && g.size[narrow] > 8) narrow++;
-    hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat, narrow);
+    static const int hashed_mode = [] { const char* e = getenv("NRC_ENC_HASHED"); return e ? atoi(e) : 1; }();
+    hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat, narrow,
+                       hashed_mode);
 }
 
 static int mlp_tiles_per_wave() {
