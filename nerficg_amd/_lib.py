@@ -6,13 +6,14 @@ There is NO CPU fallback: if the library is missing or a GPU op is called withou
 from __future__ import annotations
 
 import ctypes
+import os
 import re
 from functools import lru_cache
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 HEADER = PKG.parent / 'include' / 'nerficg_hip.h'
-LIB_PATH = PKG / 'lib' / 'libnerficg_hip.so'
+LIB_PATH = Path(os.environ['NRC_LIB_PATH']) if os.environ.get('NRC_LIB_PATH') else PKG / 'lib' / 'libnerficg_hip.so'  # override: A/B runs of two builds
 
 ERRORS = {0: 'NRC_OK', -1: 'NRC_ERR_INVALID', -2: 'NRC_ERR_LAUNCH', -3: 'NRC_ERR_UNSUPPORTED'}
 

@@ -625,21 +625,52 @@ __device__ __forceinline__ int block_compact(bool flag, int* s_wcnt, int* n_out)
     return off + __popcll(m & ((1ull << lane) - 1ull));
 }
 
+// Staging of one batch for both render kernels: thread t holds entry t of the batch (flags = bit q set when the alpha >= 1/255 ellipse box
+// of its Gaussian reaches quadrant q of the tile).  Builds, per quadrant, the ascending list of batch entries that reach it --
+// every wave then walks ONLY its own list: no per-step box test, no skipped steps (a listed pair used to cost a wave-uniform box test,
+// and 37 % of the steps of a wave were pairs that miss its quadrant).  Returns the length of the calling wave's list.
+__device__ __forceinline__ int quadrant_lists(unsigned flags, uint8_t (*s_list)[BATCH], int (*s_qcnt)[4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long m[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) m[q] = __ballot((flags >> q) & 1u);
+    if (lane < 4) s_qcnt[wave][lane] = __popcll(lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3]);
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const int c = s_qcnt[w][q]; tot += c; if (w < wave) off += c; }
+        if ((flags >> q) & 1u) s_list[q][off + __popcll(m[q] & below)] = (uint8_t)threadIdx.x;
+        if (q == wave) mine = tot;
+    }
+    __syncthreads();
+    return mine;
+}
+__device__ __forceinline__ unsigned quadrant_flags(const float2& xy, const float2& ext, float tx0, float ty0) {
+    unsigned f = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) f |= (unsigned)box_hits(xy, ext, tx0 + (float)((q & 1) * 8), ty0 + (float)((q >> 1) * 8), 7.f) << q;
+    return f;
+}
+
 __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
                                                 const float* __restrict__ points_xy, const float* __restrict__ conic_opacity,
                                                 const float* __restrict__ rgb, float bg0, float bg1, float bg2, float* __restrict__ out_color,
                                                 uint32_t* __restrict__ n_contrib, float* __restrict__ final_T) {
-    __shared__ float2 s_xy[BATCH], s_ext[BATCH];
+    __shared__ float2 s_xy[BATCH];
     __shared__ float4 s_co[BATCH];
     __shared__ float s_rgb[BATCH * 3];
-    __shared__ uint32_t s_pos[BATCH];
-    __shared__ int s_wcnt[4];
+    __shared__ uint8_t s_list[4][BATCH];
+    __shared__ int s_qcnt[4][4];
     const int tile = blockIdx.y * cam.gx + blockIdx.x;
     const int px = blockIdx.x * TILE + tile_px(threadIdx.x), py = blockIdx.y * TILE + tile_py(threadIdx.x);
     const bool inside = px < cam.W && py < cam.H;
     const float fx = (float)px, fy = (float)py;
     const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
-    const float qx0 = tx0 + (float)(((threadIdx.x >> 6) & 1u) * 8u), qy0 = ty0 + (float)((threadIdx.x >> 7) * 8u);  // this wave's quadrant
+    const int wave = threadIdx.x >> 6;  // = quadrant (tile_px / tile_py)
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
@@ -647,29 +678,26 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
     for (uint32_t base = r0; base < r1; base += BATCH) {
         if (__syncthreads_count(done) == 256) break;
         const uint32_t k = base + threadIdx.x;
-        float2 xy = make_float2(0.f, 0.f), ext = make_float2(-1.f, -1.f);
-        float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
-        int id = 0;
-        bool keep = false;
+        unsigned flags = 0;
         if (k < r1) {
-            id = point_list[k];
-            xy = make_float2(points_xy[2 * id], points_xy[2 * id + 1]);
-            co = *reinterpret_cast<const float4*>(conic_opacity + 4 * id);
-            ext = splat_extent(co);
-            keep = box_hits(xy, ext, tx0, ty0, (float)(TILE - 1));
+            const int id = point_list[k];
+            const float2 xy = make_float2(points_xy[2 * id], points_xy[2 * id + 1]);
+            const float4 co = *reinterpret_cast<const float4*>(conic_opacity + 4 * id);
+            flags = quadrant_flags(xy, splat_extent(co), tx0, ty0);
+            if (flags) {
+                s_xy[threadIdx.x] = xy; s_co[threadIdx.x] = co;
+                s_rgb[3 * threadIdx.x] = rgb[3 * id]; s_rgb[3 * threadIdx.x + 1] = rgb[3 * id + 1]; s_rgb[3 * threadIdx.x + 2] = rgb[3 * id + 2];
+            }
         }
-        int nb;
-        const int slot = block_compact(keep, s_wcnt, &nb);
-        if (keep) {
-            s_xy[slot] = xy; s_ext[slot] = ext; s_co[slot] = co; s_pos[slot] = k - r0;
-            s_rgb[3 * slot] = rgb[3 * id]; s_rgb[3 * slot + 1] = rgb[3 * id + 1]; s_rgb[3 * slot + 2] = rgb[3 * id + 2];
-        }
-        __syncthreads();
-        for (int j = 0; j < nb; j++) {
+        const int n_mine = quadrant_lists(flags, s_list, s_qcnt);
+        const uint32_t pos0 = base - r0 + 1u;  // contributor number of batch entry 0 = its position in the tile list + 1
+        int j_next = n_mine > 0 ? s_list[wave][0] : 0;
+        for (int jj = 0; jj < n_mine; jj++) {
             if (__ballot(!done) == 0ull) break;  // wave-uniform: every pixel of the quadrant is saturated
-            const float2 xy_j = s_xy[j];
-            if (!__builtin_amdgcn_readfirstlane((int)box_hits(xy_j, s_ext[j], qx0, qy0, 7.f))) continue;  // misses this wave's quadrant
+            const int j = __builtin_amdgcn_readfirstlane(j_next);
+            j_next = s_list[wave][min(jj + 1, n_mine - 1)];  // in flight while this entry is blended
             if (done) continue;
+            const float2 xy_j = s_xy[j];
             const float dx = xy_j.x - fx, dy = xy_j.y - fy;
             const float4 co_j = s_co[j];
             const float power = -0.5f * (co_j.x * dx * dx + co_j.z * dy * dy) - co_j.y * dx * dy;
@@ -680,7 +708,7 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
             if (test_T < 0.0001f) { done = true; continue; }
             C0 += s_rgb[3 * j] * alpha * T; C1 += s_rgb[3 * j + 1] * alpha * T; C2 += s_rgb[3 * j + 2] * alpha * T;
             T = test_T;
-            last = s_pos[j] + 1u;  // contributor number = position in the tile list + 1
+            last = pos0 + (uint32_t)j;
         }
         __syncthreads();
     }
@@ -712,16 +740,15 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
                                                    const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
                                                    const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D,
                                                    float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor) {
-    __shared__ int s_id[BATCH], s_pos[BATCH];
-    __shared__ float2 s_xy[BATCH], s_ext[BATCH];
+    __shared__ float2 s_xy[BATCH];
     __shared__ float4 s_co[BATCH];
     __shared__ float s_rgb[BATCH * 3];
     __shared__ float s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 4 waves, flushed once per batch
-    __shared__ int s_wcnt[4];
+    __shared__ uint8_t s_list[4][BATCH];
+    __shared__ int s_qcnt[4][4];
     const int tile = blockIdx.y * cam.gx + blockIdx.x;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // wave = quadrant
     const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
-    const float qx0 = tx0 + (float)(((threadIdx.x >> 6) & 1u) * 8u), qy0 = ty0 + (float)((threadIdx.x >> 7) * 8u);  // this wave's quadrant
     const int px = blockIdx.x * TILE + tile_px(threadIdx.x), py = blockIdx.y * TILE + tile_py(threadIdx.x);
     const bool inside = px < cam.W && py < cam.H;
     const float fx = (float)px, fy = (float)py;
@@ -747,36 +774,34 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
     if (lane == 0) atomicMax(&s_maxlast, wave_last);
     __syncthreads();
     const int n_eff = min(n_tile, s_maxlast);
-    // batches are taken from the END of the blended prefix: position p (0-based from the front) has contributor number p + 1
+    // batches are taken from the END of the blended prefix: position p (0-based from the front) has contributor number p + 1;
+    // batch entry t sits at position n_eff - 1 - done_cnt - t
     for (int done_cnt = 0; done_cnt < n_eff; done_cnt += BATCH) {
         __syncthreads();
         const int nb_raw = min(BATCH, n_eff - done_cnt);
 #pragma unroll
         for (int q = 0; q < 9; q++) s_acc[threadIdx.x][q] = 0.f;
-        // stage the batch, dropping the entries whose alpha >= 1/255 ellipse box misses the tile (see k_render)
-        float2 xy_l = make_float2(0.f, 0.f), ext_l = make_float2(-1.f, -1.f);
-        float4 co_l = make_float4(0.f, 0.f, 0.f, 0.f);
+        // stage the batch; per quadrant the list of entries whose alpha >= 1/255 ellipse box reaches it (see k_render)
         int id_l = 0;
-        bool keep = false;
+        unsigned flags = 0;
+        const int pos_top = n_eff - 1 - done_cnt;  // list position of batch entry 0
         if ((int)threadIdx.x < nb_raw) {
-            id_l = point_list[r0 + n_eff - 1 - done_cnt - threadIdx.x];
-            xy_l = make_float2(points_xy[2 * id_l], points_xy[2 * id_l + 1]);
-            co_l = *reinterpret_cast<const float4*>(conic_opacity + 4 * id_l);
-            ext_l = splat_extent(co_l);
-            keep = box_hits(xy_l, ext_l, tx0, ty0, (float)(TILE - 1));
+            id_l = point_list[r0 + pos_top - threadIdx.x];
+            const float2 xy_l = make_float2(points_xy[2 * id_l], points_xy[2 * id_l + 1]);
+            const float4 co_l = *reinterpret_cast<const float4*>(conic_opacity + 4 * id_l);
+            flags = quadrant_flags(xy_l, splat_extent(co_l), tx0, ty0);
+            if (flags) {
+                s_xy[threadIdx.x] = xy_l; s_co[threadIdx.x] = co_l;
+                s_rgb[3 * threadIdx.x] = rgb[3 * id_l]; s_rgb[3 * threadIdx.x + 1] = rgb[3 * id_l + 1]; s_rgb[3 * threadIdx.x + 2] = rgb[3 * id_l + 2];
+            }
         }
-        int nb;
-        const int slot = block_compact(keep, s_wcnt, &nb);
-        if (keep) {
-            s_id[slot] = id_l; s_pos[slot] = n_eff - 1 - done_cnt - (int)threadIdx.x;  // index from the front of the list
-            s_xy[slot] = xy_l; s_ext[slot] = ext_l; s_co[slot] = co_l;
-            s_rgb[3 * slot] = rgb[3 * id_l]; s_rgb[3 * slot + 1] = rgb[3 * id_l + 1]; s_rgb[3 * slot + 2] = rgb[3 * id_l + 2];
-        }
-        __syncthreads();
-        for (int j = 0; j < nb; j++) {
-            const int pos = s_pos[j];
+        const int n_mine = quadrant_lists(flags, s_list, s_qcnt);
+        int j_next = n_mine > 0 ? s_list[wave][0] : 0;
+        for (int jj = 0; jj < n_mine; jj++) {
+            const int j = __builtin_amdgcn_readfirstlane(j_next);
+            j_next = s_list[wave][min(jj + 1, n_mine - 1)];
+            const int pos = pos_top - j;
             if (pos >= wave_last) continue;  // wave-uniform
-            if (!__builtin_amdgcn_readfirstlane((int)box_hits(s_xy[j], s_ext[j], qx0, qy0, 7.f))) continue;  // misses this wave's quadrant
             bool active = inside && pos < last;
             float G = 0.f, alpha = 0.f, dx = 0.f, dy = 0.f;
             float4 co = s_co[j];
@@ -826,13 +851,13 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             }
         }
         __syncthreads();
-        if ((int)threadIdx.x < nb) {
+        if (flags) {  // the thread that staged the entry flushes it
             const float* a = s_acc[threadIdx.x];
             bool any = false;
 #pragma unroll
             for (int q = 0; q < 9; q++) any = any || (a[q] != 0.f);
             if (any) {
-                const int id = s_id[threadIdx.x];
+                const int id = id_l;
                 atomicAdd(dL_dcolor + 3 * id, a[0]); atomicAdd(dL_dcolor + 3 * id + 1, a[1]); atomicAdd(dL_dcolor + 3 * id + 2, a[2]);
                 atomicAdd(dL_dmean2D + 3 * id, a[3]); atomicAdd(dL_dmean2D + 3 * id + 1, a[4]);
                 atomicAdd(dL_dconic + 4 * id, a[5]); atomicAdd(dL_dconic + 4 * id + 1, a[6]); atomicAdd(dL_dconic + 4 * id + 3, a[7]);
