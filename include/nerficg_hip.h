@@ -147,10 +147,14 @@ int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int3
                       const void* save_acts, float loss_scale, float* grad_weights, float* d_in, int32_t d_in_pair_major,
                       nrc_stream_t stream);
 /* hash-grid backward: grad_table (entries,2) f32 += trilinear scatter of d_features f32, (M, 2*n_levels) or pair-major
- * [n_levels][M][2] (caller zeroes grad_table) */
+ * [n_levels][M][2] (caller zeroes grad_table).  workspace: optional (NULL allowed), nrc_grid_backward_ws_bytes(...) bytes, 16-byte
+ * aligned -- with it (and pair-major gradients, M >= 16384) the hashed levels are split into per-slice record buckets once and
+ * accumulated in LDS by one workgroup per slice instead of by atomics */
+int64_t nrc_grid_backward_ws_bytes(int64_t M, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
+                                   float per_level_scale);
 int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
                       int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table,
-                      nrc_stream_t stream);
+                      void* workspace, nrc_stream_t stream);
 /* query_model (src/Methods/InstantNGP/Renderer.py:48-53) for TRAINING as one forward and one backward call instead of ~55 small
  * launches: world positions xyzs (M,3) / directions dirs (M,3) f32 -> sigmas (M), rgbs (M,3) f32 (what VolumeRenderer consumes), and
  * dL/dsigmas, dL/drgbs -> gradients of both parameter vectors (ACCUMULATED; caller zeroes; layout of the tinycudann modules).

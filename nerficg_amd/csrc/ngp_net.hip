@@ -1173,6 +1173,196 @@ __global__ void __launch_bounds__(OWN_THREADS) k_grid_bwd_owned_q(const float* _
     }
 }
 
+// ---- bucketed ownership ("multisplit"): split once, accumulate once, in fixed point ------------------------------------------------
+// The ownership kernels above make every slice owner scan ALL samples (32 x redundant index arithmetic, and every owner streams all
+// positions and gradients through L2: 1.3 GB per backward).  Here the (sample, (y,z) corner pair) items are first split by the slice
+// that owns them -- on a hashed level the slice, index >> 13, depends only on the (y, z) hash, so both x-neighbours of a pair live in
+// the same slice:
+//   k_gb_split<false>  per-bucket counts (LDS histogram per 1024 samples, one global atomic per bucket and workgroup) and the largest
+//                      |gradient| of every level
+//   k_gb_scan          exclusive scan of the <= 1024 bucket counts; fixed-point scale of every level
+//   k_gb_split<true>   16-byte self-contained records {two slice-local entries, wy wz g (2), wx} into the buckets (workgroups reserve their
+//                      runs with one atomic per bucket)
+//   k_gb_accumulate    one workgroup per bucket: its records (one contiguous read) into an 8 K-entry LDS slice, then a plain read-modify-
+//                      write flush.  The slice accumulates 64-bit FIXED POINT: LDS float atomics run at 0.32 lane-operations per clock
+//                      and CU on this chip, integer ones (32 or 64 bit) at 1.33 (tools/micro/lds_atomics.hip) -- with f32 atomics this
+//                      kernel took 380 us, 320 of them in ds_add_f32.  scale = 2^(62 - ceil log2 max|g| - ceil log2 (2 M + 1)): no
+//                      overflow whatever the collisions, LSB <= max|g| 2^-41 for M = 264 K, and the sums no longer depend on the order of
+//                      the atomics: the hashed levels' gradient is bit-reproducible.
+// (A first version with 4-byte (sample, pair) records still gathered positions / gradients per record -- spread over all samples, i.e.
+// the same lines again.)
+#define GB_MAX_BUCKETS 1024
+#define GB_ENTRIES 8192
+#define GB_SHIFT 13
+#define GB_HEADER_BYTES 16384
+struct BucketCfg { int n_levels; int level[NRC_MAX_LEVELS]; int bucket0[NRC_MAX_LEVELS + 1]; };
+struct GbHeader {
+    uint32_t counts[GB_MAX_BUCKETS], cursor[GB_MAX_BUCKETS], base[GB_MAX_BUCKETS];
+    uint32_t level_max[NRC_MAX_LEVELS];  // bit pattern of max |g| (non-negative floats order like their bits)
+    float level_scale[NRC_MAX_LEVELS];
+};
+static_assert(sizeof(GbHeader) <= GB_HEADER_BYTES, "header");
+
+template <bool WRITE>
+__global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, GridCfg g, BucketCfg bc,
+                                                          GbHeader* __restrict__ hd, uint4* __restrict__ records) {
+    __shared__ uint32_t hist[GB_MAX_BUCKETS], gbase[GB_MAX_BUCKETS], lmax[NRC_MAX_LEVELS];
+    const int nb = bc.bucket0[bc.n_levels];
+    for (int b = threadIdx.x; b < nb; b += OWN_THREADS) hist[b] = 0u;
+    if (threadIdx.x < NRC_MAX_LEVELS) lmax[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * OWN_THREADS + threadIdx.x;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (i < M) { px = x[3 * i]; py = x[3 * i + 1]; pz = x[3 * i + 2]; }
+    // visits the four (y, z) pairs of sample i on every bucketed level whose gradient is not zero
+    auto visit = [&](auto&& per_level, auto&& fn) {
+        if (i >= M) return;
+        for (int k = 0; k < bc.n_levels; k++) {
+            const int level = bc.level[k];
+            const float2 gf = reinterpret_cast<const float2*>(d_feat)[(int64_t)level * M + i];
+            if (gf.x == 0.f && gf.y == 0.f) continue;  // masked / terminated samples
+            per_level(k, gf);
+            const float scale = g.scale[level];
+            const uint32_t mask = g.size[level] - 1u;
+            const float fy = fmaf(scale, py, 0.5f), fz = fmaf(scale, pz, 0.5f);
+            const float fly = floorf(fy), flz = floorf(fz);
+            const uint32_t gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
+            const uint32_t ty[2] = {gy * 2654435761u, gy * 2654435761u + 2654435761u}, tz[2] = {gz * 805459861u, gz * 805459861u + 805459861u};
+            const int b0 = bc.bucket0[k];
+#pragma unroll
+            for (uint32_t pair = 0; pair < 4; pair++) {
+                const uint32_t yz = (ty[pair & 1] ^ tz[pair >> 1]) & mask;
+                fn(b0 + (int)(yz >> GB_SHIFT), pair, yz, scale, fy - fly, fz - flz, gf);
+            }
+        }
+    };
+    if constexpr (!WRITE) {
+        // largest |gradient| per level: wave maximum first (one LDS atomic per wave and level, not one per lane on the same address)
+        for (int k = 0; k < bc.n_levels; k++) {
+            float m = 0.f;
+            if (i < M) {
+                const float2 gf = reinterpret_cast<const float2*>(d_feat)[(int64_t)bc.level[k] * M + i];
+                m = fmaxf(fabsf(gf.x), fabsf(gf.y));
+                if (!(m == m)) m = 0.f;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+            if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&lmax[k], __float_as_uint(m));
+        }
+        visit([&](int, const float2&) {}, [&](int b, uint32_t, uint32_t, float, float, float, const float2&) { atomicAdd(&hist[b], 1u); });
+        __syncthreads();
+        for (int b = threadIdx.x; b < nb; b += OWN_THREADS)
+            if (hist[b]) atomicAdd(&hd->counts[b], hist[b]);
+        if ((int)threadIdx.x < bc.n_levels && lmax[threadIdx.x]) atomicMax(&hd->level_max[threadIdx.x], lmax[threadIdx.x]);
+    } else {
+        visit([&](int, const float2&) {}, [&](int b, uint32_t, uint32_t, float, float, float, const float2&) { atomicAdd(&hist[b], 1u); });
+        __syncthreads();
+        for (int b = threadIdx.x; b < nb; b += OWN_THREADS) {
+            gbase[b] = hist[b] ? atomicAdd(&hd->cursor[b], hist[b]) : 0u;
+            hist[b] = 0u;
+        }
+        __syncthreads();
+        visit([&](int, const float2&) {},
+              [&](int b, uint32_t pair, uint32_t yz, float scale, float wy1, float wz1, const float2& gf) {
+                  const float fx = fmaf(scale, px, 0.5f), flx = floorf(fx);
+                  const uint32_t gx = (uint32_t)(int32_t)flx;
+                  const float wyz = ((pair & 1u) ? wy1 : 1.f - wy1) * ((pair >> 1) ? wz1 : 1.f - wz1);
+                  const uint32_t e0 = (gx ^ yz) & (GB_ENTRIES - 1u), e1 = ((gx + 1u) ^ yz) & (GB_ENTRIES - 1u);
+                  records[gbase[b] + atomicAdd(&hist[b], 1u)] =
+                      make_uint4(e0 | (e1 << 16), __float_as_uint(wyz * gf.x), __float_as_uint(wyz * gf.y), __float_as_uint(fx - flx));
+              });
+    }
+}
+
+// counts -> base (exclusive), cursor = base; per level the power-of-two fixed-point scale
+__global__ void __launch_bounds__(GB_MAX_BUCKETS) k_gb_scan(GbHeader* __restrict__ hd, int nb, int n_levels, int64_t M) {
+    __shared__ uint32_t s[GB_MAX_BUCKETS];
+    const uint32_t v = (int)threadIdx.x < nb ? hd->counts[threadIdx.x] : 0u;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < GB_MAX_BUCKETS; d <<= 1) {
+        const uint32_t o = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += o;
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < nb) { hd->base[threadIdx.x] = s[threadIdx.x] - v; hd->cursor[threadIdx.x] = s[threadIdx.x] - v; }
+    if ((int)threadIdx.x < n_levels) {
+        const float m = __uint_as_float(hd->level_max[threadIdx.x]);
+        int e_max = 0, e_cnt = 0;
+        frexpf(m > 0.f && m < __builtin_inff() ? m : 1.f, &e_max);  // m < 2^e_max
+        frexpf((float)(2 * M + 1), &e_cnt);                         // 2 M + 1 <= 2^e_cnt (an entry receives at most 2 M values of <= m)
+        hd->level_scale[threadIdx.x] = ldexpf(1.f, 62 - e_max - e_cnt);
+    }
+}
+
+__global__ void __launch_bounds__(OWN_THREADS) k_gb_accumulate(GridCfg g, BucketCfg bc, const GbHeader* __restrict__ hd, const uint4* __restrict__ records,
+                                                               float* __restrict__ grad_table) {
+    extern __shared__ long long fix_acc[];  // [GB_ENTRIES][2]
+    int li = 0;
+    while (li + 1 < bc.n_levels && (int)blockIdx.x >= bc.bucket0[li + 1]) li++;
+    const int level = bc.level[li];
+    const uint32_t chunk = (uint32_t)((int)blockIdx.x - bc.bucket0[li]);
+    const uint32_t lo = g.offset[level] + chunk * GB_ENTRIES;
+    for (uint32_t j = threadIdx.x; j < 2 * GB_ENTRIES; j += OWN_THREADS) fix_acc[j] = 0ll;
+    __syncthreads();
+    const uint32_t n = hd->counts[blockIdx.x];
+    const uint4* rec = records + hd->base[blockIdx.x];
+    const float scale = hd->level_scale[li];
+    enum { UNR = 4 };
+    for (uint32_t k0 = threadIdx.x; k0 < n; k0 += OWN_THREADS * UNR) {
+        uint4 r[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const uint32_t k = k0 + u * OWN_THREADS;
+            r[u] = rec[k < n ? k : n - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            if (k0 + u * OWN_THREADS >= n) continue;
+            const uint32_t e0 = r[u].x & 0xffffu, e1 = r[u].x >> 16;
+            const float a = __uint_as_float(r[u].y), b = __uint_as_float(r[u].z), wx1 = __uint_as_float(r[u].w), wx0 = 1.f - wx1;
+            // power-of-two scale: the product is exact, the only rounding is to the fixed-point grid
+            atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e0]), (unsigned long long)__float2ll_rn(wx0 * a * scale));
+            atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e0 + 1]), (unsigned long long)__float2ll_rn(wx0 * b * scale));
+            atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e1]), (unsigned long long)__float2ll_rn(wx1 * a * scale));
+            atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e1 + 1]), (unsigned long long)__float2ll_rn(wx1 * b * scale));
+        }
+    }
+    __syncthreads();
+    const double inv = 1.0 / (double)scale;
+    float2* out = reinterpret_cast<float2*>(grad_table) + lo;
+    for (uint32_t j = threadIdx.x; j < GB_ENTRIES; j += OWN_THREADS) {
+        const long long a0 = fix_acc[2 * j], a1 = fix_acc[2 * j + 1];
+        if (a0 != 0ll || a1 != 0ll) {
+            float2 v = out[j];
+            v.x += (float)((double)a0 * inv); v.y += (float)((double)a1 * inv);
+            out[j] = v;
+        }
+    }
+}
+
+// which levels take the bucketed path: hashed, whole 8 K slices, x corners below the slice bits; the finest first, <= GB_MAX_BUCKETS
+static void pick_bucket_levels(const GridCfg& g, int n_levels, BucketCfg& bc, bool* is_bucketed) {
+    bc.n_levels = 0; bc.bucket0[0] = 0;
+    for (int l = 0; l < NRC_MAX_LEVELS; l++) is_bucketed[l] = false;
+    static const int max_lv = [] { const char* e = getenv("NRC_GB_LEVELS"); return e ? atoi(e) : NRC_MAX_LEVELS; }();
+    int first = n_levels, units = 0;
+    for (int l = n_levels - 1; l >= 0 && n_levels - l <= max_lv; l--) {
+        if (!g.hashed[l] || g.size[l] < (uint32_t)GB_ENTRIES || (g.size[l] % GB_ENTRIES) != 0u || g.res[l] + 1u >= (uint32_t)GB_ENTRIES) break;
+        const int c = (int)(g.size[l] / GB_ENTRIES);
+        if (units + c > GB_MAX_BUCKETS) break;
+        units += c;
+        first = l;
+    }
+    for (int l = first; l < n_levels; l++) {
+        is_bucketed[l] = true;
+        bc.level[bc.n_levels] = l;
+        bc.bucket0[bc.n_levels + 1] = bc.bucket0[bc.n_levels] + (int)(g.size[l] / GB_ENTRIES);
+        bc.n_levels++;
+    }
+}
+
 // ---- fused training query (InstantNGPRayRenderingComponent.query_model, Renderer.py:48-53, as one autograd node) ----------------
 // outputs of the two networks -> what the compositor consumes: sigma = exp(h0) (TruncExp forward, custom_functions.py:201-204),
 // rgb = the colour net's sigmoid outputs, both f32
@@ -1239,8 +1429,18 @@ int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int3
     return NRC_OK;
 }
 
+int64_t nrc_grid_backward_ws_bytes(int64_t M, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale) {
+    if (M < 0) return NRC_ERR_INVALID;
+    GridCfg g;
+    if (make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr) != NRC_OK) return NRC_ERR_INVALID;
+    BucketCfg bc; bool isb[NRC_MAX_LEVELS];
+    pick_bucket_levels(g, n_levels, bc, isb);
+    return GB_HEADER_BYTES + M * 64 * bc.n_levels + 256;  // four 16-byte records per sample and bucketed level
+}
+
 int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
-                      int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table, nrc_stream_t stream) {
+                      int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table, void* workspace,
+                      nrc_stream_t stream) {
     NRC_ENTER();
     if (M < 0 || !grad_table) return NRC_ERR_INVALID;
     if (M == 0) return NRC_OK;
@@ -1252,6 +1452,34 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
     // worth in atomics, plus a 128 KB slice flush per workgroup: below ~16 K samples the atomics are cheaper)
     static const bool allow_owned = [] { const char* e = getenv("NRC_GRID_BWD_OWNED"); return !(e && e[0] == '0'); }();
     const bool owned = allow_owned && d_features_pair_major && M >= 16384;
+    hipStream_t s = (hipStream_t)stream;
+    // bucketed ownership (needs the workspace): all hashed levels in four launches, the dense ones through the run-aggregated atomics
+    static const bool allow_buckets = [] { const char* e = getenv("NRC_GRID_BWD_BUCKETS"); return !(e && e[0] == '0'); }();
+    if (owned && allow_buckets && workspace && M < (int64_t(1) << 30)) {
+        BucketCfg bc; bool isb[NRC_MAX_LEVELS];
+        pick_bucket_levels(g, n_levels, bc, isb);
+        if (bc.n_levels > 0) {
+            LevelList rest; rest.n = 0;
+            for (int l = 0; l < n_levels; l++) if (!isb[l]) rest.level[rest.n++] = l;
+            if (rest.n > 0)
+                hipLaunchKernelGGL(k_grid_bwd, dim3((unsigned)nrc_cdiv(M, 256), rest.n), dim3(256), 0, s, x01, M, d_features, (int)d_features_pair_major, g,
+                                   (int)n_levels, rest, grad_table);
+            GbHeader* hd = reinterpret_cast<GbHeader*>(workspace);
+            uint4* records = reinterpret_cast<uint4*>(reinterpret_cast<char*>(workspace) + GB_HEADER_BYTES);
+            const int nb = bc.bucket0[bc.n_levels];
+            if (hipMemsetAsync(hd, 0, sizeof(GbHeader), s) != hipSuccess) return NRC_ERR_LAUNCH;
+            const dim3 sgrid((unsigned)nrc_cdiv(M, OWN_THREADS));
+            hipLaunchKernelGGL(k_gb_split<false>, sgrid, dim3(OWN_THREADS), 0, s, x01, M, d_features, g, bc, hd, records);
+            hipLaunchKernelGGL(k_gb_scan, dim3(1), dim3(GB_MAX_BUCKETS), 0, s, hd, nb, bc.n_levels, M);
+            hipLaunchKernelGGL(k_gb_split<true>, sgrid, dim3(OWN_THREADS), 0, s, x01, M, d_features, g, bc, hd, records);
+            static const hipError_t attr_b = hipFuncSetAttribute((const void*)k_gb_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, GB_ENTRIES * 16);
+            (void)attr_b;
+            hipLaunchKernelGGL(k_gb_accumulate, dim3((unsigned)nb), dim3(OWN_THREADS), GB_ENTRIES * 16, s, g, bc, (const GbHeader*)hd, (const uint4*)records,
+                               grad_table);
+            NRC_LAUNCH_CHECK();
+            return NRC_OK;
+        }
+    }
     LevelList ll; ll.n = 0;
     OwnedCfg oc; oc.n_levels = 0; oc.unit0[0] = 0;
     // Which hashed levels are owned: the FINEST ones, as many as give one workgroup per CU (256 slices = 8 levels at T = 2^19).  A
@@ -1276,7 +1504,6 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
             ll.level[ll.n++] = l;
         }
     }
-    hipStream_t s = (hipStream_t)stream;
     if (ll.n > 0)
         hipLaunchKernelGGL(k_grid_bwd, dim3((unsigned)nrc_cdiv(M, 256), ll.n), dim3(256), 0, s, x01, M, d_features, (int)d_features_pair_major, g,
                            (int)n_levels, ll, grad_table);
@@ -1357,7 +1584,9 @@ int nrc_ngp_train_query_backward(const float* dL_dsigmas, const float* dL_drgbs,
     hipLaunchKernelGGL(k_density_dout, g1, b1, 0, s, (const float*)d_in_c, (const float*)dh0, M, d_h16);
     rc = nrc_nwie_backward(M, density_weights_f16, 1, ACT_NONE, 16, d_h16, h_f16, 16, save_in_d, save_acts_d, loss_scale, grad_density_params, d_in_d, 1, stream);
     if (rc != NRC_OK) return rc;
-    rc = nrc_grid_backward(x01, M, d_in_d, 1, n_levels, log2_hashmap_size, base_resolution, per_level_scale, grad_density_params + n_density_mlp_params, stream);
+    void* grid_ws = (char*)d_in_d + M * 128;  // nrc_grid_backward_ws_bytes (all levels at most) behind the pair-major gradients
+    rc = nrc_grid_backward(x01, M, d_in_d, 1, n_levels, log2_hashmap_size, base_resolution, per_level_scale, grad_density_params + n_density_mlp_params,
+                           grid_ws, stream);
     if (rc != NRC_OK) return rc;
     NRC_LAUNCH_CHECK();
     return NRC_OK;
@@ -1365,7 +1594,7 @@ int nrc_ngp_train_query_backward(const float* dL_dsigmas, const float* dL_drgbs,
 
 int64_t nrc_ngp_train_query_scratch_bytes(int64_t M) {
     if (M < 0) return NRC_ERR_INVALID;
-    return (M * 8 + 255) / 256 * 256 + (M * 4 + 255) / 256 * 256 + M * 128 + M * 32 + M * 128 + 256;
+    return (M * 8 + 255) / 256 * 256 + (M * 4 + 255) / 256 * 256 + M * 128 + M * 32 + M * 128 + 256 + (16384 + M * 64 * NRC_MAX_LEVELS + 256);
 }
 
 }  // extern "C"

@@ -99,8 +99,10 @@ class _NWIEFunction(torch.autograd.Function):
         if module.encoding == 0:
             g = module.grid_cfg
             table_grad = grad_params[module.n_mlp_params:]
+            gws = torch.empty(int(lib.nrc_grid_backward_ws_bytes(m, g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']))),
+                              dtype=torch.uint8, device=dev)
             _lib.check(lib.nrc_grid_backward(_lib.ptr(xin), m, _lib.ptr(d_in), pair_major, g['n_levels'], g['log2_hashmap_size'],
-                                             g['base_resolution'], float(g['per_level_scale']), _lib.ptr(table_grad), st), 'grid_backward')
+                                             g['base_resolution'], float(g['per_level_scale']), _lib.ptr(table_grad), _lib.ptr(gws), st), 'grid_backward')
         elif ctx.x_requires_grad:
             # gradient w.r.t. the identity-encoded dims; the SH-encoded direction dims get zeros (view directions are data,
             # never optimised by the reference: Renderer.py:40 feeds rays.view_direction)

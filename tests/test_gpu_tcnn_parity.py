@@ -189,6 +189,39 @@ def test_density_network_backward_grid_and_mlp(density_net, m):
     assert np.count_nonzero(got_t) > 0 and np.array_equal(got_t == 0, g_table == 0) or np.mean((got_t == 0) != (g_table == 0)) < 1e-4
 
 
+@pytest.mark.parametrize('log2_t', [19, 15, 13])
+def test_grid_backward_bucketed_path_matches_atomics_and_is_reproducible(log2_t):
+    """C ABI: nrc_grid_backward with a workspace (hashed levels: per-slice record buckets, 64-bit fixed-point LDS accumulation) against the
+    same call without one (f32 atomics / scanning slice owners) and against oracle.grid_encode_bw; the bucketed levels' sums do not depend
+    on the order of the atomics, so two runs agree bit for bit there.  T = 2^13: one 8 K slice per hashed level; 2^15: four; 2^19: 64."""
+    from nerficg_amd import _lib
+    lib = _lib.load()
+    grid = dict(n_levels=16, log2_hashmap_size=log2_t, base_resolution=16, per_level_scale=PLS)
+    total, offsets, _, _ = oracle.grid_layout(**grid)
+    m = 40_000
+    rng = np.random.default_rng(log2_t)
+    x = rng.random((m, 3)).astype(np.float32)
+    x[:3000] = x[0] + rng.normal(size=(3000, 3)).astype(np.float32) * 1e-4  # a cluster: thousands of contributions to the same entries
+    x = np.clip(x, 0.0, 1.0).astype(np.float32)
+    d = (rng.normal(size=(16, m, 2)) * 10.0 ** rng.integers(-6, 0, size=(16, m, 1))).astype(np.float32)
+    d[:, rng.random(m) < 0.3] = 0.0  # masked samples
+    tx, td = T(x), T(d)
+    ws = torch.empty(int(lib.nrc_grid_backward_ws_bytes(m, 16, log2_t, 16, PLS)), dtype=torch.uint8, device=DEV)
+
+    def run(workspace):
+        g = torch.zeros(total, 2, device=DEV)
+        _lib.check(lib.nrc_grid_backward(_lib.ptr(tx), m, _lib.ptr(td), 1, 16, log2_t, 16, PLS, _lib.ptr(g), _lib.ptr(workspace), _lib.stream_of(g)), 'grid_backward')
+        return g.cpu().numpy()
+    a, b, plain = run(ws), run(ws), run(None)
+    want = oracle.grid_encode_bw(x, np.ascontiguousarray(d.transpose(1, 0, 2).reshape(m, 32)), total, **grid)
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(a, want, rtol=2e-3, atol=2e-5 * scale)
+    np.testing.assert_allclose(plain, want, rtol=2e-3, atol=2e-5 * scale)
+    first_hashed = next(l for l in range(16) if offsets[l + 1] - offsets[l] == 2 ** log2_t)
+    np.testing.assert_array_equal(a[offsets[first_hashed]:], b[offsets[first_hashed]:])  # fixed-point sums: order-independent
+    assert np.array_equal(a == 0, want == 0) or np.mean((a == 0) != (want == 0)) < 1e-4
+
+
 def test_unsupported_configs_raise(tcnn):
     with pytest.raises(RuntimeError):
         tcnn.NetworkWithInputEncoding(3, 16, {**ENC_GRID, 'n_levels': 8}, NET_D)
