@@ -176,6 +176,26 @@ def test_update_occupancy_grid_runs_and_packs(setup):
     assert bool((model.occupancy_grid >= before * 0.95 - 1e-12).all())  # EMA: never below the decayed value
 
 
+def test_update_occupancy_grid_with_cascades_of_different_sample_counts():
+    """SCALE 1.0 -> two cascades; only cascade 0 has occupied cells, so it draws 2 n samples and cascade 1 only n (Renderer.py:190-198): the
+    ragged case is padded with ignored (-1) entries for the single device call.  Carved (-1) cells must survive."""
+    from nerficg_amd.instant_ngp import InstantNGPModel, InstantNGPRenderer
+    model = InstantNGPModel(RANDOM_SEED=2, SCALE=1.0, RESOLUTION=64, device=DEV)
+    assert model.cascades == 2
+    renderer = InstantNGPRenderer(model)
+    with torch.no_grad():
+        model.occupancy_grid[0, :5000] = 1.0
+        model.occupancy_grid[1, 100:200] = -1.0
+    torch.manual_seed(1)
+    renderer.update_occupancy_grid(warmup=False)
+    g = model.occupancy_grid
+    assert bool((g[1, 100:200] == -1.0).all()) and bool((g[0, :5000] >= 0.95 - 1e-6).all())
+    assert int((g[1] > 0).sum()) > 1000  # cascade 1 received its n uniform samples (densities of a random-init net are positive)
+    used, mean = renderer.occupancy_threshold.tolist()
+    np.testing.assert_allclose(mean, g[g > 0].double().mean().item(), rtol=1e-6)
+    np.testing.assert_array_equal(model.occupancy_bitfield.cpu().numpy(), oracle.packbits(g.float().cpu().numpy(), used))
+
+
 @pytest.mark.parametrize('cascades,dtype,n_samples', [(1, torch.float32, 20000), (2, torch.float16, 70001), (3, torch.float32, 0)])
 def test_occupancy_update_call_matches_oracle(cascades, dtype, n_samples):
     """C ABI group 11 against oracle.occupancy_update (Renderer.py:258-272): grid bit-exact, threshold within f32 rounding of the f64 mean,
