@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
     __shared__ float2 s_xy[BATCH];
     __shared__ float4 s_co[BATCH];
     __shared__ float s_rgb[BATCH * 3];
-    __shared__ uint8_t s_list[4][BATCH];
+    __shared__ __attribute__((aligned(4))) uint8_t s_list[4][BATCH];
     __shared__ int s_qcnt[4][4];
     const int tile = blockIdx.y * cam.gx + blockIdx.x;
     const int px = blockIdx.x * TILE + tile_px(threadIdx.x), py = blockIdx.y * TILE + tile_py(threadIdx.x);
@@ -691,24 +691,33 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
         }
         const int n_mine = quadrant_lists(flags, s_list, s_qcnt);
         const uint32_t pos0 = base - r0 + 1u;  // contributor number of batch entry 0 = its position in the tile list + 1
-        int j_next = n_mine > 0 ? s_list[wave][0] : 0;
-        for (int jj = 0; jj < n_mine; jj++) {
+        // the list is read four entries (one dword, wave-uniform) at a time: one dependent LDS round trip per four Gaussians
+        const uint32_t* list4 = reinterpret_cast<const uint32_t*>(s_list[wave]);
+        for (int jj = 0; jj < n_mine; jj += 4) {
             if (__ballot(!done) == 0ull) break;  // wave-uniform: every pixel of the quadrant is saturated
-            const int j = __builtin_amdgcn_readfirstlane(j_next);
-            j_next = s_list[wave][min(jj + 1, n_mine - 1)];  // in flight while this entry is blended
-            if (done) continue;
-            const float2 xy_j = s_xy[j];
-            const float dx = xy_j.x - fx, dy = xy_j.y - fy;
-            const float4 co_j = s_co[j];
-            const float power = -0.5f * (co_j.x * dx * dx + co_j.z * dy * dy) - co_j.y * dx * dy;
-            if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, co_j.w * expf(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T * (1 - alpha);
-            if (test_T < 0.0001f) { done = true; continue; }
-            C0 += s_rgb[3 * j] * alpha * T; C1 += s_rgb[3 * j + 1] * alpha * T; C2 += s_rgb[3 * j + 2] * alpha * T;
-            T = test_T;
-            last = pos0 + (uint32_t)j;
+            const uint32_t pack = (uint32_t)__builtin_amdgcn_readfirstlane((int)list4[jj >> 2]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (jj + u >= n_mine) break;
+                const int j = (int)((pack >> (8 * u)) & 0xffu);
+                // Branch-free body: the reference's four early-outs (done / power > 0 / alpha < 1/255 / saturation) become lane masks.
+                // All lanes of a wave execute the same instructions anyway; the nested `continue`s cost ~30 scalar exec-mask instructions
+                // per step next to ~45 vector ones.  Same arithmetic, same order: bit-identical pixels.
+                const float2 xy_j = s_xy[j];
+                const float dx = xy_j.x - fx, dy = xy_j.y - fy;
+                const float4 co_j = s_co[j];
+                const float power = -0.5f * (co_j.x * dx * dx + co_j.z * dy * dy) - co_j.y * dx * dy;
+                const float alpha = fminf(0.99f, co_j.w * expf(power));
+                const float test_T = T * (1 - alpha);
+                const bool valid = !done & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
+                const bool sat = valid & (test_T < 0.0001f);
+                const bool upd = valid & !sat;
+                done = done | sat;
+                const float a = upd ? alpha : 0.f;
+                C0 += s_rgb[3 * j] * a * T; C1 += s_rgb[3 * j + 1] * a * T; C2 += s_rgb[3 * j + 2] * a * T;
+                T = upd ? test_T : T;
+                last = upd ? pos0 + (uint32_t)j : last;
+            }
         }
         __syncthreads();
     }
@@ -744,7 +753,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
     __shared__ float4 s_co[BATCH];
     __shared__ float s_rgb[BATCH * 3];
     __shared__ float s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 4 waves, flushed once per batch
-    __shared__ uint8_t s_list[4][BATCH];
+    __shared__ __attribute__((aligned(4))) uint8_t s_list[4][BATCH];
     __shared__ int s_qcnt[4][4];
     const int tile = blockIdx.y * cam.gx + blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // wave = quadrant
@@ -796,10 +805,11 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             }
         }
         const int n_mine = quadrant_lists(flags, s_list, s_qcnt);
-        int j_next = n_mine > 0 ? s_list[wave][0] : 0;
+        const uint32_t* list4 = reinterpret_cast<const uint32_t*>(s_list[wave]);
         for (int jj = 0; jj < n_mine; jj++) {
-            const int j = __builtin_amdgcn_readfirstlane(j_next);
-            j_next = s_list[wave][min(jj + 1, n_mine - 1)];
+            // four list entries per (wave-uniform) dword read
+            const uint32_t pack = (uint32_t)__builtin_amdgcn_readfirstlane((int)list4[jj >> 2]);
+            const int j = (int)((pack >> (8 * (jj & 3))) & 0xffu);
             const int pos = pos_top - j;
             if (pos >= wave_last) continue;  // wave-uniform
             bool active = inside && pos < last;
