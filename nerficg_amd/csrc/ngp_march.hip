@@ -68,6 +68,7 @@ struct MarchCfg {
     uint32_t grid_size3;
     float grid_size_inv;
     float mip0_bound, mip0_bound_inv;  // cascades == 1: the mip level is always 0, its bound and reciprocal are constants (same f32 values)
+    const uint32_t* lut;               // optional LDS table expand_bits(0 .. grid_size-1), set by the kernel (march_lut)
 };
 
 // The cell containing o + t d: sample position, step, occupancy bit and (for an empty cell) the t beyond which the march resumes.
@@ -85,13 +86,24 @@ __device__ __forceinline__ bool cell_probe(const Ray& q, const MarchCfg& c, floa
     const int nx = (int)clampf(0.5f * (x * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
     const int ny = (int)clampf(0.5f * (y * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
     const int nz = (int)clampf(0.5f * (z * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
-    const uint32_t idx = (uint32_t)mip * c.grid_size3 + morton3D(nx, ny, nz);
+    // Morton index: three LDS lookups instead of 27 VALU instructions (a third of the step) when the kernel staged the table
+    const uint32_t mort = c.lut ? (c.lut[nx] | (c.lut[ny] << 1) | (c.lut[nz] << 2)) : morton3D(nx, ny, nz);
+    const uint32_t idx = (uint32_t)mip * c.grid_size3 + mort;
     const bool occ = c.bitfield[idx >> 3] & (1 << (idx & 7));
     const float tx = (((nx + 0.5f + 0.5f * signf_(q.dx)) * c.grid_size_inv * 2 - 1) * mip_bound - x) * q.dxi;
     const float ty = (((ny + 0.5f + 0.5f * signf_(q.dy)) * c.grid_size_inv * 2 - 1) * mip_bound - y) * q.dyi;
     const float tz = (((nz + 0.5f + 0.5f * signf_(q.dz)) * c.grid_size_inv * 2 - 1) * mip_bound - z) * q.dzi;
     t_target = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
     return occ;
+}
+// stages expand_bits(i), i < grid_size <= MARCH_LUT_MAX, in LDS and points the configuration at it (all threads of the block call this)
+#define MARCH_LUT_MAX 1024
+__device__ __forceinline__ void march_lut(MarchCfg& c, uint32_t* s_lut) {
+    if (c.grid_size <= MARCH_LUT_MAX) {
+        for (int i = threadIdx.x; i < c.grid_size; i += blockDim.x) s_lut[i] = expand_bits((uint32_t)i);
+        c.lut = s_lut;
+    }
+    __syncthreads();
 }
 // One DDA step.  Returns true when the cell containing o + t d is occupied (sample taken at t with step dt);
 // otherwise advances t to beyond the cell's exit face.  x,y,z,dt are outputs for the occupied case.
@@ -317,6 +329,8 @@ __global__ void __launch_bounds__(256) k_march_wave(const float* __restrict__ ra
                                                     int64_t n_rays, int32_t* __restrict__ counts, int32_t* __restrict__ block_sums,
                                                     const int64_t* __restrict__ rays_a, float* __restrict__ xyzs,
                                                     float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts) {
+    __shared__ uint32_t s_lut[MARCH_LUT_MAX];
+    march_lut(c, s_lut);
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_rays) return;
@@ -563,6 +577,8 @@ __device__ __forceinline__ int64_t tile_pixel(const RayGenCfg& g, int64_t tile, 
 __global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c, int tiles_x, int64_t tile_begin, int64_t n_tiles,
                                                       float* __restrict__ ray_od, float* __restrict__ ray_t,
                                                       int32_t* __restrict__ ray_cnt, int32_t* __restrict__ tile_rows) {
+    __shared__ uint32_t s_lut[MARCH_LUT_MAX];
+    march_lut(c, s_lut);
     const int lane = threadIdx.x & 63;
     const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // local tile
     if (lt >= n_tiles) return;
@@ -657,6 +673,8 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
                                                       const float* __restrict__ ray_t, const int32_t* __restrict__ ray_cnt,
                                                       const int32_t* __restrict__ tile_off, float* __restrict__ ts,
                                                       int32_t* __restrict__ row_tile, const int32_t* __restrict__ row_of) {
+    __shared__ uint32_t s_lut[MARCH_LUT_MAX];
+    march_lut(c, s_lut);
     const int lane = threadIdx.x & 63;
     const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (lt >= n_tiles) return;
@@ -690,6 +708,7 @@ MarchCfg make_cfg(const uint8_t* bitfield, int cascades, float scale, float esf,
     c.grid_size_inv = 1.0f / grid_size;
     c.mip0_bound = fminf(0.5f, scale);  // fminf(scalbnf(1, -1), scale)
     c.mip0_bound_inv = 1.0f / c.mip0_bound;
+    c.lut = nullptr;
     return c;
 }
 
