@@ -743,6 +743,17 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xf, 0xf, true));  // row_bcast:31
     return v;
 }
+// the same over the 16-lane DPP rows only (4 steps): lanes 15, 31, 47, 63 hold their row's sum.  The two row_bcast steps that carry the
+// sums on to lane 63 cost 18 VALU instructions per Gaussian for the nine quantities; four single-lane LDS atomics instead of one do not
+// show in the kernel time (the kernel issues VALU instructions 89 % of the time): fwd+bwd 1.93 -> 1.88 ms.  Stopping after three steps
+// (eight lanes per wave on the same LDS address) does: 2.30 ms.
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
+    return v;
+}
 __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
                                                    const float* __restrict__ points_xy, const float* __restrict__ conic_opacity,
                                                    const float* __restrict__ rgb, float bg0, float bg1, float bg2,
@@ -851,10 +862,10 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
                 d_op = G * dL_dalpha;
             }
             // wave-level reduction, then ONE atomic per wave and quantity
-            d_c0 = wave_sum_to_lane63(d_c0); d_c1 = wave_sum_to_lane63(d_c1); d_c2 = wave_sum_to_lane63(d_c2);
-            d_mx = wave_sum_to_lane63(d_mx); d_my = wave_sum_to_lane63(d_my);
-            d_cx = wave_sum_to_lane63(d_cx); d_cy = wave_sum_to_lane63(d_cy); d_cw = wave_sum_to_lane63(d_cw); d_op = wave_sum_to_lane63(d_op);
-            if (lane == 63) {  // LDS atomics: the 4 waves of the tile meet here, the global atomics happen once per (tile, Gaussian)
+            d_c0 = row_sum_to_lane15(d_c0); d_c1 = row_sum_to_lane15(d_c1); d_c2 = row_sum_to_lane15(d_c2);
+            d_mx = row_sum_to_lane15(d_mx); d_my = row_sum_to_lane15(d_my);
+            d_cx = row_sum_to_lane15(d_cx); d_cy = row_sum_to_lane15(d_cy); d_cw = row_sum_to_lane15(d_cw); d_op = row_sum_to_lane15(d_op);
+            if ((lane & 15) == 15) {  // LDS atomics: the 4 rows of each of the 4 waves meet here, the global atomics happen once per (tile, Gaussian)
                 float* a = s_acc[j];
                 atomicAdd(a + 0, d_c0); atomicAdd(a + 1, d_c1); atomicAdd(a + 2, d_c2); atomicAdd(a + 3, d_mx); atomicAdd(a + 4, d_my);
                 atomicAdd(a + 5, d_cx); atomicAdd(a + 6, d_cy); atomicAdd(a + 7, d_cw); atomicAdd(a + 8, d_op);
