@@ -865,6 +865,8 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             d_c0 = row_sum_to_lane15(d_c0); d_c1 = row_sum_to_lane15(d_c1); d_c2 = row_sum_to_lane15(d_c2);
             d_mx = row_sum_to_lane15(d_mx); d_my = row_sum_to_lane15(d_my);
             d_cx = row_sum_to_lane15(d_cx); d_cy = row_sum_to_lane15(d_cy); d_cw = row_sum_to_lane15(d_cw); d_op = row_sum_to_lane15(d_op);
+            // keep the last DPP add of each sum out of the one-lane branch below (sunk into it, it splits into v_mov_dpp + v_add)
+            asm volatile("" : "+v"(d_c0), "+v"(d_c1), "+v"(d_c2), "+v"(d_mx), "+v"(d_my), "+v"(d_cx), "+v"(d_cy), "+v"(d_cw), "+v"(d_op));
             if ((lane & 15) == 15) {  // LDS atomics: the 4 rows of each of the 4 waves meet here, the global atomics happen once per (tile, Gaussian)
                 float* a = s_acc[j];
                 atomicAdd(a + 0, d_c0); atomicAdd(a + 1, d_c1); atomicAdd(a + 2, d_c2); atomicAdd(a + 3, d_mx); atomicAdd(a + 4, d_my);
