@@ -823,44 +823,39 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             const int j = (int)((pack >> (8 * (jj & 3))) & 0xffu);
             const int pos = pos_top - j;
             if (pos >= wave_last) continue;  // wave-uniform
-            bool active = inside && pos < last;
-            float G = 0.f, alpha = 0.f, dx = 0.f, dy = 0.f;
-            float4 co = s_co[j];
-            if (active) {
-                const float2 xy = s_xy[j];
-                dx = xy.x - fx; dy = xy.y - fy;
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                if (power > 0.0f) active = false;
-                else {
-                    G = expf(power);
-                    alpha = fminf(0.99f, co.w * G);
-                    if (alpha < 1.0f / 255.0f) active = false;
-                }
-            }
+            // branch-free like the forward loop: lanes that do not blend the Gaussian carry zeros into the sums
+            const float4 co = s_co[j];
+            const float2 xy = s_xy[j];
+            const float dx = xy.x - fx, dy = xy.y - fy;
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            const float G = expf(power);
+            const float alpha = fminf(0.99f, co.w * G);
+            const bool active = inside & (pos < last) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
             if (__ballot(active) == 0ull) continue;  // nobody in this wave sees the Gaussian
-            float d_c0 = 0.f, d_c1 = 0.f, d_c2 = 0.f, d_mx = 0.f, d_my = 0.f, d_cx = 0.f, d_cy = 0.f, d_cw = 0.f, d_op = 0.f;
-            if (active) {
-                T = T / (1 - alpha);
-                const float dch = alpha * T;
-                const float c0 = s_rgb[3 * j], c1 = s_rgb[3 * j + 1], c2 = s_rgb[3 * j + 2];
-                acc0 = last_alpha * lc0 + (1 - last_alpha) * acc0; lc0 = c0;
-                acc1 = last_alpha * lc1 + (1 - last_alpha) * acc1; lc1 = c1;
-                acc2 = last_alpha * lc2 + (1 - last_alpha) * acc2; lc2 = c2;
-                float dL_dalpha = (c0 - acc0) * g0;
-                dL_dalpha += (c1 - acc1) * g1;
-                dL_dalpha += (c2 - acc2) * g2;
-                d_c0 = dch * g0; d_c1 = dch * g1; d_c2 = dch * g2;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / (1 - alpha)) * bg_dot;
-                const float dL_dG = co.w * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                const float dG_ddely = -gdy * co.z - gdx * co.y;
-                d_mx = dL_dG * dG_ddelx * ddelx_dx; d_my = dL_dG * dG_ddely * ddely_dy;
-                d_cx = -0.5f * gdx * dx * dL_dG; d_cy = -0.5f * gdx * dy * dL_dG; d_cw = -0.5f * gdy * dy * dL_dG;
-                d_op = G * dL_dalpha;
-            }
+            const float one_minus = 1 - alpha;
+            const float T_new = T / one_minus;
+            const float dch = alpha * T_new;
+            const float c0 = s_rgb[3 * j], c1 = s_rgb[3 * j + 1], c2 = s_rgb[3 * j + 2];
+            const float n_acc0 = last_alpha * lc0 + (1 - last_alpha) * acc0;
+            const float n_acc1 = last_alpha * lc1 + (1 - last_alpha) * acc1;
+            const float n_acc2 = last_alpha * lc2 + (1 - last_alpha) * acc2;
+            float dL_dalpha = (c0 - n_acc0) * g0;
+            dL_dalpha += (c1 - n_acc1) * g1;
+            dL_dalpha += (c2 - n_acc2) * g2;
+            dL_dalpha *= T_new;
+            dL_dalpha += (-T_final / one_minus) * bg_dot;
+            const float dL_dG = co.w * dL_dalpha;
+            const float gdx = G * dx, gdy = G * dy;
+            const float dG_ddelx = -gdx * co.x - gdy * co.y;
+            const float dG_ddely = -gdy * co.z - gdx * co.y;
+            float d_c0 = active ? dch * g0 : 0.f, d_c1 = active ? dch * g1 : 0.f, d_c2 = active ? dch * g2 : 0.f;
+            float d_mx = active ? dL_dG * dG_ddelx * ddelx_dx : 0.f, d_my = active ? dL_dG * dG_ddely * ddely_dy : 0.f;
+            float d_cx = active ? -0.5f * gdx * dx * dL_dG : 0.f, d_cy = active ? -0.5f * gdx * dy * dL_dG : 0.f;
+            float d_cw = active ? -0.5f * gdy * dy * dL_dG : 0.f, d_op = active ? G * dL_dalpha : 0.f;
+            T = active ? T_new : T;
+            acc0 = active ? n_acc0 : acc0; acc1 = active ? n_acc1 : acc1; acc2 = active ? n_acc2 : acc2;
+            lc0 = active ? c0 : lc0; lc1 = active ? c1 : lc1; lc2 = active ? c2 : lc2;
+            last_alpha = active ? alpha : last_alpha;
             // wave-level reduction, then ONE atomic per wave and quantity
             d_c0 = row_sum_to_lane15(d_c0); d_c1 = row_sum_to_lane15(d_c1); d_c2 = row_sum_to_lane15(d_c2);
             d_mx = row_sum_to_lane15(d_mx); d_my = row_sum_to_lane15(d_my);
