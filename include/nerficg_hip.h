@@ -253,11 +253,15 @@ int nrc_ngp_render_count(int32_t width, int32_t height, const double* intrinsics
                          const float* half3, float near_plane, float far_plane, int64_t tile_begin, int64_t n_tiles,
                          const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
                          int32_t grid_size, int32_t max_samples, float* ray_od, float* ray_t, int32_t* ray_cnt,
-                         int32_t* tile_rows, int32_t* tile_off, int32_t* counter, nrc_stream_t stream);
+                         int32_t* tile_rows, int32_t* tile_off, int32_t* counter, float* ts_provisional, nrc_stream_t stream);
+/* ts_provisional (optional, NULL allowed; nrc_ngp_render_provisional_bytes(n_tiles, max_samples) bytes = max_samples rows of 256 B per
+ * tile): the count pass parks every sample's t there and steps 2 copy them into their final rows instead of marching the rays a
+ * second time (pass the same buffer to both calls).  HBM is plentiful on this part: 2.6 GB for an 800x800 image. */
+int64_t nrc_ngp_render_provisional_bytes(int64_t n_tiles, int32_t max_samples);
 int nrc_ngp_render_write(int64_t n_tiles, const uint8_t* density_bitfield, int32_t cascades, float scale,
                          float exp_step_factor, int32_t grid_size, int32_t max_samples, const float* ray_od,
                          const float* ray_t, const int32_t* ray_cnt, const int32_t* tile_off, float* ts, int32_t* row_tile,
-                         nrc_stream_t stream);
+                         const float* ts_provisional, nrc_stream_t stream);
 int64_t nrc_ngp_query_samples_ws_bytes(int64_t n_rows, int64_t n_ray_tiles);
 int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
                           const float* xyz_min3, const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
@@ -273,7 +277,7 @@ int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float*
 int nrc_ngp_render_write_layers(int64_t n_tiles, const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
                                 int32_t grid_size, int32_t max_samples, const float* ray_od, const float* ray_t, const int32_t* ray_cnt,
                                 const int32_t* tile_rows, const int32_t* tile_off, float* ts, int32_t* row_tile, int32_t* layer_off,
-                                int32_t* row_of, nrc_stream_t stream);
+                                int32_t* row_of, const float* ts_provisional, nrc_stream_t stream);
 int64_t nrc_ngp_render_layers_ws_bytes(int64_t n_rows, int64_t n_ray_tiles);
 int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
                           const float* xyz_min3, const float* xyz_size3, const void* density_weights_f16,

@@ -576,7 +576,7 @@ __device__ __forceinline__ int64_t tile_pixel(const RayGenCfg& g, int64_t tile, 
 }
 __global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c, int tiles_x, int64_t tile_begin, int64_t n_tiles,
                                                       float* __restrict__ ray_od, float* __restrict__ ray_t,
-                                                      int32_t* __restrict__ ray_cnt, int32_t* __restrict__ tile_rows) {
+                                                      int32_t* __restrict__ ray_cnt, int32_t* __restrict__ tile_rows, float* __restrict__ ts_prov) {
     __shared__ uint32_t s_lut[MARCH_LUT_MAX];
     march_lut(c, s_lut);
     const int lane = threadIdx.x & 63;
@@ -590,8 +590,17 @@ __global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c,
     if (pix >= 0) {
         camera_ray(cam, pix, ry, t1, t2);
         float t = t1, x, y, z, dt;
-        while (t < t2 && n < c.max_samples) {
-            if (march_step(ry, c, t, x, y, z, dt)) { t += dt; n++; }
+        if (ts_prov) {
+            // the samples are parked in a per-tile arena of max_samples rows (sample k of lane l at (lt * max_samples + k) * 64 + l):
+            // the second pass copies them to their final rows instead of marching again
+            float* park = ts_prov + (size_t)lt * c.max_samples * 64 + lane;
+            while (t < t2 && n < c.max_samples) {
+                if (march_step(ry, c, t, x, y, z, dt)) { park[(size_t)n * 64] = t; t += dt; n++; }
+            }
+        } else {
+            while (t < t2 && n < c.max_samples) {
+                if (march_step(ry, c, t, x, y, z, dt)) { t += dt; n++; }
+            }
         }
     }
     float* od = ray_od + lt * 384 + lane;  // per-tile SoA [6][64]: every component is one 256-byte row
@@ -672,7 +681,8 @@ __global__ void __launch_bounds__(256) k_slab_rows(const int32_t* __restrict__ t
 __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tiles, const float* __restrict__ ray_od,
                                                       const float* __restrict__ ray_t, const int32_t* __restrict__ ray_cnt,
                                                       const int32_t* __restrict__ tile_off, float* __restrict__ ts,
-                                                      int32_t* __restrict__ row_tile, const int32_t* __restrict__ row_of) {
+                                                      int32_t* __restrict__ row_tile, const int32_t* __restrict__ row_of,
+                                                      const float* __restrict__ ts_prov) {
     __shared__ uint32_t s_lut[MARCH_LUT_MAX];
     march_lut(c, s_lut);
     const int lane = threadIdx.x & 63;
@@ -684,6 +694,23 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
     const int N = ray_cnt[q];
     auto row_at = [&](int k) -> int64_t { return row_of ? (int64_t)row_of[row0 + k] : row0 + k; };
     for (int k = lane; k < rows; k += 64) row_tile[row_at(k)] = (int32_t)lt;
+    if (ts_prov) {  // the count pass parked the samples: a coalesced copy (256-byte rows) instead of the second march
+        const float* park = ts_prov + (size_t)lt * c.max_samples * 64 + lane;
+        for (int k0 = 0; k0 < rows; k0 += 8) {  // eight rows in flight: the copy is latency-bound otherwise (327 us against 300 for the march)
+            float v[8];
+            int64_t dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = k0 + u;
+                v[u] = k < N ? park[(size_t)k * 64] : -1.0f;
+                dst[u] = k < rows ? row_at(k) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (k0 + u < rows) ts[dst[u] * 64 + lane] = v[u];
+        }
+        return;
+    }
     const float* od = ray_od + lt * 384 + lane;
     Ray ry;
     ry.ox = od[0]; ry.oy = od[64]; ry.oz = od[128]; ry.dx = od[192]; ry.dy = od[256]; ry.dz = od[320];
@@ -879,10 +906,14 @@ static void fill_raygen(RayGenCfg& g, int32_t width, int32_t height, const doubl
     }
 }
 
+int64_t nrc_ngp_render_provisional_bytes(int64_t n_tiles, int32_t max_samples) {
+    return (n_tiles < 0 || max_samples < 1) ? -1 : n_tiles * (int64_t)max_samples * 256 + 256;
+}
 int nrc_ngp_render_count(int32_t width, int32_t height, const double* intr, const double* c2w, const float* center3, const float* half3,
                          float near_plane, float far_plane, int64_t tile_begin, int64_t n_tiles, const uint8_t* bitfield,
                          int32_t cascades, float scale, float esf, int32_t grid_size, int32_t max_samples, float* ray_od,
-                         float* ray_t, int32_t* ray_cnt, int32_t* tile_rows, int32_t* tile_off, int32_t* counter, nrc_stream_t stream) {
+                         float* ray_t, int32_t* ray_cnt, int32_t* tile_rows, int32_t* tile_off, int32_t* counter, float* ts_provisional,
+                         nrc_stream_t stream) {
     NRC_ENTER();
     if (width < 1 || height < 1 || !intr || !c2w || !center3 || !half3 || n_tiles < 0 || tile_begin < 0 || cascades < 1 ||
         grid_size < 1 || max_samples < 1 || !counter || !tile_off)
@@ -898,27 +929,28 @@ int nrc_ngp_render_count(int32_t width, int32_t height, const double* intr, cons
     const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, (float)cascades);
     if (n_tiles > 0)
         hipLaunchKernelGGL(k_render_count, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, s, cam, c, tiles_x, tile_begin, n_tiles, ray_od, ray_t,
-                           ray_cnt, tile_rows);
+                           ray_cnt, tile_rows, ts_provisional);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_rows, n_tiles, tile_off, counter);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
 int nrc_ngp_render_write(int64_t n_tiles, const uint8_t* bitfield, int32_t cascades, float scale, float esf, int32_t grid_size,
                          int32_t max_samples, const float* ray_od, const float* ray_t, const int32_t* ray_cnt, const int32_t* tile_off,
-                         float* ts, int32_t* row_tile, nrc_stream_t stream) {
+                         float* ts, int32_t* row_tile, const float* ts_provisional, nrc_stream_t stream) {
     NRC_ENTER();
     if (n_tiles < 0 || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
     if (n_tiles == 0) return NRC_OK;
     if (!bitfield || !ray_od || !ray_t || !ray_cnt || !tile_off || !ts || !row_tile) return NRC_ERR_INVALID;
     const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, (float)cascades);
     hipLaunchKernelGGL(k_render_write, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, c, n_tiles, ray_od, ray_t, ray_cnt,
-                       tile_off, ts, row_tile, (const int32_t*)nullptr);
+                       tile_off, ts, row_tile, (const int32_t*)nullptr, ts_provisional);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
 int nrc_ngp_render_write_layers(int64_t n_tiles, const uint8_t* bitfield, int32_t cascades, float scale, float esf, int32_t grid_size,
                                 int32_t max_samples, const float* ray_od, const float* ray_t, const int32_t* ray_cnt, const int32_t* tile_rows,
-                                const int32_t* tile_off, float* ts, int32_t* row_tile, int32_t* layer_off, int32_t* row_of, nrc_stream_t stream) {
+                                const int32_t* tile_off, float* ts, int32_t* row_tile, int32_t* layer_off, int32_t* row_of,
+                                const float* ts_provisional, nrc_stream_t stream) {
     NRC_ENTER();
     if (n_tiles < 0 || cascades < 1 || grid_size < 1 || max_samples < 1 || max_samples > 1024) return NRC_ERR_INVALID;
     if (n_tiles == 0) return NRC_OK;
@@ -930,7 +962,7 @@ int nrc_ngp_render_write_layers(int64_t n_tiles, const uint8_t* bitfield, int32_
     hipLaunchKernelGGL(k_slab_offsets, dim3(1), dim3(64), 0, s, n_slabs, layer_off);
     hipLaunchKernelGGL(k_slab_rows, dim3(n_slabs), dim3(256), 0, s, tile_rows, tile_off, n_tiles, (const int32_t*)layer_off, row_of);
     hipLaunchKernelGGL(k_render_write, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, s, c, n_tiles, ray_od, ray_t, ray_cnt, tile_off, ts, row_tile,
-                       (const int32_t*)row_of);
+                       (const int32_t*)row_of, ts_provisional);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -213,6 +213,9 @@ class InstantNGPRenderer:
         self.ray_rendering_component = InstantNGPRayRenderingComponent(model)
         self.density_threshold = DENSITY_THRESHOLD * MAX_SAMPLES / 3 ** 0.5
         self._fused_ws: dict = {}
+        # fused image path: the count pass parks the samples in a max_samples-row arena per tile (2.6 GB at 800x800) and the write pass
+        # copies them instead of marching every ray twice; False = second march, no arena
+        self.provisional_march = True
 
     def render_rays(self, origin, view_direction, camera: Camera, train_mode: bool = False, custom_bg_color: torch.Tensor | None = None):
         bg = custom_bg_color if custom_bg_color is not None else camera.background_color.to(origin.device)
@@ -268,6 +271,8 @@ class InstantNGPRenderer:
                       tile_off=torch.empty(nt + 1, dtype=torch.int32, device=dev), counter=torch.empty(2, dtype=torch.int32, device=dev),
                       rgb=torch.zeros(hw, 3, device=dev), alpha=torch.zeros(hw, device=dev), depth=torch.zeros(hw, device=dev), cap=0,
                       skipped=torch.zeros(1, dtype=torch.int32, device=dev))
+            if self.provisional_march:  # samples parked by the count pass, copied (not re-marched) by the write pass
+                ws['ts_prov'] = torch.empty(int(lib.nrc_ngp_render_provisional_bytes(nt, self.MAX_SAMPLES)), dtype=torch.uint8, device=dev)
             self._fused_ws = {key: ws}
         if out is None:
             out = {'rgb': ws['rgb'], 'alpha': ws['alpha'], 'depth': ws['depth']}
@@ -279,7 +284,7 @@ class InstantNGPRenderer:
             ctypes.cast(center, ctypes.c_void_p), ctypes.cast(half, ctypes.c_void_p), float(camera.near_plane), float(camera.far_plane),
             int(tile_begin), nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION, self.MAX_SAMPLES,
             _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']), _lib.ptr(ws['tile_off']),
-            _lib.ptr(ws['counter']), st), 'ngp_render_count')
+            _lib.ptr(ws['counter']), _lib.ptr(ws.get('ts_prov')), st), 'ngp_render_count')
         rows = int(ws['counter'][0].item())
         if rows > ws['cap']:
             cap = int(rows * 1.25) + 64
@@ -306,7 +311,7 @@ class InstantNGPRenderer:
                 _lib.check(lib.nrc_ngp_render_write_layers(
                     nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION, self.MAX_SAMPLES, _lib.ptr(ws['ray_od']),
                     _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']), _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']),
-                    _lib.ptr(ws['row_tile']), _lib.ptr(ws['layer_off']), _lib.ptr(ws['row_of']), st), 'ngp_render_write_layers')
+                    _lib.ptr(ws['row_tile']), _lib.ptr(ws['layer_off']), _lib.ptr(ws['row_of']), _lib.ptr(ws.get('ts_prov')), st), 'ngp_render_write_layers')
             if 'qws' not in ws:  # an image without a single sample: state + background only
                 ws['qws'] = torch.empty(int(lib.nrc_ngp_render_layers_ws_bytes(0, nt)), dtype=torch.uint8, device=dev)
             _lib.check(lib.nrc_ngp_render_layers(
@@ -326,7 +331,7 @@ class InstantNGPRenderer:
         if rows > 0:
             _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION,
                                                 self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']),
-                                                _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), st), 'ngp_render_write')
+                                                _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws.get('ts_prov')), st), 'ngp_render_write')
             g = m.encoding_xyz.grid_cfg
             mn, sz = f3(m.xyz_min), f3(m.xyz_size)
             _lib.check(lib.nrc_ngp_query_samples(
