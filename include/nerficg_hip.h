@@ -59,9 +59,11 @@ int nrc_packbits(const void* density_grid, int32_t grid_dtype, int64_t n_bytes, 
  * counter[0] sample rows instead of the reference's n_rays*max_samples zero-filled rows.
  *   _count : marches every ray once, writes rays_a (n_rays,3) = (ray_idx, start_idx, n_samples) in RAY ORDER with
  *            start_idx = exclusive prefix sum (deterministic; the reference's order is atomic-arrival order) and
- *            counter[0] = total samples, counter[1] = n_rays.  workspace: nrc_raymarching_train_ws_bytes(n_rays) bytes.
- *   _write : marches again and writes xyzs/dirs (total,3), deltas/ts (total). */
-int64_t nrc_raymarching_train_ws_bytes(int64_t n_rays);
+ *            counter[0] = total samples, counter[1] = n_rays.  workspace: nrc_raymarching_train_ws_bytes(n_rays, max_samples) bytes;
+ *            for batches of <= 32768 rays the pass also parks every sample's t there (max_samples f32 per ray).
+ *   _write : writes xyzs/dirs (total,3), deltas/ts (total): with the workspace of the count pass it expands the parked positions
+ *            (no second march); with workspace == NULL it marches again. */
+int64_t nrc_raymarching_train_ws_bytes(int64_t n_rays, int32_t max_samples);
 int nrc_raymarching_train_count(const float* rays_o, const float* rays_d, const float* hits_t,
                                 const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
                                 const float* noise, int32_t grid_size, int32_t max_samples, int64_t n_rays,
@@ -70,7 +72,7 @@ int nrc_raymarching_train_write(const float* rays_o, const float* rays_d, const 
                                 const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
                                 const float* noise, int32_t grid_size, int32_t max_samples, int64_t n_rays,
                                 const int64_t* rays_a, float* xyzs, float* dirs, float* deltas, float* ts,
-                                nrc_stream_t stream);
+                                const void* workspace, nrc_stream_t stream);
 /* binding.cpp:84-106 -> raymarching.cu:407-454.  hits_t (n_total_rays,2) is advanced in place.  Outputs
  * (n_alive,N_samples[,3]) are fully written (zero beyond N_eff_samples), N_eff_samples (n_alive) i32. */
 int nrc_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t, const int64_t* alive_indices,

@@ -11,6 +11,8 @@ Python level); the C ABI underneath takes raw pointers.  Differences, all docume
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.amp import custom_bwd, custom_fwd
 
@@ -24,6 +26,7 @@ __all__ = [
 ]
 
 _f32, _i32, _i64, _u8 = torch.float32, torch.int32, torch.int64, torch.uint8
+_PARKED_MARCH = os.environ.get('NRC_TRAIN_PARK', '1') != '0'  # 0: raymarching_train marches twice instead of expanding parked positions
 
 
 def _chk(*pairs) -> None:
@@ -101,7 +104,7 @@ def raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades: int, s
     st = _lib.stream_of(rays_o)
     rays_a = torch.empty(n, 3, dtype=_i64, device=dev)
     counter = torch.empty(2, dtype=_i32, device=dev)
-    ws = torch.empty(max(int(lib.nrc_raymarching_train_ws_bytes(n)), 1), dtype=_u8, device=dev)
+    ws = torch.empty(max(int(lib.nrc_raymarching_train_ws_bytes(n, int(max_samples))), 1), dtype=_u8, device=dev)
     args = (_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(hits_t), _lib.ptr(density_bitfield), int(cascades), float(scale),
             float(exp_step_factor), _lib.ptr(noise), int(grid_size), int(max_samples), n)
     _lib.check(lib.nrc_raymarching_train_count(*args, _lib.ptr(rays_a), _lib.ptr(counter), _lib.ptr(ws), st), 'raymarching_train(count)')
@@ -111,7 +114,7 @@ def raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades: int, s
     deltas = torch.empty(total, dtype=_f32, device=dev)
     ts = torch.empty(total, dtype=_f32, device=dev)
     _lib.check(lib.nrc_raymarching_train_write(*args, _lib.ptr(rays_a), _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas),
-                                               _lib.ptr(ts), st), 'raymarching_train(write)')
+                                               _lib.ptr(ts), _lib.ptr(ws) if _PARKED_MARCH else None, st), 'raymarching_train(write)')
     return [rays_a, xyzs, dirs, deltas, ts, counter]
 
 

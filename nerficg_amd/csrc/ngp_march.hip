@@ -328,7 +328,8 @@ __global__ void __launch_bounds__(256) k_march_wave(const float* __restrict__ ra
                                                     const float* __restrict__ hits_t, const float* __restrict__ noise, MarchCfg c,
                                                     int64_t n_rays, int32_t* __restrict__ counts, int32_t* __restrict__ block_sums,
                                                     const int64_t* __restrict__ rays_a, float* __restrict__ xyzs,
-                                                    float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts) {
+                                                    float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts,
+                                                    float* __restrict__ park) {
     __shared__ uint32_t s_lut[MARCH_LUT_MAX];
     march_lut(c, s_lut);
     const int lane = threadIdx.x & 63;
@@ -379,6 +380,8 @@ __global__ void __launch_bounds__(256) k_march_wave(const float* __restrict__ ra
                 pos = j + 1;                                       // (the reference's do-while advances at least once)
             }
         }
+        if (!WRITE && park && ((samples >> lane) & 1ull))  // the count pass parks the sample positions: k_march_expand instead of a second march
+            park[r * c.max_samples + s_before + __popcll(samples & ((1ull << lane) - 1ull))] = my_t;
         if (WRITE && ((samples >> lane) & 1ull)) {
             const int64_t k = start + s_before + __popcll(samples & ((1ull << lane) - 1ull));
             xyzs[3 * k] = x; xyzs[3 * k + 1] = y; xyzs[3 * k + 2] = z;
@@ -389,6 +392,29 @@ __global__ void __launch_bounds__(256) k_march_wave(const float* __restrict__ ra
     if (!WRITE && lane == 0) {
         counts[r] = s;
         if (s) atomicAdd(&block_sums[r >> 8], s);
+    }
+}
+
+// Second pass when the count pass parked the sample positions: a wave per ray expands t into (xyz, dir, dt, t) -- the same f32
+// expressions as cell_probe / calc_dt, no march, no occupancy probes.
+__global__ void __launch_bounds__(256) k_march_expand(const float* __restrict__ rays_o, const float* __restrict__ rays_d, MarchCfg c, int64_t n_rays,
+                                                      const int64_t* __restrict__ rays_a, const float* __restrict__ park, float* __restrict__ xyzs,
+                                                      float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_rays) return;
+    const int64_t r = rays_a[3 * n], start = rays_a[3 * n + 1];
+    const int N = (int)rays_a[3 * n + 2];
+    if (N == 0) return;
+    const Ray q = load_ray(rays_o, rays_d, r);
+    const float* src = park + r * c.max_samples;
+    for (int k = lane; k < N; k += 64) {
+        const float t = src[k];
+        const int64_t o = start + k;
+        xyzs[3 * o] = q.ox + t * q.dx; xyzs[3 * o + 1] = q.oy + t * q.dy; xyzs[3 * o + 2] = q.oz + t * q.dz;
+        dirs[3 * o] = q.dx; dirs[3 * o + 1] = q.dy; dirs[3 * o + 2] = q.dz;
+        ts[o] = t;
+        deltas[o] = calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale);
     }
 }
 
@@ -807,12 +833,17 @@ int nrc_ray_sphere_intersect(const float* rays_o, const float* rays_d, const flo
     return NRC_OK;
 }
 
-int64_t nrc_raymarching_train_ws_bytes(int64_t n_rays) {
-    if (n_rays < 0) return NRC_ERR_INVALID;
+static int64_t train_ws_head_bytes(int64_t n_rays) {
     // counts[n_rays] + block_sums[ceil(n_rays/256)], both i32, 256-byte aligned sections
     const int64_t a = (n_rays * 4 + 255) / 256 * 256;
     const int64_t b = (nrc_cdiv(n_rays, 256) * 4 + 255) / 256 * 256;
     return a + b + 256;
+}
+int64_t nrc_raymarching_train_ws_bytes(int64_t n_rays, int32_t max_samples) {
+    if (n_rays < 0 || max_samples < 1) return NRC_ERR_INVALID;
+    // + the parked sample positions (max_samples f32 per ray) for batches that take the wave-per-ray path
+    const int64_t park = n_rays <= NRC_WAVE_MARCH_MAX_RAYS ? n_rays * (int64_t)max_samples * 4 : 0;
+    return train_ws_head_bytes(n_rays) + park;
 }
 int nrc_raymarching_train_count(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* bitfield,
                                 int32_t cascades, float scale, float esf, const float* noise, int32_t grid_size,
@@ -829,8 +860,9 @@ int nrc_raymarching_train_count(const float* rays_o, const float* rays_d, const 
     const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, scale);
     if (n_rays <= NRC_WAVE_MARCH_MAX_RAYS) {
         hipMemsetAsync(block_sums, 0, sizeof(int32_t) * nb, s);
+        float* park = (float*)((char*)workspace + train_ws_head_bytes(n_rays));
         hipLaunchKernelGGL(k_march_wave<false>, dim3((unsigned)nrc_cdiv(n_rays, 4)), dim3(256), 0, s, rays_o, rays_d, hits_t, noise, c, n_rays, counts,
-                           block_sums, (const int64_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                           block_sums, (const int64_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, park);
     } else {
         hipLaunchKernelGGL(k_march_count, dim3(nb), dim3(256), 0, s, rays_o, rays_d, hits_t, noise, c, n_rays, counts, block_sums);
     }
@@ -842,15 +874,18 @@ int nrc_raymarching_train_count(const float* rays_o, const float* rays_d, const 
 int nrc_raymarching_train_write(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* bitfield,
                                 int32_t cascades, float scale, float esf, const float* noise, int32_t grid_size,
                                 int32_t max_samples, int64_t n_rays, const int64_t* rays_a, float* xyzs, float* dirs,
-                                float* deltas, float* ts, nrc_stream_t stream) {
+                                float* deltas, float* ts, const void* workspace, nrc_stream_t stream) {
     NRC_ENTER();
     if (n_rays < 0 || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
     if (n_rays == 0) return NRC_OK;
     if (!rays_o || !rays_d || !hits_t || !bitfield || !noise || !rays_a) return NRC_ERR_INVALID;
     const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, scale);
-    if (n_rays <= NRC_WAVE_MARCH_MAX_RAYS)
+    if (n_rays <= NRC_WAVE_MARCH_MAX_RAYS && workspace)  // the count pass of the same workspace parked the sample positions
+        hipLaunchKernelGGL(k_march_expand, dim3((unsigned)nrc_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, c, n_rays, rays_a,
+                           (const float*)((const char*)workspace + train_ws_head_bytes(n_rays)), xyzs, dirs, deltas, ts);
+    else if (n_rays <= NRC_WAVE_MARCH_MAX_RAYS)
         hipLaunchKernelGGL(k_march_wave<true>, dim3((unsigned)nrc_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, hits_t, noise, c,
-                           n_rays, (int32_t*)nullptr, (int32_t*)nullptr, rays_a, xyzs, dirs, deltas, ts);
+                           n_rays, (int32_t*)nullptr, (int32_t*)nullptr, rays_a, xyzs, dirs, deltas, ts, (float*)nullptr);
     else
         hipLaunchKernelGGL(k_march_write, dim3(nrc_cdiv(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, hits_t,
                            noise, c, n_rays, rays_a, xyzs, dirs, deltas, ts);

@@ -48,7 +48,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.nrc_morton3D(None, -1, None, None) == -1
     assert lib.nrc_packbits(None, 7, 8, 0.0, None, None) == -1
     assert lib.nrc_ray_aabb_intersect(None, None, None, None, 4, 1, 0, None, None, None, None) == -1
-    assert lib.nrc_raymarching_train_ws_bytes(1000) >= 1000 * 4
+    assert lib.nrc_raymarching_train_ws_bytes(1000, 1024) >= 1000 * 4 + 1000 * 1024 * 4
     assert lib.nrc_morton3D(None, 0, None, None) == 0
 
 
