@@ -259,6 +259,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gs', action='store_true', help='skip the secondary 3DGS leg')
     ap.add_argument('--no-train', action='store_true', help='skip the InstantNGP training-iteration leg')
+    ap.add_argument('--no-gs-large', action='store_true', help='skip the 6 M-Gaussian run of the 3DGS leg')
     ap.add_argument('--gs-gaussians', type=int, default=1_000_000)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the code path)')
     args = ap.parse_args()
@@ -332,6 +333,13 @@ def main():
         gs_res['msplats_per_s_fwd'] = round(n_g / gs_res['ms_fwd'] / 1e3, 2)
         gs_res['msplats_per_s_fwd_bwd'] = round(n_g / gs_res['ms_fwd_bwd'] / 1e3, 2)
         del gs
+        # BASELINE config C5 size (6 M Gaussians), single-GPU runs only: the same kernels with 50 M instances per frame
+        if world == 1 and not args.no_gs_large:
+            torch.cuda.empty_cache()
+            big = build_gs_scene(device, 6_000_000)
+            gs_res['large'] = time_gs(big, reps=3, barrier=barrier)
+            del big
+            torch.cuda.empty_cache()
 
     if rank == 0:
         rays = W * H * args.steps * world
@@ -378,6 +386,15 @@ def main():
                              'frac_fwd': round(b_fwd / (gs_res['ms_fwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              'frac_fwd_bwd': round((b_fwd + b_bwd) / (gs_res['ms_fwd_bwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              'algorithmic_bytes_fwd': b_fwd, 'algorithmic_bytes_bwd': b_bwd}}
+            if 'large' in gs_res:
+                lg = gs_res['large']
+                lb_fwd = 308 * lg['visible'] + 148 * lg['instances'] + 20 * GS_W * GS_H
+                lb_bwd = 76 * lg['instances'] + 472 * lg['visible'] + 20 * GS_W * GS_H
+                result['secondary']['six_million'] = {
+                    'value_fwd': lg['msplats_per_s_fwd'], 'value_fwd_bwd': lg['msplats_per_s_fwd_bwd'], 'unit': 'Msplats/s', 'ms_fwd': lg['ms_fwd'],
+                    'ms_fwd_bwd': lg['ms_fwd_bwd'], 'gaussians': lg['gaussians'], 'visible': lg['visible'], 'instances': lg['instances'],
+                    'frac_fwd': round(lb_fwd / (lg['ms_fwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    'frac_fwd_bwd': round((lb_fwd + lb_bwd) / (lg['ms_fwd_bwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if not args.no_train:
             try:
                 result['training'] = time_train(model, renderer, cam, poses)
