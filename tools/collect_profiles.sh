@@ -1,11 +1,13 @@
 #!/bin/bash
 # tools/collect_profiles.sh -- run on the GPU box (via gpurun): kernel-trace stats of the default bench command and PMC passes
 # (separate runs, --kernel-trace only, as required on this pool) for the pipeline's kernels.  Outputs under gpurun_out/profiles_raw.
+# NOTE: gpurun MERGES gpurun_out/ back into the local copy -- delete the local gpurun_out/profiles_raw before a new collection, otherwise
+# tools/make_profile_summary.py averages the counters of old and new builds.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_raw
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-gs-large > $O/bench_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 $R/tools/bench_train.py 2200 20 > $O/train_stats.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE TA_BUSY_avr" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-32)

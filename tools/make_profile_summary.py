@@ -23,10 +23,11 @@ def short(name):
     return name.split('(')[0]
 
 
-stats = sorted(glob.glob(str(RAW / 'bench_stats' / '*' / '*kernel_stats.csv')))
+import os
+stats = sorted(glob.glob(str(RAW / 'bench_stats' / '*' / '*kernel_stats.csv')), key=os.path.getmtime)  # newest collection last
 if stats:
     shutil.copy(stats[-1], OUT / 'r01_bench_kernel_stats.csv')
-tstats = sorted(glob.glob(str(RAW / 'train_stats' / '*' / '*kernel_stats.csv')))
+tstats = sorted(glob.glob(str(RAW / 'train_stats' / '*' / '*kernel_stats.csv')), key=os.path.getmtime)
 if tstats:
     shutil.copy(tstats[-1], OUT / 'r01_train_kernel_stats.csv')
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
