@@ -1243,7 +1243,7 @@ __global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restric
             if (i < M) {
                 const float2 gf = reinterpret_cast<const float2*>(d_feat)[(int64_t)bc.level[k] * M + i];
                 m = fmaxf(fabsf(gf.x), fabsf(gf.y));
-                if (!(m == m)) m = 0.f;
+                if (!(fabsf(gf.x) < __builtin_inff()) || !(fabsf(gf.y) < __builtin_inff())) m = __builtin_inff();  // inf / NaN (AMP overflow): poisons the level
             }
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
@@ -1292,7 +1292,9 @@ __global__ void __launch_bounds__(GB_MAX_BUCKETS) k_gb_scan(GbHeader* __restrict
         int e_max = 0, e_cnt = 0;
         frexpf(m > 0.f && m < __builtin_inff() ? m : 1.f, &e_max);  // m < 2^e_max
         frexpf((float)(2 * M + 1), &e_cnt);                         // 2 M + 1 <= 2^e_cnt (an entry receives at most 2 M values of <= m)
-        hd->level_scale[threadIdx.x] = ldexpf(1.f, 62 - e_max - e_cnt);
+        // a non-finite gradient on the level (GradScaler overflow): NaN scale -> the accumulation pass marks the level's gradient NaN, the way
+        // f32 atomics would have propagated it, so that the scaler's found-inf check still sees it
+        hd->level_scale[threadIdx.x] = m < __builtin_inff() ? ldexpf(1.f, 62 - e_max - e_cnt) : __builtin_nanf("");
     }
 }
 
@@ -1309,6 +1311,10 @@ __global__ void __launch_bounds__(OWN_THREADS) k_gb_accumulate(GridCfg g, Bucket
     const uint32_t n = hd->counts[blockIdx.x];
     const uint4* rec = records + hd->base[blockIdx.x];
     const float scale = hd->level_scale[li];
+    if (!(scale == scale)) {  // poisoned level (see k_gb_scan)
+        if (threadIdx.x == 0) reinterpret_cast<float2*>(grad_table)[lo] = make_float2(scale, scale);
+        return;
+    }
     enum { UNR = 4 };
     for (uint32_t k0 = threadIdx.x; k0 < n; k0 += OWN_THREADS * UNR) {
         uint4 r[UNR];

@@ -222,6 +222,17 @@ def test_grid_backward_bucketed_path_matches_atomics_and_is_reproducible(log2_t)
     if os.environ.get('NRC_GRID_BWD_BUCKETS', '1') != '0' and os.environ.get('NRC_GRID_BWD_OWNED', '1') != '0':  # experiment switches
         np.testing.assert_array_equal(a[offsets[first_hashed]:], b[offsets[first_hashed]:])  # fixed-point sums: order-independent
     assert np.array_equal(a == 0, want == 0) or np.mean((a == 0) != (want == 0)) < 1e-4
+    # a non-finite upstream gradient (GradScaler overflow) must stay visible in the table gradient: the fixed-point path cannot carry inf / NaN,
+    # it marks every slice of the affected level instead
+    for bad in (np.inf, np.nan):
+        d2 = d.copy()
+        d2[15, 12345, 1] = bad
+        td2 = T(d2)
+        g = torch.zeros(total, 2, device=DEV)
+        _lib.check(lib.nrc_grid_backward(_lib.ptr(tx), m, _lib.ptr(td2), 1, 16, log2_t, 16, PLS, _lib.ptr(g), _lib.ptr(ws), _lib.stream_of(g)), 'grid_backward')
+        lvl = g[offsets[15]:offsets[16]]
+        assert not bool(torch.isfinite(lvl).all()), bad
+        assert bool(torch.isfinite(g[:offsets[15]]).all())  # the other levels are untouched by it
 
 
 def test_unsupported_configs_raise(tcnn):
