@@ -68,12 +68,14 @@ struct MarchCfg {
     uint32_t grid_size3;
     float grid_size_inv;
     float mip0_bound, mip0_bound_inv;  // cascades == 1: the mip level is always 0, its bound and reciprocal are constants (same f32 values)
-    const uint32_t* lut;               // optional LDS table expand_bits(0 .. grid_size-1), set by the kernel (march_lut)
+    int use_lut;                       // the kernel staged expand_bits(0 .. grid_size-1) in LDS (march_lut) and passes the array to cell_probe
 };
 
 // The cell containing o + t d: sample position, step, occupancy bit and (for an empty cell) the t beyond which the march resumes.
 // Same f32 operation sequence as raymarching.cu:200-234 / 243-279 (this file is compiled with -ffp-contract=off).
-__device__ __forceinline__ bool cell_probe(const Ray& q, const MarchCfg& c, float t, float& x, float& y, float& z, float& dt, float& t_target) {
+// `lut`: the kernel's __shared__ table, passed as a plain argument (not through the struct) so that after inlining the compiler knows it is LDS
+// and reads it with ds_read_b32 -- behind a generic pointer in MarchCfg the lookups were flat_load_dword through the vector memory path.
+__device__ __forceinline__ bool cell_probe(const Ray& q, const MarchCfg& c, const uint32_t* lut, float t, float& x, float& y, float& z, float& dt, float& t_target) {
     x = q.ox + t * q.dx; y = q.oy + t * q.dy; z = q.oz + t * q.dz;
     dt = calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale);
     int mip = 0;
@@ -87,7 +89,7 @@ __device__ __forceinline__ bool cell_probe(const Ray& q, const MarchCfg& c, floa
     const int ny = (int)clampf(0.5f * (y * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
     const int nz = (int)clampf(0.5f * (z * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
     // Morton index: three LDS lookups instead of 27 VALU instructions (a third of the step) when the kernel staged the table
-    const uint32_t mort = c.lut ? (c.lut[nx] | (c.lut[ny] << 1) | (c.lut[nz] << 2)) : morton3D(nx, ny, nz);
+    const uint32_t mort = c.use_lut ? (lut[nx] | (lut[ny] << 1) | (lut[nz] << 2)) : morton3D(nx, ny, nz);
     const uint32_t idx = (uint32_t)mip * c.grid_size3 + mort;
     const bool occ = c.bitfield[idx >> 3] & (1 << (idx & 7));
     const float tx = (((nx + 0.5f + 0.5f * signf_(q.dx)) * c.grid_size_inv * 2 - 1) * mip_bound - x) * q.dxi;
@@ -101,15 +103,15 @@ __device__ __forceinline__ bool cell_probe(const Ray& q, const MarchCfg& c, floa
 __device__ __forceinline__ void march_lut(MarchCfg& c, uint32_t* s_lut) {
     if (c.grid_size <= MARCH_LUT_MAX) {
         for (int i = threadIdx.x; i < c.grid_size; i += blockDim.x) s_lut[i] = expand_bits((uint32_t)i);
-        c.lut = s_lut;
+        c.use_lut = 1;
     }
     __syncthreads();
 }
 // One DDA step.  Returns true when the cell containing o + t d is occupied (sample taken at t with step dt);
 // otherwise advances t to beyond the cell's exit face.  x,y,z,dt are outputs for the occupied case.
-__device__ __forceinline__ bool march_step(const Ray& q, const MarchCfg& c, float& t, float& x, float& y, float& z, float& dt) {
+__device__ __forceinline__ bool march_step(const Ray& q, const MarchCfg& c, const uint32_t* lut, float& t, float& x, float& y, float& z, float& dt) {
     float t_target;
-    if (cell_probe(q, c, t, x, y, z, dt, t_target)) return true;
+    if (cell_probe(q, c, lut, t, x, y, z, dt, t_target)) return true;
     do { t += calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale); } while (t < t_target);
     return false;
 }
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(256) k_march_count(const float* __restrict__ r
         if (t1 >= 0) t1 += calc_dt(t1, c.esf, c.max_samples, c.grid_size, c.scale) * noise[r];
         float t = t1, x, y, z, dt;
         while (0 <= t && t < t2 && n < c.max_samples) {
-            if (march_step(q, c, t, x, y, z, dt)) { t += dt; n++; }
+            if (march_step(q, c, (const uint32_t*)nullptr, t, x, y, z, dt)) { t += dt; n++; }
         }
         counts[r] = n;
     }
@@ -306,7 +308,7 @@ __global__ void __launch_bounds__(256) k_march_write(const float* __restrict__ r
     float t = t1, x, y, z, dt;
     int s = 0;
     while (t < t2 && s < N) {
-        if (march_step(q, c, t, x, y, z, dt)) {
+        if (march_step(q, c, (const uint32_t*)nullptr, t, x, y, z, dt)) {
             const int64_t k = start + s;
             xyzs[3 * k] = x; xyzs[3 * k + 1] = y; xyzs[3 * k + 2] = z;
             dirs[3 * k] = q.dx; dirs[3 * k + 1] = q.dy; dirs[3 * k + 2] = q.dz;
@@ -358,7 +360,7 @@ __global__ void __launch_bounds__(256) k_march_wave(const float* __restrict__ ra
         }
         const bool valid = my_t < t2;
         float x, y, z, dt, t_target;
-        const bool occ = cell_probe(q, c, valid ? my_t : t1, x, y, z, dt, t_target) && valid;
+        const bool occ = cell_probe(q, c, s_lut, valid ? my_t : t1, x, y, z, dt, t_target) && valid;
         const unsigned long long validm = __ballot(valid), occm = __ballot(occ);
         unsigned long long samples = 0ull;
         const int s_before = s;
@@ -434,7 +436,7 @@ __global__ void __launch_bounds__(256) k_march_test(const float* __restrict__ ra
     int s = 0;
     const int64_t base = n * N_samples;
     while (t < t2 && s < N_samples) {
-        if (march_step(q, c, t, x, y, z, dt)) {
+        if (march_step(q, c, (const uint32_t*)nullptr, t, x, y, z, dt)) {
             const int64_t k = base + s;
             xyzs[3 * k] = x; xyzs[3 * k + 1] = y; xyzs[3 * k + 2] = z;
             dirs[3 * k] = q.dx; dirs[3 * k + 1] = q.dy; dirs[3 * k + 2] = q.dz;
@@ -621,11 +623,11 @@ __global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c,
             // the second pass copies them to their final rows instead of marching again
             float* park = ts_prov + (size_t)lt * c.max_samples * 64 + lane;
             while (t < t2 && n < c.max_samples) {
-                if (march_step(ry, c, t, x, y, z, dt)) { park[(size_t)n * 64] = t; t += dt; n++; }
+                if (march_step(ry, c, s_lut, t, x, y, z, dt)) { park[(size_t)n * 64] = t; t += dt; n++; }
             }
         } else {
             while (t < t2 && n < c.max_samples) {
-                if (march_step(ry, c, t, x, y, z, dt)) { t += dt; n++; }
+                if (march_step(ry, c, s_lut, t, x, y, z, dt)) { t += dt; n++; }
             }
         }
     }
@@ -745,7 +747,7 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
     const float t2 = ray_t[2 * q + 1];
     int s = 0;
     while (t < t2 && s < N) {
-        if (march_step(ry, c, t, x, y, z, dt)) {
+        if (march_step(ry, c, s_lut, t, x, y, z, dt)) {
             ts[row_at(s) * 64 + lane] = t;
             t += dt; s++;
         }
@@ -761,7 +763,7 @@ MarchCfg make_cfg(const uint8_t* bitfield, int cascades, float scale, float esf,
     c.grid_size_inv = 1.0f / grid_size;
     c.mip0_bound = fminf(0.5f, scale);  // fminf(scalbnf(1, -1), scale)
     c.mip0_bound_inv = 1.0f / c.mip0_bound;
-    c.lut = nullptr;
+    c.use_lut = 0;
     return c;
 }
 
