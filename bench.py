@@ -400,7 +400,8 @@ def main():
                 result['training'] = time_train(model, renderer, cam, poses)
             except Exception as e:  # never lose the headline line over the extra leg
                 result['training'] = {'error': repr(e)[:200]}
-        if not args.no_cpu_baseline:
+        result['cpu_baseline'] = None  # timed on rank 0 of single-GPU runs only (the host cores are shared by all ranks otherwise)
+        if not args.no_cpu_baseline and world == 1:
             if gs_res is not None:
                 result['secondary']['cpu_baseline'] = gs_cpu_baseline()
             pd = model.encoding_xyz.params.detach().half().float().cpu().numpy()
