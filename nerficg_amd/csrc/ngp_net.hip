@@ -461,6 +461,135 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
 #undef CO
 }
 
+// ---- encode + both MLPs in ONE kernel (tiled layout, inference) -------------------------------------------------------------------------
+// The encoder is bound by the texture-address path and loses nothing down to 5 waves per SIMD; its MFMA units idle.  Here a wave encodes one
+// ROW of the tiled layout (64 samples, lane = pixel of the tile, all 16 levels) into registers, the two lane halves trade half of their feature
+// dwords with 8 v_permlane32_swap -- after which the four 16-byte feature groups ARE the first-layer B fragments of two 32-sample MFMA tiles
+// (tile A = pixels 0-31: groups 0 and 2, tile B = pixels 32-63: groups 1 and 3; the same fragment-major order k_grid_encode writes to memory)
+// -- and runs the MLP chain of k_ngp_mlp on them, one tile after the other.  No feature buffer (128 B per sample of HBM traffic), no second
+// kernel; the matrix work of one wave runs in the shadow of the other waves' gathers.
+template <int SRC>
+__global__ void __launch_bounds__(256, 4) k_encode_mlp(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ table, GridCfg g, int narrow_levels,
+                                                       const h8* __restrict__ ray_sh, const __half* __restrict__ Wd, const __half* __restrict__ Wc,
+                                                       __half* __restrict__ packed) {
+    static_assert(SRC == SRC_TILED, "tiled layout only");
+    enum { F_D0 = 0, F_DO = 4, F_C0 = 8, F_C1 = 12, F_CO = 20, N_FRAG = 24 };
+    __shared__ h8 wlds[N_FRAG][64];
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    for (int f = threadIdx.x >> 6; f < N_FRAG; f += 4) {
+        h8 v;
+        if (f < F_DO) v = load_w_frag<false>(Wd, 32, 64, (f - F_D0) >> 1, (f - F_D0) & 1, r, hh);
+        else if (f < F_C0) v = load_w_frag<true>(Wd + 64 * 32, 64, 16, 0, f - F_DO, r, hh);
+        else if (f < F_C1) {
+            const int mt = (f - F_C0) >> 1, sk = (f - F_C0) & 1;
+            v = sk == 0 ? load_w_frag<false>(Wc, 32, 64, mt, 0, r, hh) : load_w_frag<true>(Wc, 32, 64, mt, 1, r, hh);
+        } else if (f < F_CO) v = load_w_frag<true>(Wc + 64 * 32, 64, 64, (f - F_C1) >> 2, (f - F_C1) & 3, r, hh);
+        else v = load_w_frag<true>(Wc + 64 * 32 + 64 * 64, 64, 16, 0, f - F_CO, r, hh);
+        wlds[f][lane] = v;
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
+    const int64_t n_rows = (n + 63) / 64;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave0; row < n_rows; row += n_waves) {
+        const int64_t j = row * 64 + lane;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        const bool live = j < n && fetch_pos<SRC>(in, base + j, px, py, pz);
+        const unsigned long long live_mask = __ballot(live);
+        if (live_mask == 0ull) continue;  // a row of holes
+        uint32_t G0[4] = {0u, 0u, 0u, 0u}, G1[4] = {0u, 0u, 0u, 0u}, G2[4] = {0u, 0u, 0u, 0u}, G3[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+        for (int grp = 0; grp < 4; grp++) {
+            uint32_t v[4] = {0u, 0u, 0u, 0u};
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int level = 4 * grp + q;
+                    Corner8 c;
+                    float f0, f1;
+                    if (g.hashed[level]) grid_corners_u<true>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
+                    else grid_corners_u<false>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
+                    if (level < narrow_levels) grid_level_features_narrow(trs, c, f0, f1);
+                    else if (g.hashed[level]) grid_level_features_hashed(trs, c, f0, f1);
+                    else grid_level_features(trs, c, f0, f1);
+                    const __half2 h = __floats2half2_rn(f0, f1);
+                    v[q] = *reinterpret_cast<const uint32_t*>(&h);
+                    asm volatile("" : "+v"(v[q]));
+                }
+            }
+            // wave-uniform group index: the four groups live in named registers
+            if (grp == 0) { G0[0] = v[0]; G0[1] = v[1]; G0[2] = v[2]; G0[3] = v[3]; }
+            else if (grp == 1) { G1[0] = v[0]; G1[1] = v[1]; G1[2] = v[2]; G1[3] = v[3]; }
+            else if (grp == 2) { G2[0] = v[0]; G2[1] = v[1]; G2[2] = v[2]; G2[3] = v[3]; }
+            else { G3[0] = v[0]; G3[1] = v[1]; G3[2] = v[2]; G3[3] = v[3]; }
+        }
+        // lanes 32-63 of G0 / G2 <-> lanes 0-31 of G1 / G3: lane 32 + r receives pixel r's groups 1 and 3 (k-half hh = 1 of tile A), lane r
+        // receives pixel 32 + r's groups 0 and 2 (k-half hh = 0 of tile B)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const auto s01 = __builtin_amdgcn_permlane32_swap(G0[q], G1[q], false, false);
+            G0[q] = s01[0]; G1[q] = s01[1];
+            const auto s23 = __builtin_amdgcn_permlane32_swap(G2[q], G3[q], false, false);
+            G2[q] = s23[0]; G3[q] = s23[1];
+        }
+        const int32_t rt = in.row_tile[(base + row * 64) >> 6];
+#pragma unroll 1
+        for (int u = 0; u < 2; u++) {
+            uint4 b0, b1;
+            if (u == 0) { b0 = make_uint4(G0[0], G0[1], G0[2], G0[3]); b1 = make_uint4(G2[0], G2[1], G2[2], G2[3]); }
+            else { b0 = make_uint4(G1[0], G1[1], G1[2], G1[3]); b1 = make_uint4(G3[0], G3[1], G3[2], G3[3]); }
+            const bool valid = (live_mask >> (32 * u + r)) & 1ull;
+            if (__ballot(valid) == 0ull) continue;
+            h8 B[2], X[2], H[4];
+            f16v acc[2], o;
+            B[0] = *reinterpret_cast<const h8*>(&b0);
+            B[1] = *reinterpret_cast<const h8*>(&b1);
+            X[0] = ray_sh[((int64_t)rt * 2 + hh) * 64 + 32 * u + r];
+            acc[0] = zero16(); acc[1] = zero16(); o = zero16();
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int sk = 0; sk < 2; sk++) acc[mt] = NRC_MFMA(wlds[F_D0 + 2 * mt + sk][lane], B[sk], acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
+#pragma unroll
+            for (int sk = 0; sk < 4; sk++) o = NRC_MFMA(wlds[F_DO + sk][lane], H[sk], o);
+            X[1] = acc_to_frag(o, 0);
+            const _Float16 h0 = X[1][0];
+            acc[0] = zero16(); acc[1] = zero16();
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int sk = 0; sk < 2; sk++) acc[mt] = NRC_MFMA(wlds[F_C0 + 2 * mt + sk][lane], X[sk], acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
+            acc[0] = zero16(); acc[1] = zero16();
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int sk = 0; sk < 4; sk++) acc[mt] = NRC_MFMA(wlds[F_C1 + 4 * mt + sk][lane], H[sk], acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
+            o = zero16();
+#pragma unroll
+            for (int sk = 0; sk < 4; sk++) o = NRC_MFMA(wlds[F_CO + sk][lane], H[sk], o);
+            if (valid && hh == 0) {
+                h4 pk;
+                pk[0] = h0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) pk[1 + c] = (_Float16)fast_sigmoid(o[c]);
+                *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(packed) + 4 * (base + row * 64 + 32 * u + r)) = pk;
+            }
+        }
+    }
+}
+
 __global__ void k_f32_to_f16(const float* __restrict__ src, __half* __restrict__ dst, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
@@ -526,6 +655,26 @@ static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void
                        hashed_mode);
 }
 
+template <int SRC>
+static void launch_encode_mlp(const QueryIn& in, int64_t base, int64_t n, const void* table, const GridCfg& g, const void* ray_sh, const void* wd,
+                              const void* wc, void* packed, hipStream_t s) {
+    int narrow = 0;
+    while (narrow < NRC_MAX_LEVELS && !g.hashed[narrow] && g.size[narrow] > 8) narrow++;
+    // persistent waves: a workgroup stages the 24 KB of weight fragments once and walks rows with a stride
+    const int64_t rows = nrc_cdiv(n, 64);
+    const int64_t want = nrc_cdiv(rows, 4);
+    const unsigned blocks = (unsigned)(want < 256 * 6 ? (want > 0 ? want : 1) : 256 * 6);
+    hipLaunchKernelGGL(k_encode_mlp<SRC>, dim3(blocks), dim3(256), 0, s, in, base, n, (const __half2*)table, g, narrow, (const h8*)ray_sh,
+                       (const __half*)wd, (const __half*)wc, (__half*)packed);
+}
+// NRC_QUERY_FUSED=1 selects k_encode_mlp.  Measured on the 800x800 bench: 65.1-65.4 Mrays/s against 66.9-67.0 for the two kernels through the
+// feature buffer (77 VGPRs, 6 waves per SIMD; prefetching the SH fragments across the encoding: 100 VGPRs, 63.3; staggered workgroup
+// starts: 64.1-65.0) -- the fused kernel costs the SUM of the two kernels, the matrix phase does not hide behind the other waves' gathers.
+// Kept as an experiment switch (and covered by a parity test), not the default.
+static bool query_fused_kernel() {
+    static const bool v = [] { const char* e = getenv("NRC_QUERY_FUSED"); return e && e[0] == '1'; }();
+    return v;
+}
 static int mlp_tiles_per_wave() {
     static const int v = [] { const char* e = getenv("NRC_MLP_NT"); return (e && e[0] == '1') ? 1 : 2; }();
     return v;
@@ -552,6 +701,9 @@ static int run_query(const QueryIn& in, int64_t M, int64_t n_ray_tiles, const vo
         hipLaunchKernelGGL(k_ray_sh, dim3((unsigned)nrc_cdiv(n_ray_tiles * 64, 256)), dim3(256), 0, s, in.ray_od, n_ray_tiles, ray_sh);
     for (int64_t base = 0; base < M; base += NRC_QUERY_CHUNK) {
         const int64_t n = (M - base) < NRC_QUERY_CHUNK ? (M - base) : NRC_QUERY_CHUNK;
+        if constexpr (SRC == SRC_TILED) {
+            if (query_fused_kernel()) { launch_encode_mlp<SRC>(in, base, n, table, g, ray_sh, wd, wc, packed, s); continue; }
+        }
         launch_encode<SRC>(in, base, n, table, g, feat, s);
         launch_mlp<SRC>(in, base, n, feat, ray_sh, wd, wc, sigmas, rgbs, packed, s);
     }
@@ -761,8 +913,12 @@ int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float*
     do {
         const int64_t cn = (M - base) < NRC_QUERY_CHUNK ? (M - base) : NRC_QUERY_CHUNK;
         if (cn > 0) {
-            launch_encode<SRC_TILED>(in, base, cn, table_f16, g, feat, s);
-            launch_mlp<SRC_TILED>(in, base, cn, feat, ray_sh, density_weights_f16, color_weights_f16, nullptr, nullptr, packed_f16, s);
+            if (query_fused_kernel()) {
+                launch_encode_mlp<SRC_TILED>(in, base, cn, table_f16, g, ray_sh, density_weights_f16, color_weights_f16, packed_f16, s);
+            } else {
+                launch_encode<SRC_TILED>(in, base, cn, table_f16, g, feat, s);
+                launch_mlp<SRC_TILED>(in, base, cn, feat, ray_sh, density_weights_f16, color_weights_f16, nullptr, nullptr, packed_f16, s);
+            }
         }
         nrc_launch_composite_layers(packed_f16, ts, ray_cnt, tile_rows, tile_off, row_of, (base + cn) / 64, width, height, tile_begin, n_ray_tiles, cascades,
                                     exp_step_factor, grid_size, max_samples, T_threshold, bg3_host, state, ray_alive, next_k, tile_alive, rgb, alpha, depth,

@@ -132,3 +132,24 @@ def test_gs_million_gaussians_gradients_are_stable_and_local(gs):
     color, _, tt, _ = _gs_render(gs, t, grad=True)
     color.backward(2.0 * g)
     assert float((tt['opacities'].grad - 2.0 * grads[0]['opacities']).abs().max()) <= 4e-5 * float(grads[0]['opacities'].abs().max())
+
+
+def test_fused_encode_mlp_kernel_paints_the_same_image():
+    """NRC_QUERY_FUSED=1 (one kernel: encode into registers, 8 v_permlane32_swap, MLP chain) against the default two kernels through the feature
+    buffer, in a subprocess because the switch is read once per process: same fp16 features, same MFMA chain -> the same picture bit for bit."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        'import sys, hashlib, torch; sys.path.insert(0, "."); import bench\n'
+        'm, r, cam, poses = bench.build_scene(torch.device("cuda", 0))\n'
+        'o = r.render_image_fused(cam, poses[4], early_termination=False)\n'
+        'print(hashlib.sha1(o["rgb"].cpu().numpy().tobytes() + o["alpha"].cpu().numpy().tobytes()).hexdigest())\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ('0', '1'):
+        env = dict(os.environ, NRC_QUERY_FUSED=flag)
+        res = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(res.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
