@@ -322,10 +322,18 @@ int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int3
  *            per call (16-byte aligned pointers take the vector path).  bias_correction_k = 1 - beta_k^step (host).  adam_w_mode = 0: L2
  *            weight decay added to the gradient (apex ADAM_MODE_0), 1: decoupled.  grad_scale / found_inf: optional DEVICE
  *            scalars of torch.amp.GradScaler (gradient divided by *grad_scale; the whole step is skipped when *found_inf != 0).
+ *            bias_corrections_dev (optional DEVICE float[2]) overrides the two host values: nrc_adam_prepare writes it once per
+ *            group and step as 1 - beta^(host_step - *skipped_steps) and advances *skipped_steps when *found_inf != 0, so the
+ *            effective step count stands still on an overflow-skipped step (with apex the scaler does not call step() then)
+ *            without a host read of found_inf.  param_f16_out (optional): the updated parameters are also written as fp16 --
+ *            the compute copy the tinycudann replacement reads (Group 3), which therefore can never go stale after a step.
  * ===================================================================================================== */
+int nrc_adam_prepare(int32_t host_step, float beta1, float beta2, const float* found_inf, int32_t* skipped_steps,
+                     float* bias_corrections, nrc_stream_t stream);
 int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t adam_w_mode, float bias_correction1,
-                  float bias_correction2, const float* grad_scale, const float* found_inf, nrc_stream_t stream);
+                  float bias_correction2, const float* bias_corrections_dev, const float* grad_scale, const float* found_inf,
+                  void* param_f16_out, nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 9 -- mean squared distance to the 3 nearest neighbours (3DGS scale initialisation): replaces simple_knn._C.distCUDA2

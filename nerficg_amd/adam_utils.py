@@ -82,7 +82,7 @@ def gather_param_groups(optimizer: torch.optim.Optimizer, src: torch.Tensor, n_o
     for _, p in groups:
         tensors.append(p.data)
         zero_new.append(False)
-        state = optimizer.state[p]
+        state = optimizer.state.get(p)
         if state:
             for key in _MOMENTS:
                 tensors.append(state[key])
@@ -91,7 +91,7 @@ def gather_param_groups(optimizer: torch.optim.Optimizer, src: torch.Tensor, n_o
     new_params = {}
     for group, old_param in groups:
         new_param = torch.nn.Parameter(next(outs))
-        state = optimizer.state[old_param]
+        state = optimizer.state.get(old_param)
         if state:
             for key in _MOMENTS:
                 state[key] = next(outs)
@@ -109,7 +109,7 @@ def replace_param_group_data(optimizer: torch.optim.Optimizer, new_values: torch
             param = _single_param(group, 'replace_param_group_data')
             param.data = new_values
             if reset_state:
-                state = optimizer.state[param]
+                state = optimizer.state.get(param)
                 if state:
                     for key in _MOMENTS:
                         state[key].zero_()
@@ -135,7 +135,7 @@ def extend_param_groups(optimizer: torch.optim.Optimizer, additional_params: dic
         extension = additional_params.get(group['name'], None)
         if extension is None:
             continue
-        state = optimizer.state[old_param]
+        state = optimizer.state.get(old_param)
         new_param = torch.nn.Parameter(torch.cat((old_param.data, extension), dim=0))
         if state:
             for key in _MOMENTS:
@@ -155,7 +155,7 @@ def reset_state(optimizer: torch.optim.Optimizer, group_names: list[str] | None 
         if group_names is not None and group['name'] not in group_names:
             continue
         param = _single_param(group, 'reset_state')
-        state = optimizer.state[param]
+        state = optimizer.state.get(param)
         if state:
             for key in _MOMENTS:
                 if indices is not None:

@@ -6,7 +6,12 @@ betas, adam_w_mode, weight_decay, bias_correction).
   group like in apex -- so the reference's optimizer-state surgery (src/Optim/adam_utils.py:6-98: prune / extend / sort / reset of
   single-parameter groups) works unchanged;
 * `_step_supports_amp_scaling`: torch.amp.GradScaler hands over its scale and found-inf tensors and the kernel applies them on the
-  device (apex's FusedAdam makes the scaler unscale in a separate pass and sync on found_inf).
+  device (apex's FusedAdam makes the scaler unscale in a separate pass and sync on found_inf).  With apex an overflow-skipped step does not
+  advance the step counter (the scaler never calls step()); here `group['step']` is advanced on the host every call and a device counter
+  of skipped steps is subtracted inside nrc_adam_prepare, so the bias corrections follow the reference's trajectory without a host sync
+  (`effective_step(group)` reads the corrected count back);
+* a parameter that belongs to a nerficg_amd.tinycudann module gets its fp16 compute copy rewritten by the same kernel and its version
+  counter bumped, so the next forward can neither see stale weights nor pay a separate conversion pass.
 Kernel: nerficg_amd/csrc/adam.hip through the C ABI (include/nerficg_hip.h group 8).
 """
 from __future__ import annotations
@@ -31,6 +36,12 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self.adam_w_mode = 1 if adam_w_mode else 0
         self.set_grad_none = set_grad_none
+        self._amp = {}  # group index -> (skipped-step counter i32[1], bias corrections f32[2]) on the device, GradScaler runs only
+
+    def effective_step(self, group) -> int:
+        """Step count that entered the bias corrections: group['step'] minus the overflow-skipped steps (host read, for tests / logging)."""
+        entry = self._amp.get(self.param_groups.index(group))
+        return group.get('step', 0) - (int(entry[0].item()) if entry is not None else 0)
 
     def zero_grad(self, set_to_none: bool | None = None):
         super().zero_grad(set_to_none=self.set_grad_none if set_to_none is None else set_to_none)
@@ -44,7 +55,7 @@ class FusedAdam(torch.optim.Optimizer):
         lib = _lib.load()
         grad_scale = getattr(self, 'grad_scale', None)
         found_inf = getattr(self, 'found_inf', None)
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             if not any(p.grad is not None for p in group['params']):
                 continue
             # like apex: one step counter per group, advanced whenever the group has gradients
@@ -54,6 +65,15 @@ class FusedAdam(torch.optim.Optimizer):
                 bc1, bc2 = 1.0 - beta1 ** group['step'], 1.0 - beta2 ** group['step']
             else:
                 bc1 = bc2 = 1.0
+            bc_dev = None
+            if found_inf is not None and group['bias_correction']:
+                entry = self._amp.get(gi)
+                if entry is None or entry[0].device != found_inf.device:
+                    entry = self._amp[gi] = (torch.zeros(1, dtype=torch.int32, device=found_inf.device),
+                                             torch.ones(2, dtype=torch.float32, device=found_inf.device))
+                bc_dev = entry[1]
+                _lib.check(lib.nrc_adam_prepare(int(group['step']), float(beta1), float(beta2), _lib.ptr(found_inf), _lib.ptr(entry[0]),
+                                                _lib.ptr(bc_dev), _lib.stream_of(found_inf)), 'adam_prepare')
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -68,8 +88,15 @@ class FusedAdam(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 for t, name in ((p, 'param'), (state['exp_avg'], 'exp_avg'), (state['exp_avg_sq'], 'exp_avg_sq')):
                     _lib.check_input(t, name, torch.float32)
+                owner = getattr(p, '_nrc_half_owner', None)
+                owner = owner() if owner is not None else None
+                half = owner._half_for_optimizer(p) if owner is not None else None
                 _lib.check(lib.nrc_adam_step(
                     _lib.ptr(p), _lib.ptr(g), _lib.ptr(state['exp_avg']), _lib.ptr(state['exp_avg_sq']), p.numel(), float(group['lr']), float(beta1),
-                    float(beta2), float(group['eps']), float(group['weight_decay']), self.adam_w_mode, float(bc1), float(bc2),
-                    _lib.ptr(grad_scale), _lib.ptr(found_inf), _lib.stream_of(p)), 'adam_step')
+                    float(beta2), float(group['eps']), float(group['weight_decay']), self.adam_w_mode, float(bc1), float(bc2), _lib.ptr(bc_dev),
+                    _lib.ptr(grad_scale), _lib.ptr(found_inf), _lib.ptr(half), _lib.stream_of(p)), 'adam_step')
+                # the kernel writes through a raw pointer: tell autograd (and every version-keyed cache) that p changed
+                torch.autograd.graph.increment_version(p)
+                if owner is not None:
+                    owner._half_written_by_optimizer(p)
         return loss

@@ -3,17 +3,35 @@
 //  src/Methods/GaussianSplatting/Model.py:131-136: six single-tensor parameter groups, eps=1e-15).
 // Pure HBM streaming, 28 B per parameter (p, g, m, v read; p, m, v written); the GradScaler's 1/scale and its found-inf skip are
 // folded in (device scalars, no host round trip), which removes the separate unscale pass of the reference's step.
+// Optional extras of the step: (a) the fp16 compute copy of the parameters that the tinycudann module reads is written by the same
+// kernel (2 B per parameter more, instead of a separate 6 B per parameter conversion pass before the next forward); (b) the bias
+// corrections can come from a device pair written by k_adam_prepare, which holds the step counter back on the device whenever the
+// GradScaler found an overflow (apex: the scaler then skips optimizer.step() altogether, so the count must not advance).
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
 #include "common.h"
 
 namespace {
 
+__global__ void k_adam_prepare(int32_t host_step, float beta1, float beta2, const float* __restrict__ found_inf, int32_t* __restrict__ skipped,
+                               float* __restrict__ bc) {
+    if (threadIdx.x | blockIdx.x) return;
+    int32_t sk = *skipped;
+    if (found_inf && *found_inf != 0.f) *skipped = ++sk;
+    int32_t step = host_step - sk;
+    if (step < 1) step = 1;
+    bc[0] = (float)(1.0 - pow((double)beta1, (double)step));
+    bc[1] = (float)(1.0 - pow((double)beta2, (double)step));
+}
+
 template <bool ALIGNED>
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                                               float lr, float beta1, float beta2, float eps, float weight_decay, int adam_w_mode, float bc1, float bc2,
-                                              const float* __restrict__ grad_scale, const float* __restrict__ found_inf) {
-    if (found_inf && *found_inf != 0.f) return;  // GradScaler: skip the step, keep the state
+                                              const float* __restrict__ bc_dev, const float* __restrict__ grad_scale, const float* __restrict__ found_inf,
+                                              __half* __restrict__ p16) {
+    if (found_inf && *found_inf != 0.f) return;  // GradScaler: skip the step, keep the state (and the fp16 copy, which still matches)
+    if (bc_dev) { bc1 = bc_dev[0]; bc2 = bc_dev[1]; }
     const float inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= n) return;
@@ -49,27 +67,45 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
         for (int k = 0; k < 4; k++)
             if (i0 + k < n) { p[i0 + k] = pv[k]; m[i0 + k] = mv[k]; v[i0 + k] = vv[k]; }
     }
+    if (p16) {  // same rounding as k_f32_to_f16 (round to nearest even)
+        if (full && (((uintptr_t)(p16 + i0)) & 7u) == 0) {
+            __half2 h[2] = {__floats2half2_rn(pv[0], pv[1]), __floats2half2_rn(pv[2], pv[3])};
+            *reinterpret_cast<uint2*>(p16 + i0) = *reinterpret_cast<const uint2*>(h);
+        } else {
+            for (int k = 0; k < 4; k++)
+                if (i0 + k < n) p16[i0 + k] = __float2half_rn(pv[k]);
+        }
+    }
 }
 
 }  // namespace
 
 extern "C" {
 
-int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int32_t adam_w_mode, float bias_correction1, float bias_correction2, const float* grad_scale,
-                  const float* found_inf, nrc_stream_t stream) {
+int nrc_adam_prepare(int32_t host_step, float beta1, float beta2, const float* found_inf, int32_t* skipped_steps, float* bias_corrections,
+                     nrc_stream_t stream) {
     NRC_ENTER();
-    if (n < 0 || !(bias_correction1 > 0.f) || !(bias_correction2 > 0.f)) return NRC_ERR_INVALID;
+    if (host_step < 1 || !skipped_steps || !bias_corrections) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, host_step, beta1, beta2, found_inf, skipped_steps, bias_corrections);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t adam_w_mode, float bias_correction1, float bias_correction2, const float* bias_corrections_dev,
+                  const float* grad_scale, const float* found_inf, void* param_f16_out, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n < 0 || (!bias_corrections_dev && (!(bias_correction1 > 0.f) || !(bias_correction2 > 0.f)))) return NRC_ERR_INVALID;
     if (n == 0) return NRC_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq) return NRC_ERR_INVALID;
     const bool aligned = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) == 0);
     const dim3 grid((unsigned)nrc_cdiv(nrc_cdiv(n, 4), 256));
     if (aligned)
         hipLaunchKernelGGL(k_adam<true>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
-                           (int)adam_w_mode, bias_correction1, bias_correction2, grad_scale, found_inf);
+                           (int)adam_w_mode, bias_correction1, bias_correction2, bias_corrections_dev, grad_scale, found_inf, (__half*)param_f16_out);
     else
         hipLaunchKernelGGL(k_adam<false>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
-                           (int)adam_w_mode, bias_correction1, bias_correction2, grad_scale, found_inf);
+                           (int)adam_w_mode, bias_correction1, bias_correction2, bias_corrections_dev, grad_scale, found_inf, (__half*)param_f16_out);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -66,25 +66,32 @@ def shard_range(n: int, rank: int | None = None, world: int | None = None) -> tu
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def _has_tensor_collectives() -> bool:
+    """reduce_scatter_tensor / all_gather_into_tensor exist on RCCL ("nccl"); gloo has all_reduce only.  Decided from the backend NAME, once
+    per call site and identically on every rank -- never by catching an exception from a collective: a rank-local failure would send that
+    rank alone into another collective and leave the job desynchronised."""
+    return dist.get_backend() != 'gloo'
+
+
 def allreduce_flat(buf: torch.Tensor, average: bool = True) -> torch.Tensor:
     """In-place sum (or mean) of a flat contiguous tensor over all ranks as reduce-scatter + all-gather (each of the 7 xGMI
-    links of a GPU then carries 1/world of the payload); falls back to all_reduce where the backend lacks the tensor forms."""
+    links of a GPU then carries 1/world of the payload); one all_reduce on gloo.  Errors of a collective propagate."""
     rank, world = world_info()
     if world == 1:
+        return buf
+    if not _has_tensor_collectives():
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if average:
+            buf.div_(world)
         return buf
     n = buf.numel()
     pad = (-n) % world
     work = buf if pad == 0 else torch.cat([buf, buf.new_zeros(pad)])
     shard = torch.empty(work.numel() // world, dtype=work.dtype, device=work.device)
-    try:
-        dist.reduce_scatter_tensor(shard, work, op=dist.ReduceOp.SUM)
-        if average:
-            shard.div_(world)
-        dist.all_gather_into_tensor(work, shard)
-    except (RuntimeError, NotImplementedError):
-        dist.all_reduce(work, op=dist.ReduceOp.SUM)
-        if average:
-            work.div_(world)
+    dist.reduce_scatter_tensor(shard, work, op=dist.ReduceOp.SUM)
+    if average:
+        shard.div_(world)
+    dist.all_gather_into_tensor(work, shard)
     if pad:
         buf.copy_(work[:n])
     return buf

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import weakref
 
 import torch
 
@@ -175,11 +176,30 @@ class NetworkWithInputEncoding(torch.nn.Module):
         self.params = torch.nn.Parameter(torch.cat(chunks).to(torch.float32), requires_grad=True)
         self._half = None
         self._half_key = None
+        # nerficg_amd.apex_optimizers.FusedAdam updates `params` through a raw pointer: it finds this module through the parameter and
+        # has the step kernel rewrite the fp16 copy as well (_half_for_optimizer / _half_written_by_optimizer)
+        self.params._nrc_half_owner = weakref.ref(self)
+
+    @staticmethod
+    def _key_of(p):
+        return (p.data_ptr(), p._version, p.device)
+
+    def _half_for_optimizer(self, p):
+        """fp16 copy for the Adam kernel to rewrite (None if `p` is not this module's live CUDA parameter). The copy is brought up to date
+        first, because an overflow-skipped step leaves it untouched."""
+        if p is not self.params or not p.is_cuda:
+            return None
+        self._refresh_half()
+        return self._half
+
+    def _half_written_by_optimizer(self, p) -> None:
+        if p is self.params and self._half is not None:
+            self._half_key = self._key_of(p)
 
     # fp16 compute copy of the fp32 master parameters, refreshed when the parameter tensor changes
     def _refresh_half(self) -> None:
         p = self.params
-        key = (p.data_ptr(), p._version, p.device)
+        key = self._key_of(p)
         if self._half is None or self._half_key != key:
             if not p.is_cuda:
                 raise RuntimeError('nerficg_amd.tinycudann: parameters must live on the GPU (no CPU fallback)')

@@ -64,6 +64,37 @@ def test_fused_adam_with_grad_scaler_and_inf_skip():
     scaler.scale(loss).backward()
     scaler.step(opt); scaler.update(); opt.zero_grad()
     assert torch.equal(tp.detach(), before) and scaler.get_scale() == 64.0  # step skipped on the device, scale backed off
+    # the skipped call must not count (apex: the scaler never calls step() on an overflow): the next step is step 2 of the oracle
+    assert opt.param_groups[0]['step'] == 2 and opt.effective_step(opt.param_groups[0]) == 1
+    loss = (tp * x).sum()
+    scaler.scale(loss).backward()
+    scaler.step(opt); scaler.update(); opt.zero_grad()
+    p2, _, _ = oracle.adam_step(p, x.cpu().numpy() * 64.0, m, v, 2, 1e-2, (0.9, 0.99), 1e-15, grad_scale=64.0)
+    np.testing.assert_allclose(tp.detach().cpu().numpy(), p2, rtol=2e-6, atol=2e-7)
+    assert opt.effective_step(opt.param_groups[0]) == 2
+
+
+def test_fused_adam_bumps_the_version_counter_and_feeds_the_tinycudann_half_copy():
+    """The step kernel writes through a raw pointer: caches keyed on the parameter version (nerficg_amd.tinycudann) must still see it."""
+    from nerficg_amd.apex_optimizers import FusedAdam
+    from nerficg_amd.tinycudann import NetworkWithInputEncoding
+    net = NetworkWithInputEncoding(3, 16, {'otype': 'Grid', 'type': 'Hash', 'n_levels': 16, 'n_features_per_level': 2, 'log2_hashmap_size': 15,
+                                           'base_resolution': 16, 'per_level_scale': 1.5},
+                                   {'otype': 'FullyFusedMLP', 'activation': 'ReLU', 'output_activation': 'None', 'n_neurons': 64, 'n_hidden_layers': 1},
+                                   seed=3).to(DEV)
+    opt = FusedAdam(net.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
+    x = torch.rand(1000, 3, device=DEV)
+    y0 = net(x).float()
+    v0 = net.params._version
+    y0.square().sum().backward()
+    opt.step()
+    assert net.params._version > v0
+    assert torch.equal(net._half_params(), net.params.detach().half())  # written by the step kernel, same rounding as the conversion pass
+    assert not torch.equal(net(x).float(), y0.detach())
+    # a parameter without a module behind it: version bump only
+    q = torch.nn.Parameter(torch.rand(10, device=DEV)); q.grad = torch.ones_like(q)
+    o2 = FusedAdam([q], lr=1e-2); v = q._version; o2.step()
+    assert q._version > v
 
 
 def test_param_group_surgery_like_adam_utils():

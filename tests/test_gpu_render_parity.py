@@ -131,19 +131,28 @@ def test_inference_loop_with_fused_query_matches(setup):
     assert (outs[0]['rgb'] - outs[1]['rgb']).abs().max().item() <= 2e-3
 
 
-def test_training_iterations_reduce_loss(setup):
-    """InstantNGP/Trainer.py:79-94 call sequence (autocast, random bg, GradScaler 128, Adam eps 1e-15) on a constant-colour target."""
+@pytest.mark.parametrize('optimizer', ['torch_adam', 'fused_adam'])
+def test_training_iterations_reduce_loss(setup, optimizer):
+    """InstantNGP/Trainer.py:79-94 call sequence (autocast, random bg, GradScaler 128, Adam eps 1e-15) on a constant-colour target, with
+    torch.optim.Adam and with the shipped apex replacement (Trainer.py:33-38) -- whose kernel writes the parameters through a raw pointer
+    and therefore has to keep the fp16 compute copy of the tinycudann modules fresh itself."""
     from nerficg_amd.instant_ngp import InstantNGPRenderer
+    from nerficg_amd.apex_optimizers import FusedAdam
     model = make_model(seed=9, table_amp=1e-4)
     renderer = InstantNGPRenderer(model)
     cam = make_camera(64, 64)
     from nerficg_amd.raygen import generate_rays
     rays = generate_rays(64, 64, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y, scenes.orbit_pose(0.5, 0.3, scenes.LEGO_RADIUS), want_direction=False)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99))
+    if optimizer == 'fused_adam':
+        opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99))
     scaler = torch.amp.GradScaler(init_scale=128.0, growth_interval=10 ** 6)
     target = torch.tensor([0.8, 0.3, 0.1], device=DEV)
     losses = []
     torch.manual_seed(0)
+    probe = torch.rand(512, 3, device=DEV)
+    first_forward = model.encoding_xyz(probe).float().clone()
     for it in range(30):
         with torch.amp.autocast('cuda'):
             bg = torch.rand(3, device=DEV)
@@ -156,7 +165,12 @@ def test_training_iterations_reduce_loss(setup):
         opt.zero_grad()
         losses.append(loss.item())
         assert int(out['rm_samples'].item()) > 0
+        if it == 0:  # ONE optimizer step must change what the network computes
+            assert not torch.equal(model.encoding_xyz(probe).float(), first_forward)
     assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses
+    # the fp16 compute copy equals a fresh conversion of the trained fp32 master parameters
+    for net in (model.encoding_xyz, model.color_mlp_with_encoding):
+        assert torch.equal(net._half_params(), net.params.detach().half())
 
 
 def test_update_occupancy_grid_runs_and_packs(setup):
