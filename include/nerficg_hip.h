@@ -97,6 +97,11 @@ int nrc_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
 int nrc_composite_test_fw(const float* sigmas, const float* rgbs, const float* deltas, const float* ts,
                           int64_t* alive_indices, int64_t n_alive, int32_t N_samples, float T_threshold,
                           const int32_t* N_eff_samples, float* opacity, float* depth, float* rgb, nrc_stream_t stream);
+/* Backward of raymarching_train w.r.t. the rays (the reference does this in Python with torch_scatter.segment_csr,
+ * custom_functions.py:122-137): row n of rays_a = (ray, start, count) gets dL_drays_o[n] = sum dL_dxyzs[start:start+count] and
+ * dL_drays_d[n] = sum (ts * dL_dxyzs + dL_ddirs)[start:start+count].  dL_ddirs may be NULL (no gradient reached the directions). */
+int nrc_raymarching_train_bw(const float* dL_dxyzs, const float* dL_ddirs, const float* ts, const int64_t* rays_a, int64_t n_rays,
+                             int64_t n_samples, float* dL_drays_o, float* dL_drays_d, nrc_stream_t stream);
 /* binding.cpp:197-209 -> losses.cu:64-109 */
 int nrc_distortion_loss_fw(const float* ws, const float* deltas, const float* ts, const int64_t* rays_a, int64_t n_rays,
                            int64_t n_samples, float* loss, float* ws_inclusive_scan, float* wts_inclusive_scan,
@@ -396,6 +401,27 @@ int64_t nrc_occupancy_update_ws_bytes(int64_t n_cells_total);
 int nrc_occupancy_update(float* grid, const int64_t* cell_indices, const void* densities, int32_t densities_dtype, int32_t cascades,
                          int64_t cells_per_cascade, int64_t samples_per_cascade, float decay, float density_threshold,
                          uint8_t* bitfield, float* threshold_out, void* workspace, nrc_stream_t stream);
+/* Which cells are re-queried and where (src/Methods/InstantNGP/Renderer.py:183-206 cell choice, :251-258 positions): mode 0 = every cell
+ * of every cascade (warm-up; per cascade grid_size^3 entries in Morton order), mode 1 = per cascade n_per_half cells drawn uniformly from
+ * the grid followed by n_per_half cells drawn uniformly from occupied_indices[c * occupied_stride + [0, occupied_counts[c])) (Morton
+ * indices of the cells with grid > threshold, e.g. from nrc_compact_mask; a cascade without any gets ignored entries, index -1).
+ * cell_indices (cascades, per) i64 Morton indices, points (cascades * per, 3) f32 = box-centred query positions
+ * ((coord / (G-1)) * 2 - 1) * (s - s/G) + U(-1,1) * s/G with s = min(2^(c-1), scale).  seed: DEVICE pointer to one i64; the draws are a pure
+ * function of it (counter-based generator), so no host synchronisation and no dependence on the launch geometry. */
+int nrc_occupancy_draw_cells(int32_t cascades, int32_t grid_size, float scale, int32_t mode, int64_t n_per_half, const int64_t* seed,
+                             const int32_t* occupied_indices, const int32_t* occupied_counts, int64_t occupied_stride,
+                             int64_t* cell_indices, float* points, nrc_stream_t stream);
+/* Frustum / alpha-mask carving (Renderer.py:208-245).  remaining (cascades, G^3) u8, cell (x,y,z) at x + G*(y + G*z), initialised by the
+ * caller to `subtractive`; one call per view: remaining = remaining OR seen (AND when subtractive), seen = the cell centre projects inside
+ * the image (world -> camera (p - position) @ R, Datasets/utils.py:1027-1031; pinhole Perspective.py:39-52) with near < depth < far and,
+ * when alpha_mask (height, width) f32 on the device is given, some pixel of the 3x3 neighbourhood of the hit pixel has alpha > 0.
+ * c2w_rotation9 / position3 / center3 are HOST arrays.  nrc_occupancy_carve_finish dilates the survivors by one cell (3x3x3) and
+ * writes grid[c][morton(x,y,z)] = 0 for them and -1 (never sampled again) for the rest. */
+int nrc_occupancy_carve_view(uint8_t* remaining, int32_t cascades, int32_t grid_size, float scale, const float* center3,
+                             const float* c2w_rotation9, const float* position3, float focal_x, float focal_y, float center_x,
+                             float center_y, int32_t width, int32_t height, float near_plane, float far_plane,
+                             const float* alpha_mask, int32_t subtractive, nrc_stream_t stream);
+int nrc_occupancy_carve_finish(const uint8_t* remaining, int32_t cascades, int32_t grid_size, float* grid, nrc_stream_t stream);
 
 #ifdef __cplusplus
 }

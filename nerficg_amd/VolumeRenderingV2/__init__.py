@@ -209,105 +209,130 @@ def distortion_loss_bw(dL_dloss, ws_inclusive_scan, wts_inclusive_scan, ws, delt
 
 
 # ----------------------------------------------------------------------------------------------- autograd layer
-class RayAABBIntersector(torch.autograd.Function):
-    """custom_functions.py:8-32."""
+# The six classes the reference star-imports from custom_functions.py (names, positional `apply` arguments and outputs are the interface the
+# reference's Renderer.py:41-78 and Optim/Losses/Distortion.py:5-9 call).  Everything behind `apply` is this package's own: every backward is
+# one C-ABI call (the ray gradients of the march included -- no torch_scatter), outputs that carry no gradient are marked so, and RayMarcher
+# takes an optional trailing `noise` so that data-parallel ranks can slice ONE seeded jitter vector (nerficg_amd.parallel).
+def _dense(grad, like, shape=None):
+    """Upstream gradient as a contiguous f32 tensor; autograd hands over None for outputs nothing depended on."""
+    if grad is None:
+        return torch.zeros(shape if shape is not None else like.shape, dtype=_f32, device=like.device)
+    return grad.to(_f32).contiguous()
+
+
+class _Intersector(torch.autograd.Function):
+    """Ray / primitive hit lists (custom_functions.py:8-58): pure index / interval outputs, nothing differentiable."""
+    op = None
+
+    @classmethod
+    def _run(cls, ctx, rays_o, rays_d, center, extent, max_hits):
+        hit_cnt, hits_t, hits_idx = cls.op(rays_o, rays_d, center, extent, max_hits)
+        ctx.mark_non_differentiable(hit_cnt, hits_t, hits_idx)
+        return hit_cnt, hits_t, hits_idx
 
     @staticmethod
-    @custom_fwd(cast_inputs=torch.float32, device_type='cuda')
+    def backward(ctx, *_):
+        return (None,) * 5
+
+
+class RayAABBIntersector(_Intersector):
+    op = staticmethod(ray_aabb_intersect)
+
+    @staticmethod
+    @custom_fwd(cast_inputs=_f32, device_type='cuda')
     def forward(ctx, rays_o, rays_d, center, half_size, max_hits):
-        return tuple(ray_aabb_intersect(rays_o, rays_d, center, half_size, max_hits))
+        return RayAABBIntersector._run(ctx, rays_o, rays_d, center, half_size, max_hits)
 
 
-class RaySphereIntersector(torch.autograd.Function):
-    """custom_functions.py:35-58."""
+class RaySphereIntersector(_Intersector):
+    op = staticmethod(ray_sphere_intersect)
 
     @staticmethod
-    @custom_fwd(cast_inputs=torch.float32, device_type='cuda')
+    @custom_fwd(cast_inputs=_f32, device_type='cuda')
     def forward(ctx, rays_o, rays_d, center, radii, max_hits):
-        return tuple(ray_sphere_intersect(rays_o, rays_d, center, radii, max_hits))
-
-
-def _segment_sum(src: torch.Tensor, rays_a: torch.Tensor) -> torch.Tensor:
-    """CSR segmented sum over the per-ray sample segments (the reference uses torch_scatter.segment_csr,
-    custom_functions.py:131-135; its indptr construction assumes rays_a rows are stored in segment order, which
-    holds here by construction)."""
-    n = rays_a.shape[0]
-    out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
-    seg = torch.repeat_interleave(torch.arange(n, device=src.device), rays_a[:, 2])
-    out.index_add_(0, seg, src)
-    return out
+        return RaySphereIntersector._run(ctx, rays_o, rays_d, center, radii, max_hits)
 
 
 class RayMarcher(torch.autograd.Function):
-    """custom_functions.py:61-137."""
+    """Training-batch sample generation (custom_functions.py:61-137): -> (rays_a, xyzs, dirs, deltas, ts, total_samples).  The first sample of
+    a ray is jittered by dt * noise; `noise` defaults to one torch.rand draw per ray on the rays' device."""
 
     @staticmethod
-    @custom_fwd(cast_inputs=torch.float32, device_type='cuda')
-    def forward(ctx, rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, grid_size, max_samples):
-        noise = torch.rand_like(rays_o[:, 0])
-        rays_a, xyzs, dirs, deltas, ts, counter = raymarching_train(
-            rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, noise, grid_size, max_samples)
-        total_samples = counter[0]
+    @custom_fwd(cast_inputs=_f32, device_type='cuda')
+    def forward(ctx, rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, grid_size, max_samples, noise=None):
+        if noise is None:
+            noise = torch.rand(rays_o.shape[0], dtype=_f32, device=rays_o.device)
+        rays_a, xyzs, dirs, deltas, ts, counter = raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor,
+                                                                    noise.contiguous(), grid_size, max_samples)
+        n_marched = counter[0]
+        ctx.mark_non_differentiable(rays_a, deltas, ts, n_marched)
         ctx.save_for_backward(rays_a, ts)
-        return rays_a, xyzs, dirs, deltas, ts, total_samples
+        return rays_a, xyzs, dirs, deltas, ts, n_marched
 
     @staticmethod
     @custom_bwd(device_type='cuda')
-    def backward(ctx, dL_drays_a, dL_dxyzs, dL_ddirs, dL_ddeltas, dL_dts, dL_dtotal_samples):
+    def backward(ctx, _g_rays_a, g_xyzs, g_dirs, _g_deltas, _g_ts, _g_count):
         rays_a, ts = ctx.saved_tensors
-        dL_drays_o = _segment_sum(dL_dxyzs, rays_a)
-        dL_drays_d = _segment_sum(dL_dxyzs * ts[:, None] + dL_ddirs, rays_a)
-        return dL_drays_o, dL_drays_d, None, None, None, None, None, None, None
+        n, m = rays_a.shape[0], ts.shape[0]
+        g_o = torch.zeros(n, 3, dtype=_f32, device=ts.device)
+        g_d = torch.zeros(n, 3, dtype=_f32, device=ts.device)
+        if n and m and (g_xyzs is not None or g_dirs is not None):
+            _lib.check(_lib.load().nrc_raymarching_train_bw(
+                _lib.ptr(_dense(g_xyzs, ts, (m, 3))), _lib.ptr(None if g_dirs is None else _dense(g_dirs, ts)), _lib.ptr(ts), _lib.ptr(rays_a), n, m,
+                _lib.ptr(g_o), _lib.ptr(g_d), _lib.stream_of(ts)), 'raymarching_train_bw')
+        return (g_o, g_d) + (None,) * 8
 
 
 class VolumeRenderer(torch.autograd.Function):
-    """custom_functions.py:140-194."""
+    """Front-to-back compositing of a training batch (custom_functions.py:140-194): -> (n composited samples, opacity, depth, rgb, ws)."""
 
     @staticmethod
-    @custom_fwd(cast_inputs=torch.float32, device_type='cuda')
+    @custom_fwd(cast_inputs=_f32, device_type='cuda')
     def forward(ctx, sigmas, rgbs, deltas, ts, rays_a, T_threshold):
-        total_samples, opacity, depth, rgb, ws = composite_train_fw(sigmas, rgbs, deltas, ts, rays_a, T_threshold)
-        ctx.save_for_backward(sigmas, rgbs, deltas, ts, rays_a, opacity, depth, rgb, ws)
-        ctx.T_threshold = T_threshold
-        return total_samples.sum(), opacity, depth, rgb, ws
+        per_ray_count, opacity, depth, rgb, ws = composite_train_fw(sigmas, rgbs, deltas, ts, rays_a, T_threshold)
+        n_composited = per_ray_count.sum()
+        ctx.mark_non_differentiable(n_composited)
+        ctx.cutoff = float(T_threshold)
+        ctx.save_for_backward(sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb)
+        return n_composited, opacity, depth, rgb, ws
 
     @staticmethod
     @custom_bwd(device_type='cuda')
-    def backward(ctx, dL_dtotal_samples, dL_dopacity, dL_ddepth, dL_drgb, dL_dws):
-        sigmas, rgbs, deltas, ts, rays_a, opacity, depth, rgb, ws = ctx.saved_tensors
-        dL_dsigmas, dL_drgbs = composite_train_bw(
-            dL_dopacity.contiguous(), dL_ddepth.contiguous(), dL_drgb.contiguous(), dL_dws.contiguous(), sigmas, rgbs, ws,
-            deltas, ts, rays_a, opacity, depth, rgb, ctx.T_threshold)
-        return dL_dsigmas, dL_drgbs, None, None, None, None
+    def backward(ctx, _g_count, g_opacity, g_depth, g_rgb, g_ws):
+        sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb = ctx.saved_tensors
+        g_sigmas, g_rgbs = composite_train_bw(_dense(g_opacity, opacity), _dense(g_depth, depth), _dense(g_rgb, rgb), _dense(g_ws, ws), sigmas, rgbs, ws,
+                                              deltas, ts, rays_a, opacity, depth, rgb, ctx.cutoff)
+        return g_sigmas, g_rgbs, None, None, None, None
 
 
 class TruncExp(torch.autograd.Function):
-    """custom_functions.py:197-208: fwd exp(x), bwd g * exp(clamp(x, -15, 15))."""
+    """Density activation (custom_functions.py:197-208): exp forward; the backward evaluates exp on the argument clamped to [-15, 15], which
+    keeps fp16-scaled gradients finite."""
+    LIMIT = 15.0
 
     @staticmethod
-    @custom_fwd(cast_inputs=torch.float32, device_type='cuda')
+    @custom_fwd(cast_inputs=_f32, device_type='cuda')
     def forward(ctx, x):
         ctx.save_for_backward(x)
-        return torch.exp(x)
+        return x.exp()
 
     @staticmethod
     @custom_bwd(device_type='cuda')
-    def backward(ctx, dL_dout):
-        x = ctx.saved_tensors[0]
-        return dL_dout * torch.exp(x.clamp(-15, 15))
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return x.clamp(-TruncExp.LIMIT, TruncExp.LIMIT).exp_().mul_(g)
 
 
 class DistortionLoss(torch.autograd.Function):
-    """custom_functions.py:211-252."""
+    """Mip-NeRF 360 distortion regulariser per ray (custom_functions.py:211-252); gradient reaches the weights only."""
 
     @staticmethod
     def forward(ctx, ws, deltas, ts, rays_a):
-        loss, ws_inclusive_scan, wts_inclusive_scan = distortion_loss_fw(ws, deltas, ts, rays_a)
-        ctx.save_for_backward(ws_inclusive_scan, wts_inclusive_scan, ws, deltas, ts, rays_a)
+        loss, ws_scan, wts_scan = distortion_loss_fw(ws, deltas, ts, rays_a)
+        ctx.save_for_backward(ws_scan, wts_scan, ws, deltas, ts, rays_a)
         return loss
 
     @staticmethod
-    def backward(ctx, dL_dloss):
-        ws_inclusive_scan, wts_inclusive_scan, ws, deltas, ts, rays_a = ctx.saved_tensors
-        dL_dws = distortion_loss_bw(dL_dloss.contiguous(), ws_inclusive_scan, wts_inclusive_scan, ws, deltas, ts, rays_a)
-        return dL_dws, None, None, None
+    def backward(ctx, g_loss):
+        ws_scan, wts_scan, ws, deltas, ts, rays_a = ctx.saved_tensors
+        return distortion_loss_bw(_dense(g_loss, ws, (rays_a.shape[0],)), ws_scan, wts_scan, ws, deltas, ts, rays_a), None, None, None

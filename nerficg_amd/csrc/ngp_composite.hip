@@ -77,6 +77,33 @@ __global__ void __launch_bounds__(256) k_composite_train_fw(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ ray gradients of the training march
+// x_i = o + t_i d  and  dir_i = d  for the samples i of a ray: dL/do = sum_i dL/dx_i,  dL/dd = sum_i (t_i dL/dx_i + dL/ddir_i)
+// (custom_functions.py:122-137 builds the same sums with torch_scatter.segment_csr).  One wave per row of rays_a, coalesced 768-byte reads.
+__global__ void __launch_bounds__(256) k_march_train_bw(const float* __restrict__ g_xyzs, const float* __restrict__ g_dirs, const float* __restrict__ ts,
+                                                        const int64_t* __restrict__ rays_a, int64_t n_rays, float* __restrict__ g_o, float* __restrict__ g_d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_rays) return;
+    const int64_t start = rays_a[3 * n + 1];
+    const int N = (int)rays_a[3 * n + 2];
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    for (int i = lane; i < N; i += 64) {
+        const int64_t s = start + i;
+        const float t = ts[s];
+        const float gx = g_xyzs[3 * s], gy = g_xyzs[3 * s + 1], gz = g_xyzs[3 * s + 2];
+        ox += gx; oy += gy; oz += gz;
+        dx += gx * t; dy += gy * t; dz += gz * t;
+        if (g_dirs) { dx += g_dirs[3 * s]; dy += g_dirs[3 * s + 1]; dz += g_dirs[3 * s + 2]; }
+    }
+    ox = nrc_group_sum<64>(ox); oy = nrc_group_sum<64>(oy); oz = nrc_group_sum<64>(oz);
+    dx = nrc_group_sum<64>(dx); dy = nrc_group_sum<64>(dy); dz = nrc_group_sum<64>(dz);
+    if (lane == 0) {
+        g_o[3 * n] = ox; g_o[3 * n + 1] = oy; g_o[3 * n + 2] = oz;
+        g_d[3 * n] = dx; g_d[3 * n + 1] = dy; g_d[3 * n + 2] = dz;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ train backward
 __global__ void __launch_bounds__(256) k_composite_train_bw(
     const float* __restrict__ dL_dopacity, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_drgb,
@@ -411,6 +438,18 @@ void nrc_launch_composite_layers(const void* packed, const float* ts, const int3
 }
 
 extern "C" {
+
+int nrc_raymarching_train_bw(const float* dL_dxyzs, const float* dL_ddirs, const float* ts, const int64_t* rays_a, int64_t n_rays, int64_t n_samples,
+                             float* dL_drays_o, float* dL_drays_d, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_rays < 0 || n_samples < 0) return NRC_ERR_INVALID;
+    if (n_rays == 0) return NRC_OK;
+    if (!rays_a || !dL_drays_o || !dL_drays_d || (n_samples > 0 && (!dL_dxyzs || !ts))) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_march_train_bw, dim3(nrc_cdiv(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, dL_dxyzs, dL_ddirs, ts, rays_a, n_rays, dL_drays_o,
+                       dL_drays_d);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
 
 int nrc_composite_train_fw(const float* sigmas, const float* rgbs, const float* deltas, const float* ts, const int64_t* rays_a,
                            int64_t n_rays, int64_t n_samples, float T_threshold, int64_t* total_samples, float* opacity,

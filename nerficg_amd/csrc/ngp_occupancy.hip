@@ -87,6 +87,120 @@ __global__ void __launch_bounds__(256) k_occ_pack(const float* __restrict__ grid
                        ((b.z > thr) << 6) | ((b.w > thr) << 7));
 }
 
+// ------------------------------------------------------------------------------------------------ cell sampling for the update
+// Which cells get a fresh density this round (Renderer.py:183-206): every cell (warm-up), or n uniformly drawn cells + n cells drawn
+// uniformly from the currently occupied ones (grid > threshold) per cascade; and where inside its cell each one is queried
+// (Renderer.py:251-258: cell centre lattice (c / (G-1) * 2 - 1) * (s - s/G), jitter U(-1,1) * s/G).  One lane per drawn cell, counter-based
+// generator (splitmix64 of seed and draw number) -- the draws are a pure function of *seed, whatever the launch geometry.
+__device__ __forceinline__ uint32_t occ_expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu; v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t occ_compact_bits(uint32_t x) {
+    x &= 0x49249249u; x = (x | (x >> 2)) & 0xC30C30C3u; x = (x | (x >> 4)) & 0x0F00F00Fu; x = (x | (x >> 8)) & 0xFF0000FFu; x = (x | (x >> 16)) & 0x0000FFFFu;
+    return x;
+}
+__device__ __forceinline__ uint64_t occ_mix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float occ_unit(uint32_t bits24) { return (float)(bits24 & 0xFFFFFFu) * (1.0f / 16777216.0f); }  // [0, 1)
+
+__global__ void __launch_bounds__(256) k_occ_draw(int cascades, int G, float scale, int mode, int64_t n_half, int64_t per_cascade,
+                                                  const int64_t* __restrict__ seed, const int32_t* __restrict__ occ_idx, const int32_t* __restrict__ occ_cnt,
+                                                  int64_t occ_stride, int64_t* __restrict__ indices, float* __restrict__ points) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)cascades * per_cascade) return;
+    const int c = (int)(e / per_cascade);
+    const int64_t k = e - (int64_t)c * per_cascade;
+    const uint64_t base = occ_mix((uint64_t)seed[0] ^ ((uint64_t)e * 0xD1342543DE82EF95ull));
+    const uint64_t r0 = occ_mix(base), r1 = occ_mix(base + 1), r2 = occ_mix(base + 2);
+    uint32_t x, y, z;
+    int64_t cell;
+    if (mode == 0) {            // all cells, in Morton order
+        cell = k;
+        x = occ_compact_bits((uint32_t)k); y = occ_compact_bits((uint32_t)k >> 1); z = occ_compact_bits((uint32_t)k >> 2);
+    } else if (k < n_half) {    // uniform over the grid
+        x = (uint32_t)(((r0 & 0xFFFFFFFFull) * (uint64_t)G) >> 32); y = (uint32_t)(((r0 >> 32) * (uint64_t)G) >> 32);
+        z = (uint32_t)(((r1 & 0xFFFFFFFFull) * (uint64_t)G) >> 32);
+        cell = (int64_t)(occ_expand_bits(x) | (occ_expand_bits(y) << 1) | (occ_expand_bits(z) << 2));
+    } else {                    // uniform over the occupied cells of this cascade (none: an ignored entry)
+        const int cnt = occ_cnt[c];
+        if (cnt <= 0) { indices[e] = -1; points[3 * e] = points[3 * e + 1] = points[3 * e + 2] = 0.f; return; }
+        const uint32_t pick = (uint32_t)(((r1 >> 32) * (uint64_t)cnt) >> 32);
+        cell = occ_idx[(int64_t)c * occ_stride + pick];
+        x = occ_compact_bits((uint32_t)cell); y = occ_compact_bits((uint32_t)cell >> 1); z = occ_compact_bits((uint32_t)cell >> 2);
+    }
+    const float s = fminf(scalbnf(1.0f, c - 1), scale);
+    const float half_cell = s / (float)G;
+    const float inv = 1.0f / (float)(G - 1);
+    const float jx = occ_unit((uint32_t)r2) * 2.f - 1.f, jy = occ_unit((uint32_t)(r2 >> 24)) * 2.f - 1.f, jz = occ_unit((uint32_t)(r2 >> 40)) * 2.f - 1.f;
+    indices[e] = cell;
+    points[3 * e] = ((float)x * inv * 2.f - 1.f) * (s - half_cell) + jx * half_cell;
+    points[3 * e + 1] = ((float)y * inv * 2.f - 1.f) * (s - half_cell) + jy * half_cell;
+    points[3 * e + 2] = ((float)z * inv * 2.f - 1.f) * (s - half_cell) + jz * half_cell;
+}
+
+// ------------------------------------------------------------------------------------------------ carving
+// Renderer.py:208-245: a cell survives when a camera sees its centre (optionally: through a pixel of the 3x3-dilated alpha mask); union over
+// the views (or intersection, "subtractive"); the survivors are dilated by one cell and everything else is frozen at -1.
+struct CarveView {
+    float R[9];       // camera-to-world rotation, row-major
+    float pos[3];     // camera position
+    float fx, fy, cx, cy, width, height, near_plane, far_plane;
+};
+
+__global__ void __launch_bounds__(256) k_carve_view(uint8_t* __restrict__ remaining, int cascades, int G, float scale, float cen_x, float cen_y, float cen_z,
+                                                    CarveView v, const float* __restrict__ alpha, int alpha_w, int alpha_h, int subtractive) {
+    const int64_t cells = (int64_t)G * G * G;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= cascades * cells) return;
+    const int c = (int)(e / cells);
+    const int64_t k = e - c * cells;
+    const int x = (int)(k % G), y = (int)((k / G) % G), z = (int)(k / ((int64_t)G * G));
+    const float s = fminf(scalbnf(1.0f, c - 1), scale);
+    const float half_cell = s / (float)G, inv = 1.0f / (float)(G - 1);
+    const float wx = ((float)x * inv * 2.f - 1.f) * (s - half_cell) + cen_x - v.pos[0];
+    const float wy = ((float)y * inv * 2.f - 1.f) * (s - half_cell) + cen_y - v.pos[1];
+    const float wz = ((float)z * inv * 2.f - 1.f) * (s - half_cell) + cen_z - v.pos[2];
+    // world -> camera: (p - position) @ R  (Datasets/utils.py:1027-1031)
+    const float px = wx * v.R[0] + wy * v.R[3] + wz * v.R[6];
+    const float py = wx * v.R[1] + wy * v.R[4] + wz * v.R[7];
+    const float depth = wx * v.R[2] + wy * v.R[5] + wz * v.R[8];
+    const float zc = fmaxf(depth, 1.0e-8f);
+    const float sx = px / zc * v.fx + v.cx, sy = py / zc * v.fy + v.cy;
+    bool seen = sx >= 0.f && sy >= 0.f && sx < v.width && sy < v.height && depth > v.near_plane && depth < v.far_plane;
+    if (seen && alpha) {
+        const int ix = (int)floorf(sx), iy = (int)floorf(sy);
+        bool lit = false;
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int qx = ix + dx, qy = iy + dy;
+                if (qx >= 0 && qy >= 0 && qx < alpha_w && qy < alpha_h) lit |= alpha[(int64_t)qy * alpha_w + qx] > 0.f;
+            }
+        seen = lit;
+    }
+    remaining[e] = subtractive ? (uint8_t)(remaining[e] && seen) : (uint8_t)(remaining[e] || seen);
+}
+
+__global__ void __launch_bounds__(256) k_carve_finish(const uint8_t* __restrict__ remaining, int cascades, int G, float* __restrict__ grid) {
+    const int64_t cells = (int64_t)G * G * G;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= cascades * cells) return;
+    const int c = (int)(e / cells);
+    const int64_t k = e - c * cells;
+    const int x = (int)(k % G), y = (int)((k / G) % G), z = (int)(k / ((int64_t)G * G));
+    const uint8_t* r = remaining + c * cells;
+    bool keep = false;
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int qx = x + dx, qy = y + dy, qz = z + dz;
+                if (qx >= 0 && qy >= 0 && qz >= 0 && qx < G && qy < G && qz < G) keep |= r[qx + (int64_t)G * (qy + (int64_t)G * qz)] != 0;
+            }
+    grid[c * cells + (occ_expand_bits((uint32_t)x) | (occ_expand_bits((uint32_t)y) << 1) | (occ_expand_bits((uint32_t)z) << 2))] = keep ? 0.f : -1.f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -124,6 +238,47 @@ int nrc_occupancy_update(float* grid, const int64_t* cell_indices, const void* d
     hipLaunchKernelGGL(k_occ_ema, dim3(nblk), dim3(OCC_THREADS), 0, st, grid, scratch, n_cells, decay, partial_sum, partial_cnt);
     hipLaunchKernelGGL(k_occ_threshold, dim3(1), dim3(256), 0, st, partial_sum, partial_cnt, nblk, density_threshold, threshold_out);
     hipLaunchKernelGGL(k_occ_pack, dim3((unsigned)nrc_cdiv(n_cells / 8, 256)), dim3(256), 0, st, grid, n_cells / 8, threshold_out, bitfield);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_occupancy_draw_cells(int32_t cascades, int32_t grid_size, float scale, int32_t mode, int64_t n_per_half, const int64_t* seed,
+                             const int32_t* occupied_indices, const int32_t* occupied_counts, int64_t occupied_stride, int64_t* cell_indices,
+                             float* points, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (cascades < 1 || grid_size < 2 || grid_size > 1024 || (mode != 0 && mode != 1) || !seed || !cell_indices || !points) return NRC_ERR_INVALID;
+    if (mode == 1 && (n_per_half < 0 || !occupied_indices || !occupied_counts)) return NRC_ERR_INVALID;
+    const int64_t per = mode == 0 ? (int64_t)grid_size * grid_size * grid_size : 2 * n_per_half;
+    if (per == 0) return NRC_OK;
+    hipLaunchKernelGGL(k_occ_draw, dim3((unsigned)nrc_cdiv(cascades * per, 256)), dim3(256), 0, (hipStream_t)stream, (int)cascades, (int)grid_size, scale,
+                       (int)mode, n_per_half, per, seed, occupied_indices, occupied_counts, occupied_stride, cell_indices, points);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_occupancy_carve_view(uint8_t* remaining, int32_t cascades, int32_t grid_size, float scale, const float* center3, const float* c2w_rotation9,
+                             const float* position3, float focal_x, float focal_y, float center_x, float center_y, int32_t width, int32_t height,
+                             float near_plane, float far_plane, const float* alpha_mask, int32_t subtractive, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (!remaining || cascades < 1 || grid_size < 2 || grid_size > 1024 || !center3 || !c2w_rotation9 || !position3 || width < 1 || height < 1)
+        return NRC_ERR_INVALID;
+    CarveView v;
+    for (int i = 0; i < 9; i++) v.R[i] = c2w_rotation9[i];
+    for (int i = 0; i < 3; i++) v.pos[i] = position3[i];
+    v.fx = focal_x; v.fy = focal_y; v.cx = center_x; v.cy = center_y; v.width = (float)width; v.height = (float)height;
+    v.near_plane = near_plane; v.far_plane = far_plane;
+    const int64_t total = (int64_t)cascades * grid_size * grid_size * grid_size;
+    hipLaunchKernelGGL(k_carve_view, dim3((unsigned)nrc_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, remaining, (int)cascades, (int)grid_size, scale,
+                       center3[0], center3[1], center3[2], v, alpha_mask, (int)width, (int)height, (int)subtractive);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_occupancy_carve_finish(const uint8_t* remaining, int32_t cascades, int32_t grid_size, float* grid, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (!remaining || !grid || cascades < 1 || grid_size < 2 || grid_size > 1024) return NRC_ERR_INVALID;
+    const int64_t total = (int64_t)cascades * grid_size * grid_size * grid_size;
+    hipLaunchKernelGGL(k_carve_finish, dim3((unsigned)nrc_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, remaining, (int)cascades, (int)grid_size, grid);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

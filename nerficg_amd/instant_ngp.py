@@ -1,13 +1,19 @@
-"""nerficg_amd.instant_ngp -- host-side mirror of the reference's InstantNGP method for the hot path
-(src/Methods/InstantNGP/Model.py, src/Methods/InstantNGP/Renderer.py), written against nerficg_amd's drop-in modules.
+"""nerficg_amd.instant_ngp -- host side of the InstantNGP hot path on top of libnerficg_hip.so.
 
-Same class / method / attribute names and argument meaning as the reference, minus its Framework plumbing (config
-objects, View/RayBatch dataclasses): rays are plain (N,3) tensors, cameras are the small `Camera` record below.  The
-reference's own method package keeps working unchanged when its native imports are redirected; this
-mirror exists so that parity tests and bench.py can drive the identical call sequence on a box without the reference.
+The reference's method package (src/Methods/InstantNGP/{Model,Renderer}.py) keeps running unchanged over nerficg_amd/shims;
+this module is NOT a copy of it.  It is the host code this repository needs for itself -- tests, bench.py, the data-parallel tools -- with
+the reference's configuration keys and method names where a caller would look for them, and its own structure underneath:
 
-On top of the mirrored op-by-op path, `InstantNGPRenderer.render_image_fused` is the MI355X-native restructuring of
-render_image (no ray tensors, no per-iteration host syncs) -- it must produce the same image (tests/test_gpu_render_parity.py).
+  InstantNGPModel        the parameters and buffers of Model.py:14-123 (same yaml keys, same flat parameter vectors, same buffers).
+  InstantNGPRenderer     render_rays(train)  : box test -> deterministic march (optional explicit jitter, so that data-parallel ranks can slice
+                                               one seeded vector) -> ONE autograd node for both networks -> wave-per-ray compositing.
+                         render_rays(eval)   : an arbitrary ray list in chunks: march everything, query everything, composite with the
+                                               early-out (the reference's alive-ray loop, Renderer.py:86-138, produces the same pixels; that
+                                               loop's two ops raymarching_test / composite_test_fw stay in the C ABI for the reference's own
+                                               Renderer.py and are tested against the oracle directly).
+                         render_image[_fused]: the tile-interleaved device pipeline (include/nerficg_hip.h group 6), one host sync.
+                         update_occupancy_grid / carve_occupancy_grid: cell choice, query positions, EMA, threshold, packing and carving
+                                               are device ops (group 11); nothing is read back.
 """
 from __future__ import annotations
 
@@ -21,6 +27,7 @@ import torch
 from . import VolumeRenderingV2 as VolumeRenderingCuda
 from . import _lib
 from . import tinycudann as tcnn
+from .ngp import query_fused, query_train
 from .raygen import generate_rays
 
 
@@ -108,128 +115,107 @@ class InstantNGPModel(torch.nn.Module):
         return loss / self.n_mlp_params
 
 
-class InstantNGPRayRenderingComponent(torch.nn.Module):
-    """src/Methods/InstantNGP/Renderer.py:19-138"""
-
-    def __init__(self, model: InstantNGPModel) -> None:
-        super().__init__()
-        self.model = model
-        self.fused_training_query = True
-        self._box_host = None
-
-    def forward(self, origin: torch.Tensor, view_direction: torch.Tensor, camera: Camera, max_samples: int, bg_color: torch.Tensor,
-                exponential_steps: bool, train_mode: bool) -> dict[str, torch.Tensor]:
-        rays_o = origin - self.model.center
-        rays_d = view_direction.contiguous()
-        hits_t = VolumeRenderingCuda.RayAABBIntersector.apply(rays_o, rays_d, torch.zeros((1, 3), device=rays_o.device), self.model.half_size, 1)[1]
-        hits_t[..., 0].clamp_min_(camera.near_plane)
-        hits_t[..., 1].clamp_max_(camera.far_plane)
-        exp_step_factor = 1 / 256 if exponential_steps else 0.0
-        render_fn = self.render_rays_training if train_mode else self.render_rays_inference
-        return render_fn(rays_o, rays_d, hits_t, max_samples, bg_color, exp_step_factor)
-
-    def query_model(self, x: torch.Tensor, d: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
-        m = self.model
-        if self.fused_training_query and torch.is_grad_enabled() and m.encoding_xyz.params.requires_grad and x.dtype == torch.float32:
-            # one autograd node for the whole statement sequence below (same arithmetic; nerficg_amd.ngp.query_train)
-            from .ngp import query_train
-            if self._box_host is None:
-                self._box_host = (m.xyz_min.detach().float().cpu().contiguous(), m.xyz_size.detach().float().cpu().contiguous())
-            return query_train(m.encoding_xyz, m.color_mlp_with_encoding, x, d, *self._box_host)
-        h = self.model.encoding_xyz((x - self.model.xyz_min) / self.model.xyz_size)
-        sigmas = VolumeRenderingCuda.TruncExp.apply(h[:, 0])
-        rgbs = self.model.color_mlp_with_encoding(torch.cat([(d * 0.5 + 0.5).to(h.dtype), h], dim=-1))
-        return sigmas, rgbs
-
-    def query_density(self, x: torch.Tensor) -> torch.Tensor:
-        h = self.model.encoding_xyz((x - self.model.xyz_min) / self.model.xyz_size)
-        return VolumeRenderingCuda.TruncExp.apply(h[:, 0])
-
-    @torch.amp.autocast('cuda')
-    def render_rays_training(self, rays_o, rays_d, hits_t, max_samples, bg_color, exp_step_factor) -> dict[str, torch.Tensor]:
-        rays_a, xyzs, dirs, deltas, ts, rm_samples = VolumeRenderingCuda.RayMarcher.apply(
-            rays_o, rays_d, hits_t[:, 0], self.model.occupancy_bitfield, self.model.cascades, self.model.SCALE, exp_step_factor,
-            self.model.RESOLUTION, max_samples)
-        sigmas, rgbs = self.query_model(xyzs, dirs)
-        vr_samples, alpha, depth, rgb, ws = VolumeRenderingCuda.VolumeRenderer.apply(sigmas, rgbs.contiguous(), deltas, ts, rays_a, 1e-4)
-        rgb = rgb + bg_color * (1 - alpha[:, None])
-        depth = depth / (alpha + 1e-6)
-        return {'rgb': rgb, 'alpha': alpha, 'depth': depth, 'rm_samples': rm_samples}
-
-    @torch.no_grad()
-    def render_rays_inference(self, rays_o, rays_d, hits_t, max_samples, bg_color, exp_step_factor, fused_query: bool = False) -> dict[str, torch.Tensor]:
-        """Renderer.py:86-138, statement for statement.  `fused_query` swaps query_model for the single-kernel equivalent."""
-        n_rays = len(rays_o)
-        device = rays_o.device
-        rgb = torch.zeros(n_rays, 3, device=device)
-        alpha = torch.zeros(n_rays, device=device)
-        depth = torch.zeros(n_rays, device=device)
-        alive_indices = torch.arange(n_rays, device=device)
-        min_samples = 1 if exp_step_factor == 0 else 4
-        samples = 0
-        hits = hits_t[:, 0]
-        while samples < max_samples:
-            n_alive = len(alive_indices)
-            if n_alive == 0:
-                break
-            n_samples = max(min(n_rays // n_alive, 64), min_samples)
-            samples += n_samples
-            xyzs, dirs, deltas, ts, n_eff_samples = VolumeRenderingCuda.raymarching_test(
-                rays_o, rays_d, hits, alive_indices, self.model.occupancy_bitfield, self.model.cascades, self.model.SCALE,
-                exp_step_factor, self.model.RESOLUTION, max_samples, n_samples)
-            xyzs = xyzs.reshape(-1, 3)
-            dirs = dirs.reshape(-1, 3)
-            valid_mask = (dirs != 0).any(dim=1)
-            if valid_mask.sum() == 0:
-                break
-            sigmas = torch.zeros(len(xyzs), device=device)
-            rgbs = torch.zeros(len(xyzs), 3, device=device)
-            if fused_query:
-                from .ngp import query_fused
-                x01 = ((xyzs[valid_mask] - self.model.xyz_min) / self.model.xyz_size).contiguous()
-                _sigmas, _rgbs = query_fused(self.model.encoding_xyz, self.model.color_mlp_with_encoding, x01, dirs[valid_mask].contiguous())
-            else:
-                with torch.amp.autocast('cuda'):
-                    _sigmas, _rgbs = self.query_model(xyzs[valid_mask], dirs[valid_mask])
-            sigmas[valid_mask], rgbs[valid_mask] = _sigmas.float(), _rgbs.float()
-            sigmas = sigmas.reshape(-1, n_samples)
-            rgbs = rgbs.reshape(-1, n_samples, 3)
-            VolumeRenderingCuda.composite_test_fw(sigmas, rgbs, deltas, ts, hits, alive_indices, 1e-4, n_eff_samples, alpha, depth, rgb)
-            alive_indices = alive_indices[alive_indices >= 0]
-        alpha.clamp_(0, 1)
-        transmittance = 1 - alpha
-        rgb += transmittance[:, None] * bg_color
-        rgb.clamp_(0, 1)
-        depth = torch.where(transmittance < 1.0, depth / alpha, 0.0)
-        return {'rgb': rgb, 'alpha': alpha, 'depth': depth}
-
-
 class InstantNGPRenderer:
-    """src/Methods/InstantNGP/Renderer.py:141-272 (MAX_SAMPLES / EXPONENTIAL_STEPS / DENSITY_THRESHOLD defaults :141-145)."""
+    """Rendering + occupancy maintenance for an InstantNGPModel.  Configuration keys as in src/Methods/InstantNGP/Renderer.py:141-145."""
+
+    RAY_CHUNK = 1 << 16        # rays per pass of the ray-list inference path
+    T_THRESHOLD = 1e-4         # transmittance below which a ray is finished (Renderer.py:79,127)
 
     def __init__(self, model: InstantNGPModel, MAX_SAMPLES: int = 1024, EXPONENTIAL_STEPS: bool = False, DENSITY_THRESHOLD: float = 0.01) -> None:
         self.model = model
         self.MAX_SAMPLES, self.EXPONENTIAL_STEPS, self.DENSITY_THRESHOLD = MAX_SAMPLES, EXPONENTIAL_STEPS, DENSITY_THRESHOLD
-        self.ray_rendering_component = InstantNGPRayRenderingComponent(model)
         self.density_threshold = DENSITY_THRESHOLD * MAX_SAMPLES / 3 ** 0.5
         self._fused_ws: dict = {}
+        self._box_host = None
+        self._zero_center = torch.zeros(1, 3, device=model.center.device)
         # fused image path: the count pass parks the samples in a max_samples-row arena per tile (2.6 GB at 800x800) and the write pass
         # copies them instead of marching every ray twice; False = second march, no arena
         self.provisional_march = True
 
-    def render_rays(self, origin, view_direction, camera: Camera, train_mode: bool = False, custom_bg_color: torch.Tensor | None = None):
-        bg = custom_bg_color if custom_bg_color is not None else camera.background_color.to(origin.device)
-        return self.ray_rendering_component(origin, view_direction, camera, self.MAX_SAMPLES, bg, self.EXPONENTIAL_STEPS, train_mode)
+    # ---------------------------------------------------------------- the two networks
+    def _box(self):
+        if self._box_host is None:
+            m = self.model
+            self._box_host = (m.xyz_min.detach().float().cpu().contiguous(), m.xyz_size.detach().float().cpu().contiguous())
+        return self._box_host
+
+    def query(self, xyzs: torch.Tensor, dirs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """(density, colour) of box-centred sample positions seen along unit directions.  With autograd on: one node that reaches both
+        parameter vectors (nerficg_amd.ngp.query_train); otherwise the two-kernel inference query."""
+        m = self.model
+        if torch.is_grad_enabled() and m.encoding_xyz.params.requires_grad:
+            return query_train(m.encoding_xyz, m.color_mlp_with_encoding, xyzs, dirs, *self._box())
+        unit = ((xyzs.float() - m.xyz_min) / m.xyz_size).contiguous()
+        return query_fused(m.encoding_xyz, m.color_mlp_with_encoding, unit, dirs.float().contiguous())
+
+    @torch.no_grad()
+    def density(self, xyzs: torch.Tensor) -> torch.Tensor:
+        """exp (in f32) of the first output of the density network at box-centred positions."""
+        m = self.model
+        return m.encoding_xyz((xyzs - m.xyz_min) / m.xyz_size)[:, 0].float().exp()
+
+    # ---------------------------------------------------------------- rays
+    def clip_rays(self, origin: torch.Tensor, view_direction: torch.Tensor, camera: Camera):
+        """Box-centred origins, contiguous directions and the [t_in, t_out] interval of every ray inside the scene box, clipped to the
+        camera's depth range (a miss is (-1, -1) before clipping and yields no sample)."""
+        o = (origin - self.model.center).contiguous()
+        d = view_direction.contiguous()
+        span = VolumeRenderingCuda.ray_aabb_intersect(o, d, self._zero_center, self.model.half_size, 1)[1][:, 0]
+        span[:, 0].clamp_(min=camera.near_plane)
+        span[:, 1].clamp_(max=camera.far_plane)
+        return o, d, span
+
+    def render_rays(self, origin: torch.Tensor, view_direction: torch.Tensor, camera: Camera, train_mode: bool = False,
+                    custom_bg_color: torch.Tensor | None = None, noise: torch.Tensor | None = None) -> dict[str, torch.Tensor]:
+        """rgb / alpha / depth (+ 'rm_samples' when training) for a list of rays.  `noise` (one value in [0,1) per ray) replaces the
+        training jitter draw."""
+        bg = (custom_bg_color if custom_bg_color is not None else camera.background_color).to(origin.device)
+        step_growth = 1 / 256 if self.EXPONENTIAL_STEPS else 0.0
+        o, d, span = self.clip_rays(origin.float(), view_direction.float(), camera)
+        if train_mode:
+            return self._render_training_batch(o, d, span, bg, step_growth, noise)
+        return self._render_ray_list(o, d, span, bg, step_growth)
+
+    def _march(self, o, d, span, step_growth, jitter):
+        m = self.model
+        return VolumeRenderingCuda.raymarching_train(o, d, span, m.occupancy_bitfield, m.cascades, m.SCALE, step_growth, jitter, m.RESOLUTION,
+                                                     self.MAX_SAMPLES)
+
+    def _render_training_batch(self, o, d, span, bg, step_growth, noise):
+        jitter = torch.rand(o.shape[0], device=o.device) if noise is None else noise.to(torch.float32).contiguous()
+        rays_a, xyzs, dirs, deltas, ts, counter = self._march(o, d, span, step_growth, jitter)
+        sigmas, rgbs = self.query(xyzs, dirs)
+        _, alpha, depth_sum, radiance, _ = VolumeRenderingCuda.VolumeRenderer.apply(sigmas, rgbs.contiguous(), deltas, ts, rays_a, self.T_THRESHOLD)
+        see_through = (1 - alpha)[:, None]
+        # training depth: weighted mean with a guarded denominator (Renderer.py:82)
+        return {'rgb': radiance + see_through * bg, 'alpha': alpha, 'depth': depth_sum / (alpha + 1e-6), 'rm_samples': counter[0]}
+
+    @torch.no_grad()
+    def _render_ray_list(self, o, d, span, bg, step_growth):
+        n = o.shape[0]
+        rgb, alpha, depth = (torch.empty(n, 3, device=o.device), torch.empty(n, device=o.device), torch.empty(n, device=o.device))
+        for lo in range(0, n, self.RAY_CHUNK):
+            hi = min(n, lo + self.RAY_CHUNK)
+            jitter = torch.zeros(hi - lo, device=o.device)
+            rays_a, xyzs, dirs, deltas, ts, _ = self._march(o[lo:hi].contiguous(), d[lo:hi].contiguous(), span[lo:hi].contiguous(), step_growth, jitter)
+            if xyzs.shape[0]:
+                sigmas, rgbs = self.query(xyzs, dirs)
+            else:
+                sigmas, rgbs = torch.empty(0, device=o.device), torch.empty(0, 3, device=o.device)
+            _, a, dsum, rad, _ = VolumeRenderingCuda.composite_train_fw(sigmas, rgbs, deltas, ts, rays_a, self.T_THRESHOLD)
+            a.clamp_(0, 1)
+            rgb[lo:hi] = (rad + (1 - a)[:, None] * bg).clamp_(0, 1)
+            alpha[lo:hi] = a
+            depth[lo:hi] = torch.where(a > 0, dsum / a, torch.zeros_like(a))  # inference depth: plain weighted mean, 0 where nothing was hit (Renderer.py:137)
+        return {'rgb': rgb, 'alpha': alpha, 'depth': depth}
 
     def render_image(self, camera: Camera, c2w: np.ndarray, to_chw: bool = False) -> dict[str, torch.Tensor]:
-        """Renderer.py:172-180: view.get_rays() -> render_rays -> reshape to images."""
-        rays = generate_rays(camera.width, camera.height, camera.focal_x, camera.focal_y, camera.center_x, camera.center_y, c2w,
-                             device=self.model.center.device, want_direction=False)
-        out = self.render_rays(rays['origin'], rays['view_direction'], camera)
-        for key in out:
-            out[key] = out[key].reshape(camera.height, camera.width, -1)
-            if to_chw:
-                out[key] = out[key].permute(2, 0, 1)
+        """(H, W, C) images (or (C, H, W)) of one view through the fused pipeline."""
+        flat = self.render_image_fused(camera, c2w)
+        out = {}
+        for key in ('rgb', 'alpha', 'depth'):
+            img = flat[key].reshape(camera.height, camera.width, -1).clone()
+            out[key] = img.permute(2, 0, 1) if to_chw else img
         return out
 
     # ---------------------------------------------------------------- MI355X-native image pipeline
@@ -350,106 +336,82 @@ class InstantNGPRenderer:
             res['n_samples'] = int(ws['ray_cnt'][:n].sum().item()) if n > 0 else 0
         return res
 
-    # ---------------------------------------------------------------- occupancy grid (Renderer.py:183-206, 247-272)
-    @torch.no_grad()
-    def get_occupancy_grid_cells(self):
-        indices = VolumeRenderingCuda.morton3D(self.model.grid_coords).long()
-        return [(indices, self.model.grid_coords)] * self.model.cascades
-
-    @torch.no_grad()
-    def sample_occupancy_grid(self, n_samples: int, density_threshold: float):
-        cells = []
-        dev = self.model.occupancy_grid.device
-        for c in range(self.model.cascades):
-            coords1 = torch.randint(self.model.RESOLUTION, (n_samples, 3), dtype=torch.int32, device=dev)
-            indices1 = VolumeRenderingCuda.morton3D(coords1).long()
-            indices2 = torch.nonzero(self.model.occupancy_grid[c] > density_threshold)[:, 0]
-            if len(indices2) > 0:
-                rand_idx = torch.randint(len(indices2), (n_samples,), device=dev)
-                indices2 = indices2[rand_idx]
-            coords2 = VolumeRenderingCuda.morton3D_invert(indices2.int())
-            cells += [(torch.cat([indices1, indices2]), torch.cat([coords1, coords2]))]
-        return cells
-
-    @torch.no_grad()
-    @torch.amp.autocast('cuda')
-    def update_occupancy_grid(self, warmup: bool = False, decay: float = 0.95) -> None:
-        """Renderer.py:247-272.  Cell sampling and jitter draw from torch's generator in the reference's order; the densities of ALL
-        cascades come from one network query, and scratch-grid scatter, EMA, masked mean, threshold and bit packing are one C-ABI call
-        (include/nerficg_hip.h group 11) that leaves the threshold on the device (`self.occupancy_threshold`, 2 floats: used, mean) --
-        the reference's `.item()` host sync is gone."""
+    # ---------------------------------------------------------------- occupancy grid
+    def _occupied_cells(self):
+        """Per cascade: ascending Morton indices of the cells above the density threshold + their count, device side (no read-back)."""
         m = self.model
-        cells = self.get_occupancy_grid_cells() if warmup else self.sample_occupancy_grid(m.RESOLUTION ** 3 // 4, self.density_threshold)
-        points = []
-        for c in range(m.cascades):
-            _, coords = cells[c]
-            s = min(2 ** (c - 1), m.SCALE)
-            half_grid_size = s / m.RESOLUTION
-            xyzs_w = (coords / (m.RESOLUTION - 1) * 2 - 1) * (s - half_grid_size)
-            xyzs_w += (torch.rand_like(xyzs_w) * 2 - 1) * half_grid_size
-            points.append(xyzs_w)
-        per_cascade = max(p.shape[0] for p in points)
-        density = self.ray_rendering_component.query_density(torch.cat(points) if len(points) > 1 else points[0]).reshape(-1)
-        if density.dtype not in (torch.float32, torch.float16):
-            density = density.float()
-        dev = m.occupancy_grid.device
-        if all(p.shape[0] == per_cascade for p in points):
-            indices = torch.stack([cells[c][0] for c in range(m.cascades)]).contiguous()
-            density = density.contiguous()
-        else:  # a cascade without occupied cells draws fewer samples: pad with ignored entries (index -1)
-            indices = torch.full((m.cascades, per_cascade), -1, dtype=torch.int64, device=dev)
-            padded = torch.zeros((m.cascades, per_cascade), dtype=density.dtype, device=dev)
-            o = 0
-            for c, p in enumerate(points):
-                indices[c, :p.shape[0]] = cells[c][0]
-                padded[c, :p.shape[0]] = density[o:o + p.shape[0]]
-                o += p.shape[0]
-            density = padded
         lib = _lib.load()
         grid = m.occupancy_grid
+        cells = grid.shape[1]
+        above = (grid > self.density_threshold).contiguous()
+        idx = torch.empty(m.cascades, cells, dtype=torch.int32, device=grid.device)
+        cnt = torch.zeros(m.cascades, dtype=torch.int32, device=grid.device)
+        ws = torch.empty(int(lib.nrc_compact_mask_ws_bytes(cells)), dtype=torch.uint8, device=grid.device)
+        for c in range(m.cascades):
+            _lib.check(lib.nrc_compact_mask(_lib.ptr(above[c]), cells, _lib.ptr(idx[c]), _lib.ptr(cnt[c:]), _lib.ptr(ws), _lib.stream_of(grid)), 'compact_mask')
+        return idx, cnt
+
+    @torch.no_grad()
+    def draw_update_cells(self, warmup: bool, seed: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+        """The cells that get a fresh density this round and one jittered query position inside each (Renderer.py:183-206, 251-258): every
+        cell while warming up, afterwards G^3/4 uniformly drawn cells + G^3/4 drawn from the occupied ones per cascade.  Returns Morton
+        indices (cascades, per) i64 (-1 = ignored entry) and box-centred positions (cascades * per, 3).  `seed`: one i64 on the device
+        (default: a draw from torch's device generator, so torch.manual_seed reproduces the sequence)."""
+        m = self.model
+        lib = _lib.load()
+        dev = m.occupancy_grid.device
+        if seed is None:
+            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=dev)
+        g = m.RESOLUTION
+        n_half = 0 if warmup else g ** 3 // 4
+        per = g ** 3 if warmup else 2 * n_half
+        indices = torch.empty(m.cascades, per, dtype=torch.int64, device=dev)
+        points = torch.empty(m.cascades * per, 3, dtype=torch.float32, device=dev)
+        occ_idx, occ_cnt = (None, None) if warmup else self._occupied_cells()
+        _lib.check(lib.nrc_occupancy_draw_cells(m.cascades, g, float(m.SCALE), 0 if warmup else 1, n_half, _lib.ptr(seed), _lib.ptr(occ_idx),
+                                                _lib.ptr(occ_cnt), g ** 3, _lib.ptr(indices), _lib.ptr(points), _lib.stream_of(points)), 'occupancy_draw_cells')
+        return indices, points
+
+    @torch.no_grad()
+    def update_occupancy_grid(self, warmup: bool = False, decay: float = 0.95) -> None:
+        """One maintenance round (Renderer.py:247-272): draw cells, query their densities in ONE network call, then scatter / EMA / masked
+        mean / threshold / bit packing in one C-ABI call that leaves the threshold on the device (`self.occupancy_threshold`: used, mean)."""
+        m = self.model
+        lib = _lib.load()
+        grid = m.occupancy_grid
+        dev = grid.device
+        indices, points = self.draw_update_cells(warmup)
+        sigma = self.density(points).reshape(-1).contiguous()
         _lib.check_input(grid, 'occupancy_grid', torch.float32)
-        n_cells = grid.numel()
-        ws_bytes = int(lib.nrc_occupancy_update_ws_bytes(n_cells))
+        ws_bytes = int(lib.nrc_occupancy_update_ws_bytes(grid.numel()))
         if getattr(self, '_occ_ws', None) is None or self._occ_ws.numel() < ws_bytes:
             self._occ_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             self.occupancy_threshold = torch.zeros(2, dtype=torch.float32, device=dev)
-        _lib.check(lib.nrc_occupancy_update(_lib.ptr(grid), _lib.ptr(indices), _lib.ptr(density), 0 if density.dtype == torch.float32 else 1, m.cascades,
-                                            grid.shape[1], per_cascade, decay, self.density_threshold, _lib.ptr(m.occupancy_bitfield),
+        _lib.check(lib.nrc_occupancy_update(_lib.ptr(grid), _lib.ptr(indices), _lib.ptr(sigma), 0 if sigma.dtype == torch.float32 else 1, m.cascades,
+                                            grid.shape[1], indices.shape[1], decay, self.density_threshold, _lib.ptr(m.occupancy_bitfield),
                                             _lib.ptr(self.occupancy_threshold), _lib.ptr(self._occ_ws), _lib.stream_of(grid)), 'occupancy_update')
 
     @torch.no_grad()
     def carve_occupancy_grid(self, views, subtractive: bool = False, use_alpha: bool = False) -> None:
-        """Renderer.py:208-245.  `views`: iterable of (Camera, c2w (4,4), alpha (1,H,W) tensor or None) -- the fields of a dataset View the
-        reference reads.  Cells outside every frustum (subtractive=False) / outside any frustum (True) get -1 (never sampled again by
-        update_occupancy_grid), the others 0; the kept set is dilated by one cell (3x3x3)."""
+        """Freezes the cells no training camera can see at -1 (never sampled again) and resets the others to 0 (Renderer.py:208-245).
+        `views`: iterable of (Camera, c2w (4,4), alpha (1,H,W) tensor or None).  Union of the frusta by default, intersection when
+        `subtractive`; with `use_alpha` a cell must also project onto the 3x3-dilated foreground mask.  The survivors are dilated by one cell."""
         m = self.model
+        lib = _lib.load()
         dev = m.occupancy_grid.device
-        cells = self.get_occupancy_grid_cells()
-        cell_positions_world = []
-        for c in range(m.cascades):
-            _, coords = cells[c]
-            s = min(2 ** (c - 1), m.SCALE)
-            half_grid_size = s / m.RESOLUTION
-            cell_positions_world.append((coords / (m.RESOLUTION - 1) * 2 - 1) * (s - half_grid_size) + m.center)
-        remaining_cells = torch.full_like(m.occupancy_grid, fill_value=subtractive, dtype=torch.bool, device=dev)
-        dilation_kernel_2d = torch.ones(1, 1, 3, 3, device=dev)
-        for camera, c2w, alpha_gt in views:
-            if use_alpha and alpha_gt is not None:
-                alpha_gt = torch.nn.functional.conv2d(alpha_gt.to(dev)[None], dilation_kernel_2d, padding=1)[0] > 0.0
-            for c in range(m.cascades):
-                xy_screen, _, in_frustum = project_points(camera, c2w, cell_positions_world[c])
-                if use_alpha and alpha_gt is not None:
-                    xy_screen = torch.floor(xy_screen[in_frustum]).long()
-                    alpha_values = alpha_gt[:, xy_screen[:, 1], xy_screen[:, 0]] > 0.0
-                    in_frustum[in_frustum.clone()] = alpha_values[0]
-                remaining_cells[c] = remaining_cells[c] & in_frustum if subtractive else remaining_cells[c] | in_frustum
-        dilation_kernel_3d = torch.ones(1, 1, 3, 3, 3, device=dev)
-        for c in range(m.cascades):
-            # `remaining_cells[c]` is indexed like grid_coords (x-major meshgrid order), exactly as in the reference
-            dilated = torch.nn.functional.conv3d(remaining_cells[c].reshape(1, 1, m.RESOLUTION, m.RESOLUTION, m.RESOLUTION).float(),
-                                                 dilation_kernel_3d, padding=1)
-            values = torch.where(dilated.flatten() > 0.0, 0.0, -1.0)
-            m.occupancy_grid[c, cells[c][0]] = values
+        g = m.RESOLUTION
+        remaining = torch.full((m.cascades, g ** 3), 1 if subtractive else 0, dtype=torch.uint8, device=dev)
+        f = lambda a: (ctypes.c_float * len(a))(*[float(v) for v in a])
+        center = f(m.center.reshape(-1).tolist())
+        st = _lib.stream_of(remaining)
+        for camera, c2w, alpha in views:
+            pose = np.asarray(c2w, dtype=np.float64)[:4, :4]
+            mask = alpha.to(dev, torch.float32).reshape(camera.height, camera.width).contiguous() if (use_alpha and alpha is not None) else None
+            _lib.check(lib.nrc_occupancy_carve_view(
+                _lib.ptr(remaining), m.cascades, g, float(m.SCALE), ctypes.cast(center, ctypes.c_void_p), ctypes.cast(f(pose[:3, :3].reshape(-1)), ctypes.c_void_p),
+                ctypes.cast(f(pose[:3, 3]), ctypes.c_void_p), float(camera.focal_x), float(camera.focal_y), float(camera.center_x), float(camera.center_y),
+                int(camera.width), int(camera.height), float(camera.near_plane), float(camera.far_plane), _lib.ptr(mask), int(subtractive), st), 'occupancy_carve_view')
+        _lib.check(lib.nrc_occupancy_carve_finish(_lib.ptr(remaining), m.cascades, g, _lib.ptr(m.occupancy_grid), st), 'occupancy_carve_finish')
 
 
 def project_points(camera: Camera, c2w, xyz_world: torch.Tensor, z_culling: bool = True):

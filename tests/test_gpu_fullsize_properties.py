@@ -1,6 +1,8 @@
 """GPU: size-independent properties at the FULL sizes of BASELINE.json's configurations -- the 800x800 InstantNGP image of bench.py
-(640 000 rays, ~77 M samples) and the 1 M-Gaussian 1297x840 3DGS frame -- where no CPU oracle finishes in seconds:
-shards compose, alternative execution orders give the same picture, the background enters linearly, reruns are deterministic."""
+(640 000 rays, ~77 M samples; configs[1]), the 1 M-Gaussian 1297x840 3DGS frame (configs[2]), one of eight tile shards of a 1600x1060
+InstantNGP image plus the data-parallel gradient split of a training batch drawn from it (configs[3]) and the 6 M-Gaussian frame (configs[4]) --
+where no CPU oracle finishes in seconds: shards compose, alternative execution orders give the same picture, the background enters linearly,
+reruns are deterministic, per-rank gradients add up to the single-GPU gradient, culled Gaussians get exactly zero gradient."""
 import numpy as np
 import pytest
 import torch
@@ -70,9 +72,96 @@ def test_ingp_background_enters_linearly(ngp):
     assert float((b['rgb'] - a['rgb'] - want)[unclamped].abs().max()) <= 2e-6
 
 
-@pytest.fixture(scope='module')
-def gs():
-    return bench.build_gs_scene(DEV, 1_000_000)
+# ------------------------------------------------------------------------------------------------ configs[3]: 1600x1060 over 8 ranks
+def _c4_camera(cam):
+    from nerficg_amd.instant_ngp import Camera
+    W, H = 1600, 1060
+    return Camera(width=W, height=H, focal_x=cam.focal_x * W / cam.width, focal_y=cam.focal_x * W / cam.width, center_x=W / 2, center_y=H / 2,
+                  near_plane=cam.near_plane, far_plane=cam.far_plane, background_color=cam.background_color)
+
+
+def test_ingp_c4_tile_shard_equals_its_part_of_the_whole_image(ngp):
+    """BASELINE configs[3]: a 1600x1060 image split into 8 contiguous tile ranges (parallel.shard_range).  Rank 3's shard, rendered alone,
+    is bit-identical to the same pixels of the whole image, leaves every other pixel untouched, and is deterministic."""
+    from nerficg_amd import parallel
+    model, renderer, cam, poses = ngp
+    big = _c4_camera(cam)
+    pose = poses[11]
+    whole = _img(renderer.render_image_fused(big, pose, early_termination=False))
+    assert whole['rgb'].shape == (1600 * 1060, 3) and bool(torch.isfinite(whole['rgb']).all())
+    nt = renderer.n_image_tiles(big)
+    assert nt == 200 * 133
+    b, e = parallel.shard_range(nt, 3, 8)
+    sentinel = {'rgb': torch.full_like(whole['rgb'], -7.0), 'alpha': torch.full_like(whole['alpha'], -7.0), 'depth': torch.full_like(whole['depth'], -7.0)}
+    res = renderer.render_image_fused(big, pose, tile_begin=b, n_tiles=e - b, out=sentinel, return_stats=True, early_termination=False)
+    assert res['n_samples'] > 5e6
+    tiles = torch.arange(b, e, device=DEV)
+    ty, tx = tiles // 200, tiles % 200
+    py = (ty[:, None] * 8 + torch.arange(64, device=DEV)[None] // 8).reshape(-1)
+    px = (tx[:, None] * 8 + torch.arange(64, device=DEV)[None] % 8).reshape(-1)
+    ok = py < 1060
+    pix = (py * 1600 + px)[ok]
+    mine = torch.zeros(1600 * 1060, dtype=torch.bool, device=DEV)
+    mine[pix] = True
+    for k in whole:
+        assert torch.equal(sentinel[k][mine], whole[k][mine]), k
+        assert bool((sentinel[k][~mine] == -7.0).all()), k
+    again = {k: torch.full_like(v, -7.0) for k, v in whole.items()}
+    renderer.render_image_fused(big, pose, tile_begin=b, n_tiles=e - b, out=again, early_termination=False)
+    for k in whole:
+        assert torch.equal(again[k], sentinel[k]), k
+    # all eight shards together: the whole image, bit for bit
+    out = {k: torch.zeros_like(v) for k, v in whole.items()}
+    for r in range(8):
+        b, e = parallel.shard_range(nt, r, 8)
+        renderer.render_image_fused(big, pose, tile_begin=b, n_tiles=e - b, out=out, early_termination=False)
+    for k in whole:
+        assert torch.equal(out[k], whole[k]), k
+
+
+def test_ingp_c4_rank_gradients_add_up_to_the_single_gpu_gradient(ngp):
+    """BASELINE configs[3], training side: a batch of rays of the 1600x1060 camera, rank r takes ray_ids[r::8] (parallel.shard_ray_ids); the sum
+    of the eight per-rank gradients (what the RCCL reduction produces) equals the gradient of the whole batch on one GPU up to the order of the
+    float additions (fp16 backward activations, f32 / fixed-point accumulation): <= 2e-3 of the gradient scale per parameter tensor."""
+    from nerficg_amd import parallel
+    from nerficg_amd.raygen import generate_rays
+    model, renderer, cam, poses = ngp
+    big = _c4_camera(cam)
+    rays = generate_rays(big.width, big.height, big.focal_x, big.focal_y, big.center_x, big.center_y, poses[5], device=DEV, want_direction=False)
+    ids = torch.randperm(big.width * big.height, generator=torch.Generator().manual_seed(0))[:4096].to(DEV)
+    target = torch.rand(big.width * big.height, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    bg = torch.tensor([0.3, 0.6, 0.9], device=DEV)
+    jitter = torch.rand(ids.shape[0], device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))  # ONE seeded vector for the global batch
+    params = list(model.parameters())
+
+    def grads_of(sel, noise):
+        for p in params:
+            p.grad = None
+        with torch.amp.autocast('cuda'):
+            out = renderer.render_rays(rays['origin'][sel], rays['view_direction'][sel], big, train_mode=True, custom_bg_color=bg, noise=noise)
+            loss = (out['rgb'].float() - target[sel]).square().sum()  # a SUM over rays: per-rank losses add up
+        (loss * 128.0).backward()
+        return [p.grad.detach().clone() / 128.0 for p in params], int(out['rm_samples'].item())
+
+    full, n_full = grads_of(ids, jitter)
+    acc, n_sum = [torch.zeros_like(g) for g in full], 0
+    for r in range(8):
+        g, n = grads_of(parallel.shard_ray_ids(ids, r, 8), parallel.shard_ray_ids(jitter, r, 8))
+        n_sum += n
+        for a, b in zip(acc, g):
+            a += b
+    assert n_sum == n_full > 100_000  # the global sample set is the single-GPU one
+    for a, f in zip(acc, full):
+        scale = float(f.abs().max())
+        assert scale > 0 and float((a - f).abs().max()) <= 2e-3 * scale, float((a - f).abs().max()) / scale
+    for p in params:
+        p.grad = None
+
+
+@pytest.fixture(scope='module', params=[1_000_000, 6_000_000], ids=['1M', '6M'])
+def gs(request):
+    """configs[2] (1 M Gaussians) and configs[4] (6 M Gaussians, the per-rank frame of the 8-GPU data-parallel run)."""
+    return bench.build_gs_scene(DEV, request.param)
 
 
 def _gs_render(gs, tensors, bg=None, grad=False):
@@ -94,7 +183,7 @@ def test_gs_million_gaussians_properties(gs):
     t = gs['tensors']
     color, radii, _, _ = _gs_render(gs, t)
     assert color.shape == (3, bench.GS_H, bench.GS_W) and bool(torch.isfinite(color).all())
-    assert 800_000 < int((radii > 0).sum()) < 900_000
+    assert 0.8 * gs['n'] < int((radii > 0).sum()) < 0.9 * gs['n']
     # determinism of the forward: binning, depth order and blending are free of atomics-order effects
     color2, radii2, _, _ = _gs_render(gs, t)
     assert torch.equal(color, color2) and torch.equal(radii, radii2)
@@ -105,7 +194,7 @@ def test_gs_million_gaussians_properties(gs):
     color3, radii3, _, _ = _gs_render(gs, shuffled)
     assert torch.equal(radii3, radii[perm])
     diff = (color3 - color).abs()
-    assert float((diff > 1e-6).float().mean()) < 1e-2 and float(diff.max()) < 2e-2 and float(diff.mean()) < 5e-6
+    assert float((diff > 1e-6).float().mean()) < (1e-2 if gs['n'] <= 1_000_000 else 6e-2) and float(diff.max()) < 5e-2 and float(diff.mean()) < 3e-5
     # background enters through the final transmittance only: C(bg) = C(0) + T_final * bg, the same factor for the three channels
     color_bg, _, _, _ = _gs_render(gs, t, bg=[0.5, 0.25, 1.0])
     tfin = (color_bg - color) / torch.tensor([0.5, 0.25, 1.0], device=DEV)[:, None, None]

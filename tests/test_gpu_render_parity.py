@@ -1,7 +1,7 @@
 """End-to-end InstantNGP rendering parity on the GPU.
 
-  op-by-op path  = statement-for-statement mirror of the reference's render_image / render_rays_inference loop
-                   (src/Methods/InstantNGP/Renderer.py:86-138,172-180) on the drop-in modules
+  ray-list path  = InstantNGPRenderer.render_rays on explicit ray tensors (ray-major ops of the drop-in module: box test, march,
+                   two-kernel query, wave-per-ray compositing)
   fused path     = InstantNGPRenderer.render_image_fused (no ray tensors, sample records, one host sync)
   oracle         = CPU composition of oracle/ngp_oracle.c + oracle/tcnn_oracle.c
 
@@ -72,11 +72,13 @@ def _oracle_image(model, cam, c2w):
 
 
 @pytest.mark.parametrize('w,h,pose', [(96, 80, (0.7, 0.4)), (64, 64, (2.9, -0.6))])
-def test_fused_image_equals_op_by_op_image_and_oracle(setup, w, h, pose):
+def test_fused_image_equals_ray_list_image_and_oracle(setup, w, h, pose):
+    from nerficg_amd.raygen import generate_rays
     model, renderer = setup
     cam = make_camera(w, h, bg=(1.0, 0.5, 0.25))
     c2w = scenes.orbit_pose(pose[0], pose[1], scenes.LEGO_RADIUS)
-    ref = renderer.render_image(cam, c2w)  # reference-shaped loop
+    rays = generate_rays(w, h, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y, c2w, want_direction=False)
+    ref = renderer.render_rays(rays['origin'], rays['view_direction'], cam)  # ray-major ops on explicit ray tensors
     fused = renderer.render_image_fused(cam, c2w, return_stats=True)
     o_rgb, o_alpha, o_depth, o_total = _oracle_image(model, cam, c2w)
     assert fused['n_samples'] == o_total  # bit-exact sample set (index parity)
@@ -111,24 +113,29 @@ def test_fused_image_shards_compose(setup):
         assert torch.equal(out[k], full[k]), k
 
 
-def test_inference_loop_with_fused_query_matches(setup):
-    """Same loop, query_model replaced by the one-kernel query: the colour net's first layer sums its 32 products in a
-    different order inside the MFMA k-step (ACC vs natural order), so rgb agrees to fp16 rounding, sigma/alpha-support exactly."""
-    model, renderer = setup
+def test_render_image_is_the_fused_picture_reshaped(setup):
+    _, renderer = setup
     cam = make_camera(48, 40)
     c2w = scenes.orbit_pose(0.2, 0.1, scenes.LEGO_RADIUS)
+    flat = {k: v.clone() for k, v in renderer.render_image_fused(cam, c2w).items()}
+    img = renderer.render_image(cam, c2w, to_chw=True)
+    assert img['rgb'].shape == (3, 40, 48) and img['alpha'].shape == (1, 40, 48)
+    assert torch.equal(img['rgb'].permute(1, 2, 0).reshape(-1, 3), flat['rgb']) and torch.equal(img['depth'].reshape(-1), flat['depth'])
+
+
+def test_ray_list_chunks_do_not_change_the_picture(setup):
     from nerficg_amd.raygen import generate_rays
-    rays = generate_rays(48, 40, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y, c2w, want_direction=False)
-    comp = renderer.ray_rendering_component
-    rays_o = rays['origin'] - model.center
-    outs = []
-    for fused_query in (False, True):
-        import nerficg_amd.VolumeRenderingV2 as vr
-        hits_t = vr.ray_aabb_intersect(rays_o, rays['view_direction'], torch.zeros(1, 3, device=DEV), model.half_size, 1)[1]
-        hits_t[..., 0].clamp_min_(cam.near_plane)
-        outs.append(comp.render_rays_inference(rays_o, rays['view_direction'], hits_t, 1024, cam.background_color.to(DEV), 0.0, fused_query=fused_query))
-    assert torch.equal(outs[0]['alpha'], outs[1]['alpha']) and torch.equal(outs[0]['depth'], outs[1]['depth'])
-    assert (outs[0]['rgb'] - outs[1]['rgb']).abs().max().item() <= 2e-3
+    _, renderer = setup
+    cam = make_camera(40, 36)
+    rays = generate_rays(40, 36, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y, scenes.orbit_pose(1.1, 0.3, scenes.LEGO_RADIUS), want_direction=False)
+    whole = renderer.render_rays(rays['origin'], rays['view_direction'], cam)
+    renderer.RAY_CHUNK = 500
+    try:
+        parts = renderer.render_rays(rays['origin'], rays['view_direction'], cam)
+    finally:
+        del renderer.RAY_CHUNK
+    for k in whole:
+        assert torch.equal(whole[k], parts[k]), k
 
 
 @pytest.mark.parametrize('optimizer', ['torch_adam', 'fused_adam'])
@@ -190,9 +197,43 @@ def test_update_occupancy_grid_runs_and_packs(setup):
     assert bool((model.occupancy_grid >= before * 0.95 - 1e-12).all())  # EMA: never below the decayed value
 
 
-def test_update_occupancy_grid_with_cascades_of_different_sample_counts():
-    """SCALE 1.0 -> two cascades; only cascade 0 has occupied cells, so it draws 2 n samples and cascade 1 only n (Renderer.py:190-198): the
-    ragged case is padded with ignored (-1) entries for the single device call.  Carved (-1) cells must survive."""
+def test_draw_update_cells_positions_and_choices():
+    """nrc_occupancy_draw_cells (Renderer.py:183-206 cell choice, :251-258 positions): Morton indices in range, every position inside its own
+    cell (lattice centre +- s/G, numpy restatement of the lattice), the second half of a cascade drawn only from cells above the threshold,
+    both halves spread over their populations, ignored entries where a cascade has no occupied cell, same seed -> same draws."""
+    from nerficg_amd.instant_ngp import InstantNGPModel, InstantNGPRenderer
+    G = 32
+    model = InstantNGPModel(RANDOM_SEED=2, SCALE=1.0, RESOLUTION=G, device=DEV)
+    renderer = InstantNGPRenderer(model)
+    occupied = np.sort(np.random.default_rng(0).choice(G ** 3, size=700, replace=False))
+    with torch.no_grad():
+        model.occupancy_grid[0, torch.from_numpy(occupied).to(DEV)] = 2 * renderer.density_threshold
+    seed = torch.tensor([1234567], dtype=torch.int64, device=DEV)
+    idx, pts = renderer.draw_update_cells(warmup=False, seed=seed)
+    n = G ** 3 // 4
+    assert idx.shape == (2, 2 * n) and pts.shape == (2 * 2 * n, 3)
+    idx_h, pts_h = idx.cpu().numpy(), pts.cpu().numpy().reshape(2, 2 * n, 3)
+    assert (idx_h[1, n:] == -1).all() and (idx_h[0] >= 0).all() and (idx_h[1, :n] >= 0).all() and idx_h.max() < G ** 3
+    assert np.isin(idx_h[0, n:], occupied).all() and len(np.unique(idx_h[0, n:])) > 600   # only occupied cells, nearly all of them drawn
+    assert len(np.unique(idx_h[0, :n])) > 0.2 * G ** 3                                      # uniform half covers the grid
+    for c in range(2):
+        s_c = min(2.0 ** (c - 1), 1.0)
+        live = idx_h[c] >= 0
+        coords = oracle.morton3D_invert(idx_h[c][live].astype(np.int32)).astype(np.float64)
+        centre = (coords / (G - 1) * 2 - 1) * (s_c - s_c / G)
+        off = np.abs(pts_h[c][live] - centre)
+        assert off.max() <= s_c / G * (1 + 1e-5) and off.mean() > 0.3 * s_c / G  # jitter fills the cell
+    idx2, pts2 = renderer.draw_update_cells(warmup=False, seed=seed)
+    assert torch.equal(idx, idx2) and torch.equal(pts, pts2)
+    idx3, _ = renderer.draw_update_cells(warmup=False, seed=seed + 1)
+    assert not torch.equal(idx, idx3)
+    all_idx, all_pts = renderer.draw_update_cells(warmup=True, seed=seed)
+    assert torch.equal(all_idx, torch.arange(G ** 3, device=DEV).expand(2, -1))
+
+
+def test_update_occupancy_grid_with_a_cascade_without_occupied_cells():
+    """SCALE 1.0 -> two cascades; only cascade 0 has occupied cells: cascade 1's second half consists of ignored (-1) entries (the reference
+    draws fewer samples there, Renderer.py:190-198).  Carved (-1) cells must survive."""
     from nerficg_amd.instant_ngp import InstantNGPModel, InstantNGPRenderer
     model = InstantNGPModel(RANDOM_SEED=2, SCALE=1.0, RESOLUTION=64, device=DEV)
     assert model.cascades == 2
@@ -322,12 +363,17 @@ def test_layer_ordered_early_termination_gives_the_same_image(table_amp):
 
 
 @pytest.mark.parametrize('m', [777, 20011])  # >= 16384: the hashed levels take the ownership backward
-def test_fused_training_query_matches_the_op_by_op_modules(m):
+def test_fused_training_query_matches_the_op_by_op_modules(m):  # noqa: E302
     """nerficg_amd.ngp.query_train (one autograd node) against the statement sequence of query_model (Renderer.py:48-53) through the
     drop-in modules: same forward bits, gradients within the fp16 rounding of the intermediate d_out tensors."""
     from nerficg_amd.instant_ngp import InstantNGPRenderer
+    import nerficg_amd.VolumeRenderingV2 as vr
     model = make_model(seed=4)
-    comp = InstantNGPRenderer(model).ray_rendering_component
+    renderer = InstantNGPRenderer(model)
+
+    def op_by_op(x, d):  # the module-level statement sequence of the reference's query (Renderer.py:48-53) on the drop-in modules
+        h = model.encoding_xyz((x - model.xyz_min) / model.xyz_size)
+        return vr.TruncExp.apply(h[:, 0]), model.color_mlp_with_encoding(torch.cat([(d * 0.5 + 0.5).to(h.dtype), h], dim=-1))
     rng = np.random.default_rng(m)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
     x = T((rng.random((m, 3)) - 0.5).astype(np.float32) * 0.98)
@@ -336,10 +382,9 @@ def test_fused_training_query_matches_the_op_by_op_modules(m):
     gs, gr = T(rng.normal(size=m).astype(np.float32) * 1e-2), T(rng.normal(size=(m, 3)).astype(np.float32) * 1e-2)  # fp16-safe magnitudes
     res = {}
     for fused in (False, True):
-        comp.fused_training_query = fused
         model.zero_grad()
         with torch.amp.autocast('cuda'):
-            sig, rgb = comp.query_model(x, d)
+            sig, rgb = renderer.query(x, d) if fused else op_by_op(x, d)
         (sig.float() * gs).sum().add((rgb.float() * gr).sum()).backward()
         res[fused] = (sig.detach().float().clone(), rgb.detach().float().clone(), model.encoding_xyz.params.grad.clone(),
                       model.color_mlp_with_encoding.params.grad.clone())
