@@ -225,10 +225,10 @@ class _Intersector(torch.autograd.Function):
     op = None
 
     @classmethod
-    def _run(cls, ctx, rays_o, rays_d, center, extent, max_hits):
-        hit_cnt, hits_t, hits_idx = cls.op(rays_o, rays_d, center, extent, max_hits)
-        ctx.mark_non_differentiable(hit_cnt, hits_t, hits_idx)
-        return hit_cnt, hits_t, hits_idx
+    def _run(cls, ctx, *args):
+        found = tuple(cls.op(*args))
+        ctx.mark_non_differentiable(*found)
+        return found
 
     @staticmethod
     def backward(ctx, *_):
@@ -236,73 +236,82 @@ class _Intersector(torch.autograd.Function):
 
 
 class RayAABBIntersector(_Intersector):
+    """apply(rays_o, rays_d, center, half_size, max_hits) -> (hit_cnt, hits_t, hits_voxel_idx)"""
     op = staticmethod(ray_aabb_intersect)
 
     @staticmethod
     @custom_fwd(cast_inputs=_f32, device_type='cuda')
-    def forward(ctx, rays_o, rays_d, center, half_size, max_hits):
-        return RayAABBIntersector._run(ctx, rays_o, rays_d, center, half_size, max_hits)
+    def forward(ctx, *rays_boxes_and_cap):
+        return RayAABBIntersector._run(ctx, *rays_boxes_and_cap)
 
 
 class RaySphereIntersector(_Intersector):
+    """apply(rays_o, rays_d, center, radii, max_hits) -> (hit_cnt, hits_t, hits_voxel_idx)"""
     op = staticmethod(ray_sphere_intersect)
 
     @staticmethod
     @custom_fwd(cast_inputs=_f32, device_type='cuda')
-    def forward(ctx, rays_o, rays_d, center, radii, max_hits):
-        return RaySphereIntersector._run(ctx, rays_o, rays_d, center, radii, max_hits)
+    def forward(ctx, *rays_spheres_and_cap):
+        return RaySphereIntersector._run(ctx, *rays_spheres_and_cap)
 
 
 class RayMarcher(torch.autograd.Function):
-    """Training-batch sample generation (custom_functions.py:61-137): -> (rays_a, xyzs, dirs, deltas, ts, total_samples).  The first sample of
-    a ray is jittered by dt * noise; `noise` defaults to one torch.rand draw per ray on the rays' device."""
+    """Training-batch sample generation (custom_functions.py:61-137): apply(rays_o, rays_d, hits_t, density_bitfield, cascades, scale,
+    exp_step_factor, grid_size, max_samples[, noise]) -> (rays_a, xyzs, dirs, deltas, ts, total_samples).  The first sample of a ray is
+    jittered by dt * noise; `noise` defaults to one torch.rand draw per ray on the rays' device."""
 
     @staticmethod
     @custom_fwd(cast_inputs=_f32, device_type='cuda')
-    def forward(ctx, rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, grid_size, max_samples, noise=None):
-        if noise is None:
-            noise = torch.rand(rays_o.shape[0], dtype=_f32, device=rays_o.device)
-        rays_a, xyzs, dirs, deltas, ts, counter = raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor,
-                                                                    noise.contiguous(), grid_size, max_samples)
+    def forward(ctx, origins, directions, spans, bitfield, *march_cfg):
+        n_cascades, box_scale, step_growth, resolution, sample_cap = march_cfg[:5]
+        jitter = march_cfg[5] if len(march_cfg) > 5 and march_cfg[5] is not None else torch.rand(origins.shape[0], dtype=_f32, device=origins.device)
+        *samples, counter = raymarching_train(origins, directions, spans, bitfield, n_cascades, box_scale, step_growth, jitter.contiguous(),
+                                              resolution, sample_cap)
+        segments, _, _, step_sizes, depths = samples
         n_marched = counter[0]
-        ctx.mark_non_differentiable(rays_a, deltas, ts, n_marched)
-        ctx.save_for_backward(rays_a, ts)
-        return rays_a, xyzs, dirs, deltas, ts, n_marched
+        ctx.mark_non_differentiable(segments, step_sizes, depths, n_marched)
+        ctx.save_for_backward(segments, depths)
+        ctx.n_inputs = 4 + len(march_cfg)
+        return (*samples, n_marched)
 
     @staticmethod
     @custom_bwd(device_type='cuda')
-    def backward(ctx, _g_rays_a, g_xyzs, g_dirs, _g_deltas, _g_ts, _g_count):
-        rays_a, ts = ctx.saved_tensors
-        n, m = rays_a.shape[0], ts.shape[0]
-        g_o = torch.zeros(n, 3, dtype=_f32, device=ts.device)
-        g_d = torch.zeros(n, 3, dtype=_f32, device=ts.device)
-        if n and m and (g_xyzs is not None or g_dirs is not None):
+    def backward(ctx, _g_segments, g_positions, g_directions, *_unused):
+        segments, depths = ctx.saved_tensors
+        n, m = segments.shape[0], depths.shape[0]
+        g_o = torch.zeros(n, 3, dtype=_f32, device=depths.device)
+        g_d = torch.zeros(n, 3, dtype=_f32, device=depths.device)
+        if n and m and (g_positions is not None or g_directions is not None):
             _lib.check(_lib.load().nrc_raymarching_train_bw(
-                _lib.ptr(_dense(g_xyzs, ts, (m, 3))), _lib.ptr(None if g_dirs is None else _dense(g_dirs, ts)), _lib.ptr(ts), _lib.ptr(rays_a), n, m,
-                _lib.ptr(g_o), _lib.ptr(g_d), _lib.stream_of(ts)), 'raymarching_train_bw')
-        return (g_o, g_d) + (None,) * 8
+                _lib.ptr(_dense(g_positions, depths, (m, 3))), _lib.ptr(None if g_directions is None else _dense(g_directions, depths)), _lib.ptr(depths),
+                _lib.ptr(segments), n, m, _lib.ptr(g_o), _lib.ptr(g_d), _lib.stream_of(depths)), 'raymarching_train_bw')
+        return (g_o, g_d) + (None,) * (ctx.n_inputs - 2)
 
 
 class VolumeRenderer(torch.autograd.Function):
-    """Front-to-back compositing of a training batch (custom_functions.py:140-194): -> (n composited samples, opacity, depth, rgb, ws)."""
+    """Front-to-back compositing of a training batch (custom_functions.py:140-194): apply(sigmas, rgbs, deltas, ts, rays_a, T_threshold) ->
+    (n composited samples, opacity, depth, rgb, ws)."""
 
     @staticmethod
     @custom_fwd(cast_inputs=_f32, device_type='cuda')
-    def forward(ctx, sigmas, rgbs, deltas, ts, rays_a, T_threshold):
-        per_ray_count, opacity, depth, rgb, ws = composite_train_fw(sigmas, rgbs, deltas, ts, rays_a, T_threshold)
+    def forward(ctx, *sample_batch):
+        density, radiance, step_sizes, depths, segments, cutoff = sample_batch
+        per_ray_count, *pixel, weights = composite_train_fw(*sample_batch)
         n_composited = per_ray_count.sum()
         ctx.mark_non_differentiable(n_composited)
-        ctx.cutoff = float(T_threshold)
-        ctx.save_for_backward(sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb)
-        return n_composited, opacity, depth, rgb, ws
+        ctx.cutoff = float(cutoff)
+        # saved in the argument order of composite_train_bw (binding.cpp:129-163), behind the four upstream gradients
+        ctx.save_for_backward(density, radiance, weights, step_sizes, depths, segments, *pixel)
+        return (n_composited, *pixel, weights)
 
     @staticmethod
     @custom_bwd(device_type='cuda')
-    def backward(ctx, _g_count, g_opacity, g_depth, g_rgb, g_ws):
-        sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb = ctx.saved_tensors
-        g_sigmas, g_rgbs = composite_train_bw(_dense(g_opacity, opacity), _dense(g_depth, depth), _dense(g_rgb, rgb), _dense(g_ws, ws), sigmas, rgbs, ws,
-                                              deltas, ts, rays_a, opacity, depth, rgb, ctx.cutoff)
-        return g_sigmas, g_rgbs, None, None, None, None
+    def backward(ctx, _g_count, *upstream):
+        saved = ctx.saved_tensors
+        pixel, weights = saved[6:9], saved[2]
+        grads = [_dense(g, like) for g, like in zip(upstream, (*pixel, weights))]
+        g_density, g_radiance = composite_train_bw(*grads, *saved, ctx.cutoff)
+        return g_density, g_radiance, None, None, None, None
 
 
 class TruncExp(torch.autograd.Function):
@@ -324,15 +333,16 @@ class TruncExp(torch.autograd.Function):
 
 
 class DistortionLoss(torch.autograd.Function):
-    """Mip-NeRF 360 distortion regulariser per ray (custom_functions.py:211-252); gradient reaches the weights only."""
+    """Mip-NeRF 360 distortion regulariser per ray (custom_functions.py:211-252): apply(ws, deltas, ts, rays_a) -> loss (N); the gradient
+    reaches the weights only."""
 
     @staticmethod
-    def forward(ctx, ws, deltas, ts, rays_a):
-        loss, ws_scan, wts_scan = distortion_loss_fw(ws, deltas, ts, rays_a)
-        ctx.save_for_backward(ws_scan, wts_scan, ws, deltas, ts, rays_a)
+    def forward(ctx, *weights_and_segments):
+        loss, *scans = distortion_loss_fw(*weights_and_segments)
+        ctx.save_for_backward(*scans, *weights_and_segments)  # = the argument order of distortion_loss_bw behind dL_dloss
         return loss
 
     @staticmethod
     def backward(ctx, g_loss):
-        ws_scan, wts_scan, ws, deltas, ts, rays_a = ctx.saved_tensors
-        return distortion_loss_bw(_dense(g_loss, ws, (rays_a.shape[0],)), ws_scan, wts_scan, ws, deltas, ts, rays_a), None, None, None
+        saved = ctx.saved_tensors
+        return distortion_loss_bw(_dense(g_loss, saved[2], (saved[-1].shape[0],)), *saved), None, None, None

@@ -17,6 +17,9 @@ __all__ = ['replace_param_group_data', 'prune_param_groups', 'extend_param_group
            'gather_rows', 'compact_mask']
 
 _MOMENTS = ('exp_avg', 'exp_avg_sq')
+Optimizer = torch.optim.Optimizer
+Names = list[str] | None          # group names to act on (None: all groups)
+Rebuilt = dict[str, torch.Tensor]  # group name -> the Parameter that replaced the old one
 
 
 def _single_param(group, who: str) -> torch.Tensor:
@@ -69,96 +72,93 @@ def compact_mask(mask: torch.Tensor) -> torch.Tensor:
     return idx[:int(count.item())]
 
 
-def gather_param_groups(optimizer: torch.optim.Optimizer, src: torch.Tensor, n_out: int, kind: torch.Tensor | None = None,
-                        group_names: list[str] | None = None, who: str = 'gather_param_groups') -> dict[str, torch.Tensor]:
+def _selected(optimizer, names, who: str):
+    """(group, its single parameter, its Adam state or None) for the groups whose 'name' is in `names` (all groups for None)."""
+    for group in optimizer.param_groups:
+        if names is None or group['name'] in names:
+            tensor = _single_param(group, who)
+            yield group, tensor, (optimizer.state.get(tensor) or None)
+
+
+def _install(optimizer, group, old: torch.Tensor, new: torch.nn.Parameter, state) -> None:
+    """`new` takes the place of `old` in its group; the state entry (already holding tensors of the new size) moves with it."""
+    if state is not None:
+        del optimizer.state[old]
+        optimizer.state[new] = state
+    group['params'][0] = new
+
+
+def _moments(state):
+    return [] if state is None else [state[key] for key in _MOMENTS]
+
+
+def gather_param_groups(optimizer: Optimizer, src: torch.Tensor, n_out: int, kind: torch.Tensor | None = None,
+                        group_names: Names = None, who: str = 'gather_param_groups') -> Rebuilt:
     """Rebuilds every (selected) single-parameter group as rows `src` of the old one -- parameter and both Adam moments of all groups
     in one kernel launch; rows with kind != 0 start with zero moments.  Returns {group name: new Parameter}."""
-    groups = []
-    for group in optimizer.param_groups:
-        if group_names is not None and group['name'] not in group_names:
+    todo = list(_selected(optimizer, group_names, who))
+    tensors, fresh_rows_are_zero = [], []
+    for _, tensor, state in todo:
+        moments = _moments(state)
+        tensors += [tensor.data, *moments]
+        fresh_rows_are_zero += [False] + [True] * len(moments)
+    gathered = iter(gather_rows(tensors, src, n_out, kind, fresh_rows_are_zero))
+    rebuilt = {}
+    for group, tensor, state in todo:
+        replacement = torch.nn.Parameter(next(gathered))
+        if state is not None:
+            for key in _MOMENTS:
+                state[key] = next(gathered)
+        _install(optimizer, group, tensor, replacement, state)
+        rebuilt[group['name']] = replacement
+    return rebuilt
+
+
+def replace_param_group_data(optimizer: Optimizer, new_values: torch.Tensor, group_name: str, reset_state: bool = True) -> None:
+    """New values (same shape) for the parameter of group `group_name`, by default with cleared Adam moments (adam_utils.py:6-18)."""
+    for _, tensor, state in _selected(optimizer, (group_name,), 'replace_param_group_data'):
+        tensor.data = new_values
+        if reset_state:
+            for moment in _moments(state):
+                moment.zero_()
+
+
+def prune_param_groups(optimizer: Optimizer, mask: torch.Tensor, group_names: Names = None) -> Rebuilt:
+    """Keeps the rows where `mask` is set (adam_utils.py:21-39)."""
+    rows = compact_mask(mask)
+    return gather_param_groups(optimizer, rows, rows.numel(), None, group_names, 'prune_param_groups')
+
+
+def sort_param_groups(optimizer: Optimizer, ordering: torch.Tensor, group_names: Names = None) -> Rebuilt:
+    """Rows in the given order (adam_utils.py:81-98)."""
+    rows = ordering.to(torch.int32).contiguous()
+    return gather_param_groups(optimizer, rows, rows.numel(), None, group_names, 'sort_param_groups')
+
+
+def extend_param_groups(optimizer: Optimizer, additional_params: dict[str, torch.Tensor]) -> Rebuilt:
+    """Appends rows to the groups named in `additional_params`; the new rows start with zero Adam moments (adam_utils.py:42-61)."""
+    rebuilt = {}
+    for group, tensor, state in _selected(optimizer, None, 'extend_param_groups'):
+        extra = additional_params.get(group['name'])
+        if extra is None:
             continue
-        groups.append((group, _single_param(group, who)))
-    tensors, zero_new = [], []
-    for _, p in groups:
-        tensors.append(p.data)
-        zero_new.append(False)
-        state = optimizer.state.get(p)
-        if state:
+        replacement = torch.nn.Parameter(torch.cat((tensor.data, extra)))
+        if state is not None:
+            n_old = tensor.shape[0]
             for key in _MOMENTS:
-                tensors.append(state[key])
-                zero_new.append(True)
-    outs = iter(gather_rows(tensors, src, n_out, kind, zero_new))
-    new_params = {}
-    for group, old_param in groups:
-        new_param = torch.nn.Parameter(next(outs))
-        state = optimizer.state.get(old_param)
-        if state:
-            for key in _MOMENTS:
-                state[key] = next(outs)
-            optimizer.state.pop(old_param)
-            optimizer.state[new_param] = state
-        group['params'][0] = new_param
-        new_params[group['name']] = new_param
-    return new_params
+                padded = state[key].new_zeros(replacement.shape)
+                padded[:n_old].copy_(state[key])
+                state[key] = padded
+        _install(optimizer, group, tensor, replacement, state)
+        rebuilt[group['name']] = replacement
+    return rebuilt
 
 
-def replace_param_group_data(optimizer: torch.optim.Optimizer, new_values: torch.Tensor, group_name: str, reset_state: bool = True) -> None:
-    """adam_utils.py:6-18"""
-    for group in optimizer.param_groups:
-        if group['name'] == group_name:
-            param = _single_param(group, 'replace_param_group_data')
-            param.data = new_values
-            if reset_state:
-                state = optimizer.state.get(param)
-                if state:
-                    for key in _MOMENTS:
-                        state[key].zero_()
-
-
-def prune_param_groups(optimizer: torch.optim.Optimizer, mask: torch.Tensor, group_names: list[str] | None = None) -> dict[str, torch.Tensor]:
-    """adam_utils.py:21-39: keeps the rows where `mask` is set."""
-    idx = compact_mask(mask)
-    return gather_param_groups(optimizer, idx, idx.numel(), None, group_names, 'prune_param_groups')
-
-
-def sort_param_groups(optimizer: torch.optim.Optimizer, ordering: torch.Tensor, group_names: list[str] | None = None) -> dict[str, torch.Tensor]:
-    """adam_utils.py:81-98: rows in the given order."""
-    idx = ordering.to(torch.int32).contiguous()
-    return gather_param_groups(optimizer, idx, idx.numel(), None, group_names, 'sort_param_groups')
-
-
-def extend_param_groups(optimizer: torch.optim.Optimizer, additional_params: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
-    """adam_utils.py:42-61: appends rows (zero Adam moments for them)."""
-    new_params = {}
-    for group in optimizer.param_groups:
-        old_param = _single_param(group, 'extend_param_groups')
-        extension = additional_params.get(group['name'], None)
-        if extension is None:
-            continue
-        state = optimizer.state.get(old_param)
-        new_param = torch.nn.Parameter(torch.cat((old_param.data, extension), dim=0))
-        if state:
-            for key in _MOMENTS:
-                grown = torch.zeros_like(new_param.data)
-                grown[:old_param.shape[0]] = state[key]
-                state[key] = grown
-            optimizer.state.pop(old_param)
-            optimizer.state[new_param] = state
-        group['params'][0] = new_param
-        new_params[group['name']] = new_param
-    return new_params
-
-
-def reset_state(optimizer: torch.optim.Optimizer, group_names: list[str] | None = None, indices: torch.Tensor | None = None) -> None:
-    """adam_utils.py:64-79"""
-    for group in optimizer.param_groups:
-        if group_names is not None and group['name'] not in group_names:
-            continue
-        param = _single_param(group, 'reset_state')
-        state = optimizer.state.get(param)
-        if state:
-            for key in _MOMENTS:
-                if indices is not None:
-                    state[key][indices] = 0
-                else:
-                    state[key].zero_()
+def reset_state(optimizer: Optimizer, group_names: Names = None, indices: torch.Tensor | None = None) -> None:
+    """Clears the Adam moments of the selected groups, entirely or at `indices` (adam_utils.py:64-79)."""
+    for _, _, state in _selected(optimizer, group_names, 'reset_state'):
+        for moment in _moments(state):
+            if indices is None:
+                moment.zero_()
+            else:
+                moment[indices] = 0

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 __all__ = ['PerspectiveCamera', 'get_projection_matrix', 'invert_3d_affine', 'make_raster_settings', 'quaternion_to_rotation_matrix',
-           'build_covariances', 'extract_upper_triangular_matrix', 'convert_sh_features', 'rgb_to_sh0', 'sh0_to_rgb', 'Gaussians',
+           'build_covariances', 'extract_upper_triangular_matrix', 'sh_basis', 'convert_sh_features', 'rgb_to_sh0', 'sh0_to_rgb', 'Gaussians',
            'render_image_training', 'render_image_inference', 'training_loss']
 
 
@@ -72,69 +72,73 @@ def make_raster_settings(cam: PerspectiveCamera, c2w: np.ndarray, sh_degree: int
 
 
 def quaternion_to_rotation_matrix(quaternions: torch.Tensor, normalize: bool = True) -> torch.Tensor:
-    """Cameras/utils.py:180-208 (torch branch)."""
-    batch_dim_added = quaternions.ndim == 1
-    if batch_dim_added:
-        quaternions = quaternions[None]
-    if normalize:
-        quaternions = torch.nn.functional.normalize(quaternions)
-    R = torch.empty((quaternions.shape[0], 3, 3), dtype=quaternions.dtype, device=quaternions.device)
-    r, i, j, k = quaternions.T
-    ii2, jj2, kk2 = i * i * 2, j * j * 2, k * k * 2
-    ij2, ik2, jk2 = i * j * 2, i * k * 2, j * k * 2
-    ri2, rj2, rk2 = r * i * 2, r * j * 2, r * k * 2
-    R[:, 0, 0] = 1 - (jj2 + kk2); R[:, 0, 1] = ij2 - rk2; R[:, 0, 2] = ik2 + rj2
-    R[:, 1, 0] = ij2 + rk2; R[:, 1, 1] = 1 - (ii2 + kk2); R[:, 1, 2] = jk2 - ri2
-    R[:, 2, 0] = ik2 - rj2; R[:, 2, 1] = jk2 + ri2; R[:, 2, 2] = 1 - (ii2 + jj2)
-    return R[0] if batch_dim_added else R
+    """(..., 4) quaternions, real part first -> (..., 3, 3) rotation matrices (same convention and values as Cameras/utils.py:180-208):
+    the nine entries of R = I + 2 (w [v]x + [v]x [v]x), v = vector part, stacked row by row."""
+    q = torch.nn.functional.normalize(quaternions, dim=-1) if normalize else quaternions
+    w, x, y, z = q.unbind(-1)
+    rows = (1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+            2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+            2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y))
+    return torch.stack(rows, dim=-1).reshape(*q.shape[:-1], 3, 3)
+
+
+_UPPER_ROWS, _UPPER_COLS = (0, 0, 0, 1, 1, 2), (0, 1, 2, 1, 2, 2)
 
 
 def build_covariances(scales: torch.Tensor, rotations: torch.Tensor) -> torch.Tensor:
-    """GaussianSplatting/utils.py:10-18: R S (R S)^T."""
-    R = quaternion_to_rotation_matrix(rotations, normalize=False)
-    batch_dim_added = scales.dim() == 1
-    if batch_dim_added:
-        scales = scales[None]
-    RS = R @ torch.diag_embed(scales)
-    RSSR = RS @ RS.transpose(-2, -1)
-    return RSSR[0] if batch_dim_added else RSSR
+    """Sigma = (R diag(s)) (R diag(s))^T for unit quaternions `rotations` (the rasterizer's cov3D step; GaussianSplatting/utils.py:10-18).
+    Scaling the columns of R replaces the product with a diagonal matrix."""
+    stretched = quaternion_to_rotation_matrix(rotations, normalize=False) * scales[..., None, :]
+    return stretched @ stretched.mT
 
 
 def extract_upper_triangular_matrix(matrix: torch.Tensor) -> torch.Tensor:
-    """utils.py:70-73"""
-    idx = torch.triu_indices(matrix.shape[-2], matrix.shape[-1])
-    return matrix[..., idx[0], idx[1]]
+    """Row-major upper triangle of (..., n, n) matrices; (..., 6) for the 3x3 covariances the rasterizer takes as cov3D_precomp."""
+    n = matrix.shape[-1]
+    if n == 3:
+        return matrix[..., _UPPER_ROWS, _UPPER_COLS]
+    rows, cols = zip(*[(r, c) for r in range(n) for c in range(r, n)])
+    return matrix[..., rows, cols]
+
+
+# real spherical-harmonics basis up to degree 3 in the sign / order convention of 3DGS (GaussianSplatting/utils.py:27-58): constants first,
+# then the polynomial each one multiplies
+_SH_C = (0.28209479177387814,
+         -0.48860251190291987, 0.48860251190291987, -0.48860251190291987,
+         1.0925484305920792, -1.0925484305920792, 0.94617469575755997, -1.0925484305920792, 0.54627421529603959,
+         0.59004358992664352, 2.8906114426405538, 0.45704579946446572, 0.3731763325901154, 0.45704579946446572, 1.4453057213202769, 0.59004358992664352)
+
+
+def sh_basis(directions: torch.Tensor, degree: int) -> torch.Tensor:
+    """(..., 3) unit directions -> (..., (degree+1)^2) basis values."""
+    x, y, z = directions.unbind(-1)
+    one = torch.ones_like(x)
+    poly = [one]
+    if degree >= 1:
+        poly += [y, z, x]
+    if degree >= 2:
+        xx, yy, zz = x * x, y * y, z * z
+        poly += [x * y, y * z, zz - 0.31539156525251999 / 0.94617469575755997, x * z, xx - yy]
+    if degree >= 3:
+        poly += [y * (yy - 3.0 * xx), x * y * z, y * (1.0 - 5.0 * zz), z * (5.0 * zz - 3.0), x * (1.0 - 5.0 * zz), z * (xx - yy), x * (3.0 * yy - xx)]
+    basis = torch.stack(poly, dim=-1)
+    return basis * torch.tensor(_SH_C[:len(poly)], dtype=basis.dtype, device=basis.device)
 
 
 def convert_sh_features(sh_features: torch.Tensor, view_directions: torch.Tensor, degree: int) -> torch.Tensor:
-    """utils.py:21-59: SH (..., 3, 16) -> RGB, +0.5 and clamped at 0 from below (the rasterizer's fused SH step)."""
-    result = 0.5 + 0.28209479177387814 * sh_features[..., 0]
-    if degree == 0:
-        return result.clamp_min(0.0)
-    x, y, z = view_directions[..., 0:1], view_directions[..., 1:2], view_directions[..., 2:3]
-    result = result + -0.48860251190291987 * y * sh_features[..., 1] + 0.48860251190291987 * z * sh_features[..., 2] + -0.48860251190291987 * x * sh_features[..., 3]
-    if degree == 1:
-        return result.clamp_min(0.0)
-    x2, y2, z2 = x * x, y * y, z * z
-    xy, yz, xz = x * y, y * z, x * z
-    result = (result + 1.0925484305920792 * xy * sh_features[..., 4] + -1.0925484305920792 * yz * sh_features[..., 5]
-              + (0.94617469575755997 * z2 - 0.31539156525251999) * sh_features[..., 6] + -1.0925484305920792 * xz * sh_features[..., 7]
-              + 0.54627421529603959 * (x2 - y2) * sh_features[..., 8])
-    if degree == 2:
-        return result.clamp_min(0.0)
-    result = (result + 0.59004358992664352 * y * (-3.0 * x2 + y2) * sh_features[..., 9] + 2.8906114426405538 * xy * z * sh_features[..., 10]
-              + 0.45704579946446572 * y * (1.0 - 5.0 * z2) * sh_features[..., 11] + 0.3731763325901154 * z * (5.0 * z2 - 3.0) * sh_features[..., 12]
-              + 0.45704579946446572 * x * (1.0 - 5.0 * z2) * sh_features[..., 13] + 1.4453057213202769 * z * (x2 - y2) * sh_features[..., 14]
-              + 0.59004358992664352 * x * (-x2 + 3.0 * y2) * sh_features[..., 15])
-    return result.clamp_min(0.0)
+    """SH coefficients (..., 3, 16) seen from view_directions (..., 1|3 broadcastable, 3) -> RGB = max(0, 0.5 + sum_k Y_k c_k): the rasterizer's
+    colour step in torch (the reference's utils.py:21-59 is pinned against this in tests/test_host_golden.py)."""
+    n = (degree + 1) ** 2
+    basis = sh_basis(view_directions[..., 0, :] if view_directions.dim() == sh_features.dim() else view_directions, degree)
+    return ((sh_features[..., :n] * basis[..., None, :]).sum(-1) + 0.5).clamp_min(0.0)
 
 
 def rgb_to_sh0(rgb):
-    return (rgb - 0.5) / 0.28209479177387814
+    return (rgb - 0.5) / _SH_C[0]
 
 
 def sh0_to_rgb(sh):
-    return sh * 0.28209479177387814 + 0.5
+    return sh * _SH_C[0] + 0.5
 
 
 class Gaussians(torch.nn.Module):
@@ -164,18 +168,17 @@ class Gaussians(torch.nn.Module):
         """initialize_from_point_cloud (Model.py:94-119): isotropic scales from the RMS distance to the 3 nearest neighbours
         (Optim/knn_utils.py:29-40 through the HIP kNN), identity rotations, opacity 0.1, DC colour from rgb."""
         from .simple_knn import distCUDA2
-        positions = positions.to(torch.float32).contiguous()
-        n, dev = positions.shape[0], positions.device
-        rgbs = torch.full_like(positions, 0.5) if colors is None else colors.to(dev, torch.float32)
-        features = torch.zeros((n, 3, (sh_degree + 1) ** 2), dtype=torch.float32, device=dev)
-        features[:, :3, 0] = rgb_to_sh0(rgbs)
-        distances = distCUDA2(positions).clamp_min(1e-7).sqrt()
-        scales = torch.log(distances)[..., None].repeat(1, 3)
-        rotations = torch.zeros((n, 4), device=dev)
-        rotations[:, 0] = 1
-        opacities = torch.special.logit(torch.full((n, 1), 0.1, dtype=torch.float32, device=dev))
-        out = cls(positions, scales.contiguous(), rotations, opacities, features[:, :, 0:1].transpose(1, 2).contiguous(),
-                  features[:, :, 1:].transpose(1, 2).contiguous(), sh_degree)
+        xyz = positions.to(torch.float32).contiguous()
+        n, dev = xyz.shape[0], xyz.device
+        n_coeff = (sh_degree + 1) ** 2
+        base_colour = torch.full((n, 3), 0.5, device=dev) if colors is None else colors.to(dev, torch.float32)
+        dc = rgb_to_sh0(base_colour).reshape(n, 1, 3).contiguous()                       # (P, 1, 3): coefficient-major like the rasterizer reads it
+        rest = torch.zeros(n, n_coeff - 1, 3, device=dev)
+        spacing = distCUDA2(xyz).clamp_min(1e-7).sqrt()                                  # RMS distance to the three nearest neighbours
+        log_scales = spacing.log().reshape(n, 1).expand(n, 3).contiguous()
+        identity = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev).expand(n, 4).contiguous()
+        opacity_logits = torch.full((n, 1), float(np.log(0.1 / 0.9)), device=dev)        # logit(0.1)
+        out = cls(xyz, log_scales, identity, opacity_logits, dc, rest, sh_degree)
         out.active_sh_degree = 0
         return out
 
@@ -218,14 +221,10 @@ class Gaussians(torch.nn.Module):
             self.training_cameras_extent = training_cameras_extent
         self.percent_dense = PERCENT_DENSE
         ext = self.training_cameras_extent
-        param_groups = [
-            {'params': [self._positions], 'lr': LEARNING_RATE_POSITION_INIT * ext, 'name': 'positions'},
-            {'params': [self._features_dc], 'lr': LEARNING_RATE_FEATURE, 'name': 'f_dc'},
-            {'params': [self._features_rest], 'lr': LEARNING_RATE_FEATURE / 20.0, 'name': 'f_rest'},
-            {'params': [self._opacities], 'lr': LEARNING_RATE_OPACITY, 'name': 'opacities'},
-            {'params': [self._scales], 'lr': LEARNING_RATE_SCALING, 'name': 'scales'},
-            {'params': [self._rotations], 'lr': LEARNING_RATE_ROTATION, 'name': 'rotations'},
-        ]
+        rates = {'positions': LEARNING_RATE_POSITION_INIT * ext, 'f_dc': LEARNING_RATE_FEATURE, 'f_rest': LEARNING_RATE_FEATURE / 20.0,
+                 'opacities': LEARNING_RATE_OPACITY, 'scales': LEARNING_RATE_SCALING, 'rotations': LEARNING_RATE_ROTATION}
+        # one single-tensor group per attribute, in the order and under the names the reference's optimizer-state surgery looks up (Model.py:121-130)
+        param_groups = [{'name': name, 'lr': rates[name], 'params': [getattr(self, attr)]} for name, attr in self._GROUP_OF.items()]
         if optimizer_class is None:
             from .apex_optimizers import FusedAdam
             self.optimizer = FusedAdam(param_groups, lr=0.0, eps=1e-15, adam_w_mode=False)
@@ -235,9 +234,10 @@ class Gaussians(torch.nn.Module):
                                                    max_steps=LEARNING_RATE_POSITION_MAX_STEPS)
 
     def update_learning_rate(self, iteration: int) -> None:
-        for param_group in self.optimizer.param_groups:
-            if param_group['name'] == 'positions':
-                param_group['lr'] = self.position_lr_scheduler(iteration)
+        rate = self.position_lr_scheduler(iteration)
+        for group in self.optimizer.param_groups:
+            if group['name'] == 'positions':
+                group['lr'] = rate
 
     def _adopt(self, tensors: dict[str, torch.Tensor]) -> None:
         for name, attr in self._GROUP_OF.items():
@@ -246,8 +246,8 @@ class Gaussians(torch.nn.Module):
     # ---------------------------------------------------------------- densification (Model.py:152-246)
     def reset_opacities(self) -> None:
         from .adam_utils import replace_param_group_data
-        opacities_new = torch.special.logit(self.get_opacities.clamp_max(0.01))
-        replace_param_group_data(self.optimizer, opacities_new, 'opacities')
+        capped = torch.special.logit(self.get_opacities.clamp(max=0.01))  # Model.py:152-155
+        replace_param_group_data(self.optimizer, capped, 'opacities')
 
     def prune_points(self, prune_mask: torch.Tensor) -> None:
         from .adam_utils import compact_mask, gather_param_groups, gather_rows
@@ -324,23 +324,23 @@ class Gaussians(torch.nn.Module):
 
     @torch.no_grad()
     def as_ply_dict(self) -> dict[str, np.ndarray]:
-        """Model.py:275-318: one 'vertex' element, every attribute f4: x y z, f_dc_0..2, f_rest_0..44 (channel-major), opacity (logit),
-        scale_0..2 (log), rot_0..3 (normalised)."""
-        if self.get_positions.shape[0] == 0:
+        """The 'vertex' element of the standard 3DGS .ply (Model.py:275-318): every property f4 -- x y z, f_dc_0..2, f_rest_0.. (channel-major),
+        opacity (logit), scale_0..2 (log), rot_0..3 (unit quaternion)."""
+        n = self._positions.shape[0]
+        if n == 0:
             return {}
-        positions = self.get_positions.detach().contiguous().cpu().numpy()
-        sh_0 = self.get_features_dc.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy()
-        sh_rest = self.get_features_rest.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy()
-        opacities = self.get_opacities.logit().detach().contiguous().cpu().numpy()
-        scales = self.get_scales.log().detach().contiguous().cpu().numpy()
-        rotations = self.get_rotations.detach().contiguous().cpu().numpy()
-        attributes = np.concatenate((positions, sh_0, sh_rest, opacities, scales, rotations), axis=1)
-        attribute_names = (['x', 'y', 'z'] + ['f_dc_0', 'f_dc_1', 'f_dc_2'] + [f'f_rest_{i}' for i in range(sh_rest.shape[-1])] + ['opacity']
-                           + ['scale_0', 'scale_1', 'scale_2'] + ['rot_0', 'rot_1', 'rot_2', 'rot_3'])
-        vertices = np.empty(positions.shape[0], dtype=[(name, 'f4') for name in attribute_names])
-        for k, name in enumerate(attribute_names):
-            vertices[name] = attributes[:, k]
-        return {'vertex': vertices}
+        channel_major = lambda t: t.detach().permute(0, 2, 1).reshape(n, -1)
+        columns = {'x y z': self._positions.detach(), 'f_dc': channel_major(self._features_dc), 'f_rest': channel_major(self._features_rest),
+                   'opacity': torch.special.logit(self.get_opacities).detach(), 'scale': torch.log(self.get_scales).detach(), 'rot': self.get_rotations.detach()}
+        names: list[str] = []
+        for key, block in columns.items():
+            width = block.shape[1]
+            names += key.split() if ' ' in key else ([key] if (width == 1 and key == 'opacity') else [f'{key}_{i}' for i in range(width)])
+        table = torch.cat([block.reshape(n, -1).float() for block in columns.values()], dim=1).cpu().numpy()
+        vertex = np.empty(n, dtype=[(name, 'f4') for name in names])
+        for column, name in enumerate(names):
+            vertex[name] = table[:, column]
+        return {'vertex': vertex}
 
 
 def render_image_training(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np.ndarray) -> dict[str, torch.Tensor]:

@@ -72,47 +72,42 @@ class InstantNGPModel(torch.nn.Module):
         self.N_DENSITY_OUTPUT_FEATURES, self.N_DENSITY_NEURONS, self.N_DENSITY_LAYERS = N_DENSITY_OUTPUT_FEATURES, N_DENSITY_NEURONS, N_DENSITY_LAYERS
         self.DIR_SH_ENCODING_DEGREE, self.N_COLOR_NEURONS, self.N_COLOR_LAYERS = DIR_SH_ENCODING_DEGREE, N_COLOR_NEURONS, N_COLOR_LAYERS
         dev = torch.device(device)
-        self.center = torch.tensor([self.CENTER], dtype=torch.float32, device=dev)
-        self.xyz_min = -torch.ones(1, 3, device=dev) * SCALE
-        self.xyz_max = torch.ones(1, 3, device=dev) * SCALE
-        self.xyz_size = self.xyz_max - self.xyz_min
-        self.half_size = self.xyz_size / 2
-        self.cascades = max(1 + int(math.ceil(math.log2(2 * SCALE))), 1)
-        g = torch.arange(RESOLUTION, dtype=torch.int32, device=dev)
-        self.grid_coords = torch.stack(torch.meshgrid([g, g, g], indexing='xy'), dim=-1).reshape(-1, 3).contiguous()
-        self.register_buffer('occupancy_grid', torch.zeros(self.cascades, RESOLUTION ** 3, device=dev))
-        self.register_buffer('occupancy_bitfield', torch.zeros(self.cascades * RESOLUTION ** 3 // 8, dtype=torch.uint8, device=dev))
-        self.encoding_xyz = tcnn.NetworkWithInputEncoding(
-            n_input_dims=3, n_output_dims=N_DENSITY_OUTPUT_FEATURES,
-            encoding_config={
-                'otype': 'Grid', 'type': 'Hash', 'n_levels': HASHGRID_N_LEVELS, 'n_features_per_level': HASHGRID_N_FEATURES_PER_LEVEL,
-                'log2_hashmap_size': HASHGRID_LOG2_SIZE, 'base_resolution': HASHGRID_BASE_RESOLUTION,
-                'per_level_scale': math.exp(math.log(HASHGRID_TARGET_RESOLUTION * (2 * SCALE) / HASHGRID_BASE_RESOLUTION) / (HASHGRID_N_LEVELS - 1)),
-                'interpolation': 'Linear'},
-            network_config={'otype': 'FullyFusedMLP', 'activation': 'ReLU', 'output_activation': 'None',
-                            'n_neurons': N_DENSITY_NEURONS, 'n_hidden_layers': N_DENSITY_LAYERS},
-            seed=RANDOM_SEED).to(dev)
-        n_params_mlp = 0
-        n_inputs = next_multiple(HASHGRID_N_FEATURES_PER_LEVEL * HASHGRID_N_LEVELS, 16)
-        for _ in range(N_DENSITY_LAYERS):
-            n_params_mlp += next_multiple(N_DENSITY_NEURONS * n_inputs, 16)
-            n_inputs = N_DENSITY_NEURONS
-        n_params_mlp += next_multiple(self.encoding_xyz.n_output_dims, 16) * n_inputs
-        self.n_params_encoding_mlp = n_params_mlp
-        self.color_mlp_with_encoding = tcnn.NetworkWithInputEncoding(
-            n_input_dims=3 + self.encoding_xyz.n_output_dims, n_output_dims=3,
-            encoding_config={'otype': 'Composite', 'nested': [
-                {'n_dims_to_encode': 3, 'otype': 'SphericalHarmonics', 'degree': DIR_SH_ENCODING_DEGREE}, {'otype': 'Identity'}]},
-            network_config={'otype': 'FullyFusedMLP', 'activation': 'ReLU', 'output_activation': 'Sigmoid',
-                            'n_neurons': N_COLOR_NEURONS, 'n_hidden_layers': N_COLOR_LAYERS},
-            seed=RANDOM_SEED).to(dev)
-        self.n_mlp_params = len(self.color_mlp_with_encoding.params) + self.n_params_encoding_mlp
+        extent = float(SCALE)
+        # the scene box [-SCALE, SCALE]^3 around CENTER and the cascade count of the multi-resolution occupancy grid (Model.py:46-52)
+        self.center = torch.tensor(self.CENTER, dtype=torch.float32, device=dev).reshape(1, 3)
+        self.xyz_max = torch.full((1, 3), extent, device=dev)
+        self.xyz_min = -self.xyz_max
+        self.xyz_size = self.xyz_max * 2
+        self.half_size = self.xyz_max.clone()
+        self.cascades = max(1, 1 + math.ceil(math.log2(2 * extent)))
+        # cell coordinates in the enumeration order of a meshgrid(indexing='xy') over three aranges: entry i*G^2 + j*G + k is (x=j, y=i, z=k)
+        flat = torch.arange(RESOLUTION ** 3, dtype=torch.int32, device=dev)
+        self.grid_coords = torch.stack(((flat // RESOLUTION) % RESOLUTION, flat // RESOLUTION ** 2, flat % RESOLUTION), dim=1).contiguous()
+        n_cells = RESOLUTION ** 3
+        self.register_buffer('occupancy_grid', torch.zeros(self.cascades, n_cells, device=dev))
+        self.register_buffer('occupancy_bitfield', torch.zeros(self.cascades * n_cells // 8, dtype=torch.uint8, device=dev))
+        # geometric growth from the base to the target resolution over the levels (Model.py:61-70)
+        growth = math.exp(math.log(HASHGRID_TARGET_RESOLUTION * (2 * SCALE) / HASHGRID_BASE_RESOLUTION) / (HASHGRID_N_LEVELS - 1))
+        grid = {'otype': 'Grid', 'type': 'Hash', 'interpolation': 'Linear', 'n_levels': HASHGRID_N_LEVELS,
+                'n_features_per_level': HASHGRID_N_FEATURES_PER_LEVEL, 'log2_hashmap_size': HASHGRID_LOG2_SIZE,
+                'base_resolution': HASHGRID_BASE_RESOLUTION, 'per_level_scale': growth}
+        mlp = lambda width, depth, out: {'otype': 'FullyFusedMLP', 'activation': 'ReLU', 'output_activation': out, 'n_neurons': width, 'n_hidden_layers': depth}
+        self.encoding_xyz = tcnn.NetworkWithInputEncoding(3, N_DENSITY_OUTPUT_FEATURES, grid, mlp(N_DENSITY_NEURONS, N_DENSITY_LAYERS, 'None'),
+                                                          seed=RANDOM_SEED).to(dev)
+        # the density MLP's weights sit at the front of encoding_xyz.params (layer widths padded to 16): the slice the weight decay acts on
+        widths = [next_multiple(HASHGRID_N_FEATURES_PER_LEVEL * HASHGRID_N_LEVELS, 16)] + [N_DENSITY_NEURONS] * N_DENSITY_LAYERS
+        hidden = sum(next_multiple(fan_in * N_DENSITY_NEURONS, 16) for fan_in in widths[:-1])
+        self.n_params_encoding_mlp = hidden + next_multiple(N_DENSITY_OUTPUT_FEATURES, 16) * widths[-1]
+        direction_and_features = {'otype': 'Composite', 'nested': [{'otype': 'SphericalHarmonics', 'degree': DIR_SH_ENCODING_DEGREE, 'n_dims_to_encode': 3},
+                                                                   {'otype': 'Identity'}]}
+        self.color_mlp_with_encoding = tcnn.NetworkWithInputEncoding(3 + N_DENSITY_OUTPUT_FEATURES, 3, direction_and_features,
+                                                                     mlp(N_COLOR_NEURONS, N_COLOR_LAYERS, 'Sigmoid'), seed=RANDOM_SEED).to(dev)
+        self.n_mlp_params = self.n_params_encoding_mlp + self.color_mlp_with_encoding.params.numel()
 
     def weight_decay_mlp(self) -> torch.Tensor:
-        """Model.py:38-44"""
-        loss = self.encoding_xyz.params[:self.n_params_encoding_mlp].pow(2).sum()
-        loss = loss + self.color_mlp_with_encoding.params.pow(2).sum()
-        return loss / self.n_mlp_params
+        """Mean squared MLP weight over both networks, hash table excluded (Model.py:38-44)."""
+        squares = lambda t: t.square().sum()
+        return (squares(self.encoding_xyz.params[:self.n_params_encoding_mlp]) + squares(self.color_mlp_with_encoding.params)) / self.n_mlp_params
 
 
 class InstantNGPRenderer:

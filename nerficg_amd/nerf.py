@@ -41,11 +41,9 @@ class NeRFBlock(torch.nn.Module):
         self.encoding_position = FrequencyEncoding(n_frequencies_position, encoding_append_input)
         self.encoding_direction = FrequencyEncoding(n_frequencies_direction, encoding_append_input)
         n_pos, n_dir = self.encoding_position.get_n_outputs(3), self.encoding_direction.get_n_outputs(3)
-        layers = []
-        for index in range(n_layers):
-            n_in = n_pos if index == 0 else (n_features + n_pos if index in self.input_skips else n_features)
-            layers.append(torch.nn.Sequential(torch.nn.Linear(n_in, n_features), torch.nn.ReLU(True)))
-        self.initial_layers = torch.nn.ModuleList(layers)
+        nn = torch.nn
+        widths_in = [n_pos] + [n_features + (n_pos if k in self.input_skips else 0) for k in range(1, n_layers)]
+        self.initial_layers = nn.ModuleList(nn.Sequential(nn.Linear(w, n_features), nn.ReLU(True)) for w in widths_in)
         self.feature_layer = torch.nn.Linear(n_features, n_features)
         self.density_layer = torch.nn.Linear(n_features, 1)
         self.density_activation = torch.nn.ReLU(True)
@@ -56,69 +54,68 @@ class NeRFBlock(torch.nn.Module):
         self.color_layers = torch.nn.Sequential(*color)
 
     def forward(self, positions: torch.Tensor, directions: torch.Tensor, random_noise_density: float = 0.0):
-        pos_enc = self.encoding_position(positions)
-        x = pos_enc
-        for index, layer in enumerate(self.initial_layers):
-            x = layer(x)
-            if index + 1 in self.input_skips:
-                x = torch.cat((x, pos_enc), dim=-1)
-        density = self.density_layer(x)
+        encoded = self.encoding_position(positions)
+        hidden = encoded
+        for depth_index, block in enumerate(self.initial_layers, start=1):
+            hidden = block(hidden)
+            if depth_index in self.input_skips:  # the encoded position re-enters behind this layer
+                hidden = torch.cat((hidden, encoded), dim=-1)
+        sigma = self.density_layer(hidden)
         if random_noise_density > 0.0:
-            density = density + random_noise_density * torch.randn_like(density)
-        density = self.density_activation(density)
-        features = torch.cat((self.feature_layer(x), self.encoding_direction(directions)), dim=-1)
-        return density, self.color_layers(features)
+            sigma = sigma + torch.randn_like(sigma) * random_noise_density
+        view_dependent = torch.cat((self.feature_layer(hidden), self.encoding_direction(directions)), dim=-1)
+        return self.density_activation(sigma), self.color_layers(view_dependent)
 
 
 def generate_samples(n_rays: int, n_samples: int, near_plane: float, far_plane: float, randomize_samples: bool, dtype=torch.float32,
                      device=None) -> torch.Tensor:
-    """utils.py:57-75: linspace(near, far) per ray, optionally jittered inside the bins spanned by the mid points."""
-    depth = torch.linspace(near_plane, far_plane, n_samples, dtype=dtype, device=device).expand(n_rays, n_samples)
-    if randomize_samples:
-        mid = 0.5 * (depth[..., 1:] + depth[..., :-1])
-        upper = torch.cat((mid, depth[..., -1:]), dim=-1)
-        lower = torch.cat((depth[..., :1], mid), dim=-1)
-        depth = lower + (upper - lower) * torch.rand(depth.shape, dtype=dtype, device=device)
-    return depth
+    """Depths of the coarse pass (utils.py:57-75): `n_samples` evenly spaced values in [near, far] for every ray; with `randomize_samples` each
+    one is redrawn uniformly inside its stratum (the strata meet at the mid points, the two outer ones end at near / far)."""
+    t = torch.linspace(near_plane, far_plane, n_samples, dtype=dtype, device=device).expand(n_rays, n_samples)
+    if not randomize_samples:
+        return t
+    cuts = (t[:, 1:] + t[:, :-1]) * 0.5
+    lower, upper = torch.cat((t[:, :1], cuts), dim=1), torch.cat((cuts, t[:, -1:]), dim=1)
+    return torch.lerp(lower, upper, torch.rand(t.shape, dtype=dtype, device=device))
 
 
 def generate_samples_from_pdf(bins: torch.Tensor, values: torch.Tensor, n_samples: int, randomize_samples: bool) -> torch.Tensor:
-    """utils.py:78-109: inverse-CDF sampling of the piecewise-constant pdf given by the inner blending weights."""
-    bins = 0.5 * (bins[..., :-1] + bins[..., 1:])
-    values = values[..., 1:-1] + 1e-5
-    pdf = values / torch.sum(values, dim=-1, keepdim=True)
-    cdf = torch.cumsum(pdf, dim=-1)
-    cdf = torch.cat((torch.zeros_like(cdf[..., :1]), cdf), dim=-1)
+    """Depths of the fine pass (utils.py:78-109): inverse-transform sampling of the piecewise-constant density whose K-2 inner masses
+    (`values` without its ends, + 1e-5) sit between the K-1 mid points of `bins`; u is uniform (random or evenly spaced)."""
+    knots = (bins[:, 1:] + bins[:, :-1]) * 0.5
+    mass = values[:, 1:-1] + 1e-5
+    cdf = torch.nn.functional.pad(torch.cumsum(mass / mass.sum(dim=1, keepdim=True), dim=1), (1, 0))  # cdf[:, 0] = 0
+    rows = cdf.shape[0]
     if randomize_samples:
-        u = torch.rand(*cdf.shape[:-1], n_samples, device=bins.device)
+        u = torch.rand(rows, n_samples, device=bins.device)
     else:
-        u = torch.linspace(0.0, 1.0, steps=n_samples, device=bins.device).expand(*cdf.shape[:-1], n_samples)
-    u = u.contiguous()
-    inds = torch.searchsorted(cdf, u, right=True)
-    below, above = (inds - 1).clamp_min(0), inds.clamp_max(cdf.shape[-1] - 1)
-    cdf_lo, cdf_hi = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
-    bin_lo, bin_hi = torch.gather(bins, 1, below), torch.gather(bins, 1, above)
-    denom = cdf_hi - cdf_lo
-    denom = torch.where(denom < 1e-5, 1.0, denom)
-    return (bin_lo + (u - cdf_lo) / denom * (bin_hi - bin_lo)).detach()
+        u = torch.linspace(0.0, 1.0, steps=n_samples, device=bins.device).expand(rows, n_samples).contiguous()
+    right = torch.searchsorted(cdf, u, right=True)
+    left, right = (right - 1).clamp(min=0), right.clamp(max=cdf.shape[1] - 1)
+    c0, c1, k0, k1 = cdf.gather(1, left), cdf.gather(1, right), knots.gather(1, left), knots.gather(1, right)
+    width = c1 - c0
+    width = torch.where(width < 1e-5, torch.ones_like(width), width)  # empty interval: take its left knot
+    return (k0 + (u - c0) / width * (k1 - k0)).detach()
 
 
 def integrate_samples(depth_samples, ray_directions, densities, colors, background_color, final_delta: float = 1.0e10):
-    """utils.py:112-136: alpha = 1 - exp(-sigma delta), T = exclusive cumprod(1 - alpha), w = alpha T; rgb = sum w c (+ T_N bg),
-    depth = sum w t / alpha_final where T_N < 1 else 0."""
-    deltas = depth_samples[:, 1:] - depth_samples[..., :-1]
-    last = torch.full_like(deltas[..., :1], final_delta)
-    deltas = torch.cat((deltas, last), dim=-1) * ray_directions.norm(dim=-1, keepdim=True)
-    alphas = 1.0 - torch.exp(-densities * deltas)
-    transmittance = torch.cumprod(torch.cat((torch.ones_like(alphas[..., :1]), 1.0 - alphas), dim=-1), dim=-1)
-    weights = alphas * transmittance[..., :-1]
-    t_final = transmittance[..., -1:]
-    alpha_final = 1.0 - t_final
-    depth = torch.where(t_final < 1.0, torch.sum(weights * depth_samples, dim=-1, keepdim=True) / alpha_final, 0.0)
-    rgb = torch.sum(weights[..., None] * colors, dim=-2)
+    """Emission-absorption quadrature along each ray (utils.py:112-136).  Segment i spans depth i .. i+1 (the last one `final_delta`), scaled
+    by |direction| because depths are in units of the unnormalised ray; opacity_i = 1 - exp(-sigma_i len_i); a sample is weighted by its
+    opacity times the transmittance of everything in front.  -> rgb (+ leftover transmittance * background), depth (weighted mean, 0 for
+    rays that hit nothing), alpha, weights."""
+    pad = torch.nn.functional.pad
+    length = pad(torch.diff(depth_samples, dim=-1), (0, 1), value=final_delta) * torch.linalg.vector_norm(ray_directions, dim=-1, keepdim=True)
+    opacity = 1.0 - torch.exp(-densities * length)
+    through = torch.cumprod(pad(1.0 - opacity, (1, 0), value=1.0), dim=-1)      # through[:, i] = transmittance in front of sample i; [:, -1] = leftover
+    weights = opacity * through[:, :-1]
+    leftover = through[:, -1:]
+    alpha = 1.0 - leftover
+    weighted_depth = (weights * depth_samples).sum(dim=-1, keepdim=True)
+    depth = torch.where(leftover < 1.0, weighted_depth / alpha, torch.zeros_like(alpha))
+    rgb = (weights.unsqueeze(-1) * colors).sum(dim=-2)
     if background_color is not None:
-        rgb = rgb + t_final * background_color
-    return rgb, depth, alpha_final, weights
+        rgb = rgb + leftover * background_color
+    return rgb, depth, alpha, weights
 
 
 def render_rays(coarse_nerf: NeRFBlock | None, nerf: NeRFBlock, origin, direction, view_direction, near_plane: float, far_plane: float,
