@@ -199,25 +199,29 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
  * clamped (P) u8 bit mask (bit c = channel c clamped), cov3D (P,6), tiles_touched (P) u32.
  * Binning state: tile_counts, tile_fill (n_tiles) u32, ranges (n_tiles,2) u32, keys (num_rendered) u64, point_list
  * (num_rendered) i32.  Image state: n_contrib (H*W) u32, final_T (H*W).
- *   nrc_gs_preprocess : stages 1-2; *num_rendered (DEVICE i64) = number of (tile, Gaussian) instances -- the caller reads it
- *                       to size keys / point_list (the reference's rasterizer pays the same device->host read).
+ *   nrc_gs_preprocess : stages 1-2; num_rendered (DEVICE i64[2]): [0] = number of (tile, Gaussian) instances -- the caller reads it
+ *                       to size keys / point_list (the reference's rasterizer pays the same device->host read); [1] = number of
+ *                       (tile row, Gaussian) span records the binning needed: if it exceeds the span capacity the workspace was
+ *                       sized for, [0] is not valid and the call is repeated with a workspace for at least [1] spans.
  *   nrc_gs_bin_render : stages 3-5 -> out_color (3,H,W) = C + T * bg, n_contrib, final_T.
  *   nrc_gs_backward   : dL_dpix (3,H,W) -> every gradient (all fully written; dL_dmean2D (P,3) is the screen-space gradient
  *                       consumed by densification, src/Methods/GaussianSplatting/Model.py:258).
  * ===================================================================================================== */
-/* bytes of the per-workgroup tile-histogram matrix `bin_hist` used by the LDS binning path (0 = image too large, pass NULL) */
-int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H);
+/* bytes of the binning workspace `bin_hist` (depth pre-sort buffers, row-span records, cursors) for `span_capacity` span records
+ * (0 = default 4 P + 65536); returns 0 when the image has more than 256 tile rows or columns: pass NULL, the per-tile key sort is used.
+ * The same span_capacity goes to nrc_gs_preprocess and nrc_gs_bin_render. */
+int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H, int64_t span_capacity);
 int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs,
                       const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                       const float* campos, float tan_fovx, float tan_fovy, int32_t* radii, float* depths, float* points_xy,
                       float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched,
-                      uint32_t* tile_counts, uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t* num_rendered,
-                      nrc_stream_t stream);
+                      uint32_t* tile_counts, uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t span_capacity,
+                      int64_t* num_rendered, nrc_stream_t stream);
 int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg, const int32_t* radii, const float* depths,
                       const float* points_xy, const float* conic_opacity, const float* rgb, const uint32_t* ranges,
-                      uint32_t* tile_fill, const uint32_t* bin_hist, uint64_t* keys, int32_t* point_list, float* out_color,
-                      uint32_t* n_contrib, float* final_T, nrc_stream_t stream);
+                      uint32_t* tile_fill, const uint32_t* bin_hist, int64_t span_capacity, uint64_t* keys, int32_t* point_list,
+                      float* out_color, uint32_t* n_contrib, float* final_T, nrc_stream_t stream);
 int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg, const float* means3D, const float* shs,
                     const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,

@@ -246,12 +246,27 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam, cons
 // passes below take their slices from the depth-ordered list and keep that order inside every tile.
 #define RS_ITEMS 16                  // keys per thread per block
 #define RS_TILE (256 * RS_ITEMS)     // keys per block
-__global__ void __launch_bounds__(256) k_depth_keys(int P, const int32_t* __restrict__ radii, const float* __restrict__ depths,
-                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+// sort key (depth bits; invisible Gaussians last), the Gaussian's index, and its tile rectangle packed as x0 | y0 << 8 | (w-1) << 16 | (h-1) << 24
+// (tile grids of at most 256 x 256; RECT_NONE = no tile).  The rectangle travels through the sort as a second value, so the binning passes
+// stream (id, rectangle) in depth order instead of gathering radii / points_xy by id (246 us at 6 M as a separate gather kernel).
+#define RECT_NONE 0xffffffffu
+__global__ void __launch_bounds__(256) k_depth_keys(int P, int gx, int gy, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+                                                    const float* __restrict__ points_xy, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                    uint32_t* __restrict__ rects) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    keys[i] = radii[i] > 0 ? __float_as_uint(depths[i]) : 0xffffffffu;  // invisible Gaussians go last
+    const int rad = radii[i];
+    uint32_t rect = RECT_NONE;
+    if (rad > 0) {
+        const float pxy[2] = {points_xy[2 * i], points_xy[2 * i + 1]};
+        int rmin[2], rmax[2];
+        tile_rect(pxy, rad, gx, gy, rmin, rmax);
+        if (rmax[0] > rmin[0] && rmax[1] > rmin[1])
+            rect = (uint32_t)rmin[0] | (uint32_t)rmin[1] << 8 | (uint32_t)(rmax[0] - rmin[0] - 1) << 16 | (uint32_t)(rmax[1] - rmin[1] - 1) << 24;
+    }
+    keys[i] = rad > 0 ? __float_as_uint(depths[i]) : 0xffffffffu;  // invisible Gaussians go last
     vals[i] = (uint32_t)i;
+    rects[i] = rect;
 }
 // counts: digit-major [256][nblk4] (rows padded to a multiple of 4 for 16-byte loads); tot[256] = digit totals (atomics)
 __global__ void __launch_bounds__(256) k_radix_count(int n, int shift, int nblk4, const uint32_t* __restrict__ keys, uint32_t* __restrict__ counts,
@@ -270,49 +285,68 @@ __global__ void __launch_bounds__(256) k_radix_count(int n, int shift, int nblk4
     counts[(size_t)threadIdx.x * nblk4 + blockIdx.x] = c;  // digit-major: the scan order of a stable LSD pass
     if (c) atomicAdd(&tot[threadIdx.x], c);
 }
-// The global offset of (digit d, block b) = sum of tot[d' < d] + sum of counts[d][b' < b]: every scatter workgroup derives its
-// 256 offsets itself (thread d reads a prefix of row d with 16-byte loads) instead of waiting for a scan kernel over the whole
-// 256 x nblk matrix, which is latency-bound in a single workgroup (37 us per pass measured, more than count + scatter together).
+// offs[d][b] = global position of block b's first element with digit d = sum of tot[d' < d] + sum of counts[d][b' < b]: one workgroup per
+// digit row (256 of them run in parallel; a single-workgroup scan of the whole matrix was latency-bound at 37 us per pass, and letting every
+// scatter workgroup sum its own row prefixes cost it ~180 dependent 16-byte loads per thread at 6 M Gaussians).
+__global__ void __launch_bounds__(256) k_radix_offsets(int nblk, int nblk4, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ tot,
+                                                       uint32_t* __restrict__ offs) {
+    __shared__ int sm[8];
+    const int d = blockIdx.x;
+    int digit_base;
+    {
+        const int t = (int)tot[threadIdx.x];
+        const int ex = nrc_block256_excl_scan_i(t, sm, nullptr);
+        __shared__ int base_s;
+        if ((int)threadIdx.x == d) base_s = ex;
+        __syncthreads();
+        digit_base = base_s;
+    }
+    const uint32_t* row = counts + (size_t)d * nblk4;
+    uint32_t* out = offs + (size_t)d * nblk4;
+    int carry = digit_base;
+    for (int b0 = 0; b0 < nblk; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < nblk ? (int)row[i] : 0;
+        int total;
+        const int ex = nrc_block256_excl_scan_i(v, sm, &total);
+        if (i < nblk) out[i] = (uint32_t)(carry + ex);
+        carry += total;
+    }
+}
+// The block's 4096 elements are first ranked INTO LDS (stable: rounds in order, inside a round wave order then lane order), digit runs
+// back to back; only then they go out, element i of the staged block to first[digit] + (i - run start): consecutive lanes write consecutive
+// addresses inside a run (16 elements = 64 B on average) instead of one isolated 4-byte store per element and array.  One barrier per
+// round: the per-wave digit counts are triple-buffered (round r fills buffer r % 3, which was cleared two rounds earlier) and the running
+// per-digit totals double-buffered, so filling round r + 1 may overlap ranking round r.
 __global__ void __launch_bounds__(256) k_radix_scatter(int n, int shift, int nblk4, const uint32_t* __restrict__ keys_in,
-                                                       const uint32_t* __restrict__ vals_in, const uint32_t* __restrict__ counts,
-                                                       const uint32_t* __restrict__ tot, uint32_t* __restrict__ keys_out,
-                                                       uint32_t* __restrict__ vals_out) {
-    __shared__ uint32_t base_s[256];
-    __shared__ uint32_t whist[4][256];
-    __shared__ uint32_t wtot[4];
+                                                       const uint32_t* __restrict__ vals_in, const uint32_t* __restrict__ rects_in,
+                                                       const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offs,
+                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t* __restrict__ rects_out) {
+    __shared__ uint32_t first_g[256];       // global position of the block's first element with digit d
+    __shared__ uint32_t run0[256];          // position of the digit's run inside the staged block
+    __shared__ uint32_t running[2][256];    // elements of the digit staged before the current round
+    __shared__ uint32_t whist[3][4][256];
+    __shared__ int scan_sm[8];
+    __shared__ uint32_t st_key[RS_TILE], st_val[RS_TILE], st_rect[RS_TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
-        const uint32_t mine = tot[threadIdx.x];
-        uint32_t incl = mine;
+        const size_t at = (size_t)threadIdx.x * nblk4 + blockIdx.x;
+        first_g[threadIdx.x] = offs[at];
+        running[0][threadIdx.x] = 0u;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wtot[wave] = incl;
-        const uint32_t* row = counts + (size_t)threadIdx.x * nblk4;
-        const int nb = (int)blockIdx.x;
-        uint32_t pre = 0;
-        int b = 0;
-#pragma unroll 4
-        for (; b + 4 <= nb; b += 4) {
-            const uint4 v = *reinterpret_cast<const uint4*>(row + b);
-            pre += v.x + v.y + v.z + v.w;
-        }
-        for (; b < nb; b++) pre += row[b];
-        __syncthreads();
-        uint32_t off = incl - mine + pre;
-        for (int w = 0; w < wave; w++) off += wtot[w];
-        base_s[threadIdx.x] = off;
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) whist[q][w][threadIdx.x] = 0u;
+        run0[threadIdx.x] = (uint32_t)nrc_block256_excl_scan_i((int)counts[at], scan_sm, nullptr);  // ends with a barrier
     }
-#pragma unroll
-    for (int w = 0; w < 4; w++) whist[w][threadIdx.x] = 0;
-    __syncthreads();
     const int base = blockIdx.x * RS_TILE;
+    int i = base + threadIdx.x;
+    uint32_t key = i < n ? keys_in[i] : 0u, val = i < n ? vals_in[i] : 0u, rect = i < n ? rects_in[i] : 0u;
     for (int r = 0; r < RS_ITEMS; r++) {
-        const int i = base + r * 256 + threadIdx.x;
         const bool valid = i < n;
-        const uint32_t key = valid ? keys_in[i] : 0u, val = valid ? vals_in[i] : 0u;
+        const int i_next = i + 256;
+        const bool more = r + 1 < RS_ITEMS && i_next < n;
+        const uint32_t key_n = more ? keys_in[i_next] : 0u, val_n = more ? vals_in[i_next] : 0u, rect_n = more ? rects_in[i_next] : 0u;
         const uint32_t d = (key >> shift) & 255u;
         // lanes of this wave holding the same digit (8 ballots), rank among them in lane order = stable
         unsigned long long peers = __ballot(valid);
@@ -322,174 +356,272 @@ __global__ void __launch_bounds__(256) k_radix_scatter(int n, int shift, int nbl
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
         const uint32_t rank_w = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-        if (valid && rank_w == 0) whist[wave][d] = (uint32_t)__popcll(peers);
+        uint32_t (*wh)[256] = whist[r % 3];
+        if (valid && rank_w == 0) wh[wave][d] = (uint32_t)__popcll(peers);
         __syncthreads();
         if (valid) {
-            uint32_t off = base_s[d];
-            for (int w = 0; w < wave; w++) off += whist[w][d];
-            keys_out[off + rank_w] = key;
-            vals_out[off + rank_w] = val;
+            uint32_t off = run0[d] + running[r & 1][d];
+            for (int w = 0; w < wave; w++) off += wh[w][d];
+            off += rank_w;
+            st_key[off] = key; st_val[off] = val; st_rect[off] = rect;
         }
-        __syncthreads();
-        {
-            uint32_t t = 0;
+        {   // thread t looks after digit t: totals for the next round, and the buffer of the round after next is cleared
+            uint32_t t = running[r & 1][threadIdx.x];
 #pragma unroll
-            for (int w = 0; w < 4; w++) { t += whist[w][threadIdx.x]; whist[w][threadIdx.x] = 0; }
-            base_s[threadIdx.x] += t;
+            for (int w = 0; w < 4; w++) { t += wh[w][threadIdx.x]; whist[(r + 2) % 3][w][threadIdx.x] = 0u; }
+            running[(r + 1) & 1][threadIdx.x] = t;
         }
-        __syncthreads();
+        i = i_next; key = key_n; val = val_n; rect = rect_n;
+    }
+    __syncthreads();
+    const int n_here = min(RS_TILE, n - base);
+    for (int k = threadIdx.x; k < n_here; k += 256) {
+        const uint32_t kk = st_key[k];
+        const uint32_t d = (kk >> shift) & 255u;
+        const uint32_t pos = first_g[d] + ((uint32_t)k - run0[d]);
+        keys_out[pos] = kk; vals_out[pos] = st_val[k]; rects_out[pos] = st_rect[k];
     }
 }
 
+// ---- stable two-level binning of the depth-ordered Gaussians ---------------------------------------------------------------
+// Target: per tile, the ids of the Gaussians whose rectangle covers it, in depth order (= the reference's sort by (tile | depth) keys),
+// written as full cache lines.  History: v1 global atomics; v2 LDS histograms + per-tile sorts; v3 depth pre-sort + finishing sort;
+// v4 depth pre-sort + one wave per slice of the depth order walking its slice serially with per-(slice, tile) cursors -- correct and
+// sort-free, but every one of its 4-byte id stores opened its own cache line (slices x tiles = 8.9 M write frontiers: WRITE_SIZE 7.8 x the
+// list, 138 us at 1 M / 1.09 ms at 6 M Gaussians, profiles/r01_pmc_summary.md).  v5 (this one) scatters in two levels, like a two-digit
+// MSD radix sort over the tile id whose first digit is the TILE ROW and whose records are row SPANS, not instances:
+//   level 1  Gaussian -> one 8-byte span record {id, x0 | x1 << 16} per tile row of its rectangle, appended to the row's span list
+//            (a rectangle of 3 x 3 tiles is 3 records, not 9);
+//   level 2  the span list of a row, cut into items of SPAN_CH spans (one wave each) -> ids appended to the tiles x0 .. x1 - 1 of that row.
+// Both levels rank with a BIT MATRIX instead of a serial walk: 64 sources (lane = Gaussian / span, in depth order) set bit `lane` in the
+// LDS word of every destination (row / tile) they cover with ds_or -- the order of the ORs is irrelevant --, then the lanes switch roles
+// (lane = destination) and pop the bits of their word in ascending order: lane order = depth order, so the appends are stable, every
+// destination has a lane-private cursor, and no step waits for another.  A wave has gy (level 1) or gx (level 2) open write frontiers and
+// the level-2 grid is capped at 2048 waves, so the lines being appended stay in the XCD's L2 until they are full.
+// Counting passes of the same shape (LDS ds_add per covered destination) + two small scans give the cursors; everything is deterministic.
 #define GS_MAX_LDS_TILES 16384
-#define GS_SLICE_MAX 2048  // slices = waves of the binning passes
-#define GS_GROUPS 32       // slice groups of the two-level column scan over the slices x tiles matrix
-// ---- stable binning: one WAVE per slice of the depth-ordered Gaussians ----------------------------------------------------
-// Counting pass: lane = Gaussian, LDS atomics (order is irrelevant for counts).
-// slice = blockIdx.  (An XCD-contiguous mapping -- slice = (blockIdx % 8) * nb/8 + blockIdx / 8, so that the id writes falling
-// into one cache line come from one XCD's L2 -- was measured slower, 172 vs 138 us: the invisible tail of the depth order then
-// sits on one XCD and the other seven carry 8/7 of the work.)
-__device__ __forceinline__ int xcd_slice(int nb) { return (int)blockIdx.x < nb ? (int)blockIdx.x : -1; }
-__global__ void __launch_bounds__(64) k_bin_count(int P, int nb, int chunk, int gx, int gy, const uint32_t* __restrict__ order,
-                                                  const int32_t* __restrict__ radii, const float* __restrict__ points_xy,
-                                                  uint32_t* __restrict__ hist) {
-    extern __shared__ uint32_t lt[];
-    const int n_tiles = gx * gy, lane = threadIdx.x;
-    const int slice = xcd_slice(nb);
-    if (slice < 0) return;
-    for (int t = lane; t < n_tiles; t += 64) lt[t] = 0u;
+#define SPAN_CH 1024         // spans per level-2 item (one wave)
+#define SPAN_NB_MAX 4096     // level-1 slices (waves) at most
+#define SPAN_DIM_MAX 256     // tile rows / columns the lane-private cursors cover (4 registers x 64 lanes): 4096 x 4096 pixels
+#define SPAN_GRID 2048       // waves of the level-2 passes (grid-stride over the items)
+
+struct SpanRect { int id, y0, y1, x01; bool ok; };
+// Gaussian j of the depth order: id and rectangle as the sort delivered them
+__device__ __forceinline__ SpanRect span_rect(int j, int end, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rects) {
+    SpanRect r = {0, 0, 0, 0, false};
+    if (j < end) {
+        const uint32_t q = rects[j];
+        r.id = (int)order[j];
+        if (q != RECT_NONE) {
+            const int x0 = (int)(q & 0xffu), y0 = (int)((q >> 8) & 0xffu);
+            r.y0 = y0; r.y1 = y0 + (int)(q >> 24) + 1; r.x01 = x0 | ((x0 + (int)((q >> 16) & 0xffu) + 1) << 16);
+            r.ok = true;
+        }
+    }
+    return r;
+}
+// level 1, counting: cnt1[y][slice] = number of Gaussians of the slice whose rectangle covers tile row y
+__global__ void __launch_bounds__(64) k_span_count(int P, int nb1, int chunk1, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rects,
+                                                   uint32_t* __restrict__ cnt1) {
+    __shared__ uint32_t cnt[SPAN_DIM_MAX];
+    const int lane = threadIdx.x, slice = blockIdx.x;
+    for (int y = lane; y < SPAN_DIM_MAX; y += 64) cnt[y] = 0u;
     __syncthreads();
-    const int begin = slice * chunk, end = min(P, begin + chunk);
+    const int begin = slice * chunk1, end = min(P, begin + chunk1);
+#pragma unroll 4
     for (int j = begin + lane; j < end; j += 64) {
-        const int id = (int)order[j];
-        const int r = radii[id];
-        if (r <= 0) continue;
-        const float pxy[2] = {points_xy[2 * id], points_xy[2 * id + 1]};
-        int rmin[2], rmax[2];
-        tile_rect(pxy, r, gx, gy, rmin, rmax);
-        for (int y = rmin[1]; y < rmax[1]; y++)
-            for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&lt[y * gx + x], 1u);
+        const SpanRect r = span_rect(j, end, order, rects);
+        if (r.ok)
+            for (int y = r.y0; y < r.y1; y++) atomicAdd(&cnt[y], 1u);
     }
     __syncthreads();
-    uint32_t* row = hist + (size_t)slice * n_tiles;
-    for (int t = lane; t < n_tiles; t += 64) row[t] = lt[t];
+    for (int y = lane; y < gy; y += 64) cnt1[(size_t)y * nb1 + slice] = cnt[y];
 }
-// Scatter pass: the wave walks its slice in depth order, one Gaussian per step, lanes = the tiles of that Gaussian's rectangle.
-// The tiles of one rectangle are distinct, so the per-tile cursors in LDS are plain read-modify-writes (no atomics), and because
-// steps run in program order every tile receives its Gaussians in depth order: the ids land directly in their final, sorted
-// positions -- no (tile|depth) keys, no per-tile sort.  (A variant with four 16-lane Gaussians per step and a claim byte per tile
-// to detect shared tiles was measured at 2x the time: rectangles are heavy-tailed, large ones need 4x the rounds at 16 lanes.)
-__global__ void __launch_bounds__(64) k_bin_scatter(int P, int nb, int chunk, int gx, int gy, const uint32_t* __restrict__ order,
-                                                    const int32_t* __restrict__ radii, const float* __restrict__ points_xy,
-                                                    const uint32_t* __restrict__ bases, int32_t* __restrict__ point_list) {
-    extern __shared__ uint32_t lt[];
-    const int n_tiles = gx * gy, lane = threadIdx.x;
-    const int slice = xcd_slice(nb);
-    if (slice < 0) return;
-    const uint32_t* row = bases + (size_t)slice * n_tiles;
-    for (int t = lane; t < n_tiles; t += 64) lt[t] = row[t];
+// exclusive scan of cnt1[y][*] over the slices (in place) and the row totals
+__global__ void __launch_bounds__(256) k_span_scan(int nb1, uint32_t* __restrict__ cnt1, uint32_t* __restrict__ rowtot) {
+    __shared__ int sm[8];
+    uint32_t* row = cnt1 + (size_t)blockIdx.x * nb1;
+    int carry = 0;
+    for (int b0 = 0; b0 < nb1; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < nb1 ? (int)row[i] : 0;
+        int tot;
+        const int ex = nrc_block256_excl_scan_i(v, sm, &tot);
+        if (i < nb1) row[i] = (uint32_t)(carry + ex);
+        carry += tot;
+    }
+    if (threadIdx.x == 0) rowtot[blockIdx.x] = (uint32_t)carry;
+}
+// per tile row: first span (roff), number of level-2 items (nitems) and first item (ioff); meta = {spans, items}
+__global__ void __launch_bounds__(256) k_span_rows(int gy, const uint32_t* __restrict__ rowtot, uint32_t* __restrict__ roff, uint32_t* __restrict__ nitems,
+                                                   uint32_t* __restrict__ ioff, int64_t* __restrict__ meta_spans, uint32_t* __restrict__ meta_items) {
+    __shared__ int sm[8];
+    const int y = threadIdx.x;
+    const int n = y < gy ? (int)rowtot[y] : 0, it = (n + SPAN_CH - 1) / SPAN_CH;
+    int tot_s, tot_i;
+    const int es = nrc_block256_excl_scan_i(n, sm, &tot_s);
+    const int ei = nrc_block256_excl_scan_i(it, sm, &tot_i);
+    if (y < gy) { roff[y] = (uint32_t)es; nitems[y] = (uint32_t)it; ioff[y] = (uint32_t)ei; }
+    if (y == 0) { *meta_spans = (int64_t)tot_s; *meta_items = (uint32_t)tot_i; }
+}
+// value of entry `idx` (wave-uniform) of a table held as 4 registers x 64 lanes
+__device__ __forceinline__ int lanes_get(const int (&v)[4], int idx) {
+    const int k = idx >> 6, l = idx & 63;
+    return __builtin_amdgcn_readlane(k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3], l);
+}
+// level 1, scatter: spans of row y start at roff[y]; this slice's first span of the row at roff[y] + cnt1[y][slice]
+__global__ void __launch_bounds__(64) k_span_scatter(int P, int nb1, int chunk1, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rects,
+                                                     const uint32_t* __restrict__ cnt1, const uint32_t* __restrict__ roff, int64_t cap,
+                                                     uint2* __restrict__ spans) {
+    __shared__ uint32_t bits[SPAN_DIM_MAX][2];
+    __shared__ uint2 rec[64];
+    const int lane = threadIdx.x, slice = blockIdx.x;
+    const int nk = (gy + 63) >> 6;
+    int64_t cur[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int y = 64 * k + lane;
+        cur[k] = y < gy ? (int64_t)roff[y] + cnt1[(size_t)y * nb1 + slice] : 0;
+        bits[y][0] = 0u; bits[y][1] = 0u;
+    }
     __syncthreads();
-    const int begin = slice * chunk, end = min(P, begin + chunk);
+    const int begin = slice * chunk1, end = min(P, begin + chunk1);
+    SpanRect r = span_rect(begin + lane, end, order, rects);
     for (int j0 = begin; j0 < end; j0 += 64) {
-        const int j = j0 + lane;
-        int id = 0;
-        uint32_t org = 0u, ext = 0u;  // x0 | y0 << 16,  w | h << 16
-        if (j < end) {
-            id = (int)order[j];
-            const int r = radii[id];
-            if (r > 0) {
-                const float pxy[2] = {points_xy[2 * id], points_xy[2 * id + 1]};
-                int rmin[2], rmax[2];
-                tile_rect(pxy, r, gx, gy, rmin, rmax);
-                org = (uint32_t)rmin[0] | (uint32_t)rmin[1] << 16;
-                ext = (uint32_t)(rmax[0] - rmin[0]) | (uint32_t)(rmax[1] - rmin[1]) << 16;
-                if ((ext & 0xffffu) == 0u || (ext >> 16) == 0u) ext = 0u;
+        const SpanRect nxt = span_rect(j0 + 64 + lane, end, order, rects);  // the next chunk's rectangles travel while this one is ranked
+        rec[lane] = make_uint2((uint32_t)r.id, (uint32_t)r.x01);
+        if (r.ok)
+            for (int y = r.y0; y < r.y1; y++) atomicOr(&bits[y][lane >> 5], 1u << (lane & 31));
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k >= nk) break;
+            const int y = 64 * k + lane;
+            uint32_t lo = bits[y][0], hi = bits[y][1];
+            if (lo | hi) { bits[y][0] = 0u; bits[y][1] = 0u; }
+            while (lo | hi) {  // ascending bit = ascending lane = depth order
+                int src;
+                if (lo) { src = __builtin_ctz(lo); lo &= lo - 1u; } else { src = 32 + __builtin_ctz(hi); hi &= hi - 1u; }
+                if (cur[k] < cap) spans[cur[k]] = rec[src];
+                cur[k]++;
             }
         }
-        const uint32_t wq = ext & 0xffffu;
-        const uint32_t magic = wq > 1u ? 0xffffffffu / wq + 1u : 0u;  // c / w == umulhi(c, magic) for c < 2^16, w >= 2
-        unsigned long long todo = __ballot(ext != 0u);
-        while (todo) {
-            const int u = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const uint32_t uorg = (uint32_t)__builtin_amdgcn_readlane((int)org, u), uext = (uint32_t)__builtin_amdgcn_readlane((int)ext, u);
-            const int uid = __builtin_amdgcn_readlane(id, u);
-            const uint32_t um = (uint32_t)__builtin_amdgcn_readlane((int)magic, u);
-            const int ux0 = uorg & 0xffffu, uy0 = uorg >> 16, uw = uext & 0xffffu, uh = uext >> 16;
-            const int un = uw * uh;
-            for (int c0 = 0; c0 < un; c0 += 64) {
-                const int c = c0 + lane;
-                if (c < un) {
-                    const int yy = uw == 1 ? c : (int)__umulhi((uint32_t)c, um);
-                    const int t = (uy0 + yy) * gx + ux0 + (c - yy * uw);
-                    const uint32_t slot = lt[t];
-                    lt[t] = slot + 1u;
-                    point_list[slot] = uid;
+        __syncthreads();
+        r = nxt;
+    }
+}
+// the level-2 item `item`: its row, its first span and its span count (row tables in 4 registers x 64 lanes)
+struct SpanItem { int y; int64_t s0; int n; };
+__device__ __forceinline__ SpanItem span_item(int item, int gy, const int (&ioff_v)[4], const int (&nit_v)[4], const int (&roff_v)[4], const int (&rtot_v)[4]) {
+    int y = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) y += __popcll(__ballot(64 * k + (int)threadIdx.x < gy && ioff_v[k] + nit_v[k] <= item));
+    // = the number of rows that end at or before `item` (a row without items ends where it starts): all rows in front of the item's row
+    const int c = item - lanes_get(ioff_v, y);
+    SpanItem it;
+    it.y = y;
+    it.s0 = (int64_t)(uint32_t)lanes_get(roff_v, y) + (int64_t)c * SPAN_CH;
+    it.n = min(SPAN_CH, lanes_get(rtot_v, y) - c * SPAN_CH);
+    return it;
+}
+#define SPAN_LOAD_ROW_TABLES()                                                                                                   \
+    int ioff_v[4], nit_v[4], roff_v[4], rtot_v[4];                                                                               \
+    _Pragma("unroll") for (int k = 0; k < 4; k++) {                                                                              \
+        const int yy = 64 * k + lane;                                                                                            \
+        ioff_v[k] = yy < gy ? (int)ioff[yy] : 0; nit_v[k] = yy < gy ? (int)nitems[yy] : 0;                                        \
+        roff_v[k] = yy < gy ? (int)roff[yy] : 0; rtot_v[k] = yy < gy ? (int)rowtot[yy] : 0;                                       \
+    }
+// level 2, counting: cnt2[item][x] = number of spans of the item that cover tile x of the item's row
+__global__ void __launch_bounds__(64) k_item_count(int gx, int gy, const uint32_t* __restrict__ rowtot, const uint32_t* __restrict__ roff,
+                                                   const uint32_t* __restrict__ nitems, const uint32_t* __restrict__ ioff, const uint32_t* __restrict__ meta_items,
+                                                   int64_t cap, int item_cap, const uint2* __restrict__ spans, uint32_t* __restrict__ cnt2) {
+    __shared__ uint32_t cnt[SPAN_DIM_MAX];
+    const int lane = threadIdx.x;
+    SPAN_LOAD_ROW_TABLES();
+    const int n_items = min((int)*meta_items, item_cap);  // more items than the workspace holds: the caller sees spans > capacity and retries
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const SpanItem it = span_item(item, gy, ioff_v, nit_v, roff_v, rtot_v);
+        for (int x = lane; x < SPAN_DIM_MAX; x += 64) cnt[x] = 0u;
+        __syncthreads();
+        for (int j = lane; j < it.n; j += 64) {
+            if (it.s0 + j >= cap) break;
+            const uint32_t x01 = spans[it.s0 + j].y;
+            for (int x = (int)(x01 & 0xffffu); x < (int)(x01 >> 16); x++) atomicAdd(&cnt[x], 1u);
+        }
+        __syncthreads();
+        for (int x = lane; x < gx; x += 64) cnt2[(size_t)item * gx + x] = cnt[x];
+        __syncthreads();
+    }
+}
+// per tile (y, x): exclusive scan of cnt2[item][x] over the items of row y (in place) and the tile total.  64 tiles x 16 item groups per workgroup.
+__global__ void __launch_bounds__(1024) k_item_scan(int gx, int item_cap, const uint32_t* __restrict__ nitems, const uint32_t* __restrict__ ioff,
+                                                    uint32_t* __restrict__ cnt2, uint32_t* __restrict__ tcount) {
+    __shared__ uint32_t gsum[16][64];
+    const int xl = threadIdx.x & 63, g = threadIdx.x >> 6, y = blockIdx.y, x = blockIdx.x * 64 + xl;
+    const int i0 = min((int)ioff[y], item_cap), ni = min((int)nitems[y], item_cap - i0);
+    const int per = (ni + 15) / 16, a = min(ni, g * per), b = min(ni, a + per);
+    uint32_t s = 0;
+    if (x < gx)
+        for (int i = a; i < b; i++) s += cnt2[(size_t)(i0 + i) * gx + x];
+    gsum[g][xl] = s;
+    __syncthreads();
+    uint32_t run = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const uint32_t v = gsum[q][xl]; tot += v; if (q < g) run += v; }
+    if (x < gx) {
+        for (int i = a; i < b; i++) {
+            const size_t k = (size_t)(i0 + i) * gx + x;
+            const uint32_t c = cnt2[k];
+            cnt2[k] = run;
+            run += c;
+        }
+        if (g == 0) tcount[(size_t)y * gx + x] = tot;
+    }
+}
+// level 2, scatter: ids of the item's spans appended to the tiles they cover; tile (y, x) of this item starts at ranges[tile].first + cnt2[item][x]
+__global__ void __launch_bounds__(64) k_item_scatter(int gx, int gy, const uint32_t* __restrict__ rowtot, const uint32_t* __restrict__ roff,
+                                                     const uint32_t* __restrict__ nitems, const uint32_t* __restrict__ ioff, const uint32_t* __restrict__ meta_items,
+                                                     const uint2* __restrict__ spans, const uint32_t* __restrict__ cnt2, const uint32_t* __restrict__ ranges,
+                                                     int32_t* __restrict__ point_list) {
+    __shared__ uint32_t bits[SPAN_DIM_MAX][2];
+    __shared__ int ids[64];
+    const int lane = threadIdx.x;
+    const int nk = (gx + 63) >> 6;
+    SPAN_LOAD_ROW_TABLES();
+    const int n_items = (int)*meta_items;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { bits[64 * k + lane][0] = 0u; bits[64 * k + lane][1] = 0u; }
+    __syncthreads();
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const SpanItem it = span_item(item, gy, ioff_v, nit_v, roff_v, rtot_v);
+        uint32_t cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = 64 * k + lane;
+            cur[k] = x < gx ? ranges[2 * ((size_t)it.y * gx + x)] + cnt2[(size_t)item * gx + x] : 0u;
+        }
+        uint2 sp = lane < it.n ? spans[it.s0 + lane] : make_uint2(0u, 0u);
+        for (int j0 = 0; j0 < it.n; j0 += 64) {
+            const uint2 nxt = j0 + 64 + lane < it.n ? spans[it.s0 + j0 + 64 + lane] : make_uint2(0u, 0u);
+            ids[lane] = (int)sp.x;
+            for (int x = (int)(sp.y & 0xffffu); x < (int)(sp.y >> 16); x++) atomicOr(&bits[x][lane >> 5], 1u << (lane & 31));
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k >= nk) break;
+                const int x = 64 * k + lane;
+                uint32_t lo = bits[x][0], hi = bits[x][1];
+                if (lo | hi) { bits[x][0] = 0u; bits[x][1] = 0u; }
+                while (lo | hi) {
+                    int src;
+                    if (lo) { src = __builtin_ctz(lo); lo &= lo - 1u; } else { src = 32 + __builtin_ctz(hi); hi &= hi - 1u; }
+                    point_list[cur[k]++] = ids[src];
                 }
             }
+            __syncthreads();
+            sp = nxt;
         }
     }
-}
-// column sums per slice group: part[g][t] = sum of hist[b][t] over the slices b of group g   (64 tiles x 4 groups per workgroup)
-__global__ void __launch_bounds__(256) k_tile_totals(int nb, int n_tiles, const uint32_t* __restrict__ hist, uint32_t* __restrict__ part) {
-    const int tx = threadIdx.x & 63, g = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int t = blockIdx.x * 64 + tx;
-    const int per = (nb + GS_GROUPS - 1) / GS_GROUPS, b0 = min(nb, g * per), b1 = min(nb, b0 + per);
-    if (t >= n_tiles) return;
-    uint32_t s = 0;
-#pragma unroll 8
-    for (int b = b0; b < b1; b++) s += hist[(size_t)b * n_tiles + t];
-    part[(size_t)g * n_tiles + t] = s;
-}
-// hist[b][t] <- first output position of slice b in tile t (exclusive column scan inside the group, seeded with the group base)
-__global__ void __launch_bounds__(256) k_tile_bases(int nb, int n_tiles, const uint32_t* __restrict__ part, uint32_t* __restrict__ hist) {
-    const int tx = threadIdx.x & 63, g = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int t = blockIdx.x * 64 + tx;
-    const int per = (nb + GS_GROUPS - 1) / GS_GROUPS, b0 = min(nb, g * per), b1 = min(nb, b0 + per);
-    if (t >= n_tiles) return;
-    uint32_t run = part[(size_t)g * n_tiles + t];
-#pragma unroll 8
-    for (int b = b0; b < b1; b++) {
-        const uint32_t c = hist[(size_t)b * n_tiles + t];
-        hist[(size_t)b * n_tiles + t] = run;
-        run += c;
-    }
-}
-// tile ranges from the group sums; part[g][t] becomes the first output position of group g in tile t
-__global__ void __launch_bounds__(1024) k_scan_tiles_grouped(uint32_t* __restrict__ part, int n, uint32_t* __restrict__ ranges,
-                                                             uint32_t* __restrict__ fill, int64_t* __restrict__ num_rendered) {
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        uint32_t pv[GS_GROUPS];
-        uint32_t v = 0;
-#pragma unroll
-        for (int g = 0; g < GS_GROUPS; g++) { pv[g] = i < n ? part[(size_t)g * n + i] : 0u; v += pv[g]; }
-        uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t off = carry_s;
-        for (int w = 0; w < wave; w++) off += wave_tot[w];
-        if (i < n) {
-            uint32_t run = off + incl - v;
-            ranges[2 * i] = run; ranges[2 * i + 1] = off + incl; fill[i] = 0u;
-#pragma unroll
-            for (int g = 0; g < GS_GROUPS; g++) { part[(size_t)g * n + i] = run; run += pv[g]; }
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = off + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *num_rendered = (int64_t)carry_s;
 }
 
 // ------------------------------------------------------------------------------------------------ 2. tile ranges
@@ -589,17 +721,18 @@ __global__ void __launch_bounds__(256) k_sort_tiles(const uint32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ 5. render
-// thread -> pixel of the 16x16 tile: every wave owns an 8x8 quadrant (not a 16x4 strip), so that fewer Gaussians of the tile list
-// touch a given wave (smaller perimeter) and more steps are skipped with the whole wave inactive
-__device__ __forceinline__ int tile_px(unsigned t) { return (int)((t & 7u) + ((t >> 6) & 1u) * 8u); }
-__device__ __forceinline__ int tile_py(unsigned t) { return (int)(((t >> 3) & 7u) + (t >> 7) * 8u); }
+// thread -> pixel of the 16x16 tile: wave = 8x8 quadrant, DPP row (16 lanes) = 4x4 block of the quadrant.  block index b = 4 * wave + row,
+// block (cx, cy) of the 4x4 block grid of the tile: cx = 2 * (wave & 1) + (row & 1), cy = 2 * (wave >> 1) + (row >> 1).
+__device__ __forceinline__ int tile_px(unsigned t) { return (int)((t & 3u) + ((t >> 4) & 1u) * 4u + ((t >> 6) & 1u) * 8u); }
+__device__ __forceinline__ int tile_py(unsigned t) { return (int)(((t >> 2) & 3u) + ((t >> 5) & 1u) * 4u + (t >> 7) * 8u); }
 // The tile lists come from the square 3-sigma bound of preprocess (reference semantics, kept bit-exact), but a pixel only blends a
 // Gaussian where alpha = o exp(power) >= 1/255, i.e. inside the ellipse A dx^2 + 2 B dx dy + C dy^2 <= 2 ln(255 o).  On the bench
-// scene 52 % of the (tile, Gaussian) pairs of a list have no such pixel in the tile, and a pair that has touches 2.5 of the 4 wave
-// quadrants (tools/gs_stats.py).  Both render kernels therefore (1) drop the pairs whose ellipse box misses the tile while a batch
-// is staged into LDS (order-preserving compaction, the list position travels with the entry), and (2) test the box against the
-// wave's 8x8 quadrant with wave-uniform arithmetic before any per-pixel work.  The box is conservative (margins below), so
-// exactly the same pixels blend exactly the same Gaussians.
+// scene 52 % of the (tile, Gaussian) pairs of a list have no such pixel in the tile, and the box of a pair that has is ~5 pixels wide
+// (tools/gs_stats.py): it reaches 2.5 of the four 8x8 quadrants (160 lanes) but only ~5 of the sixteen 4x4 blocks (80 lanes).
+// Both render kernels therefore keep ONE WORK LIST PER 4x4 BLOCK: while a batch of 256 list entries is staged into LDS every thread tests
+// its entry's box against the 16 blocks; 16 ballots and a prefix over the 4 waves turn the flags into 16 ascending index lists; and every
+// DPP row of a wave walks ITS OWN list -- the four rows of a wave blend four different Gaussians in the same instruction.  The box is
+// conservative (margins below), so exactly the same pixels blend exactly the same Gaussians in the same order: bit-identical pictures.
 __device__ __forceinline__ float2 splat_extent(const float4& co) {
     const float inf = __builtin_inff();
     if (!(co.w > 0.f)) return make_float2(-1.f, -1.f);              // alpha <= 0 everywhere
@@ -609,51 +742,57 @@ __device__ __forceinline__ float2 splat_extent(const float4& co) {
     if (!(det > 0.f) || !(co.x > 0.f) || !(co.z > 0.f)) return make_float2(inf, inf);  // not an ellipse: no culling
     return make_float2(sqrtf(tau * co.z / det) * 1.001f + 0.01f, sqrtf(tau * co.x / det) * 1.001f + 0.01f);
 }
-__device__ __forceinline__ bool box_hits(const float2& xy, const float2& ext, float x0, float y0, float span) {
-    return xy.x + ext.x >= x0 && xy.x - ext.x <= x0 + span && xy.y + ext.y >= y0 && xy.y - ext.y <= y0 + span;
-}
-// order-preserving compaction of the workgroup's flagged threads: returns this thread's slot, total in *n_out
-__device__ __forceinline__ int block_compact(bool flag, int* s_wcnt, int* n_out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(flag);
-    if (lane == 0) s_wcnt[wave] = __popcll(m);
-    __syncthreads();
-    int off = 0, tot = 0;
+// bit b set when the box xy +- ext reaches the pixel centres of block b (block = 4 pixel columns x 4 pixel rows: centres x0 .. x0 + 3)
+__device__ __forceinline__ unsigned block_flags(const float2& xy, const float2& ext, float tx0, float ty0) {
+    unsigned col = 0, row = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) { const int c = s_wcnt[w]; tot += c; if (w < wave) off += c; }
-    *n_out = tot;
-    return off + __popcll(m & ((1ull << lane) - 1ull));
-}
-
-// Staging of one batch for both render kernels: thread t holds entry t of the batch (flags = bit q set when the alpha >= 1/255 ellipse box
-// of its Gaussian reaches quadrant q of the tile).  Builds, per quadrant, the ascending list of batch entries that reach it --
-// every wave then walks ONLY its own list: no per-step box test, no skipped steps (a listed pair used to cost a wave-uniform box test,
-// and 37 % of the steps of a wave were pairs that miss its quadrant).  Returns the length of the calling wave's list.
-__device__ __forceinline__ int quadrant_lists(unsigned flags, uint8_t (*s_list)[BATCH], int (*s_qcnt)[4]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long m[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) m[q] = __ballot((flags >> q) & 1u);
-    if (lane < 4) s_qcnt[wave][lane] = __popcll(lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3]);
-    __syncthreads();
-    const unsigned long long below = (1ull << lane) - 1ull;
-    int mine = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        int off = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) { const int c = s_qcnt[w][q]; tot += c; if (w < wave) off += c; }
-        if ((flags >> q) & 1u) s_list[q][off + __popcll(m[q] & below)] = (uint8_t)threadIdx.x;
-        if (q == wave) mine = tot;
+    for (int c = 0; c < 4; c++) {
+        const float x0 = tx0 + (float)(4 * c), y0 = ty0 + (float)(4 * c);
+        col |= (unsigned)(xy.x + ext.x >= x0 && xy.x - ext.x <= x0 + 3.f) << c;
+        row |= (unsigned)(xy.y + ext.y >= y0 && xy.y - ext.y <= y0 + 3.f) << c;
     }
-    __syncthreads();
-    return mine;
-}
-__device__ __forceinline__ unsigned quadrant_flags(const float2& xy, const float2& ext, float tx0, float ty0) {
+    // block b = 4 * (2 * (cy >> 1) + (cx >> 1)) + 2 * (cy & 1) + (cx & 1): per quadrant the 2x2 product of its two column and two row bits
     unsigned f = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) f |= (unsigned)box_hits(xy, ext, tx0 + (float)((q & 1) * 8), ty0 + (float)((q >> 1) * 8), 7.f) << q;
+    for (int q = 0; q < 4; q++) {
+        const unsigned c2 = (col >> (2 * (q & 1))) & 3u, r2 = (row >> (2 * (q >> 1))) & 3u;
+        const unsigned lo = (r2 & 1u) ? c2 : 0u, hi = (r2 & 2u) ? c2 : 0u;
+        f |= (lo | (hi << 2)) << (4 * q);
+    }
     return f;
+}
+#define N_BLOCKS 16
+// Builds the 16 per-block lists of one staged batch (thread t holds entry t; flags = its block bits).  s_list[b] receives, in ascending
+// order, the batch indices of the entries that reach block b.  Returns the length of the list of the calling thread's own block (uniform
+// over a DPP row); *n_wave = the longest of the calling wave's four lists.
+__device__ __forceinline__ int block_lists(unsigned flags, uint8_t (*s_list)[BATCH], uint16_t (*s_cnt)[N_BLOCKS], int* n_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long m[N_BLOCKS];
+#pragma unroll
+    for (int b = 0; b < N_BLOCKS; b++) m[b] = __ballot((flags >> b) & 1u);
+    if (lane == 0) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_cnt[wave]);
+#pragma unroll
+        for (int b = 0; b < N_BLOCKS; b += 2) dst[b >> 1] = (uint32_t)__popcll(m[b]) | ((uint32_t)__popcll(m[b + 1]) << 16);
+    }
+    __syncthreads();
+    int base_v = 0, tot_v = 0;  // lanes 0..15: block `lane`
+    if (lane < N_BLOCKS) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const int c = s_cnt[w][lane]; tot_v += c; if (w < wave) base_v += c; }
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int b = 0; b < N_BLOCKS; b++) {
+        if (m[b] == 0ull) continue;  // wave-uniform
+        const int base = __builtin_amdgcn_readlane(base_v, b);
+        if ((flags >> b) & 1u) s_list[b][base + __popcll(m[b] & below)] = (uint8_t)threadIdx.x;
+    }
+    const int mine = __shfl(tot_v, 4 * wave + (lane >> 4), 64);
+    *n_wave = max(max(__builtin_amdgcn_readlane(mine, 0), __builtin_amdgcn_readlane(mine, 16)),
+                  max(__builtin_amdgcn_readlane(mine, 32), __builtin_amdgcn_readlane(mine, 48)));
+    __syncthreads();
+    return mine;
 }
 
 __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
@@ -662,19 +801,20 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
                                                 uint32_t* __restrict__ n_contrib, float* __restrict__ final_T) {
     __shared__ float2 s_xy[BATCH];
     __shared__ float4 s_co[BATCH];
-    __shared__ float s_rgb[BATCH * 3];
-    __shared__ __attribute__((aligned(4))) uint8_t s_list[4][BATCH];
-    __shared__ int s_qcnt[4][4];
+    __shared__ float4 s_rgb[BATCH];
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[N_BLOCKS][BATCH];
+    __shared__ __attribute__((aligned(16))) uint16_t s_cnt[4][N_BLOCKS];
     const int tile = blockIdx.y * cam.gx + blockIdx.x;
     const int px = blockIdx.x * TILE + tile_px(threadIdx.x), py = blockIdx.y * TILE + tile_py(threadIdx.x);
     const bool inside = px < cam.W && py < cam.H;
     const float fx = (float)px, fy = (float)py;
     const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
-    const int wave = threadIdx.x >> 6;  // = quadrant (tile_px / tile_py)
+    const int block = threadIdx.x >> 4;  // = 4 * wave + DPP row
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last = 0;
+    const uint32_t* list4 = reinterpret_cast<const uint32_t*>(s_list[block]);
     for (uint32_t base = r0; base < r1; base += BATCH) {
         if (__syncthreads_count(done) == 256) break;
         const uint32_t k = base + threadIdx.x;
@@ -683,40 +823,55 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
             const int id = point_list[k];
             const float2 xy = make_float2(points_xy[2 * id], points_xy[2 * id + 1]);
             const float4 co = *reinterpret_cast<const float4*>(conic_opacity + 4 * id);
-            flags = quadrant_flags(xy, splat_extent(co), tx0, ty0);
+            flags = block_flags(xy, splat_extent(co), tx0, ty0);
             if (flags) {
                 s_xy[threadIdx.x] = xy; s_co[threadIdx.x] = co;
-                s_rgb[3 * threadIdx.x] = rgb[3 * id]; s_rgb[3 * threadIdx.x + 1] = rgb[3 * id + 1]; s_rgb[3 * threadIdx.x + 2] = rgb[3 * id + 2];
+                s_rgb[threadIdx.x] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], 0.f);
             }
         }
-        const int n_mine = quadrant_lists(flags, s_list, s_qcnt);
+        int n_wave;
+        const int n_mine = block_lists(flags, s_list, s_cnt, &n_wave);
+#ifdef EXP_NO_BLEND
+        n_wave = min(n_wave, cam.D - 1000);
+#endif
         const uint32_t pos0 = base - r0 + 1u;  // contributor number of batch entry 0 = its position in the tile list + 1
-        // the list is read four entries (one dword, wave-uniform) at a time: one dependent LDS round trip per four Gaussians
-        const uint32_t* list4 = reinterpret_cast<const uint32_t*>(s_list[wave]);
-        for (int jj = 0; jj < n_mine; jj += 4) {
+        for (int jj = 0; jj < n_wave; jj += 4) {
             if (__ballot(!done) == 0ull) break;  // wave-uniform: every pixel of the quadrant is saturated
-            const uint32_t pack = (uint32_t)__builtin_amdgcn_readfirstlane((int)list4[jj >> 2]);
+            const uint32_t pack = list4[jj >> 2];   // four entries of this row's list per LDS read
+            // A dependent chain of VALU instructions issues one instruction per ~8 cycles on this chip, and more resident waves do not fill the
+            // gaps (tools/micro/valu_rate.hip: 4.5 cycles per instruction at 8 waves per SIMD and one chain, 2.3 with four independent chains per
+            // wave).  So the four entries of a pack are taken TOGETHER: (1) all LDS reads, (2) the four alphas -- independent of the pixel's
+            // running state, four interleaved chains -- and only then (3) the short serial part (transmittance test, masks, accumulation) in
+            // list order.  Entries past the end of the row's list and the reference's four early-outs (done / power > 0 / alpha < 1/255 /
+            // saturation) are lane masks; same arithmetic, same order per pixel: bit-identical pixels.
+            int j[4];
+            float2 xy_j[4];
+            float4 co_j[4], cl_j[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (jj + u >= n_mine) break;
-                const int j = (int)((pack >> (8 * u)) & 0xffu);
-                // Branch-free body: the reference's four early-outs (done / power > 0 / alpha < 1/255 / saturation) become lane masks.
-                // All lanes of a wave execute the same instructions anyway; the nested `continue`s cost ~30 scalar exec-mask instructions
-                // per step next to ~45 vector ones.  Same arithmetic, same order: bit-identical pixels.
-                const float2 xy_j = s_xy[j];
-                const float dx = xy_j.x - fx, dy = xy_j.y - fy;
-                const float4 co_j = s_co[j];
-                const float power = -0.5f * (co_j.x * dx * dx + co_j.z * dy * dy) - co_j.y * dx * dy;
-                const float alpha = fminf(0.99f, co_j.w * expf(power));
-                const float test_T = T * (1 - alpha);
-                const bool valid = !done & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
+                j[u] = (int)((pack >> (8 * u)) & 0xffu);  // bytes behind the list end are stale indices of earlier batches: readable, masked below
+                xy_j[u] = s_xy[j[u]]; co_j[u] = s_co[j[u]]; cl_j[u] = s_rgb[j[u]];
+            }
+            float alpha[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float dx = xy_j[u].x - fx, dy = xy_j[u].y - fy;
+                const float power = -0.5f * (co_j[u].x * dx * dx + co_j[u].z * dy * dy) - co_j[u].y * dx * dy;
+                alpha[u] = fminf(0.99f, co_j[u].w * expf(power));
+                ok[u] = (jj + u < n_mine) & !(power > 0.0f) & !(alpha[u] < 1.0f / 255.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float test_T = T * (1 - alpha[u]);
+                const bool valid = ok[u] & !done;
                 const bool sat = valid & (test_T < 0.0001f);
                 const bool upd = valid & !sat;
                 done = done | sat;
-                const float a = upd ? alpha : 0.f;
-                C0 += s_rgb[3 * j] * a * T; C1 += s_rgb[3 * j + 1] * a * T; C2 += s_rgb[3 * j + 2] * a * T;
+                // masked lanes add an exact 0 (a select, not a product: a stale or never-written LDS entry behind the list end may hold a NaN)
+                C0 += upd ? cl_j[u].x * alpha[u] * T : 0.f; C1 += upd ? cl_j[u].y * alpha[u] * T : 0.f; C2 += upd ? cl_j[u].z * alpha[u] * T : 0.f;
                 T = upd ? test_T : T;
-                last = upd ? pos0 + (uint32_t)j : last;
+                last = upd ? pos0 + (uint32_t)j[u] : last;
             }
         }
         __syncthreads();
@@ -730,23 +885,9 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------ 6. render backward
-// wave64 sum with DPP row operations (no LDS crossbar traffic): the total lands in lane 63.  All steps run UNMASKED
-// (row_mask = bank_mask = 0xf, out-of-row sources read 0): only lane 63 has to be right, and without masks every step is a
-// single v_add_f32_dpp -- with the textbook masks the compiler needs v_mov 0 + v_mov_dpp + v_add for four of the six steps
-// (126 instead of 54 instructions for the nine sums of a Gaussian).
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xf, 0xf, true));  // row_bcast:15
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xf, 0xf, true));  // row_bcast:31
-    return v;
-}
-// the same over the 16-lane DPP rows only (4 steps): lanes 15, 31, 47, 63 hold their row's sum.  The two row_bcast steps that carry the
-// sums on to lane 63 cost 18 VALU instructions per Gaussian for the nine quantities; four single-lane LDS atomics instead of one do not
-// show in the kernel time (the kernel issues VALU instructions 89 % of the time): fwd+bwd 1.93 -> 1.88 ms.  Stopping after three steps
-// (eight lanes per wave on the same LDS address) does: 2.30 ms.
+// sum over the 16 lanes of a DPP row with row operations (no LDS crossbar traffic): lanes 15, 31, 47, 63 hold their row's sum.  All steps
+// run UNMASKED (row_mask = bank_mask = 0xf, out-of-row sources read 0): only the last lane of a row has to be right, and without masks
+// every step is a single v_add_f32_dpp.
 __device__ __forceinline__ float row_sum_to_lane15(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
@@ -763,11 +904,13 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
     __shared__ float2 s_xy[BATCH];
     __shared__ float4 s_co[BATCH];
     __shared__ float s_rgb[BATCH * 3];
-    __shared__ float s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 4 waves, flushed once per batch
-    __shared__ __attribute__((aligned(4))) uint8_t s_list[4][BATCH];
-    __shared__ int s_qcnt[4][4];
+    __shared__ float s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 16 blocks, flushed once per batch
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[N_BLOCKS][BATCH];
+    __shared__ __attribute__((aligned(16))) uint16_t s_cnt[4][N_BLOCKS];
+    __shared__ int s_blast[N_BLOCKS];
     const int tile = blockIdx.y * cam.gx + blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // wave = quadrant
+    const int lane = threadIdx.x & 63;
+    const int block = threadIdx.x >> 4;
     const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
     const int px = blockIdx.x * TILE + tile_px(threadIdx.x), py = blockIdx.y * TILE + tile_py(threadIdx.x);
     const bool inside = px < cam.W && py < cam.H;
@@ -782,18 +925,20 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
     const float g0 = inside ? dL_dpix[pix] : 0.f, g1 = inside ? dL_dpix[hw + pix] : 0.f, g2 = inside ? dL_dpix[2 * hw + pix] : 0.f;
     const float bg_dot = bg0 * g0 + bg1 * g1 + bg2 * g2;
     const float ddelx_dx = 0.5f * cam.W, ddely_dy = 0.5f * cam.H;
-    // Only the first max(last) entries of the tile list were blended by any pixel of the tile (k_render stops at saturation,
-    // typically after a tenth of the list): the backward walk starts there, not at the end of the list, and each wave skips
-    // the entries beyond its own maximum with a scalar compare (these skips were 60 % of the kernel's time before).
-    __shared__ int s_maxlast;
-    if (threadIdx.x == 0) s_maxlast = 0;
-    __syncthreads();
-    int wave_last = last;
+    // Only the first max(last) entries of the tile list were blended by any pixel of the tile (k_render stops at saturation, typically
+    // after a tenth of the list): the backward walk starts there, not at the end of the list, and a block's list only receives the entries
+    // in front of the block's own maximum.
+    int block_last = last;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, d, 64));
-    if (lane == 0) atomicMax(&s_maxlast, wave_last);
+    for (int d = 8; d > 0; d >>= 1) block_last = max(block_last, __shfl_xor(block_last, d, 16));
+    if ((threadIdx.x & 15) == 0) s_blast[block] = block_last;
     __syncthreads();
-    const int n_eff = min(n_tile, s_maxlast);
+    const int blast_v = lane < N_BLOCKS ? s_blast[lane] : 0;  // lanes 0..15 of every wave: the 16 block maxima
+    int n_eff = blast_v;
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) n_eff = max(n_eff, __shfl_xor(n_eff, d, 16));
+    n_eff = min(n_tile, __builtin_amdgcn_readfirstlane(n_eff));
+    const uint32_t* list4 = reinterpret_cast<const uint32_t*>(s_list[block]);
     // batches are taken from the END of the blended prefix: position p (0-based from the front) has contributor number p + 1;
     // batch entry t sits at position n_eff - 1 - done_cnt - t
     for (int done_cnt = 0; done_cnt < n_eff; done_cnt += BATCH) {
@@ -801,7 +946,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
         const int nb_raw = min(BATCH, n_eff - done_cnt);
 #pragma unroll
         for (int q = 0; q < 9; q++) s_acc[threadIdx.x][q] = 0.f;
-        // stage the batch; per quadrant the list of entries whose alpha >= 1/255 ellipse box reaches it (see k_render)
+        // stage the batch; per block the list of entries whose alpha >= 1/255 ellipse box reaches it (see k_render)
         int id_l = 0;
         unsigned flags = 0;
         const int pos_top = n_eff - 1 - done_cnt;  // list position of batch entry 0
@@ -809,20 +954,22 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             id_l = point_list[r0 + pos_top - threadIdx.x];
             const float2 xy_l = make_float2(points_xy[2 * id_l], points_xy[2 * id_l + 1]);
             const float4 co_l = *reinterpret_cast<const float4*>(conic_opacity + 4 * id_l);
-            flags = quadrant_flags(xy_l, splat_extent(co_l), tx0, ty0);
+            flags = block_flags(xy_l, splat_extent(co_l), tx0, ty0);
+            const int pos_l = pos_top - (int)threadIdx.x;
+#pragma unroll
+            for (int b = 0; b < N_BLOCKS; b++)  // no pixel of block b blended anything at or behind its maximum
+                if (pos_l >= __builtin_amdgcn_readlane(blast_v, b)) flags &= ~(1u << b);
             if (flags) {
                 s_xy[threadIdx.x] = xy_l; s_co[threadIdx.x] = co_l;
                 s_rgb[3 * threadIdx.x] = rgb[3 * id_l]; s_rgb[3 * threadIdx.x + 1] = rgb[3 * id_l + 1]; s_rgb[3 * threadIdx.x + 2] = rgb[3 * id_l + 2];
             }
         }
-        const int n_mine = quadrant_lists(flags, s_list, s_qcnt);
-        const uint32_t* list4 = reinterpret_cast<const uint32_t*>(s_list[wave]);
-        for (int jj = 0; jj < n_mine; jj++) {
-            // four list entries per (wave-uniform) dword read
-            const uint32_t pack = (uint32_t)__builtin_amdgcn_readfirstlane((int)list4[jj >> 2]);
+        int n_wave;
+        const int n_mine = block_lists(flags, s_list, s_cnt, &n_wave);
+        for (int jj = 0; jj < n_wave; jj++) {
+            const uint32_t pack = list4[jj >> 2];  // four entries of this row's list per dword
             const int j = (int)((pack >> (8 * (jj & 3))) & 0xffu);
             const int pos = pos_top - j;
-            if (pos >= wave_last) continue;  // wave-uniform
             // branch-free like the forward loop: lanes that do not blend the Gaussian carry zeros into the sums
             const float4 co = s_co[j];
             const float2 xy = s_xy[j];
@@ -830,10 +977,11 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
             const float G = expf(power);
             const float alpha = fminf(0.99f, co.w * G);
-            const bool active = inside & (pos < last) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
-            if (__ballot(active) == 0ull) continue;  // nobody in this wave sees the Gaussian
+            const bool active = (jj < n_mine) & inside & (pos < last) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
+            if (__ballot(active) == 0ull) continue;  // nobody in this wave sees its Gaussian
             const float one_minus = 1 - alpha;
-            const float T_new = T / one_minus;
+            const float r_om = __builtin_amdgcn_rcpf(one_minus);  // 1 ulp; the two quotients below feed gradients only (tolerance, not bit parity)
+            const float T_new = T * r_om;
             const float dch = alpha * T_new;
             const float c0 = s_rgb[3 * j], c1 = s_rgb[3 * j + 1], c2 = s_rgb[3 * j + 2];
             const float n_acc0 = last_alpha * lc0 + (1 - last_alpha) * acc0;
@@ -843,7 +991,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             dL_dalpha += (c1 - n_acc1) * g1;
             dL_dalpha += (c2 - n_acc2) * g2;
             dL_dalpha *= T_new;
-            dL_dalpha += (-T_final / one_minus) * bg_dot;
+            dL_dalpha += (-T_final * r_om) * bg_dot;
             const float dL_dG = co.w * dL_dalpha;
             const float gdx = G * dx, gdy = G * dy;
             const float dG_ddelx = -gdx * co.x - gdy * co.y;
@@ -856,13 +1004,13 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             acc0 = active ? n_acc0 : acc0; acc1 = active ? n_acc1 : acc1; acc2 = active ? n_acc2 : acc2;
             lc0 = active ? c0 : lc0; lc1 = active ? c1 : lc1; lc2 = active ? c2 : lc2;
             last_alpha = active ? alpha : last_alpha;
-            // wave-level reduction, then ONE atomic per wave and quantity
+            // row-level reduction (row = block = one Gaussian), then ONE LDS atomic per row and quantity
             d_c0 = row_sum_to_lane15(d_c0); d_c1 = row_sum_to_lane15(d_c1); d_c2 = row_sum_to_lane15(d_c2);
             d_mx = row_sum_to_lane15(d_mx); d_my = row_sum_to_lane15(d_my);
             d_cx = row_sum_to_lane15(d_cx); d_cy = row_sum_to_lane15(d_cy); d_cw = row_sum_to_lane15(d_cw); d_op = row_sum_to_lane15(d_op);
             // keep the last DPP add of each sum out of the one-lane branch below (sunk into it, it splits into v_mov_dpp + v_add)
             asm volatile("" : "+v"(d_c0), "+v"(d_c1), "+v"(d_c2), "+v"(d_mx), "+v"(d_my), "+v"(d_cx), "+v"(d_cy), "+v"(d_cw), "+v"(d_op));
-            if ((lane & 15) == 15) {  // LDS atomics: the 4 rows of each of the 4 waves meet here, the global atomics happen once per (tile, Gaussian)
+            if ((lane & 15) == 15 && jj < n_mine) {  // LDS atomics: the blocks that blended entry j meet here, the global atomics happen once per (tile, Gaussian)
                 float* a = s_acc[j];
                 atomicAdd(a + 0, d_c0); atomicAdd(a + 1, d_c1); atomicAdd(a + 2, d_c2); atomicAdd(a + 3, d_mx); atomicAdd(a + 4, d_my);
                 atomicAdd(a + 5, d_cx); atomicAdd(a + 6, d_cy); atomicAdd(a + 7, d_cw); atomicAdd(a + 8, d_op);
@@ -1091,31 +1239,37 @@ __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam, c
 }
 
 // slices = waves; all of them should be resident at once: 160 KB of LDS per CU, (4 B x n_tiles) per wave, 256 CUs
-int gs_bin_blocks(int P, int n_tiles) {
-    int per_cu = (int)((160 * 1024) / ((int64_t)n_tiles * 4 + 512));
-    per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
-    const int cap = per_cu * 256 < GS_SLICE_MAX ? per_cu * 256 : GS_SLICE_MAX;
-    const int nb = (int)nrc_cdiv(P, 256);
-    return nb < cap ? (nb > 0 ? nb : 1) : cap;
-}
-int gs_bin_chunk(int P, int n_tiles) { const int nb = gs_bin_blocks(P, n_tiles); return (int)(nrc_cdiv(nrc_cdiv(P > 0 ? P : 1, nb), 64) * 64); }
-// binning workspace: [hist NB x n_tiles][part GS_GROUPS x n_tiles][keyA P][valA P][keyB P][valB P][pad][radix counts 256 x nblk4][tot 4 x 256]  (u32)
-struct BinWs { uint32_t *hist, *part, *keyA, *valA, *keyB, *valB, *counts, *tot; int nblk, nblk4; };
-int64_t gs_bin_ws_words(int P, int n_tiles) {
-    const int64_t nblk = nrc_cdiv(P > 0 ? P : 1, RS_TILE);
-    return (int64_t)(gs_bin_blocks(P, n_tiles) + GS_GROUPS) * n_tiles + 4 * (int64_t)(P > 0 ? P : 1) + 256 * (nblk + 4) + 1024 + 64;
-}
-BinWs gs_bin_ws(uint32_t* base, int P, int n_tiles) {
+// binning workspace (u32 words): [keyA P][valA P][rectA P][keyB P][valB P][rectB P][radix counts 256 x nblk4][offsets 256 x nblk4][tot 4 x 256] -- the depth pre-sort --
+// [cnt1 gy x nb1][rowtot gy][roff gy][nitems gy][ioff gy][meta 4][tcount n_tiles][cnt2 item_cap x gx][spans 2 x cap]
+struct BinWs {
+    uint32_t *keyA, *valA, *rectA, *keyB, *valB, *rectB, *counts, *offs, *tot, *cnt1, *rowtot, *roff, *nitems, *ioff, *meta, *tcount, *cnt2;
+    uint2* spans;
+    int nblk, nblk4, nb1, chunk1, item_cap;
+    int64_t cap, words;
+};
+int64_t gs_default_span_cap(int P) { return 4 * (int64_t)(P > 0 ? P : 1) + 65536; }
+BinWs gs_bin_ws(uint32_t* base, int P, int gx, int gy, int64_t cap) {
     BinWs w;
     const int64_t p1 = P > 0 ? P : 1;
     w.nblk = (int)nrc_cdiv(p1, RS_TILE);
-    w.hist = base;
-    w.part = w.hist + (int64_t)gs_bin_blocks(P, n_tiles) * n_tiles;
-    w.keyA = w.part + (int64_t)GS_GROUPS * n_tiles;
-    w.valA = w.keyA + p1; w.keyB = w.valA + p1; w.valB = w.keyB + p1;
     w.nblk4 = (w.nblk + 3) / 4 * 4;
-    w.counts = base + ((w.valB + p1 - base) + 3) / 4 * 4;  // 16-byte aligned rows (base itself comes 256-byte aligned from the caller)
-    w.tot = w.counts + (int64_t)256 * w.nblk4;
+    w.nb1 = (int)(nrc_cdiv(p1, 64) < SPAN_NB_MAX ? nrc_cdiv(p1, 64) : SPAN_NB_MAX);
+    w.chunk1 = (int)(nrc_cdiv(nrc_cdiv(p1, w.nb1), 64) * 64);
+    w.cap = cap;
+    w.item_cap = (int)(cap / SPAN_CH + gy + 1);
+    uint32_t* q = base;
+    auto take = [&](int64_t n, int64_t align_words) { q = base + ((q - base) + align_words - 1) / align_words * align_words; uint32_t* r = q; q += n; return r; };
+    w.keyA = take(p1, 4); w.valA = take(p1, 4); w.rectA = take(p1, 4); w.keyB = take(p1, 4); w.valB = take(p1, 4); w.rectB = take(p1, 4);
+    w.counts = take((int64_t)256 * w.nblk4, 4);  // 16-byte aligned rows (base itself comes 256-byte aligned from the caller)
+    w.offs = take((int64_t)256 * w.nblk4, 4);
+    w.tot = take(1024, 4);
+    w.cnt1 = take((int64_t)gy * w.nb1, 4);
+    w.rowtot = take(gy, 4); w.roff = take(gy, 4); w.nitems = take(gy, 4); w.ioff = take(gy, 4);
+    w.meta = take(4, 4);
+    w.tcount = take((int64_t)gx * gy, 4);
+    w.cnt2 = take((int64_t)w.item_cap * gx, 4);
+    w.spans = reinterpret_cast<uint2*>(take(2 * cap, 4));
+    w.words = (q - base) + 64;
     return w;
 }
 
@@ -1135,11 +1289,11 @@ int make_cam(GsCam& cam, int W, int H, int D, int M, const float* view, const fl
 
 extern "C" {
 
-int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H) {
-    if (P < 0 || W < 1 || H < 1) return NRC_ERR_INVALID;
-    const int64_t n_tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-    if (n_tiles > GS_MAX_LDS_TILES) return 0;  // global-atomic fallback: no histogram matrix
-    return gs_bin_ws_words(P, (int)n_tiles) * (int64_t)sizeof(uint32_t);
+int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H, int64_t span_capacity) {
+    if (P < 0 || W < 1 || H < 1 || span_capacity < 0) return NRC_ERR_INVALID;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    if (gx > SPAN_DIM_MAX || gy > SPAN_DIM_MAX) return 0;  // per-tile key sort fallback: no binning workspace
+    return gs_bin_ws(nullptr, P, gx, gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P)).words * (int64_t)sizeof(uint32_t);
 }
 
 int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs,
@@ -1147,7 +1301,7 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix_host, const float* projmatrix_host,
                       const float* campos_host, float tan_fovx, float tan_fovy, int32_t* radii, float* depths, float* points_xy,
                       float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched, uint32_t* tile_counts,
-                      uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t* num_rendered, nrc_stream_t stream) {
+                      uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t span_capacity, int64_t* num_rendered, nrc_stream_t stream) {
     NRC_ENTER();
     GsCam cam;
     const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, tan_fovx, tan_fovy, scale_modifier);
@@ -1160,7 +1314,7 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
     }
     hipStream_t s = (hipStream_t)stream;
     const int n_tiles = cam.gx * cam.gy;
-    const bool lds_path = n_tiles <= GS_MAX_LDS_TILES && bin_hist != nullptr;
+    const bool lds_path = cam.gx <= SPAN_DIM_MAX && cam.gy <= SPAN_DIM_MAX && bin_hist != nullptr;
     hipMemsetAsync(tile_counts, 0, sizeof(uint32_t) * n_tiles, s);
     if (P > 0) {
         if (!means3D || !opacities || !radii || !depths || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !tiles_touched) return NRC_ERR_INVALID;
@@ -1169,31 +1323,39 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                            cov3D_precomp, radii, depths, points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched,
                            lds_path ? (uint32_t*)nullptr : tile_counts);
         if (lds_path) {
-            const int nb = gs_bin_blocks(P, n_tiles), chunk = gs_bin_chunk(P, n_tiles);
-            const BinWs w = gs_bin_ws(bin_hist, P, n_tiles);
+            const BinWs w = gs_bin_ws(bin_hist, P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P));
             // depth pre-sort of the Gaussians: 4 stable 8-bit passes, (keyA,valA) -> ... -> (keyA,valA); valA = depth order
-            hipLaunchKernelGGL(k_depth_keys, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, radii, depths, w.keyA, w.valA);
+            hipLaunchKernelGGL(k_depth_keys, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, w.keyA, w.valA, w.rectA);
             hipMemsetAsync(w.tot, 0, sizeof(uint32_t) * 4 * 256, s);
             for (int pass = 0; pass < 4; pass++) {
-                const uint32_t *ki = (pass & 1) ? w.keyB : w.keyA, *vi = (pass & 1) ? w.valB : w.valA;
-                uint32_t *ko = (pass & 1) ? w.keyA : w.keyB, *vo = (pass & 1) ? w.valA : w.valB;
+                const uint32_t *ki = (pass & 1) ? w.keyB : w.keyA, *vi = (pass & 1) ? w.valB : w.valA, *ri = (pass & 1) ? w.rectB : w.rectA;
+                uint32_t *ko = (pass & 1) ? w.keyA : w.keyB, *vo = (pass & 1) ? w.valA : w.valB, *ro = (pass & 1) ? w.rectA : w.rectB;
                 hipLaunchKernelGGL(k_radix_count, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk4, ki, w.counts, w.tot + 256 * pass);
-                hipLaunchKernelGGL(k_radix_scatter, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk4, ki, vi, w.counts, w.tot + 256 * pass, ko, vo);
+                hipLaunchKernelGGL(k_radix_offsets, dim3(256), dim3(256), 0, s, w.nblk, w.nblk4, w.counts, w.tot + 256 * pass, w.offs);
+                hipLaunchKernelGGL(k_radix_scatter, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk4, ki, vi, ri, w.counts, w.offs, ko, vo, ro);
             }
-            const dim3 cgrid((unsigned)nrc_cdiv(n_tiles, 64), GS_GROUPS / 4);
-            hipLaunchKernelGGL(k_bin_count, dim3((nb + 7) / 8 * 8), dim3(64), n_tiles * sizeof(uint32_t), s, P, nb, chunk, cam.gx, cam.gy, w.valA, radii, points_xy, w.hist);
-            hipLaunchKernelGGL(k_tile_totals, cgrid, dim3(256), 0, s, nb, n_tiles, w.hist, w.part);
-            hipLaunchKernelGGL(k_scan_tiles_grouped, dim3(1), dim3(1024), 0, s, w.part, n_tiles, ranges, tile_fill, num_rendered);
-            hipLaunchKernelGGL(k_tile_bases, cgrid, dim3(256), 0, s, nb, n_tiles, w.part, w.hist);
+            // level 1: row spans in depth order; level 2 counting + scans: tile ranges and the per-(item, tile) cursors
+            hipLaunchKernelGGL(k_span_count, dim3(w.nb1), dim3(64), 0, s, P, w.nb1, w.chunk1, cam.gy, w.valA, w.rectA, w.cnt1);
+            hipLaunchKernelGGL(k_span_scan, dim3(cam.gy), dim3(256), 0, s, w.nb1, w.cnt1, w.rowtot);
+            hipLaunchKernelGGL(k_span_rows, dim3(1), dim3(256), 0, s, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, num_rendered + 1, w.meta);
+            hipLaunchKernelGGL(k_span_scatter, dim3(w.nb1), dim3(64), 0, s, P, w.nb1, w.chunk1, cam.gy, w.valA, w.rectA, w.cnt1, w.roff, w.cap, w.spans);
+            hipLaunchKernelGGL(k_item_count, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.cap, w.item_cap,
+                               w.spans, w.cnt2);
+            hipLaunchKernelGGL(k_item_scan, dim3((unsigned)nrc_cdiv(cam.gx, 64), cam.gy), dim3(1024), 0, s, cam.gx, w.item_cap, w.nitems, w.ioff, w.cnt2, w.tcount);
+            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, w.tcount, n_tiles, ranges, tile_fill, num_rendered);
         }
     }
-    if (!(P > 0 && lds_path)) hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, n_tiles, ranges, tile_fill, num_rendered);
+    if (!(P > 0 && lds_path)) {
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, n_tiles, ranges, tile_fill, num_rendered);
+        hipMemsetAsync(num_rendered + 1, 0, sizeof(int64_t), s);  // no span workspace in use
+    }
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
 
 int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, const int32_t* radii, const float* depths, const float* points_xy,
-                      const float* conic_opacity, const float* rgb, const uint32_t* ranges, uint32_t* tile_fill, const uint32_t* bin_hist, uint64_t* keys,
+                      const float* conic_opacity, const float* rgb, const uint32_t* ranges, uint32_t* tile_fill, const uint32_t* bin_hist, int64_t span_capacity,
+                      uint64_t* keys,
                       int32_t* point_list, float* out_color, uint32_t* n_contrib, float* final_T, nrc_stream_t stream) {
     NRC_ENTER();
     if (P < 0 || W < 1 || H < 1 || !bg_host || !ranges || !tile_fill || !out_color || !n_contrib || !final_T) return NRC_ERR_INVALID;
@@ -1203,14 +1365,10 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
     if (P > 0) {
         if (!radii || !depths || !points_xy || !conic_opacity || !rgb || !keys || !point_list) return NRC_ERR_INVALID;
         const int n_tiles = cam.gx * cam.gy;
-        if (n_tiles <= GS_MAX_LDS_TILES && bin_hist) {
-            const BinWs w = gs_bin_ws(const_cast<uint32_t*>(bin_hist), P, n_tiles);
-            // the same depth-ordered walk as the counting pass, now with the scanned matrix rows as LDS cursors: ids land sorted
-            static const hipError_t lds_attr = hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-            (void)lds_attr;  // tile grids above 12 K tiles need more than the default 64 KB of dynamic LDS
-            const int nb = gs_bin_blocks(P, n_tiles);
-            hipLaunchKernelGGL(k_bin_scatter, dim3((nb + 7) / 8 * 8), dim3(64), n_tiles * 4, s, P, nb, gs_bin_chunk(P, n_tiles), cam.gx, cam.gy,
-                               w.valA, radii, points_xy, w.hist, point_list);
+        if (cam.gx <= SPAN_DIM_MAX && cam.gy <= SPAN_DIM_MAX && bin_hist) {
+            const BinWs w = gs_bin_ws(const_cast<uint32_t*>(bin_hist), P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P));
+            hipLaunchKernelGGL(k_item_scatter, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.spans, w.cnt2, ranges,
+                               point_list);
         } else {
             hipLaunchKernelGGL(k_scatter, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, ranges, tile_fill, keys);
             hipLaunchKernelGGL((k_sort_tiles<0, 1024>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);

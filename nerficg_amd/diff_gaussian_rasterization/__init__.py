@@ -45,6 +45,9 @@ def _host_f32(t: torch.Tensor, n: int):
     return (ctypes.c_float * n)(*v.tolist())
 
 
+_SPAN_CAPACITY: dict = {}  # (device, P, W, H) -> row-span capacity of the binning workspace once the default proved too small
+
+
 def _p(arr):
     return ctypes.cast(arr, ctypes.c_void_p)
 
@@ -91,23 +94,34 @@ class _RasterizeGaussians(torch.autograd.Function):
         tile_counts = torch.empty(nt, dtype=i32, device=dev)
         tile_fill = torch.empty(nt, dtype=i32, device=dev)
         ranges = torch.empty(nt, 2, dtype=i32, device=dev)
-        num_rendered = torch.empty(1, dtype=torch.int64, device=dev)
-        hist_bytes = int(lib.nrc_gs_bin_hist_bytes(P, W, H))
-        bin_hist = torch.empty(hist_bytes // 4, dtype=i32, device=dev) if hist_bytes > 0 else None
+        num_rendered = torch.empty(2, dtype=torch.int64, device=dev)
         st = _lib.stream_of(radii)
-        _lib.check(lib.nrc_gs_preprocess(
-            P, D, M, W, H, _lib.ptr(means3D_c), _lib.ptr(sh_c), _lib.ptr(col_c), _lib.ptr(op_c), _lib.ptr(sc_c), float(rs.scale_modifier),
-            _lib.ptr(rot_c), _lib.ptr(cov_c), _p(vm), _p(pm), _p(cp), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(depths),
-            _lib.ptr(points_xy), _lib.ptr(conic_opacity), _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(tiles_touched),
-            _lib.ptr(tile_counts), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(bin_hist), _lib.ptr(num_rendered), st), 'gs_preprocess')
-        n_inst = int(num_rendered.item())
+        # binning workspace: kept per (device, P, W, H) and regrown when a frame needs more row-span records than it holds (the count comes
+        # back with the instance count in the one host read of the forward)
+        ws_key = (dev, P, W, H)
+        span_cap = _SPAN_CAPACITY.get(ws_key, 0)
+        while True:
+            hist_bytes = int(lib.nrc_gs_bin_hist_bytes(P, W, H, span_cap))
+            bin_hist = torch.empty(hist_bytes // 4, dtype=i32, device=dev) if hist_bytes > 0 else None
+            _lib.check(lib.nrc_gs_preprocess(
+                P, D, M, W, H, _lib.ptr(means3D_c), _lib.ptr(sh_c), _lib.ptr(col_c), _lib.ptr(op_c), _lib.ptr(sc_c), float(rs.scale_modifier),
+                _lib.ptr(rot_c), _lib.ptr(cov_c), _p(vm), _p(pm), _p(cp), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(depths),
+                _lib.ptr(points_xy), _lib.ptr(conic_opacity), _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(tiles_touched),
+                _lib.ptr(tile_counts), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(bin_hist), span_cap, _lib.ptr(num_rendered), st), 'gs_preprocess')
+            n_inst, n_spans = num_rendered.tolist()
+            have = span_cap if span_cap > 0 else 4 * max(P, 1) + 65536
+            if bin_hist is None or n_spans <= have:
+                break
+            span_cap = _SPAN_CAPACITY[ws_key] = int(n_spans * 1.25) + 65536
+            if len(_SPAN_CAPACITY) > 64:
+                _SPAN_CAPACITY.pop(next(iter(_SPAN_CAPACITY)))
         keys = torch.empty(max(n_inst, 1), dtype=torch.int64, device=dev)
         point_list = torch.empty(max(n_inst, 1), dtype=i32, device=dev)
         color = torch.empty(3, H, W, dtype=f32, device=dev)
         n_contrib = torch.empty(H * W, dtype=i32, device=dev)
         final_T = torch.empty(H * W, dtype=f32, device=dev)
         _lib.check(lib.nrc_gs_bin_render(P, W, H, _p(bg), _lib.ptr(radii), _lib.ptr(depths), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
-                                         _lib.ptr(rgb), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(bin_hist), _lib.ptr(keys), _lib.ptr(point_list),
+                                         _lib.ptr(rgb), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(bin_hist), span_cap, _lib.ptr(keys), _lib.ptr(point_list),
                                          _lib.ptr(color), _lib.ptr(n_contrib), _lib.ptr(final_T), st), 'gs_bin_render')
         ctx.raster_settings = rs
         ctx.host = (vm, pm, cp, bg)
