@@ -392,7 +392,8 @@ __global__ void __launch_bounds__(256) k_radix_scatter(int n, int shift, int nbl
 // MSD radix sort over the tile id whose first digit is the TILE ROW and whose records are row SPANS, not instances:
 //   level 1  Gaussian -> one 8-byte span record {id, x0 | x1 << 16} per tile row of its rectangle, appended to the row's span list
 //            (a rectangle of 3 x 3 tiles is 3 records, not 9);
-//   level 2  the span list of a row, cut into items of SPAN_CH spans (one wave each) -> ids appended to the tiles x0 .. x1 - 1 of that row.
+//   level 2  the span list of a row, cut into items of 256 .. 1024 spans (one wave each; the size is picked on the device from the span total,
+//            so that a small frame still fills the chip) -> ids appended to the tiles x0 .. x1 - 1 of that row.
 // Both levels rank with a BIT MATRIX instead of a serial walk: 64 sources (lane = Gaussian / span, in depth order) set bit `lane` in the
 // LDS word of every destination (row / tile) they cover with ds_or -- the order of the ORs is irrelevant --, then the lanes switch roles
 // (lane = destination) and pop the bits of their word in ascending order: lane order = depth order, so the appends are stable, every
@@ -400,7 +401,8 @@ __global__ void __launch_bounds__(256) k_radix_scatter(int n, int shift, int nbl
 // the level-2 grid is capped at 2048 waves, so the lines being appended stay in the XCD's L2 until they are full.
 // Counting passes of the same shape (LDS ds_add per covered destination) + two small scans give the cursors; everything is deterministic.
 #define GS_MAX_LDS_TILES 16384
-#define SPAN_CH 1024         // spans per level-2 item (one wave)
+#define SPAN_CH_MIN 256      // spans per level-2 item (one wave): 256, 512 or 1024, see k_span_rows
+#define SPAN_CH_MAX 1024
 #define SPAN_NB_MAX 4096     // level-1 slices (waves) at most
 #define SPAN_DIM_MAX 256     // tile rows / columns the lane-private cursors cover (4 registers x 64 lanes): 4096 x 4096 pixels
 #define SPAN_GRID 2048       // waves of the level-2 passes (grid-stride over the items)
@@ -452,17 +454,20 @@ __global__ void __launch_bounds__(256) k_span_scan(int nb1, uint32_t* __restrict
     }
     if (threadIdx.x == 0) rowtot[blockIdx.x] = (uint32_t)carry;
 }
-// per tile row: first span (roff), number of level-2 items (nitems) and first item (ioff); meta = {spans, items}
+// per tile row: first span (roff), number of level-2 items (nitems) and first item (ioff); meta = {items, spans per item}; *meta_spans = spans.
+// The item size follows the span total (about 10 K items at every size: ~5 waves per CU for the level-2 passes).
 __global__ void __launch_bounds__(256) k_span_rows(int gy, const uint32_t* __restrict__ rowtot, uint32_t* __restrict__ roff, uint32_t* __restrict__ nitems,
-                                                   uint32_t* __restrict__ ioff, int64_t* __restrict__ meta_spans, uint32_t* __restrict__ meta_items) {
+                                                   uint32_t* __restrict__ ioff, int64_t* __restrict__ meta_spans, uint32_t* __restrict__ meta) {
     __shared__ int sm[8];
     const int y = threadIdx.x;
-    const int n = y < gy ? (int)rowtot[y] : 0, it = (n + SPAN_CH - 1) / SPAN_CH;
+    const int n = y < gy ? (int)rowtot[y] : 0;
     int tot_s, tot_i;
     const int es = nrc_block256_excl_scan_i(n, sm, &tot_s);
+    const int ch = tot_s < (3 << 20) ? SPAN_CH_MIN : (tot_s < (6 << 20) ? 2 * SPAN_CH_MIN : SPAN_CH_MAX);
+    const int it = (n + ch - 1) / ch;
     const int ei = nrc_block256_excl_scan_i(it, sm, &tot_i);
     if (y < gy) { roff[y] = (uint32_t)es; nitems[y] = (uint32_t)it; ioff[y] = (uint32_t)ei; }
-    if (y == 0) { *meta_spans = (int64_t)tot_s; *meta_items = (uint32_t)tot_i; }
+    if (y == 0) { *meta_spans = (int64_t)tot_s; meta[0] = (uint32_t)tot_i; meta[1] = (uint32_t)ch; }
 }
 // value of entry `idx` (wave-uniform) of a table held as 4 registers x 64 lanes
 __device__ __forceinline__ int lanes_get(const int (&v)[4], int idx) {
@@ -512,7 +517,8 @@ __global__ void __launch_bounds__(64) k_span_scatter(int P, int nb1, int chunk1,
 }
 // the level-2 item `item`: its row, its first span and its span count (row tables in 4 registers x 64 lanes)
 struct SpanItem { int y; int64_t s0; int n; };
-__device__ __forceinline__ SpanItem span_item(int item, int gy, const int (&ioff_v)[4], const int (&nit_v)[4], const int (&roff_v)[4], const int (&rtot_v)[4]) {
+__device__ __forceinline__ SpanItem span_item(int item, int ch, int gy, const int (&ioff_v)[4], const int (&nit_v)[4], const int (&roff_v)[4],
+                                              const int (&rtot_v)[4]) {
     int y = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) y += __popcll(__ballot(64 * k + (int)threadIdx.x < gy && ioff_v[k] + nit_v[k] <= item));
@@ -520,8 +526,8 @@ __device__ __forceinline__ SpanItem span_item(int item, int gy, const int (&ioff
     const int c = item - lanes_get(ioff_v, y);
     SpanItem it;
     it.y = y;
-    it.s0 = (int64_t)(uint32_t)lanes_get(roff_v, y) + (int64_t)c * SPAN_CH;
-    it.n = min(SPAN_CH, lanes_get(rtot_v, y) - c * SPAN_CH);
+    it.s0 = (int64_t)(uint32_t)lanes_get(roff_v, y) + (int64_t)c * ch;
+    it.n = min(ch, lanes_get(rtot_v, y) - c * ch);
     return it;
 }
 #define SPAN_LOAD_ROW_TABLES()                                                                                                   \
@@ -538,9 +544,10 @@ __global__ void __launch_bounds__(64) k_item_count(int gx, int gy, const uint32_
     __shared__ uint32_t cnt[SPAN_DIM_MAX];
     const int lane = threadIdx.x;
     SPAN_LOAD_ROW_TABLES();
-    const int n_items = min((int)*meta_items, item_cap);  // more items than the workspace holds: the caller sees spans > capacity and retries
+    const int n_items = min((int)meta_items[0], item_cap);  // more items than the workspace holds: the caller sees spans > capacity and retries
+    const int ch = (int)meta_items[1];
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const SpanItem it = span_item(item, gy, ioff_v, nit_v, roff_v, rtot_v);
+        const SpanItem it = span_item(item, ch, gy, ioff_v, nit_v, roff_v, rtot_v);
         for (int x = lane; x < SPAN_DIM_MAX; x += 64) cnt[x] = 0u;
         __syncthreads();
         for (int j = lane; j < it.n; j += 64) {
@@ -588,12 +595,12 @@ __global__ void __launch_bounds__(64) k_item_scatter(int gx, int gy, const uint3
     const int lane = threadIdx.x;
     const int nk = (gx + 63) >> 6;
     SPAN_LOAD_ROW_TABLES();
-    const int n_items = (int)*meta_items;
+    const int n_items = (int)meta_items[0], ch = (int)meta_items[1];
 #pragma unroll
     for (int k = 0; k < 4; k++) { bits[64 * k + lane][0] = 0u; bits[64 * k + lane][1] = 0u; }
     __syncthreads();
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const SpanItem it = span_item(item, gy, ioff_v, nit_v, roff_v, rtot_v);
+        const SpanItem it = span_item(item, ch, gy, ioff_v, nit_v, roff_v, rtot_v);
         uint32_t cur[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -1256,7 +1263,7 @@ BinWs gs_bin_ws(uint32_t* base, int P, int gx, int gy, int64_t cap) {
     w.nb1 = (int)(nrc_cdiv(p1, 64) < SPAN_NB_MAX ? nrc_cdiv(p1, 64) : SPAN_NB_MAX);
     w.chunk1 = (int)(nrc_cdiv(nrc_cdiv(p1, w.nb1), 64) * 64);
     w.cap = cap;
-    w.item_cap = (int)(cap / SPAN_CH + gy + 1);
+    w.item_cap = (int)(cap / SPAN_CH_MIN + gy + 1);
     uint32_t* q = base;
     auto take = [&](int64_t n, int64_t align_words) { q = base + ((q - base) + align_words - 1) / align_words * align_words; uint32_t* r = q; q += n; return r; };
     w.keyA = take(p1, 4); w.valA = take(p1, 4); w.rectA = take(p1, 4); w.keyB = take(p1, 4); w.valB = take(p1, 4); w.rectB = take(p1, 4);

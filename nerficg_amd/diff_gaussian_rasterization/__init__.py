@@ -45,6 +45,26 @@ def _host_f32(t: torch.Tensor, n: int):
     return (ctypes.c_float * n)(*v.tolist())
 
 
+_HOST_CAMERA: dict = {}
+
+
+def _host_camera(rs):
+    """The four small camera tensors as host arrays (the C ABI takes them by value).  They cross to the host in ONE copy, and only when the
+    settings carry tensors this process has not seen yet (same storage, same version counter -> same values): a renderer that draws several
+    passes from one camera, or re-renders a pose, pays the device -> host read once."""
+    key = tuple((t.data_ptr(), t._version, t.device) for t in (rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg))
+    hit = _HOST_CAMERA.get(key)
+    if hit is None:
+        packed = torch.cat([rs.viewmatrix.reshape(-1).float(), rs.projmatrix.reshape(-1).float(), rs.campos.reshape(-1).float(),
+                            rs.bg.reshape(-1).float().to(rs.viewmatrix.device)]).cpu().tolist()
+        hit = ((ctypes.c_float * 16)(*packed[:16]), (ctypes.c_float * 16)(*packed[16:32]), (ctypes.c_float * 3)(*packed[32:35]),
+               (ctypes.c_float * 3)(*packed[35:38]), (rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg))  # the tensors are kept alive: their addresses are the key
+        if len(_HOST_CAMERA) >= 256:
+            _HOST_CAMERA.pop(next(iter(_HOST_CAMERA)))
+        _HOST_CAMERA[key] = hit
+    return hit[:4]
+
+
 _SPAN_CAPACITY: dict = {}  # (device, P, W, H) -> row-span capacity of the binning workspace once the default proved too small
 
 
@@ -76,11 +96,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         M = 0 if sh_c is None else int(sh_c.shape[1])
         gx, gy = (W + 15) // 16, (H + 15) // 16
         nt = gx * gy
-        # the four small camera tensors cross to the host in ONE copy
-        packed = torch.cat([rs.viewmatrix.reshape(-1).float(), rs.projmatrix.reshape(-1).float(), rs.campos.reshape(-1).float(),
-                            rs.bg.reshape(-1).float().to(rs.viewmatrix.device)]).cpu()
-        vm, pm = (ctypes.c_float * 16)(*packed[:16].tolist()), (ctypes.c_float * 16)(*packed[16:32].tolist())
-        cp, bg = (ctypes.c_float * 3)(*packed[32:35].tolist()), (ctypes.c_float * 3)(*packed[35:38].tolist())
+        vm, pm, cp, bg = _host_camera(rs)
         i32, u8 = torch.int32, torch.uint8
         n1 = max(P, 1)
         radii = torch.empty(n1, dtype=i32, device=dev)
