@@ -32,9 +32,11 @@ W = H = 800
 N_POSES = 100
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CHUNK_ROWS = 131072  # rows of 64 slots per encode/MLP launch = the library's NRC_QUERY_CHUNK (8 Mi slots)
-# dominant kernel = k_grid_encode.  Algorithmic bytes per LIVE sample: 16 levels x 8 corners x 2 features x 2 B of table
-# reads + 4 B sample record (t) + 64 B of encoded features written (fp16 x 32)
-ENC_BYTES_PER_SAMPLE = 512 + 4 + 64
+# dominant kernel = k_grid_encode.  Algorithmic bytes per LIVE sample, SURVEY 8(d): 16 levels x 8 corners x 2 features x 2 B of table reads
+# = 512 B.  (The kernel also reads a 4 B sample record and writes 64 B of encoded features -- artefacts of the two-kernel split, not part of the
+# algorithm: they are reported as `kernel_bytes_per_sample`, not used for `achieved`.)
+ENC_BYTES_PER_SAMPLE = 512
+ENC_KERNEL_BYTES_PER_SAMPLE = 512 + 4 + 64
 MLP_FLOP_PER_SAMPLE = 20480   # 10 240 MAC per sample (layer widths padded to 16)
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16 MFMA peak, MI355X_MICROARCH.md
 DOMINANT_KERNEL = 'k_grid_encode<SRC_TILED>'
@@ -56,58 +58,66 @@ def build_scene(device):
     return model, renderer, cam, poses
 
 
-def time_dominant_kernel(renderer, cam, pose, reps=3):
-    """Average launch duration of the dominant kernel (k_grid_encode: 128 hash-grid gathers per sample) and of its partner
-    (k_ngp_mlp) over ALL chunks (launches) of one image's sample rows, measured with HIP events on the launch stream
-    (torch's current stream = our launch stream).  Returns (encode ms, slots per launch, live samples per launch, mlp ms)."""
+def time_dominant_kernel(renderer, cam, pose_list, reps=2):
+    """Launch durations of the dominant kernel (k_grid_encode: 128 hash-grid gathers per sample) and of its partner (k_ngp_mlp) over ALL
+    chunks (launches) of the images of `pose_list` -- the poses the timed region rendered --, measured with HIP events on the launch stream
+    (torch's current stream = our launch stream).  Returns a dict: launch-weighted mean ms per launch of both kernels, the per-pose means
+    (spread: the hash is only local along x, poses differ by up to 30 %), live samples and slots per launch."""
     import torch
     from nerficg_amd import _lib
     import ctypes
     m = renderer.model
-    out = renderer.render_image_fused(cam, pose, return_stats=True)
-    ws = next(iter(renderer._fused_ws.values()))
-    n_rows = out['n_rows']
-    chunks = [(r0, min(CHUNK_ROWS, n_rows - r0)) for r0 in range(0, n_rows, CHUNK_ROWS)]  # the launches of one image
-    live = int((ws['ts'][:n_rows * 64] >= 0).sum().item())
     lib = _lib.load()
     f3 = lambda t: (ctypes.c_float * 3)(*[float(v) for v in t.reshape(-1).tolist()])
     mn, sz = f3(m.xyz_min), f3(m.xyz_size)
     g = m.encoding_xyz.grid_cfg
-    st = _lib.stream_of(ws['ts'])
     nt = renderer.n_image_tiles(cam)
-    dev = ws['ts'].device
-    feat = torch.empty(CHUNK_ROWS * 64 * 64 + 256, dtype=torch.uint8, device=dev)
-    sh_ws = torch.empty(nt * 2048, dtype=torch.uint8, device=dev)
     vp = ctypes.c_void_p
+    feat = sh_ws = None
+    enc_ms, mlp_ms, launches, live_total, slots_total = [], [], 0, 0, 0
+    for pose in pose_list:
+        out = renderer.render_image_fused(cam, pose, return_stats=True, early_termination=False)
+        ws = next(iter(renderer._fused_ws.values()))
+        n_rows = out['n_rows']
+        chunks = [(r0, min(CHUNK_ROWS, n_rows - r0)) for r0 in range(0, n_rows, CHUNK_ROWS)]  # the launches of one image
+        st = _lib.stream_of(ws['ts'])
+        dev = ws['ts'].device
+        if feat is None:
+            feat = torch.empty(CHUNK_ROWS * 64 * 64 + 256, dtype=torch.uint8, device=dev)
+            sh_ws = torch.empty(nt * 2048, dtype=torch.uint8, device=dev)
 
-    def encode(r0, rows):
-        _lib.check(lib.nrc_ngp_encode_samples(
-            vp(ws['ts'].data_ptr() + r0 * 256), vp(ws['row_tile'].data_ptr() + r0 * 4), _lib.ptr(ws['ray_od']), rows, ctypes.cast(mn, vp),
-            ctypes.cast(sz, vp), _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'],
-            g['base_resolution'], float(g['per_level_scale']), _lib.ptr(feat), st), 'ngp_encode_samples')
+        def encode(r0, rows):
+            _lib.check(lib.nrc_ngp_encode_samples(
+                vp(ws['ts'].data_ptr() + r0 * 256), vp(ws['row_tile'].data_ptr() + r0 * 4), _lib.ptr(ws['ray_od']), rows, ctypes.cast(mn, vp),
+                ctypes.cast(sz, vp), _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'],
+                g['base_resolution'], float(g['per_level_scale']), _lib.ptr(feat), st), 'ngp_encode_samples')
 
-    def mlp(r0, rows):
-        _lib.check(lib.nrc_ngp_mlp_samples(
-            vp(ws['ts'].data_ptr() + r0 * 256), vp(ws['row_tile'].data_ptr() + r0 * 4), _lib.ptr(ws['ray_od']), rows, nt, _lib.ptr(feat),
-            _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
-            vp(ws['packed'].data_ptr() + r0 * 512), _lib.ptr(sh_ws), st), 'ngp_mlp_samples')
+        def mlp(r0, rows):
+            _lib.check(lib.nrc_ngp_mlp_samples(
+                vp(ws['ts'].data_ptr() + r0 * 256), vp(ws['row_tile'].data_ptr() + r0 * 4), _lib.ptr(ws['ray_od']), rows, nt, _lib.ptr(feat),
+                _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
+                vp(ws['packed'].data_ptr() + r0 * 512), _lib.ptr(sh_ws), st), 'ngp_mlp_samples')
 
-    def timed(fn):  # every chunk of the image, `reps` times, back to back between ONE pair of events on the launch stream
-        fn(*chunks[0])
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            for c in chunks:
-                fn(*c)
-        b.record()
-        torch.cuda.synchronize()
-        return a.elapsed_time(b) / (reps * len(chunks))
+        def timed(fn):  # every chunk of the image, `reps` times, back to back between ONE pair of events on the launch stream
+            fn(*chunks[0])
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                for c in chunks:
+                    fn(*c)
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / (reps * len(chunks))
 
-    ms = timed(encode)
-    ms_mlp = timed(mlp)  # includes the (tiny) per-ray SH kernel
-    live = live / len(chunks)  # average live samples per launch
-    rows = n_rows / len(chunks)
-    return ms, int(rows * 64), int(live), ms_mlp
+        enc_ms.append(timed(encode))
+        mlp_ms.append(timed(mlp))  # includes the (tiny) per-ray SH kernel
+        launches += len(chunks)
+        live_total += int((ws['ts'][:n_rows * 64] >= 0).sum().item())
+        slots_total += n_rows * 64
+    mean = lambda v: sum(v) / len(v)
+    return {'enc_ms': mean(enc_ms), 'enc_ms_min': min(enc_ms), 'enc_ms_max': max(enc_ms), 'mlp_ms': mean(mlp_ms), 'mlp_ms_min': min(mlp_ms),
+            'mlp_ms_max': max(mlp_ms), 'live_per_launch': live_total // launches, 'slots_per_launch': slots_total // launches, 'poses': len(pose_list),
+            'launches_per_image': launches / len(pose_list)}
 
 
 # ------------------------------------------------------------------------------------------------ 3DGS leg (secondary metric)
@@ -169,23 +179,63 @@ def time_gs(gs, reps=5, barrier=None):
             'image': f'{GS_W}x{GS_H}'}
 
 
+def gs_kernel_rooflines(gs_res, pmc_all):
+    """Per-kernel entries of the 3DGS leg on SURVEY 8(d)'s per-stage byte model: blend 40 B per instance + 20 B per pixel; backward blend
+    76 B per instance + 20 B per pixel; preprocess 308 B and its backward 472 B per visible Gaussian; binning + sort 108 B per instance (the
+    reference's key / value traffic -- this build moves less).  Durations and memory-side traffic come from the committed rocprofv3 summaries
+    of the same frame (profiles/r02_gs_kernel_stats.csv = tools/bench_gs.py 1000000 under rocprofv3 --kernel-trace --stats, profiles/pmc_summary.json),
+    not from this run: the kernels are launched inside
+    the C ABI, where events cannot be placed between them."""
+    import csv
+    stats = ROOT / 'profiles' / 'r02_gs_kernel_stats.csv'
+    if not stats.exists():
+        return None
+    dur = {}
+    for r in csv.DictReader(open(stats)):
+        name = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+        dur[name] = float(r['AverageNs']) * 1e-9
+    P, D, HW = gs_res['visible'], gs_res['instances'], GS_W * GS_H
+    model = {'k_render': 40 * D + 20 * HW, 'k_render_bw': 76 * D + 20 * HW, 'k_preprocess': 308 * P, 'k_preprocess_bw': 472 * P}
+    out = {}
+    for k, nbytes in model.items():
+        if k in dur:
+            out[k] = {'ms': round(dur[k] * 1e3, 4), 'algorithmic_bytes': nbytes, 'achieved': round(nbytes / dur[k] / 1e9, 1),
+                      'frac': round(nbytes / dur[k] / 1e9 / HBM_PEAK_GBS, 4), 'traffic': pmc_all.get(k, {}).get('hbm_bytes_per_launch')}
+    binning = [k for k in dur if k.startswith(('k_depth_keys', 'k_radix', 'k_span', 'k_item', 'k_scan_tiles'))]
+    if binning:
+        passes = {k: (4 if k.startswith('k_radix') else 1) for k in binning}
+        t = sum(dur[k] * passes[k] for k in binning)
+        tr = [pmc_all.get(k, {}).get('hbm_bytes_per_launch') for k in binning]
+        out['binning (depth sort + span scatter, %d kernels)' % sum(passes.values())] = {
+            'ms': round(t * 1e3, 4), 'algorithmic_bytes': 108 * D, 'achieved': round(108 * D / t / 1e9, 1), 'frac': round(108 * D / t / 1e9 / HBM_PEAK_GBS, 4),
+            'traffic': int(sum(x * passes[k] for x, k in zip(tr, binning))) if all(x is not None for x in tr) else None}
+    return out
+
+
 def gs_cpu_baseline(n=250000, w=648, h=420):
     """CPU oracle (kind "port": the reference refuses CPU mode for GaussianSplatting, Renderer.py:32-33) on a bounded sample of the
-    same synthetic distribution: n Gaussians on a 1/2-scale image, single thread (the oracle rasterizer is scalar C)."""
+    same synthetic distribution: n Gaussians on a 1/2-scale image, OpenMP over Gaussians / pixel rows on all host cores (the instance sort is
+    a serial qsort)."""
     import oracle
     from tests import scenes
     sc = scenes.gs_random_scene(n, seed=0)
     cam = scenes.gs_camera(w, h, scenes.orbit_pose(0.8, 0.35, 4.5))
-    t0 = time.perf_counter()
-    col, radii, st = oracle.gs_forward(sc['means3D'], sc['opacities'], cam['viewmatrix'], cam['projmatrix'], cam['campos'], cam['tanfovx'], cam['tanfovy'],
-                                       w, h, np.zeros(3, np.float32), sh_degree=3, shs=sc['shs'], scales=sc['scales'], rotations=sc['rotations'])
-    t_f = time.perf_counter() - t0
-    g = np.ones((3, h, w), np.float32)
-    t0 = time.perf_counter()
-    oracle.gs_backward(st, g)
-    t_b = time.perf_counter() - t0
-    return {'value': round(n / t_f / 1e6, 5), 'value_fwd_bwd': round(n / (t_f + t_b) / 1e6, 5), 'unit': 'Msplats/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{n} Gaussians, {w}x{h} image, {st.num_rendered} instances, oracle/gs_oracle.c scalar, fwd {t_f:.2f} s + bwd {t_b:.2f} s'}
+    cores = os.cpu_count() or 1
+    before = oracle.set_threads(0)
+    try:
+        t0 = time.perf_counter()
+        col, radii, st = oracle.gs_forward(sc['means3D'], sc['opacities'], cam['viewmatrix'], cam['projmatrix'], cam['campos'], cam['tanfovx'], cam['tanfovy'],
+                                           w, h, np.zeros(3, np.float32), sh_degree=3, shs=sc['shs'], scales=sc['scales'], rotations=sc['rotations'])
+        t_f = time.perf_counter() - t0
+        g = np.ones((3, h, w), np.float32)
+        t0 = time.perf_counter()
+        oracle.gs_backward(st, g, threads=0)
+        t_b = time.perf_counter() - t0
+    finally:
+        oracle.set_threads(before)
+    return {'value': round(n / t_f / 1e6, 5), 'value_fwd_bwd': round(n / (t_f + t_b) / 1e6, 5), 'unit': 'Msplats/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} Gaussians, {w}x{h} image, {st.num_rendered} instances, oracle/gs_oracle.c with OpenMP on {cores} threads, '
+                      f'fwd {t_f:.2f} s + bwd {t_b:.2f} s'}
 
 
 def cpu_baseline(cam_full, pose, model_params, crop=96):
@@ -344,15 +394,21 @@ def main():
     if rank == 0:
         rays = W * H * args.steps * world
         value = rays / elapsed / 1e6
-        k_ms, k_slots, k_live, mlp_ms = time_dominant_kernel(renderer, cam, poses[args.warmup % N_POSES])
+        # the dominant kernel, timed on the poses the timed region of THIS rank rendered (all of them up to 20, else an even subset)
+        timed_poses = [poses[((args.warmup + i) * world + rank) % N_POSES] for i in range(args.steps)]
+        if len(timed_poses) > 20:
+            timed_poses = timed_poses[::max(1, len(timed_poses) // 20)][:20]
+        kt = time_dominant_kernel(renderer, cam, timed_poses)
+        k_ms, mlp_ms, k_live = kt['enc_ms'], kt['mlp_ms'], kt['live_per_launch']
         achieved = ENC_BYTES_PER_SAMPLE * k_live / (k_ms * 1e-3) / 1e9
-        traffic = None
+        pmc_all = {}
         pmc = ROOT / 'profiles' / 'pmc_summary.json'
         if pmc.exists():
             try:
-                traffic = json.loads(pmc.read_text()).get(DOMINANT_KERNEL, {}).get('hbm_bytes_per_launch')
+                pmc_all = json.loads(pmc.read_text())
             except Exception:
-                traffic = None
+                pmc_all = {}
+        enc_pmc = pmc_all.get(DOMINANT_KERNEL, {})
         result = {
             'metric': 'Mrays/s (INGP lego)', 'value': round(value, 4), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
@@ -361,16 +417,25 @@ def main():
                                    'random-init hash grid (T=2^19, L=16, F=2) + 64-wide MLPs, seed 0, 100 seeded orbit poses',
                        'rays_per_step_per_gpu': W * H, 'samples_per_ray': round(samples / rays, 3), 'parallelism': f'rays x{world} (weak)'},
             'msamples_per_s': round(samples / elapsed / 1e6, 3),
+            # dominant kernel on SURVEY 8(d)'s algorithmic bytes (512 B of table reads per live sample) against the HBM peak.  The 24.4 MB table
+            # is L2 / Infinity-Cache resident, so HBM is NOT what limits the kernel: `limiter` names the resource that does (L1 tag lookups,
+            # from the PMC counters in profiles/), and `traffic` is the memory-side traffic per launch measured there.
             'roofline': {'bound': 'hbm', 'kernel': DOMINANT_KERNEL, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': enc_pmc.get('hbm_bytes_per_launch'),
                          'algorithmic_bytes_per_launch': ENC_BYTES_PER_SAMPLE * k_live, 'algorithmic_bytes_per_sample': ENC_BYTES_PER_SAMPLE,
-                         'kernel_ms': round(k_ms, 4), 'samples_per_launch': k_live, 'slots_per_launch': k_slots,
-                         'note': 'table (24.4 MB) is L2/Infinity-Cache resident: the kernel is bound by the L1 texture-cache access rate, '
-                                 'not by HBM; achieved = algorithmic bytes / kernel time'},
+                         'kernel_bytes_per_sample': ENC_KERNEL_BYTES_PER_SAMPLE,
+                         'kernel_ms': round(k_ms, 4), 'kernel_ms_min_pose': round(kt['enc_ms_min'], 4), 'kernel_ms_max_pose': round(kt['enc_ms_max'], 4),
+                         'timed_over': f"{kt['poses']} poses of the timed region, {kt['launches_per_image']:.1f} launches per image, HIP events on the launch stream",
+                         'samples_per_launch': k_live, 'slots_per_launch': kt['slots_per_launch'],
+                         'limiter': {'resource': 'L1 (TCP) tag lookups', 'achieved': enc_pmc.get('tcp_accesses_per_clk_per_cu'), 'peak': 1.0,
+                                     'unit': 'cache-line lookups per clock per CU', 'l1_hit_rate': enc_pmc.get('l1_hit_rate'),
+                                     'l2_hit_rate': enc_pmc.get('l2_hit_rate'), 'source': 'profiles/pmc_summary.json (rocprofv3 --pmc)'}},
             # second kernel of the pair: the tiny-MLP chain on MFMA (20 480 FLOP per sample, padded layer widths)
             'roofline_mfma': {'bound': 'mfma', 'kernel': 'k_ngp_mlp<SRC_TILED>', 'achieved': round(MLP_FLOP_PER_SAMPLE * k_live / (mlp_ms * 1e-3) / 1e12, 2),
                               'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(MLP_FLOP_PER_SAMPLE * k_live / (mlp_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                              'traffic': None, 'kernel_ms': round(mlp_ms, 4), 'flop_per_sample': MLP_FLOP_PER_SAMPLE, 'samples_per_launch': k_live},
+                              'traffic': pmc_all.get('k_ngp_mlp<SRC_TILED>', {}).get('hbm_bytes_per_launch'), 'kernel_ms': round(mlp_ms, 4),
+                              'kernel_ms_min_pose': round(kt['mlp_ms_min'], 4), 'kernel_ms_max_pose': round(kt['mlp_ms_max'], 4),
+                              'flop_per_sample': MLP_FLOP_PER_SAMPLE, 'samples_per_launch': k_live},
         }
         if gs_res is not None:
             # bytes_fwd = 308 P_vis + 148 D + 20 H W ; bytes_bwd ~ 76 D + 472 P_vis + 20 H W
@@ -385,7 +450,8 @@ def main():
                              'achieved_fwd_bwd': round((b_fwd + b_bwd) / (gs_res['ms_fwd_bwd'] * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac_fwd': round(b_fwd / (gs_res['ms_fwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              'frac_fwd_bwd': round((b_fwd + b_bwd) / (gs_res['ms_fwd_bwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             'algorithmic_bytes_fwd': b_fwd, 'algorithmic_bytes_bwd': b_bwd}}
+                             'algorithmic_bytes_fwd': b_fwd, 'algorithmic_bytes_bwd': b_bwd,
+                             'kernels': gs_kernel_rooflines(gs_res, pmc_all)}}
             if 'large' in gs_res:
                 lg = gs_res['large']
                 lb_fwd = 308 * lg['visible'] + 148 * lg['instances'] + 20 * GS_W * GS_H

@@ -312,8 +312,24 @@ def gs_forward(means3D, opacities, viewmatrix, projmatrix, campos, tan_fovx, tan
     return color, st.radii.copy(), st
 
 
-def gs_backward(st, dL_dpix):
-    """Returns dict of gradients: mean2D (P,3), conic (P,4), opacity (P), color (P,3), mean3D (P,3), cov3D (P,6), sh (P,M,3), scale (P,3), rot (P,4)."""
+def set_threads(n: int) -> int:
+    """OpenMP threads of the oracle library (0 = all host cores); returns the previous setting."""
+    fn = lib().oracle_set_threads
+    fn.restype = ctypes.c_int
+    return int(fn(ctypes.c_int(int(n))))
+
+
+def gs_backward(st, dL_dpix, threads: int = 1):
+    """Returns dict of gradients: mean2D (P,3), conic (P,4), opacity (P), color (P,3), mean3D (P,3), cov3D (P,6), sh (P,M,3), scale (P,3), rot (P,4).
+    threads = 1 (default): the serial order of the float additions, reproducible bit for bit; 0 = all host cores (CPU-baseline timing)."""
+    before = set_threads(threads)
+    try:
+        return _gs_backward(st, dL_dpix)
+    finally:
+        set_threads(before)
+
+
+def _gs_backward(st, dL_dpix):
     dtype = st.dtype
     pre = 'gsf_' if dtype == np.float32 else 'gsd_'
     ft = ctypes.c_float if dtype == np.float32 else ctypes.c_double

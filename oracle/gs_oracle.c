@@ -4,6 +4,7 @@
  * the "parity unpinned" statement.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -35,3 +36,11 @@ static inline int IMAX(int a, int b) { return a > b ? a : b; }
 #define FMIN fmin
 #define FMAX fmax
 #include "gs_oracle_impl.h"
+
+
+/* thread count of the OpenMP loops of the whole oracle library (0 = all host cores); returns the previous maximum */
+int oracle_set_threads(int n) {
+    const int before = omp_get_max_threads();
+    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+    return before;
+}

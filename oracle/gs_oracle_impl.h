@@ -139,6 +139,8 @@ int64_t FN(preprocess)(int P, int D, int M, int W, int H, const REAL* means3D, c
     const REAL fx = W / ((REAL)2 * tan_fovx), fy = H / ((REAL)2 * tan_fovy);
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     int64_t total = 0;
+    /* OpenMP: every Gaussian is independent, the instance total is an integer reduction -- results do not depend on the thread count */
+#pragma omp parallel for schedule(static) reduction(+ : total)
     for (int i = 0; i < P; i++) {
         radii[i] = 0; tiles_touched[i] = 0;
         depths[i] = 0; points_xy[2 * i] = points_xy[2 * i + 1] = 0;
@@ -210,6 +212,8 @@ void FN(bin_and_render)(int P, int W, int H, const REAL* bg, const int32_t* radi
         if (k == n - 1 || (uint32_t)(inst[k + 1].key >> 32) != tile) ranges[2 * tile + 1] = (uint32_t)(k + 1);
     }
     free(inst);
+    /* OpenMP: pixels are independent */
+#pragma omp parallel for schedule(dynamic, 4)
     for (int py = 0; py < H; py++)
         for (int px = 0; px < W; px++) {
             const int tile = (py / TILE) * gx + px / TILE;
@@ -251,6 +255,10 @@ void FN(backward)(int P, int D, int M, int W, int H, const REAL* bg, const REAL*
     memset(dL_dsh, 0, sizeof(REAL) * 3 * (size_t)M * P); memset(dL_dscale, 0, sizeof(REAL) * 3 * P); memset(dL_drot, 0, sizeof(REAL) * 4 * P);
     /* (1) blending backward: per pixel, back to front */
     const REAL ddelx_dx = (REAL)0.5 * W, ddely_dy = (REAL)0.5 * H;
+    /* OpenMP over pixel rows with atomic adds into the per-Gaussian sums (what the reference's CUDA kernel does with atomicAdd).  With ONE
+     * thread (oracle.gs_backward's default, used by every parity test) the order of the additions is the serial one and the result is
+     * reproducible bit for bit; more threads (bench.py's CPU baseline) change only the order of the float additions. */
+#pragma omp parallel for schedule(dynamic, 4)
     for (int py = 0; py < H; py++)
         for (int px = 0; px < W; px++) {
             const int pix = py * W + px, tile = (py / TILE) * gx + px / TILE;
@@ -277,7 +285,9 @@ void FN(backward)(int P, int D, int M, int W, int H, const REAL* bg, const REAL*
                     accum[c] = last_alpha * last_color[c] + (1 - last_alpha) * accum[c];
                     last_color[c] = col;
                     dL_dalpha += (col - accum[c]) * g[c];
-                    dL_dcolor[3 * id + c] += dchannel_dcolor * g[c];
+                    { const REAL add_ = dchannel_dcolor * g[c];
+_Pragma("omp atomic")
+                    dL_dcolor[3 * id + c] += add_; }
                 }
                 dL_dalpha *= T;
                 last_alpha = alpha;
@@ -288,15 +298,28 @@ void FN(backward)(int P, int D, int M, int W, int H, const REAL* bg, const REAL*
                 const REAL gdx = G * dx, gdy = G * dy;
                 const REAL dG_ddelx = -gdx * co[0] - gdy * co[1];
                 const REAL dG_ddely = -gdy * co[2] - gdx * co[1];
-                dL_dmean2D[3 * id] += dL_dG * dG_ddelx * ddelx_dx;
-                dL_dmean2D[3 * id + 1] += dL_dG * dG_ddely * ddely_dy;
-                dL_dconic[4 * id] += (REAL)-0.5 * gdx * dx * dL_dG;
-                dL_dconic[4 * id + 1] += (REAL)-0.5 * gdx * dy * dL_dG;
-                dL_dconic[4 * id + 3] += (REAL)-0.5 * gdy * dy * dL_dG;
-                dL_dopacity[id] += G * dL_dalpha;
+                { const REAL add_ = dL_dG * dG_ddelx * ddelx_dx;
+_Pragma("omp atomic")
+                dL_dmean2D[3 * id] += add_; }
+                { const REAL add_ = dL_dG * dG_ddely * ddely_dy;
+_Pragma("omp atomic")
+                dL_dmean2D[3 * id + 1] += add_; }
+                { const REAL add_ = (REAL)-0.5 * gdx * dx * dL_dG;
+_Pragma("omp atomic")
+                dL_dconic[4 * id] += add_; }
+                { const REAL add_ = (REAL)-0.5 * gdx * dy * dL_dG;
+_Pragma("omp atomic")
+                dL_dconic[4 * id + 1] += add_; }
+                { const REAL add_ = (REAL)-0.5 * gdy * dy * dL_dG;
+_Pragma("omp atomic")
+                dL_dconic[4 * id + 3] += add_; }
+                { const REAL add_ = G * dL_dalpha;
+_Pragma("omp atomic")
+                dL_dopacity[id] += add_; }
             }
         }
-    /* (2) per-Gaussian backward */
+    /* (2) per-Gaussian backward: independent Gaussians */
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < P; i++) {
         if (!(radii[i] > 0)) continue;
         const REAL* mean = means3D + 3 * i;

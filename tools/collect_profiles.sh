@@ -7,7 +7,11 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_raw
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-gs-large > $O/bench_stats.log 2>&1
+# the driver's command line (bench.py --steps 20 --warmup 5, every leg): the per-kernel averages of the InstantNGP kernels must agree with the bench line
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_stats.log 2>&1
+# the 3DGS kernels at ONE size (the bench command runs 1 M and 6 M Gaussians through the same kernel names)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/gs_stats -- python3 $R/tools/bench_gs.py 1000000 20 > $O/gs_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/gs6_stats -- python3 $R/tools/bench_gs.py 6000000 5 > $O/gs6_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 $R/tools/bench_train.py 2200 20 > $O/train_stats.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE TA_BUSY_avr" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-32)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/make_profile_summary.py -- turns gpurun_out/profiles_raw (tools/collect_profiles.sh) into the committed summaries:
-profiles/r01_bench_kernel_stats.csv, profiles/r01_pmc_summary.md, profiles/pmc_summary.json (read by bench.py for roofline.traffic)."""
+profiles/r02_bench_kernel_stats.csv, r02_gs_kernel_stats.csv (1 M Gaussians), r02_gs6m_kernel_stats.csv, r02_train_kernel_stats.csv,
+profiles/r02_pmc_summary.md, profiles/pmc_summary.json (read by bench.py for roofline.traffic and the per-kernel 3DGS entries)."""
 import collections, csv, glob, json, re, shutil, sys
 from pathlib import Path
 
@@ -26,17 +27,21 @@ def short(name):
 import os
 stats = sorted(glob.glob(str(RAW / 'bench_stats' / '*' / '*kernel_stats.csv')), key=os.path.getmtime)  # newest collection last
 if stats:
-    shutil.copy(stats[-1], OUT / 'r01_bench_kernel_stats.csv')
+    shutil.copy(stats[-1], OUT / 'r02_bench_kernel_stats.csv')
+for tag, name in (('gs_stats', 'r02_gs_kernel_stats.csv'), ('gs6_stats', 'r02_gs6m_kernel_stats.csv')):
+    extra = sorted(glob.glob(str(RAW / tag / '*' / '*kernel_stats.csv')), key=os.path.getmtime)
+    if extra:
+        shutil.copy(extra[-1], OUT / name)
 tstats = sorted(glob.glob(str(RAW / 'train_stats' / '*' / '*kernel_stats.csv')), key=os.path.getmtime)
 if tstats:
-    shutil.copy(tstats[-1], OUT / 'r01_train_kernel_stats.csv')
+    shutil.copy(tstats[-1], OUT / 'r02_train_kernel_stats.csv')
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(str(RAW / 'pmc*' / '*' / '*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         acc[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
-keep = ('k_grid_encode', 'k_ngp_mlp', 'k_render', 'k_composite_image', 'k_preprocess', 'k_bin_', 'k_radix_', 'k_tile_', 'k_scan_tiles', 'k_march_wave',
+keep = ('k_grid_encode', 'k_ngp_mlp', 'k_render', 'k_composite_image', 'k_preprocess', 'k_span_', 'k_item_', 'k_depth_keys', 'k_radix_', 'k_scan_tiles', 'k_march_wave',
         'k_grid_bwd', 'k_nwie_', 'k_composite_train')
-lines = ['# rocprofv3 --pmc summary (MI355X, round 1)', '',
+lines = ['# rocprofv3 --pmc summary (MI355X, round 2)', '',
          'Collected by `tools/collect_profiles.sh` (one `--pmc` group per run, `--kernel-trace` only), averaged per kernel over all launches of',
          '`tools/bench_query.py` (InstantNGP 800x800 image pipeline), `tools/bench_gs.py` (3DGS, 1 M Gaussians, 1297x840) and `tools/bench_train.py`',
          '(InstantNGP training iteration, 2200 rays / 264 K samples).',
@@ -80,7 +85,7 @@ for k in sorted(acc):
     if k.startswith('k_grid_encode') or k.startswith('k_ngp_mlp'):
         key = re.sub(r'<1(, \d+)?>', '<SRC_TILED>', re.sub(r'<0(, \d+)?>', '<SRC_ARRAYS>', k))
     summary[key] = {**{n: round(v, 1) for n, v in c.items()}, **derived}
-(OUT / 'r01_pmc_summary.md').write_text('\n'.join(lines))
+(OUT / 'r02_pmc_summary.md').write_text('\n'.join(lines))
 (OUT / 'pmc_summary.json').write_text(json.dumps(summary, indent=1, sort_keys=True))
 print('\n'.join(lines[:8]))
 for k, v in summary.items():
