@@ -301,6 +301,160 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=15):
             'samples_per_iteration': int(tot / iters), 'msamples_per_s': round(tot / iters / dt / 1e6, 1)}
 
 
+# ------------------------------------------------------------------------------------------------ data-parallel training legs
+def _max_over_ranks(values, device, world):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor(values, device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t]
+
+
+def _replica_drift(flat, world):
+    """max |parameter - rank 0's parameter|: replicas that saw the same reduced gradients and took the same step differ by exactly 0"""
+    import torch.distributed as dist
+    if world == 1:
+        return 0.0
+    ref = flat.clone()
+    dist.broadcast(ref, src=0)
+    return float((flat.detach() - ref.detach()).abs().max())
+
+
+def dp_ingp_leg(model, renderer, cam, poses, rank, world, device, rays_per_rank=2200, iters=10):
+    """InstantNGP data-parallel training iteration: every rank draws the SAME seeded global batch (ray ids and march jitter), renders its share
+    ray_ids[rank::world] (parallel.shard_ray_ids: the global ray set is the single-GPU one), the encoding / MLP gradients are averaged with ONE
+    flat reduce-scatter + all-gather over RCCL (parallel.allreduce_gradients), every rank applies the same fused Adam step.  Weak scaling:
+    rays_per_rank per GPU.  Reports the iteration time, the collective alone (HIP events around it), the bytes it reduces and the bus
+    bandwidth 2 (N-1)/N * bytes / time per GPU; asserts that the replicas end bit-identical and saw the same loss."""
+    import torch
+    import torch.distributed as dist
+    from nerficg_amd import parallel
+    from nerficg_amd.apex_optimizers import FusedAdam
+    from nerficg_amd.raygen import generate_rays
+    saved = [p.detach().clone() for p in model.parameters()]
+    if world > 1:
+        parallel.broadcast_parameters(model.parameters())
+    rays = [generate_rays(cam.width, cam.height, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y, p, device=device, want_direction=False) for p in poses[:2]]
+    origin = torch.cat([r['origin'] for r in rays]); vdir = torch.cat([r['view_direction'] for r in rays])
+    perm = torch.randperm(origin.shape[0], generator=torch.Generator(device='cpu').manual_seed(0)).to(device)  # identical on every rank
+    target = torch.rand(origin.shape[0], 3, device=device, generator=torch.Generator(device=device).manual_seed(1))
+    opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)  # Trainer.py:35
+    scaler = torch.amp.GradScaler(init_scale=128.0, growth_interval=10 ** 9)
+    n_global = rays_per_rank * world
+    params = list(model.parameters())
+    coll_ms, losses = [], []
+
+    def step(i, timed):
+        gen = torch.Generator(device=device).manual_seed(1000 + i)  # the same background and jitter on every rank
+        batch = perm[(i * n_global) % (perm.numel() - n_global):][:n_global]
+        jitter = torch.rand(n_global, device=device, generator=gen)
+        bg = torch.rand(3, device=device, generator=gen)
+        ids, noise = parallel.shard_ray_ids(batch, rank, world), parallel.shard_ray_ids(jitter, rank, world)
+        with torch.amp.autocast('cuda'):
+            out = renderer.render_rays(origin[ids], vdir[ids], cam, train_mode=True, custom_bg_color=bg, noise=noise)
+            loss = torch.nn.functional.mse_loss(out['rgb'].float(), target[ids]) + 0.5e-6 * model.weight_decay_mlp()
+        scaler.scale(loss).backward()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        parallel.allreduce_gradients(params, average=True)
+        b.record()
+        scaler.step(opt); scaler.update(); opt.zero_grad()
+        if timed:
+            coll_ms.append((a, b))
+            losses.append(loss.detach())
+        return out['rm_samples']
+
+    for i in range(3):
+        step(i, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    n_samples = [step(3 + i, True) for i in range(iters)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / iters
+    coll = sum(a.elapsed_time(b) for a, b in coll_ms) / iters
+    drift = _replica_drift(torch.cat([p.detach().reshape(-1) for p in params]), world)
+    # every rank optimises its own share of the batch, so losses differ between ranks; what must agree is what the NETWORK computes afterwards
+    probe = model.encoding_xyz(torch.rand(4096, 3, device=device, generator=torch.Generator(device=device).manual_seed(7))).float()
+    out_drift = _replica_drift(probe.reshape(-1).contiguous(), world)
+    nbytes = sum(p.numel() * 4 for p in params)
+    dt, coll = _max_over_ranks([dt, coll], device, world)
+    samples = float(torch.stack(n_samples).double().mean())
+    with torch.no_grad():
+        for p, q in zip(model.parameters(), saved):
+            p.copy_(q)
+    if drift != 0.0 or out_drift != 0.0:
+        raise RuntimeError(f'InstantNGP data-parallel replicas drifted: parameters {drift:.3e}, network output {out_drift:.3e}')
+    return {'ms_per_iteration': round(dt * 1e3, 3), 'rays_per_iteration': n_global, 'samples_per_iteration_per_gpu': round(samples), 'mrays_per_s': round(n_global / dt / 1e6, 3),
+            'collective': f'one flat f32 bucket, {"all_reduce" if dist.get_backend() == "gloo" else "reduce-scatter + all-gather"} over {dist.get_backend()}' if world > 1 else None, 'bytes_reduced_per_iteration': nbytes if world > 1 else 0,
+            'collective_ms': round(coll, 3) if world > 1 else None,
+            'bus_GBps_per_gpu': round(2 * (world - 1) / world * nbytes / (coll * 1e-3) / 1e9, 1) if world > 1 and coll > 0 else None,
+            'replica_drift': drift, 'network_output_drift': out_drift, 'final_loss': round(float(losses[-1]), 6)}
+
+
+def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=8):
+    """3DGS view-parallel optimisation step: replicated Gaussians, every rank rasterizes ANOTHER view of the orbit, 0.8 L1 + 0.2 DSSIM, backward,
+    visibility-sparse gradient reduction (parallel.sparse_allreduce_gradients: only rows seen by at least one rank travel), the same fused Adam
+    step everywhere.  Weak scaling: one view per GPU and step."""
+    import torch
+    import torch.distributed as dist
+    from nerficg_amd import parallel
+    from nerficg_amd.gaussian_splatting import Gaussians, PerspectiveCamera, render_image_training, training_loss
+    from tests import scenes
+    sc = scenes.gs_random_scene(n_gaussians, seed=0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    g = Gaussians(T(sc['means3D']), torch.log(T(sc['scales'])), T(sc['rotations']), torch.logit(T(sc['opacities']).clamp(1e-4, 1 - 1e-4))[:, None].contiguous(),
+                  T(sc['shs'][:, :1]), T(sc['shs'][:, 1:]))
+    g.training_setup(training_cameras_extent=4.5)
+    params = [grp['params'][0] for grp in g.optimizer.param_groups]
+    if world > 1:
+        parallel.broadcast_parameters(params)
+    cam = PerspectiveCamera(GS_W, GS_H, 1.2 * GS_W, 1.2 * GS_W, background_color=torch.zeros(3, device=device))
+    target = torch.rand(3, GS_H, GS_W, device=device, generator=torch.Generator(device=device).manual_seed(1))
+    rows, coll_ms = [0, 0], []
+
+    def step(i, timed):
+        pose = scenes.orbit_pose(0.8 + 0.7 * (i * world + rank), 0.35, 4.5)
+        out = render_image_training(g, cam, pose)
+        training_loss(out['rgb'], target).backward()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        n_union = parallel.sparse_allreduce_gradients(params, out['visibility_mask'], average=True)
+        b.record()
+        g.optimizer.step(); g.optimizer.zero_grad()
+        if timed:
+            rows[0] += n_union; rows[1] += 1
+            coll_ms.append((a, b))
+
+    for i in range(2):
+        step(i, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        step(2 + i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / iters
+    coll = sum(a.elapsed_time(b) for a, b in coll_ms) / iters
+    drift = _replica_drift(torch.cat([p.detach().reshape(-1) for p in params]), world)
+    dt, coll = _max_over_ranks([dt, coll], device, world)
+    union_rows = rows[0] / max(rows[1], 1)
+    nbytes = int(union_rows * 59 * 4)
+    if drift != 0.0:
+        raise RuntimeError(f'3DGS view-parallel replicas drifted: {drift:.3e}')
+    return {'ms_per_step': round(dt * 1e3, 3), 'views_per_step': world, 'gaussians': n_gaussians, 'msplats_per_s': round(world * n_gaussians / dt / 1e6, 1),
+            'collective': f'max-reduce of the visibility mask + reduction of the union rows over {dist.get_backend()}' if world > 1 else None,
+            'union_rows_per_step': round(union_rows), 'bytes_reduced_per_step': nbytes if world > 1 else 0, 'collective_ms': round(coll, 3) if world > 1 else None,
+            'bus_GBps_per_gpu': round(2 * (world - 1) / world * nbytes / (coll * 1e-3) / 1e9, 1) if world > 1 and coll > 0 else None, 'replica_drift': drift}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -310,6 +464,7 @@ def main():
     ap.add_argument('--no-gs', action='store_true', help='skip the secondary 3DGS leg')
     ap.add_argument('--no-train', action='store_true', help='skip the InstantNGP training-iteration leg')
     ap.add_argument('--no-gs-large', action='store_true', help='skip the 6 M-Gaussian run of the 3DGS leg')
+    ap.add_argument('--no-dp', action='store_true', help='skip the data-parallel training legs (gradient collectives over RCCL)')
     ap.add_argument('--gs-gaussians', type=int, default=1_000_000)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the code path)')
     args = ap.parse_args()
@@ -391,6 +546,19 @@ def main():
             del big
             torch.cuda.empty_cache()
 
+    # ---- data-parallel training legs: the collectives of SURVEY 8(e) inside a timed iteration (every rank takes part)
+    dp = None
+    if not args.no_dp:
+        dp = {}
+        for name, fn in (('ingp', lambda: dp_ingp_leg(model, renderer, cam, poses, rank, world, device)), ('gs', lambda: dp_gs_leg(rank, world, device))):
+            try:
+                dp[name] = fn()
+            except RuntimeError as e:
+                if 'drifted' in str(e):
+                    raise
+                dp[name] = {'error': repr(e)[:300]}
+            torch.cuda.empty_cache()
+
     if rank == 0:
         rays = W * H * args.steps * world
         value = rays / elapsed / 1e6
@@ -466,6 +634,7 @@ def main():
                 result['training'] = time_train(model, renderer, cam, poses)
             except Exception as e:  # never lose the headline line over the extra leg
                 result['training'] = {'error': repr(e)[:200]}
+        result['dp_training'] = dp
         result['cpu_baseline'] = None  # timed on rank 0 of single-GPU runs only (the host cores are shared by all ranks otherwise)
         if not args.no_cpu_baseline and world == 1:
             if gs_res is not None:
