@@ -128,10 +128,11 @@ class NetworkWithInputEncoding(torch.nn.Module):
         if str(network_config.get('activation', 'ReLU')).lower() != 'relu':
             raise RuntimeError('nerficg_amd.tinycudann: only ReLU hidden activations are implemented')
         if int(network_config.get('n_neurons', 64)) != _WIDTH:
-            raise RuntimeError('nerficg_amd.tinycudann: only n_neurons == 64 is implemented')
+            raise RuntimeError(f"nerficg_amd.tinycudann: only n_neurons = 64 is implemented (got {network_config.get('n_neurons')}): N_DENSITY_NEURONS / N_COLOR_NEURONS "
+                               'of the InstantNGP yaml must keep their default')
         self.n_hidden = int(network_config.get('n_hidden_layers', 1))
         if self.n_hidden not in (1, 2):
-            raise RuntimeError('nerficg_amd.tinycudann: n_hidden_layers must be 1 or 2')
+            raise RuntimeError(f'nerficg_amd.tinycudann: n_hidden_layers must be 1 or 2 (got {self.n_hidden}): N_DENSITY_LAYERS / N_COLOR_LAYERS of the InstantNGP yaml')
         oa = str(network_config.get('output_activation', 'None')).lower()
         if oa not in ('none', 'sigmoid'):
             raise RuntimeError(f'nerficg_amd.tinycudann: unsupported output_activation {oa!r}')
@@ -147,7 +148,9 @@ class NetworkWithInputEncoding(torch.nn.Module):
             if str(encoding_config.get('type', 'Hash')) != 'Hash' or str(encoding_config.get('interpolation', 'Linear')) != 'Linear':
                 raise RuntimeError('nerficg_amd.tinycudann: only Hash grids with Linear interpolation are implemented')
             if int(encoding_config.get('n_levels', 16)) != 16 or int(encoding_config.get('n_features_per_level', 2)) != 2 or self.n_input_dims != 3:
-                raise RuntimeError('nerficg_amd.tinycudann: the grid encoding is implemented for 3 input dims, 16 levels x 2 features')
+                raise RuntimeError(f"nerficg_amd.tinycudann: the grid encoding is implemented for n_input_dims = 3, n_levels = 16, n_features_per_level = 2 "
+                                   f"(got {self.n_input_dims}, {encoding_config.get('n_levels')}, {encoding_config.get('n_features_per_level')}): "
+                                   'HASHGRID_N_LEVELS / HASHGRID_N_FEATURES_PER_LEVEL of the InstantNGP yaml must keep their defaults')
             self.encoding = 0
             self.grid_cfg = dict(n_levels=16, log2_hashmap_size=int(encoding_config.get('log2_hashmap_size', 19)),
                                  base_resolution=int(encoding_config.get('base_resolution', 16)),
@@ -159,7 +162,9 @@ class NetworkWithInputEncoding(torch.nn.Module):
             ok = (len(nested) == 2 and nested[0].get('otype') == 'SphericalHarmonics' and int(nested[0].get('degree', 0)) == 4
                   and int(nested[0].get('n_dims_to_encode', 0)) == 3 and nested[1].get('otype') == 'Identity' and self.n_input_dims == 19)
             if not ok:
-                raise RuntimeError('nerficg_amd.tinycudann: Composite encoding must be [SphericalHarmonics(degree 4, 3 dims), Identity(16 dims)]')
+                raise RuntimeError('nerficg_amd.tinycudann: Composite encoding must be [SphericalHarmonics(degree = 4, n_dims_to_encode = 3), Identity] with n_input_dims = 19 '
+                                   f'(got n_input_dims = {self.n_input_dims}, nested = {nested}): DIR_SH_ENCODING_DEGREE / N_DENSITY_OUTPUT_FEATURES of the InstantNGP yaml '
+                                   'must keep their defaults (4 / 16)')
             self.encoding = 1
         else:
             raise RuntimeError(f'nerficg_amd.tinycudann: unsupported encoding otype {ot!r}')

@@ -68,3 +68,143 @@ print('ok')
 ''' % (str(SHIMS), str(ROOT), str(REF), str(ROOT / 'tests' / 'golden'))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env={**os.environ, 'PYTHONPATH': ''})
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
+
+
+def _run_in_reference(body: str):
+    """Runs `body` in a subprocess with the reference tree importable on top of nerficg_amd/shims (CPU mode, Framework configured)."""
+    code = r'''
+import sys, types, math, torch, numpy as np
+sys.path[:0] = [%r, %r, %r]
+sys.path.insert(0, %r)
+from make_golden import install_shims
+install_shims()
+import Framework
+Framework.config = Framework.ConfigWrapper.fromDict({'GLOBAL': {'RANDOM_SEED': 1618033989, 'ANOMALY_DETECTION': False, 'GPU_INDICES': None,
+    'DEFAULT_DEVICE': torch.device('cpu'), 'METHOD_TYPE': 'InstantNGP'}, 'TRAINING': {'WANDB': {'ACTIVATE': False}, 'MODEL_NAME': 'probe'}, 'MODEL': {},
+    'RENDERER': {}})
+import torchmetrics.functional.image as _tfi   # three more names of absent metric packages that the method packages import at module level
+for _n in ('structural_similarity_index_measure', 'multiscale_structural_similarity_index_measure', 'learned_perceptual_image_patch_similarity'):
+    setattr(_tfi, _n, lambda *a, **k: None)
+''' % (str(SHIMS), str(ROOT), str(REF), str(ROOT / 'tests' / 'golden')) + body + "\nprint('ok')\n"
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env={**os.environ, 'PYTHONPATH': ''})
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.skipif(not REF.exists(), reason='reference tree only exists in the build container')
+def test_reference_instant_ngp_model_builds_over_the_shims():
+    """The reference's OWN InstantNGPModel(name).build() (src/Methods/InstantNGP/Model.py:46-123) constructed on the drop-in tinycudann: the
+    flat parameter vectors have the sizes and the MLP-first layout its weight decay slices on (:38-44, :80-89: 3072; :115: 7168), the buffers
+    the sizes the ray marcher expects, and yaml-settable architecture keys reach the replacement (or are refused by name)."""
+    _run_in_reference(r'''
+from Methods.InstantNGP.Model import InstantNGPModel
+import Thirdparty.TinyCudaNN as tcnn
+m = InstantNGPModel('probe').build()
+assert type(m.encoding_xyz).__module__.startswith('nerficg_amd')
+assert m.n_params_encoding_mlp == 3072 and len(m.color_mlp_with_encoding.params) == 7168 and m.n_mlp_params == 10240
+assert m.encoding_xyz.params.dtype == torch.float32 and m.encoding_xyz.params.dim() == 1
+n_table = sum(min(2 ** 19, -(-(math.ceil(16 * 1.3819128799677760 ** l - 1) + 1) ** 3 // 8) * 8) for l in range(16))
+assert n_table == 6098120 and m.encoding_xyz.params.numel() == 3072 + 2 * n_table          # SURVEY App. C.1
+assert m.encoding_xyz.n_output_dims == 16 and m.color_mlp_with_encoding.n_output_dims == 3
+assert m.occupancy_grid.shape == (1, 128 ** 3) and m.occupancy_bitfield.shape == (128 ** 3 // 8,) and m.cascades == 1
+assert m.encoding_xyz.jit_fusion and m.color_mlp_with_encoding.jit_fusion                    # Model.py:116-120
+wd = m.weight_decay_mlp()                                                                    # the reference's own slice arithmetic on our layout
+ref = (m.encoding_xyz.params[:3072].double().pow(2).sum() + m.color_mlp_with_encoding.params.double().pow(2).sum()) / 10240
+assert abs(float(wd) - float(ref)) < 1e-6 * float(ref)
+sd = m.state_dict()
+assert set(sd) == {'occupancy_grid', 'occupancy_bitfield', 'encoding_xyz.params', 'color_mlp_with_encoding.params'}
+# a yaml that changes the architecture: supported keys take effect ...
+Framework.config.MODEL = Framework.ConfigWrapper.fromDict({'SCALE': 2.0, 'RESOLUTION': 64, 'HASHGRID_LOG2_SIZE': 17, 'HASHGRID_TARGET_RESOLUTION': 1024,
+                                                           'N_COLOR_LAYERS': 1})
+m2 = InstantNGPModel('probe2').build()
+assert m2.cascades == 3 and m2.occupancy_grid.shape == (3, 64 ** 3) and len(m2.color_mlp_with_encoding.params) == 64 * 32 + 16 * 64
+assert m2.encoding_xyz.grid_cfg['log2_hashmap_size'] == 17
+# ... and an unsupported one is refused with the key's name, not silently ignored
+Framework.config.MODEL = Framework.ConfigWrapper.fromDict({'N_DENSITY_NEURONS': 128})
+try:
+    InstantNGPModel('probe3').build()
+    raise SystemExit('a 128-neuron density network was accepted')
+except RuntimeError as e:
+    assert 'n_neurons' in str(e), e
+''')
+
+
+@pytest.mark.skipif(not REF.exists(), reason='reference tree only exists in the build container')
+def test_reference_method_plugins_resolve_and_construct_over_the_shims():
+    """SURVEY 8(b) "Method plugin": the reference's own registry (src/Implementations.py:27-65) imports all three method packages over the
+    shims, every package exposes MODEL / RENDERER / TRAINING_INSTANCE, and get_model / get_renderer construct the InstantNGP pair on CPU
+    (constructors need no kernel); the 3DGS renderer refuses CPU mode exactly like the reference (Renderer.py:32-33)."""
+    _run_in_reference(r'''
+import Implementations
+assert {'InstantNGP', 'GaussianSplatting', 'NeRF'} <= set(Implementations.Methods.options)
+for method in ('InstantNGP', 'GaussianSplatting', 'NeRF'):
+    pkg = Implementations.Methods.import_method(method)
+    assert all(hasattr(pkg, a) for a in ('MODEL', 'RENDERER', 'TRAINING_INSTANCE')), method
+model = Implementations.Methods.get_model('InstantNGP', name='probe')                       # = MODEL(name).build()
+assert type(model).__name__ == 'InstantNGPModel' and model.n_mlp_params == 10240
+Framework.config.GLOBAL.GPU_INDICES = []   # CPU mode as a list: InstantNGP's component takes len() of it (Renderer.py:26)
+renderer = Implementations.Methods.get_renderer('InstantNGP', model)                       # = RENDERER(model)
+assert abs(renderer.density_threshold - 0.01 * 1024 / 3 ** 0.5) < 1e-9 and renderer.ray_rendering_component.model is model
+import Methods.InstantNGP.Renderer as R
+assert R.VolumeRenderingCuda.raymarching_train.__module__.startswith('nerficg_amd')          # the renderer's native module IS this library
+Framework.config.GLOBAL.METHOD_TYPE = 'GaussianSplatting'
+gs_model = Implementations.Methods.get_model('GaussianSplatting', name='probe')
+try:
+    Implementations.Methods.get_renderer('GaussianSplatting', gs_model)
+    raise SystemExit('3DGS renderer constructed in CPU mode')
+except Framework.RendererError:
+    pass
+''')
+
+
+@pytest.mark.skipif(not REF.exists(), reason='reference tree only exists in the build container')
+def test_reference_gaussians_and_raster_settings_over_the_shims():
+    """The reference's own Gaussians container (Model.py:18-150) with its optimizer built on the drop-in FusedAdam, and the settings tuple its
+    renderer marshals (Renderer.py:60-74) accepted by the drop-in rasterizer's settings type."""
+    _run_in_reference(r'''
+Framework.config.GLOBAL.METHOD_TYPE = 'GaussianSplatting'
+import Thirdparty.Apex as apex
+import Thirdparty.DiffGaussianRasterization as dgr
+assert apex.FusedAdam.__module__.startswith('nerficg_amd')
+from Methods.GaussianSplatting.Model import Gaussians
+g = Gaussians(3, False)
+n = 500
+gen = torch.Generator().manual_seed(0)
+g._positions = torch.nn.Parameter(torch.rand(n, 3, generator=gen))
+g._features_dc = torch.nn.Parameter(torch.rand(n, 1, 3, generator=gen)); g._features_rest = torch.nn.Parameter(torch.zeros(n, 15, 3))
+g._scales = torch.nn.Parameter(torch.full((n, 3), -4.0)); g._rotations = torch.nn.Parameter(torch.tensor([[1.0, 0, 0, 0]]).repeat(n, 1))
+g._opacities = torch.nn.Parameter(torch.zeros(n, 1))
+class Args: pass
+a = Args()
+a.LEARNING_RATE_POSITION_INIT, a.LEARNING_RATE_POSITION_FINAL, a.LEARNING_RATE_POSITION_MAX_STEPS = 0.00016, 0.0000016, 30000
+a.LEARNING_RATE_FEATURE, a.LEARNING_RATE_OPACITY, a.LEARNING_RATE_SCALING, a.LEARNING_RATE_ROTATION, a.PERCENT_DENSE = 0.0025, 0.05, 0.005, 0.001, 0.01
+g.training_cameras_extent = 4.0
+g.training_setup(a)
+assert type(g.optimizer).__module__.startswith('nerficg_amd')
+assert [grp['name'] for grp in g.optimizer.param_groups] == ['positions', 'f_dc', 'f_rest', 'opacities', 'scales', 'rotations']
+assert g.get_features.shape == (n, 16, 3) and torch.allclose(g.get_opacities, torch.full((n, 1), 0.5)) and torch.allclose(g.get_scales, torch.full((n, 3), math.exp(-4.0)))
+g.update_learning_rate(10)
+s = dgr.GaussianRasterizationSettings(image_height=64, image_width=96, tanfovx=0.5, tanfovy=0.33, bg=torch.zeros(3), scale_modifier=1.0,
+                                      viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=3, campos=torch.zeros(3), prefiltered=False, debug=False)
+r = dgr.GaussianRasterizer(raster_settings=s)
+assert r.raster_settings.image_width == 96
+try:
+    r(means3D=g.get_positions, means2D=torch.zeros_like(g.get_positions), shs=g.get_features, opacities=g.get_opacities, scales=g.get_scales, rotations=g.get_rotations)
+    raise SystemExit('the rasterizer ran on CPU tensors')
+except RuntimeError as e:
+    assert 'CUDA' in str(e)     # no CPU fallback: the product path fails loudly without a GPU
+''')
+
+
+@pytest.mark.skipif(not REF.exists(), reason='reference tree only exists in the build container')
+def test_reference_autograd_layer_sits_on_the_hip_ops():
+    """The reference's own custom_functions.py classes bound to this library's ops: applying one to CPU tensors reaches nerficg_amd's input check."""
+    _run_in_reference(r'''
+import Methods.InstantNGP.VolumeRenderingV2 as vr
+assert vr.VolumeRenderer.__module__.endswith('custom_functions') and vr.composite_train_fw.__module__.startswith('nerficg_amd')
+z = torch.zeros
+try:
+    vr.RayAABBIntersector.apply(z(4, 3), z(4, 3), z(1, 3), z(1, 3), 1)
+    raise SystemExit('ray_aabb_intersect ran on CPU tensors')
+except RuntimeError as e:
+    assert 'must be a CUDA tensor' in str(e)
+''')
