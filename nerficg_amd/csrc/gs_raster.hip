@@ -134,6 +134,29 @@ __device__ __forceinline__ void tile_rect(const float* p, int radius, int gx, in
 }
 
 // ------------------------------------------------------------------------------------------------ 1. preprocess
+// Splat record: what the two render kernels need of a Gaussian, in ONE 64-byte line (they used to gather xy, conic + opacity and rgb from
+// three arrays = three cache lines per list entry), plus the per-Gaussian part of their block tests precomputed once instead of once per
+// (tile, Gaussian) pair:  q0 = {X, Y, A, B}  q1 = {C, o, r, g}  q2 = {b, ext_x, ext_y, A tau}  q3 = {det, B / A, y_off, 1 / A}
+//   alpha >= 1/255  <=>  A dx^2 + 2 B dx dy + C dy^2 <= tau = 2 ln(255 o)   (the ellipse a pixel must be inside to blend the Gaussian)
+//   ext_x, ext_y = half extents of that ellipse's bounding box (margins: x 1.001 + 0.01 px);  ext_x = -1: never blends;  +inf: not an ellipse
+//   y_off = (B / C) sqrt(tau C / det): the ellipse's leftmost / rightmost points lie at Y +- y_off
+__device__ __forceinline__ void write_splat_record(float4 (&rec)[4], float X, float Y, float A, float B, float C, float o, const float* col) {
+    const float inf = __builtin_inff();
+    float ex = -1.f, ey = -1.f, atau = 0.f, det = 0.f, ba = 0.f, yoff = 0.f, inva = 0.f;
+    if (o > 0.f) {
+        const float tau = 2.f * (logf(255.f * o) + 1e-3f);
+        if (tau > 0.f) {
+            det = A * C - B * B;
+            if (!(det > 0.f) || !(A > 0.f) || !(C > 0.f)) { ex = inf; ey = inf; }
+            else {
+                ex = sqrtf(tau * C / det) * 1.001f + 0.01f; ey = sqrtf(tau * A / det) * 1.001f + 0.01f;
+                atau = A * tau; ba = B / A; inva = 1.0f / A; yoff = (B / C) * sqrtf(tau * C / det);
+            }
+        }
+    }
+    rec[0] = make_float4(X, Y, A, B); rec[1] = make_float4(C, o, col[0], col[1]);
+    rec[2] = make_float4(col[2], ex, ey, atau); rec[3] = make_float4(det, ba, yoff, inva);
+}
 // one Gaussian; sh_row = its SH coefficients (LDS copy, see k_preprocess)
 __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const float* __restrict__ means3D, const float* sh_row,
                                                const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -142,7 +165,7 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
                                                float* __restrict__ depths, float* __restrict__ points_xy,
                                                float* __restrict__ conic_opacity, float* __restrict__ rgb, uint8_t* __restrict__ clamped,
                                                float* __restrict__ cov3D, uint32_t* __restrict__ tiles_touched,
-                                               uint32_t* __restrict__ tile_counts) {
+                                               uint32_t* __restrict__ tile_counts, bool want_record, float4 (&splat)[4]) {
     radii[i] = 0; tiles_touched[i] = 0; depths[i] = 0.f;
     points_xy[2 * i] = 0.f; points_xy[2 * i + 1] = 0.f;
 #pragma unroll
@@ -187,17 +210,18 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
     int rmin[2], rmax[2];
     tile_rect(pix, my_radius, cam.gx, cam.gy, rmin, rmax);
     if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) return;
+    float col[3];
     if (colors_precomp) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) rgb[3 * i + k] = colors_precomp[3 * i + k];
+        for (int k = 0; k < 3; k++) col[k] = colors_precomp[3 * i + k];
     } else {
-        float col[3];
         uint8_t cl;
         sh_color(cam.D, p, cam.campos, sh_row, col, &cl);
-#pragma unroll
-        for (int k = 0; k < 3; k++) rgb[3 * i + k] = col[k];
         clamped[i] = cl;
     }
+#pragma unroll
+    for (int k = 0; k < 3; k++) rgb[3 * i + k] = col[k];
+    if (want_record) write_splat_record(splat, pix[0], pix[1], conic[0], conic[1], conic[2], opacities[i], col);  // this thread's row of the LDS image
     depths[i] = pv[2]; radii[i] = my_radius;
     points_xy[2 * i] = pix[0]; points_xy[2 * i + 1] = pix[1];
     conic_opacity[4 * i] = conic[0]; conic_opacity[4 * i + 1] = conic[1]; conic_opacity[4 * i + 2] = conic[2];
@@ -219,8 +243,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam, cons
                                                           float* __restrict__ depths, float* __restrict__ points_xy,
                                                           float* __restrict__ conic_opacity, float* __restrict__ rgb, uint8_t* __restrict__ clamped,
                                                           float* __restrict__ cov3D, uint32_t* __restrict__ tiles_touched,
-                                                          uint32_t* __restrict__ tile_counts) {
-    __shared__ float s_sh[PRE_BLOCK * (3 * PRE_MAXM + 1)];
+                                                          uint32_t* __restrict__ tile_counts, float4* __restrict__ splat) {
+    __shared__ __attribute__((aligned(16))) float s_sh[PRE_BLOCK * (3 * PRE_MAXM + 1)];
     const int first = blockIdx.x * PRE_BLOCK, i = first + threadIdx.x;
     const int row_len = 3 * cam.M, pitch = row_len + 1;
     if (shs) {
@@ -232,9 +256,27 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam, cons
         }
         __syncthreads();
     }
+    // splat records leave through LDS: a lane storing its own 64-byte record touches 64 cache lines per store instruction; from the LDS image
+    // (the SH staging area, free again once every thread has evaluated its colour) the workgroup writes its 128 x 64 B block with coalesced
+    // 16-byte stores.  Rows of culled Gaussians hold stale bytes: no tile list ever names them.
+    float4 rec[4] = {};
     if (i < P)
         preprocess_one(i, cam, means3D, s_sh + threadIdx.x * pitch, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, depths,
-                       points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched, tile_counts);
+                       points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched, tile_counts, splat != nullptr, rec);
+    if (splat) {
+        float4* s_rec = reinterpret_cast<float4*>(s_sh);  // 128 x 64 B = 8 KB of the 25 KB
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_rec[4 * threadIdx.x + k] = rec[k];
+        __syncthreads();
+        const int n4 = 4 * min(PRE_BLOCK, P - first);
+        float4* dst = splat + 4 * (size_t)first;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = threadIdx.x + PRE_BLOCK * k;
+            if (e < n4) dst[e] = s_rec[e];
+        }
+    }
 }
 
 // ---- binning without global atomics and without a per-tile sort ----------------------------------------------------------
@@ -740,62 +782,109 @@ __device__ __forceinline__ int tile_py(unsigned t) { return (int)(((t >> 2) & 3u
 // its entry's box against the 16 blocks; 16 ballots and a prefix over the 4 waves turn the flags into 16 ascending index lists; and every
 // DPP row of a wave walks ITS OWN list -- the four rows of a wave blend four different Gaussians in the same instruction.  The box is
 // conservative (margins below), so exactly the same pixels blend exactly the same Gaussians in the same order: bit-identical pictures.
-__device__ __forceinline__ float2 splat_extent(const float4& co) {
-    const float inf = __builtin_inff();
-    if (!(co.w > 0.f)) return make_float2(-1.f, -1.f);              // alpha <= 0 everywhere
-    const float tau = 2.f * (logf(255.f * co.w) + 1e-3f);
-    if (!(tau > 0.f)) return make_float2(-1.f, -1.f);               // o < 1/255: never reaches the threshold
-    const float det = co.x * co.z - co.y * co.y;
-    if (!(det > 0.f) || !(co.x > 0.f) || !(co.z > 0.f)) return make_float2(inf, inf);  // not an ellipse: no culling
-    return make_float2(sqrtf(tau * co.z / det) * 1.001f + 0.01f, sqrtf(tau * co.x / det) * 1.001f + 0.01f);
-}
-// bit b set when the box xy +- ext reaches the pixel centres of block b (block = 4 pixel columns x 4 pixel rows: centres x0 .. x0 + 3)
-__device__ __forceinline__ unsigned block_flags(const float2& xy, const float2& ext, float tx0, float ty0) {
+// bit b set when the alpha >= 1/255 ellipse of the record can reach a pixel centre of block b (block = 4 x 4 pixels of the 16 x 16 tile).
+// Two conservative tests: the ellipse's bounding box against the four column / row bands, then, per row band, the x-interval the ellipse
+// spans inside the band (chords at the band's two edges -- clamped to the ellipse's y-range --, widened to the box where the leftmost /
+// rightmost point of the ellipse lies inside the band) against the column bands.  On the bench scene the box keeps 6.2 blocks per
+// (tile, Gaussian) pair of a blended prefix, the band intervals 4.7, an exact per-pixel test 4.5 (tools/gs_stats.py).
+__device__ __forceinline__ unsigned block_flags(const float4& q0, const float4& q2, const float4& q3, float tx0, float ty0) {
+    const float X = q0.x, Y = q0.y, ex = q2.y, ey = q2.z;
+    if (!(ex >= 0.f)) return 0u;  // never reaches the threshold
     unsigned col = 0, row = 0;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const float x0 = tx0 + (float)(4 * c), y0 = ty0 + (float)(4 * c);
-        col |= (unsigned)(xy.x + ext.x >= x0 && xy.x - ext.x <= x0 + 3.f) << c;
-        row |= (unsigned)(xy.y + ext.y >= y0 && xy.y - ext.y <= y0 + 3.f) << c;
+        col |= (unsigned)(X + ex >= x0 && X - ex <= x0 + 3.f) << c;
+        row |= (unsigned)(Y + ey >= y0 && Y - ey <= y0 + 3.f) << c;
     }
-    // block b = 4 * (2 * (cy >> 1) + (cx >> 1)) + 2 * (cy & 1) + (cx & 1): per quadrant the 2x2 product of its two column and two row bits
+    if (col == 0u || row == 0u) return 0u;
+    unsigned cols[4] = {col, col, col, col};
+    if (ex < __builtin_inff()) {
+        const float atau = q2.w, det = q3.x, ba = q3.y, yoff = q3.z, inva = q3.w;
+        float lo[5], hi[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const float d = fminf(fmaxf(Y - (ty0 + (float)(4 * k)), -ey), ey);
+            const float w = __builtin_amdgcn_sqrtf(fmaxf(atau - det * d * d, 0.f)) * inva;
+            const float mid = X + ba * d;
+            lo[k] = mid - w; hi[k] = mid + w;
+        }
+        const float yl = Y + yoff, yr = Y - yoff;
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++) {
+            const float ca = fmaxf(ty0 + (float)(4 * sl), Y - ey), cb = fminf(ty0 + (float)(4 * sl + 4), Y + ey);
+            float l = fminf(lo[sl], lo[sl + 1]), h = fmaxf(hi[sl], hi[sl + 1]);
+            if ((yl >= ca && yl <= cb) || (yr >= ca && yr <= cb)) { l = fminf(l, X - ex); h = fmaxf(h, X + ex); }
+            l -= 0.02f; h += 0.02f;
+            unsigned cb4 = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float x0 = tx0 + (float)(4 * c);
+                cb4 |= (unsigned)(h >= x0 && l <= x0 + 3.f) << c;
+            }
+            cols[sl] = col & cb4;
+        }
+    }
+    // block b = 4 * (2 * (cy >> 1) + (cx >> 1)) + 2 * (cy & 1) + (cx & 1)
     unsigned f = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const unsigned c2 = (col >> (2 * (q & 1))) & 3u, r2 = (row >> (2 * (q >> 1))) & 3u;
-        const unsigned lo = (r2 & 1u) ? c2 : 0u, hi = (r2 & 2u) ? c2 : 0u;
-        f |= (lo | (hi << 2)) << (4 * q);
+    for (int cy = 0; cy < 4; cy++) {
+        const unsigned c4 = ((row >> cy) & 1u) ? cols[cy] : 0u;
+        f |= (c4 & 3u) << (8 * (cy >> 1) + 2 * (cy & 1));
+        f |= (c4 >> 2) << (8 * (cy >> 1) + 4 + 2 * (cy & 1));
     }
     return f;
 }
 #define N_BLOCKS 16
-// Builds the 16 per-block lists of one staged batch (thread t holds entry t; flags = its block bits).  s_list[b] receives, in ascending
-// order, the batch indices of the entries that reach block b.  Returns the length of the list of the calling thread's own block (uniform
-// over a DPP row); *n_wave = the longest of the calling wave's four lists.
-__device__ __forceinline__ int block_lists(unsigned flags, uint8_t (*s_list)[BATCH], uint16_t (*s_cnt)[N_BLOCKS], int* n_wave) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long m[N_BLOCKS];
-#pragma unroll
-    for (int b = 0; b < N_BLOCKS; b++) m[b] = __ballot((flags >> b) & 1u);
-    if (lane == 0) {
-        uint32_t* dst = reinterpret_cast<uint32_t*>(s_cnt[wave]);
-#pragma unroll
-        for (int b = 0; b < N_BLOCKS; b += 2) dst[b >> 1] = (uint32_t)__popcll(m[b]) | ((uint32_t)__popcll(m[b + 1]) << 16);
+// One staged batch: thread t read entry t's 64-byte record; what the blend loop needs goes to LDS as two 16-byte vectors and a scalar.
+struct StageLds {
+    float4 a[BATCH];      // X, Y, r, g
+    float4 b[BATCH];      // A, B, C, o
+    float c[BATCH];       // b
+    uint16_t flags[BATCH];
+    __attribute__((aligned(16))) uint8_t list[N_BLOCKS][BATCH];
+};
+__device__ __forceinline__ unsigned stage_entry(StageLds& st, const float4* __restrict__ splat, int id, float tx0, float ty0) {
+    const float4* rec = splat + 4 * (size_t)id;
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+    const unsigned flags = block_flags(q0, q2, q3, tx0, ty0);
+    if (flags) {
+        st.a[threadIdx.x] = make_float4(q0.x, q0.y, q1.z, q1.w);
+        st.b[threadIdx.x] = make_float4(q0.z, q0.w, q1.x, q1.y);
+        st.c[threadIdx.x] = q2.x;
     }
+    return flags;
+}
+// Builds the 16 per-block lists of a staged batch: the 16 lanes of DPP row b (= the threads whose pixels form block b) build list b, lane l
+// from the flags of entries 16 l .. 16 l + 15 (two 16-byte LDS reads), ranked with a row prefix sum.  st.list[b] receives the batch indices
+// of the entries that reach block b in ascending order.  Returns the length of the calling thread's own list; *n_wave = the longest of the
+// calling wave's four lists.
+__device__ __forceinline__ int block_lists(StageLds& st, unsigned flags, int* n_wave) {
+    st.flags[threadIdx.x] = (uint16_t)flags;
     __syncthreads();
-    int base_v = 0, tot_v = 0;  // lanes 0..15: block `lane`
-    if (lane < N_BLOCKS) {
+    const int b = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    const uint4 fa = reinterpret_cast<const uint4*>(st.flags)[2 * l16], fb = reinterpret_cast<const uint4*>(st.flags)[2 * l16 + 1];
+    const uint32_t w[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+    uint32_t mask = 0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) { const int c = s_cnt[w][lane]; tot_v += c; if (w < wave) base_v += c; }
+    for (int k = 0; k < 8; k++) {
+        const uint32_t t = (w[k] >> b) & 0x00010001u;
+        mask |= ((t & 1u) | (t >> 15)) << (2 * k);
     }
-    const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int b = 0; b < N_BLOCKS; b++) {
-        if (m[b] == 0ull) continue;  // wave-uniform
-        const int base = __builtin_amdgcn_readlane(base_v, b);
-        if ((flags >> b) & 1u) s_list[b][base + __popcll(m[b] & below)] = (uint8_t)threadIdx.x;
+    const int cnt = __popc(mask);
+    int incl = cnt;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);  // row_shr:1, zero fill
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+    const int mine = __shfl(incl, 15, 16);
+    uint8_t* dst = st.list[b] + (incl - cnt);
+    uint32_t m = mask;
+    while (m) {
+        const int i = __builtin_ctz(m);
+        m &= m - 1u;
+        *dst++ = (uint8_t)(16 * l16 + i);
     }
-    const int mine = __shfl(tot_v, 4 * wave + (lane >> 4), 64);
     *n_wave = max(max(__builtin_amdgcn_readlane(mine, 0), __builtin_amdgcn_readlane(mine, 16)),
                   max(__builtin_amdgcn_readlane(mine, 32), __builtin_amdgcn_readlane(mine, 48)));
     __syncthreads();
@@ -803,14 +892,9 @@ __device__ __forceinline__ int block_lists(unsigned flags, uint8_t (*s_list)[BAT
 }
 
 __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
-                                                const float* __restrict__ points_xy, const float* __restrict__ conic_opacity,
-                                                const float* __restrict__ rgb, float bg0, float bg1, float bg2, float* __restrict__ out_color,
+                                                const float4* __restrict__ splat, float bg0, float bg1, float bg2, float* __restrict__ out_color,
                                                 uint32_t* __restrict__ n_contrib, float* __restrict__ final_T) {
-    __shared__ float2 s_xy[BATCH];
-    __shared__ float4 s_co[BATCH];
-    __shared__ float4 s_rgb[BATCH];
-    __shared__ __attribute__((aligned(16))) uint8_t s_list[N_BLOCKS][BATCH];
-    __shared__ __attribute__((aligned(16))) uint16_t s_cnt[4][N_BLOCKS];
+    __shared__ StageLds st;
     const int tile = blockIdx.y * cam.gx + blockIdx.x;
     const int px = blockIdx.x * TILE + tile_px(threadIdx.x), py = blockIdx.y * TILE + tile_py(threadIdx.x);
     const bool inside = px < cam.W && py < cam.H;
@@ -821,26 +905,13 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last = 0;
-    const uint32_t* list4 = reinterpret_cast<const uint32_t*>(s_list[block]);
+    const uint32_t* list4 = reinterpret_cast<const uint32_t*>(st.list[block]);
     for (uint32_t base = r0; base < r1; base += BATCH) {
         if (__syncthreads_count(done) == 256) break;
         const uint32_t k = base + threadIdx.x;
-        unsigned flags = 0;
-        if (k < r1) {
-            const int id = point_list[k];
-            const float2 xy = make_float2(points_xy[2 * id], points_xy[2 * id + 1]);
-            const float4 co = *reinterpret_cast<const float4*>(conic_opacity + 4 * id);
-            flags = block_flags(xy, splat_extent(co), tx0, ty0);
-            if (flags) {
-                s_xy[threadIdx.x] = xy; s_co[threadIdx.x] = co;
-                s_rgb[threadIdx.x] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], 0.f);
-            }
-        }
+        const unsigned flags = k < r1 ? stage_entry(st, splat, point_list[k], tx0, ty0) : 0u;
         int n_wave;
-        const int n_mine = block_lists(flags, s_list, s_cnt, &n_wave);
-#ifdef EXP_NO_BLEND
-        n_wave = min(n_wave, cam.D - 1000);
-#endif
+        const int n_mine = block_lists(st, flags, &n_wave);
         const uint32_t pos0 = base - r0 + 1u;  // contributor number of batch entry 0 = its position in the tile list + 1
         for (int jj = 0; jj < n_wave; jj += 4) {
             if (__ballot(!done) == 0ull) break;  // wave-uniform: every pixel of the quadrant is saturated
@@ -852,20 +923,20 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
             // list order.  Entries past the end of the row's list and the reference's four early-outs (done / power > 0 / alpha < 1/255 /
             // saturation) are lane masks; same arithmetic, same order per pixel: bit-identical pixels.
             int j[4];
-            float2 xy_j[4];
-            float4 co_j[4], cl_j[4];
+            float4 a_j[4], b_j[4];
+            float c_j[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 j[u] = (int)((pack >> (8 * u)) & 0xffu);  // bytes behind the list end are stale indices of earlier batches: readable, masked below
-                xy_j[u] = s_xy[j[u]]; co_j[u] = s_co[j[u]]; cl_j[u] = s_rgb[j[u]];
+                a_j[u] = st.a[j[u]]; b_j[u] = st.b[j[u]]; c_j[u] = st.c[j[u]];
             }
             float alpha[4];
             bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const float dx = xy_j[u].x - fx, dy = xy_j[u].y - fy;
-                const float power = -0.5f * (co_j[u].x * dx * dx + co_j[u].z * dy * dy) - co_j[u].y * dx * dy;
-                alpha[u] = fminf(0.99f, co_j[u].w * expf(power));
+                const float dx = a_j[u].x - fx, dy = a_j[u].y - fy;
+                const float power = -0.5f * (b_j[u].x * dx * dx + b_j[u].z * dy * dy) - b_j[u].y * dx * dy;
+                alpha[u] = fminf(0.99f, b_j[u].w * expf(power));
                 ok[u] = (jj + u < n_mine) & !(power > 0.0f) & !(alpha[u] < 1.0f / 255.0f);
             }
 #pragma unroll
@@ -876,7 +947,7 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
                 const bool upd = valid & !sat;
                 done = done | sat;
                 // masked lanes add an exact 0 (a select, not a product: a stale or never-written LDS entry behind the list end may hold a NaN)
-                C0 += upd ? cl_j[u].x * alpha[u] * T : 0.f; C1 += upd ? cl_j[u].y * alpha[u] * T : 0.f; C2 += upd ? cl_j[u].z * alpha[u] * T : 0.f;
+                C0 += upd ? a_j[u].z * alpha[u] * T : 0.f; C1 += upd ? a_j[u].w * alpha[u] * T : 0.f; C2 += upd ? c_j[u] * alpha[u] * T : 0.f;
                 T = upd ? test_T : T;
                 last = upd ? pos0 + (uint32_t)j[u] : last;
             }
@@ -903,17 +974,12 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
     return v;
 }
 __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
-                                                   const float* __restrict__ points_xy, const float* __restrict__ conic_opacity,
-                                                   const float* __restrict__ rgb, float bg0, float bg1, float bg2,
+                                                   const float4* __restrict__ splat, float bg0, float bg1, float bg2,
                                                    const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
                                                    const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D,
                                                    float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor) {
-    __shared__ float2 s_xy[BATCH];
-    __shared__ float4 s_co[BATCH];
-    __shared__ float s_rgb[BATCH * 3];
+    __shared__ StageLds st;
     __shared__ float s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 16 blocks, flushed once per batch
-    __shared__ __attribute__((aligned(16))) uint8_t s_list[N_BLOCKS][BATCH];
-    __shared__ __attribute__((aligned(16))) uint16_t s_cnt[4][N_BLOCKS];
     __shared__ int s_blast[N_BLOCKS];
     const int tile = blockIdx.y * cam.gx + blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -945,7 +1011,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
 #pragma unroll
     for (int d = 8; d > 0; d >>= 1) n_eff = max(n_eff, __shfl_xor(n_eff, d, 16));
     n_eff = min(n_tile, __builtin_amdgcn_readfirstlane(n_eff));
-    const uint32_t* list4 = reinterpret_cast<const uint32_t*>(s_list[block]);
+    const uint32_t* list4 = reinterpret_cast<const uint32_t*>(st.list[block]);
     // batches are taken from the END of the blended prefix: position p (0-based from the front) has contributor number p + 1;
     // batch entry t sits at position n_eff - 1 - done_cnt - t
     for (int done_cnt = 0; done_cnt < n_eff; done_cnt += BATCH) {
@@ -959,28 +1025,29 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
         const int pos_top = n_eff - 1 - done_cnt;  // list position of batch entry 0
         if ((int)threadIdx.x < nb_raw) {
             id_l = point_list[r0 + pos_top - threadIdx.x];
-            const float2 xy_l = make_float2(points_xy[2 * id_l], points_xy[2 * id_l + 1]);
-            const float4 co_l = *reinterpret_cast<const float4*>(conic_opacity + 4 * id_l);
-            flags = block_flags(xy_l, splat_extent(co_l), tx0, ty0);
+            const float4* rec = splat + 4 * (size_t)id_l;
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            flags = block_flags(q0, q2, q3, tx0, ty0);
             const int pos_l = pos_top - (int)threadIdx.x;
 #pragma unroll
             for (int b = 0; b < N_BLOCKS; b++)  // no pixel of block b blended anything at or behind its maximum
                 if (pos_l >= __builtin_amdgcn_readlane(blast_v, b)) flags &= ~(1u << b);
             if (flags) {
-                s_xy[threadIdx.x] = xy_l; s_co[threadIdx.x] = co_l;
-                s_rgb[3 * threadIdx.x] = rgb[3 * id_l]; s_rgb[3 * threadIdx.x + 1] = rgb[3 * id_l + 1]; s_rgb[3 * threadIdx.x + 2] = rgb[3 * id_l + 2];
+                st.a[threadIdx.x] = make_float4(q0.x, q0.y, q1.z, q1.w);
+                st.b[threadIdx.x] = make_float4(q0.z, q0.w, q1.x, q1.y);
+                st.c[threadIdx.x] = q2.x;
             }
         }
         int n_wave;
-        const int n_mine = block_lists(flags, s_list, s_cnt, &n_wave);
+        const int n_mine = block_lists(st, flags, &n_wave);
         for (int jj = 0; jj < n_wave; jj++) {
             const uint32_t pack = list4[jj >> 2];  // four entries of this row's list per dword
             const int j = (int)((pack >> (8 * (jj & 3))) & 0xffu);
             const int pos = pos_top - j;
             // branch-free like the forward loop: lanes that do not blend the Gaussian carry zeros into the sums
-            const float4 co = s_co[j];
-            const float2 xy = s_xy[j];
-            const float dx = xy.x - fx, dy = xy.y - fy;
+            const float4 co = st.b[j];
+            const float4 xyrg = st.a[j];
+            const float dx = xyrg.x - fx, dy = xyrg.y - fy;
             const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
             const float G = expf(power);
             const float alpha = fminf(0.99f, co.w * G);
@@ -990,7 +1057,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             const float r_om = __builtin_amdgcn_rcpf(one_minus);  // 1 ulp; the two quotients below feed gradients only (tolerance, not bit parity)
             const float T_new = T * r_om;
             const float dch = alpha * T_new;
-            const float c0 = s_rgb[3 * j], c1 = s_rgb[3 * j + 1], c2 = s_rgb[3 * j + 2];
+            const float c0 = xyrg.z, c1 = xyrg.w, c2 = st.c[j];
             const float n_acc0 = last_alpha * lc0 + (1 - last_alpha) * acc0;
             const float n_acc1 = last_alpha * lc1 + (1 - last_alpha) * acc1;
             const float n_acc2 = last_alpha * lc2 + (1 - last_alpha) * acc2;
@@ -1308,7 +1375,8 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix_host, const float* projmatrix_host,
                       const float* campos_host, float tan_fovx, float tan_fovy, int32_t* radii, float* depths, float* points_xy,
                       float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched, uint32_t* tile_counts,
-                      uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t span_capacity, int64_t* num_rendered, nrc_stream_t stream) {
+                      uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t span_capacity, float* splat_records, int64_t* num_rendered,
+                      nrc_stream_t stream) {
     NRC_ENTER();
     GsCam cam;
     const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, tan_fovx, tan_fovy, scale_modifier);
@@ -1324,11 +1392,12 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
     const bool lds_path = cam.gx <= SPAN_DIM_MAX && cam.gy <= SPAN_DIM_MAX && bin_hist != nullptr;
     hipMemsetAsync(tile_counts, 0, sizeof(uint32_t) * n_tiles, s);
     if (P > 0) {
-        if (!means3D || !opacities || !radii || !depths || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !tiles_touched) return NRC_ERR_INVALID;
+        if (!means3D || !opacities || !radii || !depths || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !tiles_touched || !splat_records)
+            return NRC_ERR_INVALID;
         if (shs && M > PRE_MAXM) return NRC_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(k_preprocess, dim3(nrc_cdiv(P, PRE_BLOCK)), dim3(PRE_BLOCK), 0, s, P, cam, means3D, shs, colors_precomp, opacities, scales, rotations,
                            cov3D_precomp, radii, depths, points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched,
-                           lds_path ? (uint32_t*)nullptr : tile_counts);
+                           lds_path ? (uint32_t*)nullptr : tile_counts, (float4*)splat_records);
         if (lds_path) {
             const BinWs w = gs_bin_ws(bin_hist, P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P));
             // depth pre-sort of the Gaussians: 4 stable 8-bit passes, (keyA,valA) -> ... -> (keyA,valA); valA = depth order
@@ -1363,14 +1432,14 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
 int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, const int32_t* radii, const float* depths, const float* points_xy,
                       const float* conic_opacity, const float* rgb, const uint32_t* ranges, uint32_t* tile_fill, const uint32_t* bin_hist, int64_t span_capacity,
                       uint64_t* keys,
-                      int32_t* point_list, float* out_color, uint32_t* n_contrib, float* final_T, nrc_stream_t stream) {
+                      int32_t* point_list, const float* splat_records, float* out_color, uint32_t* n_contrib, float* final_T, nrc_stream_t stream) {
     NRC_ENTER();
     if (P < 0 || W < 1 || H < 1 || !bg_host || !ranges || !tile_fill || !out_color || !n_contrib || !final_T) return NRC_ERR_INVALID;
     GsCam cam = {};
     cam.W = W; cam.H = H; cam.gx = (W + TILE - 1) / TILE; cam.gy = (H + TILE - 1) / TILE;
     hipStream_t s = (hipStream_t)stream;
     if (P > 0) {
-        if (!radii || !depths || !points_xy || !conic_opacity || !rgb || !keys || !point_list) return NRC_ERR_INVALID;
+        if (!radii || !depths || !points_xy || !conic_opacity || !rgb || !keys || !point_list || !splat_records) return NRC_ERR_INVALID;
         const int n_tiles = cam.gx * cam.gy;
         if (cam.gx <= SPAN_DIM_MAX && cam.gy <= SPAN_DIM_MAX && bin_hist) {
             const BinWs w = gs_bin_ws(const_cast<uint32_t*>(bin_hist), P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P));
@@ -1383,8 +1452,8 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
             hipLaunchKernelGGL((k_sort_tiles<4096, SORT_LDS_CAP>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
         }
     }
-    hipLaunchKernelGGL(k_render, dim3(cam.gx, cam.gy), dim3(256), 0, s, cam, ranges, point_list, points_xy, conic_opacity, rgb, bg_host[0],
-                       bg_host[1], bg_host[2], out_color, n_contrib, final_T);
+    hipLaunchKernelGGL(k_render, dim3(cam.gx, cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, bg_host[0], bg_host[1],
+                       bg_host[2], out_color, n_contrib, final_T);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
@@ -1394,7 +1463,7 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
                     const float* cov3D_precomp, const float* viewmatrix_host, const float* projmatrix_host, const float* campos_host,
                     float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
                     const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list, const uint32_t* ranges,
-                    const uint32_t* n_contrib, const float* final_T, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                    const float* splat_records, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                     float* dL_drot, nrc_stream_t stream) {
     NRC_ENTER();
@@ -1414,8 +1483,8 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
     hipMemsetAsync(dL_dopacity, 0, sizeof(float) * P, s);
     hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * P, s);
     if (use_sh && M > PBW_MAXM) return NRC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_render_bw, dim3(cam.gx, cam.gy), dim3(256), 0, s, cam, ranges, point_list, points_xy, conic_opacity, rgb, bg_host[0],
-                       bg_host[1], bg_host[2], n_contrib, final_T, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+    hipLaunchKernelGGL(k_render_bw, dim3(cam.gx, cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, bg_host[0], bg_host[1],
+                       bg_host[2], n_contrib, final_T, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
     hipLaunchKernelGGL(k_preprocess_bw, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, P, cam, means3D, shs, use_sh, scales, rotations, use_sr, radii,
                        clamped, cov3D, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     NRC_LAUNCH_CHECK();
