@@ -199,6 +199,7 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
  * clamped (P) u8 bit mask (bit c = channel c clamped), cov3D (P,6), tiles_touched (P) u32.
  * splat_records (P,16) f32: one 64-byte line per Gaussian with everything the blend kernels read of it (screen position, conic, opacity,
  * colour) and the per-Gaussian part of their block-culling test; written by nrc_gs_preprocess, read by nrc_gs_bin_render / nrc_gs_backward.
+ * (tile_fill doubles as `tile_order` after nrc_gs_bin_render: the tiles sorted by list length, longest first = launch order of the blend kernels.)
  * Binning state: tile_counts, tile_fill (n_tiles) u32, ranges (n_tiles,2) u32, keys (num_rendered) u64, point_list
  * (num_rendered) i32.  Image state: n_contrib (H*W) u32, final_T (H*W).
  *   nrc_gs_preprocess : stages 1-2; num_rendered (DEVICE i64[2]): [0] = number of (tile, Gaussian) instances -- the caller reads it
@@ -229,7 +230,8 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
                     float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
                     const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list,
-                    const uint32_t* ranges, const float* splat_records, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
+                    const uint32_t* ranges, const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib,
+                    const float* final_T, const float* dL_dpix,
                     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                     float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, nrc_stream_t stream);
 

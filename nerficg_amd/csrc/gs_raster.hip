@@ -769,6 +769,39 @@ __global__ void __launch_bounds__(256) k_sort_tiles(const uint32_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 4b. launch order of the tiles
+// Tile lists are heavy-tailed (mean 1 920, max 7 010 entries on the bench frame) and a frame is only ~2 rounds of workgroups: a long tile
+// that starts late finishes alone.  The render kernels therefore take their tile from a table sorted by list length, longest first
+// (counting sort over 2 048 length classes, one workgroup).
+__global__ void __launch_bounds__(1024) k_tile_order(int n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t wsum[16];
+    for (int k = threadIdx.x; k < 2048; k += 1024) hist[k] = 0u;
+    __syncthreads();
+    auto cls = [&](int t) { const uint32_t len = ranges[2 * t + 1] - ranges[2 * t]; return 2047u - min(len >> 2, 2047u); };  // class 0 = longest
+    for (int t = threadIdx.x; t < n_tiles; t += 1024) atomicAdd(&hist[cls(t)], 1u);
+    __syncthreads();
+    // exclusive scan of the 2048 classes: two per thread
+    const uint32_t a = hist[2 * threadIdx.x], b = hist[2 * threadIdx.x + 1];
+    uint32_t incl = a + b;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t off = incl - (a + b);
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    __syncthreads();
+    hist[2 * threadIdx.x] = off; hist[2 * threadIdx.x + 1] = off + a;
+    __syncthreads();
+    // placement with an LDS cursor per class: the order inside a class depends on the atomics' arrival, which only permutes the launch order of
+    // tiles of (nearly) equal length -- every tile's result is independent of when it runs
+    for (int t = threadIdx.x; t < n_tiles; t += 1024) order[atomicAdd(&hist[cls(t)], 1u)] = (uint32_t)t;
+}
+
 // ------------------------------------------------------------------------------------------------ 5. render
 // thread -> pixel of the 16x16 tile: wave = 8x8 quadrant, DPP row (16 lanes) = 4x4 block of the quadrant.  block index b = 4 * wave + row,
 // block (cx, cy) of the 4x4 block grid of the tile: cx = 2 * (wave & 1) + (row & 1), cy = 2 * (wave >> 1) + (row >> 1).
@@ -892,14 +925,15 @@ __device__ __forceinline__ int block_lists(StageLds& st, unsigned flags, int* n_
 }
 
 __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
-                                                const float4* __restrict__ splat, float bg0, float bg1, float bg2, float* __restrict__ out_color,
-                                                uint32_t* __restrict__ n_contrib, float* __restrict__ final_T) {
+                                                const float4* __restrict__ splat, const uint32_t* __restrict__ tile_order, float bg0, float bg1, float bg2,
+                                                float* __restrict__ out_color, uint32_t* __restrict__ n_contrib, float* __restrict__ final_T) {
     __shared__ StageLds st;
-    const int tile = blockIdx.y * cam.gx + blockIdx.x;
-    const int px = blockIdx.x * TILE + tile_px(threadIdx.x), py = blockIdx.y * TILE + tile_py(threadIdx.x);
+    const int tile = (int)tile_order[blockIdx.x];  // longest lists first
+    const int tile_x = tile % cam.gx, tile_y = tile / cam.gx;
+    const int px = tile_x * TILE + tile_px(threadIdx.x), py = tile_y * TILE + tile_py(threadIdx.x);
     const bool inside = px < cam.W && py < cam.H;
     const float fx = (float)px, fy = (float)py;
-    const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
+    const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
     const int block = threadIdx.x >> 4;  // = 4 * wave + DPP row
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
     bool done = !inside;
@@ -974,18 +1008,19 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
     return v;
 }
 __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
-                                                   const float4* __restrict__ splat, float bg0, float bg1, float bg2,
+                                                   const float4* __restrict__ splat, const uint32_t* __restrict__ tile_order, float bg0, float bg1, float bg2,
                                                    const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
                                                    const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D,
                                                    float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor) {
     __shared__ StageLds st;
     __shared__ float s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 16 blocks, flushed once per batch
     __shared__ int s_blast[N_BLOCKS];
-    const int tile = blockIdx.y * cam.gx + blockIdx.x;
+    const int tile = (int)tile_order[blockIdx.x];  // longest lists first
+    const int tile_x = tile % cam.gx, tile_y = tile / cam.gx;
     const int lane = threadIdx.x & 63;
     const int block = threadIdx.x >> 4;
-    const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
-    const int px = blockIdx.x * TILE + tile_px(threadIdx.x), py = blockIdx.y * TILE + tile_py(threadIdx.x);
+    const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
+    const int px = tile_x * TILE + tile_px(threadIdx.x), py = tile_y * TILE + tile_py(threadIdx.x);
     const bool inside = px < cam.W && py < cam.H;
     const float fx = (float)px, fy = (float)py;
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
@@ -1452,8 +1487,10 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
             hipLaunchKernelGGL((k_sort_tiles<4096, SORT_LDS_CAP>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
         }
     }
-    hipLaunchKernelGGL(k_render, dim3(cam.gx, cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, bg_host[0], bg_host[1],
-                       bg_host[2], out_color, n_contrib, final_T);
+    // tile_fill has served the fallback scatter (if any): it now carries the launch order of the tiles, longest list first, for both render kernels
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cam.gx * cam.gy, ranges, tile_fill);
+    hipLaunchKernelGGL(k_render, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_fill, bg_host[0],
+                       bg_host[1], bg_host[2], out_color, n_contrib, final_T);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
@@ -1463,7 +1500,8 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
                     const float* cov3D_precomp, const float* viewmatrix_host, const float* projmatrix_host, const float* campos_host,
                     float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
                     const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list, const uint32_t* ranges,
-                    const float* splat_records, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                    const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
+                    float* dL_dmean2D, float* dL_dconic,
                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                     float* dL_drot, nrc_stream_t stream) {
     NRC_ENTER();
@@ -1483,8 +1521,8 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
     hipMemsetAsync(dL_dopacity, 0, sizeof(float) * P, s);
     hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * P, s);
     if (use_sh && M > PBW_MAXM) return NRC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_render_bw, dim3(cam.gx, cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, bg_host[0], bg_host[1],
-                       bg_host[2], n_contrib, final_T, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+    hipLaunchKernelGGL(k_render_bw, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_order, bg_host[0],
+                       bg_host[1], bg_host[2], n_contrib, final_T, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
     hipLaunchKernelGGL(k_preprocess_bw, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, P, cam, means3D, shs, use_sh, scales, rotations, use_sr, radii,
                        clamped, cov3D, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     NRC_LAUNCH_CHECK();

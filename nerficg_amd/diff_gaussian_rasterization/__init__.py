@@ -149,7 +149,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D_c, sh_c if sh_c is not None else torch.empty(0), col_c if col_c is not None else torch.empty(0),
                               sc_c if sc_c is not None else torch.empty(0), rot_c if rot_c is not None else torch.empty(0),
                               cov_c if cov_c is not None else torch.empty(0), radii, points_xy, conic_opacity, rgb, clamped, cov3D,
-                              point_list, ranges, n_contrib, final_T, splat)
+                              point_list, ranges, n_contrib, final_T, splat, tile_fill)
         ctx.debug_state = dict(depths=depths, tiles_touched=tiles_touched, keys=keys)
         radii_out = radii[:P]
         ctx.mark_non_differentiable(radii_out)
@@ -159,7 +159,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out_color, _grad_radii):
         (means3D, sh, col, sc, rot, cov, radii, points_xy, conic_opacity, rgb, clamped, cov3D, point_list, ranges, n_contrib,
-         final_T, splat) = ctx.saved_tensors
+         final_T, splat, tile_order) = ctx.saved_tensors
         has_sh, has_col, has_sr, has_cov = ctx.has
         P, D, M, W, H = ctx.dims
         rs = ctx.raster_settings
@@ -182,7 +182,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             P, D, M, W, H, _p(bg), _lib.ptr(means3D), _lib.ptr(sh if has_sh else None), _lib.ptr(col if has_col else None),
             _lib.ptr(sc if has_sr else None), float(rs.scale_modifier), _lib.ptr(rot if has_sr else None), _lib.ptr(cov if has_cov else None),
             _p(vm), _p(pm), _p(cp), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
-            _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(point_list), _lib.ptr(ranges), _lib.ptr(splat), _lib.ptr(n_contrib), _lib.ptr(final_T),
+            _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(point_list), _lib.ptr(ranges), _lib.ptr(splat), _lib.ptr(tile_order), _lib.ptr(n_contrib), _lib.ptr(final_T),
             _lib.ptr(g), _lib.ptr(dmean2D), _lib.ptr(dconic), _lib.ptr(dopacity), _lib.ptr(dcolor), _lib.ptr(dmean3D), _lib.ptr(dcov3D),
             _lib.ptr(dsh), _lib.ptr(dscale), _lib.ptr(drot), _lib.stream_of(g)), 'gs_backward')
         return (dmean3D[:P], dmean2D[:P], dsh[:P] if has_sh else None, dcolor[:P] if has_col else None,
