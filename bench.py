@@ -212,10 +212,9 @@ def gs_kernel_rooflines(gs_res, pmc_all):
     return out
 
 
-def gs_cpu_baseline(n=250000, w=648, h=420):
-    """CPU oracle (kind "port": the reference refuses CPU mode for GaussianSplatting, Renderer.py:32-33) on a bounded sample of the
-    same synthetic distribution: n Gaussians on a 1/2-scale image, OpenMP over Gaussians / pixel rows on all host cores (the instance sort is
-    a serial qsort)."""
+def gs_cpu_baseline(n=1_000_000, w=GS_W, h=GS_H):
+    """CPU oracle (kind "port": the reference refuses CPU mode for GaussianSplatting, Renderer.py:32-33) on ONE frame of the workload itself
+    (1 M Gaussians, 1297x840: ~10-20 s of CPU work), OpenMP over Gaussians / pixel rows on all host cores (the instance sort is a serial qsort)."""
     import oracle
     from tests import scenes
     sc = scenes.gs_random_scene(n, seed=0)
@@ -238,7 +237,7 @@ def gs_cpu_baseline(n=250000, w=648, h=420):
                       f'fwd {t_f:.2f} s + bwd {t_b:.2f} s'}
 
 
-def cpu_baseline(cam_full, pose, model_params, crop=96):
+def cpu_baseline(cam_full, pose, model_params, crop=160):
     """The CPU oracle (kind "port": the reference has no CPU path for InstantNGP) on a bounded sample: a crop x crop central
     window of the same camera/pose/scene, all host cores (OpenMP in the encode/MLP loops)."""
     import oracle

@@ -197,6 +197,10 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
  * (4,4) tensors the reference passes: w2c.T and w2c.T @ P.T), campos (3), bg (3) are HOST pointers.  16x16-pixel tiles.
  * Per-Gaussian state (geometry buffer): radii (P) i32, depths (P), points_xy (P,2), conic_opacity (P,4), rgb (P,3),
  * clamped (P) u8 bit mask (bit c = channel c clamped), cov3D (P,6), tiles_touched (P) u32.
+ * Model-side parameters (extension beyond the reference's call, for callers that own the Gaussians: src/Methods/GaussianSplatting/Model.py:45-87):
+ * shs_rest != NULL: `shs` is the DC part (P,1,3) and shs_rest the (P,M-1,3) remainder as the model stores them -- the (P,M,3) concatenation
+ * of get_features is never built; raw_parameters != 0: opacities are logits, scales log-scales, rotations unnormalised, and sigmoid / exp /
+ * normalisation run inside preprocess (the backward returns gradients w.r.t. the raw values; dL_dsh_rest receives the remainder's gradient).
  * splat_records (P,16) f32: one 64-byte line per Gaussian with everything the blend kernels read of it (screen position, conic, opacity,
  * colour) and the per-Gaussian part of their block-culling test; written by nrc_gs_preprocess, read by nrc_gs_bin_render / nrc_gs_backward.
  * (tile_fill doubles as `tile_order` after nrc_gs_bin_render: the tiles sorted by list length, longest first = launch order of the blend kernels.)
@@ -215,7 +219,7 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
  * The same span_capacity goes to nrc_gs_preprocess and nrc_gs_bin_render. */
 int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H, int64_t span_capacity);
 int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs,
-                      const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                      const float* shs_rest, int32_t raw_parameters, const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                       const float* campos, float tan_fovx, float tan_fovy, int32_t* radii, float* depths, float* points_xy,
                       float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched,
@@ -226,14 +230,14 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg, const in
                       uint32_t* tile_fill, const uint32_t* bin_hist, int64_t span_capacity, uint64_t* keys, int32_t* point_list,
                       const float* splat_records, float* out_color, uint32_t* n_contrib, float* final_T, nrc_stream_t stream);
 int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg, const float* means3D, const float* shs,
-                    const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                    const float* shs_rest, int32_t raw_parameters, const float* opacities, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
                     float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
                     const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list,
                     const uint32_t* ranges, const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib,
                     const float* final_T, const float* dL_dpix,
                     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-                    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, nrc_stream_t stream);
+                    float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale, float* dL_drot, nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 5 -- ray generation (replaces PerspectiveCamera.compute_local_ray_directions src/Cameras/Perspective.py:64-94

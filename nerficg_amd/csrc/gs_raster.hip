@@ -35,8 +35,22 @@ struct GsCam {
     float view[16], proj[16], campos[3];
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     int W, H, gx, gy, D, M;
+    int raw;  // 1: opacities are logits, scales log-scales, rotations unnormalised (the activations of Gaussians.get_* run inside the kernels)
 };
 
+// activations of GaussianSplatting/Model.py:45-87 for the raw-parameter mode: exp (scales), x / max(|x|, 1e-12) (rotations), sigmoid (opacities)
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ void act_scales(const float* raw, int on, float* s) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) s[k] = on ? expf(raw[k]) : raw[k];
+}
+__device__ __forceinline__ float act_rotation(const float* raw, int on, float* q) {  // returns the norm used (1 when off)
+    float n = 1.f;
+    if (on) n = fmaxf(sqrtf(raw[0] * raw[0] + raw[1] * raw[1] + raw[2] * raw[2] + raw[3] * raw[3]), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = on ? raw[k] / n : raw[k];
+    return n;
+}
 __device__ __forceinline__ void xform43(const float* p, const float* m, float* o) {
     o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
     o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
@@ -181,8 +195,9 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
 #pragma unroll
         for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * i + k];
     } else {
-        const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
-        const float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+        float s[3], q[4];
+        act_scales(scales + 3 * i, cam.raw, s);
+        act_rotation(rotations + 4 * i, cam.raw, q);
         cov3d(s, cam.scale_modifier, q, c3);
     }
 #pragma unroll
@@ -221,15 +236,41 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) rgb[3 * i + k] = col[k];
-    if (want_record) write_splat_record(splat, pix[0], pix[1], conic[0], conic[1], conic[2], opacities[i], col);  // this thread's row of the LDS image
+    const float opacity = cam.raw ? act_sigmoid(opacities[i]) : opacities[i];
+    if (want_record) write_splat_record(splat, pix[0], pix[1], conic[0], conic[1], conic[2], opacity, col);  // this thread's row of the LDS image
     depths[i] = pv[2]; radii[i] = my_radius;
     points_xy[2 * i] = pix[0]; points_xy[2 * i + 1] = pix[1];
     conic_opacity[4 * i] = conic[0]; conic_opacity[4 * i + 1] = conic[1]; conic_opacity[4 * i + 2] = conic[2];
-    conic_opacity[4 * i + 3] = opacities[i];
+    conic_opacity[4 * i + 3] = opacity;
     tiles_touched[i] = (uint32_t)((rmax[1] - rmin[1]) * (rmax[0] - rmin[0]));
     if (tile_counts) {  // fallback binning for tile grids too large for the LDS histograms
         for (int y = rmin[1]; y < rmax[1]; y++)
             for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&tile_counts[y * cam.gx + x], 1u);
+    }
+}
+// SH rows of `count` Gaussians starting at `first` <-> LDS rows of `pitch` floats.  One array (P, M, 3), or split like the model stores them
+// (Model.py:28-31: dc (P, 1, 3) + rest (P, M-1, 3)) -- the (P, M, 3) concatenation Gaussians.get_features materialises per render
+// (192 B read + written per Gaussian, and its backward split) is then never built.
+template <bool TO_LDS>
+__device__ __forceinline__ void sh_rows_copy(float* s_sh, int pitch, int row_len, int count, size_t first, float* sh, float* sh_rest, int nthreads) {
+    if (!sh_rest) {
+        float* g = sh + first * row_len;
+        for (int k = threadIdx.x; k < count * row_len; k += nthreads) {
+            const int r = k / row_len;
+            if (TO_LDS) s_sh[r * pitch + (k - r * row_len)] = g[k]; else g[k] = s_sh[r * pitch + (k - r * row_len)];
+        }
+    } else {
+        float* g0 = sh + first * 3;
+        for (int k = threadIdx.x; k < count * 3; k += nthreads) {
+            const int r = k / 3;
+            if (TO_LDS) s_sh[r * pitch + (k - r * 3)] = g0[k]; else g0[k] = s_sh[r * pitch + (k - r * 3)];
+        }
+        const int rl = row_len - 3;
+        float* g1 = sh_rest + first * rl;
+        for (int k = threadIdx.x; k < count * rl; k += nthreads) {
+            const int r = k / rl;
+            if (TO_LDS) s_sh[r * pitch + 3 + (k - r * rl)] = g1[k]; else g1[k] = s_sh[r * pitch + 3 + (k - r * rl)];
+        }
     }
 }
 // Workgroup = 128 Gaussians; their SH coefficients (one contiguous 128 x 3M float block) are staged through LDS with coalesced
@@ -237,6 +278,7 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
 #define PRE_BLOCK 128
 #define PRE_MAXM 16
 __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam, const float* __restrict__ means3D, const float* __restrict__ shs,
+                                                          const float* __restrict__ shs_rest,
                                                           const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                                                           const float* __restrict__ scales, const float* __restrict__ rotations,
                                                           const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii,
@@ -248,12 +290,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam, cons
     const int first = blockIdx.x * PRE_BLOCK, i = first + threadIdx.x;
     const int row_len = 3 * cam.M, pitch = row_len + 1;
     if (shs) {
-        const int count = min(PRE_BLOCK, P - first);
-        const float* src = shs + (size_t)first * row_len;
-        for (int k = threadIdx.x; k < count * row_len; k += PRE_BLOCK) {
-            const int r = k / row_len;
-            s_sh[r * pitch + (k - r * row_len)] = src[k];
-        }
+        sh_rows_copy<true>(s_sh, pitch, row_len, min(PRE_BLOCK, P - first), (size_t)first, const_cast<float*>(shs), const_cast<float*>(shs_rest), PRE_BLOCK);
         __syncthreads();
     }
     // splat records leave through LDS: a lane storing its own 64-byte record touches 64 cache lines per store instruction; from the LDS image
@@ -1149,7 +1186,12 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
                                                   const uint8_t* __restrict__ clamped, const float* __restrict__ cov3D,
                                                   const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic,
                                                   const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
-                                                  float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+                                                  float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+                                                  const float* __restrict__ opacities, float* __restrict__ dL_dopacity) {
+    if (cam.raw && opacities) {  // dL/dlogit = dL/dopacity * o (1 - o); dL_dopacity holds the blend kernel's sums for the activated opacity
+        const float o_act = act_sigmoid(opacities[i]);
+        dL_dopacity[i] *= o_act * (1.f - o_act);
+    }
     const float mean[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
     float c3[6];
 #pragma unroll
@@ -1264,8 +1306,9 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
 #pragma unroll
     for (int k = 0; k < 3; k++) dL_dmean3D[3 * i + k] = dmean[k];
     if (use_scale_rot) {
-        const float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
-        const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        float q[4], s[3];
+        const float q_norm = act_rotation(rotations + 4 * i, cam.raw, q);
+        act_scales(scales + 3 * i, cam.raw, s);
         const float mod = cam.scale_modifier;
         float R[9], A[9], Gs[9], dA[9], dR[9];
         quat_R(q, R);
@@ -1282,15 +1325,24 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
             for (int k = 0; k < 3; k++) dA[3 * r_ + k] = 2 * (Gs[3 * r_] * A[k] + Gs[3 * r_ + 1] * A[3 + k] + Gs[3 * r_ + 2] * A[6 + k]);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            dL_dscale[3 * i + k] = mod * (dA[k] * R[k] + dA[3 + k] * R[3 + k] + dA[6 + k] * R[6 + k]);
+            const float ds = mod * (dA[k] * R[k] + dA[3 + k] * R[3 + k] + dA[6 + k] * R[6 + k]);
+            dL_dscale[3 * i + k] = cam.raw ? ds * s[k] : ds;  // d exp(l) / dl = exp(l)
 #pragma unroll
             for (int r_ = 0; r_ < 3; r_++) dR[3 * r_ + k] = dA[3 * r_ + k] * (mod * s[k]);
         }
         const float r = q[0], x = q[1], y = q[2], z = q[3];
-        dL_drot[4 * i] = 2 * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
-        dL_drot[4 * i + 1] = 2 * (y * dR[1] + z * dR[2] + y * dR[3] - 2 * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2 * x * dR[8]);
-        dL_drot[4 * i + 2] = 2 * (-2 * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2 * y * dR[8]);
-        dL_drot[4 * i + 3] = 2 * (-2 * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2 * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+        float g[4];
+        g[0] = 2 * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+        g[1] = 2 * (y * dR[1] + z * dR[2] + y * dR[3] - 2 * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2 * x * dR[8]);
+        g[2] = 2 * (-2 * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2 * y * dR[8]);
+        g[3] = 2 * (-2 * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2 * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+        if (cam.raw) {  // through q / |q|: (g - q^ (q^ . g)) / |q|
+            const float dot = q[0] * g[0] + q[1] * g[1] + q[2] * g[2] + q[3] * g[3];
+#pragma unroll
+            for (int k = 0; k < 4; k++) g[k] = (g[k] - q[k] * dot) / q_norm;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) dL_drot[4 * i + k] = g[k];
     }
 }
 
@@ -1301,29 +1353,26 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
 #define PBW_BLOCK 128
 #define PBW_MAXM 16
 __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam, const float* __restrict__ means3D, const float* __restrict__ shs,
-                                                             int use_sh, const float* __restrict__ scales, const float* __restrict__ rotations,
+                                                             const float* __restrict__ shs_rest, const float* __restrict__ opacities, int use_sh, const float* __restrict__ scales, const float* __restrict__ rotations,
                                                              int use_scale_rot, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
                                                              const float* __restrict__ cov3D, const float* __restrict__ dL_dmean2D,
                                                              const float* __restrict__ dL_dconic, const float* __restrict__ dL_dcolor,
                                                              float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-                                                             float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+                                                             float* __restrict__ dL_dsh_rest, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+                                                             float* __restrict__ dL_dopacity) {
     __shared__ float s_sh[PBW_BLOCK * (3 * PBW_MAXM + 1)];
     const int first = blockIdx.x * PBW_BLOCK, i = first + threadIdx.x;
     const int row_len = 3 * cam.M, pitch = row_len + 1;  // +1: rows start in different LDS banks
     const int count = min(PBW_BLOCK, P - first);
     const bool visible = i < P && radii[i] > 0;
     if (use_sh) {
-        const float* src = shs + (size_t)first * row_len;
-        for (int k = threadIdx.x; k < count * row_len; k += PBW_BLOCK) {
-            const int r = k / row_len;
-            s_sh[r * pitch + (k - r * row_len)] = src[k];
-        }
+        sh_rows_copy<true>(s_sh, pitch, row_len, count, (size_t)first, const_cast<float*>(shs), const_cast<float*>(shs_rest), PBW_BLOCK);
         __syncthreads();
     }
     float* sh_row = s_sh + threadIdx.x * pitch;
     if (visible) {
         preprocess_bw_one(i, cam, means3D, sh_row, use_sh, scales, rotations, use_scale_rot, clamped, cov3D, dL_dmean2D, dL_dconic, dL_dcolor,
-                          dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot);
+                          dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, opacities, dL_dopacity);
     } else if (i < P) {
         if (use_sh) for (int k = 0; k < row_len; k++) sh_row[k] = 0.f;
 #pragma unroll
@@ -1339,11 +1388,7 @@ __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam, c
     }
     if (use_sh) {
         __syncthreads();
-        float* dst = dL_dsh + (size_t)first * row_len;
-        for (int k = threadIdx.x; k < count * row_len; k += PBW_BLOCK) {
-            const int r = k / row_len;
-            dst[k] = s_sh[r * pitch + (k - r * row_len)];
-        }
+        sh_rows_copy<false>(s_sh, pitch, row_len, count, (size_t)first, dL_dsh, dL_dsh_rest, PBW_BLOCK);
     }
 }
 
@@ -1383,7 +1428,7 @@ BinWs gs_bin_ws(uint32_t* base, int P, int gx, int gy, int64_t cap) {
 }
 
 int make_cam(GsCam& cam, int W, int H, int D, int M, const float* view, const float* proj, const float* campos, float tanx, float tany,
-             float scale_modifier) {
+             float scale_modifier, int raw) {
     if (W < 1 || H < 1 || D < 0 || D > 3 || !view || !proj || !campos || !(tanx > 0.f) || !(tany > 0.f)) return NRC_ERR_INVALID;
     for (int k = 0; k < 16; k++) { cam.view[k] = view[k]; cam.proj[k] = proj[k]; }
     for (int k = 0; k < 3; k++) cam.campos[k] = campos[k];
@@ -1391,6 +1436,7 @@ int make_cam(GsCam& cam, int W, int H, int D, int M, const float* view, const fl
     cam.focal_x = W / (2.0f * tanx); cam.focal_y = H / (2.0f * tany);
     cam.scale_modifier = scale_modifier;
     cam.W = W; cam.H = H; cam.gx = (W + TILE - 1) / TILE; cam.gy = (H + TILE - 1) / TILE; cam.D = D; cam.M = M;
+    cam.raw = raw ? 1 : 0;
     return NRC_OK;
 }
 
@@ -1405,8 +1451,8 @@ int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H, int64_t span_capa
     return gs_bin_ws(nullptr, P, gx, gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P)).words * (int64_t)sizeof(uint32_t);
 }
 
-int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs,
-                      const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs, const float* shs_rest,
+                      int32_t raw_parameters, const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix_host, const float* projmatrix_host,
                       const float* campos_host, float tan_fovx, float tan_fovy, int32_t* radii, float* depths, float* points_xy,
                       float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched, uint32_t* tile_counts,
@@ -1414,13 +1460,15 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                       nrc_stream_t stream) {
     NRC_ENTER();
     GsCam cam;
-    const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, tan_fovx, tan_fovy, scale_modifier);
+    const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, tan_fovx, tan_fovy, scale_modifier, raw_parameters);
     if (rc != NRC_OK) return rc;
     if (P < 0 || !tile_counts || !ranges || !tile_fill || !num_rendered) return NRC_ERR_INVALID;
     if (P > 0) {
         if ((shs == nullptr) == (colors_precomp == nullptr)) return NRC_ERR_INVALID;                      // exactly one colour source
         if (((scales != nullptr) && (rotations != nullptr)) == (cov3D_precomp != nullptr)) return NRC_ERR_INVALID;  // exactly one covariance source
         if (shs && M < (D + 1) * (D + 1)) return NRC_ERR_INVALID;
+        if (shs_rest && (!shs || M < 2)) return NRC_ERR_INVALID;   // split SH: shs = (P,1,3) dc part, shs_rest = (P,M-1,3)
+        if (raw_parameters && cov3D_precomp) return NRC_ERR_INVALID;  // raw log-scales / quaternions are what gets activated
     }
     hipStream_t s = (hipStream_t)stream;
     const int n_tiles = cam.gx * cam.gy;
@@ -1430,7 +1478,7 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
         if (!means3D || !opacities || !radii || !depths || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !tiles_touched || !splat_records)
             return NRC_ERR_INVALID;
         if (shs && M > PRE_MAXM) return NRC_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(k_preprocess, dim3(nrc_cdiv(P, PRE_BLOCK)), dim3(PRE_BLOCK), 0, s, P, cam, means3D, shs, colors_precomp, opacities, scales, rotations,
+        hipLaunchKernelGGL(k_preprocess, dim3(nrc_cdiv(P, PRE_BLOCK)), dim3(PRE_BLOCK), 0, s, P, cam, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations,
                            cov3D_precomp, radii, depths, points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched,
                            lds_path ? (uint32_t*)nullptr : tile_counts, (float4*)splat_records);
         if (lds_path) {
@@ -1496,17 +1544,17 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
 }
 
 int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg_host, const float* means3D, const float* shs,
-                    const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                    const float* shs_rest, int32_t raw_parameters, const float* opacities, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                     const float* cov3D_precomp, const float* viewmatrix_host, const float* projmatrix_host, const float* campos_host,
                     float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
                     const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list, const uint32_t* ranges,
                     const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
                     float* dL_dmean2D, float* dL_dconic,
-                    float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                    float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
                     float* dL_drot, nrc_stream_t stream) {
     NRC_ENTER();
     GsCam cam;
-    const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, tan_fovx, tan_fovy, scale_modifier);
+    const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, tan_fovx, tan_fovy, scale_modifier, raw_parameters);
     if (rc != NRC_OK) return rc;
     if (P < 0 || !bg_host) return NRC_ERR_INVALID;
     if (P == 0) return NRC_OK;
@@ -1515,6 +1563,7 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
         return NRC_ERR_INVALID;
     const int use_sh = colors_precomp == nullptr, use_sr = cov3D_precomp == nullptr;
     if ((use_sh && (!shs || !dL_dsh)) || (use_sr && (!scales || !rotations || !dL_dscale || !dL_drot))) return NRC_ERR_INVALID;
+    if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr) || (raw_parameters && (!opacities || !use_sr))) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     hipMemsetAsync(dL_dmean2D, 0, sizeof(float) * 3 * P, s);
     hipMemsetAsync(dL_dconic, 0, sizeof(float) * 4 * P, s);
@@ -1523,8 +1572,8 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
     if (use_sh && M > PBW_MAXM) return NRC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_render_bw, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_order, bg_host[0],
                        bg_host[1], bg_host[2], n_contrib, final_T, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
-    hipLaunchKernelGGL(k_preprocess_bw, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, P, cam, means3D, shs, use_sh, scales, rotations, use_sr, radii,
-                       clamped, cov3D, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    hipLaunchKernelGGL(k_preprocess_bw, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, P, cam, means3D, shs, shs_rest, opacities, use_sh, scales, rotations,
+                       use_sr, radii, clamped, cov3D, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, dL_dopacity);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

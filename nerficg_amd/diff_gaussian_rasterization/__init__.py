@@ -80,7 +80,7 @@ def _opt(t):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, sh_rest=None, raw=False):
         rs = raster_settings
         lib = _lib.load()
         dev = means3D.device
@@ -88,12 +88,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         prep = lambda t: None if _opt(t) is None else t.detach().to(f32).contiguous()
         means3D_c, sh_c, col_c, op_c = prep(means3D), prep(sh), prep(colors_precomp), prep(opacities)
         sc_c, rot_c, cov_c = prep(scales), prep(rotations), prep(cov3Ds_precomp)
+        rest_c = prep(sh_rest)
+        raw = bool(raw)
         if not means3D.is_cuda:
             raise RuntimeError('means3D must be a CUDA tensor')
         P = means3D_c.shape[0]
         W, H = int(rs.image_width), int(rs.image_height)
         D = int(rs.sh_degree)
-        M = 0 if sh_c is None else int(sh_c.shape[1])
+        M = 0 if sh_c is None else int(sh_c.shape[1]) + (0 if rest_c is None else int(rest_c.shape[1]))
         gx, gy = (W + 15) // 16, (H + 15) // 16
         nt = gx * gy
         vm, pm, cp, bg = _host_camera(rs)
@@ -121,7 +123,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             hist_bytes = int(lib.nrc_gs_bin_hist_bytes(P, W, H, span_cap))
             bin_hist = torch.empty(hist_bytes // 4, dtype=i32, device=dev) if hist_bytes > 0 else None
             _lib.check(lib.nrc_gs_preprocess(
-                P, D, M, W, H, _lib.ptr(means3D_c), _lib.ptr(sh_c), _lib.ptr(col_c), _lib.ptr(op_c), _lib.ptr(sc_c), float(rs.scale_modifier),
+                P, D, M, W, H, _lib.ptr(means3D_c), _lib.ptr(sh_c), _lib.ptr(rest_c), int(raw), _lib.ptr(col_c), _lib.ptr(op_c), _lib.ptr(sc_c), float(rs.scale_modifier),
                 _lib.ptr(rot_c), _lib.ptr(cov_c), _p(vm), _p(pm), _p(cp), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(depths),
                 _lib.ptr(points_xy), _lib.ptr(conic_opacity), _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(tiles_touched),
                 _lib.ptr(tile_counts), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(bin_hist), span_cap, _lib.ptr(splat), _lib.ptr(num_rendered), st), 'gs_preprocess')
@@ -149,7 +151,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D_c, sh_c if sh_c is not None else torch.empty(0), col_c if col_c is not None else torch.empty(0),
                               sc_c if sc_c is not None else torch.empty(0), rot_c if rot_c is not None else torch.empty(0),
                               cov_c if cov_c is not None else torch.empty(0), radii, points_xy, conic_opacity, rgb, clamped, cov3D,
-                              point_list, ranges, n_contrib, final_T, splat, tile_fill)
+                              point_list, ranges, n_contrib, final_T, splat, tile_fill, rest_c if rest_c is not None else torch.empty(0), op_c)
+        ctx.raw, ctx.has_rest = raw, rest_c is not None
         ctx.debug_state = dict(depths=depths, tiles_touched=tiles_touched, keys=keys)
         radii_out = radii[:P]
         ctx.mark_non_differentiable(radii_out)
@@ -159,7 +162,8 @@ class _RasterizeGaussians(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out_color, _grad_radii):
         (means3D, sh, col, sc, rot, cov, radii, points_xy, conic_opacity, rgb, clamped, cov3D, point_list, ranges, n_contrib,
-         final_T, splat, tile_order) = ctx.saved_tensors
+         final_T, splat, tile_order, sh_rest, opac) = ctx.saved_tensors
+        raw, has_rest = ctx.raw, ctx.has_rest
         has_sh, has_col, has_sr, has_cov = ctx.has
         P, D, M, W, H = ctx.dims
         rs = ctx.raster_settings
@@ -175,23 +179,25 @@ class _RasterizeGaussians(torch.autograd.Function):
         dcolor = torch.empty(n1, 3, dtype=f32, device=dev)
         dmean3D = torch.empty(n1, 3, dtype=f32, device=dev)
         dcov3D = torch.empty(n1, 6, dtype=f32, device=dev)
-        dsh = torch.empty(n1, max(M, 1), 3, dtype=f32, device=dev) if has_sh else None
+        dsh = torch.empty(n1, 1 if has_rest else max(M, 1), 3, dtype=f32, device=dev) if has_sh else None
+        dsh_rest = torch.empty(n1, M - 1, 3, dtype=f32, device=dev) if has_rest else None
         dscale = torch.empty(n1, 3, dtype=f32, device=dev) if has_sr else None
         drot = torch.empty(n1, 4, dtype=f32, device=dev) if has_sr else None
         _lib.check(lib.nrc_gs_backward(
-            P, D, M, W, H, _p(bg), _lib.ptr(means3D), _lib.ptr(sh if has_sh else None), _lib.ptr(col if has_col else None),
+            P, D, M, W, H, _p(bg), _lib.ptr(means3D), _lib.ptr(sh if has_sh else None), _lib.ptr(sh_rest if has_rest else None), int(raw),
+            _lib.ptr(opac if raw else None), _lib.ptr(col if has_col else None),
             _lib.ptr(sc if has_sr else None), float(rs.scale_modifier), _lib.ptr(rot if has_sr else None), _lib.ptr(cov if has_cov else None),
             _p(vm), _p(pm), _p(cp), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
             _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(point_list), _lib.ptr(ranges), _lib.ptr(splat), _lib.ptr(tile_order), _lib.ptr(n_contrib), _lib.ptr(final_T),
             _lib.ptr(g), _lib.ptr(dmean2D), _lib.ptr(dconic), _lib.ptr(dopacity), _lib.ptr(dcolor), _lib.ptr(dmean3D), _lib.ptr(dcov3D),
-            _lib.ptr(dsh), _lib.ptr(dscale), _lib.ptr(drot), _lib.stream_of(g)), 'gs_backward')
+            _lib.ptr(dsh), _lib.ptr(dsh_rest), _lib.ptr(dscale), _lib.ptr(drot), _lib.stream_of(g)), 'gs_backward')
         return (dmean3D[:P], dmean2D[:P], dsh[:P] if has_sh else None, dcolor[:P] if has_col else None,
                 dopacity[:P].reshape(ctx.opacity_shape), dscale[:P] if has_sr else None, drot[:P] if has_sr else None,
-                dcov3D[:P] if has_cov else None, None)
+                dcov3D[:P] if has_cov else None, None, dsh_rest[:P] if has_rest else None, None)
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, sh_rest=None, raw=False):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, sh_rest, raw)
 
 
 class GaussianRasterizer(torch.nn.Module):
@@ -206,7 +212,12 @@ class GaussianRasterizer(torch.nn.Module):
             z = positions.float() @ vm[:3, 2] + vm[3, 2]
             return z > 0.2
 
-    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, shs_rest=None,
+                raw_parameters=False):
+        """The reference's call (Renderer.py:75-81) plus two keyword extensions for callers that own the model tensors: `shs_rest` -- `shs` is then
+        the DC part (P,1,3) and shs_rest the (P,M-1,3) remainder, the concatenation of Gaussians.get_features is never built; `raw_parameters` --
+        opacities are logits, scales log-scales, rotations unnormalised: the activations of Model.py:45-87 run inside the preprocess kernel and the
+        gradients come back w.r.t. the raw tensors."""
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         if ((scales is None or rotations is None) and cov3D_precomp is None) or ((scales is not None or rotations is not None) and cov3D_precomp is not None):
@@ -214,4 +225,4 @@ class GaussianRasterizer(torch.nn.Module):
         empty = torch.Tensor([])
         return rasterize_gaussians(means3D, means2D, empty if shs is None else shs, empty if colors_precomp is None else colors_precomp, opacities,
                                    empty if scales is None else scales, empty if rotations is None else rotations,
-                                   empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings)
+                                   empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings, shs_rest, raw_parameters)

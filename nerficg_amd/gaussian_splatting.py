@@ -350,9 +350,13 @@ def render_image_training(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np.
     viewspace_points = torch.zeros_like(positions, requires_grad=True) + 0
     viewspace_points.retain_grad()
     rasterizer = GaussianRasterizer(make_raster_settings(cam, c2w, gaussians.active_sh_degree, 1.0, positions.device))
-    image, radii = rasterizer(means3D=positions, means2D=viewspace_points, shs=gaussians.get_features, opacities=gaussians.get_opacities,
-                              scales=gaussians.get_scales, rotations=gaussians.get_rotations)
-    return {'rgb': image, 'viewspace_points': viewspace_points, 'visibility_mask': radii > 0}
+    if gaussians.baked:  # a baked model holds activated values
+        image, radii = rasterizer(means3D=positions, means2D=viewspace_points, shs=gaussians.get_features_dc, shs_rest=gaussians.get_features_rest,
+                                  opacities=gaussians.get_opacities, scales=gaussians.get_scales, rotations=gaussians.get_rotations)
+    else:  # raw parameters straight into the kernels: no get_features concatenation, no separate exp / sigmoid / normalize passes (a25)
+        image, radii = rasterizer(means3D=positions, means2D=viewspace_points, shs=gaussians._features_dc, shs_rest=gaussians._features_rest,
+                                  opacities=gaussians._opacities, scales=gaussians._scales, rotations=gaussians._rotations, raw_parameters=True)
+    return {'rgb': image, 'viewspace_points': viewspace_points, 'visibility_mask': radii > 0, 'radii': radii}
 
 
 @torch.no_grad()

@@ -177,3 +177,38 @@ def test_large_tile_grid_uses_the_fallback_binning():
     # which includes / drops one contribution of at most T/255 -- bounded by 4e-3, and rare
     err = np.abs(color.detach().cpu().numpy() - o_color)
     assert err.max() < 4e-3 and err.mean() < 1e-6 and np.mean(err > 2e-5) < 1e-5
+
+
+def test_raw_parameters_and_split_sh_match_the_activated_call():
+    """GaussianRasterizer(..., shs=dc, shs_rest=rest, raw_parameters=True) -- logits / log-scales / unnormalised quaternions straight from the
+    model, activations of Model.py:45-87 inside the preprocess kernel, no (P,16,3) concatenation -- against the reference-shaped call on the
+    activated tensors (exp / sigmoid / normalize / cat as torch ops with autograd): same picture, same radii up to activation rounding, and the
+    gradients w.r.t. the RAW tensors agree with torch's chain rule through the activations."""
+    from nerficg_amd.diff_gaussian_rasterization import GaussianRasterizer
+    n, w, h = 6000, 176, 112
+    rng = np.random.default_rng(7)
+    sc = scenes.gs_random_scene(n, seed=21, extent=1.0, log_scale_mean=np.log(0.05))
+    cam = scenes.gs_camera(w, h, scenes.orbit_pose(0.4, 0.25, 3.0))
+    rast = GaussianRasterizer(_settings(cam, [0.1, 0.2, 0.3]))
+    raw = dict(means3D=sc['means3D'], dc=sc['shs'][:, :1].copy(), rest=sc['shs'][:, 1:].copy(), logit=np.log(sc['opacities'] / (1 - sc['opacities'])).astype(np.float32)[:, None],
+               log_scale=np.log(sc['scales']).astype(np.float32), quat=(sc['rotations'] * rng.uniform(0.5, 2.0, size=(n, 1))).astype(np.float32))
+    gpix = T(rng.normal(size=(3, h, w)).astype(np.float32))
+    out = {}
+    for mode in ('activated', 'raw'):
+        t = {k: T(v).requires_grad_(True) for k, v in raw.items()}
+        m2d = torch.zeros(n, 3, device=DEV, requires_grad=True)
+        if mode == 'activated':
+            color, radii = rast(means3D=t['means3D'], means2D=m2d, opacities=torch.sigmoid(t['logit']), shs=torch.cat((t['dc'], t['rest']), dim=1),
+                                scales=torch.exp(t['log_scale']), rotations=torch.nn.functional.normalize(t['quat']))
+        else:
+            color, radii = rast(means3D=t['means3D'], means2D=m2d, opacities=t['logit'], shs=t['dc'], shs_rest=t['rest'], scales=t['log_scale'],
+                                rotations=t['quat'], raw_parameters=True)
+        color.backward(gpix)
+        out[mode] = (color.detach(), radii, {k: v.grad for k, v in t.items()}, m2d.grad)
+    a, b = out['activated'], out['raw']
+    assert float((a[1] != b[1]).float().mean()) < 1e-3 and int((b[1] > 0).sum()) > 1000
+    assert float((a[0] - b[0]).abs().max()) <= 5e-5
+    for k in raw:
+        scale = float(a[2][k].abs().max())
+        assert scale > 0 and float((a[2][k] - b[2][k]).abs().max()) <= 2e-3 * scale, (k, float((a[2][k] - b[2][k]).abs().max()) / scale)
+    assert float((a[3] - b[3]).abs().max()) <= 2e-3 * float(a[3].abs().max())

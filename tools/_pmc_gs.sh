@@ -13,7 +13,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1]+'/p*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         n=r['Kernel_Name']
-        for key in ('k_render_bw','k_render','k_bin_scatter','k_bin_count','k_preprocess_bw','k_preprocess','k_radix_scatter'):
+        for key in ('k_render_bw','k_render','k_item_scatter','k_span_scatter','k_preprocess_bw','k_preprocess','k_radix_scatter'):
             if key+'(' in n or n.endswith(key) or ('::'+key+'(') in n:
                 acc[key][r['Counter_Name']].append(float(r['Counter_Value'])); break
 for k,c in acc.items():

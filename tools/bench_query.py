@@ -13,7 +13,8 @@ model, renderer, cam, poses = bench.build_scene(dev)
 for i in range(2):
     renderer.render_image_fused(cam, poses[i])
 torch.cuda.synchronize()
-ms, slots, n, ms_mlp = bench.time_dominant_kernel(renderer, cam, poses[2], reps=reps)
+kt = bench.time_dominant_kernel(renderer, cam, [poses[2]], reps=reps)
+ms, slots, n, ms_mlp = kt['enc_ms'], kt['slots_per_launch'], kt['live_per_launch'], kt['mlp_ms']
 t0 = time.perf_counter()
 for i in range(reps):
     renderer.render_image_fused(cam, poses[2])

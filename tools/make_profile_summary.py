@@ -35,10 +35,23 @@ for tag, name in (('gs_stats', 'r02_gs_kernel_stats.csv'), ('gs6_stats', 'r02_gs
 tstats = sorted(glob.glob(str(RAW / 'train_stats' / '*' / '*kernel_stats.csv')), key=os.path.getmtime)
 if tstats:
     shutil.copy(tstats[-1], OUT / 'r02_train_kernel_stats.csv')
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
+# one accumulator per collection run: pmc_* = tools/bench_query.py (InstantNGP image pipeline), pmcgs_* = tools/bench_gs.py (3DGS frame),
+# pmctr_* = tools/bench_train.py (InstantNGP training iteration).  A kernel that appears in several of them (k_grid_encode runs in the image
+# pipeline with 8 Mi-slot launches and in training with 264 K samples) is reported from the run that is about it.
+by_run = {tag: collections.defaultdict(lambda: collections.defaultdict(list)) for tag in ('pmc_', 'pmcgs_', 'pmctr_')}
 for f in glob.glob(str(RAW / 'pmc*' / '*' / '*counter_collection.csv')):
+    tag = 'pmcgs_' if '/pmcgs_' in f else ('pmctr_' if '/pmctr_' in f else 'pmc_')
     for r in csv.DictReader(open(f)):
-        acc[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+        by_run[tag][short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+home = {'k_grid_encode<1': 'pmc_', 'k_ngp_mlp': 'pmc_', 'k_render_count': 'pmc_', 'k_render_write': 'pmc_', 'k_composite_image': 'pmc_', 'k_ray_sh': 'pmc_',
+        'k_grid_encode<0': 'pmctr_', 'k_nwie': 'pmctr_', 'k_grid_bwd': 'pmctr_', 'k_gb_': 'pmctr_', 'k_march': 'pmctr_', 'k_composite_train': 'pmctr_', 'k_adam': 'pmctr_'}
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+names = set().union(*[set(v) for v in by_run.values()])
+for k in names:
+    pref = next((t for p, t in home.items() if k.startswith(p)), 'pmcgs_')
+    src = by_run[pref] if k in by_run[pref] else next(v for v in by_run.values() if k in v)
+    for n, vals in src[k].items():
+        acc[k][n] = vals
 keep = ('k_grid_encode', 'k_ngp_mlp', 'k_render', 'k_composite_image', 'k_preprocess', 'k_span_', 'k_item_', 'k_depth_keys', 'k_radix_', 'k_scan_tiles', 'k_march_wave',
         'k_grid_bwd', 'k_nwie_', 'k_composite_train')
 lines = ['# rocprofv3 --pmc summary (MI355X, round 2)', '',
