@@ -426,7 +426,7 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=8):
         b.record()
         g.optimizer.step(); g.optimizer.zero_grad()
         if timed:
-            rows[0] += n_union; rows[1] += 1
+            rows[0] += max(n_union, 0); rows[1] += 1
             coll_ms.append((a, b))
 
     for i in range(2):

@@ -157,11 +157,11 @@ def sparse_allreduce_gradients(params: Iterable[torch.nn.Parameter], visible: to
     the rows that are visible on at least one rank.  `visible`: this rank's (P,) boolean mask (radii > 0); rows outside it must have zero
     gradient here (the rasterizer backward guarantees that).  Protocol: one all-reduce (max) of the byte mask -> the same ascending
     union index list on every rank -> the union rows of all tensors packed into ONE flat buffer -> reduce-scatter + all-gather ->
-    unpack.  Payload: n_union x 236 B instead of P x 236 B (59 floats per Gaussian).  Returns n_union."""
+    unpack.  Payload: n_union x 236 B instead of P x 236 B (59 floats per Gaussian).  Returns n_union (-1 in a single-process run)."""
     rank, world = world_info()
     params = [p for p in params if p.grad is not None]
     if world == 1 or not params:
-        return int(visible.sum().item()) if visible is not None else 0
+        return -1  # nothing travels; the count of visible rows would cost a host read per step
     P = visible.shape[0]
     union = visible.to(torch.uint8).contiguous()
     dist.all_reduce(union, op=dist.ReduceOp.MAX)
