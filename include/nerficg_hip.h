@@ -73,6 +73,14 @@ int nrc_raymarching_train_write(const float* rays_o, const float* rays_d, const 
                                 const float* noise, int32_t grid_size, int32_t max_samples, int64_t n_rays,
                                 const int64_t* rays_a, float* xyzs, float* dirs, float* deltas, float* ts,
                                 const void* workspace, nrc_stream_t stream);
+/* Fixed-capacity variant for graph capture (no host read of counter[0] between _count and _write): call between the two passes with
+ * sample buffers of `sample_capacity` rows.  Rays whose segment would cross the capacity keep the samples that fit (n_samples in rays_a is
+ * cut, start_idx <= sample_capacity), rows [min(counter[0], capacity), capacity) are filled with inert samples (position = box centre,
+ * direction +z, delta = t = 0) that no ray references.  counter[0] keeps the uncut total: counter[0] > sample_capacity <=> samples were
+ * dropped.  The reference has no counterpart: it allocates n_rays*max_samples rows and slices by counter[0] on the host
+ * (custom_functions.py:112-119). */
+int nrc_raymarching_train_cap(int64_t n_rays, int64_t sample_capacity, const int32_t* counter, int64_t* rays_a, float* xyzs,
+                              float* dirs, float* deltas, float* ts, nrc_stream_t stream);
 /* binding.cpp:84-106 -> raymarching.cu:407-454.  hits_t (n_total_rays,2) is advanced in place.  Outputs
  * (n_alive,N_samples[,3]) are fully written (zero beyond N_eff_samples), N_eff_samples (n_alive) i32. */
 int nrc_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t, const int64_t* alive_indices,
@@ -342,15 +350,17 @@ int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int3
  *            bias_corrections_dev (optional DEVICE float[2]) overrides the two host values: nrc_adam_prepare writes it once per
  *            group and step as 1 - beta^(host_step - *skipped_steps) and advances *skipped_steps when *found_inf != 0, so the
  *            effective step count stands still on an overflow-skipped step (with apex the scaler does not call step() then)
- *            without a host read of found_inf.  param_f16_out (optional): the updated parameters are also written as fp16 --
+ *            without a host read of found_inf.  With device_step (optional DEVICE int32, apex's capturable mode) host_step / skipped_steps are
+ *            not used: the kernel advances *device_step itself unless *found_inf != 0, so a step recorded in a HIP graph counts on replay.
+ *            lr_dev (optional DEVICE float) overrides lr for the same reason.  param_f16_out (optional): the updated parameters are also written as fp16 --
  *            the compute copy the tinycudann replacement reads (Group 3), which therefore can never go stale after a step.
  * ===================================================================================================== */
 int nrc_adam_prepare(int32_t host_step, float beta1, float beta2, const float* found_inf, int32_t* skipped_steps,
-                     float* bias_corrections, nrc_stream_t stream);
+                     int32_t* device_step, float* bias_corrections, nrc_stream_t stream);
 int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t adam_w_mode, float bias_correction1,
-                  float bias_correction2, const float* bias_corrections_dev, const float* grad_scale, const float* found_inf,
-                  void* param_f16_out, nrc_stream_t stream);
+                  float bias_correction2, const float* bias_corrections_dev, const float* lr_dev, const float* grad_scale,
+                  const float* found_inf, void* param_f16_out, nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 9 -- mean squared distance to the 3 nearest neighbours (3DGS scale initialisation): replaces simple_knn._C.distCUDA2

@@ -94,8 +94,10 @@ def packbits(density_grid, density_threshold: float, density_bitfield) -> None:
 
 
 def raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades: int, scale: float, exp_step_factor: float, noise,
-                      grid_size: int, max_samples: int):
-    """binding.cpp:60-81. Returns [rays_a (N,3) i64, xyzs (M,3), dirs (M,3), deltas (M), ts (M), counter (2) i32], M = counter[0]."""
+                      grid_size: int, max_samples: int, sample_capacity: int | None = None):
+    """binding.cpp:60-81. Returns [rays_a (N,3) i64, xyzs (M,3), dirs (M,3), deltas (M), ts (M), counter (2) i32], M = counter[0].
+    With `sample_capacity` (not in the reference; for graph capture) M = sample_capacity and nothing is read back: rows past counter[0] are
+    inert samples no ray refers to, and counter[0] > sample_capacity tells that rays were cut short (nrc_raymarching_train_cap)."""
     _chk((rays_o, 'rays_o', _f32), (rays_d, 'rays_d', _f32), (hits_t, 'hits_t', _f32),
          (density_bitfield, 'density_bitfield', _u8), (noise, 'noise', _f32))
     lib = _lib.load()
@@ -108,11 +110,20 @@ def raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades: int, s
     args = (_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(hits_t), _lib.ptr(density_bitfield), int(cascades), float(scale),
             float(exp_step_factor), _lib.ptr(noise), int(grid_size), int(max_samples), n)
     _lib.check(lib.nrc_raymarching_train_count(*args, _lib.ptr(rays_a), _lib.ptr(counter), _lib.ptr(ws), st), 'raymarching_train(count)')
-    total = int(counter[0].item())  # same host sync the reference pays when slicing by counter[0] (custom_functions.py:112-119)
+    if sample_capacity is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('raymarching_train: sizing the sample buffers reads counter[0] on the host, which a stream capture cannot do -- '
+                               'pass sample_capacity (InstantNGPRenderer.sample_capacity / nerficg_amd.graphs.instant_ngp_iteration)')
+        total = int(counter[0].item())  # same host sync the reference pays when slicing by counter[0] (custom_functions.py:112-119)
+    else:
+        total = int(sample_capacity)
     xyzs = torch.empty(total, 3, dtype=_f32, device=dev)
     dirs = torch.empty(total, 3, dtype=_f32, device=dev)
     deltas = torch.empty(total, dtype=_f32, device=dev)
     ts = torch.empty(total, dtype=_f32, device=dev)
+    if sample_capacity is not None:
+        _lib.check(lib.nrc_raymarching_train_cap(n, total, _lib.ptr(counter), _lib.ptr(rays_a), _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas),
+                                                 _lib.ptr(ts), st), 'raymarching_train(cap)')
     _lib.check(lib.nrc_raymarching_train_write(*args, _lib.ptr(rays_a), _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas),
                                                _lib.ptr(ts), _lib.ptr(ws) if _PARKED_MARCH else None, st), 'raymarching_train(write)')
     return [rays_a, xyzs, dirs, deltas, ts, counter]

@@ -10,6 +10,9 @@ betas, adam_w_mode, weight_decay, bias_correction).
   advance the step counter (the scaler never calls step()); here `group['step']` is advanced on the host every call and a device counter
   of skipped steps is subtracted inside nrc_adam_prepare, so the bias corrections follow the reference's trajectory without a host sync
   (`effective_step(group)` reads the corrected count back);
+* `capturable=True` (apex's flag for graph capture): group['step'] is a device int32 that the kernel advances itself and the learning rate is
+  read from a device scalar per group, so a step recorded in a HIP graph (nerficg_amd.graphs) keeps counting on replay; after changing
+  group['lr'] (a scheduler) call `sync_hyperparameters()` between replays;
 * a parameter that belongs to a nerficg_amd.tinycudann module gets its fp16 compute copy rewritten by the same kernel and its version
   counter bumped, so the next forward can neither see stale weights nor pay a separate conversion pass.
 Kernel: nerficg_amd/csrc/adam.hip through the C ABI (include/nerficg_hip.h group 8).
@@ -30,18 +33,47 @@ class FusedAdam(torch.optim.Optimizer):
                  capturable=False, master_weights=False, set_grad_none=True):
         if amsgrad:
             raise RuntimeError('FusedAdam does not support the AMSGrad variant.')  # same restriction as apex
-        if capturable or master_weights:
-            raise RuntimeError('nerficg_amd FusedAdam: capturable / master_weights are not implemented')
+        if master_weights:
+            raise RuntimeError('nerficg_amd FusedAdam: master_weights is not implemented')
         defaults = dict(lr=lr, bias_correction=bias_correction, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.adam_w_mode = 1 if adam_w_mode else 0
         self.set_grad_none = set_grad_none
-        self._amp = {}  # group index -> (skipped-step counter i32[1], bias corrections f32[2]) on the device, GradScaler runs only
+        self.capturable = bool(capturable)
+        self._amp = {}  # group index -> (skipped-step counter i32[1], bias corrections f32[2]) on the device
+        self._lr_dev = {}  # capturable: group index -> [device f32[1], the host value it holds]
 
     def effective_step(self, group) -> int:
         """Step count that entered the bias corrections: group['step'] minus the overflow-skipped steps (host read, for tests / logging)."""
+        if torch.is_tensor(group.get('step')):
+            return int(group['step'].item())
         entry = self._amp.get(self.param_groups.index(group))
         return group.get('step', 0) - (int(entry[0].item()) if entry is not None else 0)
+
+    def sync_hyperparameters(self) -> None:
+        """capturable mode: write every group's current 'lr' to the device scalar the (possibly recorded) kernels read."""
+        for gi, group in enumerate(self.param_groups):
+            slot = self._lr_dev.get(gi)
+            if slot is not None and slot[1] != float(group['lr']):
+                slot[0].fill_(float(group['lr']))
+                slot[1] = float(group['lr'])
+
+    def _device_scalars(self, gi, group, device):
+        """(bias corrections f32[2], skipped-step counter, device step or None, device lr or None) of a group."""
+        entry = self._amp.get(gi)
+        if entry is None or entry[0].device != device:
+            entry = self._amp[gi] = (torch.zeros(1, dtype=torch.int32, device=device), torch.ones(2, dtype=torch.float32, device=device))
+        if not self.capturable:
+            return entry[1], entry[0], None, None
+        if not torch.is_tensor(group.get('step')):
+            group['step'] = torch.full((1,), int(group.get('step', 0)), dtype=torch.int32, device=device)
+        slot = self._lr_dev.get(gi)
+        if slot is None or slot[0].device != device:
+            slot = self._lr_dev[gi] = [torch.full((1,), float(group['lr']), dtype=torch.float32, device=device), float(group['lr'])]
+        elif slot[1] != float(group['lr']) and not torch.cuda.is_current_stream_capturing():
+            slot[0].fill_(float(group['lr']))
+            slot[1] = float(group['lr'])
+        return entry[1], entry[0], group['step'], slot[0]
 
     def zero_grad(self, set_to_none: bool | None = None):
         super().zero_grad(set_to_none=self.set_grad_none if set_to_none is None else set_to_none)
@@ -58,22 +90,25 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             if not any(p.grad is not None for p in group['params']):
                 continue
-            # like apex: one step counter per group, advanced whenever the group has gradients
-            group['step'] = group.get('step', 0) + 1
             beta1, beta2 = group['betas']
-            if group['bias_correction']:
-                bc1, bc2 = 1.0 - beta1 ** group['step'], 1.0 - beta2 ** group['step']
+            bc1 = bc2 = 1.0
+            bc_dev = lr_dev = None
+            if self.capturable:
+                device = next(p.device for p in group['params'] if p.grad is not None)
+                bc_dev, skipped, step_dev, lr_dev = self._device_scalars(gi, group, device)
+                _lib.check(lib.nrc_adam_prepare(0, float(beta1), float(beta2), _lib.ptr(found_inf), _lib.ptr(skipped), _lib.ptr(step_dev),
+                                                _lib.ptr(bc_dev), _lib.stream_of(bc_dev)), 'adam_prepare')
+                if not group['bias_correction']:
+                    bc_dev = None
             else:
-                bc1 = bc2 = 1.0
-            bc_dev = None
-            if found_inf is not None and group['bias_correction']:
-                entry = self._amp.get(gi)
-                if entry is None or entry[0].device != found_inf.device:
-                    entry = self._amp[gi] = (torch.zeros(1, dtype=torch.int32, device=found_inf.device),
-                                             torch.ones(2, dtype=torch.float32, device=found_inf.device))
-                bc_dev = entry[1]
-                _lib.check(lib.nrc_adam_prepare(int(group['step']), float(beta1), float(beta2), _lib.ptr(found_inf), _lib.ptr(entry[0]),
-                                                _lib.ptr(bc_dev), _lib.stream_of(found_inf)), 'adam_prepare')
+                # like apex: one step counter per group, advanced whenever the group has gradients
+                group['step'] = group.get('step', 0) + 1
+                if group['bias_correction']:
+                    bc1, bc2 = 1.0 - beta1 ** group['step'], 1.0 - beta2 ** group['step']
+                    if found_inf is not None:
+                        bc_dev, skipped, _, _ = self._device_scalars(gi, group, found_inf.device)
+                        _lib.check(lib.nrc_adam_prepare(int(group['step']), float(beta1), float(beta2), _lib.ptr(found_inf), _lib.ptr(skipped), None,
+                                                        _lib.ptr(bc_dev), _lib.stream_of(found_inf)), 'adam_prepare')
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -94,7 +129,7 @@ class FusedAdam(torch.optim.Optimizer):
                 _lib.check(lib.nrc_adam_step(
                     _lib.ptr(p), _lib.ptr(g), _lib.ptr(state['exp_avg']), _lib.ptr(state['exp_avg_sq']), p.numel(), float(group['lr']), float(beta1),
                     float(beta2), float(group['eps']), float(group['weight_decay']), self.adam_w_mode, float(bc1), float(bc2), _lib.ptr(bc_dev),
-                    _lib.ptr(grad_scale), _lib.ptr(found_inf), _lib.ptr(half), _lib.stream_of(p)), 'adam_step')
+                    _lib.ptr(lr_dev), _lib.ptr(grad_scale), _lib.ptr(found_inf), _lib.ptr(half), _lib.stream_of(p)), 'adam_step')
                 # the kernel writes through a raw pointer: tell autograd (and every version-keyed cache) that p changed
                 torch.autograd.graph.increment_version(p)
                 if owner is not None:

@@ -15,11 +15,18 @@
 namespace {
 
 __global__ void k_adam_prepare(int32_t host_step, float beta1, float beta2, const float* __restrict__ found_inf, int32_t* __restrict__ skipped,
-                               float* __restrict__ bc) {
+                               int32_t* __restrict__ device_step, float* __restrict__ bc) {
     if (threadIdx.x | blockIdx.x) return;
-    int32_t sk = *skipped;
-    if (found_inf && *found_inf != 0.f) *skipped = ++sk;
-    int32_t step = host_step - sk;
+    const bool overflow = found_inf && *found_inf != 0.f;
+    int32_t step;
+    if (device_step) {  // capturable mode: the count itself lives on the device and stands still on a skipped step
+        step = *device_step;
+        if (!overflow) *device_step = ++step;
+    } else {
+        int32_t sk = *skipped;
+        if (overflow) *skipped = ++sk;
+        step = host_step - sk;
+    }
     if (step < 1) step = 1;
     bc[0] = (float)(1.0 - pow((double)beta1, (double)step));
     bc[1] = (float)(1.0 - pow((double)beta2, (double)step));
@@ -28,10 +35,11 @@ __global__ void k_adam_prepare(int32_t host_step, float beta1, float beta2, cons
 template <bool ALIGNED>
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                                               float lr, float beta1, float beta2, float eps, float weight_decay, int adam_w_mode, float bc1, float bc2,
-                                              const float* __restrict__ bc_dev, const float* __restrict__ grad_scale, const float* __restrict__ found_inf,
-                                              __half* __restrict__ p16) {
+                                              const float* __restrict__ bc_dev, const float* __restrict__ lr_dev, const float* __restrict__ grad_scale,
+                                              const float* __restrict__ found_inf, __half* __restrict__ p16) {
     if (found_inf && *found_inf != 0.f) return;  // GradScaler: skip the step, keep the state (and the fp16 copy, which still matches)
     if (bc_dev) { bc1 = bc_dev[0]; bc2 = bc_dev[1]; }
+    if (lr_dev) lr = *lr_dev;
     const float inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= n) return;
@@ -82,18 +90,19 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
 
 extern "C" {
 
-int nrc_adam_prepare(int32_t host_step, float beta1, float beta2, const float* found_inf, int32_t* skipped_steps, float* bias_corrections,
-                     nrc_stream_t stream) {
+int nrc_adam_prepare(int32_t host_step, float beta1, float beta2, const float* found_inf, int32_t* skipped_steps, int32_t* device_step,
+                     float* bias_corrections, nrc_stream_t stream) {
     NRC_ENTER();
-    if (host_step < 1 || !skipped_steps || !bias_corrections) return NRC_ERR_INVALID;
-    hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, host_step, beta1, beta2, found_inf, skipped_steps, bias_corrections);
+    if (!bias_corrections || (!device_step && (host_step < 1 || !skipped_steps))) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, host_step, beta1, beta2, found_inf, skipped_steps, device_step,
+                       bias_corrections);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
 
 int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t adam_w_mode, float bias_correction1, float bias_correction2, const float* bias_corrections_dev,
-                  const float* grad_scale, const float* found_inf, void* param_f16_out, nrc_stream_t stream) {
+                  const float* lr_dev, const float* grad_scale, const float* found_inf, void* param_f16_out, nrc_stream_t stream) {
     NRC_ENTER();
     if (n < 0 || (!bias_corrections_dev && (!(bias_correction1 > 0.f) || !(bias_correction2 > 0.f)))) return NRC_ERR_INVALID;
     if (n == 0) return NRC_OK;
@@ -102,10 +111,10 @@ int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     const dim3 grid((unsigned)nrc_cdiv(nrc_cdiv(n, 4), 256));
     if (aligned)
         hipLaunchKernelGGL(k_adam<true>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
-                           (int)adam_w_mode, bias_correction1, bias_correction2, bias_corrections_dev, grad_scale, found_inf, (__half*)param_f16_out);
+                           (int)adam_w_mode, bias_correction1, bias_correction2, bias_corrections_dev, lr_dev, grad_scale, found_inf, (__half*)param_f16_out);
     else
         hipLaunchKernelGGL(k_adam<false>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
-                           (int)adam_w_mode, bias_correction1, bias_correction2, bias_corrections_dev, grad_scale, found_inf, (__half*)param_f16_out);
+                           (int)adam_w_mode, bias_correction1, bias_correction2, bias_corrections_dev, lr_dev, grad_scale, found_inf, (__half*)param_f16_out);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

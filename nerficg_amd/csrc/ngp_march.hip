@@ -420,6 +420,24 @@ __global__ void __launch_bounds__(256) k_march_expand(const float* __restrict__ 
     }
 }
 
+// Fixed sample capacity (graph capture): cut the ray segments at `cap` rows and make the unused tail inert, all from the device-side total.
+__global__ void __launch_bounds__(256) k_march_cap(int64_t n_rays, int64_t cap, const int32_t* __restrict__ counter, int64_t* __restrict__ rays_a,
+                                                   float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_rays) {
+        const int64_t start = rays_a[3 * i + 1], n = rays_a[3 * i + 2];
+        if (start + n > cap) {
+            rays_a[3 * i + 1] = min(start, cap);
+            rays_a[3 * i + 2] = max(cap - start, (int64_t)0);
+        }
+    }
+    if (i < cap && i >= (int64_t)counter[0]) {
+        xyzs[3 * i] = 0.f; xyzs[3 * i + 1] = 0.f; xyzs[3 * i + 2] = 0.f;
+        dirs[3 * i] = 0.f; dirs[3 * i + 1] = 0.f; dirs[3 * i + 2] = 1.f;
+        deltas[i] = 0.f; ts[i] = 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ ray marching (test)
 __global__ void __launch_bounds__(256) k_march_test(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                     float* __restrict__ hits_t, const int64_t* __restrict__ alive,
@@ -891,6 +909,18 @@ int nrc_raymarching_train_write(const float* rays_o, const float* rays_d, const 
     else
         hipLaunchKernelGGL(k_march_write, dim3(nrc_cdiv(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, hits_t,
                            noise, c, n_rays, rays_a, xyzs, dirs, deltas, ts);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_raymarching_train_cap(int64_t n_rays, int64_t sample_capacity, const int32_t* counter, int64_t* rays_a, float* xyzs, float* dirs,
+                              float* deltas, float* ts, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_rays < 0 || sample_capacity < 0) return NRC_ERR_INVALID;
+    const int64_t n = n_rays > sample_capacity ? n_rays : sample_capacity;
+    if (n == 0) return NRC_OK;
+    if (!counter || (n_rays && !rays_a) || (sample_capacity && (!xyzs || !dirs || !deltas || !ts))) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_march_cap, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n_rays, sample_capacity, counter, rays_a,
+                       xyzs, dirs, deltas, ts);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

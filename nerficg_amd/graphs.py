@@ -1,0 +1,125 @@
+"""nerficg_amd.graphs -- whole optimisation iterations recorded once in a HIP graph and replayed.
+
+The reference's trainers issue an iteration op by op (src/Methods/InstantNGP/Trainer.py:79-94, src/Methods/GaussianSplatting/Trainer.py): on an
+MI355X the InstantNGP iteration is ~1.0 ms of kernels behind ~90 launches and one host read, i.e. bound by the host.  Every entry point of
+the C ABI is asynchronous on the caller's stream, so the whole iteration can be captured -- what has to change is the few places where the
+op-by-op code sizes a buffer from a device count:
+
+  * ray marching: `InstantNGPRenderer.sample_capacity` fixes the number of sample rows (nrc_raymarching_train_cap makes the unused tail
+    inert and cuts rays that would cross it; `counter[0] > capacity` reports the latter);
+  * rasterizer: `diff_gaussian_rasterization.fixed_capacity(instances, spans)` fixes the length of the per-tile lists and of the row-span
+    workspace (the count comes back in `num_rendered`, nothing is read on the host), and the camera travels as a device block;
+  * FusedAdam(capturable=True): step counter and learning rate live on the device.
+
+`GraphedIteration` is the generic piece (static input buffers, eager warm-up calls, capture, replay); `instant_ngp_iteration` and
+`gaussian_splatting_step` build the two iterations of the reference on top of it.  The HIP graph is torch.cuda.CUDAGraph (hipGraph on ROCm):
+kernels launched through ctypes on torch's current stream are recorded like torch's own.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+
+__all__ = ['GraphedIteration', 'instant_ngp_iteration', 'gaussian_splatting_step']
+
+
+class GraphedIteration:
+    """body(**inputs) -> dict of tensors, run on fixed input buffers.  The first `eager_calls` calls execute `body` as it is (they create
+    lazily built state: optimizer moments, GradScaler scalars, compute copies); the next call records it; every later call copies the
+    new inputs into the buffers and replays.  Inputs must keep shape and dtype; outputs are the same tensor objects on every call
+    (overwritten by the next one).  `before_replay()` runs ahead of every replay (host-side hyper-parameter pushes)."""
+
+    def __init__(self, body: Callable[..., dict], example_inputs: dict[str, torch.Tensor], eager_calls: int = 1,
+                 before_replay: Callable[[], None] | None = None) -> None:
+        if eager_calls < 1:
+            raise ValueError('at least one eager call is needed to build lazily created state before the capture')
+        self.body = body
+        self.inputs = {k: v.detach().clone() for k, v in example_inputs.items()}
+        for k, v in self.inputs.items():
+            if not v.is_cuda:
+                raise RuntimeError(f'GraphedIteration: input {k!r} must live on the GPU')
+        self.eager_calls = eager_calls
+        self.before_replay = before_replay
+        self.calls = 0
+        self.graph: torch.cuda.CUDAGraph | None = None
+        self.outputs: dict[str, torch.Tensor] | None = None
+
+    def _load(self, inputs: dict[str, torch.Tensor]) -> None:
+        if inputs.keys() != self.inputs.keys():
+            raise KeyError(f'expected inputs {sorted(self.inputs)}, got {sorted(inputs)}')
+        for k, v in inputs.items():
+            buf = self.inputs[k]
+            if v.shape != buf.shape or v.dtype != buf.dtype:
+                raise RuntimeError(f'input {k!r}: {tuple(v.shape)} {v.dtype} does not match the recorded {tuple(buf.shape)} {buf.dtype}')
+            if v.data_ptr() != buf.data_ptr():
+                buf.copy_(v, non_blocking=True)
+
+    def __call__(self, **inputs: torch.Tensor) -> dict[str, torch.Tensor]:
+        self._load(inputs)
+        self.calls += 1
+        if self.calls <= self.eager_calls:
+            return self.body(**self.inputs)
+        if self.graph is None:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):   # records, does not execute
+                self.outputs = self.body(**self.inputs)
+        if self.before_replay is not None:
+            self.before_replay()
+        self.graph.replay()
+        return self.outputs
+
+    @property
+    def recorded(self) -> bool:
+        return self.graph is not None
+
+
+def instant_ngp_iteration(model, renderer, optimizer, scaler, camera, n_rays: int, sample_capacity: int, loss_fn: Callable | None = None,
+                          with_alpha: bool = False, ray_pool: dict[str, torch.Tensor] | None = None, eager_calls: int = 1) -> GraphedIteration:
+    """The training iteration of src/Methods/InstantNGP/Trainer.py:79-94 for batches of `n_rays` rays as a GraphedIteration:
+    call(origin=(n,3), view_direction=(n,3), rgb=(n,3)[, alpha=(n,)]) -> {'loss', 'rm_samples', 'sample_overflow'}; with
+    `ray_pool` = {'origin', 'view_direction', 'rgb'[, 'alpha']} (all rays of the training set resident on the GPU, like the reference's
+    RayPoolSampler) the call is call(ids=(n,) int64) and the gather of the batch is part of the recording.
+    loss_fn(outputs, rgb, alpha | None, bg) defaults to InstantNGPLoss (MSE on the colours over the random background + 0.5e-6 * mean squared
+    MLP weight).  `sample_capacity` rows are marched / queried per iteration whatever the occupancy; 'sample_overflow' (device, > 0 when rays
+    were cut) is for the caller to look at every now and then -- e.g. where the reference reads rm_samples to adapt its batch size.
+    The optimizer must be FusedAdam(capturable=True)."""
+    if not getattr(optimizer, 'capturable', False):
+        raise RuntimeError('instant_ngp_iteration: build the optimizer as FusedAdam(..., capturable=True)')
+    dev = model.center.device
+
+    def default_loss(out, rgb, alpha, bg):
+        target = rgb if alpha is None else rgb * alpha[:, None] + (1 - alpha)[:, None] * bg
+        return torch.nn.functional.mse_loss(out['rgb'].float(), target) + 0.5e-6 * model.weight_decay_mlp()
+
+    criterion = loss_fn or default_loss
+
+    def iteration(origin, view_direction, rgb, alpha=None):
+        renderer.sample_capacity = int(sample_capacity)
+        try:
+            with torch.amp.autocast('cuda'):
+                bg = torch.rand(3, device=dev)
+                out = renderer.render_rays(origin, view_direction, camera, train_mode=True, custom_bg_color=bg)
+                loss = criterion(out, rgb, alpha, bg)
+            scaler.scale(loss).backward()
+            scaler.step(optimizer)
+            scaler.update()
+            optimizer.zero_grad()
+        finally:
+            renderer.sample_capacity = None
+        marched = out['rm_samples']
+        return {'loss': loss.detach(), 'rm_samples': marched, 'sample_overflow': (marched - int(sample_capacity)).clamp_(min=0)}
+
+    if ray_pool is not None:
+        pool = {k: v.contiguous() for k, v in ray_pool.items()}
+
+        def body(ids):
+            return iteration(**{k: v[ids] for k, v in pool.items()})
+        example = {'ids': torch.zeros(n_rays, dtype=torch.int64, device=dev)}
+    else:
+        body = iteration
+        example = {'origin': torch.zeros(n_rays, 3, device=dev), 'view_direction': torch.zeros(n_rays, 3, device=dev), 'rgb': torch.zeros(n_rays, 3, device=dev)}
+        example['view_direction'][:, 2] = 1.0
+        if with_alpha:
+            example['alpha'] = torch.zeros(n_rays, device=dev)
+    return GraphedIteration(body, example, eager_calls=eager_calls, before_replay=optimizer.sync_hyperparameters)

@@ -126,6 +126,9 @@ class InstantNGPRenderer:
         # fused image path: the count pass parks the samples in a max_samples-row arena per tile (2.6 GB at 800x800) and the write pass
         # copies them instead of marching every ray twice; False = second march, no arena
         self.provisional_march = True
+        # training batches: None = sample buffers sized from the marched count (one host read per iteration, like the reference); an int = fixed
+        # number of sample rows and no host read (nerficg_amd.graphs captures the iteration in a HIP graph with this set)
+        self.sample_capacity: int | None = None
 
     # ---------------------------------------------------------------- the two networks
     def _box(self):
@@ -174,7 +177,7 @@ class InstantNGPRenderer:
     def _march(self, o, d, span, step_growth, jitter):
         m = self.model
         return VolumeRenderingCuda.raymarching_train(o, d, span, m.occupancy_bitfield, m.cascades, m.SCALE, step_growth, jitter, m.RESOLUTION,
-                                                     self.MAX_SAMPLES)
+                                                     self.MAX_SAMPLES, sample_capacity=self.sample_capacity)
 
     def _render_training_batch(self, o, d, span, bg, step_growth, noise):
         jitter = torch.rand(o.shape[0], device=o.device) if noise is None else noise.to(torch.float32).contiguous()

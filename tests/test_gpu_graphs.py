@@ -1,0 +1,161 @@
+"""GPU: optimisation iterations recorded in a HIP graph (nerficg_amd.graphs) against the same iterations issued op by op.
+
+The reference has no graph path: what is pinned here is that the recorded iteration IS the reference's iteration (Trainer.py:79-94) -- same
+parameters after the same batches -- and that the fixed-capacity sample buffers behave as documented (nrc_raymarching_train_cap).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import scenes
+from tests.test_gpu_render_parity import make_camera, make_model
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _rays(w=64, h=64):
+    from nerficg_amd.raygen import generate_rays
+    cam = make_camera(w, h)
+    rays = generate_rays(w, h, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y, scenes.orbit_pose(0.5, 0.3, scenes.LEGO_RADIUS), want_direction=False)
+    return cam, rays['origin'].contiguous(), rays['view_direction'].contiguous()
+
+
+def _march_inputs(n_cascades=1):
+    from nerficg_amd import VolumeRenderingV2 as vr
+    cam, o, d = _rays()
+    bits = torch.from_numpy(scenes.sphere_bitfield(128, 0.5, 0.35, n_cascades)).to(DEV)
+    o = o - 0.0
+    span = vr.ray_aabb_intersect(o, d, torch.zeros(1, 3, device=DEV), torch.full((1, 3), 0.5, device=DEV), 1)[1][:, 0].contiguous()
+    span[:, 0].clamp_(min=0.2)
+    noise = torch.rand(o.shape[0], device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    return vr, (o, d, span, bits, n_cascades, 0.5, 0.0, noise, 128, 1024)
+
+
+@pytest.mark.parametrize('slack', [0, 1, 5000])
+def test_fixed_capacity_march_equals_the_sized_march_plus_an_inert_tail(slack):
+    vr, args = _march_inputs()
+    rays_a, xyzs, dirs, deltas, ts, counter = vr.raymarching_train(*args)
+    total = int(counter[0])
+    assert total > 10000
+    cap = total + slack
+    rays_a2, xyzs2, dirs2, deltas2, ts2, counter2 = vr.raymarching_train(*args, sample_capacity=cap)
+    assert xyzs2.shape == (cap, 3) and ts2.shape == (cap,)
+    assert torch.equal(counter, counter2) and torch.equal(rays_a, rays_a2)
+    for a, b in ((xyzs, xyzs2), (dirs, dirs2), (deltas, deltas2), (ts, ts2)):
+        assert torch.equal(a, b[:total])
+    assert not xyzs2[total:].any() and not deltas2[total:].any() and not ts2[total:].any()
+    if slack:
+        assert torch.equal(dirs2[total:], torch.tensor([0.0, 0.0, 1.0], device=DEV).expand(slack, 3))
+
+
+def test_fixed_capacity_march_cuts_the_rays_that_do_not_fit():
+    vr, args = _march_inputs()
+    rays_a, xyzs, _, _, ts, counter = vr.raymarching_train(*args)
+    total = int(counter[0])
+    cap = total // 2 + 7
+    rays_a2, xyzs2, _, _, ts2, counter2 = vr.raymarching_train(*args, sample_capacity=cap)
+    assert int(counter2[0]) == total                                  # the uncut total: > capacity tells the caller that samples were dropped
+    assert torch.equal(xyzs[:cap], xyzs2) and torch.equal(ts[:cap], ts2)
+    start, n = rays_a[:, 1], rays_a[:, 2]
+    start2, n2 = rays_a2[:, 1], rays_a2[:, 2]
+    assert torch.equal(rays_a[:, 0], rays_a2[:, 0])
+    assert torch.equal(n2, (torch.minimum(start + n, torch.tensor(cap, device=DEV)) - torch.minimum(start, torch.tensor(cap, device=DEV))))
+    assert torch.equal(start2, torch.minimum(start, torch.tensor(cap, device=DEV)))
+    assert int(n2.sum()) == cap
+
+
+def _train_pair(seed):
+    from nerficg_amd.apex_optimizers import FusedAdam
+    from nerficg_amd.instant_ngp import InstantNGPRenderer
+    model = make_model(seed=seed, table_amp=1e-4)
+    renderer = InstantNGPRenderer(model)
+    return model, renderer, torch.amp.GradScaler(init_scale=128.0, growth_interval=10 ** 6)
+
+
+def test_recorded_iteration_follows_the_op_by_op_iteration():
+    """Six iterations on six different batches, background and march jitter given as inputs so that both runs see the same numbers: the
+    replayed graph must leave the same parameters as the op-by-op loop (f32 atomics in the hash-grid backward: not bit-equal)."""
+    from nerficg_amd.apex_optimizers import FusedAdam
+    from nerficg_amd.graphs import GraphedIteration
+    cam, o, d = _rays()
+    n = 2048
+    g = torch.Generator(device=DEV).manual_seed(11)
+    batches = []
+    for _ in range(6):
+        ids = torch.randint(0, o.shape[0], (n,), device=DEV, generator=g)
+        batches.append(dict(origin=o[ids].contiguous(), view_direction=d[ids].contiguous(), rgb=torch.rand(n, 3, device=DEV, generator=g),
+                            bg=torch.rand(3, device=DEV, generator=g), noise=torch.rand(n, device=DEV, generator=g)))
+    results = {}
+    for mode in ('eager', 'graph'):
+        model, renderer, scaler = _train_pair(seed=9)
+        opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=(mode == 'graph'))
+        renderer.sample_capacity = 400_000 if mode == 'graph' else None
+
+        def body(origin, view_direction, rgb, bg, noise):
+            with torch.amp.autocast('cuda'):
+                out = renderer.render_rays(origin, view_direction, cam, train_mode=True, custom_bg_color=bg, noise=noise)
+                loss = torch.nn.functional.mse_loss(out['rgb'].float(), rgb) + 0.5e-6 * model.weight_decay_mlp()
+            scaler.scale(loss).backward()
+            scaler.step(opt); scaler.update(); opt.zero_grad()
+            return {'loss': loss.detach(), 'rm_samples': out['rm_samples']}
+
+        step = GraphedIteration(body, batches[0]) if mode == 'graph' else body
+        losses, marched = [], []
+        for b in batches:
+            out = step(**b)
+            losses.append(float(out['loss'])); marched.append(int(out['rm_samples']))
+        if mode == 'graph':
+            assert step.recorded and step.calls == 6
+            assert opt.effective_step(opt.param_groups[0]) == 6
+        results[mode] = (losses, marched, [p.detach().clone() for p in model.parameters()],
+                         [net._half_params().clone() for net in (model.encoding_xyz, model.color_mlp_with_encoding)])
+    (l0, m0, p0, h0), (l1, m1, p1, h1) = results['eager'], results['graph']
+    assert m0 == m1 and max(m0) < 400_000, (m0, m1)
+    np.testing.assert_allclose(l1, l0, rtol=2e-3)
+    for a, b in zip(p0, p1):
+        changed = (a - b).abs() > 1e-4 + 1e-2 * a.abs()
+        assert float(changed.float().mean()) < 1e-3, float(changed.float().mean())   # Adam's 1/sqrt(v) amplifies the atomics' rounding on tiny gradients
+    for p, h in zip(p1, h1):
+        assert torch.equal(h, p.half())  # the fp16 compute copy was written by the replayed Adam kernels
+
+
+def test_instant_ngp_iteration_trains_and_reports_overflow():
+    from nerficg_amd.apex_optimizers import FusedAdam
+    from nerficg_amd.graphs import instant_ngp_iteration
+    cam, o, d = _rays()
+    n = 2048
+    model, renderer, scaler = _train_pair(seed=4)
+    opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
+    step = instant_ngp_iteration(model, renderer, opt, scaler, cam, n_rays=n, sample_capacity=400_000)
+    target = torch.tensor([0.8, 0.3, 0.1], device=DEV).expand(n, 3).contiguous()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    losses = []
+    for it in range(40):
+        ids = torch.randint(0, o.shape[0], (n,), device=DEV, generator=g)
+        out = step(origin=o[ids], view_direction=d[ids], rgb=target)
+        losses.append(float(out['loss']))
+        assert int(out['sample_overflow']) == 0 and 0 < int(out['rm_samples']) < 400_000
+    assert step.recorded and np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses
+    assert renderer.sample_capacity is None   # only set while the iteration runs
+    # a learning-rate change reaches the recorded kernels through the device scalar
+    before = [p.detach().clone() for p in model.parameters()]
+    opt.param_groups[0]['lr'] = 0.0
+    step(origin=o[:n].contiguous(), view_direction=d[:n].contiguous(), rgb=target)
+    for a, b in zip(before, model.parameters()):
+        assert torch.equal(a, b.detach())
+    # too small a capacity: rays are cut, nothing is written out of bounds, the count says so
+    small = instant_ngp_iteration(model, renderer, opt, scaler, cam, n_rays=n, sample_capacity=20_000)
+    for it in range(3):
+        out = small(origin=o[:n].contiguous(), view_direction=d[:n].contiguous(), rgb=target)
+        assert int(out['sample_overflow']) > 0 and np.isfinite(float(out['loss']))
+
+
+def test_capture_without_a_sample_capacity_is_refused():
+    from nerficg_amd import VolumeRenderingV2 as vr
+    _, args = _march_inputs()
+    vr.raymarching_train(*args)
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match='sample_capacity'):
+        with torch.cuda.graph(g):
+            vr.raymarching_train(*args)
