@@ -440,9 +440,12 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=8):
     target = torch.rand(3, GS_H, GS_W, device=device, generator=torch.Generator(device=device).manual_seed(1))
     rows, coll_ms = [0, 0], []
 
+    # poses as device tensors: make_raster_settings assembles the camera on the GPU, the rasterizer reads it from a device block
+    pose_of = lambda i: torch.from_numpy(np.asarray(scenes.orbit_pose(0.8 + 0.7 * (i * world + rank), 0.35, 4.5), dtype=np.float32)).to(device)  # noqa: E731
+    poses_dev = [pose_of(i) for i in range(2 + iters)]
+
     def step(i, timed):
-        pose = scenes.orbit_pose(0.8 + 0.7 * (i * world + rank), 0.35, 4.5)
-        out = render_image_training(g, cam, pose)
+        out = render_image_training(g, cam, poses_dev[i])
         training_loss(out['rgb'], target).backward()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -472,7 +475,28 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=8):
     nbytes = int(union_rows * 59 * 4)
     if drift != 0.0:
         raise RuntimeError(f'3DGS view-parallel replicas drifted: {drift:.3e}')
-    return {'ms_per_step': round(dt * 1e3, 3), 'views_per_step': world, 'gaussians': n_gaussians, 'msplats_per_s': round(world * n_gaussians / dt / 1e6, 1),
+    graphed = None
+    if world == 1:
+        # the same step (plus the densification statistics of the reference's trainer) recorded in a HIP graph: fixed list / span capacities
+        # from the counts of an op-by-op frame, pose and target as device inputs, Adam's step counters and learning rates on the device
+        from nerficg_amd import diff_gaussian_rasterization as dgr
+        from nerficg_amd.graphs import gaussian_splatting_step
+        n_inst, n_spans = dgr.last_counts().tolist()
+        caps = (int(1.3 * n_inst), int(1.3 * n_spans) + 65536)
+        g.optimizer.capturable = True
+        gstep = gaussian_splatting_step(g, cam, instance_capacity=caps[0], span_capacity=caps[1])
+        worst = torch.zeros(2, dtype=torch.int64, device=device)
+        for i in range(3):   # op by op, recording + first replay, second replay (and the first use of every torch kernel of the loop below)
+            worst = torch.maximum(worst, gstep(c2w=poses_dev[i % 2], target=target)['counts'])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(iters):
+            worst = torch.maximum(worst, gstep(c2w=poses_dev[2 + i], target=target)['counts'])
+        torch.cuda.synchronize(); dt_g = (time.perf_counter() - t0) / iters
+        worst = worst.tolist()
+        graphed = {'ms_per_step': round(dt_g * 1e3, 3), 'msplats_per_s': round(n_gaussians / dt_g / 1e6, 1), 'instance_capacity': caps[0],
+                   'span_capacity': caps[1], 'max_instances_seen': worst[0], 'max_spans_seen': worst[1],
+                   'dropped': bool(worst[0] > caps[0] or worst[1] > caps[1]), 'includes': 'densification statistics (nrc_gs_densify_stats)'}
+    return {'hip_graph': graphed, 'ms_per_step': round(dt * 1e3, 3), 'views_per_step': world, 'gaussians': n_gaussians, 'msplats_per_s': round(world * n_gaussians / dt / 1e6, 1),
             'collective': f'max-reduce of the visibility mask + reduction of the union rows over {dist.get_backend()}' if world > 1 else None,
             'union_rows_per_step': round(union_rows), 'bytes_reduced_per_step': nbytes if world > 1 else 0, 'collective_ms': round(coll, 3) if world > 1 else None,
             'bus_GBps_per_gpu': round(2 * (world - 1) / world * nbytes / (coll * 1e-3) / 1e9, 1) if world > 1 and coll > 0 else None, 'replica_drift': drift}

@@ -218,6 +218,12 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
  *                       to size keys / point_list (the reference's rasterizer pays the same device->host read); [1] = number of
  *                       (tile row, Gaussian) span records the binning needed: if it exceeds the span capacity the workspace was
  *                       sized for, [0] is not valid and the call is repeated with a workspace for at least [1] spans.
+ *                       instance_capacity > 0 (fixed-capacity mode, for graph capture): point_list has that many entries and nothing
+ *                       needs to be read back -- tile ranges are cut at the capacity, the instances that would land behind it are
+ *                       dropped (the farthest of the last tiles), and [0] > instance_capacity / [1] > span capacity report it.
+ *   camera_dev        : optional DEVICE float[38] = viewmatrix (16), projmatrix (16), campos (3), bg (3).  When given, the kernels read the
+ *                       pose from it and the host arrays (viewmatrix, projmatrix, campos, bg) may be NULL: a camera that lives in device
+ *                       tensors (GaussianRasterizationSettings) never crosses to the host, and a recorded graph follows its updates.
  *   nrc_gs_bin_render : stages 3-5 -> out_color (3,H,W) = C + T * bg, n_contrib, final_T.
  *   nrc_gs_backward   : dL_dpix (3,H,W) -> every gradient (all fully written; dL_dmean2D (P,3) is the screen-space gradient
  *                       consumed by densification, src/Methods/GaussianSplatting/Model.py:258).
@@ -229,18 +235,19 @@ int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H, int64_t span_capa
 int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs,
                       const float* shs_rest, int32_t raw_parameters, const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                      const float* campos, float tan_fovx, float tan_fovy, int32_t* radii, float* depths, float* points_xy,
-                      float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched,
+                      const float* campos, const float* camera_dev, float tan_fovx, float tan_fovy, int32_t* radii, float* depths,
+                      float* points_xy, float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched,
                       uint32_t* tile_counts, uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t span_capacity,
-                      float* splat_records, int64_t* num_rendered, nrc_stream_t stream);
-int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg, const int32_t* radii, const float* depths,
-                      const float* points_xy, const float* conic_opacity, const float* rgb, const uint32_t* ranges,
-                      uint32_t* tile_fill, const uint32_t* bin_hist, int64_t span_capacity, uint64_t* keys, int32_t* point_list,
-                      const float* splat_records, float* out_color, uint32_t* n_contrib, float* final_T, nrc_stream_t stream);
+                      int64_t instance_capacity, float* splat_records, int64_t* num_rendered, nrc_stream_t stream);
+int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg, const float* camera_dev, const int32_t* radii,
+                      const float* depths, const float* points_xy, const float* conic_opacity, const float* rgb,
+                      const uint32_t* ranges, uint32_t* tile_fill, const uint32_t* bin_hist, int64_t span_capacity,
+                      int64_t instance_capacity, uint64_t* keys, int32_t* point_list, const float* splat_records, float* out_color,
+                      uint32_t* n_contrib, float* final_T, nrc_stream_t stream);
 int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg, const float* means3D, const float* shs,
                     const float* shs_rest, int32_t raw_parameters, const float* opacities, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
-                    float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
+                    const float* camera_dev, float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
                     const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list,
                     const uint32_t* ranges, const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib,
                     const float* final_T, const float* dL_dpix,

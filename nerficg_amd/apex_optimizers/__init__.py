@@ -102,6 +102,8 @@ class FusedAdam(torch.optim.Optimizer):
                     bc_dev = None
             else:
                 # like apex: one step counter per group, advanced whenever the group has gradients
+                if torch.is_tensor(group.get('step')):  # the group was stepped in capturable mode before
+                    group['step'] = int(group['step'].item())
                 group['step'] = group.get('step', 0) + 1
                 if group['bias_correction']:
                     bc1, bc2 = 1.0 - beta1 ** group['step'], 1.0 - beta2 ** group['step']

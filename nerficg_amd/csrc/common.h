@@ -22,6 +22,28 @@ void nrc_set_last_hip_error(int e);  // lib_info.hip
 
 static inline int64_t nrc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Clearing device memory with a kernel of our own instead of hipMemsetAsync.  Outside a capture the two cost the same (ROCm runs a fill
+// kernel for the memset); inside a stream capture the memset becomes a graph memset node, and replays of graphs holding such nodes were
+// measured to finish AFTER the launch stream considered them done (an event recorded behind the replay fires early; only a device-wide
+// synchronize waits for them), so back-to-back replays raced with their own predecessor.  Kernel nodes keep the stream order.
+// `p` and `bytes` must be multiples of 4 (every caller clears 32-bit or wider elements).
+static __global__ void __launch_bounds__(256) nrc_k_zero_words(uint32_t* __restrict__ p, size_t n_words) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n_vec = ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) ? n_words / 4 : 0;
+    if (i < n_vec) reinterpret_cast<uint4*>(p)[i] = make_uint4(0u, 0u, 0u, 0u);
+    const size_t tail = n_words - 4 * n_vec;   // at most 3 words when the pointer is 16-byte aligned, everything otherwise
+    for (size_t k = i; k < tail; k += (size_t)gridDim.x * 256) p[4 * n_vec + k] = 0u;
+}
+static inline hipError_t nrc_zero_async(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if (!p || (bytes & 3u) || (reinterpret_cast<uintptr_t>(p) & 3u)) return hipErrorInvalidValue;
+    const size_t n_words = bytes / 4;
+    const bool aligned = (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+    const size_t threads = aligned ? (n_words / 4 > 0 ? n_words / 4 : 1) : (n_words < ((size_t)1 << 22) ? n_words : ((size_t)1 << 22));
+    hipLaunchKernelGGL(nrc_k_zero_words, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (uint32_t*)p, n_words);
+    return hipGetLastError();
+}
+
 // ---- wave-level primitives (64-wide) ---------------------------------------------------------
 __device__ __forceinline__ int nrc_lane() { return __lane_id(); }
 

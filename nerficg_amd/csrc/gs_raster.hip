@@ -38,6 +38,21 @@ struct GsCam {
     int raw;  // 1: opacities are logits, scales log-scales, rotations unnormalised (the activations of Gaussians.get_* run inside the kernels)
 };
 
+// Pose-dependent part of the camera from device memory (graph capture, cameras that never visit the host): 38 floats = view (16, column-major
+// as in the settings = w2c^T row-major), proj (16), campos (3), background (3).  NULL: the values of the kernel argument stand.  The address
+// is wave-uniform and the block read-only, so these are scalar loads like the kernel-argument loads they replace.
+#define GS_POSE_FLOATS 38
+__device__ __forceinline__ GsCam cam_with_pose(const GsCam& arg, const float* __restrict__ pose) {
+    GsCam c = arg;
+    if (pose) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) { c.view[k] = pose[k]; c.proj[k] = pose[16 + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) c.campos[k] = pose[32 + k];
+    }
+    return c;
+}
+
 // activations of GaussianSplatting/Model.py:45-87 for the raw-parameter mode: exp (scales), x / max(|x|, 1e-12) (rotations), sigmoid (opacities)
 __device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ void act_scales(const float* raw, int on, float* s) {
@@ -277,7 +292,7 @@ __device__ __forceinline__ void sh_rows_copy(float* s_sh, int pitch, int row_len
 // loads -- a lane walking its own 192-byte row touches 48 cache lines per wave instruction (same staging as k_preprocess_bw).
 #define PRE_BLOCK 128
 #define PRE_MAXM 16
-__global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam, const float* __restrict__ means3D, const float* __restrict__ shs,
+__global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam_arg, const float* __restrict__ pose, const float* __restrict__ means3D, const float* __restrict__ shs,
                                                           const float* __restrict__ shs_rest,
                                                           const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                                                           const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -287,6 +302,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam, cons
                                                           float* __restrict__ cov3D, uint32_t* __restrict__ tiles_touched,
                                                           uint32_t* __restrict__ tile_counts, float4* __restrict__ splat) {
     __shared__ __attribute__((aligned(16))) float s_sh[PRE_BLOCK * (3 * PRE_MAXM + 1)];
+    const GsCam cam = cam_with_pose(cam_arg, pose);
     const int first = blockIdx.x * PRE_BLOCK, i = first + threadIdx.x;
     const int row_len = 3 * cam.M, pitch = row_len + 1;
     if (shs) {
@@ -668,7 +684,7 @@ __global__ void __launch_bounds__(1024) k_item_scan(int gx, int item_cap, const 
 __global__ void __launch_bounds__(64) k_item_scatter(int gx, int gy, const uint32_t* __restrict__ rowtot, const uint32_t* __restrict__ roff,
                                                      const uint32_t* __restrict__ nitems, const uint32_t* __restrict__ ioff, const uint32_t* __restrict__ meta_items,
                                                      const uint2* __restrict__ spans, const uint32_t* __restrict__ cnt2, const uint32_t* __restrict__ ranges,
-                                                     int32_t* __restrict__ point_list) {
+                                                     uint32_t list_cap, int32_t* __restrict__ point_list) {
     __shared__ uint32_t bits[SPAN_DIM_MAX][2];
     __shared__ int ids[64];
     const int lane = threadIdx.x;
@@ -701,7 +717,8 @@ __global__ void __launch_bounds__(64) k_item_scatter(int gx, int gy, const uint3
                 while (lo | hi) {
                     int src;
                     if (lo) { src = __builtin_ctz(lo); lo &= lo - 1u; } else { src = 32 + __builtin_ctz(hi); hi &= hi - 1u; }
-                    point_list[cur[k]++] = ids[src];
+                    if (cur[k] < list_cap) point_list[cur[k]] = ids[src];
+                    cur[k]++;
                 }
             }
             __syncthreads();
@@ -711,7 +728,9 @@ __global__ void __launch_bounds__(64) k_item_scatter(int gx, int gy, const uint3
 }
 
 // ------------------------------------------------------------------------------------------------ 2. tile ranges
-__global__ void __launch_bounds__(1024) k_scan_tiles(const uint32_t* __restrict__ counts, int n, uint32_t* __restrict__ ranges,
+// `cap`: length of the instance list the caller allocated (fixed-capacity mode; 0xffffffff otherwise): ranges are cut there, the scatter drops
+// what would land behind it, num_rendered keeps the uncut total (> cap <=> instances were dropped).
+__global__ void __launch_bounds__(1024) k_scan_tiles(const uint32_t* __restrict__ counts, int n, uint32_t cap, uint32_t* __restrict__ ranges,
                                                      uint32_t* __restrict__ fill, int64_t* __restrict__ num_rendered) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
@@ -731,7 +750,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(const uint32_t* __restrict_
         __syncthreads();
         uint32_t off = carry_s;
         for (int w = 0; w < wave; w++) off += wave_tot[w];
-        if (i < n) { ranges[2 * i] = off + incl - v; ranges[2 * i + 1] = off + incl; fill[i] = 0u; }
+        if (i < n) { ranges[2 * i] = min(off + incl - v, cap); ranges[2 * i + 1] = min(off + incl, cap); fill[i] = 0u; }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = off + incl;
         __syncthreads();
@@ -963,8 +982,10 @@ __device__ __forceinline__ int block_lists(StageLds& st, unsigned flags, int* n_
 
 __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
                                                 const float4* __restrict__ splat, const uint32_t* __restrict__ tile_order, float bg0, float bg1, float bg2,
-                                                float* __restrict__ out_color, uint32_t* __restrict__ n_contrib, float* __restrict__ final_T) {
+                                                const float* __restrict__ pose, float* __restrict__ out_color, uint32_t* __restrict__ n_contrib,
+                                                float* __restrict__ final_T) {
     __shared__ StageLds st;
+    if (pose) { bg0 = pose[35]; bg1 = pose[36]; bg2 = pose[37]; }
     const int tile = (int)tile_order[blockIdx.x];  // longest lists first
     const int tile_x = tile % cam.gx, tile_y = tile / cam.gx;
     const int px = tile_x * TILE + tile_px(threadIdx.x), py = tile_y * TILE + tile_py(threadIdx.x);
@@ -1046,12 +1067,13 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
 }
 __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
                                                    const float4* __restrict__ splat, const uint32_t* __restrict__ tile_order, float bg0, float bg1, float bg2,
-                                                   const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
+                                                   const float* __restrict__ pose, const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
                                                    const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D,
                                                    float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor) {
     __shared__ StageLds st;
     __shared__ float s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 16 blocks, flushed once per batch
     __shared__ int s_blast[N_BLOCKS];
+    if (pose) { bg0 = pose[35]; bg1 = pose[36]; bg2 = pose[37]; }
     const int tile = (int)tile_order[blockIdx.x];  // longest lists first
     const int tile_x = tile % cam.gx, tile_y = tile / cam.gx;
     const int lane = threadIdx.x & 63;
@@ -1352,7 +1374,7 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
 // row is written by this kernel, zeros for culled Gaussians, so the caller does not clear 300 B per Gaussian beforehand.
 #define PBW_BLOCK 128
 #define PBW_MAXM 16
-__global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam, const float* __restrict__ means3D, const float* __restrict__ shs,
+__global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_arg, const float* __restrict__ pose, const float* __restrict__ means3D, const float* __restrict__ shs,
                                                              const float* __restrict__ shs_rest, const float* __restrict__ opacities, int use_sh, const float* __restrict__ scales, const float* __restrict__ rotations,
                                                              int use_scale_rot, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
                                                              const float* __restrict__ cov3D, const float* __restrict__ dL_dmean2D,
@@ -1361,6 +1383,7 @@ __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam, c
                                                              float* __restrict__ dL_dsh_rest, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
                                                              float* __restrict__ dL_dopacity) {
     __shared__ float s_sh[PBW_BLOCK * (3 * PBW_MAXM + 1)];
+    const GsCam cam = cam_with_pose(cam_arg, pose);
     const int first = blockIdx.x * PBW_BLOCK, i = first + threadIdx.x;
     const int row_len = 3 * cam.M, pitch = row_len + 1;  // +1: rows start in different LDS banks
     const int count = min(PBW_BLOCK, P - first);
@@ -1427,11 +1450,12 @@ BinWs gs_bin_ws(uint32_t* base, int P, int gx, int gy, int64_t cap) {
     return w;
 }
 
-int make_cam(GsCam& cam, int W, int H, int D, int M, const float* view, const float* proj, const float* campos, float tanx, float tany,
-             float scale_modifier, int raw) {
-    if (W < 1 || H < 1 || D < 0 || D > 3 || !view || !proj || !campos || !(tanx > 0.f) || !(tany > 0.f)) return NRC_ERR_INVALID;
-    for (int k = 0; k < 16; k++) { cam.view[k] = view[k]; cam.proj[k] = proj[k]; }
-    for (int k = 0; k < 3; k++) cam.campos[k] = campos[k];
+int make_cam(GsCam& cam, int W, int H, int D, int M, const float* view, const float* proj, const float* campos, const float* camera_dev, float tanx,
+             float tany, float scale_modifier, int raw) {
+    if (W < 1 || H < 1 || D < 0 || D > 3 || !(tanx > 0.f) || !(tany > 0.f)) return NRC_ERR_INVALID;
+    if (!camera_dev && (!view || !proj || !campos)) return NRC_ERR_INVALID;  // the pose comes from the host arrays or from the device block
+    for (int k = 0; k < 16; k++) { cam.view[k] = camera_dev ? 0.f : view[k]; cam.proj[k] = camera_dev ? 0.f : proj[k]; }
+    for (int k = 0; k < 3; k++) cam.campos[k] = camera_dev ? 0.f : campos[k];
     cam.tan_fovx = tanx; cam.tan_fovy = tany;
     cam.focal_x = W / (2.0f * tanx); cam.focal_y = H / (2.0f * tany);
     cam.scale_modifier = scale_modifier;
@@ -1454,15 +1478,16 @@ int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H, int64_t span_capa
 int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* means3D, const float* shs, const float* shs_rest,
                       int32_t raw_parameters, const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix_host, const float* projmatrix_host,
-                      const float* campos_host, float tan_fovx, float tan_fovy, int32_t* radii, float* depths, float* points_xy,
-                      float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched, uint32_t* tile_counts,
-                      uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t span_capacity, float* splat_records, int64_t* num_rendered,
-                      nrc_stream_t stream) {
+                      const float* campos_host, const float* camera_dev, float tan_fovx, float tan_fovy, int32_t* radii, float* depths,
+                      float* points_xy, float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched,
+                      uint32_t* tile_counts, uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t span_capacity,
+                      int64_t instance_capacity, float* splat_records, int64_t* num_rendered, nrc_stream_t stream) {
     NRC_ENTER();
     GsCam cam;
-    const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, tan_fovx, tan_fovy, scale_modifier, raw_parameters);
+    const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, camera_dev, tan_fovx, tan_fovy, scale_modifier, raw_parameters);
     if (rc != NRC_OK) return rc;
-    if (P < 0 || !tile_counts || !ranges || !tile_fill || !num_rendered) return NRC_ERR_INVALID;
+    if (P < 0 || !tile_counts || !ranges || !tile_fill || !num_rendered || instance_capacity < 0 || instance_capacity > 0xfffffffell) return NRC_ERR_INVALID;
+    const uint32_t list_cap = instance_capacity > 0 ? (uint32_t)instance_capacity : 0xffffffffu;
     if (P > 0) {
         if ((shs == nullptr) == (colors_precomp == nullptr)) return NRC_ERR_INVALID;                      // exactly one colour source
         if (((scales != nullptr) && (rotations != nullptr)) == (cov3D_precomp != nullptr)) return NRC_ERR_INVALID;  // exactly one covariance source
@@ -1473,19 +1498,20 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
     hipStream_t s = (hipStream_t)stream;
     const int n_tiles = cam.gx * cam.gy;
     const bool lds_path = cam.gx <= SPAN_DIM_MAX && cam.gy <= SPAN_DIM_MAX && bin_hist != nullptr;
-    hipMemsetAsync(tile_counts, 0, sizeof(uint32_t) * n_tiles, s);
+    if (instance_capacity > 0 && P > 0 && !lds_path) return NRC_ERR_UNSUPPORTED;  // the per-tile key sort fallback sizes its keys from the count
+    nrc_zero_async(tile_counts, sizeof(uint32_t) * n_tiles, s);
     if (P > 0) {
         if (!means3D || !opacities || !radii || !depths || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !tiles_touched || !splat_records)
             return NRC_ERR_INVALID;
         if (shs && M > PRE_MAXM) return NRC_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(k_preprocess, dim3(nrc_cdiv(P, PRE_BLOCK)), dim3(PRE_BLOCK), 0, s, P, cam, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations,
+        hipLaunchKernelGGL(k_preprocess, dim3(nrc_cdiv(P, PRE_BLOCK)), dim3(PRE_BLOCK), 0, s, P, cam, camera_dev, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations,
                            cov3D_precomp, radii, depths, points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched,
                            lds_path ? (uint32_t*)nullptr : tile_counts, (float4*)splat_records);
         if (lds_path) {
             const BinWs w = gs_bin_ws(bin_hist, P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P));
             // depth pre-sort of the Gaussians: 4 stable 8-bit passes, (keyA,valA) -> ... -> (keyA,valA); valA = depth order
             hipLaunchKernelGGL(k_depth_keys, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, w.keyA, w.valA, w.rectA);
-            hipMemsetAsync(w.tot, 0, sizeof(uint32_t) * 4 * 256, s);
+            nrc_zero_async(w.tot, sizeof(uint32_t) * 4 * 256, s);
             for (int pass = 0; pass < 4; pass++) {
                 const uint32_t *ki = (pass & 1) ? w.keyB : w.keyA, *vi = (pass & 1) ? w.valB : w.valA, *ri = (pass & 1) ? w.rectB : w.rectA;
                 uint32_t *ko = (pass & 1) ? w.keyA : w.keyB, *vo = (pass & 1) ? w.valA : w.valB, *ro = (pass & 1) ? w.rectA : w.rectB;
@@ -1501,33 +1527,38 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
             hipLaunchKernelGGL(k_item_count, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.cap, w.item_cap,
                                w.spans, w.cnt2);
             hipLaunchKernelGGL(k_item_scan, dim3((unsigned)nrc_cdiv(cam.gx, 64), cam.gy), dim3(1024), 0, s, cam.gx, w.item_cap, w.nitems, w.ioff, w.cnt2, w.tcount);
-            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, w.tcount, n_tiles, ranges, tile_fill, num_rendered);
+            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, w.tcount, n_tiles, list_cap, ranges, tile_fill, num_rendered);
         }
     }
     if (!(P > 0 && lds_path)) {
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, n_tiles, ranges, tile_fill, num_rendered);
-        hipMemsetAsync(num_rendered + 1, 0, sizeof(int64_t), s);  // no span workspace in use
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, n_tiles, list_cap, ranges, tile_fill, num_rendered);
+        nrc_zero_async(num_rendered + 1, sizeof(int64_t), s);  // no span workspace in use
     }
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
 
-int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, const int32_t* radii, const float* depths, const float* points_xy,
-                      const float* conic_opacity, const float* rgb, const uint32_t* ranges, uint32_t* tile_fill, const uint32_t* bin_hist, int64_t span_capacity,
-                      uint64_t* keys,
-                      int32_t* point_list, const float* splat_records, float* out_color, uint32_t* n_contrib, float* final_T, nrc_stream_t stream) {
+int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, const float* camera_dev, const int32_t* radii, const float* depths,
+                      const float* points_xy, const float* conic_opacity, const float* rgb, const uint32_t* ranges, uint32_t* tile_fill,
+                      const uint32_t* bin_hist, int64_t span_capacity, int64_t instance_capacity, uint64_t* keys, int32_t* point_list,
+                      const float* splat_records, float* out_color, uint32_t* n_contrib, float* final_T, nrc_stream_t stream) {
     NRC_ENTER();
-    if (P < 0 || W < 1 || H < 1 || !bg_host || !ranges || !tile_fill || !out_color || !n_contrib || !final_T) return NRC_ERR_INVALID;
+    if (P < 0 || W < 1 || H < 1 || (!bg_host && !camera_dev) || !ranges || !tile_fill || !out_color || !n_contrib || !final_T) return NRC_ERR_INVALID;
+    if (instance_capacity < 0 || instance_capacity > 0xfffffffell) return NRC_ERR_INVALID;
+    const uint32_t list_cap = instance_capacity > 0 ? (uint32_t)instance_capacity : 0xffffffffu;
+    const float bg[3] = {bg_host ? bg_host[0] : 0.f, bg_host ? bg_host[1] : 0.f, bg_host ? bg_host[2] : 0.f};
     GsCam cam = {};
     cam.W = W; cam.H = H; cam.gx = (W + TILE - 1) / TILE; cam.gy = (H + TILE - 1) / TILE;
     hipStream_t s = (hipStream_t)stream;
     if (P > 0) {
-        if (!radii || !depths || !points_xy || !conic_opacity || !rgb || !keys || !point_list || !splat_records) return NRC_ERR_INVALID;
+        if (!radii || !depths || !points_xy || !conic_opacity || !rgb || !point_list || !splat_records) return NRC_ERR_INVALID;
         const int n_tiles = cam.gx * cam.gy;
-        if (cam.gx <= SPAN_DIM_MAX && cam.gy <= SPAN_DIM_MAX && bin_hist) {
+        const bool lds_path = cam.gx <= SPAN_DIM_MAX && cam.gy <= SPAN_DIM_MAX && bin_hist;
+        if (!lds_path && (!keys || instance_capacity > 0)) return instance_capacity > 0 ? NRC_ERR_UNSUPPORTED : NRC_ERR_INVALID;
+        if (lds_path) {
             const BinWs w = gs_bin_ws(const_cast<uint32_t*>(bin_hist), P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P));
             hipLaunchKernelGGL(k_item_scatter, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.spans, w.cnt2, ranges,
-                               point_list);
+                               list_cap, point_list);
         } else {
             hipLaunchKernelGGL(k_scatter, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, ranges, tile_fill, keys);
             hipLaunchKernelGGL((k_sort_tiles<0, 1024>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
@@ -1537,8 +1568,8 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
     }
     // tile_fill has served the fallback scatter (if any): it now carries the launch order of the tiles, longest list first, for both render kernels
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cam.gx * cam.gy, ranges, tile_fill);
-    hipLaunchKernelGGL(k_render, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_fill, bg_host[0],
-                       bg_host[1], bg_host[2], out_color, n_contrib, final_T);
+    hipLaunchKernelGGL(k_render, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_fill, bg[0], bg[1], bg[2],
+                       camera_dev, out_color, n_contrib, final_T);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
@@ -1546,7 +1577,7 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
 int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg_host, const float* means3D, const float* shs,
                     const float* shs_rest, int32_t raw_parameters, const float* opacities, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                     const float* cov3D_precomp, const float* viewmatrix_host, const float* projmatrix_host, const float* campos_host,
-                    float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
+                    const float* camera_dev, float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
                     const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list, const uint32_t* ranges,
                     const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
                     float* dL_dmean2D, float* dL_dconic,
@@ -1554,9 +1585,10 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
                     float* dL_drot, nrc_stream_t stream) {
     NRC_ENTER();
     GsCam cam;
-    const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, tan_fovx, tan_fovy, scale_modifier, raw_parameters);
+    const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, camera_dev, tan_fovx, tan_fovy, scale_modifier, raw_parameters);
     if (rc != NRC_OK) return rc;
-    if (P < 0 || !bg_host) return NRC_ERR_INVALID;
+    if (P < 0 || (!bg_host && !camera_dev)) return NRC_ERR_INVALID;
+    const float bg[3] = {bg_host ? bg_host[0] : 0.f, bg_host ? bg_host[1] : 0.f, bg_host ? bg_host[2] : 0.f};
     if (P == 0) return NRC_OK;
     if (!means3D || !radii || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !point_list || !ranges || !n_contrib || !final_T ||
         !dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
@@ -1565,14 +1597,14 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
     if ((use_sh && (!shs || !dL_dsh)) || (use_sr && (!scales || !rotations || !dL_dscale || !dL_drot))) return NRC_ERR_INVALID;
     if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr) || (raw_parameters && (!opacities || !use_sr))) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    hipMemsetAsync(dL_dmean2D, 0, sizeof(float) * 3 * P, s);
-    hipMemsetAsync(dL_dconic, 0, sizeof(float) * 4 * P, s);
-    hipMemsetAsync(dL_dopacity, 0, sizeof(float) * P, s);
-    hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * P, s);
+    nrc_zero_async(dL_dmean2D, sizeof(float) * 3 * P, s);
+    nrc_zero_async(dL_dconic, sizeof(float) * 4 * P, s);
+    nrc_zero_async(dL_dopacity, sizeof(float) * P, s);
+    nrc_zero_async(dL_dcolor, sizeof(float) * 3 * P, s);
     if (use_sh && M > PBW_MAXM) return NRC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_render_bw, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_order, bg_host[0],
-                       bg_host[1], bg_host[2], n_contrib, final_T, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
-    hipLaunchKernelGGL(k_preprocess_bw, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, P, cam, means3D, shs, shs_rest, opacities, use_sh, scales, rotations,
+    hipLaunchKernelGGL(k_render_bw, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_order, bg[0], bg[1], bg[2],
+                       camera_dev, n_contrib, final_T, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+    hipLaunchKernelGGL(k_preprocess_bw, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, P, cam, camera_dev, means3D, shs, shs_rest, opacities, use_sh, scales, rotations,
                        use_sr, radii, clamped, cov3D, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, dL_dopacity);
     NRC_LAUNCH_CHECK();
     return NRC_OK;

@@ -518,12 +518,12 @@ int nrc_distortion_loss_fw(const float* ws, const float* deltas, const float* ts
     hipStream_t s = (hipStream_t)stream;
     if (n_samples > 0) {
         if (!ws_incl || !wts_incl) return NRC_ERR_INVALID;
-        hipMemsetAsync(ws_incl, 0, n_samples * sizeof(float), s);
-        hipMemsetAsync(wts_incl, 0, n_samples * sizeof(float), s);
+        nrc_zero_async(ws_incl, n_samples * sizeof(float), s);
+        nrc_zero_async(wts_incl, n_samples * sizeof(float), s);
     }
     if (n_rays == 0) return NRC_OK;
     if (!loss || !rays_a || (n_samples > 0 && (!ws || !deltas || !ts))) return NRC_ERR_INVALID;
-    hipMemsetAsync(loss, 0, n_rays * sizeof(float), s);
+    nrc_zero_async(loss, n_rays * sizeof(float), s);
     hipLaunchKernelGGL(k_distortion_fw, dim3(nrc_cdiv(n_rays, 4)), dim3(256), 0, s, ws, deltas, ts, rays_a, n_rays, loss, ws_incl, wts_incl);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
@@ -535,7 +535,7 @@ int nrc_distortion_loss_bw(const float* dL_dloss, const float* ws_incl, const fl
     NRC_ENTER();
     if (n_rays < 0 || n_samples < 0) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (n_samples > 0) { if (!dL_dws) return NRC_ERR_INVALID; hipMemsetAsync(dL_dws, 0, n_samples * sizeof(float), s); }
+    if (n_samples > 0) { if (!dL_dws) return NRC_ERR_INVALID; nrc_zero_async(dL_dws, n_samples * sizeof(float), s); }
     if (n_rays == 0 || n_samples == 0) return NRC_OK;
     if (!dL_dloss || !ws_incl || !wts_incl || !ws || !deltas || !ts || !rays_a) return NRC_ERR_INVALID;
     hipLaunchKernelGGL(k_distortion_bw, dim3(nrc_cdiv(n_rays, 4)), dim3(256), 0, s, dL_dloss, ws_incl, wts_incl, ws, deltas, ts,

@@ -872,14 +872,14 @@ int nrc_raymarching_train_count(const float* rays_o, const float* rays_d, const 
     NRC_ENTER();
     if (n_rays < 0 || !counter || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (n_rays == 0) { hipMemsetAsync(counter, 0, 8, s); return NRC_OK; }
+    if (n_rays == 0) { nrc_zero_async(counter, 8, s); return NRC_OK; }
     if (!rays_o || !rays_d || !hits_t || !bitfield || !noise || !rays_a || !workspace) return NRC_ERR_INVALID;
     const int64_t nb = nrc_cdiv(n_rays, 256);
     int32_t* counts = (int32_t*)workspace;
     int32_t* block_sums = (int32_t*)((char*)workspace + (n_rays * 4 + 255) / 256 * 256);
     const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, scale);
     if (n_rays <= NRC_WAVE_MARCH_MAX_RAYS) {
-        hipMemsetAsync(block_sums, 0, sizeof(int32_t) * nb, s);
+        nrc_zero_async(block_sums, sizeof(int32_t) * nb, s);
         float* park = (float*)((char*)workspace + train_ws_head_bytes(n_rays));
         hipLaunchKernelGGL(k_march_wave<false>, dim3((unsigned)nrc_cdiv(n_rays, 4)), dim3(256), 0, s, rays_o, rays_d, hits_t, noise, c, n_rays, counts,
                            block_sums, (const int64_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, park);

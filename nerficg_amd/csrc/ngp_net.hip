@@ -1629,7 +1629,7 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
             GbHeader* hd = reinterpret_cast<GbHeader*>(workspace);
             uint4* records = reinterpret_cast<uint4*>(reinterpret_cast<char*>(workspace) + GB_HEADER_BYTES);
             const int nb = bc.bucket0[bc.n_levels];
-            if (hipMemsetAsync(hd, 0, sizeof(GbHeader), s) != hipSuccess) return NRC_ERR_LAUNCH;
+            if (nrc_zero_async(hd, sizeof(GbHeader), s) != hipSuccess) return NRC_ERR_LAUNCH;
             const dim3 sgrid((unsigned)nrc_cdiv(M, OWN_THREADS));
             hipLaunchKernelGGL(k_gb_split<false>, sgrid, dim3(OWN_THREADS), 0, s, x01, M, d_features, g, bc, hd, records);
             hipLaunchKernelGGL(k_gb_scan, dim3(1), dim3(GB_MAX_BUCKETS), 0, s, hd, nb, bc.n_levels, M);

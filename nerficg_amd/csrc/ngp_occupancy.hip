@@ -225,7 +225,7 @@ int nrc_occupancy_update(float* grid, const int64_t* cell_indices, const void* d
     float* scratch = reinterpret_cast<float*>(workspace);
     float* partial_sum = scratch + n_cells;
     float* partial_cnt = partial_sum + nblk;
-    if (hipMemsetAsync(scratch, 0, (size_t)n_cells * 4, st) != hipSuccess) return NRC_ERR_LAUNCH;
+    if (nrc_zero_async(scratch, (size_t)n_cells * 4, st) != hipSuccess) return NRC_ERR_LAUNCH;
     const int64_t total = (int64_t)cascades * samples_per_cascade;
     if (total > 0) {
         if (densities_dtype == 0)

@@ -13,14 +13,14 @@ src/Methods/GaussianSplatting/Model.py:258).  Backed by libnerficg_hip.so (nrc_g
 """
 from __future__ import annotations
 
-import ctypes
+import contextlib
 from typing import NamedTuple
 
 import torch
 
 from .. import _lib
 
-__all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'rasterize_gaussians']
+__all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'rasterize_gaussians', 'fixed_capacity', 'last_counts']
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -38,38 +38,55 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
-def _host_f32(t: torch.Tensor, n: int):
-    v = t.detach().to(dtype=torch.float32).reshape(-1).cpu()
-    if v.numel() != n:
-        raise RuntimeError(f'expected {n} values, got {v.numel()}')
-    return (ctypes.c_float * n)(*v.tolist())
+_CAMERA_BLOCKS: dict = {}
 
 
-_HOST_CAMERA: dict = {}
-
-
-def _host_camera(rs):
-    """The four small camera tensors as host arrays (the C ABI takes them by value).  They cross to the host in ONE copy, and only when the
-    settings carry tensors this process has not seen yet (same storage, same version counter -> same values): a renderer that draws several
-    passes from one camera, or re-renders a pose, pays the device -> host read once."""
-    key = tuple((t.data_ptr(), t._version, t.device) for t in (rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg))
-    hit = _HOST_CAMERA.get(key)
+def _camera_block(rs, dev) -> torch.Tensor:
+    """viewmatrix | projmatrix | campos | bg of the settings as ONE device float[38] (the `camera_dev` block of the C ABI): the camera never
+    crosses to the host.  Built with one concatenation when the settings carry tensors this process has not seen yet (same storage, same
+    version counter -> same values), so a renderer that draws several passes from one camera pays it once.  During a stream capture it is
+    always rebuilt, so that the recorded graph re-reads the (then static) camera tensors on every replay."""
+    tensors = (rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg)
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = tuple((t.data_ptr(), t._version, t.device) for t in tensors)
+    hit = None if capturing else _CAMERA_BLOCKS.get(key)
     if hit is None:
-        packed = torch.cat([rs.viewmatrix.reshape(-1).float(), rs.projmatrix.reshape(-1).float(), rs.campos.reshape(-1).float(),
-                            rs.bg.reshape(-1).float().to(rs.viewmatrix.device)]).cpu().tolist()
-        hit = ((ctypes.c_float * 16)(*packed[:16]), (ctypes.c_float * 16)(*packed[16:32]), (ctypes.c_float * 3)(*packed[32:35]),
-               (ctypes.c_float * 3)(*packed[35:38]), (rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg))  # the tensors are kept alive: their addresses are the key
-        if len(_HOST_CAMERA) >= 256:
-            _HOST_CAMERA.pop(next(iter(_HOST_CAMERA)))
-        _HOST_CAMERA[key] = hit
-    return hit[:4]
+        block = torch.cat([t.detach().reshape(-1).to(device=dev, dtype=torch.float32) for t in tensors])
+        if block.numel() != 38:
+            raise RuntimeError(f'raster settings: viewmatrix (4,4), projmatrix (4,4), campos (3), bg (3) expected, got {block.numel()} values')
+        if capturing:
+            return block
+        if len(_CAMERA_BLOCKS) >= 256:
+            _CAMERA_BLOCKS.pop(next(iter(_CAMERA_BLOCKS)))
+        hit = _CAMERA_BLOCKS[key] = (block, tensors)  # the tensors are kept alive: their addresses are the key
+    return hit[0]
+
+
+_FIXED_CAPACITY: tuple[int, int] | None = None
+_LAST_COUNTS: torch.Tensor | None = None
+
+
+@contextlib.contextmanager
+def fixed_capacity(instances: int, spans: int = 0):
+    """Inside the block the rasterizer sizes nothing from device counts: the per-tile lists hold `instances` entries, the binning workspace
+    `spans` row-span records (0: the default 4 P + 65536), and the forward reads nothing back -- which is what a HIP-graph capture needs
+    (nerficg_amd.graphs.gaussian_splatting_step).  Instances beyond the capacity are dropped; `last_counts()` tells."""
+    global _FIXED_CAPACITY
+    if instances < 1 or spans < 0:
+        raise ValueError('fixed_capacity: instances >= 1, spans >= 0')
+    previous, _FIXED_CAPACITY = _FIXED_CAPACITY, (int(instances), int(spans))
+    try:
+        yield
+    finally:
+        _FIXED_CAPACITY = previous
+
+
+def last_counts() -> torch.Tensor | None:
+    """DEVICE int64[2] of the most recent forward: (tile, Gaussian) instances and (tile row, Gaussian) spans the frame needed."""
+    return _LAST_COUNTS
 
 
 _SPAN_CAPACITY: dict = {}  # (device, P, W, H) -> row-span capacity of the binning workspace once the default proved too small
-
-
-def _p(arr):
-    return ctypes.cast(arr, ctypes.c_void_p)
 
 
 def _opt(t):
@@ -98,7 +115,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         M = 0 if sh_c is None else int(sh_c.shape[1]) + (0 if rest_c is None else int(rest_c.shape[1]))
         gx, gy = (W + 15) // 16, (H + 15) // 16
         nt = gx * gy
-        vm, pm, cp, bg = _host_camera(rs)
+        cam_block = _camera_block(rs, dev)
         i32, u8 = torch.int32, torch.uint8
         n1 = max(P, 1)
         radii = torch.empty(n1, dtype=i32, device=dev)
@@ -115,18 +132,26 @@ class _RasterizeGaussians(torch.autograd.Function):
         ranges = torch.empty(nt, 2, dtype=i32, device=dev)
         num_rendered = torch.empty(2, dtype=torch.int64, device=dev)
         st = _lib.stream_of(radii)
+        fixed = _FIXED_CAPACITY
+        if fixed is None and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('rasterizer forward: sizing the tile lists reads num_rendered on the host, which a stream capture cannot do -- '
+                               'wrap the call in diff_gaussian_rasterization.fixed_capacity(instances, spans)')
         # binning workspace: kept per (device, P, W, H) and regrown when a frame needs more row-span records than it holds (the count comes
         # back with the instance count in the one host read of the forward)
         ws_key = (dev, P, W, H)
-        span_cap = _SPAN_CAPACITY.get(ws_key, 0)
+        span_cap = _SPAN_CAPACITY.get(ws_key, 0) if fixed is None else fixed[1]
+        inst_cap = 0 if fixed is None else fixed[0]
         while True:
             hist_bytes = int(lib.nrc_gs_bin_hist_bytes(P, W, H, span_cap))
             bin_hist = torch.empty(hist_bytes // 4, dtype=i32, device=dev) if hist_bytes > 0 else None
             _lib.check(lib.nrc_gs_preprocess(
                 P, D, M, W, H, _lib.ptr(means3D_c), _lib.ptr(sh_c), _lib.ptr(rest_c), int(raw), _lib.ptr(col_c), _lib.ptr(op_c), _lib.ptr(sc_c), float(rs.scale_modifier),
-                _lib.ptr(rot_c), _lib.ptr(cov_c), _p(vm), _p(pm), _p(cp), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(depths),
+                _lib.ptr(rot_c), _lib.ptr(cov_c), None, None, None, _lib.ptr(cam_block), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(depths),
                 _lib.ptr(points_xy), _lib.ptr(conic_opacity), _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(tiles_touched),
-                _lib.ptr(tile_counts), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(bin_hist), span_cap, _lib.ptr(splat), _lib.ptr(num_rendered), st), 'gs_preprocess')
+                _lib.ptr(tile_counts), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(bin_hist), span_cap, inst_cap, _lib.ptr(splat), _lib.ptr(num_rendered), st), 'gs_preprocess')
+            if fixed is not None:
+                n_inst = inst_cap
+                break
             n_inst, n_spans = num_rendered.tolist()
             have = span_cap if span_cap > 0 else 4 * max(P, 1) + 65536
             if bin_hist is None or n_spans <= have:
@@ -134,24 +159,25 @@ class _RasterizeGaussians(torch.autograd.Function):
             span_cap = _SPAN_CAPACITY[ws_key] = int(n_spans * 1.25) + 65536
             if len(_SPAN_CAPACITY) > 64:
                 _SPAN_CAPACITY.pop(next(iter(_SPAN_CAPACITY)))
-        keys = torch.empty(max(n_inst, 1), dtype=torch.int64, device=dev)
+        global _LAST_COUNTS
+        _LAST_COUNTS = num_rendered
+        keys = torch.empty(max(n_inst, 1) if bin_hist is None else 1, dtype=torch.int64, device=dev)  # only the per-tile key sort fallback uses them
         point_list = torch.empty(max(n_inst, 1), dtype=i32, device=dev)
         color = torch.empty(3, H, W, dtype=f32, device=dev)
         n_contrib = torch.empty(H * W, dtype=i32, device=dev)
         final_T = torch.empty(H * W, dtype=f32, device=dev)
-        _lib.check(lib.nrc_gs_bin_render(P, W, H, _p(bg), _lib.ptr(radii), _lib.ptr(depths), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
-                                         _lib.ptr(rgb), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(bin_hist), span_cap, _lib.ptr(keys), _lib.ptr(point_list), _lib.ptr(splat),
-                                         _lib.ptr(color), _lib.ptr(n_contrib), _lib.ptr(final_T), st), 'gs_bin_render')
+        _lib.check(lib.nrc_gs_bin_render(P, W, H, None, _lib.ptr(cam_block), _lib.ptr(radii), _lib.ptr(depths), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
+                                         _lib.ptr(rgb), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(bin_hist), span_cap, inst_cap, _lib.ptr(keys), _lib.ptr(point_list),
+                                         _lib.ptr(splat), _lib.ptr(color), _lib.ptr(n_contrib), _lib.ptr(final_T), st), 'gs_bin_render')
         ctx.raster_settings = rs
-        ctx.host = (vm, pm, cp, bg)
         ctx.dims = (P, D, M, W, H)
-        ctx.num_rendered = n_inst
+        ctx.num_rendered = n_inst if fixed is None else -1
         ctx.has = (sh_c is not None, col_c is not None, sc_c is not None, cov_c is not None)
         ctx.opacity_shape = tuple(opacities.shape)
         ctx.save_for_backward(means3D_c, sh_c if sh_c is not None else torch.empty(0), col_c if col_c is not None else torch.empty(0),
                               sc_c if sc_c is not None else torch.empty(0), rot_c if rot_c is not None else torch.empty(0),
                               cov_c if cov_c is not None else torch.empty(0), radii, points_xy, conic_opacity, rgb, clamped, cov3D,
-                              point_list, ranges, n_contrib, final_T, splat, tile_fill, rest_c if rest_c is not None else torch.empty(0), op_c)
+                              point_list, ranges, n_contrib, final_T, splat, tile_fill, rest_c if rest_c is not None else torch.empty(0), op_c, cam_block)
         ctx.raw, ctx.has_rest = raw, rest_c is not None
         ctx.debug_state = dict(depths=depths, tiles_touched=tiles_touched, keys=keys)
         radii_out = radii[:P]
@@ -162,12 +188,11 @@ class _RasterizeGaussians(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out_color, _grad_radii):
         (means3D, sh, col, sc, rot, cov, radii, points_xy, conic_opacity, rgb, clamped, cov3D, point_list, ranges, n_contrib,
-         final_T, splat, tile_order, sh_rest, opac) = ctx.saved_tensors
+         final_T, splat, tile_order, sh_rest, opac, cam_block) = ctx.saved_tensors
         raw, has_rest = ctx.raw, ctx.has_rest
         has_sh, has_col, has_sr, has_cov = ctx.has
         P, D, M, W, H = ctx.dims
         rs = ctx.raster_settings
-        vm, pm, cp, bg = ctx.host
         lib = _lib.load()
         dev = means3D.device
         f32 = torch.float32
@@ -184,10 +209,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         dscale = torch.empty(n1, 3, dtype=f32, device=dev) if has_sr else None
         drot = torch.empty(n1, 4, dtype=f32, device=dev) if has_sr else None
         _lib.check(lib.nrc_gs_backward(
-            P, D, M, W, H, _p(bg), _lib.ptr(means3D), _lib.ptr(sh if has_sh else None), _lib.ptr(sh_rest if has_rest else None), int(raw),
+            P, D, M, W, H, None, _lib.ptr(means3D), _lib.ptr(sh if has_sh else None), _lib.ptr(sh_rest if has_rest else None), int(raw),
             _lib.ptr(opac if raw else None), _lib.ptr(col if has_col else None),
             _lib.ptr(sc if has_sr else None), float(rs.scale_modifier), _lib.ptr(rot if has_sr else None), _lib.ptr(cov if has_cov else None),
-            _p(vm), _p(pm), _p(cp), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
+            None, None, None, _lib.ptr(cam_block), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
             _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(point_list), _lib.ptr(ranges), _lib.ptr(splat), _lib.ptr(tile_order), _lib.ptr(n_contrib), _lib.ptr(final_T),
             _lib.ptr(g), _lib.ptr(dmean2D), _lib.ptr(dconic), _lib.ptr(dopacity), _lib.ptr(dcolor), _lib.ptr(dmean3D), _lib.ptr(dcov3D),
             _lib.ptr(dsh), _lib.ptr(dsh_rest), _lib.ptr(dscale), _lib.ptr(drot), _lib.stream_of(g)), 'gs_backward')

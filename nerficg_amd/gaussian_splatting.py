@@ -59,16 +59,39 @@ def invert_3d_affine(transform: np.ndarray) -> np.ndarray:
     return inv
 
 
-def make_raster_settings(cam: PerspectiveCamera, c2w: np.ndarray, sh_degree: int, scale_modifier: float = 1.0, device='cuda'):
-    """GaussianSplatting/Renderer.py:60-74: viewmatrix = w2c.T, projmatrix = w2c.T @ P.T, tanfov = size / focal / 2."""
+_PROJECTIONS: dict = {}
+
+
+def _projection_transposed(cam: PerspectiveCamera, device) -> torch.Tensor:
+    """P.T of get_projection_matrix on `device`, built once per camera geometry (a host -> device copy per frame otherwise)."""
+    key = (cam.width, cam.height, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y, cam.near_plane, cam.far_plane, str(device))
+    hit = _PROJECTIONS.get(key)
+    if hit is None:
+        if len(_PROJECTIONS) >= 64:
+            _PROJECTIONS.pop(next(iter(_PROJECTIONS)))
+        hit = _PROJECTIONS[key] = get_projection_matrix(cam, device=device).T.contiguous()
+    return hit
+
+
+def make_raster_settings(cam: PerspectiveCamera, c2w, sh_degree: int, scale_modifier: float = 1.0, device='cuda'):
+    """GaussianSplatting/Renderer.py:60-74: viewmatrix = w2c.T, projmatrix = w2c.T @ P.T, tanfov = size / focal / 2.  `c2w`: a (4,4) / (3,4)
+    array, or a device tensor -- the pose then never visits the host (w2c.T = [[R, 0], [-(R^T t)^T, 1]] is assembled by torch on the
+    device), which is what a recorded training step needs: it re-reads the tensor on every replay."""
     from .diff_gaussian_rasterization import GaussianRasterizationSettings
-    c2w = np.asarray(c2w, dtype=np.float64)
-    w2c = torch.as_tensor(invert_3d_affine(c2w), dtype=torch.float32, device=device).T
+    if torch.is_tensor(c2w):
+        pose = c2w.to(device=device, dtype=torch.float32)
+        rot, pos = pose[:3, :3], pose[:3, 3]
+        last_row = torch.cat([-(rot.T @ pos), pose.new_ones(1)])
+        view = torch.cat([torch.cat([rot, pose.new_zeros(3, 1)], dim=1), last_row[None]], dim=0)
+        campos = pos.contiguous()
+    else:
+        c2w = np.asarray(c2w, dtype=np.float64)
+        view = torch.as_tensor(invert_3d_affine(c2w), dtype=torch.float32, device=device).T
+        campos = torch.as_tensor(c2w[:3, 3], dtype=torch.float32, device=device)
     return GaussianRasterizationSettings(
         image_height=cam.height, image_width=cam.width, tanfovx=cam.width / cam.focal_x * 0.5, tanfovy=cam.height / cam.focal_y * 0.5,
-        bg=cam.background_color.to(device), scale_modifier=scale_modifier, viewmatrix=w2c,
-        projmatrix=w2c @ get_projection_matrix(cam, device=device).T, sh_degree=sh_degree,
-        campos=torch.as_tensor(c2w[:3, 3], dtype=torch.float32, device=device), prefiltered=False, debug=False)
+        bg=cam.background_color.to(device), scale_modifier=scale_modifier, viewmatrix=view,
+        projmatrix=view @ _projection_transposed(cam, device), sh_degree=sh_degree, campos=campos, prefiltered=False, debug=False)
 
 
 def quaternion_to_rotation_matrix(quaternions: torch.Tensor, normalize: bool = True) -> torch.Tensor:
@@ -214,8 +237,9 @@ class Gaussians(torch.nn.Module):
     def training_setup(self, LEARNING_RATE_POSITION_INIT: float = 0.00016, LEARNING_RATE_POSITION_FINAL: float = 0.0000016,
                        LEARNING_RATE_POSITION_MAX_STEPS: int = 30000, LEARNING_RATE_FEATURE: float = 0.0025, LEARNING_RATE_OPACITY: float = 0.05,
                        LEARNING_RATE_SCALING: float = 0.005, LEARNING_RATE_ROTATION: float = 0.001, PERCENT_DENSE: float = 0.01,
-                       training_cameras_extent: float | None = None, optimizer_class=None) -> None:
-        """Six single-tensor groups in the reference's order and names; FusedAdam(lr=0, eps=1e-15, adam_w_mode=False) over the HIP step."""
+                       training_cameras_extent: float | None = None, optimizer_class=None, capturable: bool = False) -> None:
+        """Six single-tensor groups in the reference's order and names; FusedAdam(lr=0, eps=1e-15, adam_w_mode=False) over the HIP step.
+        capturable: step counters and learning rates on the device, for steps recorded in a HIP graph (nerficg_amd.graphs)."""
         from .lr_utils import LRDecayPolicy
         if training_cameras_extent is not None:
             self.training_cameras_extent = training_cameras_extent
@@ -227,7 +251,7 @@ class Gaussians(torch.nn.Module):
         param_groups = [{'name': name, 'lr': rates[name], 'params': [getattr(self, attr)]} for name, attr in self._GROUP_OF.items()]
         if optimizer_class is None:
             from .apex_optimizers import FusedAdam
-            self.optimizer = FusedAdam(param_groups, lr=0.0, eps=1e-15, adam_w_mode=False)
+            self.optimizer = FusedAdam(param_groups, lr=0.0, eps=1e-15, adam_w_mode=False, capturable=capturable)
         else:
             self.optimizer = optimizer_class(param_groups, lr=0.0, eps=1e-15)
         self.position_lr_scheduler = LRDecayPolicy(lr_init=LEARNING_RATE_POSITION_INIT * ext, lr_final=LEARNING_RATE_POSITION_FINAL * ext,

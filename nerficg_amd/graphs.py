@@ -28,19 +28,30 @@ class GraphedIteration:
     """body(**inputs) -> dict of tensors, run on fixed input buffers.  The first `eager_calls` calls execute `body` as it is (they create
     lazily built state: optimizer moments, GradScaler scalars, compute copies); the next call records it; every later call copies the
     new inputs into the buffers and replays.  Inputs must keep shape and dtype; outputs are the same tensor objects on every call
-    (overwritten by the next one).  `before_replay()` runs ahead of every replay (host-side hyper-parameter pushes)."""
+    (overwritten by the next one).  `before_replay()` runs ahead of every replay (host-side hyper-parameter pushes).
+    `parameters`: the leaf tensors `body` differentiates.  Autograd pins a leaf's gradient accumulator to the stream that first used it; the
+    eager calls run on the caller's stream and the recording on torch's capture stream, so the accumulators are dropped before the capture
+    (requires_grad off / on) -- otherwise the recorded backward hops over to the eager stream for every accumulation (torch warns about
+    exactly this) and the graph carries cross-stream edges it does not need.
+
+    Two findings on ROCm 7.2 that shaped this (tools/exp_gs_graph.py, tools/exp_graph_ingp.py): (1) graph MEMSET nodes -- a hipMemsetAsync
+    inside the capture -- let a replay finish after the launch stream considered it done, so back-to-back replays overran their own
+    predecessor (GPU memory faults from half-updated index buffers); the library clears memory with a kernel of its own (nrc_zero_async,
+    csrc/common.h) and recorded graphs hold kernel nodes only.  (2) Running the eager calls on a private side stream that is then used for
+    the capture produced the same faults; eager calls stay on the caller's stream."""
 
     def __init__(self, body: Callable[..., dict], example_inputs: dict[str, torch.Tensor], eager_calls: int = 1,
-                 before_replay: Callable[[], None] | None = None) -> None:
+                 before_replay: Callable[[], None] | None = None, parameters=None) -> None:
         if eager_calls < 1:
             raise ValueError('at least one eager call is needed to build lazily created state before the capture')
         self.body = body
         self.inputs = {k: v.detach().clone() for k, v in example_inputs.items()}
         for k, v in self.inputs.items():
             if not v.is_cuda:
-                raise RuntimeError(f'GraphedIteration: input {k!r} must live on the GPU')
+                raise RuntimeError(f'GraphedIteration: the buffer of input {k!r} must live on the GPU (later calls may pass host tensors)')
         self.eager_calls = eager_calls
         self.before_replay = before_replay
+        self.parameters = None if parameters is None else (parameters if callable(parameters) else list(parameters))
         self.calls = 0
         self.graph: torch.cuda.CUDAGraph | None = None
         self.outputs: dict[str, torch.Tensor] | None = None
@@ -55,15 +66,23 @@ class GraphedIteration:
             if v.data_ptr() != buf.data_ptr():
                 buf.copy_(v, non_blocking=True)
 
+    def _record(self) -> None:
+        leaves = self.parameters() if callable(self.parameters) else (self.parameters or [])
+        for p in leaves:
+            if p.requires_grad and p.is_leaf:
+                p.grad = None
+                p.requires_grad_(False).requires_grad_(True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):   # records, does not execute
+            self.outputs = self.body(**self.inputs)
+
     def __call__(self, **inputs: torch.Tensor) -> dict[str, torch.Tensor]:
         self._load(inputs)
         self.calls += 1
         if self.calls <= self.eager_calls:
             return self.body(**self.inputs)
         if self.graph is None:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):   # records, does not execute
-                self.outputs = self.body(**self.inputs)
+            self._record()
         if self.before_replay is not None:
             self.before_replay()
         self.graph.replay()
@@ -122,4 +141,39 @@ def instant_ngp_iteration(model, renderer, optimizer, scaler, camera, n_rays: in
         example['view_direction'][:, 2] = 1.0
         if with_alpha:
             example['alpha'] = torch.zeros(n_rays, device=dev)
-    return GraphedIteration(body, example, eager_calls=eager_calls, before_replay=optimizer.sync_hyperparameters)
+    return GraphedIteration(body, example, eager_calls=eager_calls, before_replay=optimizer.sync_hyperparameters, parameters=model.parameters)
+
+
+def gaussian_splatting_step(gaussians, camera, instance_capacity: int, span_capacity: int = 0, loss_fn: Callable | None = None,
+                            densification_stats: bool = True, eager_calls: int = 1) -> GraphedIteration:
+    """The optimisation step of src/Methods/GaussianSplatting/Trainer.py (render_image_training -> 0.8 L1 + 0.2 DSSIM -> backward ->
+    densification statistics -> FusedAdam) as a GraphedIteration: call(c2w=(4,4) f32, target=(3,H,W) f32) -> {'loss', 'radii', 'counts'}.
+    The pose is a device tensor (make_raster_settings assembles the camera on the device), the rasterizer runs with fixed list / span
+    capacities ('counts' = the DEVICE int64[2] the frame needed: compare with the capacities every now and then), and the optimizer must
+    have been built with training_setup(capturable=True); `update_learning_rate` keeps working (the new rate is pushed to the device
+    ahead of every replay).  Whatever replaces the parameter tensors -- densify_and_prune, reset_opacities -- invalidates the recording:
+    build a new step afterwards (the reference densifies every 100 iterations; a capture costs about as much as two eager steps)."""
+    from .diff_gaussian_rasterization import fixed_capacity, last_counts
+    from .gaussian_splatting import render_image_training, training_loss
+    optimizer = gaussians.optimizer
+    if not getattr(optimizer, 'capturable', False):
+        raise RuntimeError('gaussian_splatting_step: build the optimizer with Gaussians.training_setup(capturable=True)')
+    criterion = loss_fn or training_loss
+    dev = gaussians.get_positions.device
+
+    def body(c2w, target):
+        with fixed_capacity(int(instance_capacity), int(span_capacity)):
+            out = render_image_training(gaussians, camera, c2w)
+            loss = criterion(out['rgb'], target)
+            loss.backward()
+        counts = last_counts()
+        if densification_stats:
+            with torch.no_grad():
+                gaussians.add_densification_stats(out['viewspace_points'], out['radii'])
+        optimizer.step()
+        optimizer.zero_grad()
+        return {'loss': loss.detach(), 'radii': out['radii'], 'counts': counts}
+
+    example = {'c2w': torch.eye(4, device=dev), 'target': torch.zeros(3, camera.height, camera.width, device=dev)}
+    return GraphedIteration(body, example, eager_calls=eager_calls, before_replay=optimizer.sync_hyperparameters,
+                            parameters=lambda: [grp['params'][0] for grp in optimizer.param_groups])

@@ -127,7 +127,11 @@ def test_instant_ngp_iteration_trains_and_reports_overflow():
     n = 2048
     model, renderer, scaler = _train_pair(seed=4)
     opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
-    step = instant_ngp_iteration(model, renderer, opt, scaler, cam, n_rays=n, sample_capacity=400_000)
+    def loss_fn(out, rgb, alpha, bg):  # constant colour wherever the model puts opacity (the target of test_training_iterations_reduce_loss)
+        a = out['alpha'].detach()[:, None]
+        return torch.nn.functional.mse_loss(out['rgb'].float(), rgb * a + bg * (1 - a)) + 0.5e-6 * model.weight_decay_mlp()
+
+    step = instant_ngp_iteration(model, renderer, opt, scaler, cam, n_rays=n, sample_capacity=400_000, loss_fn=loss_fn)
     target = torch.tensor([0.8, 0.3, 0.1], device=DEV).expand(n, 3).contiguous()
     g = torch.Generator(device=DEV).manual_seed(5)
     losses = []
@@ -145,7 +149,7 @@ def test_instant_ngp_iteration_trains_and_reports_overflow():
     for a, b in zip(before, model.parameters()):
         assert torch.equal(a, b.detach())
     # too small a capacity: rays are cut, nothing is written out of bounds, the count says so
-    small = instant_ngp_iteration(model, renderer, opt, scaler, cam, n_rays=n, sample_capacity=20_000)
+    small = instant_ngp_iteration(model, renderer, opt, scaler, cam, n_rays=n, sample_capacity=20_000, loss_fn=loss_fn)
     for it in range(3):
         out = small(origin=o[:n].contiguous(), view_direction=d[:n].contiguous(), rgb=target)
         assert int(out['sample_overflow']) > 0 and np.isfinite(float(out['loss']))
@@ -159,3 +163,116 @@ def test_capture_without_a_sample_capacity_is_refused():
     with pytest.raises(RuntimeError, match='sample_capacity'):
         with torch.cuda.graph(g):
             vr.raymarching_train(*args)
+
+
+# ------------------------------------------------------------------------------------------------ 3DGS
+def _gs_setup(n_points=20000, seed=0, capturable=False):
+    from nerficg_amd.gaussian_splatting import Gaussians, PerspectiveCamera
+    W, H = 160, 120
+    cam = PerspectiveCamera(W, H, 1.1 * W, 1.1 * W, background_color=torch.tensor([0.2, 0.3, 0.4], device=DEV))
+    pts = (torch.rand(n_points, 3, generator=torch.Generator().manual_seed(seed)) - 0.5) * 1.2
+    g = Gaussians.from_point_cloud(pts.to(DEV), sh_degree=3)
+    with torch.no_grad():
+        gen = torch.Generator(device=DEV).manual_seed(seed + 1)
+        g._features_dc.add_(torch.randn(g._features_dc.shape, device=DEV, generator=gen) * 0.5)
+        g._features_rest.add_(torch.randn(g._features_rest.shape, device=DEV, generator=gen) * 0.05)
+    g.training_setup(training_cameras_extent=scenes.LEGO_RADIUS, capturable=capturable)
+    g.active_sh_degree = 3
+    poses = [scenes.orbit_pose(0.4 + 0.9 * k, 0.2 + 0.1 * k, scenes.LEGO_RADIUS) for k in range(6)]
+    return g, cam, poses
+
+
+def test_device_pose_settings_equal_the_host_pose_settings():
+    from nerficg_amd.gaussian_splatting import make_raster_settings
+    g, cam, poses = _gs_setup(n_points=16)
+    for p in poses[:3]:
+        a = make_raster_settings(cam, p, 3, 1.0, DEV)
+        b = make_raster_settings(cam, torch.from_numpy(np.asarray(p, dtype=np.float32)).to(DEV), 3, 1.0, DEV)
+        for name in ('viewmatrix', 'projmatrix', 'campos', 'bg'):
+            torch.testing.assert_close(getattr(b, name), getattr(a, name), rtol=1e-6, atol=1e-6)
+
+
+def test_fixed_capacity_rasterizer_equals_the_sized_call_and_reports_overflow():
+    from nerficg_amd import diff_gaussian_rasterization as dgr
+    from nerficg_amd.gaussian_splatting import render_image_training
+    g, cam, poses = _gs_setup()
+
+    def frame(capacity):
+        for p in g.optimizer.param_groups:
+            p['params'][0].grad = None
+        if capacity is None:
+            out = render_image_training(g, cam, poses[0])
+        else:
+            with dgr.fixed_capacity(*capacity):
+                out = render_image_training(g, cam, poses[0])
+        (out['rgb'] * torch.linspace(0.5, 1.5, out['rgb'].numel(), device=DEV).reshape(out['rgb'].shape)).sum().backward()
+        counts = dgr.last_counts().tolist()
+        grads = [p['params'][0].grad.clone() for p in g.optimizer.param_groups]
+        return out['rgb'].detach().clone(), out['radii'].clone(), grads, out['viewspace_points'].grad.clone(), counts
+
+    img, radii, grads, vs, (n_inst, n_spans) = frame(None)
+    assert n_inst > 50_000 and n_spans > 0
+    img2, radii2, grads2, vs2, counts2 = frame((n_inst + 1000, n_spans + 10))
+    assert counts2 == [n_inst, n_spans]
+    assert torch.equal(img, img2) and torch.equal(radii, radii2)
+    for a, b in zip(grads + [vs], grads2 + [vs2]):
+        torch.testing.assert_close(b, a, rtol=1e-3, atol=1e-5 * float(a.abs().max()))  # LDS float atomics: the order of the per-Gaussian sums is not fixed
+    # half the list: the frame still renders (front-most tiles complete), nothing is written behind the list, the count tells
+    img3, _, grads3, _, counts3 = frame((n_inst // 2, 0))
+    assert counts3[0] == n_inst and bool(torch.isfinite(img3).all()) and all(bool(torch.isfinite(t).all()) for t in grads3)
+    assert not torch.equal(img3, img)
+
+
+def test_recorded_gaussian_step_follows_the_op_by_op_step():
+    from nerficg_amd.gaussian_splatting import render_image_training, training_loss
+    from nerficg_amd.graphs import gaussian_splatting_step
+    results = {}
+    for mode in ('eager', 'graph'):
+        g, cam, poses = _gs_setup(capturable=(mode == 'graph'))
+        gen = torch.Generator(device=DEV).manual_seed(3)
+        targets = [torch.rand(3, cam.height, cam.width, device=DEV, generator=gen) for _ in poses]
+        step = gaussian_splatting_step(g, cam, instance_capacity=400_000) if mode == 'graph' else None
+        losses = []
+        for it, (pose, target) in enumerate(zip(poses, targets)):
+            g.update_learning_rate(it * 2000)     # the position rate changes between steps: it has to reach the recorded kernels
+            if mode == 'graph':
+                out = step(c2w=torch.from_numpy(np.asarray(pose, dtype=np.float32)), target=target)
+                assert int(out['counts'][0]) < 400_000
+                losses.append(float(out['loss']))
+            else:
+                out = render_image_training(g, cam, pose)
+                loss = training_loss(out['rgb'], target)
+                loss.backward()
+                with torch.no_grad():
+                    g.add_densification_stats(out['viewspace_points'], out['radii'])
+                g.optimizer.step(); g.optimizer.zero_grad()
+                losses.append(float(loss.detach()))
+        if mode == 'graph':
+            assert step.recorded
+            assert [g.optimizer.effective_step(grp) for grp in g.optimizer.param_groups] == [len(poses)] * 6
+        params = [grp['params'][0] for grp in g.optimizer.param_groups]
+        results[mode] = (losses, [p.detach().clone() for p in params], [g.optimizer.state[p]['exp_avg'].clone() for p in params],
+                         g.densification_gradient_accum.clone(), g.n_observations.clone())
+    (l0, p0, m0, acc0, obs0), (l1, p1, m1, acc1, obs1) = results['eager'], results['graph']
+    np.testing.assert_allclose(l1, l0, rtol=1e-4)
+    assert torch.equal(obs0, obs1)
+    torch.testing.assert_close(acc1, acc0, rtol=1e-2, atol=1e-3 * float(acc0.abs().max()))
+    for a, b in zip(m0, m1):     # first moments: linear in the gradients of all six steps (a few entries feel the parameter outliers below)
+        off = (a - b).abs() > 1e-2 * a.abs() + 1e-3 * float(a.abs().max())
+        assert float(off.float().mean()) < 1e-3, float(off.float().mean())
+    # parameters: with eps = 1e-15 Adam turns a gradient that is rounding noise (atomics order) into a full-size step of either sign, so a
+    # minority of entries may differ by up to lr * steps; the bulk must agree
+    for a, b in zip(p0, p1):
+        assert float(((a - b).abs() / (a.abs() + 1e-2)).flatten().float().quantile(0.5)) < 1e-4
+        assert float((a - b).abs().max()) <= 2 * 6 * 0.05
+
+
+def test_rasterizer_capture_without_fixed_capacity_is_refused():
+    from nerficg_amd.gaussian_splatting import render_image_training
+    g, cam, poses = _gs_setup(n_points=2000)
+    pose = torch.from_numpy(np.asarray(poses[0], dtype=np.float32)).to(DEV)
+    render_image_training(g, cam, pose)
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match='fixed_capacity'):
+        with torch.cuda.graph(graph):
+            render_image_training(g, cam, pose)
