@@ -1065,14 +1065,47 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
     return v;
 }
+// a + (b of the partner lane); CTRL: row_mirror 0x140 (lane ^ 15), row_half_mirror 0x141 (^ 7), quad_perm [3,2,1,0] 0x1b (^ 3), [1,0,3,2] 0xb1 (^ 1)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float keep, float send) {
+    return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), CTRL, 0xf, 0xf, true));
+}
+// (a + partner's a) in all lanes, (b + partner's b) in the lanes of the banks of BANKS.  The masked form has no builtin; the s_nop covers
+// the two wait states a DPP read needs after a VALU write of the same register, which the compiler cannot see through the asm.
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float dpp_add2(float a, float b) {
+    float r = dpp_add<CTRL>(a, a);
+    if constexpr (CTRL == 0x140)
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:%2" : "+v"(r) : "v"(b), "n"(BANKS));
+    else
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:%2" : "+v"(r) : "v"(b), "n"(BANKS));
+    return r;
+}
+// The nine per-Gaussian sums of a row meet the other blocks of the tile in LDS.  ds_add_f32 retires 0.33 lane-operations per clock per CU on
+// this chip however the lanes are spread over instructions (tools/micro/lds_atomic_rate.hip: 27 cycles per (row, entry) update of nine
+// values, per CU); ds_add_u64 with the nine values in nine lanes of ONE instruction takes 1.9.  So the sums travel as
+// 64-bit fixed point: scaled by a power of two chosen per tile from the largest |dL/dpixel| (every sum is linear in it, so the format is
+// scale-free) and per class of quantity from its analytic bound (colour <= 2^8, opacity <= 2^20, mean <= 2^19, conic <= 2^36 times that
+// gradient for splats up to sigma ~ 1000 px; beyond, the value saturates instead of wrapping).  Resolution 2^-51 ... 2^-25 of the tile's
+// largest pixel gradient: below what the f32 atomics of the next level keep.  Side effect: the per-tile sums no longer depend on the order
+// in which the blocks arrive.
+#define BW_S_COLOR 51
+#define BW_S_OPACITY 39
+#define BW_S_MEAN 40
+#define BW_S_CONIC 25
+#define BW_E_MIN (-60)
+#ifndef BW_PAIR
+#define BW_PAIR 1
+#endif
 __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
                                                    const float4* __restrict__ splat, const uint32_t* __restrict__ tile_order, float bg0, float bg1, float bg2,
                                                    const float* __restrict__ pose, const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
                                                    const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D,
                                                    float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor) {
     __shared__ StageLds st;
-    __shared__ float s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 16 blocks, flushed once per batch
+    __shared__ unsigned long long s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 16 blocks (fixed point), flushed once per batch
     __shared__ int s_blast[N_BLOCKS];
+    __shared__ float s_gmax[4];
     if (pose) { bg0 = pose[35]; bg1 = pose[36]; bg2 = pose[37]; }
     const int tile = (int)tile_order[blockIdx.x];  // longest lists first
     const int tile_x = tile % cam.gx, tile_y = tile / cam.gx;
@@ -1088,10 +1121,11 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
     const float T_final = inside ? final_T[pix] : 0.f;
     float T = T_final;
     const int last = inside ? (int)n_contrib[pix] : 0;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f;  // colour accumulated behind the current Gaussian
     const float g0 = inside ? dL_dpix[pix] : 0.f, g1 = inside ? dL_dpix[hw + pix] : 0.f, g2 = inside ? dL_dpix[2 * hw + pix] : 0.f;
     const float bg_dot = bg0 * g0 + bg1 * g1 + bg2 * g2;
     const float ddelx_dx = 0.5f * cam.W, ddely_dy = 0.5f * cam.H;
+    const float neg_tf_bg = -T_final * bg_dot;
     // Only the first max(last) entries of the tile list were blended by any pixel of the tile (k_render stops at saturation, typically
     // after a tenth of the list): the backward walk starts there, not at the end of the list, and a block's list only receives the entries
     // in front of the block's own maximum.
@@ -1099,7 +1133,26 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
 #pragma unroll
     for (int d = 8; d > 0; d >>= 1) block_last = max(block_last, __shfl_xor(block_last, d, 16));
     if ((threadIdx.x & 15) == 0) s_blast[block] = block_last;
+    // The blend loop below masks an inactive lane through three factors only; everything else it reads must be FINITE, also for a row that is
+    // past the end of its list and picks up a stale index: the staging arrays start as zeros (later batches leave finite records behind).
+    st.a[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); st.b[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); st.c[threadIdx.x] = 0.f;
+    float gmax = inside ? fmaxf(fmaxf(fabsf(g0), fabsf(g1)), fabsf(g2)) : 0.f;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, d, 64));
+    if (lane == 0) s_gmax[threadIdx.x >> 6] = gmax;
     __syncthreads();
+    gmax = fmaxf(fmaxf(s_gmax[0], s_gmax[1]), fmaxf(s_gmax[2], s_gmax[3]));
+    if (!(gmax > 0.f)) return;  // no gradient reaches this tile (uniform over the workgroup: nobody is left at a barrier)
+    int gexp;
+    (void)frexpf(gmax, &gexp);    // every |dL/dpixel| of the tile is < 2^gexp
+    gexp = max(gexp, BW_E_MIN);
+    // transposing row reduction (see the loop): the lane that ends up with column q of s_acc, its scale, and the partner-selection bits
+    const int l16 = lane & 15;
+    const bool b3 = l16 & 8, b2 = l16 & 4, b1 = l16 & 2, b0 = l16 & 1;
+    const bool q_has = !b0 || l16 == 1;
+    const int q_col = b0 ? 4 : (b3 ? 5 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);  // columns: c0 c1 c2 op mx | my cx cy cw
+    const int q_s = q_col < 3 ? BW_S_COLOR : q_col == 3 ? BW_S_OPACITY : q_col < 6 ? BW_S_MEAN : BW_S_CONIC;
+    const float q_scale = ldexpf(1.0f, q_s - gexp);
     const int blast_v = lane < N_BLOCKS ? s_blast[lane] : 0;  // lanes 0..15 of every wave: the 16 block maxima
     int n_eff = blast_v;
 #pragma unroll
@@ -1112,7 +1165,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
         __syncthreads();
         const int nb_raw = min(BATCH, n_eff - done_cnt);
 #pragma unroll
-        for (int q = 0; q < 9; q++) s_acc[threadIdx.x][q] = 0.f;
+        for (int q = 0; q < 9; q++) s_acc[threadIdx.x][q] = 0ull;
         // stage the batch; per block the list of entries whose alpha >= 1/255 ellipse box reaches it (see k_render)
         int id_l = 0;
         unsigned flags = 0;
@@ -1134,68 +1187,102 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
         }
         int n_wave;
         const int n_mine = block_lists(st, flags, &n_wave);
-        for (int jj = 0; jj < n_wave; jj++) {
+        // One list entry of this row: the record, this pixel's offset, alpha exactly as the forward computed it, and whether the pixel blended it.
+        struct Entry { float4 co; float cx, cy, dx, dy, c0, c1, c2, G, alpha; int j; bool active; };
+        auto entry = [&](int jj) {
+            Entry e;
             const uint32_t pack = list4[jj >> 2];  // four entries of this row's list per dword
-            const int j = (int)((pack >> (8 * (jj & 3))) & 0xffu);
-            const int pos = pos_top - j;
-            // branch-free like the forward loop: lanes that do not blend the Gaussian carry zeros into the sums
-            const float4 co = st.b[j];
-            const float4 xyrg = st.a[j];
-            const float dx = xyrg.x - fx, dy = xyrg.y - fy;
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-            const float G = expf(power);
-            const float alpha = fminf(0.99f, co.w * G);
-            const bool active = (jj < n_mine) & inside & (pos < last) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
-            if (__ballot(active) == 0ull) continue;  // nobody in this wave sees its Gaussian
-            const float one_minus = 1 - alpha;
-            const float r_om = __builtin_amdgcn_rcpf(one_minus);  // 1 ulp; the two quotients below feed gradients only (tolerance, not bit parity)
-            const float T_new = T * r_om;
-            const float dch = alpha * T_new;
-            const float c0 = xyrg.z, c1 = xyrg.w, c2 = st.c[j];
-            const float n_acc0 = last_alpha * lc0 + (1 - last_alpha) * acc0;
-            const float n_acc1 = last_alpha * lc1 + (1 - last_alpha) * acc1;
-            const float n_acc2 = last_alpha * lc2 + (1 - last_alpha) * acc2;
-            float dL_dalpha = (c0 - n_acc0) * g0;
-            dL_dalpha += (c1 - n_acc1) * g1;
-            dL_dalpha += (c2 - n_acc2) * g2;
-            dL_dalpha *= T_new;
-            dL_dalpha += (-T_final * r_om) * bg_dot;
-            const float dL_dG = co.w * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
-            const float dG_ddelx = -gdx * co.x - gdy * co.y;
-            const float dG_ddely = -gdy * co.z - gdx * co.y;
-            float d_c0 = active ? dch * g0 : 0.f, d_c1 = active ? dch * g1 : 0.f, d_c2 = active ? dch * g2 : 0.f;
-            float d_mx = active ? dL_dG * dG_ddelx * ddelx_dx : 0.f, d_my = active ? dL_dG * dG_ddely * ddely_dy : 0.f;
-            float d_cx = active ? -0.5f * gdx * dx * dL_dG : 0.f, d_cy = active ? -0.5f * gdx * dy * dL_dG : 0.f;
-            float d_cw = active ? -0.5f * gdy * dy * dL_dG : 0.f, d_op = active ? G * dL_dalpha : 0.f;
-            T = active ? T_new : T;
-            acc0 = active ? n_acc0 : acc0; acc1 = active ? n_acc1 : acc1; acc2 = active ? n_acc2 : acc2;
-            lc0 = active ? c0 : lc0; lc1 = active ? c1 : lc1; lc2 = active ? c2 : lc2;
-            last_alpha = active ? alpha : last_alpha;
-            // row-level reduction (row = block = one Gaussian), then ONE LDS atomic per row and quantity
-            d_c0 = row_sum_to_lane15(d_c0); d_c1 = row_sum_to_lane15(d_c1); d_c2 = row_sum_to_lane15(d_c2);
-            d_mx = row_sum_to_lane15(d_mx); d_my = row_sum_to_lane15(d_my);
-            d_cx = row_sum_to_lane15(d_cx); d_cy = row_sum_to_lane15(d_cy); d_cw = row_sum_to_lane15(d_cw); d_op = row_sum_to_lane15(d_op);
-            // keep the last DPP add of each sum out of the one-lane branch below (sunk into it, it splits into v_mov_dpp + v_add)
-            asm volatile("" : "+v"(d_c0), "+v"(d_c1), "+v"(d_c2), "+v"(d_mx), "+v"(d_my), "+v"(d_cx), "+v"(d_cy), "+v"(d_cw), "+v"(d_op));
-            if ((lane & 15) == 15 && jj < n_mine) {  // LDS atomics: the blocks that blended entry j meet here, the global atomics happen once per (tile, Gaussian)
-                float* a = s_acc[j];
-                atomicAdd(a + 0, d_c0); atomicAdd(a + 1, d_c1); atomicAdd(a + 2, d_c2); atomicAdd(a + 3, d_mx); atomicAdd(a + 4, d_my);
-                atomicAdd(a + 5, d_cx); atomicAdd(a + 6, d_cy); atomicAdd(a + 7, d_cw); atomicAdd(a + 8, d_op);
+            e.j = (int)((pack >> (8 * (jj & 3))) & 0xffu);
+            const int pos = pos_top - e.j;
+            e.co = st.b[e.j];
+            const float4 xyrg = st.a[e.j];
+            e.c0 = xyrg.z; e.c1 = xyrg.w; e.c2 = st.c[e.j];
+            e.dx = xyrg.x - fx; e.dy = xyrg.y - fy;
+            const float power = -0.5f * (e.co.x * e.dx * e.dx + e.co.z * e.dy * e.dy) - e.co.y * e.dx * e.dy;
+            e.G = expf(power);
+            e.alpha = fminf(0.99f, e.co.w * e.G);
+            e.active = (jj < n_mine) & inside & (pos < last) & !(power > 0.0f) & !(e.alpha < 1.0f / 255.0f);
+            return e;
+        };
+        // Gradient terms of one (pixel, Gaussian) pair and their row sums.  The per-Gaussian constants (0.5 W, 0.5 H, -1/2, signs) wait for the
+        // flush and multiply-add pairs are fused: tolerance-checked values, unlike alpha above, which repeats the forward's arithmetic exactly.
+        // The colour behind the current Gaussian is carried as ONE running value per channel (the reference keeps last alpha / last colour and
+        // rebuilds it every step: same recurrence).  Updates T and n0..n2; returns this lane's column of the row sums.
+        auto gradients = [&](const Entry& e) {
+            const float r_om = __builtin_amdgcn_rcpf(1 - e.alpha);  // 1 ulp; feeds gradients only (tolerance, not bit parity)
+            // three masked factors carry `active` through everything below: a lane that does not blend this Gaussian multiplies T by 1, moves its
+            // colour behind by 0 and adds 0 to every sum (all other factors are finite: alpha <= 0.99, and only G can overflow, when power > 0)
+            const float r_m = e.active ? r_om : 1.f, alpha_m = e.active ? e.alpha : 0.f, Gm = e.active ? e.G : 0.f;
+            const float T_new = T * r_m;
+            const float e0 = e.c0 - n0, e1 = e.c1 - n1, e2 = e.c2 - n2;   // colour of this Gaussian minus the colour accumulated behind it
+            float dL_dalpha = e0 * g0;
+            dL_dalpha = fmaf(e1, g1, dL_dalpha);
+            dL_dalpha = fmaf(e2, g2, dL_dalpha);
+            dL_dalpha = fmaf(neg_tf_bg, r_om, dL_dalpha * T_new);
+            const float dchm = alpha_m * T_new;
+            const float d_op = Gm * dL_dalpha;          // sum G dL/dalpha
+            const float wgt = e.co.w * d_op;            // G dL/dG
+            const float wx = wgt * e.dx, wy = wgt * e.dy;
+            const float d_mx = fmaf(wx, e.co.x, wy * e.co.y), d_my = fmaf(wy, e.co.z, wx * e.co.y);   // flushed with -0.5 W, -0.5 H
+            const float d_cx = wx * e.dx, d_cy = wx * e.dy, d_cw = wy * e.dy;                          // flushed with -1/2
+            const float d_c0 = dchm * g0, d_c1 = dchm * g1, d_c2 = dchm * g2;
+            T = T_new;
+            n0 = fmaf(alpha_m, e0, n0); n1 = fmaf(alpha_m, e1, n1); n2 = fmaf(alpha_m, e2, n2);   // = alpha c + (1 - alpha) n: what lies behind the next one
+            // Row-level reduction (row = block = one Gaussian) that also TRANSPOSES: four exchange steps with the partners lane ^ 15, ^ 7, ^ 3, ^ 1
+            // (DPP row_mirror, row_half_mirror and two quad permutations); at each step a lane keeps one half of its values and adds what the
+            // partner held of that half, so the nine sums end in nine different lanes (21 instructions; nine separate row sums took 36).
+            // Steps 1 and 2: the lanes that keep the other half sit in whole DPP banks (lanes 8-15: banks 2, 3; lanes 4-7, 12-15: banks 1, 3),
+            // so "pair sum of A, but pair sum of B in those lanes" is one unmasked and one bank-masked v_add_f32_dpp (two selects less per pair).
+            const float r0 = dpp_add2<0x140, 0xc>(d_c0, d_my), r1 = dpp_add2<0x140, 0xc>(d_c1, d_cx);
+            const float r2 = dpp_add2<0x140, 0xc>(d_c2, d_cy), r3 = dpp_add2<0x140, 0xc>(d_op, d_cw);
+            const float r4 = dpp_add<0x140>(d_mx, d_mx);
+            const float t0 = dpp_add2<0x141, 0xa>(r0, r2), t1 = dpp_add2<0x141, 0xa>(r1, r3);
+            const float t4 = dpp_add<0x141>(r4, r4);
+            const float u0 = dpp_add<0x1b>(b1 ? t1 : t0, b1 ? t0 : t1), u4 = dpp_add<0x1b>(t4, t4);
+            const float w0 = dpp_add<0xb1>(u0, u0), w4 = dpp_add<0xb1>(u4, u4);
+            return b0 ? w4 : w0;
+        };
+        // the nine sums of the row leave with ONE 64-bit integer LDS atomic
+        auto deposit = [&](int jj, int j, float mine) {
+            if (q_has && jj < n_mine) {
+                const float y = fminf(fmaxf(mine * q_scale, -0x1p61f), 0x1p61f);
+                atomicAdd(&s_acc[j][q_col], (unsigned long long)(long long)y);  // truncation: a bias of half a step of 2^-25 ... 2^-51
             }
+        };
+        // BW_PAIR entries per trip: their record reads, exponentials and reductions are independent instruction streams (only T and the
+        // running colour pass from one to the next), which is what this latency-bound loop lacks
+#if BW_PAIR
+        for (int jj = 0; jj < n_wave; jj += 2) {
+            const Entry ea = entry(jj), eb = entry(jj + 1);
+            if (__ballot(ea.active | eb.active) == 0ull) continue;  // nobody in this wave sees either Gaussian
+            const float ma = gradients(ea);
+            const float mb = gradients(eb);
+            deposit(jj, ea.j, ma);
+            deposit(jj + 1, eb.j, mb);
         }
+#else
+        for (int jj = 0; jj < n_wave; jj++) {
+            const Entry ea = entry(jj);
+            if (__ballot(ea.active) == 0ull) continue;  // nobody in this wave sees its Gaussian
+            deposit(jj, ea.j, gradients(ea));
+        }
+#endif
         __syncthreads();
         if (flags) {  // the thread that staged the entry flushes it
-            const float* a = s_acc[threadIdx.x];
-            bool any = false;
+            const unsigned long long* a = s_acc[threadIdx.x];
+            unsigned long long any = 0ull;
 #pragma unroll
-            for (int q = 0; q < 9; q++) any = any || (a[q] != 0.f);
+            for (int q = 0; q < 9; q++) any |= a[q];
             if (any) {
                 const int id = id_l;
-                atomicAdd(dL_dcolor + 3 * id, a[0]); atomicAdd(dL_dcolor + 3 * id + 1, a[1]); atomicAdd(dL_dcolor + 3 * id + 2, a[2]);
-                atomicAdd(dL_dmean2D + 3 * id, a[3]); atomicAdd(dL_dmean2D + 3 * id + 1, a[4]);
-                atomicAdd(dL_dconic + 4 * id, a[5]); atomicAdd(dL_dconic + 4 * id + 1, a[6]); atomicAdd(dL_dconic + 4 * id + 3, a[7]);
-                atomicAdd(dL_dopacity + id, a[8]);
+                const float ic = ldexpf(1.0f, gexp - BW_S_COLOR), io = ldexpf(1.0f, gexp - BW_S_OPACITY), im = ldexpf(1.0f, gexp - BW_S_MEAN),
+                            ix = ldexpf(1.0f, gexp - BW_S_CONIC);
+                auto val = [&](int q, float inv) { return (float)(long long)a[q] * inv; };
+                atomicAdd(dL_dcolor + 3 * id, val(0, ic)); atomicAdd(dL_dcolor + 3 * id + 1, val(1, ic)); atomicAdd(dL_dcolor + 3 * id + 2, val(2, ic));
+                atomicAdd(dL_dopacity + id, val(3, io));
+                atomicAdd(dL_dmean2D + 3 * id, val(4, -ddelx_dx * im)); atomicAdd(dL_dmean2D + 3 * id + 1, val(5, -ddely_dy * im));
+                atomicAdd(dL_dconic + 4 * id, val(6, -0.5f * ix)); atomicAdd(dL_dconic + 4 * id + 1, val(7, -0.5f * ix));
+                atomicAdd(dL_dconic + 4 * id + 3, val(8, -0.5f * ix));
             }
         }
     }
