@@ -347,7 +347,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam_arg, 
 #define RECT_NONE 0xffffffffu
 __global__ void __launch_bounds__(256) k_depth_keys(int P, int gx, int gy, const int32_t* __restrict__ radii, const float* __restrict__ depths,
                                                     const float* __restrict__ points_xy, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                    uint32_t* __restrict__ rects) {
+                                                    uint32_t* __restrict__ rects, uint32_t* __restrict__ digit_totals) {
+    if (blockIdx.x == 0) {  // the 4 x 256 digit totals the four counting passes add into start at zero (one launch less than a separate clear)
+#pragma unroll
+        for (int k = 0; k < 4; k++) digit_totals[256 * k + threadIdx.x] = 0u;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const int rad = radii[i];
@@ -681,6 +685,7 @@ __global__ void __launch_bounds__(1024) k_item_scan(int gx, int item_cap, const 
     }
 }
 // level 2, scatter: ids of the item's spans appended to the tiles they cover; tile (y, x) of this item starts at ranges[tile].first + cnt2[item][x]
+template <bool CAPPED>  // CAPPED: the caller fixed the length of point_list (graph capture); entries that would land behind it are dropped
 __global__ void __launch_bounds__(64) k_item_scatter(int gx, int gy, const uint32_t* __restrict__ rowtot, const uint32_t* __restrict__ roff,
                                                      const uint32_t* __restrict__ nitems, const uint32_t* __restrict__ ioff, const uint32_t* __restrict__ meta_items,
                                                      const uint2* __restrict__ spans, const uint32_t* __restrict__ cnt2, const uint32_t* __restrict__ ranges,
@@ -717,7 +722,7 @@ __global__ void __launch_bounds__(64) k_item_scatter(int gx, int gy, const uint3
                 while (lo | hi) {
                     int src;
                     if (lo) { src = __builtin_ctz(lo); lo &= lo - 1u; } else { src = 32 + __builtin_ctz(hi); hi &= hi - 1u; }
-                    if (cur[k] < list_cap) point_list[cur[k]] = ids[src];
+                    if (!CAPPED || cur[k] < list_cap) point_list[cur[k]] = ids[src];
                     cur[k]++;
                 }
             }
@@ -1064,6 +1069,16 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
     return v;
+}
+// the four accumulators of the blend backward's global atomics, cleared by one launch (3 + 4 + 1 + 3 floats per Gaussian)
+__global__ void __launch_bounds__(256) k_zero_grads(int P, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+                                                    float* __restrict__ dL_dcolor) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    dL_dmean2D[3 * i] = 0.f; dL_dmean2D[3 * i + 1] = 0.f; dL_dmean2D[3 * i + 2] = 0.f;
+    *reinterpret_cast<float4*>(dL_dconic + 4 * (size_t)i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    dL_dopacity[i] = 0.f;
+    dL_dcolor[3 * i] = 0.f; dL_dcolor[3 * i + 1] = 0.f; dL_dcolor[3 * i + 2] = 0.f;
 }
 // a + (b of the partner lane); CTRL: row_mirror 0x140 (lane ^ 15), row_half_mirror 0x141 (^ 7), quad_perm [3,2,1,0] 0x1b (^ 3), [1,0,3,2] 0xb1 (^ 1)
 template <int CTRL>
@@ -1586,7 +1601,7 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
     const int n_tiles = cam.gx * cam.gy;
     const bool lds_path = cam.gx <= SPAN_DIM_MAX && cam.gy <= SPAN_DIM_MAX && bin_hist != nullptr;
     if (instance_capacity > 0 && P > 0 && !lds_path) return NRC_ERR_UNSUPPORTED;  // the per-tile key sort fallback sizes its keys from the count
-    nrc_zero_async(tile_counts, sizeof(uint32_t) * n_tiles, s);
+    if (!(P > 0 && lds_path)) nrc_zero_async(tile_counts, sizeof(uint32_t) * n_tiles, s);  // only the global-atomic fallback counts into it
     if (P > 0) {
         if (!means3D || !opacities || !radii || !depths || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !tiles_touched || !splat_records)
             return NRC_ERR_INVALID;
@@ -1597,8 +1612,7 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
         if (lds_path) {
             const BinWs w = gs_bin_ws(bin_hist, P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P));
             // depth pre-sort of the Gaussians: 4 stable 8-bit passes, (keyA,valA) -> ... -> (keyA,valA); valA = depth order
-            hipLaunchKernelGGL(k_depth_keys, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, w.keyA, w.valA, w.rectA);
-            nrc_zero_async(w.tot, sizeof(uint32_t) * 4 * 256, s);
+            hipLaunchKernelGGL(k_depth_keys, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, w.keyA, w.valA, w.rectA, w.tot);
             for (int pass = 0; pass < 4; pass++) {
                 const uint32_t *ki = (pass & 1) ? w.keyB : w.keyA, *vi = (pass & 1) ? w.valB : w.valA, *ri = (pass & 1) ? w.rectB : w.rectA;
                 uint32_t *ko = (pass & 1) ? w.keyA : w.keyB, *vo = (pass & 1) ? w.valA : w.valB, *ro = (pass & 1) ? w.rectA : w.rectB;
@@ -1644,8 +1658,12 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
         if (!lds_path && (!keys || instance_capacity > 0)) return instance_capacity > 0 ? NRC_ERR_UNSUPPORTED : NRC_ERR_INVALID;
         if (lds_path) {
             const BinWs w = gs_bin_ws(const_cast<uint32_t*>(bin_hist), P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P));
-            hipLaunchKernelGGL(k_item_scatter, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.spans, w.cnt2, ranges,
-                               list_cap, point_list);
+            if (instance_capacity > 0)
+                hipLaunchKernelGGL(k_item_scatter<true>, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.spans, w.cnt2,
+                                   ranges, list_cap, point_list);
+            else
+                hipLaunchKernelGGL(k_item_scatter<false>, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.spans, w.cnt2,
+                                   ranges, list_cap, point_list);
         } else {
             hipLaunchKernelGGL(k_scatter, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, ranges, tile_fill, keys);
             hipLaunchKernelGGL((k_sort_tiles<0, 1024>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
@@ -1684,10 +1702,7 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
     if ((use_sh && (!shs || !dL_dsh)) || (use_sr && (!scales || !rotations || !dL_dscale || !dL_drot))) return NRC_ERR_INVALID;
     if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr) || (raw_parameters && (!opacities || !use_sr))) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    nrc_zero_async(dL_dmean2D, sizeof(float) * 3 * P, s);
-    nrc_zero_async(dL_dconic, sizeof(float) * 4 * P, s);
-    nrc_zero_async(dL_dopacity, sizeof(float) * P, s);
-    nrc_zero_async(dL_dcolor, sizeof(float) * 3 * P, s);
+    hipLaunchKernelGGL(k_zero_grads, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
     if (use_sh && M > PBW_MAXM) return NRC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_render_bw, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_order, bg[0], bg[1], bg[2],
                        camera_dev, n_contrib, final_T, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
