@@ -589,7 +589,7 @@ def main():
         if world == 1 and not args.no_gs_large:
             torch.cuda.empty_cache()
             big = build_gs_scene(device, 6_000_000)
-            gs_res['large'] = time_gs(big, reps=3, barrier=barrier)
+            gs_res['large'] = time_gs(big, reps=8, barrier=barrier)
             del big
             torch.cuda.empty_cache()
 
