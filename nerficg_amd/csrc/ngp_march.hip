@@ -353,10 +353,19 @@ __global__ void __launch_bounds__(256) k_march_wave(const float* __restrict__ ra
     bool done = !(0 <= t);
     while (!done && t < t2 && s < N) {
         float my_t = t;
+        if (c.esf == 0.f) {  // wave-uniform.  Fixed step: clamp(t * 0, lo, hi) = lo for every finite t, so the chain is one add per candidate instead of four
+            const float dt0 = calc_dt(0.f, 0.f, c.max_samples, c.grid_size, c.dt_scale);
 #pragma unroll 8
-        for (int k = 0; k < 64; k++) {
-            if (lane == k) my_t = t;
-            t += calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale);
+            for (int k = 0; k < 64; k++) {
+                if (lane == k) my_t = t;
+                t += dt0;
+            }
+        } else {
+#pragma unroll 8
+            for (int k = 0; k < 64; k++) {
+                if (lane == k) my_t = t;
+                t += calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale);
+            }
         }
         const bool valid = my_t < t2;
         float x, y, z, dt, t_target;
