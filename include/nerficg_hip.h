@@ -73,6 +73,19 @@ int nrc_raymarching_train_write(const float* rays_o, const float* rays_d, const 
                                 const float* noise, int32_t grid_size, int32_t max_samples, int64_t n_rays,
                                 const int64_t* rays_a, float* xyzs, float* dirs, float* deltas, float* ts,
                                 const void* workspace, nrc_stream_t stream);
+/* The ray preparation of InstantNGPRenderer.render_rays (Renderer.py:55-77: origin - centre, ray_aabb_intersect against the scene box,
+ * clamp of the interval to [near, far]) as ONE launch: origin_centred (n,3), spans (n,2) = (t_in, t_out), a miss is (near, -1).
+ * center3 / half3: HOST float[3].  Same values as nrc_ray_aabb_intersect + the two torch clamps. */
+int nrc_ngp_clip_rays(int64_t n_rays, const float* origin, const float* dirs, const float* center3, const float* half3,
+                      float near_plane, float far_plane, float* origin_centred, float* spans, nrc_stream_t stream);
+/* What render_rays_training does with the composited sums (Renderer.py:80-84), one launch each way: rgb_out = rgb + (1 - opacity) * bg,
+ * depth_out = depth / (opacity + 1e-6); bg_dev: DEVICE float[3].  _bw turns the gradients of (rgb_out, opacity as alpha, depth_out) --
+ * each may be NULL -- into dL_dopacity / dL_ddepth for nrc_composite_train_bw (dL_drgb is g_rgb itself).  nrc_composite_train_bw accepts
+ * NULL for dL_dopacity, dL_ddepth and dL_dws (no gradient reached that output). */
+int nrc_ngp_train_pixels_fw(int64_t n_rays, const float* opacity, const float* depth, const float* rgb, const float* bg_dev,
+                            float* rgb_out, float* depth_out, nrc_stream_t stream);
+int nrc_ngp_train_pixels_bw(int64_t n_rays, const float* g_rgb, const float* g_alpha, const float* g_depth, const float* opacity,
+                            const float* depth, const float* bg_dev, float* dL_dopacity, float* dL_ddepth, nrc_stream_t stream);
 /* Fixed-capacity variant for graph capture (no host read of counter[0] between _count and _write): call between the two passes with
  * sample buffers of `sample_capacity` rows.  Rays whose segment would cross the capacity keep the samples that fit (n_samples in rays_a is
  * cut, start_idx <= sample_capacity), rows [min(counter[0], capacity), capacity) are filled with inert samples (position = box centre,

@@ -120,10 +120,11 @@ __global__ void __launch_bounds__(256) k_composite_train_bw(
     const float R = rgb[3 * ray_idx], Gc = rgb[3 * ray_idx + 1], B = rgb[3 * ray_idx + 2];
     const float O = opacity[ray_idx], D = depth[ray_idx];
     const float gR = dL_drgb[3 * ray_idx], gG = dL_drgb[3 * ray_idx + 1], gB = dL_drgb[3 * ray_idx + 2];
-    const float gO = dL_dopacity[ray_idx], gD = dL_ddepth[ray_idx];
+    const float gO = dL_dopacity ? dL_dopacity[ray_idx] : 0.f, gD = dL_ddepth ? dL_ddepth[ray_idx] : 0.f;  // NULL: no gradient reached that output
     // pass 1: sum over the whole ray of dL_dws * ws  (volumerendering.cu:119-123)
     float part = 0.f;
-    for (int c = lane; c < N; c += 64) part += dL_dws[start + c] * ws[start + c];
+    if (dL_dws)
+        for (int c = lane; c < N; c += 64) part += dL_dws[start + c] * ws[start + c];
     const float dws_sum = nrc_group_sum<64>(part);
     // pass 2
     float carry = 1.0f, cr_ = 0.f, cg_ = 0.f, cb_ = 0.f, cd_ = 0.f, cs_ = 0.f;  // running prefix carries
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(256) k_composite_train_bw(
             dl = deltas[s];
             a = alpha_of(sigmas[s], dl);
             sr = rgbs[3 * s]; sg = rgbs[3 * s + 1]; sb = rgbs[3 * s + 2];
-            tt = ts[s]; gw = dL_dws[s]; wsv = ws[s];
+            tt = ts[s]; gw = dL_dws ? dL_dws[s] : 0.f; wsv = ws[s];
         }
         float Tb, Ta;
         chunk_transmittance<64>(a, lane, carry, Tb, Ta);
@@ -410,6 +411,35 @@ __global__ void __launch_bounds__(256) k_composite_layers(const __half* __restri
 
 }  // namespace
 
+// ---- training pixels: what InstantNGPRenderer.render_rays_training does with the composited sums (Renderer.py:80-84) as one launch each way ----
+// rgb_out = rgb + (1 - opacity) * bg,  depth_out = depth / (opacity + 1e-6)  (same operation order as the torch expressions they replace)
+__global__ void __launch_bounds__(256) k_train_pixels_fw(int64_t n, const float* __restrict__ opacity, const float* __restrict__ depth,
+                                                         const float* __restrict__ rgb, const float* __restrict__ bg, float* __restrict__ rgb_out,
+                                                         float* __restrict__ depth_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float see_through = 1 - opacity[i];
+#pragma unroll
+    for (int c = 0; c < 3; c++) rgb_out[3 * i + c] = rgb[3 * i + c] + see_through * bg[c];
+    depth_out[i] = depth[i] / (opacity[i] + 1e-6f);
+}
+__global__ void __launch_bounds__(256) k_train_pixels_bw(int64_t n, const float* __restrict__ g_rgb, const float* __restrict__ g_alpha,
+                                                         const float* __restrict__ g_depth, const float* __restrict__ opacity,
+                                                         const float* __restrict__ depth, const float* __restrict__ bg, float* __restrict__ dL_dopacity,
+                                                         float* __restrict__ dL_ddepth) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float gO = g_alpha ? g_alpha[i] : 0.f, gD = 0.f;
+    if (g_rgb) gO -= g_rgb[3 * i] * bg[0] + g_rgb[3 * i + 1] * bg[1] + g_rgb[3 * i + 2] * bg[2];
+    if (g_depth) {
+        const float den = opacity[i] + 1e-6f;
+        gD = g_depth[i] / den;
+        gO -= g_depth[i] * depth[i] / (den * den);
+    }
+    dL_dopacity[i] = gO;
+    dL_ddepth[i] = gD;
+}
+
 static void zero_arrays(hipStream_t s, void* p0, int64_t b0, void* p1 = nullptr, int64_t b1 = 0, void* p2 = nullptr, int64_t b2 = 0, void* p3 = nullptr,
                         int64_t b3 = 0, void* p4 = nullptr, int64_t b4 = 0) {
     ZeroList z;
@@ -480,10 +510,32 @@ int nrc_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
         zero_arrays(s, dL_dsigmas, n_samples * 4, dL_drgbs, n_samples * 12);
     }
     if (n_rays == 0 || n_samples == 0) return NRC_OK;
-    if (!dL_dopacity || !dL_ddepth || !dL_drgb || !dL_dws || !sigmas || !rgbs || !ws || !deltas || !ts || !rays_a || !opacity || !depth || !rgb)
-        return NRC_ERR_INVALID;
+    if (!dL_drgb || !sigmas || !rgbs || !ws || !deltas || !ts || !rays_a || !opacity || !depth || !rgb) return NRC_ERR_INVALID;
     hipLaunchKernelGGL(k_composite_train_bw, dim3(nrc_cdiv(n_rays, 4)), dim3(256), 0, s, dL_dopacity, dL_ddepth, dL_drgb, dL_dws,
                        sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb, n_rays, T_threshold, dL_dsigmas, dL_drgbs);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_ngp_train_pixels_fw(int64_t n_rays, const float* opacity, const float* depth, const float* rgb, const float* bg_dev, float* rgb_out,
+                            float* depth_out, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_rays < 0) return NRC_ERR_INVALID;
+    if (n_rays == 0) return NRC_OK;
+    if (!opacity || !depth || !rgb || !bg_dev || !rgb_out || !depth_out) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_train_pixels_fw, dim3(nrc_cdiv(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, n_rays, opacity, depth, rgb, bg_dev, rgb_out,
+                       depth_out);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_ngp_train_pixels_bw(int64_t n_rays, const float* g_rgb, const float* g_alpha, const float* g_depth, const float* opacity, const float* depth,
+                            const float* bg_dev, float* dL_dopacity, float* dL_ddepth, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_rays < 0) return NRC_ERR_INVALID;
+    if (n_rays == 0) return NRC_OK;
+    if (!opacity || !depth || !bg_dev || !dL_dopacity || !dL_ddepth) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_train_pixels_bw, dim3(nrc_cdiv(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, n_rays, g_rgb, g_alpha, g_depth, opacity, depth,
+                       bg_dev, dL_dopacity, dL_ddepth);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

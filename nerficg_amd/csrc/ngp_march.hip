@@ -230,6 +230,28 @@ __global__ void k_ray_prim_intersect(const float* __restrict__ rays_o, const flo
     if (max_hits > 1) sort_hits(ht, hv, max_hits);
 }
 
+// Box-centred origins and the [t_in, t_out] span of every ray in ONE launch: what InstantNGPRenderer.render_rays does with a subtraction, the
+// slab test against the scene box (the expressions of k_ray_prim_intersect with the box at the origin) and two clamps (Renderer.py:55-77).
+__global__ void __launch_bounds__(256) k_clip_rays(int64_t n, const float* __restrict__ origin, const float* __restrict__ dirs, float cx, float cy, float cz,
+                                                   float hx, float hy, float hz, float near_plane, float far_plane, float* __restrict__ o_out,
+                                                   float* __restrict__ span) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const float ox = origin[3 * r] - cx, oy = origin[3 * r + 1] - cy, oz = origin[3 * r + 2] - cz;
+    o_out[3 * r] = ox; o_out[3 * r + 1] = oy; o_out[3 * r + 2] = oz;
+    const float ix = 1.0f / dirs[3 * r], iy = 1.0f / dirs[3 * r + 1], iz = 1.0f / dirs[3 * r + 2];
+    const float ax = (0.0f - hx - ox) * ix, bx = (0.0f + hx - ox) * ix;
+    const float ay = (0.0f - hy - oy) * iy, by = (0.0f + hy - oy) * iy;
+    const float az = (0.0f - hz - oz) * iz, bz = (0.0f + hz - oz) * iz;
+    float t1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    float t2 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    if (t1 > t2) { t1 = -1.0f; t2 = -1.0f; }
+    float s0 = -1.0f, s1 = -1.0f;
+    if (t2 > 0) { s0 = fmaxf(t1, 0.0f); s1 = t2; }
+    span[2 * r] = fmaxf(s0, near_plane);      // a miss stays (near, -1): an empty interval
+    span[2 * r + 1] = fminf(s1, far_plane);
+}
+
 // ------------------------------------------------------------------------------------------------ ray marching (train)
 // Stage A: per-ray sample count (pass 1 of raymarching.cu:200-234) + per-block sums.
 __global__ void __launch_bounds__(256) k_march_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -918,6 +940,17 @@ int nrc_raymarching_train_write(const float* rays_o, const float* rays_d, const 
     else
         hipLaunchKernelGGL(k_march_write, dim3(nrc_cdiv(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, hits_t,
                            noise, c, n_rays, rays_a, xyzs, dirs, deltas, ts);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_ngp_clip_rays(int64_t n_rays, const float* origin, const float* dirs, const float* center3, const float* half3, float near_plane,
+                      float far_plane, float* origin_centred, float* spans, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_rays < 0 || !center3 || !half3) return NRC_ERR_INVALID;
+    if (n_rays == 0) return NRC_OK;
+    if (!origin || !dirs || !origin_centred || !spans) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_clip_rays, dim3(nrc_cdiv(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, n_rays, origin, dirs, center3[0], center3[1], center3[2],
+                       half3[0], half3[1], half3[2], near_plane, far_plane, origin_centred, spans);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

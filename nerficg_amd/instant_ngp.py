@@ -27,7 +27,7 @@ import torch
 from . import VolumeRenderingV2 as VolumeRenderingCuda
 from . import _lib
 from . import tinycudann as tcnn
-from .ngp import query_fused, query_train
+from .ngp import composite_over_background, query_fused, query_train
 from .raygen import generate_rays
 
 
@@ -122,6 +122,7 @@ class InstantNGPRenderer:
         self.density_threshold = DENSITY_THRESHOLD * MAX_SAMPLES / 3 ** 0.5
         self._fused_ws: dict = {}
         self._box_host = None
+        self._scene_box_host = None
         self._zero_center = torch.zeros(1, 3, device=model.center.device)
         # fused image path: the count pass parks the samples in a max_samples-row arena per tile (2.6 GB at 800x800) and the write pass
         # copies them instead of marching every ray twice; False = second march, no arena
@@ -136,6 +137,13 @@ class InstantNGPRenderer:
             m = self.model
             self._box_host = (m.xyz_min.detach().float().cpu().contiguous(), m.xyz_size.detach().float().cpu().contiguous())
         return self._box_host
+
+    def _scene_box(self):
+        """(centre, half size) of the scene box as host tensors, read once."""
+        if self._scene_box_host is None:
+            m = self.model
+            self._scene_box_host = (m.center.detach().float().reshape(-1).cpu().contiguous(), m.half_size.detach().float().reshape(-1).cpu().contiguous())
+        return self._scene_box_host
 
     def query(self, xyzs: torch.Tensor, dirs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """(density, colour) of box-centred sample positions seen along unit directions.  With autograd on: one node that reaches both
@@ -155,12 +163,16 @@ class InstantNGPRenderer:
     # ---------------------------------------------------------------- rays
     def clip_rays(self, origin: torch.Tensor, view_direction: torch.Tensor, camera: Camera):
         """Box-centred origins, contiguous directions and the [t_in, t_out] interval of every ray inside the scene box, clipped to the
-        camera's depth range (a miss is (-1, -1) before clipping and yields no sample)."""
-        o = (origin - self.model.center).contiguous()
-        d = view_direction.contiguous()
-        span = VolumeRenderingCuda.ray_aabb_intersect(o, d, self._zero_center, self.model.half_size, 1)[1][:, 0]
-        span[:, 0].clamp_(min=camera.near_plane)
-        span[:, 1].clamp_(max=camera.far_plane)
+        camera's depth range (a miss is (near, -1): an empty interval) -- one launch (nrc_ngp_clip_rays)."""
+        origin, d = origin.contiguous(), view_direction.contiguous()
+        _lib.check_input(origin, 'origin', torch.float32)
+        _lib.check_input(d, 'view_direction', torch.float32)
+        n = origin.shape[0]
+        o = torch.empty_like(origin)
+        span = torch.empty(n, 2, dtype=torch.float32, device=origin.device)
+        center, half = self._scene_box()
+        _lib.check(_lib.load().nrc_ngp_clip_rays(n, _lib.ptr(origin), _lib.ptr(d), _lib.ptr(center), _lib.ptr(half), float(camera.near_plane),
+                                                 float(camera.far_plane), _lib.ptr(o), _lib.ptr(span), _lib.stream_of(origin)), 'ngp_clip_rays')
         return o, d, span
 
     def render_rays(self, origin: torch.Tensor, view_direction: torch.Tensor, camera: Camera, train_mode: bool = False,
@@ -183,10 +195,9 @@ class InstantNGPRenderer:
         jitter = torch.rand(o.shape[0], device=o.device) if noise is None else noise.to(torch.float32).contiguous()
         rays_a, xyzs, dirs, deltas, ts, counter = self._march(o, d, span, step_growth, jitter)
         sigmas, rgbs = self.query(xyzs, dirs)
-        _, alpha, depth_sum, radiance, _ = VolumeRenderingCuda.VolumeRenderer.apply(sigmas, rgbs.contiguous(), deltas, ts, rays_a, self.T_THRESHOLD)
-        see_through = (1 - alpha)[:, None]
-        # training depth: weighted mean with a guarded denominator (Renderer.py:82)
-        return {'rgb': radiance + see_through * bg, 'alpha': alpha, 'depth': depth_sum / (alpha + 1e-6), 'rm_samples': counter[0]}
+        # compositing, background and the training depth (weighted mean with a guarded denominator, Renderer.py:78-84) as one autograd node
+        rgb, alpha, depth = composite_over_background(sigmas, rgbs, deltas, ts, rays_a, bg, self.T_THRESHOLD)
+        return {'rgb': rgb, 'alpha': alpha, 'depth': depth, 'rm_samples': counter[0]}
 
     @torch.no_grad()
     def _render_ray_list(self, o, d, span, bg, step_growth):

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-__all__ = ['query_fused', 'query_train']
+__all__ = ['query_fused', 'query_train', 'composite_over_background']
 
 
 def query_fused(density_net, color_net, xyz01: torch.Tensor, dirs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
@@ -88,3 +88,49 @@ def query_train(density_net, color_net, xyzs: torch.Tensor, dirs: torch.Tensor, 
     _lib.check_input(xyzs, 'xyzs', torch.float32)
     _lib.check_input(dirs, 'dirs', torch.float32)
     return _QueryTrain.apply(xyzs, dirs, density_net.params, color_net.params, density_net, color_net, xyz_min, xyz_size)
+
+
+class _CompositeOverBackground(torch.autograd.Function):
+    """Compositing of a training batch and the pixel arithmetic behind it (Renderer.py:78-84: rgb + (1 - alpha) * bg, depth / (alpha + 1e-6))
+    as ONE autograd node: two launches forward, two backward, instead of the compositing node plus ~5 + ~8 element-wise torch kernels."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(cast_inputs=torch.float32, device_type='cuda')
+    def forward(ctx, sigmas, rgbs, deltas, ts, rays_a, bg, cutoff):
+        from . import VolumeRenderingV2 as vr
+        _, opacity, depth, rgb, ws = vr.composite_train_fw(sigmas, rgbs.contiguous(), deltas, ts, rays_a, cutoff)
+        n = rays_a.shape[0]
+        bg = bg.to(device=opacity.device, dtype=torch.float32).contiguous()
+        rgb_out, depth_out = torch.empty_like(rgb), torch.empty_like(depth)
+        _lib.check(_lib.load().nrc_ngp_train_pixels_fw(n, _lib.ptr(opacity), _lib.ptr(depth), _lib.ptr(rgb), _lib.ptr(bg), _lib.ptr(rgb_out),
+                                                       _lib.ptr(depth_out), _lib.stream_of(opacity)), 'ngp_train_pixels_fw')
+        ctx.save_for_backward(sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb, bg)
+        ctx.cutoff = float(cutoff)
+        return rgb_out, opacity, depth_out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, g_rgb, g_alpha, g_depth):
+        sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb, bg = ctx.saved_tensors
+        lib = _lib.load()
+        n, m = rays_a.shape[0], sigmas.shape[0]
+        f32 = torch.float32
+        dense = lambda g: None if g is None else g.to(f32).contiguous()
+        g_rgb, g_alpha, g_depth = dense(g_rgb), dense(g_alpha), dense(g_depth)
+        d_op, d_depth = torch.empty(n, dtype=f32, device=opacity.device), torch.empty(n, dtype=f32, device=opacity.device)
+        st = _lib.stream_of(opacity)
+        _lib.check(lib.nrc_ngp_train_pixels_bw(n, _lib.ptr(g_rgb), _lib.ptr(g_alpha), _lib.ptr(g_depth), _lib.ptr(opacity), _lib.ptr(depth), _lib.ptr(bg),
+                                               _lib.ptr(d_op), _lib.ptr(d_depth), st), 'ngp_train_pixels_bw')
+        if g_rgb is None:
+            g_rgb = torch.zeros(n, 3, dtype=f32, device=opacity.device)
+        d_sigmas = torch.empty(m, dtype=f32, device=opacity.device)
+        d_rgbs = torch.empty(m, 3, dtype=f32, device=opacity.device)
+        _lib.check(lib.nrc_composite_train_bw(_lib.ptr(d_op), _lib.ptr(d_depth), _lib.ptr(g_rgb), None, _lib.ptr(sigmas), _lib.ptr(rgbs), _lib.ptr(ws),
+                                              _lib.ptr(deltas), _lib.ptr(ts), _lib.ptr(rays_a), _lib.ptr(opacity), _lib.ptr(depth), _lib.ptr(rgb), n, m,
+                                              ctx.cutoff, _lib.ptr(d_sigmas), _lib.ptr(d_rgbs), st), 'composite_train_bw')
+        return d_sigmas, d_rgbs, None, None, None, None, None
+
+
+def composite_over_background(sigmas, rgbs, deltas, ts, rays_a, bg, T_threshold: float):
+    """-> (rgb over `bg`, alpha, depth / (alpha + 1e-6)) of a training batch; differentiable w.r.t. sigmas / rgbs."""
+    return _CompositeOverBackground.apply(sigmas, rgbs, deltas, ts, rays_a, bg, T_threshold)
