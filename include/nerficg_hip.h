@@ -372,7 +372,10 @@ int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int3
  *            effective step count stands still on an overflow-skipped step (with apex the scaler does not call step() then)
  *            without a host read of found_inf.  With device_step (optional DEVICE int32, apex's capturable mode) host_step / skipped_steps are
  *            not used: the kernel advances *device_step itself unless *found_inf != 0, so a step recorded in a HIP graph counts on replay.
- *            lr_dev (optional DEVICE float) overrides lr for the same reason.  param_f16_out (optional): the updated parameters are also written as fp16 --
+ *            lr_dev (optional DEVICE float) overrides lr for the same reason.  l2_slice_coeff / l2_slice_count: the gradient of the first
+ *            l2_slice_count elements gets + l2_slice_coeff * parameter -- the reference's weight-decay LOSS term on the MLP weights in front of
+ *            the hash table (InstantNGP/Model.py:38-44, Loss.py:15: 0.5e-6 * mean w^2 -> coeff 1e-6 / n) applied where the parameters are
+ *            read anyway, instead of a dense 12 M-element gradient through autograd; 0 / 0 = off.  param_f16_out (optional): the updated parameters are also written as fp16 --
  *            the compute copy the tinycudann replacement reads (Group 3), which therefore can never go stale after a step.
  * ===================================================================================================== */
 int nrc_adam_prepare(int32_t host_step, float beta1, float beta2, const float* found_inf, int32_t* skipped_steps,
@@ -380,7 +383,7 @@ int nrc_adam_prepare(int32_t host_step, float beta1, float beta2, const float* f
 int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t adam_w_mode, float bias_correction1,
                   float bias_correction2, const float* bias_corrections_dev, const float* lr_dev, const float* grad_scale,
-                  const float* found_inf, void* param_f16_out, nrc_stream_t stream);
+                  const float* found_inf, void* param_f16_out, float l2_slice_coeff, int64_t l2_slice_count, nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 9 -- mean squared distance to the 3 nearest neighbours (3DGS scale initialisation): replaces simple_knn._C.distCUDA2

@@ -42,6 +42,16 @@ class FusedAdam(torch.optim.Optimizer):
         self.capturable = bool(capturable)
         self._amp = {}  # group index -> (skipped-step counter i32[1], bias corrections f32[2]) on the device
         self._lr_dev = {}  # capturable: group index -> [device f32[1], the host value it holds]
+        self._l2_slices = {}  # id(parameter) -> (count, coefficient): see set_l2_slice
+
+    def set_l2_slice(self, param: torch.Tensor, count: int, coeff: float) -> None:
+        """The step adds coeff * p to the gradient of the first `count` elements of `param` (not in apex).  A loss term lambda * mean(w^2) over
+        such a slice has exactly this gradient with coeff = 2 lambda / n, also under a GradScaler (scaled with the loss, unscaled in the
+        step); taking it here spares autograd a dense gradient of the whole parameter for a few thousand weights.  count = 0 removes it."""
+        if count <= 0:
+            self._l2_slices.pop(id(param), None)
+        else:
+            self._l2_slices[id(param)] = (int(count), float(coeff))
 
     def effective_step(self, group) -> int:
         """Step count that entered the bias corrections: group['step'] minus the overflow-skipped steps (host read, for tests / logging)."""
@@ -128,10 +138,11 @@ class FusedAdam(torch.optim.Optimizer):
                 owner = getattr(p, '_nrc_half_owner', None)
                 owner = owner() if owner is not None else None
                 half = owner._half_for_optimizer(p) if owner is not None else None
+                l2 = self._l2_slices.get(id(p), (0, 0.0))
                 _lib.check(lib.nrc_adam_step(
                     _lib.ptr(p), _lib.ptr(g), _lib.ptr(state['exp_avg']), _lib.ptr(state['exp_avg_sq']), p.numel(), float(group['lr']), float(beta1),
                     float(beta2), float(group['eps']), float(group['weight_decay']), self.adam_w_mode, float(bc1), float(bc2), _lib.ptr(bc_dev),
-                    _lib.ptr(lr_dev), _lib.ptr(grad_scale), _lib.ptr(found_inf), _lib.ptr(half), _lib.stream_of(p)), 'adam_step')
+                    _lib.ptr(lr_dev), _lib.ptr(grad_scale), _lib.ptr(found_inf), _lib.ptr(half), l2[1], l2[0], _lib.stream_of(p)), 'adam_step')
                 # the kernel writes through a raw pointer: tell autograd (and every version-keyed cache) that p changed
                 torch.autograd.graph.increment_version(p)
                 if owner is not None:

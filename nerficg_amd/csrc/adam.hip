@@ -36,7 +36,7 @@ template <bool ALIGNED>
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                                               float lr, float beta1, float beta2, float eps, float weight_decay, int adam_w_mode, float bc1, float bc2,
                                               const float* __restrict__ bc_dev, const float* __restrict__ lr_dev, const float* __restrict__ grad_scale,
-                                              const float* __restrict__ found_inf, __half* __restrict__ p16) {
+                                              const float* __restrict__ found_inf, __half* __restrict__ p16, float l2_coeff, int64_t l2_count) {
     if (found_inf && *found_inf != 0.f) return;  // GradScaler: skip the step, keep the state (and the fp16 copy, which still matches)
     if (bc_dev) { bc1 = bc_dev[0]; bc2 = bc_dev[1]; }
     if (lr_dev) lr = *lr_dev;
@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     for (int k = 0; k < 4; k++) {
         float gr = gv[k] * inv_scale;
         if (!adam_w_mode) gr += weight_decay * pv[k];  // L2 mode (apex multi_tensor_adam ADAM_MODE_0)
+        if (i0 + k < l2_count) gr += l2_coeff * pv[k];  // L2 term of the first l2_count elements only (the MLP weights in front of a hash table)
         mv[k] = beta1 * mv[k] + (1.f - beta1) * gr;
         vv[k] = beta2 * vv[k] + (1.f - beta2) * gr * gr;
         const float m_hat = mv[k] / bc1, v_hat = vv[k] / bc2;
@@ -102,7 +103,8 @@ int nrc_adam_prepare(int32_t host_step, float beta1, float beta2, const float* f
 
 int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t adam_w_mode, float bias_correction1, float bias_correction2, const float* bias_corrections_dev,
-                  const float* lr_dev, const float* grad_scale, const float* found_inf, void* param_f16_out, nrc_stream_t stream) {
+                  const float* lr_dev, const float* grad_scale, const float* found_inf, void* param_f16_out, float l2_slice_coeff,
+                  int64_t l2_slice_count, nrc_stream_t stream) {
     NRC_ENTER();
     if (n < 0 || (!bias_corrections_dev && (!(bias_correction1 > 0.f) || !(bias_correction2 > 0.f)))) return NRC_ERR_INVALID;
     if (n == 0) return NRC_OK;
@@ -111,10 +113,12 @@ int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     const dim3 grid((unsigned)nrc_cdiv(nrc_cdiv(n, 4), 256));
     if (aligned)
         hipLaunchKernelGGL(k_adam<true>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
-                           (int)adam_w_mode, bias_correction1, bias_correction2, bias_corrections_dev, lr_dev, grad_scale, found_inf, (__half*)param_f16_out);
+                           (int)adam_w_mode, bias_correction1, bias_correction2, bias_corrections_dev, lr_dev, grad_scale, found_inf, (__half*)param_f16_out, l2_slice_coeff,
+                           l2_slice_count);
     else
         hipLaunchKernelGGL(k_adam<false>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
-                           (int)adam_w_mode, bias_correction1, bias_correction2, bias_corrections_dev, lr_dev, grad_scale, found_inf, (__half*)param_f16_out);
+                           (int)adam_w_mode, bias_correction1, bias_correction2, bias_corrections_dev, lr_dev, grad_scale, found_inf, (__half*)param_f16_out, l2_slice_coeff,
+                           l2_slice_count);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -155,6 +155,48 @@ def test_instant_ngp_iteration_trains_and_reports_overflow():
         assert int(out['sample_overflow']) > 0 and np.isfinite(float(out['loss']))
 
 
+def test_folded_weight_decay_gives_the_update_of_the_loss_term():
+    """0.5e-6 * mean(w^2) as a loss term (InstantNGP/Loss.py:15) against the same gradient added inside the Adam kernel (FusedAdam.set_l2_slice):
+    one step from identical models on an identical batch, with a weight decay 1e6 times the reference's so that it shows in the update."""
+    from nerficg_amd.apex_optimizers import FusedAdam
+    cam, o, d = _rays()
+    n = 2048
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    ids = torch.randint(0, o.shape[0], (n,), device=DEV, generator=gen)
+    rgb, bg, noise = torch.rand(n, 3, device=DEV, generator=gen), torch.rand(3, device=DEV, generator=gen), torch.rand(n, device=DEV, generator=gen)
+    lam = 0.5
+    results = []
+    for folded in (False, True):
+        model, renderer, scaler = _train_pair(seed=6)
+        opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
+        if folded:
+            opt.set_l2_slice(model.encoding_xyz.params, model.n_params_encoding_mlp, 2 * lam / model.n_mlp_params)
+            opt.set_l2_slice(model.color_mlp_with_encoding.params, model.color_mlp_with_encoding.params.numel(), 2 * lam / model.n_mlp_params)
+        for _ in range(2):
+            with torch.amp.autocast('cuda'):
+                out = renderer.render_rays(o[ids], d[ids], cam, train_mode=True, custom_bg_color=bg, noise=noise)
+                loss = torch.nn.functional.mse_loss(out['rgb'].float(), rgb)
+                if not folded:
+                    loss = loss + lam * model.weight_decay_mlp()
+            scaler.scale(loss).backward()
+            scaler.step(opt); scaler.update(); opt.zero_grad()
+        results.append([p.detach().clone() for p in model.parameters()])
+    for a, b in zip(*results):
+        far = (a - b).abs() > 1e-5 + 1e-3 * a.abs()
+        assert float(far.float().mean()) < 1e-3, float(far.float().mean())
+    # and the term matters at this strength: without it the MLP weights end elsewhere
+    model, renderer, scaler = _train_pair(seed=6)
+    opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
+    for _ in range(2):
+        with torch.amp.autocast('cuda'):
+            out = renderer.render_rays(o[ids], d[ids], cam, train_mode=True, custom_bg_color=bg, noise=noise)
+            loss = torch.nn.functional.mse_loss(out['rgb'].float(), rgb)
+        scaler.scale(loss).backward()
+        scaler.step(opt); scaler.update(); opt.zero_grad()
+    plain = model.color_mlp_with_encoding.params.detach()
+    assert float((plain - results[0][1]).abs().mean()) > 10 * float((results[1][1] - results[0][1]).abs().mean())
+
+
 def test_capture_without_a_sample_capacity_is_refused():
     from nerficg_amd import VolumeRenderingV2 as vr
     _, args = _march_inputs()
