@@ -310,6 +310,10 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=15):
     restore()
     res = {'metric': 'InstantNGP training iteration (drop-in modules, fwd + bwd + Adam)', 'ms_per_iteration': round(dt * 1e3, 3), 'rays': n_rays,
            'samples_per_iteration': int(tot / iters), 'msamples_per_s': round(tot / iters / dt / 1e6, 1)}
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():  # N > 1: no recording next to a live RCCL communicator (its watchdog thread polls events)
+        res['hip_graph'] = None
+        return res
     # the same iteration recorded once in a HIP graph (nerficg_amd.graphs): fixed sample capacity, batch gathered from the resident ray pool
     # inside the recording, step counter / learning rate on the device.  One graph launch + one index copy per iteration.
     from nerficg_amd.graphs import instant_ngp_iteration
