@@ -270,7 +270,7 @@ def cpu_baseline(cam_full, pose, model_params, crop=160):
             'msamples_per_s': round(int(counter[0]) / dt / 1e6, 4)}
 
 
-def time_train(model, renderer, cam, poses, n_rays=2200, iters=15):
+def time_train(model, renderer, cam, poses, n_rays=2200, iters=60):
     """InstantNGP training iteration through the drop-in modules (Trainer.py:79-94 sequence: sample rays -> render_rays training
     path -> MSE + weight decay -> GradScaler(128) backward -> Adam), rank 0 only, reported next to the headline metric."""
     import torch
