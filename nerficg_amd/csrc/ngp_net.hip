@@ -1021,36 +1021,57 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
 #pragma unroll
     for (int a = 0; a < (N_HIDDEN > 1 ? 2 : 1); a++) { gW1[a][0] = zero16(); gW1[a][1] = zero16(); }
 
+    // The saved forward state of a tile (input, hidden activations, output and its gradient: 13 or 21 loads per lane) is requested one tile ahead:
+    // with one wave per SIMD nothing else covers the ~2 us a dependent global load takes under load.
+    struct TileState { h8 X[2], H0[4], H1[4], g, y; };
+    auto fetch = [&](int64_t tile, TileState& t) {
+        const int64_t i = tile * 32 + r;
+        const int64_t ic = i < M ? i : M - 1;
+        const _Float16* xin = reinterpret_cast<const _Float16*>(save_in) + ic * 32;
+        t.X[0] = *reinterpret_cast<const h8*>(xin + 8 * hh); t.X[1] = *reinterpret_cast<const h8*>(xin + 16 + 8 * hh);
+        const _Float16* a0 = reinterpret_cast<const _Float16*>(save_acts) + ic * 64;
+#pragma unroll
+        for (int s = 0; s < 4; s++) t.H0[s] = load_acc_order_frag(a0, s, hh);
+        if constexpr (N_HIDDEN > 1) {
+            const _Float16* a1 = reinterpret_cast<const _Float16*>(save_acts) + ((int64_t)M + ic) * 64;
+#pragma unroll
+            for (int s = 0; s < 4; s++) t.H1[s] = load_acc_order_frag(a1, s, hh);
+        }
+        // rows 8 hh .. 8 hh + 7 of the (padded) output row: 16 bytes when the row has 16 entries, the first 4 (8 bytes, hh = 0) when it has 4
+        const _Float16* gp = reinterpret_cast<const _Float16*>(d_out) + ic * out_ld;
+        const _Float16* yp = reinterpret_cast<const _Float16*>(out) + ic * out_ld;
+        t.g = zero_h8(); t.y = zero_h8();
+        if (out_ld == 16) {
+            t.g = *reinterpret_cast<const h8*>(gp + 8 * hh);
+            if constexpr (OUT_ACT == ACT_SIGMOID) t.y = *reinterpret_cast<const h8*>(yp + 8 * hh);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int row = 8 * hh + j;
+                if (row < out_ld) { t.g[j] = gp[row]; if constexpr (OUT_ACT == ACT_SIGMOID) t.y[j] = yp[row]; }
+            }
+        }
+    };
+    TileState nxt;
+    if (wave0 < n_tiles) fetch(wave0, nxt);
     for (int64_t tile = wave0; tile < n_tiles; tile += n_waves) {
         const int64_t i = tile * 32 + r;
         const bool valid = i < M;
-        const int64_t ic = valid ? i : M - 1;
-        // ---- saved forward state of this sample
-        const _Float16* xin = reinterpret_cast<const _Float16*>(save_in) + ic * 32;
-        h8 X[2] = {*reinterpret_cast<const h8*>(xin + 8 * hh), *reinterpret_cast<const h8*>(xin + 16 + 8 * hh)};
-        h8 H0[4], H1[4];
-        {
-            const _Float16* a0 = reinterpret_cast<const _Float16*>(save_acts) + ic * 64;
-#pragma unroll
-            for (int s = 0; s < 4; s++) H0[s] = load_acc_order_frag(a0, s, hh);
-            if constexpr (N_HIDDEN > 1) {
-                const _Float16* a1 = reinterpret_cast<const _Float16*>(save_acts) + ((int64_t)M + ic) * 64;
-#pragma unroll
-                for (int s = 0; s < 4; s++) H1[s] = load_acc_order_frag(a1, s, hh);
-            }
-        }
-        h8 (&HL)[4] = N_HIDDEN > 1 ? H1 : H0;  // last hidden layer
+        const TileState cur = nxt;
+        if (tile + n_waves < n_tiles) fetch(tile + n_waves, nxt);
+        const h8 (&X)[2] = cur.X;
+        const h8 (&H0)[4] = cur.H0;
+        const h8 (&H1)[4] = cur.H1;
+        const h8 (&HL)[4] = N_HIDDEN > 1 ? cur.H1 : cur.H0;  // last hidden layer
         // ---- dZ of the output layer (natural order over the 16 padded output rows)
         h8 dZo = zero_h8();
         if (valid) {
-            const _Float16* g = reinterpret_cast<const _Float16*>(d_out) + i * out_ld;
-            const _Float16* y = reinterpret_cast<const _Float16*>(out) + i * out_ld;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int row = 8 * hh + j;
                 if (row < out_ld) {
-                    float v = (float)g[row];
-                    if constexpr (OUT_ACT == ACT_SIGMOID) { const float yy = (float)y[row]; v = v * yy * (1.f - yy); }
+                    float v = (float)cur.g[j];
+                    if constexpr (OUT_ACT == ACT_SIGMOID) { const float yy = (float)cur.y[j]; v = v * yy * (1.f - yy); }
                     dZo[j] = (_Float16)(v * loss_scale);
                 }
             }
@@ -1132,20 +1153,43 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
             }
         }
     }
-    // ---- flush the wave's weight-gradient accumulators (layout of W): two 128-byte row segments per atomic instruction
+    // ---- flush the weight-gradient accumulators (layout of W).  The four waves of the workgroup first add their tiles up through LDS (the
+    // staging area is free now), tile after tile with two alternating slots, and ONE wave per tile issues the global atomics: with one flush
+    // per wave the 1 024 waves of a launch queued 1 024 float atomics on each of the 3 072 / 7 168 addresses (54 of the 160 us of the two
+    // backward launches of a training iteration), now 256.
     float* gW0p = dW;
     float* gW1p = dW + 64 * 32;
     float* gWop = dW + 64 * 32 + (N_HIDDEN - 1) * 64 * 64;
+    float* red = reinterpret_cast<float*>(&lds[0][0][0]);   // [2 slots][4 waves][16 registers][64 lanes] f32 = 32 KB of the 40 KB
+    int tile_no = 0;
+    auto reduce_flush = [&](float* G, int ld, int n_rows, int mt, int nt, f16v acc) {
+        float* slot = red + (tile_no & 1) * 4096;
+        __syncthreads();   // the slot's previous tile (two tiles ago) has been read; first tile: every wave has left the sample loop
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++) atomic_add_tile(gW0p, 32, 64, mt, 0, gW0[mt], inv_scale, r, hh);
+        for (int reg = 0; reg < 16; reg++) slot[(wv * 16 + reg) * 64 + lane] = acc[reg];
+        __syncthreads();
+        if (wv == (tile_no & 3)) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; w++) v += slot[(w * 16 + reg) * 64 + lane];   // the same order on every run
+                acc[reg] = v;
+            }
+            atomic_add_tile(G, ld, n_rows, mt, nt, acc, inv_scale, r, hh);
+        }
+        tile_no++;
+    };
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) reduce_flush(gW0p, 32, 64, mt, 0, gW0[mt]);
     if constexpr (N_HIDDEN > 1) {
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) atomic_add_tile(gW1p, 64, 64, mt, nt, gW1[mt][nt], inv_scale, r, hh);
+            for (int nt = 0; nt < 2; nt++) reduce_flush(gW1p, 64, 64, mt, nt, gW1[mt][nt]);
     }
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) atomic_add_tile(gWop, 64, n_out_rows, 0, nt, gWo[nt], inv_scale, r, hh);
+    for (int nt = 0; nt < 2; nt++) reduce_flush(gWop, 64, n_out_rows, 0, nt, gWo[nt]);
 }
 
 // hash-grid backward, small / dense levels: one lane per (sample, level); scatter-add of w_corner * dL/dfeature into the f32 table
