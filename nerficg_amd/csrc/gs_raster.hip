@@ -291,7 +291,9 @@ __device__ __forceinline__ void sh_rows_copy(float* s_sh, int pitch, int row_len
 // Workgroup = 128 Gaussians; their SH coefficients (one contiguous 128 x 3M float block) are staged through LDS with coalesced
 // loads -- a lane walking its own 192-byte row touches 48 cache lines per wave instruction (same staging as k_preprocess_bw).
 #define PRE_BLOCK 128
+#ifndef PRE_MAXM
 #define PRE_MAXM 16
+#endif
 __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam_arg, const float* __restrict__ pose, const float* __restrict__ means3D, const float* __restrict__ shs,
                                                           const float* __restrict__ shs_rest,
                                                           const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -1475,7 +1477,9 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
 // touches 48 different cache lines per wave instruction; measured 1.86 GB of HBM traffic for 0.5 GB of data).  Every output
 // row is written by this kernel, zeros for culled Gaussians, so the caller does not clear 300 B per Gaussian beforehand.
 #define PBW_BLOCK 128
+#ifndef PBW_MAXM
 #define PBW_MAXM 16
+#endif
 __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_arg, const float* __restrict__ pose, const float* __restrict__ means3D, const float* __restrict__ shs,
                                                              const float* __restrict__ shs_rest, const float* __restrict__ opacities, int use_sh, const float* __restrict__ scales, const float* __restrict__ rotations,
                                                              int use_scale_rot, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
