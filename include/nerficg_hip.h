@@ -340,7 +340,8 @@ int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float
                            const float* xyz_size3, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
                            int32_t base_resolution, float per_level_scale, void* features_f16, nrc_stream_t stream);
 /* stage 3b on its own (the MFMA kernel; bench.py's second roofline object): features as written by nrc_ngp_encode_samples for the
- * first n_rows (<= 131072) rows -> packed (h0, r, g, b) fp16; ray_sh_workspace: n_ray_tiles * 2048 bytes */
+ * first n_rows (<= 131072) rows -> packed (h0, r, g, b) fp16; ray_sh_workspace: n_ray_tiles * 2048 bytes, filled by this call with the
+ * rays' SH coefficients; n_ray_tiles = 0: it holds them already (they belong to the image, a caller looping over chunks fills it once) */
 int nrc_ngp_mlp_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
                         const void* features_f16, const void* density_weights_f16, const void* color_weights_f16,
                         void* packed_f16, void* ray_sh_workspace, nrc_stream_t stream);

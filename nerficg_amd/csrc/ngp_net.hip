@@ -832,13 +832,14 @@ int nrc_ngp_mlp_samples(const float* ts, const int32_t* row_tile, const float* r
                         void* ray_sh_workspace, nrc_stream_t stream) {
     NRC_ENTER();
     const int64_t n = n_rows * 64;
-    if (n_rows < 0 || n > NRC_QUERY_CHUNK || n_ray_tiles < 1 || !density_weights_f16 || !color_weights_f16) return NRC_ERR_INVALID;
+    if (n_rows < 0 || n > NRC_QUERY_CHUNK || n_ray_tiles < 0 || !density_weights_f16 || !color_weights_f16) return NRC_ERR_INVALID;
     if (n == 0) return NRC_OK;
     if (!ts || !row_tile || !ray_od || !features_f16 || !packed_f16 || !ray_sh_workspace) return NRC_ERR_INVALID;
     QueryIn in = {};
     in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_ray_sh, dim3((unsigned)nrc_cdiv(n_ray_tiles * 64, 256)), dim3(256), 0, s, ray_od, n_ray_tiles, (h8*)ray_sh_workspace);
+    if (n_ray_tiles > 0)  // 0: the workspace already holds the rays' SH coefficients (they are per image, not per chunk)
+        hipLaunchKernelGGL(k_ray_sh, dim3((unsigned)nrc_cdiv(n_ray_tiles * 64, 256)), dim3(256), 0, s, ray_od, n_ray_tiles, (h8*)ray_sh_workspace);
     launch_mlp<SRC_TILED>(in, 0, n, features_f16, ray_sh_workspace, density_weights_f16, color_weights_f16, nullptr, nullptr, packed_f16, s);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
