@@ -634,8 +634,12 @@ int pick_blocks(int64_t M) {
 
 }  // namespace
 
-#define NRC_QUERY_CHUNK (int64_t(8) << 20)  // samples per encode/MLP round (512 MB of features).  Measured per 800x800 image: 2 Mi 11.0 ms,
-                                            // 4 Mi 10.5, 8 Mi 10.15, 16 Mi 10.17 -- the gaps between 2 x 38 launches cost more than features spilling past the Infinity Cache
+#ifndef NRC_QUERY_CHUNK_LOG2
+#define NRC_QUERY_CHUNK_LOG2 23
+#endif
+#define NRC_QUERY_CHUNK (int64_t(1) << NRC_QUERY_CHUNK_LOG2)  // samples per encode/MLP round (8 Mi: 512 MB of features).  Measured per 800x800 image,
+                                            // round 1: 2 Mi 11.0 ms, 4 Mi 10.5, 8 Mi 10.15, 16 Mi 10.17; round 2 (tools/exp_image.py): 2 Mi 9.93, 4 Mi 9.83, 8 Mi 9.56 --
+                                            // the gaps between 2 x 38 launches cost more than features that spill past the Infinity Cache
 
 // workspace: [features of one chunk: roundup32(chunk) x 64 B][ray_sh: n_ray_tiles x 2 KB (tiled layout only)]
 static int64_t query_feat_bytes(int64_t M) {
