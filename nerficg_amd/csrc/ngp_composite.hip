@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(256) k_composite_layers(const __half* __restri
 __global__ void __launch_bounds__(256) k_train_pixels_fw(int64_t n, const float* __restrict__ opacity, const float* __restrict__ depth,
                                                          const float* __restrict__ rgb, const float* __restrict__ bg, float* __restrict__ rgb_out,
                                                          float* __restrict__ depth_out) {
+#pragma clang fp contract(off)   // rgb + (1 - a) * bg with two roundings, like the torch expression (this file is otherwise built with contraction on)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float see_through = 1 - opacity[i];

@@ -1,0 +1,121 @@
+"""GPU: the single-launch forms of the renderer's training batch against the op-by-op expressions they replace (Renderer.py:55-84)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import scenes
+from tests.test_gpu_render_parity import make_camera
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _rays(n=5000, seed=0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    o = (torch.rand(n, 3, device=DEV, generator=g) - 0.5) * 3.0
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV, generator=g), dim=-1)
+    d[::97, 0] = 0.0   # axis-parallel components: the slab test divides by them
+    return o.contiguous(), d.contiguous()
+
+
+def test_clip_rays_equals_intersect_plus_clamps():
+    from nerficg_amd import VolumeRenderingV2 as vr
+    from nerficg_amd.instant_ngp import InstantNGPModel, InstantNGPRenderer
+    model = InstantNGPModel(RANDOM_SEED=0, device=DEV)
+    renderer = InstantNGPRenderer(model)
+    cam = make_camera(8, 8)
+    o, d = _rays()
+    o2, d2, span = renderer.clip_rays(o, d, cam)
+    ref_o = (o - model.center).contiguous()
+    ref = vr.ray_aabb_intersect(ref_o, d, torch.zeros(1, 3, device=DEV), model.half_size, 1)[1][:, 0].clone()
+    ref[:, 0].clamp_(min=cam.near_plane)
+    ref[:, 1].clamp_(max=cam.far_plane)
+    assert torch.equal(o2, ref_o) and torch.equal(d2, d)
+    assert torch.equal(span, ref)
+    assert int((span[:, 1] > span[:, 0]).sum()) > 100 and int((span[:, 1] < 0).sum()) > 100   # hits and misses both present
+
+
+def test_composite_over_background_matches_the_torch_expressions():
+    from nerficg_amd import VolumeRenderingV2 as vr
+    from nerficg_amd.ngp import composite_over_background
+    g = torch.Generator(device=DEV).manual_seed(1)
+    n_rays, per_ray = 700, 37
+    m = n_rays * per_ray
+    rays_a = torch.stack([torch.arange(n_rays, device=DEV), torch.arange(n_rays, device=DEV) * per_ray,
+                          torch.full((n_rays,), per_ray, device=DEV)], dim=1).to(torch.int64)
+    rays_a[::11, 2] = 0   # rays without samples
+    deltas = torch.full((m,), 0.02, device=DEV)
+    ts = (torch.arange(per_ray, device=DEV, dtype=torch.float32) * 0.02 + 0.3).repeat(n_rays)
+    bg = torch.rand(3, device=DEV, generator=g)
+    base_s = torch.rand(m, device=DEV, generator=g) * 8.0
+    base_c = torch.rand(m, 3, device=DEV, generator=g)
+    w_rgb, w_a, w_d = torch.rand(n_rays, 3, device=DEV, generator=g), torch.rand(n_rays, device=DEV, generator=g), torch.rand(n_rays, device=DEV, generator=g)
+    results = []
+    for fused in (False, True):
+        s, c = base_s.clone().requires_grad_(True), base_c.clone().requires_grad_(True)
+        if fused:
+            rgb, alpha, depth = composite_over_background(s, c, deltas, ts, rays_a, bg, 1e-4)
+        else:
+            _, alpha, depth_sum, radiance, _ = vr.VolumeRenderer.apply(s, c, deltas, ts, rays_a, 1e-4)
+            rgb = radiance + (1 - alpha)[:, None] * bg
+            depth = depth_sum / (alpha + 1e-6)
+        ((rgb * w_rgb).sum() + (alpha * w_a).sum() + (depth * w_d).sum()).backward()
+        results.append((rgb.detach(), alpha.detach(), depth.detach(), s.grad, c.grad))
+    for a, b in zip(results[0][:3], results[1][:3]):
+        assert torch.equal(a, b)                      # same operations in the same order: bit-equal pixels
+    torch.testing.assert_close(results[1][3], results[0][3], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(results[1][4], results[0][4], rtol=1e-5, atol=1e-6)
+    # only the colour receives a gradient (the training loss): the NULL-gradient path of the kernels
+    s, c = base_s.clone().requires_grad_(True), base_c.clone().requires_grad_(True)
+    rgb, _, _ = composite_over_background(s, c, deltas, ts, rays_a, bg, 1e-4)
+    (rgb * w_rgb).sum().backward()
+    s2, c2 = base_s.clone().requires_grad_(True), base_c.clone().requires_grad_(True)
+    _, alpha, _, radiance, _ = vr.VolumeRenderer.apply(s2, c2, deltas, ts, rays_a, 1e-4)
+    ((radiance + (1 - alpha)[:, None] * bg) * w_rgb).sum().backward()
+    torch.testing.assert_close(s.grad, s2.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(c.grad, c2.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_rasterizer_abi_host_camera_equals_device_camera_block():
+    """include/nerficg_hip.h: the pose either as HOST arrays or as the DEVICE block `camera_dev`; the Python wrapper only uses the second."""
+    import ctypes
+    from nerficg_amd import _lib
+    lib = _lib.load()
+    sc = scenes.gs_random_scene(20000, seed=3)
+    W, H = 320, 200
+    cam = scenes.gs_camera(W, H, scenes.orbit_pose(0.8, 0.35, 4.5))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    means, shs, ops, scl, rot = T(sc['means3D']), T(sc['shs']), T(sc['opacities']), T(sc['scales']), T(sc['rotations'])
+    P, M = means.shape[0], shs.shape[1]
+    nt = ((W + 15) // 16) * ((H + 15) // 16)
+    f = lambda a: (ctypes.c_float * len(a))(*[float(v) for v in a])
+    vm, pm, cp = f(cam['viewmatrix'].reshape(-1)), f(cam['projmatrix'].reshape(-1)), f(cam['campos'].reshape(-1))
+    block = torch.cat([T(cam['viewmatrix']).reshape(-1), T(cam['projmatrix']).reshape(-1), T(cam['campos']).reshape(-1), torch.zeros(3, device=DEV)]).float()
+    outs = []
+    for use_block in (False, True):
+        i32, f32 = torch.int32, torch.float32
+        bufs = dict(radii=torch.empty(P, dtype=i32, device=DEV), depths=torch.empty(P, device=DEV), xy=torch.empty(P, 2, device=DEV),
+                    co=torch.empty(P, 4, device=DEV), rgb=torch.empty(P, 3, device=DEV), clamped=torch.empty(P, dtype=torch.uint8, device=DEV),
+                    cov=torch.empty(P, 6, device=DEV), tt=torch.empty(P, dtype=i32, device=DEV), splat=torch.empty(P, 16, device=DEV),
+                    tc=torch.empty(nt, dtype=i32, device=DEV), tf=torch.empty(nt, dtype=i32, device=DEV), ranges=torch.empty(nt, 2, dtype=i32, device=DEV),
+                    num=torch.empty(2, dtype=torch.int64, device=DEV))
+        hist = torch.empty(int(lib.nrc_gs_bin_hist_bytes(P, W, H, 0)) // 4, dtype=i32, device=DEV)
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        _lib.check(lib.nrc_gs_preprocess(
+            P, 3, M, W, H, _lib.ptr(means), _lib.ptr(shs), None, 0, None, _lib.ptr(ops), _lib.ptr(scl), 1.0, _lib.ptr(rot), None,
+            None if use_block else cast(vm), None if use_block else cast(pm), None if use_block else cast(cp), _lib.ptr(block) if use_block else None,
+            float(cam['tanfovx']), float(cam['tanfovy']), _lib.ptr(bufs['radii']), _lib.ptr(bufs['depths']), _lib.ptr(bufs['xy']), _lib.ptr(bufs['co']),
+            _lib.ptr(bufs['rgb']), _lib.ptr(bufs['clamped']), _lib.ptr(bufs['cov']), _lib.ptr(bufs['tt']), _lib.ptr(bufs['tc']), _lib.ptr(bufs['ranges']),
+            _lib.ptr(bufs['tf']), _lib.ptr(hist), 0, 0, _lib.ptr(bufs['splat']), _lib.ptr(bufs['num']), _lib.stream_of(means)), 'gs_preprocess')
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in bufs.items() if k in ('radii', 'depths', 'xy', 'co', 'rgb', 'clamped', 'tt', 'ranges', 'num')})
+    assert int(outs[0]['num'][0]) > 10000
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    # neither form given: refused
+    rc = lib.nrc_gs_preprocess(P, 3, M, W, H, _lib.ptr(means), _lib.ptr(shs), None, 0, None, _lib.ptr(ops), _lib.ptr(scl), 1.0, _lib.ptr(rot), None,
+                               None, None, None, None, float(cam['tanfovx']), float(cam['tanfovy']), _lib.ptr(bufs['radii']), _lib.ptr(bufs['depths']),
+                               _lib.ptr(bufs['xy']), _lib.ptr(bufs['co']), _lib.ptr(bufs['rgb']), _lib.ptr(bufs['clamped']), _lib.ptr(bufs['cov']),
+                               _lib.ptr(bufs['tt']), _lib.ptr(bufs['tc']), _lib.ptr(bufs['ranges']), _lib.ptr(bufs['tf']), _lib.ptr(hist), 0, 0,
+                               _lib.ptr(bufs['splat']), _lib.ptr(bufs['num']), _lib.stream_of(means))
+    assert rc != 0
