@@ -377,10 +377,11 @@ def dp_ingp_leg(model, renderer, cam, poses, rank, world, device, rays_per_rank=
     perm = torch.randperm(origin.shape[0], generator=torch.Generator(device='cpu').manual_seed(0)).to(device)  # identical on every rank
     target = torch.rand(origin.shape[0], 3, device=device, generator=torch.Generator(device=device).manual_seed(1))
     opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)  # Trainer.py:35
-    scaler = torch.amp.GradScaler(init_scale=128.0, growth_interval=10 ** 9)
+    # found-inf OR-ed over the ranks and the marched sample count summed, in one small collective per iteration (Trainer.py:44,89-94)
+    scaler = parallel.DataParallelGradScaler(init_scale=128.0, growth_interval=10 ** 9)
     n_global = rays_per_rank * world
     params = list(model.parameters())
-    coll_ms, losses = [], []
+    coll_ms, losses, global_samples = [], [], []
 
     def step(i, timed):
         gen = torch.Generator(device=device).manual_seed(1000 + i)  # the same background and jitter on every rank
@@ -396,10 +397,12 @@ def dp_ingp_leg(model, renderer, cam, poses, rank, world, device, rays_per_rank=
         a.record()
         parallel.allreduce_gradients(params, average=True)
         b.record()
+        scaler.piggyback = [out['rm_samples']]
         scaler.step(opt); scaler.update(); opt.zero_grad()
         if timed:
             coll_ms.append((a, b))
             losses.append(loss.detach())
+            global_samples.append(scaler.reduced[0])
         return out['rm_samples']
 
     for i in range(3):
@@ -421,6 +424,12 @@ def dp_ingp_leg(model, renderer, cam, poses, rank, world, device, rays_per_rank=
     nbytes = sum(p.numel() * 4 for p in params)
     dt, coll = _max_over_ranks([dt, coll], device, world)
     samples = float(torch.stack(n_samples).double().mean())
+    # the batch-size controller of Trainer.py:73-75 on the GLOBAL count: every rank computes the same next batch size
+    total_global = float(torch.stack(global_samples).sum())
+    next_rays = parallel.rays_per_batch_update(rays_per_rank, 262144, total_global, iters, world)
+    agree = _max_over_ranks([next_rays, -next_rays], device, world)
+    if agree[0] != -agree[1]:
+        raise RuntimeError(f'InstantNGP data-parallel replicas drifted: next rays_per_batch {next_rays} differs between ranks')
     with torch.no_grad():
         for p, q in zip(model.parameters(), saved):
             p.copy_(q)
@@ -430,6 +439,8 @@ def dp_ingp_leg(model, renderer, cam, poses, rank, world, device, rays_per_rank=
             'collective': f'one flat f32 bucket, {"all_reduce" if dist.get_backend() == "gloo" else "reduce-scatter + all-gather"} over {dist.get_backend()}' if world > 1 else None, 'bytes_reduced_per_iteration': nbytes if world > 1 else 0,
             'collective_ms': round(coll, 3) if world > 1 else None,
             'bus_GBps_per_gpu': round(2 * (world - 1) / world * nbytes / (coll * 1e-3) / 1e9, 1) if world > 1 and coll > 0 else None,
+            'scalar_collective': 'rm_samples (sum) + GradScaler found-inf (or), one packed all-reduce per iteration' if world > 1 else None,
+            'global_samples_per_iteration': round(total_global / iters), 'next_rays_per_batch': next_rays,
             'replica_drift': drift, 'network_output_drift': out_drift, 'final_loss': round(float(losses[-1]), 6)}
 
 
@@ -516,6 +527,20 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=8):
             'bus_GBps_per_gpu': round(2 * (world - 1) / world * nbytes / (coll * 1e-3) / 1e9, 1) if world > 1 and coll > 0 else None, 'replica_drift': drift}
 
 
+def spawn_ranks(n: int) -> int:
+    """Runs this script as n ranks under torch.distributed.run (the driver's own command line) and returns its exit code.  No GPU call has
+    happened in this process; the children inherit stdout, so rank 0's JSON line is the output."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -530,11 +555,19 @@ def main():
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the code path)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run, one process per GPU) BEFORE anything in
+        # this process touches the GPU -- the parent only relays the children's output and exit code
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world} -- launch with --nproc-per-node {args.gpus} (or without a launcher: '
+                         f'`python bench.py --gpus {args.gpus}` starts the ranks itself)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
     local_dev = local_rank % torch.cuda.device_count()

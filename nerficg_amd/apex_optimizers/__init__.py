@@ -19,6 +19,8 @@ Kernel: nerficg_amd/csrc/adam.hip through the C ABI (include/nerficg_hip.h group
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from .. import _lib
@@ -42,22 +44,39 @@ class FusedAdam(torch.optim.Optimizer):
         self.capturable = bool(capturable)
         self._amp = {}  # group index -> (skipped-step counter i32[1], bias corrections f32[2]) on the device
         self._lr_dev = {}  # capturable: group index -> [device f32[1], the host value it holds]
-        self._l2_slices = {}  # id(parameter) -> (count, coefficient): see set_l2_slice
+        self._l2_slices = {}  # id(parameter) -> (weak reference to the parameter, count, coefficient): see set_l2_slice
 
     def set_l2_slice(self, param: torch.Tensor, count: int, coeff: float) -> None:
         """The step adds coeff * p to the gradient of the first `count` elements of `param` (not in apex).  A loss term lambda * mean(w^2) over
         such a slice has exactly this gradient with coeff = 2 lambda / n, also under a GradScaler (scaled with the loss, unscaled in the
-        step); taking it here spares autograd a dense gradient of the whole parameter for a few thousand weights.  count = 0 removes it."""
+        step); taking it here spares autograd a dense gradient of the whole parameter for a few thousand weights.  count = 0 removes it.
+        EXCLUSIVE with the loss-term form: whoever installs a slice must drop the term from the loss (and remove the slice again before going
+        back to a loss that contains it, `clear_l2_slices()`), or the decay is applied twice.  The entry is tied to the parameter OBJECT (weak
+        reference): a tensor that replaces the parameter never inherits it, even if it reuses the id."""
         if count <= 0:
             self._l2_slices.pop(id(param), None)
         else:
-            self._l2_slices[id(param)] = (int(count), float(coeff))
+            self._l2_slices[id(param)] = (weakref.ref(param), int(count), float(coeff))
+
+    def clear_l2_slices(self) -> None:
+        self._l2_slices.clear()
+
+    def _l2_slice_of(self, p) -> tuple[int, float]:
+        entry = self._l2_slices.get(id(p))
+        if entry is None:
+            return 0, 0.0
+        if entry[0]() is not p:   # the parameter the slice was installed for is gone and its id was reused
+            del self._l2_slices[id(p)]
+            return 0, 0.0
+        return entry[1], entry[2]
 
     def effective_step(self, group) -> int:
         """Step count that entered the bias corrections: group['step'] minus the overflow-skipped steps (host read, for tests / logging)."""
         if torch.is_tensor(group.get('step')):
             return int(group['step'].item())
-        entry = self._amp.get(self.param_groups.index(group))
+        # by identity: list.index compares the group dicts with ==, which truth-tests tensor == tensor on their 'params' lists
+        gi = next((i for i, g in enumerate(self.param_groups) if g is group), None)
+        entry = self._amp.get(gi)
         return group.get('step', 0) - (int(entry[0].item()) if entry is not None else 0)
 
     def sync_hyperparameters(self) -> None:
@@ -84,6 +103,27 @@ class FusedAdam(torch.optim.Optimizer):
             slot[0].fill_(float(group['lr']))
             slot[1] = float(group['lr'])
         return entry[1], entry[0], group['step'], slot[0]
+
+    def state_dict(self):
+        """torch's layout plus, per group, 'skipped_steps': the overflow-skipped steps that nrc_adam_prepare subtracts from group['step'] for the
+        bias corrections (a device counter; without it a resumed AMP run would forget its skips).  One host read per group, at save time only."""
+        sd = super().state_dict()
+        for gi, g in enumerate(sd['param_groups']):
+            entry = self._amp.get(gi)
+            g['skipped_steps'] = int(entry[0].item()) if entry is not None else 0
+            if torch.is_tensor(g.get('step')):
+                g['step'] = int(g['step'].item())
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._amp.clear()
+        self._lr_dev.clear()
+        for gi, group in enumerate(self.param_groups):
+            skipped = int(group.pop('skipped_steps', 0))
+            if skipped:
+                device = group['params'][0].device
+                self._amp[gi] = (torch.full((1,), skipped, dtype=torch.int32, device=device), torch.ones(2, dtype=torch.float32, device=device))
 
     def zero_grad(self, set_to_none: bool | None = None):
         super().zero_grad(set_to_none=self.set_grad_none if set_to_none is None else set_to_none)
@@ -138,7 +178,7 @@ class FusedAdam(torch.optim.Optimizer):
                 owner = getattr(p, '_nrc_half_owner', None)
                 owner = owner() if owner is not None else None
                 half = owner._half_for_optimizer(p) if owner is not None else None
-                l2 = self._l2_slices.get(id(p), (0, 0.0))
+                l2 = self._l2_slice_of(p)
                 _lib.check(lib.nrc_adam_step(
                     _lib.ptr(p), _lib.ptr(g), _lib.ptr(state['exp_avg']), _lib.ptr(state['exp_avg_sq']), p.numel(), float(group['lr']), float(beta1),
                     float(beta2), float(group['eps']), float(group['weight_decay']), self.adam_w_mode, float(bc1), float(bc2), _lib.ptr(bc_dev),

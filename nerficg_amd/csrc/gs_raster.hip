@@ -7,20 +7,24 @@
 // BUILD NOTE: compiled with -ffp-contract=off.  Radii, tile rectangles and the depth keys that order the blend are integer
 // decisions taken from f32 arithmetic and must be bit-exact against the oracle (which is built the same way).
 //
-// MI355X-native structure (vs the reference's pipeline: inclusive scan -> key duplication -> DEVICE-WIDE 64-bit radix sort ->
-// range search, ~100 B of HBM traffic per (tile, Gaussian) instance):
-//   1. k_preprocess   one lane per Gaussian: cull, cov3D, EWA cov2D, conic, radius, SH -> RGB; counts instances per TILE.
-//   2. k_scan_tiles   exclusive scan of the per-tile counts = the tile ranges (no key search pass).
-//   3. k_scatter      every Gaussian drops (depth bits << 32 | id) into its tiles' segments (8 B written per instance).
-//   4. k_sort_tiles   one workgroup per tile sorts ITS segment by (depth, id) inside LDS (bitonic, 64-bit keys; segments
-//                     larger than the LDS budget fall back to the same network in global memory) and emits the id list.
-//                     The order (depth, then index) is exactly what a stable radix sort over (tile | depth) keys produces.
-//   5. k_render       16x16-pixel tile per workgroup (4 waves), 256-Gaussian batches staged in LDS, front-to-back blend.
-//   => 20 B of traffic per instance instead of ~100, and no global sort.
+// MI355X-native structure (vs the reference's pipeline: inclusive scan -> key duplication -> DEVICE-WIDE 64-bit radix sort over the D >> P
+// (tile, Gaussian) instances -> range search, ~100 B of HBM traffic per instance).  DESIGN.md 3.3 has the history and the numbers.
+//   1. k_preprocess     128 Gaussians per workgroup, SH rows staged through LDS: cull, cov3D, EWA cov2D, conic, radius, SH -> RGB, tile rectangle;
+//                       writes the geometry buffers of the API and one 64-byte splat record per Gaussian (what the blend kernels read).
+//   2. depth pre-sort   of the P Gaussians (not of the instances): k_depth_keys, then 4 x (k_radix_count, k_radix_offsets, k_radix_scatter), LSD,
+//                       8 bits per pass, stable, carrying the Gaussian's index and its packed tile rectangle.
+//   3. span binning     two-level MSD scatter over the tile id, ranked with LDS bit matrices (no serial walk, no sort):
+//                       level 1 (k_span_count / k_span_scan / k_span_rows / k_span_scatter): Gaussian -> one 8-byte span record per tile ROW;
+//                       level 2 (k_item_count / k_item_scan / k_scan_tiles / k_item_scatter): a row's spans -> ids appended to the row's tiles.
+//                       Stable in depth order, so the per-tile lists equal what a stable radix sort over (tile | depth) keys produces.
+//                       Tile grids above SPAN_DIM_MAX x SPAN_DIM_MAX fall back to k_scatter (global atomics) + k_sort_tiles (per-tile bitonic sort).
+//   4. k_tile_order     counting sort of the tiles by list length: longest lists launch first.
+//   5. k_render         16x16-pixel tile per workgroup (4 waves = 8x8 quadrants), DPP row = 4x4 pixel block with its OWN culled work list,
+//                       256-entry batches staged in LDS, branch-free front-to-back blend.
 // Backward:
-//   6. k_render_bw    same tiles, back-to-front; per-Gaussian gradients are reduced ACROSS THE WAVE with DPP shuffles and
-//                     leave as one atomic per wave and quantity (the reference issues one atomic per PIXEL and quantity).
-//   7. k_preprocess_bw one lane per Gaussian: conic -> cov2D -> cov3D -> scale/rotation, mean2D -> mean3D, colour -> SH.
+//   6. k_render_bw      same tiles and lists, back-to-front; per-Gaussian sums reduced by a transposing DPP butterfly, combined across the
+//                       tile's blocks with ONE 64-bit fixed-point LDS atomic per row, then one global f32 atomic per (tile, Gaussian) and quantity.
+//   7. k_preprocess_bw  128 Gaussians per workgroup: conic -> cov2D -> cov3D -> scale / rotation, mean2D -> mean3D, colour -> SH.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -690,14 +694,16 @@ __global__ void __launch_bounds__(1024) k_item_scan(int gx, int item_cap, const 
 template <bool CAPPED>  // CAPPED: the caller fixed the length of point_list (graph capture); entries that would land behind it are dropped
 __global__ void __launch_bounds__(64) k_item_scatter(int gx, int gy, const uint32_t* __restrict__ rowtot, const uint32_t* __restrict__ roff,
                                                      const uint32_t* __restrict__ nitems, const uint32_t* __restrict__ ioff, const uint32_t* __restrict__ meta_items,
-                                                     const uint2* __restrict__ spans, const uint32_t* __restrict__ cnt2, const uint32_t* __restrict__ ranges,
-                                                     uint32_t list_cap, int32_t* __restrict__ point_list) {
+                                                     int64_t cap, int item_cap, const uint2* __restrict__ spans, const uint32_t* __restrict__ cnt2,
+                                                     const uint32_t* __restrict__ ranges, uint32_t list_cap, int32_t* __restrict__ point_list) {
     __shared__ uint32_t bits[SPAN_DIM_MAX][2];
     __shared__ int ids[64];
     const int lane = threadIdx.x;
     const int nk = (gx + 63) >> 6;
     SPAN_LOAD_ROW_TABLES();
-    const int n_items = (int)meta_items[0], ch = (int)meta_items[1];
+    // the same clamps as k_item_count / k_item_scan: items behind item_cap have no cnt2 row, spans behind cap were never written (a frame that
+    // outgrew the workspace: the sized call retries, the fixed-capacity call reports spans > capacity and blends what fits)
+    const int n_items = min((int)meta_items[0], item_cap), ch = (int)meta_items[1];
 #pragma unroll
     for (int k = 0; k < 4; k++) { bits[64 * k + lane][0] = 0u; bits[64 * k + lane][1] = 0u; }
     __syncthreads();
@@ -709,9 +715,9 @@ __global__ void __launch_bounds__(64) k_item_scatter(int gx, int gy, const uint3
             const int x = 64 * k + lane;
             cur[k] = x < gx ? ranges[2 * ((size_t)it.y * gx + x)] + cnt2[(size_t)item * gx + x] : 0u;
         }
-        uint2 sp = lane < it.n ? spans[it.s0 + lane] : make_uint2(0u, 0u);
+        uint2 sp = lane < it.n && it.s0 + lane < cap ? spans[it.s0 + lane] : make_uint2(0u, 0u);
         for (int j0 = 0; j0 < it.n; j0 += 64) {
-            const uint2 nxt = j0 + 64 + lane < it.n ? spans[it.s0 + j0 + 64 + lane] : make_uint2(0u, 0u);
+            const uint2 nxt = j0 + 64 + lane < it.n && it.s0 + j0 + 64 + lane < cap ? spans[it.s0 + j0 + 64 + lane] : make_uint2(0u, 0u);
             ids[lane] = (int)sp.x;
             for (int x = (int)(sp.y & 0xffffu); x < (int)(sp.y >> 16); x++) atomicOr(&bits[x][lane >> 5], 1u << (lane & 31));
             __syncthreads();
@@ -1663,11 +1669,11 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
         if (lds_path) {
             const BinWs w = gs_bin_ws(const_cast<uint32_t*>(bin_hist), P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P));
             if (instance_capacity > 0)
-                hipLaunchKernelGGL(k_item_scatter<true>, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.spans, w.cnt2,
-                                   ranges, list_cap, point_list);
+                hipLaunchKernelGGL(k_item_scatter<true>, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.cap, w.item_cap, w.spans,
+                                   w.cnt2, ranges, list_cap, point_list);
             else
-                hipLaunchKernelGGL(k_item_scatter<false>, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.spans, w.cnt2,
-                                   ranges, list_cap, point_list);
+                hipLaunchKernelGGL(k_item_scatter<false>, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.cap, w.item_cap, w.spans,
+                                   w.cnt2, ranges, list_cap, point_list);
         } else {
             hipLaunchKernelGGL(k_scatter, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, ranges, tile_fill, keys);
             hipLaunchKernelGGL((k_sort_tiles<0, 1024>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);

@@ -55,6 +55,7 @@ class GraphedIteration:
         self.calls = 0
         self.graph: torch.cuda.CUDAGraph | None = None
         self.outputs: dict[str, torch.Tensor] | None = None
+        self.on_close: tuple = ()
 
     def _load(self, inputs: dict[str, torch.Tensor]) -> None:
         if inputs.keys() != self.inputs.keys():
@@ -92,6 +93,20 @@ class GraphedIteration:
     def recorded(self) -> bool:
         return self.graph is not None
 
+    def close(self) -> None:
+        """Drop the recording and run the `on_close` hooks (state an iteration installed outside itself, e.g. the folded weight decay)."""
+        self.graph = None
+        self.outputs = None
+        for hook in self.on_close:
+            hook()
+        self.on_close = ()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown
+            pass
+
 
 def instant_ngp_iteration(model, renderer, optimizer, scaler, camera, n_rays: int, sample_capacity: int, loss_fn: Callable | None = None,
                           with_alpha: bool = False, ray_pool: dict[str, torch.Tensor] | None = None, eager_calls: int = 1,
@@ -106,7 +121,9 @@ def instant_ngp_iteration(model, renderer, optimizer, scaler, camera, n_rays: in
     The optimizer must be FusedAdam(capturable=True).
     fold_weight_decay (default loss only): the 0.5e-6 * mean(w^2) term leaves the loss and its gradient, 1e-6 / n_mlp * w on the MLP weights, is
     added inside the Adam kernel (FusedAdam.set_l2_slice) -- the same update without the dense 12 M-element gradients autograd builds for a
-    term that touches 10 240 weights (~16 launches less per iteration); the reported loss is then the colour term alone."""
+    term that touches 10 240 weights (~16 launches less per iteration); the reported loss is then the colour term alone.  The slices live in
+    the optimizer while this iteration object lives: `close()` (or dropping the object) removes them, so a later op-by-op step with the default
+    loss -- which contains the term -- does not decay twice."""
     if not getattr(optimizer, 'capturable', False):
         raise RuntimeError('instant_ngp_iteration: build the optimizer as FusedAdam(..., capturable=True)')
     dev = model.center.device
@@ -152,7 +169,9 @@ def instant_ngp_iteration(model, renderer, optimizer, scaler, camera, n_rays: in
         example['view_direction'][:, 2] = 1.0
         if with_alpha:
             example['alpha'] = torch.zeros(n_rays, device=dev)
-    return GraphedIteration(body, example, eager_calls=eager_calls, before_replay=optimizer.sync_hyperparameters, parameters=model.parameters)
+    it = GraphedIteration(body, example, eager_calls=eager_calls, before_replay=optimizer.sync_hyperparameters, parameters=model.parameters)
+    it.on_close = (optimizer.clear_l2_slices,) if fold_weight_decay else ()
+    return it
 
 
 def gaussian_splatting_step(gaussians, camera, instance_capacity: int, span_capacity: int = 0, loss_fn: Callable | None = None,

@@ -15,6 +15,10 @@ The reference has no working multi-GPU path: its DataParallel 
                             after backward the encoding / MLP (InstantNGP) or Gaussian (3DGS) gradients are summed with ONE
                             bucketed collective.  xGMI is point-to-point (7 links per GPU): reduce-scatter + all-gather lets
                             every link carry 1/world of the payload instead of a ring's per-link bound.
+  * per-iteration scalars -- the marched sample count that drives update_batch_size (src/Methods/InstantNGP/Trainer.py:73-75,94) and the
+                            GradScaler's found-inf flag (Trainer.py:44,89-93) must be the SAME on every rank, or the replicas pick different
+                            batch sizes / skip different steps: allreduce_scalars moves them in ONE tiny collective, DataParallelGradScaler
+                            is the torch.amp.GradScaler that uses it.
 """
 from __future__ import annotations
 
@@ -25,7 +29,8 @@ import torch
 import torch.distributed as dist
 
 __all__ = ['init_distributed', 'world_info', 'shard_ray_ids', 'shard_range', 'allreduce_flat', 'allreduce_gradients',
-           'all_gather_pixels', 'broadcast_parameters', 'sparse_allreduce_gradients', 'allreduce_densification_stats', 'synchronized_noise']
+           'all_gather_pixels', 'broadcast_parameters', 'sparse_allreduce_gradients', 'allreduce_densification_stats', 'synchronized_noise',
+           'allreduce_scalars', 'DataParallelGradScaler', 'rays_per_batch_update']
 
 
 def init_distributed(backend: str | None = None, device: torch.device | None = None) -> tuple[int, int]:
@@ -159,20 +164,24 @@ def sparse_allreduce_gradients(params: Iterable[torch.nn.Parameter], visible: to
     union index list on every rank -> the union rows of all tensors packed into ONE flat buffer -> reduce-scatter + all-gather ->
     unpack.  Payload: n_union x 236 B instead of P x 236 B (59 floats per Gaussian).  Returns n_union (-1 in a single-process run)."""
     rank, world = world_info()
-    params = [p for p in params if p.grad is not None]
-    if world == 1 or not params:
+    params = list(params)
+    if world == 1:
         return -1  # nothing travels; the count of visible rows would cost a host read per step
+    # world > 1: EVERY rank enters both collectives whatever it holds -- a rank whose view produced no gradient (p.grad is None) contributes
+    # zero rows of the right width and receives the others' sum; an early return here would leave the other ranks waiting in the all-reduce
     P = visible.shape[0]
     union = visible.to(torch.uint8).contiguous()
     dist.all_reduce(union, op=dist.ReduceOp.MAX)
     idx = torch.nonzero(union, as_tuple=False).flatten()
     n = idx.numel()
-    if n == 0:
-        return 0
+    if n == 0 or not params:   # the same decision on every rank: the union and the parameter list are identical everywhere
+        return n
     rows = []
     for p in params:
-        if p.grad.shape[0] != P:
-            raise RuntimeError(f'sparse_allreduce_gradients: gradient with {p.grad.shape[0]} rows, visibility mask has {P}')
+        if p.shape[0] != P:
+            raise RuntimeError(f'sparse_allreduce_gradients: parameter with {p.shape[0]} rows, visibility mask has {P}')
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
         rows.append(p.grad.reshape(P, -1))
     packed = torch.cat([r[idx] for r in rows], dim=1).contiguous()  # (n_union, 59)
     allreduce_flat(packed.view(-1), average)
@@ -182,6 +191,71 @@ def sparse_allreduce_gradients(params: Iterable[torch.nn.Parameter], visible: to
         r[idx] = packed[:, off:off + w]
         off += w
     return n
+
+
+def allreduce_scalars(sums: Iterable[torch.Tensor] = (), flags: Iterable[torch.Tensor] = ()) -> tuple[list[torch.Tensor], list[torch.Tensor]]:
+    """The per-iteration scalars of SURVEY 8(e) in ONE collective, device tensors in and out (no host read): `sums` are added up over the ranks
+    (e.g. rm_samples, the marched sample count update_batch_size works from, InstantNGP/Trainer.py:73-75,94), `flags` are OR-ed (e.g. the
+    GradScaler's found-inf, Trainer.py:44,89-93: one rank's overflow must skip the step on every rank).  All values travel as float64 in one
+    packed all-reduce (SUM; a flag is set iff the sum of the ranks' flags is positive -- counts up to 2^53 are exact).  Returns
+    ([global sums, f64 scalars], [global flags, f32 0/1 scalars like GradScaler's found_inf]).  Single process: the inputs, converted."""
+    sums, flags = list(sums), list(flags)
+    if not sums and not flags:
+        return [], []
+    dev = (sums + flags)[0].device
+    pack = torch.stack([t.detach().reshape(-1)[0].to(device=dev, dtype=torch.float64) for t in sums + flags])
+    rank, world = world_info()
+    if world > 1:
+        dist.all_reduce(pack, op=dist.ReduceOp.SUM)
+    out_sums = [pack[i] for i in range(len(sums))]
+    out_flags = [(pack[len(sums) + j] > 0).to(torch.float32) for j in range(len(flags))]
+    return out_sums, out_flags
+
+
+def rays_per_batch_update(rays_per_batch: int, target_samples: int, samples_since_update: float, iterations: int, world: int | None = None) -> int:
+    """The batch-size controller of InstantNGP/Trainer.py:73-75 for replicas: `samples_since_update` is the GLOBAL marched sample count of the
+    last `iterations` iterations (allreduce_scalars of rm_samples, accumulated), every rank marches rays_per_batch rays per iteration and
+    aims at target_samples samples per iteration ON ITS OWN GPU (weak scaling), so the per-rank mean is global / (iterations * world).  The
+    input is identical on all ranks, hence so is the result.  world = 1 is the reference's rule unchanged: next multiple of 256 of
+    rays * target / measured, capped at the target."""
+    world = world_info()[1] if world is None else world
+    measured = samples_since_update / (iterations * world)
+    if measured <= 0:
+        return rays_per_batch
+    wanted = rays_per_batch * target_samples / measured
+    return int(min(-(-wanted // 256) * 256, target_samples))
+
+
+class DataParallelGradScaler(torch.amp.GradScaler):
+    """torch.amp.GradScaler whose found-inf decision is global: whenever the scaler has looked at an optimizer's gradients (unscale_, or the
+    check inside step() for optimizers that apply the scale themselves, like FusedAdam), the per-device found-inf tensors are replaced by
+    their OR over all ranks -- so every replica skips the same steps and update() moves the scale identically.  When the gradients were
+    already summed over the ranks an inf / NaN has reached every rank through the sum; the agreement then costs one tiny all-reduce and
+    protects the other orders of operations (unscale before the gradient collective, sharded optimizers).
+    `piggyback`: device scalars to add up over the ranks in the SAME collective (the marched sample count); the global values are in
+    `reduced` after step()."""
+
+    def __init__(self, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.piggyback: list[torch.Tensor] = []
+        self.reduced: list[torch.Tensor] = []
+
+    def _agree(self, optimizer) -> None:
+        found = self._per_optimizer_states[id(optimizer)]['found_inf_per_device']
+        flags = list(found.values())
+        sums, agreed = allreduce_scalars(self.piggyback, flags)
+        for t, v in zip(flags, agreed):
+            t.copy_(v.to(t.device))
+        self.reduced, self.piggyback = sums, []
+
+    def _check_inf_per_device(self, optimizer):
+        out = super()._check_inf_per_device(optimizer)
+        self._agree(optimizer)
+        return out
+
+    def unscale_(self, optimizer) -> None:
+        super().unscale_(optimizer)
+        self._agree(optimizer)
 
 
 def allreduce_densification_stats(gaussians) -> None:

@@ -13,6 +13,7 @@ Vectors produced (reference symbol -> fixture):
   LRDecayPolicy, apply_background_color, RandomSequentialSampler    -> misc.npz
   NeRFBlock.forward / NeRFRayRenderingComponent.forward (tiny model) -> nerf_render.npz         (a6, a10)
   Gaussians.densify_and_prune / add_densification_stats / as_ply_dict, adam_utils -> gs_densify.npz (8f rank 3, 4)
+  torch.autograd through integrate_samples (dL/dsigma, dL/drgb)       -> composite_bw.npz    (a17 backward)
   GaussianSplattingModel.save after bake_activations                 -> gs_reference_checkpoint.pt (8f rank 4)
 """
 import importlib.util
@@ -388,9 +389,50 @@ def make_gs_densify():
     print('gs_densify.npz:', (OUT / 'gs_densify.npz').stat().st_size, 'B; rows', P, '->', n_now, '; split noise rows', noise_log[0].shape[0])
 
 
+def make_composite_bw():
+    """Gradients of the reference's OWN differentiable compositing (integrate_samples, src/Methods/NeRF/utils.py:112-136) -> composite_bw.npz:
+    the pin of composite_train_bw (volumerendering.cu:87-202) on reference arithmetic instead of finite differences of the builder's forward.
+    The loss is linear in the four outputs the CUDA backward receives gradients for -- opacity, depth SUM (sum w t: taken from the returned
+    blending weights, so the reference's normalisation by alpha stays out), colour without background, per-sample weights -- with seeded
+    coefficients that are stored next to the gradients.  final_delta is integrate_samples' own parameter: 0.05 keeps T > 0 on every ray (no
+    early-out in either implementation, T_threshold = 0 on the other side); a second case uses the default 1e10."""
+    install_shims()
+    sys.path.insert(0, str(REF))
+    import Framework
+    Framework.config = Framework.ConfigWrapper.fromDict({
+        'GLOBAL': {'RANDOM_SEED': 1618033989, 'ANOMALY_DETECTION': False, 'GPU_INDICES': None, 'DEFAULT_DEVICE': torch.device('cpu'), 'METHOD_TYPE': 'NeRF'},
+        'TRAINING': {'WANDB': {'ACTIVATE': False}},
+    })
+    from Methods.NeRF.utils import integrate_samples
+    g = torch.Generator().manual_seed(4242)
+    n, s = 29, 48
+    depth = torch.sort(torch.rand(n, s, generator=g) * 4 + 2, dim=-1).values
+    dirs = torch.randn(n, 3, generator=g)
+    blob = dict(depth=depth.numpy(), dirs=dirs.numpy())
+    for tag, final_delta, scale in (('open', 0.05, 1.5), ('closed', 1.0e10, 1.5)):
+        dens = (torch.rand(n, s, generator=g) * scale).requires_grad_(True)
+        with torch.no_grad():
+            dens[2] = 0.0          # an empty ray
+        cols = torch.rand(n, s, 3, generator=g).requires_grad_(True)
+        go, gd = torch.randn(n, generator=g), torch.randn(n, generator=g)
+        gr, gw = torch.randn(n, 3, generator=g), torch.randn(n, s, generator=g)
+        rgb, _, alpha, w = integrate_samples(depth, dirs, dens, cols, None, final_delta)
+        loss = (go * alpha[:, 0]).sum() + (gd * (w * depth).sum(-1)).sum() + (gr * rgb).sum() + (gw * w).sum()
+        d_dens, d_cols = torch.autograd.grad(loss, (dens, cols))
+        blob.update({f'{tag}_final_delta': np.float32(final_delta), f'{tag}_dens': dens.detach().numpy(), f'{tag}_cols': cols.detach().numpy(),
+                     f'{tag}_go': go.numpy(), f'{tag}_gd': gd.numpy(), f'{tag}_gr': gr.numpy(), f'{tag}_gw': gw.numpy(),
+                     f'{tag}_d_dens': d_dens.numpy(), f'{tag}_d_cols': d_cols.numpy(), f'{tag}_weights': w.detach().numpy(),
+                     f'{tag}_alpha': alpha.detach().numpy(), f'{tag}_rgb': rgb.detach().numpy()})
+    np.savez_compressed(OUT / 'composite_bw.npz', **blob)
+    print('composite_bw.npz:', (OUT / 'composite_bw.npz').stat().st_size, 'B')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'gs_densify':
         make_gs_densify()   # only this fixture (the others keep their RNG streams)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'composite_bw':
+        make_composite_bw()
     else:
         main()
         make_gs_densify()
+        make_composite_bw()

@@ -131,3 +131,60 @@ def test_sparse_gaussian_gradient_reduction_equals_dense_allreduce():
         assert err < 1e-6 and untouched == 0.0 and n_union == n_mask and 0 < n_union < 500
         assert acc == 3.0 and nobs == 5
     assert out[0][6] == out[1][6]  # identical split noise on every rank
+
+
+def _t_scalars_and_scaler(rank, world):
+    """SURVEY 8(e)'s auxiliary reductions: rm_samples summed, found-inf OR-ed in one collective; the GradScaler built on it skips the SAME
+    step on every rank when only one rank overflowed, and a rank without gradients still enters the sparse reduction."""
+    from nerficg_amd import parallel
+    sums, flags = parallel.allreduce_scalars([torch.tensor(1000 + rank), torch.tensor(2.5)], [torch.tensor(float(rank == 1)), torch.tensor(0.0)])
+    out = {'sums': [float(v) for v in sums], 'flags': [float(v) for v in flags]}
+    out['rays'] = parallel.rays_per_batch_update(4096, 262144, float(sums[0]) * 16, 16)   # 1000.5 samples per rank and iteration from 4096 rays
+    # one parameter, three iterations; rank 1's loss overflows in iteration 1 only
+    p = torch.nn.Parameter(torch.ones(4))
+    opt = torch.optim.SGD([p], lr=0.5)
+    scaler = parallel.DataParallelGradScaler('cpu', init_scale=128.0, growth_interval=10 ** 6)
+    trace = []
+    for it in range(3):
+        x = torch.full((4,), float('inf') if (it == 1 and rank == 1) else 1.0 + rank)
+        loss = (p * x).sum()
+        scaler.scale(loss).backward()
+        parallel.allreduce_gradients([p], average=True) if not (it == 1) else None   # iteration 1: NO gradient collective, only the flag can tell rank 0
+        scaler.piggyback = [torch.tensor(100.0 * (rank + 1))]
+        scaler.step(opt)
+        scaler.update()
+        opt.zero_grad()
+        trace.append((p.detach().tolist(), float(scaler.get_scale()), float(scaler.reduced[0])))
+    out['trace'] = trace
+    # sparse reduction with a rank that holds no gradient at all (its view saw nothing)
+    P = 50
+    q = torch.nn.Parameter(torch.zeros(P, 3))
+    visible = torch.zeros(P, dtype=torch.bool)
+    if rank == 0:
+        visible[::5] = True
+        q.grad = torch.ones(P, 3) * visible[:, None]
+    n_union = parallel.sparse_allreduce_gradients([q], visible, average=False)
+    out['sparse'] = (n_union, float(q.grad.sum()))
+    return out
+
+
+def test_scalar_reductions_and_the_data_parallel_grad_scaler():
+    out = _run(_t_scalars_and_scaler)
+    for r in (0, 1):
+        assert out[r]['sums'] == [2001.0, 5.0] and out[r]['flags'] == [1.0, 0.0]
+        assert out[r]['sparse'] == (10, 30.0)
+    assert out[0]['rays'] == out[1]['rays'] == 262144   # 4096 * 262144 / 1000.5 is far above the cap
+    t0, t1 = out[0]['trace'], out[1]['trace']
+    assert t0 == t1                                         # identical parameters, scale and global sample count after every iteration
+    assert t0[0][0] == [1.0 - 0.5 * 1.5] * 4 and t0[0][1] == 128.0 and t0[0][2] == 300.0
+    assert t0[1][0] == t0[0][0] and t0[1][1] == 64.0       # iteration 1: rank 1 overflowed -> BOTH ranks skipped the step and halved the scale
+    assert t0[2][0] == [t0[1][0][0] - 0.5 * 1.5] * 4
+
+
+def test_rays_per_batch_update_is_the_reference_rule_for_one_rank():
+    from nerficg_amd import parallel
+    # Trainer.py:73-75: measured /= interval; rays = min(next_multiple(rays * target / measured, 256), target)
+    assert parallel.rays_per_batch_update(4096, 262144, 16 * 300_000.0, 16, world=1) == 3584   # 4096 * 262144 / 300000 = 3579.1 -> 3584
+    assert parallel.rays_per_batch_update(4096, 262144, 16 * 300_000.0 * 8, 16, world=8) == 3584
+    assert parallel.rays_per_batch_update(4096, 262144, 16 * 10.0, 16, world=1) == 262144
+    assert parallel.rays_per_batch_update(4096, 262144, 0.0, 16, world=1) == 4096

@@ -74,10 +74,13 @@ def _train_pair(seed):
 
 
 def test_recorded_iteration_follows_the_op_by_op_iteration():
-    """Six iterations on six different batches, background and march jitter given as inputs so that both runs see the same numbers: the
-    replayed graph must leave the same parameters as the op-by-op loop (f32 atomics in the hash-grid backward: not bit-equal)."""
+    """Six iterations on six different batches, background and march jitter given as inputs so that all runs see the same numbers: the
+    replayed graph must leave the same parameters as the op-by-op loop.  Not bit-equal: the dense hash-grid levels and the weight-gradient
+    flush add with f32 atomics, and Adam (eps = 1e-15) amplifies their rounding on tiny gradients -- so the op-by-op loop runs TWICE and its
+    own run-to-run spread is the yardstick (tests/noise.py), not a guessed constant (round 2: 0.00108 against a guessed 0.001)."""
     from nerficg_amd.apex_optimizers import FusedAdam
     from nerficg_amd.graphs import GraphedIteration
+    from tests.noise import assert_within_run_to_run_noise
     cam, o, d = _rays()
     n = 2048
     g = torch.Generator(device=DEV).manual_seed(11)
@@ -87,7 +90,7 @@ def test_recorded_iteration_follows_the_op_by_op_iteration():
         batches.append(dict(origin=o[ids].contiguous(), view_direction=d[ids].contiguous(), rgb=torch.rand(n, 3, device=DEV, generator=g),
                             bg=torch.rand(3, device=DEV, generator=g), noise=torch.rand(n, device=DEV, generator=g)))
     results = {}
-    for mode in ('eager', 'graph'):
+    for mode in ('eager', 'eager_again', 'graph'):
         model, renderer, scaler = _train_pair(seed=9)
         opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=(mode == 'graph'))
         renderer.sample_capacity = 400_000 if mode == 'graph' else None
@@ -110,12 +113,11 @@ def test_recorded_iteration_follows_the_op_by_op_iteration():
             assert opt.effective_step(opt.param_groups[0]) == 6
         results[mode] = (losses, marched, [p.detach().clone() for p in model.parameters()],
                          [net._half_params().clone() for net in (model.encoding_xyz, model.color_mlp_with_encoding)])
-    (l0, m0, p0, h0), (l1, m1, p1, h1) = results['eager'], results['graph']
-    assert m0 == m1 and max(m0) < 400_000, (m0, m1)
-    np.testing.assert_allclose(l1, l0, rtol=2e-3)
-    for a, b in zip(p0, p1):
-        changed = (a - b).abs() > 1e-4 + 1e-2 * a.abs()
-        assert float(changed.float().mean()) < 1e-3, float(changed.float().mean())   # Adam's 1/sqrt(v) amplifies the atomics' rounding on tiny gradients
+    (l0, m0, p0, h0), (l2, m2, p2, _), (l1, m1, p1, h1) = results['eager'], results['eager_again'], results['graph']
+    assert m0 == m1 == m2 and max(m0) < 400_000, (m0, m1, m2)   # sample counts are integers of the march: exact
+    spread = max(abs(a - b) / abs(a) for a, b in zip(l0, l2))
+    np.testing.assert_allclose(l1, l0, rtol=max(2e-3, 4 * spread))
+    assert_within_run_to_run_noise(p1, p0, p2, atol=1e-4, rtol=1e-2, what='parameters after six iterations')
     for p, h in zip(p1, h1):
         assert torch.equal(h, p.half())  # the fp16 compute copy was written by the replayed Adam kernels
 
@@ -159,6 +161,7 @@ def test_folded_weight_decay_gives_the_update_of_the_loss_term():
     """0.5e-6 * mean(w^2) as a loss term (InstantNGP/Loss.py:15) against the same gradient added inside the Adam kernel (FusedAdam.set_l2_slice):
     one step from identical models on an identical batch, with a weight decay 1e6 times the reference's so that it shows in the update."""
     from nerficg_amd.apex_optimizers import FusedAdam
+    from tests.noise import assert_within_run_to_run_noise
     cam, o, d = _rays()
     n = 2048
     gen = torch.Generator(device=DEV).manual_seed(2)
@@ -166,7 +169,7 @@ def test_folded_weight_decay_gives_the_update_of_the_loss_term():
     rgb, bg, noise = torch.rand(n, 3, device=DEV, generator=gen), torch.rand(3, device=DEV, generator=gen), torch.rand(n, device=DEV, generator=gen)
     lam = 0.5
     results = []
-    for folded in (False, True):
+    for folded in (False, False, True):   # the loss-term form twice: its run-to-run spread is the yardstick (tests/noise.py)
         model, renderer, scaler = _train_pair(seed=6)
         opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
         if folded:
@@ -181,9 +184,7 @@ def test_folded_weight_decay_gives_the_update_of_the_loss_term():
             scaler.scale(loss).backward()
             scaler.step(opt); scaler.update(); opt.zero_grad()
         results.append([p.detach().clone() for p in model.parameters()])
-    for a, b in zip(*results):
-        far = (a - b).abs() > 1e-5 + 1e-3 * a.abs()
-        assert float(far.float().mean()) < 1e-3, float(far.float().mean())
+    assert_within_run_to_run_noise(results[2], results[0], results[1], atol=1e-5, rtol=1e-3, what='folded weight decay')
     # and the term matters at this strength: without it the MLP weights end elsewhere
     model, renderer, scaler = _train_pair(seed=6)
     opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
@@ -194,7 +195,7 @@ def test_folded_weight_decay_gives_the_update_of_the_loss_term():
         scaler.scale(loss).backward()
         scaler.step(opt); scaler.update(); opt.zero_grad()
     plain = model.color_mlp_with_encoding.params.detach()
-    assert float((plain - results[0][1]).abs().mean()) > 10 * float((results[1][1] - results[0][1]).abs().mean())
+    assert float((plain - results[0][1]).abs().mean()) > 10 * float((results[2][1] - results[0][1]).abs().mean())
 
 
 def test_capture_without_a_sample_capacity_is_refused():
@@ -254,22 +255,69 @@ def test_fixed_capacity_rasterizer_equals_the_sized_call_and_reports_overflow():
 
     img, radii, grads, vs, (n_inst, n_spans) = frame(None)
     assert n_inst > 50_000 and n_spans > 0
+    _, _, grads_again, vs_again, _ = frame(None)
     img2, radii2, grads2, vs2, counts2 = frame((n_inst + 1000, n_spans + 10))
     assert counts2 == [n_inst, n_spans]
     assert torch.equal(img, img2) and torch.equal(radii, radii2)
-    for a, b in zip(grads + [vs], grads2 + [vs2]):
-        torch.testing.assert_close(b, a, rtol=1e-3, atol=1e-5 * float(a.abs().max()))  # LDS float atomics: the order of the per-Gaussian sums is not fixed
+    for a, b, c in zip(grads + [vs], grads2 + [vs2], grads_again + [vs_again]):
+        # one f32 global atomic per (tile, Gaussian): the order of the per-Gaussian sums over tiles is not fixed -- the sized call's own
+        # run-to-run difference is the yardstick
+        torch.testing.assert_close(b, a, rtol=1e-3, atol=max(1e-5 * float(a.abs().max()), 4 * float((a - c).abs().max())))
     # half the list: the frame still renders (front-most tiles complete), nothing is written behind the list, the count tells
     img3, _, grads3, _, counts3 = frame((n_inst // 2, 0))
     assert counts3[0] == n_inst and bool(torch.isfinite(img3).all()) and all(bool(torch.isfinite(t).all()) for t in grads3)
     assert not torch.equal(img3, img)
 
 
+def test_fixed_capacity_rasterizer_survives_a_span_workspace_that_is_too_small():
+    """Round-2 advisor finding: with fewer row-span records than the frame needs, k_item_scatter<CAPPED> read cnt2 / spans behind the workspace
+    (garbage tile columns -> LDS out of bounds, garbage ids in point_list -> the blend kernels index splat_records out of bounds).  Now clamped like
+    k_item_count: the frame blends what fits, every list entry is a Gaussian index, and last_counts() reports spans > capacity."""
+    from nerficg_amd import diff_gaussian_rasterization as dgr
+    sc = scenes.gs_random_scene(30000, seed=4, extent=1.0, log_scale_mean=np.log(0.08))   # large splats: several tile rows each
+    W, H = 320, 240
+    gcam = scenes.gs_camera(W, H, scenes.orbit_pose(0.5, 0.3, 3.0))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    rs = dgr.GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=gcam['tanfovx'], tanfovy=gcam['tanfovy'], bg=torch.zeros(3, device=DEV),
+                                           scale_modifier=1.0, viewmatrix=T(gcam['viewmatrix']), projmatrix=T(gcam['projmatrix']), sh_degree=3,
+                                           campos=T(gcam['campos']), prefiltered=False, debug=False)
+    P = sc['means3D'].shape[0]
+
+    def frame(capacity):
+        means = T(sc['means3D']).requires_grad_(True)
+        args = dict(means3D=means, means2D=torch.zeros_like(means), opacities=T(sc['opacities'])[:, None], shs=T(sc['shs']), scales=T(sc['scales']),
+                    rotations=T(sc['rotations']))
+        if capacity is None:
+            color, radii = dgr.GaussianRasterizer(rs)(**args)
+        else:
+            with dgr.fixed_capacity(*capacity):
+                color, radii = dgr.GaussianRasterizer(rs)(**args)
+        saved = color.grad_fn.saved_tensors
+        point_list, ranges = saved[12], saved[13]
+        color.sum().backward()
+        return color.detach(), means.grad, point_list, ranges, dgr.last_counts().tolist()
+
+    img, grad, _, _, (n_inst, n_spans) = frame(None)
+    assert n_spans > P and n_inst > n_spans   # the splats do cover several rows and several tiles per row
+    for spans in (n_spans // 3, 1024):
+        img2, grad2, point_list, ranges, counts = frame((n_inst + 1000, spans))
+        assert counts[1] == n_spans > spans and 0 < counts[0] < n_inst        # the span count tells the caller that spans were dropped; the
+                                                                                # instance count is what the surviving spans produced
+        assert bool(torch.isfinite(img2).all()) and bool(torch.isfinite(grad2).all())
+        r = ranges.cpu().numpy().astype(np.int64)
+        assert (r[:, 0] <= r[:, 1]).all() and r.max() <= n_inst + 1000
+        pl = point_list.cpu().numpy()
+        listed = np.concatenate([pl[a:b] for a, b in r]) if len(r) else pl[:0]
+        assert listed.size > 0 and listed.min() >= 0 and listed.max() < P
+        assert not torch.equal(img2, img)
+
+
 def test_recorded_gaussian_step_follows_the_op_by_op_step():
     from nerficg_amd.gaussian_splatting import render_image_training, training_loss
     from nerficg_amd.graphs import gaussian_splatting_step
+    from tests.noise import mismatch_fraction
     results = {}
-    for mode in ('eager', 'graph'):
+    for mode in ('eager', 'eager_again', 'graph'):   # the op-by-op loop twice: its run-to-run spread (float atomics) is the yardstick
         g, cam, poses = _gs_setup(capturable=(mode == 'graph'))
         gen = torch.Generator(device=DEV).manual_seed(3)
         targets = [torch.rand(3, cam.height, cam.width, device=DEV, generator=gen) for _ in poses]
@@ -295,13 +343,14 @@ def test_recorded_gaussian_step_follows_the_op_by_op_step():
         params = [grp['params'][0] for grp in g.optimizer.param_groups]
         results[mode] = (losses, [p.detach().clone() for p in params], [g.optimizer.state[p]['exp_avg'].clone() for p in params],
                          g.densification_gradient_accum.clone(), g.n_observations.clone())
-    (l0, p0, m0, acc0, obs0), (l1, p1, m1, acc1, obs1) = results['eager'], results['graph']
-    np.testing.assert_allclose(l1, l0, rtol=1e-4)
+    (l0, p0, m0, acc0, obs0), (l2, p2, m2, acc2, obs2), (l1, p1, m1, acc1, obs1) = results['eager'], results['eager_again'], results['graph']
+    spread = max(abs(a - b) / abs(a) for a, b in zip(l0, l2))
+    np.testing.assert_allclose(l1, l0, rtol=max(1e-4, 4 * spread))
     assert torch.equal(obs0, obs1)
-    torch.testing.assert_close(acc1, acc0, rtol=1e-2, atol=1e-3 * float(acc0.abs().max()))
-    for a, b in zip(m0, m1):     # first moments: linear in the gradients of all six steps (a few entries feel the parameter outliers below)
-        off = (a - b).abs() > 1e-2 * a.abs() + 1e-3 * float(a.abs().max())
-        assert float(off.float().mean()) < 1e-3, float(off.float().mean())
+    torch.testing.assert_close(acc1, acc0, rtol=1e-2, atol=max(1e-3 * float(acc0.abs().max()), 4 * float((acc2 - acc0).abs().max())))
+    for a, b, c in zip(m0, m1, m2):     # first moments: linear in the gradients of all six steps (a few entries feel the parameter outliers below)
+        tol = dict(atol=1e-3 * float(a.abs().max()), rtol=1e-2)
+        assert mismatch_fraction(a, b, **tol) <= 4 * mismatch_fraction(a, c, **tol) + 2e-3
     # parameters: with eps = 1e-15 Adam turns a gradient that is rounding noise (atomics order) into a full-size step of either sign, so a
     # minority of entries may differ by up to lr * steps; the bulk must agree
     for a, b in zip(p0, p1):

@@ -244,6 +244,29 @@ def test_composite_train_fw_parity(vr, n_rays, max_len):
     assert np.array_equal(got[4][keep] == 0, ref[4][keep] == 0)
 
 
+def test_composite_train_fw_bw_against_the_reference_autograd_golden(vr, golden_dir):
+    """The HIP compositing kernels against gradients the REFERENCE computed: torch.autograd through its own integrate_samples
+    (src/Methods/NeRF/utils.py:112-136), stored by tests/golden/make_golden.py::make_composite_bw ('open' case: final delta 0.05, T > 0 on every
+    ray, T_threshold = 0 here -- no early-out on either side)."""
+    g = np.load(golden_dir / 'composite_bw.npz')
+    depth, dirs = g['depth'], g['dirs']
+    n, s = depth.shape
+    dens, cols = g['open_dens'], g['open_cols']
+    deltas = (np.concatenate([depth[:, 1:] - depth[:, :-1], np.full((n, 1), g['open_final_delta'], np.float32)], -1)
+              * np.linalg.norm(dirs, axis=-1, keepdims=True)).astype(np.float32)
+    rays_a = np.stack([np.arange(n), np.arange(n) * s, np.full(n, s)], -1).astype(np.int64)
+    flat = lambda a: T(np.ascontiguousarray(a.reshape(-1, *a.shape[2:])))
+    total, opacity, dsum, rgb, ws = vr.composite_train_fw(flat(dens), flat(cols), flat(deltas), flat(depth), T(rays_a), 0.0)
+    np.testing.assert_allclose(ws.cpu().numpy().reshape(n, s), g['open_weights'], rtol=3e-5, atol=1e-7)
+    np.testing.assert_allclose(rgb.cpu().numpy(), g['open_rgb'], rtol=3e-5, atol=2e-6)
+    np.testing.assert_allclose(opacity.cpu().numpy(), g['open_alpha'][:, 0], rtol=3e-5, atol=2e-6)
+    ds, dr = vr.composite_train_bw(T(g['open_go']), T(g['open_gd']), T(g['open_gr']), flat(g['open_gw']), flat(dens), flat(cols), ws, flat(deltas),
+                                   flat(depth), T(rays_a), opacity, dsum, rgb, 0.0)
+    want_s, want_c = g['open_d_dens'], g['open_d_cols']
+    np.testing.assert_allclose(dr.cpu().numpy().reshape(n, s, 3), want_c, rtol=1e-4, atol=2e-6 * np.abs(want_c).max())
+    np.testing.assert_allclose(ds.cpu().numpy().reshape(n, s), want_s, rtol=3e-4, atol=5e-5 * np.abs(want_s).max())   # suffix sums: relative to the scale
+
+
 @pytest.mark.parametrize('n_rays,max_len', [(64, 30), (200, 300)])
 def test_composite_train_bw_parity(vr, n_rays, max_len):
     rays_a, m, sig, rgbs, dl, ts, rng = _composite_inputs(100 + n_rays, n_rays, max_len)

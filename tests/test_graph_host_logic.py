@@ -35,13 +35,48 @@ def test_fused_adam_flags():
     opt = FusedAdam([p], lr=1e-3, capturable=True)
     assert opt.capturable and opt._step_supports_amp_scaling
     opt.set_l2_slice(p, 3, 0.5)
-    assert opt._l2_slices[id(p)] == (3, 0.5)
+    assert opt._l2_slice_of(p) == (3, 0.5)
     opt.set_l2_slice(p, 0, 0.0)
-    assert id(p) not in opt._l2_slices
+    assert id(p) not in opt._l2_slices and opt._l2_slice_of(p) == (0, 0.0)
+    # the slice belongs to the parameter OBJECT: another tensor never inherits it, a dropped iteration object removes it (round-2 advisor finding)
+    opt.set_l2_slice(p, 3, 0.5)
+    q = torch.nn.Parameter(torch.zeros(4))
+    opt._l2_slices[id(q)] = opt._l2_slices[id(p)]          # what a reused id would look like
+    assert opt._l2_slice_of(q) == (0, 0.0) and id(q) not in opt._l2_slices
+    opt.clear_l2_slices()
+    assert opt._l2_slice_of(p) == (0, 0.0)
     with pytest.raises(RuntimeError, match='master_weights'):
         FusedAdam([p], master_weights=True)
     with pytest.raises(RuntimeError, match='AMSGrad'):
         FusedAdam([p], amsgrad=True)
+
+
+def test_fused_adam_group_lookup_and_saved_skips():
+    """effective_step() finds a group by identity (list.index would compare the groups' 'params' lists with ==: tensor == tensor, ambiguous
+    truth value for the reference's one-tensor-per-group layout), and the overflow-skipped steps travel in state_dict()."""
+    from nerficg_amd.apex_optimizers import FusedAdam
+    a, b = torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(6))
+    opt = FusedAdam([{'params': [a], 'name': 'a'}, {'params': [b], 'name': 'b'}], lr=1e-3)
+    opt.param_groups[1]['step'] = 5
+    assert opt.effective_step(opt.param_groups[1]) == 5 and opt.effective_step(opt.param_groups[0]) == 0
+    opt._amp[1] = (torch.full((1,), 2, dtype=torch.int32), torch.ones(2))
+    assert opt.effective_step(opt.param_groups[1]) == 3
+    sd = opt.state_dict()
+    assert [g['skipped_steps'] for g in sd['param_groups']] == [0, 2]
+    opt2 = FusedAdam([{'params': [a], 'name': 'a'}, {'params': [b], 'name': 'b'}], lr=1e-3)
+    opt2.load_state_dict(sd)
+    assert opt2.effective_step(opt2.param_groups[1]) == 3 and 'skipped_steps' not in opt2.param_groups[1]
+
+
+def test_graphed_iteration_close_runs_its_hooks():
+    from nerficg_amd.graphs import GraphedIteration
+    if not torch.cuda.is_available():
+        it = GraphedIteration.__new__(GraphedIteration)
+        it.graph = it.outputs = None
+        seen = []
+        it.on_close = (lambda: seen.append(1),)
+        it.close(); it.close()
+        assert seen == [1]
 
 
 def test_recorded_iterations_need_a_capturable_optimizer():

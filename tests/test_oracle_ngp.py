@@ -83,6 +83,32 @@ def test_composite_train_bw_matches_finite_differences():
         assert abs(fd - dr[k, 1]) <= 2e-2 * max(1.0, abs(fd)), (k, fd, dr[k, 1])
 
 
+@pytest.mark.parametrize('tag', ['open', 'closed'])
+def test_composite_train_bw_matches_reference_autograd(golden_dir, tag):
+    """composite_train_bw (volumerendering.cu:87-202) against torch.autograd through the reference's own integrate_samples
+    (src/Methods/NeRF/utils.py:112-136; tests/golden/make_golden.py::make_composite_bw): same deltas supplied explicitly, T_threshold = 0.
+    'open': final delta 0.05, T stays > 0 on every ray -- no early-out on either side.  'closed': the reference's default 1e10, where the last
+    sample drives T to exactly 0 (its own gradient d alpha / d sigma = delta * exp(-sigma delta) is 0 on both sides)."""
+    g = np.load(golden_dir / 'composite_bw.npz')
+    depth, dirs = g['depth'], g['dirs']
+    n, s = depth.shape
+    dens, cols = g[f'{tag}_dens'], g[f'{tag}_cols']
+    final = np.full((n, 1), g[f'{tag}_final_delta'], np.float32)
+    deltas = (np.concatenate([depth[:, 1:] - depth[:, :-1], final], -1) * np.linalg.norm(dirs, axis=-1, keepdims=True)).astype(np.float32)
+    rays_a = np.stack([np.arange(n), np.arange(n) * s, np.full(n, s)], -1).astype(np.int64)
+    flat = lambda a: np.ascontiguousarray(a.reshape(-1, *a.shape[2:]))
+    total, opacity, dsum, rgb, ws = oracle.composite_train_fw(flat(dens), flat(cols), flat(deltas), flat(depth), rays_a, 0.0)
+    np.testing.assert_allclose(ws.reshape(n, s), g[f'{tag}_weights'], rtol=3e-5, atol=1e-7)
+    np.testing.assert_allclose(rgb, g[f'{tag}_rgb'], rtol=3e-5, atol=1e-6)
+    ds, dr = oracle.composite_train_bw(g[f'{tag}_go'], g[f'{tag}_gd'], g[f'{tag}_gr'], flat(g[f'{tag}_gw']), flat(dens), flat(cols), ws, flat(deltas),
+                                       flat(depth), rays_a, opacity, dsum, rgb, 0.0)
+    want_s, want_c = g[f'{tag}_d_dens'], g[f'{tag}_d_cols']
+    np.testing.assert_allclose(dr.reshape(n, s, 3), want_c, rtol=1e-4, atol=1e-6 * np.abs(want_c).max())
+    # d/d sigma is a suffix sum over the ray (cancellation): tolerance relative to the tensor's scale
+    np.testing.assert_allclose(ds.reshape(n, s), want_s, rtol=2e-4, atol=2e-5 * np.abs(want_s).max())
+    assert np.abs(want_s).max() > 0.1 and np.abs(want_s[2]).max() > 0   # also on the empty ray (sigma = 0): d alpha / d sigma = delta there
+
+
 def test_composite_test_fw_chunked_equals_train_fw():
     """Compositing a ray in chunks through composite_test_fw (volumerendering.cu:205-249) reproduces composite_train_fw."""
     n, s_total, chunk = 6, 24, 8

@@ -46,7 +46,7 @@ def step(i):
         parallel.allreduce_gradients(params, average=True)
         moved[0] += g.get_positions.shape[0]
     else:
-        moved[0] += parallel.sparse_allreduce_gradients(params, out['visibility_mask'], average=True)
+        moved[0] += max(parallel.sparse_allreduce_gradients(params, out["visibility_mask"], average=True), 0)  # -1 = single process: nothing travels
     moved[1] += g.get_positions.shape[0]
     g.optimizer.step(); g.optimizer.zero_grad()
 
