@@ -180,44 +180,66 @@ def time_gs(gs, reps=5, barrier=None):
         c.backward(g)
 
     t_fb, fb_trials = timed(fwd_bwd)
+    # per-kernel durations of THIS run: the library records a HIP event on the launch stream behind each of its kernels (stage timer,
+    # include/nerficg_hip.h group 12) over `reps` more forward + backward frames, outside the timed loops above
+    from nerficg_amd import _lib
+    with _lib.stage_timer() as st:
+        for _ in range(reps):
+            fwd_bwd()
+    stage_ms = {k: (tot / reps, cnt // reps) for k, (tot, cnt) in st.by_name().items()}   # name -> (ms per frame, launches per frame)
     color, radii = fwd(True)
     n_inst = color.grad_fn.num_rendered if color.grad_fn is not None else -1
-    return {'msplats_per_s_fwd': round(n / t_fwd / 1e6, 2), 'msplats_per_s_fwd_bwd': round(n / t_fb / 1e6, 2), 'ms_fwd': round(t_fwd * 1e3, 3),
+    return {'stage_ms': stage_ms, 'stage_frames': reps, 'msplats_per_s_fwd': round(n / t_fwd / 1e6, 2), 'msplats_per_s_fwd_bwd': round(n / t_fb / 1e6, 2), 'ms_fwd': round(t_fwd * 1e3, 3),
             'ms_fwd_bwd': round(t_fb * 1e3, 3), 'trials_ms_fwd': [round(v * 1e3, 3) for v in fwd_trials],
             'trials_ms_fwd_bwd': [round(v * 1e3, 3) for v in fb_trials], 'gaussians': n, 'visible': int((radii > 0).sum().item()), 'instances': int(n_inst),
             'image': f'{GS_W}x{GS_H}'}
 
 
+def csrc_digests():
+    """sha256[:16] of every translation unit / header of the library: profiles/pmc_summary.json records them at collection time, and a counter
+    entry is only quoted for a kernel whose source file has not changed since (otherwise the line would carry numbers of another build)."""
+    import hashlib
+    return {p.name: hashlib.sha256(p.read_bytes()).hexdigest()[:16] for p in sorted((ROOT / 'nerficg_amd' / 'csrc').glob('*.h*'))}
+
+
+def pmc_entry(pmc_all, kernel, source_file):
+    """(counter entry or {}, provenance string) of `kernel` from profiles/pmc_summary.json, {} when its source changed since the collection."""
+    meta = pmc_all.get('_meta', {})
+    if kernel not in pmc_all:
+        return {}, 'no counter entry in profiles/pmc_summary.json'
+    if meta.get('csrc_sha', {}).get(source_file) != csrc_digests().get(source_file):
+        return {}, f'profiles/pmc_summary.json predates the current {source_file}: not quoted'
+    return pmc_all[kernel], f"profiles/pmc_summary.json ({meta.get('round', '?')}, rocprofv3 --pmc, same {source_file})"
+
+
 def gs_kernel_rooflines(gs_res, pmc_all):
     """Per-kernel entries of the 3DGS leg on SURVEY 8(d)'s per-stage byte model: blend 40 B per instance + 20 B per pixel; backward blend
     76 B per instance + 20 B per pixel; preprocess 308 B and its backward 472 B per visible Gaussian; binning + sort 108 B per instance (the
-    reference's key / value traffic -- this build moves less).  Durations and memory-side traffic come from the committed rocprofv3 summaries
-    of the same frame (profiles/r02_gs_kernel_stats.csv = tools/bench_gs.py 1000000 under rocprofv3 --kernel-trace --stats, profiles/pmc_summary.json),
-    not from this run: the kernels are launched inside
-    the C ABI, where events cannot be placed between them."""
-    import csv
-    stats = ROOT / 'profiles' / 'r02_gs_kernel_stats.csv'
-    if not stats.exists():
+    reference's key / value traffic -- this build moves less).  Durations are measured IN THIS RUN: HIP events the library records on the
+    launch stream behind each of its kernels (stage timer), averaged over gs_res['stage_frames'] forward + backward frames.  `traffic`
+    (memory-side bytes from rocprofv3 --pmc) can only come from a profiler run: it is quoted from profiles/pmc_summary.json when the
+    kernel's source file is unchanged since that collection, else null."""
+    stage = gs_res.get('stage_ms') or {}
+    if not stage:
         return None
-    dur = {}
-    for r in csv.DictReader(open(stats)):
-        name = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-        dur[name] = float(r['AverageNs']) * 1e-9
     P, D, HW = gs_res['visible'], gs_res['instances'], GS_W * GS_H
     model = {'k_render': 40 * D + 20 * HW, 'k_render_bw': 76 * D + 20 * HW, 'k_preprocess': 308 * P, 'k_preprocess_bw': 472 * P}
     out = {}
     for k, nbytes in model.items():
-        if k in dur:
-            out[k] = {'ms': round(dur[k] * 1e3, 4), 'algorithmic_bytes': nbytes, 'achieved': round(nbytes / dur[k] / 1e9, 1),
-                      'frac': round(nbytes / dur[k] / 1e9 / HBM_PEAK_GBS, 4), 'traffic': pmc_all.get(k, {}).get('hbm_bytes_per_launch')}
-    binning = [k for k in dur if k.startswith(('k_depth_keys', 'k_radix', 'k_span', 'k_item', 'k_scan_tiles'))]
+        if k in stage:
+            ms = stage[k][0]
+            entry, src = pmc_entry(pmc_all, k, 'gs_raster.hip')
+            out[k] = {'ms': round(ms, 4), 'algorithmic_bytes': nbytes, 'achieved': round(nbytes / ms / 1e6, 1),
+                      'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), 'traffic': entry.get('hbm_bytes_per_launch'), 'traffic_source': src}
+    binning = [k for k in stage if k.startswith(('k_depth_keys', 'k_radix', 'k_span', 'k_item', 'k_scan_tiles'))]
     if binning:
-        passes = {k: (4 if k.startswith('k_radix') else 1) for k in binning}
-        t = sum(dur[k] * passes[k] for k in binning)
-        tr = [pmc_all.get(k, {}).get('hbm_bytes_per_launch') for k in binning]
-        out['binning (depth sort + span scatter, %d kernels)' % sum(passes.values())] = {
-            'ms': round(t * 1e3, 4), 'algorithmic_bytes': 108 * D, 'achieved': round(108 * D / t / 1e9, 1), 'frac': round(108 * D / t / 1e9 / HBM_PEAK_GBS, 4),
-            'traffic': int(sum(x * passes[k] for x, k in zip(tr, binning))) if all(x is not None for x in tr) else None}
+        t = sum(stage[k][0] for k in binning)          # ms per frame, all launches of the kernel (4 per radix kernel)
+        n_launch = sum(stage[k][1] for k in binning)
+        out['binning (depth sort + span scatter, %d launches)' % n_launch] = {
+            'ms': round(t, 4), 'algorithmic_bytes': 108 * D, 'achieved': round(108 * D / t / 1e6, 1), 'frac': round(108 * D / t / 1e6 / HBM_PEAK_GBS, 4),
+            'traffic': None, 'per_kernel_ms': {k: round(stage[k][0], 4) for k in sorted(binning)}}
+    out['_all_kernels_ms_per_frame'] = round(sum(v[0] for v in stage.values()), 4)
+    out['_timing'] = f"HIP events on the launch stream behind every kernel, {gs_res.get('stage_frames')} forward + backward frames of this run"
     return out
 
 
@@ -308,9 +330,36 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=60):
             for p, q in zip(model.parameters(), saved):
                 p.copy_(q)
 
+    # the training kernels on their rooflines, timed in THIS run (stage timer: HIP events behind every kernel of the query forward / backward):
+    # SURVEY 8(d) per sample -- hash-grid encode 512 B of table reads; grid backward 512 B read + 512 B read-modify-write = 1024 B;
+    # MLP forward 20 480 FLOP, backward 2 x forward = 40 960 FLOP (both networks together)
+    from nerficg_amd import _lib
+    n_prof = 10
+    with _lib.stage_timer() as st:
+        m_prof = sum(step(3 + iters + i) for i in range(n_prof)) / n_prof
+    stage = {k: tot_ms / n_prof for k, (tot_ms, _) in st.by_name().items()}   # ms per iteration
+    roof = {}
+    def hbm(name, kernels, bytes_per_sample):
+        ms = sum(stage.get(k, 0.0) for k in kernels)
+        if ms > 0:
+            roof[name] = {'bound': 'hbm', 'kernels': [k for k in kernels if k in stage], 'ms': round(ms, 4), 'algorithmic_bytes_per_sample': bytes_per_sample,
+                          'achieved': round(bytes_per_sample * m_prof / ms / 1e6, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                          'frac': round(bytes_per_sample * m_prof / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    def mfma(name, kernels, flop_per_sample):
+        ms = sum(stage.get(k, 0.0) for k in kernels)
+        if ms > 0:
+            roof[name] = {'bound': 'mfma', 'kernels': [k for k in kernels if k in stage], 'ms': round(ms, 4), 'flop_per_sample': flop_per_sample,
+                          'achieved': round(flop_per_sample * m_prof / ms / 1e9, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                          'frac': round(flop_per_sample * m_prof / ms / 1e9 / MFMA_PEAK_TFLOPS, 4)}
+    hbm('grid_encode', ['k_grid_encode<train>'], 512)
+    hbm('grid_backward', ['k_grid_bwd', 'k_gb_split<count>', 'k_gb_scan', 'k_gb_split<write>', 'k_gb_accumulate'], 1024)
+    mfma('mlp_forward', ['k_nwie_fwd<density>', 'k_nwie_fwd<colour>'], MLP_FLOP_PER_SAMPLE)
+    mfma('mlp_backward', ['k_nwie_bwd<colour>', 'k_nwie_bwd<density>'], 2 * MLP_FLOP_PER_SAMPLE)
+    roof['_per_kernel_ms'] = {k: round(v, 4) for k, v in sorted(stage.items())}
+    roof['_timing'] = f'HIP events on the launch stream behind every kernel of the query forward / backward, {n_prof} op-by-op iterations of this run, {round(m_prof)} samples each'
     restore()
     res = {'metric': 'InstantNGP training iteration (drop-in modules, fwd + bwd + Adam)', 'ms_per_iteration': round(dt * 1e3, 3), 'rays': n_rays,
-           'samples_per_iteration': int(tot / iters), 'msamples_per_s': round(tot / iters / dt / 1e6, 1)}
+           'samples_per_iteration': int(tot / iters), 'msamples_per_s': round(tot / iters / dt / 1e6, 1), 'roofline': roof}
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():  # N > 1: no recording next to a live RCCL communicator (its watchdog thread polls events)
         res['hip_graph'] = None
@@ -670,7 +719,8 @@ def main():
                 pmc_all = json.loads(pmc.read_text())
             except Exception:
                 pmc_all = {}
-        enc_pmc = pmc_all.get(DOMINANT_KERNEL, {})
+        enc_pmc, enc_pmc_src = pmc_entry(pmc_all, DOMINANT_KERNEL, 'ngp_net.hip')
+        mlp_pmc, mlp_pmc_src = pmc_entry(pmc_all, 'k_ngp_mlp<SRC_TILED>', 'ngp_net.hip')
         result = {
             'metric': 'Mrays/s (INGP lego)', 'value': round(value, 4), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
@@ -691,11 +741,12 @@ def main():
                          'samples_per_launch': k_live, 'slots_per_launch': kt['slots_per_launch'],
                          'limiter': {'resource': 'L1 (TCP) tag lookups', 'achieved': enc_pmc.get('tcp_accesses_per_clk_per_cu'), 'peak': 1.0,
                                      'unit': 'cache-line lookups per clock per CU', 'l1_hit_rate': enc_pmc.get('l1_hit_rate'),
-                                     'l2_hit_rate': enc_pmc.get('l2_hit_rate'), 'source': 'profiles/pmc_summary.json (rocprofv3 --pmc)'}},
+                                     'l2_hit_rate': enc_pmc.get('l2_hit_rate'), 'source': enc_pmc_src},
+                         'traffic_source': enc_pmc_src},
             # second kernel of the pair: the tiny-MLP chain on MFMA (20 480 FLOP per sample, padded layer widths)
             'roofline_mfma': {'bound': 'mfma', 'kernel': 'k_ngp_mlp<SRC_TILED>', 'achieved': round(MLP_FLOP_PER_SAMPLE * k_live / (mlp_ms * 1e-3) / 1e12, 2),
                               'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(MLP_FLOP_PER_SAMPLE * k_live / (mlp_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                              'traffic': pmc_all.get('k_ngp_mlp<SRC_TILED>', {}).get('hbm_bytes_per_launch'), 'kernel_ms': round(mlp_ms, 4),
+                              'traffic': mlp_pmc.get('hbm_bytes_per_launch'), 'traffic_source': mlp_pmc_src, 'kernel_ms': round(mlp_ms, 4),
                               'kernel_ms_min_pose': round(kt['mlp_ms_min'], 4), 'kernel_ms_max_pose': round(kt['mlp_ms_max'], 4),
                               'flop_per_sample': MLP_FLOP_PER_SAMPLE, 'samples_per_launch': k_live},
         }

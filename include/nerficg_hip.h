@@ -284,8 +284,8 @@ int nrc_generate_rays(int32_t width, int32_t height, const double* intrinsics, c
  *            (tile_off[T] + k) * 64 + l.  A shard is a range of tiles [tile_begin, tile_begin + n_tiles) of the
  *            ceil(W/8) x ceil(H/8) tile grid (row-major); per-ray arrays have n_tiles*64 entries.
  *   1. nrc_ngp_render_count : pixel -> ray (Group 5 semantics) -> centre shift, box slab test, near/far clamp -> DDA sample
- *                             count; writes ray_od (n_tiles,6,64) = per-tile SoA of (o - centre, d), ray_t (n,2), ray_cnt (n), tile_rows (n_tiles),
- *                             tile_off (n_tiles+1), counter = (total rows, n_tiles).  intr/c2w/center3/half3: HOST pointers.
+ *                             count; writes ray_od (n_tiles,6,64) = per-tile SoA of (o - centre, d), ray_t (n,2), ray_cnt (n), tile_rows (2*n_tiles: rows per tile,
+ *                             then samples per tile), tile_off (n_tiles+1), counter = (total rows, total samples).  intr/c2w/center3/half3: HOST pointers.
  *   2. nrc_ngp_render_write : ts (rows*64) f32 (-1 = hole), row_tile (rows) i32.
  *   3. nrc_ngp_query_samples: slots -> packed (h0, r, g, b) fp16 (sigma = exp(h0)); xyz_min3/xyz_size3 HOST pointers;
  *                             n_ray_tiles = tiles in ray_od (their SH coefficients are evaluated once per ray);
@@ -468,6 +468,20 @@ int nrc_occupancy_carve_view(uint8_t* remaining, int32_t cascades, int32_t grid_
                              float center_y, int32_t width, int32_t height, float near_plane, float far_plane,
                              const float* alpha_mask, int32_t subtractive, nrc_stream_t stream);
 int nrc_occupancy_carve_finish(const uint8_t* remaining, int32_t cascades, int32_t grid_size, float* grid, nrc_stream_t stream);
+
+/* =====================================================================================================
+ * Group 12 -- stage timer (measurement; no reference counterpart).  bench.py's per-kernel roofline entries must be
+ * timed with HIP events on the launch stream INSIDE the run that reports them; the kernels of one entry point are
+ * launched back to back inside the library, where a caller cannot place events.  While armed, the multi-kernel entry
+ * points (nrc_gs_preprocess / nrc_gs_bin_render / nrc_gs_backward, nrc_grid_backward, nrc_ngp_train_query_forward /
+ * _backward) record an event behind each of their kernels; nothing is recorded inside a stream capture.
+ *   _begin(capacity): clears the list, arms the timer (at most `capacity` marks are kept).
+ *   _end: disarms, waits for the last mark, writes up to max_stages (name, milliseconds) pairs in launch order -- names as
+ *         32-byte zero-terminated slots -- and the number written to *count (host pointers).
+ * One harness, one stream, one call sequence at a time (not thread-safe).
+ * ===================================================================================================== */
+int nrc_stage_timer_begin(int32_t capacity);
+int nrc_stage_timer_end(int32_t max_stages, char* names, float* ms, int32_t* count);
 
 #ifdef __cplusplus
 }

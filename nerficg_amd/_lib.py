@@ -99,3 +99,34 @@ def check_input(t, name: str, dtype=None) -> None:
         raise RuntimeError(f'{name} must be contiguous')
     if dtype is not None and t.dtype != dtype:
         raise RuntimeError(f'{name} must have dtype {dtype}, got {t.dtype}')
+
+
+class stage_timer:
+    """Context manager around the library's stage timer (include/nerficg_hip.h group 12): HIP events on the launch stream behind every kernel
+    of the multi-kernel entry points, recorded by the library itself.  After the block, `.stages` is the list of (kernel name, ms) in launch
+    order and `.by_name()` the per-name (total ms, launches).  Measurement only; eager calls only (nothing is recorded inside a capture)."""
+
+    def __init__(self, capacity: int = 1 << 16) -> None:
+        self.capacity = int(capacity)
+        self.stages: list[tuple[str, float]] = []
+
+    def __enter__(self):
+        check(load().nrc_stage_timer_begin(self.capacity), 'stage_timer_begin')
+        return self
+
+    def __exit__(self, *exc):
+        names = ctypes.create_string_buffer(32 * self.capacity)
+        ms = (ctypes.c_float * self.capacity)()
+        n = ctypes.c_int32(0)
+        check(load().nrc_stage_timer_end(self.capacity, ctypes.cast(names, ctypes.c_void_p), ctypes.cast(ms, ctypes.c_void_p),
+                                         ctypes.cast(ctypes.pointer(n), ctypes.c_void_p)), 'stage_timer_end')
+        raw = names.raw
+        self.stages = [(raw[32 * i:32 * i + 32].split(b'\0', 1)[0].decode(), float(ms[i])) for i in range(n.value)]
+        return False
+
+    def by_name(self) -> dict[str, tuple[float, int]]:
+        out: dict[str, tuple[float, int]] = {}
+        for name, t in self.stages:
+            tot, cnt = out.get(name, (0.0, 0))
+            out[name] = (tot + t, cnt + 1)
+        return out

@@ -22,6 +22,13 @@ void nrc_set_last_hip_error(int e);  // lib_info.hip
 
 static inline int64_t nrc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Stage timer (include/nerficg_hip.h group 12): when armed, NRC_STAGE(s, "name") records a HIP event on the launch stream `s` behind the kernel(s)
+// just launched; the time between two consecutive marks is the stage `name`.  NRC_STAGE(s, nullptr) opens an entry point (what ran before it
+// belongs to nobody).  Disarmed (the default, and always inside a stream capture) it is one load and a predictable branch.
+extern int g_nrc_stage_timer_armed;            // lib_info.hip
+void nrc_stage_mark(hipStream_t s, const char* name);
+#define NRC_STAGE(s, name) do { if (g_nrc_stage_timer_armed) nrc_stage_mark((s), (name)); } while (0)
+
 // Clearing device memory with a kernel of our own instead of hipMemsetAsync.  Outside a capture the two cost the same (ROCm runs a fill
 // kernel for the memset); inside a stream capture the memset becomes a graph memset node, and replays of graphs holding such nodes were
 // measured to finish AFTER the launch stream considered them done (an event recorded behind the replay fires early; only a device-wide

@@ -1611,6 +1611,7 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
     const int n_tiles = cam.gx * cam.gy;
     const bool lds_path = cam.gx <= SPAN_DIM_MAX && cam.gy <= SPAN_DIM_MAX && bin_hist != nullptr;
     if (instance_capacity > 0 && P > 0 && !lds_path) return NRC_ERR_UNSUPPORTED;  // the per-tile key sort fallback sizes its keys from the count
+    NRC_STAGE(s, nullptr);
     if (!(P > 0 && lds_path)) nrc_zero_async(tile_counts, sizeof(uint32_t) * n_tiles, s);  // only the global-atomic fallback counts into it
     if (P > 0) {
         if (!means3D || !opacities || !radii || !depths || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !tiles_touched || !splat_records)
@@ -1619,26 +1620,38 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
         hipLaunchKernelGGL(k_preprocess, dim3(nrc_cdiv(P, PRE_BLOCK)), dim3(PRE_BLOCK), 0, s, P, cam, camera_dev, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations,
                            cov3D_precomp, radii, depths, points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched,
                            lds_path ? (uint32_t*)nullptr : tile_counts, (float4*)splat_records);
+        NRC_STAGE(s, "k_preprocess");
         if (lds_path) {
             const BinWs w = gs_bin_ws(bin_hist, P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P));
             // depth pre-sort of the Gaussians: 4 stable 8-bit passes, (keyA,valA) -> ... -> (keyA,valA); valA = depth order
             hipLaunchKernelGGL(k_depth_keys, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, w.keyA, w.valA, w.rectA, w.tot);
+            NRC_STAGE(s, "k_depth_keys");
             for (int pass = 0; pass < 4; pass++) {
                 const uint32_t *ki = (pass & 1) ? w.keyB : w.keyA, *vi = (pass & 1) ? w.valB : w.valA, *ri = (pass & 1) ? w.rectB : w.rectA;
                 uint32_t *ko = (pass & 1) ? w.keyA : w.keyB, *vo = (pass & 1) ? w.valA : w.valB, *ro = (pass & 1) ? w.rectA : w.rectB;
                 hipLaunchKernelGGL(k_radix_count, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk4, ki, w.counts, w.tot + 256 * pass);
+                NRC_STAGE(s, "k_radix_count");
                 hipLaunchKernelGGL(k_radix_offsets, dim3(256), dim3(256), 0, s, w.nblk, w.nblk4, w.counts, w.tot + 256 * pass, w.offs);
+                NRC_STAGE(s, "k_radix_offsets");
                 hipLaunchKernelGGL(k_radix_scatter, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk4, ki, vi, ri, w.counts, w.offs, ko, vo, ro);
+                NRC_STAGE(s, "k_radix_scatter");
             }
             // level 1: row spans in depth order; level 2 counting + scans: tile ranges and the per-(item, tile) cursors
             hipLaunchKernelGGL(k_span_count, dim3(w.nb1), dim3(64), 0, s, P, w.nb1, w.chunk1, cam.gy, w.valA, w.rectA, w.cnt1);
+            NRC_STAGE(s, "k_span_count");
             hipLaunchKernelGGL(k_span_scan, dim3(cam.gy), dim3(256), 0, s, w.nb1, w.cnt1, w.rowtot);
+            NRC_STAGE(s, "k_span_scan");
             hipLaunchKernelGGL(k_span_rows, dim3(1), dim3(256), 0, s, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, num_rendered + 1, w.meta);
+            NRC_STAGE(s, "k_span_rows");
             hipLaunchKernelGGL(k_span_scatter, dim3(w.nb1), dim3(64), 0, s, P, w.nb1, w.chunk1, cam.gy, w.valA, w.rectA, w.cnt1, w.roff, w.cap, w.spans);
+            NRC_STAGE(s, "k_span_scatter");
             hipLaunchKernelGGL(k_item_count, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.cap, w.item_cap,
                                w.spans, w.cnt2);
+            NRC_STAGE(s, "k_item_count");
             hipLaunchKernelGGL(k_item_scan, dim3((unsigned)nrc_cdiv(cam.gx, 64), cam.gy), dim3(1024), 0, s, cam.gx, w.item_cap, w.nitems, w.ioff, w.cnt2, w.tcount);
+            NRC_STAGE(s, "k_item_scan");
             hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, w.tcount, n_tiles, list_cap, ranges, tile_fill, num_rendered);
+            NRC_STAGE(s, "k_scan_tiles");
         }
     }
     if (!(P > 0 && lds_path)) {
@@ -1661,6 +1674,7 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
     GsCam cam = {};
     cam.W = W; cam.H = H; cam.gx = (W + TILE - 1) / TILE; cam.gy = (H + TILE - 1) / TILE;
     hipStream_t s = (hipStream_t)stream;
+    NRC_STAGE(s, nullptr);
     if (P > 0) {
         if (!radii || !depths || !points_xy || !conic_opacity || !rgb || !point_list || !splat_records) return NRC_ERR_INVALID;
         const int n_tiles = cam.gx * cam.gy;
@@ -1674,17 +1688,21 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
             else
                 hipLaunchKernelGGL(k_item_scatter<false>, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.cap, w.item_cap, w.spans,
                                    w.cnt2, ranges, list_cap, point_list);
+            NRC_STAGE(s, "k_item_scatter");
         } else {
             hipLaunchKernelGGL(k_scatter, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, ranges, tile_fill, keys);
             hipLaunchKernelGGL((k_sort_tiles<0, 1024>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
             hipLaunchKernelGGL((k_sort_tiles<1024, 4096>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
             hipLaunchKernelGGL((k_sort_tiles<4096, SORT_LDS_CAP>), dim3(n_tiles), dim3(256), 0, s, ranges, keys, point_list);
+            NRC_STAGE(s, "k_scatter+k_sort_tiles");
         }
     }
     // tile_fill has served the fallback scatter (if any): it now carries the launch order of the tiles, longest list first, for both render kernels
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cam.gx * cam.gy, ranges, tile_fill);
+    NRC_STAGE(s, "k_tile_order");
     hipLaunchKernelGGL(k_render, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_fill, bg[0], bg[1], bg[2],
                        camera_dev, out_color, n_contrib, final_T);
+    NRC_STAGE(s, "k_render");
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
@@ -1712,12 +1730,16 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
     if ((use_sh && (!shs || !dL_dsh)) || (use_sr && (!scales || !rotations || !dL_dscale || !dL_drot))) return NRC_ERR_INVALID;
     if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr) || (raw_parameters && (!opacities || !use_sr))) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    NRC_STAGE(s, nullptr);
     hipLaunchKernelGGL(k_zero_grads, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+    NRC_STAGE(s, "k_zero_grads");
     if (use_sh && M > PBW_MAXM) return NRC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_render_bw, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_order, bg[0], bg[1], bg[2],
                        camera_dev, n_contrib, final_T, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+    NRC_STAGE(s, "k_render_bw");
     hipLaunchKernelGGL(k_preprocess_bw, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, P, cam, camera_dev, means3D, shs, shs_rest, opacities, use_sh, scales, rotations,
                        use_sr, radii, clamped, cov3D, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, dL_dopacity);
+    NRC_STAGE(s, "k_preprocess_bw");
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

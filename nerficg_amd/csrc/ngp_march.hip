@@ -687,19 +687,24 @@ __global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c,
     int m = n;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
-    if (lane == 0) tile_rows[lt] = m;
+    const int tile_samples = nrc_group_sum_i<64>(n);
+    if (lane == 0) { tile_rows[lt] = m; tile_rows[n_tiles + lt] = tile_samples; }   // second half of the array: samples per tile (for the total)
 }
-// exclusive scan of tile_rows -> tile_off[0..n_tiles] (tile_off[n_tiles] = total rows); counter = (total rows, n_tiles)
+// exclusive scan of tile_rows[0..n_tiles) -> tile_off[0..n_tiles] (tile_off[n_tiles] = total rows); counter = (total rows, total samples: the
+// sum of tile_rows[n_tiles..2 n_tiles)), so that the caller's ONE host read sizes the sample buffers and reports the marched samples
 __global__ void __launch_bounds__(1024) k_scan_tiles(const int32_t* __restrict__ tile_rows, int64_t n_tiles, int32_t* __restrict__ tile_off,
                                                      int32_t* __restrict__ counter) {
     __shared__ int wave_tot[16];
+    __shared__ int samp_tot[16];
     __shared__ int carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
+    int samples = 0;
     for (int64_t base = 0; base < n_tiles; base += 1024) {
         const int64_t i = base + threadIdx.x;
         const int v = i < n_tiles ? tile_rows[i] : 0;
+        samples += i < n_tiles ? tile_rows[n_tiles + i] : 0;
         const int incl = nrc_wave_incl_sum_i(v, lane);
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
@@ -710,7 +715,14 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(const int32_t* __restrict__
         if (threadIdx.x == 1023) carry_s = off + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { tile_off[n_tiles] = carry_s; counter[0] = carry_s; counter[1] = (int32_t)n_tiles; }
+    samples = nrc_group_sum_i<64>(samples);
+    if (lane == 0) samp_tot[wave] = samples;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; w++) tot += samp_tot[w];
+        tile_off[n_tiles] = carry_s; counter[0] = carry_s; counter[1] = tot;
+    }
 }
 // ---- slab-major row order (front-to-back processing with early termination, see nrc_ngp_render_layers) -------------------------
 // Row k of tile T normally sits at tile_off[T] + k.  In slab order the rows of all tiles with k in [0, G) come first (tile after

@@ -234,6 +234,8 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
     const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
     uint4* out = feat + ((j >> 5) * 4) * 32 + (j & 31);
     const int rot = (int)((j >> 5) & 3);
+    const int lvl_lo = (hashed_mode >> 4) & 0xff, lvl_hi = (hashed_mode >> 12) & 0xff;  // NRC_ENC_LEVELS (measurement only; 0 .. 16 normally)
+    hashed_mode &= 0xf;
 #pragma unroll 1
     for (int grp = 0; grp < 4; grp++) {
         uint32_t v[4] = {0u, 0u, 0u, 0u};
@@ -241,6 +243,7 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int level = 4 * grp + q;
+                if (level < lvl_lo || level >= lvl_hi) continue;   // scalar, wave-uniform
                 Corner8 c;
                 float f0, f1;
                 if (g.hashed[level]) grid_corners_u<true>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
@@ -655,8 +658,16 @@ static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void
     if (narrow_env >= 0) narrow = narrow_env;
     else while (narrow < NRC_MAX_LEVELS && !g.hashed[narrow] && g.size[narrow] > 8) narrow++;
     static const int hashed_mode = [] { const char* e = getenv("NRC_ENC_HASHED"); return e ? atoi(e) : 1; }();
+    // measurement switch (profiles/: L1 lookups per level range): NRC_ENC_LEVELS=lo-hi encodes only levels lo <= l < hi, the others read nothing and
+    // come out as zeros -- WRONG pictures by design, never set outside a counter run
+    static const int lvl_range = [] {
+        const char* e = getenv("NRC_ENC_LEVELS");
+        int lo = 0, hi = NRC_MAX_LEVELS;
+        if (e && sscanf(e, "%d-%d", &lo, &hi) == 2 && lo >= 0 && hi <= NRC_MAX_LEVELS && lo <= hi) return lo | (hi << 8);
+        return NRC_MAX_LEVELS << 8;
+    }();
     hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat, narrow,
-                       hashed_mode);
+                       hashed_mode | (lvl_range << 4));
 }
 
 template <int SRC>
@@ -1672,21 +1683,27 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
         if (bc.n_levels > 0) {
             LevelList rest; rest.n = 0;
             for (int l = 0; l < n_levels; l++) if (!isb[l]) rest.level[rest.n++] = l;
+            NRC_STAGE(s, nullptr);
             if (rest.n > 0)
                 hipLaunchKernelGGL(k_grid_bwd, dim3((unsigned)nrc_cdiv(M, 256), rest.n), dim3(256), 0, s, x01, M, d_features, (int)d_features_pair_major, g,
                                    (int)n_levels, rest, grad_table);
+            NRC_STAGE(s, "k_grid_bwd");
             GbHeader* hd = reinterpret_cast<GbHeader*>(workspace);
             uint4* records = reinterpret_cast<uint4*>(reinterpret_cast<char*>(workspace) + GB_HEADER_BYTES);
             const int nb = bc.bucket0[bc.n_levels];
             if (nrc_zero_async(hd, sizeof(GbHeader), s) != hipSuccess) return NRC_ERR_LAUNCH;
             const dim3 sgrid((unsigned)nrc_cdiv(M, OWN_THREADS));
             hipLaunchKernelGGL(k_gb_split<false>, sgrid, dim3(OWN_THREADS), 0, s, x01, M, d_features, g, bc, hd, records);
+            NRC_STAGE(s, "k_gb_split<count>");
             hipLaunchKernelGGL(k_gb_scan, dim3(1), dim3(GB_MAX_BUCKETS), 0, s, hd, nb, bc.n_levels, M);
+            NRC_STAGE(s, "k_gb_scan");
             hipLaunchKernelGGL(k_gb_split<true>, sgrid, dim3(OWN_THREADS), 0, s, x01, M, d_features, g, bc, hd, records);
+            NRC_STAGE(s, "k_gb_split<write>");
             static const hipError_t attr_b = hipFuncSetAttribute((const void*)k_gb_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, GB_ENTRIES * 16);
             (void)attr_b;
             hipLaunchKernelGGL(k_gb_accumulate, dim3((unsigned)nb), dim3(OWN_THREADS), GB_ENTRIES * 16, s, g, bc, (const GbHeader*)hd, (const uint4*)records,
                                grad_table);
+            NRC_STAGE(s, "k_gb_accumulate");
             NRC_LAUNCH_CHECK();
             return NRC_OK;
         }
@@ -1758,15 +1775,20 @@ int nrc_ngp_train_query_forward(const float* xyzs, const float* dirs, int64_t M,
     QueryIn qin = {};
     qin.xyz01 = xyzs; qin.normalise = 1; qin.x01_out = x01;
     for (int k = 0; k < 3; k++) { qin.mn[k] = xyz_min3[k]; qin.sz[k] = xyz_size3[k]; }
+    NRC_STAGE(s, nullptr);
     launch_encode<SRC_ARRAYS>(qin, 0, M, table_f16, g, (uint4*)workspace, s);
+    NRC_STAGE(s, "k_grid_encode<train>");
     const dim3 grid(pick_blocks(M)), block(256);
     // density net: 32 -> 64 -> 16, linear output, all 16 columns stored (the colour net reads them back)
     hipLaunchKernelGGL((k_nwie_fwd<ENC_FEAT, 1, ACT_NONE, true>), grid, block, 0, s, (const void*)workspace, 0, M, (const __half*)density_weights_f16,
                        (const __half2*)table_f16, g, 16, (__half*)h_f16, 16, 16, (__half*)save_in_d, (__half*)save_acts_d);
+    NRC_STAGE(s, "k_nwie_fwd<density>");
     // colour net: [SH(d) | h] -> 64 -> 64 -> 3 (+1 pad), sigmoid
     hipLaunchKernelGGL((k_nwie_fwd<ENC_DIR_H, 2, ACT_SIGMOID, true>), grid, block, 0, s, (const void*)dirs, 0, M, (const __half*)color_weights_f16,
                        (const __half2*)h_f16, g, 3, (__half*)rgb_f16, 4, 4, (__half*)save_in_c, (__half*)save_acts_c);
+    NRC_STAGE(s, "k_nwie_fwd<colour>");
     hipLaunchKernelGGL(k_train_outputs, dim3((unsigned)nrc_cdiv(M, 256)), dim3(256), 0, s, (const __half*)h_f16, (const __half*)rgb_f16, M, sigmas, rgbs);
+    NRC_STAGE(s, "k_train_outputs");
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
@@ -1789,12 +1811,17 @@ int nrc_ngp_train_query_backward(const float* dL_dsigmas, const float* dL_drgbs,
     __half* d_h16 = (__half*)p; p += M * 32;
     float* d_in_d = (float*)p;
     const dim3 g1((unsigned)nrc_cdiv(M, 256)), b1(256);
+    NRC_STAGE(s, nullptr);
     hipLaunchKernelGGL(k_train_dout, g1, b1, 0, s, dL_dsigmas, dL_drgbs, (const __half*)h_f16, M, d_rgb16, dh0);
+    NRC_STAGE(s, "k_train_dout");
     int rc = nrc_nwie_backward(M, color_weights_f16, 2, ACT_SIGMOID, 3, d_rgb16, rgb_f16, 4, save_in_c, save_acts_c, loss_scale, grad_color_params, d_in_c, 0, stream);
     if (rc != NRC_OK) return rc;
+    NRC_STAGE(s, "k_nwie_bwd<colour>");
     hipLaunchKernelGGL(k_density_dout, g1, b1, 0, s, (const float*)d_in_c, (const float*)dh0, M, d_h16);
+    NRC_STAGE(s, "k_density_dout");
     rc = nrc_nwie_backward(M, density_weights_f16, 1, ACT_NONE, 16, d_h16, h_f16, 16, save_in_d, save_acts_d, loss_scale, grad_density_params, d_in_d, 1, stream);
     if (rc != NRC_OK) return rc;
+    NRC_STAGE(s, "k_nwie_bwd<density>");
     void* grid_ws = (char*)d_in_d + M * 128;  // nrc_grid_backward_ws_bytes (all levels at most) behind the pair-major gradients
     rc = nrc_grid_backward(x01, M, d_in_d, 1, n_levels, log2_hashmap_size, base_resolution, per_level_scale, grad_density_params + n_density_mlp_params,
                            grid_ws, stream);

@@ -262,7 +262,7 @@ class InstantNGPRenderer:
         ws = self._fused_ws.get(key)
         if ws is None:
             ws = dict(ray_od=torch.empty(max(n, 1), 6, device=dev), ray_t=torch.empty(max(n, 1), 2, device=dev),
-                      ray_cnt=torch.empty(max(n, 1), dtype=torch.int32, device=dev), tile_rows=torch.empty(max(nt, 1), dtype=torch.int32, device=dev),
+                      ray_cnt=torch.empty(max(n, 1), dtype=torch.int32, device=dev), tile_rows=torch.empty(2 * max(nt, 1), dtype=torch.int32, device=dev),
                       tile_off=torch.empty(nt + 1, dtype=torch.int32, device=dev), counter=torch.empty(2, dtype=torch.int32, device=dev),
                       rgb=torch.zeros(hw, 3, device=dev), alpha=torch.zeros(hw, device=dev), depth=torch.zeros(hw, device=dev), cap=0,
                       skipped=torch.zeros(1, dtype=torch.int32, device=dev))
@@ -280,7 +280,7 @@ class InstantNGPRenderer:
             int(tile_begin), nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION, self.MAX_SAMPLES,
             _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']), _lib.ptr(ws['tile_off']),
             _lib.ptr(ws['counter']), _lib.ptr(ws.get('ts_prov')), st), 'ngp_render_count')
-        rows = int(ws['counter'][0].item())
+        rows, n_samples = ws['counter'].tolist()   # THE host read of the frame: sizes the sample buffers; the marched total comes with it
         if rows > ws['cap']:
             cap = int(rows * 1.5) + 64  # poses of one scene differ by up to 30 % in rows: grow rarely (a regrowth costs milliseconds of hipMalloc)
             ws.update(ts=torch.empty(cap * 64, device=dev), row_tile=torch.empty(cap, dtype=torch.int32, device=dev),
@@ -321,7 +321,7 @@ class InstantNGPRenderer:
             if return_stats:
                 res['n_rows'] = rows
                 res['n_slots'] = rows * 64
-                res['n_samples'] = int(ws['ray_cnt'][:n].sum().item()) if n > 0 else 0
+                res['n_samples'] = n_samples
             return res
         if rows > 0:
             _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION,
@@ -342,7 +342,7 @@ class InstantNGPRenderer:
         if return_stats:
             res['n_rows'] = rows
             res['n_slots'] = rows * 64
-            res['n_samples'] = int(ws['ray_cnt'][:n].sum().item()) if n > 0 else 0
+            res['n_samples'] = n_samples
         return res
 
     # ---------------------------------------------------------------- occupancy grid

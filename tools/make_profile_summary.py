@@ -9,6 +9,7 @@ ROOT = Path(__file__).resolve().parents[1]
 RAW = ROOT / 'gpurun_out' / 'profiles_raw'
 OUT = ROOT / 'profiles'
 OUT.mkdir(exist_ok=True)
+ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r03'   # file prefix of the committed summaries
 
 
 def short(name):
@@ -27,14 +28,14 @@ def short(name):
 import os
 stats = sorted(glob.glob(str(RAW / 'bench_stats' / '*' / '*kernel_stats.csv')), key=os.path.getmtime)  # newest collection last
 if stats:
-    shutil.copy(stats[-1], OUT / 'r02_bench_kernel_stats.csv')
-for tag, name in (('gs_stats', 'r02_gs_kernel_stats.csv'), ('gs6_stats', 'r02_gs6m_kernel_stats.csv')):
+    shutil.copy(stats[-1], OUT / f'{ROUND}_bench_kernel_stats.csv')
+for tag, name in (('gs_stats', f'{ROUND}_gs_kernel_stats.csv'), ('gs6_stats', f'{ROUND}_gs6m_kernel_stats.csv')):
     extra = sorted(glob.glob(str(RAW / tag / '*' / '*kernel_stats.csv')), key=os.path.getmtime)
     if extra:
         shutil.copy(extra[-1], OUT / name)
 tstats = sorted(glob.glob(str(RAW / 'train_stats' / '*' / '*kernel_stats.csv')), key=os.path.getmtime)
 if tstats:
-    shutil.copy(tstats[-1], OUT / 'r02_train_kernel_stats.csv')
+    shutil.copy(tstats[-1], OUT / f'{ROUND}_train_kernel_stats.csv')
 # one accumulator per collection run: pmc_* = tools/bench_query.py (InstantNGP image pipeline), pmcgs_* = tools/bench_gs.py (3DGS frame),
 # pmctr_* = tools/bench_train.py (InstantNGP training iteration).  A kernel that appears in several of them (k_grid_encode runs in the image
 # pipeline with 8 Mi-slot launches and in training with 264 K samples) is reported from the run that is about it.
@@ -54,12 +55,13 @@ for k in names:
         acc[k][n] = vals
 keep = ('k_grid_encode', 'k_ngp_mlp', 'k_render', 'k_composite_image', 'k_preprocess', 'k_span_', 'k_item_', 'k_depth_keys', 'k_radix_', 'k_scan_tiles', 'k_march_wave',
         'k_grid_bwd', 'k_nwie_', 'k_composite_train')
-lines = ['# rocprofv3 --pmc summary (MI355X, round 2)', '',
+lines = [f'# rocprofv3 --pmc summary (MI355X, {ROUND})', '',
          'Collected by `tools/collect_profiles.sh` (one `--pmc` group per run, `--kernel-trace` only), averaged per kernel over all launches of',
          '`tools/bench_query.py` (InstantNGP 800x800 image pipeline), `tools/bench_gs.py` (3DGS, 1 M Gaussians, 1297x840) and `tools/bench_train.py`',
          '(InstantNGP training iteration, 2200 rays / 264 K samples).',
          'FETCH_SIZE / WRITE_SIZE are in KiB as reported; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950',
-         '(other widths uncalibrated) -- both the raw value and the 2x-corrected read bytes are listed.', '']
+         '(16-byte gathers: the same 2x -- every L2 miss is ONE 128-byte fabric request tallied at 64 B, tools/micro/gather_fetch_calib.hip,',
+         'profiles/r03_gather_calibration.md) -- both the raw value and the 2x-corrected read bytes are listed.', '']
 summary = {}
 for k in sorted(acc):
     if not any(k.startswith(p) for p in keep):
@@ -98,8 +100,13 @@ for k in sorted(acc):
     if k.startswith('k_grid_encode') or k.startswith('k_ngp_mlp'):
         key = re.sub(r'<1(, \d+)?>', '<SRC_TILED>', re.sub(r'<0(, \d+)?>', '<SRC_ARRAYS>', k))
     summary[key] = {**{n: round(v, 1) for n, v in c.items()}, **derived}
-(OUT / 'r02_pmc_summary.md').write_text('\n'.join(lines))
+(OUT / f'{ROUND}_pmc_summary.md').write_text('\n'.join(lines))
+import hashlib
+# provenance: bench.py quotes a counter entry only while the kernel's source file is the one these counters were collected on
+summary['_meta'] = {'round': ROUND, 'csrc_sha': {p.name: hashlib.sha256(p.read_bytes()).hexdigest()[:16] for p in sorted((ROOT / 'nerficg_amd' / 'csrc').glob('*.h*'))}}
 (OUT / 'pmc_summary.json').write_text(json.dumps(summary, indent=1, sort_keys=True))
 print('\n'.join(lines[:8]))
 for k, v in summary.items():
+    if k.startswith('_'):
+        continue
     print(k, {a: v[a] for a in ('hbm_bytes_per_launch', 'tcp_accesses_per_clk_per_cu', 'l1_hit_rate', 'l2_hit_rate', 'mfma_pipe_busy_frac', 'mfma_tflops_issued') if a in v})
