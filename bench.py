@@ -306,7 +306,8 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=60):
     saved = [p.detach().clone() for p in model.parameters()]
     from nerficg_amd.apex_optimizers import FusedAdam
     opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)  # Trainer.py:35
-    scaler = torch.amp.GradScaler(init_scale=128.0, growth_interval=10 ** 9)
+    from nerficg_amd.amp import GradScaler   # torch.amp.GradScaler with the inf check as one streaming kernel
+    scaler = GradScaler(init_scale=128.0, growth_interval=10 ** 9)
     target = torch.rand(origin.shape[0], 3, device=dev)
 
     def step(i):
@@ -369,7 +370,7 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=60):
     from nerficg_amd.graphs import instant_ngp_iteration
     capacity = (int(1.15 * tot / iters) + 4095) // 4096 * 4096
     opt_g = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
-    scaler_g = torch.amp.GradScaler(init_scale=128.0, growth_interval=10 ** 9)
+    scaler_g = GradScaler(init_scale=128.0, growth_interval=10 ** 9)
     graphed = instant_ngp_iteration(model, renderer, opt_g, scaler_g, cam, n_rays, capacity, ray_pool={'origin': origin, 'view_direction': vdir, 'rgb': target},
                                     fold_weight_decay=True)
     batch = lambda i: perm[(i * n_rays) % (perm.numel() - n_rays):][:n_rays]

@@ -379,6 +379,9 @@ int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int3
  *            read anyway, instead of a dense 12 M-element gradient through autograd; 0 / 0 = off.  param_f16_out (optional): the updated parameters are also written as fp16 --
  *            the compute copy the tinycudann replacement reads (Group 3), which therefore can never go stale after a step.
  * ===================================================================================================== */
+/* GradScaler's inf / NaN check of one f32 gradient tensor (torch.amp.GradScaler._check_inf_per_device, used at InstantNGP/Trainer.py:89-93 with an
+ * optimizer that applies the scale itself): *found_inf (DEVICE f32, not cleared here) is set to 1 when any of the n values is not finite. */
+int nrc_nonfinite_check(const float* grad, int64_t n, float* found_inf, nrc_stream_t stream);
 int nrc_adam_prepare(int32_t host_step, float beta1, float beta2, const float* found_inf, int32_t* skipped_steps,
                      int32_t* device_step, float* bias_corrections, nrc_stream_t stream);
 int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

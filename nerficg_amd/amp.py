@@ -1,0 +1,34 @@
+"""nerficg_amd.amp -- torch.amp.GradScaler with the inf / NaN check as ONE streaming kernel per gradient tensor.
+
+The reference trains InstantNGP under `torch.amp.GradScaler(init_scale=128, growth_interval=...)` (src/Methods/InstantNGP/Trainer.py:44,89-93).
+With an optimizer that applies the scale itself (FusedAdam: `_step_supports_amp_scaling`) the scaler's only work per iteration is the check
+of the gradients for inf / NaN -- torch runs it as a multi-tensor "unscale by 1.0 and check" pass that READS AND WRITES every gradient (37 us
+for the 48.8 MB hash-table gradient on an MI355X, plus four small kernels around it).  This subclass does the same check read-only at the
+rate the HBM delivers (nrc_nonfinite_check, include/nerficg_hip.h group 8).  Same constructor, same state dict, same update() rule; the
+reference's trainer keeps working with torch's own class -- this one is what nerficg_amd's own loops (graphs.py, bench.py) use.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+__all__ = ['GradScaler']
+
+
+class GradScaler(torch.amp.GradScaler):
+    def _check_inf_per_device(self, optimizer):
+        grads = [p.grad for group in optimizer.param_groups for p in group['params'] if p.grad is not None]
+        fast = bool(grads) and all(g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and not g.is_sparse and g.device == grads[0].device
+                                   for g in grads)
+        if not fast:
+            return super()._check_inf_per_device(optimizer)
+        _scale, _ = self._check_scale_growth_tracker('_check_inf_per_device')
+        dev = grads[0].device
+        found = torch.zeros((), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        for g in grads:
+            _lib.check(lib.nrc_nonfinite_check(_lib.ptr(g), g.numel(), _lib.ptr(found), _lib.stream_of(g)), 'nonfinite_check')
+        per_device = {dev: found} if _scale.device == dev else {dev: found, _scale.device: torch.zeros((), dtype=torch.float32, device=_scale.device)}
+        self._per_optimizer_states[id(optimizer)]['found_inf_per_device'] = per_device
+        return per_device

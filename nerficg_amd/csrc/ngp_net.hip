@@ -230,14 +230,18 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     float px, py, pz;
+    if (blockIdx.y != 0) in.x01_out = nullptr;   // level groups split over workgroup rows: the first row writes the normalised positions
     const bool live = fetch_pos<SRC>(in, base + j, px, py, pz);
     const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
     uint4* out = feat + ((j >> 5) * 4) * 32 + (j & 31);
     const int rot = (int)((j >> 5) & 3);
     const int lvl_lo = (hashed_mode >> 4) & 0xff, lvl_hi = (hashed_mode >> 12) & 0xff;  // NRC_ENC_LEVELS (measurement only; 0 .. 16 normally)
     hashed_mode &= 0xf;
+    // gridDim.y == 4: one group of four levels per workgroup row (small batches: four times the waves, a quarter of the dependent gathers each --
+    // a 264 K-sample training batch is ~4 waves per SIMD in all and runs at the latency of ONE wave's sixteen gather rounds otherwise)
+    const int grp_begin = gridDim.y == 4 ? (int)blockIdx.y : 0, grp_end = gridDim.y == 4 ? grp_begin + 1 : 4;
 #pragma unroll 1
-    for (int grp = 0; grp < 4; grp++) {
+    for (int grp = grp_begin; grp < grp_end; grp++) {
         uint32_t v[4] = {0u, 0u, 0u, 0u};
         if (live) {
 #pragma unroll
@@ -261,6 +265,41 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
             }
         }
         out[((grp + rot) & 3) * 32] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// Small batches (a training iteration: ~264 K samples, once, right after the optimizer rewrote the fp16 table): the gathers miss every XCD's L2 --
+// with one lane per sample and all sixteen levels, each of the 8 XCDs pulls the whole 24.4 MB table through its own fabric port (195 MB of L2
+// fills for 135 MB of requested bytes; measured 63-67 us = 0.24 of the HBM roofline).  Here workgroup b encodes the level PAIR b & 7 of sample
+// block b >> 3: workgroups are dealt round-robin over the XCDs, so XCD x only ever touches levels 2x and 2x+1 (<= 4 MB: its L2 holds them) and the
+// table crosses the fabric ONCE.  The same trade cost the inference path 8 reads of every sample record per image; at this size the
+// positions are 3 MB.  Placement is a speed assumption only: any workgroup-to-XCD mapping gives the same features.
+__global__ void __launch_bounds__(256) k_grid_encode_pairs(QueryIn in, int64_t n, const __half2* __restrict__ table, GridCfg g, uint2* __restrict__ feat,
+                                                           int narrow_levels, int hashed_mode) {
+    const int pair = (int)(blockIdx.x & 7u);
+    const int64_t j = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    if (j >= n) return;
+    float px, py, pz;
+    if (pair != 0) in.x01_out = nullptr;
+    fetch_pos<SRC_ARRAYS>(in, j, px, py, pz);
+    const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
+    // balanced pairs: a coarse level (few distinct cache lines per wave) with a fine one (64 lines per gather): levels p and 15 - p
+    uint32_t* out32 = reinterpret_cast<uint32_t*>(feat);
+    const int rot = (int)((j >> 5) & 3);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int level = q == 0 ? pair : NRC_MAX_LEVELS - 1 - pair;
+        Corner8 c;
+        float f0, f1;
+        if (g.hashed[level]) grid_corners_u<true>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
+        else grid_corners_u<false>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
+        if (level < narrow_levels) grid_level_features_narrow(trs, c, f0, f1);
+        else if (g.hashed[level] && hashed_mode == 1) grid_level_features_hashed(trs, c, f0, f1);
+        else if (g.hashed[level] && hashed_mode == 2) grid_level_features_pair(trs, c, f0, f1);
+        else grid_level_features(trs, c, f0, f1);
+        const __half2 h = __floats2half2_rn(f0, f1);
+        const int grp = level >> 2;
+        out32[(((j >> 5) * 4 + ((grp + rot) & 3)) * 32 + (j & 31)) * 4 + (level & 3)] = *reinterpret_cast<const uint32_t*>(&h);
     }
 }
 
@@ -631,8 +670,13 @@ int make_grid_cfg(int n_levels, int log2_T, int base_res, float pls, GridCfg& g,
 }
 
 int pick_blocks(int64_t M) {
+    // every workgroup stages the network's weight fragments in LDS (24 KB) before its first tile: few workgroups with several tiles per wave beat
+    // one tile per wave (NRC_MLP_BLOCKS: cap on the number of workgroups, default 2 048)
+    static const int64_t cap_env = [] { const char* e = getenv("NRC_MLP_BLOCKS"); return e ? atoll(e) : (int64_t)0; }();
+    // measured on a 264 K-sample batch (us, density + colour forward): 2 048 workgroups 25.7 + 47.6, 1 024: 23.8 + 40.5, 512: 22.9 + 36.8, 256: 22.9 + 37.4
+    const int64_t cap = cap_env > 0 ? cap_env : (M < (int64_t(1) << 20) ? 512 : 2048);
     const int64_t need = nrc_cdiv(nrc_cdiv(M, 32), 4);
-    return (int)(need < 2048 ? (need > 0 ? need : 1) : 2048);
+    return (int)(need < cap ? (need > 0 ? need : 1) : cap);
 }
 
 }  // namespace
@@ -666,7 +710,18 @@ static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void
         if (e && sscanf(e, "%d-%d", &lo, &hi) == 2 && lo >= 0 && hi <= NRC_MAX_LEVELS && lo <= hi) return lo | (hi << 8);
         return NRC_MAX_LEVELS << 8;
     }();
-    hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat, narrow,
+    // below ~2 M samples the chip is not full with one lane per sample: split the four level groups over workgroup rows
+    static const int64_t split_below = [] { const char* e = getenv("NRC_ENC_SPLIT_BELOW"); return e ? atoll(e) : (int64_t)2 << 20; }();
+    if constexpr (SRC == SRC_ARRAYS) {
+        static const int pairs_mode = [] { const char* e = getenv("NRC_ENC_PAIRS"); return e ? atoi(e) : 1; }();
+        if (pairs_mode && n < split_below && base == 0 && lvl_range == (NRC_MAX_LEVELS << 8)) {
+            hipLaunchKernelGGL(k_grid_encode_pairs, dim3((unsigned)(8 * nrc_cdiv(n, 256))), dim3(256), 0, s, in, n, (const __half2*)table, g, (uint2*)feat, narrow,
+                               hashed_mode);
+            return;
+        }
+    }
+    const unsigned rows = (SRC == SRC_ARRAYS && n < split_below) ? 4u : 1u;
+    hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)nrc_cdiv(n, 256), rows), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat, narrow,
                        hashed_mode | (lvl_range << 4));
 }
 

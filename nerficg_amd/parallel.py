@@ -28,6 +28,8 @@ from typing import Iterable
 import torch
 import torch.distributed as dist
 
+from .amp import GradScaler as _FastGradScaler
+
 __all__ = ['init_distributed', 'world_info', 'shard_ray_ids', 'shard_range', 'allreduce_flat', 'allreduce_gradients',
            'all_gather_pixels', 'broadcast_parameters', 'sparse_allreduce_gradients', 'allreduce_densification_stats', 'synchronized_noise',
            'allreduce_scalars', 'DataParallelGradScaler', 'rays_per_batch_update']
@@ -226,8 +228,8 @@ def rays_per_batch_update(rays_per_batch: int, target_samples: int, samples_sinc
     return int(min(-(-wanted // 256) * 256, target_samples))
 
 
-class DataParallelGradScaler(torch.amp.GradScaler):
-    """torch.amp.GradScaler whose found-inf decision is global: whenever the scaler has looked at an optimizer's gradients (unscale_, or the
+class DataParallelGradScaler(_FastGradScaler):
+    """GradScaler (nerficg_amd.amp: torch.amp.GradScaler with the streaming inf check) whose found-inf decision is global: whenever the scaler has looked at an optimizer's gradients (unscale_, or the
     check inside step() for optimizers that apply the scale themselves, like FusedAdam), the per-device found-inf tensors are replaced by
     their OR over all ranks -- so every replica skips the same steps and update() moves the scale identically.  When the gradients were
     already summed over the ranks an inf / NaN has reached every rank through the sum; the agreement then costs one tiny all-reduce and

@@ -112,3 +112,54 @@ def test_param_group_surgery_like_adam_utils():
     opt.state.pop(a); opt.state[new] = state; group['params'][0] = new
     new.grad = torch.rand_like(new); opt.step()
     assert group['step'] == 2 and torch.isfinite(new).all() and opt.state[new]['exp_avg'].shape == (60, 3)
+
+
+# ------------------------------------------------------------------------------------------------ GradScaler's inf check (nerficg_amd.amp)
+@pytest.mark.parametrize('n,offset', [(1, 0), (3, 0), (4099, 0), (1 << 20, 0), (70001, 1), (12_196_240, 0)])
+def test_streaming_nonfinite_check_equals_torch(n, offset):
+    """nrc_nonfinite_check against torch.isfinite: clean tensors leave the flag at 0; one inf / NaN anywhere -- first element, last element, the
+    unaligned tail, a view that starts 4 bytes into an allocation -- sets it."""
+    import ctypes
+    from nerficg_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device='cuda').manual_seed(n)
+    base = torch.randn(n + offset, device='cuda', generator=g) * 1e30   # large finite values: 0x7f7fffff-ish exponents must not trip the test
+    base.clamp_(-3e38, 3e38)
+    t = base[offset:]
+    flag = torch.zeros((), device='cuda')
+    _lib.check(lib.nrc_nonfinite_check(_lib.ptr(t), n, _lib.ptr(flag), _lib.stream_of(t)), 'nonfinite_check')
+    assert float(flag) == 0.0 and bool(torch.isfinite(t).all())
+    for pos, val in ((0, float('inf')), (n - 1, float('nan')), (n // 2, -float('inf')), (max(0, n - 2), float('nan'))):
+        u = t.clone() if offset == 0 else base.clone()[offset:]
+        u[pos] = val
+        flag.zero_()
+        _lib.check(lib.nrc_nonfinite_check(_lib.ptr(u), n, _lib.ptr(flag), _lib.stream_of(u)), 'nonfinite_check')
+        assert float(flag) == 1.0, (pos, val)
+
+
+def test_fast_grad_scaler_follows_torch_grad_scaler():
+    """nerficg_amd.amp.GradScaler and torch.amp.GradScaler through five FusedAdam steps, the third with an overflowing gradient: same parameters,
+    same scale, same skipped step."""
+    from nerficg_amd.amp import GradScaler
+    from nerficg_amd.apex_optimizers import FusedAdam
+    results = []
+    for cls in (torch.amp.GradScaler, GradScaler):
+        torch.manual_seed(0)
+        p = torch.nn.Parameter(torch.randn(100_003, device='cuda'))
+        q = torch.nn.Parameter(torch.randn(7, 5, device='cuda'))
+        opt = FusedAdam([{'params': [p]}, {'params': [q]}], lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
+        scaler = cls('cuda', init_scale=128.0, growth_interval=2)
+        trace = []
+        for it in range(5):
+            x = torch.full_like(p, 1.0 + it)
+            if it == 2:
+                x[77] = float('inf')
+            loss = (p * x).sum() + (q * q).sum()
+            scaler.scale(loss).backward()
+            scaler.step(opt); scaler.update(); opt.zero_grad()
+            trace.append((p.detach().clone(), q.detach().clone(), float(scaler.get_scale())))
+        results.append(trace)
+    for (pa, qa, sa), (pb, qb, sb) in zip(*results):
+        assert torch.equal(pa, pb) and torch.equal(qa, qb) and sa == sb
+    assert torch.equal(results[1][2][0], results[1][1][0])   # the overflowing iteration changed nothing
+    assert results[1][2][2] == 0.5 * results[1][1][2]         # and halved the scale

@@ -18,7 +18,8 @@ g = torch.Generator(device='cpu').manual_seed(0)
 perm = torch.randperm(origin.shape[0], generator=g).to(dev)
 from nerficg_amd.apex_optimizers import FusedAdam
 opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)  # Trainer.py:35
-scaler = torch.amp.GradScaler(init_scale=128.0, growth_interval=10 ** 9)
+from nerficg_amd.amp import GradScaler
+scaler = GradScaler(init_scale=128.0, growth_interval=10 ** 9)
 target = torch.rand(origin.shape[0], 3, device=dev)
 
 def step(i):

@@ -19,7 +19,8 @@ origin = torch.cat([r['origin'] for r in rays]); vdir = torch.cat([r['view_direc
 perm = torch.randperm(origin.shape[0], generator=torch.Generator(device='cpu').manual_seed(0)).to(dev)
 target = torch.rand(origin.shape[0], 3, device=dev)
 opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
-scaler = torch.amp.GradScaler(init_scale=128.0, growth_interval=10 ** 9)
+from nerficg_amd.amp import GradScaler
+scaler = GradScaler(init_scale=128.0, growth_interval=10 ** 9)
 step = instant_ngp_iteration(model, renderer, opt, scaler, cam, n_rays, 307200, ray_pool={'origin': origin, 'view_direction': vdir, 'rgb': target},
                              fold_weight_decay=True)
 batch = lambda i: perm[(i * n_rays) % (perm.numel() - n_rays):][:n_rays]
