@@ -278,6 +278,54 @@ __device__ __forceinline__ void grid_level_features_narrow(__amdgpu_buffer_rsrc_
     for (int k = 0; k < 8; k++) fma_half2(c.w[k], v[k], f0, f1);
 }
 
+// Wave-uniform cell (coarse levels in the tile-interleaved layout: the 64 samples of a row are 8 x 8 neighbouring pixels at the same step, a
+// footprint of ~0.01 of the box, smaller than the cells of levels 0-4 and about the size of those of levels 5-6): when every ACTIVE lane of the
+// wave sits in the same cell, the eight corners are the same eight table entries for all of them -- they are fetched ONCE through the scalar
+// cache (s_load_dword, no vector-memory instruction, no L1 tag lookups) and only the trilinear weights are per lane.  profiles/: levels 0-4
+// cost 8.0 of the kernel's 41.7 L1 lookups per sample through the vector path although they touch a handful of lines (the texture path counts
+// per 16-lane quad, not per distinct line).  Same entries, same weights, same order of the eight multiply-adds: bit-identical features.
+// Returns false (nothing computed) when the active lanes disagree; the caller then takes the vector path.
+template <bool HASHED>
+__device__ __forceinline__ bool grid_level_features_uniform(const uint32_t* __restrict__ table32, float px, float py, float pz, float scale, uint32_t res,
+                                                            uint32_t size, uint32_t off, float& f0, float& f1) {
+    const float fx = fmaf(scale, px, 0.5f), fy = fmaf(scale, py, 0.5f), fz = fmaf(scale, pz, 0.5f);
+    const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+    const uint32_t gx = (uint32_t)(int32_t)flx, gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
+    const uint32_t ux = (uint32_t)__builtin_amdgcn_readfirstlane((int)gx), uy = (uint32_t)__builtin_amdgcn_readfirstlane((int)gy),
+                   uz = (uint32_t)__builtin_amdgcn_readfirstlane((int)gz);
+    if (__ballot(((gx ^ ux) | (gy ^ uy) | (gz ^ uz)) != 0u) != 0ull) return false;
+    const float wx1 = fx - flx, wy1 = fy - fly, wz1 = fz - flz;
+    const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
+    const float wxy[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+    // entry indices exactly as grid_corners_u, on the wave-uniform cell: scalar arithmetic
+    const uint32_t my = HASHED ? 2654435761u : res, mz = HASHED ? 805459861u : res * res;
+    const uint32_t ty0 = uy * my, tz0 = uz * mz;
+    const uint32_t ty[2] = {ty0, ty0 + my}, tz[2] = {tz0, tz0 + mz};
+    const uint32_t mask = size - 1u;
+    uint32_t v[8];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const uint32_t a = ty[p & 1], b = tz[p >> 1];
+        const uint32_t yz = HASHED ? (a ^ b) : (a + b);
+#pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+            uint32_t e;
+            if constexpr (HASHED) {
+                e = ((ux + dx) ^ yz) & mask;
+            } else {
+                e = ux + dx + yz;
+                e = e >= size ? e - size : e;
+                e = min(e, mask);
+            }
+            v[2 * p + dx] = table32[off + e];   // uniform address: s_load_dword
+        }
+    }
+    f0 = 0.f; f1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) fma_half2(wxy[k & 3] * ((k & 4) ? wz1 : wz0), v[k], f0, f1);
+    return true;
+}
+
 // ---- SH degree 4 (16 coefficients) of a direction in [-1,1]^3 ------------------------------------------------------
 __device__ __forceinline__ void sh4_eval(float x, float y, float z, float* o) {
     const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;

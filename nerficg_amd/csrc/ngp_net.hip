@@ -236,7 +236,9 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
     uint4* out = feat + ((j >> 5) * 4) * 32 + (j & 31);
     const int rot = (int)((j >> 5) & 3);
     const int lvl_lo = (hashed_mode >> 4) & 0xff, lvl_hi = (hashed_mode >> 12) & 0xff;  // NRC_ENC_LEVELS (measurement only; 0 .. 16 normally)
+    const int uniform_levels = (hashed_mode >> 20) & 0xff;                             // levels that try the wave-uniform scalar path first
     hashed_mode &= 0xf;
+    const uint32_t* __restrict__ table32 = reinterpret_cast<const uint32_t*>(table);
     // gridDim.y == 4: one group of four levels per workgroup row (small batches: four times the waves, a quarter of the dependent gathers each --
     // a 264 K-sample training batch is ~4 waves per SIMD in all and runs at the latency of ONE wave's sixteen gather rounds otherwise)
     const int grp_begin = gridDim.y == 4 ? (int)blockIdx.y : 0, grp_end = gridDim.y == 4 ? grp_begin + 1 : 4;
@@ -250,12 +252,20 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
                 if (level < lvl_lo || level >= lvl_hi) continue;   // scalar, wave-uniform
                 Corner8 c;
                 float f0, f1;
-                if (g.hashed[level]) grid_corners_u<true>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
-                else grid_corners_u<false>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
-                if (level < narrow_levels) grid_level_features_narrow(trs, c, f0, f1);
-                else if (g.hashed[level] && hashed_mode == 1) grid_level_features_hashed(trs, c, f0, f1);
-                else if (g.hashed[level] && hashed_mode == 2) grid_level_features_pair(trs, c, f0, f1);
-                else grid_level_features(trs, c, f0, f1);
+                bool have = false;
+                if constexpr (SRC == SRC_TILED) {   // rows of the tiled layout are spatially compact: try the scalar-cache path on the coarse levels
+                    if (level < uniform_levels)
+                        have = g.hashed[level] ? grid_level_features_uniform<true>(table32, px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], f0, f1)
+                                               : grid_level_features_uniform<false>(table32, px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], f0, f1);
+                }
+                if (!have) {
+                    if (g.hashed[level]) grid_corners_u<true>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
+                    else grid_corners_u<false>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
+                    if (level < narrow_levels) grid_level_features_narrow(trs, c, f0, f1);
+                    else if (g.hashed[level] && hashed_mode == 1) grid_level_features_hashed(trs, c, f0, f1);
+                    else if (g.hashed[level] && hashed_mode == 2) grid_level_features_pair(trs, c, f0, f1);
+                    else grid_level_features(trs, c, f0, f1);
+                }
                 const __half2 h = __floats2half2_rn(f0, f1);
                 v[q] = *reinterpret_cast<const uint32_t*>(&h);
                 // finish this level before the next one starts: otherwise the compiler sinks all four interpolations below the
@@ -264,16 +274,20 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
                 asm volatile("" : "+v"(v[q]));
             }
         }
+        // (cache-policy variants of this store -- sc1, sc0 sc1, nt, so that the 64 B of features per sample would not take L2 lines from the hash
+        // table -- measured 0.630-0.640 ms against 0.640: no effect, removed)
         out[((grp + rot) & 3) * 32] = make_uint4(v[0], v[1], v[2], v[3]);
     }
 }
 
-// Small batches (a training iteration: ~264 K samples, once, right after the optimizer rewrote the fp16 table): the gathers miss every XCD's L2 --
-// with one lane per sample and all sixteen levels, each of the 8 XCDs pulls the whole 24.4 MB table through its own fabric port (195 MB of L2
-// fills for 135 MB of requested bytes; measured 63-67 us = 0.24 of the HBM roofline).  Here workgroup b encodes the level PAIR b & 7 of sample
-// block b >> 3: workgroups are dealt round-robin over the XCDs, so XCD x only ever touches levels 2x and 2x+1 (<= 4 MB: its L2 holds them) and the
-// table crosses the fabric ONCE.  The same trade cost the inference path 8 reads of every sample record per image; at this size the
-// positions are 3 MB.  Placement is a speed assumption only: any workgroup-to-XCD mapping gives the same features.
+// Small batches (a training iteration: ~264 K samples, once, right after the optimizer rewrote the fp16 table: every XCD's L2 is cold).  With one
+// lane per sample and all sixteen levels each of the 8 XCDs pulls the whole 24.4 MB table through its own L2 (measured 63-67 us = 0.24 of the
+// HBM roofline on 512 B per sample).  Here workgroup b encodes a level PAIR of sample block b >> 3: workgroups are dealt round-robin over the
+// XCDs, so XCD x mostly sees two levels (L2 hit rate 0.87 against 0.61, profiles/).  The pairs are BALANCED, (p, 15 - p): a coarse level (few
+// cache lines per wave) with a fine one (64 lines per gather) -- adjacent pairs (2p, 2p + 1) put both finest levels on one XCD, whose L1s then
+// bound the launch: 94 us.  Measured: 63 -> 54 us.  The same split cost the inference path more than it saved (every sample record is
+// read once per pair, 8 x 7.7 M records per launch); at this size the positions are 3 MB.  Placement is a speed assumption only: any
+// workgroup-to-XCD mapping gives the same features.
 __global__ void __launch_bounds__(256) k_grid_encode_pairs(QueryIn in, int64_t n, const __half2* __restrict__ table, GridCfg g, uint2* __restrict__ feat,
                                                            int narrow_levels, int hashed_mode) {
     const int pair = (int)(blockIdx.x & 7u);
@@ -721,8 +735,13 @@ static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void
         }
     }
     const unsigned rows = (SRC == SRC_ARRAYS && n < split_below) ? 4u : 1u;
+    // coarse levels of the tiled layout: wave-uniform cells through the scalar cache (NRC_ENC_UNIFORM = number of levels that try).  Measured
+    // (round 3, profiles/): it removes the vector lookups of those levels and changes NOTHING in time (0.643 ms off, 0.650-0.652 ms with 5, 7
+    // or 9 levels): the kernel is bound by the four finest levels' L1 misses (52 % of its time, 8.8 of 9.3 L2 requests per sample), not by
+    // the lookups of the coarse ones.  Default off; bit-identical features either way.
+    static const int uniform_levels = [] { const char* e = getenv("NRC_ENC_UNIFORM"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > NRC_MAX_LEVELS ? NRC_MAX_LEVELS : v); }();
     hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)nrc_cdiv(n, 256), rows), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat, narrow,
-                       hashed_mode | (lvl_range << 4));
+                       hashed_mode | (lvl_range << 4) | (uniform_levels << 20));
 }
 
 template <int SRC>
