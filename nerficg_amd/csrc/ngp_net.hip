@@ -194,7 +194,9 @@ __device__ __forceinline__ bool fetch_pos(const QueryIn& in, int64_t i, float& p
         return true;
     } else {
         const float t = in.ts[i];
-        const int32_t rt = in.row_tile[i >> 6];
+        // one wave = one row of the tiled layout: the row's ray tile is wave-uniform and comes through the scalar cache (no vector round trip in
+        // front of the six ray loads that depend on it)
+        const int32_t rt = in.row_tile[__builtin_amdgcn_readfirstlane((int)(i >> 6))];
         if (t < 0.f || (in.tile_alive && !in.tile_alive[rt])) { px = py = pz = 0.f; return false; }
         const float* od = in.ray_od + (int64_t)rt * 384 + (i & 63);  // per-tile SoA [6][64]
         // same roundings as the op-by-op path: xyz = o + t*d (mul, add: raymarching.cu:368), then (xyz - min) / size in torch
@@ -336,6 +338,19 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn
 
 // NT = sample tiles (32 samples each) per wave iteration.  With NT = 2 every weight fragment read from LDS feeds two MFMAs and the
 // two chains interleave (the chain of one tile is serial: MFMA -> convert -> MFMA ...).
+// ---- ablation hooks of k_ngp_mlp (tools/build_variant.sh NAME ngp_net.hip -DNRC_MLP_ABL_...): where do its cycles go?  Never defined in the product build.
+#if defined(NRC_MLP_ABL_NOCVT)   // no f32 -> f16 conversion / ReLU: the next layer's B fragment is a reinterpretation of accumulator registers
+__device__ __forceinline__ h8 mlp_frag_relu(const f16v& acc, int g) { typedef float f4 __attribute__((ext_vector_type(4))); const f4 q = {acc[8 * g], acc[8 * g + 1], acc[8 * g + 2], acc[8 * g + 3]}; return __builtin_bit_cast(h8, q); }
+__device__ __forceinline__ h8 mlp_frag(const f16v& acc, int g) { return mlp_frag_relu(acc, g); }
+#else
+__device__ __forceinline__ h8 mlp_frag_relu(const f16v& acc, int g) { return acc_to_frag_relu(acc, g); }
+__device__ __forceinline__ h8 mlp_frag(const f16v& acc, int g) { return acc_to_frag(acc, g); }
+#endif
+#if defined(NRC_MLP_ABL_NOMFMA)  // no matrix instruction: operands and accumulator stay live, nothing is issued
+__device__ __forceinline__ f16v mlp_mfma(const h8& a, const h8& b, f16v c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
+#else
+__device__ __forceinline__ f16v mlp_mfma(const h8& a, const h8& b, const f16v& c) { return NRC_MFMA(a, b, c); }
+#endif
 template <int SRC, int NT>
 __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, int64_t n, const uint4* __restrict__ feat,
                                                     const h8* __restrict__ ray_sh, const __half* __restrict__ Wd,
@@ -366,8 +381,28 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
 #define CO(s) wlds[F_CO + (s)][lane]
     // software pipeline: the loads of the NEXT group (features 2 x 16 B, SH 16 B or direction, hole flag) are issued before the MFMA
     // chain of the current one
-    struct TileIn { uint4 b0, b1; h8 sh; float dx, dy, dz; float t; };
-    auto fetch = [&](int64_t tile, TileIn& ti) {
+    // A tile's row number (hence its ray tile) is uniform over the wave and known from the tile index alone, so it is fetched through the SCALAR
+    // cache TWO wave iterations ahead (one SGPR per tile) -- when the vector loads of a tile are issued, every address is ready and nothing waits.
+    // Round 2's form loaded row_tile with a vector load inside the prefetch and waited for it (s_waitcnt vmcnt) before it could address the SH
+    // fragments and the hole flag: two exposed memory round trips per wave iteration in front of the MFMA chain; with all compute removed the
+    // kernel still took 0.178 ms of its 0.197 (round-3 ablations).
+    struct TileIn { uint4 b0, b1; h8 sh; float dx, dy, dz; float t; uint32_t alive; };
+    auto tile_rt = [&](int64_t tile) -> int32_t {
+        if constexpr (SRC == SRC_TILED) {
+            const int64_t tc = tile < n_tiles ? tile : n_tiles - 1;
+            const int row = __builtin_amdgcn_readfirstlane((int)(((base + (n > 0 ? (tc * 32 < n ? tc * 32 : n - 1) : 0)) >> 6)));
+            return in.row_tile[row];   // uniform address: s_load_dword
+        } else {
+            return 0;
+        }
+    };
+    auto fetch = [&](int64_t tile, int32_t rt, TileIn& ti) {
+#if defined(NRC_MLP_ABL_NOLOAD)   // synthetic inputs: no global load in the loop
+        ti.b0 = make_uint4(0x3c003c00u + (uint32_t)lane, 0x38003800u, 0x34003400u, 0x30003000u + (uint32_t)tile); ti.b1 = ti.b0;
+        ti.t = 1.f; ti.dx = 0.f; ti.dy = 0.f; ti.dz = 1.f; ti.alive = 1u;
+        { h8 z; for (int q = 0; q < 8; q++) z[q] = (_Float16)(0.1f * q); ti.sh = z; }
+        return;
+#endif
         const int64_t tc = tile < n_tiles ? tile : n_tiles - 1;
         const int64_t j = tc * 32 + r;
         const int64_t i = base + (j < n ? j : n - 1);
@@ -375,28 +410,46 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
         const int rot = (int)(tc & 3);
         ti.b0 = fp[((hh + rot) & 3) * 32];
         ti.b1 = fp[((2 + hh + rot) & 3) * 32];
+        ti.alive = 1u;
         if constexpr (SRC == SRC_TILED) {
-            const int32_t rt = in.row_tile[i >> 6];
-            ti.t = (in.tile_alive && !in.tile_alive[rt]) ? -1.f : in.ts[i];
+            ti.t = in.ts[i];
+            if (in.tile_alive) ti.alive = in.tile_alive[rt];   // independent of the other loads: selected at use, not waited for here
             ti.sh = ray_sh[((int64_t)rt * 2 + hh) * 64 + (i & 63)];
         } else {
             ti.t = 0.f;
             ti.dx = in.dirs[3 * i]; ti.dy = in.dirs[3 * i + 1]; ti.dz = in.dirs[3 * i + 2];
         }
     };
-    TileIn nxt[NT];
-    if (wave0 < n_groups) {
+    // PF groups in flight per wave (ring slots indexed by the unrolled p).  Measured (round 3): two or three groups ahead cost registers (NT = 1:
+    // 90 -> 126 -> 149 VGPRs, 5 -> 4 -> 3 waves per SIMD; NT = 2: 168 -> 209) and run 0.187 / 0.200 ms against 0.182 with one -- more bytes in
+    // flight is not what the kernel lacks.  PF stays 1.
+    constexpr int PF = 1;
+    TileIn ring[PF][NT];
+    int32_t rt_ring[PF][NT];   // ray tiles of the group that the NEXT visit of the slot will prefetch
 #pragma unroll
-        for (int u = 0; u < NT; u++) fetch(wave0 * NT + u, nxt[u]);
+    for (int p = 0; p < PF; p++) {
+        const int64_t g0 = wave0 + p * n_waves;
+        if (g0 < n_groups) {
+#pragma unroll
+            for (int u = 0; u < NT; u++) fetch(g0 * NT + u, tile_rt(g0 * NT + u), ring[p][u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NT; u++) rt_ring[p][u] = tile_rt((g0 + PF * n_waves) * NT + u);
     }
-    for (int64_t grp = wave0; grp < n_groups; grp += n_waves) {
+    for (int64_t grp0 = wave0; grp0 < n_groups; grp0 += PF * n_waves) {
+#pragma unroll
+      for (int p = 0; p < PF; p++) {
+        const int64_t grp = grp0 + p * n_waves;
+        if (grp >= n_groups) break;
         TileIn cur[NT];
 #pragma unroll
-        for (int u = 0; u < NT; u++) cur[u] = nxt[u];
-        if (grp + n_waves < n_groups) {
+        for (int u = 0; u < NT; u++) cur[u] = ring[p][u];
+        if (grp + PF * n_waves < n_groups) {
 #pragma unroll
-            for (int u = 0; u < NT; u++) fetch((grp + n_waves) * NT + u, nxt[u]);
+            for (int u = 0; u < NT; u++) fetch((grp + PF * n_waves) * NT + u, rt_ring[p][u], ring[p][u]);
         }
+#pragma unroll
+        for (int u = 0; u < NT; u++) rt_ring[p][u] = tile_rt((grp + 2 * PF * n_waves) * NT + u);
         bool valid[NT];
         int64_t idx[NT];
         bool any = false;
@@ -406,7 +459,7 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
             const int64_t j = tile * 32 + r;
             valid[u] = tile < n_tiles && j < n;
             idx[u] = base + (valid[u] ? j : n - 1);
-            if constexpr (SRC == SRC_TILED) valid[u] = valid[u] && cur[u].t >= 0.f;
+            if constexpr (SRC == SRC_TILED) valid[u] = valid[u] && cur[u].t >= 0.f && cur[u].alive != 0u;
             any = any || valid[u];
         }
         if (__ballot(any) == 0ull) continue;  // nothing but holes
@@ -433,24 +486,24 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
             for (int s = 0; s < 2; s++) {
                 const h8 w = D0(mt, s);
 #pragma unroll
-                for (int u = 0; u < NT; u++) acc[u][mt] = NRC_MFMA(w, B[u][s], acc[u][mt]);
+                for (int u = 0; u < NT; u++) acc[u][mt] = mlp_mfma(w, B[u][s], acc[u][mt]);
             }
 #pragma unroll
         for (int u = 0; u < NT; u++)
 #pragma unroll
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-                for (int gq = 0; gq < 2; gq++) H[u][2 * mt + gq] = acc_to_frag_relu(acc[u][mt], gq);
+                for (int gq = 0; gq < 2; gq++) H[u][2 * mt + gq] = mlp_frag_relu(acc[u][mt], gq);
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const h8 w = DO(s);
 #pragma unroll
-            for (int u = 0; u < NT; u++) o[u] = NRC_MFMA(w, H[u][s], o[u]);
+            for (int u = 0; u < NT; u++) o[u] = mlp_mfma(w, H[u][s], o[u]);
         }
         _Float16 h0[NT];
 #pragma unroll
         for (int u = 0; u < NT; u++) {
-            X[u][1] = acc_to_frag(o[u], 0);  // colour-net k-step 1 = fp16(h) straight from the accumulator (ACC order)
+            X[u][1] = mlp_frag(o[u], 0);  // colour-net k-step 1 = fp16(h) straight from the accumulator (ACC order)
             h0[u] = X[u][1][0];              // fp16 density feature 0 (lane half 0, element 0)
             acc[u][0] = zero16(); acc[u][1] = zero16();
         }
@@ -460,14 +513,14 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
             for (int s = 0; s < 2; s++) {
                 const h8 w = C0(mt, s);
 #pragma unroll
-                for (int u = 0; u < NT; u++) acc[u][mt] = NRC_MFMA(w, X[u][s], acc[u][mt]);
+                for (int u = 0; u < NT; u++) acc[u][mt] = mlp_mfma(w, X[u][s], acc[u][mt]);
             }
 #pragma unroll
         for (int u = 0; u < NT; u++) {
 #pragma unroll
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-                for (int gq = 0; gq < 2; gq++) H[u][2 * mt + gq] = acc_to_frag_relu(acc[u][mt], gq);
+                for (int gq = 0; gq < 2; gq++) H[u][2 * mt + gq] = mlp_frag_relu(acc[u][mt], gq);
             acc[u][0] = zero16(); acc[u][1] = zero16();
         }
 #pragma unroll
@@ -476,21 +529,21 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
             for (int s = 0; s < 4; s++) {
                 const h8 w = C1(mt, s);
 #pragma unroll
-                for (int u = 0; u < NT; u++) acc[u][mt] = NRC_MFMA(w, H[u][s], acc[u][mt]);
+                for (int u = 0; u < NT; u++) acc[u][mt] = mlp_mfma(w, H[u][s], acc[u][mt]);
             }
 #pragma unroll
         for (int u = 0; u < NT; u++) {
 #pragma unroll
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-                for (int gq = 0; gq < 2; gq++) H[u][2 * mt + gq] = acc_to_frag_relu(acc[u][mt], gq);
+                for (int gq = 0; gq < 2; gq++) H[u][2 * mt + gq] = mlp_frag_relu(acc[u][mt], gq);
             o[u] = zero16();
         }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const h8 w = CO(s);
 #pragma unroll
-            for (int u = 0; u < NT; u++) o[u] = NRC_MFMA(w, H[u][s], o[u]);
+            for (int u = 0; u < NT; u++) o[u] = mlp_mfma(w, H[u][s], o[u]);
         }
 #pragma unroll
         for (int u = 0; u < NT; u++) {
@@ -509,6 +562,7 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
                 }
             }
         }
+      }
     }
 #undef D0
 #undef DO
