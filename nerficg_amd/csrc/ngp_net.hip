@@ -54,7 +54,10 @@ template <int ENC, int N_HIDDEN, int OUT_ACT, bool SAVE>
 __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input, int in_ld, int64_t M, const __half* __restrict__ W,
                                                   const __half2* __restrict__ table, GridCfg g, int n_out_rows,
                                                   __half* __restrict__ out, int out_ld, int n_store, __half* __restrict__ save_in,
-                                                  __half* __restrict__ save_acts) {
+                                                  __half* __restrict__ save_acts, float* __restrict__ sigmas_f32 = nullptr, float* __restrict__ rgbs_f32 = nullptr) {
+    // sigmas_f32 / rgbs_f32 (ENC_DIR_H only, training query): the f32 outputs query_model hands to the compositor -- sigma = exp(h0) (TruncExp forward,
+    // custom_functions.py:201-204) from the density row this kernel reads anyway, rgb = the three fp16 sigmoid outputs widened -- written by the
+    // epilogue instead of a separate element-wise kernel over the two fp16 tensors
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int64_t n_tiles = (M + 31) / 32;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
@@ -78,27 +81,43 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
 #pragma unroll
     for (int s = 0; s < 4; s++) AO[s] = load_w_frag<true>(Wp, 64, n_out_rows, 0, s, r, hh);
 
+    // The raw inputs of a tile (two 16-byte vectors, or a direction + one vector) are requested ONE TILE AHEAD: a training batch is 4-16 tiles per
+    // wave, and without it every tile began with an exposed memory round trip in front of its MFMA chain (round 3: the same finding as in k_ngp_mlp).
+    struct RawIn { uint4 a, b; float d0, d1, d2; };
+    auto fetch_raw = [&](int64_t tile, RawIn& q) {
+        const int64_t i = tile * 32 + r;
+        const int64_t ic = i < M ? i : M - 1;
+        if constexpr (ENC == ENC_FEAT) {
+            const uint4* fp = reinterpret_cast<const uint4*>(input) + tile * 128 + r;
+            const int rot = (int)(tile & 3);
+            q.a = fp[((hh + rot) & 3) * 32]; q.b = fp[((2 + hh + rot) & 3) * 32];
+        } else if constexpr (ENC == ENC_DIR_H) {
+            const float* dp = reinterpret_cast<const float*>(input) + 3 * ic;
+            q.d0 = dp[0]; q.d1 = dp[1]; q.d2 = dp[2];
+            q.b = *reinterpret_cast<const uint4*>(reinterpret_cast<const _Float16*>(table) + ic * 16 + 8 * hh);
+        }
+    };
+    RawIn nxt_raw;
+    if (wave0 < n_tiles) fetch_raw(wave0, nxt_raw);
     for (int64_t tile = wave0; tile < n_tiles; tile += n_waves) {
         const int64_t i = tile * 32 + r;
         const bool valid = i < M;
         const int64_t ic = valid ? i : M - 1;
+        const RawIn raw = nxt_raw;
+        if (tile + n_waves < n_tiles) fetch_raw(tile + n_waves, nxt_raw);
         h8 B[2];
         if constexpr (ENC == ENC_GRID) {
             const float* xp = reinterpret_cast<const float*>(input) + 3 * ic;
             encode_grid(xp[0], xp[1], xp[2], hh, trs, g, B);
         } else if constexpr (ENC == ENC_FEAT) {
-            const uint4* fp = reinterpret_cast<const uint4*>(input) + tile * 128 + r;
-            const int rot = (int)(tile & 3);
-            const uint4 b0 = fp[((hh + rot) & 3) * 32], b1 = fp[((2 + hh + rot) & 3) * 32];
-            B[0] = *reinterpret_cast<const h8*>(&b0);
-            B[1] = *reinterpret_cast<const h8*>(&b1);
+            B[0] = *reinterpret_cast<const h8*>(&raw.a);
+            B[1] = *reinterpret_cast<const h8*>(&raw.b);
         } else if constexpr (ENC == ENC_DIR_H) {
             // `input` = directions (M,3) f32, `table` = the density network's output rows (M,16) fp16
-            const float* dp = reinterpret_cast<const float*>(input) + 3 * ic;
             h8 lo, hi;
-            sh4_fragments(dp[0], dp[1], dp[2], lo, hi);
+            sh4_fragments(raw.d0, raw.d1, raw.d2, lo, hi);
             B[0] = hh ? hi : lo;
-            B[1] = *reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(table) + ic * 16 + 8 * hh);
+            B[1] = *reinterpret_cast<const h8*>(&raw.b);
         } else {
             encode_sh_id(reinterpret_cast<const __half*>(input), in_ld, ic, hh, B);
         }
@@ -156,6 +175,12 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
             _Float16* p = reinterpret_cast<_Float16*>(out) + i * out_ld;
             if (4 * hh < n_store) *reinterpret_cast<h4*>(p + 4 * hh) = lo;
             if (8 + 4 * hh < n_store) *reinterpret_cast<h4*>(p + 8 + 4 * hh) = hi;
+            if constexpr (ENC == ENC_DIR_H) {
+                if (sigmas_f32 && hh == 0) {
+                    sigmas_f32[i] = expf((float)B[1][0]);   // B[1] of lane half 0 = density outputs 0-7 of this sample, as stored (fp16)
+                    rgbs_f32[3 * i] = (float)lo[0]; rgbs_f32[3 * i + 1] = (float)lo[1]; rgbs_f32[3 * i + 2] = (float)lo[2];
+                }
+            }
         }
     }
 }
@@ -253,7 +278,7 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
                 const int level = 4 * grp + q;
                 if (level < lvl_lo || level >= lvl_hi) continue;   // scalar, wave-uniform
                 Corner8 c;
-                float f0, f1;
+                float f0 = 0.f, f1 = 0.f;
                 bool have = false;
                 if constexpr (SRC == SRC_TILED) {   // rows of the tiled layout are spatially compact: try the scalar-cache path on the coarse levels
                     if (level < uniform_levels)
@@ -1205,7 +1230,6 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
         if (tile + n_waves < n_tiles) fetch(tile + n_waves, nxt);
         const h8 (&X)[2] = cur.X;
         const h8 (&H0)[4] = cur.H0;
-        const h8 (&H1)[4] = cur.H1;
         const h8 (&HL)[4] = N_HIDDEN > 1 ? cur.H1 : cur.H0;  // last hidden layer
         // ---- dZ of the output layer (natural order over the 16 padded output rows)
         h8 dZo = zero_h8();
@@ -1714,16 +1738,7 @@ static void pick_bucket_levels(const GridCfg& g, int n_levels, BucketCfg& bc, bo
 }
 
 // ---- fused training query (InstantNGPRayRenderingComponent.query_model, Renderer.py:48-53, as one autograd node) ----------------
-// outputs of the two networks -> what the compositor consumes: sigma = exp(h0) (TruncExp forward, custom_functions.py:201-204),
-// rgb = the colour net's sigmoid outputs, both f32
-__global__ void __launch_bounds__(256) k_train_outputs(const __half* __restrict__ h, const __half* __restrict__ rgb16, int64_t M,
-                                                       float* __restrict__ sigmas, float* __restrict__ rgbs) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    sigmas[i] = expf(__half2float(h[i * 16]));
-    const __half2 a = *reinterpret_cast<const __half2*>(rgb16 + i * 4), b = *reinterpret_cast<const __half2*>(rgb16 + i * 4 + 2);
-    rgbs[3 * i] = __low2float(a); rgbs[3 * i + 1] = __high2float(a); rgbs[3 * i + 2] = __low2float(b);
-}
+// (the f32 outputs the compositor consumes -- sigma = exp(h0), rgb -- are written by the colour kernel's epilogue, see k_nwie_fwd)
 // upstream gradients -> the colour net's fp16 d_out rows (M,4) and the TruncExp backward dh0 = dL/dsigma * exp(clamp(h0, -15, 15))
 __global__ void __launch_bounds__(256) k_train_dout(const float* __restrict__ dL_dsigmas, const float* __restrict__ dL_drgbs, const __half* __restrict__ h,
                                                     int64_t M, __half* __restrict__ d_rgb16, float* __restrict__ dh0) {
@@ -1913,10 +1928,8 @@ int nrc_ngp_train_query_forward(const float* xyzs, const float* dirs, int64_t M,
     NRC_STAGE(s, "k_nwie_fwd<density>");
     // colour net: [SH(d) | h] -> 64 -> 64 -> 3 (+1 pad), sigmoid
     hipLaunchKernelGGL((k_nwie_fwd<ENC_DIR_H, 2, ACT_SIGMOID, true>), grid, block, 0, s, (const void*)dirs, 0, M, (const __half*)color_weights_f16,
-                       (const __half2*)h_f16, g, 3, (__half*)rgb_f16, 4, 4, (__half*)save_in_c, (__half*)save_acts_c);
+                       (const __half2*)h_f16, g, 3, (__half*)rgb_f16, 4, 4, (__half*)save_in_c, (__half*)save_acts_c, sigmas, rgbs);
     NRC_STAGE(s, "k_nwie_fwd<colour>");
-    hipLaunchKernelGGL(k_train_outputs, dim3((unsigned)nrc_cdiv(M, 256)), dim3(256), 0, s, (const __half*)h_f16, (const __half*)rgb_f16, M, sigmas, rgbs);
-    NRC_STAGE(s, "k_train_outputs");
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
