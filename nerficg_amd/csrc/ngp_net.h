@@ -214,19 +214,21 @@ __device__ __forceinline__ void grid_level_features(__amdgpu_buffer_rsrc_t rsrc,
 
 // Hashed levels: both x-neighbours of ALL four (y, z) pairs straddle or not together -- (x ^ h) and ((x + 1) ^ h) differ by x ^ (x + 1),
 // which does not depend on h.  One predicate, one predicated region for the four fix-up loads.
+// AUX: cache-policy bits of the gathers (gfx940+ buffer loads: 1 = sc0, 2 = nt, 16 = sc1); 0 = default
+template <int AUX = 0>
 __device__ __forceinline__ void grid_level_features_hashed(__amdgpu_buffer_rsrc_t rsrc, const Corner8& c, float& f0, float& f1) {
     uint32_t v[8];
     uint4 quad[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (c.e[2 * p] & ~3u) << 2, 0, 0);
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (c.e[2 * p] & ~3u) << 2, 0, AUX);
         quad[p] = make_uint4(raw[0], raw[1], raw[2], raw[3]);
     }
     const bool straddle = ((c.e[0] ^ c.e[1]) & ~3u) != 0u;
     uint32_t fix[4] = {0u, 0u, 0u, 0u};
     if (straddle) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) fix[p] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, c.e[2 * p + 1] << 2, 0, 0);
+        for (int p = 0; p < 4; p++) fix[p] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, c.e[2 * p + 1] << 2, 0, AUX);
     }
 #pragma unroll
     for (int p = 0; p < 4; p++) {

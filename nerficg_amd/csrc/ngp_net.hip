@@ -289,6 +289,10 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
                     if (g.hashed[level]) grid_corners_u<true>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
                     else grid_corners_u<false>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
                     if (level < narrow_levels) grid_level_features_narrow(trs, c, f0, f1);
+#if defined(NRC_ENC_FINE_AUX)   // experiment build (tools/build_variant.sh ... -DNRC_ENC_FINE_AUX=n -DNRC_ENC_FINE_FROM=l): cache policy of the finest levels' gathers.
+                    // Measured with levels >= 12: sc0 0.644 ms, sc1 or sc0 sc1 (bypass L1) 0.816, nt 1.54 against 0.642 default -- the L1 does serve these levels
+                    else if (g.hashed[level] && hashed_mode == 1 && level >= NRC_ENC_FINE_FROM) grid_level_features_hashed<NRC_ENC_FINE_AUX>(trs, c, f0, f1);
+#endif
                     else if (g.hashed[level] && hashed_mode == 1) grid_level_features_hashed(trs, c, f0, f1);
                     else if (g.hashed[level] && hashed_mode == 2) grid_level_features_pair(trs, c, f0, f1);
                     else grid_level_features(trs, c, f0, f1);
