@@ -119,3 +119,44 @@ def test_rasterizer_abi_host_camera_equals_device_camera_block():
                                _lib.ptr(bufs['tt']), _lib.ptr(bufs['tc']), _lib.ptr(bufs['ranges']), _lib.ptr(bufs['tf']), _lib.ptr(hist), 0, 0,
                                _lib.ptr(bufs['splat']), _lib.ptr(bufs['num']), _lib.stream_of(means))
     assert rc != 0
+
+
+def test_stage_timer_names_and_times_the_kernels_of_an_entry_point():
+    """include/nerficg_hip.h group 12: armed, the library records a HIP event behind every kernel of the rasterizer's three entry points; the stages
+    come back in launch order with positive times that add up to no more than the wall time of the calls; disarmed, nothing is recorded."""
+    import time
+    from nerficg_amd import _lib
+    from nerficg_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from tests import scenes
+    sc = scenes.gs_random_scene(50_000, seed=2, extent=1.0, log_scale_mean=np.log(0.03))
+    cam = scenes.gs_camera(320, 240, scenes.orbit_pose(0.5, 0.3, 3.0))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    rs = GaussianRasterizationSettings(image_height=240, image_width=320, tanfovx=cam['tanfovx'], tanfovy=cam['tanfovy'], bg=torch.zeros(3, device=DEV), scale_modifier=1.0,
+                                       viewmatrix=T(cam['viewmatrix']), projmatrix=T(cam['projmatrix']), sh_degree=3, campos=T(cam['campos']), prefiltered=False, debug=False)
+
+    def frame():
+        means = T(sc['means3D']).requires_grad_(True)
+        color, _ = GaussianRasterizer(rs)(means3D=means, means2D=torch.zeros_like(means), opacities=T(sc['opacities'])[:, None], shs=T(sc['shs']),
+                                          scales=T(sc['scales']), rotations=T(sc['rotations']))
+        color.sum().backward()
+
+    frame()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with _lib.stage_timer() as st:
+        frame(); frame()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    names = [n for n, _ in st.stages]
+    per = st.by_name()
+    for k in ('k_preprocess', 'k_depth_keys', 'k_radix_scatter', 'k_span_scatter', 'k_item_scatter', 'k_render', 'k_render_bw', 'k_preprocess_bw'):
+        assert k in per, (k, sorted(per))
+    assert per['k_radix_scatter'][1] == 8 and per['k_render'][1] == 2                      # four radix passes per frame, two frames
+    assert names.index('k_preprocess') < names.index('k_render') < names.index('k_render_bw') < names.index('k_preprocess_bw')
+    assert all(t > 0 for _, t in st.stages) and sum(t for _, t in st.stages) <= wall_ms
+    with _lib.stage_timer() as empty:
+        pass
+    frame()                                                                                  # disarmed again: nothing is recorded, nothing leaks into the next use
+    with _lib.stage_timer() as again:
+        pass
+    assert empty.stages == [] and again.stages == []

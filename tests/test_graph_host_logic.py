@@ -94,3 +94,52 @@ def test_recorded_iterations_need_a_capturable_optimizer():
     g = Stub(); g.optimizer = opt
     with pytest.raises(RuntimeError, match='capturable=True'):
         gaussian_splatting_step(g, None, instance_capacity=10)
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus(tmp_path):
+    """`bench.py --gpus N` must never silently benchmark another number of ranks (round-2 review: it printed n_gpus 1 for --gpus 8)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, str(root / 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '--gpus 2 but WORLD_SIZE=1' in (r.stderr + r.stdout)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_present(monkeypatch):
+    import subprocess
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen['cmd'], seen['env'] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3'])
+    assert bench.spawn_ranks(4) == 7
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-4:] == ['--gpus', '4', '--steps', '3']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_fast_grad_scaler_falls_back_to_torch_on_host_tensors():
+    """nerficg_amd.amp.GradScaler only replaces the check for contiguous f32 device gradients; anything else takes torch's own path."""
+    from nerficg_amd.amp import GradScaler
+    p = torch.nn.Parameter(torch.ones(5))
+    opt = torch.optim.SGD([p], lr=0.1)
+    scaler = GradScaler('cpu', init_scale=4.0, growth_interval=10 ** 6)
+    for x in (1.0, float('inf'), 2.0):
+        loss = (p * x).sum()
+        scaler.scale(loss).backward()
+        scaler.step(opt); scaler.update(); opt.zero_grad()
+    assert torch.allclose(p.detach(), torch.full((5,), 1.0 - 0.1 * 1.0 - 0.1 * 2.0)) and scaler.get_scale() == 2.0
