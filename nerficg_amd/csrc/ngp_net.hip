@@ -465,6 +465,30 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
 #pragma unroll
         for (int u = 0; u < NT; u++) rt_ring[p][u] = tile_rt((g0 + PF * n_waves) * NT + u);
     }
+    // The outputs of a group leave ONE ITERATION LATER, right behind the next prefetch: a wave's vector-memory operations complete in issue
+    // order as far as s_waitcnt is concerned, and the wait for the prefetched inputs at the top of an iteration (vmcnt(0) across the loop edge)
+    // otherwise also waits for the stores the previous iteration issued a moment ago -- a store round trip per iteration in front of the chain.
+    h4 pend_pk[NT];
+    int64_t pend_idx[NT];
+    bool pend_ok[NT];
+#pragma unroll
+    for (int u = 0; u < NT; u++) { pend_ok[u] = false; pend_idx[u] = base; pend_pk[u] = h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f}; }
+    auto flush_pending = [&]() {
+#pragma unroll
+        for (int u = 0; u < NT; u++) {
+            if (pend_ok[u]) {
+                const int64_t i = pend_idx[u];
+                if constexpr (SRC == SRC_ARRAYS) {
+                    sigmas[i] = expf((float)pend_pk[u][0]);  // TruncExp forward (custom_functions.py:201-204)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) rgbs[3 * i + c] = (float)pend_pk[u][1 + c];
+                } else {
+                    *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(packed) + 4 * i) = pend_pk[u];
+                }
+            }
+            pend_ok[u] = false;
+        }
+    };
     for (int64_t grp0 = wave0; grp0 < n_groups; grp0 += PF * n_waves) {
 #pragma unroll
       for (int p = 0; p < PF; p++) {
@@ -479,6 +503,7 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
         }
 #pragma unroll
         for (int u = 0; u < NT; u++) rt_ring[p][u] = tile_rt((grp + 2 * PF * n_waves) * NT + u);
+        flush_pending();   // the previous group's outputs: issued behind this group's prefetch, complete long before the next wait
         bool valid[NT];
         int64_t idx[NT];
         bool any = false;
@@ -576,23 +601,15 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
         }
 #pragma unroll
         for (int u = 0; u < NT; u++) {
-            if (valid[u] && hh == 0) {
-                h4 pk;
-                pk[0] = h0[u];
+            pend_ok[u] = valid[u] && hh == 0;
+            pend_idx[u] = idx[u];
+            pend_pk[u][0] = h0[u];
 #pragma unroll
-                for (int c = 0; c < 3; c++) pk[1 + c] = (_Float16)fast_sigmoid(o[u][c]);
-                const int64_t i = idx[u];
-                if constexpr (SRC == SRC_ARRAYS) {
-                    sigmas[i] = expf((float)h0[u]);  // TruncExp forward (custom_functions.py:201-204)
-#pragma unroll
-                    for (int c = 0; c < 3; c++) rgbs[3 * i + c] = (float)pk[1 + c];
-                } else {
-                    *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(packed) + 4 * i) = pk;
-                }
-            }
+            for (int c = 0; c < 3; c++) pend_pk[u][1 + c] = (_Float16)fast_sigmoid(o[u][c]);
         }
       }
     }
+    flush_pending();
 #undef D0
 #undef DO
 #undef C0
