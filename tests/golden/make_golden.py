@@ -14,6 +14,7 @@ Vectors produced (reference symbol -> fixture):
   NeRFBlock.forward / NeRFRayRenderingComponent.forward (tiny model) -> nerf_render.npz         (a6, a10)
   Gaussians.densify_and_prune / add_densification_stats / as_ply_dict, adam_utils -> gs_densify.npz (8f rank 3, 4)
   torch.autograd through integrate_samples (dL/dsigma, dL/drgb)       -> composite_bw.npz    (a17 backward)
+  View.project_points + GS settings marshalling of ONE off-centre camera -> gs_projection.npz (a22: screen positions / depths of the rasterizer)
   GaussianSplattingModel.save after bake_activations                 -> gs_reference_checkpoint.pt (8f rank 4)
 """
 import importlib.util
@@ -427,12 +428,47 @@ def make_composite_bw():
     print('composite_bw.npz:', (OUT / 'composite_bw.npz').stat().st_size, 'B')
 
 
+def make_gs_projection():
+    """The rasterizer's screen-space means and depths pinned on the reference's own projection code: for ONE camera with an off-centre principal
+    point, (a) View.project_points (Datasets/utils.py:1040-1044 -> PerspectiveCamera.cam_to_screen, Cameras/Perspective.py:39-52) of 400 points
+    and (b) the matrices GaussianSplatting/Renderer.py:60-74 hands to the rasterizer (w2c.T, w2c.T @ P.T with P = get_projection_matrix,
+    Perspective.py:96-119; tanfov = W / (2 fx)).  The rasterizer's convention  pix = ((ndc + 1) * W - 1) / 2  on those matrices must land on
+    cam_to_screen - 0.5 (pixel centres at integers), and its view-space z on project_points' depth."""
+    install_shims()
+    sys.path.insert(0, str(REF))
+    import Framework
+    Framework.config = Framework.ConfigWrapper.fromDict({
+        'GLOBAL': {'RANDOM_SEED': 1618033989, 'ANOMALY_DETECTION': False, 'GPU_INDICES': None, 'DEFAULT_DEVICE': torch.device('cpu'), 'METHOD_TYPE': 'NeRF'},
+        'TRAINING': {'WANDB': {'ACTIVATE': False}},
+    })
+    from Cameras.Perspective import PerspectiveCamera
+    from Cameras.utils import SharedCameraSettings
+    from Datasets.utils import View
+    prev = np.load(OUT / 'raygen.npz')                      # the same camera, pose and points as the project_points vectors stored there
+    w, h, fx, fy, cx, cy, near, far = prev['proj_intr']
+    settings = SharedCameraSettings(background_color=torch.tensor([0.0, 0.0, 0.0]), near_plane=float(near), far_plane=float(far))
+    cam = PerspectiveCamera(shared_settings=settings, width=int(w), height=int(h), focal_x=float(fx), focal_y=float(fy), center_x=float(cx), center_y=float(cy))
+    view = View(camera=cam, camera_index=0, frame_idx=0, global_frame_idx=0, c2w=prev['proj_c2w'])
+    pts = torch.from_numpy(prev['proj_pts'])
+    xy, depth, inside = view.project_points(pts)
+    assert np.array_equal(xy.numpy(), prev['proj_xy'])      # the stored vectors are reproduced: same reference code path
+    P = cam.get_projection_matrix()
+    w2cT = view.w2c.T
+    np.savez_compressed(OUT / 'gs_projection.npz', intr=prev['proj_intr'], c2w=prev['proj_c2w'], pts=pts.numpy(), xy=xy.numpy(), depth=depth.numpy(),
+                        in_frustum=inside.numpy(), viewmatrix=w2cT.numpy(), projmatrix=(w2cT @ P.T).numpy(),
+                        tanfov=np.array([cam.width / cam.focal_x * 0.5, cam.height / cam.focal_y * 0.5], dtype=np.float64), campos=view.position.numpy())
+    print('gs_projection.npz:', (OUT / 'gs_projection.npz').stat().st_size, 'B')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'gs_densify':
         make_gs_densify()   # only this fixture (the others keep their RNG streams)
     elif len(sys.argv) > 1 and sys.argv[1] == 'composite_bw':
         make_composite_bw()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'gs_projection':
+        make_gs_projection()
     else:
         main()
         make_gs_densify()
         make_composite_bw()
+        make_gs_projection()

@@ -212,3 +212,23 @@ def test_raw_parameters_and_split_sh_match_the_activated_call():
         scale = float(a[2][k].abs().max())
         assert scale > 0 and float((a[2][k] - b[2][k]).abs().max()) <= 2e-3 * scale, (k, float((a[2][k] - b[2][k]).abs().max()) / scale)
     assert float((a[3] - b[3]).abs().max()) <= 2e-3 * float(a[3].abs().max())
+
+
+def test_screen_positions_match_the_reference_projection_golden(golden_dir):
+    """The HIP preprocess kernel on tests/golden/gs_projection.npz (the reference's own View.project_points and settings marshalling for a camera with
+    an off-centre principal point): screen positions = cam_to_screen - 0.5 within 2e-5 px, every in-frustum point visible."""
+    from nerficg_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    g = np.load(golden_dir / 'gs_projection.npz')
+    w, h = int(g['intr'][0]), int(g['intr'][1])
+    n = len(g['pts'])
+    rs = GaussianRasterizationSettings(image_height=h, image_width=w, tanfovx=float(g['tanfov'][0]), tanfovy=float(g['tanfov'][1]), bg=torch.zeros(3, device=DEV),
+                                       scale_modifier=1.0, viewmatrix=T(g['viewmatrix'].astype(np.float32)), projmatrix=T(g['projmatrix'].astype(np.float32)),
+                                       sh_degree=0, campos=T(g['campos'].astype(np.float32)), prefiltered=False, debug=False)
+    means = T(g['pts'].astype(np.float32)).requires_grad_(True)
+    color, radii = GaussianRasterizer(rs)(means3D=means, means2D=torch.zeros_like(means), opacities=torch.full((n, 1), 0.5, device=DEV),
+                                          shs=torch.zeros(n, 16, 3, device=DEV), scales=torch.full((n, 3), 0.01, device=DEV),
+                                          rotations=torch.tensor([[1.0, 0, 0, 0]], device=DEV).repeat(n, 1))
+    points_xy = color.grad_fn.saved_tensors[7].cpu().numpy()[:n]
+    vis = radii.cpu().numpy() > 0
+    assert vis.sum() >= 90 and not (g['in_frustum'] & ~vis).any()
+    np.testing.assert_allclose(points_xy[vis], g['xy'][vis] - 0.5, rtol=0, atol=2e-5)
