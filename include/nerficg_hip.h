@@ -239,7 +239,11 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
  *                       tensors (GaussianRasterizationSettings) never crosses to the host, and a recorded graph follows its updates.
  *   nrc_gs_bin_render : stages 3-5 -> out_color (3,H,W) = C + T * bg, n_contrib, final_T.
  *   nrc_gs_backward   : dL_dpix (3,H,W) -> every gradient (all fully written; dL_dmean2D (P,3) is the screen-space gradient
- *                       consumed by densification, src/Methods/GaussianSplatting/Model.py:258).
+ *                       consumed by densification, src/Methods/GaussianSplatting/Model.py:258).  grad_records: WORKSPACE (P,16) f32, 64-byte
+ *                       aligned, cleared by the call: the blend backward accumulates its nine per-Gaussian sums in one 64-byte record per
+ *                       Gaussian (colour 3, opacity 1, mean2D 2, conic 3) so that a tile's flush for a Gaussian is one contiguous group of one
+ *                       atomic instruction; dL_dmean2D / dL_dopacity (and dL_dconic (P,4) / dL_dcolor (P,3), which may be NULL) are written
+ *                       from the records by the per-Gaussian backward.
  * ===================================================================================================== */
 /* bytes of the binning workspace `bin_hist` (depth pre-sort buffers, row-span records, cursors) for `span_capacity` span records
  * (0 = default 4 P + 65536); returns 0 when the image has more than 256 tile rows or columns: pass NULL, the per-tile key sort is used.
@@ -265,7 +269,8 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
                     const uint32_t* ranges, const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib,
                     const float* final_T, const float* dL_dpix,
                     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-                    float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale, float* dL_drot, nrc_stream_t stream);
+                    float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale, float* dL_drot, float* grad_records,
+                    nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 5 -- ray generation (replaces PerspectiveCamera.compute_local_ray_directions src/Cameras/Perspective.py:64-94

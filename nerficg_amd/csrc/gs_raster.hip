@@ -1079,14 +1079,16 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
     return v;
 }
 // the four accumulators of the blend backward's global atomics, cleared by one launch (3 + 4 + 1 + 3 floats per Gaussian)
-__global__ void __launch_bounds__(256) k_zero_grads(int P, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-                                                    float* __restrict__ dL_dcolor) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    dL_dmean2D[3 * i] = 0.f; dL_dmean2D[3 * i + 1] = 0.f; dL_dmean2D[3 * i + 2] = 0.f;
-    *reinterpret_cast<float4*>(dL_dconic + 4 * (size_t)i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    dL_dopacity[i] = 0.f;
-    dL_dcolor[3 * i] = 0.f; dL_dcolor[3 * i + 1] = 0.f; dL_dcolor[3 * i + 2] = 0.f;
+// The blend backward's per-Gaussian accumulator: ONE 64-byte record per Gaussian,
+//   [0..2] dL/dcolour   [3] dL/dopacity   [4..5] dL/dmean2D (x, y)   [6..8] dL/dconic (xx, xy, yy)   [9..15] unused,
+// so that the nine sums a tile flushes for a Gaussian are one contiguous 36-byte group of ONE atomic wave-instruction.  Round 2 kept them in four
+// arrays (colour (P,3), opacity (P), mean2D (P,3), conic (P,4)): nine atomic instructions per flushing thread, every lane of each in another
+// cache line -- float atomics execute at the memory side, per 64-byte request, and that shape is the slow one (MI355X_MICROARCH.md, Global float
+// atomics: "64 lanes in 64 different rows ~17x slower").  Ablation (round 3): without the flush k_render_bw took 367 instead of 485 us.
+#define GREC 16
+__global__ void __launch_bounds__(256) k_zero_grads(int P, float4* __restrict__ grad_rec) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (int64_t)P * (GREC / 4)) grad_rec[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 // a + (b of the partner lane); CTRL: row_mirror 0x140 (lane ^ 15), row_half_mirror 0x141 (^ 7), quad_perm [3,2,1,0] 0x1b (^ 3), [1,0,3,2] 0xb1 (^ 1)
 template <int CTRL>
@@ -1123,10 +1125,10 @@ __device__ __forceinline__ float dpp_add2(float a, float b) {
 __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __restrict__ ranges, const int32_t* __restrict__ point_list,
                                                    const float4* __restrict__ splat, const uint32_t* __restrict__ tile_order, float bg0, float bg1, float bg2,
                                                    const float* __restrict__ pose, const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
-                                                   const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D,
-                                                   float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor) {
+                                                   const float* __restrict__ dL_dpix, float* __restrict__ grad_rec) {
     __shared__ StageLds st;
     __shared__ unsigned long long s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 16 blocks (fixed point), flushed once per batch
+    __shared__ int s_id[BATCH];                     // Gaussian of batch entry t (-1: nothing staged)
     __shared__ int s_blast[N_BLOCKS];
     __shared__ float s_gmax[4];
     if (pose) { bg0 = pose[35]; bg1 = pose[36]; bg2 = pose[37]; }
@@ -1208,6 +1210,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
                 st.c[threadIdx.x] = q2.x;
             }
         }
+        s_id[threadIdx.x] = flags ? id_l : -1;
         int n_wave;
         const int n_mine = block_lists(st, flags, &n_wave);
         // One list entry of this row: the record, this pixel's offset, alpha exactly as the forward computed it, and whether the pixel blended it.
@@ -1291,21 +1294,19 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
         }
 #endif
         __syncthreads();
-        if (flags) {  // the thread that staged the entry flushes it
-            const unsigned long long* a = s_acc[threadIdx.x];
-            unsigned long long any = 0ull;
-#pragma unroll
-            for (int q = 0; q < 9; q++) any |= a[q];
-            if (any) {
-                const int id = id_l;
-                const float ic = ldexpf(1.0f, gexp - BW_S_COLOR), io = ldexpf(1.0f, gexp - BW_S_OPACITY), im = ldexpf(1.0f, gexp - BW_S_MEAN),
-                            ix = ldexpf(1.0f, gexp - BW_S_CONIC);
-                auto val = [&](int q, float inv) { return (float)(long long)a[q] * inv; };
-                atomicAdd(dL_dcolor + 3 * id, val(0, ic)); atomicAdd(dL_dcolor + 3 * id + 1, val(1, ic)); atomicAdd(dL_dcolor + 3 * id + 2, val(2, ic));
-                atomicAdd(dL_dopacity + id, val(3, io));
-                atomicAdd(dL_dmean2D + 3 * id, val(4, -ddelx_dx * im)); atomicAdd(dL_dmean2D + 3 * id + 1, val(5, -ddely_dy * im));
-                atomicAdd(dL_dconic + 4 * id, val(6, -0.5f * ix)); atomicAdd(dL_dconic + 4 * id + 1, val(7, -0.5f * ix));
-                atomicAdd(dL_dconic + 4 * id + 3, val(8, -0.5f * ix));
+        // Flush: the 16 lanes of a DPP row take ONE batch entry, lane q its quantity q -- a wave-instruction adds four 36-byte groups, each inside one
+        // 64-byte record, instead of 64 lanes in 64 different lines.  Same sums, same one atomic per (tile, Gaussian, quantity).
+        {
+            const int q = threadIdx.x & 15;
+            const float inv = q < 3 ? ldexpf(1.0f, gexp - BW_S_COLOR) : q == 3 ? ldexpf(1.0f, gexp - BW_S_OPACITY)
+                            : q == 4 ? -ddelx_dx * ldexpf(1.0f, gexp - BW_S_MEAN) : q == 5 ? -ddely_dy * ldexpf(1.0f, gexp - BW_S_MEAN)
+                                                                                           : -0.5f * ldexpf(1.0f, gexp - BW_S_CONIC);
+            for (int e = threadIdx.x >> 4; e < nb_raw; e += 16) {
+                const int id = s_id[e];
+                if (id >= 0 && q < 9) {
+                    const long long a = (long long)s_acc[e][q];
+                    if (a != 0ll) atomicAdd(grad_rec + (size_t)id * GREC + q, (float)a * inv);
+                }
             }
         }
     }
@@ -1316,13 +1317,24 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
 __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const float* __restrict__ means3D, float* sh_row, int use_sh,
                                                   const float* __restrict__ scales, const float* __restrict__ rotations, int use_scale_rot,
                                                   const uint8_t* __restrict__ clamped, const float* __restrict__ cov3D,
-                                                  const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic,
-                                                  const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
+                                                  const float* __restrict__ grad_rec, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+                                                  float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
                                                   float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
                                                   const float* __restrict__ opacities, float* __restrict__ dL_dopacity) {
-    if (cam.raw && opacities) {  // dL/dlogit = dL/dopacity * o (1 - o); dL_dopacity holds the blend kernel's sums for the activated opacity
-        const float o_act = act_sigmoid(opacities[i]);
-        dL_dopacity[i] *= o_act * (1.f - o_act);
+    // the blend kernel's sums of this Gaussian: one 64-byte record (see k_zero_grads); the API's per-quantity tensors are written from it
+    const float4 r0 = *reinterpret_cast<const float4*>(grad_rec + (size_t)i * GREC), r1 = *reinterpret_cast<const float4*>(grad_rec + (size_t)i * GREC + 4);
+    const float r2x = grad_rec[(size_t)i * GREC + 8];
+    const float gcol[3] = {r0.x, r0.y, r0.z};
+    {
+        float g_op = r0.w;
+        if (cam.raw && opacities) {  // dL/dlogit = dL/dopacity * o (1 - o)
+            const float o_act = act_sigmoid(opacities[i]);
+            g_op *= o_act * (1.f - o_act);
+        }
+        dL_dopacity[i] = g_op;
+        dL_dmean2D[3 * i] = r1.x; dL_dmean2D[3 * i + 1] = r1.y; dL_dmean2D[3 * i + 2] = 0.f;
+        if (dL_dconic) *reinterpret_cast<float4*>(dL_dconic + 4 * (size_t)i) = make_float4(r1.z, r1.w, 0.f, r2x);
+        if (dL_dcolor) { dL_dcolor[3 * i] = gcol[0]; dL_dcolor[3 * i + 1] = gcol[1]; dL_dcolor[3 * i + 2] = gcol[2]; }
     }
     const float mean[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
     float c3[6];
@@ -1338,7 +1350,7 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
     const float a = Mx[0] * sx[0] + Mx[1] * sx[1] + Mx[2] * sx[2] + 0.3f;
     const float b = Mx[0] * sy[0] + Mx[1] * sy[1] + Mx[2] * sy[2];
     const float c = My[0] * sy[0] + My[1] * sy[1] + My[2] * sy[2] + 0.3f;
-    const float gcx = dL_dconic[4 * i], gcy = dL_dconic[4 * i + 1], gcz = dL_dconic[4 * i + 3];
+    const float gcx = r1.z, gcy = r1.w, gcz = r2x;
     const float denom = a * c - b * b;
     const float denom2inv = 1.0f / (denom * denom + 0.0000001f);
     float dL_da = 0, dL_db = 0, dL_dc = 0;
@@ -1377,7 +1389,7 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
     xform44(mean, pm, mh);
     const float mw = 1.0f / (mh[3] + 0.0000001f);
     const float mul1 = mh[0] * mw * mw, mul2 = mh[1] * mw * mw;
-    const float g2x = dL_dmean2D[3 * i], g2y = dL_dmean2D[3 * i + 1];
+    const float g2x = r1.x, g2y = r1.y;
     dmean[0] += (pm[0] * mw - pm[3] * mul1) * g2x + (pm[1] * mw - pm[3] * mul2) * g2y;
     dmean[1] += (pm[4] * mw - pm[7] * mul1) * g2x + (pm[5] * mw - pm[7] * mul2) * g2y;
     dmean[2] += (pm[8] * mw - pm[11] * mul1) * g2x + (pm[9] * mw - pm[11] * mul2) * g2y;
@@ -1389,7 +1401,7 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
         const uint8_t cl = clamped[i];
         float dRGB[3], ddir[3] = {0, 0, 0};
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) dRGB[ch] = ((cl >> ch) & 1) ? 0.f : dL_dcolor[3 * i + ch];
+        for (int ch = 0; ch < 3; ch++) dRGB[ch] = ((cl >> ch) & 1) ? 0.f : gcol[ch];
         float Bv[16], Bx[16], By[16], Bz[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) { Bv[k] = 0; Bx[k] = 0; By[k] = 0; Bz[k] = 0; }
@@ -1489,8 +1501,8 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
 __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_arg, const float* __restrict__ pose, const float* __restrict__ means3D, const float* __restrict__ shs,
                                                              const float* __restrict__ shs_rest, const float* __restrict__ opacities, int use_sh, const float* __restrict__ scales, const float* __restrict__ rotations,
                                                              int use_scale_rot, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
-                                                             const float* __restrict__ cov3D, const float* __restrict__ dL_dmean2D,
-                                                             const float* __restrict__ dL_dconic, const float* __restrict__ dL_dcolor,
+                                                             const float* __restrict__ cov3D, const float* __restrict__ grad_rec, float* __restrict__ dL_dmean2D,
+                                                             float* __restrict__ dL_dconic, float* __restrict__ dL_dcolor,
                                                              float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
                                                              float* __restrict__ dL_dsh_rest, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
                                                              float* __restrict__ dL_dopacity) {
@@ -1506,10 +1518,14 @@ __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_ar
     }
     float* sh_row = s_sh + threadIdx.x * pitch;
     if (visible) {
-        preprocess_bw_one(i, cam, means3D, sh_row, use_sh, scales, rotations, use_scale_rot, clamped, cov3D, dL_dmean2D, dL_dconic, dL_dcolor,
+        preprocess_bw_one(i, cam, means3D, sh_row, use_sh, scales, rotations, use_scale_rot, clamped, cov3D, grad_rec, dL_dmean2D, dL_dconic, dL_dcolor,
                           dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, opacities, dL_dopacity);
     } else if (i < P) {
         if (use_sh) for (int k = 0; k < row_len; k++) sh_row[k] = 0.f;
+        dL_dopacity[i] = 0.f;
+        dL_dmean2D[3 * i] = 0.f; dL_dmean2D[3 * i + 1] = 0.f; dL_dmean2D[3 * i + 2] = 0.f;
+        if (dL_dconic) *reinterpret_cast<float4*>(dL_dconic + 4 * (size_t)i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dL_dcolor) { dL_dcolor[3 * i] = 0.f; dL_dcolor[3 * i + 1] = 0.f; dL_dcolor[3 * i + 2] = 0.f; }
 #pragma unroll
         for (int k = 0; k < 3; k++) dL_dmean3D[3 * i + k] = 0.f;
 #pragma unroll
@@ -1715,7 +1731,7 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
                     const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
                     float* dL_dmean2D, float* dL_dconic,
                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
-                    float* dL_drot, nrc_stream_t stream) {
+                    float* dL_drot, float* grad_records, nrc_stream_t stream) {
     NRC_ENTER();
     GsCam cam;
     const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, camera_dev, tan_fovx, tan_fovy, scale_modifier, raw_parameters);
@@ -1724,21 +1740,21 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
     const float bg[3] = {bg_host ? bg_host[0] : 0.f, bg_host ? bg_host[1] : 0.f, bg_host ? bg_host[2] : 0.f};
     if (P == 0) return NRC_OK;
     if (!means3D || !radii || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !point_list || !ranges || !n_contrib || !final_T ||
-        !dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+        !dL_dpix || !dL_dmean2D || !dL_dopacity || !dL_dmean3D || !dL_dcov3D || !grad_records || (reinterpret_cast<uintptr_t>(grad_records) & 63u))
         return NRC_ERR_INVALID;
     const int use_sh = colors_precomp == nullptr, use_sr = cov3D_precomp == nullptr;
     if ((use_sh && (!shs || !dL_dsh)) || (use_sr && (!scales || !rotations || !dL_dscale || !dL_drot))) return NRC_ERR_INVALID;
     if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr) || (raw_parameters && (!opacities || !use_sr))) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     NRC_STAGE(s, nullptr);
-    hipLaunchKernelGGL(k_zero_grads, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+    hipLaunchKernelGGL(k_zero_grads, dim3((unsigned)nrc_cdiv((int64_t)P * (GREC / 4), 256)), dim3(256), 0, s, P, (float4*)grad_records);
     NRC_STAGE(s, "k_zero_grads");
     if (use_sh && M > PBW_MAXM) return NRC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_render_bw, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_order, bg[0], bg[1], bg[2],
-                       camera_dev, n_contrib, final_T, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+                       camera_dev, n_contrib, final_T, dL_dpix, grad_records);
     NRC_STAGE(s, "k_render_bw");
     hipLaunchKernelGGL(k_preprocess_bw, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, P, cam, camera_dev, means3D, shs, shs_rest, opacities, use_sh, scales, rotations,
-                       use_sr, radii, clamped, cov3D, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, dL_dopacity);
+                       use_sr, radii, clamped, cov3D, grad_records, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, dL_dopacity);
     NRC_STAGE(s, "k_preprocess_bw");
     NRC_LAUNCH_CHECK();
     return NRC_OK;

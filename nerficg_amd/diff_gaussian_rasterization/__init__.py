@@ -199,9 +199,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         g = grad_out_color.to(f32).contiguous()
         n1 = max(P, 1)
         dmean2D = torch.empty(n1, 3, dtype=f32, device=dev)
-        dconic = torch.empty(n1, 4, dtype=f32, device=dev)
+        grad_records = torch.empty(n1, 16, dtype=f32, device=dev)   # workspace: one 64-byte accumulator record per Gaussian (cleared by the call)
+        dcolor = torch.empty(n1, 3, dtype=f32, device=dev) if has_col else None   # only a caller with colors_precomp asks for it
         dopacity = torch.empty(n1, dtype=f32, device=dev)
-        dcolor = torch.empty(n1, 3, dtype=f32, device=dev)
         dmean3D = torch.empty(n1, 3, dtype=f32, device=dev)
         dcov3D = torch.empty(n1, 6, dtype=f32, device=dev)
         dsh = torch.empty(n1, 1 if has_rest else max(M, 1), 3, dtype=f32, device=dev) if has_sh else None
@@ -214,8 +214,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.ptr(sc if has_sr else None), float(rs.scale_modifier), _lib.ptr(rot if has_sr else None), _lib.ptr(cov if has_cov else None),
             None, None, None, _lib.ptr(cam_block), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
             _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(point_list), _lib.ptr(ranges), _lib.ptr(splat), _lib.ptr(tile_order), _lib.ptr(n_contrib), _lib.ptr(final_T),
-            _lib.ptr(g), _lib.ptr(dmean2D), _lib.ptr(dconic), _lib.ptr(dopacity), _lib.ptr(dcolor), _lib.ptr(dmean3D), _lib.ptr(dcov3D),
-            _lib.ptr(dsh), _lib.ptr(dsh_rest), _lib.ptr(dscale), _lib.ptr(drot), _lib.stream_of(g)), 'gs_backward')
+            _lib.ptr(g), _lib.ptr(dmean2D), None, _lib.ptr(dopacity), _lib.ptr(dcolor), _lib.ptr(dmean3D), _lib.ptr(dcov3D),
+            _lib.ptr(dsh), _lib.ptr(dsh_rest), _lib.ptr(dscale), _lib.ptr(drot), _lib.ptr(grad_records), _lib.stream_of(g)), 'gs_backward')
         return (dmean3D[:P], dmean2D[:P], dsh[:P] if has_sh else None, dcolor[:P] if has_col else None,
                 dopacity[:P].reshape(ctx.opacity_shape), dscale[:P] if has_sr else None, drot[:P] if has_sr else None,
                 dcov3D[:P] if has_cov else None, None, dsh_rest[:P] if has_rest else None, None)
