@@ -508,9 +508,16 @@ __global__ void __launch_bounds__(256) k_radix_scatter(int n, int shift, int nbl
 #define GS_MAX_LDS_TILES 16384
 #define SPAN_CH_MIN 256      // spans per level-2 item (one wave): 256, 512 or 1024, see k_span_rows
 #define SPAN_CH_MAX 1024
+#ifndef SPAN_NB_MAX
 #define SPAN_NB_MAX 4096     // level-1 slices (waves) at most
+#endif
 #define SPAN_DIM_MAX 256     // tile rows / columns the lane-private cursors cover (4 registers x 64 lanes): 4096 x 4096 pixels
-#define SPAN_GRID 2048       // waves of the level-2 passes (grid-stride over the items)
+#ifndef SPAN_GRID
+#define SPAN_GRID 2048       // waves of the level-2 scatter (grid-stride over the items): few enough that the lines being appended stay in L2
+#endif
+#ifndef SPAN_GRID_COUNT
+#define SPAN_GRID_COUNT 4096 // waves of the level-2 counting pass (no write frontiers to keep: 20 -> 15 us at 1 M Gaussians, 91 -> 55 at 6 M)
+#endif
 
 struct SpanRect { int id, y0, y1, x01; bool ok; };
 // Gaussian j of the depth order: id and rectangle as the sort delivered them
@@ -1673,7 +1680,7 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
             NRC_STAGE(s, "k_span_rows");
             hipLaunchKernelGGL(k_span_scatter, dim3(w.nb1), dim3(64), 0, s, P, w.nb1, w.chunk1, cam.gy, w.valA, w.rectA, w.cnt1, w.roff, w.cap, w.spans);
             NRC_STAGE(s, "k_span_scatter");
-            hipLaunchKernelGGL(k_item_count, dim3(SPAN_GRID), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.cap, w.item_cap,
+            hipLaunchKernelGGL(k_item_count, dim3(SPAN_GRID_COUNT), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.cap, w.item_cap,
                                w.spans, w.cnt2);
             NRC_STAGE(s, "k_item_count");
             hipLaunchKernelGGL(k_item_scan, dim3((unsigned)nrc_cdiv(cam.gx, 64), cam.gy), dim3(1024), 0, s, cam.gx, w.item_cap, w.nitems, w.ioff, w.cnt2, w.tcount);
