@@ -1382,14 +1382,21 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
 }
 
 // hash-grid backward, small / dense levels: one lane per (sample, level); scatter-add of w_corner * dL/dfeature into the f32 table
-// gradient.  Neighbouring lanes are consecutive samples of a ray and, on all but the finest levels, hit the same table entries:
-// each corner's contributions are combined over RUNS of equal entry index inside the wave (segmented scan) and only the last lane
-// of a run issues the atomic.  d_feat: pair-major [n_levels][M][2] or sample-major (M, 2 n_levels).
+// gradient.  Neighbouring lanes are consecutive samples of a ray and, on all but the finest levels, fall into the same cell: the
+// sixteen contributions (8 corners x 2 features) are combined over RUNS of equal cells inside the wave (segmented scan) and only the
+// last lane of a run has anything to add.  Those sums leave the wave COOPERATIVELY: the run's last lane parks its sixteen values and
+// eight entry indices in a wave-private LDS slot, and sixteen lanes per run issue the atomics, lane q the value q -- the two features
+// of an entry are 8 contiguous bytes and, on a dense level, the x-neighbour is the next entry, so one wave instruction adds 16-byte
+// groups (8-byte on a hashed level) instead of 64 unrelated floats twice.  Float atomics execute at the memory side per 64-byte
+// request: the request count, not the lane count, is what they cost (the same finding as k_render_bw's records, gs_raster.hip).
+// d_feat: pair-major [n_levels][M][2] or sample-major (M, 2 n_levels).
 struct LevelList { int n; int level[NRC_MAX_LEVELS]; };
 __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, int pair_major, GridCfg g,
                                                   int n_levels, LevelList ll, float* __restrict__ grad_table) {
+    __shared__ float s_val[4][64][16];
+    __shared__ uint32_t s_key[4][64][8];
     const int level = ll.level[blockIdx.y];
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool in_range = i < M;
     const int64_t ic = in_range ? i : M - 1;
@@ -1400,29 +1407,74 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, i
     Corner8 c;
     if (g.hashed[level]) grid_corners_u<true>(x[3 * ic], x[3 * ic + 1], x[3 * ic + 2], g.scale[level], g.res[level], g.size[level], g.offset[level], c);
     else grid_corners_u<false>(x[3 * ic], x[3 * ic + 1], x[3 * ic + 2], g.scale[level], g.res[level], g.size[level], g.offset[level], c);
+    // a run: consecutive live lanes whose eight entries are all the same (dead lanes split runs)
+    // (every shuffle executed by the whole wave: no short-circuit in front of a cross-lane read)
+    const int prev_live = __shfl_up((int)live, 1, 64);
+    uint32_t differ = 0u;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const uint32_t key = live ? c.e[k] : (0xffffff00u | (uint32_t)lane);  // dead lanes: unique keys, they only split runs
-        float v0 = live ? c.w[k] * gf.x : 0.f, v1 = live ? c.w[k] * gf.y : 0.f;
-        const uint32_t prev = __shfl_up(key, 1, 64), next = __shfl_down(key, 1, 64);
-        const bool head = lane == 0 || prev != key, tail = lane == 63 || next != key;
-        if (__ballot(!head) != 0ull) {  // some run is longer than one lane
-            int start = head ? lane : 0;
+    for (int k = 0; k < 8; k++) differ |= __shfl_up(c.e[k], 1, 64) ^ c.e[k];
+#if defined(NRC_GBW_NOAGG)
+    const bool same = false;
+#else
+    const bool same = lane > 0 && live && prev_live != 0 && differ == 0u;
+#endif
+    const bool head = !same;
+    const int next_head = __shfl_down((int)head, 1, 64);
+    const bool tail = lane == 63 || next_head != 0;
+    float v[16];
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(start, d, 64);
-                if (lane >= d) start = max(start, o);
-            }
+    for (int k = 0; k < 8; k++) { v[2 * k] = live ? c.w[k] * gf.x : 0.f; v[2 * k + 1] = live ? c.w[k] * gf.y : 0.f; }
+    if (__ballot(!head) != 0ull) {  // some run is longer than one lane
+        int start = head ? lane : 0;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const float o0 = __shfl_up(v0, d, 64), o1 = __shfl_up(v1, d, 64);
-                if (lane - d >= start) { v0 += o0; v1 += o1; }
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(start, d, 64);
+            if (lane >= d) start = max(start, o);
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const bool take = lane - d >= start;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const float o = __shfl_up(v[q], d, 64);
+                if (take) v[q] += o;
             }
         }
-        if (live && tail) {
-            float* p = grad_table + 2 * (size_t)key;
-            atomicAdd(p, v0);
-            atomicAdd(p + 1, v1);
+    }
+    const bool flush = live && tail;
+#if defined(NRC_GBW_DIRECT_FLUSH)
+    if (flush) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { atomicAdd(grad_table + 2 * (size_t)c.e[k], v[2 * k]); atomicAdd(grad_table + 2 * (size_t)c.e[k] + 1, v[2 * k + 1]); }
+    }
+    return;
+#endif
+    const uint64_t tails = __ballot(flush);
+    const int n_tails = __popcll(tails);
+    if (flush) {
+        const int slot = __popcll(tails & ((1ull << lane) - 1ull));
+        float4* sv = reinterpret_cast<float4*>(s_val[wv][slot]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) sv[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        uint4* sk = reinterpret_cast<uint4*>(s_key[wv][slot]);
+        sk[0] = make_uint4(c.e[0], c.e[1], c.e[2], c.e[3]);
+        sk[1] = make_uint4(c.e[4], c.e[5], c.e[6], c.e[7]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int q = lane & 15;
+#ifndef NRC_GBW_TAILS_PER_INSTR
+#define NRC_GBW_TAILS_PER_INSTR 4
+#endif
+    for (int s0 = 0; s0 < n_tails; s0 += NRC_GBW_TAILS_PER_INSTR) {
+        const int sl = s0 + (lane >> 4);
+        if ((lane >> 4) < NRC_GBW_TAILS_PER_INSTR && sl < n_tails) {
+#if defined(NRC_GBW_ABL_NOATOMIC)  // ablation build (tools/build_variant.sh): everything but the atomics
+            if (s_val[wv][sl][q] == 1.2345e-30f) grad_table[2 * (size_t)s_key[wv][sl][q >> 1] + (q & 1)] = 1.f;
+#else
+            atomicAdd(grad_table + 2 * (size_t)s_key[wv][sl][q >> 1] + (q & 1), s_val[wv][sl][q]);
+#endif
         }
     }
 }

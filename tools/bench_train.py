@@ -34,6 +34,16 @@ def step(i):
 
 for i in range(3):
     s = step(i)
+if len(sys.argv) > 3:   # per-kernel times of the query forward / backward (stage timer), early and late in the run
+    from nerficg_amd import _lib
+    done = 3
+    for label, skip in (('early', 0), ('late', int(sys.argv[3]))):
+        for i in range(skip):
+            step(done); done += 1
+        with _lib.stage_timer() as st:
+            for i in range(10):
+                step(done); done += 1
+        print(label, ' '.join(f'{k}={tot / 10 * 1e3:.1f}' for k, (tot, _) in sorted(st.by_name().items())))
 torch.cuda.synchronize(); t0 = time.perf_counter(); tot = 0
 for i in range(iters):
     tot += step(3 + i)
