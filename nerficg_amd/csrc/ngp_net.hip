@@ -1176,6 +1176,14 @@ __device__ __forceinline__ void atomic_add_tile(float* __restrict__ G, int ld, i
     }
 }
 
+#if defined(NRC_BWD_PROBE)   // developer build (tools/build_variant.sh): cycle stamps of wave 0 of workgroup 0 at the phases of the first tiles
+__device__ unsigned long long g_bwd_probe[2][128];
+#define NRC_PROBE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); g_bwd_probe[N_HIDDEN - 1][(k)] = __builtin_readcyclecounter(); } } while (0)
+#define NRC_PROBE_NW(k) do { if (blockIdx.x == 300 && threadIdx.x == 0) g_bwd_probe[0][(k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NRC_PROBE(k) do { } while (0)
+#define NRC_PROBE_NW(k) do { } while (0)
+#endif
 template <int N_HIDDEN, int OUT_ACT>
 __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __restrict__ W, int n_out_rows, const __half* __restrict__ d_out,
                                                   const __half* __restrict__ out, int out_ld, const __half* __restrict__ save_in,
@@ -1188,6 +1196,7 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
     const int64_t n_tiles = (M + 31) / 32;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, n_waves = (int64_t)gridDim.x * 4;
     const float inv_scale = 1.0f / loss_scale;
+    NRC_PROBE(0);
 
     const __half* W0 = W;
     const __half* W1 = W + 64 * 32;                                   // only when N_HIDDEN == 2
@@ -1242,13 +1251,20 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
             }
         }
     };
+    NRC_PROBE(1);
     TileState nxt;
     if (wave0 < n_tiles) fetch(wave0, nxt);
-    for (int64_t tile = wave0; tile < n_tiles; tile += n_waves) {
+    int probe_t = 0;
+    for (int64_t tile = wave0; tile < n_tiles; tile += n_waves, probe_t++) {
+        const int pb = 10 + 10 * (probe_t < 10 ? probe_t : 10);
+        (void)pb;
         const int64_t i = tile * 32 + r;
         const bool valid = i < M;
         const TileState cur = nxt;
+#if !defined(NRC_BWD_ABL_NOLOAD)   // ablation builds (tools/build_variant.sh): -DNRC_BWD_ABL_{NOLOAD,NODW,NOFLUSH}
         if (tile + n_waves < n_tiles) fetch(tile + n_waves, nxt);
+#endif
+        NRC_PROBE(pb + 0);
         const h8 (&X)[2] = cur.X;
         const h8 (&H0)[4] = cur.H0;
         const h8 (&HL)[4] = N_HIDDEN > 1 ? cur.H1 : cur.H0;  // last hidden layer
@@ -1265,7 +1281,9 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
                 }
             }
         }
+        NRC_PROBE(pb + 1);
         // ---- dWout += dZo^T . HL   (k = samples, through the transposed LDS images)
+#if !defined(NRC_BWD_ABL_NODW)
         stage_frag_T<false>(T_dz, dZo, 0, r, hh);
 #pragma unroll
         for (int s = 0; s < 4; s++) stage_frag_T<true>(T_act, HL[s], s, r, hh);
@@ -1277,6 +1295,8 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
             for (int nt = 0; nt < 2; nt++) gWo[nt] = NRC_MFMA(a, read_T_frag(T_act, 32 * nt + r, s, hh), gWo[nt]);
         }
         wave_lds_sync();
+#endif
+        NRC_PROBE(pb + 2);
         // ---- dHL^T = Wout^T . dZo^T ; dZL = relu'(HL) * dHL
         f16v acc[2] = {zero16(), zero16()};
 #pragma unroll
@@ -1286,8 +1306,10 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
         for (int mt = 0; mt < 2; mt++)
 #pragma unroll
             for (int gq = 0; gq < 2; gq++) dZ[2 * mt + gq] = masked_grad_frag(acc[mt], gq, HL[2 * mt + gq]);
+        NRC_PROBE(pb + 3);
         if constexpr (N_HIDDEN > 1) {
             // ---- dW1 += dZ1^T . H0
+#if !defined(NRC_BWD_ABL_NODW)
 #pragma unroll
             for (int s = 0; s < 4; s++) { stage_frag_T<true>(T_dz, dZ[s], s, r, hh); stage_frag_T<true>(T_act, H0[s], s, r, hh); }
             wave_lds_sync();
@@ -1300,6 +1322,8 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
                     for (int nt = 0; nt < 2; nt++) gW1[mt][nt] = NRC_MFMA(a, read_T_frag(T_act, 32 * nt + r, s, hh), gW1[mt][nt]);
                 }
             wave_lds_sync();
+#endif
+            NRC_PROBE(pb + 4);
             // ---- dH0^T = W1^T . dZ1^T ; dZ0 = relu'(H0) * dH0
             acc[0] = zero16(); acc[1] = zero16();
 #pragma unroll
@@ -1311,7 +1335,9 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) dZ[2 * mt + gq] = masked_grad_frag(acc[mt], gq, H0[2 * mt + gq]);
         }
+        NRC_PROBE(pb + 5);
         // ---- dW0 += dZ0^T . X
+#if !defined(NRC_BWD_ABL_NODW)
 #pragma unroll
         for (int s = 0; s < 4; s++) stage_frag_T<true>(T_dz, dZ[s], s, r, hh);
         stage_frag_T<false>(T_act, X[0], 0, r, hh);
@@ -1324,6 +1350,8 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
             for (int mt = 0; mt < 2; mt++) gW0[mt] = NRC_MFMA(read_T_frag(T_dz, 32 * mt + r, s, hh), b, gW0[mt]);
         }
         wave_lds_sync();
+#endif
+        NRC_PROBE(pb + 6);
         // ---- d_in^T = W0^T . dZ0^T  (32 input features x 32 samples), unscaled f32
         f16v din = zero16();
 #pragma unroll
@@ -1341,7 +1369,9 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
                 }
             }
         }
+        NRC_PROBE(pb + 7);
     }
+    NRC_PROBE(120);
     // ---- flush the weight-gradient accumulators (layout of W).  The four waves of the workgroup first add their tiles up through LDS (the
     // staging area is free now), tile after tile with two alternating slots, and ONE wave per tile issues the global atomics: with one flush
     // per wave the 1 024 waves of a launch queued 1 024 float atomics on each of the 3 072 / 7 168 addresses (54 of the 160 us of the two
@@ -1357,7 +1387,11 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) slot[(wv * 16 + reg) * 64 + lane] = acc[reg];
         __syncthreads();
+#if defined(NRC_BWD_ABL_NOFLUSH)
+        if (wv == (tile_no & 3) && acc[0] == 1.2345e-30f) {
+#else
         if (wv == (tile_no & 3)) {
+#endif
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 float v = 0.f;
@@ -1379,6 +1413,7 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
     }
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) reduce_flush(gWop, 64, n_out_rows, 0, nt, gWo[nt]);
+    NRC_PROBE(121);
 }
 
 // hash-grid backward, small / dense levels: one lane per (sample, level); scatter-add of w_corner * dL/dfeature into the f32 table
@@ -1618,175 +1653,314 @@ __global__ void __launch_bounds__(OWN_THREADS) k_grid_bwd_owned_q(const float* _
 // The ownership kernels above make every slice owner scan ALL samples (32 x redundant index arithmetic, and every owner streams all
 // positions and gradients through L2: 1.3 GB per backward).  Here the (sample, (y,z) corner pair) items are first split by the slice
 // that owns them -- on a hashed level the slice, index >> 13, depends only on the (y, z) hash, so both x-neighbours of a pair live in
-// the same slice:
-//   k_gb_split<false>  per-bucket counts (LDS histogram per 1024 samples, one global atomic per bucket and workgroup) and the largest
-//                      |gradient| of every level
-//   k_gb_scan          exclusive scan of the <= 1024 bucket counts; fixed-point scale of every level
-//   k_gb_split<true>   16-byte self-contained records {two slice-local entries, wy wz g (2), wx} into the buckets (workgroups reserve their
-//                      runs with one atomic per bucket)
-//   k_gb_accumulate    one workgroup per bucket: its records (one contiguous read) into an 8 K-entry LDS slice, then a plain read-modify-
-//                      write flush.  The slice accumulates 64-bit FIXED POINT: LDS float atomics run at 0.32 lane-operations per clock
-//                      and CU on this chip, integer ones (32 or 64 bit) at 1.33 (tools/micro/lds_atomics.hip) -- with f32 atomics this
-//                      kernel took 380 us, 320 of them in ds_add_f32.  scale = 2^(62 - ceil log2 max|g| - ceil log2 (2 M + 1)): no
-//                      overflow whatever the collisions, LSB <= max|g| 2^-41 for M = 264 K, and the sums no longer depend on the order of
-//                      the atomics: the hashed levels' gradient is bit-reproducible.
+// the same slice -- in TWO launches and without any global counting:
+//   k_gb_split       one workgroup per 1024 samples.  It ranks its items inside their buckets (one LDS atomic each, the rank kept in a
+//                    register), scans its <= 1024 bucket counts and writes 16-byte self-contained records {two slice-local entries,
+//                    wy wz g (2), wx} bucket after bucket into ITS OWN region of the workspace; a table [bucket][workgroup] holds
+//                    where each of its runs starts and how long it is, a second one its largest |gradient| per level.  Nothing is
+//                    shared between workgroups: no counters to zero, no count pass, no scan kernel (round 2 had all three: 36 us of a
+//                    training iteration and three launches).
+//   k_gb_accumulate  one workgroup per bucket: walks the table row of its bucket, reads every workgroup's run (contiguous, ~64 records
+//                    on a training batch) into an 8 K-entry LDS slice, then a plain read-modify-write flush.  The slice accumulates
+//                    64-bit FIXED POINT: LDS float atomics run at 0.32 lane-operations per clock and CU on this chip, integer ones
+//                    (32 or 64 bit) at 1.33 (tools/micro/lds_atomics.hip) -- with f32 atomics this kernel took 380 us, 320 of them in
+//                    ds_add_f32.  scale = 2^(62 - ceil log2 max|g| - ceil log2 (2 M + 1)): no overflow whatever the collisions, LSB <=
+//                    max|g| 2^-41 for M = 264 K, and the sums no longer depend on the order of the atomics: the hashed levels' gradient
+//                    is bit-reproducible.
 // (A first version with 4-byte (sample, pair) records still gathered positions / gradients per record -- spread over all samples, i.e.
 // the same lines again.)
 #define GB_MAX_BUCKETS 1024
 #define GB_ENTRIES 8192
 #define GB_SHIFT 13
-#define GB_HEADER_BYTES 16384
+#define GBA_THREADS 1024
 struct BucketCfg { int n_levels; int level[NRC_MAX_LEVELS]; int bucket0[NRC_MAX_LEVELS + 1]; };
-struct GbHeader {
-    uint32_t counts[GB_MAX_BUCKETS], cursor[GB_MAX_BUCKETS], base[GB_MAX_BUCKETS];
-    uint32_t level_max[NRC_MAX_LEVELS];  // bit pattern of max |g| (non-negative floats order like their bits)
-    float level_scale[NRC_MAX_LEVELS];
-};
-static_assert(sizeof(GbHeader) <= GB_HEADER_BYTES, "header");
+// workspace: [seg table nb x n_wg u32: start | count << 16][level maxima n_wg x NRC_MAX_LEVELS u32][records n_wg x 1024 x 4 x n_levels x 16 B]
+struct GbLayout { int64_t n_wg, seg_bytes, max_bytes, rec_per_wg, total; };
+static GbLayout gb_layout(int64_t M, int n_bucket_levels, int nb) {
+    GbLayout L;
+    L.n_wg = nrc_cdiv(M, OWN_THREADS);
+    L.seg_bytes = ((int64_t)nb * L.n_wg * 4 + 255) / 256 * 256;
+    L.max_bytes = (L.n_wg * NRC_MAX_LEVELS * 4 + 255) / 256 * 256;
+    L.rec_per_wg = (int64_t)OWN_THREADS * 4 * n_bucket_levels;
+    L.total = L.seg_bytes + L.max_bytes + L.n_wg * L.rec_per_wg * 16 + 256;
+    return L;
+}
 
-template <bool WRITE>
+#define GB_GROUP 16   // levels ranked together: 2 x GB_GROUP rank registers + 2 x GB_GROUP gradient registers per thread
 __global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, GridCfg g, BucketCfg bc,
-                                                          GbHeader* __restrict__ hd, uint4* __restrict__ records) {
-    __shared__ uint32_t hist[GB_MAX_BUCKETS], gbase[GB_MAX_BUCKETS], lmax[NRC_MAX_LEVELS];
+                                                             uint32_t* __restrict__ seg, uint32_t* __restrict__ wg_max, uint4* __restrict__ records,
+                                                             int64_t rec_per_wg) {
+    // Two workgroups per CU (eight waves per SIMD, <= 64 VGPRs: the second launch bound is waves per execution unit): a training batch of ~2^18 samples is 256-and-a-few workgroups, and with one per CU the few
+    // ran alone after the others -- twice the kernel time for a handful of samples.  Hence the level groups: the ranks and gradients of
+    // GB_GROUP levels fit the register budget, all sixteen do not.
+    __shared__ uint32_t hist[GB_MAX_BUCKETS], gbase[GB_MAX_BUCKETS], lmax[NRC_MAX_LEVELS], wave_tot[OWN_THREADS / 64];
+    extern __shared__ uint4 stage[];   // [2][4096] records: two level images
     const int nb = bc.bucket0[bc.n_levels];
-    for (int b = threadIdx.x; b < nb; b += OWN_THREADS) hist[b] = 0u;
+    const int n_wg = (int)gridDim.x;
     if (threadIdx.x < NRC_MAX_LEVELS) lmax[threadIdx.x] = 0u;
-    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * OWN_THREADS + threadIdx.x;
+    const bool in_range = i < M;
     float px = 0.f, py = 0.f, pz = 0.f;
-    if (i < M) { px = x[3 * i]; py = x[3 * i + 1]; pz = x[3 * i + 2]; }
-    // visits the four (y, z) pairs of sample i on every bucketed level whose gradient is not zero
-    auto visit = [&](auto&& per_level, auto&& fn) {
-        if (i >= M) return;
-        for (int k = 0; k < bc.n_levels; k++) {
-            const int level = bc.level[k];
-            const float2 gf = reinterpret_cast<const float2*>(d_feat)[(int64_t)level * M + i];
-            if (gf.x == 0.f && gf.y == 0.f) continue;  // masked / terminated samples
-            per_level(k, gf);
-            const float scale = g.scale[level];
-            const uint32_t mask = g.size[level] - 1u;
-            const float fy = fmaf(scale, py, 0.5f), fz = fmaf(scale, pz, 0.5f);
-            const float fly = floorf(fy), flz = floorf(fz);
-            const uint32_t gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
-            const uint32_t ty[2] = {gy * 2654435761u, gy * 2654435761u + 2654435761u}, tz[2] = {gz * 805459861u, gz * 805459861u + 805459861u};
-            const int b0 = bc.bucket0[k];
+    if (in_range) { px = x[3 * i]; py = x[3 * i + 1]; pz = x[3 * i + 2]; }
+    // the four (y, z) pairs of sample i on bucketed level k: bucket and slice-local (y, z) hash
+    auto pairs_of = [&](int k, uint32_t (&bucket)[4], uint32_t (&yz)[4], float& wy1, float& wz1) {
+        const int level = bc.level[k];
+        const float scale = g.scale[level];
+        const uint32_t mask = g.size[level] - 1u;
+        const float fy = fmaf(scale, py, 0.5f), fz = fmaf(scale, pz, 0.5f);
+        const float fly = floorf(fy), flz = floorf(fz);
+        const uint32_t gy = (uint32_t)(int32_t)fly, gz = (uint32_t)(int32_t)flz;
+        const uint32_t ty[2] = {gy * 2654435761u, gy * 2654435761u + 2654435761u}, tz[2] = {gz * 805459861u, gz * 805459861u + 805459861u};
+        wy1 = fy - fly; wz1 = fz - flz;
 #pragma unroll
-            for (uint32_t pair = 0; pair < 4; pair++) {
-                const uint32_t yz = (ty[pair & 1] ^ tz[pair >> 1]) & mask;
-                fn(b0 + (int)(yz >> GB_SHIFT), pair, yz, scale, fy - fly, fz - flz, gf);
-            }
+        for (uint32_t pair = 0; pair < 4; pair++) {
+            yz[pair] = (ty[pair & 1] ^ tz[pair >> 1]) & mask;
+            bucket[pair] = (uint32_t)bc.bucket0[k] + (yz[pair] >> GB_SHIFT);
         }
     };
-    if constexpr (!WRITE) {
-        // largest |gradient| per level: wave maximum first (one LDS atomic per wave and level, not one per lane on the same address)
-        for (int k = 0; k < bc.n_levels; k++) {
-            float m = 0.f;
-            if (i < M) {
-                const float2 gf = reinterpret_cast<const float2*>(d_feat)[(int64_t)bc.level[k] * M + i];
-                m = fmaxf(fabsf(gf.x), fabsf(gf.y));
-                if (!(fabsf(gf.x) < __builtin_inff()) || !(fabsf(gf.y) < __builtin_inff())) m = __builtin_inff();  // inf / NaN (AMP overflow): poisons the level
-            }
+    uint4* mine = records + (int64_t)blockIdx.x * rec_per_wg;
+    uint32_t region = 0u;   // records of the groups before this one
+    for (int k0 = 0; k0 < bc.n_levels; k0 += GB_GROUP) {
+        const int b_lo = bc.bucket0[k0], b_hi = bc.bucket0[min(k0 + GB_GROUP, bc.n_levels)];
+        for (int b = b_lo + threadIdx.x; b < b_hi; b += OWN_THREADS) hist[b] = 0u;
+        __syncthreads();   // (also: the previous group's gbase has been read)
+        // all gradients of the group requested at once and kept for the second pass: level after level, every one of these loads was a full
+        // memory latency in front of the LDS atomics that depend on it
+        float2 gf_all[GB_GROUP];
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-            if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&lmax[k], __float_as_uint(m));
+        for (int kk = 0; kk < GB_GROUP; kk++) {
+            gf_all[kk] = make_float2(0.f, 0.f);
+            if (k0 + kk < bc.n_levels && in_range) gf_all[kk] = reinterpret_cast<const float2*>(d_feat)[(int64_t)bc.level[k0 + kk] * M + i];
         }
-        visit([&](int, const float2&) {}, [&](int b, uint32_t, uint32_t, float, float, float, const float2&) { atomicAdd(&hist[b], 1u); });
-        __syncthreads();
-        for (int b = threadIdx.x; b < nb; b += OWN_THREADS)
-            if (hist[b]) atomicAdd(&hd->counts[b], hist[b]);
-        if ((int)threadIdx.x < bc.n_levels && lmax[threadIdx.x]) atomicMax(&hd->level_max[threadIdx.x], lmax[threadIdx.x]);
-    } else {
-        visit([&](int, const float2&) {}, [&](int b, uint32_t, uint32_t, float, float, float, const float2&) { atomicAdd(&hist[b], 1u); });
-        __syncthreads();
-        for (int b = threadIdx.x; b < nb; b += OWN_THREADS) {
-            gbase[b] = hist[b] ? atomicAdd(&hd->cursor[b], hist[b]) : 0u;
-            hist[b] = 0u;
+        // pass 1: rank of every item inside its bucket (kept in registers: 4 x 16 bit per level), largest |gradient| per level
+        uint32_t rank01[GB_GROUP], rank23[GB_GROUP];
+        uint32_t live_mask = 0u;
+#pragma unroll
+        for (int kk = 0; kk < GB_GROUP; kk++) {
+            rank01[kk] = 0u; rank23[kk] = 0u;
+            const int k = k0 + kk;
+            if (k < bc.n_levels) {   // uniform
+                const float2 gf = gf_all[kk];
+                float m = fmaxf(fabsf(gf.x), fabsf(gf.y));
+                if (!(fabsf(gf.x) < __builtin_inff()) || !(fabsf(gf.y) < __builtin_inff())) m = __builtin_inff();  // inf / NaN (AMP overflow): poisons the level
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));   // wave maximum first: one LDS atomic per wave and level
+                if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&lmax[k], __float_as_uint(m));
+                if (in_range && !(gf.x == 0.f && gf.y == 0.f)) {  // masked / terminated samples have no items
+                    live_mask |= 1u << kk;
+                    uint32_t bucket[4], yz[4]; float wy1, wz1;
+                    pairs_of(k, bucket, yz, wy1, wz1);
+                    const uint32_t r0 = atomicAdd(&hist[bucket[0]], 1u), r1 = atomicAdd(&hist[bucket[1]], 1u);
+                    const uint32_t r2 = atomicAdd(&hist[bucket[2]], 1u), r3 = atomicAdd(&hist[bucket[3]], 1u);
+                    rank01[kk] = r0 | (r1 << 16); rank23[kk] = r2 | (r3 << 16);   // a bucket holds at most 4096 items of this workgroup
+                }
+            }
         }
         __syncthreads();
-        visit([&](int, const float2&) {},
-              [&](int b, uint32_t pair, uint32_t yz, float scale, float wy1, float wz1, const float2& gf) {
-                  const float fx = fmaf(scale, px, 0.5f), flx = floorf(fx);
-                  const uint32_t gx = (uint32_t)(int32_t)flx;
-                  const float wyz = ((pair & 1u) ? wy1 : 1.f - wy1) * ((pair >> 1) ? wz1 : 1.f - wz1);
-                  const uint32_t e0 = (gx ^ yz) & (GB_ENTRIES - 1u), e1 = ((gx + 1u) ^ yz) & (GB_ENTRIES - 1u);
-                  records[gbase[b] + atomicAdd(&hist[b], 1u)] =
-                      make_uint4(e0 | (e1 << 16), __float_as_uint(wyz * gf.x), __float_as_uint(wyz * gf.y), __float_as_uint(fx - flx));
-              });
+        // exclusive scan of the group's bucket counts (two per thread): where each bucket's run starts inside this workgroup's region
+        {
+            const int t = threadIdx.x, b = b_lo + 2 * t;
+            const uint32_t c0 = b < b_hi ? hist[b] : 0u, c1 = b + 1 < b_hi ? hist[b + 1] : 0u;
+            const uint32_t cnt = c0 + c1;
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if ((t & 63) >= d) incl += o;
+            }
+            if ((t & 63) == 63) wave_tot[t >> 6] = incl;
+            __syncthreads();
+            uint32_t before = region, all = 0u;
+#pragma unroll
+            for (int w = 0; w < OWN_THREADS / 64; w++) { before += w < (t >> 6) ? wave_tot[w] : 0u; all += wave_tot[w]; }
+            const uint32_t start = before + incl - cnt;
+            if (b < b_hi) {
+                gbase[b] = start;
+                seg[(int64_t)b * n_wg + blockIdx.x] = start | (c0 << 16);   // start < 1024 * 4 * 16 = 65536, count <= 4096
+            }
+            if (b + 1 < b_hi) {
+                gbase[b + 1] = start + c0;
+                seg[(int64_t)(b + 1) * n_wg + blockIdx.x] = (start + c0) | (c1 << 16);
+            }
+            region += all;
+        }
+        __syncthreads();
+        // pass 2: the records, level by level through an LDS image of the level's part of the region (its buckets are contiguous there), then
+        // out in whole lines.  Written straight from the lanes, every store instruction touched 64 different lines (16 bytes each): 700 such
+        // instructions per workgroup were most of this kernel's time.  Two images: one barrier per level.
+#pragma unroll
+        for (int kk = 0; kk < GB_GROUP; kk++) {
+            const int k = k0 + kk;
+            if (k < bc.n_levels) {   // uniform
+                uint4* img = stage + (kk & 1) * (OWN_THREADS * 4);
+                const uint32_t lvl_lo = gbase[bc.bucket0[k]];
+                if (live_mask >> kk & 1u) {
+                    const int level = bc.level[k];
+                    const float2 gf = gf_all[kk];
+                    uint32_t bucket[4], yz[4]; float wy1, wz1;
+                    pairs_of(k, bucket, yz, wy1, wz1);
+                    const float fx = fmaf(g.scale[level], px, 0.5f), flx = floorf(fx);
+                    const uint32_t gx = (uint32_t)(int32_t)flx;
+                    const uint32_t wxb = __float_as_uint(fx - flx);
+#pragma unroll
+                    for (uint32_t pair = 0; pair < 4; pair++) {
+                        const uint32_t rank = (pair < 2 ? rank01[kk] : rank23[kk]) >> (16 * (pair & 1u)) & 0xffffu;
+                        const float wyz = ((pair & 1u) ? wy1 : 1.f - wy1) * ((pair >> 1) ? wz1 : 1.f - wz1);
+                        const uint32_t e0 = (gx ^ yz[pair]) & (GB_ENTRIES - 1u), e1 = ((gx + 1u) ^ yz[pair]) & (GB_ENTRIES - 1u);
+                        img[gbase[bucket[pair]] - lvl_lo + rank] = make_uint4(e0 | (e1 << 16), __float_as_uint(wyz * gf.x), __float_as_uint(wyz * gf.y), wxb);
+                    }
+                }
+                __syncthreads();
+                const uint32_t last = (uint32_t)bc.bucket0[k + 1] - 1u;
+                const uint32_t lvl_n = gbase[last] + hist[last] - lvl_lo;   // records of this workgroup on the level (<= 4096)
+                for (uint32_t j = threadIdx.x; j < lvl_n; j += OWN_THREADS) mine[lvl_lo + j] = img[j];
+            }
+        }
     }
-}
-
-// counts -> base (exclusive), cursor = base; per level the power-of-two fixed-point scale
-__global__ void __launch_bounds__(GB_MAX_BUCKETS) k_gb_scan(GbHeader* __restrict__ hd, int nb, int n_levels, int64_t M) {
-    __shared__ uint32_t s[GB_MAX_BUCKETS];
-    const uint32_t v = (int)threadIdx.x < nb ? hd->counts[threadIdx.x] : 0u;
-    s[threadIdx.x] = v;
     __syncthreads();
-    for (int d = 1; d < GB_MAX_BUCKETS; d <<= 1) {
-        const uint32_t o = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0u;
-        __syncthreads();
-        s[threadIdx.x] += o;
-        __syncthreads();
-    }
-    if ((int)threadIdx.x < nb) { hd->base[threadIdx.x] = s[threadIdx.x] - v; hd->cursor[threadIdx.x] = s[threadIdx.x] - v; }
-    if ((int)threadIdx.x < n_levels) {
-        const float m = __uint_as_float(hd->level_max[threadIdx.x]);
-        int e_max = 0, e_cnt = 0;
-        frexpf(m > 0.f && m < __builtin_inff() ? m : 1.f, &e_max);  // m < 2^e_max
-        frexpf((float)(2 * M + 1), &e_cnt);                         // 2 M + 1 <= 2^e_cnt (an entry receives at most 2 M values of <= m)
-        // a non-finite gradient on the level (GradScaler overflow): NaN scale -> the accumulation pass marks the level's gradient NaN, the way
-        // f32 atomics would have propagated it, so that the scaler's found-inf check still sees it
-        hd->level_scale[threadIdx.x] = m < __builtin_inff() ? ldexpf(1.f, 62 - e_max - e_cnt) : __builtin_nanf("");
-    }
+    if (threadIdx.x < NRC_MAX_LEVELS) wg_max[(int64_t)blockIdx.x * NRC_MAX_LEVELS + threadIdx.x] = lmax[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(OWN_THREADS) k_gb_accumulate(GridCfg g, BucketCfg bc, const GbHeader* __restrict__ hd, const uint4* __restrict__ records,
+__global__ void __launch_bounds__(GBA_THREADS) k_gb_accumulate(GridCfg g, BucketCfg bc, int64_t M, int n_wg, const uint32_t* __restrict__ seg,
+                                                               const uint32_t* __restrict__ wg_max, const uint4* __restrict__ records, int64_t rec_per_wg,
                                                                float* __restrict__ grad_table) {
     extern __shared__ long long fix_acc[];  // [GB_ENTRIES][2]
+    __shared__ uint32_t s_max;
+    NRC_PROBE_NW(0);
     int li = 0;
     while (li + 1 < bc.n_levels && (int)blockIdx.x >= bc.bucket0[li + 1]) li++;
     const int level = bc.level[li];
     const uint32_t chunk = (uint32_t)((int)blockIdx.x - bc.bucket0[li]);
     const uint32_t lo = g.offset[level] + chunk * GB_ENTRIES;
-    for (uint32_t j = threadIdx.x; j < 2 * GB_ENTRIES; j += OWN_THREADS) fix_acc[j] = 0ll;
+    float scale = 0.f;   // set below, before the first record is added
+    const uint32_t* row = seg + (int64_t)blockIdx.x * n_wg;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    enum { UNR = 8, WAVES = GBA_THREADS / 64, PASSES = 8 };
+    // Wave wv takes the runs of workgroups w = UNR (wv + WAVES m) + u, batch m = 0, 1, ...; the table entries of 64 of its runs come in
+    // with ONE vector load (lane 8 j + u).  The UNR runs of a batch are ONE flat item range (a run is ~64 records, not exactly: run by
+    // run, the items past the 64th cost a second, nearly empty round of LDS atomics each): item p belongs to run u = #{t : p >= pre[t]}.
+    // The records of batch m + 1 are requested before the atomics of batch m are issued (loads and LDS atomics of a wave overlap).
+    struct Batch { uint32_t start[UNR], pre[UNR + 1]; int w0; uint4 r[PASSES]; };
+    // float -> 64-bit fixed point, round to nearest even, |v| < 2^62: six VALU instructions instead of the ~25 of the generic f32 -> i64
+    // conversion (there is no such instruction; four conversions per record made this kernel VALU-bound).  rndne is exact, hi = floor(v / 2^32)
+    // fits an i32, v - hi 2^32 is an exact integer in [0, 2^32).
+    auto to_fixed = [](float v) -> unsigned long long {
+        const float vr = __builtin_rintf(v);
+        const float hf = __builtin_floorf(vr * 2.3283064365386963e-10f);
+        const int hi = (int)hf;
+        const uint32_t lo = (uint32_t)__builtin_fmaf(-hf, 4294967296.f, vr);
+        return ((unsigned long long)(uint32_t)hi << 32) | lo;
+    };
+    auto add_record = [&](const uint4& rr) {
+        const uint32_t e0 = rr.x & 0xffffu, e1 = rr.x >> 16;
+        const float a = __uint_as_float(rr.y), b = __uint_as_float(rr.z), wx1 = __uint_as_float(rr.w), wx0 = 1.f - wx1;
+#if defined(NRC_GBA_ABL_NOATOMIC)   // ablation builds (tools/build_variant.sh)
+        if (a == 1.2345e-30f) fix_acc[2 * e0] = (long long)(wx0 * b * scale) + e1;
+        return;
+#endif
+        // power-of-two scale: the product is exact, the only rounding is to the fixed-point grid
+        atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e0]), to_fixed(wx0 * a * scale));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e0 + 1]), to_fixed(wx0 * b * scale));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e1]), to_fixed(wx1 * a * scale));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e1 + 1]), to_fixed(wx1 * b * scale));
+    };
+    auto item = [&](const Batch& B, uint32_t pp) -> uint4 {   // record of flat item pp (< B.pre[UNR]) of the batch
+        uint32_t u = 0u;
+#pragma unroll
+        for (int t = 1; t < UNR; t++) u += pp >= B.pre[t] ? 1u : 0u;
+        uint32_t base = B.start[0], first = 0u;
+#pragma unroll
+        for (int t = 1; t < UNR; t++) { base = u == (uint32_t)t ? B.start[t] : base; first = u == (uint32_t)t ? B.pre[t] : first; }
+#if defined(NRC_GBA_ABL_NOLOAD)
+        return make_uint4((pp * 2654435761u) & 0x1fff1fffu, 0x3f000000u, 0x3f000000u, 0x3f000000u);
+#else
+        return records[(int64_t)(B.w0 + (int)u) * rec_per_wg + base + (pp - first)];
+#endif
+    };
+    const int n_batches = (n_wg + UNR * WAVES - 1) / (UNR * WAVES);   // per wave (the last ones may be empty for the higher waves)
+    uint32_t my_desc = 0u;
+    auto open_batch = [&](int m, Batch& B) {   // m uniform
+        if ((m & (64 / UNR - 1)) == 0) {       // a new block of 64 table entries
+            const int my_w = UNR * (wv + WAVES * (m + lane / UNR)) + (lane % UNR);
+            my_desc = my_w < n_wg ? row[my_w] : 0u;
+        }
+        B.w0 = UNR * (wv + WAVES * m);
+        B.pre[0] = 0u;
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)my_desc, (m & (64 / UNR - 1)) * UNR + u, 64));
+            B.start[u] = d & 0xffffu; B.pre[u + 1] = B.pre[u] + (d >> 16);
+        }
+#pragma unroll
+        for (int q = 0; q < PASSES; q++) {
+            const uint32_t pp = 64 * q + lane;
+            B.r[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (pp < B.pre[UNR]) B.r[q] = item(B, pp);
+        }
+    };
+    // requested first, used last: the level maxima of all split workgroups (one 64-byte line each), the table entries, the first records
+    uint32_t m_local = 0u;
+    for (int w = threadIdx.x; w < n_wg; w += GBA_THREADS) m_local = max(m_local, wg_max[(int64_t)w * NRC_MAX_LEVELS + li]);
+    Batch cur, nxt;
+    if (n_batches > 0) open_batch(0, cur);
+    NRC_PROBE_NW(1);
+    // (the first batch's records are on their way while the slice is cleared and the scale is worked out)
+    for (uint32_t j = threadIdx.x; j < 2 * GB_ENTRIES; j += GBA_THREADS) fix_acc[j] = 0ll;
+    if (threadIdx.x == 0) s_max = 0u;
     __syncthreads();
-    const uint32_t n = hd->counts[blockIdx.x];
-    const uint4* rec = records + hd->base[blockIdx.x];
-    const float scale = hd->level_scale[li];
-    if (!(scale == scale)) {  // poisoned level (see k_gb_scan)
-        if (threadIdx.x == 0) reinterpret_cast<float2*>(grad_table)[lo] = make_float2(scale, scale);
+    NRC_PROBE_NW(2);
+    // the level's largest |gradient| over all workgroups of the split (non-negative floats order like their bit patterns) -> the power-of-two
+    // fixed-point scale; every bucket of a level derives the same one
+    {
+        uint32_t m = m_local;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(&s_max, m);
+    }
+    __syncthreads();
+    NRC_PROBE_NW(3);
+    const float mx = __uint_as_float(s_max);
+    if (!(mx < __builtin_inff())) {
+        // a non-finite gradient on the level (GradScaler overflow): the fixed-point path cannot carry it; mark the slice NaN, the way f32
+        // atomics would have propagated it, so that the scaler's found-inf check still sees it
+        if (threadIdx.x == 0) reinterpret_cast<float2*>(grad_table)[lo] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
         return;
     }
-    enum { UNR = 4 };
-    for (uint32_t k0 = threadIdx.x; k0 < n; k0 += OWN_THREADS * UNR) {
-        uint4 r[UNR];
+    int e_max = 0, e_cnt = 0;
+    frexpf(mx > 0.f ? mx : 1.f, &e_max);      // mx < 2^e_max
+    frexpf((float)(2 * M + 1), &e_cnt);        // 2 M + 1 <= 2^e_cnt (an entry receives at most 2 M values of <= mx)
+    scale = ldexpf(1.f, 62 - e_max - e_cnt);
+    for (int m = 0; m < n_batches; m++) {
+        if (m + 1 < n_batches) open_batch(m + 1, nxt);
+        NRC_PROBE_NW(10 + 2 * m);
+        const uint32_t total = cur.pre[UNR];
 #pragma unroll
-        for (int u = 0; u < UNR; u++) {
-            const uint32_t k = k0 + u * OWN_THREADS;
-            r[u] = rec[k < n ? k : n - 1];
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; u++) {
-            if (k0 + u * OWN_THREADS >= n) continue;
-            const uint32_t e0 = r[u].x & 0xffffu, e1 = r[u].x >> 16;
-            const float a = __uint_as_float(r[u].y), b = __uint_as_float(r[u].z), wx1 = __uint_as_float(r[u].w), wx0 = 1.f - wx1;
-            // power-of-two scale: the product is exact, the only rounding is to the fixed-point grid
-            atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e0]), (unsigned long long)__float2ll_rn(wx0 * a * scale));
-            atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e0 + 1]), (unsigned long long)__float2ll_rn(wx0 * b * scale));
-            atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e1]), (unsigned long long)__float2ll_rn(wx1 * a * scale));
-            atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e1 + 1]), (unsigned long long)__float2ll_rn(wx1 * b * scale));
-        }
+        for (int q = 0; q < PASSES; q++)
+            if (64 * q + lane < total) add_record(cur.r[q]);
+        for (uint32_t pp = 64 * PASSES + lane; pp < total; pp += 64) add_record(item(cur, pp));   // a batch of more than 512 items (rare)
+        NRC_PROBE_NW(11 + 2 * m);
+        cur = nxt;
     }
     __syncthreads();
+    NRC_PROBE_NW(40);
     const double inv = 1.0 / (double)scale;
     float2* out = reinterpret_cast<float2*>(grad_table) + lo;
-    for (uint32_t j = threadIdx.x; j < GB_ENTRIES; j += OWN_THREADS) {
+    // read-modify-write of the slice: all of a thread's table reads first (entry by entry, each one was a full memory latency in front of its store)
+    enum { PER_THREAD = GB_ENTRIES / GBA_THREADS };
+    float2 old_v[PER_THREAD];
+#pragma unroll
+    for (int t = 0; t < PER_THREAD; t++) old_v[t] = out[threadIdx.x + t * GBA_THREADS];
+#pragma unroll
+    for (int t = 0; t < PER_THREAD; t++) {
+        const uint32_t j = threadIdx.x + t * GBA_THREADS;
         const long long a0 = fix_acc[2 * j], a1 = fix_acc[2 * j + 1];
         if (a0 != 0ll || a1 != 0ll) {
-            float2 v = out[j];
+            float2 v = old_v[t];
             v.x += (float)((double)a0 * inv); v.y += (float)((double)a1 * inv);
             out[j] = v;
         }
     }
+    NRC_PROBE_NW(41);
 }
 
 // which levels take the bucketed path: hashed, whole 8 K slices, x corners below the slice bits; the finest first, <= GB_MAX_BUCKETS
@@ -1867,13 +2041,17 @@ int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int3
     return NRC_OK;
 }
 
+#if defined(NRC_BWD_PROBE)
+extern "C" int nrc_debug_bwd_probe(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_probe), sizeof(g_bwd_probe)); }
+#endif
+
 int64_t nrc_grid_backward_ws_bytes(int64_t M, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale) {
     if (M < 0) return NRC_ERR_INVALID;
     GridCfg g;
     if (make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr) != NRC_OK) return NRC_ERR_INVALID;
     BucketCfg bc; bool isb[NRC_MAX_LEVELS];
     pick_bucket_levels(g, n_levels, bc, isb);
-    return GB_HEADER_BYTES + M * 64 * bc.n_levels + 256;  // four 16-byte records per sample and bucketed level
+    return gb_layout(M, bc.n_levels, bc.bucket0[bc.n_levels]).total;
 }
 
 int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
@@ -1891,7 +2069,7 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
     static const bool allow_owned = [] { const char* e = getenv("NRC_GRID_BWD_OWNED"); return !(e && e[0] == '0'); }();
     const bool owned = allow_owned && d_features_pair_major && M >= 16384;
     hipStream_t s = (hipStream_t)stream;
-    // bucketed ownership (needs the workspace): all hashed levels in four launches, the dense ones through the run-aggregated atomics
+    // bucketed ownership (needs the workspace): all hashed levels in two launches, the dense ones through the run-aggregated atomics
     static const bool allow_buckets = [] { const char* e = getenv("NRC_GRID_BWD_BUCKETS"); return !(e && e[0] == '0'); }();
     if (owned && allow_buckets && workspace && M < (int64_t(1) << 30)) {
         BucketCfg bc; bool isb[NRC_MAX_LEVELS];
@@ -1904,21 +2082,20 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
                 hipLaunchKernelGGL(k_grid_bwd, dim3((unsigned)nrc_cdiv(M, 256), rest.n), dim3(256), 0, s, x01, M, d_features, (int)d_features_pair_major, g,
                                    (int)n_levels, rest, grad_table);
             NRC_STAGE(s, "k_grid_bwd");
-            GbHeader* hd = reinterpret_cast<GbHeader*>(workspace);
-            uint4* records = reinterpret_cast<uint4*>(reinterpret_cast<char*>(workspace) + GB_HEADER_BYTES);
             const int nb = bc.bucket0[bc.n_levels];
-            if (nrc_zero_async(hd, sizeof(GbHeader), s) != hipSuccess) return NRC_ERR_LAUNCH;
-            const dim3 sgrid((unsigned)nrc_cdiv(M, OWN_THREADS));
-            hipLaunchKernelGGL(k_gb_split<false>, sgrid, dim3(OWN_THREADS), 0, s, x01, M, d_features, g, bc, hd, records);
-            NRC_STAGE(s, "k_gb_split<count>");
-            hipLaunchKernelGGL(k_gb_scan, dim3(1), dim3(GB_MAX_BUCKETS), 0, s, hd, nb, bc.n_levels, M);
-            NRC_STAGE(s, "k_gb_scan");
-            hipLaunchKernelGGL(k_gb_split<true>, sgrid, dim3(OWN_THREADS), 0, s, x01, M, d_features, g, bc, hd, records);
-            NRC_STAGE(s, "k_gb_split<write>");
+            const GbLayout L = gb_layout(M, bc.n_levels, nb);
+            if (L.n_wg > 0x7fffffff / nb) return NRC_ERR_INVALID;
+            uint32_t* seg = reinterpret_cast<uint32_t*>(workspace);
+            uint32_t* wg_max = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + L.seg_bytes);
+            uint4* records = reinterpret_cast<uint4*>(reinterpret_cast<char*>(workspace) + L.seg_bytes + L.max_bytes);
+            static const hipError_t attr_s = hipFuncSetAttribute((const void*)k_gb_split, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * OWN_THREADS * 4 * 16);
+            (void)attr_s;
+            hipLaunchKernelGGL(k_gb_split, dim3((unsigned)L.n_wg), dim3(OWN_THREADS), 2 * OWN_THREADS * 4 * 16, s, x01, M, d_features, g, bc, seg, wg_max, records, L.rec_per_wg);
+            NRC_STAGE(s, "k_gb_split");
             static const hipError_t attr_b = hipFuncSetAttribute((const void*)k_gb_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, GB_ENTRIES * 16);
             (void)attr_b;
-            hipLaunchKernelGGL(k_gb_accumulate, dim3((unsigned)nb), dim3(OWN_THREADS), GB_ENTRIES * 16, s, g, bc, (const GbHeader*)hd, (const uint4*)records,
-                               grad_table);
+            hipLaunchKernelGGL(k_gb_accumulate, dim3((unsigned)nb), dim3(GBA_THREADS), GB_ENTRIES * 16, s, g, bc, M, (int)L.n_wg, (const uint32_t*)seg,
+                               (const uint32_t*)wg_max, (const uint4*)records, L.rec_per_wg, grad_table);
             NRC_STAGE(s, "k_gb_accumulate");
             NRC_LAUNCH_CHECK();
             return NRC_OK;
@@ -2046,7 +2223,7 @@ int nrc_ngp_train_query_backward(const float* dL_dsigmas, const float* dL_drgbs,
 
 int64_t nrc_ngp_train_query_scratch_bytes(int64_t M) {
     if (M < 0) return NRC_ERR_INVALID;
-    return (M * 8 + 255) / 256 * 256 + (M * 4 + 255) / 256 * 256 + M * 128 + M * 32 + M * 128 + 256 + (16384 + M * 64 * NRC_MAX_LEVELS + 256);
+    return (M * 8 + 255) / 256 * 256 + (M * 4 + 255) / 256 * 256 + M * 128 + M * 32 + M * 128 + 256 + gb_layout(M, NRC_MAX_LEVELS, GB_MAX_BUCKETS).total;
 }
 
 }  // extern "C"
