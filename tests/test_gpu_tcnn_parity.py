@@ -235,6 +235,37 @@ def test_grid_backward_bucketed_path_matches_atomics_and_is_reproducible(log2_t)
         assert bool(torch.isfinite(g[:offsets[15]]).all())  # the other levels are untouched by it
 
 
+def test_grid_backward_on_samples_ordered_along_rays():
+    """Consecutive samples of a ray share cells on the coarse levels: the dense-level kernel adds whole RUNS of equal cells (segmented scan,
+    one cooperative flush per run), which random positions never exercise -- a run that starts at the last lane of a wave, dead samples inside
+    a run, several short rays per wave.  Both paths (with / without the workspace) against oracle.grid_encode_bw, per level."""
+    from nerficg_amd import _lib
+    lib = _lib.load()
+    grid = dict(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=PLS)
+    total, offsets, _, _ = oracle.grid_layout(**grid)
+    rng = np.random.default_rng(0)
+    n_rays = 400
+    lengths = rng.integers(37, 131, size=n_rays)          # ray boundaries at every lane position
+    o = rng.random((n_rays, 3)) * 0.3 + 0.1
+    d = np.abs(rng.normal(size=(n_rays, 3))); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = np.concatenate([o[r] + d[r] * (np.arange(lengths[r])[:, None] * (1.7 / 1024)) for r in range(n_rays)])
+    x = np.clip(x, 0.0, 1.0).astype(np.float32)
+    m = x.shape[0]
+    g = rng.normal(size=(16, m, 2)).astype(np.float32)
+    g[:, rng.random(m) < 0.2] = 0.0                        # terminated samples inside runs
+    tx, tg = T(x), T(g)
+    ws = torch.empty(int(lib.nrc_grid_backward_ws_bytes(m, 16, 19, 16, PLS)), dtype=torch.uint8, device=DEV)
+    want = oracle.grid_encode_bw(x, np.ascontiguousarray(g.transpose(1, 0, 2).reshape(m, 32)), total, **grid)
+    for workspace in (ws, None):
+        out = torch.zeros(total, 2, device=DEV)
+        _lib.check(lib.nrc_grid_backward(_lib.ptr(tx), m, _lib.ptr(tg), 1, 16, 19, 16, PLS, _lib.ptr(out), _lib.ptr(workspace), _lib.stream_of(out)), 'grid_backward')
+        got = out.cpu().numpy()
+        for l in range(16):
+            sl = slice(offsets[l], offsets[l + 1])
+            scale = np.abs(want[sl]).max()
+            assert np.abs(got[sl] - want[sl]).max() <= 2e-5 * scale, (workspace is None, l, float(np.abs(got[sl] - want[sl]).max() / scale))
+
+
 def test_unsupported_configs_raise(tcnn):
     with pytest.raises(RuntimeError):
         tcnn.NetworkWithInputEncoding(3, 16, {**ENC_GRID, 'n_levels': 8}, NET_D)
