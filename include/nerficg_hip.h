@@ -94,6 +94,24 @@ int nrc_ngp_train_pixels_bw(int64_t n_rays, const float* g_rgb, const float* g_a
  * (custom_functions.py:112-119). */
 int nrc_raymarching_train_cap(int64_t n_rays, int64_t sample_capacity, const int32_t* counter, int64_t* rays_a, float* xyzs,
                               float* dirs, float* deltas, float* ts, nrc_stream_t stream);
+/* Same, and *overflow (device int64, may be NULL) = max(counter[0] - sample_capacity, 0): the number of dropped samples without two more
+ * element-wise launches in a recorded iteration. */
+int nrc_raymarching_train_cap_overflow(int64_t n_rays, int64_t sample_capacity, const int32_t* counter, int64_t* rays_a, float* xyzs,
+                                       float* dirs, float* deltas, float* ts, int64_t* overflow, nrc_stream_t stream);
+/* The batch of a training iteration out of the resident ray pool (RayPoolSampler.get, src/Optim/Samplers/DatasetSamplers.py:53-66:
+ * ray_pool[indices], one fancy-index gather per field) as ONE launch: rows ids[i] of up to four pools of the same length -- three of
+ * row width 3 (origin, view direction, rgb; any may be NULL) and one of width 1 (alpha; may be NULL) -- into dense outputs.
+ * ids: int64, 0 <= ids[i] < n_pool (checked on the device: an id out of range writes zeros). */
+int nrc_gather_ray_batch(const int64_t* ids, int64_t n, int64_t n_pool, const float* pool_a3, const float* pool_b3, const float* pool_c3,
+                         const float* pool_d1, float* out_a3, float* out_b3, float* out_c3, float* out_d1, nrc_stream_t stream);
+/* The colour term of the InstantNGP loss with the GradScaler's multiplication folded in (Trainer.py:87-89: mse_loss(rgb, target),
+ * scaler.scale(loss)): out2[0] = mean((pred - target)^2) over n values, out2[1] = out2[0] * *scale (scale: DEVICE float, NULL = 1).
+ * One workgroup, fixed summation order (the result does not depend on the run).  _backward: grad_pred = 2 / n * (pred - target) *
+ * (g_loss + g_scaled * scale); g_loss / g_scaled: DEVICE floats, either may be NULL (no gradient reached that output).  Replaces
+ * seven element-wise / reduction launches of the op-by-op expression in a recorded iteration.  n <= 2^24. */
+int nrc_mse_scaled_forward(int64_t n, const float* pred, const float* target, const float* scale, float* out2, nrc_stream_t stream);
+int nrc_mse_scaled_backward(int64_t n, const float* pred, const float* target, const float* scale, const float* g_loss,
+                            const float* g_scaled, float* grad_pred, nrc_stream_t stream);
 /* binding.cpp:84-106 -> raymarching.cu:407-454.  hits_t (n_total_rays,2) is advanced in place.  Outputs
  * (n_alive,N_samples[,3]) are fully written (zero beyond N_eff_samples), N_eff_samples (n_alive) i32. */
 int nrc_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t, const int64_t* alive_indices,
@@ -201,6 +219,16 @@ int nrc_ngp_train_query_backward(const float* dL_dsigmas, const float* dL_drgbs,
                                  const void* rgb_f16, const void* save_in_d, const void* save_acts_d, const void* save_in_c,
                                  const void* save_acts_c, float loss_scale, float* grad_density_params, float* grad_color_params,
                                  int64_t n_density_mlp_params, void* scratch, nrc_stream_t stream);
+/* Same with UNINITIALISED gradient buffers of n_density_params / n_color_params values: the call SETS them (no accumulation).  What it
+ * saves: the caller's 49 MB fill of the table gradient, and the read half of the read-modify-write of the hashed levels' slices -- their
+ * owners write every entry, only the small levels and the MLP parts are zeroed first (one launch). */
+int nrc_ngp_train_query_backward_set(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01,
+                                     const void* density_weights_f16, const void* color_weights_f16, int32_t n_levels,
+                                     int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, const void* h_f16,
+                                     const void* rgb_f16, const void* save_in_d, const void* save_acts_d, const void* save_in_c,
+                                     const void* save_acts_c, float loss_scale, float* grad_density_params, float* grad_color_params,
+                                     int64_t n_density_mlp_params, int64_t n_density_params, int64_t n_color_params, void* scratch,
+                                     nrc_stream_t stream);
 /* InstantNGPRayRenderingComponent.query_model (Renderer.py:48-53) as an encode + MLP kernel pair over Infinity-Cache sized
  * chunks (workspace: nrc_ngp_query_ws_bytes(M) bytes): xyz01 (M,3) f32 in [0,1], dirs (M,3) f32 unit
  * vectors -> sigmas (M) f32 = exp(fp16 feature 0), rgbs (M,3) f32 = fp16 sigmoid outputs. */

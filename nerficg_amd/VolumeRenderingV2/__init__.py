@@ -94,10 +94,11 @@ def packbits(density_grid, density_threshold: float, density_bitfield) -> None:
 
 
 def raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades: int, scale: float, exp_step_factor: float, noise,
-                      grid_size: int, max_samples: int, sample_capacity: int | None = None):
+                      grid_size: int, max_samples: int, sample_capacity: int | None = None, return_overflow: bool = False):
     """binding.cpp:60-81. Returns [rays_a (N,3) i64, xyzs (M,3), dirs (M,3), deltas (M), ts (M), counter (2) i32], M = counter[0].
     With `sample_capacity` (not in the reference; for graph capture) M = sample_capacity and nothing is read back: rows past counter[0] are
-    inert samples no ray refers to, and counter[0] > sample_capacity tells that rays were cut short (nrc_raymarching_train_cap)."""
+    inert samples no ray refers to, and counter[0] > sample_capacity tells that rays were cut short (nrc_raymarching_train_cap); with
+    `return_overflow` a seventh entry, the device int64 max(counter[0] - sample_capacity, 0), is appended to the list."""
     _chk((rays_o, 'rays_o', _f32), (rays_d, 'rays_d', _f32), (hits_t, 'hits_t', _f32),
          (density_bitfield, 'density_bitfield', _u8), (noise, 'noise', _f32))
     lib = _lib.load()
@@ -121,12 +122,14 @@ def raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades: int, s
     dirs = torch.empty(total, 3, dtype=_f32, device=dev)
     deltas = torch.empty(total, dtype=_f32, device=dev)
     ts = torch.empty(total, dtype=_f32, device=dev)
+    overflow = None
     if sample_capacity is not None:
-        _lib.check(lib.nrc_raymarching_train_cap(n, total, _lib.ptr(counter), _lib.ptr(rays_a), _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas),
-                                                 _lib.ptr(ts), st), 'raymarching_train(cap)')
+        overflow = torch.empty((), dtype=_i64, device=dev)
+        _lib.check(lib.nrc_raymarching_train_cap_overflow(n, total, _lib.ptr(counter), _lib.ptr(rays_a), _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas),
+                                                          _lib.ptr(ts), _lib.ptr(overflow), st), 'raymarching_train(cap)')
     _lib.check(lib.nrc_raymarching_train_write(*args, _lib.ptr(rays_a), _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas),
                                                _lib.ptr(ts), _lib.ptr(ws) if _PARKED_MARCH else None, st), 'raymarching_train(write)')
-    return [rays_a, xyzs, dirs, deltas, ts, counter]
+    return [rays_a, xyzs, dirs, deltas, ts, counter] + ([overflow] if overflow is not None and return_overflow else [])
 
 
 def raymarching_test(rays_o, rays_d, hits_t, alive_indices, density_bitfield, cascades: int, scale: float,

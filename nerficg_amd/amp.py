@@ -17,6 +17,15 @@ __all__ = ['GradScaler']
 
 
 class GradScaler(torch.amp.GradScaler):
+    def scale_tensor(self, device) -> torch.Tensor:
+        """The scale as the device scalar `scale()` multiplies by (created on first use, as `scale()` does): for callers that fold the
+        multiplication into their own loss kernel (nerficg_amd.ngp.scaled_mse_loss) instead of calling scale(loss)."""
+        if not self._enabled:
+            raise RuntimeError('scale_tensor: the scaler is disabled')
+        if self._scale is None:
+            self._lazy_init_scale_growth_tracker(torch.device(device))
+        return self._scale
+
     def _check_inf_per_device(self, optimizer):
         grads = [p.grad for group in optimizer.param_groups for p in group['params'] if p.grad is not None]
         fast = bool(grads) and all(g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and not g.is_sparse and g.device == grads[0].device

@@ -441,6 +441,34 @@ __global__ void __launch_bounds__(256) k_train_pixels_bw(int64_t n, const float*
     dL_ddepth[i] = gD;
 }
 
+// colour loss of a training batch with the GradScaler's multiplication folded in (see the header): ONE workgroup, fixed order
+__global__ void __launch_bounds__(1024) k_mse_scaled_fw(int64_t n, const float* __restrict__ pred, const float* __restrict__ target,
+                                                        const float* __restrict__ scale, float* __restrict__ out2) {
+    __shared__ float part[16];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) { const float d = pred[i] - target[i]; acc += d * d; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; w++) tot += part[w];
+        const float mean = tot / (float)n;
+        out2[0] = mean;
+        out2[1] = mean * (scale ? scale[0] : 1.f);
+    }
+}
+__global__ void __launch_bounds__(256) k_mse_scaled_bw(int64_t n, const float* __restrict__ pred, const float* __restrict__ target,
+                                                       const float* __restrict__ scale, const float* __restrict__ g_loss,
+                                                       const float* __restrict__ g_scaled, float* __restrict__ grad_pred) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float up = (g_loss ? g_loss[0] : 0.f) + (g_scaled ? g_scaled[0] * (scale ? scale[0] : 1.f) : 0.f);
+    grad_pred[i] = 2.f / (float)n * (pred[i] - target[i]) * up;
+}
+
 static void zero_arrays(hipStream_t s, void* p0, int64_t b0, void* p1 = nullptr, int64_t b1 = 0, void* p2 = nullptr, int64_t b2 = 0, void* p3 = nullptr,
                         int64_t b3 = 0, void* p4 = nullptr, int64_t b4 = 0) {
     ZeroList z;
@@ -537,6 +565,23 @@ int nrc_ngp_train_pixels_bw(int64_t n_rays, const float* g_rgb, const float* g_a
     if (!opacity || !depth || !bg_dev || !dL_dopacity || !dL_ddepth) return NRC_ERR_INVALID;
     hipLaunchKernelGGL(k_train_pixels_bw, dim3(nrc_cdiv(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, n_rays, g_rgb, g_alpha, g_depth, opacity, depth,
                        bg_dev, dL_dopacity, dL_ddepth);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_mse_scaled_forward(int64_t n, const float* pred, const float* target, const float* scale, float* out2, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n <= 0 || n > (int64_t(1) << 24) || !pred || !target || !out2) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_mse_scaled_fw, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, pred, target, scale, out2);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_mse_scaled_backward(int64_t n, const float* pred, const float* target, const float* scale, const float* g_loss, const float* g_scaled,
+                            float* grad_pred, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n <= 0 || n > (int64_t(1) << 24) || !pred || !target || !grad_pred) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_mse_scaled_bw, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, pred, target, scale, g_loss, g_scaled,
+                       grad_pred);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

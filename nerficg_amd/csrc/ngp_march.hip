@@ -451,10 +451,29 @@ __global__ void __launch_bounds__(256) k_march_expand(const float* __restrict__ 
     }
 }
 
+// the batch of a training iteration out of the resident ray pool: one launch for all fields (see the header)
+__global__ void __launch_bounds__(256) k_gather_ray_batch(const int64_t* __restrict__ ids, int64_t n, int64_t n_pool, const float* __restrict__ a,
+                                                          const float* __restrict__ b, const float* __restrict__ c, const float* __restrict__ d,
+                                                          float* __restrict__ oa, float* __restrict__ ob, float* __restrict__ oc, float* __restrict__ od) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = ids[i];
+    const bool ok = r >= 0 && r < n_pool;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (a) oa[3 * i + k] = ok ? a[3 * r + k] : 0.f;
+        if (b) ob[3 * i + k] = ok ? b[3 * r + k] : 0.f;
+        if (c) oc[3 * i + k] = ok ? c[3 * r + k] : 0.f;
+    }
+    if (d) od[i] = ok ? d[r] : 0.f;
+}
+
 // Fixed sample capacity (graph capture): cut the ray segments at `cap` rows and make the unused tail inert, all from the device-side total.
 __global__ void __launch_bounds__(256) k_march_cap(int64_t n_rays, int64_t cap, const int32_t* __restrict__ counter, int64_t* __restrict__ rays_a,
-                                                   float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts) {
+                                                   float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts,
+                                                   int64_t* __restrict__ overflow) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && overflow) overflow[0] = max((int64_t)counter[0] - cap, (int64_t)0);
     if (i < n_rays) {
         const int64_t start = rays_a[3 * i + 1], n = rays_a[3 * i + 2];
         if (start + n > cap) {
@@ -966,15 +985,30 @@ int nrc_ngp_clip_rays(int64_t n_rays, const float* origin, const float* dirs, co
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
-int nrc_raymarching_train_cap(int64_t n_rays, int64_t sample_capacity, const int32_t* counter, int64_t* rays_a, float* xyzs, float* dirs,
-                              float* deltas, float* ts, nrc_stream_t stream) {
+int nrc_raymarching_train_cap_overflow(int64_t n_rays, int64_t sample_capacity, const int32_t* counter, int64_t* rays_a, float* xyzs, float* dirs,
+                              float* deltas, float* ts, int64_t* overflow, nrc_stream_t stream) {
     NRC_ENTER();
     if (n_rays < 0 || sample_capacity < 0) return NRC_ERR_INVALID;
     const int64_t n = n_rays > sample_capacity ? n_rays : sample_capacity;
     if (n == 0) return NRC_OK;
     if (!counter || (n_rays && !rays_a) || (sample_capacity && (!xyzs || !dirs || !deltas || !ts))) return NRC_ERR_INVALID;
     hipLaunchKernelGGL(k_march_cap, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n_rays, sample_capacity, counter, rays_a,
-                       xyzs, dirs, deltas, ts);
+                       xyzs, dirs, deltas, ts, overflow);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_raymarching_train_cap(int64_t n_rays, int64_t sample_capacity, const int32_t* counter, int64_t* rays_a, float* xyzs, float* dirs,
+                              float* deltas, float* ts, nrc_stream_t stream) {
+    return nrc_raymarching_train_cap_overflow(n_rays, sample_capacity, counter, rays_a, xyzs, dirs, deltas, ts, nullptr, stream);
+}
+int nrc_gather_ray_batch(const int64_t* ids, int64_t n, int64_t n_pool, const float* pool_a3, const float* pool_b3, const float* pool_c3,
+                         const float* pool_d1, float* out_a3, float* out_b3, float* out_c3, float* out_d1, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n < 0 || n_pool < 0) return NRC_ERR_INVALID;
+    if (n == 0) return NRC_OK;
+    if (!ids || (pool_a3 && !out_a3) || (pool_b3 && !out_b3) || (pool_c3 && !out_c3) || (pool_d1 && !out_d1)) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_gather_ray_batch, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ids, n, n_pool, pool_a3, pool_b3, pool_c3,
+                       pool_d1, out_a3, out_b3, out_c3, out_d1);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -1823,7 +1823,7 @@ __global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restric
 
 __global__ void __launch_bounds__(GBA_THREADS) k_gb_accumulate(GridCfg g, BucketCfg bc, int64_t M, int n_wg, const uint32_t* __restrict__ seg,
                                                                const uint32_t* __restrict__ wg_max, const uint4* __restrict__ records, int64_t rec_per_wg,
-                                                               float* __restrict__ grad_table) {
+                                                               float* __restrict__ grad_table, int assign) {
     extern __shared__ long long fix_acc[];  // [GB_ENTRIES][2]
     __shared__ uint32_t s_max;
     NRC_PROBE_NW(0);
@@ -1923,7 +1923,9 @@ __global__ void __launch_bounds__(GBA_THREADS) k_gb_accumulate(GridCfg g, Bucket
     if (!(mx < __builtin_inff())) {
         // a non-finite gradient on the level (GradScaler overflow): the fixed-point path cannot carry it; mark the slice NaN, the way f32
         // atomics would have propagated it, so that the scaler's found-inf check still sees it
-        if (threadIdx.x == 0) reinterpret_cast<float2*>(grad_table)[lo] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+        if (assign) {   // the slice has no other writer and was not initialised: all of it
+            for (uint32_t j = threadIdx.x; j < GB_ENTRIES; j += GBA_THREADS) reinterpret_cast<float2*>(grad_table)[lo + j] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+        } else if (threadIdx.x == 0) reinterpret_cast<float2*>(grad_table)[lo] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
         return;
     }
     int e_max = 0, e_cnt = 0;
@@ -1947,6 +1949,14 @@ __global__ void __launch_bounds__(GBA_THREADS) k_gb_accumulate(GridCfg g, Bucket
     float2* out = reinterpret_cast<float2*>(grad_table) + lo;
     // read-modify-write of the slice: all of a thread's table reads first (entry by entry, each one was a full memory latency in front of its store)
     enum { PER_THREAD = GB_ENTRIES / GBA_THREADS };
+    if (assign) {   // sole writer of an uninitialised slice (nrc_ngp_train_query_backward_set): every entry is written, nothing is read
+#pragma unroll
+        for (int t = 0; t < PER_THREAD; t++) {
+            const uint32_t j = threadIdx.x + t * GBA_THREADS;
+            out[j] = make_float2((float)((double)fix_acc[2 * j] * inv), (float)((double)fix_acc[2 * j + 1] * inv));
+        }
+        return;
+    }
     float2 old_v[PER_THREAD];
 #pragma unroll
     for (int t = 0; t < PER_THREAD; t++) old_v[t] = out[threadIdx.x + t * GBA_THREADS];
@@ -2054,10 +2064,21 @@ int64_t nrc_grid_backward_ws_bytes(int64_t M, int32_t n_levels, int32_t log2_has
     return gb_layout(M, bc.n_levels, bc.bucket0[bc.n_levels]).total;
 }
 
-int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
-                      int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table, void* workspace,
-                      nrc_stream_t stream) {
-    NRC_ENTER();
+}  // extern "C"
+
+// does this call take the bucketed path (all conditions of grid_backward_impl in one place: nrc_ngp_train_query_backward_set needs the answer first)
+static bool gb_will_bucket(int64_t M, int pair_major, const void* workspace, const GridCfg& g, int n_levels, BucketCfg& bc, bool* isb) {
+    static const bool allow_owned = [] { const char* e = getenv("NRC_GRID_BWD_OWNED"); return !(e && e[0] == '0'); }();
+    static const bool allow_buckets = [] { const char* e = getenv("NRC_GRID_BWD_BUCKETS"); return !(e && e[0] == '0'); }();
+    if (!(allow_owned && allow_buckets && pair_major && M >= 16384 && workspace && M < (int64_t(1) << 30))) return false;
+    pick_bucket_levels(g, n_levels, bc, isb);
+    return bc.n_levels > 0;
+}
+
+// assign != 0: the bucketed levels' slices are WRITTEN (uninitialised memory, no other writer), only valid when gb_will_bucket() holds
+static int grid_backward_impl(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
+                              int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table, void* workspace,
+                              nrc_stream_t stream, int assign) {
     if (M < 0 || !grad_table) return NRC_ERR_INVALID;
     if (M == 0) return NRC_OK;
     if (!x01 || !d_features) return NRC_ERR_INVALID;
@@ -2070,11 +2091,9 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
     const bool owned = allow_owned && d_features_pair_major && M >= 16384;
     hipStream_t s = (hipStream_t)stream;
     // bucketed ownership (needs the workspace): all hashed levels in two launches, the dense ones through the run-aggregated atomics
-    static const bool allow_buckets = [] { const char* e = getenv("NRC_GRID_BWD_BUCKETS"); return !(e && e[0] == '0'); }();
-    if (owned && allow_buckets && workspace && M < (int64_t(1) << 30)) {
+    {
         BucketCfg bc; bool isb[NRC_MAX_LEVELS];
-        pick_bucket_levels(g, n_levels, bc, isb);
-        if (bc.n_levels > 0) {
+        if (gb_will_bucket(M, d_features_pair_major, workspace, g, n_levels, bc, isb)) {
             LevelList rest; rest.n = 0;
             for (int l = 0; l < n_levels; l++) if (!isb[l]) rest.level[rest.n++] = l;
             NRC_STAGE(s, nullptr);
@@ -2095,7 +2114,7 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
             static const hipError_t attr_b = hipFuncSetAttribute((const void*)k_gb_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, GB_ENTRIES * 16);
             (void)attr_b;
             hipLaunchKernelGGL(k_gb_accumulate, dim3((unsigned)nb), dim3(GBA_THREADS), GB_ENTRIES * 16, s, g, bc, M, (int)L.n_wg, (const uint32_t*)seg,
-                               (const uint32_t*)wg_max, (const uint4*)records, L.rec_per_wg, grad_table);
+                               (const uint32_t*)wg_max, (const uint4*)records, L.rec_per_wg, grad_table, assign);
             NRC_STAGE(s, "k_gb_accumulate");
             NRC_LAUNCH_CHECK();
             return NRC_OK;
@@ -2147,6 +2166,16 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
     return NRC_OK;
 }
 
+extern "C" {
+
+int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
+                      int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table, void* workspace,
+                      nrc_stream_t stream) {
+    NRC_ENTER();
+    return grid_backward_impl(x01, M, d_features, d_features_pair_major, n_levels, log2_hashmap_size, base_resolution, per_level_scale, grad_table,
+                              workspace, stream, 0);
+}
+
 /* bytes of the scratch the two calls below need: features of all M samples */
 int64_t nrc_ngp_train_query_ws_bytes(int64_t M) { return nrc_nwie_forward_ws_bytes(M); }
 
@@ -2184,16 +2213,41 @@ int nrc_ngp_train_query_forward(const float* xyzs, const float* dirs, int64_t M,
     return NRC_OK;
 }
 
-int nrc_ngp_train_query_backward(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01, const void* density_weights_f16,
+}  // extern "C"
+
+// zeroes two float ranges in one launch (the parts of the gradient buffers nobody writes whole)
+__global__ void __launch_bounds__(256) k_zero_two(float* __restrict__ a, int64_t na, float* __restrict__ b, int64_t nb) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na; i += stride) a[i] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) b[i] = 0.f;
+}
+
+static int train_query_backward_impl(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01, const void* density_weights_f16,
                                  const void* color_weights_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                                  float per_level_scale, const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d,
                                  const void* save_in_c, const void* save_acts_c, float loss_scale, float* grad_density_params, float* grad_color_params,
-                                 int64_t n_density_mlp_params, void* scratch, nrc_stream_t stream) {
-    NRC_ENTER();
+                                 int64_t n_density_mlp_params, void* scratch, nrc_stream_t stream, int64_t n_density_params, int64_t n_color_params) {
     if (M < 0 || !density_weights_f16 || !color_weights_f16 || !grad_density_params || !grad_color_params || n_density_mlp_params < 0) return NRC_ERR_INVALID;
-    if (M == 0) return NRC_OK;
-    if (!dL_dsigmas || !dL_drgbs || !x01 || !h_f16 || !rgb_f16 || !save_in_d || !save_acts_d || !save_in_c || !save_acts_c || !scratch) return NRC_ERR_INVALID;
+    if (M > 0 && (!dL_dsigmas || !dL_drgbs || !x01 || !h_f16 || !rgb_f16 || !save_in_d || !save_acts_d || !save_in_c || !save_acts_c || !scratch)) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    // _set variant: uninitialised gradient buffers.  Bucketed levels are written by their owners; everything else is zeroed here, in one launch.
+    int assign = 0;
+    if (n_density_params > 0 || n_color_params > 0) {
+        GridCfg g; BucketCfg bc; bool isb[NRC_MAX_LEVELS];
+        const int rc0 = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
+        if (rc0 != NRC_OK) return rc0;
+        int64_t zero_d = n_density_params;
+        if (M > 0) {
+            char* q = (char*)scratch + (M * 8 + 255) / 256 * 256 + (M * 4 + 255) / 256 * 256 + M * 128 + M * 32 + M * 128;   // grid_ws, as laid out below
+            if (gb_will_bucket(M, 1, q, g, n_levels, bc, isb)) {
+                assign = 1;
+                zero_d = n_density_mlp_params + 2 * (int64_t)g.offset[bc.level[0]];   // bucketed levels are the finest ones: everything in front of the first
+                if (zero_d > n_density_params) return NRC_ERR_INVALID;
+            }
+        }
+        hipLaunchKernelGGL(k_zero_two, dim3(512), dim3(256), 0, s, grad_density_params, zero_d, grad_color_params, n_color_params);
+    }
+    if (M == 0) { NRC_LAUNCH_CHECK(); return NRC_OK; }
     // scratch: [d_rgb16 M x 4 f16][dh0 M f32][d_in_color M x 32 f32][d_h16 M x 16 f16][d_in_density 16 x M x 2 f32]
     char* p = (char*)scratch;
     __half* d_rgb16 = (__half*)p; p += (M * 8 + 255) / 256 * 256;
@@ -2214,11 +2268,36 @@ int nrc_ngp_train_query_backward(const float* dL_dsigmas, const float* dL_drgbs,
     if (rc != NRC_OK) return rc;
     NRC_STAGE(s, "k_nwie_bwd<density>");
     void* grid_ws = (char*)d_in_d + M * 128;  // nrc_grid_backward_ws_bytes (all levels at most) behind the pair-major gradients
-    rc = nrc_grid_backward(x01, M, d_in_d, 1, n_levels, log2_hashmap_size, base_resolution, per_level_scale, grad_density_params + n_density_mlp_params,
-                           grid_ws, stream);
+    rc = grid_backward_impl(x01, M, d_in_d, 1, n_levels, log2_hashmap_size, base_resolution, per_level_scale, grad_density_params + n_density_mlp_params,
+                            grid_ws, stream, assign);
     if (rc != NRC_OK) return rc;
     NRC_LAUNCH_CHECK();
     return NRC_OK;
+}
+
+extern "C" {
+
+int nrc_ngp_train_query_backward(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01, const void* density_weights_f16,
+                                 const void* color_weights_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale,
+                                 const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d, const void* save_in_c,
+                                 const void* save_acts_c, float loss_scale, float* grad_density_params, float* grad_color_params,
+                                 int64_t n_density_mlp_params, void* scratch, nrc_stream_t stream) {
+    NRC_ENTER();
+    return train_query_backward_impl(dL_dsigmas, dL_drgbs, M, x01, density_weights_f16, color_weights_f16, n_levels, log2_hashmap_size, base_resolution,
+                                     per_level_scale, h_f16, rgb_f16, save_in_d, save_acts_d, save_in_c, save_acts_c, loss_scale, grad_density_params,
+                                     grad_color_params, n_density_mlp_params, scratch, stream, 0, 0);
+}
+int nrc_ngp_train_query_backward_set(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01, const void* density_weights_f16,
+                                     const void* color_weights_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
+                                     float per_level_scale, const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d,
+                                     const void* save_in_c, const void* save_acts_c, float loss_scale, float* grad_density_params,
+                                     float* grad_color_params, int64_t n_density_mlp_params, int64_t n_density_params, int64_t n_color_params,
+                                     void* scratch, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_density_params <= 0 || n_color_params <= 0 || !grad_density_params || !grad_color_params || (M > 0 && !scratch)) return NRC_ERR_INVALID;
+    return train_query_backward_impl(dL_dsigmas, dL_drgbs, M, x01, density_weights_f16, color_weights_f16, n_levels, log2_hashmap_size, base_resolution,
+                                     per_level_scale, h_f16, rgb_f16, save_in_d, save_acts_d, save_in_c, save_acts_c, loss_scale, grad_density_params,
+                                     grad_color_params, n_density_mlp_params, scratch, stream, n_density_params, n_color_params);
 }
 
 int64_t nrc_ngp_train_query_scratch_bytes(int64_t M) {

@@ -140,27 +140,47 @@ def instant_ngp_iteration(model, renderer, optimizer, scaler, camera, n_rays: in
         return colour if fold_weight_decay else colour + 0.5e-6 * model.weight_decay_mlp()
 
     criterion = loss_fn or default_loss
+    # The default colour loss with the weight decay folded away is ONE expression: mean squared error, times the scaler's scale.  With a scaler that
+    # exposes its device scalar (nerficg_amd.amp.GradScaler.scale_tensor) it runs as one launch forward and one backward
+    # (nerficg_amd.ngp.scaled_mse_loss) instead of mse_loss + scaler.scale(loss) + their autograd nodes (seven), and backward starts from a
+    # resident one instead of a freshly filled tensor.
+    fused_loss = loss_fn is None and fold_weight_decay and hasattr(scaler, 'scale_tensor') and scaler.is_enabled()
+    one = torch.ones((), dtype=torch.float32, device=dev)
 
     def iteration(origin, view_direction, rgb, alpha=None):
+        from .ngp import scaled_mse_loss
         renderer.sample_capacity = int(sample_capacity)
         try:
             with torch.amp.autocast('cuda'):
                 bg = torch.rand(3, device=dev)
                 out = renderer.render_rays(origin, view_direction, camera, train_mode=True, custom_bg_color=bg)
-                loss = criterion(out, rgb, alpha, bg)
-            scaler.scale(loss).backward()
+                if fused_loss and alpha is None:
+                    loss, scaled = scaled_mse_loss(out['rgb'], rgb, scaler.scale_tensor(dev))
+                else:
+                    loss = criterion(out, rgb, alpha, bg)
+                    scaled = None
+            if scaled is not None:
+                torch.autograd.backward(scaled, grad_tensors=one)
+            else:
+                scaler.scale(loss).backward()
             scaler.step(optimizer)
             scaler.update()
             optimizer.zero_grad()
         finally:
             renderer.sample_capacity = None
         marched = out['rm_samples']
-        return {'loss': loss.detach(), 'rm_samples': marched, 'sample_overflow': (marched - int(sample_capacity)).clamp_(min=0)}
+        cut = out['sample_overflow'] if 'sample_overflow' in out else (marched - int(sample_capacity)).clamp_(min=0)
+        return {'loss': loss.detach(), 'rm_samples': marched, 'sample_overflow': cut}
 
     if ray_pool is not None:
         pool = {k: v.contiguous() for k, v in ray_pool.items()}
+        one_launch = set(pool) <= {'origin', 'view_direction', 'rgb', 'alpha'} and {'origin', 'view_direction'} <= set(pool) and \
+            all(v.dtype == torch.float32 and v.is_cuda for v in pool.values())
 
         def body(ids):
+            if one_launch:   # every field of the batch in one gather launch
+                from .ngp import gather_ray_batch
+                return iteration(**gather_ray_batch(ids, pool['origin'], pool['view_direction'], pool.get('rgb'), pool.get('alpha')))
             return iteration(**{k: v[ids] for k, v in pool.items()})
         example = {'ids': torch.zeros(n_rays, dtype=torch.int64, device=dev)}
     else:

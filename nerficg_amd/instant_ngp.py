@@ -189,15 +189,18 @@ class InstantNGPRenderer:
     def _march(self, o, d, span, step_growth, jitter):
         m = self.model
         return VolumeRenderingCuda.raymarching_train(o, d, span, m.occupancy_bitfield, m.cascades, m.SCALE, step_growth, jitter, m.RESOLUTION,
-                                                     self.MAX_SAMPLES, sample_capacity=self.sample_capacity)
+                                                     self.MAX_SAMPLES, sample_capacity=self.sample_capacity, return_overflow=True)
 
     def _render_training_batch(self, o, d, span, bg, step_growth, noise):
         jitter = torch.rand(o.shape[0], device=o.device) if noise is None else noise.to(torch.float32).contiguous()
-        rays_a, xyzs, dirs, deltas, ts, counter = self._march(o, d, span, step_growth, jitter)
+        rays_a, xyzs, dirs, deltas, ts, counter, *cut = self._march(o, d, span, step_growth, jitter)
         sigmas, rgbs = self.query(xyzs, dirs)
         # compositing, background and the training depth (weighted mean with a guarded denominator, Renderer.py:78-84) as one autograd node
         rgb, alpha, depth = composite_over_background(sigmas, rgbs, deltas, ts, rays_a, bg, self.T_THRESHOLD)
-        return {'rgb': rgb, 'alpha': alpha, 'depth': depth, 'rm_samples': counter[0]}
+        out = {'rgb': rgb, 'alpha': alpha, 'depth': depth, 'rm_samples': counter[0]}
+        if cut:   # fixed sample capacity: how many samples did not fit (device int64)
+            out['sample_overflow'] = cut[0]
+        return out
 
     @torch.no_grad()
     def _render_ray_list(self, o, d, span, bg, step_growth):
@@ -206,7 +209,7 @@ class InstantNGPRenderer:
         for lo in range(0, n, self.RAY_CHUNK):
             hi = min(n, lo + self.RAY_CHUNK)
             jitter = torch.zeros(hi - lo, device=o.device)
-            rays_a, xyzs, dirs, deltas, ts, _ = self._march(o[lo:hi].contiguous(), d[lo:hi].contiguous(), span[lo:hi].contiguous(), step_growth, jitter)
+            rays_a, xyzs, dirs, deltas, ts, *_ = self._march(o[lo:hi].contiguous(), d[lo:hi].contiguous(), span[lo:hi].contiguous(), step_growth, jitter)
             if xyzs.shape[0]:
                 sigmas, rgbs = self.query(xyzs, dirs)
             else:

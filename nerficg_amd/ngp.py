@@ -68,15 +68,15 @@ class _QueryTrain(torch.autograd.Function):
         lib = _lib.load()
         m, dev = x01.shape[0], x01.device
         g = density_net.grid_cfg
-        gd = torch.zeros(density_net.params.numel(), dtype=torch.float32, device=dev)
-        gc = torch.zeros(color_net.params.numel(), dtype=torch.float32, device=dev)
-        if m > 0:
-            scratch = torch.empty(int(lib.nrc_ngp_train_query_scratch_bytes(m)), dtype=torch.uint8, device=dev)
-            _lib.check(lib.nrc_ngp_train_query_backward(
-                _lib.ptr(d_sigmas.to(torch.float32).contiguous()), _lib.ptr(d_rgbs.to(torch.float32).contiguous()), m, _lib.ptr(x01), _lib.ptr(wd), _lib.ptr(wc),
-                g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(h), _lib.ptr(rgb16), _lib.ptr(sd_in),
-                _lib.ptr(sd_acts), _lib.ptr(sc_in), _lib.ptr(sc_acts), float(density_net.loss_scale), _lib.ptr(gd), _lib.ptr(gc), density_net.n_mlp_params,
-                _lib.ptr(scratch), _lib.stream_of(gd)), 'ngp_train_query_backward')
+        # uninitialised: the call sets them (the owners of the hashed levels' slices write every entry, the rest is zeroed in one launch)
+        gd = torch.empty(density_net.params.numel(), dtype=torch.float32, device=dev)
+        gc = torch.empty(color_net.params.numel(), dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(lib.nrc_ngp_train_query_scratch_bytes(m)) if m > 0 else 16, dtype=torch.uint8, device=dev)
+        _lib.check(lib.nrc_ngp_train_query_backward_set(
+            _lib.ptr(d_sigmas.to(torch.float32).contiguous()), _lib.ptr(d_rgbs.to(torch.float32).contiguous()), m, _lib.ptr(x01), _lib.ptr(wd), _lib.ptr(wc),
+            g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(h), _lib.ptr(rgb16), _lib.ptr(sd_in),
+            _lib.ptr(sd_acts), _lib.ptr(sc_in), _lib.ptr(sc_acts), float(density_net.loss_scale), _lib.ptr(gd), _lib.ptr(gc), density_net.n_mlp_params,
+            gd.numel(), gc.numel(), _lib.ptr(scratch), _lib.stream_of(gd)), 'ngp_train_query_backward_set')
         return None, None, gd, gc, None, None, None, None
 
 
@@ -106,6 +106,7 @@ class _CompositeOverBackground(torch.autograd.Function):
                                                        _lib.ptr(depth_out), _lib.stream_of(opacity)), 'ngp_train_pixels_fw')
         ctx.save_for_backward(sigmas, rgbs, ws, deltas, ts, rays_a, opacity, depth, rgb, bg)
         ctx.cutoff = float(cutoff)
+        ctx.set_materialize_grads(False)   # an output the loss does not use arrives as None in backward, not as a zero-filled tensor (one launch each)
         return rgb_out, opacity, depth_out
 
     @staticmethod
@@ -117,6 +118,8 @@ class _CompositeOverBackground(torch.autograd.Function):
         f32 = torch.float32
         dense = lambda g: None if g is None else g.to(f32).contiguous()
         g_rgb, g_alpha, g_depth = dense(g_rgb), dense(g_alpha), dense(g_depth)
+        if g_rgb is None and g_alpha is None and g_depth is None:
+            return None, None, None, None, None, None, None
         d_op, d_depth = torch.empty(n, dtype=f32, device=opacity.device), torch.empty(n, dtype=f32, device=opacity.device)
         st = _lib.stream_of(opacity)
         _lib.check(lib.nrc_ngp_train_pixels_bw(n, _lib.ptr(g_rgb), _lib.ptr(g_alpha), _lib.ptr(g_depth), _lib.ptr(opacity), _lib.ptr(depth), _lib.ptr(bg),
@@ -134,3 +137,62 @@ class _CompositeOverBackground(torch.autograd.Function):
 def composite_over_background(sigmas, rgbs, deltas, ts, rays_a, bg, T_threshold: float):
     """-> (rgb over `bg`, alpha, depth / (alpha + 1e-6)) of a training batch; differentiable w.r.t. sigmas / rgbs."""
     return _CompositeOverBackground.apply(sigmas, rgbs, deltas, ts, rays_a, bg, T_threshold)
+
+
+class _ScaledMSE(torch.autograd.Function):
+    """mean((pred - target)^2) and the same times the GradScaler's scale, one launch each way (nrc_mse_scaled_forward / _backward)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(cast_inputs=torch.float32, device_type='cuda')
+    def forward(ctx, pred, target, scale):
+        pred, target = pred.contiguous(), target.contiguous()
+        _lib.check_input(pred, 'pred', torch.float32)
+        _lib.check_input(target, 'target', torch.float32)
+        if pred.shape != target.shape:
+            raise RuntimeError(f'scaled_mse_loss: pred {tuple(pred.shape)} vs target {tuple(target.shape)}')
+        out2 = torch.empty(2, dtype=torch.float32, device=pred.device)
+        _lib.check(_lib.load().nrc_mse_scaled_forward(pred.numel(), _lib.ptr(pred), _lib.ptr(target), _lib.ptr(scale), _lib.ptr(out2), _lib.stream_of(pred)),
+                   'mse_scaled_forward')
+        ctx.save_for_backward(pred, target, scale)
+        ctx.set_materialize_grads(False)
+        return out2[0], out2[1]
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, g_loss, g_scaled):
+        pred, target, scale = ctx.saved_tensors
+        if g_loss is None and g_scaled is None:
+            return None, None, None
+        f = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        g_loss, g_scaled = f(g_loss), f(g_scaled)
+        grad = torch.empty_like(pred)
+        _lib.check(_lib.load().nrc_mse_scaled_backward(pred.numel(), _lib.ptr(pred), _lib.ptr(target), _lib.ptr(scale), _lib.ptr(g_loss), _lib.ptr(g_scaled),
+                                                       _lib.ptr(grad), _lib.stream_of(pred)), 'mse_scaled_backward')
+        return grad, None, None
+
+
+def scaled_mse_loss(pred: torch.Tensor, target: torch.Tensor, scale: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """-> (mse_loss(pred, target), the same * scale) as 0-d tensors; `scale`: the GradScaler's device scalar (Trainer.py:87-89 computes the two with
+    mse_loss + scaler.scale: seven small launches forward + backward where this takes two).  Differentiable w.r.t. pred through either output."""
+    return _ScaledMSE.apply(pred, target, scale.detach().reshape(1))
+
+
+def gather_ray_batch(ids: torch.Tensor, origin: torch.Tensor, view_direction: torch.Tensor, rgb: torch.Tensor | None = None,
+                     alpha: torch.Tensor | None = None) -> dict[str, torch.Tensor]:
+    """pool[ids] for every field of a resident ray pool in one launch (DatasetSamplers.py:53-66 does one fancy-index gather per field)."""
+    _lib.check_input(ids, 'ids', torch.int64)
+    n, n_pool, dev = ids.shape[0], origin.shape[0], ids.device
+    fields = {'origin': (origin, 3), 'view_direction': (view_direction, 3), 'rgb': (rgb, 3), 'alpha': (alpha, 1)}
+    out = {}
+    for k, (v, w) in fields.items():
+        if v is None:
+            continue
+        _lib.check_input(v, k, torch.float32)
+        if v.shape[0] != n_pool or v.numel() != n_pool * w:
+            raise RuntimeError(f'gather_ray_batch: {k} has shape {tuple(v.shape)}, expected ({n_pool}, {w})')
+        out[k] = torch.empty((n, 3) if w == 3 else (n,), dtype=torch.float32, device=dev)
+    p = lambda k: _lib.ptr(fields[k][0]) if fields[k][0] is not None else None
+    q = lambda k: _lib.ptr(out[k]) if k in out else None
+    _lib.check(_lib.load().nrc_gather_ray_batch(_lib.ptr(ids), n, n_pool, p('origin'), p('view_direction'), p('rgb'), p('alpha'), q('origin'),
+                                                q('view_direction'), q('rgb'), q('alpha'), _lib.stream_of(ids)), 'gather_ray_batch')
+    return out

@@ -160,3 +160,91 @@ def test_stage_timer_names_and_times_the_kernels_of_an_entry_point():
     with _lib.stage_timer() as again:
         pass
     assert empty.stages == [] and again.stages == []
+
+
+def test_scaled_mse_loss_equals_mse_loss_times_the_scale():
+    """nrc_mse_scaled_forward / _backward against torch.nn.functional.mse_loss + multiplication (Trainer.py:87-89): both outputs, and the
+    gradient through either one (the recorded iteration backpropagates the scaled output from a resident one)."""
+    from nerficg_amd.ngp import scaled_mse_loss
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for n in (1, 7, 2200, 40_000):
+        pred = torch.rand(n, 3, device=DEV, generator=g, requires_grad=True)
+        target = torch.rand(n, 3, device=DEV, generator=g)
+        scale = torch.tensor([128.0], device=DEV)
+        loss, scaled = scaled_mse_loss(pred, target, scale)
+        ref = torch.nn.functional.mse_loss(pred.detach().double(), target.double())
+        assert abs(float(loss.detach()) - float(ref)) <= 1e-6 * float(ref) + 1e-12
+        assert float(scaled.detach()) == float(loss.detach()) * 128.0
+        ref_grad = 2.0 / (3 * n) * (pred.detach() - target)
+        (g_scaled,) = torch.autograd.grad(scaled, pred, grad_outputs=torch.ones((), device=DEV), retain_graph=True)
+        (g_plain,) = torch.autograd.grad(loss, pred, retain_graph=True)
+        (g_both,) = torch.autograd.grad(loss + 2.0 * scaled, pred)
+        torch.testing.assert_close(g_plain, ref_grad, rtol=1e-6, atol=1e-12)
+        torch.testing.assert_close(g_scaled, 128.0 * ref_grad, rtol=1e-6, atol=1e-12)
+        torch.testing.assert_close(g_both, 257.0 * ref_grad, rtol=1e-6, atol=1e-12)
+    # the same value on every run (one workgroup, fixed order)
+    pred = torch.rand(9000, 3, device=DEV, generator=g); target = torch.rand(9000, 3, device=DEV, generator=g)
+    a = [float(scaled_mse_loss(pred, target, torch.ones(1, device=DEV))[0]) for _ in range(3)]
+    assert a[0] == a[1] == a[2]
+    with pytest.raises(RuntimeError):
+        scaled_mse_loss(pred, target[:10], torch.ones(1, device=DEV))
+
+
+def test_gather_ray_batch_equals_fancy_indexing():
+    from nerficg_amd.ngp import gather_ray_batch
+    g = torch.Generator(device=DEV).manual_seed(4)
+    pool = {k: torch.rand(50_000, 3, device=DEV, generator=g) for k in ('origin', 'view_direction', 'rgb')}
+    pool['alpha'] = torch.rand(50_000, device=DEV, generator=g)
+    ids = torch.randint(0, 50_000, (2200,), device=DEV, generator=g)
+    got = gather_ray_batch(ids, **pool)
+    for k, v in pool.items():
+        assert torch.equal(got[k], v[ids]), k
+    got = gather_ray_batch(ids, pool['origin'], pool['view_direction'])
+    assert set(got) == {'origin', 'view_direction'} and torch.equal(got['origin'], pool['origin'][ids])
+    bad = ids.clone(); bad[5] = 50_000; bad[6] = -1
+    got = gather_ray_batch(bad, **pool)   # out of range: zeros, never a read outside the pool
+    assert float(got['rgb'][5].abs().sum()) == 0.0 and float(got['alpha'][6]) == 0.0 and torch.equal(got['origin'][7:], pool['origin'][ids][7:])
+    with pytest.raises(RuntimeError):
+        gather_ray_batch(ids, pool['origin'], pool['view_direction'][:100])
+
+
+def test_train_query_backward_set_equals_zero_fill_plus_accumulate():
+    """nrc_ngp_train_query_backward_set on uninitialised (here: poisoned) gradient buffers against the accumulating call on zeroed ones: the hashed
+    levels bit for bit (fixed-point sums, written instead of added to zeros), the dense levels / MLP parts up to the order of their float atomics;
+    batches above and below the bucketed path's threshold, and an empty one."""
+    from nerficg_amd import _lib
+    from nerficg_amd.instant_ngp import InstantNGPModel
+    from nerficg_amd import ngp
+    lib = _lib.load()
+    model = InstantNGPModel(RANDOM_SEED=0, device=DEV)
+    dn, cn = model.encoding_xyz, model.color_mlp_with_encoding
+    gcfg = dn.grid_cfg
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for m in (40_000, 3000, 0):
+        xyz = (torch.rand(m, 3, device=DEV, generator=g) - 0.5) * 0.9
+        dirs = torch.nn.functional.normalize(torch.randn(m, 3, device=DEV, generator=g), dim=-1) if m else torch.zeros(0, 3, device=DEV)
+        with torch.amp.autocast('cuda'):
+            sig, rgb = ngp.query_train(dn, cn, xyz, dirs, model.xyz_min.detach().float().cpu().reshape(3).contiguous(),
+                                       model.xyz_size.detach().float().cpu().reshape(3).contiguous())
+        d_sig = torch.randn(m, device=DEV, generator=g) * 1e-3
+        d_rgb = torch.randn(m, 3, device=DEV, generator=g) * 1e-3
+        fn = sig.grad_fn
+        x01, h, rgb16, sd_in, sd_acts, sc_in, sc_acts, wd, wc = fn.saved_tensors
+        scratch = torch.empty(max(int(lib.nrc_ngp_train_query_scratch_bytes(m)), 16), dtype=torch.uint8, device=DEV)
+        common = (_lib.ptr(d_sig), _lib.ptr(d_rgb), m, _lib.ptr(x01), _lib.ptr(wd), _lib.ptr(wc), gcfg['n_levels'], gcfg['log2_hashmap_size'], gcfg['base_resolution'],
+                  float(gcfg['per_level_scale']), _lib.ptr(h), _lib.ptr(rgb16), _lib.ptr(sd_in), _lib.ptr(sd_acts), _lib.ptr(sc_in), _lib.ptr(sc_acts), float(dn.loss_scale))
+        gd0 = torch.zeros(dn.params.numel(), device=DEV); gc0 = torch.zeros(cn.params.numel(), device=DEV)
+        _lib.check(lib.nrc_ngp_train_query_backward(*common, _lib.ptr(gd0), _lib.ptr(gc0), dn.n_mlp_params, _lib.ptr(scratch), _lib.stream_of(gd0)), 'bw')
+        gd1 = torch.full((dn.params.numel(),), float('nan'), device=DEV); gc1 = torch.full((cn.params.numel(),), float('nan'), device=DEV)
+        _lib.check(lib.nrc_ngp_train_query_backward_set(*common, _lib.ptr(gd1), _lib.ptr(gc1), dn.n_mlp_params, gd1.numel(), gc1.numel(), _lib.ptr(scratch),
+                                                        _lib.stream_of(gd1)), 'bw_set')
+        assert bool(torch.isfinite(gd1).all()) and bool(torch.isfinite(gc1).all()), m
+        if m == 0:
+            assert float(gd1.abs().sum()) == 0.0 and float(gc1.abs().sum()) == 0.0
+            continue
+        scale = float(gd0.abs().max())
+        assert scale > 0 and float((gd1 - gd0).abs().max()) <= 2e-3 * scale, (m, float((gd1 - gd0).abs().max()) / scale)
+        assert float((gc1 - gc0).abs().max()) <= 2e-3 * float(gc0.abs().max())
+        if m >= 16384:   # bucketed path: the hashed levels' sums do not depend on the order of anything
+            first_hashed = dn.n_mlp_params + 2 * 351_000   # behind the five dense levels (16^3 .. 60^3 -> < 351 K entries): level 5 starts before this
+            assert torch.equal(gd1[first_hashed + 2 * (1 << 19):], gd0[first_hashed + 2 * (1 << 19):])

@@ -54,7 +54,8 @@ def test_fixed_capacity_march_cuts_the_rays_that_do_not_fit():
     rays_a, xyzs, _, _, ts, counter = vr.raymarching_train(*args)
     total = int(counter[0])
     cap = total // 2 + 7
-    rays_a2, xyzs2, _, _, ts2, counter2 = vr.raymarching_train(*args, sample_capacity=cap)
+    rays_a2, xyzs2, _, _, ts2, counter2, cut = vr.raymarching_train(*args, sample_capacity=cap, return_overflow=True)
+    assert int(cut) == total - cap and cut.dtype == torch.int64     # the dropped samples, from the capping launch itself
     assert int(counter2[0]) == total                                  # the uncut total: > capacity tells the caller that samples were dropped
     assert torch.equal(xyzs[:cap], xyzs2) and torch.equal(ts[:cap], ts2)
     start, n = rays_a[:, 1], rays_a[:, 2]
