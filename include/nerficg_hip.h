@@ -174,8 +174,10 @@ int nrc_grid_layout(int32_t n_levels, int32_t log2_hashmap_size, int32_t base_re
 int nrc_f32_to_f16(const float* src, void* dst_f16, int64_t n, nrc_stream_t stream);
 /* NetworkWithInputEncoding.forward.  input: encoding 0 -> (M,3) f32 in [0,1], input_ld ignored; encoding 1 -> (M,input_ld>=19)
  * fp16 rows [d01(3) | features(16)].  out_act: 0 none, 1 sigmoid.  out (M,out_ld) fp16, columns [0,n_store) written
- * (n_store in {4,8,12,16}).  save_in (M,32) fp16 and save_acts (n_hidden,M,64) fp16 receive the encoded inputs and the
- * post-ReLU activations for the backward pass (both NULL for inference). */
+ * (n_store in {4,8,12,16}).  save_in (R,32) fp16 and save_acts (n_hidden,R,64) fp16, R = nrc_nwie_save_rows(M) (M rounded up to whole
+ * 32-sample tiles), receive the encoded inputs and the post-ReLU activations for the backward pass (both NULL for inference) in a
+ * layout private to the two calls (MFMA-fragment-major, so that both sides move whole cache lines). */
+int64_t nrc_nwie_save_rows(int64_t M);
 /* workspace (optional, grid encoding only): nrc_nwie_forward_ws_bytes(M) bytes -> the encoding runs as its own kernel (faster);
  * NULL -> one kernel gathers and runs the MLP. */
 int64_t nrc_nwie_forward_ws_bytes(int64_t M);
@@ -204,7 +206,8 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
 /* query_model (src/Methods/InstantNGP/Renderer.py:48-53) for TRAINING as one forward and one backward call instead of ~55 small
  * launches: world positions xyzs (M,3) / directions dirs (M,3) f32 -> sigmas (M), rgbs (M,3) f32 (what VolumeRenderer consumes), and
  * dL/dsigmas, dL/drgbs -> gradients of both parameter vectors (ACCUMULATED; caller zeroes; layout of the tinycudann modules).
- * Kept between the calls: x01 (M,3) f32, h (M,16) f16, rgb (M,4) f16, save_in_* (M,32) f16, save_acts_d (1,M,64) / save_acts_c (2,M,64) f16.
+ * Kept between the calls: x01 (M,3) f32, h (M,16) f16, rgb (M,4) f16, save_in_* (R,32) f16, save_acts_d (1,R,64) / save_acts_c (2,R,64) f16,
+ * R = nrc_nwie_save_rows(M).
  * forward workspace: nrc_ngp_train_query_ws_bytes(M); backward scratch: nrc_ngp_train_query_scratch_bytes(M). */
 int64_t nrc_ngp_train_query_ws_bytes(int64_t M);
 int64_t nrc_ngp_train_query_scratch_bytes(int64_t M);

@@ -122,11 +122,18 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
             encode_sh_id(reinterpret_cast<const __half*>(input), in_ld, ic, hh, B);
         }
         if constexpr (SAVE) {
-            if (valid) {
-                _Float16* p = reinterpret_cast<_Float16*>(save_in) + i * 32 + 8 * hh;
-                *reinterpret_cast<h8*>(p) = B[0];
-                *reinterpret_cast<h8*>(p + 16) = B[1];
+            if (!valid) {   // lanes past M: a finite column (their inputs may be uninitialised workspace)
+#pragma unroll
+                for (int j = 0; j < 8; j++) { B[0][j] = (_Float16)0.f; B[1][j] = (_Float16)0.f; }
             }
+            // Saved state, FRAGMENT-major: [tile][fragment][lane half][sample of the tile] x 16 bytes, rows padded to whole tiles
+            // (nrc_nwie_save_rows).  A store instruction writes two contiguous 512-byte blocks; sample-major rows made every one of the ~20 stores
+            // of a tile touch 64 different lines, 8 or 16 bytes each -- at ~4 clocks per line in the address path that, not the MFMA chain, was
+            // the forward kernels' time on a training batch (and the backward's loads had the same shape).  Rows past M hold the activations of a
+            // zero input (finite: the backward multiplies them by a zero gradient).
+            _Float16* p = reinterpret_cast<_Float16*>(save_in) + ((tile * 4 + hh) * 32 + r) * 8;
+            *reinterpret_cast<h8*>(p) = B[0];
+            *reinterpret_cast<h8*>(p + 2 * 32 * 8) = B[1];
         }
         f16v acc[2] = {zero16(), zero16()};
 #pragma unroll
@@ -141,17 +148,9 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
             if constexpr (SAVE) {
-                if (valid) {
-                    _Float16* p = reinterpret_cast<_Float16*>(save_acts) + ((int64_t)l * M + i) * 64 + 4 * hh;
+                _Float16* p = reinterpret_cast<_Float16*>(save_acts) + ((int64_t)l * n_tiles * 32) * 64 + ((tile * 8 + hh) * 32 + r) * 8;
 #pragma unroll
-                    for (int s = 0; s < 4; s++) {
-                        h4 lo, hi;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) { lo[j] = H[s][j]; hi[j] = H[s][4 + j]; }
-                        *reinterpret_cast<h4*>(p + 16 * s) = lo;
-                        *reinterpret_cast<h4*>(p + 16 * s + 8) = hi;
-                    }
-                }
+                for (int s = 0; s < 4; s++) *reinterpret_cast<h8*>(p + s * 2 * 32 * 8) = H[s];
             }
             if (l + 1 < N_HIDDEN) {
                 acc[0] = zero16(); acc[1] = zero16();
@@ -1226,15 +1225,16 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
     auto fetch = [&](int64_t tile, TileState& t) {
         const int64_t i = tile * 32 + r;
         const int64_t ic = i < M ? i : M - 1;
-        const _Float16* xin = reinterpret_cast<const _Float16*>(save_in) + ic * 32;
-        t.X[0] = *reinterpret_cast<const h8*>(xin + 8 * hh); t.X[1] = *reinterpret_cast<const h8*>(xin + 16 + 8 * hh);
-        const _Float16* a0 = reinterpret_cast<const _Float16*>(save_acts) + ic * 64;
+        // fragment-major saved state (see k_nwie_fwd): one 16-byte load per fragment, 512 contiguous bytes per lane half
+        const _Float16* xin = reinterpret_cast<const _Float16*>(save_in) + ((tile * 4 + hh) * 32 + r) * 8;
+        t.X[0] = *reinterpret_cast<const h8*>(xin); t.X[1] = *reinterpret_cast<const h8*>(xin + 2 * 32 * 8);
+        const _Float16* a0 = reinterpret_cast<const _Float16*>(save_acts) + ((tile * 8 + hh) * 32 + r) * 8;
 #pragma unroll
-        for (int s = 0; s < 4; s++) t.H0[s] = load_acc_order_frag(a0, s, hh);
+        for (int s = 0; s < 4; s++) t.H0[s] = *reinterpret_cast<const h8*>(a0 + s * 2 * 32 * 8);
         if constexpr (N_HIDDEN > 1) {
-            const _Float16* a1 = reinterpret_cast<const _Float16*>(save_acts) + ((int64_t)M + ic) * 64;
+            const _Float16* a1 = a0 + n_tiles * 32 * 64;
 #pragma unroll
-            for (int s = 0; s < 4; s++) t.H1[s] = load_acc_order_frag(a1, s, hh);
+            for (int s = 0; s < 4; s++) t.H1[s] = *reinterpret_cast<const h8*>(a1 + s * 2 * 32 * 8);
         }
         // rows 8 hh .. 8 hh + 7 of the (padded) output row: 16 bytes when the row has 16 entries, the first 4 (8 bytes, hh = 0) when it has 4
         const _Float16* gp = reinterpret_cast<const _Float16*>(d_out) + ic * out_ld;
@@ -2054,6 +2054,8 @@ int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int3
 #if defined(NRC_BWD_PROBE)
 extern "C" int nrc_debug_bwd_probe(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_probe), sizeof(g_bwd_probe)); }
 #endif
+
+int64_t nrc_nwie_save_rows(int64_t M) { return M < 0 ? NRC_ERR_INVALID : (M + 31) / 32 * 32; }
 
 int64_t nrc_grid_backward_ws_bytes(int64_t M, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale) {
     if (M < 0) return NRC_ERR_INVALID;

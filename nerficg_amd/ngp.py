@@ -47,8 +47,9 @@ class _QueryTrain(torch.autograd.Function):
         rgb16 = torch.empty(m, 4, dtype=f16, device=dev)
         sigmas = torch.empty(m, dtype=f32, device=dev)
         rgbs = torch.empty(m, 3, dtype=f32, device=dev)
-        save = [torch.empty(m, 32, dtype=f16, device=dev), torch.empty(1, m, 64, dtype=f16, device=dev),
-                torch.empty(m, 32, dtype=f16, device=dev), torch.empty(2, m, 64, dtype=f16, device=dev)]
+        rows = (m + 31) // 32 * 32   # nrc_nwie_save_rows: the saved state is laid out in whole 32-sample tiles
+        save = [torch.empty(rows, 32, dtype=f16, device=dev), torch.empty(1, rows, 64, dtype=f16, device=dev),
+                torch.empty(rows, 32, dtype=f16, device=dev), torch.empty(2, rows, 64, dtype=f16, device=dev)]
         ws = torch.empty(int(lib.nrc_ngp_train_query_ws_bytes(m)), dtype=torch.uint8, device=dev)
         wd, wc = density_net._half_params(), color_net._half_params()
         _lib.check(lib.nrc_ngp_train_query_forward(

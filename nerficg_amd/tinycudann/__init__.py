@@ -58,8 +58,9 @@ class _NWIEFunction(torch.autograd.Function):
         w16 = module._half_params()
         need_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])  # grad mode is off inside Function.forward
         out = torch.empty(m, module._out_ld, dtype=torch.float16, device=dev)
-        save_in = torch.empty(m, 32, dtype=torch.float16, device=dev) if need_grad else None
-        save_acts = torch.empty(module.n_hidden, m, _WIDTH, dtype=torch.float16, device=dev) if need_grad else None
+        rows = (m + 31) // 32 * 32   # nrc_nwie_save_rows: the saved state is laid out in whole 32-sample tiles
+        save_in = torch.empty(rows, 32, dtype=torch.float16, device=dev) if need_grad else None
+        save_acts = torch.empty(module.n_hidden, rows, _WIDTH, dtype=torch.float16, device=dev) if need_grad else None
         if module.encoding == 0:
             xin = x.detach().to(torch.float32).contiguous()
             in_ld = 3
