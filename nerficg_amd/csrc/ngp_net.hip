@@ -1175,6 +1175,11 @@ __device__ __forceinline__ void atomic_add_tile(float* __restrict__ G, int ld, i
     }
 }
 
+// The fused training query's colour network (nrc_ngp_train_query_backward): the two element-wise kernels around its backward live in the kernel.
+//   d_rgbs   dL/drgb (M,3) f32, read INSTEAD of d_out: the fp16 output-gradient row is (half)d_rgbs[0..2], 0
+//   d_sigmas, h   dL/dsigma (M) f32 and the density network's output rows (M,16) fp16: dh0 = d_sigmas * exp(clamp(h[.,0], +-15)) (TruncExp backward)
+//   d_h16    WRITTEN instead of d_in: the density network's output-gradient rows (M,16) fp16 = (half)(d_in[., 16..31] (+ dh0 on column 0))
+struct TrainQ { const float* d_rgbs; const float* d_sigmas; const __half* h; __half* d_h16; };
 #if defined(NRC_BWD_PROBE)   // developer build (tools/build_variant.sh): cycle stamps of wave 0 of workgroup 0 at the phases of the first tiles
 __device__ unsigned long long g_bwd_probe[2][128];
 #define NRC_PROBE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); g_bwd_probe[N_HIDDEN - 1][(k)] = __builtin_readcyclecounter(); } } while (0)
@@ -1187,7 +1192,7 @@ template <int N_HIDDEN, int OUT_ACT>
 __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __restrict__ W, int n_out_rows, const __half* __restrict__ d_out,
                                                   const __half* __restrict__ out, int out_ld, const __half* __restrict__ save_in,
                                                   const __half* __restrict__ save_acts, float loss_scale, float* __restrict__ dW,
-                                                  float* __restrict__ d_in, int d_in_pair_major) {
+                                                  float* __restrict__ d_in, int d_in_pair_major, TrainQ tq = TrainQ{nullptr, nullptr, nullptr, nullptr}) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[4][2][64 * LDP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     _Float16* T_act = lds[wv][0];
@@ -1240,7 +1245,14 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
         const _Float16* gp = reinterpret_cast<const _Float16*>(d_out) + ic * out_ld;
         const _Float16* yp = reinterpret_cast<const _Float16*>(out) + ic * out_ld;
         t.g = zero_h8(); t.y = zero_h8();
-        if (out_ld == 16) {
+        if (tq.d_rgbs) {   // uniform: colour network of the fused training query
+            if (hh == 0) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) t.g[j] = (_Float16)tq.d_rgbs[3 * ic + j];
+#pragma unroll
+                for (int j = 0; j < 4; j++) if constexpr (OUT_ACT == ACT_SIGMOID) t.y[j] = yp[j];
+            }
+        } else if (out_ld == 16) {
             t.g = *reinterpret_cast<const h8*>(gp + 8 * hh);
             if constexpr (OUT_ACT == ACT_SIGMOID) t.y = *reinterpret_cast<const h8*>(yp + 8 * hh);
         } else {
@@ -1356,6 +1368,22 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
         f16v din = zero16();
 #pragma unroll
         for (int s = 0; s < 4; s++) din = NRC_MFMA(W0T[s], dZ[s], din);
+        if (valid && tq.d_h16) {
+            // accumulator registers 8..15 of lane half hh are input features 16 + 4 hh + (0..3) and 24 + 4 hh + (0..3): the density outputs
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = din[8 + j] * inv_scale;
+            if (hh == 0) {
+                const float h0 = fminf(15.f, fmaxf(-15.f, __half2float(tq.h[i * 16])));
+                v[0] += tq.d_sigmas[i] * expf(h0);
+            }
+            h4 lo, hi;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { lo[j] = (_Float16)v[j]; hi[j] = (_Float16)v[4 + j]; }
+            _Float16* p = reinterpret_cast<_Float16*>(tq.d_h16) + i * 16 + 4 * hh;
+            *reinterpret_cast<h4*>(p) = lo;
+            *reinterpret_cast<h4*>(p + 8) = hi;
+        }
         if (valid && d_in) {
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
@@ -1686,16 +1714,14 @@ static GbLayout gb_layout(int64_t M, int n_bucket_levels, int nb) {
     return L;
 }
 
-#define GB_GROUP 16   // levels ranked together: 2 x GB_GROUP rank registers + 2 x GB_GROUP gradient registers per thread
+#define GB_GROUP 16   // levels ranked together: 2 x GB_GROUP rank registers + 2 x GB_GROUP gradient registers per thread (16 = no grouping)
 __global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, GridCfg g, BucketCfg bc,
                                                              uint32_t* __restrict__ seg, uint32_t* __restrict__ wg_max, uint4* __restrict__ records,
                                                              int64_t rec_per_wg) {
-    // Two workgroups per CU (eight waves per SIMD, <= 64 VGPRs: the second launch bound is waves per execution unit): a training batch of ~2^18 samples is 256-and-a-few workgroups, and with one per CU the few
-    // ran alone after the others -- twice the kernel time for a handful of samples.  Hence the level groups: the ranks and gradients of
-    // GB_GROUP levels fit the register budget, all sixteen do not.
+    // The levels are ranked in groups of GB_GROUP (rank and gradient registers per thread grow with the group).  16 = all levels at once is the
+    // measured best: groups of 6 fit 64 VGPRs, i.e. two workgroups per CU, but spill and repeat the barriers (90 us against 56).
     __shared__ uint32_t hist[GB_MAX_BUCKETS], gbase[GB_MAX_BUCKETS], lmax[NRC_MAX_LEVELS], wave_tot[OWN_THREADS / 64];
     extern __shared__ uint4 stage[];   // [2][4096] records: two level images
-    const int nb = bc.bucket0[bc.n_levels];
     const int n_wg = (int)gridDim.x;
     if (threadIdx.x < NRC_MAX_LEVELS) lmax[threadIdx.x] = 0u;
     const int64_t i = (int64_t)blockIdx.x * OWN_THREADS + threadIdx.x;
@@ -1996,45 +2022,19 @@ static void pick_bucket_levels(const GridCfg& g, int n_levels, BucketCfg& bc, bo
 
 // ---- fused training query (InstantNGPRayRenderingComponent.query_model, Renderer.py:48-53, as one autograd node) ----------------
 // (the f32 outputs the compositor consumes -- sigma = exp(h0), rgb -- are written by the colour kernel's epilogue, see k_nwie_fwd)
-// upstream gradients -> the colour net's fp16 d_out rows (M,4) and the TruncExp backward dh0 = dL/dsigma * exp(clamp(h0, -15, 15))
-__global__ void __launch_bounds__(256) k_train_dout(const float* __restrict__ dL_dsigmas, const float* __restrict__ dL_drgbs, const __half* __restrict__ h,
-                                                    int64_t M, __half* __restrict__ d_rgb16, float* __restrict__ dh0) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    const float h0 = fminf(15.f, fmaxf(-15.f, __half2float(h[i * 16])));
-    dh0[i] = dL_dsigmas[i] * expf(h0);
-    *reinterpret_cast<__half2*>(d_rgb16 + i * 4) = __floats2half2_rn(dL_drgbs[3 * i], dL_drgbs[3 * i + 1]);
-    *reinterpret_cast<__half2*>(d_rgb16 + i * 4 + 2) = __floats2half2_rn(dL_drgbs[3 * i + 2], 0.f);
-}
-// density net d_out rows (M,16) fp16 = gradient arriving through the colour net's identity-encoded inputs (+ dh0 on column 0)
-__global__ void __launch_bounds__(256) k_density_dout(const float* __restrict__ d_in_color, const float* __restrict__ dh0, int64_t M,
-                                                      __half* __restrict__ d_h16) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    const float4* src = reinterpret_cast<const float4*>(d_in_color + i * 32 + 16);
-    __half2 o[8];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        float4 v = src[k];
-        if (k == 0) v.x += dh0[i];
-        o[2 * k] = __floats2half2_rn(v.x, v.y); o[2 * k + 1] = __floats2half2_rn(v.z, v.w);
-    }
-    uint4* dst = reinterpret_cast<uint4*>(d_h16 + i * 16);
-    dst[0] = *reinterpret_cast<const uint4*>(&o[0]); dst[1] = *reinterpret_cast<const uint4*>(&o[4]);
-}
+// (the two element-wise kernels that used to sit around the colour network's backward -- upstream gradients -> fp16 d_out rows + TruncExp backward,
+// d_in of the colour network -> d_out rows of the density network -- are part of k_nwie_bwd now: TrainQ)
 
 }  // namespace
 
-extern "C" {
-
-int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int32_t out_act, int32_t n_out_rows, const void* d_out_f16,
-                      const void* out_f16, int32_t out_ld, const void* save_in, const void* save_acts, float loss_scale,
-                      float* grad_weights, float* d_in, int32_t d_in_pair_major, nrc_stream_t stream) {
-    NRC_ENTER();
+static int nwie_backward_impl(int64_t M, const void* weights_f16, int32_t n_hidden, int32_t out_act, int32_t n_out_rows, const void* d_out_f16,
+                              const void* out_f16, int32_t out_ld, const void* save_in, const void* save_acts, float loss_scale,
+                              float* grad_weights, float* d_in, int32_t d_in_pair_major, nrc_stream_t stream, TrainQ tq) {
     if (M < 0 || !weights_f16 || !grad_weights || n_out_rows < 1 || n_out_rows > 16 || out_ld < 4 || out_ld > 16 || !(loss_scale > 0.f)) return NRC_ERR_INVALID;
     if (n_hidden < 1 || n_hidden > 2 || (out_act != ACT_NONE && out_act != ACT_SIGMOID)) return NRC_ERR_UNSUPPORTED;
     if (M == 0) return NRC_OK;
-    if (!d_out_f16 || !out_f16 || !save_in || !save_acts) return NRC_ERR_INVALID;
+    if ((!d_out_f16 && !tq.d_rgbs) || !out_f16 || !save_in || !save_acts) return NRC_ERR_INVALID;
+    if (tq.d_rgbs && (!tq.d_sigmas || !tq.h || !tq.d_h16 || n_hidden != 2 || out_ld != 4)) return NRC_ERR_INVALID;
     // every wave ends with an atomic flush of its weight-gradient accumulators (3 072 / 7 168 values): the number of waves, not the
     // batch, sets that cost -- one workgroup per CU (NRC_BWD_BLOCKS env override for experiments)
     static const int max_blocks = [] { const char* e = getenv("NRC_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
@@ -2043,12 +2043,22 @@ int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int3
     hipStream_t s = (hipStream_t)stream;
 #define NRC_BWD(H, A)                                                                                                          \
     hipLaunchKernelGGL((k_nwie_bwd<H, A>), grid, block, 0, s, M, (const __half*)weights_f16, (int)n_out_rows, (const __half*)d_out_f16, \
-                       (const __half*)out_f16, (int)out_ld, (const __half*)save_in, (const __half*)save_acts, loss_scale, grad_weights, d_in, (int)d_in_pair_major)
+                       (const __half*)out_f16, (int)out_ld, (const __half*)save_in, (const __half*)save_acts, loss_scale, grad_weights, d_in, (int)d_in_pair_major, tq)
     if (n_hidden == 1) { if (out_act == ACT_SIGMOID) NRC_BWD(1, ACT_SIGMOID); else NRC_BWD(1, ACT_NONE); }
     else { if (out_act == ACT_SIGMOID) NRC_BWD(2, ACT_SIGMOID); else NRC_BWD(2, ACT_NONE); }
 #undef NRC_BWD
     NRC_LAUNCH_CHECK();
     return NRC_OK;
+}
+
+extern "C" {
+
+int nrc_nwie_backward(int64_t M, const void* weights_f16, int32_t n_hidden, int32_t out_act, int32_t n_out_rows, const void* d_out_f16,
+                      const void* out_f16, int32_t out_ld, const void* save_in, const void* save_acts, float loss_scale,
+                      float* grad_weights, float* d_in, int32_t d_in_pair_major, nrc_stream_t stream) {
+    NRC_ENTER();
+    return nwie_backward_impl(M, weights_f16, n_hidden, out_act, n_out_rows, d_out_f16, out_f16, out_ld, save_in, save_acts, loss_scale, grad_weights, d_in,
+                              d_in_pair_major, stream, TrainQ{nullptr, nullptr, nullptr, nullptr});
 }
 
 #if defined(NRC_BWD_PROBE)
@@ -2250,22 +2260,17 @@ static int train_query_backward_impl(const float* dL_dsigmas, const float* dL_dr
         hipLaunchKernelGGL(k_zero_two, dim3(512), dim3(256), 0, s, grad_density_params, zero_d, grad_color_params, n_color_params);
     }
     if (M == 0) { NRC_LAUNCH_CHECK(); return NRC_OK; }
-    // scratch: [d_rgb16 M x 4 f16][dh0 M f32][d_in_color M x 32 f32][d_h16 M x 16 f16][d_in_density 16 x M x 2 f32]
+    // scratch: [(M x 4 f16)(M f32)(M x 32 f32): unused since the element-wise kernels moved into k_nwie_bwd][d_h16 M x 16 f16][d_in_density 16 x M x 2 f32]
     char* p = (char*)scratch;
-    __half* d_rgb16 = (__half*)p; p += (M * 8 + 255) / 256 * 256;
-    float* dh0 = (float*)p; p += (M * 4 + 255) / 256 * 256;
-    float* d_in_c = (float*)p; p += M * 128;
+    p += (M * 8 + 255) / 256 * 256; p += (M * 4 + 255) / 256 * 256; p += M * 128;
     __half* d_h16 = (__half*)p; p += M * 32;
     float* d_in_d = (float*)p;
-    const dim3 g1((unsigned)nrc_cdiv(M, 256)), b1(256);
     NRC_STAGE(s, nullptr);
-    hipLaunchKernelGGL(k_train_dout, g1, b1, 0, s, dL_dsigmas, dL_drgbs, (const __half*)h_f16, M, d_rgb16, dh0);
-    NRC_STAGE(s, "k_train_dout");
-    int rc = nrc_nwie_backward(M, color_weights_f16, 2, ACT_SIGMOID, 3, d_rgb16, rgb_f16, 4, save_in_c, save_acts_c, loss_scale, grad_color_params, d_in_c, 0, stream);
+    // colour network: dL/drgb read as it is, the TruncExp backward and the density network's output gradient written by its epilogue (TrainQ)
+    int rc = nwie_backward_impl(M, color_weights_f16, 2, ACT_SIGMOID, 3, nullptr, rgb_f16, 4, save_in_c, save_acts_c, loss_scale, grad_color_params, nullptr, 0,
+                                stream, TrainQ{dL_drgbs, dL_dsigmas, (const __half*)h_f16, d_h16});
     if (rc != NRC_OK) return rc;
     NRC_STAGE(s, "k_nwie_bwd<colour>");
-    hipLaunchKernelGGL(k_density_dout, g1, b1, 0, s, (const float*)d_in_c, (const float*)dh0, M, d_h16);
-    NRC_STAGE(s, "k_density_dout");
     rc = nrc_nwie_backward(M, density_weights_f16, 1, ACT_NONE, 16, d_h16, h_f16, 16, save_in_d, save_acts_d, loss_scale, grad_density_params, d_in_d, 1, stream);
     if (rc != NRC_OK) return rc;
     NRC_STAGE(s, "k_nwie_bwd<density>");
