@@ -703,8 +703,12 @@ __global__ void __launch_bounds__(64) k_item_scatter(int gx, int gy, const uint3
                                                      const uint32_t* __restrict__ nitems, const uint32_t* __restrict__ ioff, const uint32_t* __restrict__ meta_items,
                                                      int64_t cap, int item_cap, const uint2* __restrict__ spans, const uint32_t* __restrict__ cnt2,
                                                      const uint32_t* __restrict__ ranges, uint32_t list_cap, int32_t* __restrict__ point_list) {
+    // bits[x]: which of the chunk's 64 spans cover tile x; base[x]: where the item's next id of tile x goes.  A lane is a SPAN: it writes its id to
+    // every tile it covers at base[x] + (number of earlier spans of the chunk covering x) -- the loop runs as long as the widest span of the chunk
+    // (a few tiles), not as long as the most covered tile's list (tens of ids), which is what the earlier form (a lane per TILE picking the ids
+    // out of bits[x] one by one) was paying for.  Same positions, same order.
     __shared__ uint32_t bits[SPAN_DIM_MAX][2];
-    __shared__ int ids[64];
+    __shared__ uint32_t base[SPAN_DIM_MAX];
     const int lane = threadIdx.x;
     const int nk = (gx + 63) >> 6;
     SPAN_LOAD_ROW_TABLES();
@@ -713,33 +717,31 @@ __global__ void __launch_bounds__(64) k_item_scatter(int gx, int gy, const uint3
     const int n_items = min((int)meta_items[0], item_cap), ch = (int)meta_items[1];
 #pragma unroll
     for (int k = 0; k < 4; k++) { bits[64 * k + lane][0] = 0u; bits[64 * k + lane][1] = 0u; }
-    __syncthreads();
+    const uint32_t below_lo = lane < 32 ? (1u << lane) - 1u : 0xffffffffu, below_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const SpanItem it = span_item(item, ch, gy, ioff_v, nit_v, roff_v, rtot_v);
-        uint32_t cur[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int x = 64 * k + lane;
-            cur[k] = x < gx ? ranges[2 * ((size_t)it.y * gx + x)] + cnt2[(size_t)item * gx + x] : 0u;
+            if (x < gx) base[x] = ranges[2 * ((size_t)it.y * gx + x)] + cnt2[(size_t)item * gx + x];
         }
         uint2 sp = lane < it.n && it.s0 + lane < cap ? spans[it.s0 + lane] : make_uint2(0u, 0u);
         for (int j0 = 0; j0 < it.n; j0 += 64) {
             const uint2 nxt = j0 + 64 + lane < it.n && it.s0 + j0 + 64 + lane < cap ? spans[it.s0 + j0 + 64 + lane] : make_uint2(0u, 0u);
-            ids[lane] = (int)sp.x;
-            for (int x = (int)(sp.y & 0xffffu); x < (int)(sp.y >> 16); x++) atomicOr(&bits[x][lane >> 5], 1u << (lane & 31));
+            const int x0 = (int)(sp.y & 0xffffu), x1 = (int)(sp.y >> 16);
+            for (int x = x0; x < x1; x++) atomicOr(&bits[x][lane >> 5], 1u << (lane & 31));
+            __syncthreads();
+            for (int x = x0; x < x1; x++) {
+                const uint32_t pos = base[x] + (uint32_t)__popc(bits[x][0] & below_lo) + (uint32_t)__popc(bits[x][1] & below_hi);
+                if (!CAPPED || pos < list_cap) point_list[pos] = (int)sp.x;
+            }
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (k >= nk) break;
                 const int x = 64 * k + lane;
-                uint32_t lo = bits[x][0], hi = bits[x][1];
-                if (lo | hi) { bits[x][0] = 0u; bits[x][1] = 0u; }
-                while (lo | hi) {
-                    int src;
-                    if (lo) { src = __builtin_ctz(lo); lo &= lo - 1u; } else { src = 32 + __builtin_ctz(hi); hi &= hi - 1u; }
-                    if (!CAPPED || cur[k] < list_cap) point_list[cur[k]] = ids[src];
-                    cur[k]++;
-                }
+                const uint32_t lo = bits[x][0], hi = bits[x][1];
+                if (lo | hi) { base[x] += (uint32_t)(__popc(lo) + __popc(hi)); bits[x][0] = 0u; bits[x][1] = 0u; }
             }
             __syncthreads();
             sp = nxt;
