@@ -1125,20 +1125,43 @@ int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float*
 // =====================================================================================================================
 namespace {
 
-#define LDP 40  // LDS row pitch in halves (32 samples + 8 pad = 80 B: keeps ds_read_b128 16-byte aligned, spreads banks)
+#define LDP 40  // the wave's two LDS images are 64 * LDP halves each (5 120 B); the transposing image below uses 4 096 of them
 
-// B-style fragment (this lane = one sample) -> transposed LDS image T[neuron][sample]
+// dW = dZ^T . A sums over the SAMPLES, which sit in the lanes of every fragment this kernel holds: both operands go through an LDS image once.
+// The image is [sample 0..31][neuron 0..63] fp16 in the dual-use layout of cdna_hip_programming.md T10 (a) -- 8-row x 32-column subtiles of 512 B,
+// the 16-byte chunks of a row XOR-swizzled -- so that a lane WRITES its fragment as one 16-byte or two 8-byte pieces of its own row, and the
+// fragments whose k index is the sample are READ back with gfx950's transposing ds_read_b64_tr_b16 (two reads of four samples each).  Round 2 wrote
+// the transposed image element by element (eight 2-byte LDS writes per fragment, 150 per tile): 3.4 K of the tile's 6.1 K cycles.
+__device__ __forceinline__ int img_off(int row, int ch) {   // byte offset of 16-byte chunk ch (8 neurons) of sample row `row`
+    return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+// B-style fragment (this lane = sample c, lane half hh) -> its row of the image
 template <bool ACC_ORDER>
 __device__ __forceinline__ void stage_frag_T(_Float16* T, const h8& f, int s, int c, int hh) {
+    char* base = reinterpret_cast<char*>(T);
+    if constexpr (ACC_ORDER) {   // elements 0..3 = neurons 16 s + 4 hh + (0..3), elements 4..7 = neurons 16 s + 8 + 4 hh + (0..3)
+        h4 lo, hi;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int n = ACC_ORDER ? (16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)) : (16 * s + 8 * hh + j);
-        T[n * LDP + c] = f[j];
+        for (int j = 0; j < 4; j++) { lo[j] = f[j]; hi[j] = f[4 + j]; }
+        *reinterpret_cast<h4*>(base + img_off(c, 2 * s) + 8 * hh) = lo;
+        *reinterpret_cast<h4*>(base + img_off(c, 2 * s + 1) + 8 * hh) = hi;
+    } else {                     // elements 0..7 = neurons 16 s + 8 hh + (0..7)
+        *reinterpret_cast<h8*>(base + img_off(c, 2 * s + hh)) = f;
     }
 }
-// fragment whose k index is the SAMPLE: row/col `n` of the transposed image, samples 16s + 8hh .. +7
-__device__ __forceinline__ h8 read_T_frag(const _Float16* T, int n, int s, int hh) {
-    return *reinterpret_cast<const h8*>(T + n * LDP + 16 * s + 8 * hh);
+// fragment whose k index is the SAMPLE: neuron 32 mt + (lane & 31), samples 16 s + 8 (lane >> 5) .. + 7.  EXEC must be all ones (the read gathers
+// across lanes): call it from wave-uniform code only.
+typedef __fp16 tr_f4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ h8 read_T_frag(const _Float16* T, int mt, int s, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int row0 = 16 * s + 8 * (g >> 1), ch = 4 * mt + 2 * (g & 1) + (p >> 1);
+    const char* base = reinterpret_cast<const char*>(T);
+    const tr_f4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_f4*)(base + img_off(row0 + q, ch) + 8 * (p & 1)));
+    const tr_f4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_f4*)(base + img_off(row0 + 4 + q, ch) + 8 * (p & 1)));
+    h8 f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { f[j] = (_Float16)v0[j]; f[4 + j] = (_Float16)v1[j]; }
+    return f;
 }
 __device__ __forceinline__ h8 zero_h8() {
     h8 f;
@@ -1302,9 +1325,10 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
         wave_lds_sync();
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            const h8 a = r < 16 ? read_T_frag(T_dz, r, s, hh) : zero_h8();
+            const h8 a_all = read_T_frag(T_dz, 0, s, lane);   // (all lanes take part in the read)
+            const h8 a = r < 16 ? a_all : zero_h8();
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) gWo[nt] = NRC_MFMA(a, read_T_frag(T_act, 32 * nt + r, s, hh), gWo[nt]);
+            for (int nt = 0; nt < 2; nt++) gWo[nt] = NRC_MFMA(a, read_T_frag(T_act, nt, s, lane), gWo[nt]);
         }
         wave_lds_sync();
 #endif
@@ -1329,9 +1353,9 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
             for (int s = 0; s < 2; s++)
 #pragma unroll
                 for (int mt = 0; mt < 2; mt++) {
-                    const h8 a = read_T_frag(T_dz, 32 * mt + r, s, hh);
+                    const h8 a = read_T_frag(T_dz, mt, s, lane);
 #pragma unroll
-                    for (int nt = 0; nt < 2; nt++) gW1[mt][nt] = NRC_MFMA(a, read_T_frag(T_act, 32 * nt + r, s, hh), gW1[mt][nt]);
+                    for (int nt = 0; nt < 2; nt++) gW1[mt][nt] = NRC_MFMA(a, read_T_frag(T_act, nt, s, lane), gW1[mt][nt]);
                 }
             wave_lds_sync();
 #endif
@@ -1357,9 +1381,9 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
         wave_lds_sync();
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            const h8 b = read_T_frag(T_act, r, s, hh);
+            const h8 b = read_T_frag(T_act, 0, s, lane);
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) gW0[mt] = NRC_MFMA(read_T_frag(T_dz, 32 * mt + r, s, hh), b, gW0[mt]);
+            for (int mt = 0; mt < 2; mt++) gW0[mt] = NRC_MFMA(read_T_frag(T_dz, mt, s, lane), b, gW0[mt]);
         }
         wave_lds_sync();
 #endif
