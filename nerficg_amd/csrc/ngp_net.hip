@@ -1350,13 +1350,15 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
             for (int s = 0; s < 4; s++) { stage_frag_T<true>(T_dz, dZ[s], s, r, hh); stage_frag_T<true>(T_act, H0[s], s, r, hh); }
             wave_lds_sync();
 #pragma unroll
-            for (int s = 0; s < 2; s++)
+            for (int s = 0; s < 2; s++) {
+                const h8 b0 = read_T_frag(T_act, 0, s, lane), b1 = read_T_frag(T_act, 1, s, lane);
 #pragma unroll
                 for (int mt = 0; mt < 2; mt++) {
                     const h8 a = read_T_frag(T_dz, mt, s, lane);
-#pragma unroll
-                    for (int nt = 0; nt < 2; nt++) gW1[mt][nt] = NRC_MFMA(a, read_T_frag(T_act, nt, s, lane), gW1[mt][nt]);
+                    gW1[mt][0] = NRC_MFMA(a, b0, gW1[mt][0]);
+                    gW1[mt][1] = NRC_MFMA(a, b1, gW1[mt][1]);
                 }
+            }
             wave_lds_sync();
 #endif
             NRC_PROBE(pb + 4);
