@@ -75,12 +75,7 @@ struct MarchCfg {
 // Same f32 operation sequence as raymarching.cu:200-234 / 243-279 (this file is compiled with -ffp-contract=off).
 // `lut`: the kernel's __shared__ table, passed as a plain argument (not through the struct) so that after inlining the compiler knows it is LDS
 // and reads it with ds_read_b32 -- behind a generic pointer in MarchCfg the lookups were flat_load_dword through the vector memory path.
-// `last` (per-thread marches): the cell of the previous probe and its bit.  Inside an object a ray takes several samples per cell (step sqrt(3)/1024
-// against cells of 1/128), and each of them used to walk the whole chain -- three LUT reads, the occupancy byte from memory -- to test the bit it
-// had just tested; the same cell index is the same bit, so the chain is skipped.  Which samples exist does not change.
-struct LastCell { int nx, ny, nz, mip; bool occ; };
-__device__ __forceinline__ bool cell_probe(const Ray& q, const MarchCfg& c, const uint32_t* lut, float t, float& x, float& y, float& z, float& dt, float& t_target,
-                                           LastCell* last = nullptr) {
+__device__ __forceinline__ bool cell_probe(const Ray& q, const MarchCfg& c, const uint32_t* lut, float t, float& x, float& y, float& z, float& dt, float& t_target) {
     x = q.ox + t * q.dx; y = q.oy + t * q.dy; z = q.oz + t * q.dz;
     dt = calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale);
     int mip = 0;
@@ -94,14 +89,9 @@ __device__ __forceinline__ bool cell_probe(const Ray& q, const MarchCfg& c, cons
     const int ny = (int)clampf(0.5f * (y * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
     const int nz = (int)clampf(0.5f * (z * mip_bound_inv + 1) * c.grid_size, 0.0f, c.grid_size - 1.0f);
     // Morton index: three LDS lookups instead of 27 VALU instructions (a third of the step) when the kernel staged the table
-    bool occ;
-    if (last && last->nx == nx && last->ny == ny && last->nz == nz && last->mip == mip) occ = last->occ;
-    else {
-        const uint32_t mort = c.use_lut ? (lut[nx] | (lut[ny] << 1) | (lut[nz] << 2)) : morton3D(nx, ny, nz);
-        const uint32_t idx = (uint32_t)mip * c.grid_size3 + mort;
-        occ = c.bitfield[idx >> 3] & (1 << (idx & 7));
-        if (last) { last->nx = nx; last->ny = ny; last->nz = nz; last->mip = mip; last->occ = occ; }
-    }
+    const uint32_t mort = c.use_lut ? (lut[nx] | (lut[ny] << 1) | (lut[nz] << 2)) : morton3D(nx, ny, nz);
+    const uint32_t idx = (uint32_t)mip * c.grid_size3 + mort;
+    const bool occ = c.bitfield[idx >> 3] & (1 << (idx & 7));
     const float tx = (((nx + 0.5f + 0.5f * signf_(q.dx)) * c.grid_size_inv * 2 - 1) * mip_bound - x) * q.dxi;
     const float ty = (((ny + 0.5f + 0.5f * signf_(q.dy)) * c.grid_size_inv * 2 - 1) * mip_bound - y) * q.dyi;
     const float tz = (((nz + 0.5f + 0.5f * signf_(q.dz)) * c.grid_size_inv * 2 - 1) * mip_bound - z) * q.dzi;
@@ -119,10 +109,9 @@ __device__ __forceinline__ void march_lut(MarchCfg& c, uint32_t* s_lut) {
 }
 // One DDA step.  Returns true when the cell containing o + t d is occupied (sample taken at t with step dt);
 // otherwise advances t to beyond the cell's exit face.  x,y,z,dt are outputs for the occupied case.
-__device__ __forceinline__ bool march_step(const Ray& q, const MarchCfg& c, const uint32_t* lut, float& t, float& x, float& y, float& z, float& dt,
-                                           LastCell* last = nullptr) {
+__device__ __forceinline__ bool march_step(const Ray& q, const MarchCfg& c, const uint32_t* lut, float& t, float& x, float& y, float& z, float& dt) {
     float t_target;
-    if (cell_probe(q, c, lut, t, x, y, z, dt, t_target, last)) return true;
+    if (cell_probe(q, c, lut, t, x, y, z, dt, t_target)) return true;
     do { t += calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale); } while (t < t_target);
     return false;
 }
@@ -278,9 +267,8 @@ __global__ void __launch_bounds__(256) k_march_count(const float* __restrict__ r
         const float t2 = hits_t[2 * r + 1];
         if (t1 >= 0) t1 += calc_dt(t1, c.esf, c.max_samples, c.grid_size, c.scale) * noise[r];
         float t = t1, x, y, z, dt;
-        LastCell last = {-1, -1, -1, -1, false};
         while (0 <= t && t < t2 && n < c.max_samples) {
-            if (march_step(q, c, (const uint32_t*)nullptr, t, x, y, z, dt, &last)) { t += dt; n++; }
+            if (march_step(q, c, (const uint32_t*)nullptr, t, x, y, z, dt)) { t += dt; n++; }
         }
         counts[r] = n;
     }
@@ -341,9 +329,8 @@ __global__ void __launch_bounds__(256) k_march_write(const float* __restrict__ r
     if (t1 >= 0) t1 += calc_dt(t1, c.esf, c.max_samples, c.grid_size, c.scale) * noise[r];
     float t = t1, x, y, z, dt;
     int s = 0;
-    LastCell last = {-1, -1, -1, -1, false};
     while (t < t2 && s < N) {
-        if (march_step(q, c, (const uint32_t*)nullptr, t, x, y, z, dt, &last)) {
+        if (march_step(q, c, (const uint32_t*)nullptr, t, x, y, z, dt)) {
             const int64_t k = start + s;
             xyzs[3 * k] = x; xyzs[3 * k + 1] = y; xyzs[3 * k + 2] = z;
             dirs[3 * k] = q.dx; dirs[3 * k + 1] = q.dy; dirs[3 * k + 2] = q.dz;
@@ -516,9 +503,8 @@ __global__ void __launch_bounds__(256) k_march_test(const float* __restrict__ ra
     float x, y, z, dt, t_next = t;
     int s = 0;
     const int64_t base = n * N_samples;
-    LastCell last = {-1, -1, -1, -1, false};
     while (t < t2 && s < N_samples) {
-        if (march_step(q, c, (const uint32_t*)nullptr, t, x, y, z, dt, &last)) {
+        if (march_step(q, c, (const uint32_t*)nullptr, t, x, y, z, dt)) {
             const int64_t k = base + s;
             xyzs[3 * k] = x; xyzs[3 * k + 1] = y; xyzs[3 * k + 2] = z;
             dirs[3 * k] = q.dx; dirs[3 * k + 1] = q.dy; dirs[3 * k + 2] = q.dz;
@@ -700,17 +686,16 @@ __global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c,
     if (pix >= 0) {
         camera_ray(cam, pix, ry, t1, t2);
         float t = t1, x, y, z, dt;
-        LastCell last = {-1, -1, -1, -1, false};
         if (ts_prov) {
             // the samples are parked in a per-tile arena of max_samples rows (sample k of lane l at (lt * max_samples + k) * 64 + l):
             // the second pass copies them to their final rows instead of marching again
             float* park = ts_prov + (size_t)lt * c.max_samples * 64 + lane;
             while (t < t2 && n < c.max_samples) {
-                if (march_step(ry, c, s_lut, t, x, y, z, dt, &last)) { park[(size_t)n * 64] = t; t += dt; n++; }
+                if (march_step(ry, c, s_lut, t, x, y, z, dt)) { park[(size_t)n * 64] = t; t += dt; n++; }
             }
         } else {
             while (t < t2 && n < c.max_samples) {
-                if (march_step(ry, c, s_lut, t, x, y, z, dt, &last)) { t += dt; n++; }
+                if (march_step(ry, c, s_lut, t, x, y, z, dt)) { t += dt; n++; }
             }
         }
     }
@@ -841,9 +826,8 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
     float t = ray_t[2 * q], x, y, z, dt;
     const float t2 = ray_t[2 * q + 1];
     int s = 0;
-    LastCell last = {-1, -1, -1, -1, false};
     while (t < t2 && s < N) {
-        if (march_step(ry, c, s_lut, t, x, y, z, dt, &last)) {
+        if (march_step(ry, c, s_lut, t, x, y, z, dt)) {
             ts[row_at(s) * 64 + lane] = t;
             t += dt; s++;
         }
