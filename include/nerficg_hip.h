@@ -418,6 +418,9 @@ int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int3
 /* GradScaler's inf / NaN check of one f32 gradient tensor (torch.amp.GradScaler._check_inf_per_device, used at InstantNGP/Trainer.py:89-93 with an
  * optimizer that applies the scale itself): *found_inf (DEVICE f32, not cleared here) is set to 1 when any of the n values is not finite. */
 int nrc_nonfinite_check(const float* grad, int64_t n, float* found_inf, nrc_stream_t stream);
+/* The same for up to four tensors in ONE launch (an entry with n = 0 is skipped): the two parameter vectors of the InstantNGP model. */
+int nrc_nonfinite_check4(const float* g0, int64_t n0, const float* g1, int64_t n1, const float* g2, int64_t n2, const float* g3, int64_t n3,
+                         float* found_inf, nrc_stream_t stream);
 int nrc_adam_prepare(int32_t host_step, float beta1, float beta2, const float* found_inf, int32_t* skipped_steps,
                      int32_t* device_step, float* bias_corrections, nrc_stream_t stream);
 int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

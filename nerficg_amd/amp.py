@@ -26,6 +26,33 @@ class GradScaler(torch.amp.GradScaler):
             self._lazy_init_scale_growth_tracker(torch.device(device))
         return self._scale
 
+    def step(self, optimizer, *args, **kwargs):
+        """torch.amp.GradScaler.step for an optimizer that applies the scale itself (`_step_supports_amp_scaling`), minus two launches:
+        torch builds `found_inf` as `sum([...])` (0 + t: an add) and `grad_scale` as `scale * 1` (a multiplication) on every call; with one
+        device and no scale the caller has put on the optimizer these are the tensors themselves.  Everything else defers to torch."""
+        import inspect
+        from torch.amp.grad_scaler import OptState
+        if (not self._enabled or 'closure' in kwargs or not getattr(optimizer, '_step_supports_amp_scaling', False)
+                or hasattr(optimizer, 'grad_scale') or 'grad_scaler' in inspect.signature(optimizer.step).parameters):
+            return super().step(optimizer, *args, **kwargs)
+        self._check_scale_growth_tracker('step')
+        state = self._per_optimizer_states[id(optimizer)]
+        if state['stage'] is OptState.STEPPED:
+            raise RuntimeError('step() has already been called since the last update().')
+        if state['stage'] is OptState.READY:
+            self._check_inf_per_device(optimizer)
+        scale = self._get_scale_async()
+        found = [t.to(scale.device, non_blocking=True) for t in state['found_inf_per_device'].values()]
+        optimizer.found_inf = found[0] if len(found) == 1 else sum(found)
+        optimizer.grad_scale = None if state['stage'] == OptState.UNSCALED else scale
+        try:
+            retval = optimizer.step(*args, **kwargs)
+        finally:
+            del optimizer.grad_scale
+            del optimizer.found_inf
+        state['stage'] = OptState.STEPPED
+        return retval
+
     def _check_inf_per_device(self, optimizer):
         grads = [p.grad for group in optimizer.param_groups for p in group['params'] if p.grad is not None]
         fast = bool(grads) and all(g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and not g.is_sparse and g.device == grads[0].device
@@ -36,8 +63,12 @@ class GradScaler(torch.amp.GradScaler):
         dev = grads[0].device
         found = torch.zeros((), dtype=torch.float32, device=dev)
         lib = _lib.load()
-        for g in grads:
-            _lib.check(lib.nrc_nonfinite_check(_lib.ptr(g), g.numel(), _lib.ptr(found), _lib.stream_of(g)), 'nonfinite_check')
+        for k in range(0, len(grads), 4):   # four tensors per launch
+            four = grads[k:k + 4] + [None] * (4 - len(grads[k:k + 4]))
+            args = []
+            for g in four:
+                args += [_lib.ptr(g), g.numel() if g is not None else 0]
+            _lib.check(lib.nrc_nonfinite_check4(*args, _lib.ptr(found), _lib.stream_of(found)), 'nonfinite_check4')
         per_device = {dev: found} if _scale.device == dev else {dev: found, _scale.device: torch.zeros((), dtype=torch.float32, device=_scale.device)}
         self._per_optimizer_states[id(optimizer)]['found_inf_per_device'] = per_device
         return per_device

@@ -101,9 +101,48 @@ __global__ void __launch_bounds__(256) k_nonfinite_check(const uint32_t* __restr
     if (__syncthreads_or(bad) && threadIdx.x == 0) *found_inf = 1.0f;
 }
 
+// the same over up to four tensors in one launch: a workgroup row (blockIdx.y) per tensor
+struct FiniteList { const uint32_t* g[4]; int64_t n[4]; };
+__global__ void __launch_bounds__(256) k_nonfinite_check4(FiniteList l, float* __restrict__ found_inf) {
+    const uint32_t* __restrict__ g = l.g[blockIdx.y];
+    const int64_t n = l.n[blockIdx.y];
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) ? n / 4 : 0;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const uint4 q = reinterpret_cast<const uint4*>(g)[i];
+        bad |= ((q.x & 0x7f800000u) == 0x7f800000u) | ((q.y & 0x7f800000u) == 0x7f800000u) | ((q.z & 0x7f800000u) == 0x7f800000u) |
+               ((q.w & 0x7f800000u) == 0x7f800000u);
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) bad |= (g[i] & 0x7f800000u) == 0x7f800000u;
+    if (__syncthreads_or(bad) && threadIdx.x == 0) *found_inf = 1.0f;
+}
+
 }  // namespace
 
 extern "C" {
+
+int nrc_nonfinite_check4(const float* g0, int64_t n0, const float* g1, int64_t n1, const float* g2, int64_t n2, const float* g3, int64_t n3,
+                         float* found_inf, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (!found_inf || n0 < 0 || n1 < 0 || n2 < 0 || n3 < 0) return NRC_ERR_INVALID;
+    const float* gs[4] = {g0, g1, g2, g3};
+    const int64_t ns[4] = {n0, n1, n2, n3};
+    FiniteList l;
+    int count = 0;
+    int64_t largest = 0;
+    for (int k = 0; k < 4; k++) {
+        if (ns[k] == 0) continue;
+        if (!gs[k]) return NRC_ERR_INVALID;
+        l.g[count] = reinterpret_cast<const uint32_t*>(gs[k]); l.n[count] = ns[k]; count++;
+        largest = ns[k] > largest ? ns[k] : largest;
+    }
+    if (count == 0) return NRC_OK;
+    for (int k = count; k < 4; k++) { l.g[k] = l.g[0]; l.n[k] = 0; }
+    const int64_t blocks = nrc_cdiv(nrc_cdiv(largest, 4), 256);
+    hipLaunchKernelGGL(k_nonfinite_check4, dim3((unsigned)(blocks < 2048 ? blocks : 2048), (unsigned)count), dim3(256), 0, (hipStream_t)stream, l, found_inf);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
 
 int nrc_nonfinite_check(const float* grad, int64_t n, float* found_inf, nrc_stream_t stream) {
     NRC_ENTER();
