@@ -98,6 +98,13 @@ int nrc_raymarching_train_cap(int64_t n_rays, int64_t sample_capacity, const int
  * element-wise launches in a recorded iteration. */
 int nrc_raymarching_train_cap_overflow(int64_t n_rays, int64_t sample_capacity, const int32_t* counter, int64_t* rays_a, float* xyzs,
                                        float* dirs, float* deltas, float* ts, int64_t* overflow, nrc_stream_t stream);
+/* count + cap + write for a batch of at most 32 768 rays with a fixed sample capacity, as THREE launches (march with parked positions, one
+ * workgroup that scans the per-ray counts and writes the cut rays_a / counter / *overflow, expansion of the parked positions + inert tail):
+ * what nrc_raymarching_train_count, _cap_overflow and _write do in seven.  workspace: nrc_raymarching_train_ws_bytes(n_rays, max_samples). */
+int nrc_raymarching_train_capped(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield, int32_t cascades,
+                                 float scale, float exp_step_factor, const float* noise, int32_t grid_size, int32_t max_samples, int64_t n_rays,
+                                 int64_t sample_capacity, int64_t* rays_a, int32_t* counter, float* xyzs, float* dirs, float* deltas, float* ts,
+                                 int64_t* overflow, void* workspace, nrc_stream_t stream);
 /* The batch of a training iteration out of the resident ray pool (RayPoolSampler.get, src/Optim/Samplers/DatasetSamplers.py:53-66:
  * ray_pool[indices], one fancy-index gather per field) as ONE launch: rows ids[i] of up to four pools of the same length -- three of
  * row width 3 (origin, view direction, rgb; any may be NULL) and one of width 1 (alpha; may be NULL) -- into dense outputs.

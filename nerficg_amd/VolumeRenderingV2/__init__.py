@@ -110,6 +110,17 @@ def raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades: int, s
     ws = torch.empty(max(int(lib.nrc_raymarching_train_ws_bytes(n, int(max_samples))), 1), dtype=_u8, device=dev)
     args = (_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(hits_t), _lib.ptr(density_bitfield), int(cascades), float(scale),
             float(exp_step_factor), _lib.ptr(noise), int(grid_size), int(max_samples), n)
+    if sample_capacity is not None and _PARKED_MARCH and 0 < n <= 32768 and int(sample_capacity) > 0:
+        # small batch, fixed capacity (a recorded training iteration): count, cut and write as three launches
+        total = int(sample_capacity)
+        xyzs = torch.empty(total, 3, dtype=_f32, device=dev)
+        dirs = torch.empty(total, 3, dtype=_f32, device=dev)
+        deltas = torch.empty(total, dtype=_f32, device=dev)
+        ts = torch.empty(total, dtype=_f32, device=dev)
+        overflow = torch.empty((), dtype=_i64, device=dev)
+        _lib.check(lib.nrc_raymarching_train_capped(*args, total, _lib.ptr(rays_a), _lib.ptr(counter), _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas),
+                                                    _lib.ptr(ts), _lib.ptr(overflow), _lib.ptr(ws), st), 'raymarching_train(capped)')
+        return [rays_a, xyzs, dirs, deltas, ts, counter] + ([overflow] if return_overflow else [])
     _lib.check(lib.nrc_raymarching_train_count(*args, _lib.ptr(rays_a), _lib.ptr(counter), _lib.ptr(ws), st), 'raymarching_train(count)')
     if sample_capacity is None:
         if torch.cuda.is_current_stream_capturing():

@@ -312,6 +312,39 @@ __global__ void __launch_bounds__(256) k_assign_rays_a(const int32_t* __restrict
         rays_a[3 * r + 2] = n;
     }
 }
+// Stages B + C + the capacity cut for small batches (one workgroup over all per-ray counts): rays_a[r] = (r, start, n) with segments cut at `cap`
+// rows, counter = (uncut total, n_rays), *overflow = max(total - cap, 0).  Replaces the block-sum clear, k_scan_block_sums, k_assign_rays_a and
+// k_march_cap of a recorded training iteration (a few thousand rays) by one launch.
+__global__ void __launch_bounds__(1024) k_scan_assign_cap(const int32_t* __restrict__ counts, int64_t n_rays, int64_t cap, int64_t* __restrict__ rays_a,
+                                                          int32_t* __restrict__ counter, int64_t* __restrict__ overflow) {
+    __shared__ int wave_tot[16];
+    __shared__ int64_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_rays; base += 1024) {
+        const int64_t r = base + threadIdx.x;
+        const int v = r < n_rays ? counts[r] : 0;
+        const int incl = nrc_wave_incl_sum_i(v, lane);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int64_t off = carry_s;
+        for (int w = 0; w < wave; w++) off += wave_tot[w];
+        if (r < n_rays) {
+            const int64_t start = off + incl - v;
+            rays_a[3 * r] = r;
+            rays_a[3 * r + 1] = start + v > cap ? min(start, cap) : start;
+            rays_a[3 * r + 2] = start + v > cap ? max(cap - start, (int64_t)0) : (int64_t)v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counter[0] = (int32_t)carry_s; counter[1] = (int32_t)n_rays;
+        if (overflow) overflow[0] = max(carry_s - cap, (int64_t)0);
+    }
+}
 // Stage D: pass 2 (raymarching.cu:243-279): emit the samples of each ray into its reserved, contiguous segment.
 __global__ void __launch_bounds__(256) k_march_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                      const float* __restrict__ hits_t, const float* __restrict__ noise,
@@ -424,7 +457,7 @@ __global__ void __launch_bounds__(256) k_march_wave(const float* __restrict__ ra
     }
     if (!WRITE && lane == 0) {
         counts[r] = s;
-        if (s) atomicAdd(&block_sums[r >> 8], s);
+        if (s && block_sums) atomicAdd(&block_sums[r >> 8], s);
     }
 }
 
@@ -432,7 +465,19 @@ __global__ void __launch_bounds__(256) k_march_wave(const float* __restrict__ ra
 // expressions as cell_probe / calc_dt, no march, no occupancy probes.
 __global__ void __launch_bounds__(256) k_march_expand(const float* __restrict__ rays_o, const float* __restrict__ rays_d, MarchCfg c, int64_t n_rays,
                                                       const int64_t* __restrict__ rays_a, const float* __restrict__ park, float* __restrict__ xyzs,
-                                                      float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts) {
+                                                      float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts,
+                                                      const int32_t* __restrict__ counter = nullptr, int64_t cap = 0) {
+    // (fixed capacity, nrc_raymarching_train_capped: the workgroups behind the rays' make the rows [counter[0], cap) inert samples)
+    const int64_t ray_blocks = (n_rays + 3) / 4;
+    if ((int64_t)blockIdx.x >= ray_blocks) {
+        const int64_t i = ((int64_t)blockIdx.x - ray_blocks) * 256 + threadIdx.x;
+        if (i < cap && i >= (int64_t)counter[0]) {
+            xyzs[3 * i] = 0.f; xyzs[3 * i + 1] = 0.f; xyzs[3 * i + 2] = 0.f;
+            dirs[3 * i] = 0.f; dirs[3 * i + 1] = 0.f; dirs[3 * i + 2] = 1.f;
+            deltas[i] = 0.f; ts[i] = 0.f;
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_rays) return;
@@ -1000,6 +1045,25 @@ int nrc_raymarching_train_cap_overflow(int64_t n_rays, int64_t sample_capacity, 
 int nrc_raymarching_train_cap(int64_t n_rays, int64_t sample_capacity, const int32_t* counter, int64_t* rays_a, float* xyzs, float* dirs,
                               float* deltas, float* ts, nrc_stream_t stream) {
     return nrc_raymarching_train_cap_overflow(n_rays, sample_capacity, counter, rays_a, xyzs, dirs, deltas, ts, nullptr, stream);
+}
+int nrc_raymarching_train_capped(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* bitfield, int32_t cascades, float scale,
+                                 float esf, const float* noise, int32_t grid_size, int32_t max_samples, int64_t n_rays, int64_t sample_capacity,
+                                 int64_t* rays_a, int32_t* counter, float* xyzs, float* dirs, float* deltas, float* ts, int64_t* overflow, void* workspace,
+                                 nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_rays < 1 || n_rays > NRC_WAVE_MARCH_MAX_RAYS || sample_capacity < 1 || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
+    if (!rays_o || !rays_d || !hits_t || !bitfield || !noise || !rays_a || !counter || !xyzs || !dirs || !deltas || !ts || !workspace) return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int32_t* counts = (int32_t*)workspace;
+    float* park = (float*)((char*)workspace + train_ws_head_bytes(n_rays));
+    const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, scale);
+    hipLaunchKernelGGL(k_march_wave<false>, dim3((unsigned)nrc_cdiv(n_rays, 4)), dim3(256), 0, s, rays_o, rays_d, hits_t, noise, c, n_rays, counts,
+                       (int32_t*)nullptr, (const int64_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, park);
+    hipLaunchKernelGGL(k_scan_assign_cap, dim3(1), dim3(1024), 0, s, (const int32_t*)counts, n_rays, sample_capacity, rays_a, counter, overflow);
+    hipLaunchKernelGGL(k_march_expand, dim3((unsigned)(nrc_cdiv(n_rays, 4) + nrc_cdiv(sample_capacity, 256))), dim3(256), 0, s, rays_o, rays_d, c, n_rays,
+                       (const int64_t*)rays_a, (const float*)park, xyzs, dirs, deltas, ts, (const int32_t*)counter, sample_capacity);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
 }
 int nrc_gather_ray_batch(const int64_t* ids, int64_t n, int64_t n_pool, const float* pool_a3, const float* pool_b3, const float* pool_c3,
                          const float* pool_d1, float* out_a3, float* out_b3, float* out_c3, float* out_d1, nrc_stream_t stream) {
