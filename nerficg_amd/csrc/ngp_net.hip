@@ -206,7 +206,7 @@ struct QueryIn {
     float mn[3], sz[3];                                             // xyz_min, xyz_size of the model box (Renderer.py:50)
 };
 // returns false for a hole of the tiled layout (no sample in this slot)
-template <int SRC>
+template <int SRC, bool UNIFORM_ROW = true>
 __device__ __forceinline__ bool fetch_pos(const QueryIn& in, int64_t i, float& px, float& py, float& pz) {
     if constexpr (SRC == SRC_ARRAYS) {
         px = in.xyz01[3 * i]; py = in.xyz01[3 * i + 1]; pz = in.xyz01[3 * i + 2];
@@ -220,7 +220,7 @@ __device__ __forceinline__ bool fetch_pos(const QueryIn& in, int64_t i, float& p
         const float t = in.ts[i];
         // one wave = one row of the tiled layout: the row's ray tile is wave-uniform and comes through the scalar cache (no vector round trip in
         // front of the six ray loads that depend on it)
-        const int32_t rt = in.row_tile[__builtin_amdgcn_readfirstlane((int)(i >> 6))];
+        const int32_t rt = UNIFORM_ROW ? in.row_tile[__builtin_amdgcn_readfirstlane((int)(i >> 6))] : in.row_tile[i >> 6];
         if (t < 0.f || (in.tile_alive && !in.tile_alive[rt])) { px = py = pz = 0.f; return false; }
         const float* od = in.ray_od + (int64_t)rt * 384 + (i & 63);  // per-tile SoA [6][64]
         // same roundings as the op-by-op path: xyz = o + t*d (mul, add: raymarching.cu:368), then (xyz - min) / size in torch
@@ -253,11 +253,45 @@ __device__ __forceinline__ void fetch_dir(const QueryIn& in, int64_t i, float& d
 template <int SRC>
 __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ table, GridCfg g,
                                                          uint4* __restrict__ feat, int narrow_levels, int hashed_mode) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane_mode = (hashed_mode >> 28) & 3;   // tiled layout only: 0 lanes = the 64 pixels of a row, 1 chosen per block of 8 rows, 2 / 3 forced
+    bool remapped = false;
+    if constexpr (SRC == SRC_TILED) {
+        if (lane_mode != 0) {
+            // WHICH 64 samples a wave encodes.  Hashed entries are contiguous along x only: a wave whose samples share (y, z) columns shares cache
+            // lines, one that covers 64 columns opens 64+ lines per gather -- and the miss traffic of the four finest levels is what bounds this
+            // kernel.  Measured per pose with a wave = a row of the layout (8 x 8 pixels at one step): 0.50 ms looking along z, 0.79 ms looking along
+            // x, correlation of the time with |forward.x| = 0.90.  The 512 slots of 8 consecutive rows (the same 64 rays at 8 consecutive steps) can
+            // be dealt to the 8 waves differently:
+            //   A  a row each            (8 x 8 pixels at one step: spans the image axes u, v)
+            //   B  an image row each     (8 pixels along u x 8 steps: spans u and the viewing direction f)
+            //   C  an image column each  (8 pixels along v x 8 steps) -- measured 30-60 % slower than A on every pose, kept as a switch only
+            // Over the bench's 100 orbit poses B beats A on 74 (by up to 25 %: the steps of a ray that runs along x stay in their column), loses
+            // by 8-17 % where the rays run mostly along y, and the gain follows |forward.y| with correlation -0.87; B where |f.y| < 0.55 |f| is
+            // within 0.1 % of choosing the better one per pose (642 against 641 us; always A 693, always B 656).  The choice is made per block from
+            // the direction of the block's own first ray (scalar loads), so it follows the field of view across an image.  The slot a sample is
+            // stored in does not change, and neither does any value.
+            const int64_t blk = (base + j) >> 9;
+            const int row0 = __builtin_amdgcn_readfirstlane((int)(blk * 8));
+            int mode = lane_mode - 1;   // forced: 2 -> B, 3 -> C
+            if (lane_mode == 1) {
+                const float* od = in.ray_od + (int64_t)in.row_tile[row0] * 384;
+                const float dx0 = od[192], dy0 = od[256], dz0 = od[320];
+                mode = dy0 * dy0 < 0.3025f * (dx0 * dx0 + dy0 * dy0 + dz0 * dz0) ? 1 : 0;
+            }
+            if (mode != 0) {
+                const int64_t g512 = (base + j) & ~(int64_t)511;
+                const int w = (int)((j >> 6) & 7), l = (int)(j & 63);
+                const int64_t slot = g512 + ((int64_t)(l >> 3) << 6) + (mode == 1 ? 8 * w + (l & 7) : 8 * (l & 7) + w);
+                j = slot - base;
+                remapped = true;
+            }
+        }
+    }
+    if (j >= n || j < 0) return;
     float px, py, pz;
     if (blockIdx.y != 0) in.x01_out = nullptr;   // level groups split over workgroup rows: the first row writes the normalised positions
-    const bool live = fetch_pos<SRC>(in, base + j, px, py, pz);
+    const bool live = remapped ? fetch_pos<SRC, false>(in, base + j, px, py, pz) : fetch_pos<SRC>(in, base + j, px, py, pz);
     const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
     uint4* out = feat + ((j >> 5) * 4) * 32 + (j & 31);
     const int rot = (int)((j >> 5) & 3);
@@ -839,8 +873,12 @@ static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void
     // or 9 levels): the kernel is bound by the four finest levels' L1 misses (52 % of its time, 8.8 of 9.3 L2 requests per sample), not by
     // the lookups of the coarse ones.  Default off; bit-identical features either way.
     static const int uniform_levels = [] { const char* e = getenv("NRC_ENC_UNIFORM"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > NRC_MAX_LEVELS ? NRC_MAX_LEVELS : v); }();
-    hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)nrc_cdiv(n, 256), rows), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat, narrow,
-                       hashed_mode | (lvl_range << 4) | (uniform_levels << 20));
+    // NRC_ENC_LANES: 0 = a wave is a row of the tiled layout, 1 (default) = chosen per block of 8 rows, 2 / 3 = image row / image column x 8 steps forced
+    static const int lane_mode = [] { const char* e = getenv("NRC_ENC_LANES"); const int v = e ? atoi(e) : 1; return v < 0 || v > 3 ? 1 : v; }();
+    const int lanes = (SRC == SRC_TILED && (base & 511) == 0) ? lane_mode : 0;
+    // (the remapping permutes whole blocks of 512 slots: the launch covers whole blocks)
+    hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)(lanes ? 2 * nrc_cdiv(n, 512) : nrc_cdiv(n, 256)), rows), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat,
+                       narrow, hashed_mode | (lvl_range << 4) | (uniform_levels << 20) | (lanes << 28));
 }
 
 template <int SRC>
