@@ -252,40 +252,27 @@ __device__ __forceinline__ void fetch_dir(const QueryIn& in, int64_t i, float& d
 // channels (measured: 0.262 ms vs 0.22 ms per 2 Mi samples).  One lane per sample, all 16 levels.
 template <int SRC>
 __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ table, GridCfg g,
-                                                         uint4* __restrict__ feat, int narrow_levels, int hashed_mode) {
+                                                         uint4* __restrict__ feat, int narrow_levels, int hashed_mode, int lane_shape = 0) {
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int lane_mode = (hashed_mode >> 28) & 3;   // tiled layout only: 0 lanes = the 64 pixels of a row, 1 chosen per block of 8 rows, 2 / 3 forced
     bool remapped = false;
     if constexpr (SRC == SRC_TILED) {
-        if (lane_mode != 0) {
+        if (lane_shape != 0) {
             // WHICH 64 samples a wave encodes.  Hashed entries are contiguous along x only: a wave whose samples share (y, z) columns shares cache
             // lines, one that covers 64 columns opens 64+ lines per gather -- and the miss traffic of the four finest levels is what bounds this
-            // kernel.  Measured per pose with a wave = a row of the layout (8 x 8 pixels at one step): 0.50 ms looking along z, 0.79 ms looking along
-            // x, correlation of the time with |forward.x| = 0.90.  The 512 slots of 8 consecutive rows (the same 64 rays at 8 consecutive steps) can
-            // be dealt to the 8 waves differently:
-            //   A  a row each            (8 x 8 pixels at one step: spans the image axes u, v)
-            //   B  an image row each     (8 pixels along u x 8 steps: spans u and the viewing direction f)
-            //   C  an image column each  (8 pixels along v x 8 steps) -- measured 30-60 % slower than A on every pose, kept as a switch only
-            // Over the bench's 100 orbit poses B beats A on 74 (by up to 25 %: the steps of a ray that runs along x stay in their column), loses
-            // by 8-17 % where the rays run mostly along y, and the gain follows |forward.y| with correlation -0.87; B where |f.y| < 0.55 |f| is
-            // within 0.1 % of choosing the better one per pose (642 against 641 us; always A 693, always B 656).  The choice is made per block from
-            // the direction of the block's own first ray (scalar loads), so it follows the field of view across an image.  The slot a sample is
-            // stored in does not change, and neither does any value.
-            const int64_t blk = (base + j) >> 9;
-            const int row0 = __builtin_amdgcn_readfirstlane((int)(blk * 8));
-            int mode = lane_mode - 1;   // forced: 2 -> B, 3 -> C
-            if (lane_mode == 1) {
-                const float* od = in.ray_od + (int64_t)in.row_tile[row0] * 384;
-                const float dx0 = od[192], dy0 = od[256], dz0 = od[320];
-                mode = dy0 * dy0 < 0.3025f * (dx0 * dx0 + dy0 * dy0 + dz0 * dz0) ? 1 : 0;
-            }
-            if (mode != 0) {
-                const int64_t g512 = (base + j) & ~(int64_t)511;
-                const int w = (int)((j >> 6) & 7), l = (int)(j & 63);
-                const int64_t slot = g512 + ((int64_t)(l >> 3) << 6) + (mode == 1 ? 8 * w + (l & 7) : 8 * (l & 7) + w);
-                j = slot - base;
-                remapped = true;
-            }
+            // kernel.  With a wave = a row of the layout (8 x 8 pixels at ONE step) the time per launch followed the viewing direction: 0.50 ms
+            // looking along z, 0.79 ms along x, correlation with |forward.x| 0.90 over the bench's poses.  The slots of 16 consecutive rows (the
+            // same 64 rays at 16 consecutive steps) are therefore dealt to the 16 waves as BRICKS of 2^u pixels along the image row x 2^v image rows
+            // x 2^(6-u-v) steps.  Measured, mean / worst pose of 24, us per launch of 7.7 M samples: 8x8x1 (a row) 680 / 795, 8x1x8 628 / 828,
+            // 8x4x2 622 / 712, 4x4x4 615 / 685, 4x2x8 610 / 725, 8x2x4 604 / 723 -- the brick with the smallest cross-section next to its long
+            // (image-row) side wins on almost every pose; choosing per pose between it, 8x1x8 and a row would gain another 1 %.  Default 8 x 2 x 4.
+            // The slot a sample is stored in does not change, and neither does any value.
+            const int lu = (lane_shape >> 4) & 7, lv = lane_shape & 7, ls = 6 - lu - lv;
+            const int64_t g1024 = (base + j) & ~(int64_t)1023;
+            const int w = (int)((j >> 6) & 15), l = (int)(j & 63);
+            const int iu = l & ((1 << lu) - 1), iv = (l >> lu) & ((1 << lv) - 1), is = l >> (lu + lv);
+            const int gu = w & ((8 >> lu) - 1), gv = (w >> (3 - lu)) & ((8 >> lv) - 1), gs = w >> (6 - lu - lv);
+            j = g1024 + ((int64_t)((gs << ls) + is) << 6) + 8 * ((gv << lv) + iv) + (gu << lu) + iu - base;
+            remapped = true;
         }
     }
     if (j >= n || j < 0) return;
@@ -873,12 +860,16 @@ static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void
     // or 9 levels): the kernel is bound by the four finest levels' L1 misses (52 % of its time, 8.8 of 9.3 L2 requests per sample), not by
     // the lookups of the coarse ones.  Default off; bit-identical features either way.
     static const int uniform_levels = [] { const char* e = getenv("NRC_ENC_UNIFORM"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > NRC_MAX_LEVELS ? NRC_MAX_LEVELS : v); }();
-    // NRC_ENC_LANES: 0 = a wave is a row of the tiled layout, 1 (default) = chosen per block of 8 rows, 2 / 3 = image row / image column x 8 steps forced
-    static const int lane_mode = [] { const char* e = getenv("NRC_ENC_LANES"); const int v = e ? atoi(e) : 1; return v < 0 || v > 3 ? 1 : v; }();
-    const int lanes = (SRC == SRC_TILED && (base & 511) == 0) ? lane_mode : 0;
-    // (the remapping permutes whole blocks of 512 slots: the launch covers whole blocks)
-    hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)(lanes ? 2 * nrc_cdiv(n, 512) : nrc_cdiv(n, 256)), rows), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat,
-                       narrow, hashed_mode | (lvl_range << 4) | (uniform_levels << 20) | (lanes << 28));
+    // NRC_ENC_SHAPE=uv: a wave encodes 2^u x 2^v pixels x 2^(6-u-v) steps of the tiled layout (default 31 = 8 x 2 x 4; 33 = a row, the round-2 form)
+    static const int lane_shape = [] {
+        const char* e = getenv("NRC_ENC_SHAPE");
+        const int v = e ? atoi(e) : 31, lu = v / 10, lv = v % 10;
+        return (lu < 0 || lu > 3 || lv < 0 || lv > 3 || lu + lv < 2 || (lu == 3 && lv == 3)) ? 0 : (lu << 4) | lv;   // 2 <= u + v: at most 16 steps
+    }();
+    const int lanes = (SRC == SRC_TILED && (base & 1023) == 0) ? lane_shape : 0;
+    // (the remapping permutes whole blocks of 1024 slots: the launch covers whole blocks)
+    hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)(lanes ? 4 * nrc_cdiv(n, 1024) : nrc_cdiv(n, 256)), rows), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat,
+                       narrow, hashed_mode | (lvl_range << 4) | (uniform_levels << 20), lanes);
 }
 
 template <int SRC>
