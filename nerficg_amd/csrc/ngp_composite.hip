@@ -281,9 +281,12 @@ __global__ void __launch_bounds__(256) k_composite_image(const __half* __restric
     const int N = inside ? ray_cnt[lt * 64 + lane] : 0;
     float T = 1.0f, accR = 0.f, accG = 0.f, accB = 0.f, accD = 0.f, accO = 0.f;
     bool alive = N > 0;
-    // four rows per turn, their loads issued together (a row's loads depend on nothing but k): the serial per-lane loop was bound by
+    // several rows per turn, their loads issued together (a row's loads depend on nothing but k): the serial per-lane loop was bound by
     // one exposed load latency per sample
-    enum { CU = 4 };
+#ifndef NRC_COMPOSITE_ROWS
+#define NRC_COMPOSITE_ROWS 8   // measured per 800x800 image: 4 rows 218 us, 8 rows 202, 16 rows 210
+#endif
+    enum { CU = NRC_COMPOSITE_ROWS };
     for (int k = 0; __any(alive); k += CU) {
         uint2 raw[CU];
         float tv[CU];

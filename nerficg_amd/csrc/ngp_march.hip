@@ -75,7 +75,9 @@ struct MarchCfg {
 // Same f32 operation sequence as raymarching.cu:200-234 / 243-279 (this file is compiled with -ffp-contract=off).
 // `lut`: the kernel's __shared__ table, passed as a plain argument (not through the struct) so that after inlining the compiler knows it is LDS
 // and reads it with ds_read_b32 -- behind a generic pointer in MarchCfg the lookups were flat_load_dword through the vector memory path.
-__device__ __forceinline__ bool cell_probe(const Ray& q, const MarchCfg& c, const uint32_t* lut, float t, float& x, float& y, float& z, float& dt, float& t_target) {
+struct CellAt { int nx, ny, nz; float mip_bound; };
+// sample position, step and occupancy bit of the cell containing o + t d (no exit distance: a sample does not need it)
+__device__ __forceinline__ bool cell_locate(const Ray& q, const MarchCfg& c, const uint32_t* lut, float t, float& x, float& y, float& z, float& dt, CellAt& at) {
     x = q.ox + t * q.dx; y = q.oy + t * q.dy; z = q.oz + t * q.dz;
     dt = calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale);
     int mip = 0;
@@ -91,11 +93,20 @@ __device__ __forceinline__ bool cell_probe(const Ray& q, const MarchCfg& c, cons
     // Morton index: three LDS lookups instead of 27 VALU instructions (a third of the step) when the kernel staged the table
     const uint32_t mort = c.use_lut ? (lut[nx] | (lut[ny] << 1) | (lut[nz] << 2)) : morton3D(nx, ny, nz);
     const uint32_t idx = (uint32_t)mip * c.grid_size3 + mort;
-    const bool occ = c.bitfield[idx >> 3] & (1 << (idx & 7));
-    const float tx = (((nx + 0.5f + 0.5f * signf_(q.dx)) * c.grid_size_inv * 2 - 1) * mip_bound - x) * q.dxi;
-    const float ty = (((ny + 0.5f + 0.5f * signf_(q.dy)) * c.grid_size_inv * 2 - 1) * mip_bound - y) * q.dyi;
-    const float tz = (((nz + 0.5f + 0.5f * signf_(q.dz)) * c.grid_size_inv * 2 - 1) * mip_bound - z) * q.dzi;
-    t_target = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    at.nx = nx; at.ny = ny; at.nz = nz; at.mip_bound = mip_bound;
+    return c.bitfield[idx >> 3] & (1 << (idx & 7));
+}
+// the t beyond which the march resumes after an EMPTY cell (raymarching.cu:221-230)
+__device__ __forceinline__ float cell_exit(const Ray& q, const MarchCfg& c, const CellAt& at, float t, float x, float y, float z) {
+    const float tx = (((at.nx + 0.5f + 0.5f * signf_(q.dx)) * c.grid_size_inv * 2 - 1) * at.mip_bound - x) * q.dxi;
+    const float ty = (((at.ny + 0.5f + 0.5f * signf_(q.dy)) * c.grid_size_inv * 2 - 1) * at.mip_bound - y) * q.dyi;
+    const float tz = (((at.nz + 0.5f + 0.5f * signf_(q.dz)) * c.grid_size_inv * 2 - 1) * at.mip_bound - z) * q.dzi;
+    return t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+}
+__device__ __forceinline__ bool cell_probe(const Ray& q, const MarchCfg& c, const uint32_t* lut, float t, float& x, float& y, float& z, float& dt, float& t_target) {
+    CellAt at;
+    const bool occ = cell_locate(q, c, lut, t, x, y, z, dt, at);
+    t_target = cell_exit(q, c, at, t, x, y, z);
     return occ;
 }
 // stages expand_bits(i), i < grid_size <= MARCH_LUT_MAX, in LDS and points the configuration at it (all threads of the block call this)
@@ -110,8 +121,10 @@ __device__ __forceinline__ void march_lut(MarchCfg& c, uint32_t* s_lut) {
 // One DDA step.  Returns true when the cell containing o + t d is occupied (sample taken at t with step dt);
 // otherwise advances t to beyond the cell's exit face.  x,y,z,dt are outputs for the occupied case.
 __device__ __forceinline__ bool march_step(const Ray& q, const MarchCfg& c, const uint32_t* lut, float& t, float& x, float& y, float& z, float& dt) {
-    float t_target;
-    if (cell_probe(q, c, lut, t, x, y, z, dt, t_target)) return true;
+    // the exit distance of the cell (a dozen instructions) is worked out only when the cell is empty: the per-thread marches are VALU-bound
+    CellAt at;
+    if (cell_locate(q, c, lut, t, x, y, z, dt, at)) return true;
+    const float t_target = cell_exit(q, c, at, t, x, y, z);
     do { t += calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale); } while (t < t_target);
     return false;
 }
