@@ -279,8 +279,8 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
             const int64_t g1024 = (base + j) & ~(int64_t)1023;
             const int w = (int)((j >> 6) & 15), l = (int)(j & 63);
             const int iu = l & ((1 << lu) - 1), iv = (l >> lu) & ((1 << lv) - 1), is = l >> (lu + lv);
-            const int gu = w & ((8 >> lu) - 1), gv = (w >> (3 - lu)) & ((8 >> lv) - 1), gs = w >> (6 - lu - lv);
-            j = g1024 + ((int64_t)((gs << ls) + is) << 6) + 8 * ((gv << lv) + iv) + (gu << lu) + iu - base;
+            const int gu = w & ((NRC_TILE_W >> lu) - 1), gv = (w >> (NRC_TILE_W_LOG2 - lu)) & ((NRC_TILE_H >> lv) - 1), gs = w >> (6 - lu - lv);
+            j = g1024 + ((int64_t)((gs << ls) + is) << 6) + NRC_TILE_W * ((gv << lv) + iv) + (gu << lu) + iu - base;
             remapped = true;
         }
     }
@@ -873,7 +873,7 @@ static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void
     static const int lane_shape = [] {
         const char* e = getenv("NRC_ENC_SHAPE");
         const int v = e ? atoi(e) : 31, lu = v / 10, lv = v % 10;
-        return (lu < 0 || lu > 3 || lv < 0 || lv > 3 || lu + lv < 2 || (lu == 3 && lv == 3)) ? 0 : (lu << 4) | lv;   // 2 <= u + v: at most 16 steps
+        return (lu < 0 || lu > NRC_TILE_W_LOG2 || lv < 0 || lv > 6 - NRC_TILE_W_LOG2 || lu + lv < 2 || lu + lv == 6) ? 0 : (lu << 4) | lv;   // 2 <= u + v: at most 16 steps
     }();
     const int lanes = (SRC == SRC_TILED && (base & 1023) == 0) ? lane_shape : 0;
     static const int xcd_ranges = [] { const char* e = getenv("NRC_ENC_XCD"); return e ? (atoi(e) != 0) : 1; }();   // measured: 612 -> 591 us per launch (mean of 24 poses)
