@@ -16,6 +16,18 @@ from . import _lib
 __all__ = ['GradScaler']
 
 
+_GRAD_SCALER_KWARG: dict = {}
+
+
+def _takes_grad_scaler(optimizer_type) -> bool:
+    """Does this optimizer class's step() take the (deprecated) `grad_scaler` keyword?  (torch inspects the signature on every call; once per class here)"""
+    hit = _GRAD_SCALER_KWARG.get(optimizer_type)
+    if hit is None:
+        import inspect
+        hit = _GRAD_SCALER_KWARG[optimizer_type] = 'grad_scaler' in inspect.signature(optimizer_type.step).parameters
+    return hit
+
+
 class GradScaler(torch.amp.GradScaler):
     def scale_tensor(self, device) -> torch.Tensor:
         """The scale as the device scalar `scale()` multiplies by (created on first use, as `scale()` does): for callers that fold the
@@ -30,10 +42,9 @@ class GradScaler(torch.amp.GradScaler):
         """torch.amp.GradScaler.step for an optimizer that applies the scale itself (`_step_supports_amp_scaling`), minus two launches:
         torch builds `found_inf` as `sum([...])` (0 + t: an add) and `grad_scale` as `scale * 1` (a multiplication) on every call; with one
         device and no scale the caller has put on the optimizer these are the tensors themselves.  Everything else defers to torch."""
-        import inspect
         from torch.amp.grad_scaler import OptState
         if (not self._enabled or 'closure' in kwargs or not getattr(optimizer, '_step_supports_amp_scaling', False)
-                or hasattr(optimizer, 'grad_scale') or 'grad_scaler' in inspect.signature(optimizer.step).parameters):
+                or hasattr(optimizer, 'grad_scale') or _takes_grad_scaler(type(optimizer))):
             return super().step(optimizer, *args, **kwargs)
         self._check_scale_growth_tracker('step')
         state = self._per_optimizer_states[id(optimizer)]
