@@ -25,6 +25,12 @@ enum {
     NRC_ERR_UNSUPPORTED = -3
 };
 
+/* Version of THIS header's contract (signatures, buffer sizes, meaning of the counters).  Bumped on every incompatible change; a caller
+ * compares nrc_abi_version() of the library it loaded with the NRC_ABI_VERSION it was built against and refuses a mismatch (a stale .so under
+ * newer bindings -- or the reverse -- would pass a stream where a pointer is expected, or under-allocate a workspace).
+ * History: 1 = rounds 1-2; 2 = round 3 (nrc_gs_backward gained grad_records, nrc_ngp_render_count writes 2 * n_tiles ints into tile_rows,
+ * counter[1] = total samples, save buffers padded to nrc_nwie_save_rows); 3 = round 4 (see the notes at the changed entry points). */
+#define NRC_ABI_VERSION 3
 /* library identification; also used by the loader's symbol check */
 int nrc_abi_version(void);
 const char* nrc_build_info(void);
@@ -108,7 +114,8 @@ int nrc_raymarching_train_capped(const float* rays_o, const float* rays_d, const
 /* The batch of a training iteration out of the resident ray pool (RayPoolSampler.get, src/Optim/Samplers/DatasetSamplers.py:53-66:
  * ray_pool[indices], one fancy-index gather per field) as ONE launch: rows ids[i] of up to four pools of the same length -- three of
  * row width 3 (origin, view direction, rgb; any may be NULL) and one of width 1 (alpha; may be NULL) -- into dense outputs.
- * ids: int64, 0 <= ids[i] < n_pool (checked on the device: an id out of range writes zeros). */
+ * ids: int64, -n_pool <= ids[i] < n_pool; a negative id counts from the end like torch's indexing; an id out of range (torch: device
+ * assert) writes a NaN row, so a broken sampler shows up in the loss / the GradScaler's check instead of training on black rays. */
 int nrc_gather_ray_batch(const int64_t* ids, int64_t n, int64_t n_pool, const float* pool_a3, const float* pool_b3, const float* pool_c3,
                          const float* pool_d1, float* out_a3, float* out_b3, float* out_c3, float* out_d1, nrc_stream_t stream);
 /* The colour term of the InstantNGP loss with the GradScaler's multiplication folded in (Trainer.py:87-89: mse_loss(rgb, target),

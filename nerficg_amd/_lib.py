@@ -45,6 +45,14 @@ def parse_header(path: Path = HEADER) -> dict[str, tuple[str, list[tuple[str, st
     return protos
 
 
+def header_abi_version(path: Path = HEADER) -> int:
+    """NRC_ABI_VERSION of the header the bindings are built from."""
+    m = re.search(r'#define\s+NRC_ABI_VERSION\s+(\d+)', path.read_text())
+    if m is None:
+        raise NativeLibraryError(f'{path} does not define NRC_ABI_VERSION')
+    return int(m.group(1))
+
+
 def _ctype(type_str: str):
     if '*' in type_str:
         return ctypes.c_void_p
@@ -70,6 +78,9 @@ def load() -> ctypes.CDLL:
             raise NativeLibraryError(f'{LIB_PATH} does not export {name} declared in {HEADER.name}') from e
         fn.argtypes = [_ctype(t) for t, _ in args]
         fn.restype = ctypes.c_char_p if 'char' in ret else (ctypes.c_int64 if ret == 'int64_t' else ctypes.c_int)
+    want, got = header_abi_version(), lib.nrc_abi_version()
+    if got != want:   # a stale .so under newer bindings (or the reverse): fail here, not in an out-of-bounds write
+        raise NativeLibraryError(f'{LIB_PATH} implements ABI version {got}, {HEADER.name} declares {want}: rebuild (python -m nerficg_amd.build)')
     return lib
 
 

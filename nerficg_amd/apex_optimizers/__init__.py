@@ -46,19 +46,33 @@ class FusedAdam(torch.optim.Optimizer):
         self._lr_dev = {}  # capturable: group index -> [device f32[1], the host value it holds]
         self._l2_slices = {}  # id(parameter) -> (weak reference to the parameter, count, coefficient): see set_l2_slice
 
-    def set_l2_slice(self, param: torch.Tensor, count: int, coeff: float) -> None:
+    def set_l2_slice(self, param: torch.Tensor, count: int, coeff: float):
         """The step adds coeff * p to the gradient of the first `count` elements of `param` (not in apex).  A loss term lambda * mean(w^2) over
         such a slice has exactly this gradient with coeff = 2 lambda / n, also under a GradScaler (scaled with the loss, unscaled in the
         step); taking it here spares autograd a dense gradient of the whole parameter for a few thousand weights.  count = 0 removes it.
         EXCLUSIVE with the loss-term form: whoever installs a slice must drop the term from the loss (and remove the slice again before going
         back to a loss that contains it, `clear_l2_slices()`), or the decay is applied twice.  The entry is tied to the parameter OBJECT (weak
-        reference): a tensor that replaces the parameter never inherits it, even if it reuses the id."""
+        reference): a tensor that replaces the parameter never inherits it, even if it reuses the id.
+        Returns the installed entry as a token: `remove_l2_slice(param, token)` removes the slice only while that very entry is still the
+        installed one, so an owner that goes away late (a GraphedIteration dropped after its successor was built on the same optimizer)
+        cannot take its successor's slice with it."""
         if count <= 0:
             self._l2_slices.pop(id(param), None)
-        else:
-            self._l2_slices[id(param)] = (weakref.ref(param), int(count), float(coeff))
+            return None
+        entry = (weakref.ref(param), int(count), float(coeff))
+        self._l2_slices[id(param)] = entry
+        return entry
+
+    def remove_l2_slice(self, param: torch.Tensor, token=None) -> bool:
+        """Remove the slice of `param`; with a token (what set_l2_slice returned) only if that entry is still the installed one."""
+        entry = self._l2_slices.get(id(param))
+        if entry is None or (token is not None and entry is not token):
+            return False
+        del self._l2_slices[id(param)]
+        return True
 
     def clear_l2_slices(self) -> None:
+        """Remove every slice, whoever installed it (going back to a loss that contains the term)."""
         self._l2_slices.clear()
 
     def _l2_slice_of(self, p) -> tuple[int, float]:
@@ -106,24 +120,49 @@ class FusedAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         """torch's layout plus, per group, 'skipped_steps': the overflow-skipped steps that nrc_adam_prepare subtracts from group['step'] for the
-        bias corrections (a device counter; without it a resumed AMP run would forget its skips).  One host read per group, at save time only."""
+        bias corrections (a device counter; without it a resumed AMP run would forget its skips).  One host read per group, at save time only.
+        Capturable mode saves the EFFECTIVE step (the device counter only advances on steps that were taken) with skipped_steps = 0."""
         sd = super().state_dict()
         for gi, g in enumerate(sd['param_groups']):
             entry = self._amp.get(gi)
-            g['skipped_steps'] = int(entry[0].item()) if entry is not None else 0
             if torch.is_tensor(g.get('step')):
                 g['step'] = int(g['step'].item())
+                g['skipped_steps'] = 0
+            else:
+                g['skipped_steps'] = int(entry[0].item()) if entry is not None else 0
         return sd
 
     def load_state_dict(self, state_dict):
+        """The device scalars a recorded iteration holds raw pointers to (skipped counter, bias corrections, learning rate, capturable step)
+        keep their storage: they are UPDATED IN PLACE, never replaced (a replay after a load would otherwise read and write blocks that went
+        back to the allocator).  A checkpoint from the non-capturable mode (step = host count incl. skips, skipped_steps = k) loaded into a
+        capturable optimizer becomes device step = step - k, the count the bias corrections follow in that mode."""
+        live_steps = {gi: g['step'] for gi, g in enumerate(self.param_groups) if torch.is_tensor(g.get('step'))}
         super().load_state_dict(state_dict)
-        self._amp.clear()
-        self._lr_dev.clear()
         for gi, group in enumerate(self.param_groups):
             skipped = int(group.pop('skipped_steps', 0))
-            if skipped:
+            step = group.get('step', 0)
+            step = int(step.item()) if torch.is_tensor(step) else int(step)
+            entry = self._amp.get(gi)
+            if self.capturable:
+                step, skipped = step - skipped, 0      # the device step counts taken steps only
+                dev_step = live_steps.get(gi)
+                if dev_step is not None:
+                    dev_step.fill_(step)
+                    group['step'] = dev_step
+                else:
+                    group['step'] = step               # becomes a device tensor on the first step()
+            else:
+                group['step'] = step
+            if entry is not None:
+                entry[0].fill_(skipped)
+            elif skipped:
                 device = group['params'][0].device
                 self._amp[gi] = (torch.full((1,), skipped, dtype=torch.int32, device=device), torch.ones(2, dtype=torch.float32, device=device))
+            slot = self._lr_dev.get(gi)
+            if slot is not None:
+                slot[0].fill_(float(group['lr']))
+                slot[1] = float(group['lr'])
 
     def zero_grad(self, set_to_none: bool | None = None):
         super().zero_grad(set_to_none=self.set_grad_none if set_to_none is None else set_to_none)

@@ -57,7 +57,7 @@ int nrc_stage_timer_end(int32_t max_stages, char* names, float* ms, int32_t* cou
     g_marks.clear();
     return NRC_OK;
 }
-int nrc_abi_version(void) { return 1; }
+int nrc_abi_version(void) { return NRC_ABI_VERSION; }
 const char* nrc_build_info(void) { return "libnerficg_hip gfx950 (MI355X, CDNA4) hipcc " __VERSION__; }
 int nrc_ngp_tile_width(void) { return NRC_TILE_W; }
 int nrc_ngp_tile_height(void) { return NRC_TILE_H; }

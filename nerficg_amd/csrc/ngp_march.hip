@@ -515,15 +515,17 @@ __global__ void __launch_bounds__(256) k_gather_ray_batch(const int64_t* __restr
                                                           float* __restrict__ oa, float* __restrict__ ob, float* __restrict__ oc, float* __restrict__ od) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int64_t r = ids[i];
-    const bool ok = r >= 0 && r < n_pool;
+    int64_t r = ids[i];
+    if (r < 0) r += n_pool;                    // torch's indexing: -1 is the last row
+    const bool ok = r >= 0 && r < n_pool;      // out of range (torch raises a device assert): the row is NaN, which no loss survives silently
+    const float bad = __int_as_float(0x7fc00000);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        if (a) oa[3 * i + k] = ok ? a[3 * r + k] : 0.f;
-        if (b) ob[3 * i + k] = ok ? b[3 * r + k] : 0.f;
-        if (c) oc[3 * i + k] = ok ? c[3 * r + k] : 0.f;
+        if (a) oa[3 * i + k] = ok ? a[3 * r + k] : bad;
+        if (b) ob[3 * i + k] = ok ? b[3 * r + k] : bad;
+        if (c) oc[3 * i + k] = ok ? c[3 * r + k] : bad;
     }
-    if (d) od[i] = ok ? d[r] : 0.f;
+    if (d) od[i] = ok ? d[r] : bad;
 }
 
 // Fixed sample capacity (graph capture): cut the ray segments at `cap` rows and make the unused tail inert, all from the device-side total.

@@ -17,6 +17,7 @@ kernels launched through ctypes on torch's current stream are recorded like torc
 """
 from __future__ import annotations
 
+import weakref
 from typing import Callable
 
 import torch
@@ -131,8 +132,9 @@ def instant_ngp_iteration(model, renderer, optimizer, scaler, camera, n_rays: in
         if loss_fn is not None:
             raise ValueError('fold_weight_decay replaces the weight-decay term of the DEFAULT loss; a custom loss_fn decides for itself')
         coeff = 1e-6 / model.n_mlp_params
-        optimizer.set_l2_slice(model.encoding_xyz.params, model.n_params_encoding_mlp, coeff)
-        optimizer.set_l2_slice(model.color_mlp_with_encoding.params, model.color_mlp_with_encoding.params.numel(), coeff)
+        installed = [(p, optimizer.set_l2_slice(p, n, coeff)) for p, n in
+                     ((model.encoding_xyz.params, model.n_params_encoding_mlp),
+                      (model.color_mlp_with_encoding.params, model.color_mlp_with_encoding.params.numel()))]
 
     def default_loss(out, rgb, alpha, bg):
         target = rgb if alpha is None else rgb * alpha[:, None] + (1 - alpha)[:, None] * bg
@@ -190,7 +192,16 @@ def instant_ngp_iteration(model, renderer, optimizer, scaler, camera, n_rays: in
         if with_alpha:
             example['alpha'] = torch.zeros(n_rays, device=dev)
     it = GraphedIteration(body, example, eager_calls=eager_calls, before_replay=optimizer.sync_hyperparameters, parameters=model.parameters)
-    it.on_close = (optimizer.clear_l2_slices,) if fold_weight_decay else ()
+    if fold_weight_decay:
+        # only what THIS iteration installed: a successor built on the same optimizer before this object goes (the usual rebuild with a new
+        # n_rays) has replaced the entries, and its slices must survive this one's close() / __del__
+        def drop_own_slices(opt_ref=weakref.ref(optimizer), installed=[(weakref.ref(p), tok) for p, tok in installed]):
+            opt = opt_ref()
+            for p_ref, tok in installed:
+                p = p_ref()
+                if opt is not None and p is not None:
+                    opt.remove_l2_slice(p, tok)
+        it.on_close = (drop_own_slices,)
     return it
 
 

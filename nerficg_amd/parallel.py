@@ -80,11 +80,13 @@ def _has_tensor_collectives() -> bool:
     return dist.get_backend() != 'gloo'
 
 
-def allreduce_flat(buf: torch.Tensor, average: bool = True) -> torch.Tensor:
+def allreduce_flat(buf: torch.Tensor, average: bool = True, single_rank_collective: bool = False) -> torch.Tensor:
     """In-place sum (or mean) of a flat contiguous tensor over all ranks as reduce-scatter + all-gather (each of the 7 xGMI
-    links of a GPU then carries 1/world of the payload); one all_reduce on gloo.  Errors of a collective propagate."""
+    links of a GPU then carries 1/world of the payload); one all_reduce on gloo.  Errors of a collective propagate.
+    `single_rank_collective`: in a one-rank process group the collectives are issued anyway (a no-op sum) -- how the RCCL branch is
+    exercised on a box with one GPU (tests/test_gpu_rccl.py); without a process group it stays the identity."""
     rank, world = world_info()
-    if world == 1:
+    if world == 1 and not (single_rank_collective and dist.is_available() and dist.is_initialized()):
         return buf
     if not _has_tensor_collectives():
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
@@ -243,11 +245,22 @@ class DataParallelGradScaler(_FastGradScaler):
         self.reduced: list[torch.Tensor] = []
 
     def _agree(self, optimizer) -> None:
+        # EVERY rank enters the collective with a vector of the same length -- the piggyback values (the caller passes the same number on every
+        # rank) plus ONE flag: the OR of this rank's per-device found-inf tensors, zero when this rank's optimizer had no gradient this step (its
+        # per-device dictionary is then empty; returning early there would leave the other ranks waiting in the all-reduce).
         found = self._per_optimizer_states[id(optimizer)]['found_inf_per_device']
         flags = list(found.values())
-        sums, agreed = allreduce_scalars(self.piggyback, flags)
-        for t, v in zip(flags, agreed):
-            t.copy_(v.to(t.device))
+        if flags:
+            dev = flags[0].device
+            local = flags[0] if len(flags) == 1 else torch.stack([f.reshape(-1)[0].to(dev) for f in flags]).max().reshape(1)
+        else:
+            dev = self.piggyback[0].device if self.piggyback else (self._scale.device if self._scale is not None else torch.device('cpu'))
+            local = torch.zeros(1, dtype=torch.float32, device=dev)
+        sums, agreed = allreduce_scalars(self.piggyback, [local])
+        for t in flags:
+            t.copy_(agreed[0].to(t.device))
+        if not flags:   # torch's step() insists on a recorded check: this rank's is the agreed flag (its own step has nothing to apply)
+            found[dev] = agreed[0].reshape(1)
         self.reduced, self.piggyback = sums, []
 
     def _check_inf_per_device(self, optimizer):

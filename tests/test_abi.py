@@ -24,7 +24,7 @@ def test_header_parses_and_every_symbol_is_exported(lib):
     assert len(protos) >= 19
     for name in protos:
         assert hasattr(lib, name), name
-    assert lib.nrc_abi_version() >= 1
+    assert lib.nrc_abi_version() == _lib.header_abi_version() >= 3   # the loader refuses any other pairing (round-3 advisor finding)
     assert b'gfx950' in lib.nrc_build_info()
 
 
@@ -68,3 +68,16 @@ def test_ops_fail_loudly_on_cpu_tensors():
     import nerficg_amd.VolumeRenderingV2 as vr
     with pytest.raises(RuntimeError, match='must be a CUDA tensor'):
         vr.morton3D(torch.zeros(4, 3, dtype=torch.int32))
+
+
+def test_loader_refuses_a_library_of_another_abi_version(lib, monkeypatch):
+    """A stale .so under newer bindings must fail at load time, not in an out-of-bounds write of a resized workspace."""
+    monkeypatch.setattr(_lib, 'header_abi_version', lambda *a: 999)
+    _lib.load.cache_clear()
+    try:
+        with pytest.raises(_lib.NativeLibraryError, match='ABI version'):
+            _lib.load()
+    finally:
+        monkeypatch.undo()
+        _lib.load.cache_clear()
+        _lib.load()

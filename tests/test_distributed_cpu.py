@@ -156,6 +156,23 @@ def _t_scalars_and_scaler(rank, world):
         opt.zero_grad()
         trace.append((p.detach().tolist(), float(scaler.get_scale()), float(scaler.reduced[0])))
     out['trace'] = trace
+    # a rank whose optimizer holds NO gradient this step still enters the scaler's collective (round-3 advisor finding: it used to skip it and the
+    # other rank waited for ever) and learns about the other rank's overflow
+    q2 = torch.nn.Parameter(torch.ones(2))
+    opt2 = torch.optim.SGD([q2], lr=0.5)
+    scaler2 = parallel.DataParallelGradScaler('cpu', init_scale=8.0, growth_interval=10 ** 6)
+    lone = []
+    for it in range(2):
+        if rank == 0:
+            scaler2.scale((q2 * (float('inf') if it == 1 else 1.0)).sum()).backward()
+        else:
+            scaler2.scale(torch.zeros(()))   # initialises the scale; no backward: q2.grad stays None on this rank
+        scaler2.piggyback = [torch.tensor(1.0 + rank)]
+        scaler2.step(opt2)
+        scaler2.update()
+        opt2.zero_grad()
+        lone.append((float(scaler2.get_scale()), float(scaler2.reduced[0])))
+    out['lone'] = lone
     # sparse reduction with a rank that holds no gradient at all (its view saw nothing)
     P = 50
     q = torch.nn.Parameter(torch.zeros(P, 3))
@@ -174,6 +191,7 @@ def test_scalar_reductions_and_the_data_parallel_grad_scaler():
         assert out[r]['sums'] == [2001.0, 5.0] and out[r]['flags'] == [1.0, 0.0]
         assert out[r]['sparse'] == (10, 30.0)
     assert out[0]['rays'] == out[1]['rays'] == 262144   # 4096 * 262144 / 1000.5 is far above the cap
+    assert out[0]['lone'] == out[1]['lone'] == [(8.0, 3.0), (4.0, 3.0)]   # rank 1 never had a gradient; both halved the scale on rank 0's overflow
     t0, t1 = out[0]['trace'], out[1]['trace']
     assert t0 == t1                                         # identical parameters, scale and global sample count after every iteration
     assert t0[0][0] == [1.0 - 0.5 * 1.5] * 4 and t0[0][1] == 128.0 and t0[0][2] == 300.0

@@ -201,9 +201,13 @@ def test_gather_ray_batch_equals_fancy_indexing():
         assert torch.equal(got[k], v[ids]), k
     got = gather_ray_batch(ids, pool['origin'], pool['view_direction'])
     assert set(got) == {'origin', 'view_direction'} and torch.equal(got['origin'], pool['origin'][ids])
-    bad = ids.clone(); bad[5] = 50_000; bad[6] = -1
-    got = gather_ray_batch(bad, **pool)   # out of range: zeros, never a read outside the pool
-    assert float(got['rgb'][5].abs().sum()) == 0.0 and float(got['alpha'][6]) == 0.0 and torch.equal(got['origin'][7:], pool['origin'][ids][7:])
+    # torch's indexing rules (round-3 advisor finding): a negative id counts from the end; an id out of range -- torch raises a device assert --
+    # gives a NaN row (never a read outside the pool, never a silent black ray)
+    bad = ids.clone(); bad[5] = 50_000; bad[6] = -1; bad[7] = -50_000; bad[8] = -50_001
+    got = gather_ray_batch(bad, **pool)
+    assert torch.isnan(got['rgb'][5]).all() and torch.isnan(got['alpha'][8]) and torch.isnan(got['origin'][8]).all()
+    assert torch.equal(got['origin'][6], pool['origin'][-1]) and float(got['alpha'][7]) == float(pool['alpha'][0])
+    assert torch.equal(got['origin'][9:], pool['origin'][ids][9:])
     with pytest.raises(RuntimeError):
         gather_ray_batch(ids, pool['origin'], pool['view_direction'][:100])
 

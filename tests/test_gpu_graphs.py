@@ -199,6 +199,30 @@ def test_folded_weight_decay_gives_the_update_of_the_loss_term():
     assert float((plain - results[0][1]).abs().mean()) > 10 * float((results[2][1] - results[0][1]).abs().mean())
 
 
+def test_rebuilt_iteration_keeps_its_folded_weight_decay_when_the_old_one_goes():
+    """The usual rebuild -- `it = instant_ngp_iteration(..., n_rays=new)` -- constructs the successor before the old object is dropped; the old
+    object's close() / __del__ must remove only what IT installed (round-3 advisor finding: it used to clear the successor's slices, and the
+    weight decay silently disappeared for the rest of training)."""
+    import gc
+    from nerficg_amd.apex_optimizers import FusedAdam
+    from nerficg_amd.graphs import instant_ngp_iteration
+    cam, o, d = _rays()
+    model, renderer, _ = _train_pair(seed=4)
+    from nerficg_amd.amp import GradScaler
+    scaler = GradScaler(init_scale=128.0, growth_interval=10 ** 6)
+    opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
+    params = (model.encoding_xyz.params, model.color_mlp_with_encoding.params)
+    it = instant_ngp_iteration(model, renderer, opt, scaler, cam, n_rays=1024, sample_capacity=200_000, fold_weight_decay=True)
+    first = [opt._l2_slices[id(p)] for p in params]
+    it = instant_ngp_iteration(model, renderer, opt, scaler, cam, n_rays=2048, sample_capacity=400_000, fold_weight_decay=True)  # old object dies here
+    gc.collect()
+    for p, old in zip(params, first):
+        n, c = opt._l2_slice_of(p)
+        assert n > 0 and c == 1e-6 / model.n_mlp_params and opt._l2_slices[id(p)] is not old
+    it.close()
+    assert all(opt._l2_slice_of(p) == (0, 0.0) for p in params)
+
+
 def test_capture_without_a_sample_capacity_is_refused():
     from nerficg_amd import VolumeRenderingV2 as vr
     _, args = _march_inputs()

@@ -45,6 +45,13 @@ def test_fused_adam_flags():
     assert opt._l2_slice_of(q) == (0, 0.0) and id(q) not in opt._l2_slices
     opt.clear_l2_slices()
     assert opt._l2_slice_of(p) == (0, 0.0)
+    # a slice is removed by the token of whoever installed it: an owner that goes away AFTER its successor re-installed the slice on the same
+    # optimizer (rebuild of a recorded iteration with a new n_rays) must not take the successor's entry with it (round-3 advisor finding)
+    tok_a = opt.set_l2_slice(p, 3, 0.5)
+    tok_b = opt.set_l2_slice(p, 3, 0.25)
+    assert not opt.remove_l2_slice(p, tok_a) and opt._l2_slice_of(p) == (3, 0.25)
+    assert opt.remove_l2_slice(p, tok_b) and opt._l2_slice_of(p) == (0, 0.0)
+    assert not opt.remove_l2_slice(p, tok_b)
     with pytest.raises(RuntimeError, match='master_weights'):
         FusedAdam([p], master_weights=True)
     with pytest.raises(RuntimeError, match='AMSGrad'):
@@ -66,6 +73,29 @@ def test_fused_adam_group_lookup_and_saved_skips():
     opt2 = FusedAdam([{'params': [a], 'name': 'a'}, {'params': [b], 'name': 'b'}], lr=1e-3)
     opt2.load_state_dict(sd)
     assert opt2.effective_step(opt2.param_groups[1]) == 3 and 'skipped_steps' not in opt2.param_groups[1]
+
+
+def test_fused_adam_load_state_dict_updates_device_scalars_in_place():
+    """A recorded iteration holds raw pointers to the optimizer's device scalars: a load must write into them, not replace them, and a
+    non-capturable checkpoint (host step incl. skipped steps) becomes the effective step of the capturable mode (round-3 advisor finding)."""
+    from nerficg_amd.apex_optimizers import FusedAdam
+    a = torch.nn.Parameter(torch.zeros(4))
+    src = FusedAdam([a], lr=2e-3)
+    src.param_groups[0]['step'] = 9
+    src._amp[0] = (torch.full((1,), 2, dtype=torch.int32), torch.ones(2))
+    sd = src.state_dict()
+    assert sd['param_groups'][0]['step'] == 9 and sd['param_groups'][0]['skipped_steps'] == 2
+    cap = FusedAdam([a], lr=1e-3, capturable=True)
+    step_dev, skipped_dev, lr_dev = torch.zeros(1, dtype=torch.int32), torch.full((1,), 5, dtype=torch.int32), torch.full((1,), 1e-3)
+    cap.param_groups[0]['step'] = step_dev
+    cap._amp[0] = (skipped_dev, torch.ones(2))
+    cap._lr_dev[0] = [lr_dev, 1e-3]
+    cap.load_state_dict(sd)
+    assert cap.param_groups[0]['step'] is step_dev and int(step_dev) == 7          # 9 host steps, 2 of them skipped
+    assert cap._amp[0][0] is skipped_dev and int(skipped_dev) == 0
+    assert cap._lr_dev[0][0] is lr_dev and abs(float(lr_dev) - 2e-3) < 1e-9 and cap._lr_dev[0][1] == 2e-3
+    sd2 = cap.state_dict()
+    assert sd2['param_groups'][0]['step'] == 7 and sd2['param_groups'][0]['skipped_steps'] == 0
 
 
 def test_graphed_iteration_close_runs_its_hooks():
