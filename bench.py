@@ -58,6 +58,111 @@ def build_scene(device):
     return model, renderer, cam, poses
 
 
+C4_W, C4_H = 1600, 1060       # BASELINE configs[3]: InstantNGP on Mip-NeRF360 garden, 1600x1060 rays
+
+
+def build_c4_scene(device):
+    """The garden-SHAPED workload of BASELINE configs[3] (no dataset on the box): SCALE 2 -> three occupancy cascades (InstantNGP/Model.py:46-52),
+    EXPONENTIAL_STEPS -> exp_step_factor 1/256 (Renderer.py:44), content in every cascade (ball, two shells: tests/scenes.layered_bitfield), a
+    1600x1060 camera INSIDE the box on a seeded orbit between the shells, random-init networks (seed 0)."""
+    import torch
+    from nerficg_amd.instant_ngp import Camera, InstantNGPModel, InstantNGPRenderer
+    from tests import scenes
+    model = InstantNGPModel(SCALE=2.0, RANDOM_SEED=0, device=device)
+    with torch.no_grad():
+        model.occupancy_bitfield.copy_(torch.from_numpy(scenes.layered_bitfield(2.0, model.cascades)).to(device))
+    renderer = InstantNGPRenderer(model, EXPONENTIAL_STEPS=True)
+    cam = Camera(width=C4_W, height=C4_H, focal_x=0.9 * C4_W, focal_y=0.9 * C4_W, center_x=C4_W / 2, center_y=C4_H / 2, near_plane=0.2, far_plane=1000.0,
+                 background_color=torch.ones(3))
+    rng = np.random.default_rng(4)
+    poses = [scenes.orbit_pose(float(rng.uniform(0, 2 * math.pi)), float(rng.uniform(-0.3, 0.6)), 1.15) for _ in range(N_POSES)]
+    return model, renderer, cam, poses
+
+
+def strong_scaling_frames(renderer, cam, poses, rank, world, steps, warmup, barrier, red_dev):
+    """`--scaling strong` / the `config_c4` entry: ONE 1600x1060 frame per step, cut into `world` contiguous tile shards
+    (parallel.shard_range + render_image_fused(tile_begin, n_tiles): the protocol of scripts/inference.py:63-97 with the frame as the unit),
+    followed by the all-gather of the (N / world, 5) pixel blocks (parallel.gather_image_shards) so that every rank holds the frame.
+    Timing contract of the driver: barrier + synchronize on both sides of exactly `steps` frames, max over ranks."""
+    import torch
+    import torch.distributed as dist
+    from nerficg_amd import parallel
+    nt = renderer.n_image_tiles(cam)
+    b, e = parallel.shard_range(nt, rank, world)
+    cache = {}
+    ev = []
+    samples = 0
+
+    def frame(i, timed):
+        nonlocal samples
+        out = renderer.render_image_fused(cam, poses[i % N_POSES], tile_begin=b, n_tiles=e - b, return_stats=True)
+        if timed:
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+        parallel.gather_image_shards(out, cam.width, cam.height, nt, cache=cache)
+        if timed:
+            a1.record()
+            ev.append((a0, a1))
+            samples += out['n_samples']
+        return out
+
+    for i in range(warmup):
+        frame(i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = frame(warmup + i, True)
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0          # this rank's render + gather, before waiting for the others
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gather_ms = sum(a.elapsed_time(c) for a, c in ev) / max(steps, 1)
+    finite = bool(torch.isfinite(out['rgb']).all())
+    vals = torch.tensor([elapsed, t_local, gather_ms], device=red_dev, dtype=torch.float64)
+    tot = torch.tensor([samples], device=red_dev, dtype=torch.int64)
+    if world > 1:
+        mx = vals.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        mn = vals.clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        dist.all_reduce(tot)
+    else:
+        mx = mn = vals
+    rays = cam.width * cam.height
+    gathered = rays * 5 * 4 * (world - 1) // world if world > 1 else 0    # bytes a rank RECEIVES per frame
+    return {'elapsed': float(mx[0]), 'ms_per_frame': round(float(mx[0]) / steps * 1e3, 4), 'mrays_per_s': round(rays * steps / float(mx[0]) / 1e6, 3),
+            'per_rank_ms_max': round(float(mx[1]) / steps * 1e3, 4), 'per_rank_ms_min': round(float(mn[1]) / steps * 1e3, 4),
+            'gather_ms_max': round(float(mx[2]), 4) if world > 1 else None, 'bytes_gathered_per_rank_per_frame': gathered,
+            'tiles_per_rank': e - b, 'tiles': nt, 'samples_per_ray': round(int(tot[0]) / (rays * steps), 3), 'samples': int(tot[0]), 'finite': finite,
+            'collective': (f'all_gather of padded (rays / {world}, 5) f32 pixel blocks over {dist.get_backend()}' if world > 1 else None)}
+
+
+def nerf_c1_cpu_baseline(size=64, threads=None):
+    """BASELINE configs[0] / SURVEY 8(d) C1: vanilla NeRF (configs/nerf_lego.yaml: 8 x 256 MLP, 64 coarse + 192 fine samples, near 2, far 6,
+    white background), a size x size lego-intrinsics image through nerficg_amd.nerf -- the pure-PyTorch statement of src/Methods/NeRF/Renderer.py:132
+    -- on the HOST cores (the reference's own CPU mode, GLOBAL.GPU_INDICES: null).  No kernel of this repository runs: it is the number BASELINE.md 3.1
+    wants beside every GPU number."""
+    import torch
+    from nerficg_amd import nerf
+    from tests import scenes
+    before = torch.get_num_threads()
+    threads = threads or min(os.cpu_count() or 1, 32)   # torch's CPU GEMMs stop scaling (and regress) far below 256 threads
+    torch.set_num_threads(threads)
+    try:
+        torch.manual_seed(0)
+        coarse, fine = nerf.NeRFBlock(), nerf.NeRFBlock()
+        fx, fy, cx, cy = scenes.lego_intrinsics(size, size)
+        c2w = np.eye(4); c2w[2, 3] = -4.0
+        o, d, vd = (torch.from_numpy(a) for a in scenes.numpy_rays(size, size, c2w, fx, fy, cx, cy))
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = nerf.render_rays(coarse, fine, o, d, vd, 2.0, 6.0, torch.ones(3), ray_batch_size=8192, n_samples_coarse_nerf=64, n_samples_nerf=192)
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(before)
+    return {'value': round(size * size / dt / 1e3, 4), 'unit': 'Krays/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{size}x{size} image, 64 + 192 samples per ray, 8x256 MLPs, nerficg_amd.nerf (pure PyTorch, = src/Methods/NeRF) on {threads} host threads, {dt:.2f} s',
+            'finite': bool(torch.isfinite(out['rgb']).all())}
+
+
 def time_dominant_kernel(renderer, cam, pose_list, reps=2):
     """Launch durations of the dominant kernel (k_grid_encode: 128 hash-grid gathers per sample) and of its partner (k_ngp_mlp) over ALL
     chunks (launches) of the images of `pose_list` -- the poses the timed region rendered --, measured with HIP events on the launch stream
@@ -268,29 +373,52 @@ def gs_cpu_baseline(n=1_000_000, w=GS_W, h=GS_H):
                       f'fwd {t_f:.2f} s + bwd {t_b:.2f} s'}
 
 
-def cpu_baseline(cam_full, pose, model_params, crop=160):
-    """The CPU oracle (kind "port": the reference has no CPU path for InstantNGP) on a bounded sample: a crop x crop central
-    window of the same camera/pose/scene, all host cores (OpenMP in the encode/MLP loops)."""
+def cpu_baseline(cam_full, pose, model_params, crop=200):
+    """The CPU oracle (kind "port": the reference has no CPU path for InstantNGP) on a bounded sample: a crop x crop central window of the same
+    camera / pose / scene on ALL host cores -- every stage is OpenMP-parallel over rays or samples (march, hash-grid encode, both MLPs,
+    compositing), fp16 roundings through F16C.  `scaling`: the encode + MLP leg (98 % of the work) on one thread (a 1/32 sub-sample) and on
+    all threads, so that the line says what the threads bought."""
     import oracle
     from tests import scenes
     pd, pc, bitfield = model_params
     fx, fy, cx, cy = scenes.lego_intrinsics(W, H)
-    # central crop = same rays as the full image's centre window
-    o, _, d = scenes.numpy_rays(crop, crop, pose, fx, fy, cx - (W - crop) / 2, cy - (H - crop) / 2)
-    t0 = time.perf_counter()
-    _, ht, _ = oracle.ray_aabb_intersect(o, d, np.zeros((1, 3), np.float32), np.full((1, 3), 0.5, np.float32), 1)
-    hits = ht[:, 0].copy()
-    hits[:, 0] = np.maximum(hits[:, 0], np.float32(0.2))
-    rays_a, xyzs, dirs, deltas, ts, counter = oracle.raymarching_train(o, d, hits, bitfield, 1, 0.5, 0.0, np.zeros(len(o), np.float32), 128, 1024)
-    x01 = (xyzs + np.float32(0.5)) / np.float32(1.0)
-    sig, rgb, _ = oracle.ngp_query(x01, dirs, pd[:3072], pc, pd[3072:].reshape(-1, 2), n_levels=16, log2_hashmap_size=19, base_resolution=16,
-                                   per_level_scale=float(math.exp(math.log(2048 * 1.0 / 16) / 15)))
-    oracle.composite_train_fw(sig, rgb, deltas, ts, rays_a, 1e-4)
-    dt = time.perf_counter() - t0
     cores = os.cpu_count() or 1
+    before = oracle.set_threads(0)
+    grid_kw = dict(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=float(math.exp(math.log(2048 * 1.0 / 16) / 15)))
+    try:
+        # central crop = same rays as the full image's centre window
+        o, _, d = scenes.numpy_rays(crop, crop, pose, fx, fy, cx - (W - crop) / 2, cy - (H - crop) / 2)
+        t0 = time.perf_counter()
+        _, ht, _ = oracle.ray_aabb_intersect(o, d, np.zeros((1, 3), np.float32), np.full((1, 3), 0.5, np.float32), 1)
+        hits = ht[:, 0].copy()
+        hits[:, 0] = np.maximum(hits[:, 0], np.float32(0.2))
+        rays_a, xyzs, dirs, deltas, ts, counter = oracle.raymarching_train(o, d, hits, bitfield, 1, 0.5, 0.0, np.zeros(len(o), np.float32), 128, 1024)
+        t_march = time.perf_counter() - t0
+        x01 = (xyzs + np.float32(0.5)) / np.float32(1.0)
+        t1 = time.perf_counter()
+        sig, rgb, _ = oracle.ngp_query(x01, dirs, pd[:3072], pc, pd[3072:].reshape(-1, 2), **grid_kw)
+        t_query = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        oracle.composite_train_fw(sig, rgb, deltas, ts, rays_a, 1e-4)
+        t_comp = time.perf_counter() - t2
+        dt = time.perf_counter() - t0
+        n_all = int(counter[0])
+        sub = slice(0, max(n_all // 32, 1))
+        oracle.set_threads(1)
+        t3 = time.perf_counter()
+        oracle.ngp_query(x01[sub], dirs[sub], pd[:3072], pc, pd[3072:].reshape(-1, 2), **grid_kw)
+        t_one = time.perf_counter() - t3
+    finally:
+        oracle.set_threads(before)
+    n_sub = len(x01[sub])
+    one, allc = n_sub / t_one / 1e6, n_all / t_query / 1e6
     return {'value': round(len(o) / dt / 1e6, 6), 'unit': 'Mrays/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{crop}x{crop} central crop of one 800x800 pose ({len(o)} rays, {int(counter[0])} samples), oracle/*.c with OpenMP, {dt:.2f} s',
-            'msamples_per_s': round(int(counter[0]) / dt / 1e6, 4)}
+            'sample': f'{crop}x{crop} central crop of one 800x800 pose ({len(o)} rays, {n_all} samples), oracle/*.c with OpenMP in every stage '
+                      f'(F16C conversions: {oracle.has_f16c()}), {dt:.2f} s = march {t_march:.2f} + encode/MLP {t_query:.2f} + composite {t_comp:.2f}',
+            'msamples_per_s': round(n_all / dt / 1e6, 4),
+            'scaling': {'leg': 'hash-grid encode + both MLPs (oracle.ngp_query)', 'msamples_per_s_1_thread': round(one, 4), 'msamples_per_s_all_threads': round(allc, 4),
+                        'threads': cores, 'speedup': round(allc / one, 2), 'speedup_per_core': round(allc / one / cores, 3),
+                        'one_thread_sample': f'{n_sub} samples, {t_one:.2f} s'}}
 
 
 def time_train(model, renderer, cam, poses, n_rays=2200, iters=60):
@@ -624,6 +752,9 @@ def main():
     ap.add_argument('--no-dp', action='store_true', help='skip the data-parallel training legs (gradient collectives over RCCL)')
     ap.add_argument('--gs-gaussians', type=int, default=1_000_000)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the code path)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak (default, the headline): every rank renders its own 800x800 frame per step; strong: ONE 1600x1060 garden-shaped frame per step '
+                         'cut into contiguous tile shards over the ranks + all-gather of the pixels (BASELINE configs[3])')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -653,15 +784,38 @@ def main():
             dist.init_process_group(args.backend)
     red_dev = device if args.backend == 'nccl' else torch.device('cpu')  # where the tiny timing reductions live
 
-    model, renderer, cam, poses = build_scene(device)
-
-    def step(i):
-        return renderer.render_image_fused(cam, poses[(i * world + rank) % N_POSES], return_stats=True)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.scaling == 'strong':
+        c4_model, c4_renderer, c4_cam, c4_poses = build_c4_scene(device)
+        import gc
+        gc.collect(); gc.disable()
+        r = strong_scaling_frames(c4_renderer, c4_cam, c4_poses, rank, world, args.steps, args.warmup, barrier, red_dev)
+        gc.enable()
+        if rank == 0:
+            elapsed = r.pop('elapsed')
+            print(json.dumps({
+                'metric': 'Mrays/s (INGP garden-shaped frame, strong scaling)', 'value': r['mrays_per_s'], 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps,
+                'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+                'dtype': 'f16 (tables, weights, activations) / f32 (accumulate, march, composite)', 'data': 'synthetic',
+                'config': {'workload': f'ingp_garden_shape: ONE {C4_W}x{C4_H} frame per step ({C4_W * C4_H} rays) cut into {world} contiguous tile shards, SCALE 2 '
+                                       '(3 occupancy cascades, content in each), exponential steps 1/256, camera inside the box, random-init hash grid + MLPs seed 0; '
+                                       'every rank ends with the whole frame (all-gather of (rays / N, 5) pixel blocks)',
+                           'rays_per_step': C4_W * C4_H, 'samples_per_ray': r['samples_per_ray'], 'parallelism': f'tiles of one frame x{world} (strong)'},
+                'strong': r, 'roofline': None, 'cpu_baseline': None,
+                'note': 'roofline / cpu_baseline are carried by the default (weak, N = 1) line: same kernels, same per-sample rate'}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    model, renderer, cam, poses = build_scene(device)
+
+    def step(i):
+        return renderer.render_image_fused(cam, poses[(i * world + rank) % N_POSES], return_stats=True)
 
     samples = 0
     for i in range(args.warmup):
@@ -806,6 +960,29 @@ def main():
             except Exception as e:  # never lose the headline line over the extra leg
                 result['training'] = {'error': repr(e)[:200]}
         result['dp_training'] = dp
+        # BASELINE configs[3] shape on this one GPU (the single-rank point of `--scaling strong`) and one of eight shards of the same frames
+        if world == 1:
+            try:
+                torch.cuda.empty_cache()
+                c4_model, c4_renderer, c4_cam, c4_poses = build_c4_scene(device)
+                whole = strong_scaling_frames(c4_renderer, c4_cam, c4_poses, 0, 1, 5, 2, barrier, red_dev)
+                nt = c4_renderer.n_image_tiles(c4_cam)
+                from nerficg_amd import parallel as _par
+                b3, e3 = _par.shard_range(nt, 3, 8)
+                for i in range(2):
+                    c4_renderer.render_image_fused(c4_cam, c4_poses[i], tile_begin=b3, n_tiles=e3 - b3)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for i in range(5):
+                    c4_renderer.render_image_fused(c4_cam, c4_poses[2 + i], tile_begin=b3, n_tiles=e3 - b3)
+                torch.cuda.synchronize(); dt_shard = (time.perf_counter() - t0) / 5
+                whole.pop('elapsed', None)
+                result['config_c4'] = {'workload': f'{C4_W}x{C4_H} garden-shaped frame (3 cascades, exponential steps), one GPU', **whole,
+                                       'one_of_eight_shards_ms': round(dt_shard * 1e3, 4), 'one_of_eight_shards_tiles': e3 - b3,
+                                       'strong_scaling': 'python bench.py --gpus N --scaling strong'}
+                del c4_model, c4_renderer
+                torch.cuda.empty_cache()
+            except Exception as e:
+                result['config_c4'] = {'error': repr(e)[:300]}
         result['cpu_baseline'] = None  # timed on rank 0 of single-GPU runs only (the host cores are shared by all ranks otherwise)
         if not args.no_cpu_baseline and world == 1:
             if gs_res is not None:
@@ -813,6 +990,10 @@ def main():
             pd = model.encoding_xyz.params.detach().half().float().cpu().numpy()
             pc = model.color_mlp_with_encoding.params.detach().half().float().cpu().numpy()
             result['cpu_baseline'] = cpu_baseline(cam, poses[0], (pd, pc, model.occupancy_bitfield.cpu().numpy()))
+            try:
+                result['cpu_baseline_c1'] = nerf_c1_cpu_baseline()
+            except Exception as e:
+                result['cpu_baseline_c1'] = {'error': repr(e)[:300]}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

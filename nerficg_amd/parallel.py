@@ -31,16 +31,35 @@ import torch.distributed as dist
 from .amp import GradScaler as _FastGradScaler
 
 __all__ = ['init_distributed', 'world_info', 'shard_ray_ids', 'shard_range', 'allreduce_flat', 'allreduce_gradients',
-           'all_gather_pixels', 'broadcast_parameters', 'sparse_allreduce_gradients', 'allreduce_densification_stats', 'synchronized_noise',
-           'allreduce_scalars', 'DataParallelGradScaler', 'rays_per_batch_update']
+           'all_gather_pixels', 'tile_pixel_indices', 'gather_image_shards', 'broadcast_parameters', 'sparse_allreduce_gradients', 'allreduce_densification_stats', 'synchronized_noise',
+           'allreduce_scalars', 'DataParallelGradScaler', 'rays_per_batch_update', 'single_rank_collectives']
 
 
-def init_distributed(backend: str | None = None, device: torch.device | None = None) -> tuple[int, int]:
-    """Initialises the default process group from the torchrun environment (RANK / WORLD_SIZE / MASTER_*). Returns (rank, world)."""
+_SINGLE_RANK_COLLECTIVES = False
+
+
+def single_rank_collectives(on: bool) -> None:
+    """Testing switch: with a process group of ONE rank, issue every collective of this module anyway (each is then a no-op sum / gather of
+    the rank's own data).  This is how the RCCL branches -- reduce_scatter_tensor, all_gather_into_tensor, the device_id initialisation -- are
+    executed on a box with a single GPU (tests/test_gpu_rccl.py); production runs never set it."""
+    global _SINGLE_RANK_COLLECTIVES
+    _SINGLE_RANK_COLLECTIVES = bool(on)
+
+
+def _no_collective(world: int) -> bool:
+    return world == 1 and not (_SINGLE_RANK_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
+def init_distributed(backend: str | None = None, device: torch.device | None = None, single_rank_group: bool = False) -> tuple[int, int]:
+    """Initialises the default process group from the torchrun environment (RANK / WORLD_SIZE / MASTER_*). Returns (rank, world).
+    `single_rank_group`: create the group for WORLD_SIZE = 1 too (see single_rank_collectives)."""
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', str(rank))
+        os.environ.setdefault('WORLD_SIZE', str(world))
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC only on this platform
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -80,13 +99,11 @@ def _has_tensor_collectives() -> bool:
     return dist.get_backend() != 'gloo'
 
 
-def allreduce_flat(buf: torch.Tensor, average: bool = True, single_rank_collective: bool = False) -> torch.Tensor:
+def allreduce_flat(buf: torch.Tensor, average: bool = True) -> torch.Tensor:
     """In-place sum (or mean) of a flat contiguous tensor over all ranks as reduce-scatter + all-gather (each of the 7 xGMI
-    links of a GPU then carries 1/world of the payload); one all_reduce on gloo.  Errors of a collective propagate.
-    `single_rank_collective`: in a one-rank process group the collectives are issued anyway (a no-op sum) -- how the RCCL branch is
-    exercised on a box with one GPU (tests/test_gpu_rccl.py); without a process group it stays the identity."""
+    links of a GPU then carries 1/world of the payload); one all_reduce on gloo.  Errors of a collective propagate."""
     rank, world = world_info()
-    if world == 1 and not (single_rank_collective and dist.is_available() and dist.is_initialized()):
+    if _no_collective(world):
         return buf
     if not _has_tensor_collectives():
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
@@ -111,7 +128,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = Tr
     parameters (48.8 MB hash table + MLP, 28 KB colour MLP) -> one bucket; 3DGS: 59 floats x P in 5 tensors -> 1.4 GB at 6 M
     Gaussians in 256 MB buckets."""
     rank, world = world_info()
-    if world == 1:
+    if _no_collective(world):
         return
     grads = [p.grad for p in params if p.grad is not None]
     bucket, size = [], 0
@@ -143,7 +160,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = Tr
 def all_gather_pixels(local: torch.Tensor, counts: list[int]) -> torch.Tensor:
     """Concatenates per-rank pixel blocks of different lengths (dim 0) on every rank."""
     rank, world = world_info()
-    if world == 1:
+    if _no_collective(world):
         return local
     m = max(counts)
     padded = local if local.shape[0] == m else torch.cat([local, local.new_zeros((m - local.shape[0],) + tuple(local.shape[1:]))])
@@ -152,10 +169,53 @@ def all_gather_pixels(local: torch.Tensor, counts: list[int]) -> torch.Tensor:
     return torch.cat([o[:c] for o, c in zip(out, counts)])
 
 
+def tile_pixel_indices(width: int, height: int, tile_begin: int, n_tiles: int, tile_w: int = 8, tile_h: int = 8, device=None) -> torch.Tensor:
+    """Flat pixel indices (y * width + x, int64) of the image pixels inside the tiles [tile_begin, tile_begin + n_tiles) of the row-major tile
+    grid render_image_fused shards over, in tile order then row-major inside a tile; pixels of border tiles that fall outside the image are
+    left out.  A pure function of the frame shape, so every rank can compute every other rank's list (and its length) without a message."""
+    gx = (width + tile_w - 1) // tile_w
+    t = torch.arange(tile_begin, tile_begin + n_tiles, dtype=torch.int64, device=device)
+    ty, tx = t // gx, t % gx
+    py = (ty[:, None, None] * tile_h + torch.arange(tile_h, dtype=torch.int64, device=device)[None, :, None]).expand(-1, tile_h, tile_w)
+    px = (tx[:, None, None] * tile_w + torch.arange(tile_w, dtype=torch.int64, device=device)[None, None, :]).expand(-1, tile_h, tile_w)
+    ok = (py < height) & (px < width)
+    return (py * width + px)[ok]
+
+
+def gather_image_shards(out: dict[str, torch.Tensor], width: int, height: int, n_tiles: int, tile_w: int = 8, tile_h: int = 8,
+                        cache: dict | None = None) -> dict[str, torch.Tensor]:
+    """One frame rendered as contiguous tile shards (shard_range over the ranks; render_image_fused(tile_begin, n_tiles) wrote this rank's pixels
+    into the flat (H*W, C) buffers of `out`): packs this rank's pixels as (n_r, 5) rows [r, g, b, alpha, depth], all-gathers the blocks
+    ("all-gather of (N / world, 5)") and scatters every other rank's block into `out`, so that every rank ends with the whole
+    frame.  `cache`: a dict the caller keeps per frame shape (the index lists are static).  world = 1: nothing to do."""
+    rank, world = world_info()
+    if _no_collective(world):
+        return out
+    dev = out['rgb'].device
+    key = (width, height, n_tiles, world, str(dev))
+    if cache is None or cache.get('key') != key:
+        idx = [tile_pixel_indices(width, height, *(lambda b, e: (b, e - b))(*shard_range(n_tiles, r, world)), tile_w, tile_h, dev) for r in range(world)]
+        entry = {'key': key, 'idx': idx, 'counts': [int(i.numel()) for i in idx]}
+        if cache is not None:
+            cache.clear(); cache.update(entry)
+    else:
+        entry = cache
+    mine = entry['idx'][rank]
+    local = torch.cat([out['rgb'][mine], out['alpha'][mine, None], out['depth'][mine, None]], dim=1)
+    full = all_gather_pixels(local, entry['counts'])
+    off = 0
+    for r, (ids, c) in enumerate(zip(entry['idx'], entry['counts'])):
+        if r != rank:
+            block = full[off:off + c]
+            out['rgb'][ids] = block[:, :3]; out['alpha'][ids] = block[:, 3]; out['depth'][ids] = block[:, 4]
+        off += c
+    return out
+
+
 def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0) -> None:
     """Makes every rank start from rank `src`'s parameters (seeded init is already identical; this guards checkpoints)."""
     rank, world = world_info()
-    if world == 1:
+    if _no_collective(world):
         return
     for p in params:
         dist.broadcast(p.data if isinstance(p, torch.nn.Parameter) else p, src)
@@ -169,7 +229,7 @@ def sparse_allreduce_gradients(params: Iterable[torch.nn.Parameter], visible: to
     unpack.  Payload: n_union x 236 B instead of P x 236 B (59 floats per Gaussian).  Returns n_union (-1 in a single-process run)."""
     rank, world = world_info()
     params = list(params)
-    if world == 1:
+    if _no_collective(world):
         return -1  # nothing travels; the count of visible rows would cost a host read per step
     # world > 1: EVERY rank enters both collectives whatever it holds -- a rank whose view produced no gradient (p.grad is None) contributes
     # zero rows of the right width and receives the others' sum; an early return here would leave the other ranks waiting in the all-reduce
@@ -209,7 +269,7 @@ def allreduce_scalars(sums: Iterable[torch.Tensor] = (), flags: Iterable[torch.T
     dev = (sums + flags)[0].device
     pack = torch.stack([t.detach().reshape(-1)[0].to(device=dev, dtype=torch.float64) for t in sums + flags])
     rank, world = world_info()
-    if world > 1:
+    if not _no_collective(world):
         dist.all_reduce(pack, op=dist.ReduceOp.SUM)
     out_sums = [pack[i] for i in range(len(sums))]
     out_flags = [(pack[len(sums) + j] > 0).to(torch.float32) for j in range(len(flags))]
@@ -277,7 +337,7 @@ def allreduce_densification_stats(gaussians) -> None:
     """Sums densification_gradient_accum / n_observations (GaussianSplatting/Model.py:243-246) over the ranks; call right before
     densify_and_prune so that every rank classifies from the statistics of ALL views since the last densification."""
     rank, world = world_info()
-    if world == 1:
+    if _no_collective(world):
         return
     dist.all_reduce(gaussians.densification_gradient_accum, op=dist.ReduceOp.SUM)
     dist.all_reduce(gaussians.n_observations, op=dist.ReduceOp.SUM)

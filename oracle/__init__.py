@@ -206,6 +206,20 @@ def round_half(a):
     return np.asarray(a, f32).astype(np.float16).astype(f32)
 
 
+def round_half_c(a, soft=False):
+    """The C library's fp16 round trip: F16C instructions when compiled in (has_f16c()), `soft=True` the bit-twiddled definition."""
+    a = _c(a, f32)
+    out = np.empty_like(a)
+    _call('oracle_round_to_half_soft' if soft else 'oracle_round_to_half', a, a.size, out)
+    return out
+
+
+def has_f16c() -> bool:
+    fn = lib().oracle_has_f16c
+    fn.restype = ctypes.c_int
+    return bool(fn())
+
+
 def grid_layout(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.3819128800):
     offsets = np.zeros(n_levels + 1, np.uint32)
     scales = np.zeros(n_levels, f32)
@@ -216,12 +230,19 @@ def grid_layout(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level
     return int(total), offsets, scales, res
 
 
-def grid_encode_fw(x01, table, n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.3819128800):
-    """x01 (M,3) f32 in [0,1]; table (entries,2) fp16-representable f32 -> (M, 2*n_levels) fp16-rounded f32."""
+def _half_flag(accumulate):
+    if accumulate not in ('float', 'half'):
+        raise ValueError("accumulate must be 'float' (the definition the HIP kernels are held to) or 'half' (model of upstream's __half sums)")
+    return _i(accumulate == 'half')
+
+
+def grid_encode_fw(x01, table, n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.3819128800, accumulate='float'):
+    """x01 (M,3) f32 in [0,1]; table (entries,2) fp16-representable f32 -> (M, 2*n_levels) fp16-rounded f32.
+    accumulate='half': fp16 weights and fp16 running sums (oracle_grid_encode_fw2)."""
     x01, table = _c(x01, f32), _c(table, f32)
     out = np.empty((x01.shape[0], 2 * n_levels), f32)
-    _call('oracle_grid_encode_fw', x01, x01.shape[0], table, _i(n_levels), _i(log2_hashmap_size), _i(base_resolution),
-          float(per_level_scale), out)
+    _call('oracle_grid_encode_fw2', x01, x01.shape[0], table, _i(n_levels), _i(log2_hashmap_size), _i(base_resolution),
+          float(per_level_scale), _half_flag(accumulate), out)
     return out
 
 
@@ -240,13 +261,14 @@ def sh4_encode(d01):
     return out
 
 
-def mlp_fw(x, W, n_in=32, width=64, n_hidden=1, n_out_pad=16, out_act=0, want_acts=False):
-    """x (M,n_in), W flat -- both fp16-representable f32. Returns out (M,n_out_pad) [, acts (n_hidden,M,width)]."""
+def mlp_fw(x, W, n_in=32, width=64, n_hidden=1, n_out_pad=16, out_act=0, want_acts=False, accumulate='float'):
+    """x (M,n_in), W flat -- both fp16-representable f32. Returns out (M,n_out_pad) [, acts (n_hidden,M,width)].
+    accumulate='half': running sums rounded to fp16 after every multiply-add (oracle_mlp_fw2)."""
     x, W = _c(x, f32), _c(W, f32)
     m = x.shape[0]
     out = np.empty((m, n_out_pad), f32)
     acts = np.empty((n_hidden, m, width), f32) if want_acts else None
-    _call('oracle_mlp_fw', x, m, W, _i(n_in), _i(width), _i(n_hidden), _i(n_out_pad), _i(out_act), out, acts)
+    _call('oracle_mlp_fw2', x, m, W, _i(n_in), _i(width), _i(n_hidden), _i(n_out_pad), _i(out_act), _half_flag(accumulate), out, acts)
     return (out, acts) if want_acts else out
 
 
@@ -259,15 +281,16 @@ def mlp_bw(x, W, out, acts, d_out, n_in=32, width=64, n_hidden=1, n_out_pad=16, 
     return dW, d_in
 
 
-def ngp_query(xyz01, dirs, Wd, Wc, table, **grid_kw):
+def ngp_query(xyz01, dirs, Wd, Wc, table, accumulate='float', **grid_kw):
     """InstantNGPRayRenderingComponent.query_model (src/Methods/InstantNGP/Renderer.py:48-53) on the oracle pieces:
-    h = density_net(grid(x)); sigma = exp(h[:,0]); rgb = color_net([SH4(fp16(d*.5+.5)) | h])[:, :3]."""
-    enc = grid_encode_fw(xyz01, table, **grid_kw)
-    h = mlp_fw(enc, Wd, n_hidden=1, out_act=0)
+    h = density_net(grid(x)); sigma = exp(h[:,0]); rgb = color_net([SH4(fp16(d*.5+.5)) | h])[:, :3].
+    accumulate='half': every running sum of the encoder and of the two MLPs in fp16 (the model of upstream tiny-cuda-nn's arithmetic)."""
+    enc = grid_encode_fw(xyz01, table, accumulate=accumulate, **grid_kw)
+    h = mlp_fw(enc, Wd, n_hidden=1, out_act=0, accumulate=accumulate)
     sigma = np.exp(h[:, 0].astype(f32))
     d01 = round_half(_c(dirs, f32) * f32(0.5) + f32(0.5))
     cin = np.concatenate([sh4_encode(d01), h], axis=1)
-    rgb = mlp_fw(cin, Wc, n_hidden=2, out_act=1)[:, :3]
+    rgb = mlp_fw(cin, Wc, n_hidden=2, out_act=1, accumulate=accumulate)[:, :3]
     return sigma.astype(f32), rgb, h
 
 

@@ -139,10 +139,16 @@ int64_t oracle_raymarching_train(const float* rays_o, const float* rays_d, const
                                  int cascades, float scale, float exp_step_factor, const float* noise, int grid_size,
                                  int max_samples, int64_t n_rays, int64_t* rays_a, float* xyzs, float* dirs, float* deltas,
                                  float* ts, int32_t* counter) {
-    int64_t total = 0;
+    /* Rays are independent: both passes run over the rays in parallel (OpenMP; bench.py's cpu_baseline uses every host core), the exclusive
+     * prefix sum of the counts between them is serial.  Per-ray arithmetic and the ray-index order of the outputs are unchanged. */
+    int32_t* cnt = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_rays > 0 ? n_rays : 1));
+    float* first_t = (float*)malloc(sizeof(float) * (size_t)(n_rays > 0 ? n_rays : 1));
+    int64_t* starts = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_rays > 0 ? n_rays : 1));
+#pragma omp parallel for schedule(dynamic, 64)
     for (int64_t r = 0; r < n_rays; r++) {
         const ray_t q = load_ray(rays_o, rays_d, r);
-        float t1 = hits_t[2 * r], t2 = hits_t[2 * r + 1];
+        float t1 = hits_t[2 * r];
+        const float t2 = hits_t[2 * r + 1];
         if (t1 >= 0) { /* R:195-198 */
             const float dt = calc_dt(t1, exp_step_factor, max_samples, grid_size, scale);
             t1 += dt * noise[r];
@@ -155,23 +161,37 @@ int64_t oracle_raymarching_train(const float* rays_o, const float* rays_d, const
             if (march_probe(&q, t, dt, bitfield, cascades, grid_size, scale, &x, &y, &z, &nx, &ny, &nz, &mb)) { t += dt; n_samples++; }
             else t = march_skip(&q, t, x, y, z, nx, ny, nz, mb, exp_step_factor, max_samples, grid_size, scale);
         }
-        const int64_t start = total; total += n_samples;
-        if (rays_a) { rays_a[3 * r] = r; rays_a[3 * r + 1] = start; rays_a[3 * r + 2] = n_samples; }
-        if (!xyzs) continue;
-        /* second pass R:243-279 */
-        t = t1; int s = 0;
-        while (t < t2 && s < n_samples) {
-            float x, y, z, mb; int nx, ny, nz;
-            const float dt = calc_dt(t, exp_step_factor, max_samples, grid_size, scale);
-            if (march_probe(&q, t, dt, bitfield, cascades, grid_size, scale, &x, &y, &z, &nx, &ny, &nz, &mb)) {
-                const int64_t k = start + s;
-                xyzs[3 * k] = x; xyzs[3 * k + 1] = y; xyzs[3 * k + 2] = z;
-                dirs[3 * k] = q.dx; dirs[3 * k + 1] = q.dy; dirs[3 * k + 2] = q.dz;
-                ts[k] = t; deltas[k] = dt;
-                t += dt; s++;
-            } else t = march_skip(&q, t, x, y, z, nx, ny, nz, mb, exp_step_factor, max_samples, grid_size, scale);
+        cnt[r] = n_samples; first_t[r] = t1;
+    }
+    int64_t total = 0;
+    for (int64_t r = 0; r < n_rays; r++) { starts[r] = total; total += cnt[r]; }
+    if (rays_a) {
+#pragma omp parallel for schedule(static)
+        for (int64_t r = 0; r < n_rays; r++) { rays_a[3 * r] = r; rays_a[3 * r + 1] = starts[r]; rays_a[3 * r + 2] = cnt[r]; }
+    }
+    if (xyzs) {
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t r = 0; r < n_rays; r++) {
+            /* second pass R:243-279 */
+            const ray_t q = load_ray(rays_o, rays_d, r);
+            const float t2 = hits_t[2 * r + 1];
+            const int64_t start = starts[r];
+            const int n_samples = cnt[r];
+            float t = first_t[r]; int s = 0;
+            while (t < t2 && s < n_samples) {
+                float x, y, z, mb; int nx, ny, nz;
+                const float dt = calc_dt(t, exp_step_factor, max_samples, grid_size, scale);
+                if (march_probe(&q, t, dt, bitfield, cascades, grid_size, scale, &x, &y, &z, &nx, &ny, &nz, &mb)) {
+                    const int64_t k = start + s;
+                    xyzs[3 * k] = x; xyzs[3 * k + 1] = y; xyzs[3 * k + 2] = z;
+                    dirs[3 * k] = q.dx; dirs[3 * k + 1] = q.dy; dirs[3 * k + 2] = q.dz;
+                    ts[k] = t; deltas[k] = dt;
+                    t += dt; s++;
+                } else t = march_skip(&q, t, x, y, z, nx, ny, nz, mb, exp_step_factor, max_samples, grid_size, scale);
+            }
         }
     }
+    free(cnt); free(first_t); free(starts);
     if (counter) { counter[0] = (int32_t)total; counter[1] = (int32_t)n_rays; }
     return total;
 }
@@ -279,6 +299,8 @@ void oracle_composite_train_fw(const float* sigmas, const float* rgbs, const flo
                                int64_t* total_samples, float* opacity, float* depth, float* rgb, float* ws) {
     memset(total_samples, 0, sizeof(int64_t) * n_rays); memset(opacity, 0, sizeof(float) * n_rays);
     memset(depth, 0, sizeof(float) * n_rays); memset(rgb, 0, sizeof(float) * 3 * n_rays); memset(ws, 0, sizeof(float) * n_total);
+    /* one ray = one independent serial chain (V:6-45 is a thread per ray): parallel over rays, every ray writes its own outputs only */
+#pragma omp parallel for schedule(dynamic, 256)
     for (int64_t n = 0; n < n_rays; n++) {
         const int ray_idx = (int)rays_a[3 * n], start = (int)rays_a[3 * n + 1], N = (int)rays_a[3 * n + 2];
         int samples = 0; float T = 1.0f;

@@ -57,8 +57,20 @@ static inline float f16_bits_to_f32(uint16_t h) {
     float f; memcpy(&f, &x, 4);
     return f;
 }
-static inline float round_half(float f) { return f16_bits_to_f32(f32_to_f16_bits(f)); }
+static inline float round_half_soft(float f) { return f16_bits_to_f32(f32_to_f16_bits(f)); }
+/* The same rounding through the host's F16C conversion instructions when the compiler has them (oracle/Makefile: -mf16c): one instruction each
+ * way instead of ~25, which is most of what the CPU baseline of bench.py spent per value.  The bit-twiddled statement above stays the CHECKED
+ * definition: tests/test_oracle_tcnn.py compares the two on every binary16 boundary and on random bit patterns (oracle_round_to_half_soft). */
+#if defined(__F16C__)
+#include <immintrin.h>
+static inline float round_half(float f) { return _cvtsh_ss(_cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC)); }
+int oracle_has_f16c(void) { return 1; }
+#else
+static inline float round_half(float f) { return round_half_soft(f); }
+int oracle_has_f16c(void) { return 0; }
+#endif
 void oracle_round_to_half(const float* in, int64_t n, float* out) { for (int64_t i = 0; i < n; i++) out[i] = round_half(in[i]); }
+void oracle_round_to_half_soft(const float* in, int64_t n, float* out) { for (int64_t i = 0; i < n; i++) out[i] = round_half_soft(in[i]); }
 
 /* ------------------------------------------------------------------------------------------------ hash grid */
 #define MAX_LEVELS 32
@@ -97,15 +109,22 @@ static inline uint32_t grid_index(const uint32_t p[3], uint32_t res, uint32_t si
 }
 
 /* x (M,3) in [0,1]; table: (entries, 2) fp16-representable floats; out (M, 2*n_levels) = fp16-rounded features.
- * If w8/idx8 are non-NULL they receive the 8 trilinear weights / absolute entry indices per (sample, level). */
-void oracle_grid_encode_fw(const float* x, int64_t M, const float* table, int n_levels, int log2_hashmap_size,
-                           int base_resolution, float per_level_scale, float* out) {
+ * accumulate_half = 0 (the definition the HIP kernels are held to): f32 trilinear weights, f32 running sums, ONE fp16 rounding per feature.
+ * accumulate_half = 1: what upstream tiny-cuda-nn's kernel is understood to do when its parameters are __half (it computes
+ * `result += (T)weight * value` in T = __half; not verifiable here, the source is absent): the weight is rounded to fp16 and the running sum
+ * is rounded to fp16 after every one of the eight fused multiply-adds.  tests/test_oracle_tcnn.py reports the distance between the two. */
+void oracle_grid_encode_fw2(const float* x, int64_t M, const float* table, int n_levels, int log2_hashmap_size,
+                            int base_resolution, float per_level_scale, int accumulate_half, float* out) {
     uint32_t offsets[MAX_LEVELS + 1], res[MAX_LEVELS]; float scales[MAX_LEVELS];
     oracle_grid_layout(n_levels, log2_hashmap_size, base_resolution, per_level_scale, offsets, scales, res);
+    /* Level-synchronous order: all threads work through level l of all samples before anyone touches level l + 1, so the 4 MB slice of
+     * the table that a hashed level gathers from stays in the last-level caches of every core complex while it is in use (sample-major, every
+     * gather of the 49 MB table went to DRAM -- and on a two-socket host to the other socket half of the time).  Each (sample, level) pair is
+     * computed exactly as before; only the order of independent pairs changes. */
+    for (int l = 0; l < n_levels; l++) {
+        const uint32_t size = offsets[l + 1] - offsets[l];
 #pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < M; i++) {
-        for (int l = 0; l < n_levels; l++) {
-            const uint32_t size = offsets[l + 1] - offsets[l];
+        for (int64_t i = 0; i < M; i++) {
             float frac[3]; uint32_t g[3];
             for (int d = 0; d < 3; d++) {
                 const float p = fmaf(scales[l], x[3 * i + d], 0.5f);
@@ -119,13 +138,23 @@ void oracle_grid_encode_fw(const float* x, int64_t M, const float* table, int n_
                     if (c & (1 << d)) { w *= frac[d]; q[d] = g[d] + 1; } else { w *= 1.f - frac[d]; q[d] = g[d]; }
                 }
                 const uint32_t e = offsets[l] + grid_index(q, res[l], size);
-                acc0 = fmaf(w, table[2 * (int64_t)e], acc0);
-                acc1 = fmaf(w, table[2 * (int64_t)e + 1], acc1);
+                if (accumulate_half) {
+                    w = round_half(w);
+                    acc0 = round_half(fmaf(w, table[2 * (int64_t)e], acc0));
+                    acc1 = round_half(fmaf(w, table[2 * (int64_t)e + 1], acc1));
+                } else {
+                    acc0 = fmaf(w, table[2 * (int64_t)e], acc0);
+                    acc1 = fmaf(w, table[2 * (int64_t)e + 1], acc1);
+                }
             }
             out[i * 2 * n_levels + 2 * l] = round_half(acc0);
             out[i * 2 * n_levels + 2 * l + 1] = round_half(acc1);
         }
     }
+}
+void oracle_grid_encode_fw(const float* x, int64_t M, const float* table, int n_levels, int log2_hashmap_size,
+                           int base_resolution, float per_level_scale, float* out) {
+    oracle_grid_encode_fw2(x, M, table, n_levels, log2_hashmap_size, base_resolution, per_level_scale, 0, out);
 }
 
 /* scatter-add of d_out (M, 2*n_levels) f32 into grad_table (entries,2) f32 (zeroed by the caller) */
@@ -188,30 +217,63 @@ void oracle_sh4_encode(const float* d01, int64_t M, float* out) {
 /* ------------------------------------------------------------------------------------------------ MLP */
 /* in (M,n_in) fp16-representable; W = [W0 (width,n_in) | hidden (width,width)*(n_hidden-1) | Wout (n_out_pad,width)] row-major,
  * fp16-representable.  out_act: 0 none, 1 sigmoid.  out (M,n_out_pad) fp16-rounded.  acts (optional) receives the
- * post-ReLU hidden activations, (n_hidden, M, width). */
-void oracle_mlp_fw(const float* in, int64_t M, const float* W, int n_in, int width, int n_hidden, int n_out_pad, int out_act,
-                   float* out, float* acts) {
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < M; i++) {
-        float h[2][128];
-        const float* cur = in + i * n_in; int cur_n = n_in; const float* w = W;
-        for (int l = 0; l < n_hidden; l++) {
-            float* nxt = h[l & 1];
-            for (int o = 0; o < width; o++) {
-                float acc = 0.f;
-                for (int k = 0; k < cur_n; k++) acc = fmaf(w[o * cur_n + k], cur[k], acc);
-                nxt[o] = round_half(acc > 0.f ? acc : 0.f);
-            }
-            if (acts) memcpy(acts + ((int64_t)l * M + i) * width, nxt, sizeof(float) * width);
-            w += width * cur_n; cur = nxt; cur_n = width;
-        }
-        for (int o = 0; o < n_out_pad; o++) {
-            float acc = 0.f;
-            for (int k = 0; k < cur_n; k++) acc = fmaf(w[o * cur_n + k], cur[k], acc);
-            if (out_act == 1) acc = 1.0f / (1.0f + expf(-acc));
-            out[i * n_out_pad + o] = round_half(acc);
+ * post-ReLU hidden activations, (n_hidden, M, width).
+ * Every output is the fused-multiply-add chain over k = 0, 1, ... of its weight row, as before; the loops run k-outer over a TRANSPOSED copy
+ * of the weights so that the chains of all outputs advance together (contiguous, the compiler vectorises them) -- the per-output order of the
+ * additions, and with it every bit of the result, is unchanged.
+ * accumulate_half = 1: the running sums are rounded to fp16 after every multiply-add -- a model of upstream tiny-cuda-nn's FullyFusedMLP,
+ * whose tensor-core products accumulate in __half (not verifiable here; see oracle_grid_encode_fw2). */
+void oracle_mlp_fw2(const float* in, int64_t M, const float* W, int n_in, int width, int n_hidden, int n_out_pad, int out_act,
+                    int accumulate_half, float* out, float* acts) {
+    int64_t n_w = 0; { int k = n_in; for (int l = 0; l < n_hidden; l++) { n_w += (int64_t)width * k; k = width; } n_w += (int64_t)n_out_pad * width; }
+    float* WT = (float*)malloc(sizeof(float) * (size_t)n_w);
+    { /* layer l: (rows x cols) row-major -> (cols x rows) */
+        const float* w = W; float* t = WT; int k = n_in;
+        for (int l = 0; l <= n_hidden; l++) {
+            const int rows = l < n_hidden ? width : n_out_pad;
+            for (int o = 0; o < rows; o++) for (int c = 0; c < k; c++) t[(int64_t)c * rows + o] = w[(int64_t)o * k + c];
+            w += (int64_t)rows * k; t += (int64_t)rows * k; k = width;
         }
     }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < M; i++) {
+        float h[2][128] __attribute__((aligned(64)));
+        float acc[128] __attribute__((aligned(64)));
+        const float* cur = in + i * n_in; int cur_n = n_in; const float* wt = WT;
+        for (int l = 0; l <= n_hidden; l++) {
+            const int rows = l < n_hidden ? width : n_out_pad;
+            for (int o = 0; o < rows; o++) acc[o] = 0.f;
+            if (accumulate_half) {
+                for (int k = 0; k < cur_n; k++) {
+                    const float c = cur[k]; const float* col = wt + (int64_t)k * rows;
+                    for (int o = 0; o < rows; o++) acc[o] = round_half(fmaf(col[o], c, acc[o]));
+                }
+            } else {
+                for (int k = 0; k < cur_n; k++) {
+                    const float c = cur[k]; const float* col = wt + (int64_t)k * rows;
+                    for (int o = 0; o < rows; o++) acc[o] = fmaf(col[o], c, acc[o]);
+                }
+            }
+            if (l < n_hidden) {
+                float* nxt = h[l & 1];
+                for (int o = 0; o < rows; o++) nxt[o] = round_half(acc[o] > 0.f ? acc[o] : 0.f);
+                if (acts) memcpy(acts + ((int64_t)l * M + i) * width, nxt, sizeof(float) * width);
+                cur = nxt; 
+            } else {
+                for (int o = 0; o < rows; o++) {
+                    float a = acc[o];
+                    if (out_act == 1) a = 1.0f / (1.0f + expf(-a));
+                    out[i * n_out_pad + o] = round_half(a);
+                }
+            }
+            wt += (int64_t)rows * cur_n; cur_n = width;
+        }
+    }
+    free(WT);
+}
+void oracle_mlp_fw(const float* in, int64_t M, const float* W, int n_in, int width, int n_hidden, int n_out_pad, int out_act,
+                   float* out, float* acts) {
+    oracle_mlp_fw2(in, M, W, n_in, width, n_hidden, n_out_pad, out_act, 0, out, acts);
 }
 /* d_out (M,n_out_pad) fp16-representable upstream gradient w.r.t. the (activated) output; out = forward output.
  * Produces dW (same layout as W, f32) and d_in (M,n_in) f32. Gradients entering a matrix product are rounded to fp16

@@ -36,6 +36,24 @@ def sphere_bitfield(grid_size: int = 128, scale: float = 0.5, radius: float = 0.
     return np.packbits(bits, bitorder='little')
 
 
+def layered_bitfield(scale: float, cascades: int, grid_size: int = 128) -> np.ndarray:
+    """Occupancy of a scene with content at three distances: a solid ball r < 0.3 (lives in cascade 0), a shell 0.62 <= r < 0.9 (beyond the
+    first cascade's box) and a shell 1.45 <= r < 1.8 with a polar cap removed (beyond the second); every cascade marks the cells whose CENTRE
+    lies in that set, at its own cell size -- all cascades are populated, and rays cross empty stretches in each of them."""
+    g = np.arange(grid_size)
+    x, y, z = np.meshgrid(g, g, g, indexing='ij')
+    idx = morton3d_np(x, y, z).reshape(-1)
+    bits = np.zeros(cascades * grid_size ** 3, dtype=bool)
+    for c in range(cascades):
+        bound = min(2.0 ** (c - 1), scale)
+        cx, cy, cz = (((a + 0.5) / grid_size * 2 - 1) * bound for a in (x, y, z))
+        r = np.sqrt(cx * cx + cy * cy + cz * cz)
+        occ = (r < 0.3) | ((r >= 0.62) & (r < 0.9) & (cx > -0.5)) | ((r >= 1.45) & (r < 1.8) & (cy < 1.2))
+        bits[c * grid_size ** 3 + idx] = occ.reshape(-1)
+        assert occ.any(), c
+    return np.packbits(bits, bitorder='little')
+
+
 def orbit_pose(theta: float, phi: float, radius: float) -> np.ndarray:
     """c2w (4x4 f64), camera on an orbit looking at the origin; x right, y down, z forward."""
     pos = np.array([radius * math.cos(phi) * math.cos(theta), radius * math.sin(phi), radius * math.cos(phi) * math.sin(theta)])

@@ -96,6 +96,30 @@ def test_flat_allreduce_and_ragged_pixel_gather():
     assert out[0][1] == [[0.0, 0.0]] * 3 + [[1.0, 1.0]] * 4 == out[1][1]
 
 
+def _t_frame_shards(rank, world):
+    """One frame cut into contiguous tile shards (BASELINE configs[3] decomposition): after gather_image_shards every rank holds every pixel."""
+    from nerficg_amd import parallel
+    w, h = 52, 29                      # 7 x 4 tiles of 8 x 8 pixels, the last column / row of tiles cut by the image border
+    nt = 7 * 4
+    truth = {'rgb': torch.arange(w * h * 3, dtype=torch.float32).reshape(w * h, 3), 'alpha': torch.arange(w * h, dtype=torch.float32) * 0.5,
+             'depth': torch.arange(w * h, dtype=torch.float32) * 0.25}
+    b, e = parallel.shard_range(nt)
+    mine = parallel.tile_pixel_indices(w, h, b, e - b)
+    out = {k: torch.full_like(v, -1.0) for k, v in truth.items()}
+    for k in out:
+        out[k][mine] = truth[k][mine]   # what render_image_fused(tile_begin=b, n_tiles=e - b, out=out) leaves
+    cache = {}
+    parallel.gather_image_shards(out, w, h, nt, cache=cache)
+    again = parallel.gather_image_shards(out, w, h, nt, cache=cache)   # cached index lists
+    return all(bool(torch.equal(again[k], truth[k])) for k in truth), cache['counts'], int(mine.numel())
+
+
+def test_frame_shards_gather_to_the_whole_frame():
+    out = _run(_t_frame_shards)
+    assert out[0][0] and out[1][0]
+    assert out[0][1] == out[1][1] and sum(out[0][1]) == 52 * 29 and out[0][2] == out[0][1][0] and out[1][2] == out[1][1][1]
+
+
 def _t_sparse_reduce(rank, world):
     """View-parallel 3DGS: each rank 'sees' another subset of 500 Gaussians; sparse reduction == dense all-reduce, rows seen by nobody stay 0."""
     from types import SimpleNamespace
