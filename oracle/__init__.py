@@ -281,8 +281,8 @@ def mlp_bw(x, W, out, acts, d_out, n_in=32, width=64, n_hidden=1, n_out_pad=16, 
     return dW, d_in
 
 
-def ngp_query(xyz01, dirs, Wd, Wc, table, accumulate='float', **grid_kw):
-    """InstantNGPRayRenderingComponent.query_model (src/Methods/InstantNGP/Renderer.py:48-53) on the oracle pieces:
+def ngp_query_staged(xyz01, dirs, Wd, Wc, table, accumulate='float', **grid_kw):
+    """InstantNGPRayRenderingComponent.query_model (src/Methods/InstantNGP/Renderer.py:48-53) assembled from the stage functions:
     h = density_net(grid(x)); sigma = exp(h[:,0]); rgb = color_net([SH4(fp16(d*.5+.5)) | h])[:, :3].
     accumulate='half': every running sum of the encoder and of the two MLPs in fp16 (the model of upstream tiny-cuda-nn's arithmetic)."""
     enc = grid_encode_fw(xyz01, table, accumulate=accumulate, **grid_kw)
@@ -292,6 +292,20 @@ def ngp_query(xyz01, dirs, Wd, Wc, table, accumulate='float', **grid_kw):
     cin = np.concatenate([sh4_encode(d01), h], axis=1)
     rgb = mlp_fw(cin, Wc, n_hidden=2, out_act=1, accumulate=accumulate)[:, :3]
     return sigma.astype(f32), rgb, h
+
+
+def ngp_query(xyz01, dirs, Wd, Wc, table, accumulate='float', n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.3819128800):
+    """The same composition as ngp_query_staged in ONE C call (oracle_ngp_query: one parallel loop over blocks of samples, no numpy glue
+    between the stages) -- what the tests and bench.py's cpu_baseline use; sigma differs from the staged form by libm-expf-vs-numpy-exp only
+    where those differ (tests/test_oracle_tcnn.py pins the two against each other)."""
+    xyz01, dirs, Wd, Wc, table = _c(xyz01, f32), _c(dirs, f32), _c(Wd, f32), _c(Wc, f32), _c(table, f32)
+    m = xyz01.shape[0]
+    if Wd.size != 32 * 64 + 64 * 16 or Wc.size != 32 * 64 + 64 * 64 + 64 * 16 or n_levels != 16:
+        raise ValueError('ngp_query: the fused call is written for the shipped configuration (16 levels x 2, 64 neurons, 16 density outputs)')
+    sigma, rgb, h = np.empty(m, f32), np.empty((m, 3), f32), np.empty((m, 16), f32)
+    _call('oracle_ngp_query', xyz01, dirs, m, Wd, Wc, table, _i(n_levels), _i(log2_hashmap_size), _i(base_resolution), float(per_level_scale),
+          _half_flag(accumulate), sigma, rgb, h)
+    return sigma, rgb, h
 
 
 # ------------------------------------------------------------------------------------------------ 3DGS rasterizer

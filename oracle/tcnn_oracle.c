@@ -223,53 +223,130 @@ void oracle_sh4_encode(const float* d01, int64_t M, float* out) {
  * additions, and with it every bit of the result, is unchanged.
  * accumulate_half = 1: the running sums are rounded to fp16 after every multiply-add -- a model of upstream tiny-cuda-nn's FullyFusedMLP,
  * whose tensor-core products accumulate in __half (not verifiable here; see oracle_grid_encode_fw2). */
+static int64_t mlp_weight_count(int n_in, int width, int n_hidden, int n_out_pad) {
+    int64_t n_w = 0; int k = n_in;
+    for (int l = 0; l < n_hidden; l++) { n_w += (int64_t)width * k; k = width; }
+    return n_w + (int64_t)n_out_pad * width;
+}
+/* layer l: (rows x cols) row-major -> (cols x rows) */
+static void mlp_transpose(const float* W, int n_in, int width, int n_hidden, int n_out_pad, float* WT) {
+    const float* w = W; float* t = WT; int k = n_in;
+    for (int l = 0; l <= n_hidden; l++) {
+        const int rows = l < n_hidden ? width : n_out_pad;
+        for (int o = 0; o < rows; o++) for (int c = 0; c < k; c++) t[(int64_t)c * rows + o] = w[(int64_t)o * k + c];
+        w += (int64_t)rows * k; t += (int64_t)rows * k; k = width;
+    }
+}
+/* one sample through the network (transposed weights WT); acts_i: this sample's slot of layer 0 in the (n_hidden, M, width) array or NULL */
+static inline void mlp_one(const float* in_i, const float* WT, int n_in, int width, int n_hidden, int n_out_pad, int out_act, int accumulate_half,
+                           float* out_i, float* acts_i, int64_t acts_layer_stride) {
+    float h[2][128] __attribute__((aligned(64)));
+    float acc[128] __attribute__((aligned(64)));
+    const float* cur = in_i; int cur_n = n_in; const float* wt = WT;
+    for (int l = 0; l <= n_hidden; l++) {
+        const int rows = l < n_hidden ? width : n_out_pad;
+        for (int o = 0; o < rows; o++) acc[o] = 0.f;
+        if (accumulate_half) {
+            for (int k = 0; k < cur_n; k++) {
+                const float c = cur[k]; const float* col = wt + (int64_t)k * rows;
+                for (int o = 0; o < rows; o++) acc[o] = round_half(fmaf(col[o], c, acc[o]));
+            }
+        } else {
+            for (int k = 0; k < cur_n; k++) {
+                const float c = cur[k]; const float* col = wt + (int64_t)k * rows;
+                for (int o = 0; o < rows; o++) acc[o] = fmaf(col[o], c, acc[o]);
+            }
+        }
+        if (l < n_hidden) {
+            float* nxt = h[l & 1];
+            for (int o = 0; o < rows; o++) nxt[o] = round_half(acc[o] > 0.f ? acc[o] : 0.f);
+            if (acts_i) memcpy(acts_i + (int64_t)l * acts_layer_stride, nxt, sizeof(float) * width);
+            cur = nxt;
+        } else {
+            for (int o = 0; o < rows; o++) {
+                float a = acc[o];
+                if (out_act == 1) a = 1.0f / (1.0f + expf(-a));
+                out_i[o] = round_half(a);
+            }
+        }
+        wt += (int64_t)rows * cur_n; cur_n = width;
+    }
+}
 void oracle_mlp_fw2(const float* in, int64_t M, const float* W, int n_in, int width, int n_hidden, int n_out_pad, int out_act,
                     int accumulate_half, float* out, float* acts) {
-    int64_t n_w = 0; { int k = n_in; for (int l = 0; l < n_hidden; l++) { n_w += (int64_t)width * k; k = width; } n_w += (int64_t)n_out_pad * width; }
-    float* WT = (float*)malloc(sizeof(float) * (size_t)n_w);
-    { /* layer l: (rows x cols) row-major -> (cols x rows) */
-        const float* w = W; float* t = WT; int k = n_in;
-        for (int l = 0; l <= n_hidden; l++) {
-            const int rows = l < n_hidden ? width : n_out_pad;
-            for (int o = 0; o < rows; o++) for (int c = 0; c < k; c++) t[(int64_t)c * rows + o] = w[(int64_t)o * k + c];
-            w += (int64_t)rows * k; t += (int64_t)rows * k; k = width;
-        }
-    }
+    float* WT = (float*)malloc(sizeof(float) * (size_t)mlp_weight_count(n_in, width, n_hidden, n_out_pad));
+    mlp_transpose(W, n_in, width, n_hidden, n_out_pad, WT);
 #pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < M; i++) {
-        float h[2][128] __attribute__((aligned(64)));
-        float acc[128] __attribute__((aligned(64)));
-        const float* cur = in + i * n_in; int cur_n = n_in; const float* wt = WT;
-        for (int l = 0; l <= n_hidden; l++) {
-            const int rows = l < n_hidden ? width : n_out_pad;
-            for (int o = 0; o < rows; o++) acc[o] = 0.f;
-            if (accumulate_half) {
-                for (int k = 0; k < cur_n; k++) {
-                    const float c = cur[k]; const float* col = wt + (int64_t)k * rows;
-                    for (int o = 0; o < rows; o++) acc[o] = round_half(fmaf(col[o], c, acc[o]));
+    for (int64_t i = 0; i < M; i++)
+        mlp_one(in + i * n_in, WT, n_in, width, n_hidden, n_out_pad, out_act, accumulate_half, out + i * n_out_pad,
+                acts ? acts + i * width : NULL, M * (int64_t)width);
+    free(WT);
+}
+/* InstantNGPRayRenderingComponent.query_model (src/Methods/InstantNGP/Renderer.py:48-53) for M samples in ONE parallel loop over blocks of
+ * samples -- hash-grid encode (level by level inside the block) -> density network (32 -> 64 -> 16) -> sigma = exp(h0) -> SH4 of the fp16-rounded
+ * d * 0.5 + 0.5 next to h -> colour network (32 -> 64 -> 64 -> 16, sigmoid): the composition oracle.ngp_query used to assemble from the
+ * stage functions above with numpy glue between them (single-threaded concatenations and conversions of M x 32 floats, which is what bounded
+ * the CPU baseline on a many-core host).  Same stage arithmetic, same values (tests/test_oracle_tcnn.py compares the two).
+ * sigma (M), rgb (M,3), h (M,16). */
+void oracle_ngp_query(const float* x01, const float* dirs, int64_t M, const float* Wd, const float* Wc, const float* table, int n_levels,
+                      int log2_hashmap_size, int base_resolution, float per_level_scale, int accumulate_half, float* sigma, float* rgb, float* h_out) {
+    enum { B = 512 };
+    uint32_t offsets[MAX_LEVELS + 1], res[MAX_LEVELS]; float scales[MAX_LEVELS];
+    oracle_grid_layout(n_levels, log2_hashmap_size, base_resolution, per_level_scale, offsets, scales, res);
+    const int n_enc = 2 * n_levels;   /* 32 */
+    float* WdT = (float*)malloc(sizeof(float) * (size_t)mlp_weight_count(n_enc, 64, 1, 16));
+    float* WcT = (float*)malloc(sizeof(float) * (size_t)mlp_weight_count(32, 64, 2, 16));
+    mlp_transpose(Wd, n_enc, 64, 1, 16, WdT);
+    mlp_transpose(Wc, 32, 64, 2, 16, WcT);
+    const int64_t n_blocks = (M + B - 1) / B;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t blk = 0; blk < n_blocks; blk++) {
+        const int64_t i0 = blk * B; const int m = (int)((M - i0) < B ? (M - i0) : B);
+        float enc[B][64];
+        for (int l = 0; l < n_levels; l++) {
+            const uint32_t size = offsets[l + 1] - offsets[l];
+            for (int j = 0; j < m; j++) {
+                const float* x = x01 + 3 * (i0 + j);
+                float frac[3]; uint32_t g[3];
+                for (int d = 0; d < 3; d++) {
+                    const float p = fmaf(scales[l], x[d], 0.5f);
+                    const float fl = floorf(p);
+                    g[d] = (uint32_t)(int32_t)fl; frac[d] = p - fl;
                 }
-            } else {
-                for (int k = 0; k < cur_n; k++) {
-                    const float c = cur[k]; const float* col = wt + (int64_t)k * rows;
-                    for (int o = 0; o < rows; o++) acc[o] = fmaf(col[o], c, acc[o]);
+                float acc0 = 0.f, acc1 = 0.f;
+                for (int c = 0; c < 8; c++) {
+                    float w = 1.f; uint32_t q[3];
+                    for (int d = 0; d < 3; d++) {
+                        if (c & (1 << d)) { w *= frac[d]; q[d] = g[d] + 1; } else { w *= 1.f - frac[d]; q[d] = g[d]; }
+                    }
+                    const uint32_t e = offsets[l] + grid_index(q, res[l], size);
+                    if (accumulate_half) {
+                        w = round_half(w);
+                        acc0 = round_half(fmaf(w, table[2 * (int64_t)e], acc0));
+                        acc1 = round_half(fmaf(w, table[2 * (int64_t)e + 1], acc1));
+                    } else {
+                        acc0 = fmaf(w, table[2 * (int64_t)e], acc0);
+                        acc1 = fmaf(w, table[2 * (int64_t)e + 1], acc1);
+                    }
                 }
+                enc[j][2 * l] = round_half(acc0); enc[j][2 * l + 1] = round_half(acc1);
             }
-            if (l < n_hidden) {
-                float* nxt = h[l & 1];
-                for (int o = 0; o < rows; o++) nxt[o] = round_half(acc[o] > 0.f ? acc[o] : 0.f);
-                if (acts) memcpy(acts + ((int64_t)l * M + i) * width, nxt, sizeof(float) * width);
-                cur = nxt; 
-            } else {
-                for (int o = 0; o < rows; o++) {
-                    float a = acc[o];
-                    if (out_act == 1) a = 1.0f / (1.0f + expf(-a));
-                    out[i * n_out_pad + o] = round_half(a);
-                }
-            }
-            wt += (int64_t)rows * cur_n; cur_n = width;
+        }
+        for (int j = 0; j < m; j++) {
+            const int64_t i = i0 + j;
+            float cin[32], out[16];
+            mlp_one(enc[j], WdT, n_enc, 64, 1, 16, 0, accumulate_half, cin + 16, NULL, 0);
+            memcpy(h_out + 16 * i, cin + 16, sizeof(float) * 16);
+            sigma[i] = expf(cin[16]);
+            float d01[3], o[16];
+            for (int d = 0; d < 3; d++) d01[d] = round_half(dirs[3 * i + d] * 0.5f + 0.5f);
+            sh4(d01[0] * 2.f - 1.f, d01[1] * 2.f - 1.f, d01[2] * 2.f - 1.f, o);
+            for (int k = 0; k < 16; k++) cin[k] = round_half(o[k]);
+            mlp_one(cin, WcT, 32, 64, 2, 16, 1, accumulate_half, out, NULL, 0);
+            rgb[3 * i] = out[0]; rgb[3 * i + 1] = out[1]; rgb[3 * i + 2] = out[2];
         }
     }
-    free(WT);
+    free(WdT); free(WcT);
 }
 void oracle_mlp_fw(const float* in, int64_t M, const float* W, int n_in, int width, int n_hidden, int n_out_pad, int out_act,
                    float* out, float* acts) {

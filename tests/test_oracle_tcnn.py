@@ -149,3 +149,32 @@ def test_half_accumulation_variant_is_bounded_against_the_f32_definition():
     assert report['trained-scale table']['sample_rgb_max'] > 0
     assert report['bench initialisation']['pixel_rgb_max'] < 2e-3
     assert report['trained-scale table']['pixel_rgb_max'] < 3e-2 and report['trained-scale table']['pixel_rgb_mean'] < 5e-3
+
+
+def test_fused_query_call_equals_the_staged_composition():
+    """oracle.ngp_query (one C call, one parallel loop over sample blocks: what bench.py's cpu_baseline times) against the same composition
+    assembled from the stage functions with numpy between them: colours and density-network outputs bit for bit, sigma to an ulp (libm expf vs
+    numpy's exp), for both accumulation rules and a ragged sample count."""
+    rng = np.random.default_rng(5)
+    m = 20_003
+    x = rng.random((m, 3), dtype=np.float32)
+    d = rng.standard_normal((m, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    total = oracle.grid_layout(per_level_scale=PLS)[0]
+    table = ((rng.random((total, 2), dtype=np.float32) * 2 - 1) * 0.5).astype(np.float16).astype(np.float32)
+    Wd = (rng.standard_normal(3072).astype(np.float32) * 0.2).astype(np.float16).astype(np.float32)
+    Wc = (rng.standard_normal(7168).astype(np.float32) * 0.2).astype(np.float16).astype(np.float32)
+    for acc in ('float', 'half'):
+        sig, rgb, h = oracle.ngp_query(x, d, Wd, Wc, table, accumulate=acc, per_level_scale=PLS)
+        sig2, rgb2, h2 = oracle.ngp_query_staged(x, d, Wd, Wc, table, accumulate=acc, per_level_scale=PLS)
+        np.testing.assert_array_equal(rgb, rgb2)
+        np.testing.assert_array_equal(h, h2)
+        np.testing.assert_allclose(sig, sig2, rtol=3e-7)
+    before = oracle.set_threads(1)
+    try:
+        one = oracle.ngp_query(x, d, Wd, Wc, table, per_level_scale=PLS)
+    finally:
+        oracle.set_threads(before)
+    many = oracle.ngp_query(x, d, Wd, Wc, table, per_level_scale=PLS)
+    for a, b in zip(one, many):
+        np.testing.assert_array_equal(a, b)   # the thread count changes nothing
