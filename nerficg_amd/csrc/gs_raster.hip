@@ -292,6 +292,12 @@ __device__ __forceinline__ void sh_rows_copy(float* s_sh, int pitch, int row_len
         }
     }
 }
+#define SPAN_DIM_MAX 256     // tile rows / columns the lane-private cursors cover (4 registers x 64 lanes): 4096 x 4096 pixels
+// Header words of the sort, zeroed by the first workgroup of k_preprocess (the kernel in front): [digit totals 4 x 256][row span totals 256][tile tickets 4 + 4 spare]
+#define RS_HDR_TOT 0
+#define RS_HDR_ROWS 1024
+#define RS_HDR_TICKET (1024 + 256)
+#define RS_HDR_WORDS (1024 + 256 + 8)
 // Workgroup = 128 Gaussians; their SH coefficients (one contiguous 128 x 3M float block) are staged through LDS with coalesced
 // loads -- a lane walking its own 192-byte row touches 48 cache lines per wave instruction (same staging as k_preprocess_bw).
 #define PRE_BLOCK 128
@@ -306,8 +312,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam_arg, 
                                                           float* __restrict__ depths, float* __restrict__ points_xy,
                                                           float* __restrict__ conic_opacity, float* __restrict__ rgb, uint8_t* __restrict__ clamped,
                                                           float* __restrict__ cov3D, uint32_t* __restrict__ tiles_touched,
-                                                          uint32_t* __restrict__ tile_counts, float4* __restrict__ splat) {
+                                                          uint32_t* __restrict__ tile_counts, float4* __restrict__ splat, uint32_t* __restrict__ sort_hdr) {
     __shared__ __attribute__((aligned(16))) float s_sh[PRE_BLOCK * (3 * PRE_MAXM + 1)];
+    if (sort_hdr && blockIdx.x == 0)   // digit totals, row totals and tile tickets of the depth sort behind this kernel start at zero
+        for (int k = threadIdx.x; k < RS_HDR_WORDS; k += PRE_BLOCK) sort_hdr[k] = 0u;
     const GsCam cam = cam_with_pose(cam_arg, pose);
     const int first = blockIdx.x * PRE_BLOCK, i = first + threadIdx.x;
     const int row_len = 3 * cam.M, pitch = row_len + 1;
@@ -345,147 +353,263 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam_arg, 
 // ---- depth pre-sort of the P Gaussians (LSD radix, 4 x 8 bits, stable: equal depths keep ascending index) ---------------
 // Sorting the P Gaussians once by depth (8 B x P x 4 passes) replaces sorting the D >> P instances per tile: the binning
 // passes below take their slices from the depth-ordered list and keep that order inside every tile.
-#define RS_ITEMS 16                  // keys per thread per block
-#define RS_TILE (256 * RS_ITEMS)     // keys per block
+#ifndef RS_THREADS
+#define RS_THREADS 512               // threads per tile: 8 waves rank 512 keys each (the rounds of a wave are a serial chain: 8 rounds instead of 16)
+#endif
+#define RS_WAVES (RS_THREADS / 64)
+#define RS_TILE 4096                 // keys per tile (one workgroup)
+#define RS_ITEMS (RS_TILE / RS_THREADS)   // keys per thread
+#define RS_GROUP 64                  // tiles per group of the two-level prefix over the tiles
+#define RS_PUB 0x80000000u           // "published" bit of a status word (counts stay below 2^31)
 // sort key (depth bits; invisible Gaussians last), the Gaussian's index, and its tile rectangle packed as x0 | y0 << 8 | (w-1) << 16 | (h-1) << 24
 // (tile grids of at most 256 x 256; RECT_NONE = no tile).  The rectangle travels through the sort as a second value, so the binning passes
 // stream (id, rectangle) in depth order instead of gathering radii / points_xy by id (246 us at 6 M as a separate gather kernel).
 #define RECT_NONE 0xffffffffu
-__global__ void __launch_bounds__(256) k_depth_keys(int P, int gx, int gy, const int32_t* __restrict__ radii, const float* __restrict__ depths,
-                                                    const float* __restrict__ points_xy, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                    uint32_t* __restrict__ rects, uint32_t* __restrict__ digit_totals) {
-    if (blockIdx.x == 0) {  // the 4 x 256 digit totals the four counting passes add into start at zero (one launch less than a separate clear)
+// Round 4: ONE kernel per digit instead of three (count / offsets / scatter), and all 16 keys of a thread requested up front instead of one
+// round ahead (the old scatter's 16 rounds were 16 dependent global-load latencies: 19.6 us for 4 096 keys per workgroup).
+//   k_depth_keys   keys, rectangles, the digit totals of ALL four passes (a key's digits do not depend on where the sort has put it) and the
+//                  number of spans per tile row (LDS histograms, one global atomic per non-empty bin and workgroup);
+//   k_radix_pass   tile t = a ticket (tiles wait for LOWER tickets only: whoever holds one is running).  The tile counts its digits in LDS and
+//                  PUBLISHES the 256 counts (one sc1 store per thread, value and "published" bit in one word: no fence), ranks its keys into LDS
+//                  (stable, as before) while the other tiles publish, then adds up what the earlier tiles of its GROUP of 64 published (<= 63
+//                  independent sc1 loads per thread, issued in batches of 16; a word that is not there yet is polled again) and the totals of the
+//                  earlier groups (published by each group's last tile as soon as it has its own sum): a dependency chain of depth two,
+//                  whatever the number of tiles.  A serial decoupled look-back (the usual one-sweep formulation) would walk through every
+//                  concurrent predecessor -- all 245 tiles of a 1 M sort are resident at once on this chip -- at one L2 round trip per tile.
+// 1 M Gaussians: 4 x (9.5 + 4.9 + 19.6) + 6.4 us in 13 launches -> 5 launches (numbers in DESIGN.md section 3.3).
+#define DK_BLOCK 256
+#define DK_ITEMS 16
+__global__ void __launch_bounds__(DK_BLOCK) k_depth_keys(int P, int gx, int gy, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+                                                         const float* __restrict__ points_xy, uint32_t* __restrict__ keys, uint32_t* __restrict__ rects,
+                                                         uint32_t* __restrict__ hdr, uint32_t* __restrict__ status, int64_t n_status) {
+    __shared__ uint32_t h[4][256];
+    __shared__ uint32_t rows[SPAN_DIM_MAX];
 #pragma unroll
-        for (int k = 0; k < 4; k++) digit_totals[256 * k + threadIdx.x] = 0u;
-    }
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const int rad = radii[i];
-    uint32_t rect = RECT_NONE;
-    if (rad > 0) {
-        const float pxy[2] = {points_xy[2 * i], points_xy[2 * i + 1]};
-        int rmin[2], rmax[2];
-        tile_rect(pxy, rad, gx, gy, rmin, rmax);
-        if (rmax[0] > rmin[0] && rmax[1] > rmin[1])
-            rect = (uint32_t)rmin[0] | (uint32_t)rmin[1] << 8 | (uint32_t)(rmax[0] - rmin[0] - 1) << 16 | (uint32_t)(rmax[1] - rmin[1] - 1) << 24;
-    }
-    keys[i] = rad > 0 ? __float_as_uint(depths[i]) : 0xffffffffu;  // invisible Gaussians go last
-    vals[i] = (uint32_t)i;
-    rects[i] = rect;
-}
-// counts: digit-major [256][nblk4] (rows padded to a multiple of 4 for 16-byte loads); tot[256] = digit totals (atomics)
-__global__ void __launch_bounds__(256) k_radix_count(int n, int shift, int nblk4, const uint32_t* __restrict__ keys, uint32_t* __restrict__ counts,
-                                                     uint32_t* __restrict__ tot) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    for (int k = 0; k < 4; k++) h[k][threadIdx.x] = 0u;
+    rows[threadIdx.x] = 0u;
+    // the status words of the four passes start unpublished
+    for (int64_t k = (int64_t)blockIdx.x * DK_BLOCK + threadIdx.x; k < n_status; k += (int64_t)gridDim.x * DK_BLOCK) status[k] = 0u;
     __syncthreads();
-    const int base = blockIdx.x * RS_TILE;
-#pragma unroll 4
-    for (int r = 0; r < RS_ITEMS; r++) {
-        const int i = base + r * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    const int base = blockIdx.x * (DK_BLOCK * DK_ITEMS);
+    int rad[DK_ITEMS]; float dep[DK_ITEMS]; float2 xy[DK_ITEMS];
+#pragma unroll
+    for (int r = 0; r < DK_ITEMS; r++) {
+        const int i = base + r * DK_BLOCK + threadIdx.x;
+        rad[r] = i < P ? radii[i] : 0;
+        dep[r] = i < P ? depths[i] : 0.f;
+        xy[r] = i < P ? reinterpret_cast<const float2*>(points_xy)[i] : make_float2(0.f, 0.f);
     }
+    uint32_t top = 0xffffffffu, top_run = 0u;  // the top digit takes a handful of values: runs of equal digits of a thread's keys are added as one
+#pragma unroll
+    for (int r = 0; r < DK_ITEMS; r++) {
+        const int i = base + r * DK_BLOCK + threadIdx.x;
+        if (i >= P) break;
+        uint32_t rect = RECT_NONE;
+        if (rad[r] > 0) {
+            const float pxy[2] = {xy[r].x, xy[r].y};
+            int rmin[2], rmax[2];
+            tile_rect(pxy, rad[r], gx, gy, rmin, rmax);
+            if (rmax[0] > rmin[0] && rmax[1] > rmin[1]) {
+                rect = (uint32_t)rmin[0] | (uint32_t)rmin[1] << 8 | (uint32_t)(rmax[0] - rmin[0] - 1) << 16 | (uint32_t)(rmax[1] - rmin[1] - 1) << 24;
+                for (int y = rmin[1]; y < rmax[1]; y++) atomicAdd(&rows[y], 1u);
+            }
+        }
+        const uint32_t key = rad[r] > 0 ? __float_as_uint(dep[r]) : 0xffffffffu;  // invisible Gaussians go last
+        keys[i] = key;
+        rects[i] = rect;
+        atomicAdd(&h[0][key & 255u], 1u);
+        atomicAdd(&h[1][(key >> 8) & 255u], 1u);
+        atomicAdd(&h[2][(key >> 16) & 255u], 1u);
+        const uint32_t d3 = key >> 24;
+        if (d3 != top) {
+            if (top_run) atomicAdd(&h[3][top], top_run);
+            top = d3; top_run = 0u;
+        }
+        top_run++;
+    }
+    if (top_run) atomicAdd(&h[3][top], top_run);
     __syncthreads();
-    const uint32_t c = h[threadIdx.x];
-    counts[(size_t)threadIdx.x * nblk4 + blockIdx.x] = c;  // digit-major: the scan order of a stable LSD pass
-    if (c) atomicAdd(&tot[threadIdx.x], c);
-}
-// offs[d][b] = global position of block b's first element with digit d = sum of tot[d' < d] + sum of counts[d][b' < b]: one workgroup per
-// digit row (256 of them run in parallel; a single-workgroup scan of the whole matrix was latency-bound at 37 us per pass, and letting every
-// scatter workgroup sum its own row prefixes cost it ~180 dependent 16-byte loads per thread at 6 M Gaussians).
-__global__ void __launch_bounds__(256) k_radix_offsets(int nblk, int nblk4, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ tot,
-                                                       uint32_t* __restrict__ offs) {
-    __shared__ int sm[8];
-    const int d = blockIdx.x;
-    int digit_base;
-    {
-        const int t = (int)tot[threadIdx.x];
-        const int ex = nrc_block256_excl_scan_i(t, sm, nullptr);
-        __shared__ int base_s;
-        if ((int)threadIdx.x == d) base_s = ex;
-        __syncthreads();
-        digit_base = base_s;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t c = h[k][threadIdx.x];
+        if (c) atomicAdd(&hdr[RS_HDR_TOT + 256 * k + threadIdx.x], c);
     }
-    const uint32_t* row = counts + (size_t)d * nblk4;
-    uint32_t* out = offs + (size_t)d * nblk4;
-    int carry = digit_base;
-    for (int b0 = 0; b0 < nblk; b0 += 256) {
-        const int i = b0 + threadIdx.x;
-        const int v = i < nblk ? (int)row[i] : 0;
-        int total;
-        const int ex = nrc_block256_excl_scan_i(v, sm, &total);
-        if (i < nblk) out[i] = (uint32_t)(carry + ex);
-        carry += total;
-    }
+    if ((int)threadIdx.x < gy && rows[threadIdx.x]) atomicAdd(&hdr[RS_HDR_ROWS + threadIdx.x], rows[threadIdx.x]);
 }
-// The block's 4096 elements are first ranked INTO LDS (stable: rounds in order, inside a round wave order then lane order), digit runs
-// back to back; only then they go out, element i of the staged block to first[digit] + (i - run start): consecutive lanes write consecutive
-// addresses inside a run (16 elements = 64 B on average) instead of one isolated 4-byte store per element and array.  One barrier per
-// round: the per-wave digit counts are triple-buffered (round r fills buffer r % 3, which was cleared two rounds earlier) and the running
-// per-digit totals double-buffered, so filling round r + 1 may overlap ranking round r.
-__global__ void __launch_bounds__(256) k_radix_scatter(int n, int shift, int nblk4, const uint32_t* __restrict__ keys_in,
-                                                       const uint32_t* __restrict__ vals_in, const uint32_t* __restrict__ rects_in,
-                                                       const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offs,
-                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t* __restrict__ rects_out) {
-    __shared__ uint32_t first_g[256];       // global position of the block's first element with digit d
-    __shared__ uint32_t run0[256];          // position of the digit's run inside the staged block
-    __shared__ uint32_t running[2][256];    // elements of the digit staged before the current round
-    __shared__ uint32_t whist[3][4][256];
+__device__ __forceinline__ uint32_t rs_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rs_publish(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v | RS_PUB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// sum over words [first, first + n) x stride of a published column (this thread's digit); words not yet published are polled again
+__device__ __forceinline__ uint32_t rs_sum_published(const uint32_t* col, int n, int stride) {
+    uint32_t sum = 0u;
+    for (int t0 = 0; t0 < n; t0 += 16) {
+        uint32_t v[16];
+        bool ok;
+        do {
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = t0 + k < n ? rs_load(col + (size_t)(t0 + k) * stride) : RS_PUB;
+#pragma unroll
+            for (int k = 0; k < 16; k++) ok = ok && (v[k] & RS_PUB);
+            if (!ok) __builtin_amdgcn_s_sleep(4);
+        } while (!ok);
+#pragma unroll
+        for (int k = 0; k < 16; k++) sum += v[k] & ~RS_PUB;
+    }
+    return sum;
+}
+// vals_in == nullptr: the values are the positions themselves (first pass); keys_out == nullptr: the keys are not needed any more (last pass).
+// TICKET = false (at most 256 tiles: one 65 KB workgroup fits on every CU, so all tiles are resident whatever the dispatch order): tile = blockIdx.
+// Ranking: a wave owns 64 * RS_ITEMS CONSECUTIVE keys of the tile (round r = 64 consecutive keys) and ranks them against a wave-private table of
+// running digit counts -- 8 ballots find a lane's peers, the first peer advances the count -- so the rounds need no workgroup barrier (the old
+// scatter had one per round, 16 of them); afterwards thread d adds up the four waves' counts of digit d (published at once), one scan gives the
+// digit runs, the per-wave counts turn into the waves' offsets inside the runs, and every key goes to run start + wave offset + its rank:
+// wave-major, round-major, lane-major = ascending position = stable.  The 63 status words of the own group are requested BEFORE the keys are
+// staged and looked at afterwards.
+#if defined(NRC_SORT_PROBE)   // developer build (tools/build_variant.sh): shader-clock stamps of thread 0 of three tiles at the phases of the LAST pass
+__device__ unsigned long long g_sort_probe[3][16];
+#define RS_PROBE(k) do { if (pass == 3 && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == gridDim.x - 1)) \
+    g_sort_probe[blockIdx.x == 0 ? 0 : (blockIdx.x == 100 ? 1 : 2)][(k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RS_PROBE(k) do { } while (0)
+#endif
+template <bool TICKET>
+__global__ void __launch_bounds__(RS_THREADS) k_radix_pass(int n, int shift, int pass, int n_tiles, const uint32_t* __restrict__ keys_in,
+                                                           const uint32_t* __restrict__ vals_in, const uint32_t* __restrict__ rects_in,
+                                                           uint32_t* __restrict__ hdr, uint32_t* __restrict__ status, uint32_t* __restrict__ gstat,
+                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t* __restrict__ rects_out) {
+    __shared__ uint32_t first_g[256];           // global position of the tile's first element with digit d
+    __shared__ uint32_t run0[256];              // position of the digit's run inside the staged tile
+    __shared__ uint32_t wcnt[RS_WAVES][256];    // per wave: running count of the digit, later the wave's offset inside the tile
     __shared__ int scan_sm[8];
+    __shared__ int tile_s;
     __shared__ uint32_t st_key[RS_TILE], st_val[RS_TILE], st_rect[RS_TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {
-        const size_t at = (size_t)threadIdx.x * nblk4 + blockIdx.x;
-        first_g[threadIdx.x] = offs[at];
-        running[0][threadIdx.x] = 0u;
+    const bool digit_thread = threadIdx.x < 256;   // threads 0..255 also look after one digit each
+    RS_PROBE(0);
+    if (TICKET && threadIdx.x == 0) tile_s = (int)atomicAdd(&hdr[RS_HDR_TICKET + pass], 1u);
+    for (int k = threadIdx.x; k < RS_WAVES * 256; k += RS_THREADS) (&wcnt[0][0])[k] = 0u;
+    __syncthreads();
+    const int tile = TICKET ? tile_s : (int)blockIdx.x;
+    const int base = tile * RS_TILE, wbase = base + wave * (64 * RS_ITEMS) + lane;
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rect[RS_ITEMS], rk[RS_ITEMS];
 #pragma unroll
-        for (int q = 0; q < 3; q++)
-#pragma unroll
-            for (int w = 0; w < 4; w++) whist[q][w][threadIdx.x] = 0u;
-        run0[threadIdx.x] = (uint32_t)nrc_block256_excl_scan_i((int)counts[at], scan_sm, nullptr);  // ends with a barrier
-    }
-    const int base = blockIdx.x * RS_TILE;
-    int i = base + threadIdx.x;
-    uint32_t key = i < n ? keys_in[i] : 0u, val = i < n ? vals_in[i] : 0u, rect = i < n ? rects_in[i] : 0u;
     for (int r = 0; r < RS_ITEMS; r++) {
-        const bool valid = i < n;
-        const int i_next = i + 256;
-        const bool more = r + 1 < RS_ITEMS && i_next < n;
-        const uint32_t key_n = more ? keys_in[i_next] : 0u, val_n = more ? vals_in[i_next] : 0u, rect_n = more ? rects_in[i_next] : 0u;
-        const uint32_t d = (key >> shift) & 255u;
-        // lanes of this wave holding the same digit (8 ballots), rank among them in lane order = stable
-        unsigned long long peers = __ballot(valid);
+        const int i = wbase + r * 64;
+        key[r] = i < n ? keys_in[i] : 0u;
+        val[r] = i < n ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+        rect[r] = i < n ? rects_in[i] : 0u;
+    }
+    const uint32_t digit_total = digit_thread ? hdr[RS_HDR_TOT + 256 * pass + threadIdx.x] : 0u;
+    uint32_t* mine = wcnt[wave];
+    RS_PROBE(1);
+#if defined(NRC_SORT_PROBE)
+    if (key[0] == 0x12345678u && key[RS_ITEMS - 1] == 0x9abcdefu) __builtin_amdgcn_s_sleep(1);   // keeps the loads in front of stamp 2
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    RS_PROBE(2);
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const bool valid = wbase + r * 64 < n;
+        const uint32_t d = (key[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);   // lanes of this wave holding the same digit (8 ballots); rank among them in lane order = stable
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             const unsigned long long m = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
         const uint32_t rank_w = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-        uint32_t (*wh)[256] = whist[r % 3];
-        if (valid && rank_w == 0) wh[wave][d] = (uint32_t)__popcll(peers);
-        __syncthreads();
-        if (valid) {
-            uint32_t off = run0[d] + running[r & 1][d];
-            for (int w = 0; w < wave; w++) off += wh[w][d];
-            off += rank_w;
-            st_key[off] = key; st_val[off] = val; st_rect[off] = rect;
-        }
-        {   // thread t looks after digit t: totals for the next round, and the buffer of the round after next is cleared
-            uint32_t t = running[r & 1][threadIdx.x];
+        const uint32_t before = mine[d];
+        rk[r] = before + rank_w;
+        if (valid && rank_w == 0) mine[d] = before + (uint32_t)__popcll(peers);   // LDS operations of one wave execute in order: the next round reads this
+    }
+    RS_PROBE(3);
+    __syncthreads();
+    RS_PROBE(4);
+    // thread d: the waves' counts of digit d -> the tile's count (published at once), the digit runs (scan) and the waves' offsets inside them
+    uint32_t my_count = 0u;
+    uint32_t c[RS_WAVES];
+    if (digit_thread) {
 #pragma unroll
-            for (int w = 0; w < 4; w++) { t += wh[w][threadIdx.x]; whist[(r + 2) % 3][w][threadIdx.x] = 0u; }
-            running[(r + 1) & 1][threadIdx.x] = t;
+        for (int w = 0; w < RS_WAVES; w++) { c[w] = wcnt[w][threadIdx.x]; my_count += c[w]; }
+        rs_publish(status + (size_t)tile * 256 + threadIdx.x, my_count);
+    }
+    // two exclusive scans over the 256 digits at once (tile counts -> run starts, digit totals -> digit bases): waves 0..3 scan, everyone meets at the barriers
+    uint32_t r0 = 0u, digit_base = 0u;
+    {
+        int inc_a = 0, inc_b = 0;
+        if (digit_thread) {
+            inc_a = nrc_wave_incl_sum_i((int)my_count, lane); inc_b = nrc_wave_incl_sum_i((int)digit_total, lane);
+            if (lane == 63) { scan_sm[wave] = inc_a; scan_sm[4 + wave] = inc_b; }
         }
-        i = i_next; key = key_n; val = val_n; rect = rect_n;
+        __syncthreads();
+        if (digit_thread) {
+            int ba = 0, bb = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) { if (w < wave) { ba += scan_sm[w]; bb += scan_sm[4 + w]; } }
+            r0 = (uint32_t)(ba + inc_a) - my_count; digit_base = (uint32_t)(bb + inc_b) - digit_total;
+            run0[threadIdx.x] = r0;
+            uint32_t o = r0;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; w++) { wcnt[w][threadIdx.x] = o; o += c[w]; }
+        }
+        __syncthreads();
+    }
+    RS_PROBE(5);
+    // What the earlier tiles hold of this thread's digit: the tiles of the own group of 64 one by one, the earlier groups by their totals.  The
+    // words of the own group are requested now.  The group's LAST tile sums and publishes the group total at once (every tile of every later
+    // group waits for it); the others stage their keys first and look at the words afterwards.
+    const int group = tile / RS_GROUP, g0 = group * RS_GROUP, n_in = tile - g0;
+    const bool group_leader = tile == g0 + RS_GROUP - 1 || tile == n_tiles - 1;
+    const uint32_t* col = status + (size_t)g0 * 256 + threadIdx.x;
+    uint32_t pv[RS_GROUP];
+    uint32_t in_group = 0u;
+    if (digit_thread) {
+#pragma unroll
+        for (int k = 0; k < RS_GROUP; k++) pv[k] = k < n_in ? rs_load(col + (size_t)k * 256) : RS_PUB;
+        if (group_leader) {
+            bool all_there = true;
+#pragma unroll
+            for (int k = 0; k < RS_GROUP; k++) { all_there = all_there && (pv[k] & RS_PUB); in_group += pv[k] & ~RS_PUB; }
+            if (!all_there) in_group = rs_sum_published(col, n_in, 256);
+            rs_publish(gstat + (size_t)group * 256 + threadIdx.x, in_group + my_count);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        if (wbase + r * 64 < n) {
+            const uint32_t off = mine[(key[r] >> shift) & 255u] + rk[r];
+            st_key[off] = key[r]; st_val[off] = val[r]; st_rect[off] = rect[r];
+        }
+    }
+    RS_PROBE(6);
+    if (digit_thread) {
+        if (!group_leader) {
+            bool all_there = true;
+#pragma unroll
+            for (int k = 0; k < RS_GROUP; k++) { all_there = all_there && (pv[k] & RS_PUB); in_group += pv[k] & ~RS_PUB; }
+            RS_PROBE(7);
+            if (!all_there) in_group = rs_sum_published(col, n_in, 256);
+        }
+        RS_PROBE(8);
+        const uint32_t groups_before = rs_sum_published(gstat + threadIdx.x, group, 256);
+        RS_PROBE(9);
+        first_g[threadIdx.x] = digit_base + groups_before + in_group;
     }
     __syncthreads();
+    RS_PROBE(10);
     const int n_here = min(RS_TILE, n - base);
-    for (int k = threadIdx.x; k < n_here; k += 256) {
+    for (int k = threadIdx.x; k < n_here; k += RS_THREADS) {
         const uint32_t kk = st_key[k];
         const uint32_t d = (kk >> shift) & 255u;
         const uint32_t pos = first_g[d] + ((uint32_t)k - run0[d]);
-        keys_out[pos] = kk; vals_out[pos] = st_val[k]; rects_out[pos] = st_rect[k];
+        if (keys_out) keys_out[pos] = kk;
+        vals_out[pos] = st_val[k]; rects_out[pos] = st_rect[k];
     }
+    RS_PROBE(11);
+#if defined(NRC_SORT_PROBE)
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    RS_PROBE(12);
 }
 
 // ---- stable two-level binning of the depth-ordered Gaussians ---------------------------------------------------------------
@@ -511,7 +635,6 @@ __global__ void __launch_bounds__(256) k_radix_scatter(int n, int shift, int nbl
 #ifndef SPAN_NB_MAX
 #define SPAN_NB_MAX 4096     // level-1 slices (waves) at most
 #endif
-#define SPAN_DIM_MAX 256     // tile rows / columns the lane-private cursors cover (4 registers x 64 lanes): 4096 x 4096 pixels
 #ifndef SPAN_GRID
 #define SPAN_GRID 2048       // waves of the level-2 scatter (grid-stride over the items): few enough that the lines being appended stay in L2
 #endif
@@ -1565,20 +1688,32 @@ __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_ar
 }
 
 // slices = waves; all of them should be resident at once: 160 KB of LDS per CU, (4 B x n_tiles) per wave, 256 CUs
-// binning workspace (u32 words): [keyA P][valA P][rectA P][keyB P][valB P][rectB P][radix counts 256 x nblk4][offsets 256 x nblk4][tot 4 x 256] -- the depth pre-sort --
+// binning workspace (u32 words): [keyA P][valA P][rectA P][keyB P][valB P][rectB P][header RS_HDR_WORDS][status 4 x nblk x 256][group totals 4 x ngroups x 256] -- the depth pre-sort --
 // [cnt1 gy x nb1][rowtot gy][roff gy][nitems gy][ioff gy][meta 4][tcount n_tiles][cnt2 item_cap x gx][spans 2 x cap]
 struct BinWs {
-    uint32_t *keyA, *valA, *rectA, *keyB, *valB, *rectB, *counts, *offs, *tot, *cnt1, *rowtot, *roff, *nitems, *ioff, *meta, *tcount, *cnt2;
+    uint32_t *keyA, *valA, *rectA, *keyB, *valB, *rectB, *hdr, *status, *gstat, *cnt1, *rowtot, *roff, *nitems, *ioff, *meta, *tcount, *cnt2;
     uint2* spans;
-    int nblk, nblk4, nb1, chunk1, item_cap;
-    int64_t cap, words;
+    int nblk, ngroups, nb1, chunk1, item_cap;
+    int64_t cap, words, n_status;
 };
+// compute units of the current device (queried once per device index): the ticket-free sort variant needs every tile resident at once
+int gs_cu_count() {
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cached[dev] = n > 0 ? n : -1;
+    }
+    return cached[dev] > 0 ? cached[dev] : 0;
+}
 int64_t gs_default_span_cap(int P) { return 4 * (int64_t)(P > 0 ? P : 1) + 65536; }
 BinWs gs_bin_ws(uint32_t* base, int P, int gx, int gy, int64_t cap) {
     BinWs w;
     const int64_t p1 = P > 0 ? P : 1;
     w.nblk = (int)nrc_cdiv(p1, RS_TILE);
-    w.nblk4 = (w.nblk + 3) / 4 * 4;
+    w.ngroups = (w.nblk + RS_GROUP - 1) / RS_GROUP;
     w.nb1 = (int)(nrc_cdiv(p1, 64) < SPAN_NB_MAX ? nrc_cdiv(p1, 64) : SPAN_NB_MAX);
     w.chunk1 = (int)(nrc_cdiv(nrc_cdiv(p1, w.nb1), 64) * 64);
     w.cap = cap;
@@ -1586,9 +1721,10 @@ BinWs gs_bin_ws(uint32_t* base, int P, int gx, int gy, int64_t cap) {
     uint32_t* q = base;
     auto take = [&](int64_t n, int64_t align_words) { q = base + ((q - base) + align_words - 1) / align_words * align_words; uint32_t* r = q; q += n; return r; };
     w.keyA = take(p1, 4); w.valA = take(p1, 4); w.rectA = take(p1, 4); w.keyB = take(p1, 4); w.valB = take(p1, 4); w.rectB = take(p1, 4);
-    w.counts = take((int64_t)256 * w.nblk4, 4);  // 16-byte aligned rows (base itself comes 256-byte aligned from the caller)
-    w.offs = take((int64_t)256 * w.nblk4, 4);
-    w.tot = take(1024, 4);
+    w.hdr = take(RS_HDR_WORDS, 4);
+    w.n_status = (int64_t)4 * 256 * (w.nblk + w.ngroups);   // status of pass p at + p * 256 * nblk, the group totals behind all four
+    w.status = take(w.n_status, 4);
+    w.gstat = w.status + (int64_t)4 * 256 * w.nblk;
     w.cnt1 = take((int64_t)gy * w.nb1, 4);
     w.rowtot = take(gy, 4); w.roff = take(gy, 4); w.nitems = take(gy, 4); w.ioff = take(gy, 4);
     w.meta = take(4, 4);
@@ -1616,6 +1752,10 @@ int make_cam(GsCam& cam, int W, int H, int D, int M, const float* view, const fl
 }  // namespace
 
 extern "C" {
+
+#if defined(NRC_SORT_PROBE)
+int nrc_debug_sort_probe(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sort_probe), sizeof(g_sort_probe)); }
+#endif
 
 int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H, int64_t span_capacity) {
     if (P < 0 || W < 1 || H < 1 || span_capacity < 0) return NRC_ERR_INVALID;
@@ -1654,24 +1794,27 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
         if (!means3D || !opacities || !radii || !depths || !points_xy || !conic_opacity || !rgb || !clamped || !cov3D || !tiles_touched || !splat_records)
             return NRC_ERR_INVALID;
         if (shs && M > PRE_MAXM) return NRC_ERR_UNSUPPORTED;
+        const BinWs w = lds_path ? gs_bin_ws(bin_hist, P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P)) : BinWs{};
         hipLaunchKernelGGL(k_preprocess, dim3(nrc_cdiv(P, PRE_BLOCK)), dim3(PRE_BLOCK), 0, s, P, cam, camera_dev, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations,
                            cov3D_precomp, radii, depths, points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched,
-                           lds_path ? (uint32_t*)nullptr : tile_counts, (float4*)splat_records);
+                           lds_path ? (uint32_t*)nullptr : tile_counts, (float4*)splat_records, lds_path ? w.hdr : (uint32_t*)nullptr);
         NRC_STAGE(s, "k_preprocess");
         if (lds_path) {
-            const BinWs w = gs_bin_ws(bin_hist, P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P));
-            // depth pre-sort of the Gaussians: 4 stable 8-bit passes, (keyA,valA) -> ... -> (keyA,valA); valA = depth order
-            hipLaunchKernelGGL(k_depth_keys, dim3(nrc_cdiv(P, 256)), dim3(256), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, w.keyA, w.valA, w.rectA, w.tot);
+            // depth pre-sort of the Gaussians: 4 stable 8-bit passes, one launch each, (keyA, rectA) -> B -> A -> B -> (valA, rectA) = depth order
+            hipLaunchKernelGGL(k_depth_keys, dim3(nrc_cdiv(P, DK_BLOCK * DK_ITEMS)), dim3(DK_BLOCK), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, w.keyA, w.rectA,
+                               w.hdr, w.status, w.n_status);
             NRC_STAGE(s, "k_depth_keys");
+            const int cu_count = gs_cu_count();
             for (int pass = 0; pass < 4; pass++) {
                 const uint32_t *ki = (pass & 1) ? w.keyB : w.keyA, *vi = (pass & 1) ? w.valB : w.valA, *ri = (pass & 1) ? w.rectB : w.rectA;
                 uint32_t *ko = (pass & 1) ? w.keyA : w.keyB, *vo = (pass & 1) ? w.valA : w.valB, *ro = (pass & 1) ? w.rectA : w.rectB;
-                hipLaunchKernelGGL(k_radix_count, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk4, ki, w.counts, w.tot + 256 * pass);
-                NRC_STAGE(s, "k_radix_count");
-                hipLaunchKernelGGL(k_radix_offsets, dim3(256), dim3(256), 0, s, w.nblk, w.nblk4, w.counts, w.tot + 256 * pass, w.offs);
-                NRC_STAGE(s, "k_radix_offsets");
-                hipLaunchKernelGGL(k_radix_scatter, dim3(w.nblk), dim3(256), 0, s, P, 8 * pass, w.nblk4, ki, vi, ri, w.counts, w.offs, ko, vo, ro);
-                NRC_STAGE(s, "k_radix_scatter");
+                if (w.nblk <= cu_count)   // one 65 KB workgroup per CU: every tile is resident, tile = blockIdx is safe
+                    hipLaunchKernelGGL(k_radix_pass<false>, dim3(w.nblk), dim3(RS_THREADS), 0, s, P, 8 * pass, pass, w.nblk, ki, pass == 0 ? (const uint32_t*)nullptr : vi, ri, w.hdr,
+                                       w.status + (int64_t)pass * 256 * w.nblk, w.gstat + (int64_t)pass * 256 * w.ngroups, pass == 3 ? (uint32_t*)nullptr : ko, vo, ro);
+                else
+                    hipLaunchKernelGGL(k_radix_pass<true>, dim3(w.nblk), dim3(RS_THREADS), 0, s, P, 8 * pass, pass, w.nblk, ki, pass == 0 ? (const uint32_t*)nullptr : vi, ri, w.hdr,
+                                       w.status + (int64_t)pass * 256 * w.nblk, w.gstat + (int64_t)pass * 256 * w.ngroups, pass == 3 ? (uint32_t*)nullptr : ko, vo, ro);
+                NRC_STAGE(s, "k_radix_pass");
             }
             // level 1: row spans in depth order; level 2 counting + scans: tile ranges and the per-(item, tile) cursors
             hipLaunchKernelGGL(k_span_count, dim3(w.nb1), dim3(64), 0, s, P, w.nb1, w.chunk1, cam.gy, w.valA, w.rectA, w.cnt1);

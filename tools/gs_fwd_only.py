@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""tools/gs_fwd_only.py [N] [FRAMES] -- forward-only rasterizer frames back to back (for tools/kseq.sh / kstats2.sh: what one forward frame is made of)."""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+import bench
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = torch.device('cuda', 0)
+gs = bench.build_gs_scene(dev, n)
+t = gs['tensors']
+m2d = torch.zeros_like(t['means3D'])
+with torch.no_grad():
+    for _ in range(3):
+        gs['rast'](means3D=t['means3D'], means2D=m2d, opacities=t['opacities'], shs=t['shs'], scales=t['scales'], rotations=t['rotations'])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(frames):
+        gs['rast'](means3D=t['means3D'], means2D=m2d, opacities=t['opacities'], shs=t['shs'], scales=t['scales'], rotations=t['rotations'])
+    torch.cuda.synchronize()
+print('forward ms', (time.perf_counter() - t0) / frames * 1e3)
