@@ -750,6 +750,115 @@ __global__ void __launch_bounds__(64) k_span_scatter(int P, int nb1, int chunk1,
         r = nxt;
     }
 }
+// Level 1 in ONE launch (round 4; count / scan / rows / scatter above remain for reference builds: -DGS_SPAN_CHAIN).  A workgroup takes a tile of 4 096
+// consecutive Gaussians of the depth order, its four waves 1 024 each.  (A) every wave counts its spans per tile row (LDS atomics, wave-private
+// tables); thread y publishes the tile's count of row y and adds up what the earlier tiles published -- the same two-level prefix as the
+// depth sort (k_radix_pass) --; the row starts come from the row totals that k_depth_keys left in the sort header.  (B) every wave scatters its
+// spans with the bit-matrix ranking, cursors = row start + earlier tiles + earlier waves of the tile.  Rectangles and ids stay in registers
+// between (A) and (B).  Workgroup 0 also writes the row tables of level 2.
+#define SP_TILE 4096
+#define SP_THREADS 1024                      // 16 waves x 256 Gaussians: the scatter of a wave is a serial chain over its steps of 64, so many short chains
+#define SP_WAVES (SP_THREADS / 64)
+#define SP_ITEMS (SP_TILE / SP_THREADS)
+// exclusive scan over the values of threads 0..255 of a larger workgroup (the others pass 0 and ignore the result); everyone meets at the barriers
+__device__ __forceinline__ int scan256_of_big_block(int v, int* sm, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = 0;
+    if (wave < 4) { incl = nrc_wave_incl_sum_i(v, lane); if (lane == 63) sm[wave] = incl; }
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const int t = sm[w]; if (w < wave) base += t; }
+    if (total) *total = sm[0] + sm[1] + sm[2] + sm[3];
+    __syncthreads();
+    return base + incl - v;
+}
+template <bool TICKET>
+__global__ void __launch_bounds__(SP_THREADS) k_span_sweep(int P, int gy, int n_tiles, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rects,
+                                                           uint32_t* __restrict__ hdr, uint32_t* __restrict__ status, uint32_t* __restrict__ gstat, int64_t cap,
+                                                           uint2* __restrict__ spans, uint32_t* __restrict__ rowtot_out, uint32_t* __restrict__ roff_out,
+                                                           uint32_t* __restrict__ nitems, uint32_t* __restrict__ ioff, int64_t* __restrict__ meta_spans,
+                                                           uint32_t* __restrict__ meta) {
+    __shared__ uint32_t cnt[SP_WAVES][SPAN_DIM_MAX];        // per wave: spans per row, later the wave's first position in the row's list
+    __shared__ uint32_t bits[SP_WAVES][SPAN_DIM_MAX][2];
+    __shared__ uint2 rec[SP_WAVES][64];
+    __shared__ int sm[8];
+    __shared__ int tile_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, y_of = threadIdx.x;
+    const bool row_thread = y_of < gy;   // threads 0 .. gy - 1 also look after one tile row each
+    if (TICKET && threadIdx.x == 0) tile_s = (int)atomicAdd(&hdr[RS_HDR_TICKET + 4], 1u);
+    for (int k = threadIdx.x; k < SP_WAVES * SPAN_DIM_MAX; k += SP_THREADS) { (&cnt[0][0])[k] = 0u; (&bits[0][0][0])[2 * k] = 0u; (&bits[0][0][0])[2 * k + 1] = 0u; }
+    const int row_total = row_thread ? (int)hdr[RS_HDR_ROWS + y_of] : 0;
+    __syncthreads();
+    const int tile = TICKET ? tile_s : (int)blockIdx.x;
+    const int begin = tile * SP_TILE + wave * (64 * SP_ITEMS), end = min(P, begin + 64 * SP_ITEMS);
+    SpanRect r[SP_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SP_ITEMS; k++) r[k] = span_rect(begin + 64 * k + lane, end, order, rects);
+    uint32_t* mine = cnt[wave];
+#pragma unroll
+    for (int k = 0; k < SP_ITEMS; k++)
+        if (r[k].ok)
+            for (int y = r[k].y0; y < r[k].y1; y++) atomicAdd(&mine[y], 1u);
+    __syncthreads();
+    uint32_t my_count = 0u;
+    if (row_thread) {
+#pragma unroll
+        for (int w = 0; w < SP_WAVES; w++) my_count += cnt[w][y_of];
+        rs_publish(status + (size_t)tile * 256 + y_of, my_count);
+    }
+    // row starts (and, for workgroup 0, the level-2 tables): two scans over the rows
+    int tot_s, tot_i;
+    const int row_start = scan256_of_big_block(row_total, sm, &tot_s);
+    const int ch = tot_s < (3 << 20) ? SPAN_CH_MIN : (tot_s < (6 << 20) ? 2 * SPAN_CH_MIN : SPAN_CH_MAX);
+    const int it = (row_total + ch - 1) / ch;
+    const int item_start = scan256_of_big_block(it, sm, &tot_i);
+    if (blockIdx.x == 0) {
+        if (row_thread) { rowtot_out[y_of] = (uint32_t)row_total; roff_out[y_of] = (uint32_t)row_start; nitems[y_of] = (uint32_t)it; ioff[y_of] = (uint32_t)item_start; }
+        if (threadIdx.x == 0) { *meta_spans = (int64_t)tot_s; meta[0] = (uint32_t)tot_i; meta[1] = (uint32_t)ch; }
+    }
+    const int group = tile / RS_GROUP, g0 = group * RS_GROUP, n_in = tile - g0;
+    const bool group_leader = tile == g0 + RS_GROUP - 1 || tile == n_tiles - 1;
+    if (row_thread) {
+        const uint32_t* col = status + (size_t)g0 * 256 + y_of;
+        const uint32_t in_group = rs_sum_published(col, n_in, 256);
+        if (group_leader) rs_publish(gstat + (size_t)group * 256 + y_of, in_group + my_count);
+        uint32_t o = (uint32_t)row_start + in_group + rs_sum_published(gstat + y_of, group, 256);
+#pragma unroll
+        for (int w = 0; w < SP_WAVES; w++) { const uint32_t c = cnt[w][y_of]; cnt[w][y_of] = o; o += c; }
+    }
+    __syncthreads();
+    const int nk = (gy + 63) >> 6;
+    int64_t cur[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = (int64_t)mine[64 * k + lane];
+    uint32_t (*wbits)[2] = bits[wave];
+    uint2* wrec = rec[wave];
+#pragma unroll
+    for (int k = 0; k < SP_ITEMS; k++) {
+        if (begin + 64 * k >= end) break;
+        // one wave: its LDS operations execute in program order, so the ORs of all lanes are in place when the words are read (no workgroup barrier;
+        // the wavefront-scope fences only keep the compiler from moving the accesses)
+        wrec[lane] = make_uint2((uint32_t)r[k].id, (uint32_t)r[k].x01);
+        if (r[k].ok)
+            for (int y = r[k].y0; y < r[k].y1; y++) atomicOr(&wbits[y][lane >> 5], 1u << (lane & 31));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (q >= nk) break;
+            const int y = 64 * q + lane;
+            uint32_t lo = wbits[y][0], hi = wbits[y][1];
+            if (lo | hi) { wbits[y][0] = 0u; wbits[y][1] = 0u; }
+            while (lo | hi) {  // ascending bit = ascending lane = depth order
+                int src;
+                if (lo) { src = __builtin_ctz(lo); lo &= lo - 1u; } else { src = 32 + __builtin_ctz(hi); hi &= hi - 1u; }
+                if (cur[q] < cap) spans[cur[q]] = wrec[src];
+                cur[q]++;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
 // the level-2 item `item`: its row, its first span and its span count (row tables in 4 registers x 64 lanes)
 struct SpanItem { int y; int64_t s0; int n; };
 __device__ __forceinline__ SpanItem span_item(int item, int ch, int gy, const int (&ioff_v)[4], const int (&nit_v)[4], const int (&roff_v)[4],
@@ -796,29 +905,81 @@ __global__ void __launch_bounds__(64) k_item_count(int gx, int gy, const uint32_
     }
 }
 // per tile (y, x): exclusive scan of cnt2[item][x] over the items of row y (in place) and the tile total.  64 tiles x 16 item groups per workgroup.
-__global__ void __launch_bounds__(1024) k_item_scan(int gx, int item_cap, const uint32_t* __restrict__ nitems, const uint32_t* __restrict__ ioff,
-                                                    uint32_t* __restrict__ cnt2, uint32_t* __restrict__ tcount) {
+// Round 4: the loads of a thread's items are requested eight at a time (one at a time, each was a full L2 latency), and the workgroup that
+// finishes LAST runs what used to be two more launches: the scan of the tile totals into `ranges` (k_scan_tiles) and the launch order of the
+// tiles, longest list first (k_tile_order).  Hand-over: the totals are written through (sc1) and drained, one lane per workgroup takes a
+// ticket with a returning agent-scope atomic, the last ticket holder reads the totals with sc1 loads.
+__device__ __forceinline__ void tile_order_of(int n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order, uint32_t* hist, uint32_t* wsum);
+__global__ void __launch_bounds__(1024) k_item_scan(int gx, int gy, int item_cap, const uint32_t* __restrict__ nitems, const uint32_t* __restrict__ ioff,
+                                                    uint32_t* __restrict__ cnt2, uint32_t* __restrict__ tcount, uint32_t* __restrict__ done_counter,
+                                                    uint32_t cap, uint32_t* __restrict__ ranges, uint32_t* __restrict__ order, int64_t* __restrict__ num_rendered) {
     __shared__ uint32_t gsum[16][64];
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    __shared__ int last_s;
     const int xl = threadIdx.x & 63, g = threadIdx.x >> 6, y = blockIdx.y, x = blockIdx.x * 64 + xl;
     const int i0 = min((int)ioff[y], item_cap), ni = min((int)nitems[y], item_cap - i0);
     const int per = (ni + 15) / 16, a = min(ni, g * per), b = min(ni, a + per);
     uint32_t s = 0;
     if (x < gx)
-        for (int i = a; i < b; i++) s += cnt2[(size_t)(i0 + i) * gx + x];
+        for (int i = a; i < b; i += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = i + k < b ? cnt2[(size_t)(i0 + i + k) * gx + x] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) s += v[k];
+        }
     gsum[g][xl] = s;
     __syncthreads();
     uint32_t run = 0, tot = 0;
 #pragma unroll
     for (int q = 0; q < 16; q++) { const uint32_t v = gsum[q][xl]; tot += v; if (q < g) run += v; }
     if (x < gx) {
-        for (int i = a; i < b; i++) {
-            const size_t k = (size_t)(i0 + i) * gx + x;
-            const uint32_t c = cnt2[k];
-            cnt2[k] = run;
-            run += c;
+        for (int i = a; i < b; i += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = i + k < b ? cnt2[(size_t)(i0 + i + k) * gx + x] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (i + k < b) cnt2[(size_t)(i0 + i + k) * gx + x] = run;
+                run += v[k];
+            }
         }
-        if (g == 0) tcount[(size_t)y * gx + x] = tot;
+        if (g == 0) __hip_atomic_store(&tcount[(size_t)y * gx + x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // ---- the last workgroup to get here scans the tile totals and orders the tiles
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t ticket = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = ticket == gridDim.x * gridDim.y - 1u;
+        carry_s = 0u;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    const int n = gx * gy;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < n ? __hip_atomic_load(&tcount[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (int w = 0; w < wave; w++) off += wave_tot[w];
+        if (i < n) { ranges[2 * i] = min(off + incl - v, cap); ranges[2 * i + 1] = min(off + incl, cap); }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *num_rendered = (int64_t)carry_s;
+    tile_order_of(n, ranges, order, hist, wave_tot);
 }
 // level 2, scatter: ids of the item's spans appended to the tiles they cover; tile (y, x) of this item starts at ranges[tile].first + cnt2[item][x]
 template <bool CAPPED>  // CAPPED: the caller fixed the length of point_list (graph capture); entries that would land behind it are dropped
@@ -974,9 +1135,8 @@ __global__ void __launch_bounds__(256) k_sort_tiles(const uint32_t* __restrict__
 // Tile lists are heavy-tailed (mean 1 920, max 7 010 entries on the bench frame) and a frame is only ~2 rounds of workgroups: a long tile
 // that starts late finishes alone.  The render kernels therefore take their tile from a table sorted by list length, longest first
 // (counting sort over 2 048 length classes, one workgroup).
-__global__ void __launch_bounds__(1024) k_tile_order(int n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order) {
-    __shared__ uint32_t hist[2048];
-    __shared__ uint32_t wsum[16];
+// one workgroup of 1024 threads; hist: 2048 words, wsum: 16 words of LDS.  `ranges` may have been written by this very workgroup (behind a barrier).
+__device__ __forceinline__ void tile_order_of(int n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order, uint32_t* hist, uint32_t* wsum) {
     for (int k = threadIdx.x; k < 2048; k += 1024) hist[k] = 0u;
     __syncthreads();
     auto cls = [&](int t) { const uint32_t len = ranges[2 * t + 1] - ranges[2 * t]; return 2047u - min(len >> 2, 2047u); };  // class 0 = longest
@@ -1001,6 +1161,11 @@ __global__ void __launch_bounds__(1024) k_tile_order(int n_tiles, const uint32_t
     // placement with an LDS cursor per class: the order inside a class depends on the atomics' arrival, which only permutes the launch order of
     // tiles of (nearly) equal length -- every tile's result is independent of when it runs
     for (int t = threadIdx.x; t < n_tiles; t += 1024) order[atomicAdd(&hist[cls(t)], 1u)] = (uint32_t)t;
+}
+__global__ void __launch_bounds__(1024) k_tile_order(int n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t wsum[16];
+    tile_order_of(n_tiles, ranges, order, hist, wsum);
 }
 
 // ------------------------------------------------------------------------------------------------ 5. render
@@ -1722,9 +1887,9 @@ BinWs gs_bin_ws(uint32_t* base, int P, int gx, int gy, int64_t cap) {
     auto take = [&](int64_t n, int64_t align_words) { q = base + ((q - base) + align_words - 1) / align_words * align_words; uint32_t* r = q; q += n; return r; };
     w.keyA = take(p1, 4); w.valA = take(p1, 4); w.rectA = take(p1, 4); w.keyB = take(p1, 4); w.valB = take(p1, 4); w.rectB = take(p1, 4);
     w.hdr = take(RS_HDR_WORDS, 4);
-    w.n_status = (int64_t)4 * 256 * (w.nblk + w.ngroups);   // status of pass p at + p * 256 * nblk, the group totals behind all four
+    w.n_status = (int64_t)5 * 256 * (w.nblk + w.ngroups);   // status of sort pass p (4 = the span sweep) at + p * 256 * nblk, the group totals behind all five
     w.status = take(w.n_status, 4);
-    w.gstat = w.status + (int64_t)4 * 256 * w.nblk;
+    w.gstat = w.status + (int64_t)5 * 256 * w.nblk;
     w.cnt1 = take((int64_t)gy * w.nb1, 4);
     w.rowtot = take(gy, 4); w.roff = take(gy, 4); w.nitems = take(gy, 4); w.ioff = take(gy, 4);
     w.meta = take(4, 4);
@@ -1816,7 +1981,8 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                                        w.status + (int64_t)pass * 256 * w.nblk, w.gstat + (int64_t)pass * 256 * w.ngroups, pass == 3 ? (uint32_t*)nullptr : ko, vo, ro);
                 NRC_STAGE(s, "k_radix_pass");
             }
-            // level 1: row spans in depth order; level 2 counting + scans: tile ranges and the per-(item, tile) cursors
+            // level 1: row spans in depth order (one launch); level 2 counting + scans: tile ranges and the per-(item, tile) cursors
+#if defined(GS_SPAN_CHAIN)
             hipLaunchKernelGGL(k_span_count, dim3(w.nb1), dim3(64), 0, s, P, w.nb1, w.chunk1, cam.gy, w.valA, w.rectA, w.cnt1);
             NRC_STAGE(s, "k_span_count");
             hipLaunchKernelGGL(k_span_scan, dim3(cam.gy), dim3(256), 0, s, w.nb1, w.cnt1, w.rowtot);
@@ -1825,13 +1991,23 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
             NRC_STAGE(s, "k_span_rows");
             hipLaunchKernelGGL(k_span_scatter, dim3(w.nb1), dim3(64), 0, s, P, w.nb1, w.chunk1, cam.gy, w.valA, w.rectA, w.cnt1, w.roff, w.cap, w.spans);
             NRC_STAGE(s, "k_span_scatter");
+#else
+            static_assert(SP_TILE == RS_TILE, "the span sweep shares the sort's tile count and status layout");
+            if (w.nblk <= cu_count)
+                hipLaunchKernelGGL(k_span_sweep<false>, dim3(w.nblk), dim3(SP_THREADS), 0, s, P, cam.gy, w.nblk, w.valA, w.rectA, w.hdr, w.status + (int64_t)4 * 256 * w.nblk,
+                                   w.gstat + (int64_t)4 * 256 * w.ngroups, w.cap, w.spans, w.rowtot, w.roff, w.nitems, w.ioff, num_rendered + 1, w.meta);
+            else
+                hipLaunchKernelGGL(k_span_sweep<true>, dim3(w.nblk), dim3(SP_THREADS), 0, s, P, cam.gy, w.nblk, w.valA, w.rectA, w.hdr, w.status + (int64_t)4 * 256 * w.nblk,
+                                   w.gstat + (int64_t)4 * 256 * w.ngroups, w.cap, w.spans, w.rowtot, w.roff, w.nitems, w.ioff, num_rendered + 1, w.meta);
+            NRC_STAGE(s, "k_span_sweep");
+#endif
             hipLaunchKernelGGL(k_item_count, dim3(SPAN_GRID_COUNT), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.cap, w.item_cap,
                                w.spans, w.cnt2);
             NRC_STAGE(s, "k_item_count");
-            hipLaunchKernelGGL(k_item_scan, dim3((unsigned)nrc_cdiv(cam.gx, 64), cam.gy), dim3(1024), 0, s, cam.gx, w.item_cap, w.nitems, w.ioff, w.cnt2, w.tcount);
+            // per-(item, tile) cursors, tile totals; its last workgroup: ranges, instance count and the launch order of the tiles (into tile_fill)
+            hipLaunchKernelGGL(k_item_scan, dim3((unsigned)nrc_cdiv(cam.gx, 64), cam.gy), dim3(1024), 0, s, cam.gx, cam.gy, w.item_cap, w.nitems, w.ioff, w.cnt2, w.tcount,
+                               w.hdr + RS_HDR_TICKET + 5, list_cap, ranges, tile_fill, num_rendered);
             NRC_STAGE(s, "k_item_scan");
-            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, w.tcount, n_tiles, list_cap, ranges, tile_fill, num_rendered);
-            NRC_STAGE(s, "k_scan_tiles");
         }
     }
     if (!(P > 0 && lds_path)) {
@@ -1878,8 +2054,10 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
         }
     }
     // tile_fill has served the fallback scatter (if any): it now carries the launch order of the tiles, longest list first, for both render kernels
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cam.gx * cam.gy, ranges, tile_fill);
-    NRC_STAGE(s, "k_tile_order");
+    if (!(P > 0 && cam.gx <= SPAN_DIM_MAX && cam.gy <= SPAN_DIM_MAX && bin_hist)) {   // the span path left the order in tile_fill already (k_item_scan)
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, cam.gx * cam.gy, ranges, tile_fill);
+        NRC_STAGE(s, "k_tile_order");
+    }
     hipLaunchKernelGGL(k_render, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_fill, bg[0], bg[1], bg[2],
                        camera_dev, out_color, n_contrib, final_T);
     NRC_STAGE(s, "k_render");
