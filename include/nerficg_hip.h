@@ -269,7 +269,9 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
  * normalisation run inside preprocess (the backward returns gradients w.r.t. the raw values; dL_dsh_rest receives the remainder's gradient).
  * splat_records (P,16) f32: one 64-byte line per Gaussian with everything the blend kernels read of it (screen position, conic, opacity,
  * colour) and the per-Gaussian part of their block-culling test; written by nrc_gs_preprocess, read by nrc_gs_bin_render / nrc_gs_backward.
- * (tile_fill doubles as `tile_order` after nrc_gs_bin_render: the tiles sorted by list length, longest first = launch order of the blend kernels.)
+ * (tile_fill doubles as `tile_order`: the tiles sorted by list length, longest first = launch order of the blend kernels.  ABI 3: with a binning
+ * workspace it is written by nrc_gs_preprocess already -- the last workgroup of the tile scan orders the tiles --, otherwise by nrc_gs_bin_render;
+ * either way it is valid after nrc_gs_bin_render and must reach nrc_gs_backward unchanged.)
  * Binning state: tile_counts, tile_fill (n_tiles) u32, ranges (n_tiles,2) u32, keys (num_rendered) u64, point_list
  * (num_rendered) i32.  Image state: n_contrib (H*W) u32, final_T (H*W).
  *   nrc_gs_preprocess : stages 1-2; num_rendered (DEVICE i64[2]): [0] = number of (tile, Gaussian) instances -- the caller reads it
@@ -285,10 +287,12 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
  *   nrc_gs_bin_render : stages 3-5 -> out_color (3,H,W) = C + T * bg, n_contrib, final_T.
  *   nrc_gs_backward   : dL_dpix (3,H,W) -> every gradient (all fully written; dL_dmean2D (P,3) is the screen-space gradient
  *                       consumed by densification, src/Methods/GaussianSplatting/Model.py:258).  grad_records: WORKSPACE (P,16) f32, 64-byte
- *                       aligned, cleared by the call: the blend backward accumulates its nine per-Gaussian sums in one 64-byte record per
+ *                       aligned: the blend backward accumulates its nine per-Gaussian sums in one 64-byte record per
  *                       Gaussian (colour 3, opacity 1, mean2D 2, conic 3) so that a tile's flush for a Gaussian is one contiguous group of one
  *                       atomic instruction; dL_dmean2D / dL_dopacity (and dL_dconic (P,4) / dL_dcolor (P,3), which may be NULL) are written
- *                       from the records by the per-Gaussian backward.
+ *                       from the records by the per-Gaussian backward, WHICH LEAVES EVERY RECORD IT READ CLEARED (ABI 3).  records_clear = 0:
+ *                       the call clears the workspace first (any contents); records_clear != 0: the caller guarantees that all P x 16 floats
+ *                       are zero -- e.g. the same buffer after a previous nrc_gs_backward of the same P -- and the clearing launch is skipped.
  * ===================================================================================================== */
 /* bytes of the binning workspace `bin_hist` (depth pre-sort buffers, row-span records, cursors) for `span_capacity` span records
  * (0 = default 4 P + 65536); returns 0 when the image has more than 256 tile rows or columns: pass NULL, the per-tile key sort is used.
@@ -315,7 +319,7 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
                     const float* final_T, const float* dL_dpix,
                     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                     float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale, float* dL_drot, float* grad_records,
-                    nrc_stream_t stream);
+                    int32_t records_clear, nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 5 -- ray generation (replaces PerspectiveCamera.compute_local_ray_directions src/Cameras/Perspective.py:64-94

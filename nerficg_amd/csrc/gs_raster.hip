@@ -169,13 +169,15 @@ __device__ __forceinline__ void tile_rect(const float* p, int radius, int gx, in
 // ------------------------------------------------------------------------------------------------ 1. preprocess
 // Splat record: what the two render kernels need of a Gaussian, in ONE 64-byte line (they used to gather xy, conic + opacity and rgb from
 // three arrays = three cache lines per list entry), plus the per-Gaussian part of their block tests precomputed once instead of once per
-// (tile, Gaussian) pair:  q0 = {X, Y, A, B}  q1 = {C, o, r, g}  q2 = {b, ext_x, ext_y, A tau}  q3 = {det, B / A, y_off, 1 / A}
+// (tile, Gaussian) pair:  q0 = {X, Y, A, B}  q1 = {C, o, ext_x, ext_y}  q2 = {tau / A, det / A^2, B / A, y_off}  q3 = {r, g, b, -}
+// (round 4: the colour has the last vector to itself -- the one part of the record that the SH evaluation produces; the colour pass of the
+// preprocessing (k_preprocess<2>, side stream) writes it with one 16-byte store, the geometry pass (k_preprocess<1>) the other three vectors)
 //   alpha >= 1/255  <=>  A dx^2 + 2 B dx dy + C dy^2 <= tau = 2 ln(255 o)   (the ellipse a pixel must be inside to blend the Gaussian)
 //   ext_x, ext_y = half extents of that ellipse's bounding box (margins: x 1.001 + 0.01 px);  ext_x = -1: never blends;  +inf: not an ellipse
 //   y_off = (B / C) sqrt(tau C / det): the ellipse's leftmost / rightmost points lie at Y +- y_off
 __device__ __forceinline__ void write_splat_record(float4 (&rec)[4], float X, float Y, float A, float B, float C, float o, const float* col) {
     const float inf = __builtin_inff();
-    float ex = -1.f, ey = -1.f, atau = 0.f, det = 0.f, ba = 0.f, yoff = 0.f, inva = 0.f;
+    float ex = -1.f, ey = -1.f, ta = 0.f, da = 0.f, det = 0.f, ba = 0.f, yoff = 0.f;
     if (o > 0.f) {
         const float tau = 2.f * (logf(255.f * o) + 1e-3f);
         if (tau > 0.f) {
@@ -183,14 +185,17 @@ __device__ __forceinline__ void write_splat_record(float4 (&rec)[4], float X, fl
             if (!(det > 0.f) || !(A > 0.f) || !(C > 0.f)) { ex = inf; ey = inf; }
             else {
                 ex = sqrtf(tau * C / det) * 1.001f + 0.01f; ey = sqrtf(tau * A / det) * 1.001f + 0.01f;
-                atau = A * tau; ba = B / A; inva = 1.0f / A; yoff = (B / C) * sqrtf(tau * C / det);
+                ta = tau / A; da = det / (A * A); ba = B / A; yoff = (B / C) * sqrtf(tau * C / det);
             }
         }
     }
-    rec[0] = make_float4(X, Y, A, B); rec[1] = make_float4(C, o, col[0], col[1]);
-    rec[2] = make_float4(col[2], ex, ey, atau); rec[3] = make_float4(det, ba, yoff, inva);
+    rec[0] = make_float4(X, Y, A, B); rec[1] = make_float4(C, o, ex, ey);
+    rec[2] = make_float4(ta, da, ba, yoff); rec[3] = make_float4(col[0], col[1], col[2], 0.f);
 }
-// one Gaussian; sh_row = its SH coefficients (LDS copy, see k_preprocess)
+// one Gaussian; sh_row = its SH coefficients (LDS copy, see k_preprocess).  The same computation whatever the template flags; GEOM: the geometry
+// outputs are stored (radii, depths, screen position, conic + opacity, cov3D, tiles_touched, vectors 0..2 of the record), COLOR: the colour outputs
+// (rgb, clamped, vector 3 of the record).  The two passes of a split preprocessing decide a Gaussian's visibility identically (same arithmetic).
+template <bool GEOM, bool COLOR>
 __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const float* __restrict__ means3D, const float* sh_row,
                                                const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                                                const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -199,13 +204,17 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
                                                float* __restrict__ conic_opacity, float* __restrict__ rgb, uint8_t* __restrict__ clamped,
                                                float* __restrict__ cov3D, uint32_t* __restrict__ tiles_touched,
                                                uint32_t* __restrict__ tile_counts, bool want_record, float4 (&splat)[4]) {
-    radii[i] = 0; tiles_touched[i] = 0; depths[i] = 0.f;
-    points_xy[2 * i] = 0.f; points_xy[2 * i + 1] = 0.f;
+    if (GEOM) {
+        radii[i] = 0; tiles_touched[i] = 0; depths[i] = 0.f;
+        points_xy[2 * i] = 0.f; points_xy[2 * i + 1] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; k++) conic_opacity[4 * i + k] = 0.f;
+        for (int k = 0; k < 4; k++) conic_opacity[4 * i + k] = 0.f;
+    }
+    if (COLOR) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) rgb[3 * i + k] = 0.f;
-    clamped[i] = 0;
+        for (int k = 0; k < 3; k++) rgb[3 * i + k] = 0.f;
+        clamped[i] = 0;
+    }
     const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
     float pv[3];
     xform43(p, cam.view, pv);
@@ -219,8 +228,10 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
         act_rotation(rotations + 4 * i, cam.raw, q);
         cov3d(s, cam.scale_modifier, q, c3);
     }
+    if (GEOM) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) cov3D[6 * i + k] = c3[k];
+        for (int k = 0; k < 6; k++) cov3D[6 * i + k] = c3[k];
+    }
     if (pv[2] <= 0.2f) return;
     float ph[4];
     xform44(p, cam.proj, ph);
@@ -244,19 +255,22 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
     int rmin[2], rmax[2];
     tile_rect(pix, my_radius, cam.gx, cam.gy, rmin, rmax);
     if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) return;
-    float col[3];
-    if (colors_precomp) {
+    float col[3] = {0.f, 0.f, 0.f};
+    if (COLOR) {
+        if (colors_precomp) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) col[k] = colors_precomp[3 * i + k];
-    } else {
-        uint8_t cl;
-        sh_color(cam.D, p, cam.campos, sh_row, col, &cl);
-        clamped[i] = cl;
+            for (int k = 0; k < 3; k++) col[k] = colors_precomp[3 * i + k];
+        } else {
+            uint8_t cl;
+            sh_color(cam.D, p, cam.campos, sh_row, col, &cl);
+            clamped[i] = cl;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) rgb[3 * i + k] = col[k];
     }
-#pragma unroll
-    for (int k = 0; k < 3; k++) rgb[3 * i + k] = col[k];
     const float opacity = cam.raw ? act_sigmoid(opacities[i]) : opacities[i];
     if (want_record) write_splat_record(splat, pix[0], pix[1], conic[0], conic[1], conic[2], opacity, col);  // this thread's row of the LDS image
+    if (!GEOM) return;
     depths[i] = pv[2]; radii[i] = my_radius;
     points_xy[2 * i] = pix[0]; points_xy[2 * i + 1] = pix[1];
     conic_opacity[4 * i] = conic[0]; conic_opacity[4 * i + 1] = conic[1]; conic_opacity[4 * i + 2] = conic[2];
@@ -304,6 +318,12 @@ __device__ __forceinline__ void sh_rows_copy(float* s_sh, int pitch, int row_len
 #ifndef PRE_MAXM
 #define PRE_MAXM 16
 #endif
+// PART 0: everything in one pass (tile grids without the span binning, graph captures, armed stage timer).  PART 1: the geometry outputs -- what
+// the depth sort and the binning wait for (44 B read per Gaussian instead of 236).  PART 2: the colour outputs (rgb, clamped, vector 3 of the
+// records): the same per-Gaussian computation, the 192-byte SH rows staged through LDS, on a FEW persistent workgroups (grid-stride over the
+// 128-Gaussian blocks) of a side stream, so that it runs NEXT TO the geometry pass, the depth sort and the binning, whose kernels are
+// latency-bound and leave the memory system idle, without taking their compute units (round 4; joined before nrc_gs_preprocess returns).
+template <int PART>
 __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam_arg, const float* __restrict__ pose, const float* __restrict__ means3D, const float* __restrict__ shs,
                                                           const float* __restrict__ shs_rest,
                                                           const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -313,36 +333,45 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam_arg, 
                                                           float* __restrict__ conic_opacity, float* __restrict__ rgb, uint8_t* __restrict__ clamped,
                                                           float* __restrict__ cov3D, uint32_t* __restrict__ tiles_touched,
                                                           uint32_t* __restrict__ tile_counts, float4* __restrict__ splat, uint32_t* __restrict__ sort_hdr) {
-    __shared__ __attribute__((aligned(16))) float s_sh[PRE_BLOCK * (3 * PRE_MAXM + 1)];
-    if (sort_hdr && blockIdx.x == 0)   // digit totals, row totals and tile tickets of the depth sort behind this kernel start at zero
+    __shared__ __attribute__((aligned(16))) float s_sh[PART == 1 ? PRE_BLOCK * 12 : PRE_BLOCK * (3 * PRE_MAXM + 1)];
+    if (PART != 2 && sort_hdr && blockIdx.x == 0)   // digit totals, row totals and tile tickets of the depth sort behind this kernel start at zero
         for (int k = threadIdx.x; k < RS_HDR_WORDS; k += PRE_BLOCK) sort_hdr[k] = 0u;
     const GsCam cam = cam_with_pose(cam_arg, pose);
-    const int first = blockIdx.x * PRE_BLOCK, i = first + threadIdx.x;
     const int row_len = 3 * cam.M, pitch = row_len + 1;
-    if (shs) {
-        sh_rows_copy<true>(s_sh, pitch, row_len, min(PRE_BLOCK, P - first), (size_t)first, const_cast<float*>(shs), const_cast<float*>(shs_rest), PRE_BLOCK);
-        __syncthreads();
-    }
-    // splat records leave through LDS: a lane storing its own 64-byte record touches 64 cache lines per store instruction; from the LDS image
-    // (the SH staging area, free again once every thread has evaluated its colour) the workgroup writes its 128 x 64 B block with coalesced
-    // 16-byte stores.  Rows of culled Gaussians hold stale bytes: no tile list ever names them.
-    float4 rec[4] = {};
-    if (i < P)
-        preprocess_one(i, cam, means3D, s_sh + threadIdx.x * pitch, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, depths,
-                       points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched, tile_counts, splat != nullptr, rec);
-    if (splat) {
-        float4* s_rec = reinterpret_cast<float4*>(s_sh);  // 128 x 64 B = 8 KB of the 25 KB
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; k++) s_rec[4 * threadIdx.x + k] = rec[k];
-        __syncthreads();
-        const int n4 = 4 * min(PRE_BLOCK, P - first);
-        float4* dst = splat + 4 * (size_t)first;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = threadIdx.x + PRE_BLOCK * k;
-            if (e < n4) dst[e] = s_rec[e];
+    const int n_blocks = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int first = blk * PRE_BLOCK, i = first + threadIdx.x;
+        if (PART != 1 && shs) {
+            sh_rows_copy<true>(s_sh, pitch, row_len, min(PRE_BLOCK, P - first), (size_t)first, const_cast<float*>(shs), const_cast<float*>(shs_rest), PRE_BLOCK);
+            __syncthreads();
         }
+        // splat records leave through LDS: a lane storing its own record touches 64 cache lines per store instruction; from the LDS image (the SH
+        // staging area, free again once every thread has evaluated its colour) the workgroup writes its block with coalesced 16-byte stores.
+        // Rows of culled Gaussians hold zeros or stale bytes: no tile list ever names them.
+        float4 rec[4] = {};
+        if (i < P)
+            preprocess_one<PART != 2, PART != 1>(i, cam, means3D, s_sh + threadIdx.x * pitch, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, depths,
+                                                 points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched, tile_counts, splat != nullptr, rec);
+        if (splat) {
+            if (PART == 2) {   // vector 3 only: one 16-byte store per Gaussian
+                if (i < P) splat[4 * (size_t)i + 3] = rec[3];
+            } else {
+                constexpr int NV = PART == 0 ? 4 : 3;   // vectors of a record this pass writes
+                float4* s_rec = reinterpret_cast<float4*>(s_sh);
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < NV; k++) s_rec[NV * threadIdx.x + k] = rec[k];
+                __syncthreads();
+                const int nv = NV * min(PRE_BLOCK, P - first);
+                float4* dst = splat + 4 * (size_t)first;
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    const int e = threadIdx.x + PRE_BLOCK * k;
+                    if (e < nv) dst[NV == 4 ? e : 4 * (e / 3) + e % 3] = s_rec[e];
+                }
+            }
+        }
+        if (PART == 2) __syncthreads();   // the SH rows of the next block overwrite the staging area
     }
 }
 
@@ -1186,8 +1215,8 @@ __device__ __forceinline__ int tile_py(unsigned t) { return (int)(((t >> 2) & 3u
 // spans inside the band (chords at the band's two edges -- clamped to the ellipse's y-range --, widened to the box where the leftmost /
 // rightmost point of the ellipse lies inside the band) against the column bands.  On the bench scene the box keeps 6.2 blocks per
 // (tile, Gaussian) pair of a blended prefix, the band intervals 4.7, an exact per-pixel test 4.5 (tools/gs_stats.py).
-__device__ __forceinline__ unsigned block_flags(const float4& q0, const float4& q2, const float4& q3, float tx0, float ty0) {
-    const float X = q0.x, Y = q0.y, ex = q2.y, ey = q2.z;
+__device__ __forceinline__ unsigned block_flags(const float4& q0, const float4& q1, const float4& q2, float tx0, float ty0) {
+    const float X = q0.x, Y = q0.y, ex = q1.z, ey = q1.w;
     if (!(ex >= 0.f)) return 0u;  // never reaches the threshold
     unsigned col = 0, row = 0;
 #pragma unroll
@@ -1199,12 +1228,12 @@ __device__ __forceinline__ unsigned block_flags(const float4& q0, const float4& 
     if (col == 0u || row == 0u) return 0u;
     unsigned cols[4] = {col, col, col, col};
     if (ex < __builtin_inff()) {
-        const float atau = q2.w, det = q3.x, ba = q3.y, yoff = q3.z, inva = q3.w;
+        const float ta = q2.x, da = q2.y, ba = q2.z, yoff = q2.w;   // half chord at offset d from the centre row: sqrt(tau / A - (det / A^2) d^2)
         float lo[5], hi[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const float d = fminf(fmaxf(Y - (ty0 + (float)(4 * k)), -ey), ey);
-            const float w = __builtin_amdgcn_sqrtf(fmaxf(atau - det * d * d, 0.f)) * inva;
+            const float w = __builtin_amdgcn_sqrtf(fmaxf(ta - da * d * d, 0.f));
             const float mid = X + ba * d;
             lo[k] = mid - w; hi[k] = mid + w;
         }
@@ -1246,11 +1275,11 @@ struct StageLds {
 __device__ __forceinline__ unsigned stage_entry(StageLds& st, const float4* __restrict__ splat, int id, float tx0, float ty0) {
     const float4* rec = splat + 4 * (size_t)id;
     const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-    const unsigned flags = block_flags(q0, q2, q3, tx0, ty0);
+    const unsigned flags = block_flags(q0, q1, q2, tx0, ty0);
     if (flags) {
-        st.a[threadIdx.x] = make_float4(q0.x, q0.y, q1.z, q1.w);
+        st.a[threadIdx.x] = make_float4(q0.x, q0.y, q3.x, q3.y);
         st.b[threadIdx.x] = make_float4(q0.z, q0.w, q1.x, q1.y);
-        st.c[threadIdx.x] = q2.x;
+        st.c[threadIdx.x] = q3.z;
     }
     return flags;
 }
@@ -1501,15 +1530,15 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             id_l = point_list[r0 + pos_top - threadIdx.x];
             const float4* rec = splat + 4 * (size_t)id_l;
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-            flags = block_flags(q0, q2, q3, tx0, ty0);
+            flags = block_flags(q0, q1, q2, tx0, ty0);
             const int pos_l = pos_top - (int)threadIdx.x;
 #pragma unroll
             for (int b = 0; b < N_BLOCKS; b++)  // no pixel of block b blended anything at or behind its maximum
                 if (pos_l >= __builtin_amdgcn_readlane(blast_v, b)) flags &= ~(1u << b);
             if (flags) {
-                st.a[threadIdx.x] = make_float4(q0.x, q0.y, q1.z, q1.w);
+                st.a[threadIdx.x] = make_float4(q0.x, q0.y, q3.x, q3.y);
                 st.b[threadIdx.x] = make_float4(q0.z, q0.w, q1.x, q1.y);
-                st.c[threadIdx.x] = q2.x;
+                st.c[threadIdx.x] = q3.z;
             }
         }
         s_id[threadIdx.x] = flags ? id_l : -1;
@@ -1626,13 +1655,17 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
 __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const float* __restrict__ means3D, float* sh_row, int use_sh,
                                                   const float* __restrict__ scales, const float* __restrict__ rotations, int use_scale_rot,
                                                   const uint8_t* __restrict__ clamped, const float* __restrict__ cov3D,
-                                                  const float* __restrict__ grad_rec, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+                                                  float* __restrict__ grad_rec, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
                                                   float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
                                                   float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
                                                   const float* __restrict__ opacities, float* __restrict__ dL_dopacity) {
     // the blend kernel's sums of this Gaussian: one 64-byte record (see k_zero_grads); the API's per-quantity tensors are written from it
     const float4 r0 = *reinterpret_cast<const float4*>(grad_rec + (size_t)i * GREC), r1 = *reinterpret_cast<const float4*>(grad_rec + (size_t)i * GREC + 4);
     const float r2x = grad_rec[(size_t)i * GREC + 8];
+    // ... and the record is left cleared for the next backward (the caller keeps the buffer: no clearing launch in front of k_render_bw)
+    *reinterpret_cast<float4*>(grad_rec + (size_t)i * GREC) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(grad_rec + (size_t)i * GREC + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    grad_rec[(size_t)i * GREC + 8] = 0.f;
     const float gcol[3] = {r0.x, r0.y, r0.z};
     {
         float g_op = r0.w;
@@ -1810,7 +1843,7 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
 __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_arg, const float* __restrict__ pose, const float* __restrict__ means3D, const float* __restrict__ shs,
                                                              const float* __restrict__ shs_rest, const float* __restrict__ opacities, int use_sh, const float* __restrict__ scales, const float* __restrict__ rotations,
                                                              int use_scale_rot, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
-                                                             const float* __restrict__ cov3D, const float* __restrict__ grad_rec, float* __restrict__ dL_dmean2D,
+                                                             const float* __restrict__ cov3D, float* __restrict__ grad_rec, float* __restrict__ dL_dmean2D,
                                                              float* __restrict__ dL_dconic, float* __restrict__ dL_dcolor,
                                                              float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
                                                              float* __restrict__ dL_dsh_rest, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
@@ -1873,6 +1906,24 @@ int gs_cu_count() {
     }
     return cached[dev] > 0 ? cached[dev] : 0;
 }
+// The library's one side stream (per device, created on first use) and the two events of its fork / join: the colour pass of the
+// preprocessing runs there while the caller's stream works through the depth sort and the binning.  Never used inside a stream capture and
+// never while the stage timer is armed (the pass then runs in line, where its time can be attributed).
+struct GsSide { hipStream_t stream; hipEvent_t fork, join; bool ok; };
+GsSide* gs_side() {
+    static GsSide side[64] = {};
+    static bool tried[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!tried[dev]) {
+        tried[dev] = true;
+        GsSide& s = side[dev];
+        s.ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+    }
+    return side[dev].ok ? &side[dev] : nullptr;
+}
 int64_t gs_default_span_cap(int P) { return 4 * (int64_t)(P > 0 ? P : 1) + 65536; }
 BinWs gs_bin_ws(uint32_t* base, int P, int gx, int gy, int64_t cap) {
     BinWs w;
@@ -1900,6 +1951,13 @@ BinWs gs_bin_ws(uint32_t* base, int P, int gx, int gy, int64_t cap) {
     return w;
 }
 
+// NRC_GS_OVERLAP=1 (read once): the colour outputs of the preprocessing as a separate pass on the side stream (k_preprocess<1> + <2>).  OFF by
+// default -- measured at 1 M / 6 M Gaussians: 0.48 / 1.50 ms per forward in one pass, 0.50-0.58 / 1.78-1.95 ms split, whatever the number of
+// persistent workgroups: next to a kernel that streams 233 MB the latency-bound sort passes take 2-4 x as long (k_depth_keys 17 -> 33 us, the
+// first two radix passes 16 -> 64 and 35 us), which costs more than the 45 us the geometry pass saves over the single pass.
+const bool g_gs_no_overlap = [] { const char* e = getenv("NRC_GS_OVERLAP"); return !(e && e[0] == '1'); }();
+// NRC_GS_COLOR_BLOCKS (read once): persistent workgroups of the colour pass per compute unit (default 2)
+const int g_gs_color_blocks_per_cu = [] { const char* e = getenv("NRC_GS_COLOR_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 16 ? v : 2; }();
 int make_cam(GsCam& cam, int W, int H, int D, int M, const float* view, const float* proj, const float* campos, const float* camera_dev, float tanx,
              float tany, float scale_modifier, int raw) {
     if (W < 1 || H < 1 || D < 0 || D > 3 || !(tanx > 0.f) || !(tany > 0.f)) return NRC_ERR_INVALID;
@@ -1960,10 +2018,27 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
             return NRC_ERR_INVALID;
         if (shs && M > PRE_MAXM) return NRC_ERR_UNSUPPORTED;
         const BinWs w = lds_path ? gs_bin_ws(bin_hist, P, cam.gx, cam.gy, span_capacity > 0 ? span_capacity : gs_default_span_cap(P)) : BinWs{};
-        hipLaunchKernelGGL(k_preprocess, dim3(nrc_cdiv(P, PRE_BLOCK)), dim3(PRE_BLOCK), 0, s, P, cam, camera_dev, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations,
-                           cov3D_precomp, radii, depths, points_xy, conic_opacity, rgb, clamped, cov3D, tiles_touched,
-                           lds_path ? (uint32_t*)nullptr : tile_counts, (float4*)splat_records, lds_path ? w.hdr : (uint32_t*)nullptr);
+        // The colour outputs (192 of the 236 bytes read per Gaussian are SH coefficients) on the side stream, forked HERE -- in front of the geometry
+        // pass, so that no event sits between the kernels of the caller's stream -- and joined at the end of this call.  In line (one pass) for
+        // the fallback binning, given colours, inside a stream capture, and while the stage timer is armed.
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &capturing);
+        GsSide* side = (lds_path && shs && !colors_precomp && capturing == hipStreamCaptureStatusNone && !g_nrc_stage_timer_armed && !g_gs_no_overlap) ? gs_side() : nullptr;
+        bool forked = false;
+        const int pre_blocks = (int)nrc_cdiv(P, PRE_BLOCK);
+#define GS_PRE_ARGS P, cam, camera_dev, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, depths, points_xy, conic_opacity, rgb, \
+                    clamped, cov3D, tiles_touched, lds_path ? (uint32_t*)nullptr : tile_counts, (float4*)splat_records, lds_path ? w.hdr : (uint32_t*)nullptr
+        if (side && hipEventRecord(side->fork, s) == hipSuccess && hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess) {
+            const int cus = gs_cu_count() > 0 ? gs_cu_count() : 256;
+            hipLaunchKernelGGL(k_preprocess<2>, dim3(pre_blocks < g_gs_color_blocks_per_cu * cus ? pre_blocks : g_gs_color_blocks_per_cu * cus), dim3(PRE_BLOCK), 0, side->stream, GS_PRE_ARGS);
+            forked = hipEventRecord(side->join, side->stream) == hipSuccess;
+            if (!forked) (void)hipStreamSynchronize(side->stream);   // cannot happen short of a broken runtime: stay correct
+            hipLaunchKernelGGL(k_preprocess<1>, dim3(pre_blocks), dim3(PRE_BLOCK), 0, s, GS_PRE_ARGS);
+        } else {
+            hipLaunchKernelGGL(k_preprocess<0>, dim3(pre_blocks), dim3(PRE_BLOCK), 0, s, GS_PRE_ARGS);
+        }
         NRC_STAGE(s, "k_preprocess");
+#undef GS_PRE_ARGS
         if (lds_path) {
             // depth pre-sort of the Gaussians: 4 stable 8-bit passes, one launch each, (keyA, rectA) -> B -> A -> B -> (valA, rectA) = depth order
             hipLaunchKernelGGL(k_depth_keys, dim3(nrc_cdiv(P, DK_BLOCK * DK_ITEMS)), dim3(DK_BLOCK), 0, s, P, cam.gx, cam.gy, radii, depths, points_xy, w.keyA, w.rectA,
@@ -2008,6 +2083,7 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
             hipLaunchKernelGGL(k_item_scan, dim3((unsigned)nrc_cdiv(cam.gx, 64), cam.gy), dim3(1024), 0, s, cam.gx, cam.gy, w.item_cap, w.nitems, w.ioff, w.cnt2, w.tcount,
                                w.hdr + RS_HDR_TICKET + 5, list_cap, ranges, tile_fill, num_rendered);
             NRC_STAGE(s, "k_item_scan");
+            if (forked && hipStreamWaitEvent(s, side->join, 0) != hipSuccess) (void)hipStreamSynchronize(side->stream);   // the colours are in place for whatever the caller enqueues next
         }
     }
     if (!(P > 0 && lds_path)) {
@@ -2073,7 +2149,7 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
                     const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
                     float* dL_dmean2D, float* dL_dconic,
                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
-                    float* dL_drot, float* grad_records, nrc_stream_t stream) {
+                    float* dL_drot, float* grad_records, int32_t records_clear, nrc_stream_t stream) {
     NRC_ENTER();
     GsCam cam;
     const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, camera_dev, tan_fovx, tan_fovy, scale_modifier, raw_parameters);
@@ -2089,9 +2165,11 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
     if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr) || (raw_parameters && (!opacities || !use_sr))) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     NRC_STAGE(s, nullptr);
-    hipLaunchKernelGGL(k_zero_grads, dim3((unsigned)nrc_cdiv((int64_t)P * (GREC / 4), 256)), dim3(256), 0, s, P, (float4*)grad_records);
-    NRC_STAGE(s, "k_zero_grads");
     if (use_sh && M > PBW_MAXM) return NRC_ERR_UNSUPPORTED;
+    if (!records_clear) {
+        hipLaunchKernelGGL(k_zero_grads, dim3((unsigned)nrc_cdiv((int64_t)P * (GREC / 4), 256)), dim3(256), 0, s, P, (float4*)grad_records);
+        NRC_STAGE(s, "k_zero_grads");
+    }
     hipLaunchKernelGGL(k_render_bw, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_order, bg[0], bg[1], bg[2],
                        camera_dev, n_contrib, final_T, dL_dpix, grad_records);
     NRC_STAGE(s, "k_render_bw");
