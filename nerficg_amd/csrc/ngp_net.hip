@@ -416,6 +416,13 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
                                                     __half* __restrict__ packed) {
     enum { F_D0 = 0, F_DO = 4, F_C0 = 8, F_C1 = 12, F_CO = 20, N_FRAG = 24 };
     __shared__ h8 wlds[N_FRAG][64];
+#if defined(NRC_MLP_GLDS)
+    // Experiment build (round 4, tools/build_variant.sh ... -DNRC_MLP_GLDS): the three 16-byte input fragments of a tile (two feature vectors, the
+    // per-ray SH fragment) travel by LDS-DMA (global_load_lds_dwordx4: no VGPR destination) into a wave-private double-buffered slot and are read
+    // back with ds_read_b128 when the tile is computed, instead of sitting in 12 VGPRs per tile for a whole iteration.  Numbers: DESIGN.md 6.
+    __shared__ __attribute__((aligned(16))) uint4 glds_stage[4][2][NT][3][64];
+    int glds_slot = 0;
+#endif
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int64_t n_tiles = (n + 31) / 32;
     const int64_t n_groups = (n_tiles + NT - 1) / NT;
@@ -454,6 +461,9 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
             return 0;
         }
     };
+#if defined(NRC_MLP_GLDS)
+    int glds_fill = 0, glds_u = 0;   // slot and tile of the group being requested (set by the callers of fetch)
+#endif
     auto fetch = [&](int64_t tile, int32_t rt, TileIn& ti) {
 #if defined(NRC_MLP_ABL_NOLOAD)   // synthetic inputs: no global load in the loop
         ti.b0 = make_uint4(0x3c003c00u + (uint32_t)lane, 0x38003800u, 0x34003400u, 0x30003000u + (uint32_t)tile); ti.b1 = ti.b0;
@@ -466,6 +476,20 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
         const int64_t i = base + (j < n ? j : n - 1);
         const uint4* fp = feat + tc * 128 + r;
         const int rot = (int)(tc & 3);
+#if defined(NRC_MLP_GLDS)
+        if constexpr (SRC == SRC_TILED) {
+            typedef __attribute__((address_space(1))) const void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+            uint4 (*slot)[64] = glds_stage[threadIdx.x >> 6][glds_fill][glds_u];
+            __builtin_amdgcn_global_load_lds((gptr_t)(fp + ((hh + rot) & 3) * 32), (lptr_t)&slot[0][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(fp + ((2 + hh + rot) & 3) * 32), (lptr_t)&slot[1][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(ray_sh + ((int64_t)rt * 2 + hh) * 64 + (i & 63)), (lptr_t)&slot[2][0], 16, 0, 0);
+            ti.alive = 1u;
+            ti.t = in.ts[i];
+            if (in.tile_alive) ti.alive = in.tile_alive[rt];
+            return;
+        }
+#endif
         ti.b0 = fp[((hh + rot) & 3) * 32];
         ti.b1 = fp[((2 + hh + rot) & 3) * 32];
         ti.alive = 1u;
@@ -489,7 +513,12 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
         const int64_t g0 = wave0 + p * n_waves;
         if (g0 < n_groups) {
 #pragma unroll
-            for (int u = 0; u < NT; u++) fetch(g0 * NT + u, tile_rt(g0 * NT + u), ring[p][u]);
+            for (int u = 0; u < NT; u++) {
+#if defined(NRC_MLP_GLDS)
+                glds_fill = 0; glds_u = u;
+#endif
+                fetch(g0 * NT + u, tile_rt(g0 * NT + u), ring[p][u]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < NT; u++) rt_ring[p][u] = tile_rt((g0 + PF * n_waves) * NT + u);
@@ -526,10 +555,31 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
         TileIn cur[NT];
 #pragma unroll
         for (int u = 0; u < NT; u++) cur[u] = ring[p][u];
+#if defined(NRC_MLP_GLDS)
+        if constexpr (SRC == SRC_TILED) {   // the current group's fragments have landed (vmcnt(0)); read them out of this wave's slot before the refill
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < NT; u++) {
+                const uint4 (*slot)[64] = glds_stage[threadIdx.x >> 6][glds_slot][u];
+                cur[u].b0 = slot[0][lane]; cur[u].b1 = slot[1][lane];
+                const uint4 q = slot[2][lane];
+                cur[u].sh = __builtin_bit_cast(h8, q);
+            }
+            glds_fill = glds_slot ^ 1;
+        }
+#endif
         if (grp + PF * n_waves < n_groups) {
 #pragma unroll
-            for (int u = 0; u < NT; u++) fetch((grp + PF * n_waves) * NT + u, rt_ring[p][u], ring[p][u]);
+            for (int u = 0; u < NT; u++) {
+#if defined(NRC_MLP_GLDS)
+                glds_u = u;
+#endif
+                fetch((grp + PF * n_waves) * NT + u, rt_ring[p][u], ring[p][u]);
+            }
         }
+#if defined(NRC_MLP_GLDS)
+        glds_slot ^= 1;
+#endif
 #pragma unroll
         for (int u = 0; u < NT; u++) rt_ring[p][u] = tile_rt((grp + 2 * PF * n_waves) * NT + u);
         flush_pending();   // the previous group's outputs: issued behind this group's prefetch, complete long before the next wait

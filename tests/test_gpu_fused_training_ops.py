@@ -149,9 +149,10 @@ def test_stage_timer_names_and_times_the_kernels_of_an_entry_point():
     wall_ms = (time.perf_counter() - t0) * 1e3
     names = [n for n, _ in st.stages]
     per = st.by_name()
-    for k in ('k_preprocess', 'k_depth_keys', 'k_radix_scatter', 'k_span_scatter', 'k_item_scatter', 'k_render', 'k_render_bw', 'k_preprocess_bw'):
+    for k in ('k_preprocess', 'k_depth_keys', 'k_radix_pass', 'k_span_sweep', 'k_item_scan', 'k_item_scatter', 'k_render', 'k_render_bw', 'k_preprocess_bw'):
         assert k in per, (k, sorted(per))
-    assert per['k_radix_scatter'][1] == 8 and per['k_render'][1] == 2                      # four radix passes per frame, two frames
+    assert per['k_radix_pass'][1] == 8 and per['k_render'][1] == 2                         # four radix passes (one launch each) per frame, two frames
+    assert 'k_zero_grads' not in per or per['k_zero_grads'][1] <= 1                         # the accumulator records come back cleared: no clearing launch after the first backward
     assert names.index('k_preprocess') < names.index('k_render') < names.index('k_render_bw') < names.index('k_preprocess_bw')
     assert all(t > 0 for _, t in st.stages) and sum(t for _, t in st.stages) <= wall_ms
     with _lib.stage_timer() as empty:
