@@ -163,6 +163,72 @@ def nerf_c1_cpu_baseline(size=64, threads=None):
             'finite': bool(torch.isfinite(out['rgb']).all())}
 
 
+def trained_scene_leg(device, iters=1500, n_poses=20):
+    """`secondary_trained`: the headline renders an UNTRAINED model -- 120 samples per ray, nothing ever saturates -- which is SURVEY 8(d)'s
+    synthetic input but the opposite regime of what `scripts/inference.py -b` times on a trained scene (InstantNGP/Renderer.py:118-132: rays
+    leave the loop when they saturate).  Here a model is trained inside the benchmark -- the analytic shaded sphere of
+    tests/test_gpu_convergence.py (closed-form ground-truth views, the Trainer.py:79-94 iteration with occupancy maintenance), `iters`
+    iterations -- and 800x800 frames of it are timed through render_image_fused with early_termination='auto' (depth slabs, finished tiles
+    skipped) and with the single pass: Mrays/s, samples per ray that were marched, and the share of sample rows the slab order skipped."""
+    import torch
+    from nerficg_amd.amp import GradScaler
+    from nerficg_amd.apex_optimizers import FusedAdam
+    from nerficg_amd.instant_ngp import Camera, InstantNGPModel, InstantNGPRenderer
+    from nerficg_amd.raygen import generate_rays
+    from tests import scenes
+    from tests.test_gpu_convergence import analytic_view, orbit, psnr
+    tw = th = 100
+    fx, fy, cx, cy = scenes.lego_intrinsics(tw, th)
+    tcam = Camera(width=tw, height=th, focal_x=fx, focal_y=fy, center_x=cx, center_y=cy, near_plane=0.2, far_plane=1000.0, background_color=torch.ones(3))
+    origins, dirs, colours, alphas = [], [], [], []
+    for p in orbit(24, 0):
+        rays = generate_rays(tw, th, fx, fy, cx, cy, p, device=device, want_direction=False)
+        img, hit = analytic_view(tw, th, p, fx, fy, cx, cy, bg=(0.0, 0.0, 0.0))
+        origins.append(rays['origin']); dirs.append(rays['view_direction'])
+        colours.append(torch.from_numpy(img * hit[..., None]).reshape(-1, 3).to(device)); alphas.append(torch.from_numpy(hit.astype(np.float32)).reshape(-1).to(device))
+    origins, dirs, colours, alphas = torch.cat(origins), torch.cat(dirs), torch.cat(colours), torch.cat(alphas)
+    model = InstantNGPModel(RANDOM_SEED=0, device=device)
+    renderer = InstantNGPRenderer(model)
+    opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
+    scaler = GradScaler(init_scale=128.0, growth_interval=10 ** 9)
+    perm = torch.randperm(origins.shape[0], generator=torch.Generator().manual_seed(0)).to(device)
+    batch = 4096
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for it in range(iters):
+        if it % 16 == 0:
+            renderer.update_occupancy_grid(warmup=it < 256)
+        ids = perm[(it * batch) % (perm.numel() - batch):][:batch]
+        with torch.amp.autocast('cuda'):
+            bg = torch.rand(3, device=device)
+            out = renderer.render_rays(origins[ids], dirs[ids], tcam, train_mode=True, custom_bg_color=bg)
+            target = colours[ids] + (1 - alphas[ids])[:, None] * bg
+            loss = torch.nn.functional.mse_loss(out['rgb'].float(), target) + 0.5e-6 * model.weight_decay_mlp()
+        scaler.scale(loss).backward()
+        scaler.step(opt); scaler.update(); opt.zero_grad()
+    torch.cuda.synchronize(); t_train = time.perf_counter() - t0
+    fx8, fy8, cx8, cy8 = scenes.lego_intrinsics(W, H)
+    cam = Camera(width=W, height=H, focal_x=fx8, focal_y=fy8, center_x=cx8, center_y=cy8, near_plane=0.2, far_plane=1000.0, background_color=torch.ones(3))
+    poses = orbit(n_poses + 3, 5)
+    gt, _ = analytic_view(W, H, poses[0], fx8, fy8, cx8, cy8)
+    quality = psnr(renderer.render_image_fused(cam, poses[0])['rgb'].cpu().numpy().reshape(H, W, 3), gt)
+    res = {'scene': 'analytic shaded sphere (r = 0.3) in front of white, trained in this run', 'training_iterations': iters, 'training_s': round(t_train, 2),
+           'psnr_800x800_dB': round(quality, 2)}
+    for label, et in (('slab_order_auto', 'auto'), ('single_pass', False)):
+        for i in range(3):
+            renderer.render_image_fused(cam, poses[i], early_termination=et)
+        samples = rows = skipped = 0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(n_poses):
+            out = renderer.render_image_fused(cam, poses[3 + i], return_stats=True, early_termination=et)
+            samples += out['n_samples']; rows += out['n_rows']
+            if et == 'auto':
+                skipped += int(next(iter(renderer._fused_ws.values()))['skipped'].item())   # rows of finished tiles the slab order never queried (a device count)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n_poses
+        res[label] = {'ms_per_frame': round(dt * 1e3, 3), 'mrays_per_s': round(W * H / dt / 1e6, 2), 'samples_per_ray_marched': round(samples / (n_poses * W * H), 2),
+                      'rows_skipped_frac': round(skipped / max(rows, 1), 4) if et == 'auto' else 0.0}
+    return res
+
+
 def time_dominant_kernel(renderer, cam, pose_list, reps=2):
     """Launch durations of the dominant kernel (k_grid_encode: 128 hash-grid gathers per sample) and of its partner (k_ngp_mlp) over ALL
     chunks (launches) of the images of `pose_list` -- the poses the timed region rendered --, measured with HIP events on the launch stream
@@ -752,6 +818,7 @@ def main():
     ap.add_argument('--no-dp', action='store_true', help='skip the data-parallel training legs (gradient collectives over RCCL)')
     ap.add_argument('--gs-gaussians', type=int, default=1_000_000)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the code path)')
+    ap.add_argument('--pipeline', type=int, default=1, help='tile ranges per frame of the pipelined image path (1 = render_image_fused, one pass over the frame)')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help='weak (default, the headline): every rank renders its own 800x800 frame per step; strong: ONE 1600x1060 garden-shaped frame per step '
                          'cut into contiguous tile shards over the ranks + all-gather of the pixels (BASELINE configs[3])')
@@ -815,7 +882,10 @@ def main():
     model, renderer, cam, poses = build_scene(device)
 
     def step(i):
-        return renderer.render_image_fused(cam, poses[(i * world + rank) % N_POSES], return_stats=True)
+        pose = poses[(i * world + rank) % N_POSES]
+        if args.pipeline > 1:   # the march of tile range k + 1 next to the encode / MLP kernels of range k (InstantNGPRenderer.render_image_pipelined)
+            return renderer.render_image_pipelined(cam, pose, shards=args.pipeline, return_stats=True)
+        return renderer.render_image_fused(cam, pose, return_stats=True)
 
     samples = 0
     for i in range(args.warmup):
@@ -960,6 +1030,12 @@ def main():
             except Exception as e:  # never lose the headline line over the extra leg
                 result['training'] = {'error': repr(e)[:200]}
         result['dp_training'] = dp
+        if world == 1 and not args.no_train:
+            try:
+                result['secondary_trained'] = trained_scene_leg(device)
+            except Exception as e:
+                result['secondary_trained'] = {'error': repr(e)[:300]}
+            torch.cuda.empty_cache()
         # BASELINE configs[3] shape on this one GPU (the single-rank point of `--scaling strong`) and one of eight shards of the same frames
         if world == 1:
             try:

@@ -237,6 +237,149 @@ class InstantNGPRenderer:
         tw, th = int(lib.nrc_ngp_tile_width()), int(lib.nrc_ngp_tile_height())
         return ((camera.width + tw - 1) // tw) * ((camera.height + th - 1) // th)
 
+    # -- the stages of the fused image pipeline (one frame = frame constants + a workspace per rendered tile range) --------------------------
+    def _frame_constants(self, camera: Camera, c2w) -> dict:
+        m = self.model
+        c2w = np.ascontiguousarray(np.asarray(c2w, dtype=np.float64))
+        if c2w.shape == (3, 4):
+            c2w = np.vstack([c2w, [0.0, 0.0, 0.0, 1.0]])
+        f3 = lambda t: (ctypes.c_float * 3)(*[float(v) for v in t.reshape(-1).tolist()])
+        g = m.encoding_xyz.grid_cfg
+        return dict(intr=(ctypes.c_double * 4)(camera.focal_x, camera.focal_y, camera.center_x, camera.center_y),
+                    mat=(ctypes.c_double * 16)(*c2w.reshape(-1).tolist()), center=f3(m.center), half=f3(m.half_size), mn=f3(m.xyz_min), sz=f3(m.xyz_size),
+                    bg=f3(camera.background_color.float().cpu()), esf=1 / 256 if self.EXPONENTIAL_STEPS else 0.0, grid=g, camera=camera,
+                    hw=camera.width * camera.height)
+
+    def _fused_workspace(self, store: dict, key, nt: int, hw: int, dev, images: bool) -> dict:
+        ws = store.get(key)
+        if ws is None:
+            lib = _lib.load()
+            n = nt * 64
+            ws = dict(ray_od=torch.empty(max(n, 1), 6, device=dev), ray_t=torch.empty(max(n, 1), 2, device=dev),
+                      ray_cnt=torch.empty(max(n, 1), dtype=torch.int32, device=dev), tile_rows=torch.empty(2 * max(nt, 1), dtype=torch.int32, device=dev),
+                      tile_off=torch.empty(nt + 1, dtype=torch.int32, device=dev), counter=torch.empty(2, dtype=torch.int32, device=dev), cap=0,
+                      skipped=torch.zeros(1, dtype=torch.int32, device=dev))
+            if images:
+                ws.update(rgb=torch.zeros(hw, 3, device=dev), alpha=torch.zeros(hw, device=dev), depth=torch.zeros(hw, device=dev))
+            if self.provisional_march:  # samples parked by the count pass, copied (not re-marched) by the write pass
+                ws['ts_prov'] = torch.empty(int(lib.nrc_ngp_render_provisional_bytes(nt, self.MAX_SAMPLES)), dtype=torch.uint8, device=dev)
+            store[key] = ws
+        return ws
+
+    def _fused_count(self, fc: dict, ws: dict, tile_begin: int, nt: int) -> None:
+        m, lib, cam = self.model, _lib.load(), fc['camera']
+        vp = ctypes.c_void_p
+        _lib.check(lib.nrc_ngp_render_count(
+            cam.width, cam.height, ctypes.cast(fc['intr'], vp), ctypes.cast(fc['mat'], vp), ctypes.cast(fc['center'], vp), ctypes.cast(fc['half'], vp),
+            float(cam.near_plane), float(cam.far_plane), int(tile_begin), nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(fc['esf']),
+            m.RESOLUTION, self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']),
+            _lib.ptr(ws['tile_off']), _lib.ptr(ws['counter']), _lib.ptr(ws.get('ts_prov')), _lib.stream_of(ws['ray_od'])), 'ngp_render_count')
+
+    def _fused_size_rows(self, ws: dict, rows: int, nt: int) -> None:
+        if rows > ws['cap']:
+            lib = _lib.load()
+            dev = ws['ray_od'].device
+            cap = int(rows * 1.5) + 64  # poses of one scene differ by up to 30 % in rows: grow rarely (a regrowth costs milliseconds of hipMalloc)
+            ws.update(ts=torch.empty(cap * 64, device=dev), row_tile=torch.empty(cap, dtype=torch.int32, device=dev),
+                      packed=torch.empty(cap * 64, 4, dtype=torch.float16, device=dev),
+                      qws=torch.empty(int(lib.nrc_ngp_render_layers_ws_bytes(cap, nt)), dtype=torch.uint8, device=dev),
+                      row_of=torch.empty(cap, dtype=torch.int32, device=dev),
+                      layer_off=torch.empty(self.MAX_SAMPLES + 2, dtype=torch.int32, device=dev), cap=cap)
+
+    def _fused_write_query(self, fc: dict, ws: dict, rows: int, nt: int) -> None:
+        """single pass: the parked samples into their final rows, then encode + MLPs over all of them"""
+        if rows <= 0:
+            return
+        m, lib = self.model, _lib.load()
+        vp = ctypes.c_void_p
+        st = _lib.stream_of(ws['ray_od'])
+        g = fc['grid']
+        _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(fc['esf']), m.RESOLUTION,
+                                            self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']),
+                                            _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws.get('ts_prov')), st), 'ngp_render_write')
+        _lib.check(lib.nrc_ngp_query_samples(
+            _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(fc['mn'], vp), ctypes.cast(fc['sz'], vp),
+            _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()), _lib.ptr(m.encoding_xyz._table16()),
+            g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(ws['packed']), _lib.ptr(ws['qws']), st), 'ngp_query_samples')
+
+    def _fused_composite(self, fc: dict, ws: dict, out: dict, tile_begin: int, nt: int) -> None:
+        m, lib, cam = self.model, _lib.load(), fc['camera']
+        _lib.check(lib.nrc_ngp_composite_image(
+            _lib.ptr(ws.get('packed')), _lib.ptr(ws.get('ts')), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_off']), cam.width, cam.height,
+            int(tile_begin), nt, m.cascades, float(fc['esf']), m.RESOLUTION, self.MAX_SAMPLES, 1e-4, ctypes.cast(fc['bg'], ctypes.c_void_p),
+            _lib.ptr(out['rgb']), _lib.ptr(out['alpha']), _lib.ptr(out['depth']), _lib.stream_of(ws['ray_od'])), 'ngp_composite_image')
+
+    @torch.no_grad()
+    def render_image_pipelined(self, camera: Camera, c2w: np.ndarray, shards: int = 4, return_stats: bool = False) -> dict[str, torch.Tensor]:
+        """The single-pass image of render_image_fused with the ray march of tile range k + 1 running NEXT TO the encode / MLP kernels of range k
+        (round 4).  A frame is count -> [host read of the row count] -> write -> 10 x (encode, MLP) -> composite, strictly in sequence; the two
+        march kernels (divergent DDA, latency-bound: 0.36 + 0.14 ms of an 8.35 ms frame at 800x800) and the host read leave the chip almost
+        idle.  Here the frame is cut into `shards` contiguous tile ranges (the ranges of parallel.shard_range: they compose bit for bit,
+        tests/test_gpu_render_parity.py); the march of a range runs on a side stream, its encode / MLP / composite on the caller's stream behind
+        an event, and the host blocks on the NEXT range's row count only after it has enqueued the current range's long kernels.  Same
+        per-ray arithmetic, same pixels (tests/test_gpu_render_parity.py).
+        MEASURED SLOWER, kept as an experiment (tools/bench_pipeline.py, 800x800 bench frame, ms per frame): one pass 8.67; 2 / 3 / 4 / 6 / 8
+        ranges 8.82 / 8.91 / 8.98 / 9.29 / 9.56 -- next to the march the encoder (bound by its L1 / texture-address path) loses more than the
+        0.4 ms the overlap hides, and every range ends in a partly filled launch.  The same was seen in the 3DGS forward (a bandwidth-heavy pass
+        next to the latency-bound sort: NRC_GS_OVERLAP) -- on this chip concurrent kernels do not add up."""
+        from .parallel import shard_range
+        m = self.model
+        dev = m.center.device
+        total_tiles = self.n_image_tiles(camera)
+        shards = max(1, min(int(shards), total_tiles))
+        fc = self._frame_constants(camera, c2w)
+        hw = fc['hw']
+        store = self.__dict__.setdefault('_pipe_ws', {})
+        if store.get('_shape') != (total_tiles, hw, shards, str(dev)):
+            store.clear()
+            store['_shape'] = (total_tiles, hw, shards, str(dev))
+            store['_side'] = torch.cuda.Stream(device=dev)
+            store['_images'] = dict(rgb=torch.zeros(hw, 3, device=dev), alpha=torch.zeros(hw, device=dev), depth=torch.zeros(hw, device=dev))
+        side, out = store['_side'], store['_images']
+        main = torch.cuda.current_stream(dev)
+        ranges = [shard_range(total_tiles, k, shards) for k in range(shards)]
+        wss = [self._fused_workspace(store, ('ws', k), e - b, hw, dev, images=False) for k, (b, e) in enumerate(ranges)]
+        side.wait_stream(main)          # the march reads the occupancy bitfield / writes buffers the caller's stream may still be using
+        n_rows = n_samples = 0
+        with torch.cuda.stream(side):
+            self._fused_count(fc, wss[0], ranges[0][0], ranges[0][1] - ranges[0][0])
+        for k, ((b, e), ws) in enumerate(zip(ranges, wss)):
+            nt = e - b
+            with torch.cuda.stream(side):
+                rows, samples = ws['counter'].tolist()     # waits for the side stream only: the caller's stream keeps computing the previous range
+            # (re)allocation in the CALLER's stream context: a freed buffer goes back to that stream's pool, behind the kernels that still use it
+            self._fused_size_rows(ws, rows, nt)
+            with torch.cuda.stream(side):
+                # the write pass stays on the side stream too (it only copies the parked samples)
+                if rows > 0:
+                    lib = _lib.load()
+                    _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(fc['esf']), m.RESOLUTION,
+                                                        self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']),
+                                                        _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws.get('ts_prov')),
+                                                        _lib.stream_of(ws['ray_od'])), 'ngp_render_write')
+                marched = torch.cuda.Event()
+                marched.record(side)
+            n_rows += rows
+            n_samples += samples
+            main.wait_event(marched)
+            if rows > 0:
+                g = fc['grid']
+                vp = ctypes.c_void_p
+                _lib.check(_lib.load().nrc_ngp_query_samples(
+                    _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(fc['mn'], vp), ctypes.cast(fc['sz'], vp),
+                    _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()), _lib.ptr(m.encoding_xyz._table16()),
+                    g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(ws['packed']), _lib.ptr(ws['qws']),
+                    _lib.stream_of(ws['ray_od'])), 'ngp_query_samples')
+            self._fused_composite(fc, ws, out, b, nt)
+            if k + 1 < shards:     # the next range's count pass starts now, under the kernels just enqueued; its buffers were last used a frame ago
+                nb, ne = ranges[k + 1]
+                with torch.cuda.stream(side):
+                    self._fused_count(fc, wss[k + 1], nb, ne - nb)
+        res = dict(out)
+        if return_stats:
+            res.update(n_rows=n_rows, n_slots=n_rows * 64, n_samples=n_samples)
+        return res
+
     @torch.no_grad()
     def render_image_fused(self, camera: Camera, c2w: np.ndarray, tile_begin: int = 0, n_tiles: int | None = None,
                            return_stats: bool = False, out: dict | None = None, early_termination: bool | str = 'auto') -> dict[str, torch.Tensor]:
@@ -253,45 +396,19 @@ class InstantNGPRenderer:
         dev = m.center.device
         total_tiles = self.n_image_tiles(camera)
         nt = total_tiles - tile_begin if n_tiles is None else int(n_tiles)
-        n = nt * 64
-        c2w = np.ascontiguousarray(np.asarray(c2w, dtype=np.float64))
-        if c2w.shape == (3, 4):
-            c2w = np.vstack([c2w, [0.0, 0.0, 0.0, 1.0]])
-        intr = (ctypes.c_double * 4)(camera.focal_x, camera.focal_y, camera.center_x, camera.center_y)
-        mat = (ctypes.c_double * 16)(*c2w.reshape(-1).tolist())
-        f3 = lambda t: (ctypes.c_float * 3)(*[float(v) for v in t.reshape(-1).tolist()])
-        hw = camera.width * camera.height
+        fc = self._frame_constants(camera, c2w)
+        hw = fc['hw']
         key = (nt, hw, str(dev))
-        ws = self._fused_ws.get(key)
-        if ws is None:
-            ws = dict(ray_od=torch.empty(max(n, 1), 6, device=dev), ray_t=torch.empty(max(n, 1), 2, device=dev),
-                      ray_cnt=torch.empty(max(n, 1), dtype=torch.int32, device=dev), tile_rows=torch.empty(2 * max(nt, 1), dtype=torch.int32, device=dev),
-                      tile_off=torch.empty(nt + 1, dtype=torch.int32, device=dev), counter=torch.empty(2, dtype=torch.int32, device=dev),
-                      rgb=torch.zeros(hw, 3, device=dev), alpha=torch.zeros(hw, device=dev), depth=torch.zeros(hw, device=dev), cap=0,
-                      skipped=torch.zeros(1, dtype=torch.int32, device=dev))
-            if self.provisional_march:  # samples parked by the count pass, copied (not re-marched) by the write pass
-                ws['ts_prov'] = torch.empty(int(lib.nrc_ngp_render_provisional_bytes(nt, self.MAX_SAMPLES)), dtype=torch.uint8, device=dev)
-            self._fused_ws = {key: ws}
+        if key not in self._fused_ws:
+            self._fused_ws = {}
+        ws = self._fused_workspace(self._fused_ws, key, nt, hw, dev, images=True)
         if out is None:
             out = {'rgb': ws['rgb'], 'alpha': ws['alpha'], 'depth': ws['depth']}
         st = _lib.stream_of(ws['ray_od'])
-        esf = 1 / 256 if self.EXPONENTIAL_STEPS else 0.0
-        center, half = f3(m.center), f3(m.half_size)
-        _lib.check(lib.nrc_ngp_render_count(
-            camera.width, camera.height, ctypes.cast(intr, ctypes.c_void_p), ctypes.cast(mat, ctypes.c_void_p),
-            ctypes.cast(center, ctypes.c_void_p), ctypes.cast(half, ctypes.c_void_p), float(camera.near_plane), float(camera.far_plane),
-            int(tile_begin), nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION, self.MAX_SAMPLES,
-            _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']), _lib.ptr(ws['tile_off']),
-            _lib.ptr(ws['counter']), _lib.ptr(ws.get('ts_prov')), st), 'ngp_render_count')
+        esf = fc['esf']
+        self._fused_count(fc, ws, tile_begin, nt)
         rows, n_samples = ws['counter'].tolist()   # THE host read of the frame: sizes the sample buffers; the marched total comes with it
-        if rows > ws['cap']:
-            cap = int(rows * 1.5) + 64  # poses of one scene differ by up to 30 % in rows: grow rarely (a regrowth costs milliseconds of hipMalloc)
-            ws.update(ts=torch.empty(cap * 64, device=dev), row_tile=torch.empty(cap, dtype=torch.int32, device=dev),
-                      packed=torch.empty(cap * 64, 4, dtype=torch.float16, device=dev),
-                      qws=torch.empty(int(lib.nrc_ngp_render_layers_ws_bytes(cap, nt)), dtype=torch.uint8, device=dev),
-                      row_of=torch.empty(cap, dtype=torch.int32, device=dev),
-                      layer_off=torch.empty(self.MAX_SAMPLES + 2, dtype=torch.int32, device=dev), cap=cap)
-        bg = f3(camera.background_color.float().cpu())
+        self._fused_size_rows(ws, rows, nt)
         if early_termination == 'auto':
             pol = ws.setdefault('et_policy', {'prev_rows': 0, 'prev_layered': False, 'skip_frames': 0})
             if pol['prev_layered'] and pol['prev_rows'] > 0:  # the previous frame is complete by now (we just synchronised on this one's row count)
@@ -303,8 +420,8 @@ class InstantNGPRenderer:
         else:
             use_layers = bool(early_termination)
         if use_layers and self.MAX_SAMPLES <= 1024:
-            g = m.encoding_xyz.grid_cfg
-            mn, sz = f3(m.xyz_min), f3(m.xyz_size)
+            g = fc['grid']
+            vp = ctypes.c_void_p
             if rows > 0:
                 _lib.check(lib.nrc_ngp_render_write_layers(
                     nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION, self.MAX_SAMPLES, _lib.ptr(ws['ray_od']),
@@ -313,34 +430,16 @@ class InstantNGPRenderer:
             if 'qws' not in ws:  # an image without a single sample: state + background only
                 ws['qws'] = torch.empty(int(lib.nrc_ngp_render_layers_ws_bytes(0, nt)), dtype=torch.uint8, device=dev)
             _lib.check(lib.nrc_ngp_render_layers(
-                _lib.ptr(ws.get('ts')), _lib.ptr(ws.get('row_tile')), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(mn, ctypes.c_void_p),
-                ctypes.cast(sz, ctypes.c_void_p), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
+                _lib.ptr(ws.get('ts')), _lib.ptr(ws.get('row_tile')), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(fc['mn'], vp),
+                ctypes.cast(fc['sz'], vp), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
                 _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
                 _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']), _lib.ptr(ws['tile_off']), _lib.ptr(ws.get('row_of')), camera.width, camera.height,
-                int(tile_begin), m.cascades, float(esf), m.RESOLUTION, self.MAX_SAMPLES, 1e-4, ctypes.cast(bg, ctypes.c_void_p),
+                int(tile_begin), m.cascades, float(esf), m.RESOLUTION, self.MAX_SAMPLES, 1e-4, ctypes.cast(fc['bg'], vp),
                 _lib.ptr(ws.get('packed')), _lib.ptr(out['rgb']), _lib.ptr(out['alpha']), _lib.ptr(out['depth']), _lib.ptr(ws['skipped']),
                 _lib.ptr(ws['qws']), st), 'ngp_render_layers')
-            res = dict(out)
-            if return_stats:
-                res['n_rows'] = rows
-                res['n_slots'] = rows * 64
-                res['n_samples'] = n_samples
-            return res
-        if rows > 0:
-            _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION,
-                                                self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']),
-                                                _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws.get('ts_prov')), st), 'ngp_render_write')
-            g = m.encoding_xyz.grid_cfg
-            mn, sz = f3(m.xyz_min), f3(m.xyz_size)
-            _lib.check(lib.nrc_ngp_query_samples(
-                _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(mn, ctypes.c_void_p),
-                ctypes.cast(sz, ctypes.c_void_p), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
-                _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
-                _lib.ptr(ws['packed']), _lib.ptr(ws['qws']), st), 'ngp_query_samples')
-        _lib.check(lib.nrc_ngp_composite_image(
-            _lib.ptr(ws.get('packed')), _lib.ptr(ws.get('ts')), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_off']), camera.width, camera.height,
-            int(tile_begin), nt, m.cascades, float(esf), m.RESOLUTION, self.MAX_SAMPLES, 1e-4, ctypes.cast(bg, ctypes.c_void_p),
-            _lib.ptr(out['rgb']), _lib.ptr(out['alpha']), _lib.ptr(out['depth']), st), 'ngp_composite_image')
+        else:
+            self._fused_write_query(fc, ws, rows, nt)
+            self._fused_composite(fc, ws, out, tile_begin, nt)
         res = dict(out)
         if return_stats:
             res['n_rows'] = rows

@@ -399,3 +399,20 @@ def test_fused_training_query_matches_the_op_by_op_modules(m):  # noqa: E302
             assert np.abs(ta).max() > 0
             np.testing.assert_allclose(tb, ta, rtol=0, atol=2e-2 * np.abs(ta).max(), err_msg='hash table')
             assert np.abs(tb - ta).mean() < 2e-3 * np.abs(ta).mean() + 1e-12
+
+
+def test_pipelined_image_equals_the_one_pass_image():
+    """render_image_pipelined (the march of tile range k + 1 on a side stream next to the encode / MLP kernels of range k) paints the picture of
+    render_image_fused bit for bit, reports the same sample count, and can be called back to back (buffers of a range are reused every frame)."""
+    from nerficg_amd.instant_ngp import InstantNGPRenderer
+    model = make_model()
+    renderer = InstantNGPRenderer(model)
+    cam = make_camera(96, 80, bg=(0.2, 0.4, 0.6))
+    poses = [scenes.orbit_pose(0.3 + 0.8 * k, 0.2, scenes.LEGO_RADIUS) for k in range(3)]
+    for shards in (1, 3, 5):
+        for pose in poses:
+            ref = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in renderer.render_image_fused(cam, pose, return_stats=True, early_termination=False).items()}
+            got = renderer.render_image_pipelined(cam, pose, shards=shards, return_stats=True)
+            assert got['n_samples'] == ref['n_samples'] and got['n_rows'] >= ref['n_rows']   # every range pads its own last row
+            for k in ('rgb', 'alpha', 'depth'):
+                assert torch.equal(got[k], ref[k]), (shards, k)
