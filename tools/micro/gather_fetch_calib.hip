@@ -36,6 +36,52 @@ __global__ void __launch_bounds__(256) k_unit16(const uint4* __restrict__ buf, s
     }
     if (acc == 0x12345u) out[0] = acc;
 }
+// --- round 4: the 3DGS preprocessing kernels' access shapes (scalar 4-byte loads), for which the streaming correction had been applied unchecked ---
+//   k_stream4    every lane reads consecutive 4-byte words (a wave instruction = 256 contiguous bytes)
+//   k_stream8    consecutive 8-byte pairs (512 contiguous bytes per wave instruction)
+//   k_soa12      a (P, 3) f32 array read the way k_preprocess reads means3D / scales: lane i loads words 3 i, 3 i + 1, 3 i + 2 (three instructions,
+//                12-byte lane stride: each touches the same six lines)
+//   k_rows192    a (P, 48) f32 array (the SH coefficients) read the way sh_rows_copy stages it: 128 rows = 24 576 contiguous bytes per workgroup,
+//                thread t loads words t, t + 128, t + 256, ... (coalesced 4-byte loads)
+//   k_preproc    all of k_preprocess's reads of one Gaussian together: (P,3) + (P,48) rows + (P,1) + (P,3) + (P,4) = 236 B per Gaussian
+__global__ void __launch_bounds__(256) k_stream4(const uint32_t* __restrict__ buf, size_t n, uint32_t* __restrict__ out) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc ^= buf[i];
+    if (acc == 0x12345u) out[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_stream8(const uint2* __restrict__ buf, size_t n, uint32_t* __restrict__ out) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const uint2 v = buf[i]; acc ^= v.x ^ v.y; }
+    if (acc == 0x12345u) out[0] = acc;
+}
+__global__ void __launch_bounds__(128) k_soa12(const float* __restrict__ a, int P, uint32_t* __restrict__ out) {
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= P) return;
+    const float s = a[3 * i] + a[3 * i + 1] + a[3 * i + 2];
+    if (s == 12345.f) out[0] = 1u;
+}
+__global__ void __launch_bounds__(128) k_rows192(const float* __restrict__ rows, int P, uint32_t* __restrict__ out) {
+    const size_t first = (size_t)blockIdx.x * 128;
+    const int count = (int)((size_t)P - first < 128 ? (size_t)P - first : 128);
+    const float* g = rows + first * 48;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < count * 48; k += 128) s += g[k];
+    if (s == 12345.f) out[0] = 1u;
+}
+__global__ void __launch_bounds__(128) k_preproc(const float* __restrict__ means, const float* __restrict__ sh, const float* __restrict__ op,
+                                                 const float* __restrict__ sc, const float* __restrict__ rot, int P, uint32_t* __restrict__ out) {
+    const size_t first = (size_t)blockIdx.x * 128;
+    const int count = (int)((size_t)P - first < 128 ? (size_t)P - first : 128);
+    const float* g = sh + first * 48;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < count * 48; k += 128) s += g[k];
+    const int i = (int)first + threadIdx.x;
+    if (i < P) {
+        s += means[3 * i] + means[3 * i + 1] + means[3 * i + 2] + op[i] + sc[3 * i] + sc[3 * i + 1] + sc[3 * i + 2];
+        s += rot[4 * i] + rot[4 * i + 1] + rot[4 * i + 2] + rot[4 * i + 3];
+    }
+    if (s == 12345.f) out[0] = 1u;
+}
 __global__ void __launch_bounds__(256) k_table16(const uint4* __restrict__ table, uint32_t n_vec, int loads_per_lane, uint32_t* __restrict__ out) {
     uint32_t acc = 0, s = mix((uint32_t)(blockIdx.x * 256 + threadIdx.x) + 1u);
     for (int k = 0; k < loads_per_lane; k++) {
@@ -75,6 +121,16 @@ int main() {
     const double n_loads = (double)grid * 256 * lpl;
     timed("k_table16", [&] { hipLaunchKernelGGL(k_table16, dim3(grid), dim3(256), 0, 0, table, (uint32_t)(table_bytes / 16), lpl, out); }, n_loads * 16,
           (double)table_bytes / 128);
+    {   // round 4: the scalar-load shapes of the 3DGS preprocessing (buffers of the 1 M-Gaussian bench scene's sizes x 4, so that nothing is re-read from a cache)
+        const int P = 4000000;
+        float* f = reinterpret_cast<float*>(buf);
+        const float *means = f, *sh = f + (size_t)3 * P, *op = sh + (size_t)48 * P, *sc = op + P, *rot = sc + (size_t)3 * P;   // 59 floats x P = 944 MB of the 1 GiB
+        timed("k_stream4", [&] { hipLaunchKernelGGL(k_stream4, dim3(grid), dim3(256), 0, 0, (const uint32_t*)buf, big / 4, out); }, (double)big, (double)big / 128);
+        timed("k_stream8", [&] { hipLaunchKernelGGL(k_stream8, dim3(grid), dim3(256), 0, 0, (const uint2*)buf, big / 8, out); }, (double)big, (double)big / 128);
+        timed("k_soa12", [&] { hipLaunchKernelGGL(k_soa12, dim3((P + 127) / 128), dim3(128), 0, 0, means, P, out); }, 12.0 * P, 12.0 * P / 128);
+        timed("k_rows192", [&] { hipLaunchKernelGGL(k_rows192, dim3((P + 127) / 128), dim3(128), 0, 0, sh, P, out); }, 192.0 * P, 192.0 * P / 128);
+        timed("k_preproc", [&] { hipLaunchKernelGGL(k_preproc, dim3((P + 127) / 128), dim3(128), 0, 0, means, sh, op, sc, rot, P, out); }, 236.0 * P, 236.0 * P / 128);
+    }
     printf("k_table16: %.0f loads of 16 B over a %.1f MB table (%.0f lines): each line is read %.1f times per launch\n", n_loads, table_bytes / 1e6,
            (double)table_bytes / 128, n_loads / ((double)table_bytes / 128));
     return 0;
