@@ -232,3 +232,56 @@ def test_screen_positions_match_the_reference_projection_golden(golden_dir):
     vis = radii.cpu().numpy() > 0
     assert vis.sum() >= 90 and not (g['in_frustum'] & ~vis).any()
     np.testing.assert_allclose(points_xy[vis], g['xy'][vis] - 0.5, rtol=0, atol=2e-5)
+
+
+def _torch_tile_lists(radii, points_xy, depths, w, h):
+    """Independent statement of the binning result from the geometry buffer: per tile the ids of the Gaussians whose rectangle covers it, ordered by
+    (depth bits, id) -- what the reference's stable radix sort over (tile | depth) keys produces.  torch.sort on int64 keys, on the device."""
+    gx, gy = (w + 15) // 16, (h + 15) // 16
+    vis = torch.nonzero(radii > 0).flatten()
+    r = radii[vis].float()
+    x, y = points_xy[vis, 0], points_xy[vis, 1]
+    clampi = lambda v, hi: v.to(torch.int32).clamp(0, hi)   # (int) truncation like the kernel: values are >= -small here, trunc == floor for >= 0 after the clamp
+    x0, y0 = clampi(torch.trunc((x - r) / 16), gx), clampi(torch.trunc((y - r) / 16), gy)
+    # the kernel's f32 expression, left to right: ((p + radius) + 16) - 1 -- not p + radius + 15, which rounds differently once in a million
+    x1, y1 = clampi(torch.trunc((((x + r) + 16) - 1) / 16), gx), clampi(torch.trunc((((y + r) + 16) - 1) / 16), gy)
+    wv, hv = (x1 - x0).clamp(min=0).long(), (y1 - y0).clamp(min=0).long()
+    cnt = wv * hv
+    keep = cnt > 0
+    vis, x0, y0, wv, cnt = vis[keep], x0[keep].long(), y0[keep].long(), wv[keep], cnt[keep]
+    if vis.numel() == 0:
+        z = torch.zeros(gx * gy, 2, dtype=torch.int32, device=radii.device)
+        return torch.zeros(0, dtype=torch.int32, device=radii.device), z
+    owner = torch.repeat_interleave(torch.arange(vis.numel(), device=vis.device), cnt)
+    first = torch.cumsum(cnt, 0) - cnt
+    k = torch.arange(owner.numel(), device=vis.device) - first[owner]
+    tile = (y0[owner] + k // wv[owner]) * gx + x0[owner] + k % wv[owner]
+    dbits = depths[vis].view(torch.int32).long()[owner]   # positive floats: the bit pattern orders like the value
+    gid = vis[owner]
+    # two stable sorts (id order is the expansion order already; depth, then tile): the (tile, depth, id) order without a 96-bit key
+    assert int(gid.max()) < (1 << 22) and int(dbits.max()) < (1 << 41)
+    o1 = torch.sort(dbits * (1 << 22) + gid, stable=True).indices
+    o2 = torch.sort(tile[o1], stable=True).indices
+    order = o1[o2]
+    counts = torch.bincount(tile, minlength=gx * gy)
+    ends = torch.cumsum(counts, 0)
+    return gid[order].to(torch.int32), torch.stack([ends - counts, ends], 1).to(torch.int32)
+
+
+@pytest.mark.parametrize('n', [1, 63, 4095, 4096, 4097, 8193, 64 * 4096 - 1, 64 * 4096 + 5, 65 * 4096, 300_001, 1_100_003])
+def test_tile_lists_at_the_sort_tile_and_group_boundaries(n):
+    """The depth sort and the span sweep work in tiles of 4 096 Gaussians, groups of 64 tiles, with counts PUBLISHED between workgroups and, above
+    one tile per compute unit, tickets (round 4).  Gaussian counts on both sides of every one of those boundaries -- one short tile, exact tiles,
+    one group exactly, one group + 1 tile, several groups, the ticket variant (> 256 tiles) -- against an independent torch statement of the lists
+    (every visible Gaussian in every tile of its rectangle, ordered by depth bits then id), three frames each (the workspaces are reused)."""
+    sc = scenes.gs_random_scene(n, seed=n % 97, extent=1.3, log_scale_mean=np.log(0.012 if n > 100_000 else 0.03))
+    w, h = 321, 203
+    cam = scenes.gs_camera(w, h, scenes.orbit_pose(0.7, 0.3, 3.4))
+    for frame in range(3):
+        color, radii, _, _ = _run(sc, cam, [0, 0, 0], requires_grad=True)
+        sv, fn = _saved(color)
+        depths = fn.debug_state['depths']
+        want_list, want_ranges = _torch_tile_lists(sv['radii'][:n], sv['points_xy'][:n], depths[:n], w, h)
+        assert fn.num_rendered == want_list.numel()
+        assert torch.equal(sv['ranges'].view(-1, 2).to(torch.int32), want_ranges)
+        assert torch.equal(sv['point_list'][:want_list.numel()], want_list), (n, frame)
