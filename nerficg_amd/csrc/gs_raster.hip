@@ -810,7 +810,6 @@ __global__ void __launch_bounds__(SP_THREADS) k_span_sweep(int P, int gy, int n_
                                                            uint32_t* __restrict__ meta) {
     __shared__ uint32_t cnt[SP_WAVES][SPAN_DIM_MAX];        // per wave: spans per row, later the wave's first position in the row's list
     __shared__ uint32_t bits[SP_WAVES][SPAN_DIM_MAX][2];
-    __shared__ uint2 rec[SP_WAVES][64];
     __shared__ int sm[8];
     __shared__ int tile_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, y_of = threadIdx.x;
@@ -858,32 +857,33 @@ __global__ void __launch_bounds__(SP_THREADS) k_span_sweep(int P, int gy, int n_
     }
     __syncthreads();
     const int nk = (gy + 63) >> 6;
-    int64_t cur[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) cur[k] = (int64_t)mine[64 * k + lane];
     uint32_t (*wbits)[2] = bits[wave];
-    uint2* wrec = rec[wave];
+    const uint32_t below_lo = lane < 32 ? (1u << lane) - 1u : 0xffffffffu, below_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
 #pragma unroll
     for (int k = 0; k < SP_ITEMS; k++) {
         if (begin + 64 * k >= end) break;
-        // one wave: its LDS operations execute in program order, so the ORs of all lanes are in place when the words are read (no workgroup barrier;
-        // the wavefront-scope fences only keep the compiler from moving the accesses)
-        wrec[lane] = make_uint2((uint32_t)r[k].id, (uint32_t)r[k].x01);
+        // One wave: its LDS operations execute in program order, so the ORs of all lanes are in place when the words are read (no workgroup barrier;
+        // the wavefront-scope fences only keep the compiler from moving the accesses).  A lane is a GAUSSIAN: it writes its span record to every row
+        // of its rectangle at (the wave's next position in the row) + (number of earlier lanes of the step that cover the row) -- the loop is as
+        // long as the tallest rectangle of the step (a few rows), not as long as the most covered row's list, which is what the first form (a lane per
+        // ROW popping the bits of its word one by one) paid for: 36 -> 23 us at 1 M Gaussians, 131 -> 96 us at 6 M.  Same positions, same order.
         if (r[k].ok)
             for (int y = r[k].y0; y < r[k].y1; y++) atomicOr(&wbits[y][lane >> 5], 1u << (lane & 31));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (r[k].ok) {
+            const uint2 record = make_uint2((uint32_t)r[k].id, (uint32_t)r[k].x01);
+            for (int y = r[k].y0; y < r[k].y1; y++) {
+                const int64_t pos = (int64_t)mine[y] + __popc(wbits[y][0] & below_lo) + __popc(wbits[y][1] & below_hi);
+                if (pos < cap) spans[pos] = record;
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (q >= nk) break;
             const int y = 64 * q + lane;
-            uint32_t lo = wbits[y][0], hi = wbits[y][1];
-            if (lo | hi) { wbits[y][0] = 0u; wbits[y][1] = 0u; }
-            while (lo | hi) {  // ascending bit = ascending lane = depth order
-                int src;
-                if (lo) { src = __builtin_ctz(lo); lo &= lo - 1u; } else { src = 32 + __builtin_ctz(hi); hi &= hi - 1u; }
-                if (cur[q] < cap) spans[cur[q]] = wrec[src];
-                cur[q]++;
-            }
+            const uint32_t lo = wbits[y][0], hi = wbits[y][1];
+            if (lo | hi) { mine[y] += (uint32_t)(__popc(lo) + __popc(hi)); wbits[y][0] = 0u; wbits[y][1] = 0u; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
