@@ -11,14 +11,17 @@
 // (tile, Gaussian) instances -> range search, ~100 B of HBM traffic per instance).  DESIGN.md 3.3 has the history and the numbers.
 //   1. k_preprocess     128 Gaussians per workgroup, SH rows staged through LDS: cull, cov3D, EWA cov2D, conic, radius, SH -> RGB, tile rectangle;
 //                       writes the geometry buffers of the API and one 64-byte splat record per Gaussian (what the blend kernels read).
-//   2. depth pre-sort   of the P Gaussians (not of the instances): k_depth_keys, then 4 x (k_radix_count, k_radix_offsets, k_radix_scatter), LSD,
-//                       8 bits per pass, stable, carrying the Gaussian's index and its packed tile rectangle.
+//   2. depth pre-sort   of the P Gaussians (not of the instances): k_depth_keys (keys, rectangles, the digit totals of all four passes, the span
+//                       count of every tile row), then 4 x k_radix_pass -- ONE launch per 8-bit digit (round 4; rounds 1-3: count / offsets /
+//                       scatter): a tile publishes its digit counts (value + flag in one sc1 word) and adds up what the earlier tiles published
+//                       through a two-level prefix.  LSD, stable, carrying the Gaussian's index and its packed tile rectangle.
 //   3. span binning     two-level MSD scatter over the tile id, ranked with LDS bit matrices (no serial walk, no sort):
-//                       level 1 (k_span_count / k_span_scan / k_span_rows / k_span_scatter): Gaussian -> one 8-byte span record per tile ROW;
-//                       level 2 (k_item_count / k_item_scan / k_scan_tiles / k_item_scatter): a row's spans -> ids appended to the row's tiles.
+//                       level 1 (k_span_sweep, one launch, the same published-count prefix): Gaussian -> one 8-byte span record per tile ROW;
+//                       level 2 (k_item_count / k_item_scan / k_item_scatter): a row's spans -> ids appended to the row's tiles; the last workgroup
+//                       of k_item_scan also scans the tile totals into `ranges` and orders the tiles by list length (longest lists launch first).
 //                       Stable in depth order, so the per-tile lists equal what a stable radix sort over (tile | depth) keys produces.
-//                       Tile grids above SPAN_DIM_MAX x SPAN_DIM_MAX fall back to k_scatter (global atomics) + k_sort_tiles (per-tile bitonic sort).
-//   4. k_tile_order     counting sort of the tiles by list length: longest lists launch first.
+//                       Tile grids above SPAN_DIM_MAX x SPAN_DIM_MAX fall back to k_scatter (global atomics) + k_sort_tiles (per-tile bitonic sort)
+//   4.                  + k_scan_tiles + k_tile_order.  Forward: 21 launches in round 3, 12 now (preprocess, keys, 4 passes, sweep, 3 x item, render).
 //   5. k_render         16x16-pixel tile per workgroup (4 waves = 8x8 quadrants), DPP row = 4x4 pixel block with its OWN culled work list,
 //                       256-entry batches staged in LDS, branch-free front-to-back blend.
 // Backward:
@@ -653,17 +656,14 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_pass(int n, int shift, int
 //   level 2  the span list of a row, cut into items of 256 .. 1024 spans (one wave each; the size is picked on the device from the span total,
 //            so that a small frame still fills the chip) -> ids appended to the tiles x0 .. x1 - 1 of that row.
 // Both levels rank with a BIT MATRIX instead of a serial walk: 64 sources (lane = Gaussian / span, in depth order) set bit `lane` in the
-// LDS word of every destination (row / tile) they cover with ds_or -- the order of the ORs is irrelevant --, then the lanes switch roles
-// (lane = destination) and pop the bits of their word in ascending order: lane order = depth order, so the appends are stable, every
-// destination has a lane-private cursor, and no step waits for another.  A wave has gy (level 1) or gx (level 2) open write frontiers and
+// LDS word of every destination (row / tile) they cover with ds_or -- the order of the ORs is irrelevant --, and every source then writes its
+// record to each destination at (the destination's cursor) + (number of lower lanes whose bit is set in the destination's word): lane order =
+// depth order, so the appends are stable and no step waits for another.  A wave has gy (level 1) or gx (level 2) open write frontiers and
 // the level-2 grid is capped at 2048 waves, so the lines being appended stay in the XCD's L2 until they are full.
-// Counting passes of the same shape (LDS ds_add per covered destination) + two small scans give the cursors; everything is deterministic.
+// Counting passes of the same shape (LDS ds_add per covered destination) give the cursors; everything is deterministic.
 #define GS_MAX_LDS_TILES 16384
-#define SPAN_CH_MIN 256      // spans per level-2 item (one wave): 256, 512 or 1024, see k_span_rows
+#define SPAN_CH_MIN 256      // spans per level-2 item (one wave): 256, 512 or 1024, picked from the span total (k_span_sweep, workgroup 0)
 #define SPAN_CH_MAX 1024
-#ifndef SPAN_NB_MAX
-#define SPAN_NB_MAX 4096     // level-1 slices (waves) at most
-#endif
 #ifndef SPAN_GRID
 #define SPAN_GRID 2048       // waves of the level-2 scatter (grid-stride over the items): few enough that the lines being appended stay in L2
 #endif
@@ -686,100 +686,12 @@ __device__ __forceinline__ SpanRect span_rect(int j, int end, const uint32_t* __
     }
     return r;
 }
-// level 1, counting: cnt1[y][slice] = number of Gaussians of the slice whose rectangle covers tile row y
-__global__ void __launch_bounds__(64) k_span_count(int P, int nb1, int chunk1, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rects,
-                                                   uint32_t* __restrict__ cnt1) {
-    __shared__ uint32_t cnt[SPAN_DIM_MAX];
-    const int lane = threadIdx.x, slice = blockIdx.x;
-    for (int y = lane; y < SPAN_DIM_MAX; y += 64) cnt[y] = 0u;
-    __syncthreads();
-    const int begin = slice * chunk1, end = min(P, begin + chunk1);
-#pragma unroll 4
-    for (int j = begin + lane; j < end; j += 64) {
-        const SpanRect r = span_rect(j, end, order, rects);
-        if (r.ok)
-            for (int y = r.y0; y < r.y1; y++) atomicAdd(&cnt[y], 1u);
-    }
-    __syncthreads();
-    for (int y = lane; y < gy; y += 64) cnt1[(size_t)y * nb1 + slice] = cnt[y];
-}
-// exclusive scan of cnt1[y][*] over the slices (in place) and the row totals
-__global__ void __launch_bounds__(256) k_span_scan(int nb1, uint32_t* __restrict__ cnt1, uint32_t* __restrict__ rowtot) {
-    __shared__ int sm[8];
-    uint32_t* row = cnt1 + (size_t)blockIdx.x * nb1;
-    int carry = 0;
-    for (int b0 = 0; b0 < nb1; b0 += 256) {
-        const int i = b0 + threadIdx.x;
-        const int v = i < nb1 ? (int)row[i] : 0;
-        int tot;
-        const int ex = nrc_block256_excl_scan_i(v, sm, &tot);
-        if (i < nb1) row[i] = (uint32_t)(carry + ex);
-        carry += tot;
-    }
-    if (threadIdx.x == 0) rowtot[blockIdx.x] = (uint32_t)carry;
-}
-// per tile row: first span (roff), number of level-2 items (nitems) and first item (ioff); meta = {items, spans per item}; *meta_spans = spans.
-// The item size follows the span total (about 10 K items at every size: ~5 waves per CU for the level-2 passes).
-__global__ void __launch_bounds__(256) k_span_rows(int gy, const uint32_t* __restrict__ rowtot, uint32_t* __restrict__ roff, uint32_t* __restrict__ nitems,
-                                                   uint32_t* __restrict__ ioff, int64_t* __restrict__ meta_spans, uint32_t* __restrict__ meta) {
-    __shared__ int sm[8];
-    const int y = threadIdx.x;
-    const int n = y < gy ? (int)rowtot[y] : 0;
-    int tot_s, tot_i;
-    const int es = nrc_block256_excl_scan_i(n, sm, &tot_s);
-    const int ch = tot_s < (3 << 20) ? SPAN_CH_MIN : (tot_s < (6 << 20) ? 2 * SPAN_CH_MIN : SPAN_CH_MAX);
-    const int it = (n + ch - 1) / ch;
-    const int ei = nrc_block256_excl_scan_i(it, sm, &tot_i);
-    if (y < gy) { roff[y] = (uint32_t)es; nitems[y] = (uint32_t)it; ioff[y] = (uint32_t)ei; }
-    if (y == 0) { *meta_spans = (int64_t)tot_s; meta[0] = (uint32_t)tot_i; meta[1] = (uint32_t)ch; }
-}
 // value of entry `idx` (wave-uniform) of a table held as 4 registers x 64 lanes
 __device__ __forceinline__ int lanes_get(const int (&v)[4], int idx) {
     const int k = idx >> 6, l = idx & 63;
     return __builtin_amdgcn_readlane(k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3], l);
 }
-// level 1, scatter: spans of row y start at roff[y]; this slice's first span of the row at roff[y] + cnt1[y][slice]
-__global__ void __launch_bounds__(64) k_span_scatter(int P, int nb1, int chunk1, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rects,
-                                                     const uint32_t* __restrict__ cnt1, const uint32_t* __restrict__ roff, int64_t cap,
-                                                     uint2* __restrict__ spans) {
-    __shared__ uint32_t bits[SPAN_DIM_MAX][2];
-    __shared__ uint2 rec[64];
-    const int lane = threadIdx.x, slice = blockIdx.x;
-    const int nk = (gy + 63) >> 6;
-    int64_t cur[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int y = 64 * k + lane;
-        cur[k] = y < gy ? (int64_t)roff[y] + cnt1[(size_t)y * nb1 + slice] : 0;
-        bits[y][0] = 0u; bits[y][1] = 0u;
-    }
-    __syncthreads();
-    const int begin = slice * chunk1, end = min(P, begin + chunk1);
-    SpanRect r = span_rect(begin + lane, end, order, rects);
-    for (int j0 = begin; j0 < end; j0 += 64) {
-        const SpanRect nxt = span_rect(j0 + 64 + lane, end, order, rects);  // the next chunk's rectangles travel while this one is ranked
-        rec[lane] = make_uint2((uint32_t)r.id, (uint32_t)r.x01);
-        if (r.ok)
-            for (int y = r.y0; y < r.y1; y++) atomicOr(&bits[y][lane >> 5], 1u << (lane & 31));
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (k >= nk) break;
-            const int y = 64 * k + lane;
-            uint32_t lo = bits[y][0], hi = bits[y][1];
-            if (lo | hi) { bits[y][0] = 0u; bits[y][1] = 0u; }
-            while (lo | hi) {  // ascending bit = ascending lane = depth order
-                int src;
-                if (lo) { src = __builtin_ctz(lo); lo &= lo - 1u; } else { src = 32 + __builtin_ctz(hi); hi &= hi - 1u; }
-                if (cur[k] < cap) spans[cur[k]] = rec[src];
-                cur[k]++;
-            }
-        }
-        __syncthreads();
-        r = nxt;
-    }
-}
-// Level 1 in ONE launch (round 4; count / scan / rows / scatter above remain for reference builds: -DGS_SPAN_CHAIN).  A workgroup takes a tile of 4 096
+// Level 1 in ONE launch (round 4; rounds 2-3 ran it as count / scan over the slices / row tables / scatter: four launches).  A workgroup takes a tile of 4 096
 // consecutive Gaussians of the depth order, its four waves 1 024 each.  (A) every wave counts its spans per tile row (LDS atomics, wave-private
 // tables); thread y publishes the tile's count of row y and adds up what the earlier tiles published -- the same two-level prefix as the
 // depth sort (k_radix_pass) --; the row starts come from the row totals that k_depth_keys left in the sort header.  (B) every wave scatters its
@@ -1887,11 +1799,11 @@ __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_ar
 
 // slices = waves; all of them should be resident at once: 160 KB of LDS per CU, (4 B x n_tiles) per wave, 256 CUs
 // binning workspace (u32 words): [keyA P][valA P][rectA P][keyB P][valB P][rectB P][header RS_HDR_WORDS][status 4 x nblk x 256][group totals 4 x ngroups x 256] -- the depth pre-sort --
-// [cnt1 gy x nb1][rowtot gy][roff gy][nitems gy][ioff gy][meta 4][tcount n_tiles][cnt2 item_cap x gx][spans 2 x cap]
+// [rowtot gy][roff gy][nitems gy][ioff gy][meta 4][tcount n_tiles][cnt2 item_cap x gx][spans 2 x cap]
 struct BinWs {
-    uint32_t *keyA, *valA, *rectA, *keyB, *valB, *rectB, *hdr, *status, *gstat, *cnt1, *rowtot, *roff, *nitems, *ioff, *meta, *tcount, *cnt2;
+    uint32_t *keyA, *valA, *rectA, *keyB, *valB, *rectB, *hdr, *status, *gstat, *rowtot, *roff, *nitems, *ioff, *meta, *tcount, *cnt2;
     uint2* spans;
-    int nblk, ngroups, nb1, chunk1, item_cap;
+    int nblk, ngroups, item_cap;
     int64_t cap, words, n_status;
 };
 // compute units of the current device (queried once per device index): the ticket-free sort variant needs every tile resident at once
@@ -1930,8 +1842,6 @@ BinWs gs_bin_ws(uint32_t* base, int P, int gx, int gy, int64_t cap) {
     const int64_t p1 = P > 0 ? P : 1;
     w.nblk = (int)nrc_cdiv(p1, RS_TILE);
     w.ngroups = (w.nblk + RS_GROUP - 1) / RS_GROUP;
-    w.nb1 = (int)(nrc_cdiv(p1, 64) < SPAN_NB_MAX ? nrc_cdiv(p1, 64) : SPAN_NB_MAX);
-    w.chunk1 = (int)(nrc_cdiv(nrc_cdiv(p1, w.nb1), 64) * 64);
     w.cap = cap;
     w.item_cap = (int)(cap / SPAN_CH_MIN + gy + 1);
     uint32_t* q = base;
@@ -1941,7 +1851,6 @@ BinWs gs_bin_ws(uint32_t* base, int P, int gx, int gy, int64_t cap) {
     w.n_status = (int64_t)5 * 256 * (w.nblk + w.ngroups);   // status of sort pass p (4 = the span sweep) at + p * 256 * nblk, the group totals behind all five
     w.status = take(w.n_status, 4);
     w.gstat = w.status + (int64_t)5 * 256 * w.nblk;
-    w.cnt1 = take((int64_t)gy * w.nb1, 4);
     w.rowtot = take(gy, 4); w.roff = take(gy, 4); w.nitems = take(gy, 4); w.ioff = take(gy, 4);
     w.meta = take(4, 4);
     w.tcount = take((int64_t)gx * gy, 4);
@@ -2057,16 +1966,6 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                 NRC_STAGE(s, "k_radix_pass");
             }
             // level 1: row spans in depth order (one launch); level 2 counting + scans: tile ranges and the per-(item, tile) cursors
-#if defined(GS_SPAN_CHAIN)
-            hipLaunchKernelGGL(k_span_count, dim3(w.nb1), dim3(64), 0, s, P, w.nb1, w.chunk1, cam.gy, w.valA, w.rectA, w.cnt1);
-            NRC_STAGE(s, "k_span_count");
-            hipLaunchKernelGGL(k_span_scan, dim3(cam.gy), dim3(256), 0, s, w.nb1, w.cnt1, w.rowtot);
-            NRC_STAGE(s, "k_span_scan");
-            hipLaunchKernelGGL(k_span_rows, dim3(1), dim3(256), 0, s, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, num_rendered + 1, w.meta);
-            NRC_STAGE(s, "k_span_rows");
-            hipLaunchKernelGGL(k_span_scatter, dim3(w.nb1), dim3(64), 0, s, P, w.nb1, w.chunk1, cam.gy, w.valA, w.rectA, w.cnt1, w.roff, w.cap, w.spans);
-            NRC_STAGE(s, "k_span_scatter");
-#else
             static_assert(SP_TILE == RS_TILE, "the span sweep shares the sort's tile count and status layout");
             if (w.nblk <= cu_count)
                 hipLaunchKernelGGL(k_span_sweep<false>, dim3(w.nblk), dim3(SP_THREADS), 0, s, P, cam.gy, w.nblk, w.valA, w.rectA, w.hdr, w.status + (int64_t)4 * 256 * w.nblk,
@@ -2075,7 +1974,6 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                 hipLaunchKernelGGL(k_span_sweep<true>, dim3(w.nblk), dim3(SP_THREADS), 0, s, P, cam.gy, w.nblk, w.valA, w.rectA, w.hdr, w.status + (int64_t)4 * 256 * w.nblk,
                                    w.gstat + (int64_t)4 * 256 * w.ngroups, w.cap, w.spans, w.rowtot, w.roff, w.nitems, w.ioff, num_rendered + 1, w.meta);
             NRC_STAGE(s, "k_span_sweep");
-#endif
             hipLaunchKernelGGL(k_item_count, dim3(SPAN_GRID_COUNT), dim3(64), 0, s, cam.gx, cam.gy, w.rowtot, w.roff, w.nitems, w.ioff, w.meta, w.cap, w.item_cap,
                                w.spans, w.cnt2);
             NRC_STAGE(s, "k_item_count");
