@@ -376,6 +376,8 @@ def csrc_digests():
 def pmc_entry(pmc_all, kernel, source_file):
     """(counter entry or {}, provenance string) of `kernel` from profiles/pmc_summary.json, {} when its source changed since the collection."""
     meta = pmc_all.get('_meta', {})
+    if kernel not in pmc_all:   # template instances are listed with their arguments (k_preprocess<0>, k_radix_pass<false>): the first one of that kernel
+        kernel = next((k for k in sorted(pmc_all) if k.startswith(kernel + '<')), kernel)
     if kernel not in pmc_all:
         return {}, 'no counter entry in profiles/pmc_summary.json'
     if meta.get('csrc_sha', {}).get(source_file) != csrc_digests().get(source_file):

@@ -285,3 +285,41 @@ def test_tile_lists_at_the_sort_tile_and_group_boundaries(n):
         assert fn.num_rendered == want_list.numel()
         assert torch.equal(sv['ranges'].view(-1, 2).to(torch.int32), want_ranges)
         assert torch.equal(sv['point_list'][:want_list.numel()], want_list), (n, frame)
+
+
+def test_speculative_list_sizing_equals_the_sized_call_also_when_the_guess_was_too_small():
+    """Round 4: from the second frame on the wrapper sizes the tile lists from the recent frames and enqueues the whole forward without waiting for the
+    count; a frame that does not fit is repeated with exact sizes.  Three regimes against the stop-and-read forward (SPECULATIVE_SIZING off): a history
+    that fits, a history that is far too small (the repeat path), and a view change that triples the count."""
+    from nerficg_amd import diff_gaussian_rasterization as dgr
+    sc = scenes.gs_random_scene(30_000, seed=11, extent=1.2, log_scale_mean=np.log(0.03))
+    w, h = 200, 152
+    near, far = scenes.gs_camera(w, h, scenes.orbit_pose(0.4, 0.3, 3.0)), scenes.gs_camera(w, h, scenes.orbit_pose(0.4, 0.3, 7.0))
+
+    def frame(cam):
+        color, radii, _, _ = _run(sc, cam, [0.1, 0.2, 0.3], requires_grad=True)
+        sv, fn = _saved(color)
+        n = fn.num_rendered
+        return color.detach().clone(), sv['ranges'].clone(), sv['point_list'][:n].clone(), n
+
+    dgr._INSTANCE_HISTORY.clear()
+    old = dgr.SPECULATIVE_SIZING
+    try:
+        dgr.SPECULATIVE_SIZING = False
+        ref_near, ref_far = frame(near), frame(far)
+        assert ref_near[3] > 2 * ref_far[3] > 0            # the near view needs several times the instances of the far one
+        dgr.SPECULATIVE_SIZING = True
+        dgr._INSTANCE_HISTORY.clear()
+        first = frame(far)                                  # no history yet: the sized path, and it leaves a history entry
+        key = next(iter(dgr._INSTANCE_HISTORY))
+        assert dgr._INSTANCE_HISTORY[key] == [ref_far[3]]
+        fits = frame(far)                                   # speculative, fits
+        grown = frame(near)                                 # speculative with the far view's capacity: does not fit -> repeated with exact sizes
+        dgr._INSTANCE_HISTORY[key] = [7]                    # a history that is absurdly small
+        tiny = frame(near)
+        for got, ref in ((first, ref_far), (fits, ref_far), (grown, ref_near), (tiny, ref_near)):
+            assert got[3] == ref[3] and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]) and torch.equal(got[0], ref[0])
+        assert dgr._INSTANCE_HISTORY[key][-1] == ref_near[3]
+    finally:
+        dgr.SPECULATIVE_SIZING = old
+        dgr._INSTANCE_HISTORY.clear()

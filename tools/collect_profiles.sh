@@ -19,4 +19,4 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmcgs_$tag -- python3 $R/tools/bench_gs.py 1000000 2 > $O/pmcgs_$tag.log 2>&1
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmctr_$tag -- python3 $R/tools/bench_train.py 2200 5 > $O/pmctr_$tag.log 2>&1
 done
-ls $O
+find $O -name "*.db" -delete; find $O -name "*_agent_info.csv" -delete; find $O -path "*_stats/*" -name "*kernel_trace.csv" -delete; du -sh $O; ls -la $O | head -50; tail -5 $O/bench_stats.log
