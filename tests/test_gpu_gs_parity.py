@@ -292,9 +292,9 @@ def test_speculative_list_sizing_equals_the_sized_call_also_when_the_guess_was_t
     count; a frame that does not fit is repeated with exact sizes.  Three regimes against the stop-and-read forward (SPECULATIVE_SIZING off): a history
     that fits, a history that is far too small (the repeat path), and a view change that triples the count."""
     from nerficg_amd import diff_gaussian_rasterization as dgr
-    sc = scenes.gs_random_scene(30_000, seed=11, extent=1.2, log_scale_mean=np.log(0.03))
+    sc = scenes.gs_random_scene(120_000, seed=11, extent=1.2, log_scale_mean=np.log(0.03))
     w, h = 200, 152
-    near, far = scenes.gs_camera(w, h, scenes.orbit_pose(0.4, 0.3, 3.0)), scenes.gs_camera(w, h, scenes.orbit_pose(0.4, 0.3, 7.0))
+    near, far = scenes.gs_camera(w, h, scenes.orbit_pose(0.4, 0.3, 3.0)), scenes.gs_camera(w, h, scenes.orbit_pose(0.4, 0.3, 9.0))
 
     def frame(cam):
         color, radii, _, _ = _run(sc, cam, [0.1, 0.2, 0.3], requires_grad=True)
@@ -307,7 +307,7 @@ def test_speculative_list_sizing_equals_the_sized_call_also_when_the_guess_was_t
     try:
         dgr.SPECULATIVE_SIZING = False
         ref_near, ref_far = frame(near), frame(far)
-        assert ref_near[3] > 2 * ref_far[3] > 0            # the near view needs several times the instances of the far one
+        assert ref_near[3] > 1.3 * ref_far[3] + 65536 and ref_far[3] > 0   # the near view does not fit the capacity guessed from the far one
         dgr.SPECULATIVE_SIZING = True
         dgr._INSTANCE_HISTORY.clear()
         first = frame(far)                                  # no history yet: the sized path, and it leaves a history entry
