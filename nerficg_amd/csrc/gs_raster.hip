@@ -289,7 +289,9 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
 // (192 B read + written per Gaussian, and its backward split) is then never built.
 // (Round 4, measured and dropped: the global side as 16-byte pieces -- four scalar LDS stores per piece, lanes four words apart: 4- to 8-way
 // bank conflicts -- k_preprocess 109 us against 99 on the same box; as 8-byte pieces 144 us.  The 4-byte walk, whose lanes write consecutive LDS
-// words, stays, although a stream of 4-byte loads only reaches 4.1 TB/s against 6.2 for wider ones: profiles/r04_fetch_calibration.md.)
+// words, stays, although a stream of 4-byte loads only reaches 4.1 TB/s against 6.2 for wider ones: profiles/r04_fetch_calibration.md.
+// Also built: the (P, 16, 3) block by LDS-DMA (global_load_lds_dwordx4) into a linear image, rows read with twelve 16-byte LDS reads -- colours
+// bit-identical, k_preprocess 91.9 us against 92.9: the width of the SH loads is not what the kernel waits for.)
 template <bool TO_LDS>
 __device__ __forceinline__ void sh_rows_copy(float* s_sh, int pitch, int row_len, int count, size_t first, float* sh, float* sh_rest, int nthreads) {
     if (!sh_rest) {
