@@ -344,6 +344,10 @@ int nrc_generate_rays(int32_t width, int32_t height, const double* intrinsics, c
  *   3. nrc_ngp_query_samples: slots -> packed (h0, r, g, b) fp16 (sigma = exp(h0)); xyz_min3/xyz_size3 HOST pointers;
  *                             n_ray_tiles = tiles in ray_od (their SH coefficients are evaluated once per ray);
  *                             workspace: nrc_ngp_query_samples_ws_bytes(rows, n_ray_tiles) bytes.
+ *      ABI 3, fixed row capacity (a frame without the host read of `counter`, e.g. inside a stream capture): the caller sizes ts / row_tile /
+ *      packed / workspace for `row_capacity` rows, passes it to nrc_ngp_render_write (rows that would land behind it are not written; 0 = no
+ *      bound) and as n_rows to nrc_ngp_query_samples together with n_rows_dev = counter (DEVICE, the count pass's total): the kernels then
+ *      process only the rows that exist.  counter[0] > row_capacity afterwards means the frame overflowed and must be rendered again.
  *   4. nrc_ngp_composite_image: serial per-ray compositing + background / clamps (bg3 HOST) into full-image buffers
  *                             rgb (H*W,3), alpha (H*W), depth (H*W) -- only the shard's pixels are written.
  * ===================================================================================================== */
@@ -362,12 +366,12 @@ int64_t nrc_ngp_render_provisional_bytes(int64_t n_tiles, int32_t max_samples);
 int nrc_ngp_render_write(int64_t n_tiles, const uint8_t* density_bitfield, int32_t cascades, float scale,
                          float exp_step_factor, int32_t grid_size, int32_t max_samples, const float* ray_od,
                          const float* ray_t, const int32_t* ray_cnt, const int32_t* tile_off, float* ts, int32_t* row_tile,
-                         const float* ts_provisional, nrc_stream_t stream);
+                         const float* ts_provisional, int64_t row_capacity, nrc_stream_t stream);
 int64_t nrc_ngp_query_samples_ws_bytes(int64_t n_rows, int64_t n_ray_tiles);
 int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
                           const float* xyz_min3, const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
-                          float per_level_scale, void* packed_f16, void* workspace, nrc_stream_t stream);
+                          float per_level_scale, void* packed_f16, void* workspace, const int32_t* n_rows_dev, nrc_stream_t stream);
 /* Layer-major variant of steps 2-4: rows ordered by sample index k first (all tiles' k = 0, then k = 1, ...), so that consecutive
  * chunks of rows are depth slabs of the image; after every slab the finished tiles (all rays saturated below T_threshold or out of
  * samples) write their pixels and their remaining rows are skipped -- the early termination of the reference's alive-ray loop
@@ -402,7 +406,7 @@ int nrc_ngp_mlp_samples(const float* ts, const int32_t* row_tile, const float* r
 int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32_t* ray_cnt, const int32_t* tile_off,
                             int32_t width, int32_t height, int64_t tile_begin, int64_t n_tiles, int32_t cascades,
                             float exp_step_factor, int32_t grid_size, int32_t max_samples, float T_threshold,
-                            const float* bg3, float* rgb, float* alpha, float* depth, nrc_stream_t stream);
+                            const float* bg3, float* rgb, float* alpha, float* depth, int64_t row_capacity, nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 7 -- SSIM map and its gradient (3DGS loss): replaces fused_ssim as imported at

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) k_composite_image(const __half* __restric
                                                          int width, int height, int tiles_x, int64_t tile_begin, int64_t n_tiles,
                                                          float esf, float dt_min, float dt_max, float thr, float bg_r, float bg_g,
                                                          float bg_b, float* __restrict__ rgb, float* __restrict__ alpha_out,
-                                                         float* __restrict__ depth_out) {
+                                                         float* __restrict__ depth_out, int64_t row_cap) {
     const int lane = threadIdx.x & 63;
     const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (lt >= n_tiles) return;
@@ -278,7 +278,8 @@ __global__ void __launch_bounds__(256) k_composite_image(const __half* __restric
     const int px = (int)(tile % tiles_x) * NRC_TILE_W + (lane & (NRC_TILE_W - 1)), py = (int)(tile / tiles_x) * NRC_TILE_H + (lane >> NRC_TILE_W_LOG2);
     const bool inside = px < width && py < height;
     const int64_t row0 = tile_off[lt];
-    const int N = inside ? ray_cnt[lt * 64 + lane] : 0;
+    // row_cap (fixed-capacity frames): rows behind it were never written -- an overflowed frame reads nothing out of bounds (its picture is discarded)
+    const int N = inside ? (int)min((int64_t)ray_cnt[lt * 64 + lane], max(row_cap - row0, (int64_t)0)) : 0;
     float T = 1.0f, accR = 0.f, accG = 0.f, accB = 0.f, accD = 0.f, accO = 0.f;
     bool alive = N > 0;
     // several rows per turn, their loads issued together (a row's loads depend on nothing but k): the serial per-lane loop was bound by
@@ -648,9 +649,9 @@ int nrc_distortion_loss_bw(const float* dL_dloss, const float* ws_incl, const fl
 int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32_t* ray_cnt, const int32_t* tile_off, int32_t width,
                             int32_t height, int64_t tile_begin, int64_t n_tiles, int32_t cascades, float exp_step_factor,
                             int32_t grid_size, int32_t max_samples, float T_threshold, const float* bg3_host, float* rgb, float* alpha,
-                            float* depth, nrc_stream_t stream) {
+                            float* depth, int64_t row_capacity, nrc_stream_t stream) {
     NRC_ENTER();
-    if (n_tiles < 0 || tile_begin < 0 || width < 1 || height < 1 || !bg3_host || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
+    if (n_tiles < 0 || tile_begin < 0 || width < 1 || height < 1 || !bg3_host || grid_size < 1 || max_samples < 1 || row_capacity < 0) return NRC_ERR_INVALID;
     if (n_tiles == 0) return NRC_OK;
     if (!ray_cnt || !tile_off || !rgb || !alpha || !depth) return NRC_ERR_INVALID;
     const int tiles_x = (width + NRC_TILE_W - 1) / NRC_TILE_W;
@@ -658,7 +659,7 @@ int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32
     const float dt_min = 1.73205080757f / max_samples, dt_max = 1.73205080757f * 2 * (float)cascades / grid_size;
     hipLaunchKernelGGL(k_composite_image, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, (const __half*)packed_f16, ts, ray_cnt,
                        tile_off, (int)width, (int)height, tiles_x, tile_begin, n_tiles, exp_step_factor, dt_min, dt_max, T_threshold,
-                       bg3_host[0], bg3_host[1], bg3_host[2], rgb, alpha, depth);
+                       bg3_host[0], bg3_host[1], bg3_host[2], rgb, alpha, depth, row_capacity > 0 ? row_capacity : INT64_MAX);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

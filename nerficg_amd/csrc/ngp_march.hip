@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
                                                       const float* __restrict__ ray_t, const int32_t* __restrict__ ray_cnt,
                                                       const int32_t* __restrict__ tile_off, float* __restrict__ ts,
                                                       int32_t* __restrict__ row_tile, const int32_t* __restrict__ row_of,
-                                                      const float* __restrict__ ts_prov) {
+                                                      const float* __restrict__ ts_prov, int64_t row_cap) {
     __shared__ uint32_t s_lut[MARCH_LUT_MAX];
     march_lut(c, s_lut);
     const int lane = threadIdx.x & 63;
@@ -858,7 +858,9 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
     if (lt >= n_tiles) return;
     const int64_t q = lt * 64 + lane;
     const int64_t row0 = tile_off[lt];
-    const int rows = tile_off[lt + 1] - (int)row0;
+    // row_cap: rows the sample buffers hold (fixed-capacity frames; INT64_MAX otherwise).  A tile whose rows would cross it writes the rows that fit:
+    // nothing goes out of bounds, the frame is reported as overflowed (counter[0] > capacity) and is rendered again by the caller.
+    const int rows = (int)min((int64_t)(tile_off[lt + 1] - (int)row0), max(row_cap - row0, (int64_t)0));
     const int N = ray_cnt[q];
     auto row_at = [&](int k) -> int64_t { return row_of ? (int64_t)row_of[row0 + k] : row0 + k; };
     for (int k = lane; k < rows; k += 64) row_tile[row_at(k)] = (int32_t)lt;
@@ -888,7 +890,7 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
     int s = 0;
     while (t < t2 && s < N) {
         if (march_step(ry, c, s_lut, t, x, y, z, dt)) {
-            ts[row_at(s) * 64 + lane] = t;
+            if (s < rows) ts[row_at(s) * 64 + lane] = t;
             t += dt; s++;
         }
     }
@@ -1170,14 +1172,14 @@ int nrc_ngp_render_count(int32_t width, int32_t height, const double* intr, cons
 }
 int nrc_ngp_render_write(int64_t n_tiles, const uint8_t* bitfield, int32_t cascades, float scale, float esf, int32_t grid_size,
                          int32_t max_samples, const float* ray_od, const float* ray_t, const int32_t* ray_cnt, const int32_t* tile_off,
-                         float* ts, int32_t* row_tile, const float* ts_provisional, nrc_stream_t stream) {
+                         float* ts, int32_t* row_tile, const float* ts_provisional, int64_t row_capacity, nrc_stream_t stream) {
     NRC_ENTER();
-    if (n_tiles < 0 || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
+    if (n_tiles < 0 || cascades < 1 || grid_size < 1 || max_samples < 1 || row_capacity < 0) return NRC_ERR_INVALID;
     if (n_tiles == 0) return NRC_OK;
     if (!bitfield || !ray_od || !ray_t || !ray_cnt || !tile_off || !ts || !row_tile) return NRC_ERR_INVALID;
     const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, (float)cascades);
     hipLaunchKernelGGL(k_render_write, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, c, n_tiles, ray_od, ray_t, ray_cnt,
-                       tile_off, ts, row_tile, (const int32_t*)nullptr, ts_provisional);
+                       tile_off, ts, row_tile, (const int32_t*)nullptr, ts_provisional, row_capacity > 0 ? row_capacity : INT64_MAX);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
@@ -1196,7 +1198,7 @@ int nrc_ngp_render_write_layers(int64_t n_tiles, const uint8_t* bitfield, int32_
     hipLaunchKernelGGL(k_slab_offsets, dim3(1), dim3(64), 0, s, n_slabs, layer_off);
     hipLaunchKernelGGL(k_slab_rows, dim3(n_slabs), dim3(256), 0, s, tile_rows, tile_off, n_tiles, (const int32_t*)layer_off, row_of);
     hipLaunchKernelGGL(k_render_write, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, s, c, n_tiles, ray_od, ray_t, ray_cnt, tile_off, ts, row_tile,
-                       (const int32_t*)row_of, ts_provisional);
+                       (const int32_t*)row_of, ts_provisional, INT64_MAX);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

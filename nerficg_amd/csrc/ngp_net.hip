@@ -203,6 +203,8 @@ struct QueryIn {
                                                                     // here (torch's two roundings) and written to x01_out for the backward
     const float* ts; const int32_t* row_tile; const float* ray_od;  // SRC_TILED: slot i = (row i>>6, lane i&63), ray = row_tile[row]*64 + lane
     const uint8_t* tile_alive;                                      // SRC_TILED, optional: rows of finished tiles are treated as holes
+    const int32_t* n_rows_dev;                                      // SRC_TILED, optional: the number of rows the march produced, on the DEVICE -- a launch sized
+                                                                    // for a row CAPACITY processes only the rows that exist (fixed-capacity image pipeline)
     float mn[3], sz[3];                                             // xyz_min, xyz_size of the model box (Renderer.py:50)
 };
 // returns false for a hole of the tiled layout (no sample in this slot)
@@ -264,6 +266,12 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
     }
     int64_t j = bid * 256 + threadIdx.x;
     bool remapped = false;
+    if constexpr (SRC == SRC_TILED) {
+        if (in.n_rows_dev) {   // uniform scalar load: the slots behind the marched rows belong to nobody
+            const int64_t have = (int64_t)in.n_rows_dev[0] * 64 - base;
+            n = have < n ? have : n;
+        }
+    }
     if constexpr (SRC == SRC_TILED) {
         if (lane_shape != 0) {
             // WHICH 64 samples a wave encodes.  Hashed entries are contiguous along x only: a wave whose samples share (y, z) columns shares cache
@@ -415,6 +423,13 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
                                                     const __half* __restrict__ Wc, float* __restrict__ sigmas, float* __restrict__ rgbs,
                                                     __half* __restrict__ packed) {
     enum { F_D0 = 0, F_DO = 4, F_C0 = 8, F_C1 = 12, F_CO = 20, N_FRAG = 24 };
+    if constexpr (SRC == SRC_TILED) {
+        if (in.n_rows_dev) {   // fixed row capacity: only the rows the march produced (uniform over the launch)
+            const int64_t have = (int64_t)in.n_rows_dev[0] * 64 - base;
+            n = have < n ? have : n;
+            if (n <= 0) return;
+        }
+    }
     __shared__ h8 wlds[N_FRAG][64];
 #if defined(NRC_MLP_GLDS)
     // Experiment build (round 4, tools/build_variant.sh ... -DNRC_MLP_GLDS): the three 16-byte input fragments of a tile (two feature vectors, the
@@ -706,9 +721,21 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
 template <int SRC>
 __global__ void __launch_bounds__(256, 4) k_encode_mlp(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ table, GridCfg g, int narrow_levels,
                                                        const h8* __restrict__ ray_sh, const __half* __restrict__ Wd, const __half* __restrict__ Wc,
-                                                       __half* __restrict__ packed) {
+                                                       __half* __restrict__ packed) {    if (in.n_rows_dev) {
+        const int64_t have = (int64_t)in.n_rows_dev[0] * 64 - base;
+        n = have < n ? have : n;
+        if (n <= 0) return;
+    }
+
     static_assert(SRC == SRC_TILED, "tiled layout only");
     enum { F_D0 = 0, F_DO = 4, F_C0 = 8, F_C1 = 12, F_CO = 20, N_FRAG = 24 };
+    if constexpr (SRC == SRC_TILED) {
+        if (in.n_rows_dev) {   // fixed row capacity: only the rows the march produced (uniform over the launch)
+            const int64_t have = (int64_t)in.n_rows_dev[0] * 64 - base;
+            n = have < n ? have : n;
+            if (n <= 0) return;
+        }
+    }
     __shared__ h8 wlds[N_FRAG][64];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     for (int f = threadIdx.x >> 6; f < N_FRAG; f += 4) {
@@ -1125,7 +1152,7 @@ int nrc_ngp_mlp_samples(const float* ts, const int32_t* row_tile, const float* r
 int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles, const float* xyz_min3,
                           const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
-                          float per_level_scale, void* packed_f16, void* workspace, nrc_stream_t stream) {
+                          float per_level_scale, void* packed_f16, void* workspace, const int32_t* n_rows_dev, nrc_stream_t stream) {
     NRC_ENTER();
     const int64_t M = n_rows * 64;
     if (n_rows < 0 || n_ray_tiles < 0 || !density_weights_f16 || !color_weights_f16 || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
@@ -1136,7 +1163,7 @@ int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float*
     const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
     if (rc != NRC_OK) return rc;
     QueryIn in = {};
-    in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od;
+    in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od; in.n_rows_dev = n_rows_dev;
     for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
     run_query<SRC_TILED>(in, M, n_ray_tiles, density_weights_f16, color_weights_f16, table_f16, g, nullptr, nullptr, packed_f16, workspace, (hipStream_t)stream);
     NRC_LAUNCH_CHECK();

@@ -245,9 +245,20 @@ class InstantNGPRenderer:
             c2w = np.vstack([c2w, [0.0, 0.0, 0.0, 1.0]])
         f3 = lambda t: (ctypes.c_float * 3)(*[float(v) for v in t.reshape(-1).tolist()])
         g = m.encoding_xyz.grid_cfg
+        # the model's box lives in device buffers: read ONCE per renderer (host copies, _box / _scene_box).  Until round 4 every frame read the four
+        # vectors back (`.tolist()` of a device tensor = a stream synchronisation each): four host round trips in front of every frame's first launch,
+        # and a read-back inside a stream capture.
+        center, half = self._scene_box()
+        mn, sz = self._box()
+        bg = camera.background_color
+        if bg.is_cuda:   # a colour that lives on the device is read once per tensor object / version
+            hit = self.__dict__.get('_bg_host')
+            if hit is None or hit[0] is not bg or hit[1] != bg._version:
+                hit = self.__dict__['_bg_host'] = (bg, bg._version, bg.detach().float().cpu())
+            bg = hit[2]
         return dict(intr=(ctypes.c_double * 4)(camera.focal_x, camera.focal_y, camera.center_x, camera.center_y),
-                    mat=(ctypes.c_double * 16)(*c2w.reshape(-1).tolist()), center=f3(m.center), half=f3(m.half_size), mn=f3(m.xyz_min), sz=f3(m.xyz_size),
-                    bg=f3(camera.background_color.float().cpu()), esf=1 / 256 if self.EXPONENTIAL_STEPS else 0.0, grid=g, camera=camera,
+                    mat=(ctypes.c_double * 16)(*c2w.reshape(-1).tolist()), center=f3(center), half=f3(half), mn=f3(mn), sz=f3(sz),
+                    bg=f3(bg.float()), esf=1 / 256 if self.EXPONENTIAL_STEPS else 0.0, grid=g, camera=camera,
                     hw=camera.width * camera.height)
 
     def _fused_workspace(self, store: dict, key, nt: int, hw: int, dev, images: bool) -> dict:
@@ -286,8 +297,9 @@ class InstantNGPRenderer:
                       row_of=torch.empty(cap, dtype=torch.int32, device=dev),
                       layer_off=torch.empty(self.MAX_SAMPLES + 2, dtype=torch.int32, device=dev), cap=cap)
 
-    def _fused_write_query(self, fc: dict, ws: dict, rows: int, nt: int) -> None:
-        """single pass: the parked samples into their final rows, then encode + MLPs over all of them"""
+    def _fused_write_query(self, fc: dict, ws: dict, rows: int, nt: int, fixed: bool = False) -> None:
+        """single pass: the parked samples into their final rows, then encode + MLPs over all of them.  fixed: `rows` is a CAPACITY -- rows behind it
+        are not written, and the query kernels read the number of rows that exist from the device counter"""
         if rows <= 0:
             return
         m, lib = self.model, _lib.load()
@@ -296,18 +308,20 @@ class InstantNGPRenderer:
         g = fc['grid']
         _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(fc['esf']), m.RESOLUTION,
                                             self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']),
-                                            _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws.get('ts_prov')), st), 'ngp_render_write')
+                                            _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws.get('ts_prov')),
+                                            int(rows) if fixed else 0, st), 'ngp_render_write')
         _lib.check(lib.nrc_ngp_query_samples(
             _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(fc['mn'], vp), ctypes.cast(fc['sz'], vp),
             _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()), _lib.ptr(m.encoding_xyz._table16()),
-            g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(ws['packed']), _lib.ptr(ws['qws']), st), 'ngp_query_samples')
+            g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(ws['packed']), _lib.ptr(ws['qws']),
+            _lib.ptr(ws['counter']) if fixed else None, st), 'ngp_query_samples')
 
-    def _fused_composite(self, fc: dict, ws: dict, out: dict, tile_begin: int, nt: int) -> None:
+    def _fused_composite(self, fc: dict, ws: dict, out: dict, tile_begin: int, nt: int, row_capacity: int = 0) -> None:
         m, lib, cam = self.model, _lib.load(), fc['camera']
         _lib.check(lib.nrc_ngp_composite_image(
             _lib.ptr(ws.get('packed')), _lib.ptr(ws.get('ts')), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_off']), cam.width, cam.height,
             int(tile_begin), nt, m.cascades, float(fc['esf']), m.RESOLUTION, self.MAX_SAMPLES, 1e-4, ctypes.cast(fc['bg'], ctypes.c_void_p),
-            _lib.ptr(out['rgb']), _lib.ptr(out['alpha']), _lib.ptr(out['depth']), _lib.stream_of(ws['ray_od'])), 'ngp_composite_image')
+            _lib.ptr(out['rgb']), _lib.ptr(out['alpha']), _lib.ptr(out['depth']), int(row_capacity), _lib.stream_of(ws['ray_od'])), 'ngp_composite_image')
 
     @torch.no_grad()
     def render_image_pipelined(self, camera: Camera, c2w: np.ndarray, shards: int = 4, return_stats: bool = False) -> dict[str, torch.Tensor]:
@@ -356,7 +370,7 @@ class InstantNGPRenderer:
                     _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(fc['esf']), m.RESOLUTION,
                                                         self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']),
                                                         _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws.get('ts_prov')),
-                                                        _lib.stream_of(ws['ray_od'])), 'ngp_render_write')
+                                                        0, _lib.stream_of(ws['ray_od'])), 'ngp_render_write')
                 marched = torch.cuda.Event()
                 marched.record(side)
             n_rows += rows
@@ -369,7 +383,7 @@ class InstantNGPRenderer:
                     _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(fc['mn'], vp), ctypes.cast(fc['sz'], vp),
                     _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()), _lib.ptr(m.encoding_xyz._table16()),
                     g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(ws['packed']), _lib.ptr(ws['qws']),
-                    _lib.stream_of(ws['ray_od'])), 'ngp_query_samples')
+                    None, _lib.stream_of(ws['ray_od'])), 'ngp_query_samples')
             self._fused_composite(fc, ws, out, b, nt)
             if k + 1 < shards:     # the next range's count pass starts now, under the kernels just enqueued; its buffers were last used a frame ago
                 nb, ne = ranges[k + 1]
@@ -382,7 +396,8 @@ class InstantNGPRenderer:
 
     @torch.no_grad()
     def render_image_fused(self, camera: Camera, c2w: np.ndarray, tile_begin: int = 0, n_tiles: int | None = None,
-                           return_stats: bool = False, out: dict | None = None, early_termination: bool | str = 'auto') -> dict[str, torch.Tensor]:
+                           return_stats: bool = False, out: dict | None = None, early_termination: bool | str = 'auto',
+                           row_capacity: int | None = None) -> dict[str, torch.Tensor]:
         """Same image as render_image, flat (H*W, C) pixel-major buffers, through the tile-interleaved device pipeline
         (include/nerficg_hip.h group 6): four device stages and ONE host sync (the row count, to size the sample buffers).
         A shard renders the 8x8-pixel tiles [tile_begin, tile_begin + n_tiles) and writes only their pixels (pass `out` to
@@ -390,7 +405,11 @@ class InstantNGPRenderer:
         back, finished tiles skipped in the following slabs (Renderer.py:118-132 at slab granularity); False: one pass over all
         samples.  Both give the same image.  'auto' (default): slabs as long as they pay -- when a slab frame saved less than 10 % of
         its rows (e.g. an untrained model: no ray ever saturates, and the slab bookkeeping costs ~7 %) the next 32 frames of this
-        renderer take the single pass, then one slab frame probes again."""
+        renderer take the single pass, then one slab frame probes again.
+        row_capacity (round 4): a frame WITHOUT the host read -- the sample buffers hold `row_capacity` rows of 64 slots, the single pass is
+        enqueued for that capacity, the kernels take the number of rows that exist from the device counter, and nothing is read back: the call only
+        enqueues (it can sit inside a stream capture).  The result carries 'counter' (DEVICE int32[2]: rows, samples): rows > row_capacity means
+        the frame did not fit and its picture is not valid -- look at it when convenient and render again with more."""
         m = self.model
         lib = _lib.load()
         dev = m.center.device
@@ -407,6 +426,21 @@ class InstantNGPRenderer:
         st = _lib.stream_of(ws['ray_od'])
         esf = fc['esf']
         self._fused_count(fc, ws, tile_begin, nt)
+        if row_capacity is not None:
+            cap = int(row_capacity)
+            if cap < 1:
+                raise ValueError('row_capacity must be positive')
+            if ws['cap'] < cap:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError('render_image_fused(row_capacity=...): call it once outside the capture so that the sample buffers exist')
+                self._fused_size_rows(ws, cap, nt)        # (grows with the usual slack: 1.5 cap + 64 rows)
+                ws['row_tile'].zero_()                     # rows that were never written must name a tile that exists
+                ws['ts'].fill_(-1.0)                       # ... and hold no sample
+            self._fused_write_query(fc, ws, cap, nt, fixed=True)
+            self._fused_composite(fc, ws, out, tile_begin, nt, row_capacity=cap)
+            res = dict(out)
+            res['counter'] = ws['counter']
+            return res
         rows, n_samples = ws['counter'].tolist()   # THE host read of the frame: sizes the sample buffers; the marched total comes with it
         self._fused_size_rows(ws, rows, nt)
         if early_termination == 'auto':

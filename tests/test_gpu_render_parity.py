@@ -416,3 +416,39 @@ def test_pipelined_image_equals_the_one_pass_image():
             assert got['n_samples'] == ref['n_samples'] and got['n_rows'] >= ref['n_rows']   # every range pads its own last row
             for k in ('rgb', 'alpha', 'depth'):
                 assert torch.equal(got[k], ref[k]), (shards, k)
+
+
+def test_fixed_row_capacity_frame_needs_no_host_read_and_can_be_recorded():
+    """render_image_fused(row_capacity=N) (round 4): the frame is only ENQUEUED -- sample buffers for N rows, the kernels take the number of rows that exist
+    from the device counter -- so it paints the picture of the sized call, reports an overflow through the counter without touching memory it does not
+    own, and can sit in a HIP graph (the review's item 8: no D2H copy between nrc_ngp_render_count and nrc_ngp_composite_image)."""
+    from nerficg_amd.instant_ngp import InstantNGPRenderer
+    model = make_model()
+    cam = make_camera(96, 80, bg=(0.2, 0.4, 0.6))
+    poses = [scenes.orbit_pose(0.3 + 0.8 * k, 0.2, scenes.LEGO_RADIUS) for k in range(3)]
+    sized = InstantNGPRenderer(model)
+    fixed = InstantNGPRenderer(model)
+    refs = []
+    for pose in poses:
+        ref = sized.render_image_fused(cam, pose, return_stats=True, early_termination=False)
+        refs.append(({k: ref[k].clone() for k in ('rgb', 'alpha', 'depth')}, ref['n_rows'], ref['n_samples']))
+    cap = int(1.2 * max(r[1] for r in refs)) + 8
+    for pose, (ref, rows, samples) in zip(poses, refs):
+        got = fixed.render_image_fused(cam, pose, row_capacity=cap)
+        assert got['counter'].is_cuda and got['counter'].tolist() == [rows, samples]
+        for k in ('rgb', 'alpha', 'depth'):
+            assert torch.equal(got[k], ref[k]), k
+    # far too small a capacity: nothing is written or read outside the buffers (the run survives), and the counter says so
+    small = InstantNGPRenderer(model)
+    got = small.render_image_fused(cam, poses[0], row_capacity=max(refs[0][1] // 3, 1))
+    torch.cuda.synchronize()
+    assert got['counter'].tolist()[0] == refs[0][1] > refs[0][1] // 3 and bool(torch.isfinite(got['rgb']).all())
+    # recorded: a replay repaints the frame of the recorded pose (the pose is a kernel argument) into the same buffers
+    fixed.render_image_fused(cam, poses[1], row_capacity=cap)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fixed.render_image_fused(cam, poses[1], row_capacity=cap)
+    out['rgb'].zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out['rgb'], refs[1][0]['rgb']) and out['counter'].tolist() == [refs[1][1], refs[1][2]]
