@@ -307,3 +307,33 @@ def test_raymarching_train_cascades_and_max_samples():
     rays_a, xyzs, dirs, deltas, ts, counter = oracle.raymarching_train(o, d, hits, bitfield, 3, 2.0, 1.0 / 256, noise, 128, 64)
     assert rays_a[:, 2].max() <= 64 and counter[0] > 0
     assert np.all(deltas >= np.float32(np.sqrt(3) / 64) * (1 - 1e-6))
+
+
+def test_threaded_march_and_compositor_equal_the_single_thread_run():
+    """Round 4: oracle_raymarching_train (both passes) and oracle_composite_train_fw run their rays on all host cores for bench.py's cpu_baseline.  A
+    ray's arithmetic does not depend on who runs it and the outputs keep the ray-index order (counts -> serial prefix -> second pass), so every
+    array must be bit-identical whatever the thread count -- single cascade with constant steps, and three cascades with exponential steps."""
+    from tests import scenes
+    rng = np.random.default_rng(12)
+    o, _, d = scenes.numpy_rays(72, 56, scenes.orbit_pose(0.9, 0.3, scenes.LEGO_RADIUS))
+    for cascades, scale, esf, bits in ((1, 0.5, 0.0, scenes.sphere_bitfield(128, 0.5, 0.35, 1)), (3, 2.0, 1 / 256, scenes.layered_bitfield(2.0, 3))):
+        _, ht, _ = oracle.ray_aabb_intersect(o, d, np.zeros((1, 3), np.float32), np.full((1, 3), scale, np.float32), 1)
+        hits = ht[:, 0].copy()
+        hits[:, 0] = np.maximum(hits[:, 0], np.float32(0.2))
+        noise = rng.random(len(o)).astype(np.float32)
+        runs = []
+        for threads in (1, 0, 3):
+            before = oracle.set_threads(threads)
+            try:
+                march = oracle.raymarching_train(o, d, hits, bits, cascades, scale, esf, noise, 128, 1024)
+                m = march[1].shape[0]
+                sig = (np.random.default_rng(5).random(m) * 4).astype(np.float32)
+                rgb = np.random.default_rng(6).random((m, 3)).astype(np.float32)
+                comp = oracle.composite_train_fw(sig, rgb, march[3], march[4], march[0], 1e-4)
+            finally:
+                oracle.set_threads(before)
+            runs.append(list(march) + list(comp))
+        assert int(runs[0][5][0]) > 50_000
+        for other in runs[1:]:
+            for a, b in zip(runs[0], other):
+                np.testing.assert_array_equal(a, b)
