@@ -301,11 +301,12 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
     const int rot = (int)((j >> 5) & 3);
     const int lvl_lo = (hashed_mode >> 4) & 0xff, lvl_hi = (hashed_mode >> 12) & 0xff;  // NRC_ENC_LEVELS (measurement only; 0 .. 16 normally)
     const int uniform_levels = (hashed_mode >> 20) & 0xff;                             // levels that try the wave-uniform scalar path first
+    const bool skip_last_group = ((hashed_mode >> 29) & 1) != 0;                       // NRC_ENC_FINE_SPLIT: levels 12-15 come from k_grid_encode_fine
     hashed_mode &= 0xf;
     const uint32_t* __restrict__ table32 = reinterpret_cast<const uint32_t*>(table);
     // gridDim.y == 4: one group of four levels per workgroup row (small batches: four times the waves, a quarter of the dependent gathers each --
     // a 264 K-sample training batch is ~4 waves per SIMD in all and runs at the latency of ONE wave's sixteen gather rounds otherwise)
-    const int grp_begin = gridDim.y == 4 ? (int)blockIdx.y : 0, grp_end = gridDim.y == 4 ? grp_begin + 1 : 4;
+    const int grp_begin = gridDim.y == 4 ? (int)blockIdx.y : 0, grp_end = gridDim.y == 4 ? grp_begin + 1 : (skip_last_group ? 3 : 4);
 #pragma unroll 1
     for (int grp = grp_begin; grp < grp_end; grp++) {
         uint32_t v[4] = {0u, 0u, 0u, 0u};
@@ -346,6 +347,52 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
         // table -- measured 0.630-0.640 ms against 0.640: no effect, removed)
         out[((grp + rot) & 3) * 32] = make_uint4(v[0], v[1], v[2], v[3]);
     }
+}
+
+// Experiment (round-3 review, item 5b; NRC_ENC_FINE_SPLIT=1): the four finest levels in a launch of their own, ONE LEVEL PER XCD.  The whole table is
+// 24.4 MB and an XCD's L2 4 MB: with all sixteen levels in one kernel every L2 sees all of it (hit rate 0.70, 7.5 of the 7.9 L1 misses per sample
+// come from levels 12-15 and 30 % of those go on to the fabric).  Here workgroup b works on level 12 + (b & 3) for the slots of half (b >> 2) & 1
+// (workgroups are dealt round-robin over the XCDs), so each L2 holds ONE 2 MB level.  Price: the position of a sample is derived five times instead
+// of once and the level's 4 bytes are stored into the 16-byte group of the fragment-major record on their own.  Same values in the same places.
+template <int SRC>
+__global__ void __launch_bounds__(256) k_grid_encode_fine(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ table, GridCfg g, uint4* __restrict__ feat,
+                                                              int first_level, int lane_shape) {
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int level = first_level + (xcd & 3);
+    const int64_t per_half = (int64_t)(gridDim.x >> 3);
+    const int64_t bid = (int64_t)(xcd >> 2) * per_half + (int64_t)(blockIdx.x >> 3);
+    int64_t j = bid * 256 + threadIdx.x;
+    if constexpr (SRC == SRC_TILED) {
+        if (in.n_rows_dev) {
+            const int64_t have = (int64_t)in.n_rows_dev[0] * 64 - base;
+            n = have < n ? have : n;
+        }
+        if (lane_shape != 0) {   // the same bricks as k_grid_encode
+            const int lu = (lane_shape >> 4) & 7, lv = lane_shape & 7, ls = 6 - lu - lv;
+            const int64_t g1024 = (base + j) & ~(int64_t)1023;
+            const int w = (int)((j >> 6) & 15), l = (int)(j & 63);
+            const int iu = l & ((1 << lu) - 1), iv = (l >> lu) & ((1 << lv) - 1), is = l >> (lu + lv);
+            const int gu = w & ((NRC_TILE_W >> lu) - 1), gv = (w >> (NRC_TILE_W_LOG2 - lu)) & ((NRC_TILE_H >> lv) - 1), gs = w >> (6 - lu - lv);
+            j = g1024 + ((int64_t)((gs << ls) + is) << 6) + NRC_TILE_W * ((gv << lv) + iv) + (gu << lu) + iu - base;
+        }
+    }
+    if (j >= n || j < 0) return;
+    float px, py, pz;
+    in.x01_out = nullptr;
+    const bool live = fetch_pos<SRC, false>(in, base + j, px, py, pz);
+    const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
+    const int rot = (int)((j >> 5) & 3);
+    uint32_t* out = reinterpret_cast<uint32_t*>(feat + ((j >> 5) * 4) * 32 + (j & 31) + ((3 + rot) & 3) * 32) + (level - first_level);
+    uint32_t v = 0u;
+    if (live) {
+        Corner8 c;
+        float f0, f1;
+        grid_corners_u<true>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
+        grid_level_features_hashed(trs, c, f0, f1);
+        const __half2 h = __floats2half2_rn(f0, f1);
+        v = *reinterpret_cast<const uint32_t*>(&h);
+    }
+    *out = v;
 }
 
 // Small batches (a training iteration: ~264 K samples, once, right after the optimizer rewrote the fp16 table: every XCD's L2 is cold).  With one
@@ -955,8 +1002,19 @@ static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void
     const int lanes = (SRC == SRC_TILED && (base & 1023) == 0) ? lane_shape : 0;
     static const int xcd_ranges = [] { const char* e = getenv("NRC_ENC_XCD"); return e ? (atoi(e) != 0) : 1; }();   // measured: 612 -> 591 us per launch (mean of 24 poses)
     // (the remapping permutes whole blocks of 1024 slots: the launch covers whole blocks)
+    // NRC_ENC_FINE_SPLIT=1 (experiment, see k_grid_encode_fine): levels 12-15 in a second launch, one level per XCD
+    static const int fine_split = [] { const char* e = getenv("NRC_ENC_FINE_SPLIT"); return e ? atoi(e) : 0; }();
+    bool split = false;
+    if constexpr (SRC == SRC_TILED)
+        split = fine_split && lanes && rows == 1u && hashed_mode == 1 && lvl_range == (NRC_MAX_LEVELS << 8) && g.hashed[NRC_MAX_LEVELS - 4] && narrow <= NRC_MAX_LEVELS - 4;
     hipLaunchKernelGGL(k_grid_encode<SRC>, dim3((unsigned)(lanes ? 4 * nrc_cdiv(n, 1024) : nrc_cdiv(n, 256)), rows), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat,
-                       narrow, hashed_mode | (lvl_range << 4) | (uniform_levels << 20) | (xcd_ranges << 28), lanes);
+                       narrow, hashed_mode | (lvl_range << 4) | (uniform_levels << 20) | (xcd_ranges << 28) | ((split ? 1 : 0) << 29), lanes);
+    if constexpr (SRC == SRC_TILED) {
+        if (split) {
+            const int64_t per_half = 2 * nrc_cdiv(n, 1024);   // 256-slot blocks per half of the launch's slots
+            hipLaunchKernelGGL(k_grid_encode_fine<SRC>, dim3((unsigned)(8 * per_half)), dim3(256), 0, s, in, base, n, (const __half2*)table, g, feat, NRC_MAX_LEVELS - 4, lanes);
+        }
+    }
 }
 
 template <int SRC>

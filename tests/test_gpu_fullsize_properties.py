@@ -225,9 +225,11 @@ def test_gs_million_gaussians_gradients_are_stable_and_local(gs):
     assert float((tt['opacities'].grad - 2.0 * grads[0]['opacities']).abs().max()) <= 2e-3 * float(grads[0]['opacities'].abs().max())
 
 
-def test_fused_encode_mlp_kernel_paints_the_same_image():
-    """NRC_QUERY_FUSED=1 (one kernel: encode into registers, 8 v_permlane32_swap, MLP chain) against the default two kernels through the feature
-    buffer, in a subprocess because the switch is read once per process: same fp16 features, same MFMA chain -> the same picture bit for bit."""
+@pytest.mark.parametrize('switch', ['NRC_QUERY_FUSED', 'NRC_ENC_FINE_SPLIT'])
+def test_experiment_switches_of_the_query_paint_the_same_image(switch):
+    """NRC_QUERY_FUSED=1 (one kernel: encode into registers, 8 v_permlane32_swap, MLP chain) and NRC_ENC_FINE_SPLIT=1 (levels 12-15 in a launch of their
+    own, one level per XCD) against the default two kernels through the feature buffer, in a subprocess because the switches are read once per process:
+    same fp16 features, same MFMA chain -> the same picture bit for bit."""
     import os
     import subprocess
     import sys
@@ -239,7 +241,7 @@ def test_fused_encode_mlp_kernel_paints_the_same_image():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for flag in ('0', '1'):
-        env = dict(os.environ, NRC_QUERY_FUSED=flag)
+        env = dict(os.environ, **{switch: flag})
         res = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(res.stdout.strip().splitlines()[-1])
