@@ -29,8 +29,9 @@ enum {
  * compares nrc_abi_version() of the library it loaded with the NRC_ABI_VERSION it was built against and refuses a mismatch (a stale .so under
  * newer bindings -- or the reverse -- would pass a stream where a pointer is expected, or under-allocate a workspace).
  * History: 1 = rounds 1-2; 2 = round 3 (nrc_gs_backward gained grad_records, nrc_ngp_render_count writes 2 * n_tiles ints into tile_rows,
- * counter[1] = total samples, save buffers padded to nrc_nwie_save_rows); 3 = round 4 (see the notes at the changed entry points). */
-#define NRC_ABI_VERSION 3
+ * counter[1] = total samples, save buffers padded to nrc_nwie_save_rows); 3 = round 4 (see the notes at the changed entry points);
+ * 4 = round 4, later: nrc_gs_preprocess gained count_mailbox / mailbox_ticket, nrc_host_mailbox_alloc / _free are new. */
+#define NRC_ABI_VERSION 4
 /* library identification; also used by the loader's symbol check */
 int nrc_abi_version(void);
 const char* nrc_build_info(void);
@@ -281,6 +282,11 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
  *                       instance_capacity > 0 (fixed-capacity mode, for graph capture): point_list has that many entries and nothing
  *                       needs to be read back -- tile ranges are cut at the capacity, the instances that would land behind it are
  *                       dropped (the farthest of the last tiles), and [0] > instance_capacity / [1] > span capacity report it.
+ *                       count_mailbox (ABI 4, optional, binning-workspace path only): HOST memory from nrc_host_mailbox_alloc.  The kernel
+ *                       that finishes the counts also stores {[0], [1], mailbox_ticket} into mailbox[0..2], the ticket last: a host that wants the
+ *                       counts as soon as they exist polls mailbox[2] for the ticket it passed (a value it has not used on this mailbox
+ *                       before) instead of placing an event / copy / stream wait behind the call -- which on this runtime costs ~6 us of idle
+ *                       GPU between this call's kernels and the next, and arrives ~15 us later.  One frame in flight per mailbox.
  *   camera_dev        : optional DEVICE float[38] = viewmatrix (16), projmatrix (16), campos (3), bg (3).  When given, the kernels read the
  *                       pose from it and the host arrays (viewmatrix, projmatrix, campos, bg) may be NULL: a camera that lives in device
  *                       tensors (GaussianRasterizationSettings) never crosses to the host, and a recorded graph follows its updates.
@@ -304,7 +310,12 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                       const float* campos, const float* camera_dev, float tan_fovx, float tan_fovy, int32_t* radii, float* depths,
                       float* points_xy, float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched,
                       uint32_t* tile_counts, uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t span_capacity,
-                      int64_t instance_capacity, float* splat_records, int64_t* num_rendered, nrc_stream_t stream);
+                      int64_t instance_capacity, float* splat_records, int64_t* num_rendered, int64_t* count_mailbox, int64_t mailbox_ticket,
+                      nrc_stream_t stream);
+/* 64 bytes of pinned, device-mapped, coherent host memory (zeroed) that kernels of this library may write and the host may poll: one address on
+ * both sides; NRC_ERR_UNSUPPORTED when the runtime maps it elsewhere (use the device counters then).  Free with nrc_host_mailbox_free. */
+int nrc_host_mailbox_alloc(int64_t** mailbox);
+int nrc_host_mailbox_free(int64_t* mailbox);
 int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg, const float* camera_dev, const int32_t* radii,
                       const float* depths, const float* points_xy, const float* conic_opacity, const float* rgb,
                       const uint32_t* ranges, uint32_t* tile_fill, const uint32_t* bin_hist, int64_t span_capacity,

@@ -859,7 +859,8 @@ __global__ void __launch_bounds__(64) k_item_count(int gx, int gy, const uint32_
 __device__ __forceinline__ void tile_order_of(int n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order, uint32_t* hist, uint32_t* wsum);
 __global__ void __launch_bounds__(1024) k_item_scan(int gx, int gy, int item_cap, const uint32_t* __restrict__ nitems, const uint32_t* __restrict__ ioff,
                                                     uint32_t* __restrict__ cnt2, uint32_t* __restrict__ tcount, uint32_t* __restrict__ done_counter,
-                                                    uint32_t cap, uint32_t* __restrict__ ranges, uint32_t* __restrict__ order, int64_t* __restrict__ num_rendered) {
+                                                    uint32_t cap, uint32_t* __restrict__ ranges, uint32_t* __restrict__ order, int64_t* __restrict__ num_rendered,
+                                                    int64_t* __restrict__ mailbox, int64_t mailbox_ticket) {
     __shared__ uint32_t gsum[16][64];
     __shared__ uint32_t hist[2048];
     __shared__ uint32_t wave_tot[16];
@@ -925,7 +926,16 @@ __global__ void __launch_bounds__(1024) k_item_scan(int gx, int gy, int item_cap
         if (threadIdx.x == 1023) carry_s = off + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *num_rendered = (int64_t)carry_s;
+    if (threadIdx.x == 0) {
+        *num_rendered = (int64_t)carry_s;
+        if (mailbox) {
+            // the two counts of the frame straight into host memory (nrc_host_mailbox_alloc: pinned, mapped, coherent), the ticket LAST: the host polls
+            // the ticket and then sizes / checks the lists without an event, a copy or a stream wait (posted writes of one agent arrive in order)
+            __hip_atomic_store(mailbox, (int64_t)carry_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mailbox + 1, num_rendered[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // spans: written by k_span_sweep, two launches ago
+            __hip_atomic_store(mailbox + 2, mailbox_ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     tile_order_of(n, ranges, order, hist, wave_tot);
 }
 // level 2, scatter: ids of the item's spans appended to the tiles they cover; tile (y, x) of this item starts at ranges[tile].first + cnt2[item][x]
@@ -1883,6 +1893,28 @@ extern "C" {
 int nrc_debug_sort_probe(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sort_probe), sizeof(g_sort_probe)); }
 #endif
 
+int nrc_host_mailbox_alloc(int64_t** mailbox) {
+    NRC_ENTER();
+    if (!mailbox) return NRC_ERR_INVALID;
+    *mailbox = nullptr;
+    void* host = nullptr;
+    const hipError_t e = hipHostMalloc(&host, 8 * sizeof(int64_t), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) { (void)hipGetLastError(); nrc_set_last_hip_error((int)e); return NRC_ERR_LAUNCH; }
+    void* dev = nullptr;
+    // one address on both sides (unified addressing): the kernels take the pointer the host reads through
+    if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess || dev != host) { (void)hipGetLastError(); (void)hipHostFree(host); return NRC_ERR_UNSUPPORTED; }
+    for (int k = 0; k < 8; k++) ((volatile int64_t*)host)[k] = 0;
+    *mailbox = (int64_t*)host;
+    return NRC_OK;
+}
+int nrc_host_mailbox_free(int64_t* mailbox) {
+    if (mailbox) {
+        const hipError_t e = hipHostFree(mailbox);
+        if (e != hipSuccess) { (void)hipGetLastError(); nrc_set_last_hip_error((int)e); return NRC_ERR_LAUNCH; }
+    }
+    return NRC_OK;
+}
+
 int64_t nrc_gs_bin_hist_bytes(int32_t P, int32_t W, int32_t H, int64_t span_capacity) {
     if (P < 0 || W < 1 || H < 1 || span_capacity < 0) return NRC_ERR_INVALID;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
@@ -1896,7 +1928,8 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                       const float* campos_host, const float* camera_dev, float tan_fovx, float tan_fovy, int32_t* radii, float* depths,
                       float* points_xy, float* conic_opacity, float* rgb, uint8_t* clamped, float* cov3D, uint32_t* tiles_touched,
                       uint32_t* tile_counts, uint32_t* ranges, uint32_t* tile_fill, uint32_t* bin_hist, int64_t span_capacity,
-                      int64_t instance_capacity, float* splat_records, int64_t* num_rendered, nrc_stream_t stream) {
+                      int64_t instance_capacity, float* splat_records, int64_t* num_rendered, int64_t* count_mailbox, int64_t mailbox_ticket,
+                      nrc_stream_t stream) {
     NRC_ENTER();
     GsCam cam;
     const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, camera_dev, tan_fovx, tan_fovy, scale_modifier, raw_parameters);
@@ -1914,6 +1947,7 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
     const int n_tiles = cam.gx * cam.gy;
     const bool lds_path = cam.gx <= SPAN_DIM_MAX && cam.gy <= SPAN_DIM_MAX && bin_hist != nullptr;
     if (instance_capacity > 0 && P > 0 && !lds_path) return NRC_ERR_UNSUPPORTED;  // the per-tile key sort fallback sizes its keys from the count
+    if (count_mailbox && !(P > 0 && lds_path)) return NRC_ERR_UNSUPPORTED;        // the counts reach the mailbox from the last workgroup of k_item_scan only
     NRC_STAGE(s, nullptr);
     if (!(P > 0 && lds_path)) nrc_zero_async(tile_counts, sizeof(uint32_t) * n_tiles, s);  // only the global-atomic fallback counts into it
     if (P > 0) {
@@ -1964,7 +1998,7 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
             NRC_STAGE(s, "k_item_count");
             // per-(item, tile) cursors, tile totals; its last workgroup: ranges, instance count and the launch order of the tiles (into tile_fill)
             hipLaunchKernelGGL(k_item_scan, dim3((unsigned)nrc_cdiv(cam.gx, 64), cam.gy), dim3(1024), 0, s, cam.gx, cam.gy, w.item_cap, w.nitems, w.ioff, w.cnt2, w.tcount,
-                               w.hdr + RS_HDR_TICKET + 5, list_cap, ranges, tile_fill, num_rendered);
+                               w.hdr + RS_HDR_TICKET + 5, list_cap, ranges, tile_fill, num_rendered, count_mailbox, mailbox_ticket);
             NRC_STAGE(s, "k_item_scan");
             if (forked && hipStreamWaitEvent(s, side->join, 0) != hipSuccess) (void)hipStreamSynchronize(side->stream);   // the colours are in place for whatever the caller enqueues next
         }

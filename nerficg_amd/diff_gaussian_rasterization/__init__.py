@@ -14,6 +14,9 @@ src/Methods/GaussianSplatting/Model.py:258).  Backed by libnerficg_hip.so (nrc_g
 from __future__ import annotations
 
 import contextlib
+import ctypes
+import time
+import warnings
 from typing import NamedTuple
 
 import torch
@@ -96,6 +99,14 @@ _SPAN_CAPACITY: dict = {}  # (device, P, W, H) -> row-span capacity of the binni
 _INSTANCE_HISTORY: dict = {}   # (device, P, W, H) -> recent instance counts
 _READBACK: dict = {}           # device -> (side stream, pinned int64[2])
 SPECULATIVE_SIZING = True
+# How the count reaches the host (round 4, later).  The side-stream copy needs an event on the caller's stream between the counting kernels and the list
+# scatter -- 6-7 us of idle GPU in the kernel trace -- plus ~20 us of host calls, and the copy itself lands ~15 us after the count exists.  With a
+# MAILBOX (include/nerficg_hip.h, nrc_host_mailbox_alloc: pinned, device-mapped, coherent host memory) the last workgroup of the counting kernel
+# stores the two counts and this call's ticket straight into host memory and the host polls the ticket: no event, no copy, no second stream.
+# A mailbox that does not answer within MAILBOX_TIMEOUT_S (never observed) falls back to a stream synchronize + device read and is not used again.
+COUNT_MAILBOX = True
+MAILBOX_TIMEOUT_S = 2.0
+_MAILBOX: dict = {}            # device -> [ctypes view of the mailbox, address, last ticket] or None once it failed
 
 
 def _readback(dev):
@@ -103,6 +114,15 @@ def _readback(dev):
     if hit is None:
         hit = _READBACK[dev] = (torch.cuda.Stream(device=dev), torch.empty(2, dtype=torch.int64).pin_memory())
     return hit
+
+
+def _mailbox(dev, lib):
+    if dev not in _MAILBOX:
+        box = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            ok = lib.nrc_host_mailbox_alloc(ctypes.byref(box)) == 0 and box.value
+        _MAILBOX[dev] = [(ctypes.c_int64 * 3).from_address(box.value), box, 0] if ok else None
+    return _MAILBOX[dev]
 
 
 def _opt(t):
@@ -166,14 +186,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         final_T = torch.empty(H * W, dtype=f32, device=dev)
         global _LAST_COUNTS
 
-        def preprocess(cap_spans, cap_inst):
+        def preprocess(cap_spans, cap_inst, box=None, ticket=0):
             hist_bytes = int(lib.nrc_gs_bin_hist_bytes(P, W, H, cap_spans))
             hist = torch.empty(hist_bytes // 4, dtype=i32, device=dev) if hist_bytes > 0 else None
             _lib.check(lib.nrc_gs_preprocess(
                 P, D, M, W, H, _lib.ptr(means3D_c), _lib.ptr(sh_c), _lib.ptr(rest_c), int(raw), _lib.ptr(col_c), _lib.ptr(op_c), _lib.ptr(sc_c), float(rs.scale_modifier),
                 _lib.ptr(rot_c), _lib.ptr(cov_c), None, None, None, _lib.ptr(cam_block), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(depths),
                 _lib.ptr(points_xy), _lib.ptr(conic_opacity), _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(tiles_touched),
-                _lib.ptr(tile_counts), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(hist), cap_spans, cap_inst, _lib.ptr(splat), _lib.ptr(num_rendered), st), 'gs_preprocess')
+                _lib.ptr(tile_counts), _lib.ptr(ranges), _lib.ptr(tile_fill), _lib.ptr(hist), cap_spans, cap_inst, _lib.ptr(splat), _lib.ptr(num_rendered),
+                box if hist is not None else None, ticket, st), 'gs_preprocess')
             return hist
 
         def bin_render(hist, cap_spans, cap_inst, n_list):
@@ -186,9 +207,34 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         done = False
         if speculative:
-            bin_hist = preprocess(span_cap, inst_cap)
+            mb = _mailbox(dev, lib) if COUNT_MAILBOX else None
+            if mb is not None:
+                mb[2] += 1
+            bin_hist = preprocess(span_cap, inst_cap, mb[1] if mb is not None else None, mb[2] if mb is not None else 0)
             have = span_cap if span_cap > 0 else 4 * max(P, 1) + 65536
-            if bin_hist is not None:
+            if bin_hist is not None and mb is not None:
+                keys, point_list = bin_render(bin_hist, span_cap, inst_cap, inst_cap)
+                seen, ticket = mb[0], mb[2]
+                spins, deadline = 0, None
+                while seen[2] != ticket:
+                    spins += 1
+                    if (spins & 0xfff) == 0:     # ~ every millisecond: look at the clock
+                        now = time.monotonic()
+                        deadline = deadline or now + MAILBOX_TIMEOUT_S
+                        if now > deadline:
+                            break
+                if seen[2] == ticket:
+                    n_inst, n_spans = int(seen[0]), int(seen[1])
+                else:
+                    warnings.warn('diff_gaussian_rasterization: the count mailbox did not answer; using the device counters from now on')
+                    _MAILBOX[dev] = None
+                    n_inst, n_spans = num_rendered.tolist()
+                done = n_inst <= inst_cap and n_spans <= have
+                if done:
+                    point_list = point_list[:max(n_inst, 1)]
+                elif n_spans > have:
+                    span_cap = _SPAN_CAPACITY[ws_key] = int(n_spans * 1.25) + 65536
+            elif bin_hist is not None:
                 side, pinned = _readback(dev)
                 main = torch.cuda.current_stream(dev)
                 counted = torch.cuda.Event()

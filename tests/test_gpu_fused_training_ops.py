@@ -92,6 +92,8 @@ def test_rasterizer_abi_host_camera_equals_device_camera_block():
     vm, pm, cp = f(cam['viewmatrix'].reshape(-1)), f(cam['projmatrix'].reshape(-1)), f(cam['campos'].reshape(-1))
     block = torch.cat([T(cam['viewmatrix']).reshape(-1), T(cam['projmatrix']).reshape(-1), T(cam['campos']).reshape(-1), torch.zeros(3, device=DEV)]).float()
     outs = []
+    mailbox = ctypes.c_void_p()
+    _lib.check(lib.nrc_host_mailbox_alloc(ctypes.byref(mailbox)), 'host_mailbox_alloc')
     for use_block in (False, True):
         i32, f32 = torch.int32, torch.float32
         bufs = dict(radii=torch.empty(P, dtype=i32, device=DEV), depths=torch.empty(P, device=DEV), xy=torch.empty(P, 2, device=DEV),
@@ -106,8 +108,11 @@ def test_rasterizer_abi_host_camera_equals_device_camera_block():
             None if use_block else cast(vm), None if use_block else cast(pm), None if use_block else cast(cp), _lib.ptr(block) if use_block else None,
             float(cam['tanfovx']), float(cam['tanfovy']), _lib.ptr(bufs['radii']), _lib.ptr(bufs['depths']), _lib.ptr(bufs['xy']), _lib.ptr(bufs['co']),
             _lib.ptr(bufs['rgb']), _lib.ptr(bufs['clamped']), _lib.ptr(bufs['cov']), _lib.ptr(bufs['tt']), _lib.ptr(bufs['tc']), _lib.ptr(bufs['ranges']),
-            _lib.ptr(bufs['tf']), _lib.ptr(hist), 0, 0, _lib.ptr(bufs['splat']), _lib.ptr(bufs['num']), _lib.stream_of(means)), 'gs_preprocess')
+            _lib.ptr(bufs['tf']), _lib.ptr(hist), 0, 0, _lib.ptr(bufs['splat']), _lib.ptr(bufs['num']), mailbox, 41 + int(use_block), _lib.stream_of(means)), 'gs_preprocess')
         torch.cuda.synchronize()
+        # ABI 4: the counts also arrive in the host mailbox, the ticket of THIS call behind them
+        seen = (ctypes.c_int64 * 3).from_address(mailbox.value)
+        assert list(seen) == bufs['num'].tolist() + [41 + int(use_block)]
         outs.append({k: v.clone() for k, v in bufs.items() if k in ('radii', 'depths', 'xy', 'co', 'rgb', 'clamped', 'tt', 'ranges', 'num')})
     assert int(outs[0]['num'][0]) > 10000
     for k in outs[0]:
@@ -117,8 +122,9 @@ def test_rasterizer_abi_host_camera_equals_device_camera_block():
                                None, None, None, None, float(cam['tanfovx']), float(cam['tanfovy']), _lib.ptr(bufs['radii']), _lib.ptr(bufs['depths']),
                                _lib.ptr(bufs['xy']), _lib.ptr(bufs['co']), _lib.ptr(bufs['rgb']), _lib.ptr(bufs['clamped']), _lib.ptr(bufs['cov']),
                                _lib.ptr(bufs['tt']), _lib.ptr(bufs['tc']), _lib.ptr(bufs['ranges']), _lib.ptr(bufs['tf']), _lib.ptr(hist), 0, 0,
-                               _lib.ptr(bufs['splat']), _lib.ptr(bufs['num']), _lib.stream_of(means))
+                               _lib.ptr(bufs['splat']), _lib.ptr(bufs['num']), None, 0, _lib.stream_of(means))
     assert rc != 0
+    _lib.check(lib.nrc_host_mailbox_free(mailbox), 'host_mailbox_free')
 
 
 def test_stage_timer_names_and_times_the_kernels_of_an_entry_point():
