@@ -288,6 +288,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.debug_state = dict(depths=depths, tiles_touched=tiles_touched, keys=keys)
         radii_out = radii[:P]
         ctx.mark_non_differentiable(radii_out)
+        # radii carry no gradient: without this autograd hands the backward a zero-filled (P,) int tensor for them -- a 4 MB fill launch per step
+        ctx.set_materialize_grads(False)
         return color, radii_out
 
     @staticmethod
@@ -302,6 +304,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         lib = _lib.load()
         dev = means3D.device
         f32 = torch.float32
+        if grad_out_color is None:   # (grads are not materialised: the image did not take part in the loss)
+            grad_out_color = torch.zeros(3, H, W, dtype=f32, device=dev)
         g = grad_out_color.to(f32).contiguous()
         n1 = max(P, 1)
         dmean2D = torch.empty(n1, 3, dtype=f32, device=dev)

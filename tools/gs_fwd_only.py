@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/gs_fwd_only.py [N] [FRAMES] -- forward-only rasterizer frames back to back (for tools/kseq.sh / kstats2.sh: what one forward frame is made of)."""
+"""tools/gs_fwd_only.py [N] [FRAMES] [bwd] -- rasterizer frames back to back, forward only or (third argument `bwd`) forward + backward, nothing else
+in the process (for tools/kseq.sh / kstats2.sh: what one frame is made of, and where the GPU idles between its kernels)."""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -20,3 +21,19 @@ with torch.no_grad():
         gs['rast'](means3D=t['means3D'], means2D=m2d, opacities=t['opacities'], shs=t['shs'], scales=t['scales'], rotations=t['rotations'])
     torch.cuda.synchronize()
 print('forward ms', (time.perf_counter() - t0) / frames * 1e3)
+if len(sys.argv) > 3 and sys.argv[3] == 'bwd':
+    for k in ('means3D', 'opacities', 'shs', 'scales', 'rotations'):
+        t[k].requires_grad_(True)
+    m2d.requires_grad_(True)
+    g = torch.rand(3, bench.GS_H, bench.GS_W, device=dev)
+
+    def step():
+        color, _ = gs['rast'](means3D=t['means3D'], means2D=m2d, opacities=t['opacities'], shs=t['shs'], scales=t['scales'], rotations=t['rotations'])
+        color.backward(g)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(frames):
+        step()
+    torch.cuda.synchronize()
+    print('forward + backward ms', (time.perf_counter() - t0) / frames * 1e3)
