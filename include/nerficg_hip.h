@@ -30,7 +30,7 @@ enum {
  * newer bindings -- or the reverse -- would pass a stream where a pointer is expected, or under-allocate a workspace).
  * History: 1 = rounds 1-2; 2 = round 3 (nrc_gs_backward gained grad_records, nrc_ngp_render_count writes 2 * n_tiles ints into tile_rows,
  * counter[1] = total samples, save buffers padded to nrc_nwie_save_rows); 3 = round 4 (see the notes at the changed entry points);
- * 4 = round 4, later: nrc_gs_preprocess gained count_mailbox / mailbox_ticket, nrc_host_mailbox_alloc / _free are new. */
+ * 4 = round 4, later: nrc_gs_preprocess and nrc_ngp_render_count gained count_mailbox / mailbox_ticket, nrc_host_mailbox_alloc / _free are new. */
 #define NRC_ABI_VERSION 4
 /* library identification; also used by the loader's symbol check */
 int nrc_abi_version(void);
@@ -369,7 +369,11 @@ int nrc_ngp_render_count(int32_t width, int32_t height, const double* intrinsics
                          const float* half3, float near_plane, float far_plane, int64_t tile_begin, int64_t n_tiles,
                          const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
                          int32_t grid_size, int32_t max_samples, float* ray_od, float* ray_t, int32_t* ray_cnt,
-                         int32_t* tile_rows, int32_t* tile_off, int32_t* counter, float* ts_provisional, nrc_stream_t stream);
+                         int32_t* tile_rows, int32_t* tile_off, int32_t* counter, float* ts_provisional, int64_t* count_mailbox,
+                         int64_t mailbox_ticket, nrc_stream_t stream);
+/* count_mailbox (ABI 4, optional, NULL allowed): HOST memory from nrc_host_mailbox_alloc (group 4).  The scan that closes the count pass stores
+ * {counter[0], counter[1], mailbox_ticket} into mailbox[0..2], the ticket last; the host polls mailbox[2] for its ticket instead of copying
+ * `counter` back (no device-to-host copy and no stream wait between the count pass and nrc_ngp_render_write: 42 -> ~10 us of idle GPU per frame). */
 /* ts_provisional (optional, NULL allowed; nrc_ngp_render_provisional_bytes(n_tiles, max_samples) bytes = max_samples rows of 256 B per
  * tile): the count pass parks every sample's t there and steps 2 copy them into their final rows instead of marching the rays a
  * second time (pass the same buffer to both calls).  HBM is plentiful on this part: 2.6 GB for an 800x800 image. */

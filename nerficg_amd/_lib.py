@@ -112,6 +112,58 @@ def check_input(t, name: str, dtype=None) -> None:
         raise RuntimeError(f'{name} must have dtype {dtype}, got {t.dtype}')
 
 
+class HostMailbox:
+    """Pinned, device-mapped, coherent host memory that a kernel of the library writes and the host polls (include/nerficg_hip.h:
+    nrc_host_mailbox_alloc).  An entry point that takes (count_mailbox, mailbox_ticket) stores two counts and the ticket, the ticket last;
+    `wait(ticket)` spins on it -- no event, no device-to-host copy, no stream wait behind the call, which on this runtime cost tens of
+    microseconds of idle GPU per frame.  One call in flight per mailbox.  `for_device(dev)` returns the process-wide mailbox of a device,
+    or None when the runtime cannot map one (or after one failed to answer: callers then read the device counters)."""
+
+    TIMEOUT_S = 2.0
+    _per_device: dict = {}
+
+    def __init__(self, device) -> None:
+        import torch
+        box = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            check(load().nrc_host_mailbox_alloc(ctypes.byref(box)), 'host_mailbox_alloc')
+        self.ptr = box
+        self._seen = (ctypes.c_int64 * 3).from_address(box.value)
+        self._ticket = 0
+
+    @classmethod
+    def for_device(cls, device):
+        key = str(device)
+        if key not in cls._per_device:
+            try:
+                cls._per_device[key] = cls(device)
+            except RuntimeError:
+                cls._per_device[key] = None
+        return cls._per_device[key]
+
+    @classmethod
+    def retire(cls, device) -> None:
+        cls._per_device[str(device)] = None
+
+    def next_ticket(self) -> int:
+        self._ticket += 1
+        return self._ticket
+
+    def wait(self, ticket: int):
+        """(first, second) count once the kernel that was given `ticket` has stored them; None after TIMEOUT_S (never observed)."""
+        import time
+        seen = self._seen
+        spins, deadline = 0, None
+        while seen[2] != ticket:
+            spins += 1
+            if (spins & 0xfff) == 0:   # every few hundred microseconds: look at the clock
+                now = time.monotonic()
+                deadline = deadline or now + self.TIMEOUT_S
+                if now > deadline:
+                    return None
+        return int(seen[0]), int(seen[1])
+
+
 class stage_timer:
     """Context manager around the library's stage timer (include/nerficg_hip.h group 12): HIP events on the launch stream behind every kernel
     of the multi-kernel entry points, recorded by the library itself.  After the block, `.stages` is the list of (kernel name, ms) in launch

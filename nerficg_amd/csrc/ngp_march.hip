@@ -770,37 +770,37 @@ __global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c,
     if (lane == 0) { tile_rows[lt] = m; tile_rows[n_tiles + lt] = tile_samples; }   // second half of the array: samples per tile (for the total)
 }
 // exclusive scan of tile_rows[0..n_tiles) -> tile_off[0..n_tiles] (tile_off[n_tiles] = total rows); counter = (total rows, total samples: the
-// sum of tile_rows[n_tiles..2 n_tiles)), so that the caller's ONE host read sizes the sample buffers and reports the marched samples
+// sum of tile_rows[n_tiles..2 n_tiles)), so that the caller's ONE host read sizes the sample buffers and reports the marched samples.
+// One workgroup; thread t owns the contiguous chunk [t c, (t + 1) c) (c = ceil(n / 1024): 10 tiles of an 800x800 image) -- one block scan over the
+// chunk sums instead of one per 1024 tiles (round 4: 14 -> 6 us).  mailbox (optional, nrc_host_mailbox_alloc): the two totals and the caller's
+// ticket also go straight to host memory, the ticket last -- the host polls it instead of copying `counter` back.
 __global__ void __launch_bounds__(1024) k_scan_tiles(const int32_t* __restrict__ tile_rows, int64_t n_tiles, int32_t* __restrict__ tile_off,
-                                                     int32_t* __restrict__ counter) {
+                                                     int32_t* __restrict__ counter, int64_t* __restrict__ mailbox, int64_t mailbox_ticket) {
     __shared__ int wave_tot[16];
     __shared__ int samp_tot[16];
-    __shared__ int carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    int samples = 0;
-    for (int64_t base = 0; base < n_tiles; base += 1024) {
-        const int64_t i = base + threadIdx.x;
-        const int v = i < n_tiles ? tile_rows[i] : 0;
-        samples += i < n_tiles ? tile_rows[n_tiles + i] : 0;
-        const int incl = nrc_wave_incl_sum_i(v, lane);
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        int off = carry_s;
-        for (int w = 0; w < wave; w++) off += wave_tot[w];
-        if (i < n_tiles) tile_off[i] = off + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = off + incl;
-        __syncthreads();
-    }
+    const int64_t chunk = (n_tiles + 1023) / 1024;
+    const int64_t i0 = (int64_t)threadIdx.x * chunk, i1 = i0 + chunk < n_tiles ? i0 + chunk : n_tiles;
+    int rows = 0, samples = 0;
+    for (int64_t i = i0; i < i1; i++) { rows += tile_rows[i]; samples += tile_rows[n_tiles + i]; }
+    const int incl = nrc_wave_incl_sum_i(rows, lane);
     samples = nrc_group_sum_i<64>(samples);
+    if (lane == 63) wave_tot[wave] = incl;
     if (lane == 0) samp_tot[wave] = samples;
     __syncthreads();
+    int off = incl - rows, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { off += w < wave ? wave_tot[w] : 0; total += wave_tot[w]; }
+    for (int64_t i = i0; i < i1; i++) { tile_off[i] = off; off += tile_rows[i]; }
     if (threadIdx.x == 0) {
         int tot = 0;
         for (int w = 0; w < 16; w++) tot += samp_tot[w];
-        tile_off[n_tiles] = carry_s; counter[0] = carry_s; counter[1] = tot;
+        tile_off[n_tiles] = total; counter[0] = total; counter[1] = tot;
+        if (mailbox) {
+            __hip_atomic_store(mailbox, (int64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mailbox + 1, (int64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mailbox + 2, mailbox_ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 // ---- slab-major row order (front-to-back processing with early termination, see nrc_ngp_render_layers) -------------------------
@@ -1149,7 +1149,7 @@ int nrc_ngp_render_count(int32_t width, int32_t height, const double* intr, cons
                          float near_plane, float far_plane, int64_t tile_begin, int64_t n_tiles, const uint8_t* bitfield,
                          int32_t cascades, float scale, float esf, int32_t grid_size, int32_t max_samples, float* ray_od,
                          float* ray_t, int32_t* ray_cnt, int32_t* tile_rows, int32_t* tile_off, int32_t* counter, float* ts_provisional,
-                         nrc_stream_t stream) {
+                         int64_t* count_mailbox, int64_t mailbox_ticket, nrc_stream_t stream) {
     NRC_ENTER();
     if (width < 1 || height < 1 || !intr || !c2w || !center3 || !half3 || n_tiles < 0 || tile_begin < 0 || cascades < 1 ||
         grid_size < 1 || max_samples < 1 || !counter || !tile_off)
@@ -1166,7 +1166,7 @@ int nrc_ngp_render_count(int32_t width, int32_t height, const double* intr, cons
     if (n_tiles > 0)
         hipLaunchKernelGGL(k_render_count, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, s, cam, c, tiles_x, tile_begin, n_tiles, ray_od, ray_t,
                            ray_cnt, tile_rows, ts_provisional);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_rows, n_tiles, tile_off, counter);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_rows, n_tiles, tile_off, counter, count_mailbox, mailbox_ticket);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -14,8 +14,6 @@ src/Methods/GaussianSplatting/Model.py:258).  Backed by libnerficg_hip.so (nrc_g
 from __future__ import annotations
 
 import contextlib
-import ctypes
-import time
 import warnings
 from typing import NamedTuple
 
@@ -103,10 +101,8 @@ SPECULATIVE_SIZING = True
 # scatter -- 6-7 us of idle GPU in the kernel trace -- plus ~20 us of host calls, and the copy itself lands ~15 us after the count exists.  With a
 # MAILBOX (include/nerficg_hip.h, nrc_host_mailbox_alloc: pinned, device-mapped, coherent host memory) the last workgroup of the counting kernel
 # stores the two counts and this call's ticket straight into host memory and the host polls the ticket: no event, no copy, no second stream.
-# A mailbox that does not answer within MAILBOX_TIMEOUT_S (never observed) falls back to a stream synchronize + device read and is not used again.
+# A mailbox that does not answer within _lib.HostMailbox.TIMEOUT_S (never observed) falls back to a stream synchronize + device read and is not used again.
 COUNT_MAILBOX = True
-MAILBOX_TIMEOUT_S = 2.0
-_MAILBOX: dict = {}            # device -> [ctypes view of the mailbox, address, last ticket] or None once it failed
 
 
 def _readback(dev):
@@ -114,15 +110,6 @@ def _readback(dev):
     if hit is None:
         hit = _READBACK[dev] = (torch.cuda.Stream(device=dev), torch.empty(2, dtype=torch.int64).pin_memory())
     return hit
-
-
-def _mailbox(dev, lib):
-    if dev not in _MAILBOX:
-        box = ctypes.c_void_p()
-        with torch.cuda.device(dev):
-            ok = lib.nrc_host_mailbox_alloc(ctypes.byref(box)) == 0 and box.value
-        _MAILBOX[dev] = [(ctypes.c_int64 * 3).from_address(box.value), box, 0] if ok else None
-    return _MAILBOX[dev]
 
 
 def _opt(t):
@@ -207,28 +194,18 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         done = False
         if speculative:
-            mb = _mailbox(dev, lib) if COUNT_MAILBOX else None
-            if mb is not None:
-                mb[2] += 1
-            bin_hist = preprocess(span_cap, inst_cap, mb[1] if mb is not None else None, mb[2] if mb is not None else 0)
+            mb = _lib.HostMailbox.for_device(dev) if COUNT_MAILBOX else None
+            ticket = mb.next_ticket() if mb is not None else 0
+            bin_hist = preprocess(span_cap, inst_cap, mb.ptr if mb is not None else None, ticket)
             have = span_cap if span_cap > 0 else 4 * max(P, 1) + 65536
             if bin_hist is not None and mb is not None:
                 keys, point_list = bin_render(bin_hist, span_cap, inst_cap, inst_cap)
-                seen, ticket = mb[0], mb[2]
-                spins, deadline = 0, None
-                while seen[2] != ticket:
-                    spins += 1
-                    if (spins & 0xfff) == 0:     # ~ every millisecond: look at the clock
-                        now = time.monotonic()
-                        deadline = deadline or now + MAILBOX_TIMEOUT_S
-                        if now > deadline:
-                            break
-                if seen[2] == ticket:
-                    n_inst, n_spans = int(seen[0]), int(seen[1])
-                else:
+                counts = mb.wait(ticket)
+                if counts is None:
                     warnings.warn('diff_gaussian_rasterization: the count mailbox did not answer; using the device counters from now on')
-                    _MAILBOX[dev] = None
-                    n_inst, n_spans = num_rendered.tolist()
+                    _lib.HostMailbox.retire(dev)
+                    counts = num_rendered.tolist()
+                n_inst, n_spans = counts
                 done = n_inst <= inst_cap and n_spans <= have
                 if done:
                     point_list = point_list[:max(n_inst, 1)]

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import warnings
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -115,6 +116,7 @@ class InstantNGPRenderer:
 
     RAY_CHUNK = 1 << 16        # rays per pass of the ray-list inference path
     T_THRESHOLD = 1e-4         # transmittance below which a ray is finished (Renderer.py:79,127)
+    COUNT_MAILBOX = True       # fused image path: the row count reaches the host through a mapped host mailbox (False: device-to-host copy)
 
     def __init__(self, model: InstantNGPModel, MAX_SAMPLES: int = 1024, EXPONENTIAL_STEPS: bool = False, DENSITY_THRESHOLD: float = 0.01) -> None:
         self.model = model
@@ -277,14 +279,18 @@ class InstantNGPRenderer:
             store[key] = ws
         return ws
 
-    def _fused_count(self, fc: dict, ws: dict, tile_begin: int, nt: int) -> None:
+    def _fused_count(self, fc: dict, ws: dict, tile_begin: int, nt: int, mailbox=None) -> int:
+        """the count pass; with a `mailbox` (_lib.HostMailbox) the totals also go straight to host memory: returns the ticket to wait for"""
         m, lib, cam = self.model, _lib.load(), fc['camera']
         vp = ctypes.c_void_p
+        ticket = mailbox.next_ticket() if mailbox is not None else 0
         _lib.check(lib.nrc_ngp_render_count(
             cam.width, cam.height, ctypes.cast(fc['intr'], vp), ctypes.cast(fc['mat'], vp), ctypes.cast(fc['center'], vp), ctypes.cast(fc['half'], vp),
             float(cam.near_plane), float(cam.far_plane), int(tile_begin), nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(fc['esf']),
             m.RESOLUTION, self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']),
-            _lib.ptr(ws['tile_off']), _lib.ptr(ws['counter']), _lib.ptr(ws.get('ts_prov')), _lib.stream_of(ws['ray_od'])), 'ngp_render_count')
+            _lib.ptr(ws['tile_off']), _lib.ptr(ws['counter']), _lib.ptr(ws.get('ts_prov')), mailbox.ptr if mailbox is not None else None, ticket,
+            _lib.stream_of(ws['ray_od'])), 'ngp_render_count')
+        return ticket
 
     def _fused_size_rows(self, ws: dict, rows: int, nt: int) -> None:
         if rows > ws['cap']:
@@ -425,7 +431,11 @@ class InstantNGPRenderer:
             out = {'rgb': ws['rgb'], 'alpha': ws['alpha'], 'depth': ws['depth']}
         st = _lib.stream_of(ws['ray_od'])
         esf = fc['esf']
-        self._fused_count(fc, ws, tile_begin, nt)
+        # the frame's one host read: the row count that sizes the sample buffers.  Through a host mailbox (the closing scan of the count pass stores
+        # the totals in mapped host memory and this thread polls them) when the runtime offers one -- no device-to-host copy, no stream wait:
+        # 42 -> ~10 us of idle GPU between the count pass and the write pass
+        mailbox = _lib.HostMailbox.for_device(dev) if (row_capacity is None and self.COUNT_MAILBOX) else None
+        ticket = self._fused_count(fc, ws, tile_begin, nt, mailbox)
         if row_capacity is not None:
             cap = int(row_capacity)
             if cap < 1:
@@ -441,7 +451,13 @@ class InstantNGPRenderer:
             res = dict(out)
             res['counter'] = ws['counter']
             return res
-        rows, n_samples = ws['counter'].tolist()   # THE host read of the frame: sizes the sample buffers; the marched total comes with it
+        counts = mailbox.wait(ticket) if mailbox is not None else None
+        if counts is None:
+            if mailbox is not None:
+                warnings.warn('render_image_fused: the count mailbox did not answer; reading the device counter from now on')
+                _lib.HostMailbox.retire(dev)
+            counts = ws['counter'].tolist()
+        rows, n_samples = counts   # THE host read of the frame: sizes the sample buffers; the marched total comes with it
         self._fused_size_rows(ws, rows, nt)
         if early_termination == 'auto':
             pol = ws.setdefault('et_policy', {'prev_rows': 0, 'prev_layered': False, 'skip_frames': 0})
