@@ -851,45 +851,48 @@ __global__ void __launch_bounds__(64) k_item_count(int gx, int gy, const uint32_
         __syncthreads();
     }
 }
-// per tile (y, x): exclusive scan of cnt2[item][x] over the items of row y (in place) and the tile total.  64 tiles x 16 item groups per workgroup.
+// per tile (y, x): exclusive scan of cnt2[item][x] over the items of row y (in place) and the tile total.  32 tiles x 32 item groups per workgroup.
 // Round 4: the loads of a thread's items are requested eight at a time (one at a time, each was a full L2 latency), and the workgroup that
 // finishes LAST runs what used to be two more launches: the scan of the tile totals into `ranges` (k_scan_tiles) and the launch order of the
 // tiles, longest list first (k_tile_order).  Hand-over: the totals are written through (sc1) and drained, one lane per workgroup takes a
 // ticket with a returning agent-scope atomic, the last ticket holder reads the totals with sc1 loads.
 __device__ __forceinline__ void tile_order_of(int n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order, uint32_t* hist, uint32_t* wsum);
+#define IS_XL 32     // tiles (columns) per workgroup
+#define IS_NG 32     // item groups per workgroup: thread (xl, g) scans the g-th 1/32 of the row's items for column x, sixteen loads at a time
+                     // (~250 items per row at 1 M Gaussians: one batch for the sum, one for the prefix)
 __global__ void __launch_bounds__(1024) k_item_scan(int gx, int gy, int item_cap, const uint32_t* __restrict__ nitems, const uint32_t* __restrict__ ioff,
                                                     uint32_t* __restrict__ cnt2, uint32_t* __restrict__ tcount, uint32_t* __restrict__ done_counter,
                                                     uint32_t cap, uint32_t* __restrict__ ranges, uint32_t* __restrict__ order, int64_t* __restrict__ num_rendered,
                                                     int64_t* __restrict__ mailbox, int64_t mailbox_ticket) {
-    __shared__ uint32_t gsum[16][64];
+    __shared__ uint32_t gsum[IS_NG][IS_XL];
     __shared__ uint32_t hist[2048];
     __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
     __shared__ int last_s;
-    const int xl = threadIdx.x & 63, g = threadIdx.x >> 6, y = blockIdx.y, x = blockIdx.x * 64 + xl;
+    const int xl = threadIdx.x & (IS_XL - 1), g = threadIdx.x / IS_XL, y = blockIdx.y, x = blockIdx.x * IS_XL + xl;
     const int i0 = min((int)ioff[y], item_cap), ni = min((int)nitems[y], item_cap - i0);
-    const int per = (ni + 15) / 16, a = min(ni, g * per), b = min(ni, a + per);
+    const int per = (ni + IS_NG - 1) / IS_NG, a = min(ni, g * per), b = min(ni, a + per);
+    enum { DEPTH = 16 };
     uint32_t s = 0;
     if (x < gx)
-        for (int i = a; i < b; i += 8) {
-            uint32_t v[8];
+        for (int i = a; i < b; i += DEPTH) {
+            uint32_t v[DEPTH];
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = i + k < b ? cnt2[(size_t)(i0 + i + k) * gx + x] : 0u;
+            for (int k = 0; k < DEPTH; k++) v[k] = i + k < b ? cnt2[(size_t)(i0 + i + k) * gx + x] : 0u;
 #pragma unroll
-            for (int k = 0; k < 8; k++) s += v[k];
+            for (int k = 0; k < DEPTH; k++) s += v[k];
         }
     gsum[g][xl] = s;
     __syncthreads();
     uint32_t run = 0, tot = 0;
 #pragma unroll
-    for (int q = 0; q < 16; q++) { const uint32_t v = gsum[q][xl]; tot += v; if (q < g) run += v; }
+    for (int q = 0; q < IS_NG; q++) { const uint32_t v = gsum[q][xl]; tot += v; if (q < g) run += v; }
     if (x < gx) {
-        for (int i = a; i < b; i += 8) {
-            uint32_t v[8];
+        for (int i = a; i < b; i += DEPTH) {
+            uint32_t v[DEPTH];
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = i + k < b ? cnt2[(size_t)(i0 + i + k) * gx + x] : 0u;
+            for (int k = 0; k < DEPTH; k++) v[k] = i + k < b ? cnt2[(size_t)(i0 + i + k) * gx + x] : 0u;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < DEPTH; k++) {
                 if (i + k < b) cnt2[(size_t)(i0 + i + k) * gx + x] = run;
                 run += v[k];
             }
@@ -902,40 +905,50 @@ __global__ void __launch_bounds__(1024) k_item_scan(int gx, int gy, int item_cap
     if (threadIdx.x == 0) {
         const uint32_t ticket = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_s = ticket == gridDim.x * gridDim.y - 1u;
-        carry_s = 0u;
     }
     __syncthreads();
     if (!last_s) return;
+    // thread t owns the contiguous tiles [t c, (t + 1) c), c = ceil(n / 1024): all of its totals are requested at once and ONE block scan over the
+    // chunk sums follows (a scan per 1024 tiles, each behind its own sc1 round trip, was 12 of this launch's 20 us at 4 346 tiles)
     const int n = gx * gy;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < n ? __hip_atomic_load(&tcount[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        uint32_t incl = v;
+    const int chunk = (n + 1023) / 1024, t0 = (int)threadIdx.x * chunk, t1 = min(n, t0 + chunk);
+    uint32_t mine = 0, first[16];   // the thread's first 16 totals stay in registers (all of them up to 16 384 tiles)
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t off = carry_s;
-        for (int w = 0; w < wave; w++) off += wave_tot[w];
-        if (i < n) { ranges[2 * i] = min(off + incl - v, cap); ranges[2 * i + 1] = min(off + incl, cap); }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = off + incl;
-        __syncthreads();
+    for (int k = 0; k < 16; k++) first[k] = t0 + k < t1 ? __hip_atomic_load(&tcount[t0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) mine += first[k];
+    for (int i = t0 + 16; i < t1; i++) mine += __hip_atomic_load(&tcount[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
     }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t trun = incl - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const uint32_t t = wave_tot[w]; total += t; if (w < wave) trun += t; }
     if (threadIdx.x == 0) {
-        *num_rendered = (int64_t)carry_s;
+        *num_rendered = (int64_t)total;
         if (mailbox) {
             // the two counts of the frame straight into host memory (nrc_host_mailbox_alloc: pinned, mapped, coherent), the ticket LAST: the host polls
             // the ticket and then sizes / checks the lists without an event, a copy or a stream wait (posted writes of one agent arrive in order)
-            __hip_atomic_store(mailbox, (int64_t)carry_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mailbox, (int64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(mailbox + 1, num_rendered[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // spans: written by k_span_sweep, two launches ago
             __hip_atomic_store(mailbox + 2, mailbox_ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (t0 + k < t1) { ranges[2 * (t0 + k)] = min(trun, cap); ranges[2 * (t0 + k) + 1] = min(trun + first[k], cap); trun += first[k]; }
+    for (int i = t0 + 16; i < t1; i++) {
+        const uint32_t v = __hip_atomic_load(&tcount[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ranges[2 * i] = min(trun, cap); ranges[2 * i + 1] = min(trun + v, cap);
+        trun += v;
+    }
+    __syncthreads();
     tile_order_of(n, ranges, order, hist, wave_tot);
 }
 // level 2, scatter: ids of the item's spans appended to the tiles they cover; tile (y, x) of this item starts at ranges[tile].first + cnt2[item][x]
@@ -1997,7 +2010,7 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                                w.spans, w.cnt2);
             NRC_STAGE(s, "k_item_count");
             // per-(item, tile) cursors, tile totals; its last workgroup: ranges, instance count and the launch order of the tiles (into tile_fill)
-            hipLaunchKernelGGL(k_item_scan, dim3((unsigned)nrc_cdiv(cam.gx, 64), cam.gy), dim3(1024), 0, s, cam.gx, cam.gy, w.item_cap, w.nitems, w.ioff, w.cnt2, w.tcount,
+            hipLaunchKernelGGL(k_item_scan, dim3((unsigned)nrc_cdiv(cam.gx, IS_XL), cam.gy), dim3(1024), 0, s, cam.gx, cam.gy, w.item_cap, w.nitems, w.ioff, w.cnt2, w.tcount,
                                w.hdr + RS_HDR_TICKET + 5, list_cap, ranges, tile_fill, num_rendered, count_mailbox, mailbox_ticket);
             NRC_STAGE(s, "k_item_scan");
             if (forked && hipStreamWaitEvent(s, side->join, 0) != hipSuccess) (void)hipStreamSynchronize(side->stream);   // the colours are in place for whatever the caller enqueues next
