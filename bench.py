@@ -257,17 +257,21 @@ def time_dominant_kernel(renderer, cam, pose_list, reps=2):
             feat = torch.empty(CHUNK_ROWS * 64 * 64 + 256, dtype=torch.uint8, device=dev)
             sh_ws = torch.empty(nt * 2048, dtype=torch.uint8, device=dev)
 
+        arena = renderer.ARENA_IN_PLACE and ws.get('ts_prov') is not None   # the form the frame ran its kernels in (samples read from the count pass's arena)
+        ts_buf = ws['ts_prov'] if arena else ws['ts']
+        a_off, a_rows = (_lib.ptr(ws['tile_off']), renderer.MAX_SAMPLES) if arena else (None, 0)
+
         def encode(r0, rows):
             _lib.check(lib.nrc_ngp_encode_samples(
-                vp(ws['ts'].data_ptr() + r0 * 256), vp(ws['row_tile'].data_ptr() + r0 * 4), _lib.ptr(ws['ray_od']), rows, ctypes.cast(mn, vp),
+                _lib.ptr(ts_buf), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), r0, rows, ctypes.cast(mn, vp),
                 ctypes.cast(sz, vp), _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'],
-                g['base_resolution'], float(g['per_level_scale']), _lib.ptr(feat), st), 'ngp_encode_samples')
+                g['base_resolution'], float(g['per_level_scale']), _lib.ptr(feat), a_off, a_rows, st), 'ngp_encode_samples')
 
         def mlp(r0, rows, n_ray_tiles=0):  # 0: the per-ray SH coefficients are in sh_ws already (once per image, like the product path)
             _lib.check(lib.nrc_ngp_mlp_samples(
-                vp(ws['ts'].data_ptr() + r0 * 256), vp(ws['row_tile'].data_ptr() + r0 * 4), _lib.ptr(ws['ray_od']), rows, n_ray_tiles, _lib.ptr(feat),
+                _lib.ptr(ts_buf), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), r0, rows, n_ray_tiles, _lib.ptr(feat),
                 _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
-                vp(ws['packed'].data_ptr() + r0 * 512), _lib.ptr(sh_ws), st), 'ngp_mlp_samples')
+                _lib.ptr(ws['packed']), _lib.ptr(sh_ws), a_off, a_rows, st), 'ngp_mlp_samples')
 
         def timed(fn):  # every chunk of the image, `reps` times, back to back between ONE pair of events on the launch stream
             fn(*chunks[0])
@@ -284,7 +288,7 @@ def time_dominant_kernel(renderer, cam, pose_list, reps=2):
         mlp(*chunks[0], n_ray_tiles=nt)  # SH of this pose's rays; the timed launches below are the MLP kernel alone, as in the product's chunk loop
         mlp_ms.append(timed(mlp))
         launches += len(chunks)
-        live_total += int((ws['ts'][:n_rows * 64] >= 0).sum().item())
+        live_total += int(out['n_samples'])   # slots that hold a sample (the count pass's total; the rest of the rows' slots are holes)
         slots_total += n_rows * 64
     mean = lambda v: sum(v) / len(v)
     return {'enc_ms': mean(enc_ms), 'enc_ms_min': min(enc_ms), 'enc_ms_max': max(enc_ms), 'mlp_ms': mean(mlp_ms), 'mlp_ms_min': min(mlp_ms),

@@ -30,7 +30,8 @@ enum {
  * newer bindings -- or the reverse -- would pass a stream where a pointer is expected, or under-allocate a workspace).
  * History: 1 = rounds 1-2; 2 = round 3 (nrc_gs_backward gained grad_records, nrc_ngp_render_count writes 2 * n_tiles ints into tile_rows,
  * counter[1] = total samples, save buffers padded to nrc_nwie_save_rows); 3 = round 4 (see the notes at the changed entry points);
- * 4 = round 4, later: nrc_gs_preprocess and nrc_ngp_render_count gained count_mailbox / mailbox_ticket, nrc_host_mailbox_alloc / _free are new. */
+ * 4 = round 4, later: nrc_gs_preprocess and nrc_ngp_render_count gained count_mailbox / mailbox_ticket, nrc_host_mailbox_alloc / _free are new;
+ * nrc_ngp_query_samples gained arena_tile_off / arena_rows, nrc_ngp_composite_image arena_rows, nrc_ngp_render_write accepts ts = NULL. */
 #define NRC_ABI_VERSION 4
 /* library identification; also used by the loader's symbol check */
 int nrc_abi_version(void);
@@ -386,7 +387,14 @@ int64_t nrc_ngp_query_samples_ws_bytes(int64_t n_rows, int64_t n_ray_tiles);
 int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
                           const float* xyz_min3, const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
-                          float per_level_scale, void* packed_f16, void* workspace, const int32_t* n_rows_dev, nrc_stream_t stream);
+                          float per_level_scale, void* packed_f16, void* workspace, const int32_t* n_rows_dev, const int32_t* arena_tile_off,
+                          int32_t arena_rows, nrc_stream_t stream);
+/* ABI 4, the arena queried in place (the default of the single-pass frame): with ts_provisional the count pass has every sample's t already in
+ * 256-byte rows per tile -- sample k of local tile lt in arena row lt * max_samples + k, holes (-1) up to the tile's longest ray included -- and the
+ * compact `ts` rows differ from it only by WHERE a row lives.  nrc_ngp_render_write(ts = NULL) then writes row_tile only (the 2 x 320 MB copy of an
+ * 800x800 frame is skipped: 150 -> ~10 us), nrc_ngp_query_samples takes ts = ts_provisional, arena_tile_off = tile_off, arena_rows = max_samples and
+ * reads slot i of row r = i >> 6 at arena row row_tile[r] * arena_rows + (r - tile_off[row_tile[r]]), nrc_ngp_composite_image takes the same
+ * pointer and arena_rows (0 = compact rows).  `packed` stays indexed by compact rows.  Same values, same pictures. */
 /* Layer-major variant of steps 2-4: rows ordered by sample index k first (all tiles' k = 0, then k = 1, ...), so that consecutive
  * chunks of rows are depth slabs of the image; after every slab the finished tiles (all rays saturated below T_threshold or out of
  * samples) write their pixels and their remaining rows are skipped -- the early termination of the reference's alive-ray loop
@@ -407,21 +415,26 @@ int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float*
                           int32_t cascades, float exp_step_factor, int32_t grid_size, int32_t max_samples, float T_threshold,
                           const float* bg3_host, void* packed_f16, float* rgb, float* alpha, float* depth, int32_t* skipped_rows,
                           void* workspace, nrc_stream_t stream);
-/* stage 3a on its own (the dominant kernel of the pipeline; used by bench.py's roofline leg): hash-grid features of the first
- * n_rows (<= 131072) rows, fragment-major: the 16-byte vector [((j>>5)*4 + ((g + (j>>5))&3))*32 + (j&31)] = levels 4g..4g+3 (fp16x2) of slot j */
-int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, const float* xyz_min3,
+/* stage 3a on its own (the dominant kernel of the pipeline; used by bench.py's roofline leg): hash-grid features of the n_rows (<= 131072) rows
+ * first_row .. first_row + n_rows - 1 of the frame -- ts / row_tile are the FRAME's arrays, not offset ones (ABI 4) --, fragment-major: the 16-byte
+ * vector [((j>>5)*4 + ((g + (j>>5))&3))*32 + (j&31)] = levels 4g..4g+3 (fp16x2) of slot j of the chunk.  arena_tile_off / arena_rows: as for
+ * nrc_ngp_query_samples (NULL / 0: compact rows), so that the kernel is timed in the form the frame runs it */
+int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t first_row, int64_t n_rows, const float* xyz_min3,
                            const float* xyz_size3, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
-                           int32_t base_resolution, float per_level_scale, void* features_f16, nrc_stream_t stream);
-/* stage 3b on its own (the MFMA kernel; bench.py's second roofline object): features as written by nrc_ngp_encode_samples for the
- * first n_rows (<= 131072) rows -> packed (h0, r, g, b) fp16; ray_sh_workspace: n_ray_tiles * 2048 bytes, filled by this call with the
- * rays' SH coefficients; n_ray_tiles = 0: it holds them already (they belong to the image, a caller looping over chunks fills it once) */
-int nrc_ngp_mlp_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
+                           int32_t base_resolution, float per_level_scale, void* features_f16, const int32_t* arena_tile_off,
+                           int32_t arena_rows, nrc_stream_t stream);
+/* stage 3b on its own (the MFMA kernel; bench.py's second roofline object): features as written by nrc_ngp_encode_samples for the same
+ * n_rows (<= 131072) rows -> packed (h0, r, g, b) fp16 of the FRAME (indexed by the frame's slots); ray_sh_workspace: n_ray_tiles * 2048 bytes,
+ * filled by this call with the rays' SH coefficients; n_ray_tiles = 0: it holds them already (they belong to the image, a caller looping over
+ * chunks fills it once) */
+int nrc_ngp_mlp_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t first_row, int64_t n_rows, int64_t n_ray_tiles,
                         const void* features_f16, const void* density_weights_f16, const void* color_weights_f16,
-                        void* packed_f16, void* ray_sh_workspace, nrc_stream_t stream);
+                        void* packed_f16, void* ray_sh_workspace, const int32_t* arena_tile_off, int32_t arena_rows, nrc_stream_t stream);
 int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32_t* ray_cnt, const int32_t* tile_off,
                             int32_t width, int32_t height, int64_t tile_begin, int64_t n_tiles, int32_t cascades,
                             float exp_step_factor, int32_t grid_size, int32_t max_samples, float T_threshold,
-                            const float* bg3, float* rgb, float* alpha, float* depth, int64_t row_capacity, nrc_stream_t stream);
+                            const float* bg3, float* rgb, float* alpha, float* depth, int64_t row_capacity, int32_t arena_rows,
+                            nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 7 -- SSIM map and its gradient (3DGS loss): replaces fused_ssim as imported at

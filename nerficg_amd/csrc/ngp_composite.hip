@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) k_composite_image(const __half* __restric
                                                          int width, int height, int tiles_x, int64_t tile_begin, int64_t n_tiles,
                                                          float esf, float dt_min, float dt_max, float thr, float bg_r, float bg_g,
                                                          float bg_b, float* __restrict__ rgb, float* __restrict__ alpha_out,
-                                                         float* __restrict__ depth_out, int64_t row_cap) {
+                                                         float* __restrict__ depth_out, int64_t row_cap, int arena_rows) {
     const int lane = threadIdx.x & 63;
     const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (lt >= n_tiles) return;
@@ -296,7 +296,8 @@ __global__ void __launch_bounds__(256) k_composite_image(const __half* __restric
             const bool in = alive && k + u < N;
             const int64_t s = (row0 + (in ? k + u : 0)) * 64 + lane;
             raw[u] = in ? *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(packed) + 4 * s) : make_uint2(0u, 0u);
-            tv[u] = in ? ts[s] : 0.f;
+            // arena_rows > 0: `ts` is the count pass's arena, sample k of this tile in its row lt * arena_rows + k
+            tv[u] = in ? ts[arena_rows > 0 ? ((lt * arena_rows + k + u) << 6) + lane : s] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < CU; u++) {
@@ -649,9 +650,9 @@ int nrc_distortion_loss_bw(const float* dL_dloss, const float* ws_incl, const fl
 int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32_t* ray_cnt, const int32_t* tile_off, int32_t width,
                             int32_t height, int64_t tile_begin, int64_t n_tiles, int32_t cascades, float exp_step_factor,
                             int32_t grid_size, int32_t max_samples, float T_threshold, const float* bg3_host, float* rgb, float* alpha,
-                            float* depth, int64_t row_capacity, nrc_stream_t stream) {
+                            float* depth, int64_t row_capacity, int32_t arena_rows, nrc_stream_t stream) {
     NRC_ENTER();
-    if (n_tiles < 0 || tile_begin < 0 || width < 1 || height < 1 || !bg3_host || grid_size < 1 || max_samples < 1 || row_capacity < 0) return NRC_ERR_INVALID;
+    if (n_tiles < 0 || tile_begin < 0 || width < 1 || height < 1 || !bg3_host || grid_size < 1 || max_samples < 1 || row_capacity < 0 || arena_rows < 0) return NRC_ERR_INVALID;
     if (n_tiles == 0) return NRC_OK;
     if (!ray_cnt || !tile_off || !rgb || !alpha || !depth) return NRC_ERR_INVALID;
     const int tiles_x = (width + NRC_TILE_W - 1) / NRC_TILE_W;
@@ -659,7 +660,7 @@ int nrc_ngp_composite_image(const void* packed_f16, const float* ts, const int32
     const float dt_min = 1.73205080757f / max_samples, dt_max = 1.73205080757f * 2 * (float)cascades / grid_size;
     hipLaunchKernelGGL(k_composite_image, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, (const __half*)packed_f16, ts, ray_cnt,
                        tile_off, (int)width, (int)height, tiles_x, tile_begin, n_tiles, exp_step_factor, dt_min, dt_max, T_threshold,
-                       bg3_host[0], bg3_host[1], bg3_host[2], rgb, alpha, depth, row_capacity > 0 ? row_capacity : INT64_MAX);
+                       bg3_host[0], bg3_host[1], bg3_host[2], rgb, alpha, depth, row_capacity > 0 ? row_capacity : INT64_MAX, (int)arena_rows);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

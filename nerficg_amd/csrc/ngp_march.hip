@@ -766,6 +766,10 @@ __global__ void __launch_bounds__(256) k_render_count(RenderCam cam, MarchCfg c,
     int m = n;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    if (ts_prov) {   // holes of the tile's rows (rays with fewer samples than its longest): the arena can then be queried in place (nrc_ngp_query_samples)
+        float* park = ts_prov + (size_t)lt * c.max_samples * 64 + lane;
+        for (int k = n; k < m; k++) park[(size_t)k * 64] = -1.0f;
+    }
     const int tile_samples = nrc_group_sum_i<64>(n);
     if (lane == 0) { tile_rows[lt] = m; tile_rows[n_tiles + lt] = tile_samples; }   // second half of the array: samples per tile (for the total)
 }
@@ -864,6 +868,7 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
     const int N = ray_cnt[q];
     auto row_at = [&](int k) -> int64_t { return row_of ? (int64_t)row_of[row0 + k] : row0 + k; };
     for (int k = lane; k < rows; k += 64) row_tile[row_at(k)] = (int32_t)lt;
+    if (!ts) return;   // the arena is queried in place: only the rows' tiles are wanted
     if (ts_prov) {  // the count pass parked the samples: a coalesced copy (256-byte rows) instead of the second march
         const float* park = ts_prov + (size_t)lt * c.max_samples * 64 + lane;
         for (int k0 = 0; k0 < rows; k0 += 8) {  // eight rows in flight: the copy is latency-bound otherwise (327 us against 300 for the march)
@@ -1176,7 +1181,8 @@ int nrc_ngp_render_write(int64_t n_tiles, const uint8_t* bitfield, int32_t casca
     NRC_ENTER();
     if (n_tiles < 0 || cascades < 1 || grid_size < 1 || max_samples < 1 || row_capacity < 0) return NRC_ERR_INVALID;
     if (n_tiles == 0) return NRC_OK;
-    if (!bitfield || !ray_od || !ray_t || !ray_cnt || !tile_off || !ts || !row_tile) return NRC_ERR_INVALID;
+    if (!bitfield || !ray_od || !ray_t || !ray_cnt || !tile_off || !row_tile) return NRC_ERR_INVALID;
+    if (!ts && !ts_provisional) return NRC_ERR_INVALID;   // ts == NULL: the parked samples stay where they are (arena queried in place), row_tile only
     const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, (float)cascades);
     hipLaunchKernelGGL(k_render_write, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, c, n_tiles, ray_od, ray_t, ray_cnt,
                        tile_off, ts, row_tile, (const int32_t*)nullptr, ts_provisional, row_capacity > 0 ? row_capacity : INT64_MAX);

@@ -205,8 +205,16 @@ struct QueryIn {
     const uint8_t* tile_alive;                                      // SRC_TILED, optional: rows of finished tiles are treated as holes
     const int32_t* n_rows_dev;                                      // SRC_TILED, optional: the number of rows the march produced, on the DEVICE -- a launch sized
                                                                     // for a row CAPACITY processes only the rows that exist (fixed-capacity image pipeline)
+    const int32_t* tile_off; int32_t arena_rows;                    // SRC_TILED, optional: `ts` is the count pass's ARENA (arena_rows rows of 64 per ray tile,
+                                                                    // sample k of tile rt in arena row rt * arena_rows + k) and slot i's t is read from there --
+                                                                    // row i >> 6 is sample (i >> 6) - tile_off[rt] of its tile; the copy into compact rows is skipped
     float mn[3], sz[3];                                             // xyz_min, xyz_size of the model box (Renderer.py:50)
 };
+// index of slot i (row i >> 6 of ray tile rt) in `ts`: the slot itself, or its place in the count pass's arena
+__device__ __forceinline__ int64_t ts_slot(const QueryIn& in, int64_t i, int32_t rt) {
+    if (!in.tile_off) return i;
+    return (((int64_t)rt * in.arena_rows + ((i >> 6) - (int64_t)in.tile_off[rt])) << 6) + (i & 63);
+}
 // returns false for a hole of the tiled layout (no sample in this slot)
 template <int SRC, bool UNIFORM_ROW = true>
 __device__ __forceinline__ bool fetch_pos(const QueryIn& in, int64_t i, float& px, float& py, float& pz) {
@@ -219,10 +227,10 @@ __device__ __forceinline__ bool fetch_pos(const QueryIn& in, int64_t i, float& p
         }
         return true;
     } else {
-        const float t = in.ts[i];
         // one wave = one row of the tiled layout: the row's ray tile is wave-uniform and comes through the scalar cache (no vector round trip in
         // front of the six ray loads that depend on it)
         const int32_t rt = UNIFORM_ROW ? in.row_tile[__builtin_amdgcn_readfirstlane((int)(i >> 6))] : in.row_tile[i >> 6];
+        const float t = in.ts[ts_slot(in, i, rt)];
         if (t < 0.f || (in.tile_alive && !in.tile_alive[rt])) { px = py = pz = 0.f; return false; }
         const float* od = in.ray_od + (int64_t)rt * 384 + (i & 63);  // per-tile SoA [6][64]
         // same roundings as the op-by-op path: xyz = o + t*d (mul, add: raymarching.cu:368), then (xyz - min) / size in torch
@@ -547,7 +555,7 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
             __builtin_amdgcn_global_load_lds((gptr_t)(fp + ((2 + hh + rot) & 3) * 32), (lptr_t)&slot[1][0], 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(ray_sh + ((int64_t)rt * 2 + hh) * 64 + (i & 63)), (lptr_t)&slot[2][0], 16, 0, 0);
             ti.alive = 1u;
-            ti.t = in.ts[i];
+            ti.t = in.ts[ts_slot(in, i, rt)];
             if (in.tile_alive) ti.alive = in.tile_alive[rt];
             return;
         }
@@ -556,7 +564,7 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
         ti.b1 = fp[((2 + hh + rot) & 3) * 32];
         ti.alive = 1u;
         if constexpr (SRC == SRC_TILED) {
-            ti.t = in.ts[i];
+            ti.t = in.ts[ts_slot(in, i, rt)];   // (rt is wave-uniform here: tile_off[rt] is one scalar load)
             if (in.tile_alive) ti.alive = in.tile_alive[rt];   // independent of the other loads: selected at use, not waited for here
             ti.sh = ray_sh[((int64_t)rt * 2 + hh) * 64 + (i & 63)];
         } else {
@@ -1169,12 +1177,14 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
     return NRC_OK;
 }
 
-int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, const float* xyz_min3,
+int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t first_row, int64_t n_rows, const float* xyz_min3,
                            const float* xyz_size3, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
-                           int32_t base_resolution, float per_level_scale, void* features_f16, nrc_stream_t stream) {
+                           int32_t base_resolution, float per_level_scale, void* features_f16, const int32_t* arena_tile_off, int32_t arena_rows,
+                           nrc_stream_t stream) {
     NRC_ENTER();
     const int64_t n = n_rows * 64;
-    if (n_rows < 0 || n > NRC_QUERY_CHUNK || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
+    if (n_rows < 0 || first_row < 0 || n > NRC_QUERY_CHUNK || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
+    if ((arena_tile_off != nullptr) != (arena_rows > 0) || arena_rows < 0) return NRC_ERR_INVALID;
     if (n_levels != 16) return NRC_ERR_UNSUPPORTED;
     if (n == 0) return NRC_OK;
     if (!ts || !row_tile || !ray_od || !features_f16) return NRC_ERR_INVALID;
@@ -1182,27 +1192,28 @@ int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float
     const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
     if (rc != NRC_OK) return rc;
     QueryIn in = {};
-    in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od;
+    in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od; in.tile_off = arena_tile_off; in.arena_rows = arena_rows;
     for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
-    launch_encode<SRC_TILED>(in, 0, n, table_f16, g, (uint4*)features_f16, (hipStream_t)stream);
+    launch_encode<SRC_TILED>(in, first_row * 64, n, table_f16, g, (uint4*)features_f16, (hipStream_t)stream);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
 
-int nrc_ngp_mlp_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
+int nrc_ngp_mlp_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t first_row, int64_t n_rows, int64_t n_ray_tiles,
                         const void* features_f16, const void* density_weights_f16, const void* color_weights_f16, void* packed_f16,
-                        void* ray_sh_workspace, nrc_stream_t stream) {
+                        void* ray_sh_workspace, const int32_t* arena_tile_off, int32_t arena_rows, nrc_stream_t stream) {
     NRC_ENTER();
     const int64_t n = n_rows * 64;
-    if (n_rows < 0 || n > NRC_QUERY_CHUNK || n_ray_tiles < 0 || !density_weights_f16 || !color_weights_f16) return NRC_ERR_INVALID;
+    if (n_rows < 0 || first_row < 0 || n > NRC_QUERY_CHUNK || n_ray_tiles < 0 || !density_weights_f16 || !color_weights_f16) return NRC_ERR_INVALID;
+    if ((arena_tile_off != nullptr) != (arena_rows > 0) || arena_rows < 0) return NRC_ERR_INVALID;
     if (n == 0) return NRC_OK;
     if (!ts || !row_tile || !ray_od || !features_f16 || !packed_f16 || !ray_sh_workspace) return NRC_ERR_INVALID;
     QueryIn in = {};
-    in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od;
+    in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od; in.tile_off = arena_tile_off; in.arena_rows = arena_rows;
     hipStream_t s = (hipStream_t)stream;
     if (n_ray_tiles > 0)  // 0: the workspace already holds the rays' SH coefficients (they are per image, not per chunk)
         hipLaunchKernelGGL(k_ray_sh, dim3((unsigned)nrc_cdiv(n_ray_tiles * 64, 256)), dim3(256), 0, s, ray_od, n_ray_tiles, (h8*)ray_sh_workspace);
-    launch_mlp<SRC_TILED>(in, 0, n, features_f16, ray_sh_workspace, density_weights_f16, color_weights_f16, nullptr, nullptr, packed_f16, s);
+    launch_mlp<SRC_TILED>(in, first_row * 64, n, features_f16, ray_sh_workspace, density_weights_f16, color_weights_f16, nullptr, nullptr, packed_f16, s);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
@@ -1210,9 +1221,11 @@ int nrc_ngp_mlp_samples(const float* ts, const int32_t* row_tile, const float* r
 int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles, const float* xyz_min3,
                           const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
-                          float per_level_scale, void* packed_f16, void* workspace, const int32_t* n_rows_dev, nrc_stream_t stream) {
+                          float per_level_scale, void* packed_f16, void* workspace, const int32_t* n_rows_dev, const int32_t* arena_tile_off,
+                          int32_t arena_rows, nrc_stream_t stream) {
     NRC_ENTER();
     const int64_t M = n_rows * 64;
+    if ((arena_tile_off != nullptr) != (arena_rows > 0) || arena_rows < 0) return NRC_ERR_INVALID;
     if (n_rows < 0 || n_ray_tiles < 0 || !density_weights_f16 || !color_weights_f16 || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
     if (n_levels != 16) return NRC_ERR_UNSUPPORTED;
     if (M == 0) return NRC_OK;
@@ -1222,6 +1235,7 @@ int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float*
     if (rc != NRC_OK) return rc;
     QueryIn in = {};
     in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od; in.n_rows_dev = n_rows_dev;
+    in.tile_off = arena_tile_off; in.arena_rows = arena_rows;
     for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
     run_query<SRC_TILED>(in, M, n_ray_tiles, density_weights_f16, color_weights_f16, table_f16, g, nullptr, nullptr, packed_f16, workspace, (hipStream_t)stream);
     NRC_LAUNCH_CHECK();

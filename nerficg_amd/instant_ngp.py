@@ -117,6 +117,7 @@ class InstantNGPRenderer:
     RAY_CHUNK = 1 << 16        # rays per pass of the ray-list inference path
     T_THRESHOLD = 1e-4         # transmittance below which a ray is finished (Renderer.py:79,127)
     COUNT_MAILBOX = True       # fused image path: the row count reaches the host through a mapped host mailbox (False: device-to-host copy)
+    ARENA_IN_PLACE = True      # fused image path, single pass: the query / compositing kernels read the samples from the count pass's arena (False: copied to compact rows first)
 
     def __init__(self, model: InstantNGPModel, MAX_SAMPLES: int = 1024, EXPONENTIAL_STEPS: bool = False, DENSITY_THRESHOLD: float = 0.01) -> None:
         self.model = model
@@ -303,9 +304,10 @@ class InstantNGPRenderer:
                       row_of=torch.empty(cap, dtype=torch.int32, device=dev),
                       layer_off=torch.empty(self.MAX_SAMPLES + 2, dtype=torch.int32, device=dev), cap=cap)
 
-    def _fused_write_query(self, fc: dict, ws: dict, rows: int, nt: int, fixed: bool = False) -> None:
+    def _fused_write_query(self, fc: dict, ws: dict, rows: int, nt: int, fixed: bool = False, arena: bool = False) -> None:
         """single pass: the parked samples into their final rows, then encode + MLPs over all of them.  fixed: `rows` is a CAPACITY -- rows behind it
-        are not written, and the query kernels read the number of rows that exist from the device counter"""
+        are not written, and the query kernels read the number of rows that exist from the device counter.  arena: the parked samples are queried
+        where the count pass left them (include/nerficg_hip.h, "the arena queried in place"): no copy into compact rows"""
         if rows <= 0:
             return
         m, lib = self.model, _lib.load()
@@ -314,20 +316,22 @@ class InstantNGPRenderer:
         g = fc['grid']
         _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(fc['esf']), m.RESOLUTION,
                                             self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']),
-                                            _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws.get('ts_prov')),
+                                            _lib.ptr(ws['tile_off']), None if arena else _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws.get('ts_prov')),
                                             int(rows) if fixed else 0, st), 'ngp_render_write')
         _lib.check(lib.nrc_ngp_query_samples(
-            _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(fc['mn'], vp), ctypes.cast(fc['sz'], vp),
-            _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()), _lib.ptr(m.encoding_xyz._table16()),
-            g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(ws['packed']), _lib.ptr(ws['qws']),
-            _lib.ptr(ws['counter']) if fixed else None, st), 'ngp_query_samples')
+            _lib.ptr(ws['ts_prov'] if arena else ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(fc['mn'], vp),
+            ctypes.cast(fc['sz'], vp), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
+            _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
+            _lib.ptr(ws['packed']), _lib.ptr(ws['qws']), _lib.ptr(ws['counter']) if fixed else None,
+            _lib.ptr(ws['tile_off']) if arena else None, self.MAX_SAMPLES if arena else 0, st), 'ngp_query_samples')
 
-    def _fused_composite(self, fc: dict, ws: dict, out: dict, tile_begin: int, nt: int, row_capacity: int = 0) -> None:
+    def _fused_composite(self, fc: dict, ws: dict, out: dict, tile_begin: int, nt: int, row_capacity: int = 0, arena: bool = False) -> None:
         m, lib, cam = self.model, _lib.load(), fc['camera']
         _lib.check(lib.nrc_ngp_composite_image(
-            _lib.ptr(ws.get('packed')), _lib.ptr(ws.get('ts')), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_off']), cam.width, cam.height,
-            int(tile_begin), nt, m.cascades, float(fc['esf']), m.RESOLUTION, self.MAX_SAMPLES, 1e-4, ctypes.cast(fc['bg'], ctypes.c_void_p),
-            _lib.ptr(out['rgb']), _lib.ptr(out['alpha']), _lib.ptr(out['depth']), int(row_capacity), _lib.stream_of(ws['ray_od'])), 'ngp_composite_image')
+            _lib.ptr(ws.get('packed')), _lib.ptr(ws.get('ts_prov') if arena else ws.get('ts')), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_off']), cam.width,
+            cam.height, int(tile_begin), nt, m.cascades, float(fc['esf']), m.RESOLUTION, self.MAX_SAMPLES, 1e-4, ctypes.cast(fc['bg'], ctypes.c_void_p),
+            _lib.ptr(out['rgb']), _lib.ptr(out['alpha']), _lib.ptr(out['depth']), int(row_capacity), self.MAX_SAMPLES if arena else 0,
+            _lib.stream_of(ws['ray_od'])), 'ngp_composite_image')
 
     @torch.no_grad()
     def render_image_pipelined(self, camera: Camera, c2w: np.ndarray, shards: int = 4, return_stats: bool = False) -> dict[str, torch.Tensor]:
@@ -389,7 +393,7 @@ class InstantNGPRenderer:
                     _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(fc['mn'], vp), ctypes.cast(fc['sz'], vp),
                     _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()), _lib.ptr(m.encoding_xyz._table16()),
                     g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(ws['packed']), _lib.ptr(ws['qws']),
-                    None, _lib.stream_of(ws['ray_od'])), 'ngp_query_samples')
+                    None, None, 0, _lib.stream_of(ws['ray_od'])), 'ngp_query_samples')
             self._fused_composite(fc, ws, out, b, nt)
             if k + 1 < shards:     # the next range's count pass starts now, under the kernels just enqueued; its buffers were last used a frame ago
                 nb, ne = ranges[k + 1]
@@ -488,8 +492,9 @@ class InstantNGPRenderer:
                 _lib.ptr(ws.get('packed')), _lib.ptr(out['rgb']), _lib.ptr(out['alpha']), _lib.ptr(out['depth']), _lib.ptr(ws['skipped']),
                 _lib.ptr(ws['qws']), st), 'ngp_render_layers')
         else:
-            self._fused_write_query(fc, ws, rows, nt)
-            self._fused_composite(fc, ws, out, tile_begin, nt)
+            arena = self.ARENA_IN_PLACE and ws.get('ts_prov') is not None   # the parked samples are queried where they are: no copy into compact rows
+            self._fused_write_query(fc, ws, rows, nt, arena=arena)
+            self._fused_composite(fc, ws, out, tile_begin, nt, arena=arena)
         res = dict(out)
         if return_stats:
             res['n_rows'] = rows
