@@ -384,17 +384,19 @@ int nrc_ngp_render_write(int64_t n_tiles, const uint8_t* density_bitfield, int32
                          const float* ray_t, const int32_t* ray_cnt, const int32_t* tile_off, float* ts, int32_t* row_tile,
                          const float* ts_provisional, int64_t row_capacity, nrc_stream_t stream);
 int64_t nrc_ngp_query_samples_ws_bytes(int64_t n_rows, int64_t n_ray_tiles);
-int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
+int nrc_ngp_query_samples(const float* ts, int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
                           const float* xyz_min3, const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                           float per_level_scale, void* packed_f16, void* workspace, const int32_t* n_rows_dev, const int32_t* arena_tile_off,
                           int32_t arena_rows, nrc_stream_t stream);
 /* ABI 4, the arena queried in place (the default of the single-pass frame): with ts_provisional the count pass has every sample's t already in
  * 256-byte rows per tile -- sample k of local tile lt in arena row lt * max_samples + k, holes (-1) up to the tile's longest ray included -- and the
- * compact `ts` rows differ from it only by WHERE a row lives.  nrc_ngp_render_write(ts = NULL) then writes row_tile only (the 2 x 320 MB copy of an
- * 800x800 frame is skipped: 150 -> ~10 us), nrc_ngp_query_samples takes ts = ts_provisional, arena_tile_off = tile_off, arena_rows = max_samples and
- * reads slot i of row r = i >> 6 at arena row row_tile[r] * arena_rows + (r - tile_off[row_tile[r]]), nrc_ngp_composite_image takes the same
- * pointer and arena_rows (0 = compact rows).  `packed` stays indexed by compact rows.  Same values, same pictures. */
+ * compact `ts` rows differ from it only by WHERE a row lives.  nrc_ngp_render_write is then not needed at all (the 2 x 320 MB copy of an 800x800
+ * frame is skipped: 150 us): nrc_ngp_query_samples takes ts = ts_provisional, arena_tile_off = tile_off, arena_rows = max_samples, FILLS row_tile
+ * (n_rows entries, from tile_off, in the launch that evaluates the rays' SH) and reads slot i of row r = i >> 6 at arena row
+ * row_tile[r] * arena_rows + (r - tile_off[row_tile[r]]); nrc_ngp_composite_image takes the same pointer and arena_rows (0 = compact rows).
+ * (nrc_ngp_render_write(ts = NULL) writes row_tile only, for callers of the single stages.)  `packed` stays indexed by compact rows.  Same values,
+ * same pictures. */
 /* Layer-major variant of steps 2-4: rows ordered by sample index k first (all tiles' k = 0, then k = 1, ...), so that consecutive
  * chunks of rows are depth slabs of the image; after every slab the finished tiles (all rays saturated below T_threshold or out of
  * samples) write their pixels and their remaining rows are skipped -- the early termination of the reference's alive-ray loop

@@ -443,11 +443,19 @@ __global__ void __launch_bounds__(256) k_grid_encode_pairs(QueryIn in, int64_t n
 // SH degree 4 of the ray direction as the colour net's k-step-0 B fragments, once per RAY of the tiled layout:
 //   ray_sh[(tile * 2 + hh) * 64 + lane] = fp16 coefficients 8hh .. 8hh+7 of ray (tile, lane)
 // (a sample's direction is its ray's: evaluating per sample would repeat ~80 VALU instructions 120 times per ray)
-__global__ void __launch_bounds__(256) k_ray_sh(const float* __restrict__ ray_od, int64_t n_ray_tiles, h8* __restrict__ ray_sh) {
+// rows_tile_off / row_tile_out (arena frames): the same launch names the ray tile of every row -- rows tile_off[t] .. tile_off[t + 1] - 1 belong to
+// tile t (what nrc_ngp_render_write does next to its copy; here there is no copy and no second launch)
+__global__ void __launch_bounds__(256) k_ray_sh(const float* __restrict__ ray_od, int64_t n_ray_tiles, h8* __restrict__ ray_sh,
+                                                const int32_t* __restrict__ rows_tile_off = nullptr, int32_t* __restrict__ row_tile_out = nullptr,
+                                                int64_t n_rows = 0) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_ray_tiles * 64) return;
     const int64_t tile = i >> 6;
     const int lane = (int)(i & 63);
+    if (row_tile_out) {
+        const int64_t r1 = min((int64_t)rows_tile_off[tile + 1], n_rows);
+        for (int64_t r = (int64_t)rows_tile_off[tile] + lane; r < r1; r += 64) row_tile_out[r] = (int32_t)tile;
+    }
     const float* od = ray_od + tile * 384 + lane;
     h8 lo, hi;
     sh4_fragments(od[192], od[256], od[320], lo, hi);
@@ -1068,7 +1076,8 @@ static int run_query(const QueryIn& in, int64_t M, int64_t n_ray_tiles, const vo
     uint4* feat = (uint4*)workspace;
     h8* ray_sh = (h8*)((char*)workspace + query_feat_bytes(M));
     if constexpr (SRC == SRC_TILED)
-        hipLaunchKernelGGL(k_ray_sh, dim3((unsigned)nrc_cdiv(n_ray_tiles * 64, 256)), dim3(256), 0, s, in.ray_od, n_ray_tiles, ray_sh);
+        hipLaunchKernelGGL(k_ray_sh, dim3((unsigned)nrc_cdiv(n_ray_tiles * 64, 256)), dim3(256), 0, s, in.ray_od, n_ray_tiles, ray_sh, in.tile_off,
+                           in.tile_off ? const_cast<int32_t*>(in.row_tile) : (int32_t*)nullptr, M / 64);
     for (int64_t base = 0; base < M; base += NRC_QUERY_CHUNK) {
         const int64_t n = (M - base) < NRC_QUERY_CHUNK ? (M - base) : NRC_QUERY_CHUNK;
         if constexpr (SRC == SRC_TILED) {
@@ -1218,7 +1227,7 @@ int nrc_ngp_mlp_samples(const float* ts, const int32_t* row_tile, const float* r
     return NRC_OK;
 }
 
-int nrc_ngp_query_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles, const float* xyz_min3,
+int nrc_ngp_query_samples(const float* ts, int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles, const float* xyz_min3,
                           const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16,
                           const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                           float per_level_scale, void* packed_f16, void* workspace, const int32_t* n_rows_dev, const int32_t* arena_tile_off,

@@ -304,26 +304,31 @@ class InstantNGPRenderer:
                       row_of=torch.empty(cap, dtype=torch.int32, device=dev),
                       layer_off=torch.empty(self.MAX_SAMPLES + 2, dtype=torch.int32, device=dev), cap=cap)
 
-    def _fused_write_query(self, fc: dict, ws: dict, rows: int, nt: int, fixed: bool = False, arena: bool = False) -> None:
+    def _query_args(self, fc: dict, ws: dict, nt: int, fixed: bool, arena: bool) -> list:
+        """argument list of nrc_ngp_query_samples with the row count (index 3) still open: marshalled BEFORE the host waits for that count, so that
+        nothing but the call itself stands between the count's arrival and the launch"""
+        m, vp, g = self.model, ctypes.c_void_p, fc['grid']
+        return [_lib.ptr(ws['ts_prov'] if arena else ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), 0, nt, ctypes.cast(fc['mn'], vp),
+                ctypes.cast(fc['sz'], vp), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
+                _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
+                _lib.ptr(ws['packed']), _lib.ptr(ws['qws']), _lib.ptr(ws['counter']) if fixed else None,
+                _lib.ptr(ws['tile_off']) if arena else None, self.MAX_SAMPLES if arena else 0, _lib.stream_of(ws['ray_od'])]
+
+    def _fused_write_query(self, fc: dict, ws: dict, rows: int, nt: int, fixed: bool = False, arena: bool = False, query_args: list | None = None) -> None:
         """single pass: the parked samples into their final rows, then encode + MLPs over all of them.  fixed: `rows` is a CAPACITY -- rows behind it
         are not written, and the query kernels read the number of rows that exist from the device counter.  arena: the parked samples are queried
-        where the count pass left them (include/nerficg_hip.h, "the arena queried in place"): no copy into compact rows"""
+        where the count pass left them (include/nerficg_hip.h, "the arena queried in place"): no copy into compact rows, no write pass at all"""
         if rows <= 0:
             return
         m, lib = self.model, _lib.load()
-        vp = ctypes.c_void_p
-        st = _lib.stream_of(ws['ray_od'])
-        g = fc['grid']
-        _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(fc['esf']), m.RESOLUTION,
-                                            self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']),
-                                            _lib.ptr(ws['tile_off']), None if arena else _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws.get('ts_prov')),
-                                            int(rows) if fixed else 0, st), 'ngp_render_write')
-        _lib.check(lib.nrc_ngp_query_samples(
-            _lib.ptr(ws['ts_prov'] if arena else ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(fc['mn'], vp),
-            ctypes.cast(fc['sz'], vp), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
-            _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
-            _lib.ptr(ws['packed']), _lib.ptr(ws['qws']), _lib.ptr(ws['counter']) if fixed else None,
-            _lib.ptr(ws['tile_off']) if arena else None, self.MAX_SAMPLES if arena else 0, st), 'ngp_query_samples')
+        if not arena:
+            _lib.check(lib.nrc_ngp_render_write(nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(fc['esf']), m.RESOLUTION,
+                                                self.MAX_SAMPLES, _lib.ptr(ws['ray_od']), _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']),
+                                                _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']), _lib.ptr(ws['row_tile']), _lib.ptr(ws.get('ts_prov')),
+                                                int(rows) if fixed else 0, _lib.stream_of(ws['ray_od'])), 'ngp_render_write')
+        args = query_args if query_args is not None else self._query_args(fc, ws, nt, fixed, arena)
+        args[3] = rows
+        _lib.check(lib.nrc_ngp_query_samples(*args), 'ngp_query_samples')
 
     def _fused_composite(self, fc: dict, ws: dict, out: dict, tile_begin: int, nt: int, row_capacity: int = 0, arena: bool = False) -> None:
         m, lib, cam = self.model, _lib.load(), fc['camera']
@@ -455,6 +460,11 @@ class InstantNGPRenderer:
             res = dict(out)
             res['counter'] = ws['counter']
             return res
+        # what does not depend on the count is prepared before the wait (the sample buffers exist from the previous frame; a frame that needs
+        # more regrows them below and marshals again)
+        arena = self.ARENA_IN_PLACE and ws.get('ts_prov') is not None   # the parked samples are queried where they are: no copy into compact rows
+        ready = self._query_args(fc, ws, nt, False, arena) if ws['cap'] > 0 else None
+        cap_before = ws['cap']
         counts = mailbox.wait(ticket) if mailbox is not None else None
         if counts is None:
             if mailbox is not None:
@@ -492,8 +502,7 @@ class InstantNGPRenderer:
                 _lib.ptr(ws.get('packed')), _lib.ptr(out['rgb']), _lib.ptr(out['alpha']), _lib.ptr(out['depth']), _lib.ptr(ws['skipped']),
                 _lib.ptr(ws['qws']), st), 'ngp_render_layers')
         else:
-            arena = self.ARENA_IN_PLACE and ws.get('ts_prov') is not None   # the parked samples are queried where they are: no copy into compact rows
-            self._fused_write_query(fc, ws, rows, nt, arena=arena)
+            self._fused_write_query(fc, ws, rows, nt, arena=arena, query_args=ready if ws['cap'] == cap_before else None)
             self._fused_composite(fc, ws, out, tile_begin, nt, arena=arena)
         res = dict(out)
         if return_stats:
