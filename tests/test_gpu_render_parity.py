@@ -418,6 +418,35 @@ def test_pipelined_image_equals_the_one_pass_image():
                 assert torch.equal(got[k], ref[k]), (shards, k)
 
 
+@pytest.mark.parametrize('cascades_esf', [(1, 0.0), (3, 1.0 / 256)])
+def test_arena_in_place_and_mailbox_change_nothing(cascades_esf):
+    """The single-pass frame queries the samples where the count pass parked them (ARENA_IN_PLACE: no copy into compact rows, row_tile from the
+    SH launch) and takes its row count from a host mailbox (COUNT_MAILBOX): pictures, row and sample counts equal those of the copied / read-back
+    frame bit for bit -- also on a shard of the image, with several occupancy cascades and exponential steps, and frame after frame (the arena of
+    a frame is overwritten by the next one)."""
+    from nerficg_amd.instant_ngp import InstantNGPRenderer
+    cascades, esf = cascades_esf
+    if cascades > 1:
+        from tests.test_gpu_garden_parity import garden_model
+        model = garden_model()
+        assert model.cascades == cascades
+    else:
+        model = make_model()
+    cam = make_camera(104, 72, bg=(0.1, 0.3, 0.5))
+    a, b = InstantNGPRenderer(model, EXPONENTIAL_STEPS=esf > 0), InstantNGPRenderer(model, EXPONENTIAL_STEPS=esf > 0)
+    b.ARENA_IN_PLACE = False
+    b.COUNT_MAILBOX = False
+    n_tiles = a.n_image_tiles(cam)
+    for k in range(4):
+        pose = scenes.orbit_pose(0.4 + 0.9 * k, 0.15 + 0.1 * k, scenes.LEGO_RADIUS if cascades == 1 else 1.15)
+        for (t0, nt) in ((0, None), (n_tiles // 3, n_tiles // 2)):
+            ra = a.render_image_fused(cam, pose, tile_begin=t0, n_tiles=nt, return_stats=True, early_termination=False)
+            rb = b.render_image_fused(cam, pose, tile_begin=t0, n_tiles=nt, return_stats=True, early_termination=False)
+            assert ra['n_rows'] == rb['n_rows'] and ra['n_samples'] == rb['n_samples'] and ra['n_samples'] > 0
+            for key in ('rgb', 'alpha', 'depth'):
+                assert torch.equal(ra[key], rb[key]), (k, t0, key)
+
+
 def test_fixed_row_capacity_frame_needs_no_host_read_and_can_be_recorded():
     """render_image_fused(row_capacity=N) (round 4): the frame is only ENQUEUED -- sample buffers for N rows, the kernels take the number of rows that exist
     from the device counter -- so it paints the picture of the sized call, reports an overflow through the counter without touching memory it does not
