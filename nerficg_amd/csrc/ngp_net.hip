@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
             __builtin_amdgcn_global_load_lds((gptr_t)(fp + ((2 + hh + rot) & 3) * 32), (lptr_t)&slot[1][0], 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(ray_sh + ((int64_t)rt * 2 + hh) * 64 + (i & 63)), (lptr_t)&slot[2][0], 16, 0, 0);
             ti.alive = 1u;
-            ti.t = in.ts[ts_slot(in, i, rt)];
+            ti.t = 0.f;
             if (in.tile_alive) ti.alive = in.tile_alive[rt];
             return;
         }
@@ -572,7 +572,10 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
         ti.b1 = fp[((2 + hh + rot) & 3) * 32];
         ti.alive = 1u;
         if constexpr (SRC == SRC_TILED) {
-            ti.t = in.ts[ts_slot(in, i, rt)];   // (rt is wave-uniform here: tile_off[rt] is one scalar load)
+            // (no look at the sample's t: a hole of the layout -- 4 % of the slots -- carries the encoder's all-zero features, runs through the
+            // networks like any other slot and its output is never read (the compositor walks a ray's k < ray_cnt rows only); the 4-byte load per
+            // slot and, on arena frames, the scalar load of tile_off in front of it cost more than the holes' arithmetic)
+            ti.t = 0.f;
             if (in.tile_alive) ti.alive = in.tile_alive[rt];   // independent of the other loads: selected at use, not waited for here
             ti.sh = ray_sh[((int64_t)rt * 2 + hh) * 64 + (i & 63)];
         } else {
