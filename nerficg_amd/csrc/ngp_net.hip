@@ -269,7 +269,12 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
         // every eighth workgroup, so that neighbouring bricks (which share table lines) meet in the same L2
         if (hashed_mode & (1 << 28)) {
             const int64_t g8 = (int64_t)gridDim.x >> 3;
+#if defined(NRC_ENC_XCD_RUN)   // experiment build: XCD x takes RUNS of NRC_ENC_XCD_RUN workgroups dealt round-robin over the XCDs instead of one contiguous eighth
+            const int64_t R = NRC_ENC_XCD_RUN, jx = bid >> 3, full = (g8 / R) * R;
+            if (bid < 8 * full) bid = ((jx / R) * 8 + (bid & 7)) * R + jx % R;
+#else
             if (bid < 8 * g8) bid = (bid & 7) * g8 + (bid >> 3);
+#endif
         }
     }
     int64_t j = bid * 256 + threadIdx.x;
