@@ -130,6 +130,9 @@ class HostMailbox:
         self.ptr = box
         self._seen = (ctypes.c_int64 * 3).from_address(box.value)
         self._ticket = 0
+        # one call in flight per mailbox: a caller holds the lock from next_ticket() until wait() has returned (threads that render on the same device)
+        import threading
+        self.lock = threading.RLock()
 
     @classmethod
     def for_device(cls, device):

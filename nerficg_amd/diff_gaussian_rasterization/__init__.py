@@ -195,12 +195,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         done = False
         if speculative:
             mb = _lib.HostMailbox.for_device(dev) if COUNT_MAILBOX else None
-            ticket = mb.next_ticket() if mb is not None else 0
-            bin_hist = preprocess(span_cap, inst_cap, mb.ptr if mb is not None else None, ticket)
-            have = span_cap if span_cap > 0 else 4 * max(P, 1) + 65536
+            if mb is not None:
+                mb.lock.acquire()
+            try:
+                ticket = mb.next_ticket() if mb is not None else 0
+                bin_hist = preprocess(span_cap, inst_cap, mb.ptr if mb is not None else None, ticket)
+                have = span_cap if span_cap > 0 else 4 * max(P, 1) + 65536
+                counts = None
+                if bin_hist is not None and mb is not None:
+                    keys, point_list = bin_render(bin_hist, span_cap, inst_cap, inst_cap)
+                    counts = mb.wait(ticket)
+            finally:
+                if mb is not None:
+                    mb.lock.release()
             if bin_hist is not None and mb is not None:
-                keys, point_list = bin_render(bin_hist, span_cap, inst_cap, inst_cap)
-                counts = mb.wait(ticket)
                 if counts is None:
                     warnings.warn('diff_gaussian_rasterization: the count mailbox did not answer; using the device counters from now on')
                     _lib.HostMailbox.retire(dev)

@@ -443,9 +443,8 @@ class InstantNGPRenderer:
         # the frame's one host read: the row count that sizes the sample buffers.  Through a host mailbox (the closing scan of the count pass stores
         # the totals in mapped host memory and this thread polls them) when the runtime offers one -- no device-to-host copy, no stream wait:
         # 42 -> ~10 us of idle GPU between the count pass and the write pass
-        mailbox = _lib.HostMailbox.for_device(dev) if (row_capacity is None and self.COUNT_MAILBOX) else None
-        ticket = self._fused_count(fc, ws, tile_begin, nt, mailbox)
         if row_capacity is not None:
+            self._fused_count(fc, ws, tile_begin, nt)
             cap = int(row_capacity)
             if cap < 1:
                 raise ValueError('row_capacity must be positive')
@@ -460,12 +459,20 @@ class InstantNGPRenderer:
             res = dict(out)
             res['counter'] = ws['counter']
             return res
-        # what does not depend on the count is prepared before the wait (the sample buffers exist from the previous frame; a frame that needs
-        # more regrows them below and marshals again)
+        mailbox = _lib.HostMailbox.for_device(dev) if self.COUNT_MAILBOX else None
         arena = self.ARENA_IN_PLACE and ws.get('ts_prov') is not None   # the parked samples are queried where they are: no copy into compact rows
-        ready = self._query_args(fc, ws, nt, False, arena) if ws['cap'] > 0 else None
-        cap_before = ws['cap']
-        counts = mailbox.wait(ticket) if mailbox is not None else None
+        if mailbox is not None:
+            mailbox.lock.acquire()    # one call in flight per mailbox
+        try:
+            ticket = self._fused_count(fc, ws, tile_begin, nt, mailbox)
+            # what does not depend on the count is prepared before the wait (the sample buffers exist from the previous frame; a frame that needs
+            # more regrows them below and marshals again)
+            ready = self._query_args(fc, ws, nt, False, arena) if ws['cap'] > 0 else None
+            cap_before = ws['cap']
+            counts = mailbox.wait(ticket) if mailbox is not None else None
+        finally:
+            if mailbox is not None:
+                mailbox.lock.release()
         if counts is None:
             if mailbox is not None:
                 warnings.warn('render_image_fused: the count mailbox did not answer; reading the device counter from now on')
