@@ -31,7 +31,8 @@ enum {
  * History: 1 = rounds 1-2; 2 = round 3 (nrc_gs_backward gained grad_records, nrc_ngp_render_count writes 2 * n_tiles ints into tile_rows,
  * counter[1] = total samples, save buffers padded to nrc_nwie_save_rows); 3 = round 4 (see the notes at the changed entry points);
  * 4 = round 4, later: nrc_gs_preprocess and nrc_ngp_render_count gained count_mailbox / mailbox_ticket, nrc_host_mailbox_alloc / _free are new;
- * nrc_ngp_query_samples gained arena_tile_off / arena_rows, nrc_ngp_composite_image arena_rows, nrc_ngp_render_write accepts ts = NULL. */
+ * nrc_ngp_query_samples gained arena_tile_off / arena_rows, nrc_ngp_composite_image arena_rows, nrc_ngp_render_write accepts ts = NULL;
+ * nrc_photometric_loss_* are new. */
 #define NRC_ABI_VERSION 4
 /* library identification; also used by the loader's symbol check */
 int nrc_abi_version(void);
@@ -449,6 +450,20 @@ int nrc_ssim_forward(const float* img1, const float* img2, int64_t planes, int32
 int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int32_t H, int32_t W, const float* dL_dmap,
                       const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
                       nrc_stream_t stream);
+/* The whole photometric loss of the 3DGS trainer (src/Methods/GaussianSplatting/Loss.py:11-23: lambda_l1 * L1 + lambda_dssim * (1 - SSIM), weights
+ * Trainer.py:34-35) in three launches instead of the ~22 that the L1 term, the two means and the weighting take as tensor operations around
+ * nrc_ssim_forward / _backward (each of them >= 5 us on a scalar): the SSIM stencil also sums |image - target| and the SSIM values per workgroup,
+ * one workgroup adds the partial sums up in a fixed order (double accumulators), and the backward stencil takes dL/dmap = -lambda_dssim * g / n as a
+ * constant and adds lambda_l1 * g / n * sign(image - target); g = upstream_dev[0], the gradient of the loss VALUE, read on the device (NULL: 1).
+ * loss3 (DEVICE float[3]) = {loss, mean |image - target|, mean SSIM}; workspace: nrc_photometric_loss_ws_floats(planes, H, W) floats; the three
+ * derivative maps (planes x H x W each) as for nrc_ssim_forward (all NULL: value only).  planes = B * C, "same" padding. */
+int64_t nrc_photometric_loss_ws_floats(int64_t planes, int32_t H, int32_t W);
+int nrc_photometric_loss_forward(const float* image, const float* target, int64_t planes, int32_t H, int32_t W, float C1, float C2,
+                                 float lambda_l1, float lambda_dssim, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                                 float* workspace, float* loss3, nrc_stream_t stream);
+int nrc_photometric_loss_backward(const float* image, const float* target, int64_t planes, int32_t H, int32_t W, float lambda_l1,
+                                  float lambda_dssim, const float* upstream_dev, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                                  const float* dm_dsigma12, float* dL_dimage, nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 8 -- fused Adam step: replaces apex.optimizers.FusedAdam (src/Thirdparty/Apex.py:17) as constructed at

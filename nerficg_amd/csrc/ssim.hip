@@ -23,12 +23,15 @@ __constant__ float SSIM_G[11] = {0.001028380123898387f, 0.0075987582094967365f, 
                                  0.21300552785396576f,  0.26601171493530273f,   0.21300552785396576f,  0.10936068743467331f,
                                  0.036000773310661316f, 0.0075987582094967365f, 0.001028380123898387f};
 
-template <bool TRAIN>
+// LOSS (the fused photometric loss, nrc_photometric_loss_forward): no SSIM map is written; the workgroup's sums of the SSIM values and of |img1 - img2|
+// over its pixels go to partial[2 * block], partial[2 * block + 1] (a fixed tree inside the workgroup: the sums do not depend on scheduling)
+template <bool TRAIN, bool LOSS = false>
 __global__ void __launch_bounds__(256) k_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W, float C1, float C2,
                                                   float* __restrict__ ssim_map, float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
-                                                  float* __restrict__ dm_dsigma12) {
+                                                  float* __restrict__ dm_dsigma12, float* __restrict__ partial = nullptr) {
     __shared__ float s1[SI][SP], s2[SI][SP];
     __shared__ float xb[5][SI][ST + 1];
+    __shared__ float red[2][4];
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * ST - SR, y0 = blockIdx.y * ST - SR;
     for (int k = threadIdx.x; k < SI * SI; k += 256) {
@@ -58,25 +61,65 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(const float* __restrict__ img1
 #pragma unroll
         for (int q = 0; q < 5; q++) m[q] += g * xb[q][ty + t][tx];
     }
-    if (x >= W || y >= H) return;
+    const bool inside = x < W && y < H;
+    if (!LOSS && !inside) return;
     const float mu1 = m[0], mu2 = m[1];
     const float sg1 = m[2] - mu1 * mu1, sg2 = m[3] - mu2 * mu2, sg12 = m[4] - mu1 * mu2;
     const float A = mu1 * mu1 + mu2 * mu2 + C1, B = sg1 + sg2 + C2, C = 2.f * mu1 * mu2 + C1, D = 2.f * sg12 + C2;
     const float iAB = 1.f / (A * B);
     const size_t o = plane + (size_t)y * W + x;
-    ssim_map[o] = C * D * iAB;
-    if (TRAIN) {
-        dm_dmu1[o] = (mu2 * 2.f * D) * iAB - (mu2 * 2.f * C) * iAB - (mu1 * 2.f * C * D) * iAB / A + (mu1 * 2.f * C * D) * iAB / B;
-        dm_dsigma1_sq[o] = (-C * D) * iAB / B;
-        dm_dsigma12[o] = (2.f * C) * iAB;
+    const float ssim = C * D * iAB;
+    if (inside) {
+        if (!LOSS) ssim_map[o] = ssim;
+        if (TRAIN) {
+            dm_dmu1[o] = (mu2 * 2.f * D) * iAB - (mu2 * 2.f * C) * iAB - (mu1 * 2.f * C * D) * iAB / A + (mu1 * 2.f * C * D) * iAB / B;
+            dm_dsigma1_sq[o] = (-C * D) * iAB / B;
+            dm_dsigma12[o] = (2.f * C) * iAB;
+        }
+    }
+    if (LOSS) {
+        float a = inside ? ssim : 0.f, b = inside ? fabsf(s1[ty + SR][tx + SR] - s2[ty + SR][tx + SR]) : 0.f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            partial[2 * blk] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            partial[2 * blk + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        }
+    }
+}
+// the loss value from the workgroups' partial sums: one workgroup, double accumulators, a fixed order.  out[0] = lambda_l1 * mean|a - b| +
+// lambda_dssim * (1 - mean SSIM), out[1] = mean|a - b|, out[2] = mean SSIM
+__global__ void __launch_bounds__(256) k_photo_reduce(const float* __restrict__ partial, int64_t n_blocks, double inv_n, float lambda_l1, float lambda_dssim,
+                                                      float* __restrict__ out) {
+    __shared__ double red[2][256];
+    double a = 0.0, b = 0.0;
+    for (int64_t k = threadIdx.x; k < n_blocks; k += 256) { a += (double)partial[2 * k]; b += (double)partial[2 * k + 1]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) { red[0][threadIdx.x] += red[0][threadIdx.x + d]; red[1][threadIdx.x] += red[1][threadIdx.x + d]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double ssim = red[0][0] * inv_n, l1 = red[1][0] * inv_n;
+        out[0] = (float)((double)lambda_l1 * l1 + (double)lambda_dssim * (1.0 - ssim));
+        out[1] = (float)l1; out[2] = (float)ssim;
     }
 }
 
+// LOSS (nrc_photometric_loss_backward): dL/dmap is the same number for every pixel, -lambda_dssim * g / n with the upstream gradient g of the loss
+// value read from the device (no map is read), and lambda_l1 * g / n * sign(img1 - img2) is added to the result
+template <bool LOSS = false>
 __global__ void __launch_bounds__(256) k_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
                                                   const float* __restrict__ dL_dmap, const float* __restrict__ dm_dmu1,
                                                   const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
-                                                  float* __restrict__ dL_dimg1) {
+                                                  float* __restrict__ dL_dimg1, const float* __restrict__ upstream = nullptr, float c_ssim = 0.f,
+                                                  float c_l1 = 0.f) {
     __shared__ float p[3][SI][SP];
+    const float g_up = LOSS ? (upstream ? upstream[0] : 1.f) : 0.f;
     __shared__ float xb[3][SI][ST + 1];
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * ST - SR, y0 = blockIdx.y * ST - SR;
@@ -84,7 +127,7 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(const float* __restrict__ img1
         const int r = k / SI, c = k - r * SI, y = y0 + r, x = x0 + c;
         const bool in = y >= 0 && y < H && x >= 0 && x < W;
         const size_t o = plane + (size_t)y * W + x;
-        const float dl = in ? dL_dmap[o] : 0.f;
+        const float dl = in ? (LOSS ? c_ssim * g_up : dL_dmap[o]) : 0.f;
         p[0][r][c] = in ? dl * dm_dmu1[o] : 0.f;
         p[1][r][c] = in ? dl * dm_dsigma1_sq[o] : 0.f;
         p[2][r][c] = in ? dl * dm_dsigma12[o] : 0.f;
@@ -114,7 +157,10 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(const float* __restrict__ img1
     }
     if (x >= W || y >= H) return;
     const size_t o = plane + (size_t)y * W + x;
-    dL_dimg1[o] = b[0] + 2.f * img1[o] * b[1] + img2[o] * b[2];
+    const float u = img1[o], v = img2[o];
+    float r = b[0] + 2.f * u * b[1] + v * b[2];
+    if (LOSS) { const float d = u - v; r += c_l1 * g_up * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)); }
+    dL_dimg1[o] = r;
 }
 
 }  // namespace
@@ -147,8 +193,46 @@ int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int3
     if (planes == 0) return NRC_OK;
     if (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1) return NRC_ERR_INVALID;
     const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, (unsigned)planes);
-    hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(256), 0, (hipStream_t)stream, img1, img2, (int)H, (int)W, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
-                       dL_dimg1);
+    hipLaunchKernelGGL(k_ssim_bwd<false>, grid, dim3(256), 0, (hipStream_t)stream, img1, img2, (int)H, (int)W, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+                       dL_dimg1, (const float*)nullptr, 0.f, 0.f);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int64_t nrc_photometric_loss_ws_floats(int64_t planes, int32_t H, int32_t W) {
+    if (planes < 0 || H < 1 || W < 1) return NRC_ERR_INVALID;
+    return 2 * planes * (int64_t)((W + ST - 1) / ST) * ((H + ST - 1) / ST) + 4;
+}
+int nrc_photometric_loss_forward(const float* image, const float* target, int64_t planes, int32_t H, int32_t W, float C1, float C2, float lambda_l1,
+                                 float lambda_dssim, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, float* workspace, float* loss3,
+                                 nrc_stream_t stream) {
+    NRC_ENTER();
+    if (planes < 1 || H < 1 || W < 1 || planes > 65535 || !image || !target || !workspace || !loss3) return NRC_ERR_INVALID;
+    const bool train = dm_dmu1 || dm_dsigma1_sq || dm_dsigma12;
+    if (train && !(dm_dmu1 && dm_dsigma1_sq && dm_dsigma12)) return NRC_ERR_INVALID;
+    const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, (unsigned)planes);
+    hipStream_t s = (hipStream_t)stream;
+    if (train)
+        hipLaunchKernelGGL((k_ssim_fwd<true, true>), grid, dim3(256), 0, s, image, target, (int)H, (int)W, C1, C2, (float*)nullptr, dm_dmu1, dm_dsigma1_sq,
+                           dm_dsigma12, workspace);
+    else
+        hipLaunchKernelGGL((k_ssim_fwd<false, true>), grid, dim3(256), 0, s, image, target, (int)H, (int)W, C1, C2, (float*)nullptr, dm_dmu1, dm_dsigma1_sq,
+                           dm_dsigma12, workspace);
+    const int64_t n_blocks = (int64_t)grid.x * grid.y * grid.z;
+    hipLaunchKernelGGL(k_photo_reduce, dim3(1), dim3(256), 0, s, (const float*)workspace, n_blocks, 1.0 / ((double)planes * H * W), lambda_l1, lambda_dssim, loss3);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_photometric_loss_backward(const float* image, const float* target, int64_t planes, int32_t H, int32_t W, float lambda_l1, float lambda_dssim,
+                                  const float* upstream_dev, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimage,
+                                  nrc_stream_t stream) {
+    NRC_ENTER();
+    if (planes < 1 || H < 1 || W < 1 || planes > 65535) return NRC_ERR_INVALID;
+    if (!image || !target || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimage) return NRC_ERR_INVALID;
+    const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, (unsigned)planes);
+    const double inv_n = 1.0 / ((double)planes * H * W);
+    hipLaunchKernelGGL(k_ssim_bwd<true>, grid, dim3(256), 0, (hipStream_t)stream, image, target, (int)H, (int)W, (const float*)nullptr, dm_dmu1, dm_dsigma1_sq,
+                       dm_dsigma12, dL_dimage, upstream_dev, (float)(-(double)lambda_dssim * inv_n), (float)((double)lambda_l1 * inv_n));
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

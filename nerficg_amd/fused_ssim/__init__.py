@@ -10,7 +10,7 @@ import torch
 
 from .. import _lib
 
-__all__ = ['fused_ssim']
+__all__ = ['fused_ssim', 'photometric_loss']
 
 _ALLOWED_PADDING = ('same', 'valid')
 
@@ -64,3 +64,48 @@ def fused_ssim(img1: torch.Tensor, img2: torch.Tensor, padding: str = 'same', tr
         raise ValueError(f'fused_ssim: padding must be one of {_ALLOWED_PADDING}')
     C1, C2 = 0.01 ** 2, 0.03 ** 2
     return _FusedSSIMMap.apply(C1, C2, img1.contiguous(), img2.contiguous(), padding, train).mean()
+
+
+class _PhotometricLoss(torch.autograd.Function):
+    """lambda_l1 * L1 + lambda_dssim * (1 - SSIM) as ONE node: stencil + reduction forward, one stencil backward (include/nerficg_hip.h,
+    nrc_photometric_loss_*).  The upstream gradient of the loss value stays on the device (a GradScaler's scale, a weight of a larger loss)."""
+
+    @staticmethod
+    def forward(ctx, image, target, lambda_l1, lambda_dssim):
+        lib = _lib.load()
+        planes, h, w = _planes(image)
+        train = ctx.needs_input_grad[0]
+        d = [torch.empty_like(image) for _ in range(3)] if train else [None, None, None]
+        ws = torch.empty(int(lib.nrc_photometric_loss_ws_floats(planes, h, w)), dtype=torch.float32, device=image.device)
+        loss3 = torch.empty(3, dtype=torch.float32, device=image.device)
+        _lib.check(lib.nrc_photometric_loss_forward(_lib.ptr(image), _lib.ptr(target), planes, h, w, 0.01 ** 2, 0.03 ** 2, float(lambda_l1), float(lambda_dssim),
+                                                    _lib.ptr(d[0]), _lib.ptr(d[1]), _lib.ptr(d[2]), _lib.ptr(ws), _lib.ptr(loss3), _lib.stream_of(image)),
+                   'photometric_loss_forward')
+        if train:
+            ctx.save_for_backward(image.detach(), target, *d)
+        ctx.weights = (float(lambda_l1), float(lambda_dssim))
+        ctx.terms = loss3      # [1] = mean |image - target|, [2] = mean SSIM (device; for logging without another pass)
+        return loss3[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss):
+        image, target, d1, d2, d3 = ctx.saved_tensors
+        lib = _lib.load()
+        planes, h, w = _planes(image)
+        g = grad_loss.to(torch.float32).reshape(1).contiguous()
+        grad = torch.empty_like(image)
+        _lib.check(lib.nrc_photometric_loss_backward(_lib.ptr(image), _lib.ptr(target), planes, h, w, ctx.weights[0], ctx.weights[1], _lib.ptr(g),
+                                                     _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(d3), _lib.ptr(grad), _lib.stream_of(image)),
+                   'photometric_loss_backward')
+        return grad, None, None, None
+
+
+def photometric_loss(image: torch.Tensor, target: torch.Tensor, lambda_l1: float = 0.8, lambda_dssim: float = 0.2) -> torch.Tensor:
+    """GaussianSplattingLoss (src/Methods/GaussianSplatting/Loss.py:11-23) on (B, C, H, W) f32 images as one autograd node: the value of
+    lambda_l1 * l1_loss(image, target) + lambda_dssim * (1 - fused_ssim(image, target)), differentiable w.r.t. `image` only (like fused_ssim)."""
+    for t, name in ((image, 'image'), (target, 'target')):
+        _lib.check_input(t, name, torch.float32)
+    if image.dim() != 4 or image.shape != target.shape:
+        raise RuntimeError('photometric_loss: image and target must be (B, C, H, W) tensors of the same shape')
+    return _PhotometricLoss.apply(image, target, float(lambda_l1), float(lambda_dssim))

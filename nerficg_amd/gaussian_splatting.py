@@ -405,11 +405,17 @@ def render_image_inference(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np
     return {'rgb': image if to_chw else image.permute(1, 2, 0)}
 
 
+FUSED_PHOTOMETRIC_LOSS = True   # training_loss as one node (nerficg_amd.fused_ssim.photometric_loss); False: l1_loss + fused_ssim as tensor operations
+
+
 def training_loss(image: torch.Tensor, target: torch.Tensor, lambda_l1: float = 0.8, lambda_dssim: float = 0.2) -> torch.Tensor:
     """GaussianSplattingLoss (src/Methods/GaussianSplatting/Loss.py:11-23, weights Trainer.py:34-35): lambda_l1 * L1 + lambda_dssim *
     (1 - SSIM) on (3, H, W) images, SSIM through the HIP kernels (nerficg_amd.fused_ssim; DSSIM.py:11-18 adds the batch dimension)."""
-    from .fused_ssim import fused_ssim
-    l1 = torch.nn.functional.l1_loss(image, target)
+    from .fused_ssim import fused_ssim, photometric_loss
     a = image[None] if image.dim() == 3 else image
     b = target[None] if target.dim() == 3 else target
+    if FUSED_PHOTOMETRIC_LOSS and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 4 and a.shape == b.shape:
+        # one autograd node, three launches (stencil + reduction, stencil) instead of ~22 tensor operations around the SSIM kernels
+        return photometric_loss(a.contiguous(), b.contiguous(), lambda_l1, lambda_dssim)
+    l1 = torch.nn.functional.l1_loss(image, target)
     return lambda_l1 * l1 + lambda_dssim * (1.0 - fused_ssim(a, b))
