@@ -92,24 +92,32 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(const float* __restrict__ img1
 }
 // the loss value from the workgroups' partial sums: one workgroup, double accumulators, a fixed order.  out[0] = lambda_l1 * mean|a - b| +
 // lambda_dssim * (1 - mean SSIM), out[1] = mean|a - b|, out[2] = mean SSIM
-__global__ void __launch_bounds__(256) k_photo_reduce(const float* __restrict__ partial, int64_t n_blocks, double inv_n, float lambda_l1, float lambda_dssim,
-                                                      float* __restrict__ out) {
-    __shared__ double red[2][256];
+__global__ void __launch_bounds__(1024) k_photo_reduce(const float* __restrict__ partial, int64_t n_blocks, double inv_n, float lambda_l1, float lambda_dssim,
+                                                       float* __restrict__ out) {
+    __shared__ double red[2][16];
     double a = 0.0, b = 0.0;
-    for (int64_t k = threadIdx.x; k < n_blocks; k += 256) { a += (double)partial[2 * k]; b += (double)partial[2 * k + 1]; }
-    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
-    __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
-        if ((int)threadIdx.x < d) { red[0][threadIdx.x] += red[0][threadIdx.x + d]; red[1][threadIdx.x] += red[1][threadIdx.x + d]; }
-        __syncthreads();
+    for (int64_t k0 = threadIdx.x; k0 < n_blocks; k0 += 4 * 1024) {   // four independent loads per turn: the launch is one latency chain otherwise
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t k = k0 + (int64_t)u * 1024;
+            v[u] = k < n_blocks ? reinterpret_cast<const float2*>(partial)[k] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a += (double)v[u].x; b += (double)v[u].y; }
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const double ssim = red[0][0] * inv_n, l1 = red[1][0] * inv_n;
+        double sa = 0.0, sb = 0.0;
+        for (int w = 0; w < 16; w++) { sa += red[0][w]; sb += red[1][w]; }
+        const double ssim = sa * inv_n, l1 = sb * inv_n;
         out[0] = (float)((double)lambda_l1 * l1 + (double)lambda_dssim * (1.0 - ssim));
         out[1] = (float)l1; out[2] = (float)ssim;
     }
 }
-
 // LOSS (nrc_photometric_loss_backward): dL/dmap is the same number for every pixel, -lambda_dssim * g / n with the upstream gradient g of the loss
 // value read from the device (no map is read), and lambda_l1 * g / n * sign(img1 - img2) is added to the result
 template <bool LOSS = false>
@@ -219,7 +227,7 @@ int nrc_photometric_loss_forward(const float* image, const float* target, int64_
         hipLaunchKernelGGL((k_ssim_fwd<false, true>), grid, dim3(256), 0, s, image, target, (int)H, (int)W, C1, C2, (float*)nullptr, dm_dmu1, dm_dsigma1_sq,
                            dm_dsigma12, workspace);
     const int64_t n_blocks = (int64_t)grid.x * grid.y * grid.z;
-    hipLaunchKernelGGL(k_photo_reduce, dim3(1), dim3(256), 0, s, (const float*)workspace, n_blocks, 1.0 / ((double)planes * H * W), lambda_l1, lambda_dssim, loss3);
+    hipLaunchKernelGGL(k_photo_reduce, dim3(1), dim3(1024), 0, s, (const float*)workspace, n_blocks, 1.0 / ((double)planes * H * W), lambda_l1, lambda_dssim, loss3);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
