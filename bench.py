@@ -217,13 +217,15 @@ def trained_scene_leg(device, iters=1500, n_poses=20):
         for i in range(3):
             renderer.render_image_fused(cam, poses[i], early_termination=et)
         samples = rows = skipped = 0
+        skipped_dev = []
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(n_poses):
             out = renderer.render_image_fused(cam, poses[3 + i], return_stats=True, early_termination=et)
             samples += out['n_samples']; rows += out['n_rows']
-            if et == 'auto':
-                skipped += int(next(iter(renderer._fused_ws.values()))['skipped'].item())   # rows of finished tiles the slab order never queried (a device count)
+            if et == 'auto':   # rows of finished tiles the slab order never queried: a device count, kept on the device until the timed loop is over
+                skipped_dev.append(next(iter(renderer._fused_ws.values()))['skipped'].clone())   # (a read here would drain the GPU after every frame)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n_poses
+        skipped = sum(int(t.item()) for t in skipped_dev)
         res[label] = {'ms_per_frame': round(dt * 1e3, 3), 'mrays_per_s': round(W * H / dt / 1e6, 2), 'samples_per_ray_marched': round(samples / (n_poses * W * H), 2),
                       'rows_skipped_frac': round(skipped / max(rows, 1), 4) if et == 'auto' else 0.0}
     return res

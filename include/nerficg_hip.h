@@ -404,11 +404,14 @@ int nrc_ngp_query_samples(const float* ts, int32_t* row_tile, const float* ray_o
  * (src/Methods/InstantNGP/Renderer.py:118-132) at slab granularity, without host round trips.  Same image as steps 2-4.
  *   nrc_ngp_render_write_layers: like step 2, plus layer_off (max_samples + 1) i32 and row_of (rows) i32 = the row of (tile, k).
  *   nrc_ngp_render_layers      : steps 3 + 4 interleaved per slab; workspace nrc_ngp_render_layers_ws_bytes(rows, n_tiles);
- *                                skipped_rows (optional, 1 i32): number of rows the early termination saved. */
+ *                                skipped_rows (optional, 1 i32): number of rows the early termination saved.
+ *   ABI 4, the arena queried in place (as for the single pass): nrc_ngp_render_write_layers(ts = NULL, ..., row_k) copies nothing and also writes
+ *   row_k (rows) i32 = which sample of its tile a row is; nrc_ngp_render_layers takes ts = ts_provisional, arena_row_k = row_k, arena_rows =
+ *   max_samples and reads slot i of row r at arena row row_tile[r] * arena_rows + row_k[r] (305 -> ~10 us for the write step of an 800x800 frame). */
 int nrc_ngp_render_write_layers(int64_t n_tiles, const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
                                 int32_t grid_size, int32_t max_samples, const float* ray_od, const float* ray_t, const int32_t* ray_cnt,
                                 const int32_t* tile_rows, const int32_t* tile_off, float* ts, int32_t* row_tile, int32_t* layer_off,
-                                int32_t* row_of, const float* ts_provisional, nrc_stream_t stream);
+                                int32_t* row_of, const float* ts_provisional, int32_t* row_k, nrc_stream_t stream);
 int64_t nrc_ngp_render_layers_ws_bytes(int64_t n_rows, int64_t n_ray_tiles);
 int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
                           const float* xyz_min3, const float* xyz_size3, const void* density_weights_f16,
@@ -417,7 +420,7 @@ int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float*
                           const int32_t* tile_off, const int32_t* row_of, int32_t width, int32_t height, int64_t tile_begin,
                           int32_t cascades, float exp_step_factor, int32_t grid_size, int32_t max_samples, float T_threshold,
                           const float* bg3_host, void* packed_f16, float* rgb, float* alpha, float* depth, int32_t* skipped_rows,
-                          void* workspace, nrc_stream_t stream);
+                          void* workspace, const int32_t* arena_row_k, int32_t arena_rows, nrc_stream_t stream);
 /* stage 3a on its own (the dominant kernel of the pipeline; used by bench.py's roofline leg): hash-grid features of the n_rows (<= 131072) rows
  * first_row .. first_row + n_rows - 1 of the frame -- ts / row_tile are the FRAME's arrays, not offset ones (ABI 4) --, fragment-major: the 16-byte
  * vector [((j>>5)*4 + ((g + (j>>5))&3))*32 + (j&31)] = levels 4g..4g+3 (fp16x2) of slot j of the chunk.  arena_tile_off / arena_rows: as for

@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) k_composite_layers(const __half* __restri
                                                           float dt_min, float dt_max, float thr, float bg_r, float bg_g, float bg_b,
                                                           float* __restrict__ state, uint8_t* __restrict__ ray_alive, int32_t* __restrict__ next_k,
                                                           uint8_t* __restrict__ tile_alive, float* __restrict__ rgb, float* __restrict__ alpha_out,
-                                                          float* __restrict__ depth_out, int32_t* __restrict__ skipped_rows) {
+                                                          float* __restrict__ depth_out, int32_t* __restrict__ skipped_rows, int arena_rows) {
     const int lane = threadIdx.x & 63;
     const int64_t lt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (lt >= n_tiles || !tile_alive[lt]) return;
@@ -370,23 +370,42 @@ __global__ void __launch_bounds__(256) k_composite_layers(const __half* __restri
     float T = state[q], accR = state[plane + q], accG = state[2 * plane + q], accB = state[3 * plane + q], accD = state[4 * plane + q],
           accO = state[5 * plane + q];
     bool alive = ray_alive[q] != 0;
-    while (k < R && __any(alive)) {
-        const int64_t row = row_of[base + k];
-        if (row >= row_end) break;
-        if (alive) {
-            const int64_t s = row * 64 + lane;
-            const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(packed) + 4 * s);
-            const float2 f01 = __half22float2(*reinterpret_cast<const __half2*>(&raw.x));
-            const float2 f23 = __half22float2(*reinterpret_cast<const __half2*>(&raw.y));
-            const float t = ts[s];
-            const float dt = fmaxf(dt_min, fminf(t * esf, dt_max));
-            const float a = alpha_of(expf(f01.x), dt);
-            const float w = a * T;
-            accR += w * f01.y; accG += w * f23.x; accB += w * f23.y; accD += w * t; accO += w;
-            T *= 1.0f - a;
-            if (T <= thr || k + 1 >= N) alive = false;
+    // The rows of a slab, EIGHT at a time with their loads issued together (round 4: one row per turn was a chain of up to sixteen dependent round
+    // trips per slab, 62-75 us per launch); the arithmetic walks them in order, stops where the one-row loop stopped (row behind the chunk, all
+    // lanes finished, last row of the tile) and leaves the same k.  arena_rows > 0: `ts` is the count pass's arena (sample k of this tile in its
+    // row lt * arena_rows + k); `packed` stays indexed by the slab-major rows.
+    enum { CU = 8 };
+    bool behind = false;
+    while (k < R && !behind && __any(alive)) {
+        int64_t rows[CU];
+        uint2 raw[CU];
+        float tv[CU];
+#pragma unroll
+        for (int u = 0; u < CU; u++) rows[u] = k + u < R ? (int64_t)row_of[base + k + u] : INT64_MAX;
+#pragma unroll
+        for (int u = 0; u < CU; u++) {
+            const bool in = alive && k + u < N && rows[u] < row_end;
+            const int64_t s = rows[u] * 64 + lane;
+            raw[u] = in ? *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(packed) + 4 * s) : make_uint2(0u, 0u);
+            tv[u] = in ? ts[arena_rows > 0 ? ((lt * arena_rows + k + u) << 6) + lane : s] : 0.f;
         }
-        k++;
+#pragma unroll
+        for (int u = 0; u < CU; u++) {
+            if (k >= R || !__any(alive)) break;
+            if (rows[u] >= row_end) { behind = true; break; }
+            if (alive) {
+                const float2 f01 = __half22float2(*reinterpret_cast<const __half2*>(&raw[u].x));
+                const float2 f23 = __half22float2(*reinterpret_cast<const __half2*>(&raw[u].y));
+                const float t = tv[u];
+                const float dt = fmaxf(dt_min, fminf(t * esf, dt_max));
+                const float a = alpha_of(expf(f01.x), dt);
+                const float w = a * T;
+                accR += w * f01.y; accG += w * f23.x; accB += w * f23.y; accD += w * t; accO += w;
+                T *= 1.0f - a;
+                if (T <= thr || k + 1 >= N) alive = false;
+            }
+            k++;
+        }
     }
     const bool finished = !__any(alive) || k >= R;
     if (!finished) {
@@ -493,12 +512,12 @@ void nrc_launch_layers_init(int64_t n_tiles, const int32_t* ray_cnt, float* stat
 void nrc_launch_composite_layers(const void* packed, const float* ts, const int32_t* ray_cnt, const int32_t* tile_rows, const int32_t* tile_off,
                                  const int32_t* row_of, int64_t row_end, int width, int height, int64_t tile_begin, int64_t n_tiles, int cascades, float esf,
                                  int grid_size, int max_samples, float thr, const float* bg3, float* state, uint8_t* ray_alive, int32_t* next_k,
-                                 uint8_t* tile_alive, float* rgb, float* alpha, float* depth, int32_t* skipped_rows, hipStream_t s) {
+                                 uint8_t* tile_alive, float* rgb, float* alpha, float* depth, int32_t* skipped_rows, int arena_rows, hipStream_t s) {
     const int tiles_x = (width + NRC_TILE_W - 1) / NRC_TILE_W;
     const float dt_min = 1.73205080757f / max_samples, dt_max = 1.73205080757f * 2 * (float)cascades / grid_size;
     hipLaunchKernelGGL(k_composite_layers, dim3((unsigned)nrc_cdiv(n_tiles, 4)), dim3(256), 0, s, (const __half*)packed, ts, ray_cnt, tile_rows, tile_off,
                        row_of, row_end, width, height, tiles_x, tile_begin, n_tiles, esf, dt_min, dt_max, thr, bg3[0], bg3[1], bg3[2], state, ray_alive,
-                       next_k, tile_alive, rgb, alpha, depth, skipped_rows);
+                       next_k, tile_alive, rgb, alpha, depth, skipped_rows, arena_rows);
 }
 
 extern "C" {

@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
                                                       const float* __restrict__ ray_t, const int32_t* __restrict__ ray_cnt,
                                                       const int32_t* __restrict__ tile_off, float* __restrict__ ts,
                                                       int32_t* __restrict__ row_tile, const int32_t* __restrict__ row_of,
-                                                      const float* __restrict__ ts_prov, int64_t row_cap) {
+                                                      const float* __restrict__ ts_prov, int64_t row_cap, int32_t* __restrict__ row_k = nullptr) {
     __shared__ uint32_t s_lut[MARCH_LUT_MAX];
     march_lut(c, s_lut);
     const int lane = threadIdx.x & 63;
@@ -867,7 +867,11 @@ __global__ void __launch_bounds__(256) k_render_write(MarchCfg c, int64_t n_tile
     const int rows = (int)min((int64_t)(tile_off[lt + 1] - (int)row0), max(row_cap - row0, (int64_t)0));
     const int N = ray_cnt[q];
     auto row_at = [&](int k) -> int64_t { return row_of ? (int64_t)row_of[row0 + k] : row0 + k; };
-    for (int k = lane; k < rows; k += 64) row_tile[row_at(k)] = (int32_t)lt;
+    for (int k = lane; k < rows; k += 64) {
+        const int64_t r = row_at(k);
+        row_tile[r] = (int32_t)lt;
+        if (row_k) row_k[r] = k;   // slab-major rows queried from the arena: which sample of the tile a row is
+    }
     if (!ts) return;   // the arena is queried in place: only the rows' tiles are wanted
     if (ts_prov) {  // the count pass parked the samples: a coalesced copy (256-byte rows) instead of the second march
         const float* park = ts_prov + (size_t)lt * c.max_samples * 64 + lane;
@@ -1192,11 +1196,12 @@ int nrc_ngp_render_write(int64_t n_tiles, const uint8_t* bitfield, int32_t casca
 int nrc_ngp_render_write_layers(int64_t n_tiles, const uint8_t* bitfield, int32_t cascades, float scale, float esf, int32_t grid_size,
                                 int32_t max_samples, const float* ray_od, const float* ray_t, const int32_t* ray_cnt, const int32_t* tile_rows,
                                 const int32_t* tile_off, float* ts, int32_t* row_tile, int32_t* layer_off, int32_t* row_of,
-                                const float* ts_provisional, nrc_stream_t stream) {
+                                const float* ts_provisional, int32_t* row_k, nrc_stream_t stream) {
     NRC_ENTER();
     if (n_tiles < 0 || cascades < 1 || grid_size < 1 || max_samples < 1 || max_samples > 1024) return NRC_ERR_INVALID;
     if (n_tiles == 0) return NRC_OK;
-    if (!bitfield || !ray_od || !ray_t || !ray_cnt || !tile_rows || !tile_off || !ts || !row_tile || !layer_off || !row_of) return NRC_ERR_INVALID;
+    if (!bitfield || !ray_od || !ray_t || !ray_cnt || !tile_rows || !tile_off || !row_tile || !layer_off || !row_of) return NRC_ERR_INVALID;
+    if (!ts && !(ts_provisional && row_k)) return NRC_ERR_INVALID;   // ts == NULL: arena queried in place, the rows' tiles and sample numbers only
     hipStream_t s = (hipStream_t)stream;
     const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, (float)cascades);
     const int n_slabs = (max_samples + NRC_SLAB_G - 1) / NRC_SLAB_G;
@@ -1204,7 +1209,7 @@ int nrc_ngp_render_write_layers(int64_t n_tiles, const uint8_t* bitfield, int32_
     hipLaunchKernelGGL(k_slab_offsets, dim3(1), dim3(64), 0, s, n_slabs, layer_off);
     hipLaunchKernelGGL(k_slab_rows, dim3(n_slabs), dim3(256), 0, s, tile_rows, tile_off, n_tiles, (const int32_t*)layer_off, row_of);
     hipLaunchKernelGGL(k_render_write, dim3(nrc_cdiv(n_tiles, 4)), dim3(256), 0, s, c, n_tiles, ray_od, ray_t, ray_cnt, tile_off, ts, row_tile,
-                       (const int32_t*)row_of, ts_provisional, INT64_MAX);
+                       (const int32_t*)row_of, ts_provisional, INT64_MAX, row_k);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

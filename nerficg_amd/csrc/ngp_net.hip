@@ -208,12 +208,14 @@ struct QueryIn {
     const int32_t* tile_off; int32_t arena_rows;                    // SRC_TILED, optional: `ts` is the count pass's ARENA (arena_rows rows of 64 per ray tile,
                                                                     // sample k of tile rt in arena row rt * arena_rows + k) and slot i's t is read from there --
                                                                     // row i >> 6 is sample (i >> 6) - tile_off[rt] of its tile; the copy into compact rows is skipped
+    const int32_t* row_k;                                           // ... or, for rows in slab-major order, sample row_k[i >> 6] of its tile (tile_off unused)
     float mn[3], sz[3];                                             // xyz_min, xyz_size of the model box (Renderer.py:50)
 };
 // index of slot i (row i >> 6 of ray tile rt) in `ts`: the slot itself, or its place in the count pass's arena
 __device__ __forceinline__ int64_t ts_slot(const QueryIn& in, int64_t i, int32_t rt) {
-    if (!in.tile_off) return i;
-    return (((int64_t)rt * in.arena_rows + ((i >> 6) - (int64_t)in.tile_off[rt])) << 6) + (i & 63);
+    if (in.arena_rows <= 0) return i;
+    const int64_t k = in.row_k ? (int64_t)in.row_k[i >> 6] : (i >> 6) - (int64_t)in.tile_off[rt];
+    return (((int64_t)rt * in.arena_rows + k) << 6) + (i & 63);
 }
 // returns false for a hole of the tiled layout (no sample in this slot)
 template <int SRC, bool UNIFORM_ROW = true>
@@ -1274,9 +1276,11 @@ int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float*
                           int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, const int32_t* ray_cnt,
                           const int32_t* tile_rows, const int32_t* tile_off, const int32_t* row_of, int32_t width, int32_t height, int64_t tile_begin,
                           int32_t cascades, float exp_step_factor, int32_t grid_size, int32_t max_samples, float T_threshold, const float* bg3_host,
-                          void* packed_f16, float* rgb, float* alpha, float* depth, int32_t* skipped_rows, void* workspace, nrc_stream_t stream) {
+                          void* packed_f16, float* rgb, float* alpha, float* depth, int32_t* skipped_rows, void* workspace, const int32_t* arena_row_k,
+                          int32_t arena_rows, nrc_stream_t stream) {
     NRC_ENTER();
     const int64_t M = n_rows * 64;
+    if ((arena_row_k != nullptr) != (arena_rows > 0) || arena_rows < 0) return NRC_ERR_INVALID;
     if (n_rows < 0 || n_ray_tiles < 1 || !density_weights_f16 || !color_weights_f16 || !table_f16 || !xyz_min3 || !xyz_size3 || !bg3_host ||
         width < 1 || height < 1 || tile_begin < 0 || cascades < 1 || grid_size < 1 || max_samples < 1)
         return NRC_ERR_INVALID;
@@ -1298,6 +1302,7 @@ int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float*
     uint8_t* tile_alive = (uint8_t*)(next_k + n_ray_tiles);
     QueryIn in = {};
     in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od; in.tile_alive = tile_alive;
+    in.row_k = arena_row_k; in.arena_rows = arena_rows;
     for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
     nrc_launch_layers_init(n_ray_tiles, ray_cnt, state, ray_alive, next_k, tile_alive, skipped_rows, s);
     hipLaunchKernelGGL(k_ray_sh, dim3((unsigned)nrc_cdiv(n_ray_tiles * 64, 256)), dim3(256), 0, s, ray_od, n_ray_tiles, ray_sh);
@@ -1316,7 +1321,7 @@ int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float*
         }
         nrc_launch_composite_layers(packed_f16, ts, ray_cnt, tile_rows, tile_off, row_of, (base + cn) / 64, width, height, tile_begin, n_ray_tiles, cascades,
                                     exp_step_factor, grid_size, max_samples, T_threshold, bg3_host, state, ray_alive, next_k, tile_alive, rgb, alpha, depth,
-                                    skipped_rows, s);
+                                    skipped_rows, (int)arena_rows, s);
         base += NRC_QUERY_CHUNK;
     } while (base < M);
     NRC_LAUNCH_CHECK();

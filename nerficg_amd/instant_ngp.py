@@ -301,7 +301,7 @@ class InstantNGPRenderer:
             ws.update(ts=torch.empty(cap * 64, device=dev), row_tile=torch.empty(cap, dtype=torch.int32, device=dev),
                       packed=torch.empty(cap * 64, 4, dtype=torch.float16, device=dev),
                       qws=torch.empty(int(lib.nrc_ngp_render_layers_ws_bytes(cap, nt)), dtype=torch.uint8, device=dev),
-                      row_of=torch.empty(cap, dtype=torch.int32, device=dev),
+                      row_of=torch.empty(cap, dtype=torch.int32, device=dev), row_k=torch.empty(cap, dtype=torch.int32, device=dev),
                       layer_off=torch.empty(self.MAX_SAMPLES + 2, dtype=torch.int32, device=dev), cap=cap)
 
     def _query_args(self, fc: dict, ws: dict, nt: int, fixed: bool, arena: bool) -> list:
@@ -483,7 +483,10 @@ class InstantNGPRenderer:
         if early_termination == 'auto':
             pol = ws.setdefault('et_policy', {'prev_rows': 0, 'prev_layered': False, 'skip_frames': 0})
             if pol['prev_layered'] and pol['prev_rows'] > 0:  # the previous frame is complete by now (we just synchronised on this one's row count)
-                if int(ws['skipped'].item()) < 0.1 * pol['prev_rows']:
+                # (the previous frame's count of skipped rows was copied to pinned memory behind that frame; this frame's count pass ran behind the
+                # copy and has been waited for, so the value is there -- no device read, no stream synchronisation here)
+                skipped_prev = int(ws['skipped_host'][0]) if 'skipped_host' in ws else int(ws['skipped'].item())
+                if skipped_prev < 0.1 * pol['prev_rows']:
                     pol['skip_frames'] = 32
             use_layers = pol['skip_frames'] == 0
             pol['skip_frames'] = max(0, pol['skip_frames'] - 1)
@@ -496,18 +499,22 @@ class InstantNGPRenderer:
             if rows > 0:
                 _lib.check(lib.nrc_ngp_render_write_layers(
                     nt, _lib.ptr(m.occupancy_bitfield), m.cascades, float(m.SCALE), float(esf), m.RESOLUTION, self.MAX_SAMPLES, _lib.ptr(ws['ray_od']),
-                    _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']), _lib.ptr(ws['tile_off']), _lib.ptr(ws['ts']),
-                    _lib.ptr(ws['row_tile']), _lib.ptr(ws['layer_off']), _lib.ptr(ws['row_of']), _lib.ptr(ws.get('ts_prov')), st), 'ngp_render_write_layers')
+                    _lib.ptr(ws['ray_t']), _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']), _lib.ptr(ws['tile_off']), None if arena else _lib.ptr(ws['ts']),
+                    _lib.ptr(ws['row_tile']), _lib.ptr(ws['layer_off']), _lib.ptr(ws['row_of']), _lib.ptr(ws.get('ts_prov')),
+                    _lib.ptr(ws['row_k']) if arena else None, st), 'ngp_render_write_layers')
             if 'qws' not in ws:  # an image without a single sample: state + background only
                 ws['qws'] = torch.empty(int(lib.nrc_ngp_render_layers_ws_bytes(0, nt)), dtype=torch.uint8, device=dev)
             _lib.check(lib.nrc_ngp_render_layers(
-                _lib.ptr(ws.get('ts')), _lib.ptr(ws.get('row_tile')), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(fc['mn'], vp),
+                _lib.ptr(ws.get('ts_prov') if arena else ws.get('ts')), _lib.ptr(ws.get('row_tile')), _lib.ptr(ws['ray_od']), rows, nt, ctypes.cast(fc['mn'], vp),
                 ctypes.cast(fc['sz'], vp), _lib.ptr(m.encoding_xyz._half_params()), _lib.ptr(m.color_mlp_with_encoding._half_params()),
                 _lib.ptr(m.encoding_xyz._table16()), g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
                 _lib.ptr(ws['ray_cnt']), _lib.ptr(ws['tile_rows']), _lib.ptr(ws['tile_off']), _lib.ptr(ws.get('row_of')), camera.width, camera.height,
                 int(tile_begin), m.cascades, float(esf), m.RESOLUTION, self.MAX_SAMPLES, 1e-4, ctypes.cast(fc['bg'], vp),
                 _lib.ptr(ws.get('packed')), _lib.ptr(out['rgb']), _lib.ptr(out['alpha']), _lib.ptr(out['depth']), _lib.ptr(ws['skipped']),
-                _lib.ptr(ws['qws']), st), 'ngp_render_layers')
+                _lib.ptr(ws['qws']), _lib.ptr(ws['row_k']) if (arena and rows > 0) else None, self.MAX_SAMPLES if (arena and rows > 0) else 0, st), 'ngp_render_layers')
+            if 'skipped_host' not in ws:
+                ws['skipped_host'] = torch.zeros(1, dtype=torch.int32).pin_memory()
+            ws['skipped_host'].copy_(ws['skipped'], non_blocking=True)   # for the next frame's policy; ordered behind this frame on the stream
         else:
             self._fused_write_query(fc, ws, rows, nt, arena=arena, query_args=ready if ws['cap'] == cap_before else None)
             self._fused_composite(fc, ws, out, tile_begin, nt, arena=arena)
