@@ -405,6 +405,8 @@ int nrc_ngp_query_samples(const float* ts, int32_t* row_tile, const float* ray_o
  *   nrc_ngp_render_write_layers: like step 2, plus layer_off (max_samples + 1) i32 and row_of (rows) i32 = the row of (tile, k).
  *   nrc_ngp_render_layers      : steps 3 + 4 interleaved per slab; workspace nrc_ngp_render_layers_ws_bytes(rows, n_tiles);
  *                                skipped_rows (optional, 1 i32): number of rows the early termination saved.
+ *   ABI 4: row_tile is READ AND WRITTEN -- when a tile finishes, the slab compositor overwrites the entries of its remaining rows with -1 - tile,
+ *   which is where the query kernels of the following slabs look first (no feature is computed, read or written for such a row).
  *   ABI 4, the arena queried in place (as for the single pass): nrc_ngp_render_write_layers(ts = NULL, ..., row_k) copies nothing and also writes
  *   row_k (rows) i32 = which sample of its tile a row is; nrc_ngp_render_layers takes ts = ts_provisional, arena_row_k = row_k, arena_rows =
  *   max_samples and reads slot i of row r at arena row row_tile[r] * arena_rows + row_k[r] (305 -> ~10 us for the write step of an 800x800 frame). */
@@ -413,7 +415,7 @@ int nrc_ngp_render_write_layers(int64_t n_tiles, const uint8_t* density_bitfield
                                 const int32_t* tile_rows, const int32_t* tile_off, float* ts, int32_t* row_tile, int32_t* layer_off,
                                 int32_t* row_of, const float* ts_provisional, int32_t* row_k, nrc_stream_t stream);
 int64_t nrc_ngp_render_layers_ws_bytes(int64_t n_rows, int64_t n_ray_tiles);
-int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
+int nrc_ngp_render_layers(const float* ts, int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles,
                           const float* xyz_min3, const float* xyz_size3, const void* density_weights_f16,
                           const void* color_weights_f16, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
                           int32_t base_resolution, float per_level_scale, const int32_t* ray_cnt, const int32_t* tile_rows,

@@ -122,7 +122,7 @@ __device__ __forceinline__ int nrc_block256_excl_scan_i(int v, int* smem, int* b
 void nrc_launch_layers_init(int64_t n_tiles, const int32_t* ray_cnt, float* state, uint8_t* ray_alive, int32_t* next_k, uint8_t* tile_alive,
                             int32_t* skipped_rows, hipStream_t s);
 void nrc_launch_composite_layers(const void* packed, const float* ts, const int32_t* ray_cnt, const int32_t* tile_rows, const int32_t* tile_off,
-                                 const int32_t* row_of, int64_t row_end, int width, int height, int64_t tile_begin, int64_t n_tiles, int cascades, float esf,
+                                 const int32_t* row_of, int32_t* row_tile, int64_t row_end, int width, int height, int64_t tile_begin, int64_t n_tiles, int cascades, float esf,
                                  int grid_size, int max_samples, float thr, const float* bg3, float* state, uint8_t* ray_alive, int32_t* next_k,
                                  uint8_t* tile_alive, float* rgb, float* alpha, float* depth, int32_t* skipped_rows, int arena_rows, hipStream_t s);
 

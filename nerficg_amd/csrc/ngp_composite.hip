@@ -353,7 +353,8 @@ __global__ void __launch_bounds__(256) k_layers_init(int64_t n_tiles, const int3
 }
 __global__ void __launch_bounds__(256) k_composite_layers(const __half* __restrict__ packed, const float* __restrict__ ts,
                                                           const int32_t* __restrict__ ray_cnt, const int32_t* __restrict__ tile_rows,
-                                                          const int32_t* __restrict__ tile_off, const int32_t* __restrict__ row_of, int64_t row_end,
+                                                          const int32_t* __restrict__ tile_off, const int32_t* __restrict__ row_of, int32_t* __restrict__ row_tile,
+                                                          int64_t row_end,
                                                           int width, int height, int tiles_x, int64_t tile_begin, int64_t n_tiles, float esf,
                                                           float dt_min, float dt_max, float thr, float bg_r, float bg_g, float bg_b,
                                                           float* __restrict__ state, uint8_t* __restrict__ ray_alive, int32_t* __restrict__ next_k,
@@ -419,6 +420,9 @@ __global__ void __launch_bounds__(256) k_composite_layers(const __half* __restri
         tile_alive[lt] = 0;
         if (skipped_rows && k < R) atomicAdd(skipped_rows, R - k);  // rows no kernel will touch any more (statistics for the caller)
     }
+    // the tile's remaining rows (all in later slabs) are marked as finished where the query kernels look first: row_tile = -1 - tile
+    if (row_tile)
+        for (int kk = k + lane; kk < R; kk += 64) row_tile[row_of[base + kk]] = -1 - (int32_t)lt;
     const int64_t tile = tile_begin + lt;
     const int px = (int)(tile % tiles_x) * NRC_TILE_W + (lane & (NRC_TILE_W - 1)), py = (int)(tile / tiles_x) * NRC_TILE_H + (lane >> NRC_TILE_W_LOG2);
     if (px < width && py < height) {
@@ -510,13 +514,13 @@ void nrc_launch_layers_init(int64_t n_tiles, const int32_t* ray_cnt, float* stat
                        skipped_rows);
 }
 void nrc_launch_composite_layers(const void* packed, const float* ts, const int32_t* ray_cnt, const int32_t* tile_rows, const int32_t* tile_off,
-                                 const int32_t* row_of, int64_t row_end, int width, int height, int64_t tile_begin, int64_t n_tiles, int cascades, float esf,
-                                 int grid_size, int max_samples, float thr, const float* bg3, float* state, uint8_t* ray_alive, int32_t* next_k,
+                                 const int32_t* row_of, int32_t* row_tile, int64_t row_end, int width, int height, int64_t tile_begin, int64_t n_tiles, int cascades,
+                                 float esf, int grid_size, int max_samples, float thr, const float* bg3, float* state, uint8_t* ray_alive, int32_t* next_k,
                                  uint8_t* tile_alive, float* rgb, float* alpha, float* depth, int32_t* skipped_rows, int arena_rows, hipStream_t s) {
     const int tiles_x = (width + NRC_TILE_W - 1) / NRC_TILE_W;
     const float dt_min = 1.73205080757f / max_samples, dt_max = 1.73205080757f * 2 * (float)cascades / grid_size;
     hipLaunchKernelGGL(k_composite_layers, dim3((unsigned)nrc_cdiv(n_tiles, 4)), dim3(256), 0, s, (const __half*)packed, ts, ray_cnt, tile_rows, tile_off,
-                       row_of, row_end, width, height, tiles_x, tile_begin, n_tiles, esf, dt_min, dt_max, thr, bg3[0], bg3[1], bg3[2], state, ray_alive,
+                       row_of, row_tile, row_end, width, height, tiles_x, tile_begin, n_tiles, esf, dt_min, dt_max, thr, bg3[0], bg3[1], bg3[2], state, ray_alive,
                        next_k, tile_alive, rgb, alpha, depth, skipped_rows, arena_rows);
 }
 

@@ -202,7 +202,8 @@ struct QueryIn {
     float* x01_out; int normalise;                                  // SRC_ARRAYS, training: xyz01 holds WORLD positions, (x - mn) / sz is applied
                                                                     // here (torch's two roundings) and written to x01_out for the backward
     const float* ts; const int32_t* row_tile; const float* ray_od;  // SRC_TILED: slot i = (row i>>6, lane i&63), ray = row_tile[row]*64 + lane
-    const uint8_t* tile_alive;                                      // SRC_TILED, optional: rows of finished tiles are treated as holes
+                                                                    // SRC_TILED, slab order: a row whose tile has finished carries row_tile = -1 - tile (written by
+                                                                    // the slab compositor): the query kernels skip it without a look at anything else
     const int32_t* n_rows_dev;                                      // SRC_TILED, optional: the number of rows the march produced, on the DEVICE -- a launch sized
                                                                     // for a row CAPACITY processes only the rows that exist (fixed-capacity image pipeline)
     const int32_t* tile_off; int32_t arena_rows;                    // SRC_TILED, optional: `ts` is the count pass's ARENA (arena_rows rows of 64 per ray tile,
@@ -217,9 +218,11 @@ __device__ __forceinline__ int64_t ts_slot(const QueryIn& in, int64_t i, int32_t
     const int64_t k = in.row_k ? (int64_t)in.row_k[i >> 6] : (i >> 6) - (int64_t)in.tile_off[rt];
     return (((int64_t)rt * in.arena_rows + k) << 6) + (i & 63);
 }
-// returns false for a hole of the tiled layout (no sample in this slot)
+// row_tile entry -> ray tile (finished tiles' rows hold -1 - tile)
+__device__ __forceinline__ int32_t tile_of(int32_t rt) { return rt < 0 ? -1 - rt : rt; }
+// 1: a sample; 0: a hole of the tiled layout (no sample in this slot); -1: a row of a finished tile (slab order): nothing of it is read or written
 template <int SRC, bool UNIFORM_ROW = true>
-__device__ __forceinline__ bool fetch_pos(const QueryIn& in, int64_t i, float& px, float& py, float& pz) {
+__device__ __forceinline__ int fetch_pos(const QueryIn& in, int64_t i, float& px, float& py, float& pz) {
     if constexpr (SRC == SRC_ARRAYS) {
         px = in.xyz01[3 * i]; py = in.xyz01[3 * i + 1]; pz = in.xyz01[3 * i + 2];
         if (in.normalise) {
@@ -227,13 +230,14 @@ __device__ __forceinline__ bool fetch_pos(const QueryIn& in, int64_t i, float& p
             pz = __fdiv_rn(__fsub_rn(pz, in.mn[2]), in.sz[2]);
             if (in.x01_out) { in.x01_out[3 * i] = px; in.x01_out[3 * i + 1] = py; in.x01_out[3 * i + 2] = pz; }
         }
-        return true;
+        return 1;
     } else {
         // one wave = one row of the tiled layout: the row's ray tile is wave-uniform and comes through the scalar cache (no vector round trip in
         // front of the six ray loads that depend on it)
         const int32_t rt = UNIFORM_ROW ? in.row_tile[__builtin_amdgcn_readfirstlane((int)(i >> 6))] : in.row_tile[i >> 6];
+        if (rt < 0) { px = py = pz = 0.f; return -1; }
         const float t = in.ts[ts_slot(in, i, rt)];
-        if (t < 0.f || (in.tile_alive && !in.tile_alive[rt])) { px = py = pz = 0.f; return false; }
+        if (t < 0.f) { px = py = pz = 0.f; return 0; }
         const float* od = in.ray_od + (int64_t)rt * 384 + (i & 63);  // per-tile SoA [6][64]
         // same roundings as the op-by-op path: xyz = o + t*d (mul, add: raymarching.cu:368), then (xyz - min) / size in torch
         px = __fsub_rn(__fadd_rn(od[0], __fmul_rn(t, od[192])), in.mn[0]);
@@ -242,7 +246,7 @@ __device__ __forceinline__ bool fetch_pos(const QueryIn& in, int64_t i, float& p
         if (in.sz[0] != 1.0f || in.sz[1] != 1.0f || in.sz[2] != 1.0f) {  // x / 1.0f == x exactly: skip the IEEE division for the unit box
             px = __fdiv_rn(px, in.sz[0]); py = __fdiv_rn(py, in.sz[1]); pz = __fdiv_rn(pz, in.sz[2]);
         }
-        return true;
+        return 1;
     }
 }
 template <int SRC>
@@ -250,7 +254,7 @@ __device__ __forceinline__ void fetch_dir(const QueryIn& in, int64_t i, float& d
     if constexpr (SRC == SRC_ARRAYS) {
         dx = in.dirs[3 * i]; dy = in.dirs[3 * i + 1]; dz = in.dirs[3 * i + 2];
     } else {
-        const float* od = in.ray_od + (int64_t)in.row_tile[i >> 6] * 384 + (i & 63);
+        const float* od = in.ray_od + (int64_t)tile_of(in.row_tile[i >> 6]) * 384 + (i & 63);
         dx = od[192]; dy = od[256]; dz = od[320];
     }
 }
@@ -310,7 +314,9 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
     if (j >= n || j < 0) return;
     float px, py, pz;
     if (blockIdx.y != 0) in.x01_out = nullptr;   // level groups split over workgroup rows: the first row writes the normalised positions
-    const bool live = remapped ? fetch_pos<SRC, false>(in, base + j, px, py, pz) : fetch_pos<SRC>(in, base + j, px, py, pz);
+    const int state = remapped ? fetch_pos<SRC, false>(in, base + j, px, py, pz) : fetch_pos<SRC>(in, base + j, px, py, pz);
+    if (state < 0) return;   // a row of a finished tile (slab order): the MLP kernel skips it too, nothing reads its features
+    const bool live = state > 0;
     const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
     uint4* out = feat + ((j >> 5) * 4) * 32 + (j & 31);
     const int rot = (int)((j >> 5) & 3);
@@ -394,7 +400,9 @@ __global__ void __launch_bounds__(256) k_grid_encode_fine(QueryIn in, int64_t ba
     if (j >= n || j < 0) return;
     float px, py, pz;
     in.x01_out = nullptr;
-    const bool live = fetch_pos<SRC, false>(in, base + j, px, py, pz);
+    const int state = fetch_pos<SRC, false>(in, base + j, px, py, pz);
+    if (state < 0) return;
+    const bool live = state > 0;
     const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
     const int rot = (int)((j >> 5) & 3);
     uint32_t* out = reinterpret_cast<uint32_t*>(feat + ((j >> 5) * 4) * 32 + (j & 31) + ((3 + rot) & 3) * 32) + (level - first_level);
@@ -571,10 +579,16 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
             __builtin_amdgcn_global_load_lds((gptr_t)(ray_sh + ((int64_t)rt * 2 + hh) * 64 + (i & 63)), (lptr_t)&slot[2][0], 16, 0, 0);
             ti.alive = 1u;
             ti.t = 0.f;
-            if (in.tile_alive) ti.alive = in.tile_alive[rt];
             return;
         }
 #endif
+        if constexpr (SRC == SRC_TILED) {
+            if (rt < 0) {   // (wave-uniform) a row of a finished tile: no load, no arithmetic, no store
+                ti.b0 = make_uint4(0u, 0u, 0u, 0u); ti.b1 = ti.b0; ti.t = 0.f; ti.alive = 0u;
+                for (int q = 0; q < 8; q++) ti.sh[q] = (_Float16)0.f;
+                return;
+            }
+        }
         ti.b0 = fp[((hh + rot) & 3) * 32];
         ti.b1 = fp[((2 + hh + rot) & 3) * 32];
         ti.alive = 1u;
@@ -583,7 +597,6 @@ __global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, in
             // networks like any other slot and its output is never read (the compositor walks a ray's k < ray_cnt rows only); the 4-byte load per
             // slot and, on arena frames, the scalar load of tile_off in front of it cost more than the holes' arithmetic)
             ti.t = 0.f;
-            if (in.tile_alive) ti.alive = in.tile_alive[rt];   // independent of the other loads: selected at use, not waited for here
             ti.sh = ray_sh[((int64_t)rt * 2 + hh) * 64 + (i & 63)];
         } else {
             ti.t = 0.f;
@@ -829,7 +842,7 @@ __global__ void __launch_bounds__(256, 4) k_encode_mlp(QueryIn in, int64_t base,
     for (int64_t row = wave0; row < n_rows; row += n_waves) {
         const int64_t j = row * 64 + lane;
         float px = 0.f, py = 0.f, pz = 0.f;
-        const bool live = j < n && fetch_pos<SRC>(in, base + j, px, py, pz);
+        const bool live = j < n && fetch_pos<SRC>(in, base + j, px, py, pz) > 0;
         const unsigned long long live_mask = __ballot(live);
         if (live_mask == 0ull) continue;  // a row of holes
         uint32_t G0[4] = {0u, 0u, 0u, 0u}, G1[4] = {0u, 0u, 0u, 0u}, G2[4] = {0u, 0u, 0u, 0u}, G3[4] = {0u, 0u, 0u, 0u};
@@ -867,7 +880,7 @@ __global__ void __launch_bounds__(256, 4) k_encode_mlp(QueryIn in, int64_t base,
             const auto s23 = __builtin_amdgcn_permlane32_swap(G2[q], G3[q], false, false);
             G2[q] = s23[0]; G3[q] = s23[1];
         }
-        const int32_t rt = in.row_tile[(base + row * 64) >> 6];
+        const int32_t rt = tile_of(in.row_tile[(base + row * 64) >> 6]);
 #pragma unroll 1
         for (int u = 0; u < 2; u++) {
             uint4 b0, b1;
@@ -1271,7 +1284,7 @@ int64_t nrc_ngp_render_layers_ws_bytes(int64_t n_rows, int64_t n_ray_tiles) {
     return query_feat_bytes(n_rows * 64) + n_ray_tiles * 2048 + 256 + layers_state_bytes(n_ray_tiles);
 }
 
-int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles, const float* xyz_min3,
+int nrc_ngp_render_layers(const float* ts, int32_t* row_tile, const float* ray_od, int64_t n_rows, int64_t n_ray_tiles, const float* xyz_min3,
                           const float* xyz_size3, const void* density_weights_f16, const void* color_weights_f16, const void* table_f16,
                           int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, const int32_t* ray_cnt,
                           const int32_t* tile_rows, const int32_t* tile_off, const int32_t* row_of, int32_t width, int32_t height, int64_t tile_begin,
@@ -1301,7 +1314,7 @@ int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float*
     int32_t* next_k = (int32_t*)(st + (n * 6 * 4 + n + 3) / 4 * 4);
     uint8_t* tile_alive = (uint8_t*)(next_k + n_ray_tiles);
     QueryIn in = {};
-    in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od; in.tile_alive = tile_alive;
+    in.ts = ts; in.row_tile = row_tile; in.ray_od = ray_od;
     in.row_k = arena_row_k; in.arena_rows = arena_rows;
     for (int k = 0; k < 3; k++) { in.mn[k] = xyz_min3[k]; in.sz[k] = xyz_size3[k]; }
     nrc_launch_layers_init(n_ray_tiles, ray_cnt, state, ray_alive, next_k, tile_alive, skipped_rows, s);
@@ -1319,7 +1332,7 @@ int nrc_ngp_render_layers(const float* ts, const int32_t* row_tile, const float*
                 launch_mlp<SRC_TILED>(in, base, cn, feat, ray_sh, density_weights_f16, color_weights_f16, nullptr, nullptr, packed_f16, s);
             }
         }
-        nrc_launch_composite_layers(packed_f16, ts, ray_cnt, tile_rows, tile_off, row_of, (base + cn) / 64, width, height, tile_begin, n_ray_tiles, cascades,
+        nrc_launch_composite_layers(packed_f16, ts, ray_cnt, tile_rows, tile_off, row_of, row_tile, (base + cn) / 64, width, height, tile_begin, n_ray_tiles, cascades,
                                     exp_step_factor, grid_size, max_samples, T_threshold, bg3_host, state, ray_alive, next_k, tile_alive, rgb, alpha, depth,
                                     skipped_rows, (int)arena_rows, s);
         base += NRC_QUERY_CHUNK;
