@@ -814,7 +814,9 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(const int32_t* __restrict__
 // so that a chunk of consecutive rows is a slab of the image in DEPTH and the chunks of an image can be composited front to back.
 // G = 16 consecutive samples of a tile stay adjacent: with G = 1 (pure layer order) the encoder lost 24 % to worse cache reuse
 // between neighbouring waves.
-#define NRC_SLAB_G 16
+#ifndef NRC_SLAB_G
+#define NRC_SLAB_G 16   // rows of a tile per slab (measured: 8 and 32 in profiles/ -- see DESIGN 3.1)
+#endif
 __device__ __forceinline__ int rows_in_slab(int tile_rows, int slab) { return min(NRC_SLAB_G, max(0, tile_rows - slab * NRC_SLAB_G)); }
 __global__ void __launch_bounds__(256) k_slab_totals(const int32_t* __restrict__ tile_rows, int64_t n_tiles, int32_t* __restrict__ slab_tot) {
     __shared__ int smem[8];
@@ -837,15 +839,16 @@ __global__ void __launch_bounds__(256) k_slab_rows(const int32_t* __restrict__ t
     const int slab = blockIdx.x;
     const int first = slab_off[slab];
     if (slab_off[slab + 1] == first) return;
-    int running = 0;
-    for (int64_t base = 0; base < n_tiles; base += 256) {
-        const int64_t t = base + threadIdx.x;
-        const int c = t < n_tiles ? rows_in_slab(tile_rows[t], slab) : 0;
-        int total;
-        const int excl = nrc_block256_excl_scan_i(c, smem, &total);
-        for (int j = 0; j < c; j++) row_of[tile_off[t] + slab * NRC_SLAB_G + j] = first + running + excl + j;
-        running += total;
-        __syncthreads();
+    // thread x owns the contiguous tiles [x c, (x + 1) c): one block scan over the chunk sums (a scan per 256 tiles was 40 of them at 800x800: 44 us)
+    const int64_t per = (n_tiles + 255) / 256, t0 = (int64_t)threadIdx.x * per, t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+    int mine = 0;
+    for (int64_t t = t0; t < t1; t++) mine += rows_in_slab(tile_rows[t], slab);
+    int total;
+    int run = first + nrc_block256_excl_scan_i(mine, smem, &total);
+    for (int64_t t = t0; t < t1; t++) {
+        const int c = rows_in_slab(tile_rows[t], slab);
+        for (int j = 0; j < c; j++) row_of[tile_off[t] + slab * NRC_SLAB_G + j] = run + j;
+        run += c;
     }
 }
 // second march: ts[row(k) * 64 + lane] = t of the k-th sample; holes = -1; row_tile[row] = local tile of the row;
