@@ -440,11 +440,13 @@ def test_arena_in_place_and_mailbox_change_nothing(cascades_esf):
     for k in range(4):
         pose = scenes.orbit_pose(0.4 + 0.9 * k, 0.15 + 0.1 * k, scenes.LEGO_RADIUS if cascades == 1 else 1.15)
         for (t0, nt) in ((0, None), (n_tiles // 3, n_tiles // 2)):
-            ra = a.render_image_fused(cam, pose, tile_begin=t0, n_tiles=nt, return_stats=True, early_termination=False)
-            rb = b.render_image_fused(cam, pose, tile_begin=t0, n_tiles=nt, return_stats=True, early_termination=False)
-            assert ra['n_rows'] == rb['n_rows'] and ra['n_samples'] == rb['n_samples'] and ra['n_samples'] > 0
-            for key in ('rgb', 'alpha', 'depth'):
-                assert torch.equal(ra[key], rb[key]), (k, t0, key)
+            for slabs in (False, True):   # the single pass and the slab order (which has its own arena form: row_k)
+                ra = {kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in
+                      a.render_image_fused(cam, pose, tile_begin=t0, n_tiles=nt, return_stats=True, early_termination=slabs).items()}
+                rb = b.render_image_fused(cam, pose, tile_begin=t0, n_tiles=nt, return_stats=True, early_termination=slabs)
+                assert ra['n_rows'] == rb['n_rows'] and ra['n_samples'] == rb['n_samples'] and ra['n_samples'] > 0
+                for key in ('rgb', 'alpha', 'depth'):
+                    assert torch.equal(ra[key], rb[key]), (k, t0, slabs, key)
 
 
 def test_fixed_row_capacity_frame_needs_no_host_read_and_can_be_recorded():
