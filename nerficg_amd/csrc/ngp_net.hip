@@ -495,8 +495,11 @@ __device__ __forceinline__ f16v mlp_mfma(const h8& a, const h8& b, f16v c) { asm
 #else
 __device__ __forceinline__ f16v mlp_mfma(const h8& a, const h8& b, const f16v& c) { return NRC_MFMA(a, b, c); }
 #endif
+#ifndef NRC_MLP_WAVES
+#define NRC_MLP_WAVES 2   // workgroups per CU the register budget is set for (= waves per SIMD); A/B builds: -DNRC_MLP_WAVES=3
+#endif
 template <int SRC, int NT>
-__global__ void __launch_bounds__(256, 2) k_ngp_mlp(QueryIn in, int64_t base, int64_t n, const uint4* __restrict__ feat,
+__global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int64_t base, int64_t n, const uint4* __restrict__ feat,
                                                     const h8* __restrict__ ray_sh, const __half* __restrict__ Wd,
                                                     const __half* __restrict__ Wc, float* __restrict__ sigmas, float* __restrict__ rgbs,
                                                     __half* __restrict__ packed) {
