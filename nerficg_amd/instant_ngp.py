@@ -29,7 +29,6 @@ from . import VolumeRenderingV2 as VolumeRenderingCuda
 from . import _lib
 from . import tinycudann as tcnn
 from .ngp import composite_over_background, query_fused, query_train
-from .raygen import generate_rays
 
 
 def next_multiple(value, multiple: int) -> int:
