@@ -830,7 +830,12 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
 template <int SRC>
 __global__ void __launch_bounds__(256, 4) k_encode_mlp(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ table, GridCfg g, int narrow_levels,
                                                        const h8* __restrict__ ray_sh, const __half* __restrict__ Wd, const __half* __restrict__ Wc,
-                                                       __half* __restrict__ packed) {
+                                                       __half* __restrict__ packed) {    if (in.n_rows_dev) {
+        const int64_t have = (int64_t)in.n_rows_dev[0] * 64 - base;
+        n = have < n ? have : n;
+        if (n <= 0) return;
+    }
+
     static_assert(SRC == SRC_TILED, "tiled layout only");
     enum { F_D0 = 0, F_DO = 4, F_C0 = 8, F_C1 = 12, F_CO = 20, N_FRAG = 24 };
     if constexpr (SRC == SRC_TILED) {
