@@ -152,8 +152,21 @@ class HostMailbox:
         self._ticket += 1
         return self._ticket
 
+    def counts(self, ticket: int, device):
+        """wait(ticket); when the spin times out (seconds of queued GPU work in front of the posting kernel, say) the caller's stream is
+        synchronised and the mailbox looked at once more -- only a mailbox that is STILL silent then is broken: None, and it is retired."""
+        got = self.wait(ticket)
+        if got is None:
+            import torch
+            torch.cuda.current_stream(device).synchronize()
+            if self._seen[2] == ticket:
+                got = int(self._seen[0]), int(self._seen[1])
+            else:
+                type(self).retire(device)
+        return got
+
     def wait(self, ticket: int):
-        """(first, second) count once the kernel that was given `ticket` has stored them; None after TIMEOUT_S (never observed)."""
+        """(first, second) count once the kernel that was given `ticket` has stored them; None after TIMEOUT_S of spinning."""
         import time
         seen = self._seen
         spins, deadline = 0, None

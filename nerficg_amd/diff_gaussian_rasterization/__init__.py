@@ -204,14 +204,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 counts = None
                 if bin_hist is not None and mb is not None:
                     keys, point_list = bin_render(bin_hist, span_cap, inst_cap, inst_cap)
-                    counts = mb.wait(ticket)
+                    counts = mb.counts(ticket, dev)
             finally:
                 if mb is not None:
                     mb.lock.release()
             if bin_hist is not None and mb is not None:
-                if counts is None:
+                if counts is None:   # (the mailbox retired itself: silent even behind a stream synchronisation)
                     warnings.warn('diff_gaussian_rasterization: the count mailbox did not answer; using the device counters from now on')
-                    _lib.HostMailbox.retire(dev)
                     counts = num_rendered.tolist()
                 n_inst, n_spans = counts
                 done = n_inst <= inst_cap and n_spans <= have

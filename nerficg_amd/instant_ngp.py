@@ -468,14 +468,13 @@ class InstantNGPRenderer:
             # more regrows them below and marshals again)
             ready = self._query_args(fc, ws, nt, False, arena) if ws['cap'] > 0 else None
             cap_before = ws['cap']
-            counts = mailbox.wait(ticket) if mailbox is not None else None
+            counts = mailbox.counts(ticket, dev) if mailbox is not None else None
         finally:
             if mailbox is not None:
                 mailbox.lock.release()
         if counts is None:
             if mailbox is not None:
                 warnings.warn('render_image_fused: the count mailbox did not answer; reading the device counter from now on')
-                _lib.HostMailbox.retire(dev)
             counts = ws['counter'].tolist()
         rows, n_samples = counts   # THE host read of the frame: sizes the sample buffers; the marched total comes with it
         self._fused_size_rows(ws, rows, nt)

@@ -41,6 +41,17 @@ def test_a_ticket_that_is_never_posted_times_out_and_a_posted_one_is_seen():
         assert box.wait(box.next_ticket()) is None
     finally:
         _lib.HostMailbox.TIMEOUT_S = old
+    # a spin that gives up too early (as behind seconds of queued work) is not a broken mailbox: the stream is synchronised, the counts are there
+    frame0 = _gs_frame(seed=3)
+    frame0()
+    ref = frame0()
+    spin = _lib.HostMailbox.wait
+    _lib.HostMailbox.wait = lambda self, ticket: None          # every spin "times out"
+    try:
+        a = frame0()
+    finally:
+        _lib.HostMailbox.wait = spin
+    assert _lib.HostMailbox.for_device(DEV) is not None and a[1] == ref[1] and torch.equal(a[0], ref[0])
     # a kernel that posts: the rasterizer's counting pass (through the wrapper, which uses the per-device mailbox)
     frame = _gs_frame()
     frame(); frame()                      # the second frame is sized speculatively and takes its counts from the mailbox
