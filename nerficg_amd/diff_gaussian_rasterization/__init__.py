@@ -101,7 +101,7 @@ SPECULATIVE_SIZING = True
 # scatter -- 6-7 us of idle GPU in the kernel trace -- plus ~20 us of host calls, and the copy itself lands ~15 us after the count exists.  With a
 # MAILBOX (include/nerficg_hip.h, nrc_host_mailbox_alloc: pinned, device-mapped, coherent host memory) the last workgroup of the counting kernel
 # stores the two counts and this call's ticket straight into host memory and the host polls the ticket: no event, no copy, no second stream.
-# A mailbox that does not answer within _lib.HostMailbox.TIMEOUT_S (never observed) falls back to a stream synchronize + device read and is not used again.
+# A spin that times out (_lib.HostMailbox.TIMEOUT_S) synchronises the stream and looks again; a mailbox still silent then (never observed) is not used again.
 COUNT_MAILBOX = True
 
 
