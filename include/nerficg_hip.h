@@ -32,8 +32,8 @@ enum {
  * counter[1] = total samples, save buffers padded to nrc_nwie_save_rows); 3 = round 4 (see the notes at the changed entry points);
  * 4 = round 4, later: nrc_gs_preprocess and nrc_ngp_render_count gained count_mailbox / mailbox_ticket, nrc_host_mailbox_alloc / _free are new;
  * nrc_ngp_query_samples gained arena_tile_off / arena_rows, nrc_ngp_composite_image arena_rows, nrc_ngp_render_write accepts ts = NULL;
- * nrc_photometric_loss_* are new. */
-#define NRC_ABI_VERSION 4
+ * nrc_photometric_loss_* are new; 5 = round 5: group 13 (the fused InstantNGP training iteration) is new, nothing else changed. */
+#define NRC_ABI_VERSION 5
 /* library identification; also used by the loader's symbol check */
 int nrc_abi_version(void);
 const char* nrc_build_info(void);
@@ -596,6 +596,68 @@ int nrc_occupancy_carve_finish(const uint8_t* remaining, int32_t cascades, int32
  * ===================================================================================================== */
 int nrc_stage_timer_begin(int32_t capacity);
 int nrc_stage_timer_end(int32_t max_stages, char* names, float* ms, int32_t* count);
+
+/* =====================================================================================================
+ * Group 13 -- the InstantNGP training iteration on device-resident state (round 5).  Replaces, for ONE iteration of
+ *            src/Methods/InstantNGP/Trainer.py:79-94: RayPoolSampler.get (Optim/Samplers/DatasetSamplers.py:53-66: ray_pool[ids]), `torch.rand(3)`,
+ *            InstantNGPRayRenderingComponent.forward + render_rays_training (Renderer.py:55-84), InstantNGPLoss's colour term (Loss.py:15-22: mean
+ *            squared error; the weight-decay term is FusedAdam's L2 slice, group 8), GradScaler.scale / .step / .update (Trainer.py:88-91) and
+ *            FusedAdam.step -- as five enqueue-only calls, 13 kernel launches (the recorded iteration of round 4: 33).  Nothing is read back;
+ *            every count the host may want (marched samples, dropped samples, loss) stays in device memory for the caller to look at when convenient.
+ *
+ *   nrc_ngp_train_march : the batch and its samples.  Ray n of the batch is pool row ids[n] (ids != NULL) or order[cursor[0] + n] (the
+ *            resident sampling order; the call advances cursor[0] by the number of live rays).  n_rays_dev (DEVICE i32[1], NULL = ray_capacity):
+ *            live rays; rows behind them become rays that miss the box (the batch size can change between replays of a recorded iteration).
+ *            Outputs: rays_o (box-centred) / rays_d (ray_capacity,3), hits_t (ray_capacity,2) = [t_in, t_out] clipped to [near, far]
+ *            (nrc_ngp_clip_rays values), target_rgb (ray_capacity,3) = pool_rgb, or lerp(bg, pool_rgb, pool_alpha).clamp(0,1) when pool_alpha is
+ *            given (Datasets/utils.py:185-189), bg (3) = this iteration's random background; then the march of nrc_raymarching_train_capped on
+ *            those rays with jitter noise[n]: rays_a, counter (uncut samples, live rays), xyzs / dirs / deltas / ts (sample_capacity rows, the
+ *            unused tail inert), *overflow (may be NULL).  Random numbers: Philox4x32-10, key = rng_state[0] (seed), counter = (global ray
+ *            index ray_offset + n | iteration rng_state[1]); the call advances rng_state[1].  bg_in (3) / noise_in (ray_capacity), when given,
+ *            are used instead of the draws.  center3 / half3: HOST.  workspace: nrc_ngp_train_march_ws_bytes, ZEROED once by the caller
+ *            (it starts with arrival counters that every call leaves at zero).  ray_capacity <= 32 768 (one wave per ray).
+ *   nrc_ngp_train_query_forward (group 3) on (xyzs, dirs).
+ *   nrc_ngp_train_loss  : compositing, `rgb + (1 - alpha) bg`, mean squared error against target_rgb over the live rays (counter[1]), times
+ *            *loss_scale_dev (NULL = 1), and the whole way back: dL_dsigmas (M), dL_drgbs (M,3) of loss2[1] -- every row written.  loss2[0] =
+ *            the loss, loss2[1] = scaled; ray_rgb / ray_alpha / ray_depth (optional) = the 'rgb' / 'alpha' / 'depth' of Renderer.py:83.  The same
+ *            launch clears zero_a[0, n_zero_a) and zero_b[0, n_zero_b) (f32): what nrc_ngp_train_query_backward_cleared wants cleared.
+ *            workspace: nrc_ngp_train_loss_ws_bytes(ray_capacity), zeroed once.
+ *   nrc_ngp_train_query_backward_cleared : nrc_ngp_train_query_backward_set without its clearing launch; the caller has cleared
+ *            grad_density_params[0, nrc_ngp_train_query_clear_floats(...)) and all of grad_color_params.
+ *   nrc_amp_adam_step (group 8 family): GradScaler.step + FusedAdam(capturable).step + GradScaler.update for the (up to two) tensors of one
+ *            parameter group in two launches.  Launch 1 checks the gradients for inf / NaN; its last workgroup holds or advances *device_step,
+ *            writes bias_corrections (2), state4[1] = found_inf of this step, state4[2] = 1 / scale the gradients carry, and applies torch's
+ *            scale update rule (back off on overflow; grow after growth_interval clean steps) to *scale / *growth_tracker (scale NULL: no
+ *            scaler).  Launch 2 is the Adam update of nrc_adam_step for both tensors (skipped when found_inf).  state4 (f32[4]) and ticket
+ *            (u32[272]: a two-level arrival counter) zeroed once by the caller.  lr_dev (NULL: the host value lr).
+ * ===================================================================================================== */
+int64_t nrc_ngp_train_march_ws_bytes(int64_t ray_capacity, int32_t max_samples);
+int nrc_ngp_train_march(const int64_t* ids, const int64_t* order, int64_t* cursor, const int32_t* n_rays_dev, int64_t ray_capacity, int64_t n_pool,
+                        int64_t ray_offset, const float* pool_origin, const float* pool_dir, const float* pool_rgb, const float* pool_alpha,
+                        const float* center3, const float* half3, float near_plane, float far_plane, const uint8_t* density_bitfield, int32_t cascades,
+                        float scale, float exp_step_factor, int32_t grid_size, int32_t max_samples, uint64_t* rng_state, const float* bg_in,
+                        const float* noise_in, int64_t sample_capacity, float* rays_o, float* rays_d, float* hits_t, float* target_rgb, float* bg,
+                        int64_t* rays_a, int32_t* counter, float* xyzs, float* dirs, float* deltas, float* ts, int64_t* overflow, void* workspace,
+                        nrc_stream_t stream);
+int64_t nrc_ngp_train_loss_ws_bytes(int64_t ray_capacity);
+int nrc_ngp_train_loss(const float* sigmas, const float* rgbs, const float* deltas, const float* ts, const int64_t* rays_a, const int32_t* counter,
+                       int64_t ray_capacity, int64_t sample_capacity, float T_threshold, const float* bg_dev, const float* target_rgb,
+                       const float* loss_scale_dev, float* ray_rgb, float* ray_alpha, float* ray_depth, float* loss2, float* dL_dsigmas, float* dL_drgbs,
+                       float* zero_a, int64_t n_zero_a, float* zero_b, int64_t n_zero_b, void* workspace, nrc_stream_t stream);
+int64_t nrc_ngp_train_query_clear_floats(int64_t M, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale,
+                                         int64_t n_density_mlp_params, int64_t n_density_params);
+int nrc_ngp_train_query_backward_cleared(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01,
+                                         const void* density_weights_f16, const void* color_weights_f16, int32_t n_levels,
+                                         int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, const void* h_f16,
+                                         const void* rgb_f16, const void* save_in_d, const void* save_acts_d, const void* save_in_c,
+                                         const void* save_acts_c, float loss_scale, float* grad_density_params, float* grad_color_params,
+                                         int64_t n_density_mlp_params, int64_t n_density_params, int64_t n_color_params, void* scratch,
+                                         nrc_stream_t stream);
+int nrc_amp_adam_step(float* param_a, const float* grad_a, float* exp_avg_a, float* exp_avg_sq_a, void* param_f16_a, int64_t n_a, float l2_coeff_a,
+                      int64_t l2_count_a, float* param_b, const float* grad_b, float* exp_avg_b, float* exp_avg_sq_b, void* param_f16_b, int64_t n_b,
+                      float l2_coeff_b, int64_t l2_count_b, float lr, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                      int32_t adam_w_mode, int32_t* device_step, float* bias_corrections, float* scale, int32_t* growth_tracker, float growth_factor,
+                      float backoff_factor, int32_t growth_interval, float* state4, void* ticket, nrc_stream_t stream);
 
 #ifdef __cplusplus
 }

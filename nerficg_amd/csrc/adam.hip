@@ -32,17 +32,11 @@ __global__ void k_adam_prepare(int32_t host_step, float beta1, float beta2, cons
     bc[1] = (float)(1.0 - pow((double)beta2, (double)step));
 }
 
+// four consecutive elements starting at i0 (the body of both Adam kernels)
 template <bool ALIGNED>
-__global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                              float lr, float beta1, float beta2, float eps, float weight_decay, int adam_w_mode, float bc1, float bc2,
-                                              const float* __restrict__ bc_dev, const float* __restrict__ lr_dev, const float* __restrict__ grad_scale,
-                                              const float* __restrict__ found_inf, __half* __restrict__ p16, float l2_coeff, int64_t l2_count) {
-    if (found_inf && *found_inf != 0.f) return;  // GradScaler: skip the step, keep the state (and the fp16 copy, which still matches)
-    if (bc_dev) { bc1 = bc_dev[0]; bc2 = bc_dev[1]; }
-    if (lr_dev) lr = *lr_dev;
-    const float inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
-    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= n) return;
+__device__ __forceinline__ void adam_four(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                          int64_t i0, float lr, float beta1, float beta2, float eps, float weight_decay, int adam_w_mode, float bc1, float bc2,
+                                          float inv_scale, __half* __restrict__ p16, float l2_coeff, int64_t l2_count) {
     float pv[4], gv[4], mv[4], vv[4];
     const bool full = ALIGNED && i0 + 3 < n;  // 16-byte vector access needs all four pointers aligned (views into larger tensors may not be)
     if (full) {
@@ -85,6 +79,81 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
                 if (i0 + k < n) p16[i0 + k] = __float2half_rn(pv[k]);
         }
     }
+}
+
+template <bool ALIGNED>
+__global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                              float lr, float beta1, float beta2, float eps, float weight_decay, int adam_w_mode, float bc1, float bc2,
+                                              const float* __restrict__ bc_dev, const float* __restrict__ lr_dev, const float* __restrict__ grad_scale,
+                                              const float* __restrict__ found_inf, __half* __restrict__ p16, float l2_coeff, int64_t l2_count) {
+    if (found_inf && *found_inf != 0.f) return;  // GradScaler: skip the step, keep the state (and the fp16 copy, which still matches)
+    if (bc_dev) { bc1 = bc_dev[0]; bc2 = bc_dev[1]; }
+    if (lr_dev) lr = *lr_dev;
+    const float inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    adam_four<ALIGNED>(p, g, m, v, n, i0, lr, beta1, beta2, eps, weight_decay, adam_w_mode, bc1, bc2, inv_scale, p16, l2_coeff, l2_count);
+}
+
+// ---- GradScaler.step + FusedAdam.step + GradScaler.update of one parameter group as two launches (include/nerficg_hip.h: nrc_amp_adam_step) -------
+struct AmpTensor { float* p; const float* g; float* m; float* v; __half* p16; int64_t n; float l2_coeff; int64_t l2_count; };
+struct AmpList { AmpTensor t[2]; };
+struct AmpState {
+    int32_t* device_step; float* bc;          // step counter (advanced unless an overflow was found), bias corrections (2)
+    float* scale; int32_t* growth_tracker;    // the GradScaler's scalars (scale may be NULL: no scaler)
+    float growth_factor, backoff_factor; int32_t growth_interval;
+    float beta1, beta2;
+    float* state;                             // f32[4]: [0] raw flag of the check (0 on entry, 0 on exit), [1] found_inf of this step, [2] 1 / scale of this step
+    uint32_t* ticket;
+};
+// (1) k_nonfinite_check4 over the gradients; the last workgroup to finish is k_adam_prepare (capturable form) + torch's amp_update_scale kernel
+__global__ void __launch_bounds__(256) k_amp_check_prepare(AmpList l, AmpState a) {
+    const uint32_t* __restrict__ g = reinterpret_cast<const uint32_t*>(l.t[blockIdx.y].g);
+    const int64_t n = l.t[blockIdx.y].n;
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) ? n / 4 : 0;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const uint4 q = reinterpret_cast<const uint4*>(g)[i];
+        bad |= ((q.x & 0x7f800000u) == 0x7f800000u) | ((q.y & 0x7f800000u) == 0x7f800000u) | ((q.z & 0x7f800000u) == 0x7f800000u) |
+               ((q.w & 0x7f800000u) == 0x7f800000u);
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) bad |= (g[i] & 0x7f800000u) == 0x7f800000u;
+    const bool any = __syncthreads_or(bad);
+    if (threadIdx.x == 0 && any) __hip_atomic_store(&a.state[0], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!nrc_last_workgroup(a.ticket, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) || threadIdx.x != 0) return;
+    const bool overflow = __hip_atomic_load(&a.state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.f;
+    int32_t step = *a.device_step;
+    if (!overflow) *a.device_step = ++step;
+    if (step < 1) step = 1;
+    a.bc[0] = (float)(1.0 - pow((double)a.beta1, (double)step));
+    a.bc[1] = (float)(1.0 - pow((double)a.beta2, (double)step));
+    a.state[1] = overflow ? 1.f : 0.f;
+    float scale = a.scale ? *a.scale : 1.f;
+    a.state[2] = 1.0f / scale;
+    if (a.scale) {   // torch/aten/src/ATen/native/cuda/AmpKernels.cu, amp_update_scale_cuda_kernel: back off on an overflow, grow after growth_interval clean steps
+        if (overflow) { *a.scale = scale * a.backoff_factor; *a.growth_tracker = 0; }
+        else {
+            const int32_t ok = *a.growth_tracker + 1;
+            if (ok == a.growth_interval) {
+                const float grown = scale * a.growth_factor;
+                if (isfinite(grown)) *a.scale = grown;
+                *a.growth_tracker = 0;
+            } else *a.growth_tracker = ok;
+        }
+    }
+    __hip_atomic_store(&a.state[0], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (2) Adam on both tensors (blockIdx.y), everything it needs in device scalars
+__global__ void __launch_bounds__(256) k_amp_adam(AmpList l, const float* __restrict__ state, const float* __restrict__ bc, const float* __restrict__ lr_dev,
+                                                  float lr, float beta1, float beta2, float eps, float weight_decay, int adam_w_mode) {
+    if (state[1] != 0.f) return;
+    const AmpTensor t = l.t[blockIdx.y];
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= t.n) return;
+    if (lr_dev) lr = *lr_dev;
+    const bool aligned = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15u) == 0);   // uniform per tensor
+    if (aligned) adam_four<true>(t.p, t.g, t.m, t.v, t.n, i0, lr, beta1, beta2, eps, weight_decay, adam_w_mode, bc[0], bc[1], state[2], t.p16, t.l2_coeff, t.l2_count);
+    else adam_four<false>(t.p, t.g, t.m, t.v, t.n, i0, lr, beta1, beta2, eps, weight_decay, adam_w_mode, bc[0], bc[1], state[2], t.p16, t.l2_coeff, t.l2_count);
 }
 
 // found_inf |= any element of g is inf / NaN.  One 16-byte load per lane and round, exponent test on the raw bits (all ones = inf or NaN), one
@@ -183,6 +252,35 @@ int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
         hipLaunchKernelGGL(k_adam<false>, grid, dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
                            (int)adam_w_mode, bias_correction1, bias_correction2, bias_corrections_dev, lr_dev, grad_scale, found_inf, (__half*)param_f16_out, l2_slice_coeff,
                            l2_slice_count);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_amp_adam_step(float* param_a, const float* grad_a, float* exp_avg_a, float* exp_avg_sq_a, void* param_f16_a, int64_t n_a, float l2_coeff_a,
+                      int64_t l2_count_a, float* param_b, const float* grad_b, float* exp_avg_b, float* exp_avg_sq_b, void* param_f16_b, int64_t n_b,
+                      float l2_coeff_b, int64_t l2_count_b, float lr, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                      int32_t adam_w_mode, int32_t* device_step, float* bias_corrections, float* scale, int32_t* growth_tracker, float growth_factor,
+                      float backoff_factor, int32_t growth_interval, float* state4, void* ticket, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_a < 1 || n_b < 0 || !param_a || !grad_a || !exp_avg_a || !exp_avg_sq_a || (n_b && (!param_b || !grad_b || !exp_avg_b || !exp_avg_sq_b)) ||
+        !device_step || !bias_corrections || !state4 || !ticket || (scale && (!growth_tracker || growth_interval < 1)))
+        return NRC_ERR_INVALID;
+    AmpList l;
+    l.t[0] = AmpTensor{param_a, grad_a, exp_avg_a, exp_avg_sq_a, (__half*)param_f16_a, n_a, l2_coeff_a, l2_count_a};
+    l.t[1] = AmpTensor{param_b, grad_b, exp_avg_b, exp_avg_sq_b, (__half*)param_f16_b, n_b, l2_coeff_b, l2_count_b};
+    const int count = n_b > 0 ? 2 : 1;
+    AmpState a;
+    a.device_step = device_step; a.bc = bias_corrections; a.scale = scale; a.growth_tracker = growth_tracker; a.growth_factor = growth_factor;
+    a.backoff_factor = backoff_factor; a.growth_interval = growth_interval; a.beta1 = beta1; a.beta2 = beta2; a.state = state4; a.ticket = (uint32_t*)ticket;
+    const int64_t largest = n_a > n_b ? n_a : n_b;
+    const int64_t blocks = nrc_cdiv(nrc_cdiv(largest, 4), 256);
+    hipStream_t s = (hipStream_t)stream;
+    NRC_STAGE(s, nullptr);
+    hipLaunchKernelGGL(k_amp_check_prepare, dim3((unsigned)(blocks < 2048 ? blocks : 2048), (unsigned)count), dim3(256), 0, s, l, a);
+    NRC_STAGE(s, "k_amp_check_prepare");
+    hipLaunchKernelGGL(k_amp_adam, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, s, l, (const float*)state4, (const float*)bias_corrections, lr_dev, lr,
+                       beta1, beta2, eps, weight_decay, (int)adam_w_mode);
+    NRC_STAGE(s, "k_amp_adam");
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

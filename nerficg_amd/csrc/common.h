@@ -111,6 +111,33 @@ __device__ __forceinline__ int nrc_block256_excl_scan_i(int v, int* smem, int* b
     return base + incl - v;
 }
 
+// "Am I the last workgroup of this launch to get here?" -- for kernels whose closing step (a scan over per-workgroup results, a final sum)
+// runs in whichever workgroup finishes last instead of in a launch of its own.  A single ticket word serialises: returning atomics on ONE
+// address retire at ~11 ns each on this chip (4 096 workgroups = 47 us, measured on k_amp_check_prepare's first version), so the ticket has
+// two levels -- 16 first-level words on 16 different cache lines, the last arrival of each moves the second-level word.  `tickets`: 17 x 16
+// u32 words (NRC_TICKET_WORDS), zero before the first launch; the last workgroup puts them back to zero.  All threads of the workgroup call
+// this (it contains barriers); results written before the call must have been stored with agent-scope atomics (or be followed by
+// s_waitcnt vmcnt(0), which the call issues) and are to be read back with agent-scope loads.
+#define NRC_TICKET_WORDS (17 * 16)
+__device__ __forceinline__ bool nrc_last_workgroup(uint32_t* tickets, uint32_t block_id, uint32_t n_blocks) {
+    __shared__ bool nrc_last_s;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const uint32_t g = block_id & 15u;
+        const uint32_t in_group = (n_blocks - g + 15u) / 16u;          // workgroups whose id is congruent to g
+        const uint32_t groups = n_blocks < 16u ? n_blocks : 16u;
+        bool last = false;
+        if (__hip_atomic_fetch_add(&tickets[16 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1u)
+            last = __hip_atomic_fetch_add(&tickets[16 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u;
+        if (last)
+            for (int k = 0; k <= 16; k++) __hip_atomic_store(&tickets[16 * k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nrc_last_s = last;
+    }
+    __syncthreads();
+    return nrc_last_s;
+}
+
 // Pixel footprint of a sample-layout tile (= one wave) of the fused InstantNGP image pipeline: 2^NRC_TILE_W_LOG2 x 64/2^NRC_TILE_W_LOG2.
 #ifndef NRC_TILE_W_LOG2
 #define NRC_TILE_W_LOG2 3

@@ -497,6 +497,140 @@ __global__ void __launch_bounds__(256) k_mse_scaled_bw(int64_t n, const float* _
     grad_pred[i] = 2.f / (float)n * (pred[i] - target[i]) * up;
 }
 
+// ---- compositing + colour loss of a fused training iteration, forward AND backward, one launch (include/nerficg_hip.h group 13) -------------------
+// Renderer.py:78-84 (compositing, rgb + (1 - alpha) bg), Loss.py:15-22 (mean squared error against the ray colours), Trainer.py:88 (times the
+// GradScaler's scale) and the way back to dL/dsigma, dL/drgb of every sample: a wave owns a ray, walks it front to back for the sums, turns them into
+// the pixel, the squared error and the pixel's gradient in registers, and walks the ray again for the sample gradients (the second walk hits L2: a
+// ray is ~120 samples x 28 B).  Same expressions as k_composite_train_fw -> k_train_pixels_fw -> k_mse_scaled_fw / _bw -> k_train_pixels_bw ->
+// k_composite_train_bw, which it replaces together with their three clearing launches (nine launches of the recorded iteration of round 4).
+// The loss is summed in a fixed order by the last workgroup to finish (per-ray partials, one ticket), so it is reproducible run to run.
+// Extra workgroups behind the rays' clear what the backward pass of the networks expects cleared: the sample gradients of the rows no ray owns
+// and two caller-given float ranges (the parts of the parameter gradients that are accumulated with atomics).
+struct TrainLoss {
+    const float *sigmas, *rgbs, *deltas, *ts;
+    const int64_t* rays_a;
+    const int32_t* counter;   // [0] marched samples (uncut), [1] live rays
+    const float *bg, *target, *scale;
+    float thr;
+    int64_t n_rays, n_samples;   // capacities
+    float *ray_rgb, *ray_alpha, *ray_depth, *dL_dsigmas, *dL_drgbs, *partial, *loss2;
+    uint32_t* ticket;
+    float* zero0; int64_t n_zero0; float* zero1; int64_t n_zero1;
+};
+__global__ void __launch_bounds__(256) k_train_composite_loss(TrainLoss p) {
+    __shared__ float part_s[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ray_blocks = (p.n_rays + 3) / 4;
+    if ((int64_t)blockIdx.x >= ray_blocks) {   // clearing workgroups (grid-stride over the three ranges)
+        const int64_t stride = ((int64_t)gridDim.x - ray_blocks) * 256;
+        const int64_t i0 = ((int64_t)blockIdx.x - ray_blocks) * 256 + threadIdx.x;
+        const int64_t used = min((int64_t)p.counter[0], p.n_samples);
+        for (int64_t i = used + i0; i < p.n_samples; i += stride) { p.dL_dsigmas[i] = 0.f; p.dL_drgbs[3 * i] = 0.f; p.dL_drgbs[3 * i + 1] = 0.f; p.dL_drgbs[3 * i + 2] = 0.f; }
+        for (int64_t i = i0; i < p.n_zero0; i += stride) p.zero0[i] = 0.f;
+        for (int64_t i = i0; i < p.n_zero1; i += stride) p.zero1[i] = 0.f;
+        return;
+    }
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t n_live = p.counter[1];
+    if (n < p.n_rays) {
+        const int64_t ray_idx = p.rays_a[3 * n], start = p.rays_a[3 * n + 1];
+        const int N = (int)p.rays_a[3 * n + 2];
+        // ---- forward walk (k_composite_train_fw)
+        float carry = 1.0f, accR = 0.f, accG = 0.f, accB = 0.f, accD = 0.f, accO = 0.f;
+        for (int c = 0; c < N; c += 64) {
+            const int i = c + lane;
+            const bool valid = i < N;
+            const int64_t s = start + i;
+            float a = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, tt = 0.f;
+            if (valid) {
+                a = alpha_of(p.sigmas[s], p.deltas[s]);
+                cr = p.rgbs[3 * s]; cg = p.rgbs[3 * s + 1]; cb = p.rgbs[3 * s + 2];
+                tt = p.ts[s];
+            }
+            float Tb, Ta;
+            chunk_transmittance<64>(a, lane, carry, Tb, Ta);
+            const int fs = first_saturated<64>(valid && Ta <= p.thr, lane);
+            if (valid && lane <= fs) {
+                const float w = a * Tb;
+                accR += w * cr; accG += w * cg; accB += w * cb; accD += w * tt; accO += w;
+            }
+            if (fs < 64) break;
+        }
+        const float R = nrc_group_sum<64>(accR), Gc = nrc_group_sum<64>(accG), B = nrc_group_sum<64>(accB);
+        const float D = nrc_group_sum<64>(accD), O = nrc_group_sum<64>(accO);
+        // ---- the pixel, its squared error and its gradient (k_train_pixels_fw, k_mse_scaled_fw / _bw, k_train_pixels_bw)
+        const bool live = ray_idx < n_live;
+        const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
+        float pr, pg, pb;
+        {
+#pragma clang fp contract(off)   // rgb + (1 - a) * bg with two roundings, like the torch expression
+            const float see_through = 1 - O;
+            pr = R + see_through * bg0; pg = Gc + see_through * bg1; pb = B + see_through * bg2;
+        }
+        const float n_el = (float)max((int64_t)1, 3 * n_live);
+        const float up = p.scale ? p.scale[0] : 1.f;
+        float gR = 0.f, gG = 0.f, gB = 0.f, sq = 0.f;
+        if (live) {
+            const float dr = pr - p.target[3 * ray_idx], dg = pg - p.target[3 * ray_idx + 1], db = pb - p.target[3 * ray_idx + 2];
+            sq = dr * dr + dg * dg + db * db;
+            gR = 2.f / n_el * dr * up; gG = 2.f / n_el * dg * up; gB = 2.f / n_el * db * up;
+        }
+        const float gO = 0.f - (gR * bg0 + gG * bg1 + gB * bg2);
+        if (lane == 0) {
+            if (p.ray_rgb) { p.ray_rgb[3 * ray_idx] = pr; p.ray_rgb[3 * ray_idx + 1] = pg; p.ray_rgb[3 * ray_idx + 2] = pb; }
+            if (p.ray_alpha) p.ray_alpha[ray_idx] = O;
+            if (p.ray_depth) p.ray_depth[ray_idx] = D / (O + 1e-6f);
+            __hip_atomic_store(&p.partial[ray_idx], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- backward walk (k_composite_train_bw without dL/dws and dL/ddepth); rows behind the saturating sample get zeros
+        float cr_ = 0.f, cg_ = 0.f, cb_ = 0.f;
+        carry = 1.0f;
+        bool open = true;
+        for (int c = 0; c < N; c += 64) {
+            const int i = c + lane;
+            const bool valid = i < N;
+            const int64_t s = start + i;
+            if (!open) {
+                if (valid) { p.dL_dsigmas[s] = 0.f; p.dL_drgbs[3 * s] = 0.f; p.dL_drgbs[3 * s + 1] = 0.f; p.dL_drgbs[3 * s + 2] = 0.f; }
+                continue;
+            }
+            float a = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, dl = 0.f;
+            if (valid) {
+                dl = p.deltas[s];
+                a = alpha_of(p.sigmas[s], dl);
+                sr = p.rgbs[3 * s]; sg = p.rgbs[3 * s + 1]; sb = p.rgbs[3 * s + 2];
+            }
+            float Tb, Ta;
+            chunk_transmittance<64>(a, lane, carry, Tb, Ta);
+            const float w = a * Tb;
+            const float r = cr_ + nrc_group_incl_sum<64>(w * sr, lane);
+            const float g = cg_ + nrc_group_incl_sum<64>(w * sg, lane);
+            const float b = cb_ + nrc_group_incl_sum<64>(w * sb, lane);
+            cr_ = __shfl(r, 63, 64); cg_ = __shfl(g, 63, 64); cb_ = __shfl(b, 63, 64);
+            const int fs = first_saturated<64>(valid && Ta <= p.thr, lane);
+            if (valid) {
+                const bool in = lane <= fs;
+                p.dL_drgbs[3 * s] = in ? gR * w : 0.f; p.dL_drgbs[3 * s + 1] = in ? gG * w : 0.f; p.dL_drgbs[3 * s + 2] = in ? gB * w : 0.f;
+                p.dL_dsigmas[s] = in ? dl * (gR * (sr * Ta - (R - r)) + gG * (sg * Ta - (Gc - g)) + gB * (sb * Ta - (B - b)) + gO * (1 - O)) : 0.f;
+            }
+            if (fs < 64) open = false;
+        }
+    }
+    // ---- the last workgroup of the rays' sums the per-ray squared errors in a fixed order
+    if (!nrc_last_workgroup(p.ticket, blockIdx.x, (uint32_t)ray_blocks)) return;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < p.n_rays; i += 256) acc += __hip_atomic_load(&p.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    acc = nrc_group_sum<64>(acc);
+    if (lane == 0) part_s[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = part_s[0] + part_s[1] + part_s[2] + part_s[3];
+        const float mean = tot / (float)max((int64_t)1, 3 * n_live);
+        p.loss2[0] = mean;
+        p.loss2[1] = mean * (p.scale ? p.scale[0] : 1.f);
+    }
+}
+
 static void zero_arrays(hipStream_t s, void* p0, int64_t b0, void* p1 = nullptr, int64_t b1 = 0, void* p2 = nullptr, int64_t b2 = 0, void* p3 = nullptr,
                         int64_t b3 = 0, void* p4 = nullptr, int64_t b4 = 0) {
     ZeroList z;
@@ -610,6 +744,33 @@ int nrc_mse_scaled_backward(int64_t n, const float* pred, const float* target, c
     if (n <= 0 || n > (int64_t(1) << 24) || !pred || !target || !grad_pred) return NRC_ERR_INVALID;
     hipLaunchKernelGGL(k_mse_scaled_bw, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, pred, target, scale, g_loss, g_scaled,
                        grad_pred);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int64_t nrc_ngp_train_loss_ws_bytes(int64_t ray_capacity) { return ray_capacity < 0 ? NRC_ERR_INVALID : NRC_TICKET_WORDS * 4 + ray_capacity * 4; }
+int nrc_ngp_train_loss(const float* sigmas, const float* rgbs, const float* deltas, const float* ts, const int64_t* rays_a, const int32_t* counter,
+                       int64_t ray_capacity, int64_t sample_capacity, float T_threshold, const float* bg_dev, const float* target_rgb,
+                       const float* loss_scale_dev, float* ray_rgb, float* ray_alpha, float* ray_depth, float* loss2, float* dL_dsigmas, float* dL_drgbs,
+                       float* zero_a, int64_t n_zero_a, float* zero_b, int64_t n_zero_b, void* workspace, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (ray_capacity < 1 || sample_capacity < 1 || n_zero_a < 0 || n_zero_b < 0) return NRC_ERR_INVALID;
+    if (!sigmas || !rgbs || !deltas || !ts || !rays_a || !counter || !bg_dev || !target_rgb || !loss2 || !dL_dsigmas || !dL_drgbs || !workspace ||
+        (n_zero_a && !zero_a) || (n_zero_b && !zero_b))
+        return NRC_ERR_INVALID;
+    TrainLoss p;
+    p.sigmas = sigmas; p.rgbs = rgbs; p.deltas = deltas; p.ts = ts; p.rays_a = rays_a; p.counter = counter; p.bg = bg_dev; p.target = target_rgb;
+    p.scale = loss_scale_dev; p.thr = T_threshold; p.n_rays = ray_capacity; p.n_samples = sample_capacity; p.ray_rgb = ray_rgb; p.ray_alpha = ray_alpha;
+    p.ray_depth = ray_depth; p.dL_dsigmas = dL_dsigmas; p.dL_drgbs = dL_drgbs; p.ticket = (uint32_t*)workspace; p.partial = (float*)((char*)workspace + NRC_TICKET_WORDS * 4);
+    p.loss2 = loss2; p.zero0 = zero_a; p.n_zero0 = n_zero_a; p.zero1 = zero_b; p.n_zero1 = n_zero_b;
+    const int64_t big = n_zero_a > n_zero_b ? n_zero_a : n_zero_b;
+    int64_t clear_blocks = nrc_cdiv(big > sample_capacity ? big : sample_capacity, 256 * 4);
+    if (clear_blocks < 1) clear_blocks = 1;
+    if (clear_blocks > 1024) clear_blocks = 1024;
+    hipStream_t s = (hipStream_t)stream;
+    NRC_STAGE(s, nullptr);
+    hipLaunchKernelGGL(k_train_composite_loss, dim3((unsigned)(nrc_cdiv(ray_capacity, 4) + clear_blocks)), dim3(256), 0, s, p);
+    NRC_STAGE(s, "k_train_composite_loss");
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -393,28 +393,13 @@ __global__ void __launch_bounds__(256) k_march_write(const float* __restrict__ r
 // takes the next 64 candidates of one ray at once: the chain of 64 additions runs on the VALU, the 64 occupancy probes are
 // independent loads, and the sequential semantics -- which candidates the reference loop actually visits -- are replayed on
 // the ballots with a scalar loop (one turn per visited empty cell or run of samples).  Bit-identical to the per-thread loop.
+// the march of ONE ray by one wave (all 64 lanes call this with the same ray): returns the number of samples, parks their t (count pass) or writes
+// the sample rows (write pass)
 template <bool WRITE>
-__global__ void __launch_bounds__(256) k_march_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                    const float* __restrict__ hits_t, const float* __restrict__ noise, MarchCfg c,
-                                                    int64_t n_rays, int32_t* __restrict__ counts, int32_t* __restrict__ block_sums,
-                                                    const int64_t* __restrict__ rays_a, float* __restrict__ xyzs,
-                                                    float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts,
-                                                    float* __restrict__ park) {
-    __shared__ uint32_t s_lut[MARCH_LUT_MAX];
-    march_lut(c, s_lut);
+__device__ __forceinline__ int wave_march_ray(const Ray& q, float t1, const float t2, const MarchCfg& c, const uint32_t* s_lut, const int N, const int64_t start,
+                                              float* __restrict__ park_row, float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
+                                              float* __restrict__ ts) {
     const int lane = threadIdx.x & 63;
-    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= n_rays) return;
-    int64_t r = n, start = 0;
-    int N = c.max_samples;
-    if (WRITE) {
-        r = rays_a[3 * n]; start = rays_a[3 * n + 1]; N = (int)rays_a[3 * n + 2];
-        if (N == 0) return;
-    }
-    const Ray q = load_ray(rays_o, rays_d, r);
-    float t1 = hits_t[2 * r];
-    const float t2 = hits_t[2 * r + 1];
-    if (t1 >= 0) t1 += calc_dt(t1, c.esf, c.max_samples, c.grid_size, c.scale) * noise[r];
     float t = t1;                                     // wave-uniform: first candidate of the next chunk
     float skip_until = -__builtin_inff();             // wave-uniform: candidates below it are jumped over (empty-cell skip)
     int s = 0;
@@ -459,8 +444,8 @@ __global__ void __launch_bounds__(256) k_march_wave(const float* __restrict__ ra
                 pos = j + 1;                                       // (the reference's do-while advances at least once)
             }
         }
-        if (!WRITE && park && ((samples >> lane) & 1ull))  // the count pass parks the sample positions: k_march_expand instead of a second march
-            park[r * c.max_samples + s_before + __popcll(samples & ((1ull << lane) - 1ull))] = my_t;
+        if (!WRITE && park_row && ((samples >> lane) & 1ull))  // the count pass parks the sample positions: k_march_expand instead of a second march
+            park_row[s_before + __popcll(samples & ((1ull << lane) - 1ull))] = my_t;
         if (WRITE && ((samples >> lane) & 1ull)) {
             const int64_t k = start + s_before + __popcll(samples & ((1ull << lane) - 1ull));
             xyzs[3 * k] = x; xyzs[3 * k + 1] = y; xyzs[3 * k + 2] = z;
@@ -468,6 +453,32 @@ __global__ void __launch_bounds__(256) k_march_wave(const float* __restrict__ ra
             ts[k] = my_t; deltas[k] = dt;
         }
     }
+    return s;
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_march_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                    const float* __restrict__ hits_t, const float* __restrict__ noise, MarchCfg c,
+                                                    int64_t n_rays, int32_t* __restrict__ counts, int32_t* __restrict__ block_sums,
+                                                    const int64_t* __restrict__ rays_a, float* __restrict__ xyzs,
+                                                    float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts,
+                                                    float* __restrict__ park) {
+    __shared__ uint32_t s_lut[MARCH_LUT_MAX];
+    march_lut(c, s_lut);
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_rays) return;
+    int64_t r = n, start = 0;
+    int N = c.max_samples;
+    if (WRITE) {
+        r = rays_a[3 * n]; start = rays_a[3 * n + 1]; N = (int)rays_a[3 * n + 2];
+        if (N == 0) return;
+    }
+    const Ray q = load_ray(rays_o, rays_d, r);
+    float t1 = hits_t[2 * r];
+    const float t2 = hits_t[2 * r + 1];
+    if (t1 >= 0) t1 += calc_dt(t1, c.esf, c.max_samples, c.grid_size, c.scale) * noise[r];
+    const int s = wave_march_ray<WRITE>(q, t1, t2, c, s_lut, N, start, park ? park + r * c.max_samples : nullptr, xyzs, dirs, deltas, ts);
     if (!WRITE && lane == 0) {
         counts[r] = s;
         if (s && block_sums) atomicAdd(&block_sums[r >> 8], s);
@@ -506,6 +517,144 @@ __global__ void __launch_bounds__(256) k_march_expand(const float* __restrict__ 
         dirs[3 * o] = q.dx; dirs[3 * o + 1] = q.dy; dirs[3 * o + 2] = q.dz;
         ts[o] = t;
         deltas[o] = calc_dt(t, c.esf, c.max_samples, c.grid_size, c.dt_scale);
+    }
+}
+
+// ---- the batch of a fused training iteration (include/nerficg_hip.h group 13) -----------------------------------------------------------------
+// What Trainer.py:84-87 + Renderer.py:55-77 + the count pass of the march do before the first network call, as ONE launch: wave n takes ray
+// order[cursor + n] (or ids[n]) out of the resident pool, centres its origin, clips it against the scene box and the depth range, draws its march
+// jitter (Philox4x32-10 keyed by the iteration, counter = the ray's index in the batch: the draw does not depend on how the batch is cut over ranks)
+// and marches it (wave_march_ray: parked positions); the LAST workgroup to finish scans the per-ray counts into rays_a with the capacity cut,
+// writes counter / overflow, and advances the cursor and the iteration counter of the generator -- k_gather_ray_batch, two uniform_ launches,
+// k_clip_rays, k_march_wave and k_scan_assign_cap of the recorded iteration of round 4 (33 us of 4-5 us launches + 63 us).
+struct TrainBatch {
+    const int64_t* ids;          // (ray_capacity) or NULL: then order / cursor
+    const int64_t* order;        // resident sampling order (RandomSequentialSampler's permutation on the device)
+    int64_t* cursor;             // DEVICE i64[1]: first position of this batch; advanced by the batch size
+    const int32_t* n_rays_dev;   // DEVICE i32[1] or NULL: live rays of the batch (<= ray_capacity; the rows behind are inert)
+    int64_t n_pool, ray_offset;  // rays in the pool; index of row 0 in the GLOBAL batch (data parallel: the jitter is a function of the global index)
+    const float *pool_o, *pool_d, *pool_rgb, *pool_alpha;
+    float cx, cy, cz, hx, hy, hz, near_plane, far_plane;
+    uint64_t* rng;               // DEVICE u64[2]: seed, iterations drawn so far (advanced by one)
+    const float *bg_in, *noise_in;   // explicit background colour (3) / jitter (ray_capacity) instead of draws (tests, replays of a recorded batch)
+    float *rays_o, *rays_d, *hits_t, *target, *bg_out;
+    int64_t cap;                 // sample capacity
+    int64_t* rays_a; int32_t* counter; int64_t* overflow; uint32_t* ticket;
+};
+
+// Philox4x32-10 (Salmon et al. 2011): counter (c0..c3), key (k0, k1) -> four 32-bit words
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
+    }
+    return ctr;
+}
+__device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }   // [0, 1): 24 random bits, like torch's uniform_ for f32
+// stream 0: the jitter of global ray `index`; stream 1: the background colour of the iteration
+__device__ __forceinline__ uint4 train_draw(uint64_t seed, uint64_t iteration, uint32_t stream, uint64_t index) {
+    return philox4x32_10(make_uint4((uint32_t)index, (uint32_t)(index >> 32), (uint32_t)iteration, (uint32_t)(iteration >> 32) ^ (stream << 31)),
+                         make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+}
+
+__global__ void __launch_bounds__(256) k_train_march(TrainBatch b, MarchCfg c, int64_t ray_cap, int32_t* __restrict__ counts, float* __restrict__ park) {
+    __shared__ uint32_t s_lut[MARCH_LUT_MAX];
+    __shared__ int wave_tot[4];
+    __shared__ int64_t carry_s;
+    march_lut(c, s_lut);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+    int64_t n_live = ray_cap;
+    if (b.n_rays_dev) n_live = max((int64_t)0, min((int64_t)*b.n_rays_dev, ray_cap));
+    const uint64_t seed = b.rng ? b.rng[0] : 0ull, iteration = b.rng ? b.rng[1] : 0ull;
+    float bg[3];
+    {
+        const uint4 w = train_draw(seed, iteration, 1u, 0ull);
+        bg[0] = b.bg_in ? b.bg_in[0] : u01(w.x); bg[1] = b.bg_in ? b.bg_in[1] : u01(w.y); bg[2] = b.bg_in ? b.bg_in[2] : u01(w.z);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3) b.bg_out[threadIdx.x] = bg[threadIdx.x];
+    if (n < ray_cap) {
+        int s = 0;
+        if (n < n_live) {
+            int64_t id = b.ids ? b.ids[n] : b.order[*b.cursor + n];
+            if (id < 0) id += b.n_pool;                        // torch's indexing: -1 is the last row
+            const bool ok = id >= 0 && id < b.n_pool;          // out of range: a NaN row, which no loss survives silently (k_gather_ray_batch)
+            const float bad = __int_as_float(0x7fc00000);
+            Ray q;
+            const float gx = ok ? b.pool_o[3 * id] : bad, gy = ok ? b.pool_o[3 * id + 1] : bad, gz = ok ? b.pool_o[3 * id + 2] : bad;
+            q.dx = ok ? b.pool_d[3 * id] : bad; q.dy = ok ? b.pool_d[3 * id + 1] : bad; q.dz = ok ? b.pool_d[3 * id + 2] : bad;
+            // k_clip_rays, same expressions
+            q.ox = gx - b.cx; q.oy = gy - b.cy; q.oz = gz - b.cz;
+            q.dxi = 1.0f / q.dx; q.dyi = 1.0f / q.dy; q.dzi = 1.0f / q.dz;
+            const float ax = (0.0f - b.hx - q.ox) * q.dxi, bx = (0.0f + b.hx - q.ox) * q.dxi;
+            const float ay = (0.0f - b.hy - q.oy) * q.dyi, by = (0.0f + b.hy - q.oy) * q.dyi;
+            const float az = (0.0f - b.hz - q.oz) * q.dzi, bz = (0.0f + b.hz - q.oz) * q.dzi;
+            float ta = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+            float tb = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            if (ta > tb) { ta = -1.0f; tb = -1.0f; }
+            float s0 = -1.0f, s1 = -1.0f;
+            if (tb > 0) { s0 = fmaxf(ta, 0.0f); s1 = tb; }
+            const float h0 = fmaxf(s0, b.near_plane), t2 = fminf(s1, b.far_plane);
+            const float jitter = b.noise_in ? b.noise_in[n] : u01(train_draw(seed, iteration, 0u, (uint64_t)(b.ray_offset + n)).x);
+            if (lane == 0) {
+                b.rays_o[3 * n] = q.ox; b.rays_o[3 * n + 1] = q.oy; b.rays_o[3 * n + 2] = q.oz;
+                b.rays_d[3 * n] = q.dx; b.rays_d[3 * n + 1] = q.dy; b.rays_d[3 * n + 2] = q.dz;
+                b.hits_t[2 * n] = h0; b.hits_t[2 * n + 1] = t2;
+                if (b.target) {
+                    const float a = b.pool_alpha ? (ok ? b.pool_alpha[id] : bad) : 1.f;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        float v = b.pool_rgb ? (ok ? b.pool_rgb[3 * id + k] : bad) : 0.f;
+                        if (b.pool_alpha) {   // apply_background_color (Datasets/utils.py:185-189): lerp(bg, rgb, alpha).clamp(0, 1), torch's two-branch lerp
+                            const float diff = v - bg[k];
+                            v = a < 0.5f ? fmaf(a, diff, bg[k]) : fmaf(-diff, 1.f - a, v);   // (torch's kernel is built with contraction: one rounding)
+                            v = fminf(fmaxf(v, 0.f), 1.f);
+                        }
+                        b.target[3 * n + k] = v;
+                    }
+                }
+            }
+            float t1 = h0;
+            if (t1 >= 0) t1 += calc_dt(t1, c.esf, c.max_samples, c.grid_size, c.scale) * jitter;
+            s = wave_march_ray<false>(q, t1, t2, c, s_lut, c.max_samples, 0, park + n * c.max_samples, nullptr, nullptr, nullptr, nullptr);
+        } else if (lane == 0) {   // a row behind the live rays: a ray that misses everything
+            b.rays_o[3 * n] = 0.f; b.rays_o[3 * n + 1] = 0.f; b.rays_o[3 * n + 2] = 0.f;
+            b.rays_d[3 * n] = 0.f; b.rays_d[3 * n + 1] = 0.f; b.rays_d[3 * n + 2] = 1.f;
+            b.hits_t[2 * n] = b.near_plane; b.hits_t[2 * n + 1] = -1.f;
+            if (b.target) { b.target[3 * n] = 0.f; b.target[3 * n + 1] = 0.f; b.target[3 * n + 2] = 0.f; }
+        }
+        if (lane == 0) __hip_atomic_store(&counts[n], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the last workgroup to get here: k_scan_assign_cap over all counts, then the cursor and the generator move on
+    if (!nrc_last_workgroup(b.ticket, blockIdx.x, gridDim.x)) return;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < ray_cap; base += 256) {
+        const int64_t r = base + threadIdx.x;
+        const int v = r < ray_cap ? __hip_atomic_load(&counts[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int incl = nrc_wave_incl_sum_i(v, lane);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int64_t off = carry_s;
+        for (int w = 0; w < wave; w++) off += wave_tot[w];
+        if (r < ray_cap) {
+            const int64_t start = off + incl - v;
+            b.rays_a[3 * r] = r;
+            b.rays_a[3 * r + 1] = start + v > b.cap ? min(start, b.cap) : start;
+            b.rays_a[3 * r + 2] = start + v > b.cap ? max(b.cap - start, (int64_t)0) : (int64_t)v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        b.counter[0] = (int32_t)carry_s; b.counter[1] = (int32_t)n_live;
+        if (b.overflow) b.overflow[0] = max(carry_s - b.cap, (int64_t)0);
+        if (b.cursor && !b.ids) *b.cursor += n_live;
+        if (b.rng) b.rng[1] = iteration + 1ull;
     }
 }
 
@@ -1091,6 +1240,45 @@ int nrc_raymarching_train_capped(const float* rays_o, const float* rays_d, const
     hipLaunchKernelGGL(k_scan_assign_cap, dim3(1), dim3(1024), 0, s, (const int32_t*)counts, n_rays, sample_capacity, rays_a, counter, overflow);
     hipLaunchKernelGGL(k_march_expand, dim3((unsigned)(nrc_cdiv(n_rays, 4) + nrc_cdiv(sample_capacity, 256))), dim3(256), 0, s, rays_o, rays_d, c, n_rays,
                        (const int64_t*)rays_a, (const float*)park, xyzs, dirs, deltas, ts, (const int32_t*)counter, sample_capacity);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+static int64_t train_march_head_bytes(int64_t ray_capacity) { return NRC_TICKET_WORDS * 4 + (ray_capacity * 4 + 255) / 256 * 256; }   // [tickets][counts]
+int64_t nrc_ngp_train_march_ws_bytes(int64_t ray_capacity, int32_t max_samples) {
+    if (ray_capacity < 1 || ray_capacity > NRC_WAVE_MARCH_MAX_RAYS || max_samples < 1) return NRC_ERR_INVALID;
+    return train_march_head_bytes(ray_capacity) + ray_capacity * (int64_t)max_samples * 4;
+}
+int nrc_ngp_train_march(const int64_t* ids, const int64_t* order, int64_t* cursor, const int32_t* n_rays_dev, int64_t ray_capacity, int64_t n_pool,
+                        int64_t ray_offset, const float* pool_origin, const float* pool_dir, const float* pool_rgb, const float* pool_alpha,
+                        const float* center3, const float* half3, float near_plane, float far_plane, const uint8_t* density_bitfield, int32_t cascades,
+                        float scale, float exp_step_factor, int32_t grid_size, int32_t max_samples, uint64_t* rng_state, const float* bg_in,
+                        const float* noise_in, int64_t sample_capacity, float* rays_o, float* rays_d, float* hits_t, float* target_rgb, float* bg,
+                        int64_t* rays_a, int32_t* counter, float* xyzs, float* dirs, float* deltas, float* ts, int64_t* overflow, void* workspace,
+                        nrc_stream_t stream) {
+    NRC_ENTER();
+    if (ray_capacity < 1 || ray_capacity > NRC_WAVE_MARCH_MAX_RAYS || sample_capacity < 1 || n_pool < 1 || cascades < 1 || grid_size < 1 || max_samples < 1)
+        return NRC_ERR_INVALID;
+    if ((!ids && (!order || !cursor)) || !pool_origin || !pool_dir || !center3 || !half3 || !density_bitfield || (!rng_state && (!bg_in || !noise_in)) ||
+        (target_rgb && !pool_rgb) || !rays_o || !rays_d || !hits_t || !bg || !rays_a || !counter || !xyzs || !dirs || !deltas || !ts || !workspace)
+        return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    TrainBatch b;
+    b.ids = ids; b.order = order; b.cursor = cursor; b.n_rays_dev = n_rays_dev; b.n_pool = n_pool; b.ray_offset = ray_offset;
+    b.pool_o = pool_origin; b.pool_d = pool_dir; b.pool_rgb = pool_rgb; b.pool_alpha = pool_alpha;
+    b.cx = center3[0]; b.cy = center3[1]; b.cz = center3[2]; b.hx = half3[0]; b.hy = half3[1]; b.hz = half3[2];
+    b.near_plane = near_plane; b.far_plane = far_plane; b.rng = rng_state; b.bg_in = bg_in; b.noise_in = noise_in;
+    b.rays_o = rays_o; b.rays_d = rays_d; b.hits_t = hits_t; b.target = target_rgb; b.bg_out = bg; b.cap = sample_capacity;
+    b.rays_a = rays_a; b.counter = counter; b.overflow = overflow; b.ticket = (uint32_t*)workspace;
+    int32_t* counts = (int32_t*)((char*)workspace + NRC_TICKET_WORDS * 4);
+    float* park = (float*)((char*)workspace + train_march_head_bytes(ray_capacity));
+    const MarchCfg c = make_cfg(density_bitfield, cascades, scale, exp_step_factor, grid_size, max_samples, scale);
+    NRC_STAGE(s, nullptr);
+    hipLaunchKernelGGL(k_train_march, dim3((unsigned)nrc_cdiv(ray_capacity, 4)), dim3(256), 0, s, b, c, ray_capacity, counts, park);
+    NRC_STAGE(s, "k_train_march");
+    hipLaunchKernelGGL(k_march_expand, dim3((unsigned)(nrc_cdiv(ray_capacity, 4) + nrc_cdiv(sample_capacity, 256))), dim3(256), 0, s, (const float*)rays_o,
+                       (const float*)rays_d, c, ray_capacity, (const int64_t*)rays_a, (const float*)park, xyzs, dirs, deltas, ts, (const int32_t*)counter,
+                       sample_capacity);
+    NRC_STAGE(s, "k_march_expand");
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -2510,7 +2510,8 @@ static int train_query_backward_impl(const float* dL_dsigmas, const float* dL_dr
                                  const void* color_weights_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                                  float per_level_scale, const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d,
                                  const void* save_in_c, const void* save_acts_c, float loss_scale, float* grad_density_params, float* grad_color_params,
-                                 int64_t n_density_mlp_params, void* scratch, nrc_stream_t stream, int64_t n_density_params, int64_t n_color_params) {
+                                 int64_t n_density_mlp_params, void* scratch, nrc_stream_t stream, int64_t n_density_params, int64_t n_color_params,
+                                 bool precleared = false) {
     if (M < 0 || !density_weights_f16 || !color_weights_f16 || !grad_density_params || !grad_color_params || n_density_mlp_params < 0) return NRC_ERR_INVALID;
     if (M > 0 && (!dL_dsigmas || !dL_drgbs || !x01 || !h_f16 || !rgb_f16 || !save_in_d || !save_acts_d || !save_in_c || !save_acts_c || !scratch)) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -2529,7 +2530,8 @@ static int train_query_backward_impl(const float* dL_dsigmas, const float* dL_dr
                 if (zero_d > n_density_params) return NRC_ERR_INVALID;
             }
         }
-        hipLaunchKernelGGL(k_zero_two, dim3(512), dim3(256), 0, s, grad_density_params, zero_d, grad_color_params, n_color_params);
+        if (!precleared)   // (nrc_ngp_train_query_backward_cleared: the caller cleared exactly these ranges, nrc_ngp_train_query_clear_floats)
+            hipLaunchKernelGGL(k_zero_two, dim3(512), dim3(256), 0, s, grad_density_params, zero_d, grad_color_params, n_color_params);
     }
     if (M == 0) { NRC_LAUNCH_CHECK(); return NRC_OK; }
     // scratch: [(M x 4 f16)(M f32)(M x 32 f32): unused since the element-wise kernels moved into k_nwie_bwd][d_h16 M x 16 f16][d_in_density 16 x M x 2 f32]
@@ -2577,6 +2579,31 @@ int nrc_ngp_train_query_backward_set(const float* dL_dsigmas, const float* dL_dr
     return train_query_backward_impl(dL_dsigmas, dL_drgbs, M, x01, density_weights_f16, color_weights_f16, n_levels, log2_hashmap_size, base_resolution,
                                      per_level_scale, h_f16, rgb_f16, save_in_d, save_acts_d, save_in_c, save_acts_c, loss_scale, grad_density_params,
                                      grad_color_params, n_density_mlp_params, scratch, stream, n_density_params, n_color_params);
+}
+
+/* leading floats of grad_density_params that nrc_ngp_train_query_backward_cleared expects cleared (all of grad_color_params as well) */
+int64_t nrc_ngp_train_query_clear_floats(int64_t M, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale,
+                                         int64_t n_density_mlp_params, int64_t n_density_params) {
+    if (M < 0 || n_density_mlp_params < 0 || n_density_params < n_density_mlp_params) return NRC_ERR_INVALID;
+    GridCfg g; BucketCfg bc; bool isb[NRC_MAX_LEVELS];
+    if (make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr) != NRC_OK) return NRC_ERR_INVALID;
+    if (M > 0 && gb_will_bucket(M, 1, (const void*)16, g, n_levels, bc, isb)) {
+        const int64_t z = n_density_mlp_params + 2 * (int64_t)g.offset[bc.level[0]];
+        return z > n_density_params ? NRC_ERR_INVALID : z;
+    }
+    return n_density_params;
+}
+int nrc_ngp_train_query_backward_cleared(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01, const void* density_weights_f16,
+                                         const void* color_weights_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
+                                         float per_level_scale, const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d,
+                                         const void* save_in_c, const void* save_acts_c, float loss_scale, float* grad_density_params,
+                                         float* grad_color_params, int64_t n_density_mlp_params, int64_t n_density_params, int64_t n_color_params,
+                                         void* scratch, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_density_params <= 0 || n_color_params <= 0 || !grad_density_params || !grad_color_params || (M > 0 && !scratch)) return NRC_ERR_INVALID;
+    return train_query_backward_impl(dL_dsigmas, dL_drgbs, M, x01, density_weights_f16, color_weights_f16, n_levels, log2_hashmap_size, base_resolution,
+                                     per_level_scale, h_f16, rgb_f16, save_in_d, save_acts_d, save_in_c, save_acts_c, loss_scale, grad_density_params,
+                                     grad_color_params, n_density_mlp_params, scratch, stream, n_density_params, n_color_params, true);
 }
 
 int64_t nrc_ngp_train_query_scratch_bytes(int64_t M) {

@@ -1,0 +1,287 @@
+"""nerficg_amd.ngp_trainer -- the InstantNGP training iteration on device-resident state (include/nerficg_hip.h group 13).
+
+The reference's iteration (src/Methods/InstantNGP/Trainer.py:79-94) is: draw a batch from the ray pool -> random background -> render_rays(train) ->
+MSE + weight decay -> GradScaler.scale / backward -> GradScaler.step(FusedAdam) -> GradScaler.update -> zero_grad.  Through the drop-in modules that
+is ~90 launches and a host read; recorded op by op in a HIP graph (nerficg_amd.graphs.instant_ngp_iteration) 33 launches, 17 of them 4-5 us
+element-wise or fill kernels.  `FusedTrainingIteration` issues the same arithmetic as FIVE library calls / 13 launches on buffers that exist once:
+
+    nrc_ngp_train_march                   batch out of the resident pool + box clipping + jitter / background draws + march (2 launches)
+    nrc_ngp_train_query_forward           encode + both networks                                                          (3)
+    nrc_ngp_train_loss                    compositing, pixel, MSE, x scale, and back to dL/dsigma, dL/drgb; clears what the backward adds into  (1)
+    nrc_ngp_train_query_backward_cleared  both networks + hash-grid backward                                              (5)
+    nrc_amp_adam_step                     inf / NaN check + step counter + scale update, Adam on both parameter vectors    (2)
+
+and -- since the march of batch i + 1 depends on nothing iteration i updates (rays, the occupancy bitfield, a counter-based generator) -- runs that
+march on a forked stream NEXT TO iteration i's backward pass and Adam (`prefetch`): two sets of batch buffers, consumed alternately.  The caller says
+when the bitfield is about to change (`step(prefetch=False)` before an occupancy update), so every batch is marched against the bitfield the
+reference's loop would have used.  With `graph=True` each (buffer set, inline / prefetched march, prefetch on / off) combination is recorded once
+in a HIP graph and replayed.
+
+Parity: tests/test_gpu_ngp_trainer.py -- the same batches, backgrounds and jitter through this class (eager and recorded, with and without
+prefetch) and through the op-by-op loop leave the same parameters within the op-by-op loop's own run-to-run spread.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+__all__ = ['FusedTrainingIteration']
+
+
+class _Batch:
+    """The buffers one marched batch lives in (two of these when the next batch is marched ahead)."""
+
+    def __init__(self, n_rays: int, n_samples: int, dev) -> None:
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.rays_o, self.rays_d, self.target = (torch.zeros(n_rays, 3, **f32) for _ in range(3))
+        self.hits_t = torch.zeros(n_rays, 2, **f32)
+        self.bg = torch.zeros(3, **f32)
+        self.rays_a = torch.zeros(n_rays, 3, dtype=torch.int64, device=dev)
+        self.counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.overflow = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.xyzs, self.dirs = torch.zeros(n_samples, 3, **f32), torch.zeros(n_samples, 3, **f32)
+        self.deltas, self.ts = torch.zeros(n_samples, **f32), torch.zeros(n_samples, **f32)
+
+    def tensors(self):
+        return (self.rays_o, self.rays_d, self.target, self.hits_t, self.bg, self.rays_a, self.counter, self.overflow, self.xyzs, self.dirs, self.deltas, self.ts)
+
+
+class FusedTrainingIteration:
+    """call() -> {'loss', 'rm_samples', 'sample_overflow', 'rgb', 'alpha', 'bg'} (device tensors, overwritten by later calls).
+
+    model / renderer: nerficg_amd.instant_ngp.  optimizer: FusedAdam(capturable=True) over model.parameters() (ONE group holding both parameter
+    vectors, as Trainer.py:35 builds it); its moments, step counter and learning-rate scalar are used in place, so checkpoints and schedulers keep
+    working (`optimizer.param_groups[0]['lr']` is pushed to the device ahead of every call).  scaler: torch.amp.GradScaler or nerficg_amd.amp.GradScaler
+    (its scale / growth tracker are updated on the device by the same rule), or None.
+    ray_pool: {'origin', 'view_direction', 'rgb'[, 'alpha']} f32 on the device (dataset.get_all_rays()).  Batches: `order` (i64 on the device: the
+    sampler's permutation) is consumed front to back from a device cursor, `ray_capacity` rows per call of which `n_rays` are live
+    (`set_batch_size`); `rewind(order)` installs the next epoch's permutation.  Or pass `ids=` (i64, ray_capacity) to a call.
+    weight_decay: coefficient of Loss.py:15's 0.5e-6 * mean(w^2) over the MLP weights, applied as FusedAdam's L2 slice (gradient 2 * weight_decay / n * w
+    inside the Adam kernel); the reported loss is the colour term."""
+
+    T_THRESHOLD = 1e-4
+
+    def __init__(self, model, renderer, optimizer, scaler, camera, ray_pool: dict, ray_capacity: int, sample_capacity: int, order: torch.Tensor | None = None,
+                 seed: int = 0, weight_decay: float = 0.5e-6, prefetch: bool = True, graph: bool = True, ray_offset: int = 0) -> None:
+        if not getattr(optimizer, 'capturable', False):
+            raise RuntimeError('FusedTrainingIteration: build the optimizer as FusedAdam(..., capturable=True)')
+        if len(optimizer.param_groups) != 1:
+            raise RuntimeError('FusedTrainingIteration: one parameter group holding both parameter vectors is expected (Trainer.py:35)')
+        lib = _lib.load()
+        self.model, self.renderer, self.optimizer, self.scaler, self.camera = model, renderer, optimizer, scaler, camera
+        self.dev = dev = model.center.device
+        self.n_cap, self.m_cap = int(ray_capacity), int(sample_capacity)
+        self.ray_offset = int(ray_offset)
+        self.use_graph, self.prefetch_default = bool(graph), bool(prefetch)
+        self.pool = {k: ray_pool[k].contiguous() for k in ('origin', 'view_direction', 'rgb', 'alpha') if ray_pool.get(k) is not None}
+        for k, v in self.pool.items():
+            _lib.check_input(v, k, torch.float32)
+        self.n_pool = self.pool['origin'].shape[0]
+        self.order = None
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._cursor_host = 0
+        if order is not None:
+            self.rewind(order)
+        self.n_rays = self.n_cap
+        self.n_rays_dev = torch.full((1,), self.n_cap, dtype=torch.int32, device=dev)
+        self.rng = torch.tensor([int(seed), 0], dtype=torch.int64, device=dev)
+        self.ids = torch.zeros(self.n_cap, dtype=torch.int64, device=dev)
+        self.bg_in, self.noise_in = torch.zeros(3, device=dev), torch.zeros(self.n_cap, device=dev)
+        self.sets = [_Batch(self.n_cap, self.m_cap, dev), _Batch(self.n_cap, self.m_cap, dev) if prefetch else None]
+        ws_bytes = int(lib.nrc_ngp_train_march_ws_bytes(self.n_cap, renderer.MAX_SAMPLES))
+        if ws_bytes < 0:
+            raise RuntimeError(f'FusedTrainingIteration: ray_capacity {self.n_cap} is outside the wave-per-ray march (1 .. 32768)')
+        self.march_ws = [torch.zeros(ws_bytes, dtype=torch.uint8, device=dev) for s in self.sets if s is not None]
+        # the networks' forward state / outputs, the sample gradients, the parameter gradients: allocated once
+        m, f16, f32 = self.m_cap, torch.float16, torch.float32
+        rows = int(lib.nrc_nwie_save_rows(m))
+        e = lambda *shape, dtype=f32: torch.empty(*shape, dtype=dtype, device=dev)
+        self.x01, self.h, self.rgb16 = e(m, 3), e(m, 16, dtype=f16), e(m, 4, dtype=f16)
+        self.sigmas, self.rgbs = e(m), e(m, 3)
+        self.save = [e(rows, 32, dtype=f16), e(1, rows, 64, dtype=f16), e(rows, 32, dtype=f16), e(2, rows, 64, dtype=f16)]
+        self.fwd_ws = e(int(lib.nrc_ngp_train_query_ws_bytes(m)), dtype=torch.uint8)
+        self.d_sigmas, self.d_rgbs = e(m), e(m, 3)
+        self.ray_rgb, self.ray_alpha = torch.zeros(self.n_cap, 3, device=dev), torch.zeros(self.n_cap, device=dev)
+        self.loss2 = torch.zeros(2, device=dev)
+        self.loss_ws = torch.zeros(int(lib.nrc_ngp_train_loss_ws_bytes(self.n_cap)), dtype=torch.uint8, device=dev)
+        dn, cn = model.encoding_xyz, model.color_mlp_with_encoding
+        self.gd, self.gc = e(dn.params.numel()), e(cn.params.numel())
+        self.bwd_scratch = e(int(lib.nrc_ngp_train_query_scratch_bytes(m)), dtype=torch.uint8)
+        g = dn.grid_cfg
+        self.n_clear = int(lib.nrc_ngp_train_query_clear_floats(m, g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
+                                                                dn.n_mlp_params, dn.params.numel()))
+        if self.n_clear < 0:
+            raise RuntimeError('nrc_ngp_train_query_clear_floats refused the grid configuration')
+        self.amp_state = torch.zeros(4, device=dev)
+        self.amp_ticket = torch.zeros(17 * 16, dtype=torch.int32, device=dev)    # NRC_TICKET_WORDS
+        n_mlp = model.n_mlp_params
+        self.l2 = ((2.0 * float(weight_decay) / n_mlp, model.n_params_encoding_mlp), (2.0 * float(weight_decay) / n_mlp, cn.params.numel())) if weight_decay else ((0.0, 0), (0.0, 0))
+        self._side = torch.cuda.Stream(device=dev) if prefetch else None
+        self._ready: int | None = None      # index of the set that holds the batch marched ahead
+        self._graphs: dict = {}
+        self._signature = None
+        self._explicit = (False, False, False)
+        self.calls = 0
+
+    # ------------------------------------------------------------------------------------------------ sampling state
+    def rewind(self, order: torch.Tensor) -> None:
+        """Install a (new) sampling order -- RandomSequentialSampler's permutation, Samplers/utils.py:30-33 -- and put the cursor at its start.
+        A batch marched ahead from the old order is dropped."""
+        order = order.to(device=self.dev, dtype=torch.int64).contiguous()
+        if self.order is not None and self.order.shape == order.shape:
+            self.order.copy_(order)       # recorded iterations read this buffer
+        else:
+            self.order = order.clone()
+            self._graphs = {}
+        self.cursor.zero_()
+        self._cursor_host = 0
+        self._ready = None
+
+    def set_batch_size(self, n_rays: int) -> None:
+        """Live rays per call from now on (<= ray_capacity): what Trainer.update_batch_size (:70-75) changes every 16 iterations; recorded
+        iterations read it from the device.  A batch already marched ahead keeps its size."""
+        n = int(n_rays)
+        if not 1 <= n <= self.n_cap:
+            raise ValueError(f'batch size {n} outside 1 .. ray_capacity = {self.n_cap}')
+        if n != self.n_rays:
+            self.n_rays = n
+            self.n_rays_dev.fill_(n)
+
+    # ------------------------------------------------------------------------------------------------ the five calls
+    def _state_tensors(self):
+        """Everything whose ADDRESS a recorded iteration holds: when one of them is replaced (load_state_dict, a new occupancy buffer, ...) the
+        recordings are dropped and made again."""
+        opt, m = self.optimizer, self.model
+        group = opt.param_groups[0]
+        dn, cn = m.encoding_xyz, m.color_mlp_with_encoding
+        for p in (dn.params, cn.params):
+            st = opt.state[p]
+            if len(st) == 0:
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        bc, _skipped, step_dev, lr_dev = opt._device_scalars(0, group, self.dev)
+        scale = tracker = None
+        if self.scaler is not None and self.scaler.is_enabled():
+            if self.scaler._scale is None:
+                self.scaler._lazy_init_scale_growth_tracker(self.dev)
+            scale, tracker = self.scaler._scale, self.scaler._growth_tracker
+        return dict(pd=dn.params, pc=cn.params, hd=dn._half_for_optimizer(dn.params), hc=cn._half_for_optimizer(cn.params),
+                    md=opt.state[dn.params]['exp_avg'], vd=opt.state[dn.params]['exp_avg_sq'], mc=opt.state[cn.params]['exp_avg'],
+                    vc=opt.state[cn.params]['exp_avg_sq'], bc=bc, step=step_dev, lr=lr_dev, scale=scale, tracker=tracker, bitfield=m.occupancy_bitfield)
+
+    def _march(self, k: int, st: dict, explicit) -> None:
+        b, m, r, cam = self.sets[k], self.model, self.renderer, self.camera
+        use_ids, use_bg, use_noise = explicit
+        center, half = r._scene_box()
+        p = _lib.ptr
+        _lib.check(_lib.load().nrc_ngp_train_march(
+            p(self.ids) if use_ids else None, p(self.order), p(self.cursor), p(self.n_rays_dev), self.n_cap, self.n_pool, self.ray_offset,
+            p(self.pool['origin']), p(self.pool['view_direction']), p(self.pool.get('rgb')), p(self.pool.get('alpha')), p(center), p(half),
+            float(cam.near_plane), float(cam.far_plane), p(st['bitfield']), m.cascades, float(m.SCALE), 1 / 256 if r.EXPONENTIAL_STEPS else 0.0, m.RESOLUTION,
+            r.MAX_SAMPLES, p(self.rng), p(self.bg_in) if use_bg else None, p(self.noise_in) if use_noise else None, self.m_cap, p(b.rays_o), p(b.rays_d),
+            p(b.hits_t), p(b.target), p(b.bg), p(b.rays_a), p(b.counter), p(b.xyzs), p(b.dirs), p(b.deltas), p(b.ts), p(b.overflow), p(self.march_ws[k]),
+            _lib.stream_of(b.rays_o)), 'ngp_train_march')
+
+    def _update(self, k: int, st: dict) -> None:
+        b, m, lib, p = self.sets[k], self.model, _lib.load(), _lib.ptr
+        dn, cn = m.encoding_xyz, m.color_mlp_with_encoding
+        g = dn.grid_cfg
+        grid = (g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']))
+        mn, sz = self.renderer._box()
+        stream = _lib.stream_of(b.rays_o)
+        M = self.m_cap
+        _lib.check(lib.nrc_ngp_train_query_forward(
+            p(b.xyzs), p(b.dirs), M, p(mn), p(sz), p(st['hd']), p(st['hc']), p(st['hd'][dn.n_mlp_params:]), *grid, p(self.x01), p(self.h), p(self.rgb16),
+            p(self.sigmas), p(self.rgbs), p(self.save[0]), p(self.save[1]), p(self.save[2]), p(self.save[3]), p(self.fwd_ws), stream), 'ngp_train_query_forward')
+        _lib.check(lib.nrc_ngp_train_loss(
+            p(self.sigmas), p(self.rgbs), p(b.deltas), p(b.ts), p(b.rays_a), p(b.counter), self.n_cap, M, self.T_THRESHOLD, p(b.bg), p(b.target), p(st['scale']),
+            p(self.ray_rgb), p(self.ray_alpha), None, p(self.loss2), p(self.d_sigmas), p(self.d_rgbs), p(self.gd), self.n_clear, p(self.gc), self.gc.numel(),
+            p(self.loss_ws), stream), 'ngp_train_loss')
+        _lib.check(lib.nrc_ngp_train_query_backward_cleared(
+            p(self.d_sigmas), p(self.d_rgbs), M, p(self.x01), p(st['hd']), p(st['hc']), *grid, p(self.h), p(self.rgb16), p(self.save[0]), p(self.save[1]),
+            p(self.save[2]), p(self.save[3]), float(dn.loss_scale), p(self.gd), p(self.gc), dn.n_mlp_params, self.gd.numel(), self.gc.numel(),
+            p(self.bwd_scratch), stream), 'ngp_train_query_backward_cleared')
+        group = self.optimizer.param_groups[0]
+        beta1, beta2 = group['betas']
+        sc = self.scaler
+        _lib.check(lib.nrc_amp_adam_step(
+            p(st['pd']), p(self.gd), p(st['md']), p(st['vd']), p(st['hd']), self.gd.numel(), self.l2[0][0], self.l2[0][1],
+            p(st['pc']), p(self.gc), p(st['mc']), p(st['vc']), p(st['hc']), self.gc.numel(), self.l2[1][0], self.l2[1][1],
+            float(group['lr']), p(st['lr']), float(beta1), float(beta2), float(group['eps']), float(group['weight_decay']), self.optimizer.adam_w_mode,
+            p(st['step']), p(st['bc']), p(st['scale']), p(st['tracker']), float(sc.get_growth_factor()) if st['scale'] is not None else 2.0,
+            float(sc.get_backoff_factor()) if st['scale'] is not None else 0.5, int(sc.get_growth_interval()) if st['scale'] is not None else 1,
+            p(self.amp_state), p(self.amp_ticket), stream), 'amp_adam_step')
+
+    def _enqueue(self, cur: int, inline: bool, prefetch: bool, st: dict, explicit) -> None:
+        if inline:
+            self._march(cur, st, explicit)
+        if prefetch:
+            main = torch.cuda.current_stream(self.dev)
+            self._side.wait_stream(main)           # behind the inline march: both move the cursor and the generator
+            with torch.cuda.stream(self._side):
+                self._march(1 - cur, st, explicit)
+        self._update(cur, st)
+        if prefetch:
+            torch.cuda.current_stream(self.dev).wait_stream(self._side)
+
+    # ------------------------------------------------------------------------------------------------ one iteration
+    def __call__(self, ids: torch.Tensor | None = None, bg: torch.Tensor | None = None, noise: torch.Tensor | None = None,
+                 prefetch: bool | None = None) -> dict[str, torch.Tensor]:
+        """One training iteration.  ids / bg / noise: explicit batch rows, background colour and march jitter instead of the resident order and
+        the generator's draws (they apply to the batch marched BY this call: with prefetch on that is the NEXT iteration's batch, so callers
+        that pass explicit values run with prefetch=False).  prefetch=False: do not march ahead -- what the caller says in the iteration in
+        front of an occupancy-grid update."""
+        explicit = (ids is not None, bg is not None, noise is not None)
+        prefetch = (self.prefetch_default and not any(explicit)) if prefetch is None else bool(prefetch)
+        if prefetch and self._side is None:
+            raise RuntimeError('FusedTrainingIteration was built with prefetch=False')
+        if any(explicit) and (prefetch or self._ready is not None):
+            if prefetch:
+                raise ValueError('explicit ids / bg / noise belong to the batch this call marches: pass prefetch=False')
+            self._ready = None      # a batch marched ahead from the resident order is dropped in favour of the explicit one
+        if not explicit[0] and self.order is None:
+            raise RuntimeError('FusedTrainingIteration: no sampling order installed (rewind(order)) and no ids given')
+        if explicit[0]:
+            self.ids.copy_(ids.to(torch.int64), non_blocking=True)
+        if explicit[1]:
+            self.bg_in.copy_(bg, non_blocking=True)
+        if explicit[2]:
+            self.noise_in.copy_(noise, non_blocking=True)
+        inline = self._ready is None
+        cur = 0 if inline else self._ready
+        self.optimizer.sync_hyperparameters()
+        st = self._state_tensors()
+        signature = tuple(None if t is None else t.data_ptr() for t in st.values()) + (self.order.data_ptr() if self.order is not None else 0,)
+        if signature != self._signature:
+            self._graphs, self._signature = {}, signature
+        if not explicit[0]:      # the host mirrors the device cursor: it knows when the order runs out (Samplers/utils.py:22-23)
+            marches = int(inline) + int(prefetch)
+            if self._cursor_host + marches * self.n_rays > self.order.numel():
+                raise RuntimeError('FusedTrainingIteration: the sampling order is used up -- rewind(new_order) first (RandomSequentialSampler.reset)')
+            self._cursor_host += marches * self.n_rays
+        self.calls += 1
+        if self.use_graph and self.calls > 1:     # the first call runs eagerly: lazily created state (scaler scalars, fp16 copies) exists afterwards
+            key = (cur, inline, prefetch, explicit)
+            graph = self._graphs.get(key)
+            if graph is None:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):     # records, does not execute
+                    self._enqueue(cur, inline, prefetch, st, explicit)
+                self._graphs[key] = graph
+            graph.replay()
+        else:
+            self._enqueue(cur, inline, prefetch, st, explicit)
+        self._ready = (1 - cur) if prefetch else None
+        # the kernels wrote the parameters (and their fp16 copies) through raw pointers: tell autograd and every version-keyed cache
+        for net in (self.model.encoding_xyz, self.model.color_mlp_with_encoding):
+            torch.autograd.graph.increment_version(net.params)
+            net._half_written_by_optimizer(net.params)
+        b = self.sets[cur]
+        return {'loss': self.loss2[0], 'rm_samples': b.counter[0], 'sample_overflow': b.overflow[0], 'rgb': self.ray_rgb, 'alpha': self.ray_alpha, 'bg': b.bg}
+
+    def remaining_batches(self) -> int:
+        """Full batches of the current size left in the installed order (host arithmetic, no device read)."""
+        return 0 if self.order is None else (self.order.numel() - self._cursor_host) // self.n_rays

@@ -23,7 +23,7 @@ def golden_dir():
 # in front of 128 parity tests).
 _GPU_ORDER = ('test_gpu_ngp_parity', 'test_gpu_tcnn_parity', 'test_gpu_gs_parity', 'test_gpu_render_parity', 'test_gpu_baseline_size_parity',
               'test_gpu_garden_parity', 'test_gpu_ssim_parity', 'test_gpu_knn_parity', 'test_gpu_gs_densify_parity', 'test_gpu_adam_parity',
-              'test_gpu_fused_training_ops', 'test_gpu_fullsize_properties', 'test_gpu_gs_lifecycle', 'test_gpu_convergence', 'test_gpu_graphs')
+              'test_gpu_fused_training_ops', 'test_gpu_ngp_trainer', 'test_gpu_fullsize_properties', 'test_gpu_gs_lifecycle', 'test_gpu_convergence', 'test_gpu_graphs')
 
 
 def pytest_collection_modifyitems(session, config, items):
