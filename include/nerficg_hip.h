@@ -32,7 +32,8 @@ enum {
  * counter[1] = total samples, save buffers padded to nrc_nwie_save_rows); 3 = round 4 (see the notes at the changed entry points);
  * 4 = round 4, later: nrc_gs_preprocess and nrc_ngp_render_count gained count_mailbox / mailbox_ticket, nrc_host_mailbox_alloc / _free are new;
  * nrc_ngp_query_samples gained arena_tile_off / arena_rows, nrc_ngp_composite_image arena_rows, nrc_ngp_render_write accepts ts = NULL;
- * nrc_photometric_loss_* are new; 5 = round 5: group 13 (the fused InstantNGP training iteration) is new, nothing else changed. */
+ * nrc_photometric_loss_* are new; 5 = round 5: group 13 (the fused InstantNGP training iteration) is new; nrc_ngp_train_query_forward gained
+ * n_samples_dev (NULL = every row, as before). */
 #define NRC_ABI_VERSION 5
 /* library identification; also used by the loader's symbol check */
 int nrc_abi_version(void);
@@ -77,6 +78,14 @@ int nrc_raymarching_train_count(const float* rays_o, const float* rays_d, const 
                                 const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
                                 const float* noise, int32_t grid_size, int32_t max_samples, int64_t n_rays,
                                 int64_t* rays_a, int32_t* counter, void* workspace, nrc_stream_t stream);
+/* nrc_raymarching_train_count for batches of at most 32 768 rays as TWO launches (wave-per-ray march + one workgroup that scans the counts: no block
+ * sums to clear, no separate assignment pass), whose scan also stores (total samples, n_rays, mailbox_ticket) in HOST memory from
+ * nrc_host_mailbox_alloc (group 4) -- the caller polls the ticket and sizes xyzs / dirs / deltas / ts without a device-to-host copy or a stream wait
+ * (the one host read of the reference's training march, custom_functions.py:112-119).  Same rays_a / counter / parked positions as the plain call. */
+int nrc_raymarching_train_count_posted(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield, int32_t cascades,
+                                       float scale, float exp_step_factor, const float* noise, int32_t grid_size, int32_t max_samples, int64_t n_rays,
+                                       int64_t* rays_a, int32_t* counter, void* workspace, int64_t* count_mailbox, int64_t mailbox_ticket,
+                                       nrc_stream_t stream);
 int nrc_raymarching_train_write(const float* rays_o, const float* rays_d, const float* hits_t,
                                 const uint8_t* density_bitfield, int32_t cascades, float scale, float exp_step_factor,
                                 const float* noise, int32_t grid_size, int32_t max_samples, int64_t n_rays,
@@ -232,7 +241,8 @@ int nrc_ngp_train_query_forward(const float* xyzs, const float* dirs, int64_t M,
                                 const void* density_weights_f16, const void* color_weights_f16, const void* table_f16,
                                 int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale,
                                 float* x01, void* h_f16, void* rgb_f16, float* sigmas, float* rgbs, void* save_in_d,
-                                void* save_acts_d, void* save_in_c, void* save_acts_c, void* workspace, nrc_stream_t stream);
+                                void* save_acts_d, void* save_in_c, void* save_acts_c, void* workspace,
+                                const int32_t* n_samples_dev, nrc_stream_t stream);
 int nrc_ngp_train_query_backward(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01,
                                  const void* density_weights_f16, const void* color_weights_f16, int32_t n_levels,
                                  int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, const void* h_f16,
@@ -616,7 +626,8 @@ int nrc_stage_timer_end(int32_t max_stages, char* names, float* ms, int32_t* cou
  *            index ray_offset + n | iteration rng_state[1]); the call advances rng_state[1].  bg_in (3) / noise_in (ray_capacity), when given,
  *            are used instead of the draws.  center3 / half3: HOST.  workspace: nrc_ngp_train_march_ws_bytes, ZEROED once by the caller
  *            (it starts with arrival counters that every call leaves at zero).  ray_capacity <= 32 768 (one wave per ray).
- *   nrc_ngp_train_query_forward (group 3) on (xyzs, dirs).
+ *   nrc_ngp_train_query_forward (group 3) on (xyzs, dirs), n_samples_dev = counter: a launch sized for sample_capacity rows works on the rows that
+ *            hold samples (min(counter[0], sample_capacity)); the same pointer goes to nrc_ngp_train_query_backward_cleared.
  *   nrc_ngp_train_loss  : compositing, `rgb + (1 - alpha) bg`, mean squared error against target_rgb over the live rays (counter[1]), times
  *            *loss_scale_dev (NULL = 1), and the whole way back: dL_dsigmas (M), dL_drgbs (M,3) of loss2[1] -- every row written.  loss2[0] =
  *            the loss, loss2[1] = scaled; ray_rgb / ray_alpha / ray_depth (optional) = the 'rgb' / 'alpha' / 'depth' of Renderer.py:83.  The same
@@ -631,6 +642,14 @@ int nrc_stage_timer_end(int32_t max_stages, char* names, float* ms, int32_t* cou
  *            scaler).  Launch 2 is the Adam update of nrc_adam_step for both tensors (skipped when found_inf).  state4 (f32[4]) and ticket
  *            (u32[272]: a two-level arrival counter) zeroed once by the caller.  lr_dev (NULL: the host value lr).
  * ===================================================================================================== */
+/* InstantNGPModel.weight_decay_mlp (src/Methods/InstantNGP/Model.py:38-44: mean squared MLP weight over both networks) as one launch each way.
+ *   nrc_sum_squares_two: out[0] = (sum a[0,n_a)^2 + sum b[0,n_b)^2) * inv_n, one workgroup, fixed order.
+ *   nrc_clear_seed_two : what stands in front of nrc_ngp_train_query_backward_cleared -- grad_a[0,clear_a) / grad_b[0,clear_b) are cleared, and their
+ *                        leading seed_a / seed_b elements start at coeff * upstream_dev[0] * w instead of zero: the gradient of the weight-decay term
+ *                        (coeff = 2 / n, upstream = dL/d(term), DEVICE scalar) joins the networks' gradients without a dense 12 M-element tensor. */
+int nrc_sum_squares_two(const float* a, int64_t n_a, const float* b, int64_t n_b, float inv_n, float* out, nrc_stream_t stream);
+int nrc_clear_seed_two(float* grad_a, int64_t clear_a, const float* w_a, int64_t seed_a, float* grad_b, int64_t clear_b, const float* w_b, int64_t seed_b,
+                       const float* upstream_dev, float coeff, nrc_stream_t stream);
 int64_t nrc_ngp_train_march_ws_bytes(int64_t ray_capacity, int32_t max_samples);
 int nrc_ngp_train_march(const int64_t* ids, const int64_t* order, int64_t* cursor, const int32_t* n_rays_dev, int64_t ray_capacity, int64_t n_pool,
                         int64_t ray_offset, const float* pool_origin, const float* pool_dir, const float* pool_rgb, const float* pool_alpha,
@@ -652,7 +671,25 @@ int nrc_ngp_train_query_backward_cleared(const float* dL_dsigmas, const float* d
                                          const void* rgb_f16, const void* save_in_d, const void* save_acts_d, const void* save_in_c,
                                          const void* save_acts_c, float loss_scale, float* grad_density_params, float* grad_color_params,
                                          int64_t n_density_mlp_params, int64_t n_density_params, int64_t n_color_params, void* scratch,
-                                         nrc_stream_t stream);
+                                         const int32_t* n_samples_dev, nrc_stream_t fork_stream, nrc_stream_t stream);
+/* nrc_ngp_train_query_backward_cleared + nrc_amp_adam_step as ONE call WITHOUT the pass over the gradients: found_inf is known before the grid
+ * backward starts -- the two network backward launches flag every inf / NaN they hand on (input gradients, weight-gradient sums: state4[0]), and the
+ * hash-grid gradient is a finite-weighted sum of those -- so one thread settles step counter / bias corrections / scale (state4 as in
+ * nrc_amp_adam_step) behind them, and the 49 MB read of nrc_amp_adam_step's check goes away (7 launches: 2 network backward, 1 settle, 3 grid
+ * backward, 1 Adam over both vectors).  fork_stream (optional, also on nrc_ngp_train_query_backward_cleared): a second stream of the caller's on
+ * which the dense levels' atomics run next to the hashed levels' split / accumulate; joined before the call returns.  Same arithmetic per parameter
+ * as nrc_adam_step (csrc/adam_math.h). */
+int nrc_ngp_train_backward_step(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01, const void* density_weights_f16,
+                                const void* color_weights_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
+                                float per_level_scale, const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d,
+                                const void* save_in_c, const void* save_acts_c, float loss_scale, float* grad_density_params,
+                                float* grad_color_params, int64_t n_density_mlp_params, int64_t n_density_params, int64_t n_color_params,
+                                void* scratch, const int32_t* n_samples_dev, float* param_d, float* exp_avg_d, float* exp_avg_sq_d,
+                                void* param_f16_d, float l2_coeff_d, int64_t l2_count_d, float* param_c, float* exp_avg_c, float* exp_avg_sq_c,
+                                void* param_f16_c, float l2_coeff_c, int64_t l2_count_c, float lr, const float* lr_dev, float beta1, float beta2,
+                                float eps, float weight_decay, int32_t adam_w_mode, int32_t* device_step, float* bias_corrections, float* scale,
+                                int32_t* growth_tracker, float growth_factor, float backoff_factor, int32_t growth_interval, float* state4,
+                                nrc_stream_t fork_stream, nrc_stream_t stream);
 int nrc_amp_adam_step(float* param_a, const float* grad_a, float* exp_avg_a, float* exp_avg_sq_a, void* param_f16_a, int64_t n_a, float l2_coeff_a,
                       int64_t l2_count_a, float* param_b, const float* grad_b, float* exp_avg_b, float* exp_avg_sq_b, void* param_f16_b, int64_t n_b,
                       float l2_coeff_b, int64_t l2_count_b, float lr, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,

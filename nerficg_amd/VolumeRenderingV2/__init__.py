@@ -93,6 +93,9 @@ def packbits(density_grid, density_threshold: float, density_bitfield) -> None:
                                         _lib.ptr(density_bitfield), _lib.stream_of(density_grid)), 'packbits')
 
 
+COUNT_MAILBOX = True   # raymarching_train: the sample count reaches the host through a host mailbox (False: device-to-host copy of counter[0])
+
+
 def raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades: int, scale: float, exp_step_factor: float, noise,
                       grid_size: int, max_samples: int, sample_capacity: int | None = None, return_overflow: bool = False):
     """binding.cpp:60-81. Returns [rays_a (N,3) i64, xyzs (M,3), dirs (M,3), deltas (M), ts (M), counter (2) i32], M = counter[0].
@@ -121,12 +124,26 @@ def raymarching_train(rays_o, rays_d, hits_t, density_bitfield, cascades: int, s
         _lib.check(lib.nrc_raymarching_train_capped(*args, total, _lib.ptr(rays_a), _lib.ptr(counter), _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas),
                                                     _lib.ptr(ts), _lib.ptr(overflow), _lib.ptr(ws), st), 'raymarching_train(capped)')
         return [rays_a, xyzs, dirs, deltas, ts, counter] + ([overflow] if return_overflow else [])
-    _lib.check(lib.nrc_raymarching_train_count(*args, _lib.ptr(rays_a), _lib.ptr(counter), _lib.ptr(ws), st), 'raymarching_train(count)')
+    if sample_capacity is None and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('raymarching_train: sizing the sample buffers reads counter[0] on the host, which a stream capture cannot do -- '
+                           'pass sample_capacity (InstantNGPRenderer.sample_capacity / nerficg_amd.graphs.instant_ngp_iteration)')
+    total = None
+    mailbox = _lib.HostMailbox.for_device(dev) if (sample_capacity is None and _PARKED_MARCH and COUNT_MAILBOX and 0 < n <= 32768) else None
+    if mailbox is not None:
+        # the count reaches the host through mapped host memory that the scan kernel writes and this thread polls: no device-to-host copy, no
+        # stream synchronisation (35 us of idle GPU per training iteration through the copy; the same mechanism as the image pipeline's row count)
+        with mailbox.lock:
+            ticket = mailbox.next_ticket()
+            _lib.check(lib.nrc_raymarching_train_count_posted(*args, _lib.ptr(rays_a), _lib.ptr(counter), _lib.ptr(ws), mailbox.ptr, ticket, st),
+                       'raymarching_train(count, posted)')
+            got = mailbox.counts(ticket, dev)
+        if got is not None:
+            total = int(got[0])
+    else:
+        _lib.check(lib.nrc_raymarching_train_count(*args, _lib.ptr(rays_a), _lib.ptr(counter), _lib.ptr(ws), st), 'raymarching_train(count)')
     if sample_capacity is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('raymarching_train: sizing the sample buffers reads counter[0] on the host, which a stream capture cannot do -- '
-                               'pass sample_capacity (InstantNGPRenderer.sample_capacity / nerficg_amd.graphs.instant_ngp_iteration)')
-        total = int(counter[0].item())  # same host sync the reference pays when slicing by counter[0] (custom_functions.py:112-119)
+        if total is None:
+            total = int(counter[0].item())  # same host sync the reference pays when slicing by counter[0] (custom_functions.py:112-119)
     else:
         total = int(sample_capacity)
     xyzs = torch.empty(total, 3, dtype=_f32, device=dev)

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "adam_math.h"
 
 namespace {
 
@@ -50,18 +51,9 @@ __device__ __forceinline__ void adam_four(float* __restrict__ p, const float* __
             pv[k] = in ? p[i0 + k] : 0.f; gv[k] = in ? g[i0 + k] : 0.f; mv[k] = in ? m[i0 + k] : 0.f; vv[k] = in ? v[i0 + k] : 0.f;
         }
     }
+    const NrcAdamHyper h{lr, beta1, beta2, eps, weight_decay, adam_w_mode, bc1, bc2, inv_scale};
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        float gr = gv[k] * inv_scale;
-        if (!adam_w_mode) gr += weight_decay * pv[k];  // L2 mode (apex multi_tensor_adam ADAM_MODE_0)
-        if (i0 + k < l2_count) gr += l2_coeff * pv[k];  // L2 term of the first l2_count elements only (the MLP weights in front of a hash table)
-        mv[k] = beta1 * mv[k] + (1.f - beta1) * gr;
-        vv[k] = beta2 * vv[k] + (1.f - beta2) * gr * gr;
-        const float m_hat = mv[k] / bc1, v_hat = vv[k] / bc2;
-        float update = m_hat / (sqrtf(v_hat) + eps);
-        if (adam_w_mode) update += weight_decay * pv[k];
-        pv[k] -= lr * update;
-    }
+    for (int k = 0; k < 4; k++) nrc_adam_update(pv[k], gv[k], mv[k], vv[k], h, i0 + k < l2_count, l2_coeff);
     if (full) {
         *reinterpret_cast<float4*>(p + i0) = *reinterpret_cast<const float4*>(pv);
         *reinterpret_cast<float4*>(m + i0) = *reinterpret_cast<const float4*>(mv);
@@ -106,21 +98,8 @@ struct AmpState {
     float* state;                             // f32[4]: [0] raw flag of the check (0 on entry, 0 on exit), [1] found_inf of this step, [2] 1 / scale of this step
     uint32_t* ticket;
 };
-// (1) k_nonfinite_check4 over the gradients; the last workgroup to finish is k_adam_prepare (capturable form) + torch's amp_update_scale kernel
-__global__ void __launch_bounds__(256) k_amp_check_prepare(AmpList l, AmpState a) {
-    const uint32_t* __restrict__ g = reinterpret_cast<const uint32_t*>(l.t[blockIdx.y].g);
-    const int64_t n = l.t[blockIdx.y].n;
-    const int64_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) ? n / 4 : 0;
-    bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const uint4 q = reinterpret_cast<const uint4*>(g)[i];
-        bad |= ((q.x & 0x7f800000u) == 0x7f800000u) | ((q.y & 0x7f800000u) == 0x7f800000u) | ((q.z & 0x7f800000u) == 0x7f800000u) |
-               ((q.w & 0x7f800000u) == 0x7f800000u);
-    }
-    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) bad |= (g[i] & 0x7f800000u) == 0x7f800000u;
-    const bool any = __syncthreads_or(bad);
-    if (threadIdx.x == 0 && any) __hip_atomic_store(&a.state[0], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!nrc_last_workgroup(a.ticket, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) || threadIdx.x != 0) return;
+// what ONE thread does once it is known whether the gradients are finite (state[0]): k_adam_prepare (capturable form) + torch's amp_update_scale kernel
+__device__ __forceinline__ void amp_prepare_thread(const AmpState& a) {
     const bool overflow = __hip_atomic_load(&a.state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.f;
     int32_t step = *a.device_step;
     if (!overflow) *a.device_step = ++step;
@@ -142,6 +121,28 @@ __global__ void __launch_bounds__(256) k_amp_check_prepare(AmpList l, AmpState a
         }
     }
     __hip_atomic_store(&a.state[0], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (1) k_nonfinite_check4 over the gradients; the last workgroup to finish is k_adam_prepare (capturable form) + torch's amp_update_scale kernel
+__global__ void __launch_bounds__(256) k_amp_check_prepare(AmpList l, AmpState a) {
+    const uint32_t* __restrict__ g = reinterpret_cast<const uint32_t*>(l.t[blockIdx.y].g);
+    const int64_t n = l.t[blockIdx.y].n;
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) ? n / 4 : 0;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const uint4 q = reinterpret_cast<const uint4*>(g)[i];
+        bad |= ((q.x & 0x7f800000u) == 0x7f800000u) | ((q.y & 0x7f800000u) == 0x7f800000u) | ((q.z & 0x7f800000u) == 0x7f800000u) |
+               ((q.w & 0x7f800000u) == 0x7f800000u);
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) bad |= (g[i] & 0x7f800000u) == 0x7f800000u;
+    const bool any = __syncthreads_or(bad);
+    if (threadIdx.x == 0 && any) __hip_atomic_store(&a.state[0], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!nrc_last_workgroup(a.ticket, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) || threadIdx.x != 0) return;
+    amp_prepare_thread(a);
+}
+// the same closing step as a launch of its own: for callers whose PRODUCERS flag non-finite gradients (state[0]) -- nrc_ngp_train_backward_step
+__global__ void k_amp_prepare(AmpState a) {
+    if (threadIdx.x | blockIdx.x) return;
+    amp_prepare_thread(a);
 }
 // (2) Adam on both tensors (blockIdx.y), everything it needs in device scalars
 __global__ void __launch_bounds__(256) k_amp_adam(AmpList l, const float* __restrict__ state, const float* __restrict__ bc, const float* __restrict__ lr_dev,
@@ -187,6 +188,25 @@ __global__ void __launch_bounds__(256) k_nonfinite_check4(FiniteList l, float* _
 }
 
 }  // namespace
+
+// internal launchers for nrc_ngp_train_backward_step (ngp_net.hip); declared in common.h
+void nrc_launch_amp_prepare(int32_t* device_step, float* bias_corrections, float* scale, int32_t* growth_tracker, float growth_factor, float backoff_factor,
+                            int32_t growth_interval, float beta1, float beta2, float* state4, hipStream_t s) {
+    AmpState a;
+    a.device_step = device_step; a.bc = bias_corrections; a.scale = scale; a.growth_tracker = growth_tracker; a.growth_factor = growth_factor;
+    a.backoff_factor = backoff_factor; a.growth_interval = growth_interval; a.beta1 = beta1; a.beta2 = beta2; a.state = state4; a.ticket = nullptr;
+    hipLaunchKernelGGL(k_amp_prepare, dim3(1), dim3(64), 0, s, a);
+}
+void nrc_launch_amp_adam(float* pa, const float* ga, float* ma, float* va, void* ha, int64_t na, float l2c_a, int64_t l2n_a, float* pb, const float* gb, float* mb,
+                         float* vb, void* hb, int64_t nb, float l2c_b, int64_t l2n_b, const float* state4, const float* bias_corrections, const float* lr_dev, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int adam_w_mode, hipStream_t s) {
+    AmpList l;
+    l.t[0] = AmpTensor{pa, ga, ma, va, (__half*)ha, na, l2c_a, l2n_a};
+    l.t[1] = AmpTensor{pb, gb, mb, vb, (__half*)hb, nb, l2c_b, l2n_b};
+    const int64_t largest = na > nb ? na : nb;
+    hipLaunchKernelGGL(k_amp_adam, dim3((unsigned)nrc_cdiv(nrc_cdiv(largest, 4), 256), (unsigned)(nb > 0 ? 2 : 1)), dim3(256), 0, s, l, state4, bias_corrections, lr_dev, lr,
+                       beta1, beta2, eps, weight_decay, adam_w_mode);
+}
 
 extern "C" {
 

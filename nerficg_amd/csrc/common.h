@@ -152,4 +152,9 @@ void nrc_launch_composite_layers(const void* packed, const float* ts, const int3
                                  const int32_t* row_of, int32_t* row_tile, int64_t row_end, int width, int height, int64_t tile_begin, int64_t n_tiles, int cascades, float esf,
                                  int grid_size, int max_samples, float thr, const float* bg3, float* state, uint8_t* ray_alive, int32_t* next_k,
                                  uint8_t* tile_alive, float* rgb, float* alpha, float* depth, int32_t* skipped_rows, int arena_rows, hipStream_t s);
-
+// internal launchers of the optimizer step (adam.hip), used by nrc_ngp_train_backward_step (ngp_net.hip)
+void nrc_launch_amp_prepare(int32_t* device_step, float* bias_corrections, float* scale, int32_t* growth_tracker, float growth_factor, float backoff_factor,
+                            int32_t growth_interval, float beta1, float beta2, float* state4, hipStream_t s);
+void nrc_launch_amp_adam(float* pa, const float* ga, float* ma, float* va, void* ha, int64_t na, float l2c_a, int64_t l2n_a, float* pb, const float* gb, float* mb,
+                         float* vb, void* hb, int64_t nb, float l2c_b, int64_t l2n_b, const float* state4, const float* bias_corrections, const float* lr_dev, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int adam_w_mode, hipStream_t s);

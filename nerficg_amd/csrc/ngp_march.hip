@@ -329,7 +329,8 @@ __global__ void __launch_bounds__(256) k_assign_rays_a(const int32_t* __restrict
 // rows, counter = (uncut total, n_rays), *overflow = max(total - cap, 0).  Replaces the block-sum clear, k_scan_block_sums, k_assign_rays_a and
 // k_march_cap of a recorded training iteration (a few thousand rays) by one launch.
 __global__ void __launch_bounds__(1024) k_scan_assign_cap(const int32_t* __restrict__ counts, int64_t n_rays, int64_t cap, int64_t* __restrict__ rays_a,
-                                                          int32_t* __restrict__ counter, int64_t* __restrict__ overflow) {
+                                                          int32_t* __restrict__ counter, int64_t* __restrict__ overflow, int64_t* __restrict__ mailbox = nullptr,
+                                                          int64_t mailbox_ticket = 0) {
     __shared__ int wave_tot[16];
     __shared__ int64_t carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -356,6 +357,11 @@ __global__ void __launch_bounds__(1024) k_scan_assign_cap(const int32_t* __restr
     if (threadIdx.x == 0) {
         counter[0] = (int32_t)carry_s; counter[1] = (int32_t)n_rays;
         if (overflow) overflow[0] = max(carry_s - cap, (int64_t)0);
+        if (mailbox) {   // the total straight into mapped host memory, the ticket LAST (nrc_host_mailbox_alloc): the host sizes the sample buffers without a copy or a stream wait
+            __hip_atomic_store(mailbox, carry_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mailbox + 1, n_rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mailbox + 2, mailbox_ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 // Stage D: pass 2 (raymarching.cu:243-279): emit the samples of each ray into its reserved, contiguous segment.
@@ -1173,6 +1179,23 @@ int nrc_raymarching_train_count(const float* rays_o, const float* rays_d, const 
     }
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, n_rays, counter);
     hipLaunchKernelGGL(k_assign_rays_a, dim3(nb), dim3(256), 0, s, counts, block_sums, n_rays, rays_a);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_raymarching_train_count_posted(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* bitfield, int32_t cascades, float scale,
+                                       float esf, const float* noise, int32_t grid_size, int32_t max_samples, int64_t n_rays, int64_t* rays_a, int32_t* counter,
+                                       void* workspace, int64_t* count_mailbox, int64_t mailbox_ticket, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_rays < 1 || n_rays > NRC_WAVE_MARCH_MAX_RAYS || !counter || cascades < 1 || grid_size < 1 || max_samples < 1) return NRC_ERR_INVALID;
+    if (!rays_o || !rays_d || !hits_t || !bitfield || !noise || !rays_a || !workspace || !count_mailbox) return NRC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int32_t* counts = (int32_t*)workspace;
+    float* park = (float*)((char*)workspace + train_ws_head_bytes(n_rays));
+    const MarchCfg c = make_cfg(bitfield, cascades, scale, esf, grid_size, max_samples, scale);
+    hipLaunchKernelGGL(k_march_wave<false>, dim3((unsigned)nrc_cdiv(n_rays, 4)), dim3(256), 0, s, rays_o, rays_d, hits_t, noise, c, n_rays, counts,
+                       (int32_t*)nullptr, (const int64_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, park);
+    hipLaunchKernelGGL(k_scan_assign_cap, dim3(1), dim3(1024), 0, s, (const int32_t*)counts, n_rays, (int64_t)1 << 62, rays_a, counter, (int64_t*)nullptr,
+                       count_mailbox, mailbox_ticket);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

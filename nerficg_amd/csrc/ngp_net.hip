@@ -54,11 +54,16 @@ template <int ENC, int N_HIDDEN, int OUT_ACT, bool SAVE>
 __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input, int in_ld, int64_t M, const __half* __restrict__ W,
                                                   const __half2* __restrict__ table, GridCfg g, int n_out_rows,
                                                   __half* __restrict__ out, int out_ld, int n_store, __half* __restrict__ save_in,
-                                                  __half* __restrict__ save_acts, float* __restrict__ sigmas_f32 = nullptr, float* __restrict__ rgbs_f32 = nullptr) {
+                                                  __half* __restrict__ save_acts, float* __restrict__ sigmas_f32 = nullptr, float* __restrict__ rgbs_f32 = nullptr,
+                                                  const int32_t* __restrict__ m_live = nullptr) {
     // sigmas_f32 / rgbs_f32 (ENC_DIR_H only, training query): the f32 outputs query_model hands to the compositor -- sigma = exp(h0) (TruncExp forward,
     // custom_functions.py:201-204) from the density row this kernel reads anyway, rgb = the three fp16 sigmoid outputs widened -- written by the
     // epilogue instead of a separate element-wise kernel over the two fp16 tensors
+    // m_live (optional, DEVICE): the rows that hold samples -- a launch sized for a row CAPACITY (fixed-capacity training batches) works on those only;
+    // the layout of the saved state keeps following the capacity
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int64_t n_tiles_cap = (M + 31) / 32;
+    if (m_live) M = min(M, (int64_t)max(*m_live, 0));
     const int64_t n_tiles = (M + 31) / 32;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
     const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
@@ -148,7 +153,7 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
             if constexpr (SAVE) {
-                _Float16* p = reinterpret_cast<_Float16*>(save_acts) + ((int64_t)l * n_tiles * 32) * 64 + ((tile * 8 + hh) * 32 + r) * 8;
+                _Float16* p = reinterpret_cast<_Float16*>(save_acts) + ((int64_t)l * n_tiles_cap * 32) * 64 + ((tile * 8 + hh) * 32 + r) * 8;
 #pragma unroll
                 for (int s = 0; s < 4; s++) *reinterpret_cast<h8*>(p + s * 2 * 32 * 8) = H[s];
             }
@@ -211,6 +216,7 @@ struct QueryIn {
                                                                     // row i >> 6 is sample (i >> 6) - tile_off[rt] of its tile; the copy into compact rows is skipped
     const int32_t* row_k;                                           // ... or, for rows in slab-major order, sample row_k[i >> 6] of its tile (tile_off unused)
     float mn[3], sz[3];                                             // xyz_min, xyz_size of the model box (Renderer.py:50)
+    const int32_t* m_live;                                          // SRC_ARRAYS, optional: rows that hold samples (DEVICE), see k_nwie_fwd
 };
 // index of slot i (row i >> 6 of ray tile rt) in `ts`: the slot itself, or its place in the count pass's arena
 __device__ __forceinline__ int64_t ts_slot(const QueryIn& in, int64_t i, int32_t rt) {
@@ -427,9 +433,10 @@ __global__ void __launch_bounds__(256) k_grid_encode_fine(QueryIn in, int64_t ba
 // read once per pair, 8 x 7.7 M records per launch); at this size the positions are 3 MB.  Placement is a speed assumption only: any
 // workgroup-to-XCD mapping gives the same features.
 __global__ void __launch_bounds__(256) k_grid_encode_pairs(QueryIn in, int64_t n, const __half2* __restrict__ table, GridCfg g, uint2* __restrict__ feat,
-                                                           int narrow_levels, int hashed_mode) {
+                                                           int narrow_levels, int hashed_mode, const int32_t* __restrict__ m_live = nullptr) {
     const int pair = (int)(blockIdx.x & 7u);
     const int64_t j = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    if (m_live) n = min(n, ((int64_t)max(*m_live, 0) + 31) / 32 * 32);   // whole MLP tiles of the live rows (the rows behind them hold finite, inert samples)
     if (j >= n) return;
     float px, py, pz;
     if (pair != 0) in.x01_out = nullptr;
@@ -1045,7 +1052,7 @@ static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void
         static const int pairs_mode = [] { const char* e = getenv("NRC_ENC_PAIRS"); return e ? atoi(e) : 1; }();
         if (pairs_mode && n < split_below && base == 0 && lvl_range == (NRC_MAX_LEVELS << 8)) {
             hipLaunchKernelGGL(k_grid_encode_pairs, dim3((unsigned)(8 * nrc_cdiv(n, 256))), dim3(256), 0, s, in, n, (const __half2*)table, g, (uint2*)feat, narrow,
-                               hashed_mode);
+                               hashed_mode, in.m_live);
             return;
         }
     }
@@ -1461,11 +1468,18 @@ template <int N_HIDDEN, int OUT_ACT>
 __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __restrict__ W, int n_out_rows, const __half* __restrict__ d_out,
                                                   const __half* __restrict__ out, int out_ld, const __half* __restrict__ save_in,
                                                   const __half* __restrict__ save_acts, float loss_scale, float* __restrict__ dW,
-                                                  float* __restrict__ d_in, int d_in_pair_major, TrainQ tq = TrainQ{nullptr, nullptr, nullptr, nullptr}) {
+                                                  float* __restrict__ d_in, int d_in_pair_major, TrainQ tq = TrainQ{nullptr, nullptr, nullptr, nullptr},
+                                                  const int32_t* __restrict__ m_live = nullptr, float* __restrict__ bad_flag = nullptr) {
+    // bad_flag (optional, DEVICE f32): set to 1 when a value this kernel hands on -- an input gradient or a weight-gradient sum -- is inf / NaN.
+    // Everything downstream (the hash-grid gradient) is a finite-weighted sum of those, so the flags of the two backward launches ARE the
+    // GradScaler's found_inf, known before the grid backward starts (nrc_ngp_train_backward_step applies the step inside that backward)
+    bool bad = false;
     __shared__ __attribute__((aligned(16))) _Float16 lds[4][2][64 * LDP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     _Float16* T_act = lds[wv][0];
     _Float16* T_dz = lds[wv][1];
+    const int64_t M_cap = M, n_tiles_cap = (M + 31) / 32;   // the layouts (saved state, pair-major input gradients) follow the capacity
+    if (m_live) M = min(M, (int64_t)max(*m_live, 0));       // ... the work the rows that hold samples (see k_nwie_fwd)
     const int64_t n_tiles = (M + 31) / 32;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, n_waves = (int64_t)gridDim.x * 4;
     const float inv_scale = 1.0f / loss_scale;
@@ -1506,7 +1520,7 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
 #pragma unroll
         for (int s = 0; s < 4; s++) t.H0[s] = *reinterpret_cast<const h8*>(a0 + s * 2 * 32 * 8);
         if constexpr (N_HIDDEN > 1) {
-            const _Float16* a1 = a0 + n_tiles * 32 * 64;
+            const _Float16* a1 = a0 + n_tiles_cap * 32 * 64;
 #pragma unroll
             for (int s = 0; s < 4; s++) t.H1[s] = *reinterpret_cast<const h8*>(a1 + s * 2 * 32 * 8);
         }
@@ -1660,10 +1674,11 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 float4 v = make_float4(din[4 * gq] * inv_scale, din[4 * gq + 1] * inv_scale, din[4 * gq + 2] * inv_scale, din[4 * gq + 3] * inv_scale);
+                bad = bad || !(fabsf(v.x) < __builtin_inff()) || !(fabsf(v.y) < __builtin_inff()) || !(fabsf(v.z) < __builtin_inff()) || !(fabsf(v.w) < __builtin_inff());
                 if (d_in_pair_major) {  // [16 pairs][M][2]: what the grid backward reads, coalesced over the samples
                     const int pair = 4 * gq + 2 * hh;
-                    *reinterpret_cast<float2*>(d_in + ((int64_t)pair * M + i) * 2) = make_float2(v.x, v.y);
-                    *reinterpret_cast<float2*>(d_in + ((int64_t)(pair + 1) * M + i) * 2) = make_float2(v.z, v.w);
+                    *reinterpret_cast<float2*>(d_in + ((int64_t)pair * M_cap + i) * 2) = make_float2(v.x, v.y);
+                    *reinterpret_cast<float2*>(d_in + ((int64_t)(pair + 1) * M_cap + i) * 2) = make_float2(v.z, v.w);
                 } else {
                     *reinterpret_cast<float4*>(d_in + i * 32 + 8 * gq + 4 * hh) = v;
                 }
@@ -1698,6 +1713,7 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
 #pragma unroll
                 for (int w = 0; w < 4; w++) v += slot[(w * 16 + reg) * 64 + lane];   // the same order on every run
                 acc[reg] = v;
+                bad |= !(fabsf(v) < __builtin_inff());
             }
             atomic_add_tile(G, ld, n_rows, mt, nt, acc, inv_scale, r, hh);
         }
@@ -1713,6 +1729,7 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
     }
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) reduce_flush(gWop, 64, n_out_rows, 0, nt, gWo[nt]);
+    if (bad_flag && __ballot(bad) != 0ull && lane == 0) __hip_atomic_store(bad_flag, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     NRC_PROBE(121);
 }
 
@@ -1727,15 +1744,17 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
 // d_feat: pair-major [n_levels][M][2] or sample-major (M, 2 n_levels).
 struct LevelList { int n; int level[NRC_MAX_LEVELS]; };
 __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, int pair_major, GridCfg g,
-                                                  int n_levels, LevelList ll, float* __restrict__ grad_table) {
+                                                  int n_levels, LevelList ll, float* __restrict__ grad_table, const int32_t* __restrict__ m_live = nullptr) {
     __shared__ float s_val[4][64][16];
     __shared__ uint32_t s_key[4][64][8];
     const int level = ll.level[blockIdx.y];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t M_cap = M;
+    if (m_live) M = min(M, (int64_t)max(*m_live, 0));
     const bool in_range = i < M;
-    const int64_t ic = in_range ? i : M - 1;
-    const float2 gf = pair_major ? *reinterpret_cast<const float2*>(d_feat + ((int64_t)level * M + ic) * 2)
+    const int64_t ic = in_range ? i : max(M - 1, (int64_t)0);
+    const float2 gf = pair_major ? *reinterpret_cast<const float2*>(d_feat + ((int64_t)level * M_cap + ic) * 2)
                                  : *reinterpret_cast<const float2*>(d_feat + ic * 2 * n_levels + 2 * level);
     const bool live = in_range && !(gf.x == 0.f && gf.y == 0.f);
     if (__ballot(live) == 0ull) return;
@@ -1989,7 +2008,7 @@ static GbLayout gb_layout(int64_t M, int n_bucket_levels, int nb) {
 #define GB_GROUP 16   // levels ranked together: 2 x GB_GROUP rank registers + 2 x GB_GROUP gradient registers per thread (16 = no grouping)
 __global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, GridCfg g, BucketCfg bc,
                                                              uint32_t* __restrict__ seg, uint32_t* __restrict__ wg_max, uint4* __restrict__ records,
-                                                             int64_t rec_per_wg) {
+                                                             int64_t rec_per_wg, const int32_t* __restrict__ m_live = nullptr) {
     // The levels are ranked in groups of GB_GROUP (rank and gradient registers per thread grow with the group).  16 = all levels at once is the
     // measured best: groups of 6 fit 64 VGPRs, i.e. two workgroups per CU, but spill and repeat the barriers (90 us against 56).
     __shared__ uint32_t hist[GB_MAX_BUCKETS], gbase[GB_MAX_BUCKETS], lmax[NRC_MAX_LEVELS], wave_tot[OWN_THREADS / 64];
@@ -1997,6 +2016,8 @@ __global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restric
     const int n_wg = (int)gridDim.x;
     if (threadIdx.x < NRC_MAX_LEVELS) lmax[threadIdx.x] = 0u;
     const int64_t i = (int64_t)blockIdx.x * OWN_THREADS + threadIdx.x;
+    const int64_t M_cap = M;
+    if (m_live) M = min(M, (int64_t)max(*m_live, 0));   // workgroups behind the live rows still publish their (empty) runs
     const bool in_range = i < M;
     float px = 0.f, py = 0.f, pz = 0.f;
     if (in_range) { px = x[3 * i]; py = x[3 * i + 1]; pz = x[3 * i + 2]; }
@@ -2028,7 +2049,7 @@ __global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restric
 #pragma unroll
         for (int kk = 0; kk < GB_GROUP; kk++) {
             gf_all[kk] = make_float2(0.f, 0.f);
-            if (k0 + kk < bc.n_levels && in_range) gf_all[kk] = reinterpret_cast<const float2*>(d_feat)[(int64_t)bc.level[k0 + kk] * M + i];
+            if (k0 + kk < bc.n_levels && in_range) gf_all[kk] = reinterpret_cast<const float2*>(d_feat)[(int64_t)bc.level[k0 + kk] * M_cap + i];
         }
         // pass 1: rank of every item inside its bucket (kept in registers: 4 x 16 bit per level), largest |gradient| per level
         uint32_t rank01[GB_GROUP], rank23[GB_GROUP];
@@ -2122,16 +2143,17 @@ __global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restric
 __global__ void __launch_bounds__(GBA_THREADS) k_gb_accumulate(GridCfg g, BucketCfg bc, int64_t M, int n_wg, const uint32_t* __restrict__ seg,
                                                                const uint32_t* __restrict__ wg_max, const uint4* __restrict__ records, int64_t rec_per_wg,
                                                                float* __restrict__ grad_table, int assign) {
+    const int bid = (int)blockIdx.x;
     extern __shared__ long long fix_acc[];  // [GB_ENTRIES][2]
     __shared__ uint32_t s_max;
     NRC_PROBE_NW(0);
     int li = 0;
-    while (li + 1 < bc.n_levels && (int)blockIdx.x >= bc.bucket0[li + 1]) li++;
+    while (li + 1 < bc.n_levels && bid >= bc.bucket0[li + 1]) li++;
     const int level = bc.level[li];
-    const uint32_t chunk = (uint32_t)((int)blockIdx.x - bc.bucket0[li]);
+    const uint32_t chunk = (uint32_t)(bid - bc.bucket0[li]);
     const uint32_t lo = g.offset[level] + chunk * GB_ENTRIES;
     float scale = 0.f;   // set below, before the first record is added
-    const uint32_t* row = seg + (int64_t)blockIdx.x * n_wg;
+    const uint32_t* row = seg + (int64_t)bid * n_wg;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     enum { UNR = 8, WAVES = GBA_THREADS / 64, PASSES = 8 };
     // Wave wv takes the runs of workgroups w = UNR (wv + WAVES m) + u, batch m = 0, 1, ...; the table entries of 64 of its runs come in
@@ -2301,7 +2323,8 @@ static void pick_bucket_levels(const GridCfg& g, int n_levels, BucketCfg& bc, bo
 
 static int nwie_backward_impl(int64_t M, const void* weights_f16, int32_t n_hidden, int32_t out_act, int32_t n_out_rows, const void* d_out_f16,
                               const void* out_f16, int32_t out_ld, const void* save_in, const void* save_acts, float loss_scale,
-                              float* grad_weights, float* d_in, int32_t d_in_pair_major, nrc_stream_t stream, TrainQ tq) {
+                              float* grad_weights, float* d_in, int32_t d_in_pair_major, nrc_stream_t stream, TrainQ tq, const int32_t* m_live = nullptr,
+                              float* bad_flag = nullptr) {
     if (M < 0 || !weights_f16 || !grad_weights || n_out_rows < 1 || n_out_rows > 16 || out_ld < 4 || out_ld > 16 || !(loss_scale > 0.f)) return NRC_ERR_INVALID;
     if (n_hidden < 1 || n_hidden > 2 || (out_act != ACT_NONE && out_act != ACT_SIGMOID)) return NRC_ERR_UNSUPPORTED;
     if (M == 0) return NRC_OK;
@@ -2315,7 +2338,7 @@ static int nwie_backward_impl(int64_t M, const void* weights_f16, int32_t n_hidd
     hipStream_t s = (hipStream_t)stream;
 #define NRC_BWD(H, A)                                                                                                          \
     hipLaunchKernelGGL((k_nwie_bwd<H, A>), grid, block, 0, s, M, (const __half*)weights_f16, (int)n_out_rows, (const __half*)d_out_f16, \
-                       (const __half*)out_f16, (int)out_ld, (const __half*)save_in, (const __half*)save_acts, loss_scale, grad_weights, d_in, (int)d_in_pair_major, tq)
+                       (const __half*)out_f16, (int)out_ld, (const __half*)save_in, (const __half*)save_acts, loss_scale, grad_weights, d_in, (int)d_in_pair_major, tq, m_live, bad_flag)
     if (n_hidden == 1) { if (out_act == ACT_SIGMOID) NRC_BWD(1, ACT_SIGMOID); else NRC_BWD(1, ACT_NONE); }
     else { if (out_act == ACT_SIGMOID) NRC_BWD(2, ACT_SIGMOID); else NRC_BWD(2, ACT_NONE); }
 #undef NRC_BWD
@@ -2350,6 +2373,23 @@ int64_t nrc_grid_backward_ws_bytes(int64_t M, int32_t n_levels, int32_t log2_has
 
 }  // extern "C"
 
+// the optimizer step behind a training query's backward pass (nrc_ngp_train_backward_step)
+struct TrainStep {
+    float *param_d, *m_d, *v_d; void* h_d; float l2c_d; int64_t l2n_d;
+    float *param_c, *m_c, *v_c; void* h_c; float l2c_c; int64_t l2n_c;
+    float lr; const float* lr_dev; float beta1, beta2, eps, weight_decay; int adam_w_mode;
+    int32_t* device_step; float* bc; float* scale; int32_t* growth_tracker; float growth_factor, backoff_factor; int32_t growth_interval;
+    float* state4; hipStream_t fork_stream;
+    float *grad_d, *grad_c; int64_t n_mlp_d, n_d, n_c;   // gradient vectors and sizes (filled in by train_query_backward_impl)
+};
+// Adam on elements [from, to) of the density vector (l2 slice relative to the vector's start) and, with_colour, on the whole colour vector
+static void step_adam_range(const TrainStep& st, int64_t from, int64_t to, bool with_colour, hipStream_t s) {
+    const int64_t l2n = st.l2n_d > from ? st.l2n_d - from : 0;
+    nrc_launch_amp_adam(st.param_d + from, st.grad_d + from, st.m_d + from, st.v_d + from, st.h_d ? (void*)((__half*)st.h_d + from) : nullptr, to - from, st.l2c_d, l2n,
+                        st.param_c, st.grad_c, st.m_c, st.v_c, st.h_c, with_colour ? st.n_c : 0, st.l2c_c, st.l2n_c, st.state4, st.bc, st.lr_dev, st.lr, st.beta1,
+                        st.beta2, st.eps, st.weight_decay, st.adam_w_mode, s);
+}
+
 // does this call take the bucketed path (all conditions of grid_backward_impl in one place: nrc_ngp_train_query_backward_set needs the answer first)
 static bool gb_will_bucket(int64_t M, int pair_major, const void* workspace, const GridCfg& g, int n_levels, BucketCfg& bc, bool* isb) {
     static const bool allow_owned = [] { const char* e = getenv("NRC_GRID_BWD_OWNED"); return !(e && e[0] == '0'); }();
@@ -2362,7 +2402,7 @@ static bool gb_will_bucket(int64_t M, int pair_major, const void* workspace, con
 // assign != 0: the bucketed levels' slices are WRITTEN (uninitialised memory, no other writer), only valid when gb_will_bucket() holds
 static int grid_backward_impl(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
                               int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table, void* workspace,
-                              nrc_stream_t stream, int assign) {
+                              nrc_stream_t stream, int assign, const int32_t* m_live = nullptr, hipStream_t fork_stream = nullptr) {
     if (M < 0 || !grad_table) return NRC_ERR_INVALID;
     if (M == 0) return NRC_OK;
     if (!x01 || !d_features) return NRC_ERR_INVALID;
@@ -2381,9 +2421,19 @@ static int grid_backward_impl(const float* x01, int64_t M, const float* d_featur
             LevelList rest; rest.n = 0;
             for (int l = 0; l < n_levels; l++) if (!isb[l]) rest.level[rest.n++] = l;
             NRC_STAGE(s, nullptr);
+            // fork_stream (optional): the dense levels' atomics run there, next to the bucketed levels' split / accumulate on `stream` (memory-side
+            // atomics against LDS atomics: 12-17 us of a training iteration); the two events belong to the library
+            enum { MAX_EV = 2 };
+            static hipEvent_t ev[MAX_EV] = {};
+            hipStream_t side = fork_stream ? fork_stream : s;
+            const bool forked = side != s;
+            if (forked) {
+                if (!ev[0]) for (int k = 0; k < MAX_EV; k++) hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+                hipEventRecord(ev[0], s); hipStreamWaitEvent(side, ev[0], 0);
+            }
             if (rest.n > 0)
-                hipLaunchKernelGGL(k_grid_bwd, dim3((unsigned)nrc_cdiv(M, 256), rest.n), dim3(256), 0, s, x01, M, d_features, (int)d_features_pair_major, g,
-                                   (int)n_levels, rest, grad_table);
+                hipLaunchKernelGGL(k_grid_bwd, dim3((unsigned)nrc_cdiv(M, 256), rest.n), dim3(256), 0, side, x01, M, d_features, (int)d_features_pair_major, g,
+                                   (int)n_levels, rest, grad_table, m_live);
             NRC_STAGE(s, "k_grid_bwd");
             const int nb = bc.bucket0[bc.n_levels];
             const GbLayout L = gb_layout(M, bc.n_levels, nb);
@@ -2393,13 +2443,14 @@ static int grid_backward_impl(const float* x01, int64_t M, const float* d_featur
             uint4* records = reinterpret_cast<uint4*>(reinterpret_cast<char*>(workspace) + L.seg_bytes + L.max_bytes);
             static const hipError_t attr_s = hipFuncSetAttribute((const void*)k_gb_split, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * OWN_THREADS * 4 * 16);
             (void)attr_s;
-            hipLaunchKernelGGL(k_gb_split, dim3((unsigned)L.n_wg), dim3(OWN_THREADS), 2 * OWN_THREADS * 4 * 16, s, x01, M, d_features, g, bc, seg, wg_max, records, L.rec_per_wg);
+            hipLaunchKernelGGL(k_gb_split, dim3((unsigned)L.n_wg), dim3(OWN_THREADS), 2 * OWN_THREADS * 4 * 16, s, x01, M, d_features, g, bc, seg, wg_max, records, L.rec_per_wg, m_live);
             NRC_STAGE(s, "k_gb_split");
             static const hipError_t attr_b = hipFuncSetAttribute((const void*)k_gb_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, GB_ENTRIES * 16);
             (void)attr_b;
             hipLaunchKernelGGL(k_gb_accumulate, dim3((unsigned)nb), dim3(GBA_THREADS), GB_ENTRIES * 16, s, g, bc, M, (int)L.n_wg, (const uint32_t*)seg,
                                (const uint32_t*)wg_max, (const uint4*)records, L.rec_per_wg, grad_table, assign);
             NRC_STAGE(s, "k_gb_accumulate");
+            if (forked) { hipEventRecord(ev[1], side); hipStreamWaitEvent(s, ev[1], 0); }
             NRC_LAUNCH_CHECK();
             return NRC_OK;
         }
@@ -2467,7 +2518,7 @@ int nrc_ngp_train_query_forward(const float* xyzs, const float* dirs, int64_t M,
                                 const void* density_weights_f16, const void* color_weights_f16, const void* table_f16, int32_t n_levels,
                                 int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* x01, void* h_f16, void* rgb_f16,
                                 float* sigmas, float* rgbs, void* save_in_d, void* save_acts_d, void* save_in_c, void* save_acts_c, void* workspace,
-                                nrc_stream_t stream) {
+                                const int32_t* n_samples_dev, nrc_stream_t stream) {
     NRC_ENTER();
     if (M < 0 || !density_weights_f16 || !color_weights_f16 || !table_f16 || !xyz_min3 || !xyz_size3) return NRC_ERR_INVALID;
     if (n_levels != 16) return NRC_ERR_UNSUPPORTED;
@@ -2479,7 +2530,7 @@ int nrc_ngp_train_query_forward(const float* xyzs, const float* dirs, int64_t M,
     if (rc != NRC_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     QueryIn qin = {};
-    qin.xyz01 = xyzs; qin.normalise = 1; qin.x01_out = x01;
+    qin.xyz01 = xyzs; qin.normalise = 1; qin.x01_out = x01; qin.m_live = n_samples_dev;
     for (int k = 0; k < 3; k++) { qin.mn[k] = xyz_min3[k]; qin.sz[k] = xyz_size3[k]; }
     NRC_STAGE(s, nullptr);
     launch_encode<SRC_ARRAYS>(qin, 0, M, table_f16, g, (uint4*)workspace, s);
@@ -2487,11 +2538,11 @@ int nrc_ngp_train_query_forward(const float* xyzs, const float* dirs, int64_t M,
     const dim3 grid(pick_blocks(M)), block(256);
     // density net: 32 -> 64 -> 16, linear output, all 16 columns stored (the colour net reads them back)
     hipLaunchKernelGGL((k_nwie_fwd<ENC_FEAT, 1, ACT_NONE, true>), grid, block, 0, s, (const void*)workspace, 0, M, (const __half*)density_weights_f16,
-                       (const __half2*)table_f16, g, 16, (__half*)h_f16, 16, 16, (__half*)save_in_d, (__half*)save_acts_d);
+                       (const __half2*)table_f16, g, 16, (__half*)h_f16, 16, 16, (__half*)save_in_d, (__half*)save_acts_d, (float*)nullptr, (float*)nullptr, n_samples_dev);
     NRC_STAGE(s, "k_nwie_fwd<density>");
     // colour net: [SH(d) | h] -> 64 -> 64 -> 3 (+1 pad), sigmoid
     hipLaunchKernelGGL((k_nwie_fwd<ENC_DIR_H, 2, ACT_SIGMOID, true>), grid, block, 0, s, (const void*)dirs, 0, M, (const __half*)color_weights_f16,
-                       (const __half2*)h_f16, g, 3, (__half*)rgb_f16, 4, 4, (__half*)save_in_c, (__half*)save_acts_c, sigmas, rgbs);
+                       (const __half2*)h_f16, g, 3, (__half*)rgb_f16, 4, 4, (__half*)save_in_c, (__half*)save_acts_c, sigmas, rgbs, n_samples_dev);
     NRC_STAGE(s, "k_nwie_fwd<colour>");
     NRC_LAUNCH_CHECK();
     return NRC_OK;
@@ -2506,12 +2557,40 @@ __global__ void __launch_bounds__(256) k_zero_two(float* __restrict__ a, int64_t
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) b[i] = 0.f;
 }
 
+// ---- Model.weight_decay_mlp (Model.py:38-44) as one launch each way ---------------------------------------------------------------------------------
+// forward: (sum a[0, na)^2 + sum b[0, nb)^2) * inv_n, ONE workgroup, fixed summation order (reproducible)
+__global__ void __launch_bounds__(1024) k_sumsq_two(const float* __restrict__ a, int64_t na, const float* __restrict__ b, int64_t nb, float inv_n, float* __restrict__ out) {
+    __shared__ float part[16];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < na; i += 1024) acc += a[i] * a[i];
+    for (int64_t i = threadIdx.x; i < nb; i += 1024) acc += b[i] * b[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; w++) tot += part[w];
+        out[0] = tot * inv_n;
+    }
+}
+// backward, folded into the clearing of the gradient buffers in front of a training query's backward pass: ga[0, za) and gb[0, zb) are cleared and
+// their leading seed_a / seed_b elements start at coeff * up[0] * w instead of zero (the gradient of up * mean-square: 2 / n * w * up)
+__global__ void __launch_bounds__(256) k_zero_seed_two(float* __restrict__ ga, int64_t za, const float* __restrict__ wa, int64_t seed_a, float* __restrict__ gb, int64_t zb,
+                                                       const float* __restrict__ wb, int64_t seed_b, const float* __restrict__ up, float coeff) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float c = coeff * up[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < za; i += stride) ga[i] = i < seed_a ? c * wa[i] : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < zb; i += stride) gb[i] = i < seed_b ? c * wb[i] : 0.f;
+}
+
 static int train_query_backward_impl(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01, const void* density_weights_f16,
                                  const void* color_weights_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
                                  float per_level_scale, const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d,
                                  const void* save_in_c, const void* save_acts_c, float loss_scale, float* grad_density_params, float* grad_color_params,
                                  int64_t n_density_mlp_params, void* scratch, nrc_stream_t stream, int64_t n_density_params, int64_t n_color_params,
-                                 bool precleared = false) {
+                                 bool precleared = false, const int32_t* m_live = nullptr, const TrainStep* step = nullptr, hipStream_t fork_stream = nullptr) {
     if (M < 0 || !density_weights_f16 || !color_weights_f16 || !grad_density_params || !grad_color_params || n_density_mlp_params < 0) return NRC_ERR_INVALID;
     if (M > 0 && (!dL_dsigmas || !dL_drgbs || !x01 || !h_f16 || !rgb_f16 || !save_in_d || !save_acts_d || !save_in_c || !save_acts_c || !scratch)) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -2542,16 +2621,33 @@ static int train_query_backward_impl(const float* dL_dsigmas, const float* dL_dr
     NRC_STAGE(s, nullptr);
     // colour network: dL/drgb read as it is, the TruncExp backward and the density network's output gradient written by its epilogue (TrainQ)
     int rc = nwie_backward_impl(M, color_weights_f16, 2, ACT_SIGMOID, 3, nullptr, rgb_f16, 4, save_in_c, save_acts_c, loss_scale, grad_color_params, nullptr, 0,
-                                stream, TrainQ{dL_drgbs, dL_dsigmas, (const __half*)h_f16, d_h16});
+                                stream, TrainQ{dL_drgbs, dL_dsigmas, (const __half*)h_f16, d_h16}, m_live, step ? step->state4 : nullptr);
     if (rc != NRC_OK) return rc;
     NRC_STAGE(s, "k_nwie_bwd<colour>");
-    rc = nrc_nwie_backward(M, density_weights_f16, 1, ACT_NONE, 16, d_h16, h_f16, 16, save_in_d, save_acts_d, loss_scale, grad_density_params, d_in_d, 1, stream);
+    rc = nwie_backward_impl(M, density_weights_f16, 1, ACT_NONE, 16, d_h16, h_f16, 16, save_in_d, save_acts_d, loss_scale, grad_density_params, d_in_d, 1, stream,
+                            TrainQ{nullptr, nullptr, nullptr, nullptr}, m_live, step ? step->state4 : nullptr);
     if (rc != NRC_OK) return rc;
     NRC_STAGE(s, "k_nwie_bwd<density>");
     void* grid_ws = (char*)d_in_d + M * 128;  // nrc_grid_backward_ws_bytes (all levels at most) behind the pair-major gradients
+    TrainStep st;
+    if (step) {
+        // found_inf is known: the two launches above flagged every non-finite value they handed on.  Step counter, bias corrections, 1 / scale
+        // and the scale update in one thread in front of the grid backward (measured: Adam level group by level group on the fork stream next to the
+        // accumulation of the next group -- 0.413 against 0.380 ms per iteration; the step inside the slice owners -- 0.386; both dropped, LABBOOK.md)
+        nrc_launch_amp_prepare(step->device_step, step->bc, step->scale, step->growth_tracker, step->growth_factor, step->backoff_factor, step->growth_interval,
+                               step->beta1, step->beta2, step->state4, s);
+        NRC_STAGE(s, "k_amp_prepare");
+        st = *step;
+        st.grad_d = grad_density_params; st.grad_c = grad_color_params; st.n_mlp_d = n_density_mlp_params; st.n_d = n_density_params; st.n_c = n_color_params;
+    }
     rc = grid_backward_impl(x01, M, d_in_d, 1, n_levels, log2_hashmap_size, base_resolution, per_level_scale, grad_density_params + n_density_mlp_params,
-                            grid_ws, stream, assign);
+                            grid_ws, stream, assign, m_live, fork_stream);
     if (rc != NRC_OK) return rc;
+    if (step) {   // one Adam launch over everything, no pass over the gradients in front of it
+        NRC_STAGE(s, nullptr);
+        step_adam_range(st, 0, n_density_params, true, s);
+        NRC_STAGE(s, "k_amp_adam");
+    }
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }
@@ -2598,12 +2694,61 @@ int nrc_ngp_train_query_backward_cleared(const float* dL_dsigmas, const float* d
                                          float per_level_scale, const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d,
                                          const void* save_in_c, const void* save_acts_c, float loss_scale, float* grad_density_params,
                                          float* grad_color_params, int64_t n_density_mlp_params, int64_t n_density_params, int64_t n_color_params,
-                                         void* scratch, nrc_stream_t stream) {
+                                         void* scratch, const int32_t* n_samples_dev, nrc_stream_t fork_stream, nrc_stream_t stream) {
     NRC_ENTER();
     if (n_density_params <= 0 || n_color_params <= 0 || !grad_density_params || !grad_color_params || (M > 0 && !scratch)) return NRC_ERR_INVALID;
     return train_query_backward_impl(dL_dsigmas, dL_drgbs, M, x01, density_weights_f16, color_weights_f16, n_levels, log2_hashmap_size, base_resolution,
                                      per_level_scale, h_f16, rgb_f16, save_in_d, save_acts_d, save_in_c, save_acts_c, loss_scale, grad_density_params,
-                                     grad_color_params, n_density_mlp_params, scratch, stream, n_density_params, n_color_params, true);
+                                     grad_color_params, n_density_mlp_params, scratch, stream, n_density_params, n_color_params, true, n_samples_dev, nullptr, (hipStream_t)fork_stream);
+}
+
+int nrc_ngp_train_backward_step(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01, const void* density_weights_f16,
+                                const void* color_weights_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale,
+                                const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d, const void* save_in_c,
+                                const void* save_acts_c, float loss_scale, float* grad_density_params, float* grad_color_params, int64_t n_density_mlp_params,
+                                int64_t n_density_params, int64_t n_color_params, void* scratch, const int32_t* n_samples_dev, float* param_d, float* exp_avg_d,
+                                float* exp_avg_sq_d, void* param_f16_d, float l2_coeff_d, int64_t l2_count_d, float* param_c, float* exp_avg_c,
+                                float* exp_avg_sq_c, void* param_f16_c, float l2_coeff_c, int64_t l2_count_c, float lr, const float* lr_dev, float beta1,
+                                float beta2, float eps, float weight_decay, int32_t adam_w_mode, int32_t* device_step, float* bias_corrections, float* scale,
+                                int32_t* growth_tracker, float growth_factor, float backoff_factor, int32_t growth_interval, float* state4,
+                                nrc_stream_t fork_stream, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_density_params <= 0 || n_color_params <= 0 || !grad_density_params || !grad_color_params || (M > 0 && !scratch) || !param_d || !exp_avg_d ||
+        !exp_avg_sq_d || !param_c || !exp_avg_c || !exp_avg_sq_c || !device_step || !bias_corrections || !state4 || (scale && (!growth_tracker || growth_interval < 1)) ||
+        l2_count_d > n_density_mlp_params)
+        return NRC_ERR_INVALID;
+    TrainStep st;
+    st.param_d = param_d; st.m_d = exp_avg_d; st.v_d = exp_avg_sq_d; st.h_d = param_f16_d; st.l2c_d = l2_coeff_d; st.l2n_d = l2_count_d;
+    st.param_c = param_c; st.m_c = exp_avg_c; st.v_c = exp_avg_sq_c; st.h_c = param_f16_c; st.l2c_c = l2_coeff_c; st.l2n_c = l2_count_c;
+    st.lr = lr; st.lr_dev = lr_dev; st.beta1 = beta1; st.beta2 = beta2; st.eps = eps; st.weight_decay = weight_decay; st.adam_w_mode = adam_w_mode;
+    st.device_step = device_step; st.bc = bias_corrections; st.scale = scale; st.growth_tracker = growth_tracker; st.growth_factor = growth_factor;
+    st.backoff_factor = backoff_factor; st.growth_interval = growth_interval; st.state4 = state4; st.fork_stream = (hipStream_t)fork_stream;
+    return train_query_backward_impl(dL_dsigmas, dL_drgbs, M, x01, density_weights_f16, color_weights_f16, n_levels, log2_hashmap_size, base_resolution,
+                                     per_level_scale, h_f16, rgb_f16, save_in_d, save_acts_d, save_in_c, save_acts_c, loss_scale, grad_density_params,
+                                     grad_color_params, n_density_mlp_params, scratch, stream, n_density_params, n_color_params, true, n_samples_dev, &st, (hipStream_t)fork_stream);
+}
+
+int nrc_sum_squares_two(const float* a, int64_t n_a, const float* b, int64_t n_b, float inv_n, float* out, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_a < 0 || n_b < 0 || (n_a && !a) || (n_b && !b) || !out) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_sumsq_two, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, n_a, b, n_b, inv_n, out);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_clear_seed_two(float* grad_a, int64_t clear_a, const float* w_a, int64_t seed_a, float* grad_b, int64_t clear_b, const float* w_b, int64_t seed_b,
+                       const float* upstream_dev, float coeff, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (clear_a < 0 || clear_b < 0 || seed_a < 0 || seed_b < 0 || seed_a > clear_a || seed_b > clear_b || (clear_a && !grad_a) || (clear_b && !grad_b) ||
+        (seed_a && !w_a) || (seed_b && !w_b) || ((seed_a || seed_b) && !upstream_dev))
+        return NRC_ERR_INVALID;
+    const int64_t big = clear_a > clear_b ? clear_a : clear_b;
+    if (big == 0) return NRC_OK;
+    static const float one = 1.f; (void)one;
+    const int64_t blocks = nrc_cdiv(big, 256 * 4);
+    hipLaunchKernelGGL(k_zero_seed_two, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, (hipStream_t)stream, grad_a, clear_a, w_a, seed_a, grad_b,
+                       clear_b, w_b, seed_b, upstream_dev ? upstream_dev : grad_a, coeff);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
 }
 
 int64_t nrc_ngp_train_query_scratch_bytes(int64_t M) {

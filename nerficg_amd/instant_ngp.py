@@ -105,9 +105,10 @@ class InstantNGPModel(torch.nn.Module):
         self.n_mlp_params = self.n_params_encoding_mlp + self.color_mlp_with_encoding.params.numel()
 
     def weight_decay_mlp(self) -> torch.Tensor:
-        """Mean squared MLP weight over both networks, hash table excluded (Model.py:38-44)."""
-        squares = lambda t: t.square().sum()
-        return (squares(self.encoding_xyz.params[:self.n_params_encoding_mlp]) + squares(self.color_mlp_with_encoding.params)) / self.n_mlp_params
+        """Mean squared MLP weight over both networks, hash table excluded (Model.py:38-44): one launch, and a backward that costs no launch and no
+        dense gradient (nerficg_amd.ngp.weight_decay_mlp)."""
+        from .ngp import weight_decay_mlp
+        return weight_decay_mlp(self.encoding_xyz, self.color_mlp_with_encoding, self.n_params_encoding_mlp, self.n_mlp_params)
 
 
 class InstantNGPRenderer:
@@ -199,7 +200,10 @@ class InstantNGPRenderer:
         sigmas, rgbs = self.query(xyzs, dirs)
         # compositing, background and the training depth (weighted mean with a guarded denominator, Renderer.py:78-84) as one autograd node
         rgb, alpha, depth = composite_over_background(sigmas, rgbs, deltas, ts, rays_a, bg, self.T_THRESHOLD)
-        out = {'rgb': rgb, 'alpha': alpha, 'depth': depth, 'rm_samples': counter[0]}
+        # 'rm_samples' (Trainer.py:94 reads it with .item() every iteration): without a fixed capacity the host sized the sample buffers from that
+        # very count a moment ago -- it comes back as a HOST scalar tensor, and the trainer's .item() is not a second stream synchronisation
+        marched = counter[0] if self.sample_capacity is not None else torch.tensor(xyzs.shape[0], dtype=torch.int32)
+        out = {'rgb': rgb, 'alpha': alpha, 'depth': depth, 'rm_samples': marched}
         if cut:   # fixed sample capacity: how many samples did not fit (device int64)
             out['sample_overflow'] = cut[0]
         return out

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-__all__ = ['query_fused', 'query_train', 'composite_over_background']
+__all__ = ['query_fused', 'query_train', 'composite_over_background', 'weight_decay_mlp']
 
 
 def query_fused(density_net, color_net, xyz01: torch.Tensor, dirs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
@@ -29,6 +29,81 @@ def query_fused(density_net, color_net, xyz01: torch.Tensor, dirs: torch.Tensor)
         g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(sig), _lib.ptr(rgb), _lib.ptr(ws),
         _lib.stream_of(sig)), 'ngp_query_fused')
     return sig, rgb
+
+
+# ---- the weight-decay term of InstantNGPLoss (Loss.py:15: 0.5e-6 * Model.weight_decay_mlp()) without its dense gradients -----------------------------
+# weight_decay_mlp() touches 10 240 MLP weights, but through torch's slicing / square / sum its backward builds a zero-filled gradient of the whole
+# 12.2 M-element parameter vector and adds it to the networks' gradient (~14 launches, a 49 MB fill and a 49 MB add per iteration).  Here the term is
+# one launch forward; backward it launches NOTHING: it leaves a "seed" -- (dL/dterm on the device, 2 / n, how many leading weights) -- for the
+# parameter, and the backward of the training query, which runs later in the same backward pass and has to clear its gradient buffers anyway,
+# starts the MLP part of them at seed * w instead of zero (nrc_clear_seed_two).  A seed nobody picked up by the end of the backward pass (the query was
+# not part of this graph) is added to p.grad the ordinary way by a callback the engine runs when the pass ends -- the result is the term's gradient
+# either way.
+_GRAD_SEEDS: dict[int, tuple] = {}   # parameter storage address -> (weak reference to the parameter, upstream 0-d f32 on the device, coefficient, count)
+
+
+def _take_seed(param):
+    hit = _GRAD_SEEDS.get(param.data_ptr())
+    if hit is None or hit[0]() is not param:
+        return None
+    del _GRAD_SEEDS[param.data_ptr()]
+    return hit
+
+
+def _flush_seeds() -> None:
+    """End of a backward pass: seeds that the training query did not consume become ordinary gradient contributions."""
+    while _GRAD_SEEDS:
+        _, (ref, up, coeff, count) = _GRAD_SEEDS.popitem()
+        p = ref()
+        if p is None:
+            continue
+        with torch.no_grad():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            p.grad[:count].add_(p.detach()[:count] * (coeff * up.to(p.dtype)))
+
+
+def weight_decay_mlp(density_net, color_net, n_density_mlp: int, n_total: int) -> torch.Tensor:
+    """Model.weight_decay_mlp (Model.py:38-44): mean squared MLP weight over both networks, the hash table excluded -- one launch forward, no launch
+    and no dense gradient backward (see _GRAD_SEEDS).  Falls back to the torch expression for parameters that are not plain f32 device vectors."""
+    pd, pc = density_net.params, color_net.params
+    plain = all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in (pd, pc))
+    if not plain or not torch.is_grad_enabled() or not (pd.requires_grad and pc.requires_grad):
+        return (pd[:n_density_mlp].square().sum() + pc.square().sum()) / n_total
+    return _WeightDecayNode.apply(pd, pc, int(n_density_mlp), int(n_total))
+
+
+class _WeightDecayNode(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, params_d, params_c, n_d, n_total):
+        out = torch.empty(1, dtype=torch.float32, device=params_d.device)
+        _lib.check(_lib.load().nrc_sum_squares_two(_lib.ptr(params_d), n_d, _lib.ptr(params_c), params_c.numel(), 1.0 / n_total, _lib.ptr(out),
+                                                   _lib.stream_of(out)), 'sum_squares_two')
+        ctx.save_for_backward(params_d, params_c)
+        ctx.n_d, ctx.n_total = n_d, n_total
+        return out.reshape(())
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        import weakref
+        params_d, params_c = ctx.saved_tensors
+        up = g.detach().to(torch.float32).reshape(1).contiguous()
+        was_empty = not _GRAD_SEEDS
+        for p, count in ((params_d, ctx.n_d), (params_c, params_c.numel())):
+            prev = _GRAD_SEEDS.get(p.data_ptr())
+            if prev is not None and prev[0]() is p:      # a second term on the same parameter in one pass: settle the first the ordinary way
+                _GRAD_SEEDS.pop(p.data_ptr())
+                with torch.no_grad():
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                    p.grad[:prev[3]].add_(p.detach()[:prev[3]] * (prev[2] * prev[1]))
+            _GRAD_SEEDS[p.data_ptr()] = (weakref.ref(p), up, 2.0 / ctx.n_total, count)
+        if was_empty:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_seeds)
+        return None, None, None, None
 
 
 class _QueryTrain(torch.autograd.Function):
@@ -55,7 +130,7 @@ class _QueryTrain(torch.autograd.Function):
         _lib.check(lib.nrc_ngp_train_query_forward(
             _lib.ptr(xyzs), _lib.ptr(dirs), m, _lib.ptr(xyz_min), _lib.ptr(xyz_size), _lib.ptr(wd), _lib.ptr(wc), _lib.ptr(density_net._table16()),
             g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(x01), _lib.ptr(h), _lib.ptr(rgb16),
-            _lib.ptr(sigmas), _lib.ptr(rgbs), _lib.ptr(save[0]), _lib.ptr(save[1]), _lib.ptr(save[2]), _lib.ptr(save[3]), _lib.ptr(ws),
+            _lib.ptr(sigmas), _lib.ptr(rgbs), _lib.ptr(save[0]), _lib.ptr(save[1]), _lib.ptr(save[2]), _lib.ptr(save[3]), _lib.ptr(ws), None,
             _lib.stream_of(sigmas)), 'ngp_train_query_forward')
         ctx.save_for_backward(x01, h, rgb16, *save, wd, wc)
         ctx.nets = (density_net, color_net)
@@ -73,11 +148,23 @@ class _QueryTrain(torch.autograd.Function):
         gd = torch.empty(density_net.params.numel(), dtype=torch.float32, device=dev)
         gc = torch.empty(color_net.params.numel(), dtype=torch.float32, device=dev)
         scratch = torch.empty(int(lib.nrc_ngp_train_query_scratch_bytes(m)) if m > 0 else 16, dtype=torch.uint8, device=dev)
-        _lib.check(lib.nrc_ngp_train_query_backward_set(
-            _lib.ptr(d_sigmas.to(torch.float32).contiguous()), _lib.ptr(d_rgbs.to(torch.float32).contiguous()), m, _lib.ptr(x01), _lib.ptr(wd), _lib.ptr(wc),
-            g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(h), _lib.ptr(rgb16), _lib.ptr(sd_in),
-            _lib.ptr(sd_acts), _lib.ptr(sc_in), _lib.ptr(sc_acts), float(density_net.loss_scale), _lib.ptr(gd), _lib.ptr(gc), density_net.n_mlp_params,
-            gd.numel(), gc.numel(), _lib.ptr(scratch), _lib.stream_of(gd)), 'ngp_train_query_backward_set')
+        common = (_lib.ptr(d_sigmas.to(torch.float32).contiguous()), _lib.ptr(d_rgbs.to(torch.float32).contiguous()), m, _lib.ptr(x01), _lib.ptr(wd), _lib.ptr(wc),
+                  g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), _lib.ptr(h), _lib.ptr(rgb16), _lib.ptr(sd_in),
+                  _lib.ptr(sd_acts), _lib.ptr(sc_in), _lib.ptr(sc_acts), float(density_net.loss_scale), _lib.ptr(gd), _lib.ptr(gc), density_net.n_mlp_params,
+                  gd.numel(), gc.numel(), _lib.ptr(scratch))
+        # a weight-decay term waiting for these parameters (weight_decay_mlp): its gradient is where the buffers start instead of zero
+        seed_d, seed_c = _take_seed(density_net.params), _take_seed(color_net.params)
+        if seed_d is not None and seed_c is not None and seed_d[1] is seed_c[1] and seed_d[2] == seed_c[2]:
+            n_clear = int(lib.nrc_ngp_train_query_clear_floats(m, g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
+                                                               density_net.n_mlp_params, gd.numel()))
+            _lib.check(lib.nrc_clear_seed_two(_lib.ptr(gd), n_clear, _lib.ptr(density_net.params), min(seed_d[3], n_clear), _lib.ptr(gc), gc.numel(),
+                                              _lib.ptr(color_net.params), seed_c[3], _lib.ptr(seed_d[1]), seed_d[2], _lib.stream_of(gd)), 'clear_seed_two')
+            _lib.check(lib.nrc_ngp_train_query_backward_cleared(*common, None, None, _lib.stream_of(gd)), 'ngp_train_query_backward_cleared')
+        else:
+            for seed in (seed_d, seed_c):      # only one of the two (or mismatched): back into the registry, the end-of-pass callback settles it
+                if seed is not None:
+                    _GRAD_SEEDS[seed[0]().data_ptr()] = seed
+            _lib.check(lib.nrc_ngp_train_query_backward_set(*common, _lib.stream_of(gd)), 'ngp_train_query_backward_set')
         return None, None, gd, gc, None, None, None, None
 
 

@@ -3,19 +3,22 @@
 The reference's iteration (src/Methods/InstantNGP/Trainer.py:79-94) is: draw a batch from the ray pool -> random background -> render_rays(train) ->
 MSE + weight decay -> GradScaler.scale / backward -> GradScaler.step(FusedAdam) -> GradScaler.update -> zero_grad.  Through the drop-in modules that
 is ~90 launches and a host read; recorded op by op in a HIP graph (nerficg_amd.graphs.instant_ngp_iteration) 33 launches, 17 of them 4-5 us
-element-wise or fill kernels.  `FusedTrainingIteration` issues the same arithmetic as FIVE library calls / 13 launches on buffers that exist once:
+element-wise or fill kernels.  `FusedTrainingIteration` issues the same arithmetic as FOUR library calls / 13 launches on buffers that exist once:
 
     nrc_ngp_train_march                   batch out of the resident pool + box clipping + jitter / background draws + march (2 launches)
     nrc_ngp_train_query_forward           encode + both networks                                                          (3)
     nrc_ngp_train_loss                    compositing, pixel, MSE, x scale, and back to dL/dsigma, dL/drgb; clears what the backward adds into  (1)
-    nrc_ngp_train_query_backward_cleared  both networks + hash-grid backward                                              (5)
-    nrc_amp_adam_step                     inf / NaN check + step counter + scale update, Adam on both parameter vectors    (2)
+    nrc_ngp_train_backward_step           both networks backward (they flag inf / NaN), step counter + scale update, hash-grid backward whose slice
+                                          owners apply Adam to the hashed levels themselves, Adam on the rest                 (7)
+    (fused_step=False -- what data-parallel ranks take, who need the gradients on the wire:
+     nrc_ngp_train_query_backward_cleared (5) + nrc_amp_adam_step: inf / NaN check + step counter + scale update, Adam       (2))
 
 and -- since the march of batch i + 1 depends on nothing iteration i updates (rays, the occupancy bitfield, a counter-based generator) -- runs that
 march on a forked stream NEXT TO iteration i's backward pass and Adam (`prefetch`): two sets of batch buffers, consumed alternately.  The caller says
 when the bitfield is about to change (`step(prefetch=False)` before an occupancy update), so every batch is marched against the bitfield the
-reference's loop would have used.  With `graph=True` each (buffer set, inline / prefetched march, prefetch on / off) combination is recorded once
-in a HIP graph and replayed.
+reference's loop would have used.  The calls only enqueue (85-110 us of host time per iteration for ~0.35-0.4 ms of kernels), so the iteration
+needs no recording; with `graph=True` each (buffer set, inline / prefetched march, prefetch on / off) combination is recorded once in a HIP graph
+and replayed anyway (measured SLOWER than the eager calls on ROCm 7.2: 0.478 against 0.447 ms -- a replay pays a few microseconds per kernel node).
 
 Parity: tests/test_gpu_ngp_trainer.py -- the same batches, backgrounds and jitter through this class (eager and recorded, with and without
 prefetch) and through the op-by-op loop leave the same parameters within the op-by-op loop's own run-to-run spread.
@@ -65,7 +68,8 @@ class FusedTrainingIteration:
     T_THRESHOLD = 1e-4
 
     def __init__(self, model, renderer, optimizer, scaler, camera, ray_pool: dict, ray_capacity: int, sample_capacity: int, order: torch.Tensor | None = None,
-                 seed: int = 0, weight_decay: float = 0.5e-6, prefetch: bool = True, graph: bool = True, ray_offset: int = 0) -> None:
+                 seed: int = 0, weight_decay: float = 0.5e-6, prefetch: bool = True, graph: bool = False, ray_offset: int = 0, fused_step: bool = True,
+                 fork_dense_levels: bool = True) -> None:
         if not getattr(optimizer, 'capturable', False):
             raise RuntimeError('FusedTrainingIteration: build the optimizer as FusedAdam(..., capturable=True)')
         if len(optimizer.param_groups) != 1:
@@ -75,7 +79,8 @@ class FusedTrainingIteration:
         self.dev = dev = model.center.device
         self.n_cap, self.m_cap = int(ray_capacity), int(sample_capacity)
         self.ray_offset = int(ray_offset)
-        self.use_graph, self.prefetch_default = bool(graph), bool(prefetch)
+        self.use_graph, self.prefetch_default, self.fused_step = bool(graph), bool(prefetch), bool(fused_step)
+        self._gb_side = torch.cuda.Stream(device=dev) if fork_dense_levels else None
         self.pool = {k: ray_pool[k].contiguous() for k in ('origin', 'view_direction', 'rgb', 'alpha') if ray_pool.get(k) is not None}
         for k, v in self.pool.items():
             _lib.check_input(v, k, torch.float32)
@@ -195,32 +200,40 @@ class FusedTrainingIteration:
         M = self.m_cap
         _lib.check(lib.nrc_ngp_train_query_forward(
             p(b.xyzs), p(b.dirs), M, p(mn), p(sz), p(st['hd']), p(st['hc']), p(st['hd'][dn.n_mlp_params:]), *grid, p(self.x01), p(self.h), p(self.rgb16),
-            p(self.sigmas), p(self.rgbs), p(self.save[0]), p(self.save[1]), p(self.save[2]), p(self.save[3]), p(self.fwd_ws), stream), 'ngp_train_query_forward')
+            p(self.sigmas), p(self.rgbs), p(self.save[0]), p(self.save[1]), p(self.save[2]), p(self.save[3]), p(self.fwd_ws), p(b.counter), stream), 'ngp_train_query_forward')
         _lib.check(lib.nrc_ngp_train_loss(
             p(self.sigmas), p(self.rgbs), p(b.deltas), p(b.ts), p(b.rays_a), p(b.counter), self.n_cap, M, self.T_THRESHOLD, p(b.bg), p(b.target), p(st['scale']),
             p(self.ray_rgb), p(self.ray_alpha), None, p(self.loss2), p(self.d_sigmas), p(self.d_rgbs), p(self.gd), self.n_clear, p(self.gc), self.gc.numel(),
             p(self.loss_ws), stream), 'ngp_train_loss')
-        _lib.check(lib.nrc_ngp_train_query_backward_cleared(
-            p(self.d_sigmas), p(self.d_rgbs), M, p(self.x01), p(st['hd']), p(st['hc']), *grid, p(self.h), p(self.rgb16), p(self.save[0]), p(self.save[1]),
-            p(self.save[2]), p(self.save[3]), float(dn.loss_scale), p(self.gd), p(self.gc), dn.n_mlp_params, self.gd.numel(), self.gc.numel(),
-            p(self.bwd_scratch), stream), 'ngp_train_query_backward_cleared')
         group = self.optimizer.param_groups[0]
         beta1, beta2 = group['betas']
         sc = self.scaler
+        backward = (p(self.d_sigmas), p(self.d_rgbs), M, p(self.x01), p(st['hd']), p(st['hc']), *grid, p(self.h), p(self.rgb16), p(self.save[0]), p(self.save[1]),
+                    p(self.save[2]), p(self.save[3]), float(dn.loss_scale), p(self.gd), p(self.gc), dn.n_mlp_params, self.gd.numel(), self.gc.numel(),
+                    p(self.bwd_scratch), p(b.counter))
+        hyper = (float(group['lr']), p(st['lr']), float(beta1), float(beta2), float(group['eps']), float(group['weight_decay']), self.optimizer.adam_w_mode,
+                 p(st['step']), p(st['bc']), p(st['scale']), p(st['tracker']), float(sc.get_growth_factor()) if st['scale'] is not None else 2.0,
+                 float(sc.get_backoff_factor()) if st['scale'] is not None else 0.5, int(sc.get_growth_interval()) if st['scale'] is not None else 1, p(self.amp_state))
+        fork = ctypes.c_void_p(self._gb_side.cuda_stream) if self._gb_side is not None else None
+        if self.fused_step:
+            _lib.check(lib.nrc_ngp_train_backward_step(
+                *backward, p(st['pd']), p(st['md']), p(st['vd']), p(st['hd']), self.l2[0][0], self.l2[0][1], p(st['pc']), p(st['mc']), p(st['vc']), p(st['hc']),
+                self.l2[1][0], self.l2[1][1], *hyper, fork, stream), 'ngp_train_backward_step')
+            return
+        _lib.check(lib.nrc_ngp_train_query_backward_cleared(*backward, fork, stream), 'ngp_train_query_backward_cleared')
         _lib.check(lib.nrc_amp_adam_step(
             p(st['pd']), p(self.gd), p(st['md']), p(st['vd']), p(st['hd']), self.gd.numel(), self.l2[0][0], self.l2[0][1],
             p(st['pc']), p(self.gc), p(st['mc']), p(st['vc']), p(st['hc']), self.gc.numel(), self.l2[1][0], self.l2[1][1],
-            float(group['lr']), p(st['lr']), float(beta1), float(beta2), float(group['eps']), float(group['weight_decay']), self.optimizer.adam_w_mode,
-            p(st['step']), p(st['bc']), p(st['scale']), p(st['tracker']), float(sc.get_growth_factor()) if st['scale'] is not None else 2.0,
-            float(sc.get_backoff_factor()) if st['scale'] is not None else 0.5, int(sc.get_growth_interval()) if st['scale'] is not None else 1,
-            p(self.amp_state), p(self.amp_ticket), stream), 'amp_adam_step')
+            *hyper, p(self.amp_ticket), stream), 'amp_adam_step')
 
     def _enqueue(self, cur: int, inline: bool, prefetch: bool, st: dict, explicit) -> None:
         if inline:
             self._march(cur, st, explicit)
         if prefetch:
+            # the fork sits in FRONT of the forward pass (measured against forks behind the loss and in front of Adam: 0.380 / 0.395 / 0.407 ms per
+            # iteration) and behind the inline march: both marches move the cursor and the generator
             main = torch.cuda.current_stream(self.dev)
-            self._side.wait_stream(main)           # behind the inline march: both move the cursor and the generator
+            self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 self._march(1 - cur, st, explicit)
         self._update(cur, st)

@@ -314,9 +314,9 @@ class DataParallelGradScaler(_FastGradScaler):
             dev = flags[0].device
             local = flags[0] if len(flags) == 1 else torch.stack([f.reshape(-1)[0].to(dev) for f in flags]).max().reshape(1)
         else:
-            dev = self.piggyback[0].device if self.piggyback else (self._scale.device if self._scale is not None else torch.device('cpu'))
+            dev = self._scale.device if self._scale is not None else (self.piggyback[0].device if self.piggyback else torch.device('cpu'))
             local = torch.zeros(1, dtype=torch.float32, device=dev)
-        sums, agreed = allreduce_scalars(self.piggyback, [local])
+        sums, agreed = allreduce_scalars([t.to(dev) for t in self.piggyback], [local])    # (a count the host already knows travels as a host scalar)
         for t in flags:
             t.copy_(agreed[0].to(t.device))
         if not flags:   # torch's step() insists on a recorded check: this rank's is the agreed flag (its own step has nothing to apply)

@@ -259,3 +259,67 @@ def test_train_query_backward_set_equals_zero_fill_plus_accumulate():
         if m >= 16384:   # bucketed path: the hashed levels' sums do not depend on the order of anything
             first_hashed = dn.n_mlp_params + 2 * 351_000   # behind the five dense levels (16^3 .. 60^3 -> < 351 K entries): level 5 starts before this
             assert torch.equal(gd1[first_hashed + 2 * (1 << 19):], gd0[first_hashed + 2 * (1 << 19):])
+
+
+def _wd_reference(model):
+    """Model.py:38-44 as torch expressions (what weight_decay_mlp computed before it became one node)."""
+    squares = lambda t: t.square().sum()
+    return (squares(model.encoding_xyz.params[:model.n_params_encoding_mlp]) + squares(model.color_mlp_with_encoding.params)) / model.n_mlp_params
+
+
+def test_weight_decay_node_alone_leaves_the_gradient_of_the_torch_expression():
+    """No training query in the graph: nobody picks the gradient seeds up, the end-of-pass callback turns them into ordinary gradients."""
+    from nerficg_amd.instant_ngp import InstantNGPModel
+    from nerficg_amd import ngp
+    model = InstantNGPModel(RANDOM_SEED=3, device=DEV)
+    value = model.weight_decay_mlp()
+    ref = _wd_reference(model)
+    np.testing.assert_allclose(float(value), float(ref), rtol=2e-6)
+    (128.0 * 0.5e-6 * value).backward()
+    got = [p.grad.clone() for p in model.parameters()]
+    assert not ngp._GRAD_SEEDS
+    model.zero_grad()
+    (128.0 * 0.5e-6 * ref).backward()
+    for a, b in zip(got, (p.grad for p in model.parameters())):
+        assert torch.allclose(a, b, rtol=1e-6, atol=0) and float(a.abs().max()) > 0
+    # under no_grad / for frozen parameters the torch expression answers
+    with torch.no_grad():
+        np.testing.assert_allclose(float(model.weight_decay_mlp()), float(ref), rtol=2e-6)
+
+
+def test_weight_decay_seeds_join_the_training_query_gradient():
+    """The trainer's loss (Loss.py:15-22) through render_rays: the seeds are consumed by the query's backward (nrc_clear_seed_two) and the parameters'
+    gradients equal those of the torch-expression term within the run-to-run spread of the atomics; with a weight decay 1e6 times the reference's so
+    that the term shows."""
+    from nerficg_amd import ngp
+    from nerficg_amd.instant_ngp import InstantNGPRenderer
+    from tests.noise import assert_within_run_to_run_noise
+    from tests.test_gpu_graphs import _rays as image_rays
+    from tests.test_gpu_render_parity import make_model
+    cam, o, d = image_rays()
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    ids = torch.randint(0, o.shape[0], (1024,), device=DEV, generator=gen)
+    rgb, bg, noise = torch.rand(1024, 3, device=DEV, generator=gen), torch.rand(3, device=DEV, generator=gen), torch.rand(1024, device=DEV, generator=gen)
+    results = []
+    for form in ('torch', 'torch', 'node'):
+        model = make_model(seed=6, table_amp=1e-4)
+        renderer = InstantNGPRenderer(model)
+        with torch.amp.autocast('cuda'):
+            out = renderer.render_rays(o[ids], d[ids], cam, train_mode=True, custom_bg_color=bg, noise=noise)
+            term = model.weight_decay_mlp() if form == 'node' else _wd_reference(model)
+            loss = torch.nn.functional.mse_loss(out['rgb'].float(), rgb) + 0.5 * term
+        (128.0 * loss).backward()
+        assert not ngp._GRAD_SEEDS
+        assert out['rm_samples'].device.type == 'cpu' and int(out['rm_samples']) > 0      # the host already knew the count
+        results.append([p.grad.detach().clone() for p in model.parameters()])
+    assert_within_run_to_run_noise(results[2], results[0], results[1], atol=1e-6, rtol=1e-3, what='gradients with the weight-decay seeds')
+    n = results[0][0].numel()
+    mlp = slice(0, 3072)
+    plain = make_model(seed=6, table_amp=1e-4)     # the term matters at this strength: the MLP gradient without it is elsewhere
+    renderer = InstantNGPRenderer(plain)
+    with torch.amp.autocast('cuda'):
+        out = renderer.render_rays(o[ids], d[ids], cam, train_mode=True, custom_bg_color=bg, noise=noise)
+        loss = torch.nn.functional.mse_loss(out['rgb'].float(), rgb)
+    (128.0 * loss).backward()
+    without = plain.encoding_xyz.params.grad
+    assert float((without[mlp] - results[0][0][mlp]).abs().mean()) > 10 * float((results[2][0][mlp] - results[0][0][mlp]).abs().mean())

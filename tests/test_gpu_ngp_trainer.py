@@ -170,8 +170,8 @@ def _op_by_op(batches, seed, cam, pool, weight_decay=0.5e-6):
     return losses, marched, [p.detach().clone() for p in model.parameters()], model
 
 
-@pytest.mark.parametrize('graph', [False, True])
-def test_fused_iterations_follow_the_op_by_op_iterations(graph):
+@pytest.mark.parametrize('graph,fused_step', [(False, True), (True, True), (False, False), (True, False)])
+def test_fused_iterations_follow_the_op_by_op_iterations(graph, fused_step):
     from tests.noise import assert_within_run_to_run_noise
     cam, pool = _pool()
     n = 2048
@@ -181,7 +181,7 @@ def test_fused_iterations_follow_the_op_by_op_iterations(graph):
     l0, m0, p0, _ = _op_by_op(batches, 9, cam, pool)
     l2, m2, p2, _ = _op_by_op(batches, 9, cam, pool)
     model, renderer, _ = _train_pair(seed=9)
-    it, opt, scaler = _fused(model, renderer, cam, pool, n, 400_000, prefetch=False, graph=graph)
+    it, opt, scaler = _fused(model, renderer, cam, pool, n, 400_000, prefetch=False, graph=graph, fused_step=fused_step)
     l1, m1 = [], []
     for b in batches:
         out = it(ids=b['ids'], bg=b['bg'], noise=b['noise'])
@@ -228,14 +228,15 @@ def test_marching_ahead_changes_nothing_but_the_schedule():
     assert_within_run_to_run_noise(p1, p0, p2, atol=1e-4, rtol=1e-2, what='parameters after nine iterations, batches marched ahead')
 
 
-def test_overflow_skips_the_step_and_backs_the_scale_off():
+@pytest.mark.parametrize('fused_step', [True, False])
+def test_overflow_skips_the_step_and_backs_the_scale_off(fused_step):
     """A loss scale that overflows the scaled loss (the case the GradScaler exists for): every gradient is inf / NaN, so parameters and moments
     stay, the step counter stands still, the scale is backed off and the growth tracker resets -- torch.amp.GradScaler's rule
     (Trainer.py:89-91), executed on the device; the next iteration is taken again."""
     cam, pool = _pool()
     model, renderer, _ = _train_pair(seed=1)
     n = 1024
-    it, opt, scaler = _fused(model, renderer, cam, pool, n, 200_000, prefetch=False, graph=True)
+    it, opt, scaler = _fused(model, renderer, cam, pool, n, 200_000, prefetch=False, graph=True, fused_step=fused_step)
     g = torch.Generator(device=DEV).manual_seed(3)
     ids = lambda: torch.randint(0, pool['origin'].shape[0], (n,), device=DEV, generator=g)
     it(ids=ids()); it(ids=ids())
@@ -248,7 +249,7 @@ def test_overflow_skips_the_step_and_backs_the_scale_off():
     for a, b in zip(before, model.parameters()):
         assert torch.equal(a, b.detach())
     assert torch.equal(m_before, opt.state[model.encoding_xyz.params]['exp_avg'])
-    assert opt.effective_step(opt.param_groups[0]) == 2 and float(scaler.get_scale()) == 1.5e38 and int(scaler._growth_tracker) == 0
+    assert opt.effective_step(opt.param_groups[0]) == 2 and float(scaler.get_scale()) == float(np.float32(3e38) * np.float32(0.5)) and int(scaler._growth_tracker) == 0
     scaler._scale.fill_(128.0)
     it(ids=ids())
     assert opt.effective_step(opt.param_groups[0]) == 3 and float(scaler.get_scale()) == 128.0 and int(scaler._growth_tracker) == 1

@@ -12,6 +12,7 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 prefetch = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
 graph = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
 accumulate = bool(int(sys.argv[5])) if len(sys.argv) > 5 else True
+fused_step = bool(int(sys.argv[6])) if len(sys.argv) > 6 else True
 dev = torch.device('cuda', 0)
 model, renderer, cam, poses = bench.build_scene(dev)
 rays = [generate_rays(cam.width, cam.height, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y, p, device=dev, want_direction=False) for p in poses[:2]]
@@ -25,7 +26,7 @@ opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_
 scaler = GradScaler(init_scale=128.0, growth_interval=10 ** 9)
 capacity = (int(1.15 * 264000 * n_rays / 2200) + 4095) // 4096 * 4096
 it = FusedTrainingIteration(model, renderer, opt, scaler, cam, {'origin': origin, 'view_direction': vdir, 'rgb': target}, n_rays, capacity, order=perm,
-                            prefetch=prefetch, graph=graph)
+                            prefetch=prefetch, graph=graph, fused_step=fused_step)
 for i in range(4):
     out = it()
 for block in range(3):
@@ -36,5 +37,5 @@ for block in range(3):
         if accumulate:
             marched += out['rm_samples']
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / iters
-    print(f'fused iteration (prefetch={prefetch}, graph={graph}, accumulate={accumulate}), block {block}: {dt * 1e3:.3f} ms, {int(marched) / iters:.0f} samples / iteration, loss {float(out["loss"]):.4f}, '
+    print(f'fused iteration (prefetch={prefetch}, graph={graph}, accumulate={accumulate}, fused_step={fused_step}), block {block}: {dt * 1e3:.3f} ms, {int(marched) / iters:.0f} samples / iteration, loss {float(out["loss"]):.4f}, '
           f'overflow {int(out["sample_overflow"])}, graphs {len(it._graphs)}')
