@@ -512,11 +512,17 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=60):
     scaler = GradScaler(init_scale=128.0, growth_interval=10 ** 9)
     target = torch.rand(origin.shape[0], 3, device=dev)
 
+    from nerficg_amd.instant_ngp import InstantNGPLoss    # Loss.py:11-26 (MSE + 0.5e-6 x mean squared MLP weight) as one node
+    from nerficg_amd.ngp import gather_ray_batch          # RayPoolSampler.get (DatasetSamplers.py:53-66): ray_pool[ids], every field in one launch
+    criterion = InstantNGPLoss(model)
+
     def step(i):
         ids = perm[(i * n_rays) % (perm.numel() - n_rays):][:n_rays]
+        batch = gather_ray_batch(ids, origin, vdir, target)
         with torch.amp.autocast('cuda'):
-            out = renderer.render_rays(origin[ids], vdir[ids], cam, train_mode=True, custom_bg_color=torch.rand(3, device=dev))
-            loss = torch.nn.functional.mse_loss(out['rgb'].float(), target[ids]) + 0.5e-6 * model.weight_decay_mlp()
+            bg = torch.rand(3, device=dev)
+            out = renderer.render_rays(batch['origin'], batch['view_direction'], cam, train_mode=True, custom_bg_color=bg)
+            loss = criterion(out, batch, bg)
         scaler.scale(loss).backward()
         scaler.step(opt); scaler.update(); opt.zero_grad()
         return int(out['rm_samples'].item())
@@ -576,7 +582,7 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=60):
                        f'{round(m_prof)} samples each; rooflines and _per_kernel_ms: iterations 4-13 from the initial parameters (a gradient on every sample); '
                        f'_per_kernel_ms_late: iterations {4 + iters}-{3 + iters + n_prof} (most samples behind a saturated ray: zero gradient, skipped by the grid backward)')
     restore()
-    res = {'metric': 'InstantNGP training iteration (drop-in modules, fwd + bwd + Adam)', 'ms_per_iteration': round(dt * 1e3, 3), 'rays': n_rays,
+    res = {'metric': 'InstantNGP training iteration (drop-in modules, fwd + bwd + Adam); hip_graph = the same modules recorded; fused = nerficg_amd.ngp_trainer', 'ms_per_iteration': round(dt * 1e3, 3), 'rays': n_rays,
            'samples_per_iteration': int(tot / iters), 'msamples_per_s': round(tot / iters / dt / 1e6, 1), 'roofline': roof}
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():  # N > 1: no recording next to a live RCCL communicator (its watchdog thread polls events)
@@ -608,6 +614,36 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=60):
     res['hip_graph'] = {'ms_per_iteration': round(dt_g * 1e3, 3), 'ms_per_iteration_first_third': round(dt_first * 1e3, 3),
                         'ms_per_iteration_last_third': round(dt_last * 1e3, 3), 'weight_decay': 'in the Adam kernel (FusedAdam.set_l2_slice)', 'sample_capacity': capacity, 'samples_per_iteration': int(marched.item() / iters),
                         'samples_cut': int(cut.item()), 'msamples_per_s': round(marched.item() / iters / dt_g / 1e6, 1)}
+    # The same iteration as FOUR library calls / 13 launches on device-resident state (nerficg_amd.ngp_trainer, include/nerficg_hip.h group 13), the next
+    # batch marched ahead on a side stream; no recording -- the calls only enqueue.  Same regime as the recorded leg: 60 iterations from the restored
+    # parameters (a gradient on every sample at the start).
+    from nerficg_amd.ngp_trainer import FusedTrainingIteration
+    del graphed
+    opt_f = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
+    scaler_f = GradScaler(init_scale=128.0, growth_interval=10 ** 9)
+    fused = FusedTrainingIteration(model, renderer, opt_f, scaler_f, cam, {'origin': origin, 'view_direction': vdir, 'rgb': target}, n_rays, capacity, order=perm)
+    marched = torch.zeros((), dtype=torch.int64, device=dev); cut = torch.zeros((), dtype=torch.int64, device=dev)
+    for i in range(3):
+        out = fused()
+        marched += out['rm_samples']; cut += out['sample_overflow']     # (also loads the accumulation kernels before the clock starts)
+    marched.zero_(); cut.zero_()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    marks = {}
+    for i in range(iters):
+        if i in (third, iters - third):
+            torch.cuda.synchronize(); marks[i] = time.perf_counter()
+        out = fused()
+        marched += out['rm_samples']; cut += out['sample_overflow']
+    torch.cuda.synchronize(); t1 = time.perf_counter(); dt_f = (t1 - t0) / iters
+    dt_first = (marks.get(third, t1) - t0) / third; dt_last = (t1 - marks.get(iters - third, t0)) / third
+    loss_f = float(out['loss'])
+    restore()
+    res['fused'] = {'what': 'FusedTrainingIteration: batch + clip + draws + march | encode + MLPs | compositing + loss fwd/bwd | MLP + grid backward + Adam; 13 launches, '
+                            'next batch marched ahead on a side stream, eager calls (no HIP graph)',
+                    'ms_per_iteration': round(dt_f * 1e3, 3), 'ms_per_iteration_first_third': round(dt_first * 1e3, 3),
+                    'ms_per_iteration_last_third': round(dt_last * 1e3, 3), 'sample_capacity': capacity, 'samples_per_iteration': int(marched.item() / iters),
+                    'samples_cut': int(cut.item()), 'msamples_per_s': round(marched.item() / iters / dt_f / 1e6, 1), 'loss_last': round(loss_f, 4),
+                    'weight_decay': 'L2 slice inside the Adam launch', 'launches_per_iteration': 13}
     return res
 
 

@@ -229,6 +229,11 @@ int64_t nrc_grid_backward_ws_bytes(int64_t M, int32_t n_levels, int32_t log2_has
 int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
                       int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table,
                       void* workspace, nrc_stream_t stream);
+/* nrc_grid_backward over the rows that hold samples: n_samples_dev (DEVICE i32[1]) <= M, the capacity the launch and the workspace are sized for
+ * (the pair-major layout of d_features keeps following M).  NULL = all M rows. */
+int nrc_grid_backward_live(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
+                           int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table, void* workspace,
+                           const int32_t* n_samples_dev, nrc_stream_t stream);
 /* query_model (src/Methods/InstantNGP/Renderer.py:48-53) for TRAINING as one forward and one backward call instead of ~55 small
  * launches: world positions xyzs (M,3) / directions dirs (M,3) f32 -> sigmas (M), rgbs (M,3) f32 (what VolumeRenderer consumes), and
  * dL/dsigmas, dL/drgbs -> gradients of both parameter vectors (ACCUMULATED; caller zeroes; layout of the tinycudann modules).
@@ -640,13 +645,19 @@ int nrc_stage_timer_end(int32_t max_stages, char* names, float* ms, int32_t* cou
  *            writes bias_corrections (2), state4[1] = found_inf of this step, state4[2] = 1 / scale the gradients carry, and applies torch's
  *            scale update rule (back off on overflow; grow after growth_interval clean steps) to *scale / *growth_tracker (scale NULL: no
  *            scaler).  Launch 2 is the Adam update of nrc_adam_step for both tensors (skipped when found_inf).  state4 (f32[4]) and ticket
- *            (u32[272]: a two-level arrival counter) zeroed once by the caller.  lr_dev (NULL: the host value lr).
+ *            (u32[272]: a two-level arrival counter) zeroed once by the caller.  lr_dev (NULL: the host value lr).  skipped_steps (optional, i32[1]): counts
+ *            the steps an overflow skipped.
  * ===================================================================================================== */
 /* InstantNGPModel.weight_decay_mlp (src/Methods/InstantNGP/Model.py:38-44: mean squared MLP weight over both networks) as one launch each way.
  *   nrc_sum_squares_two: out[0] = (sum a[0,n_a)^2 + sum b[0,n_b)^2) * inv_n, one workgroup, fixed order.
  *   nrc_clear_seed_two : what stands in front of nrc_ngp_train_query_backward_cleared -- grad_a[0,clear_a) / grad_b[0,clear_b) are cleared, and their
  *                        leading seed_a / seed_b elements start at coeff * upstream_dev[0] * w instead of zero: the gradient of the weight-decay term
  *                        (coeff = 2 / n, upstream = dL/d(term), DEVICE scalar) joins the networks' gradients without a dense 12 M-element tensor. */
+/* InstantNGPLoss.forward (src/Methods/InstantNGP/Loss.py:18-26) as one launch: out3 = (mse + weight_decay_weight * wd, mse, wd) with
+ * mse = mean((pred - target)^2) over n elements and wd = (sum a^2 + sum b^2) * inv_n_weights.  Backward: nrc_mse_scaled_backward for pred, and the
+ * weight-decay gradient as seeds of nrc_clear_seed_two. */
+int nrc_ngp_loss_forward(int64_t n, const float* pred, const float* target, const float* weights_a, int64_t n_a, const float* weights_b, int64_t n_b,
+                         float inv_n_weights, float weight_decay_weight, float* out3, nrc_stream_t stream);
 int nrc_sum_squares_two(const float* a, int64_t n_a, const float* b, int64_t n_b, float inv_n, float* out, nrc_stream_t stream);
 int nrc_clear_seed_two(float* grad_a, int64_t clear_a, const float* w_a, int64_t seed_a, float* grad_b, int64_t clear_b, const float* w_b, int64_t seed_b,
                        const float* upstream_dev, float coeff, nrc_stream_t stream);
@@ -694,7 +705,7 @@ int nrc_amp_adam_step(float* param_a, const float* grad_a, float* exp_avg_a, flo
                       int64_t l2_count_a, float* param_b, const float* grad_b, float* exp_avg_b, float* exp_avg_sq_b, void* param_f16_b, int64_t n_b,
                       float l2_coeff_b, int64_t l2_count_b, float lr, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                       int32_t adam_w_mode, int32_t* device_step, float* bias_corrections, float* scale, int32_t* growth_tracker, float growth_factor,
-                      float backoff_factor, int32_t growth_interval, float* state4, void* ticket, nrc_stream_t stream);
+                      float backoff_factor, int32_t growth_interval, float* state4, void* ticket, int32_t* skipped_steps, nrc_stream_t stream);
 
 #ifdef __cplusplus
 }

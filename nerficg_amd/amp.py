@@ -50,6 +50,14 @@ class GradScaler(torch.amp.GradScaler):
         state = self._per_optimizer_states[id(optimizer)]
         if state['stage'] is OptState.STEPPED:
             raise RuntimeError('step() has already been called since the last update().')
+        if (state['stage'] is OptState.READY and type(self)._check_inf_per_device is GradScaler._check_inf_per_device and not args and not kwargs
+                and hasattr(optimizer, '_amp_fused_step') and len(self._per_optimizer_states) == 1):
+            # the whole of step() + update() as one library call: check, step counter, scale rule, Adam (nrc_amp_adam_step).  update() then has
+            # nothing left to launch.  (Subclasses that hook the check -- the data-parallel scaler's agreement -- and multi-optimizer setups take the general path.)
+            if optimizer._amp_fused_step(self._scale, self._growth_tracker, self._growth_factor, self._backoff_factor, self._growth_interval):
+                state['stage'] = OptState.STEPPED
+                self._fused_update_done = True
+                return None
         if state['stage'] is OptState.READY:
             self._check_inf_per_device(optimizer)
         scale = self._get_scale_async()
@@ -63,6 +71,28 @@ class GradScaler(torch.amp.GradScaler):
             del optimizer.found_inf
         state['stage'] = OptState.STEPPED
         return retval
+
+    def update(self, new_scale=None):
+        """torch.amp.GradScaler.update; after a fused step (see step()) the scale rule has been applied on the device already: only the per-optimizer
+        bookkeeping is reset.  An explicit new_scale is honoured as in torch."""
+        if getattr(self, '_fused_update_done', False):
+            self._fused_update_done = False
+            if new_scale is None:
+                from collections import defaultdict
+                from torch.amp.grad_scaler import _refresh_per_optimizer_state
+                self._per_optimizer_states = defaultdict(_refresh_per_optimizer_state)
+                return
+            # (an explicit scale overrides whatever the rule did)
+            _scale, _ = self._check_scale_growth_tracker('update')
+            if isinstance(new_scale, float):
+                self._scale.fill_(new_scale)
+            else:
+                self._scale.copy_(new_scale)
+            from collections import defaultdict
+            from torch.amp.grad_scaler import _refresh_per_optimizer_state
+            self._per_optimizer_states = defaultdict(_refresh_per_optimizer_state)
+            return
+        return super().update(new_scale)
 
     def _check_inf_per_device(self, optimizer):
         grads = [p.grad for group in optimizer.param_groups for p in group['params'] if p.grad is not None]

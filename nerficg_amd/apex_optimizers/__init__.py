@@ -138,7 +138,20 @@ class FusedAdam(torch.optim.Optimizer):
         back to the allocator).  A checkpoint from the non-capturable mode (step = host count incl. skips, skipped_steps = k) loaded into a
         capturable optimizer becomes device step = step - k, the count the bias corrections follow in that mode."""
         live_steps = {gi: g['step'] for gi, g in enumerate(self.param_groups) if torch.is_tensor(g.get('step'))}
+        # the moment tensors too: torch's load replaces them with new storage, but a recorded iteration (nerficg_amd.graphs) holds raw pointers to
+        # the LIVE exp_avg / exp_avg_sq -- the loaded values are copied into those and the live tensors go back into the state (advisor finding, round 4)
+        live_moments = {id(p): (st['exp_avg'], st['exp_avg_sq']) for p, st in self.state.items() if 'exp_avg' in st and 'exp_avg_sq' in st}
         super().load_state_dict(state_dict)
+        for p, st in self.state.items():
+            kept = live_moments.get(id(p))
+            if kept is None or 'exp_avg' not in st:
+                continue
+            for name, live in zip(('exp_avg', 'exp_avg_sq'), kept):
+                loaded = st[name]
+                if loaded is not live and loaded.shape == live.shape and loaded.dtype == live.dtype and loaded.device == live.device:
+                    live.copy_(loaded)
+                    st[name] = live
+        self.__dict__.pop('_fused_mirror', None)      # (the fused scaler step re-derives its device step counter from the loaded counts)
         for gi, group in enumerate(self.param_groups):
             skipped = int(group.pop('skipped_steps', 0))
             step = group.get('step', 0)
@@ -163,6 +176,63 @@ class FusedAdam(torch.optim.Optimizer):
             if slot is not None:
                 slot[0].fill_(float(group['lr']))
                 slot[1] = float(group['lr'])
+
+    def _amp_fused_step(self, scale: torch.Tensor, growth_tracker: torch.Tensor, growth_factor: float, backoff_factor: float, growth_interval: int) -> bool:
+        """GradScaler.step + this step + GradScaler.update as ONE library call / two launches (nrc_amp_adam_step): inf / NaN check of the gradients
+        whose last workgroup settles the step counter, the bias corrections and the scaler's scale rule, then Adam on the (one or two) parameter
+        vectors.  For nerficg_amd.amp.GradScaler, which calls it when the optimizer has ONE group of at most two contiguous f32 device vectors with
+        gradients (InstantNGP: Trainer.py:35) and returns False otherwise (the caller then takes the general path).  Same arithmetic as step()."""
+        if len(self.param_groups) != 1:
+            return False
+        group = self.param_groups[0]
+        params = [p for p in group['params'] if p.grad is not None]
+        if not 1 <= len(params) <= 2 or not group['bias_correction']:
+            return False
+        dev = params[0].device
+        if scale.device != dev or any(p.device != dev or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse or not p.is_contiguous()
+                                      or not p.grad.is_contiguous() for p in params):
+            return False
+        lib = _lib.load()
+        beta1, beta2 = group['betas']
+        bc_dev, skipped, step_dev, lr_dev = self._device_scalars(0, group, dev)
+        if not self.capturable:
+            # the host counts every call (apex), the kernel counts the steps that were taken: a device counter = host count - skipped steps rides
+            # along; it is (re)derived with one host read whenever something else has moved the host count since the last fused step
+            if torch.is_tensor(group.get('step')):
+                group['step'] = int(group['step'].item())
+            mirror = self.__dict__.setdefault('_fused_mirror', {})
+            slot = mirror.get(0)
+            if slot is None or slot[1] != group.get('step', 0) or slot[0].device != dev:
+                slot = mirror[0] = [torch.full((1,), int(group.get('step', 0)) - int(skipped.item()), dtype=torch.int32, device=dev), group.get('step', 0)]
+            step_dev = slot[0]
+            group['step'] = slot[1] = group.get('step', 0) + 1
+        aux = self.__dict__.setdefault('_fused_aux', {})
+        if aux.get('dev') != dev:
+            aux.update(dev=dev, state=torch.zeros(4, dtype=torch.float32, device=dev), ticket=torch.zeros(17 * 16, dtype=torch.int32, device=dev))
+        args = []
+        owners = []
+        for p in params:
+            state = self.state[p]
+            if len(state) == 0:
+                state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            owner = getattr(p, '_nrc_half_owner', None)
+            owner = owner() if owner is not None else None
+            half = owner._half_for_optimizer(p) if owner is not None else None
+            l2 = self._l2_slice_of(p)
+            args += [_lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(state['exp_avg']), _lib.ptr(state['exp_avg_sq']), _lib.ptr(half), p.numel(), l2[1], l2[0]]
+            owners.append(owner)
+        if len(params) == 1:
+            args += [None, None, None, None, None, 0, 0.0, 0]
+        _lib.check(lib.nrc_amp_adam_step(*args, float(group['lr']), _lib.ptr(lr_dev), float(beta1), float(beta2), float(group['eps']), float(group['weight_decay']),
+                                         self.adam_w_mode, _lib.ptr(step_dev), _lib.ptr(bc_dev), _lib.ptr(scale), _lib.ptr(growth_tracker), float(growth_factor),
+                                         float(backoff_factor), int(growth_interval), _lib.ptr(aux['state']), _lib.ptr(aux['ticket']),
+                                         None if self.capturable else _lib.ptr(skipped), _lib.stream_of(params[0])), 'amp_adam_step')
+        for p, owner in zip(params, owners):
+            torch.autograd.graph.increment_version(p)
+            if owner is not None:
+                owner._half_written_by_optimizer(p)
+        return True
 
     def zero_grad(self, set_to_none: bool | None = None):
         super().zero_grad(set_to_none=self.set_grad_none if set_to_none is None else set_to_none)

@@ -92,6 +92,7 @@ struct AmpTensor { float* p; const float* g; float* m; float* v; __half* p16; in
 struct AmpList { AmpTensor t[2]; };
 struct AmpState {
     int32_t* device_step; float* bc;          // step counter (advanced unless an overflow was found), bias corrections (2)
+    int32_t* skipped;                         // optional: counts the overflow-skipped steps (FusedAdam's non-capturable bookkeeping)
     float* scale; int32_t* growth_tracker;    // the GradScaler's scalars (scale may be NULL: no scaler)
     float growth_factor, backoff_factor; int32_t growth_interval;
     float beta1, beta2;
@@ -103,6 +104,7 @@ __device__ __forceinline__ void amp_prepare_thread(const AmpState& a) {
     const bool overflow = __hip_atomic_load(&a.state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.f;
     int32_t step = *a.device_step;
     if (!overflow) *a.device_step = ++step;
+    else if (a.skipped) *a.skipped += 1;
     if (step < 1) step = 1;
     a.bc[0] = (float)(1.0 - pow((double)a.beta1, (double)step));
     a.bc[1] = (float)(1.0 - pow((double)a.beta2, (double)step));
@@ -194,7 +196,7 @@ void nrc_launch_amp_prepare(int32_t* device_step, float* bias_corrections, float
                             int32_t growth_interval, float beta1, float beta2, float* state4, hipStream_t s) {
     AmpState a;
     a.device_step = device_step; a.bc = bias_corrections; a.scale = scale; a.growth_tracker = growth_tracker; a.growth_factor = growth_factor;
-    a.backoff_factor = backoff_factor; a.growth_interval = growth_interval; a.beta1 = beta1; a.beta2 = beta2; a.state = state4; a.ticket = nullptr;
+    a.backoff_factor = backoff_factor; a.growth_interval = growth_interval; a.beta1 = beta1; a.beta2 = beta2; a.state = state4; a.ticket = nullptr; a.skipped = nullptr;
     hipLaunchKernelGGL(k_amp_prepare, dim3(1), dim3(64), 0, s, a);
 }
 void nrc_launch_amp_adam(float* pa, const float* ga, float* ma, float* va, void* ha, int64_t na, float l2c_a, int64_t l2n_a, float* pb, const float* gb, float* mb,
@@ -280,7 +282,7 @@ int nrc_amp_adam_step(float* param_a, const float* grad_a, float* exp_avg_a, flo
                       int64_t l2_count_a, float* param_b, const float* grad_b, float* exp_avg_b, float* exp_avg_sq_b, void* param_f16_b, int64_t n_b,
                       float l2_coeff_b, int64_t l2_count_b, float lr, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                       int32_t adam_w_mode, int32_t* device_step, float* bias_corrections, float* scale, int32_t* growth_tracker, float growth_factor,
-                      float backoff_factor, int32_t growth_interval, float* state4, void* ticket, nrc_stream_t stream) {
+                      float backoff_factor, int32_t growth_interval, float* state4, void* ticket, int32_t* skipped_steps, nrc_stream_t stream) {
     NRC_ENTER();
     if (n_a < 1 || n_b < 0 || !param_a || !grad_a || !exp_avg_a || !exp_avg_sq_a || (n_b && (!param_b || !grad_b || !exp_avg_b || !exp_avg_sq_b)) ||
         !device_step || !bias_corrections || !state4 || !ticket || (scale && (!growth_tracker || growth_interval < 1)))
@@ -292,6 +294,7 @@ int nrc_amp_adam_step(float* param_a, const float* grad_a, float* exp_avg_a, flo
     AmpState a;
     a.device_step = device_step; a.bc = bias_corrections; a.scale = scale; a.growth_tracker = growth_tracker; a.growth_factor = growth_factor;
     a.backoff_factor = backoff_factor; a.growth_interval = growth_interval; a.beta1 = beta1; a.beta2 = beta2; a.state = state4; a.ticket = (uint32_t*)ticket;
+    a.skipped = skipped_steps;
     const int64_t largest = n_a > n_b ? n_a : n_b;
     const int64_t blocks = nrc_cdiv(nrc_cdiv(largest, 4), 256);
     hipStream_t s = (hipStream_t)stream;

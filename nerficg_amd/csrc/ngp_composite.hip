@@ -488,6 +488,28 @@ __global__ void __launch_bounds__(1024) k_mse_scaled_fw(int64_t n, const float* 
         out2[1] = mean * (scale ? scale[0] : 1.f);
     }
 }
+// InstantNGPLoss.forward (Loss.py:18-26: MSE of the colours + 0.5e-6 * mean squared MLP weight) as ONE launch: a workgroup, both sums in a fixed order.
+// out3 = (mse + wd_weight * wd, mse, wd)
+__global__ void __launch_bounds__(1024) k_ngp_loss_fw(int64_t n, const float* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ wa,
+                                                      int64_t na, const float* __restrict__ wb, int64_t nb, float inv_n_weights, float wd_weight,
+                                                      float* __restrict__ out3) {
+    __shared__ float part[2][16];
+    float acc = 0.f, sq = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) { const float d = pred[i] - target[i]; acc += d * d; }
+    for (int64_t i = threadIdx.x; i < na; i += 1024) sq += wa[i] * wa[i];
+    for (int64_t i = threadIdx.x; i < nb; i += 1024) sq += wb[i] * wb[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { acc += __shfl_xor(acc, d, 64); sq += __shfl_xor(sq, d, 64); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = acc; part[1][threadIdx.x >> 6] = sq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { t0 += part[0][w]; t1 += part[1][w]; }
+        const float mse = t0 / (float)n, wd = t1 * inv_n_weights;
+        out3[0] = mse + wd_weight * wd; out3[1] = mse; out3[2] = wd;
+    }
+}
 __global__ void __launch_bounds__(256) k_mse_scaled_bw(int64_t n, const float* __restrict__ pred, const float* __restrict__ target,
                                                        const float* __restrict__ scale, const float* __restrict__ g_loss,
                                                        const float* __restrict__ g_scaled, float* __restrict__ grad_pred) {
@@ -735,6 +757,14 @@ int nrc_mse_scaled_forward(int64_t n, const float* pred, const float* target, co
     NRC_ENTER();
     if (n <= 0 || n > (int64_t(1) << 24) || !pred || !target || !out2) return NRC_ERR_INVALID;
     hipLaunchKernelGGL(k_mse_scaled_fw, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, pred, target, scale, out2);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_ngp_loss_forward(int64_t n, const float* pred, const float* target, const float* weights_a, int64_t n_a, const float* weights_b, int64_t n_b,
+                         float inv_n_weights, float weight_decay_weight, float* out3, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n <= 0 || n > (int64_t(1) << 24) || n_a < 0 || n_b < 0 || !pred || !target || (n_a && !weights_a) || (n_b && !weights_b) || !out3) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_ngp_loss_fw, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, pred, target, weights_a, n_a, weights_b, n_b, inv_n_weights, weight_decay_weight, out3);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -703,7 +703,9 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
 #if defined(NRC_MLP_GLDS)
                 glds_u = u;
 #endif
-                const bool same = CONTIG && rt_ring[p][u] == rt_have[p][u];   // (scalar) the next row of this wave is a row of the same ray tile
+                // (scalar) the next row of this wave is a row of the same ray tile -- AND slot u keeps its tile parity from group to group (NT even): with one
+                // tile per group, consecutive groups are the two halves of a row and read different lanes of the ray's SH fragment (advisor finding, round 4)
+                const bool same = CONTIG && (NT % 2 == 0) && rt_ring[p][u] == rt_have[p][u];
                 fetch((grp + PF * g_step) * NT + u, rt_ring[p][u], ring[p][u], same ? &cur[u] : nullptr);
                 rt_have[p][u] = rt_ring[p][u];
             }
@@ -837,12 +839,7 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
 template <int SRC>
 __global__ void __launch_bounds__(256, 4) k_encode_mlp(QueryIn in, int64_t base, int64_t n, const __half2* __restrict__ table, GridCfg g, int narrow_levels,
                                                        const h8* __restrict__ ray_sh, const __half* __restrict__ Wd, const __half* __restrict__ Wc,
-                                                       __half* __restrict__ packed) {    if (in.n_rows_dev) {
-        const int64_t have = (int64_t)in.n_rows_dev[0] * 64 - base;
-        n = have < n ? have : n;
-        if (n <= 0) return;
-    }
-
+                                                       __half* __restrict__ packed) {
     static_assert(SRC == SRC_TILED, "tiled layout only");
     enum { F_D0 = 0, F_DO = 4, F_C0 = 8, F_C1 = 12, F_CO = 20, N_FRAG = 24 };
     if constexpr (SRC == SRC_TILED) {
@@ -2009,15 +2006,18 @@ static GbLayout gb_layout(int64_t M, int n_bucket_levels, int nb) {
 __global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, GridCfg g, BucketCfg bc,
                                                              uint32_t* __restrict__ seg, uint32_t* __restrict__ wg_max, uint4* __restrict__ records,
                                                              int64_t rec_per_wg, const int32_t* __restrict__ m_live = nullptr) {
+    // (measured and dropped, round 5: dealing a batch of more than 256 x 1 024 samples evenly over one workgroup per CU in several passes instead of a
+    // second, almost empty round of workgroups -- 0.398 against 0.392 ms per training iteration: the few workgroups of the second round are cheap)
     // The levels are ranked in groups of GB_GROUP (rank and gradient registers per thread grow with the group).  16 = all levels at once is the
     // measured best: groups of 6 fit 64 VGPRs, i.e. two workgroups per CU, but spill and repeat the barriers (90 us against 56).
     __shared__ uint32_t hist[GB_MAX_BUCKETS], gbase[GB_MAX_BUCKETS], lmax[NRC_MAX_LEVELS], wave_tot[OWN_THREADS / 64];
     extern __shared__ uint4 stage[];   // [2][4096] records: two level images
-    const int n_wg = (int)gridDim.x;
-    if (threadIdx.x < NRC_MAX_LEVELS) lmax[threadIdx.x] = 0u;
-    const int64_t i = (int64_t)blockIdx.x * OWN_THREADS + threadIdx.x;
     const int64_t M_cap = M;
     if (m_live) M = min(M, (int64_t)max(*m_live, 0));   // workgroups behind the live rows still publish their (empty) runs
+    const int n_wg = (int)gridDim.x;
+    const int v = (int)blockIdx.x;
+    if (threadIdx.x < NRC_MAX_LEVELS) lmax[threadIdx.x] = 0u;
+    const int64_t i = (int64_t)blockIdx.x * OWN_THREADS + threadIdx.x;
     const bool in_range = i < M;
     float px = 0.f, py = 0.f, pz = 0.f;
     if (in_range) { px = x[3 * i]; py = x[3 * i + 1]; pz = x[3 * i + 2]; }
@@ -2037,7 +2037,7 @@ __global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restric
             bucket[pair] = (uint32_t)bc.bucket0[k] + (yz[pair] >> GB_SHIFT);
         }
     };
-    uint4* mine = records + (int64_t)blockIdx.x * rec_per_wg;
+    uint4* mine = records + (int64_t)v * rec_per_wg;
     uint32_t region = 0u;   // records of the groups before this one
     for (int k0 = 0; k0 < bc.n_levels; k0 += GB_GROUP) {
         const int b_lo = bc.bucket0[k0], b_hi = bc.bucket0[min(k0 + GB_GROUP, bc.n_levels)];
@@ -2095,11 +2095,11 @@ __global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restric
             const uint32_t start = before + incl - cnt;
             if (b < b_hi) {
                 gbase[b] = start;
-                seg[(int64_t)b * n_wg + blockIdx.x] = start | (c0 << 16);   // start < 1024 * 4 * 16 = 65536, count <= 4096
+                seg[(int64_t)b * n_wg + v] = start | (c0 << 16);   // start < 1024 * 4 * 16 = 65536, count <= 4096
             }
             if (b + 1 < b_hi) {
                 gbase[b + 1] = start + c0;
-                seg[(int64_t)(b + 1) * n_wg + blockIdx.x] = (start + c0) | (c1 << 16);
+                seg[(int64_t)(b + 1) * n_wg + v] = (start + c0) | (c1 << 16);
             }
             region += all;
         }
@@ -2137,7 +2137,7 @@ __global__ void __launch_bounds__(OWN_THREADS) k_gb_split(const float* __restric
         }
     }
     __syncthreads();
-    if (threadIdx.x < NRC_MAX_LEVELS) wg_max[(int64_t)blockIdx.x * NRC_MAX_LEVELS + threadIdx.x] = lmax[threadIdx.x];
+    if (threadIdx.x < NRC_MAX_LEVELS) wg_max[(int64_t)v * NRC_MAX_LEVELS + threadIdx.x] = lmax[threadIdx.x];
 }
 
 __global__ void __launch_bounds__(GBA_THREADS) k_gb_accumulate(GridCfg g, BucketCfg bc, int64_t M, int n_wg, const uint32_t* __restrict__ seg,
@@ -2509,6 +2509,15 @@ int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int3
     NRC_ENTER();
     return grid_backward_impl(x01, M, d_features, d_features_pair_major, n_levels, log2_hashmap_size, base_resolution, per_level_scale, grad_table,
                               workspace, stream, 0);
+}
+
+/* nrc_grid_backward over the first n_samples_dev[0] of M rows (a launch sized for a row capacity: fixed-capacity training batches) */
+int nrc_grid_backward_live(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels, int32_t log2_hashmap_size,
+                           int32_t base_resolution, float per_level_scale, float* grad_table, void* workspace, const int32_t* n_samples_dev,
+                           nrc_stream_t stream) {
+    NRC_ENTER();
+    return grid_backward_impl(x01, M, d_features, d_features_pair_major, n_levels, log2_hashmap_size, base_resolution, per_level_scale, grad_table,
+                              workspace, stream, 0, n_samples_dev);
 }
 
 /* bytes of the scratch the two calls below need: features of all M samples */

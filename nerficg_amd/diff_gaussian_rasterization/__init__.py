@@ -87,7 +87,7 @@ def last_counts() -> torch.Tensor | None:
     return _LAST_COUNTS
 
 
-_GRAD_RECORDS: dict = {}   # (device, rows, stream) -> (rows, 16) f32 accumulator records known to be all zero (see backward)
+_GRAD_RECORDS: dict = {}   # (device, stream) -> (rows, (rows, 16) f32 accumulator records known to be all zero): ONE buffer per device and stream (see backward)
 _SPAN_CAPACITY: dict = {}  # (device, P, W, H) -> row-span capacity of the binning workspace once the default proved too small
 # Speculative sizing of the tile lists (round 4).  The forward used to STOP at the instance count: D2H copy, host wait, allocation, and only then
 # the list scatter and the blend -- 33-37 us of idle GPU per frame at 1 M Gaussians (rocprofv3 kernel trace).  Now the lists are sized from the
@@ -297,8 +297,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         # previous backward of the same size is all zero again and is reused without a clearing launch (one buffer per device, size and stream).
         # A recording (HIP-graph capture) takes a buffer of its own and keeps the clearing launch: the recorded pointer must not be shared.
         capturing = torch.cuda.is_current_stream_capturing()
-        rec_key = (dev, n1, torch.cuda.current_stream(dev).cuda_stream)
-        grad_records = None if capturing else _GRAD_RECORDS.pop(rec_key, None)
+        rec_key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        kept = None if capturing else _GRAD_RECORDS.pop(rec_key, None)
+        # the kept buffer serves the same number of Gaussians only (densification changes P every few hundred steps: the old buffer is dropped then,
+        # not parked -- eight parked sizes were ~3 GB at 6 M Gaussians, advisor finding of round 4)
+        grad_records = kept[1] if kept is not None and kept[0] == n1 else None
         records_clear = grad_records is not None
         if grad_records is None:
             grad_records = torch.empty(n1, 16, dtype=f32, device=dev)
@@ -318,10 +321,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(point_list), _lib.ptr(ranges), _lib.ptr(splat), _lib.ptr(tile_order), _lib.ptr(n_contrib), _lib.ptr(final_T),
             _lib.ptr(g), _lib.ptr(dmean2D), None, _lib.ptr(dopacity), _lib.ptr(dcolor), _lib.ptr(dmean3D), _lib.ptr(dcov3D),
             _lib.ptr(dsh), _lib.ptr(dsh_rest), _lib.ptr(dscale), _lib.ptr(drot), _lib.ptr(grad_records), int(records_clear), _lib.stream_of(g)), 'gs_backward')
-        if not capturing:
-            if len(_GRAD_RECORDS) >= 8:
-                _GRAD_RECORDS.pop(next(iter(_GRAD_RECORDS)))
-            _GRAD_RECORDS[rec_key] = grad_records   # only after a call that went through: a failed one leaves the entry popped (contents unknown)
+        if not capturing and P > 0:   # (P == 0: the library returned before touching the uninitialised buffer -- it is NOT known to be zero)
+            _GRAD_RECORDS[rec_key] = (n1, grad_records)   # only after a call that went through: a failed one leaves the entry popped (contents unknown)
         return (dmean3D[:P], dmean2D[:P], dsh[:P] if has_sh else None, dcolor[:P] if has_col else None,
                 dopacity[:P].reshape(ctx.opacity_shape), dscale[:P] if has_sr else None, drot[:P] if has_sr else None,
                 dcov3D[:P] if has_cov else None, None, dsh_rest[:P] if has_rest else None, None)

@@ -111,6 +111,33 @@ class InstantNGPModel(torch.nn.Module):
         return weight_decay_mlp(self.encoding_xyz, self.color_mlp_with_encoding, self.n_params_encoding_mlp, self.n_mlp_params)
 
 
+class InstantNGPLoss(torch.nn.Module):
+    """src/Methods/InstantNGP/Loss.py:11-26: 'MSE_Color' (weight 1) + 'Weight_Decay_MLP' (weight 0.5e-6) on a training batch, same call signature
+    forward(outputs, rays, bg_color) with `rays` anything that has `.rgb` and `.alpha` (RayBatch) or a dict with those keys.  One node / one launch
+    each way (nerficg_amd.ngp.instant_ngp_loss); `last` holds (loss, mse, weight decay) of the latest call on the device, `psnr()` the quality
+    metric the reference logs (computed when asked, not every iteration)."""
+
+    def __init__(self, model: InstantNGPModel, weight_decay_weight: float = 1.0e-6 / 2.0) -> None:
+        super().__init__()
+        self.model, self.weight_decay_weight = model, float(weight_decay_weight)
+        self.last: torch.Tensor | None = None
+
+    def forward(self, outputs: dict, rays, bg_color: torch.Tensor) -> torch.Tensor:
+        from .ngp import instant_ngp_loss
+        field = (lambda k: rays.get(k)) if isinstance(rays, dict) else (lambda k: getattr(rays, k, None))
+        rgb, alpha = field('rgb'), field('alpha')
+        if alpha is not None:   # apply_background_color (Datasets/utils.py:185-189)
+            rgb = torch.lerp(bg_color.to(rgb.device), rgb, alpha.reshape(-1, 1)).clamp(0, 1)
+        m = self.model
+        loss, self.last = instant_ngp_loss(outputs['rgb'], rgb, m.encoding_xyz, m.color_mlp_with_encoding, m.n_params_encoding_mlp, m.n_mlp_params,
+                                           self.weight_decay_weight)
+        return loss
+
+    def psnr(self) -> torch.Tensor:
+        """10 log10(1 / MSE) of the latest batch (torchmetrics' peak_signal_noise_ratio with data_range 1, Loss.py:17)"""
+        return -10.0 * torch.log10(self.last[1])
+
+
 class InstantNGPRenderer:
     """Rendering + occupancy maintenance for an InstantNGPModel.  Configuration keys as in src/Methods/InstantNGP/Renderer.py:141-145."""
 
@@ -135,18 +162,25 @@ class InstantNGPRenderer:
         self.sample_capacity: int | None = None
 
     # ---------------------------------------------------------------- the two networks
+    @staticmethod
+    def _host_copies(cache, tensors):
+        """host copies of small device tensors, re-read only when one of them is another object or was written to (identity + version counter): a
+        checkpoint loaded into the model, or a box set by hand, reaches the next frame (advisor finding of round 4: the copies were read once per renderer)"""
+        key = tuple((id(t), t._version) for t in tensors)
+        if cache is None or cache[0] != key:
+            cache = (key, tuple(t.detach().float().reshape(-1).cpu().contiguous() for t in tensors))
+        return cache
+
     def _box(self):
-        if self._box_host is None:
-            m = self.model
-            self._box_host = (m.xyz_min.detach().float().cpu().contiguous(), m.xyz_size.detach().float().cpu().contiguous())
-        return self._box_host
+        m = self.model
+        self._box_host = self._host_copies(self._box_host, (m.xyz_min, m.xyz_size))
+        return self._box_host[1]
 
     def _scene_box(self):
-        """(centre, half size) of the scene box as host tensors, read once."""
-        if self._scene_box_host is None:
-            m = self.model
-            self._scene_box_host = (m.center.detach().float().reshape(-1).cpu().contiguous(), m.half_size.detach().float().reshape(-1).cpu().contiguous())
-        return self._scene_box_host
+        """(centre, half size) of the scene box as host tensors; read again when the model's buffers change."""
+        m = self.model
+        self._scene_box_host = self._host_copies(self._scene_box_host, (m.center, m.half_size))
+        return self._scene_box_host[1]
 
     def query(self, xyzs: torch.Tensor, dirs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """(density, colour) of box-centred sample positions seen along unit directions.  With autograd on: one node that reaches both

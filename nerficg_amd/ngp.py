@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-__all__ = ['query_fused', 'query_train', 'composite_over_background', 'weight_decay_mlp']
+__all__ = ['query_fused', 'query_train', 'composite_over_background', 'weight_decay_mlp', 'instant_ngp_loss']
 
 
 def query_fused(density_net, color_net, xyz01: torch.Tensor, dirs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
@@ -88,22 +88,66 @@ class _WeightDecayNode(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type='cuda')
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        import weakref
         params_d, params_c = ctx.saved_tensors
         up = g.detach().to(torch.float32).reshape(1).contiguous()
-        was_empty = not _GRAD_SEEDS
-        for p, count in ((params_d, ctx.n_d), (params_c, params_c.numel())):
-            prev = _GRAD_SEEDS.get(p.data_ptr())
-            if prev is not None and prev[0]() is p:      # a second term on the same parameter in one pass: settle the first the ordinary way
-                _GRAD_SEEDS.pop(p.data_ptr())
-                with torch.no_grad():
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                    p.grad[:prev[3]].add_(p.detach()[:prev[3]] * (prev[2] * prev[1]))
-            _GRAD_SEEDS[p.data_ptr()] = (weakref.ref(p), up, 2.0 / ctx.n_total, count)
-        if was_empty:
-            torch.autograd.Variable._execution_engine.queue_callback(_flush_seeds)
+        _leave_seeds(((params_d, ctx.n_d), (params_c, params_c.numel())), up, 2.0 / ctx.n_total)
         return None, None, None, None
+
+
+def _leave_seeds(params_and_counts, up, coeff: float) -> None:
+    """register (up * coeff * w) as the pending gradient of the leading weights of each parameter (see _GRAD_SEEDS)"""
+    import weakref
+    was_empty = not _GRAD_SEEDS
+    for p, count in params_and_counts:
+        prev = _GRAD_SEEDS.get(p.data_ptr())
+        if prev is not None and prev[0]() is p:      # a second term on the same parameter in one pass: settle the first the ordinary way
+            _GRAD_SEEDS.pop(p.data_ptr())
+            with torch.no_grad():
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                p.grad[:prev[3]].add_(p.detach()[:prev[3]] * (prev[2] * prev[1]))
+        _GRAD_SEEDS[p.data_ptr()] = (weakref.ref(p), up, coeff, count)
+    if was_empty:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_seeds)
+
+
+class _NGPLoss(torch.autograd.Function):
+    """InstantNGPLoss.forward (Loss.py:18-26): mse_loss(rgb, colour) + 0.5e-6 * weight_decay_mlp() as one node -- one launch forward, one backward."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, pred, target, params_d, params_c, n_d, n_total, wd_weight):
+        pred, target = pred.contiguous(), target.contiguous()
+        if pred.shape != target.shape:
+            raise RuntimeError(f'instant_ngp_loss: prediction {tuple(pred.shape)} vs target {tuple(target.shape)}')
+        out3 = torch.empty(3, dtype=torch.float32, device=pred.device)
+        _lib.check(_lib.load().nrc_ngp_loss_forward(pred.numel(), _lib.ptr(pred), _lib.ptr(target), _lib.ptr(params_d), n_d, _lib.ptr(params_c), params_c.numel(),
+                                                    1.0 / n_total, float(wd_weight), _lib.ptr(out3), _lib.stream_of(pred)), 'ngp_loss_forward')
+        ctx.save_for_backward(pred, target, params_d, params_c)
+        ctx.n_d, ctx.n_total, ctx.wd_weight = n_d, n_total, float(wd_weight)
+        _NGPLoss.parts = out3      # (loss, mse, weight decay) of the latest call, for logging: not an output of the node
+        return out3[0]
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        pred, target, params_d, params_c = ctx.saved_tensors
+        up = g.detach().to(torch.float32).reshape(1).contiguous()
+        grad = torch.empty_like(pred)
+        _lib.check(_lib.load().nrc_mse_scaled_backward(pred.numel(), _lib.ptr(pred), _lib.ptr(target), None, _lib.ptr(up), None, _lib.ptr(grad),
+                                                       _lib.stream_of(pred)), 'mse_scaled_backward')
+        if ctx.wd_weight != 0.0 and params_d.requires_grad:
+            _leave_seeds(((params_d, ctx.n_d), (params_c, params_c.numel())), up, ctx.wd_weight * 2.0 / ctx.n_total)
+        return grad, None, None, None, None, None, None
+
+
+def instant_ngp_loss(pred_rgb: torch.Tensor, target_rgb: torch.Tensor, density_net, color_net, n_density_mlp: int, n_total: int,
+                     weight_decay_weight: float = 0.5e-6) -> tuple[torch.Tensor, torch.Tensor]:
+    """-> (loss, parts) with loss = mse_loss(pred_rgb, target_rgb) + weight_decay_weight * weight_decay_mlp() (0-d, differentiable w.r.t. the prediction and,
+    through the gradient seeds, the MLP weights) and parts = (loss, mse, weight decay) as a non-differentiable (3,) tensor for logging."""
+    loss = _NGPLoss.apply(pred_rgb, target_rgb, density_net.params, color_net.params, int(n_density_mlp), int(n_total), float(weight_decay_weight))
+    return loss, _NGPLoss.parts.detach()
 
 
 class _QueryTrain(torch.autograd.Function):

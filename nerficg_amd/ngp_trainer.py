@@ -224,7 +224,7 @@ class FusedTrainingIteration:
         _lib.check(lib.nrc_amp_adam_step(
             p(st['pd']), p(self.gd), p(st['md']), p(st['vd']), p(st['hd']), self.gd.numel(), self.l2[0][0], self.l2[0][1],
             p(st['pc']), p(self.gc), p(st['mc']), p(st['vc']), p(st['hc']), self.gc.numel(), self.l2[1][0], self.l2[1][1],
-            *hyper, p(self.amp_ticket), stream), 'amp_adam_step')
+            *hyper, p(self.amp_ticket), None, stream), 'amp_adam_step')
 
     def _enqueue(self, cur: int, inline: bool, prefetch: bool, st: dict, explicit) -> None:
         if inline:

@@ -163,3 +163,25 @@ def test_fast_grad_scaler_follows_torch_grad_scaler():
         assert torch.equal(pa, pb) and torch.equal(qa, qb) and sa == sb
     assert torch.equal(results[1][2][0], results[1][1][0])   # the overflowing iteration changed nothing
     assert results[1][2][2] == 0.5 * results[1][1][2]         # and halved the scale
+
+
+def test_load_state_dict_keeps_the_live_moment_tensors():
+    """A recorded iteration holds raw pointers to exp_avg / exp_avg_sq: load_state_dict must fill the LIVE tensors instead of replacing them
+    (advisor finding of round 4), for the capturable and the plain mode."""
+    from nerficg_amd.apex_optimizers import FusedAdam
+    for capturable in (False, True):
+        p = torch.nn.Parameter(torch.randn(5000, device=DEV))
+        opt = FusedAdam([p], lr=1e-2, capturable=capturable)
+        for _ in range(3):
+            p.grad = torch.randn_like(p)
+            opt.step()
+        ptrs = (opt.state[p]['exp_avg'].data_ptr(), opt.state[p]['exp_avg_sq'].data_ptr())
+        sd = {k: (v if k != 'state' else {i: {n: t.clone() for n, t in st.items()} for i, st in v.items()}) for k, v in opt.state_dict().items()}
+        want = sd['state'][0]['exp_avg'].clone()
+        p.grad = torch.randn_like(p)
+        opt.step()                                      # the live moments move on ...
+        assert not torch.equal(opt.state[p]['exp_avg'], want)
+        opt.load_state_dict(sd)                         # ... and come back through the load, in the same storage
+        assert (opt.state[p]['exp_avg'].data_ptr(), opt.state[p]['exp_avg_sq'].data_ptr()) == ptrs
+        assert torch.equal(opt.state[p]['exp_avg'], want)
+        assert opt.effective_step(opt.param_groups[0]) == 3

@@ -323,3 +323,66 @@ def test_weight_decay_seeds_join_the_training_query_gradient():
     (128.0 * loss).backward()
     without = plain.encoding_xyz.params.grad
     assert float((without[mlp] - results[0][0][mlp]).abs().mean()) > 10 * float((results[2][0][mlp] - results[0][0][mlp]).abs().mean())
+
+
+def test_instant_ngp_loss_module_equals_the_reference_expression_and_the_fused_scaler_step_the_plain_one():
+    """InstantNGPLoss (Loss.py:11-26) as one node + GradScaler.step / update as one library call (nrc_amp_adam_step) against the statement-by-statement
+    forms: mse_loss + 0.5e-6 * (torch expression of the weight decay), torch.amp.GradScaler around the same FusedAdam.  Three iterations each; the
+    weight decay 1e6 times the reference's so that it shows."""
+    from nerficg_amd.amp import GradScaler
+    from nerficg_amd.apex_optimizers import FusedAdam
+    from nerficg_amd.instant_ngp import InstantNGPLoss, InstantNGPRenderer
+    from tests.noise import assert_within_run_to_run_noise
+    from tests.test_gpu_graphs import _rays as image_rays
+    from tests.test_gpu_render_parity import make_model
+    cam, o, d = image_rays()
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    batches = [dict(ids=torch.randint(0, o.shape[0], (1024,), device=DEV, generator=gen), rgb=torch.rand(1024, 3, device=DEV, generator=gen),
+                    alpha=torch.rand(1024, device=DEV, generator=gen), bg=torch.rand(3, device=DEV, generator=gen), noise=torch.rand(1024, device=DEV, generator=gen))
+               for _ in range(3)]
+    results, losses = [], []
+    for form in ('plain', 'plain', 'fused'):
+        model = make_model(seed=6, table_amp=1e-4)
+        renderer = InstantNGPRenderer(model)
+        opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
+        scaler = GradScaler(init_scale=128.0, growth_interval=2) if form == 'fused' else torch.amp.GradScaler(init_scale=128.0, growth_interval=2)
+        criterion = InstantNGPLoss(model, weight_decay_weight=0.5)
+        ls = []
+        for b in batches:
+            ids = b['ids']
+            with torch.amp.autocast('cuda'):
+                out = renderer.render_rays(o[ids], d[ids], cam, train_mode=True, custom_bg_color=b['bg'], noise=b['noise'])
+                if form == 'fused':
+                    loss = criterion(out, {'rgb': b['rgb'], 'alpha': b['alpha']}, b['bg'])
+                else:
+                    gt = torch.lerp(b['bg'], b['rgb'], b['alpha'][:, None]).clamp(0, 1)
+                    loss = torch.nn.functional.mse_loss(out['rgb'].float(), gt) + 0.5 * _wd_reference(model)
+            scaler.scale(loss).backward()
+            scaler.step(opt); scaler.update(); opt.zero_grad()
+            ls.append(float(loss))
+        results.append([p.detach().clone() for p in model.parameters()])
+        losses.append(ls)
+        assert float(scaler.get_scale()) == 256.0 and opt.effective_step(opt.param_groups[0]) == 3      # one growth after two clean steps
+        if form == 'fused':
+            np.testing.assert_allclose(float(criterion.last[0]), ls[-1], rtol=1e-6)
+            np.testing.assert_allclose(float(criterion.psnr()), -10 * np.log10(float(criterion.last[1])), rtol=1e-5)
+    np.testing.assert_allclose(losses[2], losses[0], rtol=2e-3)
+    assert_within_run_to_run_noise(results[2], results[0], results[1], atol=1e-5, rtol=1e-3, what='three iterations, fused loss node and fused scaler step')
+
+
+def test_renderer_follows_a_box_that_changes_after_the_first_frame():
+    """The renderer keeps HOST copies of the model's box (no read-back per frame); they must be re-read when the buffers are written or replaced --
+    a checkpoint with another CENTER loaded into an existing model (advisor finding of round 4)."""
+    from nerficg_amd.instant_ngp import InstantNGPModel, InstantNGPRenderer
+    model = InstantNGPModel(RANDOM_SEED=0, device=DEV)
+    renderer = InstantNGPRenderer(model)
+    c0, h0 = renderer._scene_box()
+    assert renderer._scene_box()[0] is c0                       # cached while nothing changes
+    model.center.add_(0.25)                                     # written in place
+    c1, _ = renderer._scene_box()
+    assert torch.allclose(c1, c0 + 0.25)
+    model.xyz_min = model.xyz_min * 2                           # replaced by a new tensor
+    assert torch.allclose(renderer._box()[0], torch.full((3,), -1.0))
+    o, d = _rays(2000)
+    o2, _, _ = renderer.clip_rays(o, d, make_camera(8, 8))
+    assert torch.equal(o2, o - model.center)

@@ -294,7 +294,7 @@ def test_amp_adam_step_equals_check_prepare_adam_update(poison):
     state, ticket = torch.zeros(4, device=DEV), torch.zeros(17 * 16, dtype=torch.int32, device=DEV)
     for ga, gb in steps:
         _lib.check(lib.nrc_amp_adam_step(p(pa), p(ga), p(ma), p(va), p(ha), na, 1e-3, 3000, p(pb), p(gb), p(mb), p(vb), p(hb), nb, 0.0, 0, 1e-2, None, 0.9, 0.99,
-                                         1e-15, 0.0, 0, p(step), p(bc), p(scale), p(tracker), 2.0, 0.5, 2, p(state), p(ticket), _lib.stream_of(pa)), 'amp_adam_step')
+                                         1e-15, 0.0, 0, p(step), p(bc), p(scale), p(tracker), 2.0, 0.5, 2, p(state), p(ticket), None, _lib.stream_of(pa)), 'amp_adam_step')
     assert torch.equal(pa, ra.detach()) and torch.equal(pb, rb.detach())
     assert torch.equal(ma, opt.state[ra]['exp_avg']) and torch.equal(vb, opt.state[rb]['exp_avg_sq'])
     assert torch.equal(ha, pa.half()) and torch.equal(hb, pb.half())

@@ -298,3 +298,48 @@ def test_amp_training_step_updates_params(density_net, color_net):
     with torch.no_grad():
         for b, p in zip(before, params):
             p.copy_(b)
+
+
+@pytest.mark.parametrize('m', [262_144, 262_145, 300_001, 540_000])
+def test_grid_backward_above_one_round_of_split_workgroups(m):
+    """Batches around and above 256 x 1 024 samples (more split workgroups than CUs) and launches sized for a row CAPACITY with the live count on the
+    device (nrc_grid_backward_live): the bucketed gradient equals the atomics path's (to f32 summation order), rows behind the live ones are not
+    read, and the fixed-point sums of the hashed levels do not depend on the layout -- bit-identical between the two."""
+    from nerficg_amd import _lib
+    lib = _lib.load()
+    grid = dict(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=PLS)
+    total, offsets, _, _ = oracle.grid_layout(**grid)
+    gen = torch.Generator(device=DEV).manual_seed(m)
+    # consecutive samples along rays, like a training batch
+    n_rays = m // 120 + 1
+    o = torch.rand(n_rays, 3, device=DEV, generator=gen) * 0.2 + 0.1
+    dirs = torch.nn.functional.normalize(torch.rand(n_rays, 3, device=DEV, generator=gen) + 0.1, dim=-1)
+    t = torch.arange(120, device=DEV) * (3 ** 0.5 / 1024)
+    x = (o[:, None, :] + t[None, :, None] * dirs[:, None, :]).reshape(-1, 3)[:m].clamp(0, 1).contiguous()
+    d = torch.randn(16, m, 2, device=DEV, generator=gen) * 1e-3
+    d[:, torch.rand(m, device=DEV, generator=gen) < 0.3] = 0.0
+    d = d.contiguous()
+
+    def run(cap, workspace=True):
+        xs, ds = x, d
+        live = None
+        if cap > m:     # rows behind the live ones: garbage that must not be read
+            xs = torch.cat([x, torch.full((cap - m, 3), 0.5, device=DEV)]).contiguous()
+            ds = torch.cat([d, torch.full((16, cap - m, 2), 7.0, device=DEV)], dim=1).contiguous()
+            live = torch.tensor([m, 0], dtype=torch.int32, device=DEV)
+        ws = torch.empty(int(lib.nrc_grid_backward_ws_bytes(cap, 16, 19, 16, PLS)), dtype=torch.uint8, device=DEV) if workspace else None
+        g = torch.zeros(total, 2, device=DEV)
+        if live is None:
+            _lib.check(lib.nrc_grid_backward(_lib.ptr(xs), cap, _lib.ptr(ds), 1, 16, 19, 16, PLS, _lib.ptr(g), _lib.ptr(ws), _lib.stream_of(g)), 'grid_backward')
+        else:
+            _lib.check(lib.nrc_grid_backward_live(_lib.ptr(xs), cap, _lib.ptr(ds), 1, 16, 19, 16, PLS, _lib.ptr(g), _lib.ptr(ws), _lib.ptr(live), _lib.stream_of(g)),
+                       'grid_backward_live')
+        return g
+    a, plain, other = run(m), run(m, workspace=False), run(m + 70_000)
+    first_hashed = next(l for l in range(16) if offsets[l + 1] - offsets[l] == 2 ** 19)
+    h0 = offsets[first_hashed]
+    assert torch.equal(a[h0:], other[h0:])                       # fixed-point sums: independent of how the samples were dealt to workgroups
+    scale = float(plain.abs().max())
+    assert float((a - plain).abs().max()) <= 2e-5 * scale + 1e-12, float((a - plain).abs().max()) / scale
+    assert float((other[:h0] - plain[:h0]).abs().max()) <= 2e-5 * scale + 1e-12
+    assert int((a[h0:] != 0).sum()) > m

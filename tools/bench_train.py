@@ -22,12 +22,17 @@ from nerficg_amd.amp import GradScaler
 scaler = GradScaler(init_scale=128.0, growth_interval=10 ** 9)
 target = torch.rand(origin.shape[0], 3, device=dev)
 
+from nerficg_amd.instant_ngp import InstantNGPLoss
+from nerficg_amd.ngp import gather_ray_batch
+criterion = InstantNGPLoss(model)
+
 def step(i):
     ids = perm[(i * n_rays) % (perm.numel() - n_rays):][:n_rays]
+    batch = gather_ray_batch(ids, origin, vdir, target)       # RayPoolSampler.get: ray_pool[ids], every field in one launch
     with torch.amp.autocast('cuda'):
         bg = torch.rand(3, device=dev)
-        out = renderer.render_rays(origin[ids], vdir[ids], cam, train_mode=True, custom_bg_color=bg)
-        loss = torch.nn.functional.mse_loss(out['rgb'].float(), target[ids]) + 0.5e-6 * model.weight_decay_mlp()
+        out = renderer.render_rays(batch['origin'], batch['view_direction'], cam, train_mode=True, custom_bg_color=bg)
+        loss = criterion(out, batch, bg)
     scaler.scale(loss).backward()
     scaler.step(opt); scaler.update(); opt.zero_grad()
     return int(out['rm_samples'].item())
