@@ -1204,6 +1204,15 @@ __device__ __forceinline__ unsigned block_flags(const float4& q0, const float4& 
     }
     return f;
 }
+// The exponent of a Gaussian at a pixel: -1/2 (A dx^2 + C dy^2) - B dx dy, as SEVEN instructions with explicit fused multiply-adds where the source-order
+// form takes nine (this translation unit is built without contraction: the integer decisions of the per-Gaussian kernels must not move).  The blend
+// kernels are bound by VALU issue (profiles/: 0.70-0.78 of the issue slots at 315 M blends per frame), so instructions per blend are what they cost.
+// The upstream binary is an nvcc build with -fmad=true, i.e. it fuses in these places too; WHICH pairs it fuses is not recoverable, so the oracle
+// (oracle/gs_oracle_impl.h: GS_BLEND_POWER / test_T / the colour sums) states the same fusions and n_contrib / final_T stay bit-exact against it.
+__device__ __forceinline__ float blend_power(float A, float B, float C, float dx, float dy) {
+    const float t2 = fmaf(C * dy, dy, (A * dx) * dx);
+    return fmaf(-0.5f, t2, -((B * dx) * dy));
+}
 #define N_BLOCKS 16
 // One staged batch: thread t read entry t's 64-byte record; what the blend loop needs goes to LDS as two 16-byte vectors and a scalar.
 struct StageLds {
@@ -1278,6 +1287,9 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last = 0;
     const uint32_t* list4 = reinterpret_cast<const uint32_t*>(st.list[block]);
+    // everything the blend loop reads from LDS must be FINITE also for a row that is past the end of its list and picks up a stale index (see the
+    // weight below): thread t clears slot t, which only thread t ever stages into
+    st.a[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); st.b[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); st.c[threadIdx.x] = 0.f;
     for (uint32_t base = r0; base < r1; base += BATCH) {
         if (__syncthreads_count(done) == 256) break;
         const uint32_t k = base + threadIdx.x;
@@ -1312,19 +1324,22 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const float dx = a_j[u].x - fx, dy = a_j[u].y - fy;
-                const float power = -0.5f * (b_j[u].x * dx * dx + b_j[u].z * dy * dy) - b_j[u].y * dx * dy;
-                alpha[u] = fminf(0.99f, b_j[u].w * expf(power));
+                alpha[u] = fminf(0.99f, b_j[u].w * expf(blend_power(b_j[u].x, b_j[u].y, b_j[u].z, dx, dy)));
+                const float power = blend_power(b_j[u].x, b_j[u].y, b_j[u].z, dx, dy);
                 ok[u] = (jj + u < n_mine) & !(power > 0.0f) & !(alpha[u] < 1.0f / 255.0f);
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const float test_T = T * (1 - alpha[u]);
+                const float test_T = fmaf(-T, alpha[u], T);   // T (1 - alpha), one rounding (blend_power's note)
                 const bool valid = ok[u] & !done;
                 const bool sat = valid & (test_T < 0.0001f);
                 const bool upd = valid & !sat;
                 done = done | sat;
-                // masked lanes add an exact 0 (a select, not a product: a stale or never-written LDS entry behind the list end may hold a NaN)
-                C0 += upd ? a_j[u].z * alpha[u] * T : 0.f; C1 += upd ? a_j[u].w * alpha[u] * T : 0.f; C2 += upd ? c_j[u] * alpha[u] * T : 0.f;
+                // One weight alpha T per Gaussian -- an exact 0 for a masked lane (a select: alpha of a stale entry behind the list end is finite but
+                // arbitrary) -- and three multiply-adds: 5 VALU instructions where the unfused, per-channel-masked form took 15.  The colours of a
+                // masked entry are multiplied by that 0: they are finite, because the staging arrays start as zeros and only ever receive records.
+                const float w = upd ? alpha[u] * T : 0.f;
+                C0 = fmaf(a_j[u].z, w, C0); C1 = fmaf(a_j[u].w, w, C1); C2 = fmaf(c_j[u], w, C2);
                 T = upd ? test_T : T;
                 last = upd ? pos0 + (uint32_t)j[u] : last;
             }
@@ -1496,7 +1511,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             const float4 xyrg = st.a[e.j];
             e.c0 = xyrg.z; e.c1 = xyrg.w; e.c2 = st.c[e.j];
             e.dx = xyrg.x - fx; e.dy = xyrg.y - fy;
-            const float power = -0.5f * (e.co.x * e.dx * e.dx + e.co.z * e.dy * e.dy) - e.co.y * e.dx * e.dy;
+            const float power = blend_power(e.co.x, e.co.y, e.co.z, e.dx, e.dy);
             e.G = expf(power);
             e.alpha = fminf(0.99f, e.co.w * e.G);
             e.active = (jj < n_mine) & inside & (pos < last) & !(power > 0.0f) & !(e.alpha < 1.0f / 255.0f);

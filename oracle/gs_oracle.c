@@ -19,6 +19,7 @@ static inline int IMAX(int a, int b) { return a > b ? a : b; }
 #define CEIL ceilf
 #define FMIN fminf
 #define FMAX fmaxf
+#define FMA fmaf
 #include "gs_oracle_impl.h"
 #undef REAL
 #undef FN
@@ -27,6 +28,8 @@ static inline int IMAX(int a, int b) { return a > b ? a : b; }
 #undef CEIL
 #undef FMIN
 #undef FMAX
+#undef FMA
+#undef GS_BLEND_POWER
 
 #define REAL double
 #define FN(name) gsd_##name
@@ -35,6 +38,7 @@ static inline int IMAX(int a, int b) { return a > b ? a : b; }
 #define CEIL ceil
 #define FMIN fmin
 #define FMAX fmax
+#define FMA fma
 #include "gs_oracle_impl.h"
 
 

@@ -1,6 +1,7 @@
 /*
  * oracle/gs_oracle_impl.h -- body of the 3D Gaussian Splatting rasterizer oracle, instantiated twice by gs_oracle.c:
- *   REAL = float  -> gsf_*  : the parity oracle for the HIP rasterizer (same f32 arithmetic, source order, no FMA)
+ *   REAL = float  -> gsf_*  : the parity oracle for the HIP rasterizer (same f32 arithmetic, source order, no FMA -- except in the
+ *                             per-pixel blend, see GS_BLEND_POWER)
  *   REAL = double -> gsd_*  : used only by tests to validate the analytic backward against finite differences
  *
  * TEST INFRASTRUCTURE ONLY.
@@ -21,6 +22,12 @@
  */
 
 #define TILE 16
+
+/* The per-pixel blend arithmetic (round 5).  The upstream rasterizer is an nvcc build (-fmad=true): its forward / backward blend loops contain fused
+ * multiply-adds, which pairs exactly is not recoverable from source.  The HIP blend kernels are bound by VALU issue, so they state the exponent, the
+ * transmittance update and the colour sums with EXPLICIT fused multiply-adds (csrc/gs_raster.hip: blend_power); the oracle states the same
+ * fusions here, so the integer outputs that depend on them (n_contrib) and final_T stay bit-exact.  FMA is fmaf / fma: correctly rounded. */
+#define GS_BLEND_POWER(A, B, C, dx, dy) FMA((REAL)-0.5, FMA((C) * (dy), (dy), ((A) * (dx)) * (dx)), -(((B) * (dx)) * (dy)))
 
 static inline void FN(xform43)(const REAL* p, const REAL* m, REAL* o) {
     o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
@@ -224,13 +231,14 @@ void FN(bin_and_render)(int P, int W, int H, const REAL* bg, const int32_t* radi
                 const int id = point_list[k];
                 const REAL dx = points_xy[2 * id] - (REAL)px, dy = points_xy[2 * id + 1] - (REAL)py;
                 const REAL* co = conic_opacity + 4 * id;
-                const REAL power = (REAL)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                const REAL power = GS_BLEND_POWER(co[0], co[1], co[2], dx, dy);
                 if (power > 0) continue;
                 const REAL alpha = FMIN((REAL)0.99, co[3] * EXP(power));
                 if (alpha < (REAL)1 / (REAL)255) continue;
-                const REAL test_T = T * (1 - alpha);
+                const REAL test_T = FMA(-T, alpha, T);
                 if (test_T < (REAL)0.0001) break;
-                for (int c = 0; c < 3; c++) C[c] += rgb[3 * id + c] * alpha * T;
+                const REAL w = alpha * T;
+                for (int c = 0; c < 3; c++) C[c] = FMA(rgb[3 * id + c], w, C[c]);
                 T = test_T;
                 last = contributor;
             }
@@ -272,7 +280,7 @@ void FN(backward)(int P, int D, int M, int W, int H, const REAL* bg, const REAL*
                 const int id = point_list[k];
                 const REAL dx = points_xy[2 * id] - (REAL)px, dy = points_xy[2 * id + 1] - (REAL)py;
                 const REAL* co = conic_opacity + 4 * id;
-                const REAL power = (REAL)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                const REAL power = GS_BLEND_POWER(co[0], co[1], co[2], dx, dy);
                 if (power > 0) continue;
                 const REAL G = EXP(power);
                 const REAL alpha = FMIN((REAL)0.99, co[3] * G);
