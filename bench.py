@@ -144,7 +144,8 @@ def nerf_c1_cpu_baseline(size=64, threads=None):
     from nerficg_amd import nerf
     from tests import scenes
     before = torch.get_num_threads()
-    threads = threads or min(os.cpu_count() or 1, 32)   # torch's CPU GEMMs stop scaling (and regress) far below 256 threads
+    import oracle as _oracle
+    threads = threads or min(_oracle.usable_cpus(), 32)   # what the cgroup grants (16 on the pool's boxes); torch's CPU GEMMs stop scaling far below 256 threads anyway
     torch.set_num_threads(threads)
     try:
         torch.manual_seed(0)
@@ -300,23 +301,27 @@ def time_dominant_kernel(renderer, cam, pose_list, reps=2):
 
 # ------------------------------------------------------------------------------------------------ 3DGS leg (secondary metric)
 GS_W, GS_H = 1297, 840  # gs_garden.yaml: IMAGE_SCALE_FACTOR 0.25 of Mip-NeRF360 garden
+C3B_W, C3B_H = 1600, 1060  # the size BASELINE.json names for the garden frames (SURVEY 8d lists both)
+N_SIMDS = 256 * 4          # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+VALU_ISSUE_CYCLES_LO, VALU_ISSUE_CYCLES_HI = 2.8, 3.1   # measured cycles per dependent f32 VALU instruction and wave (tools/micro/pk_rate.hip)
 
 
-def build_gs_scene(device, n=1_000_000, seed=0):
+def build_gs_scene(device, n=1_000_000, seed=0, w=None, h=None):
     """1 M synthetic Gaussians (positions U([-1.5,1.5]^3) + ground-plane cluster, log-scales N(log 0.01, 0.5^2), unit
     quaternions, opacity logits N(0, 2^2), SH degree 3), 1297x840 camera, black background."""
     import torch
     from nerficg_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from tests import scenes
     sc = scenes.gs_random_scene(n, seed=seed)
-    cam = scenes.gs_camera(GS_W, GS_H, scenes.orbit_pose(0.8, 0.35, 4.5))
+    w, h = w or GS_W, h or GS_H
+    cam = scenes.gs_camera(w, h, scenes.orbit_pose(0.8, 0.35, 4.5))
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     settings = GaussianRasterizationSettings(
-        image_height=GS_H, image_width=GS_W, tanfovx=cam['tanfovx'], tanfovy=cam['tanfovy'], bg=torch.zeros(3, device=device), scale_modifier=1.0,
+        image_height=h, image_width=w, tanfovx=cam['tanfovx'], tanfovy=cam['tanfovy'], bg=torch.zeros(3, device=device), scale_modifier=1.0,
         viewmatrix=T(cam['viewmatrix']), projmatrix=T(cam['projmatrix']), sh_degree=3, campos=T(cam['campos']), prefiltered=False, debug=False)
     t = {k: T(v) for k, v in sc.items() if k != 'sh_degree'}
     t['opacities'] = t['opacities'][:, None].contiguous()
-    return dict(rast=GaussianRasterizer(settings), tensors=t, n=n, scene=sc, cam=cam)
+    return dict(rast=GaussianRasterizer(settings), tensors=t, n=n, scene=sc, cam=cam, w=w, h=h)
 
 
 def time_gs(gs, reps=5, barrier=None):
@@ -369,7 +374,7 @@ def time_gs(gs, reps=5, barrier=None):
     return {'stage_ms': stage_ms, 'stage_frames': reps, 'msplats_per_s_fwd': round(n / t_fwd / 1e6, 2), 'msplats_per_s_fwd_bwd': round(n / t_fb / 1e6, 2), 'ms_fwd': round(t_fwd * 1e3, 3),
             'ms_fwd_bwd': round(t_fb * 1e3, 3), 'trials_ms_fwd': [round(v * 1e3, 3) for v in fwd_trials],
             'trials_ms_fwd_bwd': [round(v * 1e3, 3) for v in fb_trials], 'gaussians': n, 'visible': int((radii > 0).sum().item()), 'instances': int(n_inst),
-            'image': f'{GS_W}x{GS_H}'}
+            'image': f"{gs.get('w', GS_W)}x{gs.get('h', GS_H)}", 'pixels': gs.get('w', GS_W) * gs.get('h', GS_H)}
 
 
 def csrc_digests():
@@ -401,7 +406,7 @@ def gs_kernel_rooflines(gs_res, pmc_all):
     stage = gs_res.get('stage_ms') or {}
     if not stage:
         return None
-    P, D, HW = gs_res['visible'], gs_res['instances'], GS_W * GS_H
+    P, D, HW = gs_res['visible'], gs_res['instances'], gs_res.get('pixels', GS_W * GS_H)
     model = {'k_render': 40 * D + 20 * HW, 'k_render_bw': 76 * D + 20 * HW, 'k_preprocess': 308 * P, 'k_preprocess_bw': 472 * P}
     out = {}
     for k, nbytes in model.items():
@@ -410,6 +415,19 @@ def gs_kernel_rooflines(gs_res, pmc_all):
             entry, src = pmc_entry(pmc_all, k, 'gs_raster.hip')
             out[k] = {'ms': round(ms, 4), 'algorithmic_bytes': nbytes, 'achieved': round(nbytes / ms / 1e6, 1),
                       'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), 'traffic': entry.get('hbm_bytes_per_launch'), 'traffic_source': src}
+            if k in ('k_render', 'k_render_bw'):
+                # The blend kernels are NOT byte-bound (counter traffic 0.4-0.6 x the byte model): the ruler that binds is VALU issue.  From the
+                # counter collection of the same source (sha-gated like `traffic`): wave-instructions issued per SIMD-cycle, times the cycles one
+                # dependent f32 instruction holds its wave's issue slot at this kernel's occupancy (tools/micro/valu_rate.hip / pk_rate.hip: 2.8-3.1).
+                insts, cycles = entry.get('SQ_INSTS_VALU'), entry.get('kernel_cycles')
+                if insts and cycles:
+                    per_simd_clk = insts / (cycles * N_SIMDS)
+                    out[k]['roofline_valu'] = {'bound': 'valu issue', 'valu_wave_instructions_per_launch': insts, 'gpu_cycles_per_launch': cycles, 'simds': N_SIMDS,
+                                               'wave_instructions_per_simd_cycle': round(per_simd_clk, 4), 'issue_cycles_per_instruction': [VALU_ISSUE_CYCLES_LO, VALU_ISSUE_CYCLES_HI],
+                                               'frac': [round(per_simd_clk * VALU_ISSUE_CYCLES_LO, 3), round(per_simd_clk * VALU_ISSUE_CYCLES_HI, 3)],
+                                               'source': src + '; issue cycles: tools/micro/pk_rate.hip (round 3)'}
+                else:
+                    out[k]['roofline_valu'] = {'bound': 'valu issue', 'frac': None, 'source': src}
     binning = [k for k in stage if k.startswith(('k_depth_keys', 'k_radix', 'k_span', 'k_item', 'k_scan_tiles'))]
     if binning:
         t = sum(stage[k][0] for k in binning)          # ms per frame, all launches of the kernel (4 per radix kernel)
@@ -429,7 +447,7 @@ def gs_cpu_baseline(n=1_000_000, w=GS_W, h=GS_H):
     from tests import scenes
     sc = scenes.gs_random_scene(n, seed=0)
     cam = scenes.gs_camera(w, h, scenes.orbit_pose(0.8, 0.35, 4.5))
-    cores = os.cpu_count() or 1
+    cores = oracle.usable_cpus()      # affinity capped by the cgroup quota (16 of the 256 logical CPUs on the pool's boxes)
     before = oracle.set_threads(0)
     try:
         t0 = time.perf_counter()
@@ -443,25 +461,28 @@ def gs_cpu_baseline(n=1_000_000, w=GS_W, h=GS_H):
     finally:
         oracle.set_threads(before)
     return {'value': round(n / t_f / 1e6, 5), 'value_fwd_bwd': round(n / (t_f + t_b) / 1e6, 5), 'unit': 'Msplats/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} Gaussians, {w}x{h} image, {st.num_rendered} instances, oracle/gs_oracle.c with OpenMP on {cores} threads, '
+            'sample': f'{n} Gaussians, {w}x{h} image, {st.num_rendered} instances, oracle/gs_oracle.c with OpenMP on {cores} threads (the CPUs the cgroup grants of {os.cpu_count()} logical), '
                       f'fwd {t_f:.2f} s + bwd {t_b:.2f} s'}
 
 
-def cpu_baseline(cam_full, pose, model_params, crop=200):
-    """The CPU oracle (kind "port": the reference has no CPU path for InstantNGP) on a bounded sample: a crop x crop central window of the same
-    camera / pose / scene on ALL host cores -- every stage is OpenMP-parallel over rays or samples (march, hash-grid encode, both MLPs,
-    compositing), fp16 roundings through F16C.  `scaling`: the encode + MLP leg (98 % of the work) on one thread (a 1/32 sub-sample) and on
-    all threads, so that the line says what the threads bought."""
+def cpu_baseline(cam_full, pose, model_params, stride=4):
+    """The CPU oracle (kind "port": the reference has no CPU path for InstantNGP) on a bounded sample of THE SAME FRAME: every stride-th pixel of every
+    stride-th row of the 800x800 image (40 000 rays spread over the whole picture, so samples per ray equal the frame's ~120 -- rounds 3-4 took a
+    central crop, whose rays all cross the object: 397 samples per ray, a Mrays/s figure 3.3 x off), same camera / pose / scene, on the CPUs the
+    process may use (oracle.usable_cpus(): affinity capped by the cgroup quota) -- every stage is OpenMP-parallel over rays or samples (march, hash-grid
+    encode, both MLPs, compositing), fp16 roundings through F16C.  `scaling`: the encode + MLP leg (98 % of the work) on one thread (a sub-sample) and
+    on all of them."""
     import oracle
     from tests import scenes
     pd, pc, bitfield = model_params
     fx, fy, cx, cy = scenes.lego_intrinsics(W, H)
-    cores = os.cpu_count() or 1
+    cores = oracle.usable_cpus()
     before = oracle.set_threads(0)
     grid_kw = dict(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=float(math.exp(math.log(2048 * 1.0 / 16) / 15)))
     try:
-        # central crop = same rays as the full image's centre window
-        o, _, d = scenes.numpy_rays(crop, crop, pose, fx, fy, cx - (W - crop) / 2, cy - (H - crop) / 2)
+        o_all, _, d_all = scenes.numpy_rays(W, H, pose, fx, fy, cx, cy)
+        pick = (np.arange(0, H, stride)[:, None] * W + np.arange(0, W, stride)[None, :]).reshape(-1)
+        o, d = np.ascontiguousarray(o_all[pick]), np.ascontiguousarray(d_all[pick])
         t0 = time.perf_counter()
         _, ht, _ = oracle.ray_aabb_intersect(o, d, np.zeros((1, 3), np.float32), np.full((1, 3), 0.5, np.float32), 1)
         hits = ht[:, 0].copy()
@@ -477,7 +498,7 @@ def cpu_baseline(cam_full, pose, model_params, crop=200):
         t_comp = time.perf_counter() - t2
         dt = time.perf_counter() - t0
         n_all = int(counter[0])
-        sub = slice(0, max(n_all // 32, 1))
+        sub = slice(0, max(n_all // 16, 1))
         oracle.set_threads(1)
         t3 = time.perf_counter()
         oracle.ngp_query(x01[sub], dirs[sub], pd[:3072], pc, pd[3072:].reshape(-1, 2), **grid_kw)
@@ -487,9 +508,10 @@ def cpu_baseline(cam_full, pose, model_params, crop=200):
     n_sub = len(x01[sub])
     one, allc = n_sub / t_one / 1e6, n_all / t_query / 1e6
     return {'value': round(len(o) / dt / 1e6, 6), 'unit': 'Mrays/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{crop}x{crop} central crop of one 800x800 pose ({len(o)} rays, {n_all} samples), oracle/*.c with OpenMP in every stage '
-                      f'(F16C conversions: {oracle.has_f16c()}), {dt:.2f} s = march {t_march:.2f} + encode/MLP {t_query:.2f} + composite {t_comp:.2f}',
-            'msamples_per_s': round(n_all / dt / 1e6, 4),
+            'sample': f'every {stride}th pixel of every {stride}th row of one 800x800 pose ({len(o)} rays, {n_all} samples = {n_all / len(o):.1f} per ray, the frame: ~120), '
+                      f'oracle/*.c with OpenMP in every stage on {cores} threads (what the cgroup grants of {os.cpu_count()} logical CPUs; F16C conversions: {oracle.has_f16c()}), '
+                      f'{dt:.2f} s = march {t_march:.2f} + encode/MLP {t_query:.2f} + composite {t_comp:.2f}',
+            'samples_per_ray': round(n_all / len(o), 1), 'msamples_per_s': round(n_all / dt / 1e6, 4),
             'scaling': {'leg': 'hash-grid encode + both MLPs (oracle.ngp_query)', 'msamples_per_s_1_thread': round(one, 4), 'msamples_per_s_all_threads': round(allc, 4),
                         'threads': cores, 'speedup': round(allc / one, 2), 'speedup_per_core': round(allc / one / cores, 3),
                         'one_thread_sample': f'{n_sub} samples, {t_one:.2f} s'}}
@@ -978,6 +1000,12 @@ def main():
             gs_res['large'] = time_gs(big, reps=8, barrier=barrier)
             del big
             torch.cuda.empty_cache()
+        # the same 1 M Gaussians at BASELINE's 1600x1060 (SURVEY 8d names both image sizes for C3 / C5)
+        if world == 1:
+            wide = build_gs_scene(device, args.gs_gaussians, w=C3B_W, h=C3B_H)
+            gs_res['c3_1600x1060'] = time_gs(wide, reps=8, barrier=barrier)
+            del wide
+            torch.cuda.empty_cache()
 
     # ---- data-parallel training legs: the collectives of SURVEY 8(e) inside a timed iteration (every rank takes part)
     dp = None
@@ -1068,6 +1096,18 @@ def main():
                     'instances': lg['instances'],
                     'frac_fwd': round(lb_fwd / (lg['ms_fwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     'frac_fwd_bwd': round((lb_fwd + lb_bwd) / (lg['ms_fwd_bwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if 'c3_1600x1060' in gs_res:
+                wd = gs_res['c3_1600x1060']
+                wb_fwd = 308 * wd['visible'] + 148 * wd['instances'] + 20 * wd['pixels']
+                wb_bwd = 76 * wd['instances'] + 472 * wd['visible'] + 20 * wd['pixels']
+                result['secondary']['c3_1600x1060'] = {
+                    'workload': f"{wd['gaussians']} Gaussians, {wd['image']} (the image size BASELINE.json names; the reference yaml's IMAGE_SCALE_FACTOR 0.25 gives 1297x840)",
+                    'value_fwd': wd['msplats_per_s_fwd'], 'value_fwd_bwd': wd['msplats_per_s_fwd_bwd'], 'unit': 'Msplats/s', 'ms_fwd': wd['ms_fwd'],
+                    'ms_fwd_bwd': wd['ms_fwd_bwd'], 'trials_ms_fwd': wd.get('trials_ms_fwd'), 'trials_ms_fwd_bwd': wd.get('trials_ms_fwd_bwd'),
+                    'visible': wd['visible'], 'instances': wd['instances'],
+                    'frac_fwd': round(wb_fwd / (wd['ms_fwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    'frac_fwd_bwd': round((wb_fwd + wb_bwd) / (wd['ms_fwd_bwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    'per_kernel_ms': {k: round(v[0], 4) for k, v in sorted((wd.get('stage_ms') or {}).items())}}
         if not args.no_train:
             try:
                 result['training'] = time_train(model, renderer, cam, poses)

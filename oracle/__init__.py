@@ -349,11 +349,33 @@ def gs_forward(means3D, opacities, viewmatrix, projmatrix, campos, tan_fovx, tan
     return color, st.radii.copy(), st
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota.  The GPU boxes of the pool show 256 logical CPUs and
+    grant 16 (cpu.max = 1600000 100000): 256 OpenMP threads on a 16-CPU quota are throttled and run SLOWER than 32 (measured round 5, oracle.mlp_fw:
+    1 / 8 / 32 / 64 / 128 / 256 threads = 1.7 / 13.0 / 41.9 / 22.7 / 10.3 / 3.7 Msamples/s) -- which is what rounds 3-4 reported as "8.5 x on 256 threads"."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]            # cgroup v2
+        if quota != 'max':
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())              # cgroup v1
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0:
+                n = min(n, max(1, math.ceil(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def set_threads(n: int) -> int:
-    """OpenMP threads of the oracle library (0 = all host cores); returns the previous setting."""
+    """OpenMP threads of the oracle library (0 = every CPU this process may use, usable_cpus()); returns the previous setting."""
     fn = lib().oracle_set_threads
     fn.restype = ctypes.c_int
-    return int(fn(ctypes.c_int(int(n))))
+    return int(fn(ctypes.c_int(int(n) if int(n) > 0 else usable_cpus())))
 
 
 def gs_backward(st, dL_dpix, threads: int = 1):

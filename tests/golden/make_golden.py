@@ -460,6 +460,83 @@ def make_gs_projection():
     print('gs_projection.npz:', (OUT / 'gs_projection.npz').stat().st_size, 'B')
 
 
+def run_ingp_orchestration():
+    """The reference's OWN InstantNGP host code -- InstantNGPRenderer.render_rays -> InstantNGPRayRenderingComponent.forward / render_rays_training /
+    render_rays_inference / query_model (src/Methods/InstantNGP/Renderer.py:30-180) through VolumeRenderingV2/custom_functions.py's autograd classes
+    -- executed in THIS container on CPU, with the native ops it calls (the twelve VolumeRenderingV2 functions, the two tinycudann networks) patched
+    to the CPU oracle behind their own signatures (tests/oracle_ops.py).  Returns the inputs, the outputs of a training batch and of the alive-ray
+    inference loop, and the sequence of native calls: what tests/golden/ingp_orchestration.npz holds and what the GPU mirror
+    (nerficg_amd/instant_ngp.py) is compared with on the same rays."""
+    import json
+    install_shims()
+    shims = str(Path(__file__).resolve().parents[2] / 'nerficg_amd' / 'shims')
+    root = str(Path(__file__).resolve().parents[2])
+    for q in (str(REF), root, shims):
+        if q not in sys.path:
+            sys.path.insert(0, q)
+    import Framework
+    Framework.config = Framework.ConfigWrapper.fromDict({
+        'GLOBAL': {'RANDOM_SEED': 1618033989, 'ANOMALY_DETECTION': False, 'GPU_INDICES': [], 'DEFAULT_DEVICE': torch.device('cpu'), 'METHOD_TYPE': 'InstantNGP'},
+        'TRAINING': {'WANDB': {'ACTIVATE': False}, 'MODEL_NAME': 'probe'}, 'MODEL': {}, 'RENDERER': {}})
+    import torchmetrics.functional.image as _tfi   # names of absent metric packages that the method packages import at module level
+    for _n in ('structural_similarity_index_measure', 'multiscale_structural_similarity_index_measure', 'learned_perceptual_image_patch_similarity'):
+        setattr(_tfi, _n, lambda *a, **k: None)
+    from Cameras.Perspective import PerspectiveCamera
+    from Cameras.utils import SharedCameraSettings
+    from Datasets.utils import View
+    from Methods.InstantNGP.Model import InstantNGPModel
+    from Methods.InstantNGP.Renderer import InstantNGPRenderer
+    import Methods.InstantNGP.VolumeRenderingV2 as package
+    import VolumeRenderingV2 as shim
+    import nerficg_amd.tinycudann as tcnn
+    from tests import oracle_ops, scenes
+    oracle_ops.install(shim, package, tcnn.NetworkWithInputEncoding)
+    w = h = 40
+    table_gain, radius = 2.0e4, 0.35
+    model = InstantNGPModel('probe').build()
+    with torch.no_grad():     # U(-1e-4, 1e-4) renders a constant: the table of the fixture is the seeded initialisation times a constant
+        model.encoding_xyz.params[model.n_params_encoding_mlp:] *= table_gain
+        model.occupancy_bitfield.copy_(torch.from_numpy(scenes.sphere_bitfield(model.RESOLUTION, model.SCALE, radius, model.cascades)))
+    renderer = InstantNGPRenderer(model)
+    fx, fy, cx, cy = scenes.lego_intrinsics(w, h)
+    settings = SharedCameraSettings(background_color=torch.tensor([1.0, 1.0, 1.0]), near_plane=0.2, far_plane=1000.0)
+    cam = PerspectiveCamera(shared_settings=settings, width=w, height=h, focal_x=fx, focal_y=fy, center_x=cx, center_y=cy)
+    c2w = scenes.orbit_pose(0.5, 0.3, scenes.LEGO_RADIUS)
+    rays = View(camera=cam, camera_index=0, frame_idx=0, global_frame_idx=0, c2w=c2w).get_rays()
+    bg = torch.tensor([0.2, 0.7, 0.4])
+    blob = dict(size=np.array([w, h]), intr=np.array([fx, fy, cx, cy], dtype=np.float64), c2w=c2w, table_gain=np.float64(table_gain), radius=np.float64(radius),
+                seed=np.int64(1618033989), origin=rays.origin.numpy(), view_direction=rays.view_direction.numpy(), bg=bg.numpy())
+    # ---- a training batch (the march jitter is the reference's own torch.rand_like draw: recorded from the patched op's argument)
+    oracle_ops.TRACE.clear()
+    noise_seen = []
+    inner = shim.raymarching_train
+    def spy(*args):
+        noise_seen.append(args[7].clone())
+        return inner(*args)
+    shim.raymarching_train = spy
+    torch.manual_seed(7)
+    out = renderer.render_rays(rays, cam, train_mode=True, custom_bg_color=bg)
+    shim.raymarching_train = inner
+    trace_train = list(oracle_ops.TRACE)
+    blob.update(noise=noise_seen[0].numpy(), train_rgb=out['rgb'].detach().float().numpy(), train_alpha=out['alpha'].detach().float().numpy(),
+                train_depth=out['depth'].detach().float().numpy(), train_rm_samples=np.int64(int(out['rm_samples'])))
+    # ---- the same rays through the alive-ray inference loop
+    oracle_ops.TRACE.clear()
+    with torch.no_grad():
+        out = renderer.render_rays(rays, cam, train_mode=False)
+    trace_eval = list(oracle_ops.TRACE)
+    blob.update(eval_rgb=out['rgb'].float().numpy(), eval_alpha=out['alpha'].float().numpy(), eval_depth=out['depth'].float().numpy())
+    blob['trace_train'] = np.array(json.dumps(trace_train))
+    blob['trace_eval'] = np.array(json.dumps(trace_eval))
+    return blob
+
+
+def make_ingp_orchestration():
+    blob = run_ingp_orchestration()
+    np.savez_compressed(OUT / 'ingp_orchestration.npz', **blob)
+    print('ingp_orchestration.npz:', (OUT / 'ingp_orchestration.npz').stat().st_size, 'B;', int(blob['train_rm_samples']), 'training samples')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'gs_densify':
         make_gs_densify()   # only this fixture (the others keep their RNG streams)
@@ -467,6 +544,8 @@ if __name__ == '__main__':
         make_composite_bw()
     elif len(sys.argv) > 1 and sys.argv[1] == 'gs_projection':
         make_gs_projection()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'ingp_orchestration':
+        make_ingp_orchestration()
     else:
         main()
         make_gs_densify()

@@ -483,3 +483,39 @@ def test_fixed_row_capacity_frame_needs_no_host_read_and_can_be_recorded():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out['rgb'], refs[1][0]['rgb']) and out['counter'].tolist() == [refs[1][1], refs[1][2]]
+
+
+def test_mirror_follows_the_reference_orchestration_fixture(golden_dir):
+    """tests/golden/ingp_orchestration.npz = the reference's OWN host code (InstantNGPRenderer.render_rays -> InstantNGPRayRenderingComponent, Renderer.py:30-180,
+    through custom_functions.py) run in the build container on the oracle's ops (tests/test_shims.py reproduces it from the reference there).  The GPU
+    mirror -- nerficg_amd.instant_ngp.InstantNGPRenderer on the HIP ops, own structure -- must paint the same training batch (same jitter, custom
+    background, training depth) and the same inference picture (camera background, the alive-ray loop's early-out, inference depth) on those rays:
+    the reference's orchestration is pinned by execution.  Tolerances: the fp16 network outputs differ from the oracle's by an fp16 ulp at most."""
+    from nerficg_amd.instant_ngp import Camera, InstantNGPModel, InstantNGPRenderer
+    fx = np.load(golden_dir / 'ingp_orchestration.npz')
+    w, h = (int(v) for v in fx['size'])
+    model = InstantNGPModel(RANDOM_SEED=int(fx['seed']), device=DEV)
+    with torch.no_grad():
+        model.encoding_xyz.params[model.n_params_encoding_mlp:] *= float(fx['table_gain'])
+        model.occupancy_bitfield.copy_(torch.from_numpy(scenes.sphere_bitfield(model.RESOLUTION, model.SCALE, float(fx['radius']), model.cascades)).to(DEV))
+    renderer = InstantNGPRenderer(model)
+    f = fx['intr']
+    cam = Camera(width=w, height=h, focal_x=float(f[0]), focal_y=float(f[1]), center_x=float(f[2]), center_y=float(f[3]), near_plane=0.2, far_plane=1000.0,
+                 background_color=torch.tensor([1.0, 1.0, 1.0]))
+    # the rays themselves: the reference's View.get_rays against nrc_generate_rays
+    from nerficg_amd.raygen import generate_rays
+    rays = generate_rays(w, h, cam.focal_x, cam.focal_y, cam.center_x, cam.center_y, fx['c2w'], device=DEV, want_direction=False)
+    np.testing.assert_allclose(rays['origin'].cpu().numpy(), fx['origin'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rays['view_direction'].cpu().numpy(), fx['view_direction'], rtol=0, atol=2e-6)
+    o, d = torch.from_numpy(fx['origin']).to(DEV), torch.from_numpy(fx['view_direction']).to(DEV)
+    out = renderer.render_rays(o, d, cam, train_mode=True, custom_bg_color=torch.from_numpy(fx['bg']).to(DEV), noise=torch.from_numpy(fx['noise']).to(DEV))
+    assert int(out['rm_samples']) == int(fx['train_rm_samples'])                      # the march is integer-exact
+    for key, tol in (('rgb', 4e-3), ('alpha', 4e-3), ('depth', 2e-2)):
+        got, want = out[key].detach().float().cpu().numpy(), fx['train_' + key]
+        assert np.abs(got - want).max() <= tol and np.abs(got - want).mean() <= tol / 20, (key, np.abs(got - want).max(), np.abs(got - want).mean())
+    with torch.no_grad():
+        ev = renderer.render_rays(o, d, cam, train_mode=False)
+    for key, tol in (('rgb', 4e-3), ('alpha', 4e-3), ('depth', 2e-2)):
+        got, want = ev[key].float().cpu().numpy(), fx['eval_' + key]
+        assert np.abs(got - want).max() <= tol and np.abs(got - want).mean() <= tol / 20, (key, np.abs(got - want).max(), np.abs(got - want).mean())
+    assert float(fx['train_alpha'].max()) > 0.3 and float((fx['eval_alpha'] > 0).mean()) > 0.3    # the fixture is not an empty picture

@@ -208,3 +208,44 @@ try:
 except RuntimeError as e:
     assert 'must be a CUDA tensor' in str(e)
 ''')
+
+
+@pytest.mark.skipif(not REF.exists(), reason='reference tree only exists in the build container')
+def test_reference_host_code_runs_over_the_shims_and_reproduces_the_orchestration_fixture():
+    """The reference's OWN InstantNGPRenderer / InstantNGPRayRenderingComponent / custom_functions.py (src/Methods/InstantNGP/Renderer.py:30-180) executed
+    on CPU with the native ops patched to the oracle behind their own signatures (tests/oracle_ops.py): (1) the committed fixture
+    tests/golden/ingp_orchestration.npz is what this run produces, bit for bit -- the fixture IS the reference's orchestration, not a restatement;
+    (2) the native calls it makes are the ones the GPU mirror (nerficg_amd/instant_ngp.py, compared with the fixture in tests/test_gpu_render_parity.py)
+    has to account for: one box test, then march -> grid network -> SH network -> compositing for a training batch, and the same four per round of the
+    alive-ray loop, with the argument shapes / dtypes / scalars of binding.cpp:234-250."""
+    code = r'''
+import sys, json
+import numpy as np
+sys.path[:0] = [%r, %r]
+import make_golden
+blob = make_golden.run_ingp_orchestration()
+ref = np.load(%r)
+for k in ref.files:
+    a, b = ref[k], blob[k]
+    if k.startswith('trace_'):
+        assert str(a) == str(b), k
+    else:
+        assert np.array_equal(np.asarray(a), np.asarray(b)), (k, np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+tt = json.loads(str(blob['trace_train'])); te = json.loads(str(blob['trace_eval']))
+n = int(blob['origin'].shape[0]); m = int(blob['train_rm_samples'])
+assert [t[0] for t in tt] == ['ray_aabb_intersect', 'raymarching_train', 'network_forward:grid', 'network_forward:sh_identity', 'composite_train_fw']
+assert tt[0][1] == [[[n, 3], 'float32'], [[n, 3], 'float32'], [[1, 3], 'float32'], [[1, 3], 'float32'], 1]
+assert tt[1][1][2] == [[n, 2], 'float32'] and tt[1][1][4:7] == [1, 0.5, 0.0] and tt[1][1][7] == [[n], 'float32'] and tt[1][1][8:] == [128, 1024]
+assert tt[2][1] == [[[m, 3], 'float32']] and tt[3][1][0][0] == [m, 19] and tt[4][1][:2] == [[[m], 'float32'], [[m, 3], 'float32']] and tt[4][1][5] == 1e-4
+assert te[0][0] == 'ray_aabb_intersect' and (len(te) - 1) %% 4 in (0, 1)     # a last march that finds no sample ends the loop (Renderer.py:118-120)
+if (len(te) - 1) %% 4 == 1:
+    assert te[-1][0] == 'raymarching_test'
+rounds = [te[1 + 4 * r: 5 + 4 * r] for r in range((len(te) - 1) // 4)]
+assert all([c[0] for c in r] == ['raymarching_test', 'network_forward:grid', 'network_forward:sh_identity', 'composite_test_fw'] for r in rounds)
+samples = [r[0][1][-1] for r in rounds]            # N_samples per round: max(min(n_rays // n_alive, 64), 1) -- grows as rays finish (Renderer.py:108)
+assert samples[0] == 1 and samples == sorted(samples) and max(samples) <= 64 and sum(samples) <= 1024 + 64
+alive = [r[0][1][3][0][0] for r in rounds]           # alive rays per round shrink
+assert alive[0] == n and alive == sorted(alive, reverse=True)
+''' % (str(ROOT / 'tests' / 'golden'), str(ROOT), str(ROOT / 'tests' / 'golden' / 'ingp_orchestration.npz'))
+    r = subprocess.run([sys.executable, '-c', code + "\nprint('ok')\n"], capture_output=True, text=True, env={**os.environ, 'PYTHONPATH': ''})
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (r.stdout[-1500:], r.stderr[-3000:])
