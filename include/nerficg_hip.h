@@ -442,6 +442,11 @@ int nrc_ngp_render_layers(const float* ts, int32_t* row_tile, const float* ray_o
  * first_row .. first_row + n_rows - 1 of the frame -- ts / row_tile are the FRAME's arrays, not offset ones (ABI 4) --, fragment-major: the 16-byte
  * vector [((j>>5)*4 + ((g + (j>>5))&3))*32 + (j&31)] = levels 4g..4g+3 (fp16x2) of slot j of the chunk.  arena_tile_off / arena_rows: as for
  * nrc_ngp_query_samples (NULL / 0: compact rows), so that the kernel is timed in the form the frame runs it */
+/* The brick of the tiled layout that ONE WAVE of the encoder gathers for: 2^log2_x x 2^log2_y pixels of a ray tile x 2^(6 - log2_x - log2_y) consecutive
+ * steps (default 8 x 2 x 4).  Hash-table entries are contiguous along world x only, so which brick shares the most cache lines depends on how the
+ * image axes and the viewing direction lie to that axis: the host may pick a shape per pose (InstantNGPRenderer does, from the camera's axes).
+ * Both < 0: back to the default.  Process-wide setting, read at launch; the features are identical for every shape. */
+int nrc_ngp_set_encoder_shape(int32_t log2_x, int32_t log2_y);
 int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t first_row, int64_t n_rows, const float* xyz_min3,
                            const float* xyz_size3, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
                            int32_t base_resolution, float per_level_scale, void* features_f16, const int32_t* arena_tile_off,

@@ -1027,6 +1027,7 @@ static int64_t query_feat_bytes(int64_t M) {
     return ((c > 0 ? c : 1) + 31) / 32 * 32 * 64 + 256;
 }
 
+static int g_enc_shape_override = 0;   // nrc_ngp_set_encoder_shape: (log2 pixels along x) << 4 | (log2 pixels along y) of a wave's brick, 0 = the default
 template <int SRC>
 static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void* table, const GridCfg& g, uint4* feat, hipStream_t s) {
     // levels whose cells are larger than a wave's footprint: narrow gathers (see grid_level_features_narrow)
@@ -1065,7 +1066,7 @@ static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void
         const int v = e ? atoi(e) : 31, lu = v / 10, lv = v % 10;
         return (lu < 0 || lu > NRC_TILE_W_LOG2 || lv < 0 || lv > 6 - NRC_TILE_W_LOG2 || lu + lv < 2 || lu + lv == 6) ? 0 : (lu << 4) | lv;   // 2 <= u + v: at most 16 steps
     }();
-    const int lanes = (SRC == SRC_TILED && (base & 1023) == 0) ? lane_shape : 0;
+    const int lanes = (SRC == SRC_TILED && (base & 1023) == 0) ? (g_enc_shape_override ? g_enc_shape_override : lane_shape) : 0;
     static const int xcd_ranges = [] { const char* e = getenv("NRC_ENC_XCD"); return e ? (atoi(e) != 0) : 1; }();   // measured: 612 -> 591 us per launch (mean of 24 poses)
     // (the remapping permutes whole blocks of 1024 slots: the launch covers whole blocks)
     // NRC_ENC_FINE_SPLIT=1 (experiment, see k_grid_encode_fine): levels 12-15 in a second launch, one level per XCD
@@ -1236,6 +1237,12 @@ int nrc_ngp_query_fused(const float* xyz01, const float* dirs, int64_t M, const 
     return NRC_OK;
 }
 
+int nrc_ngp_set_encoder_shape(int32_t log2_x, int32_t log2_y) {
+    if (log2_x < 0 && log2_y < 0) { g_enc_shape_override = 0; return NRC_OK; }
+    if (log2_x < 0 || log2_x > NRC_TILE_W_LOG2 || log2_y < 0 || log2_y > 6 - NRC_TILE_W_LOG2 || log2_x + log2_y < 2 || log2_x + log2_y == 6) return NRC_ERR_INVALID;
+    g_enc_shape_override = (log2_x << 4) | log2_y;
+    return NRC_OK;
+}
 int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t first_row, int64_t n_rows, const float* xyz_min3,
                            const float* xyz_size3, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,
                            int32_t base_resolution, float per_level_scale, void* features_f16, const int32_t* arena_tile_off, int32_t arena_rows,
