@@ -1297,12 +1297,7 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
         int n_wave;
         const int n_mine = block_lists(st, flags, &n_wave);
         const uint32_t pos0 = base - r0 + 1u;  // contributor number of batch entry 0 = its position in the tile list + 1
-#if defined(NRC_FW_ABL_NOBLEND)   // ablation hook: staging and list building only
-        if (n_mine == 12345) C0 += 1.f;
-        for (int jj = 0; jj < 0; jj += 4) {
-#else
         for (int jj = 0; jj < n_wave; jj += 4) {
-#endif
             if (__ballot(!done) == 0ull) break;  // wave-uniform: every pixel of the quadrant is saturated
             const uint32_t pack = list4[jj >> 2];   // four entries of this row's list per LDS read
             // A dependent chain of VALU instructions issues one instruction per ~8 cycles on this chip, and more resident waves do not fill the
@@ -1546,9 +1541,6 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             // partner held of that half, so the nine sums end in nine different lanes (21 instructions; nine separate row sums took 36).
             // Steps 1 and 2: the lanes that keep the other half sit in whole DPP banks (lanes 8-15: banks 2, 3; lanes 4-7, 12-15: banks 1, 3),
             // so "pair sum of A, but pair sum of B in those lanes" is one unmasked and one bank-masked v_add_f32_dpp (two selects less per pair).
-#if defined(NRC_BW_ABL_NOREDUCE)
-            return d_c0 + d_c1 + d_c2 + d_op + d_mx + d_my + d_cx + d_cy + d_cw;
-#endif
             const float r0 = dpp_add2<0x140, 0xc>(d_c0, d_my), r1 = dpp_add2<0x140, 0xc>(d_c1, d_cx);
             const float r2 = dpp_add2<0x140, 0xc>(d_c2, d_cy), r3 = dpp_add2<0x140, 0xc>(d_op, d_cw);
             const float r4 = dpp_add<0x140>(d_mx, d_mx);
@@ -1560,14 +1552,10 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
         };
         // the nine sums of the row leave with ONE 64-bit integer LDS atomic
         auto deposit = [&](int jj, int j, float mine) {
-#if !defined(NRC_BW_ABL_NODEPOSIT)   // ablation hooks (tools/build_variant.sh NAME gs_raster.hip -DNRC_BW_ABL_...): never defined in the product build
             if (q_has && jj < n_mine) {
                 const float y = fminf(fmaxf(mine * q_scale, -0x1p61f), 0x1p61f);
                 atomicAdd(&s_acc[j][q_col], (unsigned long long)(long long)y);  // truncation: a bias of half a step of 2^-25 ... 2^-51
             }
-#else
-            if (mine == 123.456f) s_acc[j][q_col] = 1ull;
-#endif
         };
         // BW_PAIR entries per trip: their record reads, exponentials and reductions are independent instruction streams (only T and the
         // running colour pass from one to the next), which is what this latency-bound loop lacks

@@ -281,12 +281,7 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
         // every eighth workgroup, so that neighbouring bricks (which share table lines) meet in the same L2
         if (hashed_mode & (1 << 28)) {
             const int64_t g8 = (int64_t)gridDim.x >> 3;
-#if defined(NRC_ENC_XCD_RUN)   // experiment build: XCD x takes RUNS of NRC_ENC_XCD_RUN workgroups dealt round-robin over the XCDs instead of one contiguous eighth
-            const int64_t R = NRC_ENC_XCD_RUN, jx = bid >> 3, full = (g8 / R) * R;
-            if (bid < 8 * full) bid = ((jx / R) * 8 + (bid & 7)) * R + jx % R;
-#else
             if (bid < 8 * g8) bid = (bid & 7) * g8 + (bid >> 3);
-#endif
         }
     }
     int64_t j = bid * 256 + threadIdx.x;
@@ -354,10 +349,6 @@ __global__ void __launch_bounds__(256) k_grid_encode(QueryIn in, int64_t base, i
                     if (g.hashed[level]) grid_corners_u<true>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
                     else grid_corners_u<false>(px, py, pz, g.scale[level], g.res[level], g.size[level], g.offset[level], c);
                     if (level < narrow_levels) grid_level_features_narrow(trs, c, f0, f1);
-#if defined(NRC_ENC_FINE_AUX)   // experiment build (tools/build_variant.sh ... -DNRC_ENC_FINE_AUX=n -DNRC_ENC_FINE_FROM=l): cache policy of the finest levels' gathers.
-                    // Measured with levels >= 12: sc0 0.644 ms, sc1 or sc0 sc1 (bypass L1) 0.816, nt 1.54 against 0.642 default -- the L1 does serve these levels
-                    else if (g.hashed[level] && hashed_mode == 1 && level >= NRC_ENC_FINE_FROM) grid_level_features_hashed<NRC_ENC_FINE_AUX>(trs, c, f0, f1);
-#endif
                     else if (g.hashed[level] && hashed_mode == 1) grid_level_features_hashed(trs, c, f0, f1);
                     else if (g.hashed[level] && hashed_mode == 2) grid_level_features_pair(trs, c, f0, f1);
                     else grid_level_features(trs, c, f0, f1);
@@ -489,19 +480,10 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn
 
 // NT = sample tiles (32 samples each) per wave iteration.  With NT = 2 every weight fragment read from LDS feeds two MFMAs and the
 // two chains interleave (the chain of one tile is serial: MFMA -> convert -> MFMA ...).
-// ---- ablation hooks of k_ngp_mlp (tools/build_variant.sh NAME ngp_net.hip -DNRC_MLP_ABL_...): where do its cycles go?  Never defined in the product build.
-#if defined(NRC_MLP_ABL_NOCVT)   // no f32 -> f16 conversion / ReLU: the next layer's B fragment is a reinterpretation of accumulator registers
-__device__ __forceinline__ h8 mlp_frag_relu(const f16v& acc, int g) { typedef float f4 __attribute__((ext_vector_type(4))); const f4 q = {acc[8 * g], acc[8 * g + 1], acc[8 * g + 2], acc[8 * g + 3]}; return __builtin_bit_cast(h8, q); }
-__device__ __forceinline__ h8 mlp_frag(const f16v& acc, int g) { return mlp_frag_relu(acc, g); }
-#else
+// (the three wrappers below were the seams of the round-2/3 ablation builds -- no conversion, no MFMA, synthetic inputs; numbers in LABBOOK.md)
 __device__ __forceinline__ h8 mlp_frag_relu(const f16v& acc, int g) { return acc_to_frag_relu(acc, g); }
 __device__ __forceinline__ h8 mlp_frag(const f16v& acc, int g) { return acc_to_frag(acc, g); }
-#endif
-#if defined(NRC_MLP_ABL_NOMFMA)  // no matrix instruction: operands and accumulator stay live, nothing is issued
-__device__ __forceinline__ f16v mlp_mfma(const h8& a, const h8& b, f16v c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
-#else
 __device__ __forceinline__ f16v mlp_mfma(const h8& a, const h8& b, const f16v& c) { return NRC_MFMA(a, b, c); }
-#endif
 #ifndef NRC_MLP_WAVES
 #define NRC_MLP_WAVES 2   // workgroups per CU the register budget is set for (= waves per SIMD); A/B builds: -DNRC_MLP_WAVES=3
 #endif
@@ -519,13 +501,6 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
         }
     }
     __shared__ h8 wlds[N_FRAG][64];
-#if defined(NRC_MLP_GLDS)
-    // Experiment build (round 4, tools/build_variant.sh ... -DNRC_MLP_GLDS): the three 16-byte input fragments of a tile (two feature vectors, the
-    // per-ray SH fragment) travel by LDS-DMA (global_load_lds_dwordx4: no VGPR destination) into a wave-private double-buffered slot and are read
-    // back with ds_read_b128 when the tile is computed, instead of sitting in 12 VGPRs per tile for a whole iteration.  Numbers: DESIGN.md 6.
-    __shared__ __attribute__((aligned(16))) uint4 glds_stage[4][2][NT][3][64];
-    int glds_slot = 0;
-#endif
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int64_t n_tiles = (n + 31) / 32;
     const int64_t n_groups = (n_tiles + NT - 1) / NT;
@@ -564,34 +539,12 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
             return 0;
         }
     };
-#if defined(NRC_MLP_GLDS)
-    int glds_fill = 0, glds_u = 0;   // slot and tile of the group being requested (set by the callers of fetch)
-#endif
     auto fetch = [&](int64_t tile, int32_t rt, TileIn& ti, const TileIn* same_ray_tile = nullptr) {
-#if defined(NRC_MLP_ABL_NOLOAD)   // synthetic inputs: no global load in the loop
-        ti.b0 = make_uint4(0x3c003c00u + (uint32_t)lane, 0x38003800u, 0x34003400u, 0x30003000u + (uint32_t)tile); ti.b1 = ti.b0;
-        ti.t = 1.f; ti.dx = 0.f; ti.dy = 0.f; ti.dz = 1.f; ti.alive = 1u;
-        { h8 z; for (int q = 0; q < 8; q++) z[q] = (_Float16)(0.1f * q); ti.sh = z; }
-        return;
-#endif
         const int64_t tc = tile < n_tiles ? tile : n_tiles - 1;
         const int64_t j = tc * 32 + r;
         const int64_t i = base + (j < n ? j : n - 1);
         const uint4* fp = feat + tc * 128 + r;
         const int rot = (int)(tc & 3);
-#if defined(NRC_MLP_GLDS)
-        if constexpr (SRC == SRC_TILED) {
-            typedef __attribute__((address_space(1))) const void* gptr_t;
-            typedef __attribute__((address_space(3))) void* lptr_t;
-            uint4 (*slot)[64] = glds_stage[threadIdx.x >> 6][glds_fill][glds_u];
-            __builtin_amdgcn_global_load_lds((gptr_t)(fp + ((hh + rot) & 3) * 32), (lptr_t)&slot[0][0], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(fp + ((2 + hh + rot) & 3) * 32), (lptr_t)&slot[1][0], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(ray_sh + ((int64_t)rt * 2 + hh) * 64 + (i & 63)), (lptr_t)&slot[2][0], 16, 0, 0);
-            ti.alive = 1u;
-            ti.t = 0.f;
-            return;
-        }
-#endif
         if constexpr (SRC == SRC_TILED) {
             if (rt < 0) {   // (wave-uniform) a row of a finished tile: no load, no arithmetic, no store
                 ti.b0 = make_uint4(0u, 0u, 0u, 0u); ti.b1 = ti.b0; ti.t = 0.f; ti.alive = 0u;
@@ -642,9 +595,6 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
         if (g0 < g_stop) {
 #pragma unroll
             for (int u = 0; u < NT; u++) {
-#if defined(NRC_MLP_GLDS)
-                glds_fill = 0; glds_u = u;
-#endif
                 rt_have[p][u] = tile_rt(g0 * NT + u);
                 fetch(g0 * NT + u, rt_have[p][u], ring[p][u]);
             }
@@ -684,25 +634,9 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
         TileIn cur[NT];
 #pragma unroll
         for (int u = 0; u < NT; u++) cur[u] = ring[p][u];
-#if defined(NRC_MLP_GLDS)
-        if constexpr (SRC == SRC_TILED) {   // the current group's fragments have landed (vmcnt(0)); read them out of this wave's slot before the refill
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int u = 0; u < NT; u++) {
-                const uint4 (*slot)[64] = glds_stage[threadIdx.x >> 6][glds_slot][u];
-                cur[u].b0 = slot[0][lane]; cur[u].b1 = slot[1][lane];
-                const uint4 q = slot[2][lane];
-                cur[u].sh = __builtin_bit_cast(h8, q);
-            }
-            glds_fill = glds_slot ^ 1;
-        }
-#endif
         if (grp + PF * g_step < g_stop) {
 #pragma unroll
             for (int u = 0; u < NT; u++) {
-#if defined(NRC_MLP_GLDS)
-                glds_u = u;
-#endif
                 // (scalar) the next row of this wave is a row of the same ray tile -- AND slot u keeps its tile parity from group to group (NT even): with one
                 // tile per group, consecutive groups are the two halves of a row and read different lanes of the ray's SH fragment (advisor finding, round 4)
                 const bool same = CONTIG && (NT % 2 == 0) && rt_ring[p][u] == rt_have[p][u];
@@ -710,9 +644,6 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
                 rt_have[p][u] = rt_ring[p][u];
             }
         }
-#if defined(NRC_MLP_GLDS)
-        glds_slot ^= 1;
-#endif
 #pragma unroll
         for (int u = 0; u < NT; u++) rt_ring[p][u] = tile_rt((grp + 2 * PF * g_step) * NT + u);
         flush_pending();   // the previous group's outputs: issued behind this group's prefetch, complete long before the next wait
@@ -1560,9 +1491,7 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
         const int64_t i = tile * 32 + r;
         const bool valid = i < M;
         const TileState cur = nxt;
-#if !defined(NRC_BWD_ABL_NOLOAD)   // ablation builds (tools/build_variant.sh): -DNRC_BWD_ABL_{NOLOAD,NODW,NOFLUSH}
         if (tile + n_waves < n_tiles) fetch(tile + n_waves, nxt);
-#endif
         NRC_PROBE(pb + 0);
         const h8 (&X)[2] = cur.X;
         const h8 (&H0)[4] = cur.H0;
@@ -1582,7 +1511,6 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
         }
         NRC_PROBE(pb + 1);
         // ---- dWout += dZo^T . HL   (k = samples, through the transposed LDS images)
-#if !defined(NRC_BWD_ABL_NODW)
         stage_frag_T<false>(T_dz, dZo, 0, r, hh);
 #pragma unroll
         for (int s = 0; s < 4; s++) stage_frag_T<true>(T_act, HL[s], s, r, hh);
@@ -1595,7 +1523,6 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
             for (int nt = 0; nt < 2; nt++) gWo[nt] = NRC_MFMA(a, read_T_frag(T_act, nt, s, lane), gWo[nt]);
         }
         wave_lds_sync();
-#endif
         NRC_PROBE(pb + 2);
         // ---- dHL^T = Wout^T . dZo^T ; dZL = relu'(HL) * dHL
         f16v acc[2] = {zero16(), zero16()};
@@ -1609,7 +1536,6 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
         NRC_PROBE(pb + 3);
         if constexpr (N_HIDDEN > 1) {
             // ---- dW1 += dZ1^T . H0
-#if !defined(NRC_BWD_ABL_NODW)
 #pragma unroll
             for (int s = 0; s < 4; s++) { stage_frag_T<true>(T_dz, dZ[s], s, r, hh); stage_frag_T<true>(T_act, H0[s], s, r, hh); }
             wave_lds_sync();
@@ -1624,7 +1550,6 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
                 }
             }
             wave_lds_sync();
-#endif
             NRC_PROBE(pb + 4);
             // ---- dH0^T = W1^T . dZ1^T ; dZ0 = relu'(H0) * dH0
             acc[0] = zero16(); acc[1] = zero16();
@@ -1639,7 +1564,6 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
         }
         NRC_PROBE(pb + 5);
         // ---- dW0 += dZ0^T . X
-#if !defined(NRC_BWD_ABL_NODW)
 #pragma unroll
         for (int s = 0; s < 4; s++) stage_frag_T<true>(T_dz, dZ[s], s, r, hh);
         stage_frag_T<false>(T_act, X[0], 0, r, hh);
@@ -1652,7 +1576,6 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
             for (int mt = 0; mt < 2; mt++) gW0[mt] = NRC_MFMA(read_T_frag(T_dz, mt, s, lane), b, gW0[mt]);
         }
         wave_lds_sync();
-#endif
         NRC_PROBE(pb + 6);
         // ---- d_in^T = W0^T . dZ0^T  (32 input features x 32 samples), unscaled f32
         f16v din = zero16();
@@ -1706,11 +1629,7 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) slot[(wv * 16 + reg) * 64 + lane] = acc[reg];
         __syncthreads();
-#if defined(NRC_BWD_ABL_NOFLUSH)
-        if (wv == (tile_no & 3) && acc[0] == 1.2345e-30f) {
-#else
         if (wv == (tile_no & 3)) {
-#endif
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 float v = 0.f;
@@ -1771,11 +1690,7 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, i
     uint32_t differ = 0u;
 #pragma unroll
     for (int k = 0; k < 8; k++) differ |= __shfl_up(c.e[k], 1, 64) ^ c.e[k];
-#if defined(NRC_GBW_NOAGG)
-    const bool same = false;
-#else
     const bool same = lane > 0 && live && prev_live != 0 && differ == 0u;
-#endif
     const bool head = !same;
     const int next_head = __shfl_down((int)head, 1, 64);
     const bool tail = lane == 63 || next_head != 0;
@@ -1800,13 +1715,6 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, i
         }
     }
     const bool flush = live && tail;
-#if defined(NRC_GBW_DIRECT_FLUSH)
-    if (flush) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) { atomicAdd(grad_table + 2 * (size_t)c.e[k], v[2 * k]); atomicAdd(grad_table + 2 * (size_t)c.e[k] + 1, v[2 * k + 1]); }
-    }
-    return;
-#endif
     const uint64_t tails = __ballot(flush);
     const int n_tails = __popcll(tails);
     if (flush) {
@@ -1828,11 +1736,7 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, i
     for (int s0 = 0; s0 < n_tails; s0 += NRC_GBW_TAILS_PER_INSTR) {
         const int sl = s0 + (lane >> 4);
         if ((lane >> 4) < NRC_GBW_TAILS_PER_INSTR && sl < n_tails) {
-#if defined(NRC_GBW_ABL_NOATOMIC)  // ablation build (tools/build_variant.sh): everything but the atomics
-            if (s_val[wv][sl][q] == 1.2345e-30f) grad_table[2 * (size_t)s_key[wv][sl][q >> 1] + (q & 1)] = 1.f;
-#else
             atomicAdd(grad_table + 2 * (size_t)s_key[wv][sl][q >> 1] + (q & 1), s_val[wv][sl][q]);
-#endif
         }
     }
 }
@@ -2181,10 +2085,6 @@ __global__ void __launch_bounds__(GBA_THREADS) k_gb_accumulate(GridCfg g, Bucket
     auto add_record = [&](const uint4& rr) {
         const uint32_t e0 = rr.x & 0xffffu, e1 = rr.x >> 16;
         const float a = __uint_as_float(rr.y), b = __uint_as_float(rr.z), wx1 = __uint_as_float(rr.w), wx0 = 1.f - wx1;
-#if defined(NRC_GBA_ABL_NOATOMIC)   // ablation builds (tools/build_variant.sh)
-        if (a == 1.2345e-30f) fix_acc[2 * e0] = (long long)(wx0 * b * scale) + e1;
-        return;
-#endif
         // power-of-two scale: the product is exact, the only rounding is to the fixed-point grid
         atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e0]), to_fixed(wx0 * a * scale));
         atomicAdd(reinterpret_cast<unsigned long long*>(&fix_acc[2 * e0 + 1]), to_fixed(wx0 * b * scale));
@@ -2198,11 +2098,7 @@ __global__ void __launch_bounds__(GBA_THREADS) k_gb_accumulate(GridCfg g, Bucket
         uint32_t base = B.start[0], first = 0u;
 #pragma unroll
         for (int t = 1; t < UNR; t++) { base = u == (uint32_t)t ? B.start[t] : base; first = u == (uint32_t)t ? B.pre[t] : first; }
-#if defined(NRC_GBA_ABL_NOLOAD)
-        return make_uint4((pp * 2654435761u) & 0x1fff1fffu, 0x3f000000u, 0x3f000000u, 0x3f000000u);
-#else
         return records[(int64_t)(B.w0 + (int)u) * rec_per_wg + base + (pp - first)];
-#endif
     };
     const int n_batches = (n_wg + UNR * WAVES - 1) / (UNR * WAVES);   // per wave (the last ones may be empty for the higher waves)
     uint32_t my_desc = 0u;
