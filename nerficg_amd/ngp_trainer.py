@@ -68,14 +68,29 @@ class FusedTrainingIteration:
     T_THRESHOLD = 1e-4
 
     def __init__(self, model, renderer, optimizer, scaler, camera, ray_pool: dict, ray_capacity: int, sample_capacity: int, order: torch.Tensor | None = None,
-                 seed: int = 0, weight_decay: float = 0.5e-6, prefetch: bool = True, graph: bool = False, ray_offset: int = 0, fused_step: bool = True,
-                 fork_dense_levels: bool = True) -> None:
+                 seed: int = 0, weight_decay: float = 0.5e-6, prefetch: bool = True, graph: bool = False, ray_offset: int | None = None, fused_step: bool = True,
+                 fork_dense_levels: bool = True, data_parallel: bool | None = None) -> None:
         if not getattr(optimizer, 'capturable', False):
             raise RuntimeError('FusedTrainingIteration: build the optimizer as FusedAdam(..., capturable=True)')
         if len(optimizer.param_groups) != 1:
             raise RuntimeError('FusedTrainingIteration: one parameter group holding both parameter vectors is expected (Trainer.py:35)')
         lib = _lib.load()
         self.model, self.renderer, self.optimizer, self.scaler, self.camera = model, renderer, optimizer, scaler, camera
+        # Data parallel (BASELINE configs[3]): every rank holds the whole pool and the same global order / seed; rank r marches rows
+        # [r n, (r + 1) n) of every global batch of W n rays (parallel.rank_batch_order) with the jitter of their GLOBAL indices and the iteration's one
+        # background colour, so W ranks do the arithmetic one rank would do on W n rays; the two gradient vectors live in ONE flat buffer that is
+        # averaged by one reduce-scatter + all-gather over RCCL (parallel.allreduce_flat) between the backward pass and the step -- an inf / NaN reaches
+        # every rank through the sum, so all replicas skip the same steps.  The gradients have to exist on the wire: fused_step and recording are off.
+        from . import parallel
+        self.rank, self.world = parallel.world_info()
+        self.data_parallel = (self.world > 1) if data_parallel is None else bool(data_parallel)
+        if self.data_parallel:
+            fused_step, graph = False, False
+            if ray_offset is None:
+                ray_offset = self.rank * int(ray_capacity)
+            if order is not None:
+                order = parallel.rank_batch_order(order.to(model.center.device), int(ray_capacity), self.rank, self.world)
+        ray_offset = 0 if ray_offset is None else ray_offset
         self.dev = dev = model.center.device
         self.n_cap, self.m_cap = int(ray_capacity), int(sample_capacity)
         self.ray_offset = int(ray_offset)
@@ -113,7 +128,8 @@ class FusedTrainingIteration:
         self.loss2 = torch.zeros(2, device=dev)
         self.loss_ws = torch.zeros(int(lib.nrc_ngp_train_loss_ws_bytes(self.n_cap)), dtype=torch.uint8, device=dev)
         dn, cn = model.encoding_xyz, model.color_mlp_with_encoding
-        self.gd, self.gc = e(dn.params.numel()), e(cn.params.numel())
+        self.grads = e(dn.params.numel() + cn.params.numel())      # one buffer: one collective in data-parallel runs
+        self.gd, self.gc = self.grads[:dn.params.numel()], self.grads[dn.params.numel():]
         self.bwd_scratch = e(int(lib.nrc_ngp_train_query_scratch_bytes(m)), dtype=torch.uint8)
         g = dn.grid_cfg
         self.n_clear = int(lib.nrc_ngp_train_query_clear_floats(m, g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
@@ -134,7 +150,7 @@ class FusedTrainingIteration:
     # ------------------------------------------------------------------------------------------------ sampling state
     def rewind(self, order: torch.Tensor) -> None:
         """Install a (new) sampling order -- RandomSequentialSampler's permutation, Samplers/utils.py:30-33 -- and put the cursor at its start.
-        A batch marched ahead from the old order is dropped."""
+        A batch marched ahead from the old order is dropped.  (Data parallel: pass this rank's order, parallel.rank_batch_order(global_order, n).)"""
         order = order.to(device=self.dev, dtype=torch.int64).contiguous()
         if self.order is not None and self.order.shape == order.shape:
             self.order.copy_(order)       # recorded iterations read this buffer
@@ -149,6 +165,8 @@ class FusedTrainingIteration:
         """Live rays per call from now on (<= ray_capacity): what Trainer.update_batch_size (:70-75) changes every 16 iterations; recorded
         iterations read it from the device.  A batch already marched ahead keeps its size."""
         n = int(n_rays)
+        if getattr(self, 'data_parallel', False) and n != self.n_cap:
+            raise RuntimeError('data-parallel ranks consume fixed slices of a global batch: the batch size is the ray capacity')
         if not 1 <= n <= self.n_cap:
             raise ValueError(f'batch size {n} outside 1 .. ray_capacity = {self.n_cap}')
         if n != self.n_rays:
@@ -221,6 +239,9 @@ class FusedTrainingIteration:
                 self.l2[1][0], self.l2[1][1], *hyper, fork, stream), 'ngp_train_backward_step')
             return
         _lib.check(lib.nrc_ngp_train_query_backward_cleared(*backward, fork, stream), 'ngp_train_query_backward_cleared')
+        if self.data_parallel:
+            from . import parallel
+            parallel.allreduce_flat(self.grads, average=True)
         _lib.check(lib.nrc_amp_adam_step(
             p(st['pd']), p(self.gd), p(st['md']), p(st['vd']), p(st['hd']), self.gd.numel(), self.l2[0][0], self.l2[0][1],
             p(st['pc']), p(self.gc), p(st['mc']), p(st['vc']), p(st['hc']), self.gc.numel(), self.l2[1][0], self.l2[1][1],

@@ -82,6 +82,18 @@ def shard_ray_ids(ray_ids: torch.Tensor, rank: int | None = None, world: int | N
     return ray_ids[rank::world]
 
 
+def rank_batch_order(order: torch.Tensor, n_rays: int, rank: int | None = None, world: int | None = None) -> torch.Tensor:
+    """The sampling order of ONE rank when `world` ranks each consume n_rays rows per iteration from a GLOBAL order (the RandomSequentialSampler's
+    permutation, identical on every rank): iteration k's global batch is order[k W n : (k + 1) W n] and rank r takes rows [r n, (r + 1) n) of it, so the
+    rank's own order is the concatenation of those slices -- consumed front to back with a local cursor (nerficg_amd.ngp_trainer).  The union over the
+    ranks of iteration k is exactly the global batch; a tail that does not fill a global batch is dropped (the sampler rewinds there anyway)."""
+    r, w = world_info()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    n_iter = order.numel() // (world * n_rays)
+    return order[:n_iter * world * n_rays].reshape(n_iter, world, n_rays)[:, rank].reshape(-1).contiguous()
+
+
 def shard_range(n: int, rank: int | None = None, world: int | None = None) -> tuple[int, int]:
     """Contiguous, balanced [begin, end) share of n units (image tiles, views) for this rank."""
     r, w = world_info()

@@ -230,3 +230,18 @@ def test_rays_per_batch_update_is_the_reference_rule_for_one_rank():
     assert parallel.rays_per_batch_update(4096, 262144, 16 * 300_000.0 * 8, 16, world=8) == 3584
     assert parallel.rays_per_batch_update(4096, 262144, 16 * 10.0, 16, world=1) == 262144
     assert parallel.rays_per_batch_update(4096, 262144, 0.0, 16, world=1) == 4096
+
+
+def test_rank_batch_orders_tile_the_global_batches():
+    """parallel.rank_batch_order (host logic of the data-parallel fused trainer): for every iteration the ranks' slices are disjoint and their union, in
+    rank order, IS the global batch order[k W n : (k + 1) W n]; a tail that does not fill a global batch is dropped."""
+    import torch
+    from nerficg_amd import parallel
+    order = torch.randperm(10_007, generator=torch.Generator().manual_seed(3))
+    for world, n in ((2, 512), (8, 100), (1, 1000)):
+        per_rank = [parallel.rank_batch_order(order, n, r, world) for r in range(world)]
+        n_iter = 10_007 // (world * n)
+        assert all(p.numel() == n_iter * n for p in per_rank)
+        for k in range(n_iter):
+            union = torch.cat([p[k * n:(k + 1) * n] for p in per_rank])
+            assert torch.equal(union, order[k * world * n:(k + 1) * world * n])

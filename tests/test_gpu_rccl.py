@@ -119,3 +119,40 @@ def test_every_rccl_collective_of_the_data_parallel_path_runs_on_one_gpu(tmp_pat
     n_union, n_visible, same = out['sparse']
     assert n_union == n_visible > 0 and same
     assert out['stats'] == [2.0, 3]
+
+
+TRAINER_CHILD = r'''
+import json, os, sys
+sys.path.insert(0, os.environ['NRC_ROOT'])
+import torch
+from nerficg_amd import parallel
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+parallel.init_distributed('nccl', dev, single_rank_group=True)
+parallel.single_rank_collectives(True)
+from tests.test_gpu_ngp_trainer import _fused, _pool
+from tests.test_gpu_graphs import _train_pair
+cam, pool = _pool(size=96)
+order = torch.randperm(pool['origin'].shape[0], generator=torch.Generator().manual_seed(4)).to(dev)
+res = {}
+for mode in ('plain', 'dp'):
+    model, renderer, _ = _train_pair(seed=3)
+    it, opt, _ = _fused(model, renderer, cam, pool, 1024, 200_000, prefetch=True, graph=False, order=order, seed=21, fused_step=False, data_parallel=(mode == 'dp'))
+    losses = [float(it()['loss']) for _ in range(6)]
+    res[mode] = dict(losses=losses, cursor=int(it.cursor), dp=bool(it.data_parallel), checksum=float(model.encoding_xyz.params.double().abs().sum()))
+print(json.dumps(res))
+'''
+
+
+def test_fused_trainer_data_parallel_path_on_a_one_rank_group():
+    """nerficg_amd.ngp_trainer with data_parallel=True: per-rank order, one flat gradient buffer, parallel.allreduce_flat between the backward pass and the
+    step -- executed on a one-rank RCCL group (the average over one rank is the identity): the same batches, losses and (to the atomics' run-to-run noise)
+    parameters as the plain trainer."""
+    env = {**os.environ, 'NRC_ROOT': str(ROOT), 'MASTER_PORT': '29517'}
+    r = subprocess.run([sys.executable, '-c', TRAINER_CHILD], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads(next(l for l in reversed(r.stdout.strip().splitlines()) if l.startswith('{')))     # (RCCL prints its library path behind it)
+    assert res['dp']['dp'] and not res['plain']['dp'] and res['dp']['cursor'] == res['plain']['cursor'] == 7 * 1024     # six iterations + the batch marched ahead
+    for a, b in zip(res['plain']['losses'], res['dp']['losses']):
+        assert abs(a - b) <= 2e-3 * abs(a), (res['plain']['losses'], res['dp']['losses'])
+    assert abs(res['plain']['checksum'] - res['dp']['checksum']) <= 1e-4 * res['plain']['checksum']
