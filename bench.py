@@ -766,7 +766,32 @@ def dp_ingp_leg(model, renderer, cam, poses, rank, world, device, rays_per_rank=
             p.copy_(q)
     if drift != 0.0 or out_drift != 0.0:
         raise RuntimeError(f'InstantNGP data-parallel replicas drifted: parameters {drift:.3e}, network output {out_drift:.3e}')
-    return {'ms_per_iteration': round(dt * 1e3, 3), 'rays_per_iteration': n_global, 'samples_per_iteration_per_gpu': round(samples), 'mrays_per_s': round(n_global / dt / 1e6, 3),
+    # the same data-parallel iteration through the fused trainer (nerficg_amd.ngp_trainer, data_parallel: per-rank slices of the global batch, ONE
+    # flat gradient buffer, one reduce-scatter + all-gather between the backward pass and the step); N > 1 only -- at N = 1 it is `training.fused`
+    fused_dp = None
+    if world > 1:
+        try:
+            from nerficg_amd.amp import GradScaler as _GS
+            from nerficg_amd.ngp_trainer import FusedTrainingIteration
+            opt_f = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
+            it = FusedTrainingIteration(model, renderer, opt_f, _GS(init_scale=128.0, growth_interval=10 ** 9), cam, {'origin': origin, 'view_direction': vdir, 'rgb': target},
+                                        rays_per_rank, (int(1.15 * samples) + 4095) // 4096 * 4096, order=perm, seed=5)
+            for _ in range(3):
+                it()
+            torch.cuda.synchronize(); dist.barrier(); t0 = time.perf_counter()
+            for _ in range(3 * iters):
+                out_f = it()
+            torch.cuda.synchronize(); dist.barrier()
+            dt_f = _max_over_ranks([(time.perf_counter() - t0) / (3 * iters)], device, world)[0]
+            drift_f = _replica_drift(torch.cat([p.detach().reshape(-1) for p in params]), world)
+            fused_dp = {'ms_per_iteration': round(dt_f * 1e3, 3), 'rays_per_iteration': n_global, 'mrays_per_s': round(n_global / dt_f / 1e6, 3),
+                        'replica_drift': drift_f, 'samples_cut': int(out_f['sample_overflow'])}
+        except Exception as e:   # an extra leg must never take the line down
+            fused_dp = {'error': repr(e)[:300]}
+        with torch.no_grad():
+            for p, q in zip(model.parameters(), saved):
+                p.copy_(q)
+    return {'fused_trainer': fused_dp, 'ms_per_iteration': round(dt * 1e3, 3), 'rays_per_iteration': n_global, 'samples_per_iteration_per_gpu': round(samples), 'mrays_per_s': round(n_global / dt / 1e6, 3),
             'collective': f'one flat f32 bucket, {"all_reduce" if dist.get_backend() == "gloo" else "reduce-scatter + all-gather"} over {dist.get_backend()}' if world > 1 else None, 'bytes_reduced_per_iteration': nbytes if world > 1 else 0,
             'collective_ms': round(coll, 3) if world > 1 else None,
             'bus_GBps_per_gpu': round(2 * (world - 1) / world * nbytes / (coll * 1e-3) / 1e9, 1) if world > 1 and coll > 0 else None,

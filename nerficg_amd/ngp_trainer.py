@@ -86,6 +86,11 @@ class FusedTrainingIteration:
         self.data_parallel = (self.world > 1) if data_parallel is None else bool(data_parallel)
         if self.data_parallel:
             fused_step, graph = False, False
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'gloo':
+                # gloo's device all-reduce waits for the whole device, the side stream's march included, and the two then take turns:
+                # 129 ms per iteration against 14 (two ranks on one GPU, tools/exp_fused_dp.py).  RCCL's collectives are stream-ordered.
+                prefetch = False
             if ray_offset is None:
                 ray_offset = self.rank * int(ray_capacity)
             if order is not None:
