@@ -98,7 +98,13 @@ def ptr(t):
 
 
 def stream_of(t) -> ctypes.c_void_p:
+    """torch's current stream on the tensor's device as the raw handle (the launch stream of every entry point).  Through torch's C accessor: the Python
+    route -- torch.cuda.current_stream(dev).cuda_stream builds a Stream object -- cost ~6 us a call, eight calls per training iteration."""
     import torch
+    raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    if raw is not None:
+        idx = t.device.index
+        return ctypes.c_void_p(raw(idx if idx is not None else torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 

@@ -519,3 +519,37 @@ def test_mirror_follows_the_reference_orchestration_fixture(golden_dir):
         got, want = ev[key].float().cpu().numpy(), fx['eval_' + key]
         assert np.abs(got - want).max() <= tol and np.abs(got - want).mean() <= tol / 20, (key, np.abs(got - want).max(), np.abs(got - want).mean())
     assert float(fx['train_alpha'].max()) > 0.3 and float((fx['eval_alpha'] > 0).mean()) > 0.3    # the fixture is not an empty picture
+
+
+def test_pose_dependent_encoder_shape_paints_the_same_picture():
+    """InstantNGPRenderer.POSE_ENCODER_SHAPE: the brick of samples a wave of the encoder gathers for follows the camera's axes (nrc_ngp_set_encoder_shape).
+    Every shape computes the same features: the picture of a pose whose image columns run along world x (shape 4 x 4 x 1) and of one looking down x
+    (4 x 2 x 8) is bit-identical to the picture with the fixed default brick."""
+    from nerficg_amd.instant_ngp import InstantNGPRenderer
+    model = make_model()
+    cam = make_camera(96, 80)
+    def look(fwd, down):
+        fwd, down = np.asarray(fwd, np.float64), np.asarray(down, np.float64)
+        fwd /= np.linalg.norm(fwd)
+        right = np.cross(down, fwd); right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        c2w = np.eye(4)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, -1.3 * fwd
+        return c2w
+    poses = {'columns along x': look((0.1, 0.2, 1.0), (1.0, 0.1, 0.0)), 'looking down x': look((1.0, 0.05, 0.1), (0.0, 1.0, 0.0)), 'rows along x': look((0.0, 0.3, 1.0), (0.0, 1.0, 0.0))}
+    shapes = set()
+    for name, c2w in poses.items():
+        pics = {}
+        for on in (True, False):
+            r = InstantNGPRenderer(model)
+            r.POSE_ENCODER_SHAPE = on
+            out = r.render_image_fused(cam, c2w, early_termination=False)
+            pics[on] = {k: out[k].clone() for k in ('rgb', 'alpha', 'depth')}
+            if on:
+                shapes.add(r._frame_constants(cam, c2w)['enc_shape'])
+        for k in pics[True]:
+            assert torch.equal(pics[True][k], pics[False][k]), (name, k)
+        assert float(pics[True]['alpha'].max()) > 0.5, name
+    assert shapes == {(3, 1), (2, 2), (2, 1)}, shapes
+    from nerficg_amd import _lib
+    _lib.load().nrc_ngp_set_encoder_shape(-1, -1)

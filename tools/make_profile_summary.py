@@ -36,16 +36,19 @@ for tag, name in (('gs_stats', f'{ROUND}_gs_kernel_stats.csv'), ('gs6_stats', f'
 tstats = sorted(glob.glob(str(RAW / 'train_stats' / '*' / '*kernel_stats.csv')), key=os.path.getmtime)
 if tstats:
     shutil.copy(tstats[-1], OUT / f'{ROUND}_train_kernel_stats.csv')
+fstats = sorted(glob.glob(str(RAW / 'fused_stats' / '*' / '*kernel_stats.csv')), key=os.path.getmtime)
+if fstats:
+    shutil.copy(fstats[-1], OUT / f'{ROUND}_fused_train_kernel_stats.csv')
 # one accumulator per collection run: pmc_* = tools/bench_query.py (InstantNGP image pipeline), pmcgs_* = tools/bench_gs.py (3DGS frame),
 # pmctr_* = tools/bench_train.py (InstantNGP training iteration).  A kernel that appears in several of them (k_grid_encode runs in the image
 # pipeline with 8 Mi-slot launches and in training with 264 K samples) is reported from the run that is about it.
-by_run = {tag: collections.defaultdict(lambda: collections.defaultdict(list)) for tag in ('pmc_', 'pmcgs_', 'pmctr_')}
+by_run = {tag: collections.defaultdict(lambda: collections.defaultdict(list)) for tag in ('pmc_', 'pmcgs_', 'pmctr_', 'pmcfu_')}
 for f in glob.glob(str(RAW / 'pmc*' / '*' / '*counter_collection.csv')):
-    tag = 'pmcgs_' if '/pmcgs_' in f else ('pmctr_' if '/pmctr_' in f else 'pmc_')
+    tag = 'pmcgs_' if '/pmcgs_' in f else ('pmctr_' if '/pmctr_' in f else ('pmcfu_' if '/pmcfu_' in f else 'pmc_'))
     for r in csv.DictReader(open(f)):
         by_run[tag][short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
 home = {'k_grid_encode<1': 'pmc_', 'k_ngp_mlp': 'pmc_', 'k_render_count': 'pmc_', 'k_render_write': 'pmc_', 'k_composite_image': 'pmc_', 'k_ray_sh': 'pmc_',
-        'k_grid_encode<0': 'pmctr_', 'k_nwie': 'pmctr_', 'k_grid_bwd': 'pmctr_', 'k_gb_': 'pmctr_', 'k_march': 'pmctr_', 'k_composite_train': 'pmctr_', 'k_adam': 'pmctr_'}
+        'k_grid_encode<0': 'pmctr_', 'k_nwie': 'pmctr_', 'k_grid_bwd': 'pmctr_', 'k_gb_': 'pmctr_', 'k_march': 'pmctr_', 'k_composite_train': 'pmctr_', 'k_adam': 'pmctr_', 'k_train_': 'pmcfu_', 'k_amp_': 'pmcfu_'}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 names = set().union(*[set(v) for v in by_run.values()])
 for k in names:
@@ -54,7 +57,7 @@ for k in names:
     for n, vals in src[k].items():
         acc[k][n] = vals
 keep = ('k_grid_encode', 'k_ngp_mlp', 'k_render', 'k_composite_image', 'k_preprocess', 'k_span_', 'k_item_', 'k_depth_keys', 'k_radix_', 'k_scan_tiles', 'k_march_wave',
-        'k_grid_bwd', 'k_nwie_', 'k_composite_train')
+        'k_grid_bwd', 'k_nwie_', 'k_composite_train', 'k_gb_', 'k_train_', 'k_amp_', 'k_adam')
 lines = [f'# rocprofv3 --pmc summary (MI355X, {ROUND})', '',
          'Collected by `tools/collect_profiles.sh` (one `--pmc` group per run, `--kernel-trace` only), averaged per kernel over all launches of',
          '`tools/bench_query.py` (InstantNGP 800x800 image pipeline), `tools/bench_gs.py` (3DGS, 1 M Gaussians, 1297x840) and `tools/bench_train.py`',
