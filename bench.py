@@ -1082,7 +1082,7 @@ def main():
                          'kernel_ms': round(k_ms, 4), 'kernel_ms_min_pose': round(kt['enc_ms_min'], 4), 'kernel_ms_max_pose': round(kt['enc_ms_max'], 4),
                          'timed_over': f"{kt['poses']} poses of the timed region, {kt['launches_per_image']:.1f} launches per image, HIP events on the launch stream",
                          'samples_per_launch': k_live, 'slots_per_launch': kt['slots_per_launch'],
-                         'limiter': {'resource': 'L1 (TCP): tag lookups, and behind them the L1 misses of the four finest levels (8.8 of the 9.3 L2 requests per sample, 52 % of the kernel: profiles/r03_encoder_levels.md)',
+                         'limiter': {'resource': 'L1 (TCP): tag lookups, and behind them the L1 misses of the four finest levels (7.3 of the 7.8 L2 requests per sample, 47 % of the kernel: profiles/r05_encoder_levels.md)',
                                      'achieved': enc_pmc.get('tcp_accesses_per_clk_per_cu'), 'peak': 1.0,
                                      'unit': 'cache-line lookups per clock per CU', 'l1_hit_rate': enc_pmc.get('l1_hit_rate'),
                                      'l2_hit_rate': enc_pmc.get('l2_hit_rate'), 'source': enc_pmc_src},
