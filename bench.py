@@ -641,6 +641,9 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=60):
     # parameters (a gradient on every sample at the start).
     from nerficg_amd.ngp_trainer import FusedTrainingIteration
     del graphed
+    import gc
+    gc.collect(); torch.cuda.synchronize()   # the recording (its closures form cycles) is torn down HERE: collected inside the timed loop below, the release of
+                                             # the graph's private pool stalled the device for ~80 ms once (first third 4.1 ms per iteration in one run of five)
     opt_f = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
     scaler_f = GradScaler(init_scale=128.0, growth_interval=10 ** 9)
     fused = FusedTrainingIteration(model, renderer, opt_f, scaler_f, cam, {'origin': origin, 'view_direction': vdir, 'rgb': target}, n_rays, capacity, order=perm)
