@@ -773,12 +773,20 @@ def dp_ingp_leg(model, renderer, cam, poses, rank, world, device, rays_per_rank=
     # flat gradient buffer, one reduce-scatter + all-gather between the backward pass and the step); N > 1 only -- at N = 1 it is `training.fused`
     fused_dp = None
     if world > 1:
+        it, built = None, None
         try:
             from nerficg_amd.amp import GradScaler as _GS
             from nerficg_amd.ngp_trainer import FusedTrainingIteration
             opt_f = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
             it = FusedTrainingIteration(model, renderer, opt_f, _GS(init_scale=128.0, growth_interval=10 ** 9), cam, {'origin': origin, 'view_direction': vdir, 'rgb': target},
                                         rays_per_rank, (int(1.15 * samples) + 4095) // 4096 * 4096, order=perm, seed=5)
+        except Exception as e:
+            built = repr(e)[:300]
+        # every rank enters the iterations (they hold a collective) or none does: a rank that failed to build must not leave the others waiting
+        n_failed = _max_over_ranks([0.0 if built is None else 1.0], device, world)[0]
+        try:
+            if n_failed:
+                raise RuntimeError(built or 'another rank failed to build the fused trainer')
             for _ in range(3):
                 it()
             torch.cuda.synchronize(); dist.barrier(); t0 = time.perf_counter()

@@ -1213,6 +1213,21 @@ __device__ __forceinline__ float blend_power(float A, float B, float C, float dx
     const float t2 = fmaf(C * dy, dy, (A * dx) * dx);
     return fmaf(-0.5f, t2, -((B * dx) * dy));
 }
+// expf for the blend loops, WITHOUT the two range guards of the library routine: the same nine instructions (Cody-Waite split of x log2(e), v_exp_f32 on the
+// fraction, v_ldexp_f32 by the integer part), hence bit for bit the library's value wherever the result is a normal number, -87.3 <= x <= 88.72
+// (tools/micro/exp_blend_check.hip: 2 x 10^8 inputs -- a sweep of [-104, 0], every float in [-1e-3, 0], 2^13 floats around every multiple of ln 2 --
+// 0 differences there; below, where the result is a denormal, the two differ in how they flush: a blend needs alpha >= 1/255, i.e. x >= -5.6, so none
+// of those values is ever used).  The four instructions dropped -- two compares and two selects forcing 0 / inf outside the range -- were a tenth of
+// k_render's VALU instructions per blend (40 -> 36; 168 -> 157 us at 1 M Gaussians).  x > 88.72 (power > 0: the blend discards the entry) overflows to
+// inf in v_ldexp_f32 like the library's select.
+__device__ __forceinline__ float exp_blend(float x) {
+    const float ph = x * 0x1.715476p+0f;
+    float pl = fmaf(x, 0x1.715476p+0f, -ph);
+    pl = fmaf(x, 0x1.4ae0bep-26f, pl);
+    const float e = __builtin_rintf(ph);
+    const float a = (ph - e) + pl;
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+}
 #define N_BLOCKS 16
 // One staged batch: thread t read entry t's 64-byte record; what the blend loop needs goes to LDS as two 16-byte vectors and a scalar.
 struct StageLds {
@@ -1319,7 +1334,7 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const float dx = a_j[u].x - fx, dy = a_j[u].y - fy;
-                alpha[u] = fminf(0.99f, b_j[u].w * expf(blend_power(b_j[u].x, b_j[u].y, b_j[u].z, dx, dy)));
+                alpha[u] = fminf(0.99f, b_j[u].w * exp_blend(blend_power(b_j[u].x, b_j[u].y, b_j[u].z, dx, dy)));
                 const float power = blend_power(b_j[u].x, b_j[u].y, b_j[u].z, dx, dy);
                 ok[u] = (jj + u < n_mine) & !(power > 0.0f) & !(alpha[u] < 1.0f / 255.0f);
             }
@@ -1507,7 +1522,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             e.c0 = xyrg.z; e.c1 = xyrg.w; e.c2 = st.c[e.j];
             e.dx = xyrg.x - fx; e.dy = xyrg.y - fy;
             const float power = blend_power(e.co.x, e.co.y, e.co.z, e.dx, e.dy);
-            e.G = expf(power);
+            e.G = exp_blend(power);
             e.alpha = fminf(0.99f, e.co.w * e.G);
             e.active = (jj < n_mine) & inside & (pos < last) & !(power > 0.0f) & !(e.alpha < 1.0f / 255.0f);
             return e;
