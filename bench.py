@@ -598,6 +598,19 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=60):
     hbm('grid_backward', ['k_grid_bwd', 'k_gb_split', 'k_gb_accumulate'], 1024)
     mfma('mlp_forward', ['k_nwie_fwd<density>', 'k_nwie_fwd<colour>'], MLP_FLOP_PER_SAMPLE)
     mfma('mlp_backward', ['k_nwie_bwd<colour>', 'k_nwie_bwd<density>'], 2 * MLP_FLOP_PER_SAMPLE)
+    # The limiter-correct ruler for the two training MLP entries.  SURVEY 8(d) prices a15 in FLOP, and at 77 M samples per frame (k_ngp_mlp) that is the
+    # bound; a TRAINING forward also WRITES what the backward needs (fp16 inputs and post-ReLU activations of both networks) and the backward reads it
+    # back -- per sample, forward: density 64 (features) + 64 (inputs kept) + 128 (hidden kept) + 32 (outputs) and colour 12 + 32 + 64 + 256 + 8 + 16
+    # (f32 sigma / rgb) = 676 B; backward: colour 64 + 256 + 16 + 32 and density 64 + 128 + 32 + 128 (pair-major f32 feature gradients) = 720 B --
+    # the chip's balance point is 2.5 PFLOP/s / 8 TB/s = 312 FLOP per byte; these kernels do 20 480 / 676 = 30 and 40 960 / 720 = 57: they stream.
+    def mlp_bytes(name, bytes_per_sample):
+        r = roof.get(name)
+        if r:
+            r['roofline_hbm'] = {'bound': 'hbm', 'algorithmic_bytes_per_sample': bytes_per_sample, 'achieved': round(bytes_per_sample * m_prof / r['ms'] / 1e6, 1),
+                                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(bytes_per_sample * m_prof / r['ms'] / 1e6 / HBM_PEAK_GBS, 4),
+                                 'what': 'inputs + the forward state kept for the backward (fp16, fragment-major) + outputs; the FLOP fraction above is SURVEY 8(d)\'s ruler, this one is what the kernel waits for'}
+    mlp_bytes('mlp_forward', 676)
+    mlp_bytes('mlp_backward', 720)
     roof['_per_kernel_ms'] = {k: round(v, 4) for k, v in sorted(stage.items())}
     roof['_per_kernel_ms_late'] = {k: round(v, 4) for k, v in sorted(stage_late.items())}
     roof['_timing'] = (f'HIP events on the launch stream behind every kernel of the query forward / backward, {n_prof} op-by-op iterations of this run, '

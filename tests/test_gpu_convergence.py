@@ -105,6 +105,75 @@ def test_instant_ngp_trains_to_psnr_on_the_analytic_sphere():
     assert after >= 27.5, after   # measured: 29.85 dB
 
 
+def test_fused_training_iteration_trains_to_psnr_on_the_analytic_sphere():
+    """The same optimisation through nerficg_amd.ngp_trainer.FusedTrainingIteration (C ABI group 13): resident ray pool with alpha (the target is
+    lerp(bg, rgb, alpha) inside the march kernel, Datasets/utils.py:185-189), the batch drawn from a device-resident permutation, background and jitter
+    from the in-kernel generator, the next batch marched ahead on a side stream, GradScaler + Adam inside the last launch -- nothing is read back except
+    the marched-sample total every 16 iterations, where the reference's trainer reads it too (Trainer.py:66-75: occupancy update + rays_per_batch
+    controller at 262 144 samples per batch).  Same schedule, same threshold as the op-by-op test above."""
+    from nerficg_amd import parallel
+    from nerficg_amd.amp import GradScaler
+    from nerficg_amd.apex_optimizers import FusedAdam
+    from nerficg_amd.instant_ngp import Camera, InstantNGPModel, InstantNGPRenderer
+    from nerficg_amd.ngp_trainer import FusedTrainingIteration
+    from nerficg_amd.raygen import generate_rays
+    W = H = 100
+    fx, fy, cx, cy = scenes.lego_intrinsics(W, H)
+    cam = Camera(width=W, height=H, focal_x=fx, focal_y=fy, center_x=cx, center_y=cy, near_plane=0.2, far_plane=1000.0, background_color=torch.ones(3))
+    train_poses, test_poses = orbit(24, 0), orbit(4, 1)
+    origins, dirs, colours, alphas = [], [], [], []
+    for p in train_poses:
+        rays = generate_rays(W, H, fx, fy, cx, cy, p, device=DEV, want_direction=False)
+        img, hit = analytic_view(W, H, p, fx, fy, cx, cy, bg=(0.0, 0.0, 0.0))
+        origins.append(rays['origin']); dirs.append(rays['view_direction'])
+        colours.append(torch.from_numpy(img).reshape(-1, 3).to(DEV)); alphas.append(torch.from_numpy(hit.astype(np.float32)).reshape(-1).to(DEV))
+    pool = {'origin': torch.cat(origins), 'view_direction': torch.cat(dirs), 'rgb': torch.cat(colours), 'alpha': torch.cat(alphas)}
+    model = InstantNGPModel(RANDOM_SEED=0, device=DEV)
+    renderer = InstantNGPRenderer(model)
+    opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
+    scaler = GradScaler(init_scale=128.0, growth_interval=10 ** 9)
+    n_pool = pool['origin'].shape[0]
+    new_order = lambda epoch: torch.randperm(n_pool, generator=torch.Generator().manual_seed(epoch)).to(DEV)
+    n_iters, rays_per_batch, target_samples = 1500, 4096, 262144
+    it = FusedTrainingIteration(model, renderer, opt, scaler, cam, pool, ray_capacity=16384, sample_capacity=int(1.5 * target_samples), order=new_order(0), seed=0)
+    it.set_batch_size(rays_per_batch)
+
+    def held_out_psnr():
+        vals = []
+        for p in test_poses:
+            out = renderer.render_image_fused(cam, p)
+            gt, _ = analytic_view(W, H, p, fx, fy, cx, cy)
+            vals.append(psnr(out['rgb'].cpu().numpy().reshape(H, W, 3), gt))
+        return float(np.mean(vals))
+
+    with torch.no_grad():
+        model.occupancy_bitfield.fill_(255)
+    before = held_out_psnr()
+    with torch.no_grad():
+        model.occupancy_bitfield.zero_()
+    marched = torch.zeros((), dtype=torch.int64, device=DEV)
+    cut = torch.zeros((), dtype=torch.int64, device=DEV)
+    epoch, sizes = 0, []
+    for i in range(n_iters):
+        if i % 16 == 0:
+            renderer.update_occupancy_grid(warmup=i < 256)                                           # Trainer.py:61-64
+            if i > 0:                                                                                 # Trainer.py:70-75
+                rays_per_batch = min(parallel.rays_per_batch_update(rays_per_batch, target_samples, float(marched), 16, 1), it.n_cap)
+                it.set_batch_size(rays_per_batch); sizes.append(rays_per_batch)
+                marched.zero_()
+        if it.remaining_batches() < 2:
+            epoch += 1
+            it.rewind(new_order(epoch))
+        out = it(prefetch=(i + 1) % 16 != 0)     # the call in front of an occupancy update does not march the next batch against the old grid
+        marched += out['rm_samples']; cut += out['sample_overflow']
+    after = held_out_psnr()
+    print(f'InstantNGP analytic sphere, fused iteration: held-out PSNR {before:.2f} dB -> {after:.2f} dB after {n_iters} iterations, final loss '
+          f'{float(out["loss"]):.2e}, rays per batch {sizes[0]} ... {sizes[-1]}, samples cut by the capacity {int(cut)}, epochs {epoch + 1}')
+    assert before < 15.0
+    assert after >= 27.5, after
+    assert opt.effective_step(opt.param_groups[0]) == n_iters and float(scaler.get_scale()) == 128.0    # no step was skipped
+
+
 def test_gaussian_splatting_trains_to_psnr_on_the_analytic_sphere():
     from nerficg_amd.gaussian_splatting import Gaussians, PerspectiveCamera, render_image_inference, render_image_training, training_loss
     W, H = 160, 120
