@@ -29,7 +29,8 @@ PER_FILE_FLAGS = {
     'gs_densify.hip': ['-ffp-contract=off'],   # thresholds decide the row list: same f32 sequence as oracle/gs_densify.py   # squared distances decide the neighbour set: same f32 sequence as oracle/knn_oracle.c
   # HBM-bound anyway; keeps the update bit-identical to oracle/adam_oracle.c
     # + no atomic optimizer: it rewrites the one-lane LDS atomics of k_render_bw into 15-instruction wave-reduction loops
-    'gs_raster.hip': ['-ffp-contract=off', '-mllvm', '-amdgpu-atomic-optimizer-strategy=None'],
+    # + no SLP vectoriser: it packs the blend arithmetic of two list entries into v_pk_* and pays in v_mov (the blend states its own pairs: blend_power)
+    'gs_raster.hip': ['-ffp-contract=off', '-fno-slp-vectorize', '-mllvm', '-amdgpu-atomic-optimizer-strategy=None'],
 }
 
 

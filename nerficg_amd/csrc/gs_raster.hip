@@ -1204,14 +1204,19 @@ __device__ __forceinline__ unsigned block_flags(const float4& q0, const float4& 
     }
     return f;
 }
-// The exponent of a Gaussian at a pixel: -1/2 (A dx^2 + C dy^2) - B dx dy, as SEVEN instructions with explicit fused multiply-adds where the source-order
+// The exponent of a Gaussian at a pixel: -1/2 (A dx^2 + C dy^2) - B dx dy, as SIX instructions (one of them packed) with explicit fused multiply-adds where the source-order
 // form takes nine (this translation unit is built without contraction: the integer decisions of the per-Gaussian kernels must not move).  The blend
 // kernels are bound by VALU issue (profiles/: 0.70-0.78 of the issue slots at 315 M blends per frame), so instructions per blend are what they cost.
 // The upstream binary is an nvcc build with -fmad=true, i.e. it fuses in these places too; WHICH pairs it fuses is not recoverable, so the oracle
 // (oracle/gs_oracle_impl.h: GS_BLEND_POWER / test_T / the colour sums) states the same fusions and n_contrib / final_T stay bit-exact against it.
-__device__ __forceinline__ float blend_power(float A, float B, float C, float dx, float dy) {
-    const float t2 = fmaf(C * dy, dy, (A * dx) * dx);
-    return fmaf(-0.5f, t2, -((B * dx) * dy));
+typedef float v2f __attribute__((ext_vector_type(2)));
+// (A, C) and (dx, dy) travel as register PAIRS: the two first products are one v_pk_mul_f32, the pixel offset one v_pk_add_f32 -- the same
+// roundings as the scalar form, two VALU instructions less per blend.  (This translation unit is built with -fno-slp-vectorize: left to itself
+// the vectoriser pairs the products of two DIFFERENT list entries and pays the packing back in v_mov, 20 per four blends.)
+__device__ __forceinline__ float blend_power(v2f ac, float B, v2f d) {
+    const v2f p = ac * d;                                  // (A dx, C dy)
+    const float t2 = fmaf(p.y, d.y, p.x * d.x);
+    return fmaf(-0.5f, t2, -((B * d.x) * d.y));
 }
 // expf for the blend loops, WITHOUT the two range guards of the library routine: the same nine instructions (Cody-Waite split of x log2(e), v_exp_f32 on the
 // fraction, v_ldexp_f32 by the integer part), hence bit for bit the library's value wherever the result is a normal number, -87.3 <= x <= 88.72
@@ -1232,7 +1237,7 @@ __device__ __forceinline__ float exp_blend(float x) {
 // One staged batch: thread t read entry t's 64-byte record; what the blend loop needs goes to LDS as two 16-byte vectors and a scalar.
 struct StageLds {
     float4 a[BATCH];      // X, Y, r, g
-    float4 b[BATCH];      // A, B, C, o
+    float4 b[BATCH];      // A, C, B, o  (conic xx, yy, xy, opacity: the pair (A, C) is what blend_power multiplies with (dx, dy))
     float c[BATCH];       // b
     uint16_t flags[BATCH];
     __attribute__((aligned(16))) uint8_t list[N_BLOCKS][BATCH];
@@ -1243,7 +1248,7 @@ __device__ __forceinline__ unsigned stage_entry(StageLds& st, const float4* __re
     const unsigned flags = block_flags(q0, q1, q2, tx0, ty0);
     if (flags) {
         st.a[threadIdx.x] = make_float4(q0.x, q0.y, q3.x, q3.y);
-        st.b[threadIdx.x] = make_float4(q0.z, q0.w, q1.x, q1.y);
+        st.b[threadIdx.x] = make_float4(q0.z, q1.x, q0.w, q1.y);
         st.c[threadIdx.x] = q3.z;
     }
     return flags;
@@ -1312,6 +1317,7 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
         int n_wave;
         const int n_mine = block_lists(st, flags, &n_wave);
         const uint32_t pos0 = base - r0 + 1u;  // contributor number of batch entry 0 = its position in the tile list + 1
+        int last_j = -1;
         for (int jj = 0; jj < n_wave; jj += 4) {
             if (__ballot(!done) == 0ull) break;  // wave-uniform: every pixel of the quadrant is saturated
             const uint32_t pack = list4[jj >> 2];   // four entries of this row's list per LDS read
@@ -1333,9 +1339,9 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
             bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const float dx = a_j[u].x - fx, dy = a_j[u].y - fy;
-                alpha[u] = fminf(0.99f, b_j[u].w * exp_blend(blend_power(b_j[u].x, b_j[u].y, b_j[u].z, dx, dy)));
-                const float power = blend_power(b_j[u].x, b_j[u].y, b_j[u].z, dx, dy);
+                const v2f d = (v2f){a_j[u].x, a_j[u].y} - (v2f){fx, fy};
+                const float power = blend_power((v2f){b_j[u].x, b_j[u].y}, b_j[u].z, d);
+                alpha[u] = fminf(0.99f, b_j[u].w * exp_blend(power));
                 ok[u] = (jj + u < n_mine) & !(power > 0.0f) & !(alpha[u] < 1.0f / 255.0f);
             }
 #pragma unroll
@@ -1351,9 +1357,10 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
                 const float w = upd ? alpha[u] * T : 0.f;
                 C0 = fmaf(a_j[u].z, w, C0); C1 = fmaf(a_j[u].w, w, C1); C2 = fmaf(c_j[u], w, C2);
                 T = upd ? test_T : T;
-                last = upd ? pos0 + (uint32_t)j[u] : last;
+                last_j = upd ? j[u] : last_j;
             }
         }
+        if (last_j >= 0) last = pos0 + (uint32_t)last_j;   // contributor number of the last entry this pixel blended (one add per batch, not per blend)
         __syncthreads();
     }
     if (inside) {
@@ -1503,7 +1510,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
                 if (pos_l >= __builtin_amdgcn_readlane(blast_v, b)) flags &= ~(1u << b);
             if (flags) {
                 st.a[threadIdx.x] = make_float4(q0.x, q0.y, q3.x, q3.y);
-                st.b[threadIdx.x] = make_float4(q0.z, q0.w, q1.x, q1.y);
+                st.b[threadIdx.x] = make_float4(q0.z, q1.x, q0.w, q1.y);
                 st.c[threadIdx.x] = q3.z;
             }
         }
@@ -1520,8 +1527,9 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             e.co = st.b[e.j];
             const float4 xyrg = st.a[e.j];
             e.c0 = xyrg.z; e.c1 = xyrg.w; e.c2 = st.c[e.j];
-            e.dx = xyrg.x - fx; e.dy = xyrg.y - fy;
-            const float power = blend_power(e.co.x, e.co.y, e.co.z, e.dx, e.dy);
+            const v2f d = (v2f){xyrg.x, xyrg.y} - (v2f){fx, fy};
+            e.dx = d.x; e.dy = d.y;
+            const float power = blend_power((v2f){e.co.x, e.co.y}, e.co.z, d);
             e.G = exp_blend(power);
             e.alpha = fminf(0.99f, e.co.w * e.G);
             e.active = (jj < n_mine) & inside & (pos < last) & !(power > 0.0f) & !(e.alpha < 1.0f / 255.0f);
@@ -1546,7 +1554,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             const float d_op = Gm * dL_dalpha;          // sum G dL/dalpha
             const float wgt = e.co.w * d_op;            // G dL/dG
             const float wx = wgt * e.dx, wy = wgt * e.dy;
-            const float d_mx = fmaf(wx, e.co.x, wy * e.co.y), d_my = fmaf(wy, e.co.z, wx * e.co.y);   // flushed with -0.5 W, -0.5 H
+            const float d_mx = fmaf(wx, e.co.x, wy * e.co.z), d_my = fmaf(wy, e.co.y, wx * e.co.z);   // co = (A, C, B, o); flushed with -0.5 W, -0.5 H
             const float d_cx = wx * e.dx, d_cy = wx * e.dy, d_cw = wy * e.dy;                          // flushed with -1/2
             const float d_c0 = dchm * g0, d_c1 = dchm * g1, d_c2 = dchm * g2;
             T = T_new;

@@ -7,7 +7,7 @@ name=$1; file=$2; shift 2
 stem=$(basename "$file" .hip)
 extra=""
 case "$stem" in
-  gs_raster) extra="-ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None";;
+  gs_raster) extra="-ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None";;
   ngp_march|adam|knn|gs_densify) extra="-ffp-contract=off";;
 esac
 mkdir -p _ab
