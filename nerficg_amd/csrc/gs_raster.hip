@@ -1235,21 +1235,26 @@ __device__ __forceinline__ float exp_blend(float x) {
 }
 #define N_BLOCKS 16
 // One staged batch: thread t read entry t's 64-byte record; what the blend loop needs goes to LDS as two 16-byte vectors and a scalar.
-struct StageLds {
+// LT = what a block list holds per entry: uint8_t = the batch index j (k_render_bw: its LDS budget, with the 18 KB of per-Gaussian sums, has no
+// room for more), uint16_t = 16 j, the BYTE OFFSET of the entry's records in a[] / b[] / c[] (k_render: the address arrives with the list read, three
+// VALU instructions per blend less).  Blue sits in a float4 array of its own so that all three records of an entry live at the same offset.
+template <typename LT>
+struct StageLdsT {
     float4 a[BATCH];      // X, Y, r, g
     float4 b[BATCH];      // A, C, B, o  (conic xx, yy, xy, opacity: the pair (A, C) is what blend_power multiplies with (dx, dy))
-    float c[BATCH];       // b
+    float4 c[BATCH];      // b, -, -, -
     uint16_t flags[BATCH];
-    __attribute__((aligned(16))) uint8_t list[N_BLOCKS][BATCH];
+    __attribute__((aligned(16))) LT list[N_BLOCKS][BATCH];
 };
-__device__ __forceinline__ unsigned stage_entry(StageLds& st, const float4* __restrict__ splat, int id, float tx0, float ty0) {
+template <typename LT>
+__device__ __forceinline__ unsigned stage_entry(StageLdsT<LT>& st, const float4* __restrict__ splat, int id, float tx0, float ty0) {
     const float4* rec = splat + 4 * (size_t)id;
     const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
     const unsigned flags = block_flags(q0, q1, q2, tx0, ty0);
     if (flags) {
         st.a[threadIdx.x] = make_float4(q0.x, q0.y, q3.x, q3.y);
         st.b[threadIdx.x] = make_float4(q0.z, q1.x, q0.w, q1.y);
-        st.c[threadIdx.x] = q3.z;
+        st.c[threadIdx.x].x = q3.z;
     }
     return flags;
 }
@@ -1257,7 +1262,8 @@ __device__ __forceinline__ unsigned stage_entry(StageLds& st, const float4* __re
 // from the flags of entries 16 l .. 16 l + 15 (two 16-byte LDS reads), ranked with a row prefix sum.  st.list[b] receives the batch indices
 // of the entries that reach block b in ascending order.  Returns the length of the calling thread's own list; *n_wave = the longest of the
 // calling wave's four lists.
-__device__ __forceinline__ int block_lists(StageLds& st, unsigned flags, int* n_wave) {
+template <typename LT>
+__device__ __forceinline__ int block_lists(StageLdsT<LT>& st, unsigned flags, int* n_wave) {
     st.flags[threadIdx.x] = (uint16_t)flags;
     __syncthreads();
     const int b = threadIdx.x >> 4, l16 = threadIdx.x & 15;
@@ -1276,12 +1282,12 @@ __device__ __forceinline__ int block_lists(StageLds& st, unsigned flags, int* n_
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
     const int mine = __shfl(incl, 15, 16);
-    uint8_t* dst = st.list[b] + (incl - cnt);
+    LT* dst = st.list[b] + (incl - cnt);
     uint32_t m = mask;
     while (m) {
         const int i = __builtin_ctz(m);
         m &= m - 1u;
-        *dst++ = (uint8_t)(16 * l16 + i);
+        *dst++ = (LT)((16 * l16 + i) * (sizeof(LT) == 2 ? 16 : 1));
     }
     *n_wave = max(max(__builtin_amdgcn_readlane(mine, 0), __builtin_amdgcn_readlane(mine, 16)),
                   max(__builtin_amdgcn_readlane(mine, 32), __builtin_amdgcn_readlane(mine, 48)));
@@ -1293,7 +1299,7 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
                                                 const float4* __restrict__ splat, const uint32_t* __restrict__ tile_order, float bg0, float bg1, float bg2,
                                                 const float* __restrict__ pose, float* __restrict__ out_color, uint32_t* __restrict__ n_contrib,
                                                 float* __restrict__ final_T) {
-    __shared__ StageLds st;
+    __shared__ StageLdsT<uint16_t> st;
     if (pose) { bg0 = pose[35]; bg1 = pose[36]; bg2 = pose[37]; }
     const int tile = (int)tile_order[blockIdx.x];  // longest lists first
     const int tile_x = tile % cam.gx, tile_y = tile / cam.gx;
@@ -1306,10 +1312,13 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last = 0;
-    const uint32_t* list4 = reinterpret_cast<const uint32_t*>(st.list[block]);
+    const uint2* list4 = reinterpret_cast<const uint2*>(st.list[block]);   // four 16-bit entries of this row's list per LDS read
     // everything the blend loop reads from LDS must be FINITE also for a row that is past the end of its list and picks up a stale index (see the
     // weight below): thread t clears slot t, which only thread t ever stages into
-    st.a[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); st.b[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); st.c[threadIdx.x] = 0.f;
+    st.a[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); st.b[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); st.c[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ... and every list entry it can pick up must be a valid offset: the lists start as zeros too (later batches leave offsets of earlier entries behind)
+    reinterpret_cast<uint4*>(&st.list[0][0])[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    reinterpret_cast<uint4*>(&st.list[0][0])[256 + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
     for (uint32_t base = r0; base < r1; base += BATCH) {
         if (__syncthreads_count(done) == 256) break;
         const uint32_t k = base + threadIdx.x;
@@ -1317,23 +1326,25 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
         int n_wave;
         const int n_mine = block_lists(st, flags, &n_wave);
         const uint32_t pos0 = base - r0 + 1u;  // contributor number of batch entry 0 = its position in the tile list + 1
-        int last_j = -1;
+        int last_off = -1;
         for (int jj = 0; jj < n_wave; jj += 4) {
             if (__ballot(!done) == 0ull) break;  // wave-uniform: every pixel of the quadrant is saturated
-            const uint32_t pack = list4[jj >> 2];   // four entries of this row's list per LDS read
+            const uint2 pack = list4[jj >> 2];
             // A dependent chain of VALU instructions issues one instruction per ~8 cycles on this chip, and more resident waves do not fill the
             // gaps (tools/micro/valu_rate.hip: 4.5 cycles per instruction at 8 waves per SIMD and one chain, 2.3 with four independent chains per
             // wave).  So the four entries of a pack are taken TOGETHER: (1) all LDS reads, (2) the four alphas -- independent of the pixel's
             // running state, four interleaved chains -- and only then (3) the short serial part (transmittance test, masks, accumulation) in
             // list order.  Entries past the end of the row's list and the reference's four early-outs (done / power > 0 / alpha < 1/255 /
             // saturation) are lane masks; same arithmetic, same order per pixel: bit-identical pixels.
-            int j[4];
+            int off[4];   // 16 j: entries behind the list end are stale offsets of earlier batches (or zeros): readable, masked below
+            off[0] = (int)(pack.x & 0xffffu); off[1] = (int)(pack.x >> 16); off[2] = (int)(pack.y & 0xffffu); off[3] = (int)(pack.y >> 16);
             float4 a_j[4], b_j[4];
             float c_j[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                j[u] = (int)((pack >> (8 * u)) & 0xffu);  // bytes behind the list end are stale indices of earlier batches: readable, masked below
-                a_j[u] = st.a[j[u]]; b_j[u] = st.b[j[u]]; c_j[u] = st.c[j[u]];
+                a_j[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(st.a) + off[u]);
+                b_j[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(st.b) + off[u]);
+                c_j[u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(st.c) + off[u]);
             }
             float alpha[4];
             bool ok[4];
@@ -1357,10 +1368,10 @@ __global__ void __launch_bounds__(256) k_render(GsCam cam, const uint32_t* __res
                 const float w = upd ? alpha[u] * T : 0.f;
                 C0 = fmaf(a_j[u].z, w, C0); C1 = fmaf(a_j[u].w, w, C1); C2 = fmaf(c_j[u], w, C2);
                 T = upd ? test_T : T;
-                last_j = upd ? j[u] : last_j;
+                last_off = upd ? off[u] : last_off;
             }
         }
-        if (last_j >= 0) last = pos0 + (uint32_t)last_j;   // contributor number of the last entry this pixel blended (one add per batch, not per blend)
+        if (last_off >= 0) last = pos0 + ((uint32_t)last_off >> 4);   // contributor number of the last entry this pixel blended (one add per batch, not per blend)
         __syncthreads();
     }
     if (inside) {
@@ -1430,7 +1441,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
                                                    const float4* __restrict__ splat, const uint32_t* __restrict__ tile_order, float bg0, float bg1, float bg2,
                                                    const float* __restrict__ pose, const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
                                                    const float* __restrict__ dL_dpix, float* __restrict__ grad_rec) {
-    __shared__ StageLds st;
+    __shared__ StageLdsT<uint8_t> st;
     __shared__ unsigned long long s_acc[BATCH][9];  // per-Gaussian gradient sums of the tile's 16 blocks (fixed point), flushed once per batch
     __shared__ int s_id[BATCH];                     // Gaussian of batch entry t (-1: nothing staged)
     __shared__ int s_blast[N_BLOCKS];
@@ -1464,7 +1475,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
     if ((threadIdx.x & 15) == 0) s_blast[block] = block_last;
     // The blend loop below masks an inactive lane through three factors only; everything else it reads must be FINITE, also for a row that is
     // past the end of its list and picks up a stale index: the staging arrays start as zeros (later batches leave finite records behind).
-    st.a[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); st.b[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); st.c[threadIdx.x] = 0.f;
+    st.a[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); st.b[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); st.c[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     float gmax = inside ? fmaxf(fmaxf(fabsf(g0), fabsf(g1)), fabsf(g2)) : 0.f;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, d, 64));
@@ -1511,7 +1522,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             if (flags) {
                 st.a[threadIdx.x] = make_float4(q0.x, q0.y, q3.x, q3.y);
                 st.b[threadIdx.x] = make_float4(q0.z, q1.x, q0.w, q1.y);
-                st.c[threadIdx.x] = q3.z;
+                st.c[threadIdx.x].x = q3.z;
             }
         }
         s_id[threadIdx.x] = flags ? id_l : -1;
@@ -1526,7 +1537,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             const int pos = pos_top - e.j;
             e.co = st.b[e.j];
             const float4 xyrg = st.a[e.j];
-            e.c0 = xyrg.z; e.c1 = xyrg.w; e.c2 = st.c[e.j];
+            e.c0 = xyrg.z; e.c1 = xyrg.w; e.c2 = st.c[e.j].x;
             const v2f d = (v2f){xyrg.x, xyrg.y} - (v2f){fx, fy};
             e.dx = d.x; e.dy = d.y;
             const float power = blend_power((v2f){e.co.x, e.co.y}, e.co.z, d);
@@ -1570,14 +1581,21 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             const float t0 = dpp_add2<0x141, 0xa>(r0, r2), t1 = dpp_add2<0x141, 0xa>(r1, r3);
             const float t4 = dpp_add<0x141>(r4, r4);
             const float u0 = dpp_add<0x1b>(b1 ? t1 : t0, b1 ? t0 : t1), u4 = dpp_add<0x1b>(t4, t4);
-            const float w0 = dpp_add<0xb1>(u0, u0), w4 = dpp_add<0xb1>(u4, u4);
-            return b0 ? w4 : w0;
+            // last step: a lane keeps ONE of (u0, u4) and its partner lane ^ 1 the other -- select what I keep and what the partner needs first, then
+            // one exchange-and-add (selecting afterwards took two exchanges)
+            return dpp_add<0xb1>(b0 ? u4 : u0, b0 ? u0 : u4);
         };
         // the nine sums of the row leave with ONE 64-bit integer LDS atomic
         auto deposit = [&](int jj, int j, float mine) {
             if (q_has && jj < n_mine) {
-                const float y = fminf(fmaxf(mine * q_scale, -0x1p61f), 0x1p61f);
-                atomicAdd(&s_acc[j][q_col], (unsigned long long)(long long)y);  // truncation: a bias of half a step of 2^-25 ... 2^-51
+                const float y = __builtin_amdgcn_fmed3f(mine * q_scale, -0x1p61f, 0x1p61f);
+                // float -> two's-complement 64-bit, truncating (a bias of half a step of 2^-25 ... 2^-51), in six instructions: the generic
+                // (long long) conversion is thirteen -- a seventh of this loop's VALU instructions with the reduction.  t is an integer-valued float,
+                // hi = floor(t / 2^32) fits an i32, t - hi 2^32 is an exact integer in [0, 2^32) (the low mantissa bits of t): same bits as the cast.
+                const float t = __builtin_truncf(y);
+                const float hf = __builtin_floorf(t * 0x1p-32f);
+                const uint32_t lo32 = (uint32_t)__builtin_fmaf(-hf, 0x1p32f, t);
+                atomicAdd(&s_acc[j][q_col], ((unsigned long long)(uint32_t)(int)hf << 32) | lo32);
             }
         };
         // BW_PAIR entries per trip: their record reads, exponentials and reductions are independent instruction streams (only T and the
