@@ -1529,12 +1529,13 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
         int n_wave;
         const int n_mine = block_lists(st, flags, &n_wave);
         // One list entry of this row: the record, this pixel's offset, alpha exactly as the forward computed it, and whether the pixel blended it.
+        // entry j of the batch sits at list position pos_top - j; this pixel blended the positions < last (0 for a pixel outside the image): j > pos_top - last
+        const int j_behind = pos_top - last;
         struct Entry { float4 co; float cx, cy, dx, dy, c0, c1, c2, G, alpha; int j; bool active; };
         auto entry = [&](int jj) {
             Entry e;
             const uint32_t pack = list4[jj >> 2];  // four entries of this row's list per dword
-            e.j = (int)((pack >> (8 * (jj & 3))) & 0xffu);
-            const int pos = pos_top - e.j;
+            e.j = (int)__builtin_amdgcn_ubfe(pack, 8u * ((uint32_t)jj & 3u), 8u);   // one v_bfe_u32 (the shift is wave-uniform)
             e.co = st.b[e.j];
             const float4 xyrg = st.a[e.j];
             e.c0 = xyrg.z; e.c1 = xyrg.w; e.c2 = st.c[e.j].x;
@@ -1543,7 +1544,7 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
             const float power = blend_power((v2f){e.co.x, e.co.y}, e.co.z, d);
             e.G = exp_blend(power);
             e.alpha = fminf(0.99f, e.co.w * e.G);
-            e.active = (jj < n_mine) & inside & (pos < last) & !(power > 0.0f) & !(e.alpha < 1.0f / 255.0f);
+            e.active = (jj < n_mine) & (e.j > j_behind) & !(power > 0.0f) & !(e.alpha < 1.0f / 255.0f);
             return e;
         };
         // Gradient terms of one (pixel, Gaussian) pair and their row sums.  The per-Gaussian constants (0.5 W, 0.5 H, -1/2, signs) wait for the
@@ -1551,11 +1552,12 @@ __global__ void __launch_bounds__(256) k_render_bw(GsCam cam, const uint32_t* __
         // The colour behind the current Gaussian is carried as ONE running value per channel (the reference keeps last alpha / last colour and
         // rebuilds it every step: same recurrence).  Updates T and n0..n2; returns this lane's column of the row sums.
         auto gradients = [&](const Entry& e) {
-            const float r_om = __builtin_amdgcn_rcpf(1 - e.alpha);  // 1 ulp; feeds gradients only (tolerance, not bit parity)
-            // three masked factors carry `active` through everything below: a lane that does not blend this Gaussian multiplies T by 1, moves its
-            // colour behind by 0 and adds 0 to every sum (all other factors are finite: alpha <= 0.99, and only G can overflow, when power > 0)
-            const float r_m = e.active ? r_om : 1.f, alpha_m = e.active ? e.alpha : 0.f, Gm = e.active ? e.G : 0.f;
-            const float T_new = T * r_m;
+            // two masked factors carry `active` through everything below: a lane that does not blend this Gaussian multiplies T by 1 / (1 - 0) = 1
+            // exactly, moves its colour behind by 0 and adds 0 to every sum (all other factors are finite: alpha <= 0.99, and only G can overflow,
+            // when power > 0)
+            const float alpha_m = e.active ? e.alpha : 0.f, Gm = e.active ? e.G : 0.f;
+            const float r_om = __builtin_amdgcn_rcpf(1 - alpha_m);  // 1 ulp; feeds gradients only (tolerance, not bit parity); rcp(1) = 1
+            const float T_new = T * r_om;
             const float e0 = e.c0 - n0, e1 = e.c1 - n1, e2 = e.c2 - n2;   // colour of this Gaussian minus the colour accumulated behind it
             float dL_dalpha = e0 * g0;
             dL_dalpha = fmaf(e1, g1, dL_dalpha);
