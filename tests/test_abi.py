@@ -52,6 +52,29 @@ def test_argument_validation_without_gpu(lib):
     assert lib.nrc_morton3D(None, 0, None, None) == 0
 
 
+def test_group_13_entry_points_validate_before_they_launch(lib):
+    """The fused training iteration's entry points (include/nerficg_hip.h group 13) called with null pointers / zero sizes on a machine WITHOUT a GPU:
+    every one returns a status (NRC_ERR_INVALID, or NRC_OK for an empty call) before any HIP call -- none dereferences, none launches."""
+    protos = _lib.parse_header()
+    prefixes = ('nrc_ngp_train_', 'nrc_amp_adam_step', 'nrc_grid_backward_live', 'nrc_sum_squares_two', 'nrc_clear_seed_two', 'nrc_ngp_loss_forward',
+                'nrc_raymarching_train_count_posted')
+    names = [n for n in protos if n.startswith(prefixes) and not n.endswith('_bytes') and not n.endswith('_floats')]
+    assert len(names) >= 12, names
+    status = {}
+    for n in names:
+        args = [None if ('*' in t or t == 'nrc_stream_t') else (0.0 if t in ('float', 'double') else 0) for t, _ in protos[n][1]]
+        status[n] = getattr(lib, n)(*args)
+    assert set(status.values()) <= {0, -1}, status
+    for n in ('nrc_ngp_train_march', 'nrc_ngp_train_loss', 'nrc_ngp_train_backward_step', 'nrc_ngp_train_query_backward_cleared', 'nrc_amp_adam_step',
+              'nrc_ngp_train_query_forward', 'nrc_grid_backward_live', 'nrc_raymarching_train_count_posted'):
+        assert status[n] == -1, (n, status[n])
+    # sizes: the wave-per-ray march takes 1 .. 32 768 rays; the encoder's brick must tile the 8 x 8 footprint
+    assert lib.nrc_ngp_train_march_ws_bytes(0, 1024) == -1 and lib.nrc_ngp_train_march_ws_bytes(32769, 1024) == -1
+    assert lib.nrc_ngp_train_march_ws_bytes(4096, 1024) >= 4096 * 1024 * 4
+    assert lib.nrc_ngp_set_encoder_shape(3, 1) == 0 and lib.nrc_ngp_set_encoder_shape(2, 2) == 0 and lib.nrc_ngp_set_encoder_shape(-1, -1) == 0
+    assert lib.nrc_ngp_set_encoder_shape(0, 0) == -1 and lib.nrc_ngp_set_encoder_shape(3, 3) == -1 and lib.nrc_ngp_set_encoder_shape(4, 0) == -1
+
+
 def test_python_mirror_exposes_reference_names():
     import nerficg_amd.VolumeRenderingV2 as vr
     # csrc/binding.cpp:234-250 + custom_functions.py classes
