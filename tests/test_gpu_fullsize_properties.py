@@ -158,10 +158,12 @@ def test_ingp_c4_rank_gradients_add_up_to_the_single_gpu_gradient(ngp):
         p.grad = None
 
 
-@pytest.fixture(scope='module', params=[1_000_000, 6_000_000], ids=['1M', '6M'])
+@pytest.fixture(scope='module', params=[(1_000_000, None, None), (1_000_000, 1600, 1060), (6_000_000, None, None)], ids=['1M', '1M@1600x1060', '6M'])
 def gs(request):
-    """configs[2] (1 M Gaussians) and configs[4] (6 M Gaussians, the per-rank frame of the 8-GPU data-parallel run)."""
-    return bench.build_gs_scene(DEV, request.param)
+    """configs[2] (1 M Gaussians; at the reference yaml's 1297x840 and at the 1600x1060 BASELINE.json names -- SURVEY 8(d) lists both) and configs[4]
+    (6 M Gaussians, the per-rank frame of the 8-GPU data-parallel run)."""
+    n, w, h = request.param
+    return bench.build_gs_scene(DEV, n, w=w, h=h)
 
 
 def _gs_render(gs, tensors, bg=None, grad=False):
@@ -182,7 +184,7 @@ def _gs_render(gs, tensors, bg=None, grad=False):
 def test_gs_million_gaussians_properties(gs):
     t = gs['tensors']
     color, radii, _, _ = _gs_render(gs, t)
-    assert color.shape == (3, bench.GS_H, bench.GS_W) and bool(torch.isfinite(color).all())
+    assert color.shape == (3, gs['h'], gs['w']) and bool(torch.isfinite(color).all())
     assert 0.8 * gs['n'] < int((radii > 0).sum()) < 0.9 * gs['n']
     # determinism of the forward: binning, depth order and blending are free of atomics-order effects
     color2, radii2, _, _ = _gs_render(gs, t)
@@ -204,7 +206,7 @@ def test_gs_million_gaussians_properties(gs):
 
 def test_gs_million_gaussians_gradients_are_stable_and_local(gs):
     t = gs['tensors']
-    g = torch.rand(3, bench.GS_H, bench.GS_W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    g = torch.rand(3, gs['h'], gs['w'], device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
     grads = []
     for _ in range(2):
         color, radii, tt, m2d = _gs_render(gs, t, grad=True)
