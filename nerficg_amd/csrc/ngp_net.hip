@@ -1363,11 +1363,22 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // dZ = (H > 0) ? dH : 0 as next B fragments; H fragments (ACC order) coincide element-for-element with the D layout
+// Packed: H is a post-ReLU activation (fp16 max(x, +0): never negative), so H > 0 <=> its 16 bits are not all zero; min_u16(bits, 1) is 0 / 1 per
+// half, its negation 0x0000 / 0xffff, and the mask is ANDed onto the packed conversion of the accumulators -- 4 v_cvt_pk_f16_f32 + 3 x 4 packed integer
+// instructions per fragment where the element-wise select compiled to 8 x (convert, compare, select) + 4 packs (28; it was 224 of the 402 vector
+// instructions the colour network's backward issued per 32-sample tile).  A NaN activation (forward overflow) lets its gradient through instead of
+// zeroing it; the scaler's check sees either.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ h8 masked_grad_frag(const f16v& acc, int g, const h8& H) {
-    h8 f;
+    const u32x4 f = __builtin_bit_cast(u32x4, acc_to_frag(acc, g)), hb = __builtin_bit_cast(u32x4, H);
+    u32x4 out;
 #pragma unroll
-    for (int j = 0; j < 8; j++) f[j] = (float)H[j] > 0.f ? (_Float16)acc[8 * g + j] : (_Float16)0.f;
-    return f;
+    for (int q = 0; q < 4; q++) {
+        uint32_t m;   // (inline assembly: written with vector types the optimiser turns the mask back into eight compares and selects)
+        asm("v_pk_min_u16 %0, %1, %2\n\tv_pk_sub_u16 %0, 0, %0" : "=v"(m) : "v"(hb[q]), "v"(0x00010001u));
+        out[q] = f[q] & m;
+    }
+    return __builtin_bit_cast(h8, out);
 }
 __device__ __forceinline__ h8 load_acc_order_frag(const _Float16* row64, int s, int hh) {
     const h4 a = *reinterpret_cast<const h4*>(row64 + 16 * s + 4 * hh);

@@ -11,6 +11,7 @@ for f in nerficg_amd/csrc/*.hip; do
   case "$stem" in
     gs_raster) extra="-ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None";;
     ngp_march|adam|knn|gs_densify) extra="-ffp-contract=off";;
+  ngp_net) extra="-fno-slp-vectorize";;
   esac
   /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wno-unused-function -Wno-unused-result -Wno-unused-value -fno-gpu-rdc -DNDEBUG $extra "$@" -c $f -o _ab/$name/$stem.o 2>/dev/null
   objs="$objs _ab/$name/$stem.o"

@@ -9,6 +9,7 @@ extra=""
 case "$stem" in
   gs_raster) extra="-ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None";;
   ngp_march|adam|knn|gs_densify) extra="-ffp-contract=off";;
+  ngp_net) extra="-fno-slp-vectorize";;
 esac
 mkdir -p _ab
 /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value -fno-gpu-rdc -DNDEBUG \
