@@ -445,7 +445,8 @@ int nrc_ngp_render_layers(const float* ts, int32_t* row_tile, const float* ray_o
 /* The brick of the tiled layout that ONE WAVE of the encoder gathers for: 2^log2_x x 2^log2_y pixels of a ray tile x 2^(6 - log2_x - log2_y) consecutive
  * steps (default 8 x 2 x 4).  Hash-table entries are contiguous along world x only, so which brick shares the most cache lines depends on how the
  * image axes and the viewing direction lie to that axis: the host may pick a shape per pose (InstantNGPRenderer does, from the camera's axes).
- * Both < 0: back to the default.  Process-wide setting, read at launch; the features are identical for every shape. */
+ * Both < 0: back to the default.  A setting of the CALLING HOST THREAD, read when that thread launches the encoder (set it on the thread that
+ * enqueues the frame); the features are identical for every shape. */
 int nrc_ngp_set_encoder_shape(int32_t log2_x, int32_t log2_y);
 int nrc_ngp_encode_samples(const float* ts, const int32_t* row_tile, const float* ray_od, int64_t first_row, int64_t n_rows, const float* xyz_min3,
                            const float* xyz_size3, const void* table_f16, int32_t n_levels, int32_t log2_hashmap_size,

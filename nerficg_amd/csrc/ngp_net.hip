@@ -958,7 +958,8 @@ static int64_t query_feat_bytes(int64_t M) {
     return ((c > 0 ? c : 1) + 31) / 32 * 32 * 64 + 256;
 }
 
-static int g_enc_shape_override = 0;   // nrc_ngp_set_encoder_shape: (log2 pixels along x) << 4 | (log2 pixels along y) of a wave's brick, 0 = the default
+static thread_local int g_enc_shape_override = 0;   // nrc_ngp_set_encoder_shape: (log2 pixels along x) << 4 | (log2 pixels along y) of a wave's brick, 0 = the default;
+                                                    // per host thread: the renderer sets it and enqueues the frame from the same thread
 template <int SRC>
 static void launch_encode(const QueryIn& in, int64_t base, int64_t n, const void* table, const GridCfg& g, uint4* feat, hipStream_t s) {
     // levels whose cells are larger than a wave's footprint: narrow gathers (see grid_level_features_narrow)
@@ -2337,13 +2338,21 @@ static int grid_backward_impl(const float* x01, int64_t M, const float* d_featur
             NRC_STAGE(s, nullptr);
             // fork_stream (optional): the dense levels' atomics run there, next to the bucketed levels' split / accumulate on `stream` (memory-side
             // atomics against LDS atomics: 12-17 us of a training iteration); the two events belong to the library
-            enum { MAX_EV = 2 };
-            static hipEvent_t ev[MAX_EV] = {};
+            // (per host thread and device: a record / wait pair is issued back to back by one thread, so two threads driving two streams never see
+            // each other's records; an event belongs to the device it was created on)
+            enum { MAX_EV = 2, MAX_DEV = 64 };
+            static thread_local hipEvent_t ev_of[MAX_DEV][MAX_EV] = {};
             hipStream_t side = fork_stream ? fork_stream : s;
+            int dev = 0;
+            if (side != s && (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV)) side = s;   // no events for this device: one stream
             const bool forked = side != s;
+            hipEvent_t* ev = ev_of[dev];
             if (forked) {
-                if (!ev[0]) for (int k = 0; k < MAX_EV; k++) hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
-                hipEventRecord(ev[0], s); hipStreamWaitEvent(side, ev[0], 0);
+                if (!ev[0]) {
+                    for (int k = 0; k < MAX_EV; k++)
+                        if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { ev[0] = nullptr; return NRC_ERR_LAUNCH; }
+                }
+                if (hipEventRecord(ev[0], s) != hipSuccess || hipStreamWaitEvent(side, ev[0], 0) != hipSuccess) return NRC_ERR_LAUNCH;
             }
             if (rest.n > 0)
                 hipLaunchKernelGGL(k_grid_bwd, dim3((unsigned)nrc_cdiv(M, 256), rest.n), dim3(256), 0, side, x01, M, d_features, (int)d_features_pair_major, g,
@@ -2364,7 +2373,7 @@ static int grid_backward_impl(const float* x01, int64_t M, const float* d_featur
             hipLaunchKernelGGL(k_gb_accumulate, dim3((unsigned)nb), dim3(GBA_THREADS), GB_ENTRIES * 16, s, g, bc, M, (int)L.n_wg, (const uint32_t*)seg,
                                (const uint32_t*)wg_max, (const uint4*)records, L.rec_per_wg, grad_table, assign);
             NRC_STAGE(s, "k_gb_accumulate");
-            if (forked) { hipEventRecord(ev[1], side); hipStreamWaitEvent(s, ev[1], 0); }
+            if (forked && (hipEventRecord(ev[1], side) != hipSuccess || hipStreamWaitEvent(s, ev[1], 0) != hipSuccess)) return NRC_ERR_LAUNCH;
             NRC_LAUNCH_CHECK();
             return NRC_OK;
         }
