@@ -292,26 +292,44 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
 // words, stays, although a stream of 4-byte loads only reaches 4.1 TB/s against 6.2 for wider ones: profiles/r04_fetch_calibration.md.
 // Also built: the (P, 16, 3) block by LDS-DMA (global_load_lds_dwordx4) into a linear image, rows read with twelve 16-byte LDS reads -- colours
 // bit-identical, k_preprocess 91.9 us against 92.9: the width of the SH loads is not what the kernel waits for.)
+// (Round 5: the row / column of element k used to be k / row_len and the remainder -- an integer division by a runtime value is ~25 vector
+// instructions, 48 of them per thread and direction: more than the whole per-Gaussian arithmetic of these kernels.  k advances by the block size, so
+// (row, column) advance by its quotient and remainder: one division per call, four instructions per element.)
+template <bool TO_LDS>
+__device__ __forceinline__ void sh_block_copy(float* s_sh, int pitch, int col0, int len, int count, float* g, int nthreads) {
+    const int dq = nthreads / len, dr = nthreads - dq * len;
+    int r = (int)threadIdx.x / len, c = (int)threadIdx.x - r * len;
+    const int n = count * len;
+    int k = threadIdx.x;
+    // eight elements per trip, their loads issued together (the compiler does not batch them across the carried (row, column) by itself:
+    // one load per trip and a wait behind it ran at half the speed of the divisions it replaced)
+    for (; k + 7 * nthreads < n; k += 8 * nthreads) {
+        float v[8];
+        int off[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            off[u] = r * pitch + col0 + c;
+            v[u] = TO_LDS ? g[k + u * nthreads] : s_sh[off[u]];
+            r += dq; c += dr;
+            if (c >= len) { c -= len; r++; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { if (TO_LDS) s_sh[off[u]] = v[u]; else g[k + u * nthreads] = v[u]; }
+    }
+    for (; k < n; k += nthreads) {
+        if (TO_LDS) s_sh[r * pitch + col0 + c] = g[k]; else g[k] = s_sh[r * pitch + col0 + c];
+        r += dq; c += dr;
+        if (c >= len) { c -= len; r++; }
+    }
+}
 template <bool TO_LDS>
 __device__ __forceinline__ void sh_rows_copy(float* s_sh, int pitch, int row_len, int count, size_t first, float* sh, float* sh_rest, int nthreads) {
     if (!sh_rest) {
-        float* g = sh + first * row_len;
-        for (int k = threadIdx.x; k < count * row_len; k += nthreads) {
-            const int r = k / row_len;
-            if (TO_LDS) s_sh[r * pitch + (k - r * row_len)] = g[k]; else g[k] = s_sh[r * pitch + (k - r * row_len)];
-        }
+        sh_block_copy<TO_LDS>(s_sh, pitch, 0, row_len, count, sh + first * row_len, nthreads);
     } else {
-        float* g0 = sh + first * 3;
-        for (int k = threadIdx.x; k < count * 3; k += nthreads) {
-            const int r = k / 3;
-            if (TO_LDS) s_sh[r * pitch + (k - r * 3)] = g0[k]; else g0[k] = s_sh[r * pitch + (k - r * 3)];
-        }
+        sh_block_copy<TO_LDS>(s_sh, pitch, 0, 3, count, sh + first * 3, nthreads);
         const int rl = row_len - 3;
-        float* g1 = sh_rest + first * rl;
-        for (int k = threadIdx.x; k < count * rl; k += nthreads) {
-            const int r = k / rl;
-            if (TO_LDS) s_sh[r * pitch + 3 + (k - r * rl)] = g1[k]; else g1[k] = s_sh[r * pitch + 3 + (k - r * rl)];
-        }
+        if (rl > 0) sh_block_copy<TO_LDS>(s_sh, pitch, 3, rl, count, sh_rest + first * rl, nthreads);
     }
 }
 #define SPAN_DIM_MAX 256     // tile rows / columns the lane-private cursors cover (4 registers x 64 lanes): 4096 x 4096 pixels
