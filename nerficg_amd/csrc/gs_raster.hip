@@ -295,26 +295,29 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
 // (Round 5: the row / column of element k used to be k / row_len and the remainder -- an integer division by a runtime value is ~25 vector
 // instructions, 48 of them per thread and direction: more than the whole per-Gaussian arithmetic of these kernels.  k advances by the block size, so
 // (row, column) advance by its quotient and remainder: one division per call, four instructions per element.)
+#ifndef SHB_U
+#define SHB_U 16   // loads per trip: 8 / 12 / 16 -> k_preprocess 101 / 99 / 95-98 us at 1 M Gaussians (k_preprocess_bw indifferent)
+#endif
 template <bool TO_LDS>
 __device__ __forceinline__ void sh_block_copy(float* s_sh, int pitch, int col0, int len, int count, float* g, int nthreads) {
     const int dq = nthreads / len, dr = nthreads - dq * len;
     int r = (int)threadIdx.x / len, c = (int)threadIdx.x - r * len;
     const int n = count * len;
     int k = threadIdx.x;
-    // eight elements per trip, their loads issued together (the compiler does not batch them across the carried (row, column) by itself:
+    // SHB_U elements per trip, their loads issued together (the compiler does not batch them across the carried (row, column) by itself:
     // one load per trip and a wait behind it ran at half the speed of the divisions it replaced)
-    for (; k + 7 * nthreads < n; k += 8 * nthreads) {
-        float v[8];
-        int off[8];
+    for (; k + (SHB_U - 1) * nthreads < n; k += SHB_U * nthreads) {
+        float v[SHB_U];
+        int off[SHB_U];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < SHB_U; u++) {
             off[u] = r * pitch + col0 + c;
             v[u] = TO_LDS ? g[k + u * nthreads] : s_sh[off[u]];
             r += dq; c += dr;
             if (c >= len) { c -= len; r++; }
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) { if (TO_LDS) s_sh[off[u]] = v[u]; else g[k + u * nthreads] = v[u]; }
+        for (int u = 0; u < SHB_U; u++) { if (TO_LDS) s_sh[off[u]] = v[u]; else g[k + u * nthreads] = v[u]; }
     }
     for (; k < n; k += nthreads) {
         if (TO_LDS) s_sh[r * pitch + col0 + c] = g[k]; else g[k] = s_sh[r * pitch + col0 + c];
