@@ -111,6 +111,32 @@ def test_generator_draws_are_uniform_reproducible_and_independent_of_the_cut():
     assert u.numel() > 1500 and abs(float(u.mean()) - 0.5) < 0.03 and abs(float(u.var()) - 1 / 12) < 0.01
 
 
+def test_generator_is_philox4x32_10_bit_for_bit():
+    """The in-kernel generator of the fused iteration against tests/philox_ref.py (numpy Philox4x32-10, pinned on Random123's known-answer vectors in the
+    CPU suite): the background colour of iterations 0 .. 2 bit for bit, and every marched ray's jitter -- recovered from its first sample, which sits
+    on the lattice t0 + (jitter + k) dt -- within the float error of the march's additions."""
+    from tests import philox_ref
+    cam, pool = _pool(size=160)      # 25 600 rays: three batches of 2 048 stay inside the order
+    model, renderer, _ = _train_pair(seed=2)
+    n, seed, offset = 2048, 0x1234_5678_9abc, 4096
+    order = torch.randperm(pool['origin'].shape[0], generator=torch.Generator().manual_seed(3)).to(DEV)   # every batch sees the object
+    it, _, _ = _fused(model, renderer, cam, pool, n, 600_000, prefetch=False, graph=False, order=order, seed=seed, ray_offset=offset)
+    dt = 3 ** 0.5 / renderer.MAX_SAMPLES
+    checked = 0
+    for iteration in range(3):
+        it._march(0, it._state_tensors(), (False, False, False))
+        b = it.sets[0]
+        np.testing.assert_array_equal(b.bg.cpu().numpy(), philox_ref.background(seed, iteration))
+        want = philox_ref.u01(philox_ref.train_draw(seed, iteration, 0, np.arange(offset, offset + n, dtype=np.uint64))[0])
+        hit = (b.rays_a[:, 2] > 0).cpu().numpy()
+        first = ((b.ts[b.rays_a[:, 1].clamp(min=0)] - b.hits_t[:, 0]) / dt).cpu().numpy()
+        resid = (first - want + 0.5) % 1.0 - 0.5          # distance to the lattice point, wrap-aware
+        assert hit.sum() > 300, hit.sum()
+        assert np.abs(resid[hit]).max() < 2e-3, np.abs(resid[hit]).max()   # measured 1.1e-3: ~600 additions of dt in f32 behind the first candidate
+        checked += int(hit.sum())
+    assert checked > 1000
+
+
 def test_fused_loss_kernel_equals_the_chain_it_replaces():
     """nrc_ngp_train_loss against composite_over_background + scaled_mse_loss + their autograd backward on the same samples."""
     from nerficg_amd import _lib

@@ -337,3 +337,13 @@ def test_threaded_march_and_compositor_equal_the_single_thread_run():
         for other in runs[1:]:
             for a, b in zip(runs[0], other):
                 np.testing.assert_array_equal(a, b)
+
+
+def test_philox_reference_reproduces_the_random123_known_answers():
+    """tests/philox_ref.py (the checker of the fused iteration's in-kernel generator) against the known-answer vectors of Random123 for philox4x32, 10 rounds."""
+    from tests import philox_ref
+    for ctr, key, want in philox_ref.KAT:
+        got = philox_ref.philox4x32_10([np.array([c]) for c in ctr], [np.array([k]) for k in key])
+        assert tuple(int(g[0]) for g in got) == want
+    u = philox_ref.u01(np.array([0, 0xff, 0x100, 0xffffffff], dtype=np.uint32))
+    assert u[0] == 0.0 and u[1] == 0.0 and u[2] == np.float32(2.0 ** -24) and u[3] < 1.0 and u[3] == np.float32(1.0 - 2.0 ** -24)
