@@ -196,6 +196,89 @@ def _op_by_op(batches, seed, cam, pool, weight_decay=0.5e-6):
     return losses, marched, [p.detach().clone() for p in model.parameters()], model
 
 
+def test_fused_iteration_equals_one_iteration_of_the_cpu_oracle():
+    """ONE training iteration, end to end, restated on the CPU oracle (oracle/*.c): march -> hash-grid encode -> density MLP -> TruncExp -> [SH | h] ->
+    colour MLP -> compositing -> pixel over background -> MSE -> compositing backward -> both MLP backwards -> hash-grid backward, on the batch, jitter
+    and background the fused iteration used.  Compared: the marched samples (bit for bit), the loss, and the three gradient blocks the fused iteration
+    hands to Adam (colour MLP, density MLP, hash table) -- tolerances ten to thirty times the measured differences (fp16 intermediates are restated by
+    the oracle; what is left is MFMA summation order and float atomics on the coarse levels)."""
+    import oracle
+    from tests.test_gpu_render_parity import make_model
+    from nerficg_amd.instant_ngp import InstantNGPRenderer
+    cam, pool = _pool(size=96)
+    model = make_model(seed=7, table_amp=1.0)        # a table with structure: densities and colours vary over the scene
+    renderer = InstantNGPRenderer(model)
+    n, S = 384, 128.0
+    g = torch.Generator(device=DEV).manual_seed(2)
+    ids = torch.randint(0, pool['origin'].shape[0], (n,), device=DEV, generator=g)
+    bg, noise = torch.rand(3, device=DEV, generator=g), torch.rand(n, device=DEV, generator=g)
+    dn, cn = model.encoding_xyz, model.color_mlp_with_encoding
+    p_d = oracle.round_half(dn.params.detach().cpu().numpy())
+    p_c = oracle.round_half(cn.params.detach().cpu().numpy())
+    n_mlp_d = dn.n_mlp_params
+    it, opt, scaler = _fused(model, renderer, cam, pool, n, 120_000, prefetch=False, graph=False, fused_step=False)
+    out = it(ids=ids, bg=bg, noise=noise)
+    b = it.sets[0]
+    m = int(b.counter[0])
+    assert 20_000 < m <= 120_000 and int(out['sample_overflow']) == 0
+    # ---- march (the clipped rays are the kernel's: nrc_ngp_clip_rays is compared with the oracle in test_gpu_ngp_parity.py)
+    cpu = lambda t: t.detach().cpu().numpy()
+    r = renderer
+    rays_a, xyzs, dirs, deltas, ts, counter = oracle.raymarching_train(cpu(b.rays_o), cpu(b.rays_d), cpu(b.hits_t), cpu(model.occupancy_bitfield), model.cascades,
+                                                                       float(model.SCALE), 0.0, cpu(noise), model.RESOLUTION, r.MAX_SAMPLES)
+    assert int(counter[0]) == m
+    np.testing.assert_array_equal(cpu(b.rays_a), rays_a)
+    for name, want in (('xyzs', xyzs), ('dirs', dirs), ('deltas', deltas), ('ts', ts)):
+        np.testing.assert_array_equal(cpu(getattr(b, name))[:m], want[:m], err_msg=name)
+    # ---- query
+    mn, sz = (cpu(t) for t in r._box())
+    x01 = (xyzs[:m] - mn) / sz          # (x - xyz_min) / xyz_size, Renderer.py:50
+    grid = dict(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=float(dn.grid_cfg['per_level_scale']))
+    table = p_d[n_mlp_d:].reshape(-1, 2)
+    enc = oracle.grid_encode_fw(x01.astype(np.float32), table, **grid)
+    h, acts_d = oracle.mlp_fw(enc, p_d[:n_mlp_d], n_hidden=1, out_act=0, want_acts=True)
+    h16 = oracle.round_half(h)
+    sigmas = np.exp(h16[:, 0])
+    d01 = oracle.round_half(dirs[:m] * np.float32(0.5) + np.float32(0.5))
+    cin = np.concatenate([oracle.sh4_encode(d01), h16], 1)
+    rgb_out, acts_c = oracle.mlp_fw(cin, p_c, n_hidden=2, out_act=1, want_acts=True)
+    rgbs = oracle.round_half(rgb_out[:, :3])
+    # ---- compositing, pixel, loss
+    T_thr = it.T_THRESHOLD
+    _, opacity, depth, rgb, ws = oracle.composite_train_fw(sigmas, rgbs, deltas[:m], ts[:m], rays_a, T_thr)
+    bg_np, target = cpu(bg), cpu(pool['rgb'][ids])
+    pixel = rgb + (1.0 - opacity)[:, None] * bg_np[None]
+    loss = float(((pixel - target) ** 2).mean())
+    assert abs(float(out['loss']) - loss) <= 1e-5 * loss, (float(out['loss']), loss)      # measured 3e-7
+    # ---- backward: d(S * loss) / d pixel, through the compositor, the two networks and the encoding
+    d_pix = (2.0 * S / (3 * n)) * (pixel - target)
+    ds, dr = oracle.composite_train_bw(-(d_pix * bg_np[None]).sum(1), np.zeros(n, np.float32), d_pix.astype(np.float32), np.zeros(m, np.float32), sigmas, rgbs, ws,
+                                       deltas[:m], ts[:m], rays_a, opacity, depth, rgb, T_thr)
+    g_pad = np.zeros((m, 16), np.float32)
+    g_pad[:, :3] = dr * 128.0                                  # tiny-cuda-nn's internal loss scale, applied before the fp16 rounding of dZ
+    dW_c, d_cin = oracle.mlp_bw(cin, p_c, rgb_out, acts_c, g_pad, n_hidden=2, out_act=1)
+    d_h = d_cin[:, 16:] / 128.0
+    d_h[:, 0] += ds * np.exp(np.clip(h16[:, 0], -15.0, 15.0))  # TruncExp backward (custom_functions.py:207-210)
+    d_h16 = oracle.round_half(d_h)
+    dW_d, d_enc = oracle.mlp_bw(enc, p_d[:n_mlp_d], h, acts_d, d_h16 * 128.0, n_hidden=1, out_act=0)
+    g_table = oracle.grid_encode_bw(x01.astype(np.float32), d_enc / 128.0, table.shape[0], **grid)
+    # ---- the fused iteration's gradient buffers (scaled by the GradScaler's S; cleared regions are exact zeros)
+    got_c, got_d = cpu(it.gc) / S, cpu(it.gd) / S
+    dW_c, dW_d = dW_c / (128.0 * S), dW_d / (128.0 * S)
+    g_table = g_table / S
+    # measured on MI355X: largest error 3e-5 (colour MLP), 7e-6 (density MLP), 6e-5 (table) of each block's largest entry
+    np.testing.assert_allclose(got_c, dW_c, rtol=2e-2, atol=5e-4 * np.abs(dW_c).max())
+    np.testing.assert_allclose(got_d[:n_mlp_d], dW_d, rtol=2e-2, atol=5e-4 * np.abs(dW_d).max())
+    got_t = got_d[n_mlp_d:].reshape(-1, 2)
+    np.testing.assert_allclose(got_t, g_table, rtol=2e-2, atol=1e-3 * np.abs(g_table).max())
+    assert np.count_nonzero(g_table) > 10_000 and np.mean((got_t == 0) != (g_table == 0)) < 1e-3
+    print('fused iteration vs oracle iteration: samples', m, 'loss', float(out['loss']), loss, 'max |dW_c err| / max', np.abs(got_c - dW_c).max() / np.abs(dW_c).max(),
+          'dW_d', np.abs(got_d[:n_mlp_d] - dW_d).max() / np.abs(dW_d).max(), 'table', np.abs(got_t - g_table).max() / np.abs(g_table).max())
+    # correlation: a scale error or a missing factor cannot hide behind the tolerances
+    for a_, b_ in ((got_c, dW_c), (got_d[:n_mlp_d], dW_d), (got_t.ravel(), g_table.ravel())):
+        assert abs(float(np.dot(a_, b_) / np.dot(b_, b_)) - 1.0) < 2e-3
+
+
 @pytest.mark.parametrize('graph,fused_step', [(False, True), (True, True), (False, False), (True, False)])
 def test_fused_iterations_follow_the_op_by_op_iterations(graph, fused_step):
     from tests.noise import assert_within_run_to_run_noise
