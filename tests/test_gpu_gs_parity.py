@@ -118,6 +118,40 @@ def test_backward_matches_oracle(n, w, h, deg):
         assert err.mean() <= 1e-4 * scale + 1e-7, (name, err.mean(), scale)
 
 
+def test_one_optimisation_step_gradients_equal_the_oracle_chain():
+    """The 3DGS training step as ONE statement on the CPU oracle: rasterize (oracle.gs_forward) -> 0.8 L1 + 0.2 (1 - SSIM) against a target
+    (oracle.ssim_forward / ssim_backward, GaussianSplatting/Loss.py:11-23) -> rasterizer backward (oracle.gs_backward) -> the gradients FusedAdam
+    receives, against the product path render -> photometric_loss -> .backward() on the same Gaussians and target."""
+    from nerficg_amd.fused_ssim import photometric_loss
+    n, w, h = 4000, 144, 96
+    sc = scenes.gs_random_scene(n, seed=17, extent=1.0, log_scale_mean=np.log(0.06), sh_degree=3)
+    cam = scenes.gs_camera(w, h, scenes.orbit_pose(1.1, 0.3, 3.0))
+    bg = [0.0, 0.0, 0.0]
+    target = np.random.default_rng(4).random((3, h, w)).astype(np.float32)
+    color, radii, t, m2d = _run(sc, cam, bg, requires_grad=True)
+    loss = photometric_loss(color[None], T(target)[None], 0.8, 0.2)
+    loss.backward()
+    o_color, o_radii, st = _oracle(sc, cam, bg)
+    np.testing.assert_array_equal(radii.cpu().numpy(), o_radii)
+    img = o_color[None].astype(np.float32)
+    m, d1, d2, d3 = oracle.ssim_forward(img, target[None])
+    count = img.size
+    ref_loss = 0.8 * np.abs(img.astype(np.float64) - target[None]).mean() + 0.2 * (1.0 - m.astype(np.float64).mean())
+    assert abs(float(loss.detach()) - ref_loss) < 5e-6, (float(loss.detach()), ref_loss)
+    d_img = oracle.ssim_backward(img, target[None], np.full(img.shape, -0.2 / count, np.float32), d1, d2, d3) + 0.8 / count * np.sign(img - target[None])
+    ref = oracle.gs_backward(st, d_img[0].astype(np.float32))
+    for name, got in (('mean3D', t['means3D'].grad), ('mean2D', m2d.grad), ('opacity', t['opacities'].grad), ('scale', t['scales'].grad), ('rot', t['rotations'].grad),
+                      ('sh', t['shs'].grad)):
+        r = ref[name]
+        gnp = got.cpu().numpy().reshape(r.shape)
+        scale = np.abs(r).max()
+        assert scale > 0, name
+        err = np.abs(gnp - r)
+        assert err.max() <= 2e-3 * scale + 1e-9, (name, err.max(), scale)
+        assert err.mean() <= 1e-4 * scale + 1e-10, (name, err.mean(), scale)
+        assert abs(float(np.vdot(gnp, r) / np.vdot(r, r)) - 1.0) < 1e-3, name      # no missing factor
+
+
 def test_precomputed_colors_and_covariances_path():
     from nerficg_amd.diff_gaussian_rasterization import GaussianRasterizer
     n = 2000
