@@ -137,6 +137,35 @@ def test_generator_is_philox4x32_10_bit_for_bit():
     assert checked > 1000
 
 
+def test_two_rank_slices_of_a_batch_average_to_the_whole_batch_gradient():
+    """Data parallelism of the fused iteration without a process group: 'rank' r marches rows [r n/2, (r + 1) n/2) of the global batch (its slice of the
+    order, ray_offset = r n/2, the same seed -> the same background and, per GLOBAL ray index, the same jitter).  The loss is a mean over rays, so the
+    average of the two ranks' gradient buffers -- what parallel.allreduce_flat(average=True) leaves on every rank -- must be the gradient of one
+    rank marching the whole batch; the marched sample counts add up exactly."""
+    cam, pool = _pool(size=96)
+    n = 1024
+    order = torch.randperm(pool['origin'].shape[0], generator=torch.Generator().manual_seed(8)).to(DEV)
+
+    def grads(n_rays, order_r, offset):
+        model, renderer, _ = _train_pair(seed=4)
+        it, _, _ = _fused(model, renderer, cam, pool, n_rays, 300_000, prefetch=False, graph=False, fused_step=False, order=order_r, seed=31, ray_offset=offset)
+        out = it()
+        return it.grads.detach().clone(), int(out['rm_samples']), float(out['loss']), it.sets[0].bg.clone()
+
+    g_all, m_all, loss_all, bg_all = grads(n, order, 0)
+    g_again, _, _, _ = grads(n, order, 0)
+    parts = [grads(n // 2, order[r * n // 2:], r * n // 2) for r in range(2)]
+    assert parts[0][1] + parts[1][1] == m_all and m_all > 50_000
+    assert torch.equal(parts[0][3], bg_all) and torch.equal(parts[1][3], bg_all)
+    np.testing.assert_allclose(0.5 * (parts[0][2] + parts[1][2]), loss_all, rtol=1e-5)
+    g_avg = 0.5 * (parts[0][0] + parts[1][0])
+    scale = float(g_all.abs().max())
+    noise = float((g_all - g_again).abs().max())                      # float atomics on the coarse levels: two runs of ONE code differ by this much
+    err = float((g_avg - g_all).abs().max())
+    assert err <= max(4 * noise, 2e-4 * scale), (err, noise, scale)
+    assert abs(float(torch.dot(g_avg, g_all) / torch.dot(g_all, g_all)) - 1.0) < 1e-4
+
+
 def test_fused_loss_kernel_equals_the_chain_it_replaces():
     """nrc_ngp_train_loss against composite_over_background + scaled_mse_loss + their autograd backward on the same samples."""
     from nerficg_amd import _lib
