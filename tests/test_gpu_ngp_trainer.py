@@ -166,6 +166,41 @@ def test_two_rank_slices_of_a_batch_average_to_the_whole_batch_gradient():
     assert abs(float(torch.dot(g_avg, g_all) / torch.dot(g_all, g_all)) - 1.0) < 1e-4
 
 
+@pytest.mark.parametrize('case', ['empty_grid', 'one_ray', 'tiny_capacity'])
+@pytest.mark.parametrize('fused_step', [True, False])
+def test_edge_batches_run_clean(case, fused_step):
+    """Batches a trainer meets at the edges: an occupancy grid without a set bit (no sample at all: the pixels are the background, the hash table gets
+    no gradient, the MLP weights move by their weight decay alone), a batch of ONE ray, and a sample capacity a tenth of what the batch marches (the
+    cut is reported, nothing is written out of bounds, the step is taken).  Four iterations each, marching ahead."""
+    cam, pool = _pool(size=96)
+    model, renderer, _ = _train_pair(seed=4)
+    n, cap = (1 if case == 'one_ray' else 512), (4096 if case == 'tiny_capacity' else 100_000)
+    if case == 'empty_grid':
+        with torch.no_grad():
+            model.occupancy_bitfield.zero_()
+    order = torch.randperm(pool['origin'].shape[0], generator=torch.Generator().manual_seed(8)).to(DEV)
+    it, opt, scaler = _fused(model, renderer, cam, pool, n, cap, prefetch=True, graph=False, fused_step=fused_step, order=order, seed=1)
+    dn = model.encoding_xyz
+    table0 = dn.params.detach()[dn.n_mlp_params:].clone()
+    mlp0 = dn.params.detach()[:dn.n_mlp_params].clone()
+    outs = [it() for _ in range(4)]
+    torch.cuda.synchronize()
+    o = outs[-1]
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters()) and bool(torch.isfinite(o['loss']))
+    assert opt.effective_step(opt.param_groups[0]) == 4 and float(scaler.get_scale()) == 128.0
+    if case == 'empty_grid':
+        assert int(o['rm_samples']) == 0 and int(o['sample_overflow']) == 0
+        assert torch.equal(dn.params.detach()[dn.n_mlp_params:], table0)                       # no sample, no table gradient, no table update
+        assert float((dn.params.detach()[:dn.n_mlp_params] - mlp0).abs().max()) > 0             # weight decay alone moves the MLP weights
+        ids = order[3 * n:4 * n]                                                                 # the last batch: its pixels are the background colour
+        want = float(((o['bg'][None] - pool['rgb'][ids]) ** 2).mean())
+        np.testing.assert_allclose(float(o['loss']), want, rtol=1e-5)
+    elif case == 'one_ray':
+        assert 0 <= int(o['rm_samples']) <= renderer.MAX_SAMPLES and int(o['sample_overflow']) == 0
+    else:
+        assert int(o['rm_samples']) > 10 * cap // 2 and int(o['sample_overflow']) == int(o['rm_samples']) - cap
+
+
 def test_fused_loss_kernel_equals_the_chain_it_replaces():
     """nrc_ngp_train_loss against composite_over_background + scaled_mse_loss + their autograd backward on the same samples."""
     from nerficg_amd import _lib
