@@ -343,7 +343,9 @@ __device__ __forceinline__ void sh_rows_copy(float* s_sh, int pitch, int row_len
 #define RS_HDR_WORDS (1024 + 256 + 8)
 // Workgroup = 128 Gaussians; their SH coefficients (one contiguous 128 x 3M float block) are staged through LDS with coalesced
 // loads -- a lane walking its own 192-byte row touches 48 cache lines per wave instruction (same staging as k_preprocess_bw).
-#define PRE_BLOCK 128
+#ifndef PRE_BLOCK
+#define PRE_BLOCK 128   // measured 64 / 128 / 256 in round 5: see LABBOOK A.4b
+#endif
 #ifndef PRE_MAXM
 #define PRE_MAXM 16
 #endif
@@ -1844,7 +1846,9 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
 // block of shs / dL_dsh: it is staged through LDS with coalesced transfers (a lane reading or writing its own 192-byte row
 // touches 48 different cache lines per wave instruction; measured 1.86 GB of HBM traffic for 0.5 GB of data).  Every output
 // row is written by this kernel, zeros for culled Gaussians, so the caller does not clear 300 B per Gaussian beforehand.
+#ifndef PBW_BLOCK
 #define PBW_BLOCK 128
+#endif
 #ifndef PBW_MAXM
 #define PBW_MAXM 16
 #endif
