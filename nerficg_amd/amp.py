@@ -29,6 +29,27 @@ def _takes_grad_scaler(optimizer_type) -> bool:
 
 
 class GradScaler(torch.amp.GradScaler):
+    """`single_optimizer` (keyword, default True): the scaler serves ONE optimizer per iteration, as the reference's trainers do (Trainer.py:44,89-93), so the
+    first step() of an iteration may apply the scale rule on the device together with the Adam update (nrc_amp_adam_step).  A scaler shared by several
+    optimizers cannot be recognised at that first step() -- torch's per-optimizer table is rebuilt by every update() -- so such setups say
+    `single_optimizer=False` and take torch's general path; stepping or unscaling a SECOND optimizer behind a fused step raises instead of unscaling with the
+    already-updated scale."""
+
+    def __init__(self, *args, single_optimizer: bool = True, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self._single_optimizer = bool(single_optimizer)
+        self._fused_update_done = False
+        self._fused_optimizer_id = None
+
+    def _refuse_second_optimizer(self, optimizer, what: str) -> None:
+        if self._fused_update_done and id(optimizer) != self._fused_optimizer_id:
+            raise RuntimeError(f'nerficg_amd.amp.GradScaler.{what}: another optimizer has already been stepped in this iteration through the fused step + update '
+                               '(the scale rule has been applied on the device); a scaler shared by several optimizers must be built with single_optimizer=False')
+
+    def unscale_(self, optimizer) -> None:
+        self._refuse_second_optimizer(optimizer, 'unscale_')
+        return super().unscale_(optimizer)
+
     def scale_tensor(self, device) -> torch.Tensor:
         """The scale as the device scalar `scale()` multiplies by (created on first use, as `scale()` does): for callers that fold the
         multiplication into their own loss kernel (nerficg_amd.ngp.scaled_mse_loss) instead of calling scale(loss)."""
@@ -43,6 +64,7 @@ class GradScaler(torch.amp.GradScaler):
         torch builds `found_inf` as `sum([...])` (0 + t: an add) and `grad_scale` as `scale * 1` (a multiplication) on every call; with one
         device and no scale the caller has put on the optimizer these are the tensors themselves.  Everything else defers to torch."""
         from torch.amp.grad_scaler import OptState
+        self._refuse_second_optimizer(optimizer, 'step')
         if (not self._enabled or 'closure' in kwargs or not getattr(optimizer, '_step_supports_amp_scaling', False)
                 or hasattr(optimizer, 'grad_scale') or _takes_grad_scaler(type(optimizer))):
             return super().step(optimizer, *args, **kwargs)
@@ -51,12 +73,13 @@ class GradScaler(torch.amp.GradScaler):
         if state['stage'] is OptState.STEPPED:
             raise RuntimeError('step() has already been called since the last update().')
         if (state['stage'] is OptState.READY and type(self)._check_inf_per_device is GradScaler._check_inf_per_device and not args and not kwargs
-                and hasattr(optimizer, '_amp_fused_step') and len(self._per_optimizer_states) == 1):
+                and hasattr(optimizer, '_amp_fused_step') and self._single_optimizer and len(self._per_optimizer_states) == 1):
             # the whole of step() + update() as one library call: check, step counter, scale rule, Adam (nrc_amp_adam_step).  update() then has
-            # nothing left to launch.  (Subclasses that hook the check -- the data-parallel scaler's agreement -- and multi-optimizer setups take the general path.)
+            # nothing left to launch.  (Subclasses that hook the check -- the data-parallel scaler's agreement -- and scalers built with single_optimizer=False take the general path.)
             if optimizer._amp_fused_step(self._scale, self._growth_tracker, self._growth_factor, self._backoff_factor, self._growth_interval):
                 state['stage'] = OptState.STEPPED
                 self._fused_update_done = True
+                self._fused_optimizer_id = id(optimizer)
                 return None
         if state['stage'] is OptState.READY:
             self._check_inf_per_device(optimizer)
@@ -77,6 +100,7 @@ class GradScaler(torch.amp.GradScaler):
         bookkeeping is reset.  An explicit new_scale is honoured as in torch."""
         if getattr(self, '_fused_update_done', False):
             self._fused_update_done = False
+            self._fused_optimizer_id = None
             if new_scale is None:
                 from collections import defaultdict
                 from torch.amp.grad_scaler import _refresh_per_optimizer_state

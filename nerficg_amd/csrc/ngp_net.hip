@@ -1763,8 +1763,10 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, i
 #define OWN_THREADS 1024
 struct OwnedCfg { int n_levels; int level[NRC_MAX_LEVELS]; int unit0[NRC_MAX_LEVELS + 1]; };
 __global__ void __launch_bounds__(OWN_THREADS) k_grid_bwd_owned(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, GridCfg g,
-                                                                OwnedCfg oc, float* __restrict__ grad_table) {
+                                                                OwnedCfg oc, float* __restrict__ grad_table, const int32_t* __restrict__ m_live) {
     extern __shared__ float own_acc[];  // [OWN_ENTRIES][2]
+    const int64_t M_cap = M;            // d_feat is pair-major over the row CAPACITY; only the live rows hold samples
+    if (m_live) M = min(M, (int64_t)max(*m_live, 0));
     int li = 0;
     while (li + 1 < oc.n_levels && (int)blockIdx.x >= oc.unit0[li + 1]) li++;
     const int level = oc.level[li];
@@ -1775,7 +1777,7 @@ __global__ void __launch_bounds__(OWN_THREADS) k_grid_bwd_owned(const float* __r
     __syncthreads();
     const float scale = g.scale[level];
     const uint32_t res = g.res[level], size = g.size[level], off = g.offset[level];
-    const float2* gfp = reinterpret_cast<const float2*>(d_feat) + (int64_t)level * M;
+    const float2* gfp = reinterpret_cast<const float2*>(d_feat) + (int64_t)level * M_cap;
     for (int64_t i = threadIdx.x; i < M; i += OWN_THREADS) {
         const float2 gf = gfp[i];
         if (gf.x == 0.f && gf.y == 0.f) continue;
@@ -1809,8 +1811,10 @@ __global__ void __launch_bounds__(OWN_THREADS) k_grid_bwd_owned(const float* __r
 // densely (all lanes busy) with the full corner arithmetic.  ~70 instead of ~140 instructions per sample and slice.
 #define OWN_Q 128  // queue entries per wave
 __global__ void __launch_bounds__(OWN_THREADS) k_grid_bwd_owned_q(const float* __restrict__ x, int64_t M, const float* __restrict__ d_feat, GridCfg g,
-                                                                  OwnedCfg oc, float* __restrict__ grad_table) {
+                                                                  OwnedCfg oc, float* __restrict__ grad_table, const int32_t* __restrict__ m_live) {
     extern __shared__ float own_acc[];  // [OWN_ENTRIES][2] then the queues
+    const int64_t M_cap = M;            // d_feat is pair-major over the row CAPACITY; only the live rows hold samples
+    if (m_live) M = min(M, (int64_t)max(*m_live, 0));
     uint32_t* queue = reinterpret_cast<uint32_t*>(own_acc + 2 * OWN_ENTRIES) + (threadIdx.x >> 6) * OWN_Q;
     int li = 0;
     while (li + 1 < oc.n_levels && (int)blockIdx.x >= oc.unit0[li + 1]) li++;
@@ -1822,7 +1826,7 @@ __global__ void __launch_bounds__(OWN_THREADS) k_grid_bwd_owned_q(const float* _
     __syncthreads();
     const float scale = g.scale[level];
     const uint32_t res = g.res[level], size = g.size[level], off = g.offset[level], mask = size - 1u;
-    const float2* gfp = reinterpret_cast<const float2*>(d_feat) + (int64_t)level * M;
+    const float2* gfp = reinterpret_cast<const float2*>(d_feat) + (int64_t)level * M_cap;
     const int lane = threadIdx.x & 63;
     auto scatter = [&](int64_t i) {  // all eight corners of sample i, the ones inside the slice are accumulated
         const float2 gf = gfp[i];
@@ -1848,7 +1852,7 @@ __global__ void __launch_bounds__(OWN_THREADS) k_grid_bwd_owned_q(const float* _
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             const int64_t i = i0 + (int64_t)u * OWN_THREADS;
-            const int64_t ic = i < M ? i : M - 1;
+            const int64_t ic = i < M ? i : max(M - 1, (int64_t)0);
             gfv[u] = gfp[ic];
             yv[u] = x[3 * ic + 1]; zv[u] = x[3 * ic + 2];
         }
@@ -2404,7 +2408,7 @@ static int grid_backward_impl(const float* x01, int64_t M, const float* d_featur
     }
     if (ll.n > 0)
         hipLaunchKernelGGL(k_grid_bwd, dim3((unsigned)nrc_cdiv(M, 256), ll.n), dim3(256), 0, s, x01, M, d_features, (int)d_features_pair_major, g,
-                           (int)n_levels, ll, grad_table);
+                           (int)n_levels, ll, grad_table, m_live);   // every path walks the LIVE rows only (rows behind them are uninitialised)
     if (oc.n_levels > 0) {
         static const hipError_t attr = hipFuncSetAttribute((const void*)k_grid_bwd_owned, hipFuncAttributeMaxDynamicSharedMemorySize, OWN_ENTRIES * 8);
         static const hipError_t attr_q = hipFuncSetAttribute((const void*)k_grid_bwd_owned_q, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2415,10 +2419,10 @@ static int grid_backward_impl(const float* x01, int64_t M, const float* d_featur
         static const bool allow_q = [] { const char* e = getenv("NRC_GRID_BWD_SPARSE"); return !(e && e[0] == '0'); }();
         if (sparse_ok && allow_q)
             hipLaunchKernelGGL(k_grid_bwd_owned_q, dim3((unsigned)oc.unit0[oc.n_levels]), dim3(OWN_THREADS), OWN_ENTRIES * 8 + (OWN_THREADS / 64) * OWN_Q * 4,
-                               s, x01, M, d_features, g, oc, grad_table);
+                               s, x01, M, d_features, g, oc, grad_table, m_live);
         else
             hipLaunchKernelGGL(k_grid_bwd_owned, dim3((unsigned)oc.unit0[oc.n_levels]), dim3(OWN_THREADS), OWN_ENTRIES * 8, s, x01, M, d_features, g, oc,
-                               grad_table);
+                               grad_table, m_live);
     }
     NRC_LAUNCH_CHECK();
     return NRC_OK;

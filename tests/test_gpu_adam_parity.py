@@ -185,3 +185,39 @@ def test_load_state_dict_keeps_the_live_moment_tensors():
         assert (opt.state[p]['exp_avg'].data_ptr(), opt.state[p]['exp_avg_sq'].data_ptr()) == ptrs
         assert torch.equal(opt.state[p]['exp_avg'], want)
         assert opt.effective_step(opt.param_groups[0]) == 3
+
+
+def test_scaler_shared_by_two_optimizers_follows_torch_and_the_fused_step_refuses_a_second_one():
+    """nerficg_amd.amp.GradScaler(single_optimizer=False) around TWO FusedAdam optimizers: a clean step, an overflow in the second optimizer's gradients (both steps of
+    that iteration are skipped?  no -- torch skips per optimizer and backs the scale off once), then growth -- the same parameters, scale and step counts as
+    torch.amp.GradScaler.  The default scaler takes the fused step + update for the first optimizer of an iteration and raises when a second one follows."""
+    from nerficg_amd.amp import GradScaler
+    from nerficg_amd.apex_optimizers import FusedAdam
+    rng = np.random.default_rng(11)
+    a0, b0 = rng.normal(size=3000).astype(np.float32), rng.normal(size=777).astype(np.float32)
+    xs = [(rng.normal(size=3000).astype(np.float32), rng.normal(size=777).astype(np.float32)) for _ in range(4)]
+
+    def run(make_scaler):
+        pa, pb = torch.nn.Parameter(torch.from_numpy(a0.copy()).to(DEV)), torch.nn.Parameter(torch.from_numpy(b0.copy()).to(DEV))
+        oa = FusedAdam([pa], lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
+        ob = FusedAdam([pb], lr=3e-3, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False)
+        scaler = make_scaler()
+        scales = []
+        for it, (xa, xb) in enumerate(xs):
+            loss = (pa * torch.from_numpy(xa).to(DEV)).sum() + (pb * torch.from_numpy(xb).to(DEV)).sum()
+            scaler.scale(loss).backward()
+            if it == 1:
+                pb.grad[5] = float('inf')
+            scaler.step(oa); scaler.step(ob); scaler.update()
+            oa.zero_grad(); ob.zero_grad()
+            scales.append(float(scaler.get_scale()))
+        return pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), scales, oa.effective_step(oa.param_groups[0]), ob.effective_step(ob.param_groups[0])
+
+    ref = run(lambda: torch.amp.GradScaler(init_scale=128.0, growth_interval=2))
+    got = run(lambda: GradScaler(init_scale=128.0, growth_interval=2, single_optimizer=False))
+    assert got[2] == ref[2] == [128.0, 64.0, 64.0, 128.0]
+    assert got[3:] == ref[3:] == (4, 3)
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+    with pytest.raises(RuntimeError, match='single_optimizer=False'):
+        run(lambda: GradScaler(init_scale=128.0, growth_interval=2))

@@ -343,3 +343,31 @@ def test_grid_backward_above_one_round_of_split_workgroups(m):
     assert float((a - plain).abs().max()) <= 2e-5 * scale + 1e-12, float((a - plain).abs().max()) / scale
     assert float((other[:h0] - plain[:h0]).abs().max()) <= 2e-5 * scale + 1e-12
     assert int((a[h0:] != 0).sum()) > m
+
+
+@pytest.mark.parametrize('cap,live_rows,workspace', [(8192, 3000, True), (8192, 3000, False), (40_000, 17_001, False), (40_000, 0, False)])
+def test_grid_backward_live_count_is_honoured_on_every_path(cap, live_rows, workspace):
+    """nrc_grid_backward_live's contract -- only the first n_samples_dev[0] rows are read -- on the paths that are NOT the bucketed one: a capacity
+    below 16 384 rows (run-aggregated atomics for every level) and a launch without the workspace (atomics + the slice owners' sparse scan).  The
+    rows behind the live count hold NaN positions and huge gradients: the table gradient must equal the one of the live rows alone."""
+    from nerficg_amd import _lib
+    lib = _lib.load()
+    total, _, _, _ = oracle.grid_layout(n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=PLS)
+    gen = torch.Generator(device=DEV).manual_seed(cap + live_rows)
+    x = torch.rand(cap, 3, device=DEV, generator=gen)
+    d = torch.randn(16, cap, 2, device=DEV, generator=gen) * 1e-3
+    x[live_rows:] = float('nan')
+    d[:, live_rows:] = 3e38
+    x, d = x.contiguous(), d.contiguous()
+    live = torch.tensor([live_rows, 0], dtype=torch.int32, device=DEV)
+    ws = torch.empty(int(lib.nrc_grid_backward_ws_bytes(cap, 16, 19, 16, PLS)), dtype=torch.uint8, device=DEV) if workspace else None
+    g = torch.zeros(total, 2, device=DEV)
+    _lib.check(lib.nrc_grid_backward_live(_lib.ptr(x), cap, _lib.ptr(d), 1, 16, 19, 16, PLS, _lib.ptr(g), _lib.ptr(ws), _lib.ptr(live), _lib.stream_of(g)), 'grid_backward_live')
+    ref = torch.zeros(total, 2, device=DEV)
+    if live_rows:
+        xr, dr = x[:live_rows].contiguous(), d[:, :live_rows].contiguous()
+        _lib.check(lib.nrc_grid_backward(_lib.ptr(xr), live_rows, _lib.ptr(dr), 1, 16, 19, 16, PLS, _lib.ptr(ref), None, _lib.stream_of(ref)), 'grid_backward')
+    assert bool(torch.isfinite(g).all())
+    scale = float(ref.abs().max()) if live_rows else 1.0
+    assert float((g - ref).abs().max()) <= 2e-5 * scale + 1e-12
+    assert live_rows == 0 or int((g != 0).sum()) > live_rows
