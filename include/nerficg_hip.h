@@ -34,7 +34,7 @@ enum {
  * nrc_ngp_query_samples gained arena_tile_off / arena_rows, nrc_ngp_composite_image arena_rows, nrc_ngp_render_write accepts ts = NULL;
  * nrc_photometric_loss_* are new; 5 = round 5: group 13 (the fused InstantNGP training iteration) is new; nrc_ngp_train_query_forward gained
  * n_samples_dev (NULL = every row, as before). */
-#define NRC_ABI_VERSION 5
+#define NRC_ABI_VERSION 6
 /* library identification; also used by the loader's symbol check */
 int nrc_abi_version(void);
 const char* nrc_build_info(void);
@@ -712,6 +712,38 @@ int nrc_amp_adam_step(float* param_a, const float* grad_a, float* exp_avg_a, flo
                       float l2_coeff_b, int64_t l2_count_b, float lr, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                       int32_t adam_w_mode, int32_t* device_step, float* bias_corrections, float* scale, int32_t* growth_tracker, float growth_factor,
                       float backoff_factor, int32_t growth_interval, float* state4, void* ticket, int32_t* skipped_steps, nrc_stream_t stream);
+
+/* =====================================================================================================
+ * Group 14 -- the training iteration of a DATA-PARALLEL rank, in pieces (round 6).  The reference has no counterpart (its DataParallel wrapper is a
+ *            no-op for ray batches, src/Methods/Base/Renderer.py:24-33); SURVEY 8(e) names the shape: reduce-scatter of the gradients, Adam on the
+ *            rank's 1/N of the parameters, all-gather of what the kernels read.  The collectives are the host's (torch.distributed over RCCL); these
+ *            calls are what stands between them, enqueue-only like group 13:
+ *   nrc_ngp_train_networks_backward : the two network launches of nrc_ngp_train_query_backward_cleared (same arguments); *nonfinite_flag (DEVICE f32,
+ *            cleared by the caller) is set to 1 when a launch hands on an inf / NaN.  After it the MLP-weight gradients are final -- the caller's small
+ *            all-reduce (both MLPs' gradients + the flag) can start while the grid backward runs.
+ *   nrc_ngp_train_grid_backward     : the hash-grid backward of the same call (reads the input gradient the first call left in `scratch`).
+ *   nrc_amp_settle                  : one thread: found_inf = (*flag_sum != 0) (a sum of the ranks' flags), step counter, bias corrections, scale update
+ *            rule, state4[2] = 1 / (scale * grad_divisor) -- grad_divisor = world size when the gradients are a SUM over the ranks.  state4 as in nrc_amp_adam_step.
+ *   nrc_amp_adam_slices             : the Adam launch of nrc_amp_adam_step on two arbitrary slices (pointers already offset; l2_count relative to the
+ *            slice) -- a rank's shard of the table, or the replicated MLP weights.  Skipped when state4[1] says so.  Either slice may be empty.
+ * ===================================================================================================== */
+int nrc_ngp_train_networks_backward(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01, const void* density_weights_f16,
+                                    const void* color_weights_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
+                                    float per_level_scale, const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d,
+                                    const void* save_in_c, const void* save_acts_c, float loss_scale, float* grad_density_params,
+                                    float* grad_color_params, int64_t n_density_mlp_params, int64_t n_density_params, int64_t n_color_params,
+                                    void* scratch, const int32_t* n_samples_dev, float* nonfinite_flag, nrc_stream_t stream);
+int nrc_ngp_train_grid_backward(int64_t M, const float* x01, const void* density_weights_f16, const void* color_weights_f16, int32_t n_levels,
+                                int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_density_params,
+                                float* grad_color_params, int64_t n_density_mlp_params, int64_t n_density_params, int64_t n_color_params, void* scratch,
+                                const int32_t* n_samples_dev, nrc_stream_t fork_stream, nrc_stream_t stream);
+int nrc_amp_settle(const float* flag_sum, float grad_divisor, float beta1, float beta2, int32_t* device_step, float* bias_corrections, float* scale,
+                   int32_t* growth_tracker, float growth_factor, float backoff_factor, int32_t growth_interval, float* state4, int32_t* skipped_steps,
+                   nrc_stream_t stream);
+int nrc_amp_adam_slices(float* param_a, const float* grad_a, float* exp_avg_a, float* exp_avg_sq_a, void* param_f16_a, int64_t n_a, float l2_coeff_a,
+                        int64_t l2_count_a, float* param_b, const float* grad_b, float* exp_avg_b, float* exp_avg_sq_b, void* param_f16_b, int64_t n_b,
+                        float l2_coeff_b, int64_t l2_count_b, float lr, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                        int32_t adam_w_mode, const float* bias_corrections, const float* state4, nrc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,7 @@ struct AmpState {
     float beta1, beta2;
     float* state;                             // f32[4]: [0] raw flag of the check (0 on entry, 0 on exit), [1] found_inf of this step, [2] 1 / scale of this step
     uint32_t* ticket;
+    float grad_divisor;                       // the gradients are a SUM over this many ranks (data parallel): state[2] = 1 / (scale * divisor); 1 otherwise
 };
 // what ONE thread does once it is known whether the gradients are finite (state[0]): k_adam_prepare (capturable form) + torch's amp_update_scale kernel
 __device__ __forceinline__ void amp_prepare_thread(const AmpState& a) {
@@ -110,7 +111,7 @@ __device__ __forceinline__ void amp_prepare_thread(const AmpState& a) {
     a.bc[1] = (float)(1.0 - pow((double)a.beta2, (double)step));
     a.state[1] = overflow ? 1.f : 0.f;
     float scale = a.scale ? *a.scale : 1.f;
-    a.state[2] = 1.0f / scale;
+    a.state[2] = 1.0f / (scale * a.grad_divisor);   // (divisor a power of two: the same bits as dividing the gradient first)
     if (a.scale) {   // torch/aten/src/ATen/native/cuda/AmpKernels.cu, amp_update_scale_cuda_kernel: back off on an overflow, grow after growth_interval clean steps
         if (overflow) { *a.scale = scale * a.backoff_factor; *a.growth_tracker = 0; }
         else {
@@ -144,6 +145,13 @@ __global__ void __launch_bounds__(256) k_amp_check_prepare(AmpList l, AmpState a
 // the same closing step as a launch of its own: for callers whose PRODUCERS flag non-finite gradients (state[0]) -- nrc_ngp_train_backward_step
 __global__ void k_amp_prepare(AmpState a) {
     if (threadIdx.x | blockIdx.x) return;
+    amp_prepare_thread(a);
+}
+// the closing step for a data-parallel rank: the flag is a SUM of the ranks' flags that arrived with the small all-reduce (nrc_amp_settle)
+__global__ void k_amp_settle(AmpState a, const float* __restrict__ flag) {
+    if (threadIdx.x | blockIdx.x) return;
+    const float f = *flag;
+    __hip_atomic_store(&a.state[0], (f != 0.f) ? 1.f : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // NaN != 0 as well: a poisoned flag is an overflow
     amp_prepare_thread(a);
 }
 // (2) Adam on both tensors (blockIdx.y), everything it needs in device scalars
@@ -197,6 +205,7 @@ void nrc_launch_amp_prepare(int32_t* device_step, float* bias_corrections, float
     AmpState a;
     a.device_step = device_step; a.bc = bias_corrections; a.scale = scale; a.growth_tracker = growth_tracker; a.growth_factor = growth_factor;
     a.backoff_factor = backoff_factor; a.growth_interval = growth_interval; a.beta1 = beta1; a.beta2 = beta2; a.state = state4; a.ticket = nullptr; a.skipped = nullptr;
+    a.grad_divisor = 1.f;
     hipLaunchKernelGGL(k_amp_prepare, dim3(1), dim3(64), 0, s, a);
 }
 void nrc_launch_amp_adam(float* pa, const float* ga, float* ma, float* va, void* ha, int64_t na, float l2c_a, int64_t l2n_a, float* pb, const float* gb, float* mb,
@@ -294,7 +303,7 @@ int nrc_amp_adam_step(float* param_a, const float* grad_a, float* exp_avg_a, flo
     AmpState a;
     a.device_step = device_step; a.bc = bias_corrections; a.scale = scale; a.growth_tracker = growth_tracker; a.growth_factor = growth_factor;
     a.backoff_factor = backoff_factor; a.growth_interval = growth_interval; a.beta1 = beta1; a.beta2 = beta2; a.state = state4; a.ticket = (uint32_t*)ticket;
-    a.skipped = skipped_steps;
+    a.skipped = skipped_steps; a.grad_divisor = 1.f;
     const int64_t largest = n_a > n_b ? n_a : n_b;
     const int64_t blocks = nrc_cdiv(nrc_cdiv(largest, 4), 256);
     hipStream_t s = (hipStream_t)stream;
@@ -304,6 +313,40 @@ int nrc_amp_adam_step(float* param_a, const float* grad_a, float* exp_avg_a, flo
     hipLaunchKernelGGL(k_amp_adam, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, s, l, (const float*)state4, (const float*)bias_corrections, lr_dev, lr,
                        beta1, beta2, eps, weight_decay, (int)adam_w_mode);
     NRC_STAGE(s, "k_amp_adam");
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+/* ---- group 14: the optimizer step of a data-parallel rank, in pieces (include/nerficg_hip.h) ---- */
+int nrc_amp_settle(const float* flag_sum, float grad_divisor, float beta1, float beta2, int32_t* device_step, float* bias_corrections, float* scale,
+                   int32_t* growth_tracker, float growth_factor, float backoff_factor, int32_t growth_interval, float* state4, int32_t* skipped_steps,
+                   nrc_stream_t stream) {
+    NRC_ENTER();
+    if (!flag_sum || !(grad_divisor >= 1.f) || !device_step || !bias_corrections || !state4 || (scale && (!growth_tracker || growth_interval < 1))) return NRC_ERR_INVALID;
+    AmpState a;
+    a.device_step = device_step; a.bc = bias_corrections; a.scale = scale; a.growth_tracker = growth_tracker; a.growth_factor = growth_factor;
+    a.backoff_factor = backoff_factor; a.growth_interval = growth_interval; a.beta1 = beta1; a.beta2 = beta2; a.state = state4; a.ticket = nullptr;
+    a.skipped = skipped_steps; a.grad_divisor = grad_divisor;
+    hipLaunchKernelGGL(k_amp_settle, dim3(1), dim3(64), 0, (hipStream_t)stream, a, flag_sum);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_amp_adam_slices(float* param_a, const float* grad_a, float* exp_avg_a, float* exp_avg_sq_a, void* param_f16_a, int64_t n_a, float l2_coeff_a,
+                        int64_t l2_count_a, float* param_b, const float* grad_b, float* exp_avg_b, float* exp_avg_sq_b, void* param_f16_b, int64_t n_b,
+                        float l2_coeff_b, int64_t l2_count_b, float lr, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                        int32_t adam_w_mode, const float* bias_corrections, const float* state4, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_a < 0 || n_b < 0 || !bias_corrections || !state4 || (n_a && (!param_a || !grad_a || !exp_avg_a || !exp_avg_sq_a)) ||
+        (n_b && (!param_b || !grad_b || !exp_avg_b || !exp_avg_sq_b)))
+        return NRC_ERR_INVALID;
+    if (n_a == 0 && n_b == 0) return NRC_OK;
+    if (n_a == 0)   // the kernel's grid is sized by the larger slice and its second row is optional: an empty first slice moves the second one up
+        nrc_launch_amp_adam(param_b, grad_b, exp_avg_b, exp_avg_sq_b, param_f16_b, n_b, l2_coeff_b, l2_count_b, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0,
+                            state4, bias_corrections, lr_dev, lr, beta1, beta2, eps, weight_decay, (int)adam_w_mode, (hipStream_t)stream);
+    else
+        nrc_launch_amp_adam(param_a, grad_a, exp_avg_a, exp_avg_sq_a, param_f16_a, n_a, l2_coeff_a, l2_count_a, param_b, grad_b, exp_avg_b, exp_avg_sq_b, param_f16_b, n_b,
+                            l2_coeff_b, l2_count_b, state4, bias_corrections, lr_dev, lr, beta1, beta2, eps, weight_decay, (int)adam_w_mode, (hipStream_t)stream);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -2526,9 +2526,14 @@ static int train_query_backward_impl(const float* dL_dsigmas, const float* dL_dr
                                  float per_level_scale, const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d,
                                  const void* save_in_c, const void* save_acts_c, float loss_scale, float* grad_density_params, float* grad_color_params,
                                  int64_t n_density_mlp_params, void* scratch, nrc_stream_t stream, int64_t n_density_params, int64_t n_color_params,
-                                 bool precleared = false, const int32_t* m_live = nullptr, const TrainStep* step = nullptr, hipStream_t fork_stream = nullptr) {
+                                 bool precleared = false, const int32_t* m_live = nullptr, const TrainStep* step = nullptr, hipStream_t fork_stream = nullptr,
+                                 int phases = 3, float* nonfinite_flag = nullptr) {
+    // phases: 1 = the two network backward launches, 2 = the hash-grid backward behind them (group 14 issues them as two calls so that a data-parallel
+    // rank can start its small collective in between); nonfinite_flag: where the network launches flag inf / NaN when there is no TrainStep
+    if (step) nonfinite_flag = step->state4;
     if (M < 0 || !density_weights_f16 || !color_weights_f16 || !grad_density_params || !grad_color_params || n_density_mlp_params < 0) return NRC_ERR_INVALID;
-    if (M > 0 && (!dL_dsigmas || !dL_drgbs || !x01 || !h_f16 || !rgb_f16 || !save_in_d || !save_acts_d || !save_in_c || !save_acts_c || !scratch)) return NRC_ERR_INVALID;
+    if (M > 0 && (phases & 1) && (!dL_dsigmas || !dL_drgbs || !h_f16 || !rgb_f16 || !save_in_d || !save_acts_d || !save_in_c || !save_acts_c)) return NRC_ERR_INVALID;
+    if (M > 0 && (!x01 || !scratch)) return NRC_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     // _set variant: uninitialised gradient buffers.  Bucketed levels are written by their owners; everything else is zeroed here, in one launch.
     int assign = 0;
@@ -2545,7 +2550,7 @@ static int train_query_backward_impl(const float* dL_dsigmas, const float* dL_dr
                 if (zero_d > n_density_params) return NRC_ERR_INVALID;
             }
         }
-        if (!precleared)   // (nrc_ngp_train_query_backward_cleared: the caller cleared exactly these ranges, nrc_ngp_train_query_clear_floats)
+        if (!precleared && (phases & 1))   // (nrc_ngp_train_query_backward_cleared: the caller cleared exactly these ranges, nrc_ngp_train_query_clear_floats)
             hipLaunchKernelGGL(k_zero_two, dim3(512), dim3(256), 0, s, grad_density_params, zero_d, grad_color_params, n_color_params);
     }
     if (M == 0) { NRC_LAUNCH_CHECK(); return NRC_OK; }
@@ -2555,15 +2560,19 @@ static int train_query_backward_impl(const float* dL_dsigmas, const float* dL_dr
     __half* d_h16 = (__half*)p; p += M * 32;
     float* d_in_d = (float*)p;
     NRC_STAGE(s, nullptr);
+    int rc = NRC_OK;
+    if (phases & 1) {
     // colour network: dL/drgb read as it is, the TruncExp backward and the density network's output gradient written by its epilogue (TrainQ)
-    int rc = nwie_backward_impl(M, color_weights_f16, 2, ACT_SIGMOID, 3, nullptr, rgb_f16, 4, save_in_c, save_acts_c, loss_scale, grad_color_params, nullptr, 0,
-                                stream, TrainQ{dL_drgbs, dL_dsigmas, (const __half*)h_f16, d_h16}, m_live, step ? step->state4 : nullptr);
+    rc = nwie_backward_impl(M, color_weights_f16, 2, ACT_SIGMOID, 3, nullptr, rgb_f16, 4, save_in_c, save_acts_c, loss_scale, grad_color_params, nullptr, 0,
+                            stream, TrainQ{dL_drgbs, dL_dsigmas, (const __half*)h_f16, d_h16}, m_live, nonfinite_flag);
     if (rc != NRC_OK) return rc;
     NRC_STAGE(s, "k_nwie_bwd<colour>");
     rc = nwie_backward_impl(M, density_weights_f16, 1, ACT_NONE, 16, d_h16, h_f16, 16, save_in_d, save_acts_d, loss_scale, grad_density_params, d_in_d, 1, stream,
-                            TrainQ{nullptr, nullptr, nullptr, nullptr}, m_live, step ? step->state4 : nullptr);
+                            TrainQ{nullptr, nullptr, nullptr, nullptr}, m_live, nonfinite_flag);
     if (rc != NRC_OK) return rc;
     NRC_STAGE(s, "k_nwie_bwd<density>");
+    }
+    if (!(phases & 2)) { NRC_LAUNCH_CHECK(); return NRC_OK; }
     void* grid_ws = (char*)d_in_d + M * 128;  // nrc_grid_backward_ws_bytes (all levels at most) behind the pair-major gradients
     TrainStep st;
     if (step) {
@@ -2636,6 +2645,31 @@ int nrc_ngp_train_query_backward_cleared(const float* dL_dsigmas, const float* d
     return train_query_backward_impl(dL_dsigmas, dL_drgbs, M, x01, density_weights_f16, color_weights_f16, n_levels, log2_hashmap_size, base_resolution,
                                      per_level_scale, h_f16, rgb_f16, save_in_d, save_acts_d, save_in_c, save_acts_c, loss_scale, grad_density_params,
                                      grad_color_params, n_density_mlp_params, scratch, stream, n_density_params, n_color_params, true, n_samples_dev, nullptr, (hipStream_t)fork_stream);
+}
+
+/* group 14: the backward pass of nrc_ngp_train_query_backward_cleared as two calls */
+int nrc_ngp_train_networks_backward(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01, const void* density_weights_f16,
+                                    const void* color_weights_f16, int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution,
+                                    float per_level_scale, const void* h_f16, const void* rgb_f16, const void* save_in_d, const void* save_acts_d,
+                                    const void* save_in_c, const void* save_acts_c, float loss_scale, float* grad_density_params,
+                                    float* grad_color_params, int64_t n_density_mlp_params, int64_t n_density_params, int64_t n_color_params,
+                                    void* scratch, const int32_t* n_samples_dev, float* nonfinite_flag, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_density_params <= 0 || n_color_params <= 0 || !grad_density_params || !grad_color_params || (M > 0 && !scratch)) return NRC_ERR_INVALID;
+    return train_query_backward_impl(dL_dsigmas, dL_drgbs, M, x01, density_weights_f16, color_weights_f16, n_levels, log2_hashmap_size, base_resolution,
+                                     per_level_scale, h_f16, rgb_f16, save_in_d, save_acts_d, save_in_c, save_acts_c, loss_scale, grad_density_params,
+                                     grad_color_params, n_density_mlp_params, scratch, stream, n_density_params, n_color_params, true, n_samples_dev, nullptr, nullptr,
+                                     1, nonfinite_flag);
+}
+int nrc_ngp_train_grid_backward(int64_t M, const float* x01, const void* density_weights_f16, const void* color_weights_f16, int32_t n_levels,
+                                int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_density_params,
+                                float* grad_color_params, int64_t n_density_mlp_params, int64_t n_density_params, int64_t n_color_params, void* scratch,
+                                const int32_t* n_samples_dev, nrc_stream_t fork_stream, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_density_params <= 0 || n_color_params <= 0 || !grad_density_params || !grad_color_params || (M > 0 && !scratch)) return NRC_ERR_INVALID;
+    return train_query_backward_impl(nullptr, nullptr, M, x01, density_weights_f16, color_weights_f16, n_levels, log2_hashmap_size, base_resolution,
+                                     per_level_scale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, grad_density_params, grad_color_params,
+                                     n_density_mlp_params, scratch, stream, n_density_params, n_color_params, true, n_samples_dev, nullptr, (hipStream_t)fork_stream, 2);
 }
 
 int nrc_ngp_train_backward_step(const float* dL_dsigmas, const float* dL_drgbs, int64_t M, const float* x01, const void* density_weights_f16,

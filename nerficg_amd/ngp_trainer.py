@@ -69,7 +69,8 @@ class FusedTrainingIteration:
 
     def __init__(self, model, renderer, optimizer, scaler, camera, ray_pool: dict, ray_capacity: int, sample_capacity: int, order: torch.Tensor | None = None,
                  seed: int = 0, weight_decay: float = 0.5e-6, prefetch: bool = True, graph: bool = False, ray_offset: int | None = None, fused_step: bool = True,
-                 fork_dense_levels: bool = True, data_parallel: bool | None = None) -> None:
+                 fork_dense_levels: bool = True, data_parallel: bool | None = None, sharded: bool | None = None, prefetch_at: str | None = None,
+                 dp_timing: bool = False) -> None:
         if not getattr(optimizer, 'capturable', False):
             raise RuntimeError('FusedTrainingIteration: build the optimizer as FusedAdam(..., capturable=True)')
         if len(optimizer.param_groups) != 1:
@@ -81,6 +82,7 @@ class FusedTrainingIteration:
         # background colour, so W ranks do the arithmetic one rank would do on W n rays; the two gradient vectors live in ONE flat buffer that is
         # averaged by one reduce-scatter + all-gather over RCCL (parallel.allreduce_flat) between the backward pass and the step -- an inf / NaN reaches
         # every rank through the sum, so all replicas skip the same steps.  The gradients have to exist on the wire: fused_step and recording are off.
+        # `sharded` (round 6, the default whenever the table divides by the world size): the step of SURVEY 8(e) -- see _update_sharded.
         from . import parallel
         self.rank, self.world = parallel.world_info()
         self.data_parallel = (self.world > 1) if data_parallel is None else bool(data_parallel)
@@ -133,8 +135,20 @@ class FusedTrainingIteration:
         self.loss2 = torch.zeros(2, device=dev)
         self.loss_ws = torch.zeros(int(lib.nrc_ngp_train_loss_ws_bytes(self.n_cap)), dtype=torch.uint8, device=dev)
         dn, cn = model.encoding_xyz, model.color_mlp_with_encoding
-        self.grads = e(dn.params.numel() + cn.params.numel())      # one buffer: one collective in data-parallel runs
-        self.gd, self.gc = self.grads[:dn.params.numel()], self.grads[dn.params.numel():]
+        # one buffer, in the order a data-parallel iteration finishes its pieces: [colour MLP | aux | density MLP | hash table] (parallel.ShardedStepLayout)
+        self.layout = L = parallel.ShardedStepLayout(cn.params.numel(), dn.n_mlp_params, dn.params.numel() - dn.n_mlp_params, self.rank, self.world)
+        self.grads = torch.zeros(L.total, dtype=f32, device=dev)
+        self.gc, self.aux, self.gd = self.grads[:L.off_aux], self.grads[L.off_aux:L.off_density], self.grads[L.off_density:]
+        self.sharded = self.data_parallel and L.sharded and (sharded is None or bool(sharded))
+        if sharded and not self.sharded:
+            raise RuntimeError(f'FusedTrainingIteration(sharded=True): needs data_parallel and a table of {L.n_table} floats that divides by the world size {self.world}')
+        self.prefetch_at = prefetch_at or ('collective' if self.sharded else 'forward')
+        if self.prefetch_at not in ('forward', 'collective') or (self.prefetch_at == 'collective' and not self.sharded):
+            raise ValueError("prefetch_at: 'forward' (march the next batch beside this iteration's forward / backward pass) or, sharded step only, 'collective'")
+        self._comm = torch.cuda.Stream(device=dev) if self.sharded else None
+        self._ev = [torch.cuda.Event(), torch.cuda.Event()] if self.sharded else None
+        self._master_stale = False       # sharded step: the fp32 master / moments of the table are current in this rank's shard only (gather_state())
+        self.dp_timing, self._dp_events = bool(dp_timing), []
         self.bwd_scratch = e(int(lib.nrc_ngp_train_query_scratch_bytes(m)), dtype=torch.uint8)
         g = dn.grid_cfg
         self.n_clear = int(lib.nrc_ngp_train_query_clear_floats(m, g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']),
@@ -179,12 +193,16 @@ class FusedTrainingIteration:
             self.n_rays_dev.fill_(n)
 
     # ------------------------------------------------------------------------------------------------ the five calls
-    def _state_tensors(self):
+    def _state_tensors(self, check: bool = True):
         """Everything whose ADDRESS a recorded iteration holds: when one of them is replaced (load_state_dict, a new occupancy buffer, ...) the
         recordings are dropped and made again."""
         opt, m = self.optimizer, self.model
         group = opt.param_groups[0]
         dn, cn = m.encoding_xyz, m.color_mlp_with_encoding
+        if check and self._master_stale and dn._half_key != dn._key_of(dn.params):
+            # the fp16 table would be rebuilt from an fp32 master that is current in this rank's shard only
+            raise RuntimeError('FusedTrainingIteration (sharded step): the density parameters were written outside the trainer while their fp32 master was '
+                               'sharded over the ranks -- call gather_state() on every rank before editing / loading parameters')
         for p in (dn.params, cn.params):
             st = opt.state[p]
             if len(st) == 0:
@@ -213,7 +231,7 @@ class FusedTrainingIteration:
             p(b.hits_t), p(b.target), p(b.bg), p(b.rays_a), p(b.counter), p(b.xyzs), p(b.dirs), p(b.deltas), p(b.ts), p(b.overflow), p(self.march_ws[k]),
             _lib.stream_of(b.rays_o)), 'ngp_train_march')
 
-    def _update(self, k: int, st: dict) -> None:
+    def _update(self, k: int, st: dict, fork_prefetch=None) -> None:
         b, m, lib, p = self.sets[k], self.model, _lib.load(), _lib.ptr
         dn, cn = m.encoding_xyz, m.color_mlp_with_encoding
         g = dn.grid_cfg
@@ -226,7 +244,7 @@ class FusedTrainingIteration:
             p(self.sigmas), p(self.rgbs), p(self.save[0]), p(self.save[1]), p(self.save[2]), p(self.save[3]), p(self.fwd_ws), p(b.counter), stream), 'ngp_train_query_forward')
         _lib.check(lib.nrc_ngp_train_loss(
             p(self.sigmas), p(self.rgbs), p(b.deltas), p(b.ts), p(b.rays_a), p(b.counter), self.n_cap, M, self.T_THRESHOLD, p(b.bg), p(b.target), p(st['scale']),
-            p(self.ray_rgb), p(self.ray_alpha), None, p(self.loss2), p(self.d_sigmas), p(self.d_rgbs), p(self.gd), self.n_clear, p(self.gc), self.gc.numel(),
+            p(self.ray_rgb), p(self.ray_alpha), None, p(self.loss2), p(self.d_sigmas), p(self.d_rgbs), p(self.gd), self.n_clear, p(self.gc), self.gc.numel() + self.aux.numel(),
             p(self.loss_ws), stream), 'ngp_train_loss')
         group = self.optimizer.param_groups[0]
         beta1, beta2 = group['betas']
@@ -243,6 +261,8 @@ class FusedTrainingIteration:
                 *backward, p(st['pd']), p(st['md']), p(st['vd']), p(st['hd']), self.l2[0][0], self.l2[0][1], p(st['pc']), p(st['mc']), p(st['vc']), p(st['hc']),
                 self.l2[1][0], self.l2[1][1], *hyper, fork, stream), 'ngp_train_backward_step')
             return
+        if self.sharded:
+            return self._update_sharded(st, backward, hyper, fork, stream, fork_prefetch)
         _lib.check(lib.nrc_ngp_train_query_backward_cleared(*backward, fork, stream), 'ngp_train_query_backward_cleared')
         if self.data_parallel:
             from . import parallel
@@ -252,17 +272,99 @@ class FusedTrainingIteration:
             p(st['pc']), p(self.gc), p(st['mc']), p(st['vc']), p(st['hc']), self.gc.numel(), self.l2[1][0], self.l2[1][1],
             *hyper, p(self.amp_ticket), None, stream), 'amp_adam_step')
 
+    def _update_sharded(self, st: dict, backward: tuple, hyper: tuple, fork, stream, fork_prefetch) -> None:
+        """The data-parallel step of SURVEY 8(e), wire time beside compute where the dependencies allow it (DESIGN 5 has the byte / time model):
+
+            main stream                                   communication stream
+            networks backward (flags inf / NaN) --E0-->   all-reduce [colour MLP | flag | density MLP] gradients (41 KB; hides under the grid backward)
+            grid backward                       --E1-->   reduce-scatter (in place) of the table gradient: 7/8 x 48.8 MB leave each GPU at N = 8
+            [next batch's march forks here]               settle: flag -> found_inf, step counter, 1 / (scale x world), scale rule       (1 thread)
+                                                          Adam on the MLP weights (every rank, redundantly) and on THIS RANK'S table shard (1 / N of 12.2 M)
+                                                          all-gather (in place) of the fp16 table the kernels read: 7/8 x 24.4 MB
+            wait  <------------------------------------   done
+
+        The fp32 master and the moments of the table stay sharded (gather_state() before a checkpoint).  Nothing here reads a value back."""
+        from . import parallel
+        lib, p, L = _lib.load(), _lib.ptr, self.layout
+        dn, cn = self.model.encoding_xyz, self.model.color_mlp_with_encoding
+        main = torch.cuda.current_stream(self.dev)
+        (lr, lr_dev, beta1, beta2, eps, wd, adam_w, step_dev, bc, scale, tracker, growth, backoff, interval, amp_state) = hyper
+        _lib.check(lib.nrc_ngp_train_networks_backward(*backward, p(self.aux), stream), 'ngp_train_networks_backward')
+        self._ev[0].record(main)
+        # (backward = dL_dsigmas, dL_drgbs, M, x01, weights d / c, grid (4), h, rgb16, saves (4), loss_scale, gd, gc, n_mlp, n_d, n_c, scratch, counter)
+        M, x01, wd16, wc16 = backward[2], backward[3], backward[4], backward[5]
+        _lib.check(lib.nrc_ngp_train_grid_backward(M, x01, wd16, wc16, *backward[6:10], *backward[17:24], fork, stream), 'ngp_train_grid_backward')
+        self._ev[1].record(main)
+        if fork_prefetch is not None:
+            fork_prefetch()
+        comm = self._comm
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if self.dp_timing else None
+        comm.wait_event(self._ev[0])
+        with torch.cuda.stream(comm):
+            cs = ctypes.c_void_p(comm.cuda_stream)
+            n_dm = L.n_density_mlp
+            at = lambda t, off: ctypes.c_void_p(t.data_ptr() + off * t.element_size())
+            slices = lambda *a: _lib.check(lib.nrc_amp_adam_slices(*a, lr, lr_dev, beta1, beta2, eps, wd, adam_w, bc, amp_state, cs), 'amp_adam_slices')
+
+            def settle(aux):
+                _lib.check(lib.nrc_amp_settle(p(aux), float(self.world), beta1, beta2, step_dev, bc, scale, tracker, growth, backoff, interval, amp_state, None, cs), 'amp_settle')
+
+            def adam_small():
+                slices(p(st['pd']), p(self.gd), p(st['md']), p(st['vd']), p(st['hd']), n_dm, self.l2[0][0], min(self.l2[0][1], n_dm),
+                       p(st['pc']), p(self.gc), p(st['mc']), p(st['vc']), p(st['hc']), self.gc.numel(), self.l2[1][0], self.l2[1][1])
+
+            def adam_table(begin, count):
+                b = n_dm + begin
+                slices(at(st['pd'], b), at(self.gd, b), at(st['md'], b), at(st['vd'], b), at(st['hd'], b), count, 0.0, 0, None, None, None, None, None, 0, 0.0, 0)
+
+            parallel.sharded_step(L, self.grads, st['hd'][n_dm:], settle, adam_small, adam_table, before_table=lambda: comm.wait_event(self._ev[1]),
+                                  mark=(lambda k: ev[k].record(comm)) if ev else None)
+        main.wait_stream(comm)
+        self._master_stale = True
+        if ev:
+            ev[4].record(main)           # the iteration continues here: [1]..[4] is what the step adds behind the backward pass
+            self._dp_events.append(ev)
+
+    def dp_times(self, clear: bool = True) -> dict | None:
+        """dp_timing=True: mean milliseconds per sharded step since the last call -- `reduce_scatter_ms`, `adam_ms` (settle + both Adam launches), `all_gather_ms`,
+        `exposed_ms` (end of the backward pass -> the main stream may continue).  Synchronises the device."""
+        if not self._dp_events:
+            return None
+        torch.cuda.synchronize(self.dev)
+        rows = [(e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3]), e[0].elapsed_time(e[4])) for e in self._dp_events]
+        if clear:
+            self._dp_events = []
+        mean = [sum(r[k] for r in rows) / len(rows) for k in range(4)]
+        return {'reduce_scatter_ms': mean[0], 'adam_ms': mean[1], 'all_gather_ms': mean[2], 'exposed_ms': mean[3], 'iterations': len(rows)}
+
+    def gather_state(self) -> None:
+        """Sharded step: all-gathers the table's fp32 master parameters and both Adam moments (each rank has kept only its shard current), so that
+        model.state_dict() / optimizer.state_dict() hold the whole state on every rank.  A collective: every rank calls it (before a checkpoint, before
+        anything outside this class reads or edits `params`).  3 x 7/8 x 48.8 MB per GPU at N = 8, off the iteration path."""
+        if not self.sharded or not self._master_stale:
+            return
+        from . import parallel
+        st, n_dm = self._state_tensors(check=False), self.layout.n_density_mlp
+        for t in (st['pd'], st['md'], st['vd']):
+            parallel.all_gather_(t.detach()[n_dm:], self.rank, self.world)
+        self._master_stale = False
+
     def _enqueue(self, cur: int, inline: bool, prefetch: bool, st: dict, explicit) -> None:
         if inline:
             self._march(cur, st, explicit)
-        if prefetch:
-            # the fork sits in FRONT of the forward pass (measured against forks behind the loss and in front of Adam: 0.380 / 0.395 / 0.407 ms per
-            # iteration) and behind the inline march: both marches move the cursor and the generator
+
+        def fork():
             main = torch.cuda.current_stream(self.dev)
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 self._march(1 - cur, st, explicit)
-        self._update(cur, st)
+        at_collective = prefetch and self.prefetch_at == 'collective'
+        if prefetch and not at_collective:
+            # the fork sits in FRONT of the forward pass (measured against forks behind the loss and in front of Adam: 0.380 / 0.395 / 0.407 ms per
+            # iteration) and behind the inline march: both marches move the cursor and the generator.  (Sharded data-parallel step: behind the grid
+            # backward instead, where the GPU would otherwise wait for the wire -- prefetch_at.)
+            fork()
+        self._update(cur, st, fork if at_collective else None)
         if prefetch:
             torch.cuda.current_stream(self.dev).wait_stream(self._side)
 

@@ -32,7 +32,8 @@ from .amp import GradScaler as _FastGradScaler
 
 __all__ = ['init_distributed', 'world_info', 'shard_ray_ids', 'shard_range', 'allreduce_flat', 'allreduce_gradients',
            'all_gather_pixels', 'tile_pixel_indices', 'gather_image_shards', 'broadcast_parameters', 'sparse_allreduce_gradients', 'allreduce_densification_stats', 'synchronized_noise',
-           'allreduce_scalars', 'DataParallelGradScaler', 'rays_per_batch_update', 'single_rank_collectives']
+           'allreduce_scalars', 'DataParallelGradScaler', 'rays_per_batch_update', 'single_rank_collectives', 'ShardedStepLayout', 'allreduce_sum_',
+           'reduce_scatter_sum_', 'all_gather_', 'sharded_step']
 
 
 _SINGLE_RANK_COLLECTIVES = False
@@ -105,10 +106,136 @@ def shard_range(n: int, rank: int | None = None, world: int | None = None) -> tu
 
 
 def _has_tensor_collectives() -> bool:
-    """reduce_scatter_tensor / all_gather_into_tensor exist on RCCL ("nccl"); gloo has all_reduce only.  Decided from the backend NAME, once
-    per call site and identically on every rank -- never by catching an exception from a collective: a rank-local failure would send that
-    rank alone into another collective and leave the job desynchronised."""
+    """reduce_scatter_tensor / all_gather_into_tensor exist on RCCL ("nccl"); allreduce_flat keeps gloo on one all_reduce (the round-3 wire format of
+    the CPU tests).  Decided from the backend NAME, once per call site and identically on every rank -- never by catching an exception from a
+    collective: a rank-local failure would send that rank alone into another collective and leave the job desynchronised."""
     return dist.get_backend() != 'gloo'
+
+
+# ---- the three collectives of the sharded optimizer step (SURVEY 8e: "reduce-scatter + sharded Adam + all-gather"), all IN PLACE on resident buffers -------
+def _staged(t: torch.Tensor) -> bool:
+    """gloo moves host memory: a device tensor is staged through the host (the 2-rank tests that share ONE GPU; production runs are RCCL)."""
+    return t.is_cuda and dist.get_backend() == 'gloo'
+
+
+def allreduce_sum_(buf: torch.Tensor) -> torch.Tensor:
+    """In-place SUM of a small flat tensor over the ranks (the MLP-weight gradients + the overflow flag of a data-parallel iteration: 41 KB)."""
+    rank, world = world_info()
+    if _no_collective(world):
+        return buf
+    if _staged(buf):
+        host = buf.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        buf.copy_(host)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf
+
+
+def reduce_scatter_sum_(buf: torch.Tensor, rank: int | None = None, world: int | None = None) -> torch.Tensor:
+    """In-place reduce-scatter (SUM) of a flat contiguous tensor whose length is a multiple of the world size: afterwards rows
+    [rank * n / world, (rank + 1) * n / world) of `buf` hold the sum over the ranks (the rest of `buf` is this rank's own contribution still).  Returns that
+    shard (a view).  RCCL's in-place form (receive buffer = send buffer + rank * count): no second 48.8 MB buffer, each xGMI link carries 1 / world."""
+    r, w = world_info()
+    rank, world = (r if rank is None else rank), (w if world is None else world)
+    n = buf.numel()
+    if n % world:
+        raise RuntimeError(f'reduce_scatter_sum_: {n} elements do not divide by {world} ranks')
+    shard = buf[rank * (n // world):(rank + 1) * (n // world)]
+    if _no_collective(world):
+        return shard
+    if _staged(buf):
+        host = buf.cpu()
+        out = torch.empty(n // world, dtype=buf.dtype)
+        dist.reduce_scatter_tensor(out, host, op=dist.ReduceOp.SUM)
+        shard.copy_(out)
+    else:
+        dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM)
+    return shard
+
+
+def all_gather_(buf: torch.Tensor, rank: int | None = None, world: int | None = None) -> torch.Tensor:
+    """In-place all-gather: every rank contributes rows [rank * n / world, (rank + 1) * n / world) of its `buf` and ends with all of them."""
+    r, w = world_info()
+    rank, world = (r if rank is None else rank), (w if world is None else world)
+    n = buf.numel()
+    if n % world:
+        raise RuntimeError(f'all_gather_: {n} elements do not divide by {world} ranks')
+    if _no_collective(world):
+        return buf
+    shard = buf[rank * (n // world):(rank + 1) * (n // world)]
+    if _staged(buf):
+        host = torch.empty(n, dtype=buf.dtype)
+        dist.all_gather_into_tensor(host, shard.cpu())
+        buf.copy_(host)
+    else:
+        dist.all_gather_into_tensor(buf, shard)
+    return buf
+
+
+def sharded_step(layout: 'ShardedStepLayout', grads: torch.Tensor, half_table: torch.Tensor, settle, adam_small, adam_table,
+                 before_table=None, mark=None) -> None:
+    """The optimizer step of one data-parallel rank on a gradient buffer laid out as `layout` says -- the ORDER of collectives and updates, shared by
+    nerficg_amd.ngp_trainer (callbacks = library calls on the communication stream) and the CPU tests (callbacks = the CPU oracle):
+
+        1. all-reduce (SUM) of [colour MLP | aux | density MLP]: aux[0] becomes the number of ranks that saw an inf / NaN
+        2. before_table(): the caller waits for its grid backward here (the small collective above ran beside it)
+        3. reduce-scatter (SUM, in place) of the table gradient: this rank's shard now holds the sum over the ranks
+        4. settle(aux): found_inf = aux[0] != 0, step counter, 1 / (scale x world), scale update -- identical on every rank, no further agreement needed
+        5. adam_small(): the MLP weights, on every rank redundantly;  adam_table(begin, count): this rank's shard (offsets relative to the table)
+        6. all-gather (in place) of `half_table`, the fp16 (or whatever the kernels read) copy of the table, whose shard step 5 rewrote
+
+    mark(k), optional: called behind steps 2, 3, 5, 6 (k = 0..3) -- the trainer records timing events there."""
+    L = layout
+    if not L.sharded:
+        raise RuntimeError('sharded_step: the table does not divide by the world size (ShardedStepLayout.sharded)')
+    allreduce_sum_(grads[:L.off_table])
+    if before_table is not None:
+        before_table()
+    if mark: mark(0)
+    reduce_scatter_sum_(grads[L.off_table:L.total], L.rank, L.world)
+    if mark: mark(1)
+    settle(grads[L.off_aux:L.off_density])
+    adam_small()
+    adam_table(L.shard_begin, L.shard)
+    if mark: mark(2)
+    all_gather_(half_table, L.rank, L.world)
+    if mark: mark(3)
+
+
+class ShardedStepLayout:
+    """Where the pieces of ONE flat f32 gradient buffer of an InstantNGP model live, in the order a data-parallel iteration finishes them:
+
+        [ colour-MLP gradient (n_color) | aux (AUX floats: [0] = overflow flag) | density-MLP gradient (n_density_mlp) | hash-table gradient (n_table) ]
+          `-------------------------- small: ONE all-reduce right behind the network backward ---------------'   `-- reduce-scatter behind the grid backward
+
+    The table is cut into `world` equal shards; rank r runs Adam on table[r s, (r + 1) s) only (its moments and fp32 master are current THERE only) and on the
+    10 240 MLP weights, which every rank keeps in step redundantly; the fp16 table copy the kernels read is all-gathered.  `sharded` is False when the table
+    does not divide by the world size (the caller then reduces the whole buffer and steps redundantly -- a world of 3, 6 or 7 GPUs).
+    wire_bytes(): bytes a GPU SENDS per iteration, the (world - 1) / world factors of ring / direct reduce-scatter and all-gather included."""
+    AUX = 32    # floats: keeps the density vector 128-byte aligned behind the colour vector
+
+    def __init__(self, n_color: int, n_density_mlp: int, n_table: int, rank: int | None = None, world: int | None = None) -> None:
+        r, w = world_info()
+        self.rank, self.world = (r if rank is None else int(rank)), (w if world is None else int(world))
+        self.n_color, self.n_density_mlp, self.n_table = int(n_color), int(n_density_mlp), int(n_table)
+        self.off_aux = self.n_color
+        self.off_density = self.n_color + self.AUX
+        self.off_table = self.off_density + self.n_density_mlp
+        self.total = self.off_table + self.n_table
+        self.sharded = self.n_table % self.world == 0
+        self.shard = self.n_table // self.world if self.sharded else self.n_table
+        self.shard_begin = self.rank * self.shard if self.sharded else 0      # relative to the table
+
+    def wire_bytes(self, table_wire_bytes: int = 4, half_bytes: int = 2) -> dict:
+        f = (self.world - 1) / self.world
+        small = 2 * f * self.off_table * 4
+        if self.sharded:
+            rs, ag = f * self.n_table * table_wire_bytes, f * self.n_table * half_bytes
+        else:
+            rs, ag = f * self.n_table * 4, f * self.n_table * 4
+        return {'small_allreduce': int(small), 'reduce_scatter': int(rs), 'all_gather': int(ag), 'total': int(small + rs + ag),
+                'adam_elements_per_rank': self.off_table - self.AUX + self.shard}
 
 
 def allreduce_flat(buf: torch.Tensor, average: bool = True) -> torch.Tensor:

@@ -245,3 +245,110 @@ def test_rank_batch_orders_tile_the_global_batches():
         for k in range(n_iter):
             union = torch.cat([p[k * n:(k + 1) * n] for p in per_rank])
             assert torch.equal(union, order[k * world * n:(k + 1) * world * n])
+
+
+def _t_sharded_step(rank, world):
+    """Five optimizer steps of a 2-rank job, an overflow on ONE rank in the middle, through (A) the replicated step -- allreduce_flat(average) of the whole
+    gradient, inf / NaN scan of the result, Adam on everything on every rank -- and (B) parallel.sharded_step -- small all-reduce carrying the ranks' flags,
+    in-place reduce-scatter, Adam on the rank's table shard with 1 / (scale x world), in-place all-gather of the fp16 copy.  Adam is oracle/adam_oracle.c in both."""
+    import numpy as np
+    import oracle
+    from nerficg_amd import parallel
+    n_c, n_dm, n_t = 96, 64, 4096
+    L = parallel.ShardedStepLayout(n_c, n_dm, n_t)
+    assert (L.rank, L.world, L.sharded, L.shard, L.shard_begin) == (rank, world, True, n_t // world, rank * n_t // world)
+    lr, betas, eps, growth_interval = 1e-2, (0.9, 0.99), 1e-15, 2
+    init = np.random.default_rng(0).normal(size=n_c + n_dm + n_t).astype(np.float32)       # [colour | density MLP | table], the same on every rank
+
+    def fresh():
+        return dict(p=init.copy(), m=np.zeros_like(init), v=np.zeros_like(init), h=init.astype(np.float16), step=0, scale=128.0, tracker=0, skipped=0)
+    A, B = fresh(), fresh()
+
+    def scale_rule(S, overflow):      # torch's amp_update_scale
+        if overflow:
+            S['scale'] *= 0.5; S['tracker'] = 0; S['skipped'] += 1
+        else:
+            S['step'] += 1
+            S['tracker'] += 1
+            if S['tracker'] == growth_interval:
+                S['scale'] *= 2.0; S['tracker'] = 0
+
+    def adam(S, lo, hi, g, grad_scale):
+        S['p'][lo:hi], S['m'][lo:hi], S['v'][lo:hi] = oracle.adam_step(S['p'][lo:hi], g, S['m'][lo:hi], S['v'][lo:hi], S['step'], lr, betas, eps, grad_scale=grad_scale)
+        S['h'][lo:hi] = S['p'][lo:hi].astype(np.float16)
+
+    for it in range(5):
+        g = (np.random.default_rng(100 * it + rank).normal(size=n_c + n_dm + n_t) * A['scale']).astype(np.float32)   # this rank's scaled gradient
+        assert A['scale'] == B['scale']
+        flag = 0.0
+        if it == 2 and rank == 1:
+            g[n_c + n_dm + 7] = np.inf       # in rank 0's table shard, produced on rank 1: only the flag (B) / the sum (A) can tell rank 0
+            flag = 1.0
+        # (A) replicated
+        buf = torch.from_numpy(g.copy())
+        parallel.allreduce_flat(buf, average=True)
+        ga = buf.numpy()
+        overflow = not np.isfinite(ga).all()
+        scale_a = A['scale']
+        scale_rule(A, overflow)
+        if not overflow:
+            adam(A, 0, ga.size, ga, scale_a)
+        # (B) sharded: the layout's buffer, flag in aux[0]
+        grads = torch.zeros(L.total)
+        grads[:n_c] = torch.from_numpy(g[:n_c]); grads[L.off_aux] = flag
+        grads[L.off_density:] = torch.from_numpy(g[n_c:])
+        half_table = torch.from_numpy(B['h'][n_c + n_dm:].copy())
+        ctx = {}
+
+        def settle(aux):
+            ctx['overflow'] = float(aux[0]) != 0.0
+            ctx['grad_scale'] = B['scale'] * world          # 1 / (scale x world) on a SUM = 1 / scale on the mean (world a power of two: the same bits)
+            scale_rule(B, ctx['overflow'])
+
+        def adam_small():
+            if not ctx['overflow']:
+                adam(B, 0, n_c, grads[:n_c].numpy(), ctx['grad_scale'])
+                adam(B, n_c, n_c + n_dm, grads[L.off_density:L.off_table].numpy(), ctx['grad_scale'])
+
+        def adam_table(begin, count):
+            if not ctx['overflow']:
+                lo = n_c + n_dm + begin
+                adam(B, lo, lo + count, grads[L.off_table + begin:L.off_table + begin + count].numpy(), ctx['grad_scale'])
+                half_table[begin:begin + count] = torch.from_numpy(B['h'][lo:lo + count].copy())
+        parallel.sharded_step(L, grads, half_table, settle, adam_small, adam_table)
+        B['h'][n_c + n_dm:] = half_table.numpy()
+        assert ctx['overflow'] == overflow == (it == 2)
+    # the fp16 copy is whole on every rank after every step; master and moments of the table are gathered on demand (FusedTrainingIteration.gather_state)
+    same_half = bool(np.array_equal(A['h'], B['h']))
+    other = slice(n_c + n_dm + (1 - rank) * L.shard, n_c + n_dm + (2 - rank) * L.shard)
+    stale_before = bool(np.array_equal(B['p'][other], init[other]))      # the other rank's shard of the master was never touched here
+    for k in ('p', 'm', 'v'):
+        t = torch.from_numpy(B[k][n_c + n_dm:].copy())
+        parallel.all_gather_(t)
+        B[k][n_c + n_dm:] = t.numpy()
+    same = all(bool(np.array_equal(A[k], B[k])) for k in ('p', 'm', 'v', 'h'))
+    wire = L.wire_bytes()
+    return same_half, stale_before, same, (A['step'], A['scale'], A['skipped']), (B['step'], B['scale'], B['skipped']), wire
+
+
+def test_sharded_optimizer_step_is_bit_identical_to_the_replicated_one():
+    out = _run(_t_sharded_step)
+    for r in (0, 1):
+        same_half, stale_before, same, a, b, wire = out[r]
+        assert same_half and stale_before and same
+        assert a == b == (4, 256.0, 1)        # two clean steps grow the scale to 256, the overflow halves it and skips the step, two clean steps grow it again
+    assert out[0][5] == out[1][5]
+    w = out[0][5]
+    assert w['reduce_scatter'] == 4096 * 4 // 2 and w['all_gather'] == 4096 * 2 // 2 and w['adam_elements_per_rank'] == 96 + 64 + 2048
+
+
+def test_sharded_layout_at_the_instant_ngp_sizes():
+    """The shipped InstantNGP configuration at 8 ranks: what leaves a GPU per iteration and how many elements its Adam touches."""
+    from nerficg_amd import parallel
+    L = parallel.ShardedStepLayout(7168, 3072, 12_196_240, rank=3, world=8)
+    assert L.sharded and L.shard == 1_524_530 and L.shard_begin == 3 * 1_524_530 and (L.off_density * 4) % 128 == 0 and (L.off_table * 4) % 128 == 0
+    w = L.wire_bytes()
+    assert w['reduce_scatter'] == 42_686_840 and w['all_gather'] == 21_343_420 and w['small_allreduce'] == int(2 * 7 / 8 * (7168 + 32 + 3072) * 4)
+    assert w['adam_elements_per_rank'] == 7168 + 3072 + 1_524_530            # 1.53 M instead of 12.2 M
+    replicated = parallel.ShardedStepLayout(7168, 3072, 12_196_240, rank=0, world=3)
+    assert not replicated.sharded and replicated.wire_bytes()['adam_elements_per_rank'] == 7168 + 3072 + 12_196_240

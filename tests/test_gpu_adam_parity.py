@@ -188,8 +188,8 @@ def test_load_state_dict_keeps_the_live_moment_tensors():
 
 
 def test_scaler_shared_by_two_optimizers_follows_torch_and_the_fused_step_refuses_a_second_one():
-    """nerficg_amd.amp.GradScaler(single_optimizer=False) around TWO FusedAdam optimizers: a clean step, an overflow in the second optimizer's gradients (both steps of
-    that iteration are skipped?  no -- torch skips per optimizer and backs the scale off once), then growth -- the same parameters, scale and step counts as
+    """nerficg_amd.amp.GradScaler(single_optimizer=False) around TWO FusedAdam optimizers: a clean step, an overflow in the second optimizer's gradients (torch
+    skips per optimizer and backs the scale off once), then growth -- the same parameters, scale and step counts as
     torch.amp.GradScaler.  The default scaler takes the fused step + update for the first optimizer of an iteration and raises when a second one follows."""
     from nerficg_amd.amp import GradScaler
     from nerficg_amd.apex_optimizers import FusedAdam
@@ -221,3 +221,54 @@ def test_scaler_shared_by_two_optimizers_follows_torch_and_the_fused_step_refuse
     np.testing.assert_array_equal(got[1], ref[1])
     with pytest.raises(RuntimeError, match='single_optimizer=False'):
         run(lambda: GradScaler(init_scale=128.0, growth_interval=2))
+
+
+@pytest.mark.parametrize('overflow', [False, True])
+def test_settle_plus_adam_slices_equal_the_one_call_step_bit_for_bit(overflow):
+    """C-ABI group 14 against group 8 on the SAME gradients: nrc_amp_adam_step on the mean of two ranks' gradients (what a replica does behind
+    parallel.allreduce_flat(average=True)) and nrc_amp_settle(divisor 2) + nrc_amp_adam_slices on their SUM, MLP weights and the two table shards as separate
+    launches (what the sharded ranks do between them): parameters, moments, fp16 copies, step counter, scale and growth tracker bit for bit -- also on an
+    overflow, where nothing but the scale may change."""
+    from nerficg_amd import _lib
+    lib, p = _lib.load(), _lib.ptr
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    n_mlp, n_t, n_c = 3072, 40_000, 7168
+    n_a = n_mlp + n_t
+    l2 = 2.0 * 0.5 / (n_mlp + n_c)
+
+    def state():
+        g2 = torch.Generator(device=DEV).manual_seed(9)
+        S = dict(pa=torch.randn(n_a, device=DEV, generator=g2), pb=torch.randn(n_c, device=DEV, generator=g2))
+        for k, n in (('a', n_a), ('b', n_c)):
+            S['m' + k], S['v' + k] = torch.rand(n, device=DEV, generator=g2) * 1e-3, torch.rand(n, device=DEV, generator=g2) * 1e-6
+            S['h' + k] = S['p' + k].half()
+        S.update(step=torch.full((1,), 3, dtype=torch.int32, device=DEV), bc=torch.zeros(2, device=DEV), scale=torch.full((1,), 128.0, device=DEV),
+                 tracker=torch.full((1,), 1, dtype=torch.int32, device=DEV), state4=torch.zeros(4, device=DEV), ticket=torch.zeros(17 * 16, dtype=torch.int32, device=DEV))
+        return S
+    g0a, g1a = torch.randn(n_a, device=DEV, generator=gen) * 128, torch.randn(n_a, device=DEV, generator=gen) * 128
+    g0b, g1b = torch.randn(n_c, device=DEV, generator=gen) * 128, torch.randn(n_c, device=DEV, generator=gen) * 128
+    if overflow:
+        g1a[n_mlp + 11] = float('inf')
+    hyper = (1e-2, None, 0.9, 0.99, 1e-15, 0.0, 0)
+    A = state()
+    mean_a, mean_b = ((g0a + g1a) / 2).contiguous(), ((g0b + g1b) / 2).contiguous()
+    _lib.check(lib.nrc_amp_adam_step(p(A['pa']), p(mean_a), p(A['ma']), p(A['va']), p(A['ha']), n_a, l2, n_mlp, p(A['pb']), p(mean_b), p(A['mb']), p(A['vb']), p(A['hb']), n_c, l2, n_c,
+                                     *hyper, p(A['step']), p(A['bc']), p(A['scale']), p(A['tracker']), 2.0, 0.5, 2, p(A['state4']), p(A['ticket']), None, _lib.stream_of(mean_a)), 'amp_adam_step')
+    B = state()
+    sum_a, sum_b = (g0a + g1a).contiguous(), (g0b + g1b).contiguous()
+    flag = torch.tensor([1.0 if overflow else 0.0], device=DEV)      # the sum of the ranks' producer flags
+    s = _lib.stream_of(sum_a)
+    _lib.check(lib.nrc_amp_settle(p(flag), 2.0, 0.9, 0.99, p(B['step']), p(B['bc']), p(B['scale']), p(B['tracker']), 2.0, 0.5, 2, p(B['state4']), None, s), 'amp_settle')
+    tail = (*hyper, p(B['bc']), p(B['state4']), s)
+    _lib.check(lib.nrc_amp_adam_slices(p(B['pa']), p(sum_a), p(B['ma']), p(B['va']), p(B['ha']), n_mlp, l2, n_mlp, p(B['pb']), p(sum_b), p(B['mb']), p(B['vb']), p(B['hb']), n_c, l2, n_c, *tail), 'slices')
+    at = lambda t, off: __import__('ctypes').c_void_p(t.data_ptr() + off * t.element_size())
+    half = n_t // 2
+    for shard in (1, 0):          # "rank 1" first: the order must not matter
+        b = n_mlp + shard * half
+        _lib.check(lib.nrc_amp_adam_slices(at(B['pa'], b), at(sum_a, b), at(B['ma'], b), at(B['va'], b), at(B['ha'], b), half, 0.0, 0, None, None, None, None, None, 0, 0.0, 0, *tail), 'slices')
+    torch.cuda.synchronize()
+    for k in ('pa', 'pb', 'ma', 'mb', 'va', 'vb', 'ha', 'hb', 'step', 'scale', 'tracker'):
+        assert torch.equal(A[k], B[k]), k
+    assert int(A['step']) == (3 if overflow else 4) and float(A['scale']) == (64.0 if overflow else 256.0)
+    fresh = state()
+    assert torch.equal(A['pa'], fresh['pa']) == overflow
