@@ -786,35 +786,59 @@ def dp_ingp_leg(model, renderer, cam, poses, rank, world, device, rays_per_rank=
     # flat gradient buffer, one reduce-scatter + all-gather between the backward pass and the step); N > 1 only -- at N = 1 it is `training.fused`
     fused_dp = None
     if world > 1:
-        it, built = None, None
-        try:
-            from nerficg_amd.amp import GradScaler as _GS
-            from nerficg_amd.ngp_trainer import FusedTrainingIteration
-            opt_f = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
-            it = FusedTrainingIteration(model, renderer, opt_f, _GS(init_scale=128.0, growth_interval=10 ** 9), cam, {'origin': origin, 'view_direction': vdir, 'rgb': target},
-                                        rays_per_rank, (int(1.15 * samples) + 4095) // 4096 * 4096, order=perm, seed=5)
-        except Exception as e:
-            built = repr(e)[:300]
-        # every rank enters the iterations (they hold a collective) or none does: a rank that failed to build must not leave the others waiting
-        n_failed = _max_over_ranks([0.0 if built is None else 1.0], device, world)[0]
-        try:
-            if n_failed:
-                raise RuntimeError(built or 'another rank failed to build the fused trainer')
-            for _ in range(3):
-                it()
-            torch.cuda.synchronize(); dist.barrier(); t0 = time.perf_counter()
-            for _ in range(3 * iters):
-                out_f = it()
-            torch.cuda.synchronize(); dist.barrier()
-            dt_f = _max_over_ranks([(time.perf_counter() - t0) / (3 * iters)], device, world)[0]
-            drift_f = _replica_drift(torch.cat([p.detach().reshape(-1) for p in params]), world)
-            fused_dp = {'ms_per_iteration': round(dt_f * 1e3, 3), 'rays_per_iteration': n_global, 'mrays_per_s': round(n_global / dt_f / 1e6, 3),
-                        'replica_drift': drift_f, 'samples_cut': int(out_f['sample_overflow'])}
-        except Exception as e:   # an extra leg must never take the line down
-            fused_dp = {'error': repr(e)[:300]}
-        with torch.no_grad():
-            for p, q in zip(model.parameters(), saved):
-                p.copy_(q)
+        from nerficg_amd.amp import GradScaler as _GS
+        from nerficg_amd.ngp_trainer import FusedTrainingIteration
+
+        def fused_leg(sharded):
+            """sharded=True: round 6's step (small all-reduce beside the grid backward, in-place reduce-scatter, Adam on the rank's shard, all-gather of the fp16
+            table, next batch marched beside the collective); False: round 5's (one flat reduce-scatter + all-gather of the f32 gradient, Adam on everything)."""
+            it, built = None, None
+            try:
+                opt_f = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
+                it = FusedTrainingIteration(model, renderer, opt_f, _GS(init_scale=128.0, growth_interval=10 ** 9), cam, {'origin': origin, 'view_direction': vdir, 'rgb': target},
+                                            rays_per_rank, (int(1.15 * samples) + 4095) // 4096 * 4096, order=perm, seed=5, sharded=sharded, dp_timing=bool(sharded))
+            except Exception as e:
+                built = repr(e)[:300]
+            # every rank enters the iterations (they hold a collective) or none does: a rank that failed to build must not leave the others waiting
+            n_failed = _max_over_ranks([0.0 if built is None else 1.0], device, world)[0]
+            try:
+                if n_failed:
+                    raise RuntimeError(built or 'another rank failed to build the fused trainer')
+                for _ in range(3):
+                    it()
+                it.dp_times()
+                torch.cuda.synchronize(); dist.barrier(); t0 = time.perf_counter()
+                for _ in range(3 * iters):
+                    out_f = it()
+                torch.cuda.synchronize(); dist.barrier()
+                dt_f = _max_over_ranks([(time.perf_counter() - t0) / (3 * iters)], device, world)[0]
+                times = it.dp_times()
+                it.gather_state()
+                drift_f = _replica_drift(torch.cat([p.detach().reshape(-1) for p in params]), world)
+                half_drift = _replica_drift(model.encoding_xyz._half_params().float(), world)
+                leg = {'ms_per_iteration': round(dt_f * 1e3, 3), 'rays_per_iteration': n_global, 'mrays_per_s': round(n_global / dt_f / 1e6, 3),
+                       'replica_drift': drift_f, 'fp16_table_drift': half_drift, 'samples_cut': int(out_f['sample_overflow']), 'sharded_step': bool(it.sharded),
+                       'next_batch_marched_beside': it.prefetch_at if it.prefetch_default else None}
+                wire = it.layout.wire_bytes()
+                if it.sharded:
+                    tm = _max_over_ranks([times['reduce_scatter_ms'], times['adam_ms'], times['all_gather_ms'], times['exposed_ms']], device, world)
+                    leg.update(wire_bytes_per_gpu=wire['total'], wire=wire, adam_elements_per_rank=wire['adam_elements_per_rank'],
+                               collective_ms=round(tm[0] + tm[2], 4), reduce_scatter_ms=round(tm[0], 4), sharded_adam_ms=round(tm[1], 4), all_gather_ms=round(tm[2], 4),
+                               exposed_ms=round(tm[3], 4), exposed_note='end of the backward pass (and of the small all-reduce) -> the main stream continues: reduce-scatter + settle + Adam + all-gather')
+                else:
+                    n_all = it.grads.numel()
+                    leg.update(wire_bytes_per_gpu=int(2 * (world - 1) / world * n_all * 4), adam_elements_per_rank=n_all - it.aux.numel())
+                if drift_f != 0.0 or half_drift != 0.0:
+                    leg['error'] = f'replicas drifted: parameters {drift_f:.3e}, fp16 table {half_drift:.3e}'
+                return leg
+            except Exception as e:   # an extra leg must never take the line down
+                return {'error': repr(e)[:300]}
+            finally:
+                with torch.no_grad():
+                    for p, q in zip(model.parameters(), saved):
+                        p.copy_(q)
+        fused_dp = fused_leg(True)
+        fused_dp['replicated_step'] = fused_leg(False)
     return {'fused_trainer': fused_dp, 'ms_per_iteration': round(dt * 1e3, 3), 'rays_per_iteration': n_global, 'samples_per_iteration_per_gpu': round(samples), 'mrays_per_s': round(n_global / dt / 1e6, 3),
             'collective': f'one flat f32 bucket, {"all_reduce" if dist.get_backend() == "gloo" else "reduce-scatter + all-gather"} over {dist.get_backend()}' if world > 1 else None, 'bytes_reduced_per_iteration': nbytes if world > 1 else 0,
             'collective_ms': round(coll, 3) if world > 1 else None,

@@ -178,7 +178,7 @@ def test_fused_trainer_data_parallel_path_on_a_one_rank_group():
 
 
 TWO_RANK_CHILD = r'''
-import hashlib, json, os, sys
+import copy, hashlib, json, os, sys
 sys.path.insert(0, os.environ['NRC_ROOT'])
 import torch
 from nerficg_amd import parallel
@@ -188,7 +188,7 @@ rank, world = parallel.init_distributed('gloo')
 from tests.test_gpu_ngp_trainer import _fused, _pool
 from tests.test_gpu_graphs import _train_pair
 from tests.noise import mismatch_fraction
-cam, pool = _pool(size=96)
+cam, pool = _pool(size=128)      # 16 384 rays: eight global batches of 2 x 1 024
 order = torch.randperm(pool['origin'].shape[0], generator=torch.Generator().manual_seed(4)).to(dev)
 POISON_AT = 2
 
@@ -214,7 +214,7 @@ def run(sharded, iterations=5, resume=None):
     torch.cuda.synchronize()
     params = [p.detach().clone() for p in model.parameters()]
     moments = [opt.state[p][k].clone() for p in model.parameters() for k in ('exp_avg', 'exp_avg_sq')]
-    ckpt = dict(model={k: v.clone() for k, v in model.state_dict().items()}, optimizer=opt.state_dict(), scaler=scaler.state_dict(), cursor=int(it.cursor), rng=it.rng.clone())
+    ckpt = dict(model={k: v.clone() for k, v in model.state_dict().items()}, optimizer=copy.deepcopy(opt.state_dict()), scaler=scaler.state_dict(), cursor=int(it.cursor), rng=it.rng.clone())      # (state_dict() hands out the LIVE moment tensors)
     return dict(it=it, trace=trace, params=params, moments=moments, ckpt=ckpt, stale=stale, half=model.encoding_xyz._half_params().clone(), wire=it.layout.wire_bytes())
 
 
