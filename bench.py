@@ -873,12 +873,15 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=8):
     pose_of = lambda i: torch.from_numpy(np.asarray(scenes.orbit_pose(0.8 + 0.7 * (i * world + rank), 0.35, 4.5), dtype=np.float32)).to(device)  # noqa: E731
     poses_dev = [pose_of(i) for i in range(2 + iters)]
 
+    exchange = parallel.UnionRowExchange(n_gaussians, device)
+
     def step(i, timed):
         out = render_image_training(g, cam, poses_dev[i])
+        exchange.begin(out['visibility_mask'])      # mask max-reduce + device compaction + count to the host, beside the backward pass
         training_loss(out['rgb'], target).backward()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        n_union = parallel.sparse_allreduce_gradients(params, out['visibility_mask'], average=True)
+        n_union = exchange.finish(params, average=True)   # pack (1 launch) -> reduce-scatter + all-gather -> unpack (1 launch)
         b.record()
         g.optimizer.step(); g.optimizer.zero_grad()
         if timed:
@@ -926,7 +929,8 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=8):
                    'span_capacity': caps[1], 'max_instances_seen': worst[0], 'max_spans_seen': worst[1],
                    'dropped': bool(worst[0] > caps[0] or worst[1] > caps[1]), 'includes': 'densification statistics (nrc_gs_densify_stats)'}
     return {'hip_graph': graphed, 'ms_per_step': round(dt * 1e3, 3), 'views_per_step': world, 'gaussians': n_gaussians, 'msplats_per_s': round(world * n_gaussians / dt / 1e6, 1),
-            'collective': f'max-reduce of the visibility mask + reduction of the union rows over {dist.get_backend()}' if world > 1 else None,
+            'collective': f'max-reduce of the visibility mask beside the backward pass (device compaction, count read under it) + one packed reduction of the union rows over {dist.get_backend()}' if world > 1 else None,
+            'wire_bytes_per_gpu': int(2 * (world - 1) / world * nbytes + (world - 1) / world * 2 * n_gaussians) if world > 1 else 0,
             'union_rows_per_step': round(union_rows), 'bytes_reduced_per_step': nbytes if world > 1 else 0, 'collective_ms': round(coll, 3) if world > 1 else None,
             'bus_GBps_per_gpu': round(2 * (world - 1) / world * nbytes / (coll * 1e-3) / 1e9, 1) if world > 1 and coll > 0 else None, 'replica_drift': drift}
 

@@ -551,6 +551,8 @@ int nrc_knn3_mean_sq_dist(const float* points_morton_sorted, int64_t n, float* o
  *                          (prune / extend / sort of src/Optim/adam_utils.py:21-98 for every group and both Adam moments at once);
  *                          tensors with zero_new[t] != 0 get zeros in rows with kind[o] != 0 (the moments of new Gaussians).  in, out,
  *                          row_floats, zero_new are HOST arrays of n_tensors entries; kind may be NULL (pure permutation / prune).
+ *   nrc_scatter_rows     : the inverse for a list of distinct rows: out[t][dst[r], :] = in[t][r, :], r < n_in (the reduced union rows of a view-parallel
+ *                          step go back into the gradient tensors: nerficg_amd.parallel.UnionRowExchange; no reference counterpart).
  *   nrc_compact_mask     : indices[0..*count) = ascending positions where mask != 0 (u8); workspace nrc_compact_mask_ws_bytes(n).
  * ===================================================================================================== */
 int nrc_gs_densify_stats(const float* viewspace_grad, int32_t ld, const int32_t* radii, int64_t P, float* grad_accum,
@@ -564,6 +566,8 @@ int nrc_gs_densify_split_children(const int32_t* src, const int32_t* kind, const
                                   float* log_scales_out, nrc_stream_t stream);
 int nrc_gather_rows(const float* const* in, float* const* out, const int32_t* row_floats, const int32_t* zero_new, int32_t n_tensors,
                     const int32_t* src, const int32_t* kind, int64_t n_out, nrc_stream_t stream);
+int nrc_scatter_rows(const float* const* in, float* const* out, const int32_t* row_floats, int32_t n_tensors, const int32_t* dst, int64_t n_in,
+                     nrc_stream_t stream);
 int64_t nrc_compact_mask_ws_bytes(int64_t n);
 int nrc_compact_mask(const uint8_t* mask, int64_t n, int32_t* indices, int32_t* count, void* workspace, nrc_stream_t stream);
 

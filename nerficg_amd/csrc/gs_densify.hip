@@ -230,6 +230,20 @@ __global__ void __launch_bounds__(256) k_gather_rows(GatherSet s, const int* __r
     }
 }
 
+// the inverse of k_gather_rows for a list of DISTINCT rows: out[t][dst[r], :] = in[t][r, :] (unpacking the reduced union rows of a view-parallel step)
+__global__ void __launch_bounds__(256) k_scatter_rows(GatherSet s, const int* __restrict__ dst, int64_t n_in) {
+    const int t = blockIdx.y;
+    const int row = s.row[t];
+    const float* __restrict__ in = s.in[t];
+    float* __restrict__ out = s.out[t];
+    const int64_t total = n_in * row;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / row;
+        const int c = (int)(e - r * row);
+        out[(int64_t)dst[r] * row + c] = in[e];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_split_children(const int* __restrict__ src, const int* __restrict__ kind, const int* __restrict__ aux, int64_t n_out,
                                                         const float* __restrict__ positions, const float* __restrict__ log_scales,
                                                         const float* __restrict__ rotations, const float* __restrict__ noise,
@@ -330,6 +344,27 @@ int nrc_gather_rows(const float* const* in, float* const* out, const int32_t* ro
     if (bx > 65535 * 16) bx = 65535 * 16;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, s, src, kind, n_out);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_scatter_rows(const float* const* in, float* const* out, const int32_t* row_floats, int32_t n_tensors, const int32_t* dst, int64_t n_in,
+                     nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n_tensors < 0 || n_tensors > GATHER_MAX || n_in < 0) return NRC_ERR_INVALID;
+    if (n_tensors == 0 || n_in == 0) return NRC_OK;
+    if (!in || !out || !row_floats || !dst) return NRC_ERR_INVALID;
+    GatherSet s{};
+    int max_row = 1;
+    for (int t = 0; t < n_tensors; t++) {
+        if (!in[t] || !out[t] || row_floats[t] < 1) return NRC_ERR_INVALID;
+        s.in[t] = in[t]; s.out[t] = out[t]; s.row[t] = row_floats[t]; s.zero_new[t] = 0;
+        if (row_floats[t] > max_row) max_row = row_floats[t];
+    }
+    int64_t bx = nrc_cdiv(n_in * max_row, 256 * 4);
+    if (bx > 65535 * 16) bx = 65535 * 16;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, s, dst, n_in);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

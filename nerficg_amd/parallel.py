@@ -33,7 +33,7 @@ from .amp import GradScaler as _FastGradScaler
 __all__ = ['init_distributed', 'world_info', 'shard_ray_ids', 'shard_range', 'allreduce_flat', 'allreduce_gradients',
            'all_gather_pixels', 'tile_pixel_indices', 'gather_image_shards', 'broadcast_parameters', 'sparse_allreduce_gradients', 'allreduce_densification_stats', 'synchronized_noise',
            'allreduce_scalars', 'DataParallelGradScaler', 'rays_per_batch_update', 'single_rank_collectives', 'ShardedStepLayout', 'allreduce_sum_',
-           'reduce_scatter_sum_', 'all_gather_', 'sharded_step']
+           'reduce_scatter_sum_', 'all_gather_', 'sharded_step', 'UnionRowExchange']
 
 
 _SINGLE_RANK_COLLECTIVES = False
@@ -360,40 +360,140 @@ def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0) -> None:
         dist.broadcast(p.data if isinstance(p, torch.nn.Parameter) else p, src)
 
 
-def sparse_allreduce_gradients(params: Iterable[torch.nn.Parameter], visible: torch.Tensor, average: bool = True) -> int:
-    """View-parallel 3DGS: sums (averages) the per-Gaussian gradients of `params` (each (P, ...)) over all ranks, moving only
-    the rows that are visible on at least one rank.  `visible`: this rank's (P,) boolean mask (radii > 0); rows outside it must have zero
-    gradient here (the rasterizer backward guarantees that).  Protocol: one all-reduce (max) of the byte mask -> the same ascending
-    union index list on every rank -> the union rows of all tensors packed into ONE flat buffer -> reduce-scatter + all-gather ->
-    unpack.  Payload: n_union x 236 B instead of P x 236 B (59 floats per Gaussian).  Returns n_union (-1 in a single-process run)."""
-    rank, world = world_info()
-    params = list(params)
-    if _no_collective(world):
-        return -1  # nothing travels; the count of visible rows would cost a host read per step
-    # world > 1: EVERY rank enters both collectives whatever it holds -- a rank whose view produced no gradient (p.grad is None) contributes
-    # zero rows of the right width and receives the others' sum; an early return here would leave the other ranks waiting in the all-reduce
-    P = visible.shape[0]
-    union = visible.to(torch.uint8).contiguous()
-    dist.all_reduce(union, op=dist.ReduceOp.MAX)
-    idx = torch.nonzero(union, as_tuple=False).flatten()
-    n = idx.numel()
-    if n == 0 or not params:   # the same decision on every rank: the union and the parameter list are identical everywhere
+class UnionRowExchange:
+    """View-parallel 3DGS: the per-Gaussian gradients of `params` (each (P, ...)) are summed (averaged) over the ranks, moving only the rows
+    some rank saw.  Two calls per step, shaped so that nothing waits for the wire or the host that does not have to:
+
+        begin(visible)    right after the forward pass (radii are known, the backward pass is not enqueued yet), on a communication stream:
+                          max-all-reduce of the byte visibility mask -> nrc_compact_mask (device scan: the same ascending union list on every rank) ->
+                          the count goes to pinned host memory behind an event.  The caller now enqueues the backward pass; mask traffic and scan run beside it.
+        finish(params)    behind the backward pass: the host reads the count (the device is busy with the backward pass meanwhile -- the read that used to
+                          stall the step, torch.nonzero, sat between backward and collective), nrc_gather_rows packs the union rows of ALL tensors into one
+                          flat buffer in ONE launch (tensor-major: n rows of tensor 0, n rows of tensor 1, ...), reduce-scatter + all-gather
+                          (allreduce_flat), nrc_scatter_rows puts them back in ONE launch.  Rows outside the union keep their (zero) gradient.
+
+    Payload: n_union x 236 B instead of P x 236 B.  Every rank enters both collectives whatever it holds: a rank without gradients contributes zero rows.
+    Adam stays replicated here: a row's moments would have to live with a fixed owner while the union changes every step, and shipping the updated
+    parameters of the owner's rows costs what the all-gather of the reduced gradients costs."""
+
+    def __init__(self, n_rows: int, device) -> None:
+        from . import _lib
+        self.P, self.dev = int(n_rows), torch.device(device)
+        self._cuda = self.dev.type == 'cuda'
+        self.union = torch.zeros(self.P, dtype=torch.uint8, device=self.dev)
+        self.n: int | None = None
+        if self._cuda:
+            lib = _lib.load()
+            self.idx = torch.empty(self.P, dtype=torch.int32, device=self.dev)
+            self.count = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self.ws = torch.empty(int(lib.nrc_compact_mask_ws_bytes(self.P)), dtype=torch.uint8, device=self.dev)
+            self.count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self.comm = torch.cuda.Stream(device=self.dev)
+            self.ready = torch.cuda.Event()
+            self.packed = None
+
+    def begin(self, visible: torch.Tensor) -> None:
+        rank, world = world_info()
+        if visible.shape[0] != self.P:
+            raise RuntimeError(f'UnionRowExchange: visibility mask with {visible.shape[0]} rows, built for {self.P}')
+        self.n = None
+        if _no_collective(world):
+            self.n = -1
+            return
+        if not self._cuda:      # CPU tensors (the gloo tests): the same protocol with torch ops
+            self.union.copy_(visible.to(torch.uint8))
+            dist.all_reduce(self.union, op=dist.ReduceOp.MAX)
+            self.idx = torch.nonzero(self.union, as_tuple=False).flatten().to(torch.int32)
+            self.n = int(self.idx.numel())
+            return
+        from . import _lib
+        main = torch.cuda.current_stream(self.dev)
+        self.comm.wait_stream(main)
+        visible.record_stream(self.comm)
+        with torch.cuda.stream(self.comm):
+            self.union.copy_(visible)                      # bool -> u8
+            if _staged(self.union):
+                host = self.union.cpu(); dist.all_reduce(host, op=dist.ReduceOp.MAX); self.union.copy_(host)
+            else:
+                dist.all_reduce(self.union, op=dist.ReduceOp.MAX)
+            _lib.check(_lib.load().nrc_compact_mask(_lib.ptr(self.union), self.P, _lib.ptr(self.idx), _lib.ptr(self.count), _lib.ptr(self.ws),
+                                                    _lib.stream_of(self.union)), 'compact_mask')
+            self.count_host.copy_(self.count, non_blocking=True)
+            self.ready.record(self.comm)
+
+    def finish(self, params: Iterable[torch.nn.Parameter], average: bool = True) -> int:
+        params = list(params)
+        if self.n == -1:
+            return -1
+        if self.n is None:
+            if not self._cuda:
+                raise RuntimeError('UnionRowExchange.finish() without begin()')
+            self.ready.synchronize()
+            self.n = int(self.count_host[0])
+            torch.cuda.current_stream(self.dev).wait_stream(self.comm)
+        n = self.n
+        if n == 0 or not params:   # the same decision on every rank: the union and the parameter list are identical everywhere
+            return n
+        rows, widths = [], []
+        for p in params:
+            if p.shape[0] != self.P:
+                raise RuntimeError(f'UnionRowExchange: parameter with {p.shape[0]} rows, visibility mask has {self.P}')
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            if not p.grad.is_contiguous():
+                raise RuntimeError('UnionRowExchange expects contiguous gradients')
+            rows.append(p.grad.reshape(self.P, -1))
+            widths.append(rows[-1].shape[1])
+        total = sum(widths)
+        if not self._cuda:
+            idx = self.idx.long()
+            packed = torch.cat([r[idx].reshape(-1) for r in rows])
+            allreduce_flat(packed, average)
+            off = 0
+            for r, w in zip(rows, widths):
+                r[idx] = packed[off:off + n * w].view(n, w)
+                off += n * w
+            return n
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        if self.packed is None or self.packed.numel() < n * total:
+            self.packed = torch.empty(max(n * total, self.P * total // 2), dtype=torch.float32, device=self.dev)      # grows to the largest union seen
+        packed = self.packed[:n * total]
+        k = len(rows)
+        offs = [0]
+        for w in widths:
+            offs.append(offs[-1] + n * w)
+        a_grad = (ctypes.c_void_p * k)(*[r.data_ptr() for r in rows])
+        a_pack = (ctypes.c_void_p * k)(*[packed.data_ptr() + 4 * offs[t] for t in range(k)])
+        a_row = (ctypes.c_int32 * k)(*widths)
+        a_zero = (ctypes.c_int32 * k)(*([0] * k))
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        s = _lib.stream_of(packed)
+        _lib.check(lib.nrc_gather_rows(cast(a_grad), cast(a_pack), cast(a_row), cast(a_zero), k, _lib.ptr(self.idx), None, n, s), 'gather_rows')
+        if _staged(packed):
+            host = packed.cpu(); allreduce_flat(host, average); packed.copy_(host)
+        else:
+            allreduce_flat(packed, average)
+        _lib.check(lib.nrc_scatter_rows(cast(a_pack), cast(a_grad), cast(a_row), k, _lib.ptr(self.idx), n, s), 'scatter_rows')
         return n
-    rows = []
-    for p in params:
-        if p.shape[0] != P:
-            raise RuntimeError(f'sparse_allreduce_gradients: parameter with {p.shape[0]} rows, visibility mask has {P}')
-        if p.grad is None:
-            p.grad = torch.zeros_like(p)
-        rows.append(p.grad.reshape(P, -1))
-    packed = torch.cat([r[idx] for r in rows], dim=1).contiguous()  # (n_union, 59)
-    allreduce_flat(packed.view(-1), average)
-    off = 0
-    for r in rows:
-        w = r.shape[1]
-        r[idx] = packed[:, off:off + w]
-        off += w
-    return n
+
+
+def sparse_allreduce_gradients(params: Iterable[torch.nn.Parameter], visible: torch.Tensor, average: bool = True, exchange: UnionRowExchange | None = None) -> int:
+    """UnionRowExchange.begin + finish back to back (callers that cannot split the two around their backward pass).  `visible`: this rank's (P,) boolean
+    mask (radii > 0); rows outside it must have zero gradient here (the rasterizer backward guarantees that).  Returns n_union (-1 in a single-process run).
+    `exchange`: a UnionRowExchange to reuse (its buffers are sized once); by default one is kept per (P, device)."""
+    key = (int(visible.shape[0]), str(visible.device))
+    ex = exchange or _EXCHANGES.get(key)
+    if ex is None:
+        ex = _EXCHANGES[key] = UnionRowExchange(visible.shape[0], visible.device)
+        while len(_EXCHANGES) > 4:
+            _EXCHANGES.pop(next(iter(_EXCHANGES)))
+    ex.begin(visible)
+    return ex.finish(params, average)
+
+
+_EXCHANGES: dict = {}
 
 
 def allreduce_scalars(sums: Iterable[torch.Tensor] = (), flags: Iterable[torch.Tensor] = ()) -> tuple[list[torch.Tensor], list[torch.Tensor]]:
