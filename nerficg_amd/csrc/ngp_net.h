@@ -96,6 +96,63 @@ __device__ __forceinline__ h8 acc_to_frag(const f16v& acc, int g) {
 
 #define NRC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
+// ---- 16-row output layers on v_mfma_f32_16x16x32_f16 (round 6) ------------------------------------------------------------------------------------
+// A 16-neuron head (density features, rgb) run as a 32-row tile spends half of its matrix passes on padding rows.  The 16x16x32 form has no padding:
+// A = W (16 neurons x 32 k), B = activations (32 k x 16 samples), D = 16 x 16 f32 with lane l holding column (sample) l&15, rows 4 (l>>4) + reg.
+// Its operands want lane l = 16 kg + n to hold k-slots 8 kg .. 8 kg + 7 of sample n, while the 64-wide layer in front leaves lane 32 hh + r with values of
+// sample r.  In units of 16-lane rows the wave holds [samples 0-15 | 16-31 | 0-15 | 16-31] (hh = 0, 0, 1, 1); v_permlane16_swap_b32 X, Y swaps the odd rows
+// of X with the even rows of Y:  X' = [X0 Y0 X2 Y2],  Y' = [X1 Y1 X3 Y3]  -- X' holds samples 0-15 in all four rows, Y' samples 16-31: the B operands of
+// the two 16-sample blocks, k-groups (X hh=0, Y hh=0, X hh=1, Y hh=1).  One swap per dword pair, the k order is folded into the weight fragment.
+typedef float f4v __attribute__((ext_vector_type(4)));
+#define NRC_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+// H[0..3]: the four ACC-order fragments of a 64-wide layer (H[2 mt + gq]).  B[nb][ks]: block nb (samples 16 nb ..), k-step ks (neurons 32 ks ..).
+__device__ __forceinline__ void head_split(const h8 (&H)[4], h8 (&B)[2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+        const uint4 x = *reinterpret_cast<const uint4*>(&H[2 * ks]), y = *reinterpret_cast<const uint4*>(&H[2 * ks + 1]);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+        const auto s2 = __builtin_amdgcn_permlane16_swap(x.z, y.z, false, false);
+        const auto s3 = __builtin_amdgcn_permlane16_swap(x.w, y.w, false, false);
+        const uint4 a = make_uint4(s0[0], s1[0], s2[0], s3[0]), b = make_uint4(s0[1], s1[1], s2[1], s3[1]);
+        B[0][ks] = *reinterpret_cast<const h8*>(&a);
+        B[1][ks] = *reinterpret_cast<const h8*>(&b);
+    }
+}
+// the A fragment that goes with head_split: W row-major [n_rows <= 16][ld], k-step ks; lane l = 16 kg + m, element e <-> neuron
+// 32 ks + (e & 3) + 8 (2 (kg & 1) + (e >> 2)) + 4 (kg >> 1)   (the ACC order of fragment H[2 ks + (kg & 1)], lane half kg >> 1)
+__device__ __forceinline__ h8 load_w_head_frag(const __half* __restrict__ W, int ld, int n_rows, int ks, int lane) {
+    h8 f;
+    const int m = lane & 15, kg = lane >> 4;
+    const _Float16* p = reinterpret_cast<const _Float16*>(W) + (size_t)m * ld;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int k = 32 * ks + (e & 3) + 8 * (2 * (kg & 1) + (e >> 2)) + 4 * (kg >> 1);
+        f[e] = m < n_rows ? p[k] : (_Float16)0.f;
+    }
+    return f;
+}
+// two head accumulators (blocks 0 and 1: lane 16 kg + n holds neurons 4 kg .. 4 kg + 3 of sample 16 nb + n) -> fp16, back on the sample's own lanes:
+// lane 32 hh + r receives neurons 8 hh .. 8 hh + 7 of sample r -- the NATURAL-order B fragment of a 16-wide k-step of the 32x32x16 form.
+__device__ __forceinline__ h8 head_join(const f4v& o0, const f4v& o1) {
+    const h2 p00 = {(_Float16)o0[0], (_Float16)o0[1]}, p01 = {(_Float16)o0[2], (_Float16)o0[3]};
+    const h2 p10 = {(_Float16)o1[0], (_Float16)o1[1]}, p11 = {(_Float16)o1[2], (_Float16)o1[3]};
+    const auto s0 = __builtin_amdgcn_permlane16_swap(*reinterpret_cast<const uint32_t*>(&p00), *reinterpret_cast<const uint32_t*>(&p10), false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(*reinterpret_cast<const uint32_t*>(&p01), *reinterpret_cast<const uint32_t*>(&p11), false, false);
+    const uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    return *reinterpret_cast<const h8*>(&v);
+}
+// neurons 0..2 of the two blocks (k-group 0: lanes 0-15 of each accumulator) as f32 on the sample's own lane (lanes 0-31): three swaps, so that the
+// sigmoid runs ONCE per sample on three values instead of on both accumulators
+__device__ __forceinline__ void head_join_rgb(const f4v& o0, const f4v& o1, float (&rgb)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(o0[c]), __float_as_uint(o1[c]), false, false);
+        rgb[c] = __uint_as_float(s[0]);      // [o0 row 0 | o1 row 0 | ...]: lane r < 32 holds sample r
+    }
+}
+
 // ---- hash-grid encoding of one sample for one level -> (f0, f1) --------------------------------------------------
 // Entry index of a corner.  Dense levels: x + y*res + z*res^2, wrapped once at `size` (inputs in [0,1] never exceed
 // 2*size; anything beyond is clamped into the level so that the gather stays in bounds).  Hashed levels: the spatial hash

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
     const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
 
-    h8 A0[2][2], AH[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1][2][4], AO[4];
+    h8 A0[2][2], AH[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1][2][4], AO[2];
     const __half* Wp = W;
 #pragma unroll
     for (int mt = 0; mt < 2; mt++)
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
         Wp += 64 * 64;
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++) AO[s] = load_w_frag<true>(Wp, 64, n_out_rows, 0, s, r, hh);
+    for (int s = 0; s < 2; s++) AO[s] = load_w_head_frag(Wp, 64, n_out_rows, s, lane);   // 16-row output layer: v_mfma_f32_16x16x32_f16 (ngp_net.h), as in k_ngp_mlp
 
     // The raw inputs of a tile (two 16-byte vectors, or a direction + one vector) are requested ONE TILE AHEAD: a training batch is 4-16 tiles per
     // wave, and without it every tile began with an exposed memory round trip in front of its MFMA chain (round 3: the same finding as in k_ngp_mlp).
@@ -165,20 +165,23 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
                     for (int s = 0; s < 4; s++) acc[mt] = NRC_MFMA(AH[l][mt][s], H[s], acc[mt]);
             }
         }
-        f16v o = zero16();
+        h8 HB[2][2];
+        head_split(H, HB);
+        f4v o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) o = NRC_MFMA(AO[s], H[s], o);
+        for (int s = 0; s < 2; s++) { o0 = NRC_MFMA16(AO[s], HB[0][s], o0); o1 = NRC_MFMA16(AO[s], HB[1][s], o1); }
+        if constexpr (OUT_ACT == ACT_SIGMOID) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { o0[j] = 1.f / (1.f + expf(-o0[j])); o1[j] = 1.f / (1.f + expf(-o1[j])); }
+        }
+        const h8 ov = head_join(o0, o1);     // element j = output neuron 8 hh + j of this lane's sample
         if (valid) {
             h4 lo, hi;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float a = o[j], b = o[4 + j];
-                if constexpr (OUT_ACT == ACT_SIGMOID) { a = 1.f / (1.f + expf(-a)); b = 1.f / (1.f + expf(-b)); }
-                lo[j] = (_Float16)a; hi[j] = (_Float16)b;
-            }
+            for (int j = 0; j < 4; j++) { lo[j] = ov[j]; hi[j] = ov[4 + j]; }
             _Float16* p = reinterpret_cast<_Float16*>(out) + i * out_ld;
-            if (4 * hh < n_store) *reinterpret_cast<h4*>(p + 4 * hh) = lo;
-            if (8 + 4 * hh < n_store) *reinterpret_cast<h4*>(p + 8 + 4 * hh) = hi;
+            if (8 * hh < n_store) *reinterpret_cast<h4*>(p + 8 * hh) = lo;
+            if (8 * hh + 4 < n_store) *reinterpret_cast<h4*>(p + 8 * hh + 4) = hi;
             if constexpr (ENC == ENC_DIR_H) {
                 if (sigmas_f32 && hh == 0) {
                     sigmas_f32[i] = expf((float)B[1][0]);   // B[1] of lane half 0 = density outputs 0-7 of this sample, as stored (fp16)
@@ -508,12 +511,12 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
     for (int f = threadIdx.x >> 6; f < N_FRAG; f += 4) {
         h8 v;
         if (f < F_DO) v = load_w_frag<false>(Wd, 32, 64, (f - F_D0) >> 1, (f - F_D0) & 1, r, hh);
-        else if (f < F_C0) v = load_w_frag<true>(Wd + 64 * 32, 64, 16, 0, f - F_DO, r, hh);
+        else if (f < F_C0) v = load_w_head_frag(Wd + 64 * 32, 64, 16, (f - F_DO) & 1, lane);     // 16-row head: two 16x16x32 k-steps (slots F_DO + 2, + 3 unused)
         else if (f < F_C1) {
-            const int mt = (f - F_C0) >> 1, s = (f - F_C0) & 1;  // k-step 0 = SH coefficients (natural), 1 = density features (ACC order)
-            v = s == 0 ? load_w_frag<false>(Wc, 32, 64, mt, 0, r, hh) : load_w_frag<true>(Wc, 32, 64, mt, 1, r, hh);
+            const int mt = (f - F_C0) >> 1, s = (f - F_C0) & 1;  // k-step 0 = SH coefficients, 1 = density features: both natural order (head_join)
+            v = load_w_frag<false>(Wc, 32, 64, mt, s, r, hh);
         } else if (f < F_CO) v = load_w_frag<true>(Wc + 64 * 32, 64, 64, (f - F_C1) >> 2, (f - F_C1) & 3, r, hh);
-        else v = load_w_frag<true>(Wc + 64 * 32 + 64 * 64, 64, 16, 0, f - F_CO, r, hh);
+        else v = load_w_head_frag(Wc + 64 * 32 + 64 * 64, 64, 16, (f - F_CO) & 1, lane);
         wlds[f][lane] = v;
     }
     __syncthreads();
@@ -663,7 +666,9 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
         // first-layer B fragments straight from the encoder's fragment-major records (512 contiguous bytes per half wave);
         // element (2q, 2q+1) of k-step s <- features of level 8s + 4hh + q
         h8 B[NT][2], X[NT][2], H[NT][4];
-        f16v acc[NT][2], o[NT];
+        f16v acc[NT][2];
+        h8 HB[NT][2][2];      // head operands: [sample block][k-step] (head_split)
+        f4v o[NT][2];         // head accumulators, one per 16-sample block
 #pragma unroll
         for (int u = 0; u < NT; u++) {
             B[u][0] = *reinterpret_cast<const h8*>(&cur[u].b0);
@@ -675,7 +680,8 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
                 sh4_fragments(cur[u].dx, cur[u].dy, cur[u].dz, lo, hi);
                 X[u][0] = hh ? hi : lo;
             }
-            acc[u][0] = zero16(); acc[u][1] = zero16(); o[u] = zero16();
+            acc[u][0] = zero16(); acc[u][1] = zero16();
+            o[u][0] = f4v{0.f, 0.f, 0.f, 0.f}; o[u][1] = o[u][0];
         }
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
@@ -686,21 +692,26 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
                 for (int u = 0; u < NT; u++) acc[u][mt] = mlp_mfma(w, B[u][s], acc[u][mt]);
             }
 #pragma unroll
-        for (int u = 0; u < NT; u++)
+        for (int u = 0; u < NT; u++) {
 #pragma unroll
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) H[u][2 * mt + gq] = mlp_frag_relu(acc[u][mt], gq);
+            head_split(H[u], HB[u]);
+        }
+        // density head, 64 -> 16: two 16x16x32 k-steps per 16-sample block instead of four 32x32x16 steps over a half-empty tile
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int s = 0; s < 2; s++) {
             const h8 w = DO(s);
 #pragma unroll
-            for (int u = 0; u < NT; u++) o[u] = mlp_mfma(w, H[u][s], o[u]);
+            for (int u = 0; u < NT; u++)
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++) o[u][nb] = NRC_MFMA16(w, HB[u][nb][s], o[u][nb]);
         }
         _Float16 h0[NT];
 #pragma unroll
         for (int u = 0; u < NT; u++) {
-            X[u][1] = mlp_frag(o[u], 0);  // colour-net k-step 1 = fp16(h) straight from the accumulator (ACC order)
+            X[u][1] = head_join(o[u][0], o[u][1]);  // colour-net k-step 1 = fp16(h), natural order, back on the sample's lanes
             h0[u] = X[u][1][0];              // fp16 density feature 0 (lane half 0, element 0)
             acc[u][0] = zero16(); acc[u][1] = zero16();
         }
@@ -734,21 +745,27 @@ __global__ void __launch_bounds__(256, NRC_MLP_WAVES) k_ngp_mlp(QueryIn in, int6
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) H[u][2 * mt + gq] = mlp_frag_relu(acc[u][mt], gq);
-            o[u] = zero16();
+            head_split(H[u], HB[u]);
+            o[u][0] = f4v{0.f, 0.f, 0.f, 0.f}; o[u][1] = o[u][0];
         }
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int s = 0; s < 2; s++) {
             const h8 w = CO(s);
 #pragma unroll
-            for (int u = 0; u < NT; u++) o[u] = mlp_mfma(w, H[u][s], o[u]);
+            for (int u = 0; u < NT; u++)
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++) o[u][nb] = NRC_MFMA16(w, HB[u][nb][s], o[u][nb]);
         }
 #pragma unroll
         for (int u = 0; u < NT; u++) {
             pend_ok[u] = valid[u] && hh == 0;
             pend_idx[u] = idx[u];
             pend_pk[u][0] = h0[u];
+            // rgb = neurons 0..2: lanes 0-15 of each block (k-group 0); a row swap puts sample r's triple on lane r, the sigmoid runs there
+            float rgb[3];
+            head_join_rgb(o[u][0], o[u][1], rgb);
 #pragma unroll
-            for (int c = 0; c < 3; c++) pend_pk[u][1 + c] = (_Float16)fast_sigmoid(o[u][c]);
+            for (int c = 0; c < 3; c++) pend_pk[u][1 + c] = (_Float16)fast_sigmoid(rgb[c]);
         }
       }
     }
@@ -785,12 +802,12 @@ __global__ void __launch_bounds__(256, 4) k_encode_mlp(QueryIn in, int64_t base,
     for (int f = threadIdx.x >> 6; f < N_FRAG; f += 4) {
         h8 v;
         if (f < F_DO) v = load_w_frag<false>(Wd, 32, 64, (f - F_D0) >> 1, (f - F_D0) & 1, r, hh);
-        else if (f < F_C0) v = load_w_frag<true>(Wd + 64 * 32, 64, 16, 0, f - F_DO, r, hh);
+        else if (f < F_C0) v = load_w_head_frag(Wd + 64 * 32, 64, 16, (f - F_DO) & 1, lane);     // as in k_ngp_mlp: the two kernels paint the same picture bit for bit
         else if (f < F_C1) {
             const int mt = (f - F_C0) >> 1, sk = (f - F_C0) & 1;
-            v = sk == 0 ? load_w_frag<false>(Wc, 32, 64, mt, 0, r, hh) : load_w_frag<true>(Wc, 32, 64, mt, 1, r, hh);
+            v = load_w_frag<false>(Wc, 32, 64, mt, sk, r, hh);
         } else if (f < F_CO) v = load_w_frag<true>(Wc + 64 * 32, 64, 64, (f - F_C1) >> 2, (f - F_C1) & 3, r, hh);
-        else v = load_w_frag<true>(Wc + 64 * 32 + 64 * 64, 64, 16, 0, f - F_CO, r, hh);
+        else v = load_w_head_frag(Wc + 64 * 32 + 64 * 64, 64, 16, (f - F_CO) & 1, lane);
         wlds[f][lane] = v;
     }
     __syncthreads();
@@ -846,12 +863,13 @@ __global__ void __launch_bounds__(256, 4) k_encode_mlp(QueryIn in, int64_t base,
             else { b0 = make_uint4(G1[0], G1[1], G1[2], G1[3]); b1 = make_uint4(G3[0], G3[1], G3[2], G3[3]); }
             const bool valid = (live_mask >> (32 * u + r)) & 1ull;
             if (__ballot(valid) == 0ull) continue;
-            h8 B[2], X[2], H[4];
-            f16v acc[2], o;
+            h8 B[2], X[2], H[4], HB[2][2];
+            f16v acc[2];
+            f4v o[2];
             B[0] = *reinterpret_cast<const h8*>(&b0);
             B[1] = *reinterpret_cast<const h8*>(&b1);
             X[0] = ray_sh[((int64_t)rt * 2 + hh) * 64 + 32 * u + r];
-            acc[0] = zero16(); acc[1] = zero16(); o = zero16();
+            acc[0] = zero16(); acc[1] = zero16(); o[0] = f4v{0.f, 0.f, 0.f, 0.f}; o[1] = o[0];
 #pragma unroll
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
@@ -860,9 +878,12 @@ __global__ void __launch_bounds__(256, 4) k_encode_mlp(QueryIn in, int64_t base,
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
+            head_split(H, HB);
 #pragma unroll
-            for (int sk = 0; sk < 4; sk++) o = NRC_MFMA(wlds[F_DO + sk][lane], H[sk], o);
-            X[1] = acc_to_frag(o, 0);
+            for (int sk = 0; sk < 2; sk++)
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++) o[nb] = NRC_MFMA16(wlds[F_DO + sk][lane], HB[nb][sk], o[nb]);
+            X[1] = head_join(o[0], o[1]);
             const _Float16 h0 = X[1][0];
             acc[0] = zero16(); acc[1] = zero16();
 #pragma unroll
@@ -882,14 +903,19 @@ __global__ void __launch_bounds__(256, 4) k_encode_mlp(QueryIn in, int64_t base,
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
-            o = zero16();
+            head_split(H, HB);
+            o[0] = f4v{0.f, 0.f, 0.f, 0.f}; o[1] = o[0];
 #pragma unroll
-            for (int sk = 0; sk < 4; sk++) o = NRC_MFMA(wlds[F_CO + sk][lane], H[sk], o);
+            for (int sk = 0; sk < 2; sk++)
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++) o[nb] = NRC_MFMA16(wlds[F_CO + sk][lane], HB[nb][sk], o[nb]);
+            float rgb[3];
+            head_join_rgb(o[0], o[1], rgb);
             if (valid && hh == 0) {
                 h4 pk;
                 pk[0] = h0;
 #pragma unroll
-                for (int c = 0; c < 3; c++) pk[1 + c] = (_Float16)fast_sigmoid(o[c]);
+                for (int c = 0; c < 3; c++) pk[1 + c] = (_Float16)fast_sigmoid(rgb[c]);
                 *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(packed) + 4 * (base + row * 64 + 32 * u + r)) = pk;
             }
         }
