@@ -188,7 +188,10 @@ int nrc_morton_encode(const float* positions, int64_t n, int64_t* codes, void* w
  * Group 3 -- tinycudann subset  (replaces the tiny-cuda-nn modules built at src/Methods/InstantNGP/Model.py:58-114 and
  *            queried at src/Methods/InstantNGP/Renderer.py:48-60; external dependency src/Thirdparty/TinyCudaNN.py:10)
  * Networks: input encoding (32 features) -> 64-wide ReLU MLP (n_hidden 1 or 2, no bias) -> 16 padded outputs.
- *   encoding 0: multiresolution hash grid, n_levels 16 x 2 features, fp16 table of nrc_grid_layout()[n_levels] entries
+ *   encoding 0: multiresolution hash grid, fp16 table of nrc_grid_layout()[n_levels] entries x F features; F = (encoding >> 8) & 0xff (0 = 2).
+ *               16 levels x 2 features (the shipped yaml) runs on the tuned kernels; any other F in {2, 4} with n_levels * F <= 32 -- what
+ *               HASHGRID_N_LEVELS / HASHGRID_N_FEATURES_PER_LEVEL of src/Methods/InstantNGP/Model.py:18-29 can ask for within the 32 first-layer
+ *               inputs -- on a general kernel (input k = level * F + c, zero behind n_levels * F; backward: nrc_grid_backward_general)
  *   encoding 1: [SphericalHarmonics degree 4 of input dims 0..2 | Identity of input dims 3..18]
  * weights_f16: [W0 (64,32) | hidden (64,64) x (n_hidden-1) | Wout (16,64)] row-major fp16 (rows >= n_out_rows read as 0).
  * ===================================================================================================== */
@@ -196,6 +199,9 @@ int nrc_morton_encode(const float* positions, int64_t n, int64_t* codes, void* w
 /* HOST helper: entry offsets of the levels, offsets_host[n_levels+1] (last = total entries); NULL only validates */
 int nrc_grid_layout(int32_t n_levels, int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale,
                     uint32_t* offsets_host);
+/* backward of the general grid: d_in (M,32) f32 as nrc_nwie_backward writes it with d_in_pair_major = 0; grad_table (entries, F) f32, ACCUMULATED */
+int nrc_grid_backward_general(const float* x01, int64_t M, const float* d_in, int32_t n_levels, int32_t n_features, int32_t log2_hashmap_size,
+                              int32_t base_resolution, float per_level_scale, float* grad_table, nrc_stream_t stream);
 /* fp32 master parameters -> fp16 compute copy */
 int nrc_f32_to_f16(const float* src, void* dst_f16, int64_t n, nrc_stream_t stream);
 /* NetworkWithInputEncoding.forward.  input: encoding 0 -> (M,3) f32 in [0,1], input_ld ignored; encoding 1 -> (M,input_ld>=19)

@@ -13,7 +13,7 @@
 
 namespace {
 
-enum { ENC_GRID = 0, ENC_SH_ID = 1, ENC_FEAT = 2, ENC_DIR_H = 3 };  // ENC_DIR_H: SH of f32 directions + the density net's 16 fp16 outputs (fused training query)  // ENC_FEAT: fragment-major features written by k_grid_encode (see there)
+enum { ENC_GRID = 0, ENC_SH_ID = 1, ENC_FEAT = 2, ENC_DIR_H = 3, ENC_GRID_F2 = 4, ENC_GRID_F4 = 5 };  // ENC_GRID_F2 / F4: any (levels, 2 or 4 features per level) with levels x features <= 32  // ENC_DIR_H: SH of f32 directions + the density net's 16 fp16 outputs (fused training query)  // ENC_FEAT: fragment-major features written by k_grid_encode (see there)
 enum { ACT_NONE = 0, ACT_SIGMOID = 1 };
 
 // ---- first-layer B fragments from the encodings -------------------------------------------------------------------
@@ -37,6 +37,45 @@ __device__ __forceinline__ void encode_grid(float px, float py, float pz, int hh
         }
     }
 }
+// Any grid the reference's yaml can ask for whose encoding fits the 32 first-layer inputs (src/Methods/InstantNGP/Model.py:18-29,58-70 forward
+// HASHGRID_N_LEVELS and HASHGRID_N_FEATURES_PER_LEVEL into the tcnn config): F = 2 or 4 features per table entry, input k = level * F + c, zero behind
+// n_levels * F (tiny-cuda-nn pads the encoding to a multiple of 16).  Plain 4- / 8-byte gathers, eight per level: the shipped 16 x 2 configuration keeps
+// its own kernels (k_grid_encode and encode_grid above); this is the drop-in's general path, not the headline's.
+template <int F>
+__device__ __forceinline__ void encode_grid_general(float px, float py, float pz, int hh, __amdgpu_buffer_rsrc_t table, const GridCfg& g, int n_levels, h8 (&B)[2]) {
+    constexpr int LPS = 8 / F;   // levels per lane half and k-step
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int q = 0; q < LPS; q++) {
+            const int l0 = s * (16 / F) + q, l1 = l0 + LPS;  // level of lane half 0 / 1 (uniform indices -> SGPR loads + select)
+            const float scale = hh ? g.scale[l1] : g.scale[l0];
+            const uint32_t res = hh ? g.res[l1] : g.res[l0];
+            const uint32_t size = hh ? g.size[l1] : g.size[l0];
+            const uint32_t off = hh ? g.offset[l1] : g.offset[l0];
+            const bool hashed = hh ? g.hashed[l1] : g.hashed[l0];
+            const bool live = (hh ? l1 : l0) < n_levels;    // levels behind the grid: the defaults of make_grid_cfg (in bounds), then zeroed
+            Corner8 c;
+            grid_corners(px, py, pz, scale, res, size, off, hashed, c);
+            float acc[F];
+#pragma unroll
+            for (int f = 0; f < F; f++) acc[f] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if constexpr (F == 2) {
+                    const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(table, c.e[k] << 2, 0, 0);
+                    fma_half2(c.w[k], v, acc[0], acc[1]);
+                } else {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(table, c.e[k] << 3, 0, 0);
+                    fma_half2(c.w[k], v[0], acc[0], acc[1]);
+                    fma_half2(c.w[k], v[1], acc[2], acc[3]);
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < F; f++) B[s][F * q + f] = live ? (_Float16)acc[f] : (_Float16)0.f;
+        }
+    }
+}
 // input row: [d01 (3) | h (16)] fp16, row stride `ld` halves
 __device__ __forceinline__ void encode_sh_id(const __half* __restrict__ in, int ld, int64_t i, int hh, h8 (&B)[2]) {
     const _Float16* row = reinterpret_cast<const _Float16*>(in) + i * ld;
@@ -55,7 +94,7 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
                                                   const __half2* __restrict__ table, GridCfg g, int n_out_rows,
                                                   __half* __restrict__ out, int out_ld, int n_store, __half* __restrict__ save_in,
                                                   __half* __restrict__ save_acts, float* __restrict__ sigmas_f32 = nullptr, float* __restrict__ rgbs_f32 = nullptr,
-                                                  const int32_t* __restrict__ m_live = nullptr) {
+                                                  const int32_t* __restrict__ m_live = nullptr, int grid_levels = 16) {
     // sigmas_f32 / rgbs_f32 (ENC_DIR_H only, training query): the f32 outputs query_model hands to the compositor -- sigma = exp(h0) (TruncExp forward,
     // custom_functions.py:201-204) from the density row this kernel reads anyway, rgb = the three fp16 sigmoid outputs widened -- written by the
     // epilogue instead of a separate element-wise kernel over the two fp16 tensors
@@ -66,7 +105,7 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
     if (m_live) M = min(M, (int64_t)max(*m_live, 0));
     const int64_t n_tiles = (M + 31) / 32;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
-    const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * 4u);
+    const __amdgpu_buffer_rsrc_t trs = make_table_rsrc(table, g.total_entries * (ENC == ENC_GRID_F4 ? 8u : 4u));
 
     h8 A0[2][2], AH[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1][2][4], AO[2];
     const __half* Wp = W;
@@ -114,6 +153,9 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
         if constexpr (ENC == ENC_GRID) {
             const float* xp = reinterpret_cast<const float*>(input) + 3 * ic;
             encode_grid(xp[0], xp[1], xp[2], hh, trs, g, B);
+        } else if constexpr (ENC == ENC_GRID_F2 || ENC == ENC_GRID_F4) {
+            const float* xp = reinterpret_cast<const float*>(input) + 3 * ic;
+            encode_grid_general<(ENC == ENC_GRID_F4 ? 4 : 2)>(xp[0], xp[1], xp[2], hh, trs, g, grid_levels, B);
         } else if constexpr (ENC == ENC_FEAT) {
             B[0] = *reinterpret_cast<const h8*>(&raw.a);
             B[1] = *reinterpret_cast<const h8*>(&raw.b);
@@ -1121,13 +1163,19 @@ int nrc_nwie_forward(int32_t encoding, const void* input, int32_t input_ld, int6
                      void* save_in, void* save_acts, void* workspace, nrc_stream_t stream) {
     NRC_ENTER();
     if (M < 0 || !weights_f16 || n_out_rows < 1 || n_out_rows > 16 || out_ld < n_store || n_store < 4 || n_store > 16 || (n_store & 3)) return NRC_ERR_INVALID;
+    // encoding: low byte = kind; kind 0: bits 8..15 = features per table entry (0 = 2)
+    const int n_features = (encoding >> 8) & 0xff ? (encoding >> 8) & 0xff : 2;
+    encoding &= 0xff;
     if (encoding != ENC_GRID && encoding != ENC_SH_ID) return NRC_ERR_UNSUPPORTED;
     if (n_hidden < 1 || n_hidden > 2 || (out_act != ACT_NONE && out_act != ACT_SIGMOID)) return NRC_ERR_UNSUPPORTED;
     if (M == 0) return NRC_OK;
     if (!input || !out_f16) return NRC_ERR_INVALID;
     GridCfg g;
+    bool general = false;
     if (encoding == ENC_GRID) {
-        if (n_levels != 16 || !table_f16) return NRC_ERR_UNSUPPORTED;  // 16 levels x 2 features = the 32 MLP inputs
+        if (!table_f16) return NRC_ERR_INVALID;
+        if ((n_features != 2 && n_features != 4) || n_levels < 1 || n_levels * n_features > 32) return NRC_ERR_UNSUPPORTED;  // the encoding feeds 32 first-layer inputs
+        general = !(n_levels == 16 && n_features == 2);
         const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
         if (rc != NRC_OK) return rc;
     } else {
@@ -1141,10 +1189,14 @@ int nrc_nwie_forward(int32_t encoding, const void* input, int32_t input_ld, int6
 #define NRC_FWD(E, H, A, S)                                                                                                   \
     hipLaunchKernelGGL((k_nwie_fwd<E, H, A, S>), grid, block, 0, s, input, (int)input_ld, M, (const __half*)weights_f16,       \
                        (const __half2*)table_f16, g, (int)n_out_rows, (__half*)out_f16, (int)out_ld, (int)n_store,             \
-                       (__half*)save_in, (__half*)save_acts)
+                       (__half*)save_in, (__half*)save_acts, (float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, (int)n_levels)
 #define NRC_FWD_S(E, H, A) do { if (save) NRC_FWD(E, H, A, true); else NRC_FWD(E, H, A, false); } while (0)
 #define NRC_FWD_A(E, H) do { if (out_act == ACT_SIGMOID) NRC_FWD_S(E, H, ACT_SIGMOID); else NRC_FWD_S(E, H, ACT_NONE); } while (0)
-    if (encoding == ENC_GRID && workspace) {
+    if (encoding == ENC_GRID && general) {
+        // any other (levels, features) the yaml asks for: one kernel, plain gathers (the drop-in's general path)
+        if (n_features == 4) { if (n_hidden == 1) NRC_FWD_A(ENC_GRID_F4, 1); else NRC_FWD_A(ENC_GRID_F4, 2); }
+        else { if (n_hidden == 1) NRC_FWD_A(ENC_GRID_F2, 1); else NRC_FWD_A(ENC_GRID_F2, 2); }
+    } else if (encoding == ENC_GRID && workspace) {
         // split form (what the image pipeline uses): all 128 gathers of a sample by a low-register, 8-waves-per-SIMD kernel, then the
         // MFMA chain from the fragment-major features; the single-kernel form below is 3x slower on a 264 K-sample batch (130 us)
         QueryIn qin = {};
@@ -1783,8 +1835,28 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, i
 // chip whatever their locality (measured per level: 4.2 M atomics = 0.2 ms, 1.3 of the 1.5 ms of the whole backward), and a
 // sample's corners on these levels are pseudo-random, so nothing can be combined.  Instead every workgroup OWNS a 16 K-entry
 // slice of one level's table, keeps it in LDS (128 KB), walks ALL samples, recomputes their eight corner indices and keeps the
+// (general grids: see k_grid_bwd_general below)
 // ones that fall into its slice (LDS atomics).  32x redundant index arithmetic, zero global atomics; the slice is added to the
 // gradient table with plain coalesced read-modify-writes (the workgroup is its only writer).
+template <int F>
+__global__ void __launch_bounds__(256) k_grid_bwd_general(const float* __restrict__ x, int64_t M, const float* __restrict__ d_in, GridCfg g, float* __restrict__ grad_table) {
+    const int level = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    float gl[F];
+    bool any = false;
+#pragma unroll
+    for (int f = 0; f < F; f++) { gl[f] = d_in[i * 32 + level * F + f]; any = any || gl[f] != 0.f; }
+    if (!any) return;
+    Corner8 c;
+    if (g.hashed[level]) grid_corners_u<true>(x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scale[level], g.res[level], g.size[level], g.offset[level], c);
+    else grid_corners_u<false>(x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scale[level], g.res[level], g.size[level], g.offset[level], c);
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int f = 0; f < F; f++) atomicAdd(grad_table + (size_t)c.e[k] * F + f, c.w[k] * gl[f]);
+}
+
 #define OWN_ENTRIES 16384
 #define OWN_THREADS 1024
 struct OwnedCfg { int n_levels; int level[NRC_MAX_LEVELS]; int unit0[NRC_MAX_LEVELS + 1]; };
@@ -2455,6 +2527,24 @@ static int grid_backward_impl(const float* x01, int64_t M, const float* d_featur
 }
 
 extern "C" {
+
+/* the general grid's backward (see encode_grid_general): d_in (M, 32) f32 sample-major, input k = level * F + c; plain f32 atomics, one lane per (sample, level) */
+int nrc_grid_backward_general(const float* x01, int64_t M, const float* d_in, int32_t n_levels, int32_t n_features, int32_t log2_hashmap_size,
+                              int32_t base_resolution, float per_level_scale, float* grad_table, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (M < 0 || !grad_table) return NRC_ERR_INVALID;
+    if ((n_features != 2 && n_features != 4) || n_levels < 1 || n_levels * n_features > 32) return NRC_ERR_UNSUPPORTED;
+    if (M == 0) return NRC_OK;
+    if (!x01 || !d_in) return NRC_ERR_INVALID;
+    GridCfg g;
+    const int rc = make_grid_cfg(n_levels, log2_hashmap_size, base_resolution, per_level_scale, g, nullptr);
+    if (rc != NRC_OK) return rc;
+    const dim3 grid((unsigned)nrc_cdiv(M, 256), (unsigned)n_levels);
+    if (n_features == 4) hipLaunchKernelGGL(k_grid_bwd_general<4>, grid, dim3(256), 0, (hipStream_t)stream, x01, M, d_in, g, grad_table);
+    else hipLaunchKernelGGL(k_grid_bwd_general<2>, grid, dim3(256), 0, (hipStream_t)stream, x01, M, d_in, g, grad_table);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
 
 int nrc_grid_backward(const float* x01, int64_t M, const float* d_features, int32_t d_features_pair_major, int32_t n_levels,
                       int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_table, void* workspace,

@@ -271,6 +271,16 @@ class InstantNGPRenderer:
             out[key] = img.permute(2, 0, 1) if to_chw else img
         return out
 
+    @torch.no_grad()
+    def _render_image_general(self, camera: Camera, c2w) -> dict[str, torch.Tensor]:
+        """One frame as a list of rays through render_rays (march -> query through the tcnn modules -> composite): flat (H*W, C) buffers like the fused frame."""
+        from .raygen import generate_rays
+        dev = self.model.center.device
+        c2w = c2w.detach().cpu().numpy() if isinstance(c2w, torch.Tensor) else c2w
+        rays = generate_rays(camera.width, camera.height, camera.focal_x, camera.focal_y, camera.center_x, camera.center_y, c2w, device=dev)
+        out = self.render_rays(rays['origin'], rays['view_direction'], camera, train_mode=False)
+        return {'rgb': out['rgb'], 'alpha': out['alpha'], 'depth': out['depth']}
+
     # ---------------------------------------------------------------- MI355X-native image pipeline
     @staticmethod
     def n_image_tiles(camera: Camera) -> int:
@@ -472,6 +482,14 @@ class InstantNGPRenderer:
         enqueues (it can sit inside a stream capture).  The result carries 'counter' (DEVICE int32[2]: rows, samples): rows > row_capacity means
         the frame did not fit and its picture is not valid -- look at it when convenient and render again with more."""
         m = self.model
+        from .ngp import default_layout
+        if not default_layout(m.encoding_xyz, m.color_mlp_with_encoding):
+            # the tile pipeline's kernels are built for the shipped 16 x 2 grid / degree-4 SH; any other yaml configuration renders through the
+            # drop-in modules, ray list by ray list (what the reference's render_image does, Renderer.py:100-138)
+            if tile_begin or n_tiles is not None or row_capacity is not None or out is not None:
+                raise RuntimeError('render_image_fused: tile shards / fixed-capacity frames need the default HASHGRID_N_LEVELS = 16, HASHGRID_N_FEATURES_PER_LEVEL = 2, '
+                                   'DIR_SH_ENCODING_DEGREE = 4; this model renders whole frames through the general path')
+            return self._render_image_general(camera, c2w)
         lib = _lib.load()
         dev = m.center.device
         total_tiles = self.n_image_tiles(camera)

@@ -10,11 +10,33 @@ import torch
 
 from . import _lib
 
-__all__ = ['query_fused', 'query_train', 'composite_over_background', 'weight_decay_mlp', 'instant_ngp_loss']
+__all__ = ['query_fused', 'query_train', 'query_modules', 'default_layout', 'composite_over_background', 'weight_decay_mlp', 'instant_ngp_loss']
+
+
+def default_layout(density_net, color_net) -> bool:
+    """Are both networks the configuration the fused paths of this module (and of nerficg_amd.instant_ngp / ngp_trainer) are built for -- 16 x 2 hash grid,
+    degree-4 SH?  Any other configuration the yaml can ask for (HASHGRID_N_LEVELS, HASHGRID_N_FEATURES_PER_LEVEL, DIR_SH_ENCODING_DEGREE) runs through the
+    drop-in modules' own forward / backward (query_modules), which is what the reference's Renderer.py:48-53 does."""
+    return bool(getattr(density_net, 'default_layout', True) and getattr(color_net, 'default_layout', True))
+
+
+def query_modules(density_net, color_net, xyz01: torch.Tensor, dirs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """query_model exactly as src/Methods/InstantNGP/Renderer.py:48-53 composes it from the two tcnn modules (differentiable through them): the path of
+    every configuration the fused kernels are not built for."""
+    h = density_net(xyz01)
+    sigmas = torch.exp(h[:, 0].float())       # TruncExp forward (custom_functions.py:201-204); its clamp only acts in the backward
+    if torch.is_grad_enabled() and h.requires_grad:
+        from .VolumeRenderingV2 import TruncExp
+        sigmas = TruncExp.apply(h[:, 0])
+    rgbs = color_net(torch.cat([(dirs * 0.5 + 0.5).to(h.dtype), h], dim=-1)).float()
+    return sigmas, rgbs
 
 
 def query_fused(density_net, color_net, xyz01: torch.Tensor, dirs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
     """query_model (Renderer.py:48-53) as one encode + one MLP kernel per chunk: xyz01 (M,3) f32 in [0,1], dirs (M,3) unit f32 -> sigmas (M) f32, rgbs (M,3) f32."""
+    if not default_layout(density_net, color_net):
+        with torch.no_grad():
+            return query_modules(density_net, color_net, xyz01, dirs)
     _lib.check_input(xyz01, 'xyz01', torch.float32)
     _lib.check_input(dirs, 'dirs', torch.float32)
     m = xyz01.shape[0]
@@ -219,6 +241,9 @@ def query_train(density_net, color_net, xyzs: torch.Tensor, dirs: torch.Tensor, 
     dirs = dirs.detach().to(torch.float32).contiguous()
     _lib.check_input(xyzs, 'xyzs', torch.float32)
     _lib.check_input(dirs, 'dirs', torch.float32)
+    if not default_layout(density_net, color_net):
+        x01 = (xyzs - xyz_min.to(xyzs.device).reshape(1, 3)) / xyz_size.to(xyzs.device).reshape(1, 3)
+        return query_modules(density_net, color_net, x01, dirs)
     return _QueryTrain.apply(xyzs, dirs, density_net.params, color_net.params, density_net, color_net, xyz_min, xyz_size)
 
 

@@ -76,6 +76,10 @@ class FusedTrainingIteration:
         if len(optimizer.param_groups) != 1:
             raise RuntimeError('FusedTrainingIteration: one parameter group holding both parameter vectors is expected (Trainer.py:35)')
         lib = _lib.load()
+        from .ngp import default_layout
+        if not default_layout(model.encoding_xyz, model.color_mlp_with_encoding):
+            raise RuntimeError('FusedTrainingIteration is built for the default HASHGRID_N_LEVELS = 16, HASHGRID_N_FEATURES_PER_LEVEL = 2, DIR_SH_ENCODING_DEGREE = 4; '
+                               'other configurations train through the op-by-op loop (renderer.render_rays + InstantNGPLoss + FusedAdam)')
         self.model, self.renderer, self.optimizer, self.scaler, self.camera = model, renderer, optimizer, scaler, camera
         # Data parallel (BASELINE configs[3]): every rank holds the whole pool and the same global order / seed; rank r marches rows
         # [r n, (r + 1) n) of every global batch of W n rays (parallel.rank_batch_order) with the jitter of their GLOBAL indices and the iteration's one

@@ -7,10 +7,11 @@ src/Thirdparty/TinyCudaNN.py (`from tinycudann import *`) and uses in src/Method
     free_temporary_memory(), supports_jit_fusion()
 
 backed by hand-written gfx950 kernels (libnerficg_hip.so: nrc_nwie_forward / nrc_nwie_backward / nrc_grid_backward).
-Supported configurations = the family the reference instantiates (anything else raises, loudly):
-  encoding  {'otype':'Grid','type':'Hash', n_levels 16, n_features_per_level 2, interpolation 'Linear', any
+Supported configurations = the family src/Methods/InstantNGP/Model.py:18-29,58-114 can instantiate from its yaml keys (anything else raises, by key name):
+  encoding  {'otype':'Grid','type':'Hash', interpolation 'Linear', n_levels L, n_features_per_level F in {2, 4} with L x F <= 32, any
              log2_hashmap_size / base_resolution / per_level_scale}   with n_input_dims == 3
-            {'otype':'Composite','nested':[{'n_dims_to_encode':3,'otype':'SphericalHarmonics','degree':4},
+             (16 x 2, the shipped yaml, runs on the tuned kernels -- every other (L, F) on the general ones: nrc_nwie_forward's encoding bits)
+            {'otype':'Composite','nested':[{'n_dims_to_encode':3,'otype':'SphericalHarmonics','degree': 1..4},
              {'otype':'Identity'}]}                                    with n_input_dims == 19
   network   {'otype':'FullyFusedMLP','activation':'ReLU','output_activation':'None'|'Sigmoid','n_neurons':64,
              'n_hidden_layers': 1|2}                                   with n_output_dims <= 16
@@ -70,7 +71,7 @@ class _NWIEFunction(torch.autograd.Function):
         g = module.grid_cfg
         ws = torch.empty(int(lib.nrc_nwie_forward_ws_bytes(m)), dtype=torch.uint8, device=dev) if module.encoding == 0 else None
         _lib.check(lib.nrc_nwie_forward(
-            module.encoding, _lib.ptr(xin), in_ld, m, _lib.ptr(w16), _lib.ptr(module._table16()), g['n_levels'],
+            module.encoding | (module.n_features << 8), _lib.ptr(xin), in_ld, m, _lib.ptr(w16), _lib.ptr(module._table16()), g['n_levels'],
             g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']), module.n_hidden, module.out_act,
             _PAD, _lib.ptr(out), module._out_ld, module._out_ld, _lib.ptr(save_in), _lib.ptr(save_acts), _lib.ptr(ws),
             _lib.stream_of(out)), 'nwie_forward')
@@ -90,8 +91,9 @@ class _NWIEFunction(torch.autograd.Function):
         m = xin.shape[0]
         dev = xin.device
         d_out = d_out.to(torch.float16).contiguous()
-        grad_params = torch.zeros(module.params.numel(), dtype=torch.float32, device=dev)
-        pair_major = 1 if module.encoding == 0 else 0  # the grid backward reads [16 levels][m][2]
+        general_grid = module.encoding == 0 and not (module.grid_cfg['n_levels'] == 16 and module.n_features == 2)
+        grad_params = torch.zeros(module._n_kernel_mlp + (module.params.numel() - module.n_mlp_params), dtype=torch.float32, device=dev)   # kernel layout
+        pair_major = 1 if module.encoding == 0 and not general_grid else 0  # the tuned grid backward reads [16 levels][m][2]
         d_in = torch.empty(m, 32, dtype=torch.float32, device=dev)
         st = _lib.stream_of(d_out)
         _lib.check(lib.nrc_nwie_backward(
@@ -100,7 +102,11 @@ class _NWIEFunction(torch.autograd.Function):
         grad_x = None
         if module.encoding == 0:
             g = module.grid_cfg
-            table_grad = grad_params[module.n_mlp_params:]
+            table_grad = grad_params[module._n_kernel_mlp:]
+            if general_grid:
+                _lib.check(lib.nrc_grid_backward_general(_lib.ptr(xin), m, _lib.ptr(d_in), g['n_levels'], module.n_features, g['log2_hashmap_size'],
+                                                         g['base_resolution'], float(g['per_level_scale']), _lib.ptr(table_grad), st), 'grid_backward_general')
+                return grad_x, module._grad_to_master(grad_params), None
             gws = torch.empty(int(lib.nrc_grid_backward_ws_bytes(m, g['n_levels'], g['log2_hashmap_size'], g['base_resolution'], float(g['per_level_scale']))),
                               dtype=torch.uint8, device=dev)
             _lib.check(lib.nrc_grid_backward(_lib.ptr(xin), m, _lib.ptr(d_in), pair_major, g['n_levels'], g['log2_hashmap_size'],
@@ -110,7 +116,7 @@ class _NWIEFunction(torch.autograd.Function):
             # never optimised by the reference: Renderer.py:40 feeds rays.view_direction)
             grad_x = torch.zeros(m, xin.shape[1], dtype=ctx.x_dtype, device=dev)
             grad_x[:, 3:19] = d_in[:, 16:32].to(ctx.x_dtype)
-        return grad_x, grad_params, None
+        return grad_x, module._grad_to_master(grad_params), None
 
 
 class NetworkWithInputEncoding(torch.nn.Module):
@@ -148,32 +154,47 @@ class NetworkWithInputEncoding(torch.nn.Module):
         if ot in ('Grid', 'HashGrid'):
             if str(encoding_config.get('type', 'Hash')) != 'Hash' or str(encoding_config.get('interpolation', 'Linear')) != 'Linear':
                 raise RuntimeError('nerficg_amd.tinycudann: only Hash grids with Linear interpolation are implemented')
-            if int(encoding_config.get('n_levels', 16)) != 16 or int(encoding_config.get('n_features_per_level', 2)) != 2 or self.n_input_dims != 3:
-                raise RuntimeError(f"nerficg_amd.tinycudann: the grid encoding is implemented for n_input_dims = 3, n_levels = 16, n_features_per_level = 2 "
-                                   f"(got {self.n_input_dims}, {encoding_config.get('n_levels')}, {encoding_config.get('n_features_per_level')}): "
-                                   'HASHGRID_N_LEVELS / HASHGRID_N_FEATURES_PER_LEVEL of the InstantNGP yaml must keep their defaults')
+            n_levels, n_feat = int(encoding_config.get('n_levels', 16)), int(encoding_config.get('n_features_per_level', 2))
+            if self.n_input_dims != 3 or n_feat not in (2, 4) or n_levels < 1 or n_levels * n_feat > 32:
+                raise RuntimeError(f"nerficg_amd.tinycudann: the grid encoding is implemented for n_input_dims = 3, n_features_per_level in (2, 4) and "
+                                   f"n_levels * n_features_per_level <= 32 (got {self.n_input_dims}, {n_levels} levels, {n_feat} features): "
+                                   'HASHGRID_N_LEVELS / HASHGRID_N_FEATURES_PER_LEVEL of the InstantNGP yaml (16 x 2 by default; e.g. 8 x 4 or 12 x 2 are fine, 16 x 4 is not)')
             self.encoding = 0
-            self.grid_cfg = dict(n_levels=16, log2_hashmap_size=int(encoding_config.get('log2_hashmap_size', 19)),
+            self.n_features = n_feat
+            self.grid_cfg = dict(n_levels=n_levels, log2_hashmap_size=int(encoding_config.get('log2_hashmap_size', 19)),
                                  base_resolution=int(encoding_config.get('base_resolution', 16)),
                                  per_level_scale=float(encoding_config.get('per_level_scale', 2.0)))
             self.grid_offsets = _grid_offsets(self.grid_cfg)
-            n_table = self.grid_offsets[-1] * 2
+            n_table = self.grid_offsets[-1] * n_feat
+            n_encoded = n_levels * n_feat
+            cols = [k if k < n_encoded else -1 for k in range(32)]           # kernel input k = level * F + c, as tiny-cuda-nn orders them
         elif ot == 'Composite':
             nested = encoding_config.get('nested', [])
-            ok = (len(nested) == 2 and nested[0].get('otype') == 'SphericalHarmonics' and int(nested[0].get('degree', 0)) == 4
+            degree = int(nested[0].get('degree', 0)) if len(nested) == 2 else 0
+            ok = (len(nested) == 2 and nested[0].get('otype') == 'SphericalHarmonics' and 1 <= degree <= 4
                   and int(nested[0].get('n_dims_to_encode', 0)) == 3 and nested[1].get('otype') == 'Identity' and self.n_input_dims == 19)
             if not ok:
-                raise RuntimeError('nerficg_amd.tinycudann: Composite encoding must be [SphericalHarmonics(degree = 4, n_dims_to_encode = 3), Identity] with n_input_dims = 19 '
+                raise RuntimeError('nerficg_amd.tinycudann: Composite encoding must be [SphericalHarmonics(degree = 1..4, n_dims_to_encode = 3), Identity] with n_input_dims = 19 '
                                    f'(got n_input_dims = {self.n_input_dims}, nested = {nested}): DIR_SH_ENCODING_DEGREE / N_DENSITY_OUTPUT_FEATURES of the InstantNGP yaml '
-                                   'must keep their defaults (4 / 16)')
+                                   '(1..4 / 16)')
             self.encoding = 1
+            self.n_features = 0
+            self.sh_degree = degree
+            n_encoded = degree * degree + 16
+            # the kernels evaluate all 16 degree-4 coefficients into inputs 0..15 and take the 16 identity dims as inputs 16..31; tiny-cuda-nn's columns are
+            # [SH 0 .. d^2 - 1 | identity 0 .. 15 | padding]: coefficients the configuration does not have meet zero weights
+            cols = [k if k < degree * degree else -1 for k in range(16)] + [degree * degree + j for j in range(16)]
         else:
             raise RuntimeError(f'nerficg_amd.tinycudann: unsupported encoding otype {ot!r}')
+        self.n_in_padded = (n_encoded + 15) // 16 * 16     # tiny-cuda-nn pads the encoded width to a multiple of 16: the first layer is (64, n_in_padded)
+        # first-layer columns: kernel input k reads master column _w0_cols[k] (-1: no such input, weight 0).  None = the master layout IS the kernel layout
+        self._w0_cols = None if cols == list(range(32)) and self.n_in_padded == 32 else cols
         # ---- parameters: [W0 (64,32) | hidden (64,64)... | Wout (16,64)] then the grid table (Model.py:40 slices on this order)
-        self.n_mlp_params = _WIDTH * 32 + (self.n_hidden - 1) * _WIDTH * _WIDTH + _PAD * _WIDTH
+        self.n_mlp_params = _WIDTH * self.n_in_padded + (self.n_hidden - 1) * _WIDTH * _WIDTH + _PAD * _WIDTH
+        self._n_kernel_mlp = _WIDTH * 32 + (self.n_hidden - 1) * _WIDTH * _WIDTH + _PAD * _WIDTH      # what the kernels read: the first layer always (64, 32)
         gen = torch.Generator(device='cpu').manual_seed(self.seed)
         chunks = []
-        shapes = [(_WIDTH, 32)] + [(_WIDTH, _WIDTH)] * (self.n_hidden - 1) + [(_PAD, _WIDTH)]
+        shapes = [(_WIDTH, self.n_in_padded)] + [(_WIDTH, _WIDTH)] * (self.n_hidden - 1) + [(_PAD, _WIDTH)]
         for fan_out, fan_in in shapes:  # Xavier uniform, like tiny-cuda-nn's FullyFusedMLP::initialize_params
             s = math.sqrt(6.0 / (fan_in + fan_out))
             chunks.append((torch.rand(fan_out * fan_in, generator=gen) * 2 - 1) * s)
@@ -193,7 +214,7 @@ class NetworkWithInputEncoding(torch.nn.Module):
     def _half_for_optimizer(self, p):
         """fp16 copy for the Adam kernel to rewrite (None if `p` is not this module's live CUDA parameter). The copy is brought up to date
         first, because an overflow-skipped step leaves it untouched."""
-        if p is not self.params or not p.is_cuda:
+        if p is not self.params or not p.is_cuda or self._w0_cols is not None:   # (a remapped first layer: the copy is not a 1:1 mirror, rebuilt on use instead)
             return None
         self._refresh_half()
         return self._half
@@ -209,16 +230,42 @@ class NetworkWithInputEncoding(torch.nn.Module):
         if self._half is None or self._half_key != key:
             if not p.is_cuda:
                 raise RuntimeError('nerficg_amd.tinycudann: parameters must live on the GPU (no CPU fallback)')
-            half = torch.empty(p.numel(), dtype=torch.float16, device=p.device)
-            _lib.check(_lib.load().nrc_f32_to_f16(_lib.ptr(p.detach()), _lib.ptr(half), p.numel(), _lib.stream_of(half)), 'f32_to_f16')
+            if self._w0_cols is None:
+                half = torch.empty(p.numel(), dtype=torch.float16, device=p.device)
+                _lib.check(_lib.load().nrc_f32_to_f16(_lib.ptr(p.detach()), _lib.ptr(half), p.numel(), _lib.stream_of(half)), 'f32_to_f16')
+            else:   # kernel layout: first layer (64, 32) gathered from the master's (64, n_in_padded) columns, everything behind it unchanged
+                pd, n0 = p.detach(), _WIDTH * self.n_in_padded
+                idx, live = self._w0_index(p.device)
+                w0 = pd[:n0].view(_WIDTH, self.n_in_padded)[:, idx] * live
+                half = torch.cat([w0.reshape(-1), pd[n0:]]).to(torch.float16)
             self._half, self._half_key = half, key
+
+    def _w0_index(self, device):
+        """(master column per kernel input, clamped; 0 / 1 mask of the inputs that exist) for a remapped first layer."""
+        cols = torch.tensor(self._w0_cols, dtype=torch.long, device=device)
+        return cols.clamp_min(0), (cols >= 0).to(torch.float32)
+
+    def _grad_to_master(self, grad_kernel: torch.Tensor) -> torch.Tensor:
+        """Gradient in the kernels' parameter layout -> the layout of `params` (identity unless the first layer is remapped)."""
+        if self._w0_cols is None:
+            return grad_kernel
+        n0k = _WIDTH * 32
+        idx, live = self._w0_index(grad_kernel.device)
+        g0 = torch.zeros(_WIDTH, self.n_in_padded, dtype=grad_kernel.dtype, device=grad_kernel.device)
+        g0.index_add_(1, idx, grad_kernel[:n0k].view(_WIDTH, 32) * live)
+        return torch.cat([g0.reshape(-1), grad_kernel[n0k:]])
 
     def _half_params(self) -> torch.Tensor:
         self._refresh_half()
         return self._half
 
     def _table16(self):
-        return self._half[self.n_mlp_params:] if self.encoding == 0 else None
+        return self._half[self._n_kernel_mlp:] if self.encoding == 0 else None
+
+    @property
+    def default_layout(self) -> bool:
+        """The configuration the fused InstantNGP paths are built for (16 x 2 grid / degree-4 SH): the general ones go through this module's forward."""
+        return self._w0_cols is None and (self.encoding != 0 or (self.grid_cfg['n_levels'] == 16 and self.n_features == 2))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:

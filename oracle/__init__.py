@@ -237,19 +237,22 @@ def _half_flag(accumulate):
 
 
 def grid_encode_fw(x01, table, n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.3819128800, accumulate='float'):
-    """x01 (M,3) f32 in [0,1]; table (entries,2) fp16-representable f32 -> (M, 2*n_levels) fp16-rounded f32.
-    accumulate='half': fp16 weights and fp16 running sums (oracle_grid_encode_fw2)."""
+    """x01 (M,3) f32 in [0,1]; table (entries,F) fp16-representable f32 -> (M, F*n_levels) fp16-rounded f32, level-major (F = table.shape[1]:
+    n_features_per_level).  accumulate='half': fp16 weights and fp16 running sums (oracle_grid_encode_fwF)."""
     x01, table = _c(x01, f32), _c(table, f32)
-    out = np.empty((x01.shape[0], 2 * n_levels), f32)
-    _call('oracle_grid_encode_fw2', x01, x01.shape[0], table, _i(n_levels), _i(log2_hashmap_size), _i(base_resolution),
+    n_feat = int(table.shape[1]) if table.ndim == 2 else 2
+    out = np.empty((x01.shape[0], n_feat * n_levels), f32)
+    _call('oracle_grid_encode_fwF', x01, x01.shape[0], table, _i(n_levels), _i(n_feat), _i(log2_hashmap_size), _i(base_resolution),
           float(per_level_scale), _half_flag(accumulate), out)
     return out
 
 
 def grid_encode_bw(x01, d_out, n_entries, n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.3819128800):
+    """d_out (M, F*n_levels) -> gradient table (n_entries, F) f32; F = d_out.shape[1] / n_levels."""
     x01, d_out = _c(x01, f32), _c(d_out, f32)
-    grad = np.zeros((n_entries, 2), f32)
-    _call('oracle_grid_encode_bw', x01, x01.shape[0], d_out, _i(n_levels), _i(log2_hashmap_size), _i(base_resolution),
+    n_feat = d_out.shape[1] // n_levels
+    grad = np.zeros((n_entries, n_feat), f32)
+    _call('oracle_grid_encode_bwF', x01, x01.shape[0], d_out, _i(n_levels), _i(n_feat), _i(log2_hashmap_size), _i(base_resolution),
           float(per_level_scale), grad)
     return grad
 

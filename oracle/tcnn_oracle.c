@@ -113,8 +113,11 @@ static inline uint32_t grid_index(const uint32_t p[3], uint32_t res, uint32_t si
  * accumulate_half = 1: what upstream tiny-cuda-nn's kernel is understood to do when its parameters are __half (it computes
  * `result += (T)weight * value` in T = __half; not verifiable here, the source is absent): the weight is rounded to fp16 and the running sum
  * is rounded to fp16 after every one of the eight fused multiply-adds.  tests/test_oracle_tcnn.py reports the distance between the two. */
-void oracle_grid_encode_fw2(const float* x, int64_t M, const float* table, int n_levels, int log2_hashmap_size,
+/* oracle_grid_encode_fwF: n_features F values per table entry (1 .. 8; tiny-cuda-nn's n_features_per_level, src/Methods/InstantNGP/Model.py:63
+ * forwards HASHGRID_N_FEATURES_PER_LEVEL), table (entries, F), out (M, F * n_levels) level-major.  oracle_grid_encode_fw2 is F = 2. */
+void oracle_grid_encode_fwF(const float* x, int64_t M, const float* table, int n_levels, int n_features, int log2_hashmap_size,
                             int base_resolution, float per_level_scale, int accumulate_half, float* out) {
+    const int F = n_features;
     uint32_t offsets[MAX_LEVELS + 1], res[MAX_LEVELS]; float scales[MAX_LEVELS];
     oracle_grid_layout(n_levels, log2_hashmap_size, base_resolution, per_level_scale, offsets, scales, res);
     /* Level-synchronous order: all threads work through level l of all samples before anyone touches level l + 1, so the 4 MB slice of
@@ -131,7 +134,7 @@ void oracle_grid_encode_fw2(const float* x, int64_t M, const float* table, int n
                 const float fl = floorf(p);
                 g[d] = (uint32_t)(int32_t)fl; frac[d] = p - fl;
             }
-            float acc0 = 0.f, acc1 = 0.f;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             for (int c = 0; c < 8; c++) {
                 float w = 1.f; uint32_t q[3];
                 for (int d = 0; d < 3; d++) {
@@ -140,17 +143,18 @@ void oracle_grid_encode_fw2(const float* x, int64_t M, const float* table, int n
                 const uint32_t e = offsets[l] + grid_index(q, res[l], size);
                 if (accumulate_half) {
                     w = round_half(w);
-                    acc0 = round_half(fmaf(w, table[2 * (int64_t)e], acc0));
-                    acc1 = round_half(fmaf(w, table[2 * (int64_t)e + 1], acc1));
+                    for (int f = 0; f < F; f++) acc[f] = round_half(fmaf(w, table[F * (int64_t)e + f], acc[f]));
                 } else {
-                    acc0 = fmaf(w, table[2 * (int64_t)e], acc0);
-                    acc1 = fmaf(w, table[2 * (int64_t)e + 1], acc1);
+                    for (int f = 0; f < F; f++) acc[f] = fmaf(w, table[F * (int64_t)e + f], acc[f]);
                 }
             }
-            out[i * 2 * n_levels + 2 * l] = round_half(acc0);
-            out[i * 2 * n_levels + 2 * l + 1] = round_half(acc1);
+            for (int f = 0; f < F; f++) out[i * F * n_levels + F * l + f] = round_half(acc[f]);
         }
     }
+}
+void oracle_grid_encode_fw2(const float* x, int64_t M, const float* table, int n_levels, int log2_hashmap_size,
+                            int base_resolution, float per_level_scale, int accumulate_half, float* out) {
+    oracle_grid_encode_fwF(x, M, table, n_levels, 2, log2_hashmap_size, base_resolution, per_level_scale, accumulate_half, out);
 }
 void oracle_grid_encode_fw(const float* x, int64_t M, const float* table, int n_levels, int log2_hashmap_size,
                            int base_resolution, float per_level_scale, float* out) {
@@ -158,8 +162,9 @@ void oracle_grid_encode_fw(const float* x, int64_t M, const float* table, int n_
 }
 
 /* scatter-add of d_out (M, 2*n_levels) f32 into grad_table (entries,2) f32 (zeroed by the caller) */
-void oracle_grid_encode_bw(const float* x, int64_t M, const float* d_out, int n_levels, int log2_hashmap_size,
-                           int base_resolution, float per_level_scale, float* grad_table) {
+void oracle_grid_encode_bwF(const float* x, int64_t M, const float* d_out, int n_levels, int n_features, int log2_hashmap_size,
+                            int base_resolution, float per_level_scale, float* grad_table) {
+    const int F = n_features;
     uint32_t offsets[MAX_LEVELS + 1], res[MAX_LEVELS]; float scales[MAX_LEVELS];
     oracle_grid_layout(n_levels, log2_hashmap_size, base_resolution, per_level_scale, offsets, scales, res);
     for (int64_t i = 0; i < M; i++) {
@@ -171,17 +176,21 @@ void oracle_grid_encode_bw(const float* x, int64_t M, const float* d_out, int n_
                 const float fl = floorf(p);
                 g[d] = (uint32_t)(int32_t)fl; frac[d] = p - fl;
             }
-            const float g0 = d_out[i * 2 * n_levels + 2 * l], g1 = d_out[i * 2 * n_levels + 2 * l + 1];
+            const float* gl = d_out + i * F * n_levels + F * l;
             for (int c = 0; c < 8; c++) {
                 float w = 1.f; uint32_t q[3];
                 for (int d = 0; d < 3; d++) {
                     if (c & (1 << d)) { w *= frac[d]; q[d] = g[d] + 1; } else { w *= 1.f - frac[d]; q[d] = g[d]; }
                 }
                 const int64_t e = offsets[l] + grid_index(q, res[l], size);
-                grad_table[2 * e] += w * g0; grad_table[2 * e + 1] += w * g1;
+                for (int f = 0; f < F; f++) grad_table[F * e + f] += w * gl[f];
             }
         }
     }
+}
+void oracle_grid_encode_bw(const float* x, int64_t M, const float* d_out, int n_levels, int log2_hashmap_size,
+                           int base_resolution, float per_level_scale, float* grad_table) {
+    oracle_grid_encode_bwF(x, M, d_out, n_levels, 2, log2_hashmap_size, base_resolution, per_level_scale, grad_table);
 }
 
 /* ------------------------------------------------------------------------------------------------ SH degree 4 */

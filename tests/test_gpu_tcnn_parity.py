@@ -268,7 +268,7 @@ def test_grid_backward_on_samples_ordered_along_rays():
 
 def test_unsupported_configs_raise(tcnn):
     with pytest.raises(RuntimeError):
-        tcnn.NetworkWithInputEncoding(3, 16, {**ENC_GRID, 'n_levels': 8}, NET_D)
+        tcnn.NetworkWithInputEncoding(3, 16, {**ENC_GRID, 'n_features_per_level': 4}, NET_D)      # 16 x 4 = 64 inputs (other grids: tests/test_gpu_tcnn_configs.py)
     with pytest.raises(RuntimeError):
         tcnn.NetworkWithInputEncoding(3, 16, ENC_GRID, {**NET_D, 'n_neurons': 128})
     with pytest.raises(RuntimeError):
