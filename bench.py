@@ -877,7 +877,7 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=8):
 
     def step(i, timed):
         out = render_image_training(g, cam, poses_dev[i])
-        exchange.begin(out['visibility_mask'])      # mask max-reduce + device compaction + count to the host, beside the backward pass
+        exchange.begin(out['radii'])      # (visible = radius > 0) mask max-reduce + device compaction + count to the host, beside the backward pass
         training_loss(out['rgb'], target).backward()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()

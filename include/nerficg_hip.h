@@ -339,6 +339,10 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
  * both sides; NRC_ERR_UNSUPPORTED when the runtime maps it elsewhere (use the device counters then).  Free with nrc_host_mailbox_free. */
 int nrc_host_mailbox_alloc(int64_t** mailbox);
 int nrc_host_mailbox_free(int64_t* mailbox);
+/* camera_dev of a frame from a DEVICE pose: c2w_dev = the first 12 floats of a row-major camera-to-world (3,4) / (4,4), proj_t_dev = P^T (16) of
+ * Cameras/Perspective.py's projection, bg3_dev (optional): out[0..16) = viewmatrix = w2c^T, [16..32) = viewmatrix @ P^T, [32..35) = camera position,
+ * [35..38) = background (GaussianSplatting/Renderer.py:60-74 in one launch; the pose never visits the host). */
+int nrc_gs_camera_block(const float* c2w_dev, const float* proj_t_dev, const float* bg3_dev, float* camera_dev_out, nrc_stream_t stream);
 int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg, const float* camera_dev, const int32_t* radii,
                       const float* depths, const float* points_xy, const float* conic_opacity, const float* rgb,
                       const uint32_t* ranges, uint32_t* tile_fill, const uint32_t* bin_hist, int64_t span_capacity,
@@ -526,6 +530,13 @@ int nrc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float beta2, float eps, float weight_decay, int32_t adam_w_mode, float bias_correction1,
                   float bias_correction2, const float* bias_corrections_dev, const float* lr_dev, const float* grad_scale,
                   const float* found_inf, void* param_f16_out, float l2_slice_coeff, int64_t l2_slice_count, nrc_stream_t stream);
+/* nrc_adam_step on up to 12 tensors in ONE launch, each with its own learning rate and bias corrections (host values: the plain, non-capturable step of
+ * apex.optimizers.FusedAdam over several single-tensor groups -- src/Methods/GaussianSplatting/Model.py:121-138 builds six; apex's multi_tensor_apply).
+ * params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors device pointers; sizes / lrs / bias_correction1 / bias_correction2: HOST arrays.
+ * Same arithmetic per element as nrc_adam_step (csrc/adam_math.h). */
+int nrc_adam_step_multi(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                        const int64_t* sizes, const float* lrs, const float* bias_correction1, const float* bias_correction2, float beta1, float beta2,
+                        float eps, float weight_decay, int32_t adam_w_mode, nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 9 -- mean squared distance to the 3 nearest neighbours (3DGS scale initialisation): replaces simple_knn._C.distCUDA2

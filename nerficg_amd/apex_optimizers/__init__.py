@@ -19,6 +19,7 @@ Kernel: nerficg_amd/csrc/adam.hip through the C ABI (include/nerficg_hip.h group
 """
 from __future__ import annotations
 
+import ctypes
 import weakref
 
 import torch
@@ -234,6 +235,52 @@ class FusedAdam(torch.optim.Optimizer):
                 owner._half_written_by_optimizer(p)
         return True
 
+    def _step_multi(self, lib) -> bool:
+        """The plain step over several groups as ONE launch (nrc_adam_step_multi: apex's multi-tensor apply; the 3DGS model's six single-tensor groups with
+        their own learning rates, Model.py:121-138).  False (nothing done) when a group needs something the multi-tensor kernel does not carry -- other
+        betas / eps / weight decay than the first group, an L2 slice, an fp16 compute copy, non-f32 or non-contiguous tensors, more than 12 tensors."""
+        first = self.param_groups[0]
+        todo = []
+        for group in self.param_groups:
+            if (group['betas'] != first['betas'] or group['eps'] != first['eps'] or group['weight_decay'] != first['weight_decay']
+                    or torch.is_tensor(group.get('step'))):
+                return False
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if (p.grad.is_sparse or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous()
+                        or not p.grad.is_contiguous() or getattr(p, '_nrc_half_owner', None) is not None or self._l2_slice_of(p)[0]):
+                    return False
+                todo.append((group, p))
+        if not 1 < len(todo) <= 12 or len({p.device for _, p in todo}) != 1:
+            return False
+        stepped = set()
+        rows = []
+        for group, p in todo:
+            if id(group) not in stepped:       # like apex: one step counter per group, advanced whenever the group has gradients
+                group['step'] = group.get('step', 0) + 1
+                stepped.add(id(group))
+            state = self.state[p]
+            if len(state) == 0:
+                state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            beta1, beta2 = group['betas']
+            bc = (1.0 - beta1 ** group['step'], 1.0 - beta2 ** group['step']) if group['bias_correction'] else (1.0, 1.0)
+            rows.append((p, p.grad, state['exp_avg'], state['exp_avg_sq'], float(group['lr']), bc))
+        n = len(rows)
+        ptrs = lambda k: ctypes.cast((ctypes.c_void_p * n)(*[r[k].data_ptr() for r in rows]), ctypes.c_void_p)
+        sizes = (ctypes.c_int64 * n)(*[r[0].numel() for r in rows])
+        lrs = (ctypes.c_float * n)(*[r[4] for r in rows])
+        bc1 = (ctypes.c_float * n)(*[r[5][0] for r in rows])
+        bc2 = (ctypes.c_float * n)(*[r[5][1] for r in rows])
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        beta1, beta2 = first['betas']
+        _lib.check(lib.nrc_adam_step_multi(n, ptrs(0), ptrs(1), ptrs(2), ptrs(3), cast(sizes), cast(lrs), cast(bc1), cast(bc2), float(beta1), float(beta2),
+                                           float(first['eps']), float(first['weight_decay']), self.adam_w_mode, _lib.stream_of(rows[0][0])), 'adam_step_multi')
+        for r in rows:
+            torch.autograd.graph.increment_version(r[0])
+        return True
+
     def zero_grad(self, set_to_none: bool | None = None):
         super().zero_grad(set_to_none=self.set_grad_none if set_to_none is None else set_to_none)
 
@@ -246,6 +293,8 @@ class FusedAdam(torch.optim.Optimizer):
         lib = _lib.load()
         grad_scale = getattr(self, 'grad_scale', None)
         found_inf = getattr(self, 'found_inf', None)
+        if not self.capturable and grad_scale is None and found_inf is None and len(self.param_groups) > 1 and self._step_multi(lib):
+            return loss
         for gi, group in enumerate(self.param_groups):
             if not any(p.grad is not None for p in group['params']):
                 continue

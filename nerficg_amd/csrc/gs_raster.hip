@@ -298,41 +298,78 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
 #ifndef SHB_U
 #define SHB_U 16   // loads per trip: 8 / 12 / 16 -> k_preprocess 101 / 99 / 95-98 us at 1 M Gaussians (k_preprocess_bw indifferent)
 #endif
-template <bool TO_LDS>
+template <bool TO_LDS, int SHB_U_ = SHB_U>
 __device__ __forceinline__ void sh_block_copy(float* s_sh, int pitch, int col0, int len, int count, float* g, int nthreads) {
+    constexpr int U = SHB_U_;
     const int dq = nthreads / len, dr = nthreads - dq * len;
     int r = (int)threadIdx.x / len, c = (int)threadIdx.x - r * len;
     const int n = count * len;
     int k = threadIdx.x;
-    // SHB_U elements per trip, their loads issued together (the compiler does not batch them across the carried (row, column) by itself:
+    // U elements per trip, their loads issued together (the compiler does not batch them across the carried (row, column) by itself:
     // one load per trip and a wait behind it ran at half the speed of the divisions it replaced)
-    for (; k + (SHB_U - 1) * nthreads < n; k += SHB_U * nthreads) {
-        float v[SHB_U];
-        int off[SHB_U];
+    for (; k + (U - 1) * nthreads < n; k += U * nthreads) {
+        float v[U];
+        int off[U];
 #pragma unroll
-        for (int u = 0; u < SHB_U; u++) {
+        for (int u = 0; u < U; u++) {
             off[u] = r * pitch + col0 + c;
             v[u] = TO_LDS ? g[k + u * nthreads] : s_sh[off[u]];
             r += dq; c += dr;
             if (c >= len) { c -= len; r++; }
         }
 #pragma unroll
-        for (int u = 0; u < SHB_U; u++) { if (TO_LDS) s_sh[off[u]] = v[u]; else g[k + u * nthreads] = v[u]; }
+        for (int u = 0; u < U; u++) { if (TO_LDS) s_sh[off[u]] = v[u]; else g[k + u * nthreads] = v[u]; }
     }
-    for (; k < n; k += nthreads) {
-        if (TO_LDS) s_sh[r * pitch + col0 + c] = g[k]; else g[k] = s_sh[r * pitch + col0 + c];
-        r += dq; c += dr;
-        if (c >= len) { c -= len; r++; }
+    // the rest (a block of 45-float rows -- the model's split `rest` tensor -- leaves 13 of 45 elements per thread, the 3-float dc rows all 3): ONE more
+    // batched trip with predicated accesses.  Round 6: this used to be a one-load-one-wait loop, 13 + 3 dependent round trips per thread -- the split
+    // form of the training step cost k_preprocess +24 us and k_preprocess_bw +31 us over the concatenated (P, 16, 3) form (tools/exp_gs_pre.py)
+    if (k < n) {
+        float v[U];
+        int off[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool in = k + u * nthreads < n;
+            off[u] = r * pitch + col0 + c;
+            v[u] = 0.f;
+            if (in) v[u] = TO_LDS ? g[k + u * nthreads] : s_sh[off[u]];
+            r += dq; c += dr;
+            if (c >= len) { c -= len; r++; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (k + u * nthreads < n) { if (TO_LDS) s_sh[off[u]] = v[u]; else g[k + u * nthreads] = v[u]; }
+        }
     }
 }
-template <bool TO_LDS>
+template <bool TO_LDS, int SHB_U_ = SHB_U>
 __device__ __forceinline__ void sh_rows_copy(float* s_sh, int pitch, int row_len, int count, size_t first, float* sh, float* sh_rest, int nthreads) {
     if (!sh_rest) {
-        sh_block_copy<TO_LDS>(s_sh, pitch, 0, row_len, count, sh + first * row_len, nthreads);
+        sh_block_copy<TO_LDS, SHB_U_>(s_sh, pitch, 0, row_len, count, sh + first * row_len, nthreads);
     } else {
-        sh_block_copy<TO_LDS>(s_sh, pitch, 0, 3, count, sh + first * 3, nthreads);
+        // the three dc floats per Gaussian ride along with the first trip of the `rest` block: their loads are issued in front of it and land in LDS
+        // behind it (a separate one-trip copy was a dependent round trip of its own, per direction, in kernels that run a few waves per CU)
+        float* dc = sh + first * 3;
+        const int n3 = count * 3;
+        float dv[3];
+        int doff[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int k = (int)threadIdx.x + u * nthreads;
+            const int r = k / 3, c = k - 3 * r;
+            doff[u] = r * pitch + c;
+            dv[u] = 0.f;
+            if (k < n3) dv[u] = TO_LDS ? dc[k] : s_sh[doff[u]];
+        }
+        if (!TO_LDS) {
+#pragma unroll
+            for (int u = 0; u < 3; u++) { const int k = (int)threadIdx.x + u * nthreads; if (k < n3) dc[k] = dv[u]; }
+        }
         const int rl = row_len - 3;
-        if (rl > 0) sh_block_copy<TO_LDS>(s_sh, pitch, 3, rl, count, sh_rest + first * rl, nthreads);
+        if (rl > 0) sh_block_copy<TO_LDS, SHB_U_>(s_sh, pitch, 3, rl, count, sh_rest + first * rl, nthreads);
+        if (TO_LDS) {
+#pragma unroll
+            for (int u = 0; u < 3; u++) { const int k = (int)threadIdx.x + u * nthreads; if (k < n3) s_sh[doff[u]] = dv[u]; }
+        }
     }
 }
 #define SPAN_DIM_MAX 256     // tile rows / columns the lane-private cursors cover (4 registers x 64 lanes): 4096 x 4096 pixels
@@ -1849,6 +1886,9 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
 #ifndef PBW_BLOCK
 #define PBW_BLOCK 128
 #endif
+#ifndef PBW_SHB_U
+#define PBW_SHB_U 12
+#endif
 #ifndef PBW_MAXM
 #define PBW_MAXM 16
 #endif
@@ -1867,7 +1907,9 @@ __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_ar
     const int count = min(PBW_BLOCK, P - first);
     const bool visible = i < P && radii[i] > 0;
     if (use_sh) {
-        sh_rows_copy<true>(s_sh, pitch, row_len, count, (size_t)first, const_cast<float*>(shs), const_cast<float*>(shs_rest), PBW_BLOCK);
+        // 12 elements per trip here (k_preprocess: 16): with 16 this kernel's 204 VGPRs left the split-SH form of the training step at 168-179 us against
+        // 133-138 with 12 or 8 (the concatenated form 139 -> 128; tools/exp_gs_pre.py, round 6)
+        sh_rows_copy<true, PBW_SHB_U>(s_sh, pitch, row_len, count, (size_t)first, const_cast<float*>(shs), const_cast<float*>(shs_rest), PBW_BLOCK);
         __syncthreads();
     }
     float* sh_row = s_sh + threadIdx.x * pitch;
@@ -1893,7 +1935,7 @@ __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_ar
     }
     if (use_sh) {
         __syncthreads();
-        sh_rows_copy<false>(s_sh, pitch, row_len, count, (size_t)first, dL_dsh, dL_dsh_rest, PBW_BLOCK);
+        sh_rows_copy<false, PBW_SHB_U>(s_sh, pitch, row_len, count, (size_t)first, dL_dsh, dL_dsh_rest, PBW_BLOCK);
     }
 }
 
@@ -1955,6 +1997,32 @@ BinWs gs_bin_ws(uint32_t* base, int P, int gx, int gy, int64_t cap) {
 const bool g_gs_no_overlap = [] { const char* e = getenv("NRC_GS_OVERLAP"); return !(e && e[0] == '1'); }();
 // NRC_GS_COLOR_BLOCKS (read once): persistent workgroups of the colour pass per compute unit (default 2)
 const int g_gs_color_blocks_per_cu = [] { const char* e = getenv("NRC_GS_COLOR_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 16 ? v : 2; }();
+// The camera block of a frame (GS_POSE_FLOATS) from a camera-to-world pose that lives on the DEVICE: what GaussianSplatting/Renderer.py:60-74 computes on the
+// host -- viewmatrix = w2c^T = [[R, 0], [-(R^T t)^T, 1]], projmatrix = viewmatrix @ P^T, campos = t -- as one launch of one wave (the tensor-op form was
+// eleven launches of 4-5 us in front of every training step: transpose, matrix-vector product, negation, four concatenations, two fills, a 4x4 product).
+__global__ void k_camera_block(const float* __restrict__ c2w, const float* __restrict__ proj_t, const float* __restrict__ bg3, float* __restrict__ out) {
+    __shared__ float view[16];
+    const int k = threadIdx.x;
+    if (k < 16) {
+        const int r = k >> 2, c = k & 3;
+        float v;
+        if (r < 3) v = c < 3 ? c2w[4 * r + c] : 0.f;
+        else if (c == 3) v = 1.f;
+        else v = -(c2w[c] * c2w[3] + c2w[4 + c] * c2w[7] + c2w[8 + c] * c2w[11]);   // -(R^T t)_c
+        view[k] = v;
+        out[k] = v;
+    }
+    __syncthreads();
+    if (k < 16) {
+        const int r = k >> 2, c = k & 3;
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) a = fmaf(view[4 * r + j], proj_t[4 * j + c], a);
+        out[16 + k] = a;
+    }
+    if (k < 3) { out[32 + k] = c2w[4 * k + 3]; out[35 + k] = bg3 ? bg3[k] : 0.f; }
+}
+
 int make_cam(GsCam& cam, int W, int H, int D, int M, const float* view, const float* proj, const float* campos, const float* camera_dev, float tanx,
              float tany, float scale_modifier, int raw) {
     if (W < 1 || H < 1 || D < 0 || D > 3 || !(tanx > 0.f) || !(tany > 0.f)) return NRC_ERR_INVALID;
@@ -2091,6 +2159,14 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_counts, n_tiles, list_cap, ranges, tile_fill, num_rendered);
         nrc_zero_async(num_rendered + 1, sizeof(int64_t), s);  // no span workspace in use
     }
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+
+int nrc_gs_camera_block(const float* c2w_dev, const float* proj_t_dev, const float* bg3_dev, float* camera_dev_out, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (!c2w_dev || !proj_t_dev || !camera_dev_out) return NRC_ERR_INVALID;
+    hipLaunchKernelGGL(k_camera_block, dim3(1), dim3(64), 0, (hipStream_t)stream, c2w_dev, proj_t_dev, bg3_dev, camera_dev_out);
     NRC_LAUNCH_CHECK();
     return NRC_OK;
 }

@@ -40,6 +40,13 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 _CAMERA_BLOCKS: dict = {}
+_ADOPTED_BLOCK: list = [None]   # the latest camera block written by nrc_gs_camera_block (gaussian_splatting.make_raster_settings)
+
+
+def adopt_camera_block(block: torch.Tensor) -> None:
+    """Registers a float[38] device block whose slices a GaussianRasterizationSettings is about to carry (viewmatrix = block[:16], projmatrix = block[16:32],
+    campos = block[32:35], bg = block[35:38]): _camera_block() then uses it as it is."""
+    _ADOPTED_BLOCK[0] = block
 
 
 def _camera_block(rs, dev) -> torch.Tensor:
@@ -48,6 +55,12 @@ def _camera_block(rs, dev) -> torch.Tensor:
     version counter -> same values), so a renderer that draws several passes from one camera pays it once.  During a stream capture it is
     always rebuilt, so that the recorded graph re-reads the (then static) camera tensors on every replay."""
     tensors = (rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg)
+    blk = _ADOPTED_BLOCK[0]
+    if blk is not None and blk.device == torch.device(dev) and all(t.is_cuda and t.dtype == torch.float32 for t in tensors):
+        base = blk.data_ptr()
+        if (rs.viewmatrix.data_ptr() == base and rs.projmatrix.data_ptr() == base + 64 and rs.campos.data_ptr() == base + 128 and rs.bg.data_ptr() == base + 140
+                and rs.viewmatrix.is_contiguous() and rs.projmatrix.is_contiguous()):
+            return blk     # (also inside a stream capture: the launch that fills the block is part of the recording)
     capturing = torch.cuda.is_current_stream_capturing()
     key = tuple((t.data_ptr(), t._version, t.device) for t in tensors)
     hit = None if capturing else _CAMERA_BLOCKS.get(key)
@@ -323,9 +336,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.ptr(dsh), _lib.ptr(dsh_rest), _lib.ptr(dscale), _lib.ptr(drot), _lib.ptr(grad_records), int(records_clear), _lib.stream_of(g)), 'gs_backward')
         if not capturing and P > 0:   # (P == 0: the library returned before touching the uninitialised buffer -- it is NOT known to be zero)
             _GRAD_RECORDS[rec_key] = (n1, grad_records)   # only after a call that went through: a failed one leaves the entry popped (contents unknown)
-        return (dmean3D[:P], dmean2D[:P], dsh[:P] if has_sh else None, dcolor[:P] if has_col else None,
-                dopacity[:P].reshape(ctx.opacity_shape), dscale[:P] if has_sr else None, drot[:P] if has_sr else None,
-                dcov3D[:P] if has_cov else None, None, dsh_rest[:P] if has_rest else None, None)
+        cut = (lambda t: t) if P == n1 else (lambda t: t[:P])     # (whole buffers when nothing is cut: a gradient that is not a view can be adopted as .grad without a copy)
+        return (cut(dmean3D), cut(dmean2D), cut(dsh) if has_sh else None, cut(dcolor) if has_col else None,
+                cut(dopacity).reshape(ctx.opacity_shape), cut(dscale) if has_sr else None, cut(drot) if has_sr else None,
+                cut(dcov3D) if has_cov else None, None, cut(dsh_rest) if has_rest else None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, sh_rest=None, raw=False):

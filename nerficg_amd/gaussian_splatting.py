@@ -78,7 +78,22 @@ def make_raster_settings(cam: PerspectiveCamera, c2w, sh_degree: int, scale_modi
     array, or a device tensor -- the pose then never visits the host (w2c.T = [[R, 0], [-(R^T t)^T, 1]] is assembled by torch on the
     device), which is what a recorded training step needs: it re-reads the tensor on every replay."""
     from .diff_gaussian_rasterization import GaussianRasterizationSettings
-    if torch.is_tensor(c2w):
+    if torch.is_tensor(c2w) and c2w.is_cuda:
+        # one launch writes the rasterizer's whole camera block (view | view @ P^T | position | background); the settings' tensors are views of it and
+        # the rasterizer recognises the block (diff_gaussian_rasterization.adopt_camera_block) instead of concatenating its own
+        from . import _lib
+        from .diff_gaussian_rasterization import adopt_camera_block
+        pose = c2w.to(device=device, dtype=torch.float32).contiguous()
+        bg = cam.background_color.to(device=device, dtype=torch.float32).contiguous()
+        block = torch.empty(38, dtype=torch.float32, device=pose.device)
+        _lib.check(_lib.load().nrc_gs_camera_block(_lib.ptr(pose), _lib.ptr(_projection_transposed(cam, device)), _lib.ptr(bg), _lib.ptr(block), _lib.stream_of(block)),
+                   'gs_camera_block')
+        adopt_camera_block(block)
+        return GaussianRasterizationSettings(
+            image_height=cam.height, image_width=cam.width, tanfovx=cam.width / cam.focal_x * 0.5, tanfovy=cam.height / cam.focal_y * 0.5,
+            bg=block[35:38], scale_modifier=scale_modifier, viewmatrix=block[:16].view(4, 4), projmatrix=block[16:32].view(4, 4), sh_degree=sh_degree,
+            campos=block[32:35], prefiltered=False, debug=False)
+    elif torch.is_tensor(c2w):
         pose = c2w.to(device=device, dtype=torch.float32)
         rot, pos = pose[:3, :3], pose[:3, 3]
         last_row = torch.cat([-(rot.T @ pos), pose.new_ones(1)])
@@ -371,8 +386,9 @@ def render_image_training(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np.
     """GaussianSplatting/Renderer.py:51-86."""
     from .diff_gaussian_rasterization import GaussianRasterizer
     positions = gaussians.get_positions
-    viewspace_points = torch.zeros_like(positions, requires_grad=True) + 0
-    viewspace_points.retain_grad()
+    # the carrier of the screen-space gradient (Renderer.py:56-58: zeros_like + 0, retain_grad): the rasterizer never reads its VALUES, only hands it a
+    # gradient -- a leaf of uninitialised memory receives the same .grad without a 12 MB fill and a 24 MB add per step
+    viewspace_points = torch.empty_like(positions).requires_grad_(True)
     rasterizer = GaussianRasterizer(make_raster_settings(cam, c2w, gaussians.active_sh_degree, 1.0, positions.device))
     if gaussians.baked:  # a baked model holds activated values
         image, radii = rasterizer(means3D=positions, means2D=viewspace_points, shs=gaussians.get_features_dc, shs_rest=gaussians.get_features_rest,
@@ -380,7 +396,21 @@ def render_image_training(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np.
     else:  # raw parameters straight into the kernels: no get_features concatenation, no separate exp / sigmoid / normalize passes (a25)
         image, radii = rasterizer(means3D=positions, means2D=viewspace_points, shs=gaussians._features_dc, shs_rest=gaussians._features_rest,
                                   opacities=gaussians._opacities, scales=gaussians._scales, rotations=gaussians._rotations, raw_parameters=True)
-    return {'rgb': image, 'viewspace_points': viewspace_points, 'visibility_mask': radii > 0, 'radii': radii}
+    return _TrainingOutputs({'rgb': image, 'viewspace_points': viewspace_points, 'radii': radii})
+
+
+class _TrainingOutputs(dict):
+    """The outputs of Renderer.py:83-86; 'visibility_mask' (radii > 0) is built when somebody asks for it -- the densification statistics and the view-parallel
+    exchange take `radii` itself, so the plain step does not pay the launch."""
+
+    def __missing__(self, key):
+        if key == 'visibility_mask':
+            self[key] = self['radii'] > 0
+            return self[key]
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == 'visibility_mask' or super().__contains__(key)
 
 
 @torch.no_grad()

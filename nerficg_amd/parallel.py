@@ -364,7 +364,7 @@ class UnionRowExchange:
     """View-parallel 3DGS: the per-Gaussian gradients of `params` (each (P, ...)) are summed (averaged) over the ranks, moving only the rows
     some rank saw.  Two calls per step, shaped so that nothing waits for the wire or the host that does not have to:
 
-        begin(visible)    right after the forward pass (radii are known, the backward pass is not enqueued yet), on a communication stream:
+        begin(visible)    (a boolean mask, or the rasterizer's integer radii) right after the forward pass (the backward pass is not enqueued yet), on a communication stream:
                           max-all-reduce of the byte visibility mask -> nrc_compact_mask (device scan: the same ascending union list on every rank) ->
                           the count goes to pinned host memory behind an event.  The caller now enqueues the backward pass; mask traffic and scan run beside it.
         finish(params)    behind the backward pass: the host reads the count (the device is busy with the backward pass meanwhile -- the read that used to
@@ -401,7 +401,7 @@ class UnionRowExchange:
             self.n = -1
             return
         if not self._cuda:      # CPU tensors (the gloo tests): the same protocol with torch ops
-            self.union.copy_(visible.to(torch.uint8))
+            self.union.copy_((visible if visible.dtype == torch.bool else visible > 0).to(torch.uint8))
             dist.all_reduce(self.union, op=dist.ReduceOp.MAX)
             self.idx = torch.nonzero(self.union, as_tuple=False).flatten().to(torch.int32)
             self.n = int(self.idx.numel())
@@ -411,7 +411,7 @@ class UnionRowExchange:
         self.comm.wait_stream(main)
         visible.record_stream(self.comm)
         with torch.cuda.stream(self.comm):
-            self.union.copy_(visible)                      # bool -> u8
+            self.union.copy_(visible if visible.dtype == torch.bool else visible > 0)     # bool (or the rasterizer's radii: visible = radius > 0) -> u8
             if _staged(self.union):
                 host = self.union.cpu(); dist.all_reduce(host, op=dist.ReduceOp.MAX); self.union.copy_(host)
             else:

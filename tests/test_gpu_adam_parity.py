@@ -272,3 +272,35 @@ def test_settle_plus_adam_slices_equal_the_one_call_step_bit_for_bit(overflow):
     assert int(A['step']) == (3 if overflow else 4) and float(A['scale']) == (64.0 if overflow else 256.0)
     fresh = state()
     assert torch.equal(A['pa'], fresh['pa']) == overflow
+
+
+def test_multi_tensor_step_equals_the_per_tensor_launches_bit_for_bit(monkeypatch):
+    """Six single-tensor groups with their own learning rates (src/Methods/GaussianSplatting/Model.py:121-138) through nrc_adam_step_multi (one launch) and
+    through six nrc_adam_step launches: the same parameters and moments bit for bit over three steps, one group without a gradient in step 2 (its step counter
+    must not advance), odd sizes and a misaligned view among them."""
+    from nerficg_amd.apex_optimizers import FusedAdam
+    shapes = [(1000, 3), (1000, 1, 3), (1000, 15, 3), (1000, 1), (1000, 3), (1001,)]
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 5e-2, 5e-3, 1e-3]
+
+    def run(multi):
+        gen = torch.Generator(device=DEV).manual_seed(4)
+        base = torch.randn(1002, device=DEV, generator=gen)
+        params = [torch.nn.Parameter(torch.randn(s, device=DEV, generator=gen)) for s in shapes[:-1]] + [torch.nn.Parameter(base[1:])]   # the last one 4 bytes off a 16-byte boundary
+        opt = FusedAdam([{'params': [p], 'lr': lr, 'name': str(k)} for k, (p, lr) in enumerate(zip(params, lrs))], lr=0.0, eps=1e-15)
+        if not multi:
+            monkeypatch.setattr(opt, '_step_multi', lambda lib: False)
+        calls = []
+        real = opt._step_multi
+        if multi:
+            monkeypatch.setattr(opt, '_step_multi', lambda lib: (calls.append(1), real(lib))[1])
+        for it in range(3):
+            for k, p in enumerate(params):
+                p.grad = None if (it == 1 and k == 3) else torch.randn(p.shape, device=DEV, generator=gen) * 10.0 ** (k - 3)
+            opt.step()
+        assert (len(calls) == 3) == multi
+        return [p.detach().clone() for p in params], [opt.state[p][n].clone() for p in params for n in ('exp_avg', 'exp_avg_sq')], [g['step'] for g in opt.param_groups]
+
+    a, b = run(True), run(False)
+    assert a[2] == b[2] == [3, 3, 3, 2, 3, 3]
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        assert torch.equal(x, y)
