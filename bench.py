@@ -862,6 +862,7 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=8):
     g = Gaussians(T(sc['means3D']), torch.log(T(sc['scales'])), T(sc['rotations']), torch.logit(T(sc['opacities']).clamp(1e-4, 1 - 1e-4))[:, None].contiguous(),
                   T(sc['shs'][:, :1]), T(sc['shs'][:, 1:]))
     g.training_setup(training_cameras_extent=4.5)
+    g.fuse_rest_step = world == 1      # one GPU: the f_rest Adam step runs inside the preprocessing backward; view-parallel ranks need that gradient on the wire
     params = [grp['params'][0] for grp in g.optimizer.param_groups]
     if world > 1:
         parallel.broadcast_parameters(params)

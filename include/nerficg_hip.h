@@ -358,6 +358,19 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
                     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                     float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale, float* dL_drot, float* grad_records,
                     int32_t records_clear, nrc_stream_t stream);
+/* nrc_gs_backward + the optimizer step of the `rest` SH tensor in one pass (round 6): 45 of a Gaussian's 59 parameters are SH coefficients above the dc term, and
+ * their gradient rows sit in LDS at the end of the preprocessing backward -- Adam (apex FusedAdam, src/Methods/GaussianSplatting/Model.py:121-138, group 'f_rest':
+ * no weight decay, eps as given) is applied THERE: dL/d shs_rest is never written and read back (180 B per Gaussian each way), the parameters are not read a second time.
+ * shs_rest_param: the (P, M-1, 3) tensor the forward read, updated in place; rest_exp_avg / rest_exp_avg_sq its moments; bias corrections as host values.  Device camera
+ * block only.  Same per-element arithmetic as nrc_adam_step.  The caller's optimizer must skip that tensor in this step (its .grad stays empty). */
+int nrc_gs_backward_rest_step(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg_host, const float* means3D, const float* shs,
+                    float* shs_rest_param, int32_t raw_parameters, const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                    const float* camera_dev, float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
+                    const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list, const uint32_t* ranges,
+                    const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
+                    float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                    float* dL_drot, float* grad_records, int32_t records_clear, float* rest_exp_avg, float* rest_exp_avg_sq, float lr, float beta1, float beta2,
+                    float eps, float bias_correction1, float bias_correction2, nrc_stream_t stream);
 
 /* =====================================================================================================
  * Group 5 -- ray generation (replaces PerspectiveCamera.compute_local_ray_directions src/Cameras/Perspective.py:64-94

@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "adam_math.h"
 
 #define TILE 16
 #define BATCH 256
@@ -1889,6 +1890,10 @@ __device__ __forceinline__ void preprocess_bw_one(int i, const GsCam& cam, const
 #ifndef PBW_SHB_U
 #define PBW_SHB_U 12
 #endif
+// Adam on the `rest` SH coefficients (45 of a Gaussian's 59 parameters: 76 % of the optimizer's traffic) INSIDE the preprocessing backward: the gradient
+// rows sit in LDS at the end of this kernel, so the step reads them there instead of the kernel writing 180 B per Gaussian and the optimizer reading them and
+// the parameters back (nrc_gs_backward_rest_step).  p == nullptr: the gradient is written as usual.  Same per-element arithmetic as k_adam (adam_math.h).
+struct RestAdam { float* p; float* m; float* v; float lr, beta1, beta2, eps, bc1, bc2; };
 #ifndef PBW_MAXM
 #define PBW_MAXM 16
 #endif
@@ -1899,7 +1904,7 @@ __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_ar
                                                              float* __restrict__ dL_dconic, float* __restrict__ dL_dcolor,
                                                              float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
                                                              float* __restrict__ dL_dsh_rest, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-                                                             float* __restrict__ dL_dopacity) {
+                                                             float* __restrict__ dL_dopacity, RestAdam ra) {
     __shared__ float s_sh[PBW_BLOCK * (3 * PBW_MAXM + 1)];
     const GsCam cam = cam_with_pose(cam_arg, pose);
     const int first = blockIdx.x * PBW_BLOCK, i = first + threadIdx.x;
@@ -1935,7 +1940,39 @@ __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_ar
     }
     if (use_sh) {
         __syncthreads();
-        sh_rows_copy<false, PBW_SHB_U>(s_sh, pitch, row_len, count, (size_t)first, dL_dsh, dL_dsh_rest, PBW_BLOCK);
+        if (ra.p == nullptr) {
+            sh_rows_copy<false, PBW_SHB_U>(s_sh, pitch, row_len, count, (size_t)first, dL_dsh, dL_dsh_rest, PBW_BLOCK);
+        } else {
+            // dc gradient rows as usual (3 floats per Gaussian), then Adam over the block's `rest` rows: element k of the contiguous (count, row_len - 3) block, gradient
+            // from LDS (invisible Gaussians: zeros -- their moments decay and their parameters move like in the optimizer's own launch)
+            sh_block_copy<false, PBW_SHB_U>(s_sh, pitch, 0, 3, count, dL_dsh + (size_t)first * 3, PBW_BLOCK);
+            const int len = row_len - 3, n = count * len;
+            const size_t g0 = (size_t)first * len;
+            const int dq = PBW_BLOCK / len, dr = PBW_BLOCK - dq * len;
+            int r = (int)threadIdx.x / len, c = (int)threadIdx.x - r * len;
+            const NrcAdamHyper h{ra.lr, ra.beta1, ra.beta2, ra.eps, 0.f, 0, ra.bc1, ra.bc2, 1.0f};
+            enum { RU = 4 };
+            for (int k = threadIdx.x; k < n; k += RU * PBW_BLOCK) {
+                float pv[RU], mv[RU], vv[RU], gv[RU];
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    const int kk = k + u * PBW_BLOCK;
+                    const bool in = kk < n;
+                    gv[u] = in ? s_sh[r * pitch + 3 + c] : 0.f;
+                    pv[u] = in ? ra.p[g0 + kk] : 0.f; mv[u] = in ? ra.m[g0 + kk] : 0.f; vv[u] = in ? ra.v[g0 + kk] : 0.f;
+                    r += dq; c += dr;
+                    if (c >= len) { c -= len; r++; }
+                }
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    const int kk = k + u * PBW_BLOCK;
+                    if (kk < n) {
+                        nrc_adam_update(pv[u], gv[u], mv[u], vv[u], h, false, 0.f);
+                        ra.p[g0 + kk] = pv[u]; ra.m[g0 + kk] = mv[u]; ra.v[g0 + kk] = vv[u];
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -2218,7 +2255,7 @@ int nrc_gs_bin_render(int32_t P, int32_t W, int32_t H, const float* bg_host, con
     return NRC_OK;
 }
 
-int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg_host, const float* means3D, const float* shs,
+static int gs_backward_impl(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg_host, const float* means3D, const float* shs,
                     const float* shs_rest, int32_t raw_parameters, const float* opacities, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                     const float* cov3D_precomp, const float* viewmatrix_host, const float* projmatrix_host, const float* campos_host,
                     const float* camera_dev, float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
@@ -2226,8 +2263,7 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
                     const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
                     float* dL_dmean2D, float* dL_dconic,
                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
-                    float* dL_drot, float* grad_records, int32_t records_clear, nrc_stream_t stream) {
-    NRC_ENTER();
+                    float* dL_drot, float* grad_records, int32_t records_clear, nrc_stream_t stream, RestAdam ra) {
     GsCam cam;
     const int rc = make_cam(cam, W, H, D, M, viewmatrix_host, projmatrix_host, campos_host, camera_dev, tan_fovx, tan_fovy, scale_modifier, raw_parameters);
     if (rc != NRC_OK) return rc;
@@ -2239,7 +2275,8 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
         return NRC_ERR_INVALID;
     const int use_sh = colors_precomp == nullptr, use_sr = cov3D_precomp == nullptr;
     if ((use_sh && (!shs || !dL_dsh)) || (use_sr && (!scales || !rotations || !dL_dscale || !dL_drot))) return NRC_ERR_INVALID;
-    if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr) || (raw_parameters && (!opacities || !use_sr))) return NRC_ERR_INVALID;
+    if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr || ra.p != nullptr) || (raw_parameters && (!opacities || !use_sr))) return NRC_ERR_INVALID;
+    if (ra.p && (ra.p != shs_rest || !ra.m || !ra.v || !use_sh || dL_dsh_rest || !(ra.bc1 > 0.f) || !(ra.bc2 > 0.f))) return NRC_ERR_INVALID;   // the step updates the tensor the kernels read
     hipStream_t s = (hipStream_t)stream;
     NRC_STAGE(s, nullptr);
     if (use_sh && M > PBW_MAXM) return NRC_ERR_UNSUPPORTED;
@@ -2251,10 +2288,45 @@ int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const
                        camera_dev, n_contrib, final_T, dL_dpix, grad_records);
     NRC_STAGE(s, "k_render_bw");
     hipLaunchKernelGGL(k_preprocess_bw, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, P, cam, camera_dev, means3D, shs, shs_rest, opacities, use_sh, scales, rotations,
-                       use_sr, radii, clamped, cov3D, grad_records, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, dL_dopacity);
+                       use_sr, radii, clamped, cov3D, grad_records, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, dL_dopacity, ra);
     NRC_STAGE(s, "k_preprocess_bw");
     NRC_LAUNCH_CHECK();
     return NRC_OK;
+}
+
+int nrc_gs_backward(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg_host, const float* means3D, const float* shs,
+                    const float* shs_rest, int32_t raw_parameters, const float* opacities, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                    const float* cov3D_precomp, const float* viewmatrix_host, const float* projmatrix_host, const float* campos_host,
+                    const float* camera_dev, float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
+                    const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list, const uint32_t* ranges,
+                    const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
+                    float* dL_dmean2D, float* dL_dconic,
+                    float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
+                    float* dL_drot, float* grad_records, int32_t records_clear, nrc_stream_t stream) {
+    NRC_ENTER();
+    return gs_backward_impl(P, D, M, W, H, bg_host, means3D, shs, shs_rest, raw_parameters, opacities, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                            viewmatrix_host, projmatrix_host, campos_host, camera_dev, tan_fovx, tan_fovy, radii, points_xy, conic_opacity, rgb, clamped, cov3D, point_list,
+                            ranges, splat_records, tile_order, n_contrib, final_T, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+                            dL_dsh_rest, dL_dscale, dL_drot, grad_records, records_clear, stream, RestAdam{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f});
+}
+
+/* nrc_gs_backward whose preprocessing backward applies the optimizer's Adam step to the `rest` SH tensor itself (shs_rest_param = the tensor passed as shs_rest in the
+ * forward; exp_avg / exp_avg_sq its moments): dL/d shs_rest is not materialised.  Everything else as nrc_gs_backward. */
+int nrc_gs_backward_rest_step(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, const float* bg_host, const float* means3D, const float* shs,
+                    float* shs_rest_param, int32_t raw_parameters, const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                    const float* camera_dev, float tan_fovx, float tan_fovy, const int32_t* radii, const float* points_xy, const float* conic_opacity,
+                    const float* rgb, const uint8_t* clamped, const float* cov3D, const int32_t* point_list, const uint32_t* ranges,
+                    const float* splat_records, const uint32_t* tile_order, const uint32_t* n_contrib, const float* final_T, const float* dL_dpix,
+                    float* dL_dmean2D, float* dL_dopacity, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                    float* dL_drot, float* grad_records, int32_t records_clear, float* rest_exp_avg, float* rest_exp_avg_sq, float lr, float beta1, float beta2,
+                    float eps, float bias_correction1, float bias_correction2, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (!shs_rest_param || !rest_exp_avg || !rest_exp_avg_sq || !camera_dev) return NRC_ERR_INVALID;
+    return gs_backward_impl(P, D, M, W, H, nullptr, means3D, shs, shs_rest_param, raw_parameters, opacities, nullptr, scales, scale_modifier, rotations, nullptr,
+                            nullptr, nullptr, nullptr, camera_dev, tan_fovx, tan_fovy, radii, points_xy, conic_opacity, rgb, clamped, cov3D, point_list,
+                            ranges, splat_records, tile_order, n_contrib, final_T, dL_dpix, dL_dmean2D, nullptr, dL_dopacity, nullptr, dL_dmean3D, dL_dcov3D, dL_dsh,
+                            nullptr, dL_dscale, dL_drot, grad_records, records_clear, stream,
+                            RestAdam{shs_rest_param, rest_exp_avg, rest_exp_avg_sq, lr, beta1, beta2, eps, bias_correction1, bias_correction2});
 }
 
 }  // extern "C"

@@ -133,7 +133,7 @@ def _opt(t):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, sh_rest=None, raw=False):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, sh_rest=None, raw=False, rest_step=None):
         rs = raster_settings
         lib = _lib.load()
         dev = means3D.device
@@ -282,6 +282,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                               cov_c if cov_c is not None else torch.empty(0), radii, points_xy, conic_opacity, rgb, clamped, cov3D,
                               point_list, ranges, n_contrib, final_T, splat, tile_fill, rest_c if rest_c is not None else torch.empty(0), op_c, cam_block)
         ctx.raw, ctx.has_rest = raw, rest_c is not None
+        ctx.rest_step = rest_step
+        if rest_step is not None and (rest_c is None or rest_c.data_ptr() != sh_rest.data_ptr() or sc_c is None or col_c is not None or cov_c is not None):
+            raise RuntimeError('rest_step: needs shs_rest as a contiguous f32 CUDA tensor (updated in place), scales / rotations, no colors_precomp / cov3D_precomp')
         ctx.debug_state = dict(depths=depths, tiles_touched=tiles_touched, keys=keys)
         radii_out = radii[:P]
         ctx.mark_non_differentiable(radii_out)
@@ -323,27 +326,42 @@ class _RasterizeGaussians(torch.autograd.Function):
         dmean3D = torch.empty(n1, 3, dtype=f32, device=dev)
         dcov3D = torch.empty(n1, 6, dtype=f32, device=dev)
         dsh = torch.empty(n1, 1 if has_rest else max(M, 1), 3, dtype=f32, device=dev) if has_sh else None
-        dsh_rest = torch.empty(n1, M - 1, 3, dtype=f32, device=dev) if has_rest else None
+        rest_step = ctx.rest_step
+        dsh_rest = torch.empty(n1, M - 1, 3, dtype=f32, device=dev) if has_rest and rest_step is None else None
         dscale = torch.empty(n1, 3, dtype=f32, device=dev) if has_sr else None
         drot = torch.empty(n1, 4, dtype=f32, device=dev) if has_sr else None
-        _lib.check(lib.nrc_gs_backward(
-            P, D, M, W, H, None, _lib.ptr(means3D), _lib.ptr(sh if has_sh else None), _lib.ptr(sh_rest if has_rest else None), int(raw),
-            _lib.ptr(opac if raw else None), _lib.ptr(col if has_col else None),
-            _lib.ptr(sc if has_sr else None), float(rs.scale_modifier), _lib.ptr(rot if has_sr else None), _lib.ptr(cov if has_cov else None),
-            None, None, None, _lib.ptr(cam_block), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
-            _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(point_list), _lib.ptr(ranges), _lib.ptr(splat), _lib.ptr(tile_order), _lib.ptr(n_contrib), _lib.ptr(final_T),
-            _lib.ptr(g), _lib.ptr(dmean2D), None, _lib.ptr(dopacity), _lib.ptr(dcolor), _lib.ptr(dmean3D), _lib.ptr(dcov3D),
-            _lib.ptr(dsh), _lib.ptr(dsh_rest), _lib.ptr(dscale), _lib.ptr(drot), _lib.ptr(grad_records), int(records_clear), _lib.stream_of(g)), 'gs_backward')
+        if rest_step is not None:
+            # the optimizer step of the `rest` SH tensor inside the preprocessing backward (nrc_gs_backward_rest_step): no gradient tensor for it
+            param, m_rest, v_rest, lr, beta1, beta2, eps, bc1, bc2 = rest_step.take()
+            if param.data_ptr() != sh_rest.data_ptr():
+                raise RuntimeError('rest_step: the tensor to update is not the one the forward pass read')
+            _lib.check(lib.nrc_gs_backward_rest_step(
+                P, D, M, W, H, None, _lib.ptr(means3D), _lib.ptr(sh), _lib.ptr(sh_rest), int(raw), _lib.ptr(opac if raw else None), _lib.ptr(sc), float(rs.scale_modifier),
+                _lib.ptr(rot), _lib.ptr(cam_block), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(points_xy), _lib.ptr(conic_opacity), _lib.ptr(rgb),
+                _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(point_list), _lib.ptr(ranges), _lib.ptr(splat), _lib.ptr(tile_order), _lib.ptr(n_contrib), _lib.ptr(final_T),
+                _lib.ptr(g), _lib.ptr(dmean2D), _lib.ptr(dopacity), _lib.ptr(dmean3D), _lib.ptr(dcov3D), _lib.ptr(dsh), _lib.ptr(dscale), _lib.ptr(drot),
+                _lib.ptr(grad_records), int(records_clear), _lib.ptr(m_rest), _lib.ptr(v_rest), float(lr), float(beta1), float(beta2), float(eps), float(bc1), float(bc2),
+                _lib.stream_of(g)), 'gs_backward_rest_step')
+            torch.autograd.graph.increment_version(param)      # written through a raw pointer
+        else:
+            _lib.check(lib.nrc_gs_backward(
+                P, D, M, W, H, None, _lib.ptr(means3D), _lib.ptr(sh if has_sh else None), _lib.ptr(sh_rest if has_rest else None), int(raw),
+                _lib.ptr(opac if raw else None), _lib.ptr(col if has_col else None),
+                _lib.ptr(sc if has_sr else None), float(rs.scale_modifier), _lib.ptr(rot if has_sr else None), _lib.ptr(cov if has_cov else None),
+                None, None, None, _lib.ptr(cam_block), float(rs.tanfovx), float(rs.tanfovy), _lib.ptr(radii), _lib.ptr(points_xy), _lib.ptr(conic_opacity),
+                _lib.ptr(rgb), _lib.ptr(clamped), _lib.ptr(cov3D), _lib.ptr(point_list), _lib.ptr(ranges), _lib.ptr(splat), _lib.ptr(tile_order), _lib.ptr(n_contrib), _lib.ptr(final_T),
+                _lib.ptr(g), _lib.ptr(dmean2D), None, _lib.ptr(dopacity), _lib.ptr(dcolor), _lib.ptr(dmean3D), _lib.ptr(dcov3D),
+                _lib.ptr(dsh), _lib.ptr(dsh_rest), _lib.ptr(dscale), _lib.ptr(drot), _lib.ptr(grad_records), int(records_clear), _lib.stream_of(g)), 'gs_backward')
         if not capturing and P > 0:   # (P == 0: the library returned before touching the uninitialised buffer -- it is NOT known to be zero)
             _GRAD_RECORDS[rec_key] = (n1, grad_records)   # only after a call that went through: a failed one leaves the entry popped (contents unknown)
         cut = (lambda t: t) if P == n1 else (lambda t: t[:P])     # (whole buffers when nothing is cut: a gradient that is not a view can be adopted as .grad without a copy)
         return (cut(dmean3D), cut(dmean2D), cut(dsh) if has_sh else None, cut(dcolor) if has_col else None,
                 cut(dopacity).reshape(ctx.opacity_shape), cut(dscale) if has_sr else None, cut(drot) if has_sr else None,
-                cut(dcov3D) if has_cov else None, None, cut(dsh_rest) if has_rest else None, None)
+                cut(dcov3D) if has_cov else None, None, cut(dsh_rest) if dsh_rest is not None else None, None, None)
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, sh_rest=None, raw=False):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, sh_rest, raw)
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, sh_rest=None, raw=False, rest_step=None):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, sh_rest, raw, rest_step)
 
 
 class GaussianRasterizer(torch.nn.Module):
@@ -359,8 +377,10 @@ class GaussianRasterizer(torch.nn.Module):
             return z > 0.2
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, shs_rest=None,
-                raw_parameters=False):
+                raw_parameters=False, rest_step=None):
         """The reference's call (Renderer.py:75-81) plus two keyword extensions for callers that own the model tensors: `shs_rest` -- `shs` is then
+        (`rest_step`, round 6: an object whose take() returns (parameter, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, bc1, bc2) -- the backward pass then applies
+        the optimizer's Adam step to shs_rest itself and returns no gradient for it: nerficg_amd.gaussian_splatting.RestStep)
         the DC part (P,1,3) and shs_rest the (P,M-1,3) remainder, the concatenation of Gaussians.get_features is never built; `raw_parameters` --
         opacities are logits, scales log-scales, rotations unnormalised: the activations of Model.py:45-87 run inside the preprocess kernel and the
         gradients come back w.r.t. the raw tensors."""
@@ -371,4 +391,4 @@ class GaussianRasterizer(torch.nn.Module):
         empty = torch.Tensor([])
         return rasterize_gaussians(means3D, means2D, empty if shs is None else shs, empty if colors_precomp is None else colors_precomp, opacities,
                                    empty if scales is None else scales, empty if rotations is None else rotations,
-                                   empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings, shs_rest, raw_parameters)
+                                   empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings, shs_rest, raw_parameters, rest_step)

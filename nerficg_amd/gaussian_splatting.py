@@ -382,8 +382,37 @@ class Gaussians(torch.nn.Module):
         return {'vertex': vertex}
 
 
-def render_image_training(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np.ndarray) -> dict[str, torch.Tensor]:
-    """GaussianSplatting/Renderer.py:51-86."""
+class RestStep:
+    """The optimizer step of the model's `f_rest` group, handed to the rasterizer's backward pass (which applies it where the gradient rows are: C ABI
+    nrc_gs_backward_rest_step).  take() is called once per backward: it advances the group's step counter like FusedAdam.step would (apex: one counter per
+    group, advanced whenever the group has gradients) and returns the tensors and host scalars of this step.  The optimizer's own step() then finds no
+    gradient on the tensor and leaves it alone.  Plain (non-capturable) FusedAdam only; eps / betas / learning rate as the group has them."""
+
+    def __init__(self, gaussians: 'Gaussians') -> None:
+        opt = gaussians.optimizer
+        self.opt = opt
+        self.group = next(g for g in opt.param_groups if g.get('name') == 'f_rest')
+        self.param = self.group['params'][0]
+        from .apex_optimizers import FusedAdam
+        if not isinstance(opt, FusedAdam) or opt.capturable or self.group.get('weight_decay', 0.0) != 0.0 or opt.adam_w_mode:
+            raise RuntimeError('RestStep: a plain (non-capturable) nerficg_amd FusedAdam in L2 mode without weight decay is expected (Model.py:131-136)')
+
+    def take(self):
+        g, p = self.group, self.param
+        state = self.opt.state[p]
+        if len(state) == 0:
+            state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        g['step'] = g.get('step', 0) + 1
+        beta1, beta2 = g['betas']
+        bc = (1.0 - beta1 ** g['step'], 1.0 - beta2 ** g['step']) if g.get('bias_correction', True) else (1.0, 1.0)
+        return p, state['exp_avg'], state['exp_avg_sq'], float(g['lr']), float(beta1), float(beta2), float(g['eps']), bc[0], bc[1]
+
+
+def render_image_training(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np.ndarray, fuse_rest_step: bool | None = None) -> dict[str, torch.Tensor]:
+    """GaussianSplatting/Renderer.py:51-86.  fuse_rest_step (default: gaussians.fuse_rest_step, False unless set): the backward pass of this frame applies the
+    optimizer's step to the `f_rest` SH tensor itself -- for loops that run exactly one backward pass and one optimizer.step() per frame on one GPU (the
+    view-parallel exchange needs the gradient on the wire, gradient accumulation needs it in .grad: both leave this off)."""
     from .diff_gaussian_rasterization import GaussianRasterizer
     positions = gaussians.get_positions
     # the carrier of the screen-space gradient (Renderer.py:56-58: zeros_like + 0, retain_grad): the rasterizer never reads its VALUES, only hands it a
@@ -394,8 +423,10 @@ def render_image_training(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np.
         image, radii = rasterizer(means3D=positions, means2D=viewspace_points, shs=gaussians.get_features_dc, shs_rest=gaussians.get_features_rest,
                                   opacities=gaussians.get_opacities, scales=gaussians.get_scales, rotations=gaussians.get_rotations)
     else:  # raw parameters straight into the kernels: no get_features concatenation, no separate exp / sigmoid / normalize passes (a25)
+        fuse = getattr(gaussians, 'fuse_rest_step', False) if fuse_rest_step is None else bool(fuse_rest_step)
+        rest_step = RestStep(gaussians) if fuse and torch.is_grad_enabled() and gaussians._features_rest.requires_grad and gaussians._features_rest.shape[1] > 0 and torch.is_tensor(c2w) else None
         image, radii = rasterizer(means3D=positions, means2D=viewspace_points, shs=gaussians._features_dc, shs_rest=gaussians._features_rest,
-                                  opacities=gaussians._opacities, scales=gaussians._scales, rotations=gaussians._rotations, raw_parameters=True)
+                                  opacities=gaussians._opacities, scales=gaussians._scales, rotations=gaussians._rotations, raw_parameters=True, rest_step=rest_step)
     return _TrainingOutputs({'rgb': image, 'viewspace_points': viewspace_points, 'radii': radii})
 
 

@@ -78,3 +78,39 @@ def test_precomputed_rays_form_a_collection():
     assert torch.equal(col[1].direction, second.direction) and torch.equal(col[1].rgb, second.rgb)
     host = compute_all_rays(views, store_on_cpu=True)
     assert not host.origin.is_cuda and torch.equal(host.origin, col.all_rays.origin.cpu())
+
+
+def test_rest_step_inside_the_backward_pass_equals_the_optimizers_own_launch():
+    """render_image_training(fuse_rest_step=True): the Adam step of the 45 higher SH coefficients runs inside the preprocessing backward (C ABI
+    nrc_gs_backward_rest_step) -- three steps leave the same parameters, moments and step counters as the optimizer's own launch, to within the run-to-run spread of
+    the unfused loop (the per-Gaussian sums across tiles are float atomics); the gradient of that tensor is never materialised."""
+    import numpy as np
+    from nerficg_amd.gaussian_splatting import Gaussians, PerspectiveCamera, render_image_training, training_loss
+    from tests import scenes
+    from tests.noise import assert_within_run_to_run_noise
+    dev = torch.device('cuda', 0)
+    sc = scenes.gs_random_scene(30_000, seed=5, extent=1.0, log_scale_mean=np.log(0.03))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    cam = PerspectiveCamera(320, 200, 380.0, 380.0, background_color=torch.zeros(3, device=dev))
+    target = torch.rand(3, 200, 320, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    poses = [torch.from_numpy(np.asarray(scenes.orbit_pose(0.5 + 0.9 * i, 0.3, 3.0), dtype=np.float32)).to(dev) for i in range(3)]
+
+    def run(fuse):
+        g = Gaussians(T(sc['means3D']), torch.log(T(sc['scales'])), T(sc['rotations']), torch.logit(T(sc['opacities']).clamp(1e-4, 1 - 1e-4))[:, None].contiguous(),
+                      T(sc['shs'][:, :1]), T(sc['shs'][:, 1:]))
+        g.training_setup(training_cameras_extent=3.0)
+        g.fuse_rest_step = fuse
+        for i in range(3):
+            out = render_image_training(g, cam, poses[i])
+            training_loss(out['rgb'], target).backward()
+            assert (g._features_rest.grad is None) == fuse and g._features_dc.grad is not None
+            g.optimizer.step(); g.optimizer.zero_grad()
+        params = [grp['params'][0].detach().clone() for grp in g.optimizer.param_groups]
+        moments = [g.optimizer.state[grp['params'][0]][k].clone() for grp in g.optimizer.param_groups for k in ('exp_avg', 'exp_avg_sq')]
+        return params + moments, [grp['step'] for grp in g.optimizer.param_groups]
+
+    ref, ref2, got = run(False), run(False), run(True)
+    assert got[1] == ref[1] == [3] * 6
+    assert_within_run_to_run_noise(got[0], ref[0], ref2[0], atol=1e-6, rtol=1e-3, what='three steps, rest step inside the backward pass')
+    moved = float((got[0][2] - T(sc['shs'][:, 1:])).abs().max())
+    assert moved > 1e-5     # the tensor really was stepped
