@@ -299,7 +299,7 @@ __device__ __forceinline__ void preprocess_one(int i, const GsCam& cam, const fl
 #ifndef SHB_U
 #define SHB_U 16   // loads per trip: 8 / 12 / 16 -> k_preprocess 101 / 99 / 95-98 us at 1 M Gaussians (k_preprocess_bw indifferent)
 #endif
-template <bool TO_LDS, int SHB_U_ = SHB_U>
+template <bool TO_LDS, int SHB_U_ = SHB_U, bool BATCH_TAIL = true>
 __device__ __forceinline__ void sh_block_copy(float* s_sh, int pitch, int col0, int len, int count, float* g, int nthreads) {
     constexpr int U = SHB_U_;
     const int dq = nthreads / len, dr = nthreads - dq * len;
@@ -324,7 +324,13 @@ __device__ __forceinline__ void sh_block_copy(float* s_sh, int pitch, int col0, 
     // the rest (a block of 45-float rows -- the model's split `rest` tensor -- leaves 13 of 45 elements per thread, the 3-float dc rows all 3): ONE more
     // batched trip with predicated accesses.  Round 6: this used to be a one-load-one-wait loop, 13 + 3 dependent round trips per thread -- the split
     // form of the training step cost k_preprocess +24 us and k_preprocess_bw +31 us over the concatenated (P, 16, 3) form (tools/exp_gs_pre.py)
-    if (k < n) {
+    if constexpr (!BATCH_TAIL) {   // whole (P, M, 3) rows: 48 floats per thread are three full trips of 16; only the last workgroup of a launch has a remainder
+        for (; k < n; k += nthreads) {
+            if (TO_LDS) s_sh[r * pitch + col0 + c] = g[k]; else g[k] = s_sh[r * pitch + col0 + c];
+            r += dq; c += dr;
+            if (c >= len) { c -= len; r++; }
+        }
+    } else if (k < n) {
         float v[U];
         int off[U];
 #pragma unroll
@@ -342,10 +348,12 @@ __device__ __forceinline__ void sh_block_copy(float* s_sh, int pitch, int col0, 
         }
     }
 }
-template <bool TO_LDS, int SHB_U_ = SHB_U>
+// SPLIT: the form is a compile-time property of the kernel instance (round 6: one kernel carrying both forms spilled scalar registers in the path of the
+// other -- the concatenated form of the bench frame lost 10 % to code it never runs)
+template <bool TO_LDS, int SHB_U_ = SHB_U, bool SPLIT = false>
 __device__ __forceinline__ void sh_rows_copy(float* s_sh, int pitch, int row_len, int count, size_t first, float* sh, float* sh_rest, int nthreads) {
-    if (!sh_rest) {
-        sh_block_copy<TO_LDS, SHB_U_>(s_sh, pitch, 0, row_len, count, sh + first * row_len, nthreads);
+    if constexpr (!SPLIT) {
+        sh_block_copy<TO_LDS, SHB_U, false>(s_sh, pitch, 0, row_len, count, sh + first * row_len, nthreads);
     } else {
         // the three dc floats per Gaussian ride along with the first trip of the `rest` block: their loads are issued in front of it and land in LDS
         // behind it (a separate one-trip copy was a dependent round trip of its own, per direction, in kernels that run a few waves per CU)
@@ -392,7 +400,7 @@ __device__ __forceinline__ void sh_rows_copy(float* s_sh, int pitch, int row_len
 // records): the same per-Gaussian computation, the 192-byte SH rows staged through LDS, on a FEW persistent workgroups (grid-stride over the
 // 128-Gaussian blocks) of a side stream, so that it runs NEXT TO the geometry pass, the depth sort and the binning, whose kernels are
 // latency-bound and leave the memory system idle, without taking their compute units (round 4; joined before nrc_gs_preprocess returns).
-template <int PART>
+template <int PART, bool SPLIT = false>
 __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam_arg, const float* __restrict__ pose, const float* __restrict__ means3D, const float* __restrict__ shs,
                                                           const float* __restrict__ shs_rest,
                                                           const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -411,7 +419,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, GsCam cam_arg, 
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const int first = blk * PRE_BLOCK, i = first + threadIdx.x;
         if (PART != 1 && shs) {
-            sh_rows_copy<true>(s_sh, pitch, row_len, min(PRE_BLOCK, P - first), (size_t)first, const_cast<float*>(shs), const_cast<float*>(shs_rest), PRE_BLOCK);
+            sh_rows_copy<true, SHB_U, SPLIT>(s_sh, pitch, row_len, min(PRE_BLOCK, P - first), (size_t)first, const_cast<float*>(shs), const_cast<float*>(shs_rest), PRE_BLOCK);
             __syncthreads();
         }
         // splat records leave through LDS: a lane storing its own record touches 64 cache lines per store instruction; from the LDS image (the SH
@@ -1897,6 +1905,7 @@ struct RestAdam { float* p; float* m; float* v; float lr, beta1, beta2, eps, bc1
 #ifndef PBW_MAXM
 #define PBW_MAXM 16
 #endif
+template <int FORM>   // 0: one (P, M, 3) SH tensor; 1: dc + rest; 2: dc + rest with the Adam step of `rest` inside (RestAdam)
 __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_arg, const float* __restrict__ pose, const float* __restrict__ means3D, const float* __restrict__ shs,
                                                              const float* __restrict__ shs_rest, const float* __restrict__ opacities, int use_sh, const float* __restrict__ scales, const float* __restrict__ rotations,
                                                              int use_scale_rot, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
@@ -1914,7 +1923,7 @@ __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_ar
     if (use_sh) {
         // 12 elements per trip here (k_preprocess: 16): with 16 this kernel's 204 VGPRs left the split-SH form of the training step at 168-179 us against
         // 133-138 with 12 or 8 (the concatenated form 139 -> 128; tools/exp_gs_pre.py, round 6)
-        sh_rows_copy<true, PBW_SHB_U>(s_sh, pitch, row_len, count, (size_t)first, const_cast<float*>(shs), const_cast<float*>(shs_rest), PBW_BLOCK);
+        sh_rows_copy<true, (FORM == 0 ? SHB_U : PBW_SHB_U), FORM != 0>(s_sh, pitch, row_len, count, (size_t)first, const_cast<float*>(shs), const_cast<float*>(shs_rest), PBW_BLOCK);
         __syncthreads();
     }
     float* sh_row = s_sh + threadIdx.x * pitch;
@@ -1940,8 +1949,8 @@ __global__ void __launch_bounds__(PBW_BLOCK) k_preprocess_bw(int P, GsCam cam_ar
     }
     if (use_sh) {
         __syncthreads();
-        if (ra.p == nullptr) {
-            sh_rows_copy<false, PBW_SHB_U>(s_sh, pitch, row_len, count, (size_t)first, dL_dsh, dL_dsh_rest, PBW_BLOCK);
+        if constexpr (FORM != 2) {
+            sh_rows_copy<false, (FORM == 0 ? SHB_U : PBW_SHB_U), FORM != 0>(s_sh, pitch, row_len, count, (size_t)first, dL_dsh, dL_dsh_rest, PBW_BLOCK);
         } else {
             // dc gradient rows as usual (3 floats per Gaussian), then Adam over the block's `rest` rows: element k of the contiguous (count, row_len - 3) block, gradient
             // from LDS (invisible Gaussians: zeros -- their moments decay and their parameters move like in the optimizer's own launch)
@@ -2156,12 +2165,14 @@ int nrc_gs_preprocess(int32_t P, int32_t D, int32_t M, int32_t W, int32_t H, con
                     clamped, cov3D, tiles_touched, lds_path ? (uint32_t*)nullptr : tile_counts, (float4*)splat_records, lds_path ? w.hdr : (uint32_t*)nullptr
         if (side && hipEventRecord(side->fork, s) == hipSuccess && hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess) {
             const int cus = 256;   // MI355X; only the experiment's grid size depends on it
-            hipLaunchKernelGGL(k_preprocess<2>, dim3(pre_blocks < g_gs_color_blocks_per_cu * cus ? pre_blocks : g_gs_color_blocks_per_cu * cus), dim3(PRE_BLOCK), 0, side->stream, GS_PRE_ARGS);
+            if (shs_rest) hipLaunchKernelGGL((k_preprocess<2, true>), dim3(pre_blocks < g_gs_color_blocks_per_cu * cus ? pre_blocks : g_gs_color_blocks_per_cu * cus), dim3(PRE_BLOCK), 0, side->stream, GS_PRE_ARGS);
+            else hipLaunchKernelGGL((k_preprocess<2, false>), dim3(pre_blocks < g_gs_color_blocks_per_cu * cus ? pre_blocks : g_gs_color_blocks_per_cu * cus), dim3(PRE_BLOCK), 0, side->stream, GS_PRE_ARGS);
             forked = hipEventRecord(side->join, side->stream) == hipSuccess;
             if (!forked) (void)hipStreamSynchronize(side->stream);   // cannot happen short of a broken runtime: stay correct
-            hipLaunchKernelGGL(k_preprocess<1>, dim3(pre_blocks), dim3(PRE_BLOCK), 0, s, GS_PRE_ARGS);
+            hipLaunchKernelGGL((k_preprocess<1, false>), dim3(pre_blocks), dim3(PRE_BLOCK), 0, s, GS_PRE_ARGS);
         } else {
-            hipLaunchKernelGGL(k_preprocess<0>, dim3(pre_blocks), dim3(PRE_BLOCK), 0, s, GS_PRE_ARGS);
+            if (shs_rest) hipLaunchKernelGGL((k_preprocess<0, true>), dim3(pre_blocks), dim3(PRE_BLOCK), 0, s, GS_PRE_ARGS);
+            else hipLaunchKernelGGL((k_preprocess<0, false>), dim3(pre_blocks), dim3(PRE_BLOCK), 0, s, GS_PRE_ARGS);
         }
         NRC_STAGE(s, "k_preprocess");
 #undef GS_PRE_ARGS
@@ -2287,8 +2298,12 @@ static int gs_backward_impl(int32_t P, int32_t D, int32_t M, int32_t W, int32_t 
     hipLaunchKernelGGL(k_render_bw, dim3(cam.gx * cam.gy), dim3(256), 0, s, cam, ranges, point_list, (const float4*)splat_records, tile_order, bg[0], bg[1], bg[2],
                        camera_dev, n_contrib, final_T, dL_dpix, grad_records);
     NRC_STAGE(s, "k_render_bw");
-    hipLaunchKernelGGL(k_preprocess_bw, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, P, cam, camera_dev, means3D, shs, shs_rest, opacities, use_sh, scales, rotations,
-                       use_sr, radii, clamped, cov3D, grad_records, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, dL_dopacity, ra);
+#define GS_PBW_ARGS P, cam, camera_dev, means3D, shs, shs_rest, opacities, use_sh, scales, rotations, use_sr, radii, clamped, cov3D, grad_records, dL_dmean2D, dL_dconic, dL_dcolor, \
+                    dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, dL_dopacity, ra
+    if (ra.p) hipLaunchKernelGGL(k_preprocess_bw<2>, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, GS_PBW_ARGS);
+    else if (shs_rest) hipLaunchKernelGGL(k_preprocess_bw<1>, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, GS_PBW_ARGS);
+    else hipLaunchKernelGGL(k_preprocess_bw<0>, dim3(nrc_cdiv(P, PBW_BLOCK)), dim3(PBW_BLOCK), 0, s, GS_PBW_ARGS);
+#undef GS_PBW_ARGS
     NRC_STAGE(s, "k_preprocess_bw");
     NRC_LAUNCH_CHECK();
     return NRC_OK;

@@ -424,7 +424,7 @@ def render_image_training(gaussians: Gaussians, cam: PerspectiveCamera, c2w: np.
                                   opacities=gaussians.get_opacities, scales=gaussians.get_scales, rotations=gaussians.get_rotations)
     else:  # raw parameters straight into the kernels: no get_features concatenation, no separate exp / sigmoid / normalize passes (a25)
         fuse = getattr(gaussians, 'fuse_rest_step', False) if fuse_rest_step is None else bool(fuse_rest_step)
-        rest_step = RestStep(gaussians) if fuse and torch.is_grad_enabled() and gaussians._features_rest.requires_grad and gaussians._features_rest.shape[1] > 0 and torch.is_tensor(c2w) else None
+        rest_step = RestStep(gaussians) if fuse and not getattr(gaussians.optimizer, 'capturable', False) and not torch.cuda.is_current_stream_capturing() and torch.is_grad_enabled() and gaussians._features_rest.requires_grad and gaussians._features_rest.shape[1] > 0 and torch.is_tensor(c2w) else None
         image, radii = rasterizer(means3D=positions, means2D=viewspace_points, shs=gaussians._features_dc, shs_rest=gaussians._features_rest,
                                   opacities=gaussians._opacities, scales=gaussians._scales, rotations=gaussians._rotations, raw_parameters=True, rest_step=rest_step)
     return _TrainingOutputs({'rgb': image, 'viewspace_points': viewspace_points, 'radii': radii})
