@@ -789,14 +789,14 @@ def dp_ingp_leg(model, renderer, cam, poses, rank, world, device, rays_per_rank=
         from nerficg_amd.amp import GradScaler as _GS
         from nerficg_amd.ngp_trainer import FusedTrainingIteration
 
-        def fused_leg(sharded):
+        def fused_leg(sharded, wire_dtype=torch.float32):
             """sharded=True: round 6's step (small all-reduce beside the grid backward, in-place reduce-scatter, Adam on the rank's shard, all-gather of the fp16
             table, next batch marched beside the collective); False: round 5's (one flat reduce-scatter + all-gather of the f32 gradient, Adam on everything)."""
             it, built = None, None
             try:
                 opt_f = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
                 it = FusedTrainingIteration(model, renderer, opt_f, _GS(init_scale=128.0, growth_interval=10 ** 9), cam, {'origin': origin, 'view_direction': vdir, 'rgb': target},
-                                            rays_per_rank, (int(1.15 * samples) + 4095) // 4096 * 4096, order=perm, seed=5, sharded=sharded, dp_timing=bool(sharded))
+                                            rays_per_rank, (int(1.15 * samples) + 4095) // 4096 * 4096, order=perm, seed=5, sharded=sharded, dp_timing=bool(sharded), wire_dtype=wire_dtype)
             except Exception as e:
                 built = repr(e)[:300]
             # every rank enters the iterations (they hold a collective) or none does: a rank that failed to build must not leave the others waiting
@@ -819,7 +819,9 @@ def dp_ingp_leg(model, renderer, cam, poses, rank, world, device, rays_per_rank=
                 leg = {'ms_per_iteration': round(dt_f * 1e3, 3), 'rays_per_iteration': n_global, 'mrays_per_s': round(n_global / dt_f / 1e6, 3),
                        'replica_drift': drift_f, 'fp16_table_drift': half_drift, 'samples_cut': int(out_f['sample_overflow']), 'sharded_step': bool(it.sharded),
                        'next_batch_marched_beside': it.prefetch_at if it.prefetch_default else None}
-                wire = it.layout.wire_bytes()
+                wire = it.layout.wire_bytes(2 if it.wire is not None else 4)
+                if it.wire is not None:
+                    leg['wire_dtype'], leg['wire_values_saturated'] = 'fp16 (saturating, summed in fp16 over the ranks)', int(it.wire_saturated)
                 if it.sharded:
                     tm = _max_over_ranks([times['reduce_scatter_ms'], times['adam_ms'], times['all_gather_ms'], times['exposed_ms']], device, world)
                     leg.update(wire_bytes_per_gpu=wire['total'], wire=wire, adam_elements_per_rank=wire['adam_elements_per_rank'],
@@ -839,6 +841,7 @@ def dp_ingp_leg(model, renderer, cam, poses, rank, world, device, rays_per_rank=
                         p.copy_(q)
         fused_dp = fused_leg(True)
         fused_dp['replicated_step'] = fused_leg(False)
+        fused_dp['sharded_step_fp16_wire'] = fused_leg(True, torch.float16)      # optional: half the reduce-scatter's bytes, fp16 summation (off by default)
     return {'fused_trainer': fused_dp, 'ms_per_iteration': round(dt * 1e3, 3), 'rays_per_iteration': n_global, 'samples_per_iteration_per_gpu': round(samples), 'mrays_per_s': round(n_global / dt / 1e6, 3),
             'collective': f'one flat f32 bucket, {"all_reduce" if dist.get_backend() == "gloo" else "reduce-scatter + all-gather"} over {dist.get_backend()}' if world > 1 else None, 'bytes_reduced_per_iteration': nbytes if world > 1 else 0,
             'collective_ms': round(coll, 3) if world > 1 else None,

@@ -758,6 +758,9 @@ int nrc_amp_adam_step(float* param_a, const float* grad_a, float* exp_avg_a, flo
  *   nrc_ngp_train_grid_backward     : the hash-grid backward of the same call (reads the input gradient the first call left in `scratch`).
  *   nrc_amp_settle                  : one thread: found_inf = (*flag_sum != 0) (a sum of the ranks' flags), step counter, bias corrections, scale update
  *            rule, state4[2] = 1 / (scale * grad_divisor) -- grad_divisor = world size when the gradients are a SUM over the ranks.  state4 as in nrc_amp_adam_step.
+ *   nrc_wire_pack_f16 / nrc_wire_unpack_f16 : the optional 16-bit wire of the table's reduce-scatter -- f32 -> fp16 round-to-nearest, saturating at +-65504
+ *            (*saturated, optional DEVICE u64, counts the clamped values; NaN stays NaN), and the reduced shard back to f32.  Halves the reduce-scatter's
+ *            bytes; the sum over the ranks is then formed in fp16 (what tiny-cuda-nn's own fp16 gradient storage does under the same loss scale).  Off by default.
  *   nrc_amp_adam_slices             : the Adam launch of nrc_amp_adam_step on two arbitrary slices (pointers already offset; l2_count relative to the
  *            slice) -- a rank's shard of the table, or the replicated MLP weights.  Skipped when state4[1] says so.  Either slice may be empty.
  * ===================================================================================================== */
@@ -771,6 +774,8 @@ int nrc_ngp_train_grid_backward(int64_t M, const float* x01, const void* density
                                 int32_t log2_hashmap_size, int32_t base_resolution, float per_level_scale, float* grad_density_params,
                                 float* grad_color_params, int64_t n_density_mlp_params, int64_t n_density_params, int64_t n_color_params, void* scratch,
                                 const int32_t* n_samples_dev, nrc_stream_t fork_stream, nrc_stream_t stream);
+int nrc_wire_pack_f16(const float* src, void* dst_f16, int64_t n, uint64_t* saturated, nrc_stream_t stream);
+int nrc_wire_unpack_f16(const void* src_f16, float* dst, int64_t n, nrc_stream_t stream);
 int nrc_amp_settle(const float* flag_sum, float grad_divisor, float beta1, float beta2, int32_t* device_step, float* bias_corrections, float* scale,
                    int32_t* growth_tracker, float growth_factor, float backoff_factor, int32_t growth_interval, float* state4, int32_t* skipped_steps,
                    nrc_stream_t stream);

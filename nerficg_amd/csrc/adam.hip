@@ -165,6 +165,36 @@ __global__ void k_amp_prepare(AmpState a) {
     if (threadIdx.x | blockIdx.x) return;
     amp_prepare_thread(a);
 }
+// ---- 16-bit wire of the sharded step's reduce-scatter (optional): f32 gradient -> fp16, SATURATING at +-65504 (a finite f32 value must not become an inf
+// that no producer flagged; NaN stays NaN), and the reduced shard back to f32 for the Adam launch.  tiny-cuda-nn itself keeps hash-grid gradients in fp16
+// under the same loss scale; here it is the wire format only -- gradients are produced, and the moments kept, in f32.
+__global__ void __launch_bounds__(256) k_wire_pack_f16(const float* __restrict__ src, __half* __restrict__ dst, int64_t n, unsigned long long* __restrict__ saturated) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    float v[4];
+    const bool full = i + 3 < n && ((reinterpret_cast<uintptr_t>(src + i) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(dst + i) & 7u) == 0);
+    if (full) *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(src + i);
+    else for (int k = 0; k < 4; k++) v[k] = i + k < n ? src[i + k] : 0.f;
+    int sat = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);      // (fminf / fmaxf return the other operand for a NaN: restore it)
+        sat += (c != v[k] && v[k] == v[k]) ? 1 : 0;
+        v[k] = v[k] == v[k] ? c : v[k];
+    }
+    if (full) {
+        __half2 h[2] = {__floats2half2_rn(v[0], v[1]), __floats2half2_rn(v[2], v[3])};
+        *reinterpret_cast<uint2*>(dst + i) = *reinterpret_cast<const uint2*>(h);
+    } else {
+        for (int k = 0; k < 4; k++) if (i + k < n) dst[i + k] = __float2half_rn(v[k]);
+    }
+    if (saturated && sat) atomicAdd(saturated, (unsigned long long)sat);
+}
+__global__ void __launch_bounds__(256) k_wire_unpack_f16(const __half* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = __half2float(src[i]);
+}
+
 // the closing step for a data-parallel rank: the flag is a SUM of the ranks' flags that arrived with the small all-reduce (nrc_amp_settle)
 __global__ void k_amp_settle(AmpState a, const float* __restrict__ flag) {
     if (threadIdx.x | blockIdx.x) return;
@@ -362,6 +392,22 @@ int nrc_amp_adam_step(float* param_a, const float* grad_a, float* exp_avg_a, flo
 }
 
 /* ---- group 14: the optimizer step of a data-parallel rank, in pieces (include/nerficg_hip.h) ---- */
+int nrc_wire_pack_f16(const float* src, void* dst_f16, int64_t n, uint64_t* saturated, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n < 0 || (n > 0 && (!src || !dst_f16))) return NRC_ERR_INVALID;
+    if (n == 0) return NRC_OK;
+    hipLaunchKernelGGL(k_wire_pack_f16, dim3((unsigned)nrc_cdiv(nrc_cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, src, (__half*)dst_f16, n, (unsigned long long*)saturated);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
+int nrc_wire_unpack_f16(const void* src_f16, float* dst, int64_t n, nrc_stream_t stream) {
+    NRC_ENTER();
+    if (n < 0 || (n > 0 && (!src_f16 || !dst))) return NRC_ERR_INVALID;
+    if (n == 0) return NRC_OK;
+    hipLaunchKernelGGL(k_wire_unpack_f16, dim3((unsigned)nrc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)src_f16, dst, n);
+    NRC_LAUNCH_CHECK();
+    return NRC_OK;
+}
 int nrc_amp_settle(const float* flag_sum, float grad_divisor, float beta1, float beta2, int32_t* device_step, float* bias_corrections, float* scale,
                    int32_t* growth_tracker, float growth_factor, float backoff_factor, int32_t growth_interval, float* state4, int32_t* skipped_steps,
                    nrc_stream_t stream) {

@@ -174,7 +174,7 @@ def all_gather_(buf: torch.Tensor, rank: int | None = None, world: int | None = 
 
 
 def sharded_step(layout: 'ShardedStepLayout', grads: torch.Tensor, half_table: torch.Tensor, settle, adam_small, adam_table,
-                 before_table=None, mark=None) -> None:
+                 before_table=None, mark=None, wire: torch.Tensor | None = None, pack=None, unpack=None) -> None:
     """The optimizer step of one data-parallel rank on a gradient buffer laid out as `layout` says -- the ORDER of collectives and updates, shared by
     nerficg_amd.ngp_trainer (callbacks = library calls on the communication stream) and the CPU tests (callbacks = the CPU oracle):
 
@@ -185,7 +185,9 @@ def sharded_step(layout: 'ShardedStepLayout', grads: torch.Tensor, half_table: t
         5. adam_small(): the MLP weights, on every rank redundantly;  adam_table(begin, count): this rank's shard (offsets relative to the table)
         6. all-gather (in place) of `half_table`, the fp16 (or whatever the kernels read) copy of the table, whose shard step 5 rewrote
 
-    mark(k), optional: called behind steps 2, 3, 5, 6 (k = 0..3) -- the trainer records timing events there."""
+    mark(k), optional: called behind steps 2, 3, 5, 6 (k = 0..3) -- the trainer records timing events there.
+    wire / pack / unpack (optional, all three): the 16-bit wire of step 3 -- pack() converts the table gradient into `wire` (n_table elements of a 16-bit
+    dtype), the reduce-scatter runs on `wire`, unpack(begin, count) brings this rank's reduced shard back into grads[table] for step 5."""
     L = layout
     if not L.sharded:
         raise RuntimeError('sharded_step: the table does not divide by the world size (ShardedStepLayout.sharded)')
@@ -193,7 +195,12 @@ def sharded_step(layout: 'ShardedStepLayout', grads: torch.Tensor, half_table: t
     if before_table is not None:
         before_table()
     if mark: mark(0)
-    reduce_scatter_sum_(grads[L.off_table:L.total], L.rank, L.world)
+    if wire is not None:
+        pack()
+        reduce_scatter_sum_(wire, L.rank, L.world)
+        unpack(L.shard_begin, L.shard)
+    else:
+        reduce_scatter_sum_(grads[L.off_table:L.total], L.rank, L.world)
     if mark: mark(1)
     settle(grads[L.off_aux:L.off_density])
     adam_small()

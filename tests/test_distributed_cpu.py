@@ -352,3 +352,33 @@ def test_sharded_layout_at_the_instant_ngp_sizes():
     assert w['adam_elements_per_rank'] == 7168 + 3072 + 1_524_530            # 1.53 M instead of 12.2 M
     replicated = parallel.ShardedStepLayout(7168, 3072, 12_196_240, rank=0, world=3)
     assert not replicated.sharded and replicated.wire_bytes()['adam_elements_per_rank'] == 7168 + 3072 + 12_196_240
+
+
+def _t_sharded_wire(rank, world):
+    """parallel.sharded_step with the optional 16-bit wire: pack -> reduce-scatter of the fp16 buffer -> unpack of the rank's shard; the shard the Adam callback sees is
+    the fp16-rounded sum of the fp16-rounded contributions, the small piece and the flag still travel in f32."""
+    from nerficg_amd import parallel
+    L = parallel.ShardedStepLayout(8, 8, 64)
+    g = torch.Generator().manual_seed(rank)
+    grads = torch.randn(L.total, generator=g)
+    grads[L.off_aux:L.off_density] = 0
+    mine = grads.clone()
+    wire = torch.zeros(L.n_table, dtype=torch.float16)
+    half_table = torch.full((L.n_table,), float(rank), dtype=torch.float16)
+    seen = {}
+    parallel.sharded_step(L, grads, half_table, settle=lambda aux: seen.setdefault('flag', float(aux[0])), adam_small=lambda: None,
+                          adam_table=lambda b, n: seen.setdefault('shard', grads[L.off_table + b:L.off_table + b + n].clone()),
+                          wire=wire, pack=lambda: wire.copy_(grads[L.off_table:].clamp(-65504, 65504).half()),
+                          unpack=lambda b, n: grads[L.off_table + b:L.off_table + b + n].copy_(wire[b:b + n].float()))
+    others = [torch.randn(L.total, generator=torch.Generator().manual_seed(r)) for r in range(world)]
+    want = sum(o[L.off_table:].half() for o in others).float()[L.shard_begin:L.shard_begin + L.shard]      # fp16 addends, fp16 sum
+    small = sum(o[:L.off_table] for o in others)
+    small[L.off_aux:L.off_density] = 0
+    return bool(torch.equal(seen['shard'], want)), bool(torch.allclose(grads[:L.off_table], small)), seen['flag'], half_table.tolist()[::L.shard], L.wire_bytes(2)['reduce_scatter']
+
+
+def test_sharded_step_with_the_16_bit_wire():
+    out = _run(_t_sharded_wire)
+    for r in (0, 1):
+        shard_ok, small_ok, flag, gathered, rs_bytes = out[r]
+        assert shard_ok and small_ok and flag == 0.0 and gathered == [0.0, 1.0] and rs_bytes == 64 * 2 // 2

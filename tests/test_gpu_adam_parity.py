@@ -304,3 +304,26 @@ def test_multi_tensor_step_equals_the_per_tensor_launches_bit_for_bit(monkeypatc
     assert a[2] == b[2] == [3, 3, 3, 2, 3, 3]
     for x, y in zip(a[0] + a[1], b[0] + b[1]):
         assert torch.equal(x, y)
+
+
+def test_wire_pack_saturates_and_unpack_round_trips():
+    """nrc_wire_pack_f16 / nrc_wire_unpack_f16 (the optional 16-bit wire of the sharded step): round-to-nearest fp16 of the clamped value, the clamped count on the
+    device, NaN passed on, odd lengths and a misaligned start."""
+    from nerficg_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    base = torch.randn(100_004, device=DEV, generator=gen) * 10.0 ** torch.randint(-6, 6, (100_004,), device=DEV, generator=gen).float()
+    for off, n in ((0, 100_004), (1, 100_003), (0, 5)):
+        src = base[off:off + n]
+        src_bad = src.clone()
+        if n > 100:
+            src_bad[7], src_bad[11], src_bad[13] = 1e9, -3e7, float('nan')
+        dst = torch.zeros(n, dtype=torch.float16, device=DEV)
+        sat = torch.zeros(1, dtype=torch.int64, device=DEV)
+        _lib.check(lib.nrc_wire_pack_f16(_lib.ptr(src_bad), _lib.ptr(dst), n, _lib.ptr(sat), _lib.stream_of(dst)), 'wire_pack_f16')
+        ref = src_bad.clamp(-65504.0, 65504.0).half()
+        assert torch.equal(dst[~torch.isnan(src_bad)], ref[~torch.isnan(src_bad)]) and bool(torch.isnan(dst[torch.isnan(src_bad)]).all())
+        assert int(sat) == int((src_bad.abs() > 65504.0).sum()) and bool(torch.isfinite(dst[~torch.isnan(src_bad)]).all())
+        back = torch.zeros(n, device=DEV)
+        _lib.check(lib.nrc_wire_unpack_f16(_lib.ptr(dst), _lib.ptr(back), n, _lib.stream_of(back)), 'wire_unpack_f16')
+        assert torch.equal(back[~torch.isnan(src_bad)], dst.float()[~torch.isnan(src_bad)])
