@@ -352,6 +352,21 @@ def gs_forward(means3D, opacities, viewmatrix, projmatrix, campos, tan_fovx, tan
     return color, st.radii.copy(), st
 
 
+def gs_render_source_order(st, bg):
+    """(color (3,H,W), n_contrib (H*W), final_T (H*W)) of the tile lists in `st` (gs_forward's state) with the blend in the published source's order --
+    no fused multiply-add, T (1 - alpha), colour + c alpha T (gs_oracle_impl.h: render_source_order).  The fused statement the kernels and gs_forward share is
+    held against this one with a bounded-mismatch criterion."""
+    pre = 'gsf_' if st.dtype == np.float32 else 'gsd_'
+    color = np.zeros((3, st.H, st.W), st.dtype)
+    n_contrib = np.zeros(st.H * st.W, np.uint32)
+    final_T = np.zeros(st.H * st.W, st.dtype)
+    fn = getattr(lib(), pre + 'render_source_order')
+    fn.restype = None
+    fn(_i(st.W), _i(st.H), _p(np.ascontiguousarray(bg, dtype=st.dtype)), _p(st.points_xy), _p(st.conic_opacity), _p(st.rgb), _p(st.point_list), _p(st.ranges),
+       _p(color), _p(n_contrib), _p(final_T))
+    return color, n_contrib, final_T
+
+
 def usable_cpus() -> int:
     """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota.  The GPU boxes of the pool show 256 logical CPUs and
     grant 16 (cpu.max = 1600000 100000): 256 OpenMP threads on a 16-CPU quota are throttled and run SLOWER than 32 (measured round 5, oracle.mlp_fw:

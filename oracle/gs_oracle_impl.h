@@ -29,6 +29,12 @@
  * fusions here, so the integer outputs that depend on them (n_contrib) and final_T stay bit-exact.  FMA is fmaf / fma: correctly rounded. */
 #define GS_BLEND_POWER(A, B, C, dx, dy) FMA((REAL)-0.5, FMA((C) * (dy), (dy), ((A) * (dx)) * (dx)), -(((B) * (dx)) * (dy)))
 
+/* The SAME blend in the order the published source states it (forward.cu renderCUDA of diff-gaussian-rasterization, as described in Kerbl et al. 2023, appendix A):
+ *   power = -0.5 (A dx^2 + C dy^2) - B dx dy;  alpha = min(0.99, o exp(power));  test_T = T (1 - alpha);  C_ch += c_ch alpha T
+ * with NO fused multiply-add anywhere (this file is built with -ffp-contract=off).  FN(render_source_order) below uses it: the kernels and FN(bin_and_render)
+ * state explicit fusions (GS_BLEND_POWER), an algebraic restatement of these expressions -- tests/test_oracle_gs.py and tests/test_gpu_gs_parity.py bound how far
+ * the fused statement drifts from this one (last contributor on a tiny fraction of pixels, colour and transmittance by ulps), so that the bit-exact comparison of
+ * kernel and fused oracle is not a comparison of the kernel with itself (advisor finding, round 5). */
 static inline void FN(xform43)(const REAL* p, const REAL* m, REAL* o) {
     o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
     o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
@@ -239,6 +245,37 @@ void FN(bin_and_render)(int P, int W, int H, const REAL* bg, const int32_t* radi
                 if (test_T < (REAL)0.0001) break;
                 const REAL w = alpha * T;
                 for (int c = 0; c < 3; c++) C[c] = FMA(rgb[3 * id + c], w, C[c]);
+                T = test_T;
+                last = contributor;
+            }
+            final_T[py * W + px] = T;
+            n_contrib[py * W + px] = last;
+            for (int c = 0; c < 3; c++) out_color[(size_t)c * H * W + py * W + px] = C[c] + T * bg[c];
+        }
+}
+
+/* the image of given tile lists (ranges / point_list of FN(bin_and_render)) with the source-order blend */
+void FN(render_source_order)(int W, int H, const REAL* bg, const REAL* points_xy, const REAL* conic_opacity, const REAL* rgb, const int32_t* point_list,
+                             const uint32_t* ranges, REAL* out_color, uint32_t* n_contrib, REAL* final_T) {
+    const int gx = (W + TILE - 1) / TILE;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            const int tile = (py / TILE) * gx + px / TILE;
+            REAL T = 1, C[3] = {0, 0, 0};
+            uint32_t contributor = 0, last = 0;
+            for (uint32_t k = ranges[2 * tile]; k < ranges[2 * tile + 1]; k++) {
+                contributor++;
+                const int id = point_list[k];
+                const REAL dx = points_xy[2 * id] - (REAL)px, dy = points_xy[2 * id + 1] - (REAL)py;
+                const REAL* co = conic_opacity + 4 * id;
+                const REAL power = (REAL)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > 0) continue;
+                const REAL alpha = FMIN((REAL)0.99, co[3] * EXP(power));
+                if (alpha < (REAL)1 / (REAL)255) continue;
+                const REAL test_T = T * (1 - alpha);
+                if (test_T < (REAL)0.0001) break;
+                for (int c = 0; c < 3; c++) C[c] += rgb[3 * id + c] * alpha * T;
                 T = test_T;
                 last = contributor;
             }

@@ -81,6 +81,27 @@ def test_forward_internal_state_matches_oracle():
     np.testing.assert_allclose(sv['final_T'].cpu().numpy(), st.final_T, rtol=0, atol=2e-6)
 
 
+def test_kernel_against_the_blend_in_the_published_source_order():
+    """The kernel is bit-exact against the oracle's FUSED blend statement (above), which was written to state the kernel's own fusions.  This test holds the kernel
+    against the SOURCE-ORDER statement of the published algorithm (oracle.gs_render_source_order: no fused multiply-add, T (1 - alpha), C += c alpha T): the last
+    contributor may differ only on the rare pixel where alpha or T sits within an ulp of a threshold, everything else by rounding."""
+    sc = scenes.gs_random_scene(20000, seed=8, extent=1.2, log_scale_mean=np.log(0.04))
+    cam = scenes.gs_camera(257, 131, scenes.orbit_pose(1.1, 0.35, 3.0))
+    bg = [0.2, 0.1, 0.4]
+    color, radii, _, _ = _run(sc, cam, bg, requires_grad=True)
+    _, _, st = _oracle(sc, cam, bg)
+    sv, _ = _saved(color)
+    c2, n2, t2 = oracle.gs_render_source_order(st, np.asarray(bg, np.float32))
+    n_k = sv['n_contrib'].cpu().numpy().astype(np.uint32).reshape(-1)
+    differ = float(np.mean(n_k != n2))
+    assert n2.max() > 20 and differ <= 2e-3, differ
+    same = n_k == n2
+    np.testing.assert_allclose(sv['final_T'].cpu().numpy().reshape(-1)[same], t2[same], rtol=2e-5, atol=1e-9)
+    img = color.detach().cpu().numpy()
+    np.testing.assert_allclose(img.reshape(3, -1)[:, same], c2.reshape(3, -1)[:, same], rtol=0, atol=4e-6)
+    assert np.abs(img - c2).max() <= 1e-3
+
+
 def test_oversized_tile_segment_sorts_in_global_memory():
     """> 8192 Gaussians on one tile exercise the global-memory path of the per-tile sort."""
     n = 12000
