@@ -377,6 +377,59 @@ def time_gs(gs, reps=5, barrier=None):
             'image': f"{gs.get('w', GS_W)}x{gs.get('h', GS_H)}", 'pixels': gs.get('w', GS_W) * gs.get('h', GS_H)}
 
 
+def _second_ruler(kernel, in_frame_ms, units_per_launch, peak, ms_to_s):
+    """frac of a kernel by its IN-FRAME duration (stage timer of this run) and by its rocprofv3 duration (profiles/kernel_durations.json, sha-gated), next to the
+    back-to-back figure the entry's `frac` is computed from.  units_per_launch: GB or TFLOP per average launch."""
+    out = {'why': 'kernel_ms above = the kernel back to back with itself between one pair of events; in_frame = behind / in front of its partner kernel as the frame issues them '
+                  '(the encoder then starts behind 0.5 GB of feature traffic, the MLP kernel reads features written a moment ago): the pair sums agree, the split moves'}
+    if in_frame_ms:
+        out['in_frame_ms'] = round(in_frame_ms, 4)
+        out['in_frame_frac'] = round(units_per_launch / (in_frame_ms * ms_to_s) / peak, 4)
+    ms, src = kernel_durations_entry(kernel, 'ngp_net.hip')
+    out['rocprof_ms'] = round(ms, 4) if ms else None
+    out['rocprof_frac'] = round(units_per_launch / (ms * ms_to_s) / peak, 4) if ms else None
+    out['rocprof_source'] = src
+    return out
+
+
+def time_kernels_in_frame(renderer, cam, pose_list):
+    """The second ruler for the pair of kernels (round-5 review, "weak" 5): their durations INSIDE the frame -- encode, MLP, encode, MLP, ... as the product issues
+    them -- from the library's stage timer (a HIP event behind every kernel of the frame's query loop), over the same poses as time_dominant_kernel.  That function
+    times each kernel back to back with itself: the encoder then finds its table in L2 and the MLP kernel finds its features evicted by the encoder launches of the
+    other chunks; in the frame it is the other way round (the MLP kernel reads features the encoder wrote a moment ago, the encoder starts behind 0.5 GB of feature
+    traffic).  The SUMS agree; the split does not -- both are reported."""
+    import torch
+    from nerficg_amd import _lib
+    tot = {'k_grid_encode': [0.0, 0], 'k_ngp_mlp': [0.0, 0]}
+    for pose in pose_list:
+        with _lib.stage_timer() as st:
+            renderer.render_image_fused(cam, pose, early_termination=False)
+            torch.cuda.synchronize()
+        for name, (ms, n) in st.by_name().items():
+            if name in tot:
+                tot[name][0] += ms; tot[name][1] += n
+    return {k: (v[0] / v[1] if v[1] else None) for k, v in tot.items()}
+
+
+def kernel_durations_entry(kernel_prefix, source_file):
+    """(mean ms per launch or None, provenance) of a kernel from profiles/kernel_durations.json -- rocprofv3 --kernel-trace --stats of THIS command line, written by
+    tools/make_profile_summary.py next to pmc_summary.json and gated on the same source digests."""
+    f = ROOT / 'profiles' / 'kernel_durations.json'
+    if not f.exists():
+        return None, 'no profiles/kernel_durations.json'
+    try:
+        d = json.loads(f.read_text())
+    except Exception:
+        return None, 'profiles/kernel_durations.json unreadable'
+    meta = d.get('_meta', {})
+    if meta.get('csrc_sha', {}).get(source_file) != csrc_digests().get(source_file):
+        return None, f'profiles/kernel_durations.json predates the current {source_file}: not quoted'
+    name = next((k for k in sorted(d) if k.startswith(kernel_prefix)), None)
+    if name is None:
+        return None, f'no {kernel_prefix} in profiles/kernel_durations.json'
+    return d[name]['avg_us'] / 1e3, f"profiles/kernel_durations.json ({meta.get('round', '?')}: rocprofv3 --kernel-trace --stats of `{meta.get('command', 'python bench.py')}`, {d[name]['calls']} launches, same {source_file})"
+
+
 def csrc_digests():
     """sha256[:16] of every translation unit / header of the library: profiles/pmc_summary.json records them at collection time, and a counter
     entry is only quoted for a kernel whose source file has not changed since (otherwise the line would carry numbers of another build)."""
@@ -1110,6 +1163,7 @@ def main():
             timed_poses = timed_poses[::max(1, len(timed_poses) // 20)][:20]
         kt = time_dominant_kernel(renderer, cam, timed_poses)
         k_ms, mlp_ms, k_live = kt['enc_ms'], kt['mlp_ms'], kt['live_per_launch']
+        in_frame = time_kernels_in_frame(renderer, cam, timed_poses)
         achieved = ENC_BYTES_PER_SAMPLE * k_live / (k_ms * 1e-3) / 1e9
         pmc_all = {}
         pmc = ROOT / 'profiles' / 'pmc_summary.json'
@@ -1137,6 +1191,7 @@ def main():
                          'kernel_bytes_per_sample': ENC_KERNEL_BYTES_PER_SAMPLE,
                          'kernel_ms': round(k_ms, 4), 'kernel_ms_min_pose': round(kt['enc_ms_min'], 4), 'kernel_ms_max_pose': round(kt['enc_ms_max'], 4),
                          'timed_over': f"{kt['poses']} poses of the timed region, {kt['launches_per_image']:.1f} launches per image, HIP events on the launch stream",
+                         'second_ruler': _second_ruler('k_grid_encode<1', in_frame.get('k_grid_encode'), ENC_BYTES_PER_SAMPLE * k_live / 1e9, HBM_PEAK_GBS, 1e-3),
                          'samples_per_launch': k_live, 'slots_per_launch': kt['slots_per_launch'],
                          'limiter': {'resource': 'L1 (TCP): tag lookups, and behind them the L1 misses of the four finest levels (7.3 of the 7.8 L2 requests per sample, 47 % of the kernel: profiles/r05_encoder_levels.md)',
                                      'achieved': enc_pmc.get('tcp_accesses_per_clk_per_cu'), 'peak': 1.0,
@@ -1148,7 +1203,8 @@ def main():
                               'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(MLP_FLOP_PER_SAMPLE * k_live / (mlp_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                               'traffic': mlp_pmc.get('hbm_bytes_per_launch'), 'traffic_source': mlp_pmc_src, 'kernel_ms': round(mlp_ms, 4),
                               'kernel_ms_min_pose': round(kt['mlp_ms_min'], 4), 'kernel_ms_max_pose': round(kt['mlp_ms_max'], 4),
-                              'flop_per_sample': MLP_FLOP_PER_SAMPLE, 'samples_per_launch': k_live},
+                              'flop_per_sample': MLP_FLOP_PER_SAMPLE, 'samples_per_launch': k_live,
+                              'second_ruler': _second_ruler('k_ngp_mlp<1', in_frame.get('k_ngp_mlp'), MLP_FLOP_PER_SAMPLE * k_live / 1e12, MFMA_PEAK_TFLOPS, 1e-3)},
         }
         if gs_res is not None:
             # bytes_fwd = 308 P_vis + 148 D + 20 H W ; bytes_bwd ~ 76 D + 472 P_vis + 20 H W

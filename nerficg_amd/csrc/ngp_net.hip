@@ -1129,13 +1129,16 @@ static int run_query(const QueryIn& in, int64_t M, int64_t n_ray_tiles, const vo
     if constexpr (SRC == SRC_TILED)
         hipLaunchKernelGGL(k_ray_sh, dim3((unsigned)nrc_cdiv(n_ray_tiles * 64, 256)), dim3(256), 0, s, in.ray_od, n_ray_tiles, ray_sh, in.tile_off,
                            in.tile_off ? const_cast<int32_t*>(in.row_tile) : (int32_t*)nullptr, M / 64);
+    NRC_STAGE(s, nullptr);      // (armed stage timer: the two kernels of every chunk IN the frame's own sequence -- bench.py's in-frame ruler)
     for (int64_t base = 0; base < M; base += NRC_QUERY_CHUNK) {
         const int64_t n = (M - base) < NRC_QUERY_CHUNK ? (M - base) : NRC_QUERY_CHUNK;
         if constexpr (SRC == SRC_TILED) {
-            if (query_fused_kernel()) { launch_encode_mlp<SRC>(in, base, n, table, g, ray_sh, wd, wc, packed, s); continue; }
+            if (query_fused_kernel()) { launch_encode_mlp<SRC>(in, base, n, table, g, ray_sh, wd, wc, packed, s); NRC_STAGE(s, "k_encode_mlp"); continue; }
         }
         launch_encode<SRC>(in, base, n, table, g, feat, s);
+        NRC_STAGE(s, "k_grid_encode");
         launch_mlp<SRC>(in, base, n, feat, ray_sh, wd, wc, sigmas, rgbs, packed, s);
+        NRC_STAGE(s, "k_ngp_mlp");
     }
     return NRC_OK;
 }

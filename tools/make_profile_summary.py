@@ -29,6 +29,14 @@ import os
 stats = sorted(glob.glob(str(RAW / 'bench_stats' / '*' / '*kernel_stats.csv')), key=os.path.getmtime)  # newest collection last
 if stats:
     shutil.copy(stats[-1], OUT / f'{ROUND}_bench_kernel_stats.csv')
+    # per-kernel mean durations of the bench command as JSON (bench.py's second ruler: roofline.second_ruler.rocprof_ms), gated on the source digests below
+    import hashlib as _hl
+    durations = {}
+    for r in csv.DictReader(open(stats[-1])):
+        durations[short(r['Name'])] = {'calls': int(r['Calls']), 'avg_us': round(float(r['AverageNs']) / 1e3, 3), 'total_us': round(float(r['TotalDurationNs']) / 1e3, 1)}
+    durations['_meta'] = {'round': ROUND, 'command': 'python bench.py --steps 20 --warmup 5',
+                          'csrc_sha': {p.name: _hl.sha256(p.read_bytes()).hexdigest()[:16] for p in sorted((ROOT / 'nerficg_amd' / 'csrc').glob('*.h*'))}}
+    (OUT / 'kernel_durations.json').write_text(json.dumps(durations, indent=1, sort_keys=True))
 for tag, name in (('gs_stats', f'{ROUND}_gs_kernel_stats.csv'), ('gs6_stats', f'{ROUND}_gs6m_kernel_stats.csv')):
     extra = sorted(glob.glob(str(RAW / tag / '*' / '*kernel_stats.csv')), key=os.path.getmtime)
     if extra:
