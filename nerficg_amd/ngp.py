@@ -99,6 +99,7 @@ class _WeightDecayNode(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, params_d, params_c, n_d, n_total):
+        _GRAD_SEEDS.clear()      # a seed that survived until the NEXT forward pass belongs to a backward pass that never finished: it must not reach this one's query
         out = torch.empty(1, dtype=torch.float32, device=params_d.device)
         _lib.check(_lib.load().nrc_sum_squares_two(_lib.ptr(params_d), n_d, _lib.ptr(params_c), params_c.numel(), 1.0 / n_total, _lib.ptr(out),
                                                    _lib.stream_of(out)), 'sum_squares_two')
@@ -119,7 +120,6 @@ class _WeightDecayNode(torch.autograd.Function):
 def _leave_seeds(params_and_counts, up, coeff: float) -> None:
     """register (up * coeff * w) as the pending gradient of the leading weights of each parameter (see _GRAD_SEEDS)"""
     import weakref
-    was_empty = not _GRAD_SEEDS
     for p, count in params_and_counts:
         prev = _GRAD_SEEDS.get(p.data_ptr())
         if prev is not None and prev[0]() is p:      # a second term on the same parameter in one pass: settle the first the ordinary way
@@ -129,8 +129,9 @@ def _leave_seeds(params_and_counts, up, coeff: float) -> None:
                     p.grad = torch.zeros_like(p)
                 p.grad[:prev[3]].add_(p.detach()[:prev[3]] * (prev[2] * prev[1]))
         _GRAD_SEEDS[p.data_ptr()] = (weakref.ref(p), up, coeff, count)
-    if was_empty:
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_seeds)
+    # ALWAYS queue the end-of-pass settlement (it pops whatever is left and is a no-op on an empty registry): "only when the registry was empty" left a seed of a pass
+    # that raised before its callbacks ran in place for ever -- no callback was queued for the next pass, whose query then consumed the stale seed (advisor, round 5)
+    torch.autograd.Variable._execution_engine.queue_callback(_flush_seeds)
 
 
 class _NGPLoss(torch.autograd.Function):
@@ -139,6 +140,7 @@ class _NGPLoss(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, pred, target, params_d, params_c, n_d, n_total, wd_weight):
+        _GRAD_SEEDS.clear()      # (see _WeightDecayNode.forward)
         pred, target = pred.contiguous(), target.contiguous()
         if pred.shape != target.shape:
             raise RuntimeError(f'instant_ngp_loss: prediction {tuple(pred.shape)} vs target {tuple(target.shape)}')
