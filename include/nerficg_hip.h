@@ -684,7 +684,7 @@ int nrc_stage_timer_end(int32_t max_stages, char* names, float* ms, int32_t* cou
  *            parameter group in two launches.  Launch 1 checks the gradients for inf / NaN; its last workgroup holds or advances *device_step,
  *            writes bias_corrections (2), state4[1] = found_inf of this step, state4[2] = 1 / scale the gradients carry, and applies torch's
  *            scale update rule (back off on overflow; grow after growth_interval clean steps) to *scale / *growth_tracker (scale NULL: no
- *            scaler).  Launch 2 is the Adam update of nrc_adam_step for both tensors (skipped when found_inf).  state4 (f32[4]) and ticket
+ *            scaler).  state4[3] (sticky): set when the Adam launch met an inf / NaN gradient element and left that element alone (round 6).  Launch 2 is the Adam update of nrc_adam_step for both tensors (skipped when found_inf).  state4 (f32[4]) and ticket
  *            (u32[272]: a two-level arrival counter) zeroed once by the caller.  lr_dev (NULL: the host value lr).  skipped_steps (optional, i32[1]): counts
  *            the steps an overflow skipped.
  * ===================================================================================================== */

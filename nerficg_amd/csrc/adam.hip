@@ -34,10 +34,13 @@ __global__ void k_adam_prepare(int32_t host_step, float beta1, float beta2, cons
 }
 
 // four consecutive elements starting at i0 (the body of both Adam kernels)
-template <bool ALIGNED>
+// GUARD (k_amp_adam): an element whose gradient is inf / NaN is left alone (parameter, moments, fp16 copy) and *guard_flag is raised.  The fused training step takes
+// found_inf from its producers' flags (state4[0]) without a pass over the summed gradients; a sum of finite values that overflows behind those flags -- it needs
+// |g| ~ 1e38 -- would otherwise enter the moments as inf and leave NaN parameters behind (advisor, round 5).  Bit-identical for finite gradients.
+template <bool ALIGNED, bool GUARD = false>
 __device__ __forceinline__ void adam_four(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                                           int64_t i0, float lr, float beta1, float beta2, float eps, float weight_decay, int adam_w_mode, float bc1, float bc2,
-                                          float inv_scale, __half* __restrict__ p16, float l2_coeff, int64_t l2_count) {
+                                          float inv_scale, __half* __restrict__ p16, float l2_coeff, int64_t l2_count, float* __restrict__ guard_flag = nullptr) {
     float pv[4], gv[4], mv[4], vv[4];
     const bool full = ALIGNED && i0 + 3 < n;  // 16-byte vector access needs all four pointers aligned (views into larger tensors may not be)
     if (full) {
@@ -52,8 +55,19 @@ __device__ __forceinline__ void adam_four(float* __restrict__ p, const float* __
         }
     }
     const NrcAdamHyper h{lr, beta1, beta2, eps, weight_decay, adam_w_mode, bc1, bc2, inv_scale};
+    if constexpr (GUARD) {
+        bool bad = false;
 #pragma unroll
-    for (int k = 0; k < 4; k++) nrc_adam_update(pv[k], gv[k], mv[k], vv[k], h, i0 + k < l2_count, l2_coeff);
+        for (int k = 0; k < 4; k++) {
+            const bool finite = (__float_as_uint(gv[k]) & 0x7f800000u) != 0x7f800000u;
+            if (finite) nrc_adam_update(pv[k], gv[k], mv[k], vv[k], h, i0 + k < l2_count, l2_coeff);
+            bad = bad || !finite;
+        }
+        if (bad && guard_flag) *guard_flag = 1.0f;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) nrc_adam_update(pv[k], gv[k], mv[k], vv[k], h, i0 + k < l2_count, l2_coeff);
+    }
     if (full) {
         *reinterpret_cast<float4*>(p + i0) = *reinterpret_cast<const float4*>(pv);
         *reinterpret_cast<float4*>(m + i0) = *reinterpret_cast<const float4*>(mv);
@@ -211,8 +225,9 @@ __global__ void __launch_bounds__(256) k_amp_adam(AmpList l, const float* __rest
     if (i0 >= t.n) return;
     if (lr_dev) lr = *lr_dev;
     const bool aligned = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15u) == 0);   // uniform per tensor
-    if (aligned) adam_four<true>(t.p, t.g, t.m, t.v, t.n, i0, lr, beta1, beta2, eps, weight_decay, adam_w_mode, bc[0], bc[1], state[2], t.p16, t.l2_coeff, t.l2_count);
-    else adam_four<false>(t.p, t.g, t.m, t.v, t.n, i0, lr, beta1, beta2, eps, weight_decay, adam_w_mode, bc[0], bc[1], state[2], t.p16, t.l2_coeff, t.l2_count);
+    float* guard = const_cast<float*>(state) + 3;      // state4[3]: sticky "an inf / NaN gradient reached the Adam launch and was left out" (the caller looks when it likes)
+    if (aligned) adam_four<true, true>(t.p, t.g, t.m, t.v, t.n, i0, lr, beta1, beta2, eps, weight_decay, adam_w_mode, bc[0], bc[1], state[2], t.p16, t.l2_coeff, t.l2_count, guard);
+    else adam_four<false, true>(t.p, t.g, t.m, t.v, t.n, i0, lr, beta1, beta2, eps, weight_decay, adam_w_mode, bc[0], bc[1], state[2], t.p16, t.l2_coeff, t.l2_count, guard);
 }
 
 // found_inf |= any element of g is inf / NaN.  One 16-byte load per lane and round, exponent test on the raw bits (all ones = inf or NaN), one

@@ -327,3 +327,26 @@ def test_wire_pack_saturates_and_unpack_round_trips():
         back = torch.zeros(n, device=DEV)
         _lib.check(lib.nrc_wire_unpack_f16(_lib.ptr(dst), _lib.ptr(back), n, _lib.stream_of(back)), 'wire_unpack_f16')
         assert torch.equal(back[~torch.isnan(src_bad)], dst.float()[~torch.isnan(src_bad)])
+
+
+def test_adam_launch_leaves_out_a_nonfinite_gradient_element_and_says_so():
+    """The fused step trusts its producers' overflow flags and runs no pass over the summed gradients; should an inf / NaN reach the Adam launch all the same (a sum of
+    finite values overflowing behind the flags), that element keeps its parameter and moments, every other element is updated, and state4[3] is raised."""
+    from nerficg_amd import _lib
+    lib, p = _lib.load(), _lib.ptr
+    n = 10_001
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    P0, G = torch.randn(n, device=DEV, generator=gen), torch.randn(n, device=DEV, generator=gen) * 128
+    G[17], G[4096], G[n - 1] = float('inf'), float('nan'), float('-inf')
+    Pm, M, V, H = P0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), P0.half()
+    step, bc, scale, tracker, state4 = (torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(2, device=DEV), torch.full((1,), 128.0, device=DEV),
+                                        torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(4, device=DEV))
+    flag = torch.zeros(1, device=DEV)       # the producers saw nothing
+    s = _lib.stream_of(Pm)
+    _lib.check(lib.nrc_amp_settle(p(flag), 1.0, 0.9, 0.99, p(step), p(bc), p(scale), p(tracker), 2.0, 0.5, 1000, p(state4), None, s), 'amp_settle')
+    _lib.check(lib.nrc_amp_adam_slices(p(Pm), p(G), p(M), p(V), p(H), n, 0.0, 0, None, None, None, None, None, 0, 0.0, 0, 1e-2, None, 0.9, 0.99, 1e-15, 0.0, 0,
+                                       p(bc), p(state4), s), 'amp_adam_slices')
+    bad = ~torch.isfinite(G)
+    assert float(state4[3]) == 1.0 and int(step) == 1
+    assert torch.equal(Pm[bad], P0[bad]) and bool((M[bad] == 0).all()) and bool((V[bad] == 0).all()) and torch.equal(H[bad], P0.half()[bad])
+    assert bool(torch.isfinite(Pm).all()) and bool((Pm[~bad] != P0[~bad]).all()) and torch.equal(H[~bad], Pm.half()[~bad])
