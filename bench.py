@@ -904,7 +904,7 @@ def dp_ingp_leg(model, renderer, cam, poses, rank, world, device, rays_per_rank=
             'replica_drift': drift, 'network_output_drift': out_drift, 'final_loss': round(float(losses[-1]), 6)}
 
 
-def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=8):
+def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=20):
     """3DGS view-parallel optimisation step: replicated Gaussians, every rank rasterizes ANOTHER view of the orbit, 0.8 L1 + 0.2 DSSIM, backward,
     visibility-sparse gradient reduction (parallel.sparse_allreduce_gradients: only rows seen by at least one rank travel), the same fused Adam
     step everywhere.  Weak scaling: one view per GPU and step."""
@@ -936,14 +936,17 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=8):
         out = render_image_training(g, cam, poses_dev[i])
         exchange.begin(out['radii'])      # (visible = radius > 0) mask max-reduce + device compaction + count to the host, beside the backward pass
         training_loss(out['rgb'], target).backward()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
+        if world > 1:       # (timing events are stream markers of their own: not in the single-GPU step, which has no collective to time)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
         n_union = exchange.finish(params, average=True)   # pack (1 launch) -> reduce-scatter + all-gather -> unpack (1 launch)
-        b.record()
+        if world > 1:
+            b.record()
         g.optimizer.step(); g.optimizer.zero_grad()
         if timed:
             rows[0] += max(n_union, 0); rows[1] += 1
-            coll_ms.append((a, b))
+            if world > 1:
+                coll_ms.append((a, b))
 
     for i in range(2):
         step(i, False)
@@ -957,7 +960,7 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=8):
     if world > 1:
         dist.barrier()
     dt = (time.perf_counter() - t0) / iters
-    coll = sum(a.elapsed_time(b) for a, b in coll_ms) / iters
+    coll = sum(a.elapsed_time(b) for a, b in coll_ms) / iters if coll_ms else 0.0
     drift = _replica_drift(torch.cat([p.detach().reshape(-1) for p in params]), world)
     dt, coll = _max_over_ranks([dt, coll], device, world)
     union_rows = rows[0] / max(rows[1], 1)
