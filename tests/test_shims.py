@@ -118,6 +118,22 @@ Framework.config.MODEL = Framework.ConfigWrapper.fromDict({'SCALE': 2.0, 'RESOLU
 m2 = InstantNGPModel('probe2').build()
 assert m2.cascades == 3 and m2.occupancy_grid.shape == (3, 64 ** 3) and len(m2.color_mlp_with_encoding.params) == 64 * 32 + 16 * 64
 assert m2.encoding_xyz.grid_cfg['log2_hashmap_size'] == 17
+# ... also the grid / SH keys (round 6): 8 levels x 4 features, SH degree 3 -- the reference's own slice arithmetic (Model.py:80-89,115) on the module's layout
+Framework.config.MODEL = Framework.ConfigWrapper.fromDict({'HASHGRID_N_LEVELS': 8, 'HASHGRID_N_FEATURES_PER_LEVEL': 4, 'DIR_SH_ENCODING_DEGREE': 3, 'HASHGRID_LOG2_SIZE': 15})
+m3 = InstantNGPModel('probe_keys').build()
+assert m3.encoding_xyz.grid_cfg['n_levels'] == 8 and m3.encoding_xyz.n_features == 4 and m3.color_mlp_with_encoding.sh_degree == 3
+assert m3.n_params_encoding_mlp == m3.encoding_xyz.n_mlp_params == 64 * 32 + 16 * 64 and len(m3.color_mlp_with_encoding.params) == 7168
+assert m3.encoding_xyz.params.numel() == m3.encoding_xyz.n_mlp_params + 4 * m3.encoding_xyz.grid_offsets[-1]
+assert not m3.encoding_xyz.default_layout and not m3.color_mlp_with_encoding.default_layout
+Framework.config.MODEL = Framework.ConfigWrapper.fromDict({'HASHGRID_N_LEVELS': 8, 'HASHGRID_N_FEATURES_PER_LEVEL': 2})      # 16 encoded inputs: a (64, 16) first layer in the master
+m4 = InstantNGPModel('probe_narrow').build()
+assert m4.n_params_encoding_mlp == m4.encoding_xyz.n_mlp_params == 64 * 16 + 16 * 64
+Framework.config.MODEL = Framework.ConfigWrapper.fromDict({'HASHGRID_N_FEATURES_PER_LEVEL': 4})      # 16 x 4 = 64 encoded inputs: refused by key name
+try:
+    InstantNGPModel('probe_wide').build()
+    raise SystemExit('a 64-input first layer was accepted')
+except RuntimeError as e:
+    assert 'HASHGRID_N_LEVELS' in str(e) and 'HASHGRID_N_FEATURES_PER_LEVEL' in str(e), e
 # ... and an unsupported one is refused with the key's name, not silently ignored
 Framework.config.MODEL = Framework.ConfigWrapper.fromDict({'N_DENSITY_NEURONS': 128})
 try:
