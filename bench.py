@@ -1144,20 +1144,8 @@ def main():
             del wide
             torch.cuda.empty_cache()
 
-    # ---- data-parallel training legs: the collectives of SURVEY 8(e) inside a timed iteration (every rank takes part)
-    dp = None
-    if not args.no_dp:
-        dp = {}
-        for name, fn in (('ingp', lambda: dp_ingp_leg(model, renderer, cam, poses, rank, world, device)), ('gs', lambda: dp_gs_leg(rank, world, device))):
-            try:
-                dp[name] = fn()
-            except RuntimeError as e:
-                if 'drifted' in str(e):
-                    raise
-                dp[name] = {'error': repr(e)[:300]}
-            torch.cuda.empty_cache()
-
-    if rank == 0:
+    def headline_result():
+        """Rank 0: the line's headline part -- value, rooflines of the frame's two kernels, the 3DGS secondary -- without the training legs."""
         rays = W * H * args.steps * world
         value = rays / elapsed / 1e6
         # the dominant kernel, timed on the poses the timed region of THIS rank rendered (all of them up to 20, else an even subset)
@@ -1248,6 +1236,43 @@ def main():
                     'frac_fwd': round(wb_fwd / (wd['ms_fwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     'frac_fwd_bwd': round((wb_fwd + wb_bwd) / (wd['ms_fwd_bwd'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     'per_kernel_ms': {k: round(v[0], 4) for k, v in sorted((wd.get('stage_ms') or {}).items())}}
+        return result
+
+    # N > 1: rank 0 builds the headline part BEFORE the collectives of the data-parallel legs, and every rank arms a watchdog around them: a rank that
+    # fails alone leaves the others waiting inside a collective (try / except cannot reach that), and the line must not be lost over an extra leg.
+    result = None
+    watchdog = None
+    if world > 1 and not args.no_dp:
+        if rank == 0:
+            result = headline_result()
+        deadline = float(os.environ.get('NRC_BENCH_DP_DEADLINE', 300))
+
+        def bail():
+            if rank == 0:
+                print(json.dumps({**result, 'dp_training': {'error': f'watchdog: the data-parallel legs did not return within {deadline:.0f} s; the headline, the rooflines '
+                                                                     'and the 3DGS secondary above were measured before them'}, 'cpu_baseline': None}), flush=True)
+            os._exit(0)
+        import threading
+        watchdog = threading.Timer(deadline + (0.0 if rank == 0 else 10.0), bail)
+        watchdog.daemon = True
+        watchdog.start()
+
+    # ---- data-parallel training legs: the collectives of SURVEY 8(e) inside a timed iteration (every rank takes part)
+    dp = None
+    if not args.no_dp:
+        dp = {}
+        for name, fn in (('ingp', lambda: dp_ingp_leg(model, renderer, cam, poses, rank, world, device)), ('gs', lambda: dp_gs_leg(rank, world, device))):
+            try:
+                dp[name] = fn()
+            except Exception as e:   # replica drift included: reported in the line (every rank sees the same reduced drift, so every rank leaves the leg together)
+                dp[name] = {'error': repr(e)[:300]}
+            torch.cuda.empty_cache()
+    if watchdog is not None:
+        watchdog.cancel()
+
+    if rank == 0:
+        if result is None:
+            result = headline_result()
         if not args.no_train:
             try:
                 result['training'] = time_train(model, renderer, cam, poses)
@@ -1296,8 +1321,12 @@ def main():
                 result['cpu_baseline_c1'] = {'error': repr(e)[:300]}
         print(json.dumps(result), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:   # a peer left through its watchdog: rank 0's line is out (or will never be), nothing is gained by a traceback here
+            print(f'bench.py rank {rank}: the closing barrier failed ({repr(e)[:120]})', file=sys.stderr, flush=True)
+            os._exit(0)
 
 
 if __name__ == '__main__':
