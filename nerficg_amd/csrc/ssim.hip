@@ -20,7 +20,7 @@ namespace {
 #define SR 5           // window radius
 #define SI (ST + 2 * SR)  // 42: input tile edge
 #define SP (SI + 1)    // LDS pitch of the input tiles
-#define XP 40          // LDS pitch of the horizontally blurred rows: the two 4-row groups of a wave land 32 banks apart
+#define XP 33          // LDS pitch of the horizontally blurred rows: odd, so that the 4 rows x 8 column groups a half-wave writes in the horizontal pass land in 32 different banks
 #define SQ 4           // outputs per thread and pass
 #define SLD ((SI * SI + 255) / 256)  // halo elements per thread
 
@@ -37,21 +37,30 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(const float* __restrict__ img1
     __shared__ float s1[SI][SP], s2[SI][SP];
     __shared__ float xb[5][SI][XP];
     __shared__ float red[2][4];
+    // the plane's base is wave-uniform (scalar registers); inside the plane 32-bit offsets, stepped from load to load: element k + 256 of the (SI x SI) halo
+    // is 6 rows and 4 columns further (256 = 6 x 42 + 4), one row more when the column wraps -- no multiply, no 64-bit vector arithmetic per load
     const size_t plane = (size_t)blockIdx.z * H * W;
+    img1 += plane; img2 += plane;
     const int x0 = blockIdx.x * ST - SR, y0 = blockIdx.y * ST - SR;
     {   // all of a thread's halo loads are issued before the first LDS store: one HBM latency per tile, not one per loop trip
         float r1[SLD], r2[SLD];
+        int r = (int)threadIdx.x / SI, c = (int)threadIdx.x - r * SI;
+        int off = (y0 + r) * W + x0 + c;
 #pragma unroll
         for (int it = 0; it < SLD; it++) {
-            const int k = threadIdx.x + 256 * it, r = k / SI, c = k - r * SI, y = y0 + r, x = x0 + c;
-            const bool in = k < SI * SI && y >= 0 && y < H && x >= 0 && x < W;
-            r1[it] = in ? img1[plane + (size_t)y * W + x] : 0.f;
-            r2[it] = in ? img2[plane + (size_t)y * W + x] : 0.f;
+            const int y = y0 + r, x = x0 + c;
+            const bool in = r < SI && y >= 0 && y < H && x >= 0 && x < W;
+            r1[it] = in ? img1[off] : 0.f;
+            r2[it] = in ? img2[off] : 0.f;
+            r += 256 / SI; c += 256 % SI; off += (256 / SI) * W + 256 % SI;
+            if (c >= SI) { c -= SI; r++; off += W - SI; }
         }
+        r = (int)threadIdx.x / SI; c = (int)threadIdx.x - r * SI;
 #pragma unroll
         for (int it = 0; it < SLD; it++) {
-            const int k = threadIdx.x + 256 * it, r = k / SI, c = k - r * SI;
-            if (k < SI * SI) { s1[r][c] = r1[it]; s2[r][c] = r2[it]; }
+            if (r < SI) { s1[r][c] = r1[it]; s2[r][c] = r2[it]; }
+            r += 256 / SI; c += 256 % SI;
+            if (c >= SI) { c -= SI; r++; }
         }
     }
     __syncthreads();
@@ -102,7 +111,7 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(const float* __restrict__ img1
         const float iAB = 1.f / (A * B);
         const float ssim = C * D * iAB;
         if (inside) {
-            const size_t o = plane + (size_t)y * W + x;
+            const size_t o = plane + (size_t)(y * W + x);
             if (!LOSS) ssim_map[o] = ssim;
             if (TRAIN) {
                 dm_dmu1[o] = (mu2 * 2.f * D) * iAB - (mu2 * 2.f * C) * iAB - (mu1 * 2.f * C * D) * iAB / A + (mu1 * 2.f * C * D) * iAB / B;
@@ -164,24 +173,31 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(const float* __restrict__ img1
     __shared__ float p[3][SI][SP];
     const float g_up = LOSS ? (upstream ? upstream[0] : 1.f) : 0.f;
     __shared__ float xb[3][SI][XP];
-    const size_t plane = (size_t)blockIdx.z * H * W;
+    const size_t plane = (size_t)blockIdx.z * H * W;   // wave-uniform base, 32-bit offsets inside the plane stepped from load to load (see k_ssim_fwd)
+    img1 += plane; img2 += plane; dm_dmu1 += plane; dm_dsigma1_sq += plane; dm_dsigma12 += plane; dL_dimg1 += plane;
+    if (!LOSS) dL_dmap += plane;
     const int x0 = blockIdx.x * ST - SR, y0 = blockIdx.y * ST - SR;
     {
         float r0[SLD], r1[SLD], r2[SLD], dl[SLD];
+        int r = (int)threadIdx.x / SI, c = (int)threadIdx.x - r * SI;
+        int off = (y0 + r) * W + x0 + c;
 #pragma unroll
         for (int it = 0; it < SLD; it++) {
-            const int k = threadIdx.x + 256 * it, r = k / SI, c = k - r * SI, y = y0 + r, x = x0 + c;
-            const bool in = k < SI * SI && y >= 0 && y < H && x >= 0 && x < W;
-            const size_t o = plane + (size_t)y * W + x;
-            dl[it] = in ? (LOSS ? c_ssim * g_up : dL_dmap[o]) : 0.f;
-            r0[it] = in ? dm_dmu1[o] : 0.f;
-            r1[it] = in ? dm_dsigma1_sq[o] : 0.f;
-            r2[it] = in ? dm_dsigma12[o] : 0.f;
+            const int y = y0 + r, x = x0 + c;
+            const bool in = r < SI && y >= 0 && y < H && x >= 0 && x < W;
+            dl[it] = in ? (LOSS ? c_ssim * g_up : dL_dmap[off]) : 0.f;
+            r0[it] = in ? dm_dmu1[off] : 0.f;
+            r1[it] = in ? dm_dsigma1_sq[off] : 0.f;
+            r2[it] = in ? dm_dsigma12[off] : 0.f;
+            r += 256 / SI; c += 256 % SI; off += (256 / SI) * W + 256 % SI;
+            if (c >= SI) { c -= SI; r++; off += W - SI; }
         }
+        r = (int)threadIdx.x / SI; c = (int)threadIdx.x - r * SI;
 #pragma unroll
         for (int it = 0; it < SLD; it++) {
-            const int k = threadIdx.x + 256 * it, r = k / SI, c = k - r * SI;
-            if (k < SI * SI) { p[0][r][c] = dl[it] * r0[it]; p[1][r][c] = dl[it] * r1[it]; p[2][r][c] = dl[it] * r2[it]; }
+            if (r < SI) { p[0][r][c] = dl[it] * r0[it]; p[1][r][c] = dl[it] * r1[it]; p[2][r][c] = dl[it] * r2[it]; }
+            r += 256 / SI; c += 256 % SI;
+            if (c >= SI) { c -= SI; r++; }
         }
     }
     __syncthreads();
@@ -223,7 +239,7 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(const float* __restrict__ img1
     for (int i = 0; i < SQ; i++) {
         const int y = blockIdx.y * ST + ty0 + i;
         if (y >= H) break;
-        const size_t o = plane + (size_t)y * W + x;
+        const int o = y * W + x;
         const float u = img1[o], v = img2[o];
         float r = b[i][0] + 2.f * u * b[i][1] + v * b[i][2];
         if (LOSS) { const float d = u - v; r += c_l1 * g_up * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)); }
@@ -238,7 +254,7 @@ extern "C" {
 int nrc_ssim_forward(const float* img1, const float* img2, int64_t planes, int32_t H, int32_t W, float C1, float C2, float* ssim_map,
                      float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, nrc_stream_t stream) {
     NRC_ENTER();
-    if (planes < 0 || H < 1 || W < 1 || planes > 65535) return NRC_ERR_INVALID;
+    if (planes < 0 || H < 1 || W < 1 || planes > 65535 || (int64_t)H * W > 0x7fffffff) return NRC_ERR_INVALID;
     if (planes == 0) return NRC_OK;
     if (!img1 || !img2 || !ssim_map) return NRC_ERR_INVALID;
     const bool train = dm_dmu1 || dm_dsigma1_sq || dm_dsigma12;
@@ -257,7 +273,7 @@ int nrc_ssim_forward(const float* img1, const float* img2, int64_t planes, int32
 int nrc_ssim_backward(const float* img1, const float* img2, int64_t planes, int32_t H, int32_t W, const float* dL_dmap, const float* dm_dmu1,
                       const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1, nrc_stream_t stream) {
     NRC_ENTER();
-    if (planes < 0 || H < 1 || W < 1 || planes > 65535) return NRC_ERR_INVALID;
+    if (planes < 0 || H < 1 || W < 1 || planes > 65535 || (int64_t)H * W > 0x7fffffff) return NRC_ERR_INVALID;
     if (planes == 0) return NRC_OK;
     if (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1) return NRC_ERR_INVALID;
     const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, (unsigned)planes);
@@ -275,7 +291,7 @@ int nrc_photometric_loss_forward(const float* image, const float* target, int64_
                                  float lambda_dssim, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, float* workspace, float* loss3,
                                  nrc_stream_t stream) {
     NRC_ENTER();
-    if (planes < 1 || H < 1 || W < 1 || planes > 65535 || !image || !target || !workspace || !loss3) return NRC_ERR_INVALID;
+    if (planes < 1 || H < 1 || W < 1 || planes > 65535 || (int64_t)H * W > 0x7fffffff || !image || !target || !workspace || !loss3) return NRC_ERR_INVALID;
     const bool train = dm_dmu1 || dm_dsigma1_sq || dm_dsigma12;
     if (train && !(dm_dmu1 && dm_dsigma1_sq && dm_dsigma12)) return NRC_ERR_INVALID;
     const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, (unsigned)planes);
@@ -295,7 +311,7 @@ int nrc_photometric_loss_backward(const float* image, const float* target, int64
                                   const float* upstream_dev, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimage,
                                   nrc_stream_t stream) {
     NRC_ENTER();
-    if (planes < 1 || H < 1 || W < 1 || planes > 65535) return NRC_ERR_INVALID;
+    if (planes < 1 || H < 1 || W < 1 || planes > 65535 || (int64_t)H * W > 0x7fffffff) return NRC_ERR_INVALID;
     if (!image || !target || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimage) return NRC_ERR_INVALID;
     const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, (unsigned)planes);
     const double inv_n = 1.0 / ((double)planes * H * W);
