@@ -918,7 +918,7 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=20):
     g = Gaussians(T(sc['means3D']), torch.log(T(sc['scales'])), T(sc['rotations']), torch.logit(T(sc['opacities']).clamp(1e-4, 1 - 1e-4))[:, None].contiguous(),
                   T(sc['shs'][:, :1]), T(sc['shs'][:, 1:]))
     g.training_setup(training_cameras_extent=4.5)
-    g.fuse_rest_step = world == 1      # one GPU: the f_rest Adam step runs inside the preprocessing backward; view-parallel ranks need that gradient on the wire
+    g.fuse_rest_step = False           # the reference's step order first (backward, then optimizer.step() on all six groups); the in-backward f_rest step is timed below
     params = [grp['params'][0] for grp in g.optimizer.param_groups]
     if world > 1:
         parallel.broadcast_parameters(params)
@@ -968,7 +968,20 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=20):
     if drift != 0.0:
         raise RuntimeError(f'3DGS view-parallel replicas drifted: {drift:.3e}')
     graphed = None
+    rest_in_backward = None
     if world == 1:
+        # opt-in variant: Adam of the f_rest group inside the preprocessing backward.  Same parameters as the plain step on every iteration in
+        # which optimizer.step() follows the backward pass directly; the reference's trainer lets densify / reset_opacities run between the two on some
+        # iterations (Trainer.py:100-128), which drops that iteration's update there -- a loop using the variant switches it off for those iterations.
+        g.fuse_rest_step = True
+        for i in range(2):
+            step(i, False)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(iters):
+            step(2 + i, False)
+        torch.cuda.synchronize()
+        rest_in_backward = {'ms_per_step': round((time.perf_counter() - t0) / iters * 1e3, 3), 'what': 'Gaussians.fuse_rest_step = True: nrc_gs_backward_rest_step + nrc_adam_step_multi'}
+        g.fuse_rest_step = False
         # the same step (plus the densification statistics of the reference's trainer) recorded in a HIP graph: fixed list / span capacities
         # from the counts of an op-by-op frame, pose and target as device inputs, Adam's step counters and learning rates on the device
         from nerficg_amd import diff_gaussian_rasterization as dgr
@@ -988,7 +1001,7 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=20):
         graphed = {'ms_per_step': round(dt_g * 1e3, 3), 'msplats_per_s': round(n_gaussians / dt_g / 1e6, 1), 'instance_capacity': caps[0],
                    'span_capacity': caps[1], 'max_instances_seen': worst[0], 'max_spans_seen': worst[1],
                    'dropped': bool(worst[0] > caps[0] or worst[1] > caps[1]), 'includes': 'densification statistics (nrc_gs_densify_stats)'}
-    return {'hip_graph': graphed, 'ms_per_step': round(dt * 1e3, 3), 'views_per_step': world, 'gaussians': n_gaussians, 'msplats_per_s': round(world * n_gaussians / dt / 1e6, 1),
+    return {'hip_graph': graphed, 'ms_per_step': round(dt * 1e3, 3), 'rest_step_in_backward': rest_in_backward, 'views_per_step': world, 'gaussians': n_gaussians, 'msplats_per_s': round(world * n_gaussians / dt / 1e6, 1),
             'collective': f'max-reduce of the visibility mask beside the backward pass (device compaction, count read under it) + one packed reduction of the union rows over {dist.get_backend()}' if world > 1 else None,
             'wire_bytes_per_gpu': int(2 * (world - 1) / world * nbytes + (world - 1) / world * 2 * n_gaussians) if world > 1 else 0,
             'union_rows_per_step': round(union_rows), 'bytes_reduced_per_step': nbytes if world > 1 else 0, 'collective_ms': round(coll, 3) if world > 1 else None,
