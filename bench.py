@@ -16,6 +16,7 @@ Prints ONE JSON line on rank 0 (metric/value/... + "roofline" for the dominant k
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import math
 import os
@@ -339,9 +340,9 @@ def time_gs(gs, reps=5, barrier=None):
                             rotations=args['rotations'])
         return color, radii
 
-    def timed(body, trials=3):
+    def timed(body, trials=5):
         """Median of `trials` averages over `reps` back-to-back calls (one sync per trial): a single average is thrown off by the odd slow trial
-        on a shared box (seen: 1.25 / 1.25 / 1.8 ms for the same frame); all three are reported."""
+        on a shared box (seen: 1.25 / 1.25 / 1.8 ms for the same frame, and 1.25 / 1.32 / 0.91 on a lease whose host stalled: five trials since); all are reported."""
         body()
         barrier()
         avgs = []
@@ -602,6 +603,9 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=60):
         scaler.step(opt); scaler.update(); opt.zero_grad()
         return int(out['rm_samples'].item())
 
+    # what earlier legs left behind (a torn-down HIP graph, 6 M-Gaussian scenes) is released HERE, not by a collection inside the timed loop: this leg is ~90 host
+    # launches per iteration, and one 75 ms collection in sixty iterations had it at 1.9 ms instead of 0.6-0.7 on one lease (profiles/r06_bench_runs.md)
+    gc.collect()
     for i in range(3):
         step(i)
     torch.cuda.synchronize(); t0 = time.perf_counter(); tot = 0
@@ -707,7 +711,6 @@ def time_train(model, renderer, cam, poses, n_rays=2200, iters=60):
     # parameters (a gradient on every sample at the start).
     from nerficg_amd.ngp_trainer import FusedTrainingIteration
     del graphed
-    import gc
     gc.collect(); torch.cuda.synchronize()   # the recording (its closures form cycles) is torn down HERE: collected inside the timed loop below, the release of
                                              # the graph's private pool stalled the device for ~80 ms once (first third 4.1 ms per iteration in one run of five)
     opt_f = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, betas=(0.9, 0.99), adam_w_mode=False, capturable=True)
@@ -948,6 +951,7 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=20):
             if world > 1:
                 coll_ms.append((a, b))
 
+    gc.collect()      # before the warm-up steps, not between them and the timed loop: the chip must not sit idle (and clock down) in front of the first timed step
     for i in range(2):
         step(i, False)
     torch.cuda.synchronize()
@@ -980,7 +984,7 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=20):
         for i in range(iters):
             step(2 + i, False)
         torch.cuda.synchronize()
-        rest_in_backward = {'ms_per_step': round((time.perf_counter() - t0) / iters * 1e3, 3), 'what': 'Gaussians.fuse_rest_step = True: nrc_gs_backward_rest_step + nrc_adam_step_multi'}
+        rest_in_backward = {'ms_per_step': round((time.perf_counter() - t0) / iters * 1e3, 3), 'what': 'Gaussians.fuse_rest_step = True: nrc_gs_backward_rest_step + nrc_adam_step_multi; with rest_step_schedule it applies to 29 856 of the 30 000 iterations of the reference schedule (all but those in which densify_and_prune runs between backward and optimizer.step())'}
         g.fuse_rest_step = False
         # the same step (plus the densification statistics of the reference's trainer) recorded in a HIP graph: fixed list / span capacities
         # from the counts of an op-by-op frame, pose and target as device inputs, Adam's step counters and learning rates on the device
@@ -1047,6 +1051,10 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # The cyclic collector stays OFF for the whole run and runs at the leg boundaries instead (gc.collect() below and inside the legs): a collection inside a
+    # timed loop -- e.g. the teardown of an earlier leg's HIP graph, tens of milliseconds -- is not part of any path under test (r05: fused leg; r06: the
+    # drop-in training leg at 1.9 instead of 0.6-0.7 ms on one lease).  Reference counting frees tensors as usual.
+    gc.disable()
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -1074,10 +1082,8 @@ def main():
 
     if args.scaling == 'strong':
         c4_model, c4_renderer, c4_cam, c4_poses = build_c4_scene(device)
-        import gc
         gc.collect(); gc.disable()
         r = strong_scaling_frames(c4_renderer, c4_cam, c4_poses, rank, world, args.steps, args.warmup, barrier, red_dev)
-        gc.enable()
         if rank == 0:
             elapsed = r.pop('elapsed')
             print(json.dumps({
@@ -1104,12 +1110,11 @@ def main():
         return renderer.render_image_fused(cam, pose, return_stats=True)
 
     samples = 0
+    gc.collect()  # (the collector is off for the whole run: a full collection in the middle of the timed steps costs tens of milliseconds and is not part of the path
+                  # under test; collected in FRONT of the warm-up frames so that nothing stands between them and the timed ones)
     for i in range(args.warmup):
         step(i)
     barrier()
-    import gc
-    gc.collect()
-    gc.disable()  # a full collection in the middle of the timed steps costs tens of milliseconds and is not part of the path under test
     t0 = time.perf_counter()
     _dbg = []
     for i in range(args.steps):
@@ -1118,7 +1123,6 @@ def main():
         _dbg.append(time.perf_counter() - _t)
     barrier()
     elapsed_now = time.perf_counter() - t0
-    gc.enable()
     if os.environ.get('NRC_BENCH_DEBUG'):
         print('per-step ms:', ' '.join(f'{x * 1e3:.1f}' for x in _dbg), file=sys.stderr)
     elapsed = elapsed_now
@@ -1217,7 +1221,7 @@ def main():
             result['secondary'] = {
                 'metric': 'Msplats/s (3DGS, 1 M synthetic Gaussians, 1297x840)', 'value_fwd': gs_res['msplats_per_s_fwd'],
                 'value_fwd_bwd': gs_res['msplats_per_s_fwd_bwd'], 'unit': 'Msplats/s', 'ms_fwd': gs_res['ms_fwd'], 'ms_fwd_bwd': gs_res['ms_fwd_bwd'],
-                'timing': 'median of three averages over %d back-to-back frames each' % max(3, args.steps // 2),
+                'timing': 'median of five averages over %d back-to-back frames each' % max(3, args.steps // 2),
                 'trials_ms_fwd': gs_res.get('trials_ms_fwd'), 'trials_ms_fwd_bwd': gs_res.get('trials_ms_fwd_bwd'),
                 'gaussians_per_gpu': gs_res['gaussians'], 'visible': gs_res['visible'], 'instances': gs_res['instances'], 'dtype': 'f32',
                 'roofline': {'bound': 'hbm', 'scope': 'whole forward / forward+backward (all rasterizer kernels)',
@@ -1275,6 +1279,7 @@ def main():
     if not args.no_dp:
         dp = {}
         for name, fn in (('ingp', lambda: dp_ingp_leg(model, renderer, cam, poses, rank, world, device)), ('gs', lambda: dp_gs_leg(rank, world, device))):
+            gc.collect()
             try:
                 dp[name] = fn()
             except Exception as e:   # replica drift included: reported in the line (every rank sees the same reduced drift, so every rank leaves the leg together)
@@ -1286,12 +1291,14 @@ def main():
     if rank == 0:
         if result is None:
             result = headline_result()
+        gc.collect()
         if not args.no_train:
             try:
                 result['training'] = time_train(model, renderer, cam, poses)
             except Exception as e:  # never lose the headline line over the extra leg
                 result['training'] = {'error': repr(e)[:200]}
         result['dp_training'] = dp
+        gc.collect()
         if world == 1 and not args.no_train:
             try:
                 result['secondary_trained'] = trained_scene_leg(device)
@@ -1299,6 +1306,7 @@ def main():
                 result['secondary_trained'] = {'error': repr(e)[:300]}
             torch.cuda.empty_cache()
         # BASELINE configs[3] shape on this one GPU (the single-rank point of `--scaling strong`) and one of eight shards of the same frames
+        gc.collect()
         if world == 1:
             try:
                 torch.cuda.empty_cache()

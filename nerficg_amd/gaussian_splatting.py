@@ -13,7 +13,7 @@ import torch
 
 __all__ = ['PerspectiveCamera', 'get_projection_matrix', 'invert_3d_affine', 'make_raster_settings', 'quaternion_to_rotation_matrix',
            'build_covariances', 'extract_upper_triangular_matrix', 'sh_basis', 'convert_sh_features', 'rgb_to_sh0', 'sh0_to_rgb', 'Gaussians',
-           'render_image_training', 'render_image_inference', 'training_loss']
+           'render_image_training', 'render_image_inference', 'training_loss', 'rest_step_schedule', 'RestStep']
 
 
 @dataclass
@@ -277,6 +277,11 @@ class Gaussians(torch.nn.Module):
         for group in self.optimizer.param_groups:
             if group['name'] == 'positions':
                 group['lr'] = rate
+        # the reference's trainer calls this first thing in iteration `iteration - 1` (Trainer.py:84): with a schedule installed the in-backward f_rest step is
+        # switched per iteration, off where densify_and_prune will run between the backward pass and optimizer.step() (rest_step_schedule below)
+        schedule = getattr(self, 'fuse_rest_schedule', None)
+        if schedule is not None:
+            self.fuse_rest_step = bool(schedule(iteration - 1))
 
     def _adopt(self, tensors: dict[str, torch.Tensor]) -> None:
         for name, attr in self._GROUP_OF.items():
@@ -380,6 +385,25 @@ class Gaussians(torch.nn.Module):
         for column, name in enumerate(names):
             vertex[name] = table[:, column]
         return {'vertex': vertex}
+
+
+def rest_step_schedule(densify_start_iteration: int, densify_end_iteration: int, densification_interval: int):
+    """iteration -> may the f_rest optimizer step of that iteration run inside the backward pass (Gaussians.fuse_rest_step) without leaving the reference's trajectory?
+
+    The reference's trainer runs `densify` (priority 90) between `loss.backward()` (priority 100) and `optimizer.step()` (priority 70), Trainer.py:76-128.  A callback
+    fires when start <= iteration <= end and (iteration - start) % stride == 0 (Base/Trainer.py:238-243); `densify` returns at once in its first and last iteration
+    (Trainer.py:104-105) and otherwise calls densify_and_prune, whose prune_points replaces ALL six parameter tensors by fresh nn.Parameters without .grad
+    (Model.py:157-167, 242-252): the optimizer then finds no gradient and that iteration's update is dropped.  A step applied inside the backward pass has already
+    happened by then, so those iterations keep the plain order.  `reset_opacities` (priority 80) replaces the opacity tensor only: the f_rest step is not affected.
+    Install with `gaussians.fuse_rest_schedule = rest_step_schedule(DENSIFY_START_ITERATION, DENSIFY_END_ITERATION, DENSIFICATION_INTERVAL)`; the trainer's own
+    `update_learning_rate(iteration + 1)` call then sets `fuse_rest_step` for the iteration."""
+    a, b, k = int(densify_start_iteration), int(densify_end_iteration), int(densification_interval)
+    if k <= 0:
+        raise ValueError('densification_interval must be positive')
+
+    def clean(iteration: int) -> bool:
+        return not (a < iteration < b and (iteration - a) % k == 0)
+    return clean
 
 
 class RestStep:

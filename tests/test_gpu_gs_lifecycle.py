@@ -114,3 +114,46 @@ def test_rest_step_inside_the_backward_pass_equals_the_optimizers_own_launch():
     assert_within_run_to_run_noise(got[0], ref[0], ref2[0], atol=1e-6, rtol=1e-3, what='three steps, rest step inside the backward pass')
     moved = float((got[0][2] - T(sc['shs'][:, 1:])).abs().max())
     assert moved > 1e-5     # the tensor really was stepped
+
+
+def test_rest_step_schedule_keeps_the_reference_order_where_an_update_is_dropped():
+    """Gaussians.fuse_rest_schedule (rest_step_schedule): the trainer's own update_learning_rate(iteration + 1) call switches the in-backward f_rest step per iteration.
+    The loop below is the reference's order -- backward, [on densify iterations: the parameters lose their gradients, here by zero_grad(), as prune_points' fresh
+    nn.Parameters do], optimizer.step() -- with start 1, end 6, interval 2: iterations 3 and 5 drop their update.  With the schedule the fused loop lands where the
+    plain loop does (run-to-run spread of the float atomics); without it the f_rest tensor has taken two steps the reference drops."""
+    import numpy as np
+    from nerficg_amd.gaussian_splatting import Gaussians, PerspectiveCamera, render_image_training, training_loss, rest_step_schedule
+    from tests.noise import assert_within_run_to_run_noise
+    sc = scenes.gs_random_scene(20_000, seed=6, extent=1.0, log_scale_mean=np.log(0.03))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)   # noqa: E731
+    cam = PerspectiveCamera(256, 160, 300.0, 300.0, background_color=torch.zeros(3, device=DEV))
+    target = torch.rand(3, 160, 256, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    poses = [torch.from_numpy(np.asarray(scenes.orbit_pose(0.4 + 0.8 * i, 0.3, 3.0), dtype=np.float32)).to(DEV) for i in range(7)]
+    clean = rest_step_schedule(1, 6, 2)
+    assert [it for it in range(7) if not clean(it)] == [3, 5]
+
+    def run(mode):
+        g = Gaussians(T(sc['means3D']), torch.log(T(sc['scales'])), T(sc['rotations']), torch.logit(T(sc['opacities']).clamp(1e-4, 1 - 1e-4))[:, None].contiguous(),
+                      T(sc['shs'][:, :1]), T(sc['shs'][:, 1:]))
+        g.training_setup(training_cameras_extent=3.0)
+        if mode == 'scheduled':
+            g.fuse_rest_schedule = clean
+        elif mode == 'always':
+            g.fuse_rest_step = True
+        fused_in = []
+        for it in range(7):
+            g.update_learning_rate(it + 1)                      # Trainer.py:84
+            out = render_image_training(g, cam, poses[it])
+            training_loss(out['rgb'], target).backward()
+            fused_in.append(g._features_rest.grad is None)
+            if not clean(it):
+                g.optimizer.zero_grad()                         # what densify_and_prune leaves for optimizer.step(): parameters without gradients
+            g.optimizer.step(); g.optimizer.zero_grad()
+        return [grp['params'][0].detach().clone() for grp in g.optimizer.param_groups], fused_in
+
+    plain, plain2, sched, always = run('plain'), run('plain'), run('scheduled'), run('always')
+    assert plain[1] == [False] * 7 and always[1] == [True] * 7 and sched[1] == [True, True, True, False, True, False, True]
+    assert_within_run_to_run_noise(sched[0], plain[0], plain2[0], atol=1e-6, rtol=1e-3, what='seven iterations, scheduled rest step')
+    rest = 2     # param group order of training_setup: positions, f_dc, f_rest, ...
+    spread = float((plain[0][rest] - plain2[0][rest]).abs().max())
+    assert float((always[0][rest] - plain[0][rest]).abs().max()) > 100 * max(spread, 1e-7)      # two extra steps of ~lr each: not noise

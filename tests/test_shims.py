@@ -265,3 +265,40 @@ assert alive[0] == n and alive == sorted(alive, reverse=True)
 ''' % (str(ROOT / 'tests' / 'golden'), str(ROOT), str(ROOT / 'tests' / 'golden' / 'ingp_orchestration.npz'))
     r = subprocess.run([sys.executable, '-c', code + "\nprint('ok')\n"], capture_output=True, text=True, env={**os.environ, 'PYTHONPATH': ''})
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.skipif(not REF.exists(), reason='reference tree only exists in the build container')
+def test_rest_step_schedule_follows_the_reference_trainers_own_callbacks():
+    """nerficg_amd.gaussian_splatting.rest_step_schedule against the reference's code: the callbacks of GaussianSplattingTrainer with their registered priorities /
+    start / end / stride (Trainer.py:76-128), the skip rule of the training loop (Base/Trainer.py:238-243, restated), and the reference's OWN `densify` and
+    `reset_opacities` bodies executed on a recording stand-in for the model -- an iteration is 'clean' when nothing that runs between loss.backward() (priority 100)
+    and optimizer.step() (priority 70) replaces the f_rest parameter, i.e. when densify_and_prune is not called."""
+    _run_in_reference(r'''
+Framework.config.GLOBAL.METHOD_TYPE = 'GaussianSplatting'
+from Methods.GaussianSplatting.Trainer import GaussianSplattingTrainer as T
+from nerficg_amd.gaussian_splatting import rest_step_schedule
+cfg = dict(T.get_default_parameters()) if not isinstance(T.get_default_parameters(), dict) else T.get_default_parameters()
+cfg = {k: cfg[k] for k in ('DENSIFY_START_ITERATION', 'DENSIFY_END_ITERATION', 'DENSIFICATION_INTERVAL', 'OPACITY_RESET_INTERVAL', 'NUM_ITERATIONS', 'DENSIFY_GRAD_THRESHOLD')}
+assert (cfg['DENSIFY_START_ITERATION'], cfg['DENSIFY_END_ITERATION'], cfg['DENSIFICATION_INTERVAL'], cfg['OPACITY_RESET_INTERVAL']) == (500, 15000, 100, 3000)
+between = [f for f in (getattr(T, n) for n in dir(T)) if callable(f) and getattr(f, 'callback_type', None) == 0 and 70 < f.priority < 100]
+assert sorted(f.__name__ for f in between) == ['densify', 'reset_opacities', 'reset_opacities_white_background']
+assert T.training_iteration.priority == 100 and T.perform_optimizer_step.priority == 70
+calls = []
+gaussians = types.SimpleNamespace(densify_and_prune=lambda *a: calls.append('densify_and_prune'), reset_opacities=lambda: calls.append('reset_opacities'))
+me = types.SimpleNamespace(model=types.SimpleNamespace(gaussians=gaussians), **cfg)
+value = lambda v: cfg[v] if isinstance(v, str) else v
+clean = rest_step_schedule(cfg['DENSIFY_START_ITERATION'], cfg['DENSIFY_END_ITERATION'], cfg['DENSIFICATION_INTERVAL'])
+dirty = 0
+dataset = types.SimpleNamespace(default_camera=types.SimpleNamespace(background_color=torch.zeros(3)))
+for it in range(cfg['NUM_ITERATIONS']):
+    calls.clear()
+    for f in sorted(between, key=lambda f: -f.priority):
+        start, end, stride = value(f.start_iteration), value(f.end_iteration), value(f.iteration_stride)
+        if (start is not None and it < start) or (end is not None and it > end) or (stride is not None and (it - (start or 0)) % stride != 0):
+            continue
+        f(me, it, dataset)
+    replaced_f_rest = 'densify_and_prune' in calls          # prune_points rebuilds all six groups (Model.py:157-167); reset_opacities only the opacities (:152-155)
+    assert clean(it) == (not replaced_f_rest), it
+    dirty += replaced_f_rest
+assert dirty == 144        # iterations 600, 700, ..., 14 900
+''')
