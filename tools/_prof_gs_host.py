@@ -9,7 +9,7 @@ sc = scenes.gs_random_scene(1_000_000, seed=0)
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 g = Gaussians(T(sc['means3D']), torch.log(T(sc['scales'])), T(sc['rotations']), torch.logit(T(sc['opacities']).clamp(1e-4, 1 - 1e-4))[:, None].contiguous(), T(sc['shs'][:, :1]), T(sc['shs'][:, 1:]))
 g.training_setup(training_cameras_extent=4.5)
-g.fuse_rest_step = True
+g.fuse_rest_step = len(sys.argv) > 1 and sys.argv[1] == 'fuse'
 cam = PerspectiveCamera(bench.GS_W, bench.GS_H, 1.2 * bench.GS_W, 1.2 * bench.GS_W, background_color=torch.zeros(3, device=dev))
 target = torch.rand(3, bench.GS_H, bench.GS_W, device=dev)
 poses = [torch.from_numpy(np.asarray(scenes.orbit_pose(0.8 + 0.7 * i, 0.35, 4.5), dtype=np.float32)).to(dev) for i in range(8)]

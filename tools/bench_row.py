@@ -11,4 +11,4 @@ for f in sys.argv[1:]:
         f.split('/')[-1], d['value'], d['ms_per_step'], r['frac'], rr['in_frame_frac'], rr.get('rocprof_frac') or 0, m['frac'], mr['in_frame_frac'], mr.get('rocprof_frac') or 0,
         s['ms_fwd'], s['ms_fwd_bwd'], s['roofline']['frac_fwd'], s['roofline']['frac_fwd_bwd'], s['six_million']['ms_fwd'], s['six_million']['ms_fwd_bwd'],
         s['c3_1600x1060']['ms_fwd'], s['c3_1600x1060']['ms_fwd_bwd'], t['ms_per_iteration'], t['hip_graph']['ms_per_iteration'], t['fused']['ms_per_iteration'],
-        g['ms_per_step'], ('%.3f' % rib['ms_per_step']) if rib else '—', g['hip_graph']['ms_per_step'], d['secondary_trained']['mrays_per_s'] if 'mrays_per_s' in d.get('secondary_trained', {}) else float('nan')))
+        g['ms_per_step'], ('%.3f' % rib['ms_per_step']) if rib else '—', g['hip_graph']['ms_per_step'], (d.get('secondary_trained') or {}).get('slab_order_auto', {}).get('mrays_per_s', float('nan'))))
