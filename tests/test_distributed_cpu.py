@@ -339,7 +339,7 @@ def _t_sharded_step(rank, world):
     return same_half, stale_before, same, (A['step'], A['scale'], A['skipped']), (B['step'], B['scale'], B['skipped']), wire, digest
 
 
-@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('world', [2, 4, 8])
 def test_sharded_optimizer_step_is_bit_identical_to_the_replicated_one(world):
     out = _run(_t_sharded_step, world=world)
     for r in range(world):
