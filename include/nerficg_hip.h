@@ -208,7 +208,9 @@ int nrc_f32_to_f16(const float* src, void* dst_f16, int64_t n, nrc_stream_t stre
  * fp16 rows [d01(3) | features(16)].  out_act: 0 none, 1 sigmoid.  out (M,out_ld) fp16, columns [0,n_store) written
  * (n_store in {4,8,12,16}).  save_in (R,32) fp16 and save_acts (n_hidden,R,64) fp16, R = nrc_nwie_save_rows(M) (M rounded up to whole
  * 32-sample tiles), receive the encoded inputs and the post-ReLU activations for the backward pass (both NULL for inference) in a
- * layout private to the two calls (MFMA-fragment-major, so that both sides move whole cache lines). */
+ * layout private to the two calls (MFMA-fragment-major, so that both sides move whole cache lines).  Of a network with two hidden layers only the FIRST layer's
+ * activations are written (the buffer keeps its documented size): the backward pass recomputes the second from the first with the forward's own eight matrix
+ * instructions per 32 samples -- 128 B per sample less in either direction (round 6). */
 int64_t nrc_nwie_save_rows(int64_t M);
 /* workspace (optional, grid encoding only): nrc_nwie_forward_ws_bytes(M) bytes -> the encoding runs as its own kernel (faster);
  * NULL -> one kernel gathers and runs the MLP. */

@@ -88,6 +88,9 @@ __device__ __forceinline__ void encode_sh_id(const __half* __restrict__ in, int 
     }
 }
 
+#ifndef NRC_BWD_RECOMPUTE
+#define NRC_BWD_RECOMPUTE 1   // the second hidden layer's activations are recomputed in the backward pass instead of saved by the forward pass (A/B builds: -DNRC_BWD_RECOMPUTE=0)
+#endif
 // ---- generic per-network forward -----------------------------------------------------------------------------------
 template <int ENC, int N_HIDDEN, int OUT_ACT, bool SAVE>
 __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input, int in_ld, int64_t M, const __half* __restrict__ W,
@@ -194,7 +197,9 @@ __global__ void __launch_bounds__(256) k_nwie_fwd(const void* __restrict__ input
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) H[2 * mt + gq] = acc_to_frag_relu(acc[mt], gq);
-            if constexpr (SAVE) {
+            // (the SECOND hidden layer of a two-hidden-layer network is not saved: k_nwie_bwd recomputes it from the first with the same eight MFMAs --
+            //  128 B per sample less to write here and to read there, NRC_BWD_RECOMPUTE)
+            if constexpr (SAVE) if (!(NRC_BWD_RECOMPUTE && l == 1)) {
                 _Float16* p = reinterpret_cast<_Float16*>(save_acts) + ((int64_t)l * n_tiles_cap * 32) * 64 + ((tile * 8 + hh) * 32 + r) * 8;
 #pragma unroll
                 for (int s = 0; s < 4; s++) *reinterpret_cast<h8*>(p + s * 2 * 32 * 8) = H[s];
@@ -1528,6 +1533,14 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
     }
 #pragma unroll
     for (int s = 0; s < 4; s++) W0T[s] = load_wT_frag<true>(W0, 32, 64, 32, 0, s, r, hh);
+    // the second hidden layer forward again (k_nwie_fwd's own fragments and instruction order: the same bits it had there)
+    h8 A1[(N_HIDDEN > 1 && NRC_BWD_RECOMPUTE) ? 2 : 1][4];
+    if constexpr (N_HIDDEN > 1 && NRC_BWD_RECOMPUTE) {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) A1[mt][s] = load_w_frag<true>(W1, 64, 64, mt, s, r, hh);
+    }
 
     f16v gWo[2] = {zero16(), zero16()};
     f16v gW1[N_HIDDEN > 1 ? 2 : 1][2];
@@ -1537,7 +1550,7 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
 
     // The saved forward state of a tile (input, hidden activations, output and its gradient: 13 or 21 loads per lane) is requested one tile ahead:
     // with one wave per SIMD nothing else covers the ~2 us a dependent global load takes under load.
-    struct TileState { h8 X[2], H0[4], H1[4], g, y; };
+    struct TileState { h8 X[2], H0[4], H1[(N_HIDDEN > 1 && !NRC_BWD_RECOMPUTE) ? 4 : 1], g, y; };
     auto fetch = [&](int64_t tile, TileState& t) {
         const int64_t i = tile * 32 + r;
         const int64_t ic = i < M ? i : M - 1;
@@ -1547,7 +1560,7 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
         const _Float16* a0 = reinterpret_cast<const _Float16*>(save_acts) + ((tile * 8 + hh) * 32 + r) * 8;
 #pragma unroll
         for (int s = 0; s < 4; s++) t.H0[s] = *reinterpret_cast<const h8*>(a0 + s * 2 * 32 * 8);
-        if constexpr (N_HIDDEN > 1) {
+        if constexpr (N_HIDDEN > 1 && !NRC_BWD_RECOMPUTE) {
             const _Float16* a1 = a0 + n_tiles_cap * 32 * 64;
 #pragma unroll
             for (int s = 0; s < 4; s++) t.H1[s] = *reinterpret_cast<const h8*>(a1 + s * 2 * 32 * 8);
@@ -1588,7 +1601,22 @@ __global__ void __launch_bounds__(256) k_nwie_bwd(int64_t M, const __half* __res
         NRC_PROBE(pb + 0);
         const h8 (&X)[2] = cur.X;
         const h8 (&H0)[4] = cur.H0;
-        const h8 (&HL)[4] = N_HIDDEN > 1 ? cur.H1 : cur.H0;  // last hidden layer
+        h8 H1r[4];
+        if constexpr (N_HIDDEN > 1 && NRC_BWD_RECOMPUTE) {
+            f16v a2[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) a2[mt] = NRC_MFMA(A1[mt][s], H0[s], a2[mt]);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) H1r[2 * mt + gq] = acc_to_frag_relu(a2[mt], gq);
+        } else if constexpr (N_HIDDEN > 1) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) H1r[s] = cur.H1[s];
+        }
+        const h8 (&HL)[4] = N_HIDDEN > 1 ? H1r : cur.H0;  // last hidden layer
         // ---- dZ of the output layer (natural order over the 16 padded output rows)
         h8 dZo = zero_h8();
         if (valid) {
