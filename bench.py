@@ -952,7 +952,7 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=20):
                 coll_ms.append((a, b))
 
     gc.collect()      # before the warm-up steps, not between them and the timed loop: the chip must not sit idle (and clock down) in front of the first timed step
-    for i in range(2):
+    for i in range(4):    # (four: the plain step takes its 236 MB of gradient tensors from torch's allocator, emptied behind the previous leg -- 2 of 20 leases had this leg at 1.45 / 1.56 ms with two)
         step(i, False)
     torch.cuda.synchronize()
     if world > 1:
@@ -978,7 +978,7 @@ def dp_gs_leg(rank, world, device, n_gaussians=1_000_000, iters=20):
         # which optimizer.step() follows the backward pass directly; the reference's trainer lets densify / reset_opacities run between the two on some
         # iterations (Trainer.py:100-128), which drops that iteration's update there -- a loop using the variant switches it off for those iterations.
         g.fuse_rest_step = True
-        for i in range(2):
+        for i in range(4):
             step(i, False)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(iters):
